@@ -1,0 +1,97 @@
+/*
+ * ocrf_hip.h — C ABI of libocrf_hip.so: the MI355X (gfx950) implementation of OcRFDet's
+ * render + BEV-pool + HOA hot path.  Plain pointers and sizes only; every pointer is a DEVICE
+ * pointer unless its comment says "host".  Every function returns 0 on success or a hipError_t
+ * value (as int); nothing is allocated, freed or synchronised inside a call (all of them are
+ * hipGraph-capturable), the caller owns every buffer, and `stream` is a hipStream_t (NULL =
+ * the legacy default stream, which is what the reference launches on).
+ *
+ * File:line citations are into the reference tree (Mingqj/OcRFDet), i.e. the interface each
+ * entry point replaces.
+ */
+#ifndef OCRF_HIP_H
+#define OCRF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *ocrf_stream_t; /* hipStream_t */
+
+/* Library / build identification: returns e.g. "ocrf_hip 0.1 gfx950". Host pointer, static. */
+const char *ocrf_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * BEVPoolv2 voxel pooling
+ * ------------------------------------------------------------------------------------------ */
+
+/*
+ * Exact signature of the reference's C-level launcher
+ *   void bev_pool_v2(int c, int n_intervals, const float* depth, const float* feat,
+ *                    const int* ranks_depth, const int* ranks_feat, const int* ranks_bev,
+ *                    const int* interval_starts, const int* interval_lengths, float* out)
+ * (mmdet3d/ops/bev_pool_v2/src/bev_pool.cpp:7-9, defined src/bev_pool_cuda.cu:123-131).
+ * Same contract: `out` is (B,Z,Y,X,C) and must be pre-zeroed by the caller; for interval k,
+ *   out[ranks_bev[starts[k]]*c + ch] = sum_i depth[ranks_depth[starts[k]+i]] * feat[ranks_feat[starts[k]+i]*c + ch]
+ * (assignment, accumulated in list order); launches on the legacy default stream; any interval
+ * layout is accepted (one lane group per interval).  No error is reported (the reference
+ * reports none) — use ocrf_bev_pool_v2 for an error code, a stream and the load-balanced kernel.
+ */
+void bev_pool_v2(int c, int n_intervals, const float *depth, const float *feat,
+                 const int *ranks_depth, const int *ranks_feat, const int *ranks_bev,
+                 const int *interval_starts, const int *interval_lengths, float *out);
+
+/*
+ * Exact signature of the reference's backward launcher (src/bev_pool.cpp:11-14,
+ * src/bev_pool_cuda.cu:133-140).  Intervals are runs of equal ranks_feat (the Python wrapper
+ * re-sorts, bev_pool.py:47-57).  depth_grad/feat_grad must be pre-zeroed.
+ *   feat_grad[ranks_feat[s]*c + ch] = sum_i out_grad[ranks_bev[s+i]*c + ch] * depth[ranks_depth[s+i]]
+ *   depth_grad[ranks_depth[p]]      = sum_ch out_grad[ranks_bev[p]*c + ch] * feat[ranks_feat[p]*c + ch]
+ */
+void bev_pool_v2_grad(int c, int n_intervals, const float *out_grad, const float *depth,
+                      const float *feat, const int *ranks_depth, const int *ranks_feat,
+                      const int *ranks_bev, const int *interval_starts,
+                      const int *interval_lengths, float *depth_grad, float *feat_grad);
+
+/*
+ * Load-balanced forward.  Same arithmetic contract as bev_pool_v2 with these additions:
+ *   n_points        length of the three rank vectors (the reference passes it implicitly as
+ *                   tensor sizes, bev_pool.cpp:30-57);
+ *   workspace       scratch of at least ocrf_bev_pool_v2_workspace_bytes(c, n_points) bytes
+ *                   (may be NULL when that is 0); contents are don't-care on entry and exit;
+ *   stream          hipStream_t.
+ * Precondition (always true for the reference's producers, view_transformer.py:240-255,
+ * view_transformer_ocrf.py:837-852): interval_starts is ascending and intervals do not overlap
+ * (gaps are allowed: points outside every interval are ignored).  Check it with
+ * ocrf_bev_pool_v2_check_intervals when in doubt; bev_pool_v2 above accepts anything.
+ * Results are bitwise reproducible run to run (no float atomics).
+ */
+int ocrf_bev_pool_v2(int c, int n_intervals, int n_points, const float *depth, const float *feat,
+                     const int *ranks_depth, const int *ranks_feat, const int *ranks_bev,
+                     const int *interval_starts, const int *interval_lengths, float *out,
+                     void *workspace, size_t workspace_bytes, ocrf_stream_t stream);
+
+size_t ocrf_bev_pool_v2_workspace_bytes(int c, int n_points);
+
+/*
+ * Writes *flag (device int) = 0 if interval_starts/lengths satisfy the precondition of
+ * ocrf_bev_pool_v2 for n_points points, else a non-zero bit mask
+ * (1: not ascending / overlapping, 2: interval exceeds n_points, 4: negative start or length).
+ */
+int ocrf_bev_pool_v2_check_intervals(int n_intervals, int n_points, const int *interval_starts,
+                                     const int *interval_lengths, int *flag, ocrf_stream_t stream);
+
+/* Stream-taking, error-returning form of bev_pool_v2_grad (same arithmetic; deterministic). */
+int ocrf_bev_pool_v2_grad(int c, int n_intervals, const float *out_grad, const float *depth,
+                          const float *feat, const int *ranks_depth, const int *ranks_feat,
+                          const int *ranks_bev, const int *interval_starts,
+                          const int *interval_lengths, float *depth_grad, float *feat_grad,
+                          ocrf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCRF_HIP_H */

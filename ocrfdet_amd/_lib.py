@@ -1,0 +1,104 @@
+"""Loader for ``libocrf_hip.so`` — the C-ABI HIP library behind every op in this package.
+
+There is no CPU or PyTorch fallback anywhere in ``ocrfdet_amd``: if the library cannot be loaded
+the ops raise.  ``build()`` compiles it in-tree with hipcc for gfx950 (cross-compiles without a
+GPU); the built ``.so`` is git-ignored but travels with the source tree.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+_SO = os.path.join(_CSRC, "libocrf_hip.so")
+_LIB = None
+
+
+class OcrfHipError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """Compile every ``csrc/*.hip`` into ``csrc/libocrf_hip.so`` (``--offload-arch=gfx950``)."""
+    args = ["make", "-C", _CSRC, "-j4", "libocrf_hip.so"]
+    if force:
+        subprocess.check_call(["make", "-C", _CSRC, "clean"], stdout=subprocess.DEVNULL)
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(args, stdout=out)
+    return _SO
+
+
+def lib():
+    """The loaded library.  Raises ``OcrfHipError`` if it is missing — never falls back."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_SO):
+            raise OcrfHipError(
+                f"{_SO} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C ocrfdet_amd/csrc` (hipcc, gfx950). ocrfdet_amd has no fallback path.")
+        try:
+            _LIB = ctypes.CDLL(_SO)
+        except OSError as e:  # pragma: no cover
+            raise OcrfHipError(f"cannot load {_SO}: {e}") from e
+        _declare(_LIB)
+    return _LIB
+
+
+def _declare(L):
+    c_int, c_size_t, c_void_p, c_float = ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_float
+    L.ocrf_version.restype = ctypes.c_char_p
+    L.ocrf_version.argtypes = []
+    L.bev_pool_v2.restype = None
+    L.bev_pool_v2.argtypes = [c_int, c_int] + [c_void_p] * 8
+    L.bev_pool_v2_grad.restype = None
+    L.bev_pool_v2_grad.argtypes = [c_int, c_int] + [c_void_p] * 10
+    L.ocrf_bev_pool_v2.restype = c_int
+    L.ocrf_bev_pool_v2.argtypes = [c_int, c_int, c_int] + [c_void_p] * 8 + [c_void_p, c_size_t, c_void_p]
+    L.ocrf_bev_pool_v2_workspace_bytes.restype = c_size_t
+    L.ocrf_bev_pool_v2_workspace_bytes.argtypes = [c_int, c_int]
+    L.ocrf_bev_pool_v2_check_intervals.restype = c_int
+    L.ocrf_bev_pool_v2_check_intervals.argtypes = [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
+    L.ocrf_bev_pool_v2_grad.restype = c_int
+    L.ocrf_bev_pool_v2_grad.argtypes = [c_int, c_int] + [c_void_p] * 10 + [c_void_p]
+
+
+def check(err, what):
+    if err != 0:
+        raise OcrfHipError(f"{what} failed with hipError_t {err}")
+
+
+def stream_ptr(device=None):
+    """hipStream_t of torch's current stream on ``device`` as an integer for ctypes."""
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise OcrfHipError(
+                "ocrfdet_amd ops run on the GPU only (HIP kernels, no CPU fallback); got a "
+                f"{t.device} tensor")
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr() if t is not None and t.numel() > 0 else 0)
+
+
+class Workspace:
+    """Per-device grow-only scratch buffer (a torch uint8 tensor), so that steady-state calls
+    allocate nothing.  Stream-ordered reuse is safe because every user runs on the current stream."""
+
+    def __init__(self):
+        self._bufs = {}
+
+    def get(self, device, nbytes, tag="default"):
+        key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+        buf = self._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+            self._bufs[key] = buf
+        return buf
+
+
+workspace = Workspace()

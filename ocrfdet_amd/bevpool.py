@@ -1,0 +1,168 @@
+"""BEVPoolv2 voxel pooling — the MI355X op behind the reference's ``bev_pool_v2``.
+
+Public surface (identical names / argument order / tensor conventions to
+``mmdet3d/ops/bev_pool_v2/bev_pool.py`` so the reference's import line is the only edit):
+
+``bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts,
+interval_lengths)``  -> ``(B, C, Z, Y, X)`` contiguous fp32                     [bev_pool.py:86-92]
+    depth ``(B,N,D,H,W)`` any float dtype, feat ``(B,N,H,W,C)`` channels-last, 1-D integer ranks,
+    ``bev_feat_shape = (B,Z,Y,X,C)``.  Differentiable w.r.t. depth and feat.  Empty voxels are 0.
+``QuickCumsumCuda``   the autograd Function (returns the pre-permute ``(B,Z,Y,X,C)`` tensor)
+                                                                                [bev_pool.py:11-83]
+``TRTBEVPoolv2``      export shim with the ``mmdeploy::bev_pool_v2`` symbolic   [bev_pool.py:95-142]
+``bev_pool_v2_ext``   object with ``bev_pool_v2_forward`` / ``bev_pool_v2_backward`` taking the
+                      pybind module's argument order — ``interval_lengths`` BEFORE
+                      ``interval_starts``                               [src/bev_pool.cpp:30-39,74-85]
+
+All compute is in ``csrc/bev_pool.hip`` behind the C ABI of ``include/ocrf_hip.h``.  There is no
+CPU path: CPU tensors raise ``OcrfHipError``.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _lib
+
+__all__ = ['bev_pool_v2', 'TRTBEVPoolv2', 'QuickCumsumCuda', 'bev_pool_v2_ext', 'runs_of']
+
+
+def _want(t, dtype, name):
+    if t.dtype != dtype or not t.is_contiguous():
+        raise _lib.OcrfHipError(f'{name}: expected contiguous {dtype}, got {t.dtype} '
+                                f'contiguous={t.is_contiguous()}')
+
+
+def runs_of(sorted_ranks):
+    """(starts, lengths) int32 of the runs of equal values in a sorted 1-D tensor — what
+    view_transformer.py:245-252 and bev_pool.py:50-57 build with a boolean mask."""
+    _, counts = torch.unique_consecutive(sorted_ranks, return_counts=True)
+    ends = torch.cumsum(counts, 0)
+    return (ends - counts).int(), counts.int()
+
+
+class _ExtensionAPI:
+    """Call-compatible stand-in for the reference's pybind module (src/bev_pool.cpp:106-111)."""
+
+    @staticmethod
+    def bev_pool_v2_forward(depth, feat, out, ranks_depth, ranks_feat, ranks_bev,
+                            interval_lengths, interval_starts):
+        _lib.require_cuda(depth, feat, out, ranks_depth, ranks_feat, ranks_bev, interval_lengths,
+                          interval_starts)
+        for name, t in (('depth', depth), ('feat', feat), ('out', out)):
+            _want(t, torch.float32, name)
+        for name, t in (('ranks_depth', ranks_depth), ('ranks_feat', ranks_feat),
+                        ('ranks_bev', ranks_bev), ('interval_lengths', interval_lengths),
+                        ('interval_starts', interval_starts)):
+            _want(t, torch.int32, name)
+        channels = feat.size(4)                       # `c = _feat.size(4)`, bev_pool.cpp:40
+        n_iv = interval_lengths.size(0)
+        n_pts = ranks_depth.numel()
+        if ranks_feat.numel() != n_pts or ranks_bev.numel() != n_pts or interval_starts.numel() != n_iv:
+            raise _lib.OcrfHipError('rank / interval vectors disagree in length')
+        L = _lib.lib()
+        dev = depth.device
+        with torch.cuda.device(dev):                  # OptionalCUDAGuard, bev_pool.cpp:42
+            stream = _lib.stream_ptr(dev)
+            if os.environ.get('OCRF_CHECK_INTERVALS', '0') == '1':
+                flag = torch.zeros(1, dtype=torch.int32, device=dev)
+                _lib.check(L.ocrf_bev_pool_v2_check_intervals(
+                    n_iv, n_pts, _lib.ptr(interval_starts), _lib.ptr(interval_lengths),
+                    _lib.ptr(flag), stream), 'ocrf_bev_pool_v2_check_intervals')
+                bad = int(flag.item())
+                if bad:
+                    raise _lib.OcrfHipError(
+                        f'intervals are not an ascending non-overlapping cover (flag={bad}); the '
+                        'C entry point bev_pool_v2() accepts arbitrary layouts')
+            need = L.ocrf_bev_pool_v2_workspace_bytes(channels, n_pts)
+            scratch = _lib.workspace.get(dev, need, 'bev_pool')
+            _lib.check(L.ocrf_bev_pool_v2(
+                channels, n_iv, n_pts, _lib.ptr(depth), _lib.ptr(feat), _lib.ptr(ranks_depth),
+                _lib.ptr(ranks_feat), _lib.ptr(ranks_bev), _lib.ptr(interval_starts),
+                _lib.ptr(interval_lengths), _lib.ptr(out), _lib.ptr(scratch),
+                ctypes.c_size_t(scratch.numel()), stream), 'ocrf_bev_pool_v2')
+
+    @staticmethod
+    def bev_pool_v2_backward(out_grad, depth_grad, feat_grad, depth, feat, ranks_depth,
+                             ranks_feat, ranks_bev, interval_lengths, interval_starts):
+        _lib.require_cuda(out_grad, depth_grad, feat_grad, depth, feat, ranks_depth, ranks_feat,
+                          ranks_bev, interval_lengths, interval_starts)
+        for name, t in (('out_grad', out_grad), ('depth_grad', depth_grad),
+                        ('feat_grad', feat_grad), ('depth', depth), ('feat', feat)):
+            _want(t, torch.float32, name)
+        for name, t in (('ranks_depth', ranks_depth), ('ranks_feat', ranks_feat),
+                        ('ranks_bev', ranks_bev), ('interval_lengths', interval_lengths),
+                        ('interval_starts', interval_starts)):
+            _want(t, torch.int32, name)
+        channels = out_grad.size(4)                   # `c = _out_grad.size(4)`, bev_pool.cpp:86
+        L = _lib.lib()
+        dev = out_grad.device
+        with torch.cuda.device(dev):
+            _lib.check(L.ocrf_bev_pool_v2_grad(
+                channels, interval_lengths.size(0), _lib.ptr(out_grad), _lib.ptr(depth),
+                _lib.ptr(feat), _lib.ptr(ranks_depth), _lib.ptr(ranks_feat), _lib.ptr(ranks_bev),
+                _lib.ptr(interval_starts), _lib.ptr(interval_lengths), _lib.ptr(depth_grad),
+                _lib.ptr(feat_grad), _lib.stream_ptr(dev)), 'ocrf_bev_pool_v2_grad')
+
+
+bev_pool_v2_ext = _ExtensionAPI()
+
+
+class QuickCumsumCuda(torch.autograd.Function):
+    """Autograd wrapper with the reference's name and call signature (bev_pool.py:11-83)."""
+
+    @staticmethod
+    def forward(ctx, depth, feat, ranks_depth, ranks_feat, ranks_bev,
+                bev_feat_shape, interval_starts, interval_lengths):
+        # dtype/contiguity normalisation as bev_pool.py:19-25
+        rb = ranks_bev.int().contiguous()
+        rd = ranks_depth.int().contiguous()
+        rf = ranks_feat.int().contiguous()
+        d32 = depth.float().contiguous()
+        f32 = feat.float().contiguous()
+        starts = interval_starts.int().contiguous()
+        lengths = interval_lengths.int().contiguous()
+        pooled = f32.new_zeros(tuple(int(s) for s in bev_feat_shape))    # bev_pool.py:27
+        bev_pool_v2_ext.bev_pool_v2_forward(d32, f32, pooled, rd, rf, rb, lengths, starts)
+        ctx.save_for_backward(rb, d32, f32, rf, rd)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, grad_pooled):
+        rb, d32, f32, rf, rd = ctx.saved_tensors
+        # regroup the point list by feature pixel (bev_pool.py:47-57); stable so that runs of
+        # equal ranks_feat keep their forward order
+        rf_sorted, perm = torch.sort(rf, stable=True)
+        starts_bp, lengths_bp = runs_of(rf_sorted)
+        g_depth = torch.zeros_like(d32)
+        g_feat = torch.zeros_like(f32)
+        bev_pool_v2_ext.bev_pool_v2_backward(
+            grad_pooled.contiguous(), g_depth, g_feat, d32, f32, rd[perm].contiguous(),
+            rf_sorted.contiguous(), rb[perm].contiguous(), lengths_bp, starts_bp)
+        return g_depth, g_feat, None, None, None, None, None, None
+
+
+def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev,
+                bev_feat_shape, interval_starts, interval_lengths):
+    pooled = QuickCumsumCuda.apply(depth, feat, ranks_depth, ranks_feat, ranks_bev,
+                                   bev_feat_shape, interval_starts, interval_lengths)
+    return pooled.permute(0, 4, 1, 2, 3).contiguous()        # (B,Z,Y,X,C) -> (B,C,Z,Y,X)
+
+
+class TRTBEVPoolv2(torch.autograd.Function):
+    """Export shim (bev_pool.py:95-142): depth (N,D,H,W), feat (N,H,W,C) -> (1,Y,X,C)."""
+
+    @staticmethod
+    def symbolic(g, depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts,
+                 interval_lengths, out_height=128, out_width=128):
+        return g.op('mmdeploy::bev_pool_v2', depth, feat, ranks_depth, ranks_feat, ranks_bev,
+                    interval_starts, interval_lengths,
+                    out_height_i=out_height, out_width_i=out_width)
+
+    @staticmethod
+    def forward(g, depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts,
+                interval_lengths, out_height=128, out_width=128):
+        shape = (1, 1, out_height, out_width, feat.shape[-1])                  # (B,Z,Y,X,C)
+        bev = bev_pool_v2(depth[None], feat[None], ranks_depth, ranks_feat, ranks_bev, shape,
+                          interval_starts, interval_lengths)
+        return bev.squeeze(2).permute(0, 2, 3, 1)

@@ -1,0 +1,141 @@
+"""Synthetic nuScenes-like workload for tests, ``smoke()`` and ``bench.py``.
+
+Everything is closed-form or drawn from a seeded ``numpy`` generator, so the same inputs can be
+rebuilt bit-for-bit anywhere (the GPU box has no dataset and no reference tree).
+
+Rig: 6 cameras at yaw [55, 0, -55, 110, 180, -110] deg, ``R_cam->ego = Rz(yaw) @ [[0,0,1],[-1,0,0],
+[0,-1,0]]``, ``t = Rz @ (1.5,0,0) + (0,0,1.5)``; ``K = [[1266,0,816],[0,1266,491],[0,0,1]]`` for a
+1600x900 sensor; image augmentation ``post_rot = diag(s,s,1)``, ``post_tran = (0,-crop_h,0)`` with
+``s = W_in/1600`` and ``crop_h = int(900*s) - H_in``; ``bda = I``.  These are the 7 geometry tensors
+of the reference's ``img_inputs`` tuple (mmdet3d/models/detectors/bevdet.py:412-476).
+"""
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+YAWS_DEG = (55.0, 0.0, -55.0, 110.0, 180.0, -110.0)
+
+
+@dataclass
+class PathConfig:
+    """Shapes of one configuration of the hot path (BASELINE.json ``configs``)."""
+    name: str
+    n_cams: int = 6
+    n_frames: int = 1
+    batch: int = 1
+    input_size: tuple = (256, 704)          # (H_in, W_in)
+    downsample: int = 16
+    channels: int = 80
+    grid: dict = field(default_factory=lambda: dict(
+        x=[-51.2, 51.2, 0.8], y=[-51.2, 51.2, 0.8], z=[-5.0, 3.0, 8.0], depth=[1.0, 60.0, 0.5]))
+    pc_range: tuple = (-51.2, -51.2, -5.0, 51.2, 51.2, 3.0)
+    num_height: int = 13
+    render: bool = False
+    hoa: bool = False
+
+    @property
+    def feat_hw(self):
+        return self.input_size[0] // self.downsample, self.input_size[1] // self.downsample
+
+    @property
+    def D(self):
+        d = self.grid['depth']
+        return len(np.arange(d[0], d[1], d[2]))
+
+    @property
+    def bev_xyz(self):
+        return tuple(int(round((self.grid[a][1] - self.grid[a][0]) / self.grid[a][2])) for a in 'xyz')
+
+
+def _grid(lim, step, z):
+    return dict(x=[-lim, lim, step], y=[-lim, lim, step], z=list(z), depth=[1.0, 60.0, 0.5])
+
+
+CONFIGS = {
+    # BASELINE.json configs[0]: plumbing case, CPU-runnable
+    'cfg0_1cam_128x352_bev64x64x4': PathConfig(
+        'cfg0_1cam_128x352_bev64x64x4', n_cams=1, input_size=(128, 352),
+        grid=_grid(25.6, 0.8, (-5.0, 3.0, 2.0)), pc_range=(-25.6, -25.6, -5.0, 25.6, 25.6, 3.0)),
+    # configs[1]
+    'cfg1_6cam_256x704_bev128x128x8': PathConfig(
+        'cfg1_6cam_256x704_bev128x128x8', grid=_grid(51.2, 0.8, (-5.0, 3.0, 1.0))),
+    # the reference's own shape (configs/ocrfdet/ocrfdet.py:19-40): 128x128x1
+    'ref_6cam_256x704_bev128x128x1': PathConfig('ref_6cam_256x704_bev128x128x1'),
+    # configs[2]: the headline — 6 cams x 2 frames, 200x200 BEV (+-40 m @ 0.4 m), render + HOA
+    'cfg2_6cam_2frame_bev200x200_render_hoa': PathConfig(
+        'cfg2_6cam_2frame_bev200x200_render_hoa', n_frames=2,
+        grid=_grid(40.0, 0.4, (-5.0, 3.0, 8.0)), pc_range=(-40.0, -40.0, -5.0, 40.0, 40.0, 3.0),
+        render=True, hoa=True),
+    # configs[4]: test-set shape
+    'cfg4_6cam_8frame_512x1408_bev200x200': PathConfig(
+        'cfg4_6cam_8frame_512x1408_bev200x200', n_frames=8, input_size=(512, 1408),
+        grid=_grid(40.0, 0.4, (-5.0, 3.0, 8.0)), pc_range=(-40.0, -40.0, -5.0, 40.0, 40.0, 3.0),
+        render=True, hoa=True),
+}
+
+
+def rig(n_cams=6, input_size=(256, 704), batch=1, dtype=np.float32):
+    """-> dict of numpy arrays: rots (B,N,3,3), trans (B,N,3), intrins (B,N,3,3), post_rots
+    (B,N,3,3), post_trans (B,N,3), bda (B,3,3), c2w (B,N,4,4)."""
+    H_in, W_in = input_size
+    base = np.array([[0, 0, 1], [-1, 0, 0], [0, -1, 0]], dtype=np.float64)
+    rots, trans, c2w = [], [], []
+    for yaw in YAWS_DEG[:n_cams]:
+        a = math.radians(yaw)
+        Rz = np.array([[math.cos(a), -math.sin(a), 0], [math.sin(a), math.cos(a), 0], [0, 0, 1]])
+        R = Rz @ base
+        t = Rz @ np.array([1.5, 0.0, 0.0]) + np.array([0.0, 0.0, 1.5])
+        M = np.eye(4)
+        M[:3, :3] = R
+        M[:3, 3] = t
+        rots.append(R), trans.append(t), c2w.append(M)
+    K = np.array([[1266.0, 0, 816.0], [0, 1266.0, 491.0], [0, 0, 1.0]])
+    s = W_in / 1600.0
+    crop_h = int(900 * s) - H_in
+    post_rot = np.diag([s, s, 1.0])
+    post_tran = np.array([0.0, -float(crop_h), 0.0])
+    rep = lambda a: np.broadcast_to(np.asarray(a, dtype=dtype), (batch,) + np.shape(a)).copy()  # noqa: E731
+    N = n_cams
+    return dict(
+        rots=rep(np.stack(rots)), trans=rep(np.stack(trans)), intrins=rep(np.stack([K] * N)),
+        post_rots=rep(np.stack([post_rot] * N)), post_trans=rep(np.stack([post_tran] * N)),
+        bda=rep(np.eye(3)), c2w=rep(np.stack(c2w)), resize=s, crop_h=crop_h)
+
+
+def rig_tensors(cfg, device='cpu'):
+    r = rig(cfg.n_cams, cfg.input_size, cfg.batch)
+    return {k: (torch.from_numpy(v).to(device) if isinstance(v, np.ndarray) else v) for k, v in r.items()}
+
+
+def depth_and_feat(cfg, seed=0, device='cpu'):
+    """Softmax depth over D bins with sub-threshold bins zeroed and masked image features, as
+    ``OcRFViewTransformerFull.forward`` hands them to the pooling (view_transformer_ocrf.py:1327-1331).
+    -> depth (B*N, D, H, W), feat (B*N, C, H, W) float32."""
+    rng = np.random.default_rng(seed)
+    H, W = cfg.feat_hw
+    BN = cfg.batch * cfg.n_cams
+    logits = rng.standard_normal((BN, cfg.D, H, W)).astype(np.float32)
+    logits -= logits.max(1, keepdims=True)
+    p = np.exp(logits)
+    p /= p.sum(1, keepdims=True)
+    p[p < np.float32(1.0 / cfg.D)] = 0
+    feat = rng.standard_normal((BN, cfg.channels, H, W)).astype(np.float32)
+    feat *= (rng.random((BN, 1, H, W)) < 0.5).astype(np.float32)
+    return torch.from_numpy(p).to(device), torch.from_numpy(feat).to(device)
+
+
+def stress_gaussians(n, seed=0, extent=40.0, device='cpu'):
+    """The 'stress' Gaussian set of SURVEY §8d: scales U(0.2,1.0), opacity U(0.05,0.95), random unit
+    quaternions, RGB U(0,1), centres uniform in a +-extent box (z in [-4.5, 2.5])."""
+    rng = np.random.default_rng(seed)
+    xyz = np.stack([rng.uniform(-extent, extent, n), rng.uniform(-extent, extent, n),
+                    rng.uniform(-4.5, 2.5, n)], 1).astype(np.float32)
+    scales = rng.uniform(0.2, 1.0, (n, 3)).astype(np.float32)
+    q = rng.standard_normal((n, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    opacity = rng.uniform(0.05, 0.95, (n, 1)).astype(np.float32)
+    rgb = rng.uniform(0.0, 1.0, (n, 3)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(device)  # noqa: E731
+    return dict(xyz=t(xyz), scales=t(scales), rotations=t(q), opacity=t(opacity), rgb=t(rgb))

@@ -1,0 +1,311 @@
+"""Generates the golden vectors under tests/golden/ by importing the reference's own Python
+(read-only at /root/reference) with dependency stubs (tests/golden/_ref_import.py) and running
+its functions on the CPU.  Run in the build container only:
+
+    python tests/golden/make_golden.py
+
+The ``.npz`` files are committed; the reference source is not copied anywhere.  Every array is
+an input or an output of a reference function — the file:line of the function is the key prefix
+documented in tests/golden/README.md.
+"""
+import hashlib
+import os
+import random
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+warnings.filterwarnings('ignore')
+
+import _ref_import  # noqa: E402
+from ocrfdet_amd import synthetic  # noqa: E402
+
+vt, vto, ca, du = _ref_import.install()
+T = torch.from_numpy
+
+
+def digest(a):
+    a = np.ascontiguousarray(a)
+    return np.frombuffer(hashlib.sha256(a.tobytes()).digest(), dtype=np.uint8).copy()
+
+
+def canonical(rb, rd, rf):
+    t = np.stack((rb.astype(np.int64), rd.astype(np.int64), rf.astype(np.int64)), 1)
+    return t[np.lexsort((t[:, 2], t[:, 1], t[:, 0]))]
+
+
+class _Self:
+    """Attribute bag used as ``self`` for unbound reference methods."""
+
+
+def lss_golden(cfg, full):
+    """create_frustum, get_lidar_coor, voxel_pooling_prepare_v2 (view_transformer.py:77-255)."""
+    lss = vt.LSSViewTransformer(grid_config=cfg.grid, input_size=cfg.input_size,
+                                downsample=cfg.downsample, in_channels=8, out_channels=cfg.channels)
+    r = synthetic.rig(cfg.n_cams, cfg.input_size, cfg.batch)
+    args = [T(r[k]) for k in ('rots', 'trans', 'intrins', 'post_rots', 'post_trans', 'bda')]
+    with torch.no_grad():
+        coor = lss.get_lidar_coor(*args)
+        rb, rd, rf, st, ln = lss.voxel_pooling_prepare_v2(coor)
+        inv_post = torch.inverse(args[3])
+        combine = args[0].matmul(torch.inverse(args[2]))
+    out = dict(
+        grid_lower_bound=lss.grid_lower_bound.numpy(), grid_interval=lss.grid_interval.numpy(),
+        grid_size=lss.grid_size.numpy(), D=np.int64(lss.D),
+        inv_post_rots=inv_post.numpy(), combine=combine.numpy(),
+        interval_starts=st.numpy(), interval_lengths=ln.numpy(),
+        n_points=np.int64(rb.numel()))
+    tri = canonical(rb.numpy(), rd.numpy(), rf.numpy())
+    out['triples_sha256'] = digest(tri)
+    out['coor_sha256'] = digest(coor.numpy())
+    out['frustum_sha256'] = digest(lss.frustum.numpy())
+    if full:
+        out.update(frustum=lss.frustum.numpy(), coor=coor.numpy(), triples=tri.astype(np.int32))
+    else:
+        # per-camera / per-depth-bin slices keep the file small but still localise a mismatch
+        out.update(frustum_d=lss.frustum[:, 0, 0, 2].numpy(), frustum_x=lss.frustum[0, 0, :, 0].numpy(),
+                   frustum_y=lss.frustum[0, :, 0, 1].numpy(),
+                   coor_slice=coor[0, :, ::13, ::5, ::7].contiguous().numpy())
+    return out
+
+
+def ht_golden(cfg, full):
+    """get_reference_points_3d, get_projection, get_sampling_point, fast_sample_prepare
+    (view_transformer_ocrf.py:651-852)."""
+    s = _Self()
+    Hf, Wf = cfg.feat_hw
+    s.W, s.H, s.D = Wf, Hf, cfg.D                       # ints, set at :894-895
+    X, Y, _ = cfg.bev_xyz
+    r = synthetic.rig(cfg.n_cams, cfg.input_size, cfg.batch)
+    args = [T(r[k]) for k in ('rots', 'trans', 'intrins', 'post_rots', 'post_trans', 'bda')]
+    cls = vto.OcRFViewTransformerFull
+    with torch.no_grad():
+        lidar2img, img_aug, l2i_R, l2i_t = cls.get_projection(s, *args)
+        ref = cls.get_reference_points_3d(s, Y, X, bs=cfg.batch, num_points_in_pillar=cfg.num_height,
+                                          device='cpu')
+        ref_norm = ref.clone()
+        coor, mask, (pts_lidar, pts_cam, _) = cls.get_sampling_point(
+            s, ref, list(cfg.pc_range), cfg.grid['depth'], lidar2img, img_aug, cfg.input_size)
+        coor_in = coor.clone()
+        rb, rd, rf, st, ln = cls.fast_sample_prepare(s, coor.clone(), mask)
+    out = dict(lidar2img=lidar2img.numpy(), img_aug=img_aug.numpy(),
+               interval_starts=st.numpy(), interval_lengths=ln.numpy(),
+               n_points=np.int64(rb.numel()), n_mask=np.int64(mask.sum().item()))
+    tri = canonical(rb.numpy(), rd.numpy(), rf.numpy())
+    out['triples_sha256'] = digest(tri)
+    out['coor_sha256'] = digest(coor_in.numpy())
+    out['mask_sha256'] = digest(mask.numpy())
+    out['voxel_sha256'] = digest(ref.numpy())           # scaled in place by get_sampling_point
+    if full:
+        out.update(ref_norm=ref_norm.numpy(), voxel=ref.numpy(), coor=coor_in.numpy(),
+                   mask=mask.numpy(), triples=tri.astype(np.int32))
+    else:
+        out.update(ref_norm_z=ref_norm[0, :, 0, 2].numpy(), ref_norm_x=ref_norm[0, 0, :X, 0].numpy(),
+                   coor_slice=coor_in[0, :, ::3, ::97].contiguous().numpy(),
+                   mask_slice=mask[0, :, ::3, ::97].contiguous().numpy())
+    return out
+
+
+def camera_golden():
+    """Camera set-up of the render call (view_transformer_ocrf.py:1135-1152 with
+    data_utils.py:703-733)."""
+    r = synthetic.rig(6, (256, 704), 1)
+    out = {}
+    H_in, W_in = 256, 704
+    for cam in range(6):
+        K = T(r['intrins'][0, cam])
+        c2w = T(r['c2w'][0, cam])
+        R_ex, T_ex = c2w[:3, :3], c2w[:3, 3]
+        fov_x = 2 * torch.atan(torch.tensor(W_in).float() / (2 * K[0, 0]))
+        fov_y = 2 * torch.atan(torch.tensor(H_in).float() / (2 * K[1, 1]))
+        # numpy>=2 refuses float32 scalars in the 0-d tensor item assignment used by
+        # getProjectionMatrix; float64 K reproduces numpy-1 promotion (python float x np.float32)
+        proj = torch.tensor(du.getProjectionMatrix(znear=0.01, zfar=999.9, K=K.numpy().astype(np.float64),
+                                                   h=H_in, w=W_in).transpose(0, 1))
+        w2v = torch.tensor(du.getWorld2View2(R_ex.numpy(), T_ex.numpy(), np.array([0.0, 0.0, 0.0]), 1.0)).transpose(0, 1)
+        full = w2v.unsqueeze(0).bmm(proj.unsqueeze(0)).squeeze(0)
+        center = w2v.inverse()[3, :3]
+        out[f'cam{cam}_K'] = K.numpy()
+        out[f'cam{cam}_c2w'] = c2w.numpy()
+        out[f'cam{cam}_fov'] = np.array([fov_x.item(), fov_y.item()], np.float64)
+        out[f'cam{cam}_projection'] = proj.numpy()
+        out[f'cam{cam}_world_view'] = w2v.numpy()
+        out[f'cam{cam}_full_proj'] = full.numpy()
+        out[f'cam{cam}_center'] = center.numpy()
+    return out
+
+
+def state_np(m, prefix):
+    return {f'{prefix}.{k}': v.detach().numpy() for k, v in m.state_dict().items()}
+
+
+def hoa_golden():
+    """HeightAttention :421-461, OpacityVoxelToBEVConverter :463-518, ObatinOpacityMask :230-242,
+    DeformableAttention2D (mmdet3d/ops/cross_attention_2d.py:93-220) and the HOA-1 glue
+    (view_transformer_ocrf.py:1159-1161) in eval mode with seeded weights."""
+    torch.manual_seed(1234)
+    out = {}
+    Y = X = 48
+    # HOA-3
+    m = vto.ObatinOpacityMask().eval()
+    x = torch.randn(2, 80, Y, X)
+    ob = torch.randn(2, 1, Y, X)
+    with torch.no_grad():
+        y = m(x, ob)
+    out.update(state_np(m, 'mask'))
+    out.update(mask_in_x=x.numpy(), mask_in_opacity=ob.numpy(), mask_out=y.numpy(),
+               mask_gated=(x * y).numpy())
+    # HeightAttention
+    for ch in (4, 8, 16):
+        m = vto.HeightAttention(ch, ch, 1).eval()
+        x = torch.randn(2, ch, 20, 28)
+        with torch.no_grad():
+            y = m(x)
+        out.update(state_np(m, f'ha{ch}'))
+        out[f'ha{ch}_in'] = x.numpy()
+        out[f'ha{ch}_out'] = y.numpy()
+    # HOA-2
+    m = vto.OpacityVoxelToBEVConverter(input_channel=13)
+    for mod in m.modules():      # non-trivial BN statistics
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.2)
+            mod.running_var.uniform_(0.5, 1.5)
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0, 0.2)
+    m.eval()
+    x = torch.rand(2, 13, Y, X)
+    pos = torch.randn(2, 4, Y, X) * 0.1
+    with torch.no_grad():
+        y = m(x, pos)
+    out.update(state_np(m, 'v2b'))
+    out.update(v2b_in=x.numpy(), v2b_pos=pos.numpy(), v2b_out=y.numpy())
+    # HOA-1: deformable cross attention on (1,13,21,21) + the interpolate glue
+    m = ca.DeformableAttention2D(dim=13, dim_head=8, heads=1, dropout=0.1, downsample_factor=4,
+                                 offset_scale=4, offset_groups=None, offset_kernel_size=6).eval()
+    q = torch.rand(1, 13, 21, 21)
+    kv = torch.rand(1, 13, 21, 21)
+    with torch.no_grad():
+        y = m(q, kv)
+    out.update(state_np(m, 'dca'))
+    out.update(dca_q=q.numpy(), dca_kv=kv.numpy(), dca_out=y.numpy())
+    Hh, Wd, Ln = 13, 128, 128
+    opacity = torch.rand(Hh * Wd * Ln, 1)
+    alpha_lidar = torch.rand(1, Hh, Wd, Ln)
+    with torch.no_grad():
+        F = torch.nn.functional
+        o_up = F.interpolate(opacity.view(1, Hh, Wd, Ln), size=(int(Wd / 6), int(Ln / 6)), mode='bilinear', align_corners=True)
+        a_up = F.interpolate(alpha_lidar, size=(int(Wd / 6), int(Ln / 6)), mode='bilinear', align_corners=True)
+        oa = F.interpolate(m(o_up, a_up), size=(Wd, Ln), mode='bilinear', align_corners=True) + opacity.view(1, Hh, Wd, Ln)
+    out.update(hoa1_opacity=opacity.numpy().astype(np.float16).astype(np.float32),
+               hoa1_alpha=alpha_lidar.numpy().astype(np.float16).astype(np.float32))
+    # store fp16-rounded inputs (exactly representable) and recompute the output from them
+    opacity = T(out['hoa1_opacity'])
+    alpha_lidar = T(out['hoa1_alpha'])
+    with torch.no_grad():
+        o_up = F.interpolate(opacity.view(1, Hh, Wd, Ln), size=(int(Wd / 6), int(Ln / 6)), mode='bilinear', align_corners=True)
+        a_up = F.interpolate(alpha_lidar, size=(int(Wd / 6), int(Ln / 6)), mode='bilinear', align_corners=True)
+        oa = F.interpolate(m(o_up, a_up), size=(Wd, Ln), mode='bilinear', align_corners=True) + opacity.view(1, Hh, Wd, Ln)
+    out['hoa1_opacity'] = out['hoa1_opacity'].astype(np.float16)
+    out['hoa1_alpha'] = out['hoa1_alpha'].astype(np.float16)
+    out['hoa1_o_up'] = o_up.numpy()
+    out['hoa1_out_slice'] = oa[:, :, ::5, ::3].contiguous().numpy()
+    out['hoa1_out_sha256'] = digest(oa.numpy())
+    return out
+
+
+def heads_golden():
+    """Gaussian parameter heads (view_transformer_ocrf.py:272-320, calls :1130-1133) and the
+    voxel lift VoxelFeatureExtractor (:520-531, call :1051)."""
+    torch.manual_seed(4321)
+    out = {}
+    n = 4096
+    feat = torch.randn(n, 80)
+    rgb = torch.rand(n, 3)
+    mods = dict(S=vto.ScaleFactorMLP(80, 4, 3), R=vto.RotationFactorMLP(80, 4, 4),
+                A=vto.OpacityFactorMLP(80, 4, 1), C=vto.ColorFactorMLPGaussian(80, 4, 3))
+    with torch.no_grad():
+        out['heads_feat'] = feat.numpy()
+        out['heads_rgb'] = rgb.numpy()
+        out['S_out'] = mods['S'](feat).numpy()
+        out['R_out'] = mods['R'](feat).numpy()
+        out['A_out'] = mods['A'](feat).numpy()
+        out['C_out'] = mods['C'](torch.cat((feat, rgb), -1)).numpy()
+    for k, m in mods.items():
+        out.update(state_np(m, k))
+    vfe = vto.VoxelFeatureExtractor()
+    bn = vfe.conv[1]
+    bn.running_mean.normal_(0, 0.2), bn.running_var.uniform_(0.5, 1.5)
+    bn.weight.data.uniform_(0.5, 1.5), bn.bias.data.normal_(0, 0.2)
+    vfe.eval()
+    bev = torch.randn(1, 80, 16, 16)
+    with torch.no_grad():
+        vox = vfe(bev.permute(0, 2, 3, 1).unsqueeze(1))
+    out.update(state_np(vfe, 'vfe'))
+    out.update(vfe_in=bev.numpy(), vfe_out=vox.numpy())
+    return out
+
+
+def color_golden():
+    """lidar_points_to_image_values :924-942, color_voxels :945-971, retain_valid_pixels
+    :1004-1024 on the 1-camera plumbing config."""
+    torch.manual_seed(99)
+    cfg = synthetic.CONFIGS['cfg0_1cam_128x352_bev64x64x4']
+    s = _Self()
+    cls = vto.OcRFViewTransformerFull
+    X, Y, _ = cfg.bev_xyz
+    r = synthetic.rig(cfg.n_cams, cfg.input_size, 1)
+    args = [T(r[k]) for k in ('rots', 'trans', 'intrins', 'post_rots', 'post_trans', 'bda')]
+    Himg, Wimg = cfg.input_size
+    imgs = torch.randint(0, 256, (1, cfg.n_cams, 3, Himg, Wimg)).float()
+    with torch.no_grad():
+        lidar2img, img_aug, _, _ = cls.get_projection(s, *args)
+        ref = cls.get_reference_points_3d(s, Y, X, bs=1, num_points_in_pillar=cfg.num_height, device='cpu')
+        coor, mask, (_, pts_cam, _) = cls.get_sampling_point(
+            s, ref, list(cfg.pc_range), cfg.grid['depth'], lidar2img, img_aug, cfg.input_size)
+        pix = pts_cam.clone()                       # (B,N,Z,Nq,2) normalised
+        pix[..., 0] *= Wimg
+        pix[..., 1] *= Himg
+        vals = cls.lidar_points_to_image_values(s, pix, imgs, mask)
+        colored, avg, valid = cls.color_voxels(s, ref, vals, mask)
+        sparse = cls.retain_valid_pixels(s, imgs, pix.view(1, cfg.n_cams, cfg.num_height, Y, X, 2),
+                                         mask.view(1, cfg.n_cams, cfg.num_height, Y, X, 1))
+    return dict(imgs=imgs.numpy().astype(np.uint8), pix=pix.numpy(), mask=mask.numpy(),
+                voxel=ref.numpy(), img_values_sha256=digest(vals.numpy()),
+                img_values_slice=vals[0, :, :, ::37].contiguous().numpy(),
+                avg_color=avg.numpy(), valid_mask=valid.numpy(),
+                sparse_sha256=digest(sparse.numpy()),
+                sparse_nkept=np.int64((sparse != 255).any(2).sum().item()),
+                sparse=sparse.numpy().astype(np.uint8))
+
+
+def main():
+    random.seed(0)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    cfgs = synthetic.CONFIGS
+
+    def save(name, d):
+        path = os.path.join(HERE, name)
+        np.savez_compressed(path, **d)
+        print(f'{name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(d)} arrays')
+
+    save('lss_cfg0.npz', lss_golden(cfgs['cfg0_1cam_128x352_bev64x64x4'], full=True))
+    save('ht_cfg0.npz', ht_golden(cfgs['cfg0_1cam_128x352_bev64x64x4'], full=True))
+    for key in ('ref_6cam_256x704_bev128x128x1', 'cfg1_6cam_256x704_bev128x128x8',
+                'cfg2_6cam_2frame_bev200x200_render_hoa'):
+        tag = key.split('_')[0]
+        save(f'lss_{tag}.npz', lss_golden(cfgs[key], full=False))
+        save(f'ht_{tag}.npz', ht_golden(cfgs[key], full=False))
+    save('camera.npz', camera_golden())
+    save('hoa.npz', hoa_golden())
+    save('heads.npz', heads_golden())
+    save('color_cfg0.npz', color_golden())
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,55 @@
+"""Shared input builders for the tests (seeded, synthetic)."""
+import numpy as np
+
+from oracle import index_prep as ip
+from ocrfdet_amd import synthetic
+
+
+def lss_ranks(cfg):
+    """Reference-style LSS rank vectors for a config, from the numpy oracle."""
+    r = synthetic.rig(cfg.n_cams, cfg.input_size, cfg.batch)
+    fr = ip.create_frustum(cfg.grid['depth'], cfg.input_size, cfg.downsample)
+    coor = ip.get_lidar_coor(fr, r['rots'], r['trans'], r['intrins'], r['post_rots'], r['post_trans'], r['bda'])
+    lower = [cfg.grid[a][0] for a in 'xyz']
+    interval = [cfg.grid[a][2] for a in 'xyz']
+    return ip.voxel_pooling_prepare_v2(coor, lower, interval, cfg.bev_xyz)
+
+
+def ht_ranks(cfg):
+    r = synthetic.rig(cfg.n_cams, cfg.input_size, cfg.batch)
+    X, Y, _ = cfg.bev_xyz
+    ref = ip.get_reference_points_3d(Y, X, bs=cfg.batch, num_points_in_pillar=cfg.num_height)
+    l2i, aug = ip.get_projection(r['rots'], r['trans'], r['intrins'], r['post_rots'], r['post_trans'], r['bda'])
+    coor, mask, _ = ip.get_sampling_point(ref, cfg.pc_range, cfg.grid['depth'], l2i, aug, cfg.input_size)
+    Hf, Wf = cfg.feat_hw
+    return ip.fast_sample_prepare(coor, mask, Wf, Hf, cfg.D)
+
+
+def pool_inputs(cfg, seed=0):
+    """depth (B,N,D,H,W), feat channels-last (B,N,H,W,C) as numpy float32."""
+    depth, feat = synthetic.depth_and_feat(cfg, seed)
+    B, N = cfg.batch, cfg.n_cams
+    H, W = cfg.feat_hw
+    depth = depth.numpy().reshape(B, N, cfg.D, H, W)
+    feat = np.ascontiguousarray(feat.numpy().reshape(B, N, cfg.channels, H, W).transpose(0, 1, 3, 4, 2))
+    return depth, feat
+
+
+def random_pool_problem(rng, n_points, n_voxels, c, n_depth=5000, n_feat=700, skew=True):
+    """A random but valid bev_pool problem: sorted ranks_bev with (optionally skewed) interval
+    lengths, random gather indices."""
+    if skew:
+        w = rng.pareto(1.2, n_voxels) + 0.05
+    else:
+        w = np.ones(n_voxels)
+    vox = rng.choice(n_voxels, size=n_points, p=w / w.sum())
+    rb = np.sort(vox).astype(np.int32)
+    rd = rng.integers(0, n_depth, n_points).astype(np.int32)
+    rf = rng.integers(0, n_feat, n_points).astype(np.int32)
+    depth = rng.random(n_depth, dtype=np.float32)
+    feat = rng.standard_normal((n_feat, c)).astype(np.float32)
+    kept = np.ones(n_points, bool)
+    kept[1:] = rb[1:] != rb[:-1]
+    starts = np.nonzero(kept)[0].astype(np.int32)
+    lengths = np.diff(np.append(starts, n_points)).astype(np.int32)
+    return depth, feat, rd, rf, rb, starts, lengths

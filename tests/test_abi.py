@@ -1,0 +1,55 @@
+"""CPU: the C-ABI library builds/loads without a GPU and exports every symbol that
+include/ocrf_hip.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+from ocrfdet_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'ocrf_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b((?:ocrf_|bev_pool_v2)\w*)\s*\(', text)))
+
+
+def test_header_declares_entry_points():
+    syms = declared_symbols()
+    assert 'bev_pool_v2' in syms and 'bev_pool_v2_grad' in syms and 'ocrf_bev_pool_v2' in syms
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.lib()
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, f'libocrf_hip.so lacks {missing}'
+    assert b'gfx950' in lib.ocrf_version()
+
+
+def test_code_object_is_gfx950_only():
+    so = os.path.join(ROOT, 'ocrfdet_amd', 'csrc', 'libocrf_hip.so')
+    blob = open(so, 'rb').read()
+    assert b'gfx950' in blob
+    for other in (b'gfx90a', b'gfx942', b'sm_80'):
+        assert other not in blob
+
+
+def test_workspace_query_is_host_only():
+    lib = _lib.lib()
+    assert lib.ocrf_bev_pool_v2_workspace_bytes(80, 0) == 0
+    n = lib.ocrf_bev_pool_v2_workspace_bytes(80, 447232)
+    groups = (447232 + 63) // 64
+    assert n >= groups * 2 * 80 * 4 + groups * 16
+    assert lib.ocrf_bev_pool_v2_workspace_bytes(3, 1000) == 0     # scalar path needs none
+
+
+def test_ops_refuse_cpu_tensors():
+    import pytest
+    import torch
+    from ocrfdet_amd import bevpool
+    d = torch.zeros(1, 1, 2, 2, 2)
+    f = torch.zeros(1, 1, 2, 2, 4)
+    r = torch.zeros(4, dtype=torch.int32)
+    with pytest.raises(_lib.OcrfHipError):
+        bevpool.bev_pool_v2(d, f, r, r, r, (1, 1, 2, 2, 4), r[:1], r[:1])

@@ -1,0 +1,193 @@
+"""GPU parity: HIP bev_pool_v2 (through the C ABI) vs the C oracle on the same inputs.
+
+Tolerance: north_star states BEV features within 1e-4 fp32; intervals that fit one 64-point
+sub-chunk are summed in list order exactly like the reference (bit-exact), longer ones are
+re-associated (deterministically)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from ocrfdet_amd import _lib, bevpool, synthetic
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+ATOL = RTOL = 1e-4
+
+
+def _dev(a, cuda):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+
+def _run(cuda, depth, feat, rd, rf, rb, shape, st, ln):
+    out = bevpool.bev_pool_v2(_dev(depth, cuda), _dev(feat, cuda), _dev(rd, cuda), _dev(rf, cuda),
+                              _dev(rb, cuda), shape, _dev(st, cuda), _dev(ln, cuda))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def test_kat_forward_backward(cuda):
+    """The reference's own known-answer test (bev_pool.py:145-176), verbatim numbers."""
+    depth = torch.tensor([0.3, 0.4, 0.2, 0.1, 0.7, 0.6, 0.8, 0.9], device=cuda).view(1, 1, 2, 2, 2).requires_grad_()
+    feat = torch.ones(1, 1, 2, 2, 2, device=cuda).requires_grad_()
+    rd = torch.tensor([0, 4, 1, 6], dtype=torch.int32, device=cuda)
+    rf = torch.tensor([0, 0, 1, 2], dtype=torch.int32, device=cuda)
+    rb = torch.tensor([0, 0, 1, 1], dtype=torch.int32, device=cuda)
+    st, ln = bevpool.runs_of(rb)
+    bev = bevpool.bev_pool_v2(depth, feat, rd, rf, rb, (1, 1, 2, 2, 2), st, ln)
+    loss = bev.sum()
+    loss.backward()
+    assert loss.item() == pytest.approx(4.4, abs=1e-6)
+    assert torch.allclose(depth.grad.view(-1).cpu(), torch.tensor([2., 2., 0., 0., 2., 0., 2., 0.]))
+    assert torch.allclose(feat.grad.view(-1).cpu(), torch.tensor([1., 1., .4, .4, .8, .8, 0., 0.]))
+
+
+@pytest.mark.parametrize('cfg_name', ['cfg0_1cam_128x352_bev64x64x4', 'ref_6cam_256x704_bev128x128x1',
+                                      'cfg1_6cam_256x704_bev128x128x8'])
+@pytest.mark.parametrize('branch', ['lss', 'ht'])
+def test_parity_reference_shapes(cuda, oracle_lib, cfg_name, branch):
+    cfg = synthetic.CONFIGS[cfg_name]
+    depth, feat = helpers.pool_inputs(cfg)
+    X, Y, Z = cfg.bev_xyz
+    if branch == 'lss':
+        rb, rd, rf, st, ln = helpers.lss_ranks(cfg)
+        shape = (cfg.batch, Z, Y, X, cfg.channels)
+    else:
+        rb, rd, rf, st, ln = helpers.ht_ranks(cfg)
+        shape = (cfg.batch, 1, Y, X, cfg.channels)
+    want = oracle_lib.bev_pool_v2(depth, feat, rd, rf, rb, shape, st, ln)
+    got = _run(cuda, depth, feat, rd, rf, rb, shape, st, ln)
+    assert got.shape == want.shape and got.dtype == np.float32
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
+    # intervals no longer than 64 points that do not straddle a sub-chunk are bit-exact
+    short = (ln <= 64) & ((st // 64) == ((st + ln - 1) // 64))
+    vox = rb[st[short]]
+    g = got.transpose(0, 2, 3, 4, 1).reshape(-1, cfg.channels)[vox]
+    w = want.transpose(0, 2, 3, 4, 1).reshape(-1, cfg.channels)[vox]
+    np.testing.assert_array_equal(g, w)
+
+
+@pytest.mark.parametrize('c', [32, 64, 80, 128, 256, 3, 20, 512])
+def test_parity_channel_counts_and_skew(cuda, oracle_lib, c):
+    rng = np.random.default_rng(c)
+    n_vox = 2000
+    depth, feat, rd, rf, rb, st, ln = helpers.random_pool_problem(rng, 50000, n_vox, c)
+    shape = (1, 1, 1, n_vox, c)
+    d5, f5 = depth.reshape(1, 1, -1, 1, 1), feat.reshape(1, 1, 1, -1, c)
+    want = oracle_lib.bev_pool_v2(d5, f5, rd, rf, rb, shape, st, ln)
+    got = _run(cuda, d5, f5, rd, rf, rb, shape, st, ln)
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL * max(1.0, np.abs(want).max()))
+
+
+def test_edge_cases(cuda, oracle_lib):
+    rng = np.random.default_rng(7)
+    c = 80
+    # one interval covering every point (longest possible chain of partial rows)
+    depth, feat, rd, rf, rb, st, ln = helpers.random_pool_problem(rng, 10000, 1, c)
+    shape = (1, 1, 1, 4, c)
+    want = oracle_lib.bev_pool_v2(depth.reshape(1, 1, -1, 1, 1), feat.reshape(1, 1, 1, -1, c), rd, rf, rb, shape, st, ln)
+    got = _run(cuda, depth.reshape(1, 1, -1, 1, 1), feat.reshape(1, 1, 1, -1, c), rd, rf, rb, shape, st, ln)
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-3)
+    # every point its own interval; point counts around the 64 / 768 boundaries
+    for n in (1, 63, 64, 65, 767, 768, 769, 1537):
+        rb = np.arange(n, dtype=np.int32)
+        rd = rng.integers(0, 100, n).astype(np.int32)
+        rf = rng.integers(0, 50, n).astype(np.int32)
+        depth = rng.random(100, dtype=np.float32)
+        feat = rng.standard_normal((50, c)).astype(np.float32)
+        st, ln = np.arange(n, dtype=np.int32), np.ones(n, np.int32)
+        shape = (1, 1, 1, n, c)
+        want = oracle_lib.bev_pool_v2(depth.reshape(1, 1, -1, 1, 1), feat.reshape(1, 1, 1, -1, c), rd, rf, rb, shape, st, ln)
+        got = _run(cuda, depth.reshape(1, 1, -1, 1, 1), feat.reshape(1, 1, 1, -1, c), rd, rf, rb, shape, st, ln)
+        np.testing.assert_array_equal(got, want)
+    # gaps: points outside every interval are ignored (intervals need not cover the list)
+    depth, feat, rd, rf, rb, st, ln = helpers.random_pool_problem(rng, 5000, 300, c)
+    keep = np.arange(len(st)) % 3 != 1
+    want = oracle_lib.bev_pool_v2(depth.reshape(1, 1, -1, 1, 1), feat.reshape(1, 1, 1, -1, c), rd, rf, rb, (1, 1, 1, 300, c), st[keep], ln[keep])
+    got = _run(cuda, depth.reshape(1, 1, -1, 1, 1), feat.reshape(1, 1, 1, -1, c), rd, rf, rb, (1, 1, 1, 300, c), st[keep], ln[keep])
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
+
+
+def test_empty_inputs(cuda):
+    e = torch.zeros(0, dtype=torch.int32, device=cuda)
+    out = bevpool.bev_pool_v2(torch.zeros(1, 1, 2, 2, 2, device=cuda), torch.zeros(1, 1, 2, 2, 80, device=cuda),
+                              e, e, e, (1, 1, 4, 4, 80), e, e)
+    assert out.shape == (1, 80, 1, 4, 4) and float(out.abs().sum()) == 0.0
+
+
+def test_run_to_run_bitwise_reproducible(cuda):
+    cfg = synthetic.CONFIGS['ref_6cam_256x704_bev128x128x1']
+    depth, feat = helpers.pool_inputs(cfg)
+    rb, rd, rf, st, ln = helpers.lss_ranks(cfg)
+    X, Y, Z = cfg.bev_xyz
+    a = _run(cuda, depth, feat, rd, rf, rb, (1, Z, Y, X, cfg.channels), st, ln)
+    for _ in range(3):
+        b = _run(cuda, depth, feat, rd, rf, rb, (1, Z, Y, X, cfg.channels), st, ln)
+        np.testing.assert_array_equal(a, b)
+
+
+def test_linearity_and_total_mass_full_size(cuda):
+    """Size-independent properties at the headline size (6 cams, 200x200 BEV)."""
+    cfg = synthetic.CONFIGS['cfg2_6cam_2frame_bev200x200_render_hoa']
+    depth, feat = helpers.pool_inputs(cfg)
+    rb, rd, rf, st, ln = helpers.lss_ranks(cfg)
+    X, Y, Z = cfg.bev_xyz
+    shape = (1, Z, Y, X, cfg.channels)
+    a = _run(cuda, depth, feat, rd, rf, rb, shape, st, ln)
+    b = _run(cuda, depth, 2.0 * feat, rd, rf, rb, shape, st, ln)
+    np.testing.assert_array_equal(2.0 * a, b)                  # exact: scaling by 2 commutes with fp32 rounding
+    # sum over voxels of out[:, c] == sum over kept points of depth*feat[:, c]
+    tot = (depth.reshape(-1)[rd].astype(np.float64)[:, None] *
+           feat.reshape(-1, cfg.channels)[rf].astype(np.float64)).sum(0)
+    np.testing.assert_allclose(a.astype(np.float64).sum((0, 2, 3, 4)), tot, rtol=1e-5, atol=1e-3)
+    # untouched voxels stay zero
+    touched = np.zeros(Z * Y * X, bool)
+    touched[rb] = True
+    assert not a.transpose(0, 2, 3, 4, 1).reshape(-1, cfg.channels)[~touched].any()
+
+
+def test_exact_signature_entry_and_interval_checker(cuda, oracle_lib):
+    """`bev_pool_v2(c, n_intervals, ...)` with the reference's exact C signature
+    (src/bev_pool.cpp:7-9) accepts unsorted / overlapping intervals."""
+    rng = np.random.default_rng(11)
+    c = 80
+    depth, feat, rd, rf, rb, st, ln = helpers.random_pool_problem(rng, 6000, 200, c)
+    perm = rng.permutation(len(st))
+    st_p, ln_p = np.ascontiguousarray(st[perm]), np.ascontiguousarray(ln[perm])
+    want = oracle_lib.bev_pool_v2_raw(depth.reshape(1, 1, -1, 1, 1), feat.reshape(1, 1, 1, -1, c), rd, rf, rb, (1, 1, 1, 200, c), st_p, ln_p)
+    L = _lib.lib()
+    t = [_dev(x, cuda) for x in (depth, feat, rd, rf, rb, st_p, ln_p)]
+    out = torch.zeros(1, 1, 1, 200, c, device=cuda)
+    torch.cuda.synchronize()
+    L.bev_pool_v2(c, len(st_p), *[_lib.ptr(x) for x in t], _lib.ptr(out))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), want)     # same sequential order -> bit-exact
+    flag = torch.zeros(1, dtype=torch.int32, device=cuda)
+    _lib.check(L.ocrf_bev_pool_v2_check_intervals(len(st_p), 6000, _lib.ptr(t[5]), _lib.ptr(t[6]), _lib.ptr(flag),
+                                                   _lib.stream_ptr(cuda)), 'check')
+    assert int(flag.item()) & 1
+    _lib.check(L.ocrf_bev_pool_v2_check_intervals(len(st), 6000, _lib.ptr(_dev(st, cuda)), _lib.ptr(_dev(ln, cuda)),
+                                                   _lib.ptr(flag), _lib.stream_ptr(cuda)), 'check')
+    assert int(flag.item()) == 0
+    # bad arguments are reported, not launched
+    assert L.ocrf_bev_pool_v2(c, 5, 100, None, None, None, None, None, None, None, None, None,
+                              ctypes.c_size_t(0), None) != 0
+
+
+def test_backward_parity(cuda, oracle_lib):
+    cfg = synthetic.CONFIGS['cfg0_1cam_128x352_bev64x64x4']
+    depth, feat = helpers.pool_inputs(cfg)
+    rb, rd, rf, st, ln = helpers.lss_ranks(cfg)     # LSS: every depth cell appears once -> no store race
+    X, Y, Z = cfg.bev_xyz
+    shape = (1, Z, Y, X, cfg.channels)
+    rng = np.random.default_rng(5)
+    og = rng.standard_normal(shape).astype(np.float32)
+    want_d, want_f = oracle_lib.bev_pool_v2_backward(og, depth, feat, rd, rf, rb)
+    d = _dev(depth, cuda).requires_grad_()
+    f = _dev(feat, cuda).requires_grad_()
+    out = bevpool.QuickCumsumCuda.apply(d, f, _dev(rd, cuda), _dev(rf, cuda), _dev(rb, cuda), shape,
+                                        _dev(st, cuda), _dev(ln, cuda))
+    out.backward(_dev(og, cuda))
+    np.testing.assert_allclose(d.grad.cpu().numpy(), want_d, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), want_f, rtol=1e-4, atol=1e-4)
