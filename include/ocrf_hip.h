@@ -91,6 +91,27 @@ int ocrf_bev_pool_v2_grad(int c, int n_intervals, const float *out_grad, const f
                           const int *interval_lengths, float *depth_grad, float *feat_grad,
                           ocrf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Per-kernel device timer (measurement aid for bench.py; not part of the reference's surface)
+ * ------------------------------------------------------------------------------------------
+ * While a timer is armed for kernel id K, every launch of K inside the library is bracketed by
+ * a hipEvent pair recorded on the launch stream (hipExtLaunchKernelGGL), up to `capacity`
+ * launches.  ocrf_timer_read waits for the recorded pairs and returns their elapsed
+ * milliseconds.  Arming with timer == NULL disarms.  Host-side only; one armed timer at a time. */
+enum {
+  OCRF_K_BEV_POOL_FWD = 1,      /* bev_pool_fwd_chunked_kernel */
+  OCRF_K_BEV_POOL_FIXUP = 2,    /* bev_pool_fwd_fixup_kernel */
+  OCRF_K_BEV_POOL_INTERVAL = 3, /* bev_pool_interval_kernel */
+  OCRF_K_BEV_POOL_GRAD = 4,     /* bev_pool_grad_vec_kernel */
+  OCRF_K_RASTER_PREPROCESS = 10,
+  OCRF_K_RASTER_BLEND = 11
+};
+const char *ocrf_kernel_name(int kernel_id);           /* symbol as rocprofv3 prints it */
+int ocrf_timer_create(int capacity, void **timer_out); /* host pointers */
+int ocrf_timer_arm(void *timer, int kernel_id);
+int ocrf_timer_read(void *timer, float *ms_out /* host */, int capacity, int *count_out /* host */);
+int ocrf_timer_destroy(void *timer);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,16 @@ def _declare(L):
     L.ocrf_bev_pool_v2_check_intervals.argtypes = [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
     L.ocrf_bev_pool_v2_grad.restype = c_int
     L.ocrf_bev_pool_v2_grad.argtypes = [c_int, c_int] + [c_void_p] * 10 + [c_void_p]
+    L.ocrf_kernel_name.restype = ctypes.c_char_p
+    L.ocrf_kernel_name.argtypes = [c_int]
+    L.ocrf_timer_create.restype = c_int
+    L.ocrf_timer_create.argtypes = [c_int, ctypes.POINTER(c_void_p)]
+    L.ocrf_timer_arm.restype = c_int
+    L.ocrf_timer_arm.argtypes = [c_void_p, c_int]
+    L.ocrf_timer_read.restype = c_int
+    L.ocrf_timer_read.argtypes = [c_void_p, ctypes.POINTER(c_float), c_int, ctypes.POINTER(c_int)]
+    L.ocrf_timer_destroy.restype = c_int
+    L.ocrf_timer_destroy.argtypes = [c_void_p]
 
 
 def check(err, what):
@@ -102,3 +112,38 @@ class Workspace:
 
 
 workspace = Workspace()
+
+
+K_BEV_POOL_FWD, K_BEV_POOL_FIXUP, K_BEV_POOL_INTERVAL, K_BEV_POOL_GRAD = 1, 2, 3, 4
+K_RASTER_PREPROCESS, K_RASTER_BLEND = 10, 11
+
+
+class KernelTimer:
+    """Device duration of every launch of ONE kernel of the library while armed (HIP events on
+    the launch stream, ``ocrf_timer_*`` in include/ocrf_hip.h).  Used by bench.py's roofline leg."""
+
+    def __init__(self, kernel_id, capacity):
+        self.kernel_id, self.capacity = kernel_id, int(capacity)
+        self._h = ctypes.c_void_p()
+        check(lib().ocrf_timer_create(self.capacity, ctypes.byref(self._h)), 'ocrf_timer_create')
+
+    @property
+    def kernel_name(self):
+        return lib().ocrf_kernel_name(self.kernel_id).decode()
+
+    def arm(self):
+        check(lib().ocrf_timer_arm(self._h, self.kernel_id), 'ocrf_timer_arm')
+
+    def disarm(self):
+        check(lib().ocrf_timer_arm(None, 0), 'ocrf_timer_arm')
+
+    def read_ms(self):
+        buf = (ctypes.c_float * self.capacity)()
+        n = ctypes.c_int(0)
+        check(lib().ocrf_timer_read(self._h, buf, self.capacity, ctypes.byref(n)), 'ocrf_timer_read')
+        return [float(buf[i]) for i in range(n.value)]
+
+    def close(self):
+        if self._h:
+            lib().ocrf_timer_destroy(self._h)
+            self._h = ctypes.c_void_p()

@@ -17,6 +17,7 @@
 //   * the arithmetic is fp32 fmaf, like the reference's contracted `psum += f*d`.
 #include <hip/hip_runtime.h>
 
+#include "launch.h"
 #include "ocrf_hip.h"
 
 namespace {
@@ -330,9 +331,9 @@ int ocrf_bev_pool_v2(int c, int n_intervals, int n_points, const float* depth, c
     // scalar mapping of the reference; correct for every C and alignment
     const long total = (long)n_intervals * c;
     const unsigned grid = (unsigned)((total + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(bev_pool_interval_kernel, dim3(grid), dim3(kBlock), 0, stream, c,
-                       n_intervals, depth, feat, ranks_depth, ranks_feat, ranks_bev,
-                       interval_starts, interval_lengths, out);
+    ocrf::launch(OCRF_K_BEV_POOL_INTERVAL, bev_pool_interval_kernel, dim3(grid), dim3(kBlock), 0,
+                 stream, c, n_intervals, depth, feat, ranks_depth, ranks_feat, ranks_bev,
+                 interval_starts, interval_lengths, out);
     return (int)hipGetLastError();
   }
   const size_t need = ocrf_bev_pool_v2_workspace_bytes(c, n_points);
@@ -348,15 +349,16 @@ int ocrf_bev_pool_v2(int c, int n_intervals, int n_points, const float* depth, c
                                        align_up((size_t)ng * 2 * c * sizeof(float), 256));
   const unsigned grid1 = (unsigned)((n_points + BP - 1) / BP);
   const size_t lds = (size_t)(4 * BP + 2 * kBlock) * sizeof(int);
-  hipLaunchKernelGGL(bev_pool_fwd_chunked_kernel, dim3(grid1), dim3(kBlock), lds, stream, c4, gpw,
-                     n_intervals, n_points, ng, depth, reinterpret_cast<const float4*>(feat),
-                     ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths,
-                     reinterpret_cast<float4*>(out), part, meta);
+  ocrf::launch(OCRF_K_BEV_POOL_FWD, bev_pool_fwd_chunked_kernel, dim3(grid1), dim3(kBlock), lds,
+               stream, c4, gpw, n_intervals, n_points, ng, depth,
+               reinterpret_cast<const float4*>(feat), ranks_depth, ranks_feat, ranks_bev,
+               interval_starts, interval_lengths, reinterpret_cast<float4*>(out), part, meta);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
   const unsigned grid2 = (unsigned)((ng + gpb - 1) / gpb);
-  hipLaunchKernelGGL(bev_pool_fwd_fixup_kernel, dim3(grid2), dim3(kBlock), 0, stream, c4, gpw, ng,
-                     reinterpret_cast<float4*>(out), part, meta);
+  ocrf::launch(OCRF_K_BEV_POOL_FIXUP, bev_pool_fwd_fixup_kernel, dim3(grid2), dim3(kBlock), 0, stream,
+               c4, gpw, ng, reinterpret_cast<float4*>(out), static_cast<const float4*>(part),
+               static_cast<const int4*>(meta));
   return (int)hipGetLastError();
 }
 

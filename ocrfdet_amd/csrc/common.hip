@@ -1,6 +1,107 @@
-// Library identification for libocrf_hip.so.
+// Library identification and the per-kernel event timer of libocrf_hip.so.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+#include <vector>
+
+#include "launch.h"
 #include "ocrf_hip.h"
 
-extern "C" const char* ocrf_version(void) { return "ocrf_hip 0.1 gfx950"; }
+namespace {
+
+struct Timer {
+  int kernel_id = 0;
+  std::vector<hipEvent_t> start, stop;
+  int used = 0;
+};
+
+std::mutex g_mu;
+Timer* g_armed = nullptr;
+
+}  // namespace
+
+namespace ocrf {
+
+bool timer_next(int kernel_id, hipEvent_t* start, hipEvent_t* stop) {
+  if (!g_armed) return false;   // fast path: no lock when no timer is armed
+  std::lock_guard<std::mutex> lk(g_mu);
+  Timer* t = g_armed;
+  if (!t || t->kernel_id != kernel_id || t->used >= (int)t->start.size()) return false;
+  *start = t->start[t->used];
+  *stop = t->stop[t->used];
+  ++t->used;
+  return true;
+}
+
+}  // namespace ocrf
+
+extern "C" {
+
+const char* ocrf_version(void) { return "ocrf_hip 0.1 gfx950"; }
+
+const char* ocrf_kernel_name(int kernel_id) {
+  switch (kernel_id) {
+    case OCRF_K_BEV_POOL_FWD: return "bev_pool_fwd_chunked_kernel";
+    case OCRF_K_BEV_POOL_FIXUP: return "bev_pool_fwd_fixup_kernel";
+    case OCRF_K_BEV_POOL_INTERVAL: return "bev_pool_interval_kernel";
+    case OCRF_K_BEV_POOL_GRAD: return "bev_pool_grad_vec_kernel";
+    case OCRF_K_RASTER_PREPROCESS: return "raster_preprocess_kernel";
+    case OCRF_K_RASTER_BLEND: return "raster_blend_kernel";
+    default: return "";
+  }
+}
+
+int ocrf_timer_create(int capacity, void** timer_out) {
+  if (capacity <= 0 || !timer_out) return (int)hipErrorInvalidValue;
+  Timer* t = new Timer();
+  t->start.resize(capacity);
+  t->stop.resize(capacity);
+  for (int i = 0; i < capacity; ++i) {
+    hipError_t e = hipEventCreate(&t->start[i]);
+    if (e == hipSuccess) e = hipEventCreate(&t->stop[i]);
+    if (e != hipSuccess) { delete t; return (int)e; }
+  }
+  *timer_out = t;
+  return 0;
+}
+
+int ocrf_timer_arm(void* timer, int kernel_id) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  Timer* t = static_cast<Timer*>(timer);
+  if (t) { t->kernel_id = kernel_id; t->used = 0; }
+  g_armed = t;
+  return 0;
+}
+
+int ocrf_timer_read(void* timer, float* ms_out, int capacity, int* count_out) {
+  Timer* t = static_cast<Timer*>(timer);
+  if (!t || !count_out) return (int)hipErrorInvalidValue;
+  int n = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    n = t->used;
+  }
+  if (n > capacity) n = capacity;
+  for (int i = 0; i < n; ++i) {
+    hipError_t e = hipEventSynchronize(t->stop[i]);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms_out[i], t->start[i], t->stop[i]);
+    if (e != hipSuccess) return (int)e;
+  }
+  *count_out = n;
+  return 0;
+}
+
+int ocrf_timer_destroy(void* timer) {
+  Timer* t = static_cast<Timer*>(timer);
+  if (!t) return 0;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_armed == t) g_armed = nullptr;
+  }
+  for (auto e : t->start) (void)hipEventDestroy(e);
+  for (auto e : t->stop) (void)hipEventDestroy(e);
+  delete t;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,26 @@
+// Internal launch helper shared by the .hip files: a plain hipLaunchKernelGGL unless a kernel
+// timer (ocrf_timer_*, include/ocrf_hip.h) is armed for this kernel id, in which case the launch
+// is bracketed by a hipEvent pair on the launch stream (hipExtLaunchKernelGGL), so bench.py can
+// read the exact device duration of one kernel inside its timed region.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include "ocrf_hip.h"
+
+namespace ocrf {
+
+bool timer_next(int kernel_id, hipEvent_t* start, hipEvent_t* stop);
+
+template <typename F, typename... Args>
+inline void launch(int kernel_id, F kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream,
+                   Args... args) {
+  hipEvent_t a = nullptr, b = nullptr;
+  if (timer_next(kernel_id, &a, &b)) {
+    hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)lds, stream, a, b, 0, args...);
+  } else {
+    hipLaunchKernelGGL(kernel, grid, block, (unsigned)lds, stream, args...);
+  }
+}
+
+}  // namespace ocrf

@@ -1,0 +1,108 @@
+"""The hot path as one object: cached index preparation + LSS pool + HT pool (+ render + HOA).
+
+This is the build's analogue of ``OcRFViewTransformerFull.view_transform_core``
+(mmdet3d/models/necks/view_transformer_ocrf.py:1040-1201) restricted to the custom-kernel stages,
+with the rank vectors pre-computed once per calibration as the reference's ``accelerate=True``
+path intends (``pre_compute``, view_transformer_ocrf.py:854-866).  ``bench.py``,
+``__graft_entry__.smoke()`` and the sharded runner drive it; frames are treated as extra batch
+entries because they are independent until the channel concat (detectors/ocrfdet.py:274).
+"""
+import torch
+
+from . import bevpool, index_prep, synthetic
+
+
+class PoolPlan:
+    """Rank vectors of one bev_pool_v2 call, resident on the device."""
+
+    def __init__(self, ranks_bev, ranks_depth, ranks_feat, starts, lengths, bev_shape):
+        self.ranks_bev, self.ranks_depth, self.ranks_feat = ranks_bev, ranks_depth, ranks_feat
+        self.starts, self.lengths = starts, lengths
+        self.bev_shape = tuple(int(v) for v in bev_shape)      # (B, Z, Y, X, C)
+
+    @property
+    def n_points(self):
+        return int(self.ranks_bev.numel())
+
+    @property
+    def n_intervals(self):
+        return int(self.starts.numel())
+
+    def algorithmic_bytes(self, depth_numel, feat_numel):
+        """4*(depth + feat + 3*Np + 2*Nv + B*Z*Y*X*C)."""
+        out = 1
+        for v in self.bev_shape:
+            out *= v
+        return 4 * (depth_numel + feat_numel + 3 * self.n_points + 2 * self.n_intervals + out)
+
+
+class HotPath:
+    def __init__(self, cfg, device, cams=None):
+        """``cams``: optional list of camera indices this instance owns (camera sharding)."""
+        self.cfg, self.device = cfg, torch.device(device)
+        self.cams = list(range(cfg.n_cams)) if cams is None else list(cams)
+        self.batch = cfg.batch * cfg.n_frames                  # frames ride along as batch entries
+        self._prepare()
+
+    def _prepare(self):
+        cfg, dev = self.cfg, self.device
+        r = synthetic.rig(cfg.n_cams, cfg.input_size, self.batch)
+        sel = self.cams
+        g = {k: torch.from_numpy(r[k][:, sel] if r[k].ndim >= 3 and k != 'bda' else r[k]).to(dev)
+             for k in ('rots', 'trans', 'intrins', 'post_rots', 'post_trans', 'bda', 'c2w')}
+        self.geom = g
+        args = [g[k] for k in ('rots', 'trans', 'intrins', 'post_rots', 'post_trans', 'bda')]
+        X, Y, Z = cfg.bev_xyz
+        Hf, Wf = cfg.feat_hw
+        C = cfg.channels
+        # LSS branch (view_transformer.py:108-147,197-255)
+        frustum = index_prep.create_frustum(cfg.grid['depth'], cfg.input_size, cfg.downsample)
+        coor = index_prep.get_lidar_coor(frustum, *args)
+        lower, interval, size = index_prep.grid_infos(cfg.grid)
+        self.lss = PoolPlan(*self._or_empty(index_prep.voxel_pooling_prepare_v2(coor, lower, interval, size)),
+                            (self.batch, Z, Y, X, C))
+        del coor
+        # HT branch (view_transformer_ocrf.py:651-852)
+        lidar2img, img_aug, _, _ = index_prep.get_projection(*args)
+        ref = index_prep.get_reference_points_3d(Y, X, bs=self.batch, num_points_in_pillar=cfg.num_height,
+                                                 device=dev)
+        coor, mask, _ = index_prep.get_sampling_point(ref, list(cfg.pc_range), cfg.grid['depth'],
+                                                      lidar2img, img_aug, cfg.input_size)
+        self.voxel_xyz = ref                                    # metric voxel centres (B, Zh, Y*X, 3)
+        self.ht = PoolPlan(*self._or_empty(index_prep.fast_sample_prepare(coor, mask, Wf, Hf, cfg.D)),
+                           (self.batch, 1, Y, X, C))
+
+    def _or_empty(self, five):
+        if five[0] is None:
+            e = torch.zeros(0, dtype=torch.int32, device=self.device)
+            return e, e, e, e, e
+        return five
+
+    def make_inputs(self, seed=0):
+        """depth (B, N, D, H, W), feat (B, N, H, W, C) channels-last, on the device."""
+        cfg = self.cfg
+        full = synthetic.PathConfig(**{**cfg.__dict__, 'batch': self.batch})
+        depth, feat = synthetic.depth_and_feat(full, seed)
+        Hf, Wf = cfg.feat_hw
+        depth = depth.view(self.batch, cfg.n_cams, cfg.D, Hf, Wf)[:, self.cams].contiguous()
+        feat = feat.view(self.batch, cfg.n_cams, cfg.channels, Hf, Wf)[:, self.cams]
+        feat = feat.permute(0, 1, 3, 4, 2).contiguous()
+        return depth.to(self.device), feat.to(self.device)
+
+    def pool(self, plan, depth, feat):
+        return bevpool.bev_pool_v2(depth, feat, plan.ranks_depth, plan.ranks_feat, plan.ranks_bev,
+                                   plan.bev_shape, plan.starts, plan.lengths)
+
+    def step(self, depth, feat):
+        """One pass: LSS BEV (B, C*Z, Y, X) and HT BEV (B, C, Y, X) (view_transformer.py:194,
+        view_transformer_ocrf.py:781)."""
+        lss = self.pool(self.lss, depth, feat)
+        lss = torch.cat(lss.unbind(dim=2), 1)
+        ht = self.pool(self.ht, depth, feat)
+        ht = torch.cat(ht.unbind(dim=2), 1)
+        return lss, ht
+
+    @property
+    def bev_voxels_per_step(self):
+        X, Y, Z = self.cfg.bev_xyz
+        return self.batch * Z * Y * X
