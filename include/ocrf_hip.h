@@ -77,6 +77,28 @@ int ocrf_bev_pool_v2(int c, int n_intervals, int n_points, const float *depth, c
 size_t ocrf_bev_pool_v2_workspace_bytes(int c, int n_points);
 
 /*
+ * Fused forward: ocrf_bev_pool_v2 + the layout passes the reference runs after it.  Writes EVERY
+ * element of `out` (empty voxels as 0), so `out` needs no pre-zeroing, directly in channel-major
+ * order:
+ *   layout 0: out[b][c][z][y][x]      == bev_pool_v2(...) of the reference, i.e. the op's
+ *                                        permute(0,4,1,2,3).contiguous() (bev_pool.py:91);
+ *   layout 1: out[b][z*C + c][y][x]   == torch.cat(bev_feat.unbind(dim=2), 1), what
+ *                                        voxel_pooling_v2 / fast_sampling return
+ *                                        (view_transformer.py:194, view_transformer_ocrf.py:781).
+ * (B,Z,Y,X) is the reference's bev_feat_shape without C.  Needs C % 4 == 0, 32 <= C <= 256 and
+ * the interval precondition of ocrf_bev_pool_v2; ranks_bev values must be < B*Z*Y*X.
+ * workspace >= ocrf_bev_pool_v2_nchw_workspace_bytes(c, n_intervals, n_points, B*Z*Y*X).
+ */
+int ocrf_bev_pool_v2_nchw(int c, int n_intervals, int n_points, const float *depth,
+                          const float *feat, const int *ranks_depth, const int *ranks_feat,
+                          const int *ranks_bev, const int *interval_starts,
+                          const int *interval_lengths, float *out, int B, int Z, int Y, int X,
+                          int layout, void *workspace, size_t workspace_bytes,
+                          ocrf_stream_t stream);
+
+size_t ocrf_bev_pool_v2_nchw_workspace_bytes(int c, int n_intervals, int n_points, long n_voxels);
+
+/*
  * Writes *flag (device int) = 0 if interval_starts/lengths satisfy the precondition of
  * ocrf_bev_pool_v2 for n_points points, else a non-zero bit mask
  * (1: not ascending / overlapping, 2: interval exceeds n_points, 4: negative start or length).
@@ -103,6 +125,7 @@ enum {
   OCRF_K_BEV_POOL_FIXUP = 2,    /* bev_pool_fwd_fixup_kernel */
   OCRF_K_BEV_POOL_INTERVAL = 3, /* bev_pool_interval_kernel */
   OCRF_K_BEV_POOL_GRAD = 4,     /* bev_pool_grad_vec_kernel */
+  OCRF_K_BEV_POOL_NCHW = 5,     /* bev_pool_rows_to_nchw_kernel */
   OCRF_K_RASTER_PREPROCESS = 10,
   OCRF_K_RASTER_BLEND = 11
 };

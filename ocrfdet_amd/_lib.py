@@ -57,6 +57,11 @@ def _declare(L):
     L.ocrf_bev_pool_v2.argtypes = [c_int, c_int, c_int] + [c_void_p] * 8 + [c_void_p, c_size_t, c_void_p]
     L.ocrf_bev_pool_v2_workspace_bytes.restype = c_size_t
     L.ocrf_bev_pool_v2_workspace_bytes.argtypes = [c_int, c_int]
+    L.ocrf_bev_pool_v2_nchw.restype = c_int
+    L.ocrf_bev_pool_v2_nchw.argtypes = ([c_int, c_int, c_int] + [c_void_p] * 8 + [c_int] * 5 +
+                                        [c_void_p, c_size_t, c_void_p])
+    L.ocrf_bev_pool_v2_nchw_workspace_bytes.restype = c_size_t
+    L.ocrf_bev_pool_v2_nchw_workspace_bytes.argtypes = [c_int, c_int, c_int, ctypes.c_long]
     L.ocrf_bev_pool_v2_check_intervals.restype = c_int
     L.ocrf_bev_pool_v2_check_intervals.argtypes = [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
     L.ocrf_bev_pool_v2_grad.restype = c_int
@@ -114,7 +119,7 @@ class Workspace:
 workspace = Workspace()
 
 
-K_BEV_POOL_FWD, K_BEV_POOL_FIXUP, K_BEV_POOL_INTERVAL, K_BEV_POOL_GRAD = 1, 2, 3, 4
+K_BEV_POOL_FWD, K_BEV_POOL_FIXUP, K_BEV_POOL_INTERVAL, K_BEV_POOL_GRAD, K_BEV_POOL_NCHW = 1, 2, 3, 4, 5
 K_RASTER_PREPROCESS, K_RASTER_BLEND = 10, 11
 
 

@@ -24,7 +24,8 @@ import torch
 
 from . import _lib
 
-__all__ = ['bev_pool_v2', 'TRTBEVPoolv2', 'QuickCumsumCuda', 'bev_pool_v2_ext', 'runs_of']
+__all__ = ['bev_pool_v2', 'bev_pool_v2_collapsed', 'TRTBEVPoolv2', 'QuickCumsumCuda',
+           'bev_pool_v2_ext', 'runs_of']
 
 
 def _want(t, dtype, name):
@@ -142,11 +143,88 @@ class QuickCumsumCuda(torch.autograd.Function):
         return g_depth, g_feat, None, None, None, None, None, None
 
 
+def _fusable(channels):
+    return channels % 4 == 0 and 32 <= channels <= 256
+
+
+class _FusedPool(torch.autograd.Function):
+    """bev_pool_v2 + the reference's layout passes in one go (C ABI ``ocrf_bev_pool_v2_nchw``):
+    ``layout`` 0 -> (B,C,Z,Y,X) (bev_pool.py:91), 1 -> (B,Z*C,Y,X) (view_transformer.py:194).
+    The output is written exactly once (no zero-fill, no permute, no cat)."""
+
+    @staticmethod
+    def forward(ctx, depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape,
+                interval_starts, interval_lengths, layout):
+        rb = ranks_bev.int().contiguous()
+        rd = ranks_depth.int().contiguous()
+        rf = ranks_feat.int().contiguous()
+        d32 = depth.float().contiguous()
+        f32 = feat.float().contiguous()
+        starts = interval_starts.int().contiguous()
+        lengths = interval_lengths.int().contiguous()
+        _lib.require_cuda(d32, f32, rb, rd, rf, starts, lengths)
+        B, Z, Y, X, C = (int(v) for v in bev_feat_shape)
+        if f32.size(-1) != C:
+            raise _lib.OcrfHipError(f'feat has {f32.size(-1)} channels, bev_feat_shape says {C}')
+        n_iv, n_pts = starts.numel(), rd.numel()
+        if rf.numel() != n_pts or rb.numel() != n_pts or lengths.numel() != n_iv:
+            raise _lib.OcrfHipError('rank / interval vectors disagree in length')
+        dev = d32.device
+        out = torch.empty((B, C, Z, Y, X) if layout == 0 else (B, Z * C, Y, X),
+                          dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            need = L.ocrf_bev_pool_v2_nchw_workspace_bytes(C, n_iv, n_pts, B * Z * Y * X)
+            scratch = _lib.workspace.get(dev, need, 'bev_pool_nchw')
+            _lib.check(L.ocrf_bev_pool_v2_nchw(
+                C, n_iv, n_pts, _lib.ptr(d32), _lib.ptr(f32), _lib.ptr(rd), _lib.ptr(rf),
+                _lib.ptr(rb), _lib.ptr(starts), _lib.ptr(lengths), _lib.ptr(out), B, Z, Y, X,
+                int(layout), _lib.ptr(scratch), ctypes.c_size_t(scratch.numel()),
+                _lib.stream_ptr(dev)), 'ocrf_bev_pool_v2_nchw')
+        ctx.save_for_backward(rb, d32, f32, rf, rd)
+        ctx.geom = (B, Z, Y, X, C, int(layout))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        rb, d32, f32, rf, rd = ctx.saved_tensors
+        B, Z, Y, X, C, layout = ctx.geom
+        if layout == 0:
+            g = grad_out.permute(0, 2, 3, 4, 1)                       # (B,Z,Y,X,C)
+        else:
+            g = grad_out.view(B, Z, C, Y, X).permute(0, 1, 3, 4, 2)
+        rf_sorted, perm = torch.sort(rf, stable=True)
+        starts_bp, lengths_bp = runs_of(rf_sorted)
+        g_depth = torch.zeros_like(d32)
+        g_feat = torch.zeros_like(f32)
+        bev_pool_v2_ext.bev_pool_v2_backward(
+            g.contiguous().float(), g_depth, g_feat, d32, f32, rd[perm].contiguous(),
+            rf_sorted.contiguous(), rb[perm].contiguous(), lengths_bp, starts_bp)
+        return g_depth, g_feat, None, None, None, None, None, None, None
+
+
 def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev,
                 bev_feat_shape, interval_starts, interval_lengths):
+    """The reference's op: -> (B, C, Z, Y, X) contiguous fp32 (bev_pool.py:86-92)."""
+    if _fusable(int(bev_feat_shape[-1])):
+        return _FusedPool.apply(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape,
+                                interval_starts, interval_lengths, 0)
     pooled = QuickCumsumCuda.apply(depth, feat, ranks_depth, ranks_feat, ranks_bev,
                                    bev_feat_shape, interval_starts, interval_lengths)
     return pooled.permute(0, 4, 1, 2, 3).contiguous()        # (B,Z,Y,X,C) -> (B,C,Z,Y,X)
+
+
+def bev_pool_v2_collapsed(depth, feat, ranks_depth, ranks_feat, ranks_bev,
+                          bev_feat_shape, interval_starts, interval_lengths):
+    """``torch.cat(bev_pool_v2(...).unbind(dim=2), 1)`` -> (B, Z*C, Y, X), the tensor
+    ``voxel_pooling_v2`` / ``fast_sampling`` hand on (view_transformer.py:190-195,
+    view_transformer_ocrf.py:776-782), produced without the intermediate copies."""
+    if _fusable(int(bev_feat_shape[-1])):
+        return _FusedPool.apply(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape,
+                                interval_starts, interval_lengths, 1)
+    x = bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape,
+                    interval_starts, interval_lengths)
+    return torch.cat(x.unbind(dim=2), 1)
 
 
 class TRTBEVPoolv2(torch.autograd.Function):

@@ -24,7 +24,8 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
-constexpr int kSub = 64;  // S: points per lane group
+constexpr int kSubDefault = 32;  // S: points per lane group (tunable: ocrf_tune_set(0, 32|64))
+int g_sub = kSubDefault;
 
 __device__ __forceinline__ float4 fma4(float4 f, float d, float4 a) {
   a.x = fmaf(f.x, d, a.x);
@@ -60,35 +61,83 @@ __global__ __launch_bounds__(kBlock) void bev_pool_interval_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // Load-balanced forward, pass 1.
-//   c4   = C/4 (lanes per group), gpw = 64/c4 groups per wave, gpb = 4*gpw groups per block.
-//   part = workspace rows [2*n_groups][c4] float4: row 2g = head partial, 2g+1 = tail partial.
-//   meta = workspace [n_groups] int4 {head: 0 none / 1 ends here / 2 runs through,
-//                                     tail: 0/1, tail_row: ranks_bev of the tail interval, 0}.
-// Dynamic LDS: s_rd[BP] s_rf[BP] s_st[BP+256] s_ln[BP+256], BP = gpb*kSub.
+//   c4  = C/4 lanes per group, gpw = 64/c4 groups per wave, gpb = 4*gpw groups per block,
+//   BP  = gpb*kSub points per block.
+//   dst = row-addressed float4 output: row r, lane lg -> dst[r*c4 + lg].  The row of interval j
+//         is ranks_bev[start_j] (scatter into the (B,Z,Y,X,C) tensor, the reference's contract)
+//         or, with compact_rows, the interval's own index (dense [n_intervals][C] table that the
+//         NCHW epilogue consumes).
+//   part = workspace rows [2*n_blocks][c4] float4: 2b = block head partial, 2b+1 = tail partial.
+//   bmeta = workspace [n_blocks] int4 {head: 0 none / 1 ends in this block / 2 runs through,
+//                                      tail: 0/1, tail_row, 0}.
+// Phases: (1) stage per-point {depth weight, code} and the feat row index in LDS; (2) 256-ary
+// cooperative search for the first interval of the block; (3) stage the block's intervals;
+// (3b) one thread per interval marks the LAST point of each of its pieces (a piece = interval
+// /\ sub-chunk) with an emit code, zeroes the weight of points outside every interval and fills
+// the per-sub-chunk head/tail table; (4) each lane group walks its kSub points branch-free —
+// acc = fma(feat_row, w, acc); on a marked point it emits acc and restarts — with the row gathers
+// of the next 8 points in flight while 8 are consumed; (5) pieces of intervals cut by sub-chunk
+// borders are combined through LDS in ascending order, pieces cut by BLOCK borders go to `part`.
+// Dynamic LDS: int2 s_wc[BP] {w bits, code}; int s_rf[BP] s_st[BP+256] s_ln[BP+256]
+//              s_row[BP+256] s_meta[4*gpb]; float4 s_part[2*gpb][c4].
+// code: 1 | (local interval index << 2) = last point of a whole interval -> store to its dst
+// row; 2 = last point of a head piece -> keep in a register; tail pieces are the leftover.
 // ---------------------------------------------------------------------------------------------
+struct Batch {
+  float4 v[8];
+  int2 wc[8];
+};
+
+__device__ __forceinline__ void load_batch(Batch& q, int l0, const int* s_rf, const int2* s_wc,
+                                           const float4* __restrict__ feat4, int c4, int lg) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) q.v[k] = feat4[(long)s_rf[l0 + k] * c4 + lg];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) q.wc[k] = s_wc[l0 + k];
+}
+
+template <bool STAMP, int kSub>
 __global__ __launch_bounds__(kBlock) void bev_pool_fwd_chunked_kernel(
-    int c4, int gpw, int n_intervals, int n_points, int n_groups, const float* __restrict__ depth,
-    const float4* __restrict__ feat4, const int* __restrict__ ranks_depth,
-    const int* __restrict__ ranks_feat, const int* __restrict__ ranks_bev,
-    const int* __restrict__ interval_starts, const int* __restrict__ interval_lengths,
-    float4* __restrict__ out4, float4* __restrict__ part, int4* __restrict__ meta) {
-  extern __shared__ int smem[];
+    unsigned long long* __restrict__ stamps,
+    int c4, int gpw, int n_intervals, int n_points, int compact_rows,
+    const float* __restrict__ depth, const float4* __restrict__ feat4,
+    const int* __restrict__ ranks_depth, const int* __restrict__ ranks_feat,
+    const int* __restrict__ ranks_bev, const int* __restrict__ interval_starts,
+    const int* __restrict__ interval_lengths, float4* __restrict__ dst, float4* __restrict__ part,
+    int4* __restrict__ bmeta, int* __restrict__ row_of_vox) {
+  extern __shared__ __attribute__((aligned(16))) int smem[];
   const int tid = threadIdx.x;
   const int gpb = gpw * (kBlock / kWave);
   const int BP = gpb * kSub;
-  int* s_rd = smem;
-  int* s_rf = s_rd + BP;
+  int2* s_wc = reinterpret_cast<int2*>(smem);              // {float bits of depth weight, code}
+  int* s_rf = smem + 2 * BP;
   int* s_st = s_rf + BP;
   int* s_ln = s_st + BP + kBlock;
+  int* s_row = s_ln + BP + kBlock;
+  int* s_meta = s_row + BP + kBlock;                       // [gpb][4]: head, tail, tail_j, -
+  float4* s_part = reinterpret_cast<float4*>(s_meta + 4 * gpb);   // [2*gpb][c4]
 
   const int bs = blockIdx.x * BP;             // first point of this block
   const int be = min(bs + BP, n_points);      // one past its last point
+  auto stamp = [&](int slot) {
+    if constexpr (STAMP) {
+      if (tid == 0) stamps[(long)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memtime();
+    }
+  };
+  stamp(0);
 
-  // (1) stage the rank pairs of the block's points (coalesced).
-  for (int i = tid; i < be - bs; i += kBlock) {
-    s_rd[i] = ranks_depth[bs + i];
-    s_rf[i] = ranks_feat[bs + i];
+  // (1) stage the block's points (coalesced index reads, one depth gather per point).
+  for (int i = tid; i < BP; i += kBlock) {
+    float w = 0.f;
+    int rf = 0;
+    if (bs + i < be) {
+      w = depth[ranks_depth[bs + i]];
+      rf = ranks_feat[bs + i];
+    }
+    s_wc[i] = make_int2(__float_as_int(w), 0);
+    s_rf[i] = rf;
   }
+  if (tid < 4 * gpb) s_meta[tid] = 0;
 
   // (2) cooperative 256-ary search: k_lo = last interval with start <= bs (0 if none).
   int lo = 0, hi = n_intervals;
@@ -104,6 +153,7 @@ __global__ __launch_bounds__(kBlock) void bev_pool_fwd_chunked_kernel(
     lo = nlo;
   }
   const int k_lo = lo;
+  stamp(1);
 
   // (3) stage the intervals that can overlap [bs, be): at most BP+1 of them (lengths >= 1).
   const int ni_max = min(BP + 1, n_intervals - k_lo);
@@ -111,100 +161,236 @@ __global__ __launch_bounds__(kBlock) void bev_pool_fwd_chunked_kernel(
   for (int base = 0; base < ni_max; base += kBlock) {
     const int t = base + tid;
     if (t < ni_max) {
-      s_st[t] = interval_starts[k_lo + t];
+      const int st = interval_starts[k_lo + t];
+      s_st[t] = st;
       s_ln[t] = interval_lengths[k_lo + t];
+      const int vox = ranks_bev[st];
+      s_row[t] = compact_rows ? (k_lo + t) : vox;
+      // the block in which an interval starts publishes voxel -> row (+1; 0 = empty voxel)
+      if (compact_rows && st >= bs && st < be) row_of_vox[vox] = k_lo + t + 1;
     }
     __syncthreads();
     n_loaded = min(base + kBlock, ni_max);
     if (s_st[n_loaded - 1] >= be) break;   // uniform: everything after starts past the block
   }
   __syncthreads();
+  stamp(2);
 
-  // (4) one lane group per sub-chunk.
+  // (3b) mark piece ends, zero the weights of uncovered points, fill the sub-chunk table.
+  const bool exhausted = (k_lo + n_loaded >= n_intervals);
+  for (int t = tid; t < n_loaded; t += kBlock) {
+    const int is = s_st[t];
+    const int ie = is + s_ln[t];
+    if (t == 0) {
+      for (int q = bs; q < min(is, be); ++q) s_wc[q - bs].x = 0;          // before the first interval
+    }
+    const int nis = (t + 1 < n_loaded) ? s_st[t + 1] : (exhausted ? 0x7fffffff : be);
+    for (int q = max(ie, bs); q < min(nis, be); ++q) s_wc[q - bs].x = 0;   // gap after this one
+    const int plo = max(is, bs), phi = min(ie, be);
+    if (plo >= phi) continue;
+    const int g0 = (plo - bs) / kSub, g1 = (phi - 1 - bs) / kSub;
+    for (int g = g0; g <= g1; ++g) {
+      const int sg = bs + g * kSub;
+      const int eg = min(sg + kSub, be);
+      const int pb = min(ie, eg);                  // one past the piece's last point
+      const bool before = is < sg, after = ie > eg;
+      // whole interval -> 1, head piece -> 2; a tail piece is whatever is left in the
+      // accumulator when the sub-chunk ends, so it needs no mark
+      if (!before && !after) s_wc[pb - 1 - bs].y = 1 | (t << 2);
+      else if (before) s_wc[pb - 1 - bs].y = 2;
+      if (before) {
+        s_meta[4 * g + 0] = after ? 2 : 1;
+      } else if (after) {
+        s_meta[4 * g + 1] = 1;
+        s_meta[4 * g + 2] = t;
+      }
+    }
+  }
+  __syncthreads();
+
+  // (4) one lane group per sub-chunk, branch-free accumulate with marked emits.
   const int wave = tid / kWave, lane = tid % kWave;
   const int gi = lane / c4, lg = lane % c4;
-  if (gi >= gpw) return;
   const int gb = wave * gpw + gi;
-  const int gid = blockIdx.x * gpb + gb;
-  if (gid >= n_groups) return;
-  const int s = gid * kSub;
-  const int e = min(s + kSub, n_points);
+  const int s = bs + gb * kSub;
+  const bool active = (gi < gpw) && (s < be);
 
-  // last staged interval with start <= s (or 0)
-  int j0 = 0;
-  {
-    int a = 0, b = n_loaded;   // invariant: answer in [a, b)
-    while (b - a > 1) {
-      const int m = (a + b) >> 1;
-      if (s_st[m] <= s) a = m; else b = m;
-    }
-    j0 = a;
-  }
-
-  int head = 0, tail = 0, tail_row = 0;
-  for (int j = j0; j < n_loaded; ++j) {
-    const int is = s_st[j];
-    if (is >= e) break;
-    const int ie = is + s_ln[j];
-    const int a = max(is, s), b = min(ie, e);
-    if (a >= b) continue;
+  if (active) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    int p = a - bs;
-    const int pe = b - bs;
-    for (; p + 4 <= pe; p += 4) {
-      const int d0 = s_rd[p], d1 = s_rd[p + 1], d2 = s_rd[p + 2], d3 = s_rd[p + 3];
-      const int f0 = s_rf[p], f1 = s_rf[p + 1], f2 = s_rf[p + 2], f3 = s_rf[p + 3];
-      const float w0 = depth[d0], w1 = depth[d1], w2 = depth[d2], w3 = depth[d3];
-      const float4 v0 = feat4[(long)f0 * c4 + lg];
-      const float4 v1 = feat4[(long)f1 * c4 + lg];
-      const float4 v2 = feat4[(long)f2 * c4 + lg];
-      const float4 v3 = feat4[(long)f3 * c4 + lg];
-      acc = fma4(v0, w0, acc);
-      acc = fma4(v1, w1, acc);
-      acc = fma4(v2, w2, acc);
-      acc = fma4(v3, w3, acc);
+    float4 head_acc = acc;
+    auto consume = [&](const Batch& q, int l0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int2 wc = q.wc[k];
+        acc = fma4(q.v[k], __int_as_float(wc.x), acc);
+        const int code = wc.y;
+        // the only memory operation in the loop is this global store: an LDS store here would
+        // make hipcc merge both into one flat store, whose wait drains the gathers in flight
+        if (code & 1) dst[(long)s_row[code >> 2] * c4 + lg] = acc;
+        const bool is_head = code == 2;
+        head_acc.x = is_head ? acc.x : head_acc.x;
+        head_acc.y = is_head ? acc.y : head_acc.y;
+        head_acc.z = is_head ? acc.z : head_acc.z;
+        head_acc.w = is_head ? acc.w : head_acc.w;
+        acc.x = code ? 0.f : acc.x;
+        acc.y = code ? 0.f : acc.y;
+        acc.z = code ? 0.f : acc.z;
+        acc.w = code ? 0.f : acc.w;
+      }
+    };
+    Batch A, B;
+    const int l0 = gb * kSub;
+    load_batch(A, l0, s_rf, s_wc, feat4, c4, lg);
+#pragma unroll
+    for (int b = 0; b < kSub / 8; b += 2) {
+      load_batch(B, l0 + 8 * (b + 1), s_rf, s_wc, feat4, c4, lg);
+      consume(A, l0 + 8 * b);
+      if (b + 2 < kSub / 8) load_batch(A, l0 + 8 * (b + 2), s_rf, s_wc, feat4, c4, lg);
+      consume(B, l0 + 8 * (b + 1));
     }
-    for (; p < pe; ++p) {
-      const float w = depth[s_rd[p]];
-      const float4 v = feat4[(long)s_rf[p] * c4 + lg];
-      acc = fma4(v, w, acc);
+    s_part[(2 * gb) * c4 + lg] = head_acc;       // head piece (meaningful iff s_meta says so)
+    s_part[(2 * gb + 1) * c4 + lg] = acc;        // tail piece: what the last interval left
+  }
+  stamp(3);
+  __syncthreads();
+  stamp(4);
+
+  // (5) combine the pieces of intervals cut by sub-chunk borders, in ascending sub-chunk order.
+  if (!active) return;
+  const int n_gb = (be - bs + kSub - 1) / kSub;    // sub-chunks in use in this block
+  const int head = s_meta[4 * gb + 0], tail = s_meta[4 * gb + 1], tail_j = s_meta[4 * gb + 2];
+  if (tail) {
+    float4 acc = s_part[(2 * gb + 1) * c4 + lg];
+    for (int g2 = gb + 1; g2 < n_gb; ++g2) {
+      const int h = s_meta[4 * g2];
+      if (h == 0) break;
+      const float4 v = s_part[(2 * g2) * c4 + lg];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      if (h == 1) break;
     }
-    const bool before = is < s, after = ie > e;
-    if (!before && !after) {
-      out4[(long)ranks_bev[is] * c4 + lg] = acc;
-    } else if (before) {
-      part[(long)(2 * gid) * c4 + lg] = acc;
-      head = after ? 2 : 1;
+    const int row = s_row[tail_j];
+    if (s_st[tail_j] + s_ln[tail_j] > be) {         // runs past the block: leave a block tail
+      part[(long)(2 * blockIdx.x + 1) * c4 + lg] = acc;
+      if (lg == 0) { bmeta[blockIdx.x].y = 1; bmeta[blockIdx.x].z = row; }
     } else {
-      part[(long)(2 * gid + 1) * c4 + lg] = acc;
-      tail = 1;
-      tail_row = ranks_bev[is];
+      dst[(long)row * c4 + lg] = acc;
     }
   }
-  if (lg == 0) meta[gid] = make_int4(head, tail, tail_row, 0);
+  if (gb == 0) {
+    int btype = 0;
+    if (head) {
+      float4 acc = s_part[lg];
+      btype = head;
+      if (head == 2) {
+        for (int g2 = 1; g2 < n_gb; ++g2) {
+          const int h = s_meta[4 * g2];
+          if (h == 0) { btype = 1; break; }
+          const float4 v = s_part[(2 * g2) * c4 + lg];
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+          if (h == 1) { btype = 1; break; }
+        }
+      }
+      part[(long)(2 * blockIdx.x) * c4 + lg] = acc;
+    }
+    if (lg == 0) {
+      bmeta[blockIdx.x].x = btype;
+      // exactly one writer of the tail flag: the owner of an interval running past `be` (above)
+      // or, when there is none, this lane
+      bool open = false;
+      for (int g2 = 0; g2 < n_gb; ++g2) {
+        if (s_meta[4 * g2 + 1]) {
+          const int tj = s_meta[4 * g2 + 2];
+          open = open || (s_st[tj] + s_ln[tj] > be);
+        }
+      }
+      if (!open) bmeta[blockIdx.x].y = 0;
+    }
+  }
+  stamp(5);
 }
 
-// Pass 2: the sub-chunk in which a cut interval starts owns it: tail + head + head + ...
+// Pass 2: the block in which an interval cut by block borders starts owns it.
 __global__ __launch_bounds__(kBlock) void bev_pool_fwd_fixup_kernel(
-    int c4, int gpw, int n_groups, float4* __restrict__ out4, const float4* __restrict__ part,
-    const int4* __restrict__ meta) {
+    int c4, int gpw, int n_blocks, float4* __restrict__ dst, const float4* __restrict__ part,
+    const int4* __restrict__ bmeta) {
   const int tid = threadIdx.x;
   const int wave = tid / kWave, lane = tid % kWave;
   const int gi = lane / c4, lg = lane % c4;
   if (gi >= gpw) return;
-  const int gid = (blockIdx.x * (kBlock / kWave) + wave) * gpw + gi;
-  if (gid >= n_groups) return;
-  const int4 m = meta[gid];
+  const int b = (blockIdx.x * (kBlock / kWave) + wave) * gpw + gi;
+  if (b >= n_blocks) return;
+  const int4 m = bmeta[b];
   if (!m.y) return;
-  float4 acc = part[(long)(2 * gid + 1) * c4 + lg];
-  for (int j = gid + 1; j < n_groups; ++j) {
-    const int h = meta[j].x;
+  float4 acc = part[(long)(2 * b + 1) * c4 + lg];
+  for (int j = b + 1; j < n_blocks; ++j) {
+    const int h = bmeta[j].x;
     if (h == 0) break;
     const float4 v = part[(long)(2 * j) * c4 + lg];
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     if (h == 1) break;
   }
-  out4[(long)m.z * c4 + lg] = acc;
+  dst[(long)m.z * c4 + lg] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Epilogue of the fused forward: dense channel-major output from the compact row table.
+// One workgroup per tile of kTile consecutive x of one (b, z, y) row: the rows of the non-empty
+// voxels go through LDS ([kTile][C+1] floats) and every channel leaves as one contiguous run of
+// kTile floats, zeros included — the output is written exactly once, never pre-zeroed, and the
+// reference's permute(0,4,1,2,3).contiguous() (bev_pool.py:91) and cat(unbind(2),1)
+// (view_transformer.py:194) passes disappear.
+//   layout 0: out[((b*C + c)*Z + z)*Y*X + y*X + x]      (B,C,Z,Y,X)
+//   layout 1: out[((b*Z + z)*C + c)*Y*X + y*X + x]      (B,Z*C,Y,X)
+// ---------------------------------------------------------------------------------------------
+constexpr int kTile = 64;
+
+__global__ __launch_bounds__(kBlock) void bev_pool_rows_to_nchw_kernel(
+    int c4, int B, int Z, int Y, int X, int tiles_x, int layout, const float4* __restrict__ rows,
+    const int* __restrict__ row_of_vox, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float s_tile[];
+  const int C = 4 * c4;
+  const int ld = C + 1;
+  int* s_rowid = reinterpret_cast<int*>(s_tile + kTile * ld);
+  const int tid = threadIdx.x;
+  long t = blockIdx.x;
+  const int tx = (int)(t % tiles_x); t /= tiles_x;
+  const int y = (int)(t % Y); t /= Y;
+  const int z = (int)(t % Z);
+  const int b = (int)(t / Z);
+  const int x0 = tx * kTile;
+  const int nx = min(kTile, X - x0);
+  const long vox0 = (((long)b * Z + z) * Y + y) * X + x0;
+  int any = 0;
+  if (tid < kTile) {
+    const int r = (tid < nx) ? row_of_vox[vox0 + tid] : 0;
+    s_rowid[tid] = r;
+    any = r != 0;
+  }
+  const int n_any = __syncthreads_count(any);
+  const long plane = (long)Y * X;
+  const long base0 = (layout == 0) ? ((long)b * C * Z + z) * plane : (((long)b * Z + z) * C) * plane;
+  const long cstride = (layout == 0) ? (long)Z * plane : plane;
+  const long rowoff = (long)y * X + x0;
+  if (n_any == 0) {
+    for (int i = tid; i < C * kTile; i += kBlock) {
+      const int ch = i / kTile, xx = i % kTile;
+      if (xx < nx) out[base0 + ch * cstride + rowoff + xx] = 0.f;
+    }
+    return;
+  }
+  // gather rows (c4 lanes per row, float4 each) into the padded tile
+  for (int i = tid; i < kTile * c4; i += kBlock) {
+    const int v = i / c4, q = i % c4;
+    const int r = s_rowid[v];
+    const float4 val = r ? rows[(long)(r - 1) * c4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float* d = s_tile + v * ld + 4 * q;
+    d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+  }
+  __syncthreads();
+  for (int i = tid; i < C * kTile; i += kBlock) {
+    const int ch = i / kTile, xx = i % kTile;
+    if (xx < nx) out[base0 + ch * cstride + rowoff + xx] = s_tile[xx * ld + ch];
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void bev_pool_check_intervals_kernel(
@@ -293,7 +479,6 @@ __global__ __launch_bounds__(kBlock) void bev_pool_grad_scalar_kernel(
 
 inline bool vec_ok(int c) { return c >= 32 && c <= 256 && (c % 4) == 0; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-inline int n_groups_for(int n_points) { return (n_points + kSub - 1) / kSub; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
@@ -311,10 +496,82 @@ void bev_pool_v2(int c, int n_intervals, const float* depth, const float* feat,
                      interval_lengths, out);
 }
 
+namespace {
+struct FwdGeom {
+  int c4, gpw, gpb, BP, n_blocks;
+  size_t lds, part_bytes, total_bytes;
+};
+inline FwdGeom fwd_geom(int c, int n_points) {
+  FwdGeom g;
+  const int kSub = g_sub;
+  g.c4 = c / 4;
+  g.gpw = kWave / g.c4;
+  g.gpb = g.gpw * (kBlock / kWave);
+  g.BP = g.gpb * kSub;
+  g.n_blocks = (n_points + g.BP - 1) / g.BP;
+  g.lds = (size_t)(6 * g.BP + 3 * kBlock + 4 * g.gpb) * sizeof(int) + (size_t)2 * g.gpb * g.c4 * sizeof(float4);
+  g.part_bytes = align_up((size_t)g.n_blocks * 2 * c * sizeof(float), 256);
+  g.total_bytes = g.part_bytes + (size_t)g.n_blocks * sizeof(int4);
+  return g;
+}
+
+// Shared by the scatter (reference contract) and compact-row (NCHW epilogue) forms.
+int launch_fwd(int c, int n_intervals, int n_points, int compact_rows, const float* depth,
+               const float* feat, const int* ranks_depth, const int* ranks_feat,
+               const int* ranks_bev, const int* interval_starts, const int* interval_lengths,
+               float* dst, void* workspace, int* row_of_vox, hipStream_t stream) {
+  const FwdGeom g = fwd_geom(c, n_points);
+  float4* part = static_cast<float4*>(workspace);
+  int4* bmeta = reinterpret_cast<int4*>(static_cast<char*>(workspace) + g.part_bytes);
+  auto kern = (g_sub == 64) ? bev_pool_fwd_chunked_kernel<false, 64>
+                             : bev_pool_fwd_chunked_kernel<false, 32>;
+  ocrf::launch(OCRF_K_BEV_POOL_FWD, kern, dim3(g.n_blocks),
+               dim3(kBlock), g.lds, stream, (unsigned long long*)nullptr, g.c4, g.gpw, n_intervals,
+               n_points, compact_rows, depth,
+               reinterpret_cast<const float4*>(feat), ranks_depth, ranks_feat, ranks_bev,
+               interval_starts, interval_lengths, reinterpret_cast<float4*>(dst), part, bmeta,
+               row_of_vox);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return (int)err;
+  const unsigned grid2 = (unsigned)((g.n_blocks + g.gpb - 1) / g.gpb);
+  ocrf::launch(OCRF_K_BEV_POOL_FIXUP, bev_pool_fwd_fixup_kernel, dim3(grid2), dim3(kBlock), 0, stream,
+               g.c4, g.gpw, g.n_blocks, reinterpret_cast<float4*>(dst),
+               static_cast<const float4*>(part), static_cast<const int4*>(bmeta));
+  return (int)hipGetLastError();
+}
+}  // namespace
+
+// Diagnostic knob (A/B timing of kernel variants in one process): key 0 = points per lane group.
+int ocrf_tune_set(int key, int value) {
+  if (key == 0 && (value == 32 || value == 64)) { g_sub = value; return 0; }
+  return (int)hipErrorInvalidValue;
+}
+
+// Diagnostic build of pass 1 that records s_memtime at six phase boundaries per workgroup into
+// stamps[n_blocks][8] (never used by the product path; see DESIGN.md "In-kernel stamps").
+int ocrf_diag_bev_pool_v2_stamps(int c, int n_intervals, int n_points, const float* depth,
+                                 const float* feat, const int* ranks_depth, const int* ranks_feat,
+                                 const int* ranks_bev, const int* interval_starts,
+                                 const int* interval_lengths, float* out, void* workspace,
+                                 unsigned long long* stamps, ocrf_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (!vec_ok(c) || n_points <= 0) return (int)hipErrorInvalidValue;
+  const FwdGeom g = fwd_geom(c, n_points);
+  float4* part = static_cast<float4*>(workspace);
+  int4* bmeta = reinterpret_cast<int4*>(static_cast<char*>(workspace) + g.part_bytes);
+  auto kern = (g_sub == 64) ? bev_pool_fwd_chunked_kernel<true, 64>
+                             : bev_pool_fwd_chunked_kernel<true, 32>;
+  hipLaunchKernelGGL(kern, dim3(g.n_blocks), dim3(kBlock), g.lds,
+                     stream, stamps, g.c4, g.gpw, n_intervals, n_points, 0, depth,
+                     reinterpret_cast<const float4*>(feat), ranks_depth, ranks_feat, ranks_bev,
+                     interval_starts, interval_lengths, reinterpret_cast<float4*>(out), part, bmeta,
+                     (int*)nullptr);
+  return (int)hipGetLastError();
+}
+
 size_t ocrf_bev_pool_v2_workspace_bytes(int c, int n_points) {
   if (!vec_ok(c) || n_points <= 0) return 0;
-  const size_t ng = (size_t)n_groups_for(n_points);
-  return align_up(ng * 2 * (size_t)c * sizeof(float), 256) + ng * sizeof(int4);
+  return fwd_geom(c, n_points).total_bytes;
 }
 
 int ocrf_bev_pool_v2(int c, int n_intervals, int n_points, const float* depth, const float* feat,
@@ -339,26 +596,65 @@ int ocrf_bev_pool_v2(int c, int n_intervals, int n_points, const float* depth, c
   const size_t need = ocrf_bev_pool_v2_workspace_bytes(c, n_points);
   if (!workspace || workspace_bytes < need || !aligned16(workspace))
     return (int)hipErrorInvalidValue;
-  const int c4 = c / 4;
-  const int gpw = kWave / c4;
-  const int gpb = gpw * (kBlock / kWave);
-  const int BP = gpb * kSub;
-  const int ng = n_groups_for(n_points);
-  float4* part = static_cast<float4*>(workspace);
-  int4* meta = reinterpret_cast<int4*>(static_cast<char*>(workspace) +
-                                       align_up((size_t)ng * 2 * c * sizeof(float), 256));
-  const unsigned grid1 = (unsigned)((n_points + BP - 1) / BP);
-  const size_t lds = (size_t)(4 * BP + 2 * kBlock) * sizeof(int);
-  ocrf::launch(OCRF_K_BEV_POOL_FWD, bev_pool_fwd_chunked_kernel, dim3(grid1), dim3(kBlock), lds,
-               stream, c4, gpw, n_intervals, n_points, ng, depth,
-               reinterpret_cast<const float4*>(feat), ranks_depth, ranks_feat, ranks_bev,
-               interval_starts, interval_lengths, reinterpret_cast<float4*>(out), part, meta);
-  hipError_t err = hipGetLastError();
+  return launch_fwd(c, n_intervals, n_points, 0, depth, feat, ranks_depth, ranks_feat, ranks_bev,
+                    interval_starts, interval_lengths, out, workspace, nullptr, stream);
+}
+
+namespace {
+struct NchwGeom {
+  size_t fwd_bytes, rows_off, map_off, total;
+};
+inline NchwGeom nchw_geom(int c, int n_intervals, int n_points, long n_voxels) {
+  NchwGeom g;
+  g.fwd_bytes = n_points > 0 ? align_up(fwd_geom(c, n_points).total_bytes, 256) : 0;
+  g.rows_off = g.fwd_bytes;
+  g.map_off = g.rows_off + align_up((size_t)n_intervals * c * sizeof(float), 256);
+  g.total = g.map_off + align_up((size_t)n_voxels * sizeof(int), 256);
+  return g;
+}
+}  // namespace
+
+size_t ocrf_bev_pool_v2_nchw_workspace_bytes(int c, int n_intervals, int n_points, long n_voxels) {
+  if (!vec_ok(c) || n_intervals < 0 || n_points < 0 || n_voxels <= 0) return 0;
+  return nchw_geom(c, n_intervals, n_points, n_voxels).total;
+}
+
+int ocrf_bev_pool_v2_nchw(int c, int n_intervals, int n_points, const float* depth,
+                          const float* feat, const int* ranks_depth, const int* ranks_feat,
+                          const int* ranks_bev, const int* interval_starts,
+                          const int* interval_lengths, float* out, int B, int Z, int Y, int X,
+                          int layout, void* workspace, size_t workspace_bytes,
+                          ocrf_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (!vec_ok(c) || n_intervals < 0 || n_points < 0 || B <= 0 || Z <= 0 || Y <= 0 || X <= 0 ||
+      (layout != 0 && layout != 1) || !out)
+    return (int)hipErrorInvalidValue;
+  const long n_vox = (long)B * Z * Y * X;
+  if (n_vox > 0x7fffffffL) return (int)hipErrorInvalidValue;
+  const NchwGeom g = nchw_geom(c, n_intervals, n_points, n_vox);
+  if (!workspace || workspace_bytes < g.total || !aligned16(workspace) || !aligned16(feat))
+    return (int)hipErrorInvalidValue;
+  char* ws = static_cast<char*>(workspace);
+  float* rows = reinterpret_cast<float*>(ws + g.rows_off);
+  int* row_of_vox = reinterpret_cast<int*>(ws + g.map_off);
+  hipError_t err = hipMemsetAsync(row_of_vox, 0, (size_t)n_vox * sizeof(int), stream);
   if (err != hipSuccess) return (int)err;
-  const unsigned grid2 = (unsigned)((ng + gpb - 1) / gpb);
-  ocrf::launch(OCRF_K_BEV_POOL_FIXUP, bev_pool_fwd_fixup_kernel, dim3(grid2), dim3(kBlock), 0, stream,
-               c4, gpw, ng, reinterpret_cast<float4*>(out), static_cast<const float4*>(part),
-               static_cast<const int4*>(meta));
+  if (n_intervals > 0 && n_points > 0) {
+    if (!depth || !feat || !ranks_depth || !ranks_feat || !ranks_bev || !interval_starts ||
+        !interval_lengths)
+      return (int)hipErrorInvalidValue;
+    const int rc = launch_fwd(c, n_intervals, n_points, 1, depth, feat, ranks_depth, ranks_feat,
+                              ranks_bev, interval_starts, interval_lengths, rows, workspace,
+                              row_of_vox, stream);
+    if (rc != 0) return rc;
+  }
+  const int c4 = c / 4;
+  const int tiles_x = (X + kTile - 1) / kTile;
+  const long n_tiles = (long)B * Z * Y * tiles_x;
+  const size_t lds = (size_t)kTile * (c + 1) * sizeof(float) + kTile * sizeof(int);
+  ocrf::launch(OCRF_K_BEV_POOL_NCHW, bev_pool_rows_to_nchw_kernel, dim3((unsigned)n_tiles),
+               dim3(kBlock), lds, stream, c4, B, Z, Y, X, tiles_x, layout,
+               reinterpret_cast<const float4*>(rows), static_cast<const int*>(row_of_vox), out);
   return (int)hipGetLastError();
 }
 

@@ -41,10 +41,11 @@ const char* ocrf_version(void) { return "ocrf_hip 0.1 gfx950"; }
 
 const char* ocrf_kernel_name(int kernel_id) {
   switch (kernel_id) {
-    case OCRF_K_BEV_POOL_FWD: return "bev_pool_fwd_chunked_kernel";
+    case OCRF_K_BEV_POOL_FWD: return "bev_pool_fwd_chunked_kernel<false>";
     case OCRF_K_BEV_POOL_FIXUP: return "bev_pool_fwd_fixup_kernel";
     case OCRF_K_BEV_POOL_INTERVAL: return "bev_pool_interval_kernel";
     case OCRF_K_BEV_POOL_GRAD: return "bev_pool_grad_vec_kernel";
+    case OCRF_K_BEV_POOL_NCHW: return "bev_pool_rows_to_nchw_kernel";
     case OCRF_K_RASTER_PREPROCESS: return "raster_preprocess_kernel";
     case OCRF_K_RASTER_BLEND: return "raster_blend_kernel";
     default: return "";

@@ -90,17 +90,14 @@ class HotPath:
         return depth.to(self.device), feat.to(self.device)
 
     def pool(self, plan, depth, feat):
-        return bevpool.bev_pool_v2(depth, feat, plan.ranks_depth, plan.ranks_feat, plan.ranks_bev,
-                                   plan.bev_shape, plan.starts, plan.lengths)
+        """-> (B, Z*C, Y, X): pooled BEV with Z collapsed into channels (view_transformer.py:194)."""
+        return bevpool.bev_pool_v2_collapsed(depth, feat, plan.ranks_depth, plan.ranks_feat,
+                                             plan.ranks_bev, plan.bev_shape, plan.starts, plan.lengths)
 
     def step(self, depth, feat):
-        """One pass: LSS BEV (B, C*Z, Y, X) and HT BEV (B, C, Y, X) (view_transformer.py:194,
+        """One pass: LSS BEV (B, Z*C, Y, X) and HT BEV (B, C, Y, X) (view_transformer.py:194,
         view_transformer_ocrf.py:781)."""
-        lss = self.pool(self.lss, depth, feat)
-        lss = torch.cat(lss.unbind(dim=2), 1)
-        ht = self.pool(self.ht, depth, feat)
-        ht = torch.cat(ht.unbind(dim=2), 1)
-        return lss, ht
+        return self.pool(self.lss, depth, feat), self.pool(self.ht, depth, feat)
 
     @property
     def bev_voxels_per_step(self):

@@ -1,6 +1,6 @@
 """GPU parity: HIP bev_pool_v2 (through the C ABI) vs the C oracle on the same inputs.
 
-Tolerance: north_star states BEV features within 1e-4 fp32; intervals that fit one 64-point
+Tolerance: north_star states BEV features within 1e-4 fp32; intervals that fit one 32-point
 sub-chunk are summed in list order exactly like the reference (bit-exact), longer ones are
 re-associated (deterministically)."""
 import ctypes
@@ -14,6 +14,7 @@ from tests import helpers
 
 pytestmark = pytest.mark.gpu
 ATOL = RTOL = 1e-4
+SUB = 32     # points per lane group in csrc/bev_pool.hip (kSubDefault)
 
 
 def _dev(a, cuda):
@@ -60,8 +61,8 @@ def test_parity_reference_shapes(cuda, oracle_lib, cfg_name, branch):
     got = _run(cuda, depth, feat, rd, rf, rb, shape, st, ln)
     assert got.shape == want.shape and got.dtype == np.float32
     np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
-    # intervals no longer than 64 points that do not straddle a sub-chunk are bit-exact
-    short = (ln <= 64) & ((st // 64) == ((st + ln - 1) // 64))
+    # intervals that do not straddle a 32-point sub-chunk border are bit-exact
+    short = (st // SUB) == ((st + ln - 1) // SUB)
     vox = rb[st[short]]
     g = got.transpose(0, 2, 3, 4, 1).reshape(-1, cfg.channels)[vox]
     w = want.transpose(0, 2, 3, 4, 1).reshape(-1, cfg.channels)[vox]
@@ -89,8 +90,8 @@ def test_edge_cases(cuda, oracle_lib):
     want = oracle_lib.bev_pool_v2(depth.reshape(1, 1, -1, 1, 1), feat.reshape(1, 1, 1, -1, c), rd, rf, rb, shape, st, ln)
     got = _run(cuda, depth.reshape(1, 1, -1, 1, 1), feat.reshape(1, 1, 1, -1, c), rd, rf, rb, shape, st, ln)
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-3)
-    # every point its own interval; point counts around the 64 / 768 boundaries
-    for n in (1, 63, 64, 65, 767, 768, 769, 1537):
+    # every point its own interval; point counts around sub-chunk (32) and workgroup (384) borders
+    for n in (1, 31, 32, 33, 63, 64, 65, 383, 384, 385, 767, 768, 769, 1537):
         rb = np.arange(n, dtype=np.int32)
         rd = rng.integers(0, 100, n).astype(np.int32)
         rf = rng.integers(0, 50, n).astype(np.int32)
@@ -167,7 +168,8 @@ def test_exact_signature_entry_and_interval_checker(cuda, oracle_lib):
     _lib.check(L.ocrf_bev_pool_v2_check_intervals(len(st_p), 6000, _lib.ptr(t[5]), _lib.ptr(t[6]), _lib.ptr(flag),
                                                    _lib.stream_ptr(cuda)), 'check')
     assert int(flag.item()) & 1
-    _lib.check(L.ocrf_bev_pool_v2_check_intervals(len(st), 6000, _lib.ptr(_dev(st, cuda)), _lib.ptr(_dev(ln, cuda)),
+    st_d, ln_d = _dev(st, cuda), _dev(ln, cuda)       # keep alive: raw pointers cross the C ABI
+    _lib.check(L.ocrf_bev_pool_v2_check_intervals(len(st), 6000, _lib.ptr(st_d), _lib.ptr(ln_d),
                                                    _lib.ptr(flag), _lib.stream_ptr(cuda)), 'check')
     assert int(flag.item()) == 0
     # bad arguments are reported, not launched
@@ -191,3 +193,31 @@ def test_backward_parity(cuda, oracle_lib):
     out.backward(_dev(og, cuda))
     np.testing.assert_allclose(d.grad.cpu().numpy(), want_d, rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(f.grad.cpu().numpy(), want_f, rtol=1e-4, atol=1e-4)
+
+
+def test_layouts_agree_with_reference_wrapper_ops(cuda, oracle_lib):
+    """(B,C,Z,Y,X) from the fused kernel == QuickCumsumCuda + permute (the reference's wrapper,
+    bev_pool.py:86-92); the collapsed form == cat(unbind(dim=2), 1) (view_transformer.py:194)."""
+    cfg = synthetic.CONFIGS['cfg0_1cam_128x352_bev64x64x4']
+    depth, feat = helpers.pool_inputs(cfg)
+    rb, rd, rf, st, ln = helpers.lss_ranks(cfg)
+    X, Y, Z = cfg.bev_xyz
+    shape = (1, Z, Y, X, cfg.channels)
+    t = [_dev(x, cuda) for x in (depth, feat, rd, rf, rb)]
+    st_d, ln_d = _dev(st, cuda), _dev(ln, cuda)
+    fused = bevpool.bev_pool_v2(*t, shape, st_d, ln_d)
+    legacy = bevpool.QuickCumsumCuda.apply(*t, shape, st_d, ln_d).permute(0, 4, 1, 2, 3).contiguous()
+    assert fused.is_contiguous() and fused.shape == (1, cfg.channels, Z, Y, X)
+    torch.testing.assert_close(fused, legacy, rtol=0, atol=0)
+    coll = bevpool.bev_pool_v2_collapsed(*t, shape, st_d, ln_d)
+    torch.testing.assert_close(coll, torch.cat(legacy.unbind(dim=2), 1), rtol=0, atol=0)
+    want = oracle_lib.bev_pool_v2(depth, feat, rd, rf, rb, shape, st, ln)
+    np.testing.assert_allclose(fused.cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+    # ragged x tiles (X not a multiple of 64) and several batches
+    rng = np.random.default_rng(2)
+    B, Zz, Yy, Xx, c = 2, 2, 5, 200, 80
+    dep, fe, rd2, rf2, rb2, st2, ln2 = helpers.random_pool_problem(rng, 20000, B * Zz * Yy * Xx, c, skew=False)
+    shape2 = (B, Zz, Yy, Xx, c)
+    want = oracle_lib.bev_pool_v2(dep.reshape(1, 1, -1, 1, 1), fe.reshape(1, 1, 1, -1, c), rd2, rf2, rb2, shape2, st2, ln2)
+    got = _run(cuda, dep.reshape(1, 1, -1, 1, 1), fe.reshape(1, 1, 1, -1, c), rd2, rf2, rb2, shape2, st2, ln2)
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
