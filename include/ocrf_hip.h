@@ -114,6 +114,44 @@ int ocrf_bev_pool_v2_grad(int c, int n_intervals, const float *out_grad, const f
                           ocrf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Gaussian rasteriser forward (RGB + depth + transmittance), batched over views
+ * ------------------------------------------------------------------------------------------
+ * Replaces `rasterize_gaussians` of the w-depth `diff_gaussian_rasterization` extension,
+ *   std::tuple<int, Tensor color, Tensor radii, Tensor geomBuffer, Tensor binningBuffer,
+ *              Tensor imgBuffer[, Tensor depth]>
+ *   RasterizeGaussiansCUDA(background, means3D, colors, opacity, scales, rotations,
+ *                          scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx,
+ *                          tan_fovy, image_height, image_width, sh, degree, campos, prefiltered)
+ * (mmdet3d/models/necks/MVSGaussian/lib/submodules/diff-gaussian-rasterization/
+ *  rasterize_points.cu:35-115), for the argument combination OcRFDet uses
+ * (gaussian_renderer/__init__.py:62-70): colours precomputed (no SH evaluation), covariance from
+ * (scales, rotations) or cov3D_precomp.  One call renders n_views cameras over the same P
+ * Gaussians (n_views = 1 is the reference's call).
+ *
+ *   means3D (P,3)  colors (P,3)  opacities (P)  scales (P,3)  rotations (P,4) [r,x,y,z; not
+ *   normalised, forward.cu:127]  cov3D_precomp (P,6) or NULL (then scales/rotations are used)
+ *   cameras (n_views, 36) floats: viewmatrix[16] | projmatrix[16] | tanfovx | tanfovy |
+ *           focal_x = W/(2 tanfovx) | focal_y = H/(2 tanfovy); both matrices are the TRANSPOSED
+ *           (row-vector) 4x4 the reference passes (auxiliary.h:58-77)
+ *   bg (3)         depth_mode 0 = median depth (w-depth default, 15.0 where T never crosses 0.5),
+ *                             1 = mean depth (the fork's commented-out alternative)
+ * outputs (caller-allocated, fully written):
+ *   out_color (n_views,3,H,W)  out_depth (n_views,H,W)  out_final_T (n_views,H,W) [= 1 - accumulated
+ *   opacity]  out_n_contrib (n_views,H,W)  radii (n_views,P)  tiles_touched (n_views,P) or NULL
+ * P == 0 zero-fills the outputs like the reference (rasterize_points.cu:68-69).
+ * No host synchronisation happens (the reference reads num_rendered back, rasterizer_impl.cu:281).
+ */
+int ocrf_rasterize_forward(int P, int n_views, int H, int W, const float *means3D,
+                           const float *colors, const float *opacities, const float *scales,
+                           float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                           const float *cameras, const float *bg, int depth_mode, float *out_color,
+                           float *out_depth, float *out_final_T, uint32_t *out_n_contrib, int *radii,
+                           uint32_t *tiles_touched, void *workspace, size_t workspace_bytes,
+                           ocrf_stream_t stream);
+
+size_t ocrf_rasterize_workspace_bytes(int P, int n_views);
+
+/* ------------------------------------------------------------------------------------------
  * Per-kernel device timer (measurement aid for bench.py; not part of the reference's surface)
  * ------------------------------------------------------------------------------------------
  * While a timer is armed for kernel id K, every launch of K inside the library is bracketed by
@@ -126,8 +164,9 @@ enum {
   OCRF_K_BEV_POOL_INTERVAL = 3, /* bev_pool_interval_kernel */
   OCRF_K_BEV_POOL_GRAD = 4,     /* bev_pool_grad_vec_kernel */
   OCRF_K_BEV_POOL_NCHW = 5,     /* bev_pool_rows_to_nchw_kernel */
-  OCRF_K_RASTER_PREPROCESS = 10,
-  OCRF_K_RASTER_BLEND = 11
+  OCRF_K_RASTER_PREPROCESS = 10, /* raster_preprocess_kernel */
+  OCRF_K_RASTER_BLEND = 11,      /* raster_blend_kernel */
+  OCRF_K_RASTER_GATHER = 12      /* raster_gather_kernel */
 };
 const char *ocrf_kernel_name(int kernel_id);           /* symbol as rocprofv3 prints it */
 int ocrf_timer_create(int capacity, void **timer_out); /* host pointers */

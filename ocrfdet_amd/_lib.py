@@ -66,6 +66,11 @@ def _declare(L):
     L.ocrf_bev_pool_v2_check_intervals.argtypes = [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
     L.ocrf_bev_pool_v2_grad.restype = c_int
     L.ocrf_bev_pool_v2_grad.argtypes = [c_int, c_int] + [c_void_p] * 10 + [c_void_p]
+    L.ocrf_rasterize_forward.restype = c_int
+    L.ocrf_rasterize_forward.argtypes = ([c_int] * 4 + [c_void_p] * 4 + [c_float] + [c_void_p] * 4 +
+                                         [c_int] + [c_void_p] * 6 + [c_void_p, c_size_t, c_void_p])
+    L.ocrf_rasterize_workspace_bytes.restype = c_size_t
+    L.ocrf_rasterize_workspace_bytes.argtypes = [c_int, c_int]
     L.ocrf_kernel_name.restype = ctypes.c_char_p
     L.ocrf_kernel_name.argtypes = [c_int]
     L.ocrf_timer_create.restype = c_int
@@ -120,7 +125,7 @@ workspace = Workspace()
 
 
 K_BEV_POOL_FWD, K_BEV_POOL_FIXUP, K_BEV_POOL_INTERVAL, K_BEV_POOL_GRAD, K_BEV_POOL_NCHW = 1, 2, 3, 4, 5
-K_RASTER_PREPROCESS, K_RASTER_BLEND = 10, 11
+K_RASTER_PREPROCESS, K_RASTER_BLEND, K_RASTER_GATHER = 10, 11, 12
 
 
 class KernelTimer:

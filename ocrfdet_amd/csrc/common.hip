@@ -48,6 +48,7 @@ const char* ocrf_kernel_name(int kernel_id) {
     case OCRF_K_BEV_POOL_NCHW: return "bev_pool_rows_to_nchw_kernel";
     case OCRF_K_RASTER_PREPROCESS: return "raster_preprocess_kernel";
     case OCRF_K_RASTER_BLEND: return "raster_blend_kernel";
+    case OCRF_K_RASTER_GATHER: return "raster_gather_kernel";
     default: return "";
   }
 }

@@ -1,0 +1,158 @@
+"""Gaussian rasteriser with depth output — drop-in for the ``diff_gaussian_rasterization`` module
+OcRFDet imports (the JonathonLuiten *w-depth* fork; call site
+``mmdet3d/models/necks/MVSGaussian/lib/gaussian_renderer/__init__.py:14,39-70``).
+
+Surface kept (names, argument order, return arity of the fork):
+
+``GaussianRasterizationSettings(image_height, image_width, tanfovx, tanfovy, bg, scale_modifier,
+viewmatrix, projmatrix, sh_degree, campos, prefiltered[, debug])``
+    the fork's 11 fields; ``debug`` (the stock 12th field,
+    ``.../diff_gaussian_rasterization/__init__.py:157-169``) is accepted and defaults to False.
+``GaussianRasterizer(raster_settings)(means3D, means2D, opacities, shs=None, colors_precomp=None,
+scales=None, rotations=None, cov3D_precomp=None) -> (color (3,H,W), radii (P,) int32,
+depth (1,H,W))``
+    exactly one of shs / colors_precomp and one of (scales, rotations) / cov3D_precomp, else the
+    reference's ``Exception`` (``__init__.py:191-195``).  ``viewmatrix`` / ``projmatrix`` are the
+    transposed (row-vector) 4x4 matrices.
+``rasterize_gaussians(...)`` and ``GaussianRasterizer.markVisible``.
+
+Beyond the reference: ``rasterize_views`` renders a batch of cameras over one Gaussian set in a
+single launch sequence and also returns ``final_T`` (1 - accumulated opacity) and ``n_contrib``.
+
+Compute: ``csrc/rasterize.hip`` through the C ABI (``ocrf_rasterize_forward``).  Forward only in
+this round: the backward raises.  SH colours are outside the path OcRFDet
+uses (``shs=None`` at the call site) and raise ``NotImplementedError``.
+"""
+import ctypes
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+__all__ = ['GaussianRasterizationSettings', 'GaussianRasterizer', 'rasterize_gaussians', 'rasterize_views']
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool = False
+
+
+def _f32c(t):
+    return t.detach().contiguous().float()
+
+
+def rasterize_views(means3D, colors, opacities, scales, rotations, viewmatrices, projmatrices,
+                    tanfovx, tanfovy, image_height, image_width, bg, scale_modifier=1.0,
+                    cov3D_precomp=None, depth_mode='median', want_tiles_touched=False):
+    """Render ``V`` cameras over the same ``P`` Gaussians.
+
+    ``viewmatrices`` / ``projmatrices``: (V,4,4) transposed matrices as the reference passes them;
+    ``tanfovx`` / ``tanfovy``: length-V sequences (or scalars).  Returns a dict of fresh tensors:
+    ``color`` (V,3,H,W), ``depth`` (V,1,H,W), ``final_T`` (V,H,W), ``n_contrib`` (V,H,W) int32,
+    ``radii`` (V,P) int32 [, ``tiles_touched`` (V,P) int32]."""
+    _lib.require_cuda(means3D, colors, opacities, viewmatrices, projmatrices, bg)
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RuntimeError('means3D must have dimensions (num_points, 3)')     # rasterize_points.cu:57-59
+    dev = means3D.device
+    P = means3D.size(0)
+    vm = _f32c(viewmatrices).reshape(-1, 16)
+    pm = _f32c(projmatrices).reshape(-1, 16)
+    V = vm.size(0)
+    H, W = int(image_height), int(image_width)
+    tfx = torch.as_tensor(tanfovx, dtype=torch.float64).reshape(-1).expand(V) if not torch.is_tensor(tanfovx) \
+        else tanfovx.detach().double().reshape(-1).cpu().expand(V)
+    tfy = torch.as_tensor(tanfovy, dtype=torch.float64).reshape(-1).expand(V) if not torch.is_tensor(tanfovy) \
+        else tanfovy.detach().double().reshape(-1).cpu().expand(V)
+    # focal = size / (2 * tan) evaluated in float32 like rasterizer_impl.cu:222-223
+    tf = torch.stack((tfx, tfy), 1).float()
+    focal = torch.stack((torch.tensor(float(W)) / (2.0 * tf[:, 0]), torch.tensor(float(H)) / (2.0 * tf[:, 1])), 1)
+    cams = torch.cat((vm, pm, tf.to(dev), focal.float().to(dev)), 1).contiguous()        # (V,36)
+    means3D, colors, opac = _f32c(means3D), _f32c(colors), _f32c(opacities).reshape(-1)
+    if cov3D_precomp is not None and cov3D_precomp.numel() > 0:
+        cov, sc, rot = _f32c(cov3D_precomp), None, None
+    else:
+        cov, sc, rot = None, _f32c(scales), _f32c(rotations)
+    bg = _f32c(bg).reshape(3)
+    out = dict(color=torch.empty(V, 3, H, W, device=dev), depth=torch.empty(V, 1, H, W, device=dev),
+               final_T=torch.empty(V, H, W, device=dev),
+               n_contrib=torch.empty(V, H, W, dtype=torch.int32, device=dev),
+               radii=torch.empty(V, max(P, 0), dtype=torch.int32, device=dev))
+    tt = torch.empty(V, P, dtype=torch.int32, device=dev) if want_tiles_touched else None
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        need = L.ocrf_rasterize_workspace_bytes(P, V)
+        ws = _lib.workspace.get(dev, need, 'raster')
+        _lib.check(L.ocrf_rasterize_forward(
+            P, V, H, W, _lib.ptr(means3D), _lib.ptr(colors), _lib.ptr(opac), _lib.ptr(sc),
+            ctypes.c_float(scale_modifier), _lib.ptr(rot), _lib.ptr(cov), _lib.ptr(cams), _lib.ptr(bg),
+            {'median': 0, 'mean': 1}[depth_mode], _lib.ptr(out['color']), _lib.ptr(out['depth']),
+            _lib.ptr(out['final_T']), _lib.ptr(out['n_contrib']), _lib.ptr(out['radii']), _lib.ptr(tt),
+            _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_ptr(dev)), 'ocrf_rasterize_forward')
+    if tt is not None:
+        out['tiles_touched'] = tt
+    return out
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                cov3Ds_precomp, raster_settings):
+        rs = raster_settings
+        if sh is not None and sh.numel() > 0:
+            raise NotImplementedError('SH colours are not on the OcRFDet path (shs=None, '
+                                      'gaussian_renderer/__init__.py:65); pass colors_precomp')
+        out = rasterize_views(means3D, colors_precomp, opacities, scales, rotations,
+                              rs.viewmatrix.reshape(1, 4, 4), rs.projmatrix.reshape(1, 4, 4),
+                              float(rs.tanfovx), float(rs.tanfovy), rs.image_height, rs.image_width,
+                              rs.bg, float(rs.scale_modifier),
+                              cov3Ds_precomp if cov3Ds_precomp is not None and cov3Ds_precomp.numel() else None)
+        color, radii, depth = out['color'][0], out['radii'][0], out['depth'][0]
+        ctx.mark_non_differentiable(radii, depth)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_color, _r, _d):
+        raise NotImplementedError(
+            'ocrfdet_amd rasteriser: backward not built yet (SURVEY.md section 8(f) rank 1); the '
+            'w-depth fork has no depth backward either (diff-gaussian-rasterization-w-depth/README.md:13)')
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                        cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales,
+                                     rotations, cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Near-plane test of ``in_frustum`` (auxiliary.h:139-164): view-space z > 0.2."""
+        with torch.no_grad():
+            vm = self.raster_settings.viewmatrix.reshape(4, 4).to(positions)
+            z = positions[:, 0] * vm[0, 2] + positions[:, 1] * vm[1, 2] + positions[:, 2] * vm[2, 2] + vm[3, 2]
+            return z > 0.2
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
+                rotations=None, cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, self.raster_settings)

@@ -53,3 +53,30 @@ def random_pool_problem(rng, n_points, n_voxels, c, n_depth=5000, n_feat=700, sk
     starts = np.nonzero(kept)[0].astype(np.int32)
     lengths = np.diff(np.append(starts, n_points)).astype(np.int32)
     return depth, feat, rd, rf, rb, starts, lengths
+
+
+def simple_camera(W, H, fx=None, fy=None, cam_pos=(0.0, 0.0, 0.0)):
+    """Camera at ``cam_pos`` looking down +z with identity rotation; returns the transposed view /
+    full-projection matrices and tan(fov/2), built with the product's camera helpers."""
+    import torch
+    from ocrfdet_amd import gaussian_renderer as gr
+    fx = fx or 0.8 * W
+    fy = fy or fx
+    K = np.array([[fx, 0, W / 2.0], [0, fy, H / 2.0], [0, 0, 1.0]])
+    proj = gr.getProjectionMatrix(0.01, 999.9, K, H, W).transpose(0, 1)
+    w2v = np.eye(4, dtype=np.float32)
+    w2v[:3, 3] = -np.asarray(cam_pos, np.float32)
+    view_t = torch.from_numpy(w2v).transpose(0, 1).contiguous()
+    full = view_t.unsqueeze(0).bmm(proj.unsqueeze(0)).squeeze(0)
+    return view_t.numpy(), full.numpy(), W / (2 * fx), H / (2 * fy)
+
+
+def random_gaussians(rng, n, z_range=(1.0, 30.0), xy_extent=12.0, scale=(0.05, 0.8)):
+    xyz = np.stack([rng.uniform(-xy_extent, xy_extent, n), rng.uniform(-xy_extent * 0.4, xy_extent * 0.4, n),
+                    rng.uniform(*z_range, n)], 1).astype(np.float32)
+    scales = rng.uniform(*scale, (n, 3)).astype(np.float32)
+    q = rng.standard_normal((n, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    opac = rng.uniform(0.05, 0.95, (n, 1)).astype(np.float32)
+    rgb = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    return xyz, rgb, opac, scales, q

@@ -30,9 +30,9 @@ def test_library_exports_every_declared_symbol():
 def test_code_object_is_gfx950_only():
     so = os.path.join(ROOT, 'ocrfdet_amd', 'csrc', 'libocrf_hip.so')
     blob = open(so, 'rb').read()
-    assert b'gfx950' in blob
-    for other in (b'gfx90a', b'gfx942', b'sm_80'):
-        assert other not in blob
+    import re
+    targets = set(re.findall(rb'amdgcn-amd-amdhsa--(gfx[0-9a-f]+)', blob))   # offload bundle entry ids
+    assert targets == {b'gfx950'}, targets
 
 
 def test_workspace_query_is_host_only():
