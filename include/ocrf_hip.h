@@ -138,6 +138,9 @@ int ocrf_bev_pool_v2_grad(int c, int n_intervals, const float *out_grad, const f
  * outputs (caller-allocated, fully written):
  *   out_color (n_views,3,H,W)  out_depth (n_views,H,W)  out_final_T (n_views,H,W) [= 1 - accumulated
  *   opacity]  out_n_contrib (n_views,H,W)  radii (n_views,P)  tiles_touched (n_views,P) or NULL
+ *   status (device int, may be NULL; caller zeroes it): bit 0 is set if some tile met more than
+ *   3840 Gaussians inside ONE 0.2 %-wide depth bucket, the capacity of the in-LDS exact sort; the
+ *   pixels of such a tile were blended in bucket order but possibly not in exact depth order.
  * P == 0 zero-fills the outputs like the reference (rasterize_points.cu:68-69).
  * No host synchronisation happens (the reference reads num_rendered back, rasterizer_impl.cu:281).
  */
@@ -146,8 +149,8 @@ int ocrf_rasterize_forward(int P, int n_views, int H, int W, const float *means3
                            float scale_modifier, const float *rotations, const float *cov3D_precomp,
                            const float *cameras, const float *bg, int depth_mode, float *out_color,
                            float *out_depth, float *out_final_T, uint32_t *out_n_contrib, int *radii,
-                           uint32_t *tiles_touched, void *workspace, size_t workspace_bytes,
-                           ocrf_stream_t stream);
+                           uint32_t *tiles_touched, int *status, void *workspace,
+                           size_t workspace_bytes, ocrf_stream_t stream);
 
 size_t ocrf_rasterize_workspace_bytes(int P, int n_views);
 
@@ -166,7 +169,9 @@ enum {
   OCRF_K_BEV_POOL_NCHW = 5,     /* bev_pool_rows_to_nchw_kernel */
   OCRF_K_RASTER_PREPROCESS = 10, /* raster_preprocess_kernel */
   OCRF_K_RASTER_BLEND = 11,      /* raster_blend_kernel */
-  OCRF_K_RASTER_GATHER = 12      /* raster_gather_kernel */
+  OCRF_K_RASTER_GATHER = 12,     /* raster_scatter_kernel */
+  OCRF_K_RASTER_SCAN = 13,       /* raster_bucket_scan_kernel */
+  OCRF_K_RASTER_REDUCE = 14      /* raster_bucket_reduce_kernel */
 };
 const char *ocrf_kernel_name(int kernel_id);           /* symbol as rocprofv3 prints it */
 int ocrf_timer_create(int capacity, void **timer_out); /* host pointers */

@@ -68,7 +68,7 @@ def _declare(L):
     L.ocrf_bev_pool_v2_grad.argtypes = [c_int, c_int] + [c_void_p] * 10 + [c_void_p]
     L.ocrf_rasterize_forward.restype = c_int
     L.ocrf_rasterize_forward.argtypes = ([c_int] * 4 + [c_void_p] * 4 + [c_float] + [c_void_p] * 4 +
-                                         [c_int] + [c_void_p] * 6 + [c_void_p, c_size_t, c_void_p])
+                                         [c_int] + [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p])
     L.ocrf_rasterize_workspace_bytes.restype = c_size_t
     L.ocrf_rasterize_workspace_bytes.argtypes = [c_int, c_int]
     L.ocrf_kernel_name.restype = ctypes.c_char_p

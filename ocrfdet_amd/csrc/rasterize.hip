@@ -12,21 +12,23 @@
 // keys, derives tile ranges and needs a blocking device->host read of R to size its buffers.
 // Here (DESIGN.md "rasteriser"):
 //   1. preprocess  — one thread per (view, Gaussian); same arithmetic, fp-contract off so that
-//                    radii / tile rectangles are compiler-independent;
-//   2. depth sort  — ONE sort of the P per-view (depth bits, id) pairs (P <= 0.5 M), not of R;
-//   3. gather      — per-Gaussian state re-laid out in depth order (streamed, not gathered, later);
-//   4. blend       — one 16x16-pixel workgroup per (tile, view) walks the depth-ordered list,
-//                    keeps the entries whose tile rectangle covers its tile (wave ballot +
-//                    prefix -> order-preserving compaction into LDS) and alpha-blends them front
-//                    to back, stopping as soon as every pixel is saturated.  The per-tile list
-//                    is therefore identical, element for element, to the reference's sorted
-//                    range (same (depth, id) order), but no R-sized buffer, no 64-bit R sort, no
-//                    range pass and no host synchronisation exist; the whole forward is
-//                    hipGraph-capturable and batches any number of views over one Gaussian set.
+//                    radii / tile rectangles are compiler-independent; visible Gaussians also
+//                    count themselves into a histogram of 8192 depth buckets per view (bucket =
+//                    top 18 bits of the positive depth float: 0.2 % wide);
+//   2. bucket scan — exclusive scan of the histogram (one workgroup per view);
+//   3. scatter     — every visible Gaussian drops its (tile rect, depth|id) record into its
+//                    bucket's range: the list is now ordered by bucket, unordered inside one;
+//   4. blend       — one 16x16-pixel workgroup per (tile, view) scans the bucket-ordered list,
+//                    keeps the records whose tile rectangle covers its tile (wave ballot + prefix
+//                    compaction into LDS), sorts what it holds EXACTLY by (depth bits, id) in LDS
+//                    (bitonic), blends the records of complete buckets front to back and carries
+//                    an incomplete last bucket into the next round; it stops as soon as every
+//                    pixel is saturated, i.e. usually after a few hundred records.
+// The sequence each pixel blends is therefore identical, element for element, to the reference's
+// sorted per-tile range — (depth, id) ascending — but nothing R-sized is ever built, only the
+// front of each tile's list is ever sorted, and there is no host synchronisation: the whole
+// forward is hipGraph-capturable and batches any number of views over one Gaussian set.
 #include <hip/hip_runtime.h>
-
-#include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "launch.h"
 #include "ocrf_hip.h"
@@ -35,8 +37,14 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kTileX = 16, kTileY = 16;     // cuda_rasterizer/config.h:15-17
-constexpr int kCap = 512;                    // LDS list capacity of the blend kernel
-constexpr unsigned kInvisible = 0xFFFFFFFFu;
+constexpr int kBuckets = 8192;               // depth buckets per view
+constexpr int kBucketShift = 14;             // bucket = (depth bits >> 14) - base: 9 mantissa bits
+constexpr unsigned kBucketBase = 0x3E4CCCCDu >> kBucketShift;   // depth > 0.2f always (auxiliary.h:154)
+constexpr int kCopies = 32;                  // replicated histograms: spreads same-bucket atomics
+constexpr int kCapRec = 4096;                // LDS record capacity of the blend kernel
+constexpr int kStage = 256;                  // payload entries staged per blend batch
+constexpr int kScanUnroll = 4;               // rect batches in flight in the scan
+constexpr unsigned long long kPad = ~0ull;
 
 struct Camera {            // 36 floats per view, see ocrf_hip.h
   float view[16];
@@ -46,6 +54,32 @@ struct Camera {            // 36 floats per view, see ocrf_hip.h
 
 struct __attribute__((aligned(8))) Rect { unsigned short x0, y0, x1, y1; };
 
+__device__ __forceinline__ int bucket_of(unsigned key) {
+  const int b = (int)(key >> kBucketShift) - (int)kBucketBase;
+  return min(max(b, 0), kBuckets - 1);
+}
+
+// Lanes of a wave that are adjacent and want the same bucket form a run; the run's first lane
+// does ONE atomic for the whole run (neighbouring Gaussians of a regular grid share a depth
+// bucket for cameras looking across the fast grid axis: 64 same-address atomics become one).
+// Returns the slot base for this lane's run (valid on active lanes) and its rank inside the run.
+__device__ __forceinline__ int run_atomic_add(int* counters, int bucket, bool active, int* rank_out) {
+  const int lane = threadIdx.x & 63;
+  const int key = active ? bucket : -1 - lane;              // inactive lanes never match
+  const int prev = __shfl_up(key, 1);
+  const bool head = (lane == 0) || (prev != key);
+  const unsigned long long heads = __ballot(head);
+  const unsigned long long upto = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+  const int head_lane = 63 - __clzll(upto);
+  const unsigned long long after = heads & ~((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+  const int next_head = after ? (__ffsll((long long)after) - 1) : 64;
+  int base = 0;
+  if (active && head) base = atomicAdd(&counters[bucket], next_head - lane);
+  base = __shfl(base, head_lane);
+  *rank_out = lane - head_lane;
+  return base;
+}
+
 // auxiliary.h:41-44 — the reference evaluates this in double precision (its literals are double)
 __device__ __forceinline__ float ndc2pix(float v, int S) {
   return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5);
@@ -53,23 +87,25 @@ __device__ __forceinline__ float ndc2pix(float v, int S) {
 
 // ---------------------------------------------------------------------------------------------
 // 1. preprocess (forward.cu:155-256).  Expression order mirrors oracle/rasterize_ref.c exactly.
+//    Per-Gaussian state is kept in id order: key (depth bits, 0xFFFFFFFF = not rendered), rect,
+//    xy, conic_opacity.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
     int P, int W, int H, int gx, int gy, const float* __restrict__ means3D,
     const float* __restrict__ opacities, const float* __restrict__ scales, float scale_modifier,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
-    const Camera* __restrict__ cams, unsigned long long* __restrict__ keys,
-    unsigned* __restrict__ vals, Rect* __restrict__ rects, float2* __restrict__ xy,
-    float4* __restrict__ conic_o, int* __restrict__ radii, unsigned* __restrict__ tiles_touched,
-    int* __restrict__ n_vis) {
-  const int idx = blockIdx.x * kBlock + threadIdx.x;
+    const Camera* __restrict__ cams, unsigned* __restrict__ keys, Rect* __restrict__ rects,
+    float2* __restrict__ xy, float4* __restrict__ conic_o, int* __restrict__ radii,
+    unsigned* __restrict__ tiles_touched, int* __restrict__ hist) {
+  const int idx_raw = blockIdx.x * kBlock + threadIdx.x;
   const int v = blockIdx.y;
-  if (idx >= P) return;
+  const bool in_range = idx_raw < P;
+  const int idx = in_range ? idx_raw : P - 1;       // tail lanes recompute the last Gaussian, store nothing
   const long o = (long)v * P + idx;
   const Camera& cam = cams[v];
   const float* vm = cam.view;
   const float* pm = cam.proj;
-  unsigned key = kInvisible;
+  unsigned key = 0xFFFFFFFFu;
   int my_radii = 0;
   unsigned touched = 0;
 
@@ -154,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
       const int y0 = min(gy, max(0, (int)((pixy - (float)rad) / (float)kTileY)));
       const int x1 = min(gx, max(0, (int)((pixx + (float)rad + (float)(kTileX - 1)) / (float)kTileX)));
       const int y1 = min(gy, max(0, (int)((pixy + (float)rad + (float)(kTileY - 1)) / (float)kTileY)));
-      if ((x1 - x0) * (y1 - y0) != 0) {
+      if (in_range && (x1 - x0) * (y1 - y0) != 0) {
         key = __float_as_uint(vz);        // vz > 0.2: the raw bits order like the value
         my_radii = rad;
         touched = (unsigned)((y1 - y0) * (x1 - x0));
@@ -164,53 +200,194 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
         rects[o] = rc;
         xy[o] = make_float2(pixx, pixy);
         conic_o[o] = make_float4(con_x, con_y, con_z, opacities[idx]);
-        atomicAdd(&n_vis[v], 1);
       }
     }
   }
-  keys[o] = ((unsigned long long)v << 32) | key;
-  vals[o] = (unsigned)idx;
+  {
+    int rank;
+    // hist[v][bucket][copy], copy = workgroup index mod kCopies: a depth slice of a regular grid
+    // puts thousands of Gaussians into ONE bucket; same-address atomics serialise in L2
+    (void)run_atomic_add(hist + (long)v * kBuckets * kCopies + (blockIdx.x % kCopies), bucket_of(key) * kCopies,
+                         key != 0xFFFFFFFFu, &rank);
+  }
+  if (!in_range) return;
+  keys[o] = key;
   radii[o] = my_radii;
   if (tiles_touched) tiles_touched[o] = touched;
 }
 
 // ---------------------------------------------------------------------------------------------
-// 3. gather the visible Gaussians' state into depth order.
-//    sa = (x, y, conic.x, conic.y)  sb = (conic.z, opacity, depth, r)  sc = (g, b)
+// 2a. per bucket: total over the kCopies replicas -> tot[v][b]; the replicas are overwritten by
+//     their exclusive prefix inside the bucket (the scatter cursors).  One thread per bucket.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void raster_gather_kernel(
-    int P, const unsigned long long* __restrict__ keys_sorted, const unsigned* __restrict__ vals_sorted,
-    const Rect* __restrict__ rects, const float2* __restrict__ xy, const float4* __restrict__ conic_o,
-    const float* __restrict__ colors, const int* __restrict__ n_vis, Rect* __restrict__ s_rect,
-    float4* __restrict__ sa, float4* __restrict__ sb, float2* __restrict__ sc) {
-  const int k = blockIdx.x * kBlock + threadIdx.x;
+__global__ __launch_bounds__(kBlock) void raster_bucket_reduce_kernel(int* __restrict__ hist,
+                                                                      int* __restrict__ tot) {
+  const long b = (long)blockIdx.x * kBlock + threadIdx.x;      // over n_views * kBuckets
+  int4* h = reinterpret_cast<int4*>(hist + b * kCopies);
+  int run = 0;
+#pragma unroll
+  for (int q = 0; q < kCopies / 4; ++q) {
+    int4 x = h[q];
+    int4 y;
+    y.x = run; run += x.x;
+    y.y = run; run += x.y;
+    y.z = run; run += x.z;
+    y.w = run; run += x.w;
+    h[q] = y;
+  }
+  tot[b] = run;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2b. exclusive scan of each view's bucket totals: starts[v][0..kBuckets] (last = visible count).
+//     One workgroup per view, 32 buckets per thread.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void raster_bucket_scan_kernel(const int* __restrict__ tot,
+                                                                    int* __restrict__ starts) {
+  __shared__ int s_sum[kBlock];
+  constexpr int per = kBuckets / kBlock;
+  const int v = blockIdx.x, tid = threadIdx.x;
+  const int* h = tot + (long)v * kBuckets + tid * per;
+  int local[per];
+  int sum = 0;
+#pragma unroll
+  for (int i = 0; i < per; ++i) { local[i] = sum; sum += h[i]; }
+  s_sum[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < kBlock; off <<= 1) {      // Hillis-Steele inclusive scan
+    const int add = tid >= off ? s_sum[tid - off] : 0;
+    __syncthreads();
+    s_sum[tid] += add;
+    __syncthreads();
+  }
+  const int base = s_sum[tid] - sum;
+  int* st = starts + (long)v * (kBuckets + 1) + tid * per;
+#pragma unroll
+  for (int i = 0; i < per; ++i) st[i] = base + local[i];
+  if (tid == kBlock - 1) starts[(long)v * (kBuckets + 1) + kBuckets] = s_sum[tid];
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3. scatter the visible Gaussians into bucket order: b_rect, b_comp = (depth bits << 32) | id.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void raster_scatter_kernel(
+    int P, const unsigned* __restrict__ keys, const Rect* __restrict__ rects,
+    const int* __restrict__ starts, int* __restrict__ cursor, Rect* __restrict__ b_rect,
+    unsigned long long* __restrict__ b_comp) {
+  const int idx = blockIdx.x * kBlock + threadIdx.x;
   const int v = blockIdx.y;
-  if (k >= n_vis[v]) return;
-  const long o = (long)v * P + k;
-  const unsigned id = vals_sorted[o];
-  const long g = (long)v * P + id;
-  const float2 p = xy[g];
-  const float4 co = conic_o[g];
-  const float depth = __uint_as_float((unsigned)(keys_sorted[o] & 0xFFFFFFFFull));
-  s_rect[o] = rects[g];
-  sa[o] = make_float4(p.x, p.y, co.x, co.y);
-  sb[o] = make_float4(co.z, co.w, depth, colors[3 * (long)id]);
-  sc[o] = make_float2(colors[3 * (long)id + 1], colors[3 * (long)id + 2]);
+  const long o = (long)v * P + min(idx, P - 1);
+  const unsigned key = idx < P ? keys[o] : 0xFFFFFFFFu;
+  const bool vis = key != 0xFFFFFFFFu;
+  int rank;
+  const int bkt = bucket_of(key);
+  const int slot0 = run_atomic_add(cursor + (long)v * kBuckets * kCopies + (blockIdx.x % kCopies),
+                                   bkt * kCopies, vis, &rank);
+  if (!vis) return;
+  const int slot = starts[(long)v * (kBuckets + 1) + bkt] + slot0 + rank;
+  b_rect[(long)v * P + slot] = rects[o];
+  b_comp[(long)v * P + slot] = ((unsigned long long)key << 32) | (unsigned)idx;
 }
 
 // ---------------------------------------------------------------------------------------------
 // 4. blend (forward.cu:261-374 + w-depth README:5-11).
+// Dynamic LDS: u64 rec[kCapRec]; float4 l_a[kStage], l_b[kStage]; float2 l_c[kStage].
 // ---------------------------------------------------------------------------------------------
+// Bitonic sort of 256*R u64 records held in LDS, R consecutive records per thread in registers:
+// exchange distances below R are register moves, below 64*R wave shuffles, and only the last
+// log2(4)=2 distances of the last merges go through LDS with a workgroup barrier.
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long x, int lane_mask) {
+  const unsigned lo = __shfl_xor((unsigned)(x & 0xFFFFFFFFull), lane_mask);
+  const unsigned hi = __shfl_xor((unsigned)(x >> 32), lane_mask);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int R>
+__device__ __forceinline__ void bitonic_sort_regs(unsigned long long* rec, int tid) {
+  constexpr int n = kBlock * R;
+  const int lane = tid & 63;
+  unsigned long long x[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) x[r] = rec[tid * R + r];
+#pragma unroll
+  for (int k = 2; k <= n; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j < R) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if ((r & j) == 0) {
+            const bool up = (((tid * R + r) & k) == 0);
+            const unsigned long long a = x[r], b = x[r | j];
+            const bool sw = (a > b) == up;
+            x[r] = sw ? b : a;
+            x[r | j] = sw ? a : b;
+          }
+        }
+      } else if (j < 64 * R) {
+        const int lm = j / R;
+        const bool lower = (lane & lm) == 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const unsigned long long y = shfl_xor_u64(x[r], lm);
+          const bool up = (((tid * R + r) & k) == 0);
+          const bool take_min = lower == up;
+          const unsigned long long mn = x[r] < y ? x[r] : y, mx = x[r] < y ? y : x[r];
+          x[r] = take_min ? mn : mx;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) rec[tid * R + r] = x[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int i = tid * R + r;
+          const unsigned long long y = rec[i ^ j];
+          const bool up = ((i & k) == 0);
+          const bool take_min = ((i & j) == 0) == up;
+          const unsigned long long mn = x[r] < y ? x[r] : y, mx = x[r] < y ? y : x[r];
+          x[r] = take_min ? mn : mx;
+        }
+        __syncthreads();
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) rec[tid * R + r] = x[r];
+  __syncthreads();
+}
+
+// generic fallback for more than 1024 records (rare: only after carries pile up)
+__device__ __forceinline__ void bitonic_sort_lds(unsigned long long* rec, int n_pow2, int tid) {
+  for (int k = 2; k <= n_pow2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (n_pow2 >> 1); t += kBlock) {     // one compare-exchange per thread
+        const int i = 2 * t - (t & (j - 1));                  // lower index of the t-th pair
+        const int ixj = i + j;
+        const unsigned long long a = rec[i], b = rec[ixj];
+        const bool up = (i & k) == 0;
+        if ((a > b) == up) { rec[i] = b; rec[ixj] = a; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <bool STAMP>
 __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
-    int P, int W, int H, int gx, int depth_mode, const int* __restrict__ n_vis,
-    const Rect* __restrict__ s_rect, const float4* __restrict__ sa, const float4* __restrict__ sb,
-    const float2* __restrict__ sc, const float* __restrict__ bg, float* __restrict__ out_color,
+    unsigned long long* __restrict__ stamps,
+    int P, int W, int H, int depth_mode, const int* __restrict__ starts,
+    const Rect* __restrict__ b_rect, const unsigned long long* __restrict__ b_comp,
+    const float2* __restrict__ xy, const float4* __restrict__ conic_o,
+    const float* __restrict__ colors, const float* __restrict__ bg, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_final_T,
-    unsigned* __restrict__ out_n_contrib) {
-  __shared__ float4 l_a[kCap];
-  __shared__ float4 l_b[kCap];
-  __shared__ float2 l_c[kCap];
-  __shared__ int l_wtot[kBlock / 64];
+    unsigned* __restrict__ out_n_contrib, int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long rec[];
+  float4* l_a = reinterpret_cast<float4*>(rec + kCapRec);
+  float4* l_b = l_a + kStage;
+  float2* l_c = reinterpret_cast<float2*>(l_b + kStage);
+  __shared__ int l_wtot[kScanUnroll * (kBlock / 64)];
+  __shared__ int l_ready;
 
   const int tid = threadIdx.x;
   const int tx = blockIdx.x, ty = blockIdx.y, v = blockIdx.z;
@@ -219,7 +396,7 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
   const bool inside = pxi < W && pyi < H;
   const float pixf_x = (float)pxi, pixf_y = (float)pyi;
   const long base = (long)v * P;
-  const int nv = n_vis[v];
+  const int nv = starts[(long)v * (kBuckets + 1) + kBuckets];
   const int wave = tid / 64, lane = tid % 64;
 
   bool done = !inside;
@@ -228,65 +405,180 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
   float C0 = 0.f, C1 = 0.f, C2 = 0.f;
   float D = depth_mode == 0 ? 15.0f : 0.0f;
 
-  int scan = 0;
-  while (true) {
-    // ---- fill: scan the depth-ordered list, keep the entries whose rect covers this tile ----
-    int count = 0;
-    while (count < kBlock && scan < nv) {
-      const int i = scan + tid;
-      bool hit = false;
-      if (i < nv) {
-        const Rect rc = s_rect[base + i];
-        hit = (tx >= rc.x0) && (tx < rc.x1) && (ty >= rc.y0) && (ty < rc.y1);
-      }
-      const unsigned long long m = __ballot(hit);
-      const int rank = __popcll(m & ((1ull << lane) - 1ull));
-      if (lane == 0) l_wtot[wave] = __popcll(m);
-      __syncthreads();
-      int off = count, tot = 0;
+  int scan = 0;      // next list entry to look at
+  int nrec = 0;      // records held in LDS (sorted prefix left over from the previous round)
+  bool all_done = false;
+  unsigned long long t_prev = 0, t_acc[6] = {0, 0, 0, 0, 0, 0};
+  auto stamp = [&](int slot) {
+    if constexpr (STAMP) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      if (slot >= 0) t_acc[slot] += t - t_prev;
+      t_prev = t;
+    }
+  };
+  stamp(-1);
+  while (!all_done) {
+    // ---- scan: keep the records whose rect covers this tile, until ~2 batches are held ----
+    // stop once ~half a batch of new records is in: nrec then lands in (128, 384] on the first
+    // round, so the sort pads to 256 or 512.  kScanUnroll batches of 256 rects are in flight at
+    // once (the scan is latency-bound: one dependent global load per batch otherwise).
+    const int target = min(nrec + kBlock / 2 + 1, kCapRec - kScanUnroll * kBlock);
+    while (scan < nv && nrec < target) {
+      // dense scenes fill a round from the first 256 entries: look at one batch first, then four
+      const int n_u = (scan == 0) ? 1 : kScanUnroll;
+      bool hit[kScanUnroll];
 #pragma unroll
-      for (int w = 0; w < kBlock / 64; ++w) {
-        const int c = l_wtot[w];
-        if (w < wave) off += c;
-        tot += c;
+      for (int u = 0; u < kScanUnroll; ++u) {
+        const int i = scan + u * kBlock + tid;
+        hit[u] = false;
+        if (u < n_u && i < nv) {
+          const Rect rc = b_rect[base + i];
+          hit[u] = (tx >= rc.x0) && (tx < rc.x1) && (ty >= rc.y0) && (ty < rc.y1);
+        }
       }
-      if (hit) {
-        l_a[off + rank] = sa[base + i];
-        l_b[off + rank] = sb[base + i];
-        l_c[off + rank] = sc[base + i];
+      int rank[kScanUnroll];
+#pragma unroll
+      for (int u = 0; u < kScanUnroll; ++u) {
+        const unsigned long long m = __ballot(hit[u]);
+        rank[u] = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) l_wtot[u * (kBlock / 64) + wave] = __popcll(m);
       }
-      count += tot;
-      scan += kBlock;
+      __syncthreads();
+      int off = nrec;
+#pragma unroll
+      for (int u = 0; u < kScanUnroll; ++u) {
+        int mine = off;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) {
+          const int c = l_wtot[u * (kBlock / 64) + w];
+          if (w < wave) mine += c;
+          off += c;
+        }
+        if (hit[u]) rec[mine + rank[u]] = b_comp[base + scan + u * kBlock + tid];
+      }
+      nrec = off;
+      scan += n_u * kBlock;
       __syncthreads();
     }
-    if (count == 0) break;     // list exhausted
-    // ---- blend the `count` staged entries front to back ----
-    for (int j = 0; j < count && !done; ++j) {
-      contributor++;
-      const float4 a = l_a[j];
-      const float4 b = l_b[j];
-      const float dx = a.x - pixf_x, dy = a.y - pixf_y;
-      const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-      if (power > 0.0f) continue;
-      const float alpha = fminf(0.99f, b.y * __expf(power));
-      if (alpha < 1.0f / 255.0f) continue;
-      const float test_T = T * (1 - alpha);
-      if (test_T < 0.0001f) { done = true; continue; }
-      const float2 c = l_c[j];
-      const float wgt = alpha * T;
-      C0 = fmaf(b.w, wgt, C0);
-      C1 = fmaf(c.x, wgt, C1);
-      C2 = fmaf(c.y, wgt, C2);
-      if (depth_mode == 0) {
-        if (T > 0.5f && test_T < 0.5f) D = b.z;
-      } else {
-        D = fmaf(b.z, wgt, D);
-      }
-      T = test_T;
-      last_contributor = contributor;
+    stamp(0);
+    const bool at_end = scan >= nv;
+    if (nrec == 0) {
+      if (at_end) break;
+      continue;
     }
-    // every pixel saturated -> stop scanning (forward.cu:304-307)
-    if (__syncthreads_count(done) == kBlock) break;
+    // ---- exact order of what is held: bitonic sort on (depth bits, id) ----
+    int n2 = kBlock;
+    while (n2 < nrec) n2 <<= 1;
+    for (int i = nrec + tid; i < n2; i += kBlock) rec[i] = kPad;
+    __syncthreads();
+    if (n2 == kBlock) bitonic_sort_regs<1>(rec, tid);
+    else if (n2 == 2 * kBlock) bitonic_sort_regs<2>(rec, tid);
+    else if (n2 == 4 * kBlock) bitonic_sort_regs<4>(rec, tid);
+    else bitonic_sort_lds(rec, n2, tid);
+    stamp(1);
+    // ---- records of buckets that cannot receive further entries are final ----
+    int n_ready = nrec;
+    if (!at_end) {
+      // every unscanned entry lies in bucket >= bucket(entry scan-1): earlier buckets are complete
+      const unsigned last_key = (unsigned)(b_comp[base + scan - 1] >> 32);
+      const int b_last = bucket_of(last_key);
+      if (tid == 0) l_ready = 0;
+      __syncthreads();
+      int cnt = 0;
+      for (int i = tid; i < nrec; i += kBlock) cnt += bucket_of((unsigned)(rec[i] >> 32)) < b_last;
+      for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+      if (lane == 0 && cnt) atomicAdd(&l_ready, cnt);
+      __syncthreads();
+      n_ready = l_ready;
+      if (n_ready == 0) {
+        if (nrec >= kCapRec - kScanUnroll * kBlock) {
+          // one depth bucket alone overflows the LDS capacity for this tile: flag it (the host
+          // wrapper turns this into an error) and fall through blending in the order held
+          if (tid == 0) atomicOr(status, 1);
+          n_ready = nrec;
+        } else {
+          continue;      // keep scanning: the only bucket held is still open
+        }
+      }
+    }
+    stamp(2);
+    // ---- blend the final records front to back, kStage at a time ----
+    for (int s0 = 0; s0 < n_ready && !all_done; s0 += kStage) {
+      const int ns = min(kStage, n_ready - s0);
+      if (tid < ns) {
+        const unsigned long long c = rec[s0 + tid];
+        const unsigned id = (unsigned)(c & 0xFFFFFFFFull);
+        const float2 p = xy[base + id];
+        const float4 co = conic_o[base + id];
+        l_a[tid] = make_float4(p.x, p.y, co.x, co.y);
+        l_b[tid] = make_float4(co.z, co.w, __uint_as_float((unsigned)(c >> 32)), colors[3 * (long)id]);
+        l_c[tid] = make_float2(colors[3 * (long)id + 1], colors[3 * (long)id + 2]);
+      }
+      __syncthreads();
+      // Branch-free per-record update so that the LDS reads of the next records can be issued
+      // ahead (4 records per trip); a wave leaves the batch as soon as its 64 pixels are done.
+      for (int j0 = 0; j0 < ns; j0 += 4) {
+        if (__ballot(!done) == 0ull) break;
+        float4 ra[4], rb[4];
+        float2 rc2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = min(j0 + u, ns - 1);
+          ra[u] = l_a[j];
+          rb[u] = l_b[j];
+          rc2[u] = l_c[j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool live = !done && (j0 + u < ns);
+          contributor += live ? 1u : 0u;
+          const float4 a = ra[u];
+          const float4 b = rb[u];
+          const float dx = a.x - pixf_x, dy = a.y - pixf_y;
+          const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+          const float alpha = fminf(0.99f, b.y * __expf(power));
+          const bool valid = live && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+          const float test_T = T * (1 - alpha);
+          const bool stop = valid && (test_T < 0.0001f);
+          const bool contrib = valid && !stop;
+          const float wgt = contrib ? alpha * T : 0.f;
+          C0 = fmaf(b.w, wgt, C0);
+          C1 = fmaf(rc2[u].x, wgt, C1);
+          C2 = fmaf(rc2[u].y, wgt, C2);
+          if (depth_mode == 0) {
+            D = (contrib && T > 0.5f && test_T < 0.5f) ? b.z : D;
+          } else {
+            D = fmaf(b.z, wgt, D);
+          }
+          T = contrib ? test_T : T;
+          last_contributor = contrib ? contributor : last_contributor;
+          done = done || stop;
+        }
+      }
+      // every pixel saturated -> stop (forward.cu:304-307)
+      all_done = __syncthreads_count(done) == kBlock;
+    }
+    stamp(3);
+    if (all_done || (at_end && n_ready == nrec)) break;
+    // ---- carry the records of the open bucket to the front (still sorted) ----
+    const int left = nrec - n_ready;
+    for (int i0 = 0; i0 < left; i0 += kBlock) {
+      unsigned long long c = 0;
+      if (i0 + tid < left) c = rec[n_ready + i0 + tid];
+      __syncthreads();
+      if (i0 + tid < left) rec[i0 + tid] = c;
+      __syncthreads();
+    }
+    nrec = left;
+    stamp(4);
+  }
+  if constexpr (STAMP) {
+    if (tid == 0) {
+      const long w = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      for (int k = 0; k < 5; ++k) stamps[w * 8 + k] = t_acc[k];
+      stamps[w * 8 + 5] = (unsigned long long)scan;
+      stamps[w * 8 + 6] = (unsigned long long)contributor;
+    }
   }
 
   if (inside) {
@@ -304,51 +596,40 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct RasterWs {
-  size_t keys_in, keys_out, vals_in, vals_out, rects, xy, conic_o, s_rect, sa, sb, sc, n_vis, sort_tmp,
-      total;
-  size_t sort_tmp_bytes;
+  size_t keys, rects, xy, conic_o, b_rect, b_comp, hist, starts, cursor, status, total;
 };
 
-inline hipError_t raster_layout(int P, int n_views, RasterWs* ws) {
+inline void raster_layout(int P, int n_views, RasterWs* ws) {
   const size_t n = (size_t)P * n_views;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
-  ws->keys_in = take(n * 8);
-  ws->keys_out = take(n * 8);
-  ws->vals_in = take(n * 4);
-  ws->vals_out = take(n * 4);
+  ws->keys = take(n * 4);
   ws->rects = take(n * sizeof(Rect));
   ws->xy = take(n * sizeof(float2));
   ws->conic_o = take(n * sizeof(float4));
-  ws->s_rect = take(n * sizeof(Rect));
-  ws->sa = take(n * sizeof(float4));
-  ws->sb = take(n * sizeof(float4));
-  ws->sc = take(n * sizeof(float2));
-  ws->n_vis = take((size_t)n_views * sizeof(int));
-  size_t tmp = 0;
-  hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, (const unsigned long long*)nullptr,
-                                           (unsigned long long*)nullptr, (const unsigned*)nullptr,
-                                           (unsigned*)nullptr, n, 0, 64, nullptr);
-  ws->sort_tmp_bytes = tmp;
-  ws->sort_tmp = take(tmp);
+  ws->b_rect = take(n * sizeof(Rect));
+  ws->b_comp = take(n * 8);
+  ws->hist = take((size_t)n_views * kBuckets * kCopies * sizeof(int));   // becomes the cursors
+  ws->starts = take((size_t)n_views * (kBuckets + 1) * sizeof(int));
+  ws->cursor = take((size_t)n_views * kBuckets * sizeof(int));            // bucket totals
+  ws->status = take(256);
   ws->total = off;
-  return e;
-}
-
-inline int bits_for(int n) {
-  int b = 0;
-  while ((1 << b) < n) ++b;
-  return b;
 }
 
 }  // namespace
 
+unsigned long long* g_stamps = nullptr;   // diagnostic: per-tile phase cycles (ocrf_diag_raster_stamps)
+
 extern "C" {
+
+// Diagnostic: when set (device buffer of tiles*views*8 u64), the next forwards run the stamped
+// build of the blend kernel.  Never used by the product path.
+int ocrf_diag_raster_stamps(unsigned long long* buf) { g_stamps = buf; return 0; }
 
 size_t ocrf_rasterize_workspace_bytes(int P, int n_views) {
   if (P <= 0 || n_views <= 0) return 0;
   RasterWs ws;
-  if (raster_layout(P, n_views, &ws) != hipSuccess) return 0;
+  raster_layout(P, n_views, &ws);
   return ws.total;
 }
 
@@ -357,8 +638,8 @@ int ocrf_rasterize_forward(int P, int n_views, int H, int W, const float* means3
                            float scale_modifier, const float* rotations, const float* cov3D_precomp,
                            const float* cameras, const float* bg, int depth_mode, float* out_color,
                            float* out_depth, float* out_final_T, uint32_t* out_n_contrib, int* radii,
-                           uint32_t* tiles_touched, void* workspace, size_t workspace_bytes,
-                           ocrf_stream_t stream_) {
+                           uint32_t* tiles_touched, int* status, void* workspace,
+                           size_t workspace_bytes, ocrf_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (P < 0 || n_views <= 0 || H <= 0 || W <= 0 || (depth_mode != 0 && depth_mode != 1) ||
       !out_color || !out_depth || !out_final_T || !out_n_contrib || !bg || !cameras)
@@ -376,47 +657,57 @@ int ocrf_rasterize_forward(int P, int n_views, int H, int W, const float* means3
   const int gx = (W + kTileX - 1) / kTileX, gy = (H + kTileY - 1) / kTileY;
   if (gx > 65535 || gy > 65535) return (int)hipErrorInvalidValue;
   RasterWs ws;
-  hipError_t e = raster_layout(P, n_views, &ws);
-  if (e != hipSuccess) return (int)e;
+  raster_layout(P, n_views, &ws);
   if (!workspace || workspace_bytes < ws.total) return (int)hipErrorInvalidValue;
   char* base = static_cast<char*>(workspace);
-  auto* keys_in = reinterpret_cast<unsigned long long*>(base + ws.keys_in);
-  auto* keys_out = reinterpret_cast<unsigned long long*>(base + ws.keys_out);
-  auto* vals_in = reinterpret_cast<unsigned*>(base + ws.vals_in);
-  auto* vals_out = reinterpret_cast<unsigned*>(base + ws.vals_out);
+  auto* keys = reinterpret_cast<unsigned*>(base + ws.keys);
   auto* rects = reinterpret_cast<Rect*>(base + ws.rects);
   auto* xy = reinterpret_cast<float2*>(base + ws.xy);
   auto* conic_o = reinterpret_cast<float4*>(base + ws.conic_o);
-  auto* s_rect = reinterpret_cast<Rect*>(base + ws.s_rect);
-  auto* sa = reinterpret_cast<float4*>(base + ws.sa);
-  auto* sb = reinterpret_cast<float4*>(base + ws.sb);
-  auto* sc = reinterpret_cast<float2*>(base + ws.sc);
-  auto* n_vis = reinterpret_cast<int*>(base + ws.n_vis);
+  auto* b_rect = reinterpret_cast<Rect*>(base + ws.b_rect);
+  auto* b_comp = reinterpret_cast<unsigned long long*>(base + ws.b_comp);
+  auto* hist = reinterpret_cast<int*>(base + ws.hist);
+  auto* starts = reinterpret_cast<int*>(base + ws.starts);
+  auto* cursor = reinterpret_cast<int*>(base + ws.cursor);
+  int* st = status ? status : reinterpret_cast<int*>(base + ws.status);
   const Camera* cams = reinterpret_cast<const Camera*>(cameras);
 
-  e = hipMemsetAsync(n_vis, 0, (size_t)n_views * sizeof(int), stream);
+  hipError_t e = hipMemsetAsync(hist, 0, (size_t)n_views * kBuckets * kCopies * sizeof(int), stream);
   if (e != hipSuccess) return (int)e;
   const dim3 pgrid((P + kBlock - 1) / kBlock, n_views);
   ocrf::launch(OCRF_K_RASTER_PREPROCESS, raster_preprocess_kernel, pgrid, dim3(kBlock), 0, stream, P,
                W, H, gx, gy, means3D, opacities, scales, scale_modifier, rotations, cov3D_precomp,
-               cams, keys_in, vals_in, rects, xy, conic_o, radii, tiles_touched, n_vis);
+               cams, keys, rects, xy, conic_o, radii, tiles_touched, hist);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  size_t tmp = ws.sort_tmp_bytes;
-  e = rocprim::radix_sort_pairs(base + ws.sort_tmp, tmp, keys_in, keys_out, vals_in, vals_out,
-                                (size_t)P * n_views, 0, 32 + bits_for(n_views), stream);
-  if (e != hipSuccess) return (int)e;
-  ocrf::launch(OCRF_K_RASTER_GATHER, raster_gather_kernel, pgrid, dim3(kBlock), 0, stream, P,
-               static_cast<const unsigned long long*>(keys_out), static_cast<const unsigned*>(vals_out),
-               static_cast<const Rect*>(rects), static_cast<const float2*>(xy),
-               static_cast<const float4*>(conic_o), colors, static_cast<const int*>(n_vis), s_rect, sa,
-               sb, sc);
+  int* tot = cursor;
+  ocrf::launch(OCRF_K_RASTER_REDUCE, raster_bucket_reduce_kernel,
+               dim3((unsigned)((size_t)n_views * kBuckets / kBlock)), dim3(kBlock), 0, stream, hist, tot);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  ocrf::launch(OCRF_K_RASTER_BLEND, raster_blend_kernel, dim3(gx, gy, n_views), dim3(kBlock), 0, stream,
-               P, W, H, gx, depth_mode, static_cast<const int*>(n_vis), static_cast<const Rect*>(s_rect),
-               static_cast<const float4*>(sa), static_cast<const float4*>(sb),
-               static_cast<const float2*>(sc), bg, out_color, out_depth, out_final_T, out_n_contrib);
+  ocrf::launch(OCRF_K_RASTER_SCAN, raster_bucket_scan_kernel, dim3(n_views), dim3(kBlock), 0, stream,
+               static_cast<const int*>(tot), starts);
+  e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  ocrf::launch(OCRF_K_RASTER_GATHER, raster_scatter_kernel, pgrid, dim3(kBlock), 0, stream, P,
+               static_cast<const unsigned*>(keys), static_cast<const Rect*>(rects),
+               static_cast<const int*>(starts), hist, b_rect, b_comp);
+  e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  const size_t lds = (size_t)kCapRec * 8 + (size_t)kStage * (16 + 16 + 8);
+  if (g_stamps) {
+    hipLaunchKernelGGL(raster_blend_kernel<true>, dim3(gx, gy, n_views), dim3(kBlock), lds, stream,
+                       g_stamps, P, W, H, depth_mode, static_cast<const int*>(starts),
+                       static_cast<const Rect*>(b_rect), static_cast<const unsigned long long*>(b_comp),
+                       static_cast<const float2*>(xy), static_cast<const float4*>(conic_o), colors, bg,
+                       out_color, out_depth, out_final_T, out_n_contrib, st);
+    return (int)hipGetLastError();
+  }
+  ocrf::launch(OCRF_K_RASTER_BLEND, raster_blend_kernel<false>, dim3(gx, gy, n_views), dim3(kBlock), lds,
+               stream, (unsigned long long*)nullptr, P, W, H, depth_mode, static_cast<const int*>(starts),
+               static_cast<const Rect*>(b_rect), static_cast<const unsigned long long*>(b_comp),
+               static_cast<const float2*>(xy), static_cast<const float4*>(conic_o), colors, bg,
+               out_color, out_depth, out_final_T, out_n_contrib, st);
   return (int)hipGetLastError();
 }
 

@@ -90,6 +90,7 @@ def rasterize_views(means3D, colors, opacities, scales, rotations, viewmatrices,
                n_contrib=torch.empty(V, H, W, dtype=torch.int32, device=dev),
                radii=torch.empty(V, max(P, 0), dtype=torch.int32, device=dev))
     tt = torch.empty(V, P, dtype=torch.int32, device=dev) if want_tiles_touched else None
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
     L = _lib.lib()
     with torch.cuda.device(dev):
         need = L.ocrf_rasterize_workspace_bytes(P, V)
@@ -99,9 +100,10 @@ def rasterize_views(means3D, colors, opacities, scales, rotations, viewmatrices,
             ctypes.c_float(scale_modifier), _lib.ptr(rot), _lib.ptr(cov), _lib.ptr(cams), _lib.ptr(bg),
             {'median': 0, 'mean': 1}[depth_mode], _lib.ptr(out['color']), _lib.ptr(out['depth']),
             _lib.ptr(out['final_T']), _lib.ptr(out['n_contrib']), _lib.ptr(out['radii']), _lib.ptr(tt),
-            _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_ptr(dev)), 'ocrf_rasterize_forward')
+            _lib.ptr(status), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_ptr(dev)), 'ocrf_rasterize_forward')
     if tt is not None:
         out['tiles_touched'] = tt
+    out['status'] = status     # device int; bit 0 = a depth bucket overflowed the exact LDS sort
     return out
 
 

@@ -7,9 +7,13 @@ path intends (``pre_compute``, view_transformer_ocrf.py:854-866).  ``bench.py``,
 ``__graft_entry__.smoke()`` and the sharded runner drive it; frames are treated as extra batch
 entries because they are independent until the channel concat (detectors/ocrfdet.py:274).
 """
+import math
+
+import numpy as np
 import torch
 
-from . import bevpool, index_prep, synthetic
+from . import bevpool, gaussian_renderer, index_prep, synthetic
+from .diff_gaussian_rasterization import rasterize_views
 
 
 class PoolPlan:
@@ -72,6 +76,62 @@ class HotPath:
         self.ht = PoolPlan(*self._or_empty(index_prep.fast_sample_prepare(coor, mask, Wf, Hf, cfg.D)),
                            (self.batch, 1, Y, X, C))
 
+        if cfg.render:
+            self._prepare_render(r)
+
+    def _prepare_render(self, r, convention='corrected', seed=0):
+        """Cameras + synthetic Gaussian parameters of the OcRF render.
+
+        convention 'reference': the reference's own set-up, quirks included
+        (view_transformer_ocrf.py:1135-1152: unscaled 1600x900 intrinsics with the network-input
+        viewport, c2w fed as world->view); 'corrected': intrinsics scaled/cropped to the network
+        input and a proper world->view transform (the headline of SURVEY.md 8d)."""
+        cfg, dev = self.cfg, self.device
+        H, W = cfg.input_size
+        vms, pms, tfx, tfy = [], [], [], []
+        for n in self.cams:
+            K = r['intrins'][0, n].astype(np.float64)
+            c2w = r['c2w'][0, n].astype(np.float64)
+            if convention == 'corrected':
+                s, crop = r['resize'], r['crop_h']
+                K = np.array([[K[0, 0] * s, 0, K[0, 2] * s], [0, K[1, 1] * s, K[1, 2] * s - crop], [0, 0, 1.0]])
+                w2c = np.linalg.inv(c2w)
+                c2w_arg = np.eye(4)
+                c2w_arg[:3, :3] = c2w[:3, :3]          # getWorld2View2 transposes R itself
+                c2w_arg[:3, 3] = w2c[:3, 3]
+            else:
+                c2w_arg = c2w
+            cam = gaussian_renderer.camera_from_calibration(K.astype(np.float32), c2w_arg.astype(np.float32), H, W)
+            vms.append(cam['world_view_transform']), pms.append(cam['full_proj_transform'])
+            tfx.append(math.tan(float(cam['FovX']) * 0.5)), tfy.append(math.tan(float(cam['FovY']) * 0.5))
+        self.render_cams = dict(vm=torch.stack(vms).to(dev), pm=torch.stack(pms).to(dev), tfx=tfx, tfy=tfy)
+        P = self.voxel_xyz.shape[1] * self.voxel_xyz.shape[2]
+        rng = np.random.default_rng(seed)
+        q = rng.standard_normal((P, 4)).astype(np.float32)
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+        # ranges of the reference's Gaussian heads at seeded init (SURVEY.md 8d probe)
+        self.gauss = dict(scales=t(rng.uniform(0.69, 0.84, (P, 3)).astype(np.float32)), rotations=t(q),
+                          opacity=t(rng.uniform(0.35, 0.45, (P, 1)).astype(np.float32)),
+                          rgb=t(rng.uniform(0.0, 1.0, (P, 3)).astype(np.float32)))
+        self.bg = torch.zeros(3, device=dev)
+        self.render_convention = convention
+
+    def render(self):
+        """All owned cameras of every frame: list (one per frame) of dicts from rasterize_views."""
+        cfg, rc, g = self.cfg, self.render_cams, self.gauss
+        H, W = cfg.input_size
+        outs = []
+        for b in range(self.batch):
+            xyz = self.voxel_xyz[b].reshape(-1, 3)
+            outs.append(rasterize_views(xyz, g['rgb'], g['opacity'], g['scales'], g['rotations'], rc['vm'],
+                                        rc['pm'], rc['tfx'], rc['tfy'], H, W, self.bg))
+        return outs
+
+    @property
+    def views_per_step(self):
+        return self.batch * len(self.cams) if self.cfg.render else 0
+
     def _or_empty(self, five):
         if five[0] is None:
             e = torch.zeros(0, dtype=torch.int32, device=self.device)
@@ -97,7 +157,10 @@ class HotPath:
     def step(self, depth, feat):
         """One pass: LSS BEV (B, Z*C, Y, X) and HT BEV (B, C, Y, X) (view_transformer.py:194,
         view_transformer_ocrf.py:781)."""
-        return self.pool(self.lss, depth, feat), self.pool(self.ht, depth, feat)
+        lss, ht = self.pool(self.lss, depth, feat), self.pool(self.ht, depth, feat)
+        if self.cfg.render:
+            return lss, ht, self.render()
+        return lss, ht
 
     @property
     def bev_voxels_per_step(self):

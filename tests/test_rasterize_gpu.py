@@ -34,6 +34,7 @@ def _both(oracle_lib, cuda, xyz, rgb, opac, sc, rot, view, full, tfx, tfy, H, W,
                               _t(view, cuda).view(1, 4, 4), _t(full, cuda).view(1, 4, 4), [tfx], [tfy], H, W,
                               _t(np.float32(bg), cuda), depth_mode=depth_mode, want_tiles_touched=True)
     torch.cuda.synchronize()
+    assert int(got['status'].item()) == 0, 'a depth bucket overflowed the in-LDS exact sort'
     return want, {k: v.cpu().numpy() for k, v in got.items()}
 
 
