@@ -155,6 +155,37 @@ int ocrf_rasterize_forward(int P, int n_views, int H, int W, const float *means3
 size_t ocrf_rasterize_workspace_bytes(int P, int n_views);
 
 /* ------------------------------------------------------------------------------------------
+ * Height-aware Opacity-based Attention (HOA) reductions
+ * ------------------------------------------------------------------------------------------
+ * All tensors float32, NCHW contiguous.
+ *
+ * ocrf_hoa_channel_stats + ocrf_hoa_opacity_mask_gate replace ObatinOpacityMask.forward
+ * (mmdet3d/models/necks/view_transformer_ocrf.py:236-242) and `geom_feat * opacity_mask`
+ * (:1197-1199):
+ *   stats[b][0] = mean_c x[b][c], stats[b][1] = max_c x[b][c]                       (B,2,Y,X)
+ *   mask  = sigmoid(conv2d(stats, conv_w (1,2,k,k), padding k/2, no bias) + opacity_bev)  (B,1,Y,X)
+ *   gated = x * mask (skipped when gated == NULL)                                    (B,C,Y,X)
+ */
+int ocrf_hoa_channel_stats(const float *x, int B, int C, int Y, int X, float *stats,
+                           ocrf_stream_t stream);
+int ocrf_hoa_opacity_mask_gate(const float *x, const float *stats, const float *opacity_bev,
+                               const float *conv_w, int k, int B, int C, int Y, int X, float *mask,
+                               float *gated, ocrf_stream_t stream);
+
+/*
+ * HeightAttention.forward (view_transformer_ocrf.py:447-461) and its use `ca(x) * x`
+ * (:499-514): the C channels are four height quarters of q = C/4 channels; per quarter g
+ *   gate[b][g*q + o] = sigmoid( sum_h w2[g][o][h] * relu( sum_i w1[g][h][i] * max_{y,x} x[b][g*q+i] ) )
+ * w1 is [4][hid][q] (convN.0.weight), w2 is [4][q][hid] (convN.2.weight), no biases.
+ *   gate (B,C) is always written; gated = gate * x (B,C,Y,X) when gated != NULL.
+ * C % 4 == 0, C <= 64, 4*hid <= 64.  workspace >= ocrf_hoa_height_attention_workspace_bytes(B, C).
+ */
+int ocrf_hoa_height_attention(const float *x, int B, int C, int hid, int Y, int X, const float *w1,
+                              const float *w2, float *gate, float *gated, void *workspace,
+                              size_t workspace_bytes, ocrf_stream_t stream);
+size_t ocrf_hoa_height_attention_workspace_bytes(int B, int C);
+
+/* ------------------------------------------------------------------------------------------
  * Per-kernel device timer (measurement aid for bench.py; not part of the reference's surface)
  * ------------------------------------------------------------------------------------------
  * While a timer is armed for kernel id K, every launch of K inside the library is bracketed by
@@ -171,7 +202,11 @@ enum {
   OCRF_K_RASTER_BLEND = 11,      /* raster_blend_kernel */
   OCRF_K_RASTER_GATHER = 12,     /* raster_scatter_kernel */
   OCRF_K_RASTER_SCAN = 13,       /* raster_bucket_scan_kernel */
-  OCRF_K_RASTER_REDUCE = 14      /* raster_bucket_reduce_kernel */
+  OCRF_K_RASTER_REDUCE = 14,     /* raster_bucket_reduce_kernel */
+  OCRF_K_HOA_STATS = 20,         /* hoa_channel_stats_kernel */
+  OCRF_K_HOA_MASK_GATE = 21,     /* hoa_mask_gate_kernel */
+  OCRF_K_HOA_HEIGHT_MAX = 22,    /* hoa_height_max_kernel */
+  OCRF_K_HOA_HEIGHT_GATE = 23    /* hoa_height_gate_kernel */
 };
 const char *ocrf_kernel_name(int kernel_id);           /* symbol as rocprofv3 prints it */
 int ocrf_timer_create(int capacity, void **timer_out); /* host pointers */

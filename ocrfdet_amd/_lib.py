@@ -71,6 +71,15 @@ def _declare(L):
                                          [c_int] + [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p])
     L.ocrf_rasterize_workspace_bytes.restype = c_size_t
     L.ocrf_rasterize_workspace_bytes.argtypes = [c_int, c_int]
+    L.ocrf_hoa_channel_stats.restype = c_int
+    L.ocrf_hoa_channel_stats.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
+    L.ocrf_hoa_opacity_mask_gate.restype = c_int
+    L.ocrf_hoa_opacity_mask_gate.argtypes = [c_void_p] * 4 + [c_int] * 5 + [c_void_p] * 3
+    L.ocrf_hoa_height_attention.restype = c_int
+    L.ocrf_hoa_height_attention.argtypes = ([c_void_p] + [c_int] * 5 + [c_void_p] * 4 +
+                                            [c_void_p, c_size_t, c_void_p])
+    L.ocrf_hoa_height_attention_workspace_bytes.restype = c_size_t
+    L.ocrf_hoa_height_attention_workspace_bytes.argtypes = [c_int, c_int]
     L.ocrf_kernel_name.restype = ctypes.c_char_p
     L.ocrf_kernel_name.argtypes = [c_int]
     L.ocrf_timer_create.restype = c_int
@@ -126,6 +135,7 @@ workspace = Workspace()
 
 K_BEV_POOL_FWD, K_BEV_POOL_FIXUP, K_BEV_POOL_INTERVAL, K_BEV_POOL_GRAD, K_BEV_POOL_NCHW = 1, 2, 3, 4, 5
 K_RASTER_PREPROCESS, K_RASTER_BLEND, K_RASTER_GATHER = 10, 11, 12
+K_HOA_STATS, K_HOA_MASK_GATE, K_HOA_HEIGHT_MAX, K_HOA_HEIGHT_GATE = 20, 21, 22, 23
 
 
 class KernelTimer:

@@ -1,0 +1,263 @@
+"""Height-aware Opacity-based Attention (HOA) — modules with the reference's class names,
+constructor arguments, forward signatures and ``state_dict`` keys, so checkpoints and the config's
+per-layer options (configs/ocrfdet/ocrfdet.py:259-337) carry over:
+
+``HeightAttention(input_channel, output_channel, ratio=16).forward(x) -> (B,C,1,1)``
+    view_transformer_ocrf.py:421-461
+``OpacityVoxelToBEVConverter(input_channel=13).forward(x, position) -> (B,1,Y,X)``   (HOA-2)
+    view_transformer_ocrf.py:463-518
+``ObatinOpacityMask(kernel_size=7).forward(x, opacity_bev) -> (B,1,Y,X)``            (HOA-3)
+    view_transformer_ocrf.py:230-242; ``.gate(x, opacity_bev)`` also returns ``x * mask`` (:1199)
+``DeformableAttention2D(dim, dim_head, heads, dropout, downsample_factor, offset_scale,
+offset_groups, offset_kernel_size).forward(x_q, x_kv)``                               (HOA-1)
+    mmdet3d/ops/cross_attention_2d.py:93-220 and ``hoa1`` = the glue at
+    view_transformer_ocrf.py:1159-1161
+
+The channel reductions and gates run as HIP kernels (``csrc/hoa.hip`` through the C ABI):
+channel mean/max + 7x7 conv + sigmoid + gate for HOA-3, global max + quarter MLPs + sigmoid (+ the
+``ca(x) * x`` multiply) for HeightAttention.  The small dense convolutions of the UNet and of the
+deformable attention stay PyTorch-ROCm ops (plumbing; SURVEY.md 8a rows a24-a25 note they are
+~40 tiny launches, not custom-kernel targets of the reference either).  GPU tensors only.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib
+
+__all__ = ['HeightAttention', 'OpacityVoxelToBEVConverter', 'ObatinOpacityMask', 'DeformableAttention2D',
+           'CPB', 'hoa1']
+
+
+def _f32c(t):
+    return t.contiguous().float()
+
+
+class HeightAttention(nn.Module):
+    def __init__(self, input_channel, output_channel, ratio=16):
+        super().__init__()
+        qi, qo = input_channel // 4, output_channel // 4
+        self.q_in, self.q_out, self.hid = qi, qo, qi // ratio
+
+        def branch():
+            return nn.Sequential(nn.Conv2d(qi, qi // ratio, 1, bias=False), nn.ReLU(inplace=True),
+                                 nn.Conv2d(qi // ratio, qo, 1, bias=False))
+        self.max_pool1, self.conv1 = nn.AdaptiveMaxPool2d(1), branch()
+        self.max_pool2, self.conv2 = nn.AdaptiveMaxPool2d(1), branch()
+        self.max_pool3, self.conv3 = nn.AdaptiveMaxPool2d(1), branch()
+        self.max_pool4, self.conv4 = nn.AdaptiveMaxPool2d(1), branch()
+        self.tanh = nn.Sigmoid()           # the reference names its sigmoid `tanh` (:445)
+
+    def _packed(self):
+        convs = (self.conv1, self.conv2, self.conv3, self.conv4)
+        w1 = torch.stack([c[0].weight.reshape(self.hid, self.q_in) for c in convs]).contiguous().float()
+        w2 = torch.stack([c[2].weight.reshape(self.q_out, self.hid) for c in convs]).contiguous().float()
+        return w1, w2
+
+    def _run(self, x, want_gated):
+        _lib.require_cuda(x)
+        B, C, Y, X = x.shape
+        if C != 4 * self.q_in or self.q_in != self.q_out:
+            raise _lib.OcrfHipError(f'HeightAttention built for {4 * self.q_in}->{4 * self.q_out} channels, got {C}')
+        x = _f32c(x)
+        w1, w2 = self._packed()
+        gate = torch.empty(B, C, device=x.device)
+        gated = torch.empty_like(x) if want_gated else None
+        L = _lib.lib()
+        with torch.cuda.device(x.device):
+            ws = _lib.workspace.get(x.device, L.ocrf_hoa_height_attention_workspace_bytes(B, C), 'hoa')
+            _lib.check(L.ocrf_hoa_height_attention(
+                _lib.ptr(x), B, C, self.hid, Y, X, _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(gate), _lib.ptr(gated),
+                _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_ptr(x.device)), 'ocrf_hoa_height_attention')
+        return gate.view(B, C, 1, 1), gated
+
+    def forward(self, x):
+        return self._run(x, False)[0]
+
+    def gate_apply(self, x):
+        """``self(x) * x`` in one pass (view_transformer_ocrf.py:499-514)."""
+        return self._run(x, True)[1]
+
+
+class OpacityVoxelToBEVConverter(nn.Module):
+    def __init__(self, input_channel=13):
+        super().__init__()
+        self.encoder1 = self.conv_block(input_channel, 4)
+        self.ca1 = HeightAttention(4, 4, 1)
+        self.encoder2 = self.conv_block(4, 8)
+        self.ca2 = HeightAttention(8, 8, 1)
+        self.pool = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.bottleneck = self.conv_block(8, 16)
+        self.ca_bottleneck = HeightAttention(16, 16, 1)
+        self.upconv2 = self.upconv(16, 8)
+        self.decoder2 = self.conv_block(16, 8)
+        self.ca_dec2 = HeightAttention(8, 8, 1)
+        self.upconv1 = self.upconv(8, 4)
+        self.decoder1 = self.conv_block(8, 4)
+        self.ca_dec1 = HeightAttention(4, 4, 1)
+        self.output_conv = nn.Conv2d(4, 1, kernel_size=1)
+
+    @staticmethod
+    def conv_block(in_channels, out_channels):
+        return nn.Sequential(nn.Conv2d(in_channels, in_channels, 3, padding=1, groups=in_channels),
+                             nn.Conv2d(in_channels, out_channels, 1), nn.BatchNorm2d(out_channels),
+                             nn.ReLU(inplace=True))
+
+    @staticmethod
+    def upconv(in_channels, out_channels):
+        return nn.ConvTranspose2d(in_channels, out_channels, kernel_size=2, stride=2)
+
+    def forward(self, x, position):
+        enc1 = self.ca1.gate_apply(self.encoder1(x) + position)
+        enc2 = self.ca2.gate_apply(self.encoder2(self.pool(enc1)))
+        mid = self.ca_bottleneck.gate_apply(self.bottleneck(self.pool(enc2)))
+        dec2 = self.ca_dec2.gate_apply(self.decoder2(torch.cat((self.upconv2(mid), enc2), dim=1)))
+        dec1 = self.ca_dec1.gate_apply(self.decoder1(torch.cat((self.upconv1(dec2), enc1), dim=1)))
+        return self.output_conv(dec1)
+
+
+class ObatinOpacityMask(nn.Module):          # sic: the reference's spelling
+    def __init__(self, kernel_size=7):
+        super().__init__()
+        self.conv = nn.Conv2d(2, 1, kernel_size, padding=kernel_size // 2, bias=False)
+        self.sigmoid = nn.Sigmoid()
+
+    def _run(self, x, opacity_bev, want_gated):
+        _lib.require_cuda(x, opacity_bev)
+        B, C, Y, X = x.shape
+        x, ob = _f32c(x), _f32c(opacity_bev)
+        w = _f32c(self.conv.weight)
+        k = w.shape[-1]
+        stats = torch.empty(B, 2, Y, X, device=x.device)
+        mask = torch.empty(B, 1, Y, X, device=x.device)
+        gated = torch.empty_like(x) if want_gated else None
+        L = _lib.lib()
+        with torch.cuda.device(x.device):
+            st = _lib.stream_ptr(x.device)
+            _lib.check(L.ocrf_hoa_channel_stats(_lib.ptr(x), B, C, Y, X, _lib.ptr(stats), st), 'ocrf_hoa_channel_stats')
+            _lib.check(L.ocrf_hoa_opacity_mask_gate(_lib.ptr(x), _lib.ptr(stats), _lib.ptr(ob), _lib.ptr(w), k, B, C,
+                                                    Y, X, _lib.ptr(mask), _lib.ptr(gated), st),
+                       'ocrf_hoa_opacity_mask_gate')
+        return mask, gated
+
+    def forward(self, x, opacity_bev):
+        return self._run(x, opacity_bev, False)[0]
+
+    def gate(self, x, opacity_bev):
+        """-> (mask, x * mask): view_transformer_ocrf.py:1197-1199 in two HBM passes."""
+        return self._run(x, opacity_bev, True)
+
+
+# ------------------------------------------------------------------------------------------------
+# HOA-1: deformable cross attention on the (1,13,21,21) opacity / alpha maps
+# ------------------------------------------------------------------------------------------------
+def _grid_like(t, dim=0):
+    h, w = t.shape[-2:]
+    xs = torch.arange(w, device=t.device)
+    ys = torch.arange(h, device=t.device)
+    gx, gy = torch.meshgrid(xs, ys, indexing='xy')
+    return torch.stack((gx, gy), dim=dim).type_as(t)
+
+
+def _normalize_grid(grid, dim=1, out_dim=-1):
+    # as written in the reference (cross_attention_2d.py:30-38): channel 0 over (h-1), 1 over (w-1)
+    h, w = grid.shape[-2:]
+    g0, g1 = grid.unbind(dim=dim)
+    return torch.stack((2.0 * g0 / max(h - 1, 1) - 1.0, 2.0 * g1 / max(w - 1, 1) - 1.0), dim=out_dim)
+
+
+class _Scale(nn.Module):
+    def __init__(self, scale):
+        super().__init__()
+        self.scale = scale
+
+    def forward(self, x):
+        return x * self.scale
+
+
+class CPB(nn.Module):
+    """Continuous positional bias MLP (cross_attention_2d.py:49-89)."""
+
+    def __init__(self, dim, *, heads, offset_groups, depth):
+        super().__init__()
+        self.heads, self.offset_groups = heads, offset_groups
+        self.mlp = nn.ModuleList([nn.Sequential(nn.Linear(2, dim), nn.ReLU())])
+        for _ in range(depth - 1):
+            self.mlp.append(nn.Sequential(nn.Linear(dim, dim), nn.ReLU()))
+        self.mlp.append(nn.Linear(dim, heads // offset_groups))
+
+    def forward(self, grid_q, grid_kv):
+        gq = grid_q.reshape(1, -1, grid_q.shape[-1])
+        gk = grid_kv.reshape(grid_kv.shape[0], -1, grid_kv.shape[-1])
+        pos = gq[:, :, None, :] - gk[:, None, :, :]
+        bias = torch.sign(pos) * torch.log(pos.abs() + 1)
+        for layer in self.mlp:
+            bias = layer(bias)
+        bg, i, j, o = bias.shape
+        g = self.offset_groups
+        return bias.view(bg // g, g, i, j, o).permute(0, 1, 4, 2, 3).reshape(bg // g, g * o, i, j)
+
+
+class DeformableAttention2D(nn.Module):
+    def __init__(self, *, dim, dim_head=64, heads=8, dropout=0., downsample_factor=4, offset_scale=None,
+                 offset_groups=None, offset_kernel_size=6, group_queries=True, group_key_values=True):
+        super().__init__()
+        offset_scale = downsample_factor if offset_scale is None else offset_scale
+        assert offset_kernel_size >= downsample_factor
+        assert (offset_kernel_size - downsample_factor) % 2 == 0
+        offset_groups = heads if offset_groups is None else offset_groups
+        assert heads % offset_groups == 0
+        inner = dim_head * heads
+        self.scale = dim_head ** -0.5
+        self.heads, self.offset_groups, self.downsample_factor = heads, offset_groups, downsample_factor
+        od = inner // offset_groups
+        self.to_offsets = nn.Sequential(
+            nn.Conv2d(od, od, offset_kernel_size, groups=od, stride=downsample_factor,
+                      padding=(offset_kernel_size - downsample_factor) // 2),
+            nn.GELU(), nn.Conv2d(od, 2, 1, bias=False), nn.Tanh(), _Scale(offset_scale))
+        self.rel_pos_bias = CPB(dim // 4, offset_groups=offset_groups, heads=heads, depth=2)
+        self.dropout = nn.Dropout(dropout)
+        self.to_q = nn.Conv2d(dim, inner, 1, groups=offset_groups if group_queries else 1, bias=False)
+        self.to_k = nn.Conv2d(dim, inner, 1, groups=offset_groups if group_key_values else 1, bias=False)
+        self.to_v = nn.Conv2d(dim, inner, 1, groups=offset_groups if group_key_values else 1, bias=False)
+        self.to_out = nn.Conv2d(inner, dim, 1)
+
+    def forward(self, x_q, x_kv, return_vgrid=False):
+        b, _, h, w = x_q.shape
+        g, heads = self.offset_groups, self.heads
+        q = self.to_q(x_q)
+
+        def grp(t):                               # 'b (g d) ... -> (b g) d ...'
+            return t.reshape(t.shape[0] * g, t.shape[1] // g, *t.shape[2:])
+        offsets = self.to_offsets(grp(q))
+        vgrid = _grid_like(offsets) + offsets
+        vgrid_scaled = _normalize_grid(vgrid)
+        kv = F.grid_sample(grp(x_kv), vgrid_scaled, mode='bilinear', padding_mode='zeros', align_corners=False)
+        kv = kv.reshape(b, -1, *kv.shape[2:])
+        k, v = self.to_k(kv), self.to_v(kv)
+        q = q * self.scale
+
+        def split(t):                             # 'b (h d) ... -> b h (...) d'
+            return t.reshape(t.shape[0], heads, t.shape[1] // heads, -1).transpose(2, 3)
+        q, k, v = split(q), split(k), split(v)
+        sim = q @ k.transpose(-1, -2)
+        grid_scaled = _normalize_grid(_grid_like(x_kv), dim=0)
+        sim = sim + self.rel_pos_bias(grid_scaled, vgrid_scaled)
+        sim = sim - sim.amax(dim=-1, keepdim=True).detach()
+        attn = self.dropout(sim.softmax(dim=-1))
+        out = (attn @ v).transpose(2, 3).reshape(b, -1, h, w)
+        out = self.to_out(out)
+        return (out, vgrid) if return_vgrid else out
+
+
+def hoa1(defor_cross_attention, opacity, alpha_lidar, heights, Y, X):
+    """view_transformer_ocrf.py:1159-1161: opacity (heights*Y*X, 1) from A_MLP, alpha_lidar
+    (1,heights,Y,X) -> opacity_alpha (1,heights,Y,X)."""
+    o = opacity.view(1, heights, Y, X)
+    size = (int(Y / 6), int(X / 6))
+    o_up = F.interpolate(o, size=size, mode='bilinear', align_corners=True)
+    a_up = F.interpolate(alpha_lidar, size=size, mode='bilinear', align_corners=True)
+    att = defor_cross_attention(o_up, a_up)
+    return F.interpolate(att, size=(Y, X), mode='bilinear', align_corners=True) + o

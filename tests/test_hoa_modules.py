@@ -1,0 +1,97 @@
+"""HOA modules of ocrfdet_amd.hoa: state_dict compatibility with the reference (strict load of the
+reference's own weights from tests/golden/hoa.npz) on the CPU, numerics on the GPU (HIP kernels
+through the C ABI) against the reference's outputs and the numpy oracle."""
+import numpy as np
+import pytest
+import torch
+
+from ocrfdet_amd import hoa
+
+
+def _sd(g, prefix):
+    return {k[len(prefix) + 1:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith(prefix + '.')}
+
+
+@pytest.fixture(scope='module')
+def g(golden):
+    return dict(golden('hoa.npz'))
+
+
+def test_state_dicts_load_strictly(g):
+    hoa.ObatinOpacityMask().load_state_dict(_sd(g, 'mask'), strict=True)
+    for ch in (4, 8, 16):
+        hoa.HeightAttention(ch, ch, 1).load_state_dict(_sd(g, f'ha{ch}'), strict=True)
+    hoa.OpacityVoxelToBEVConverter(13).load_state_dict(_sd(g, 'v2b'), strict=True)
+    hoa.DeformableAttention2D(dim=13, dim_head=8, heads=1, dropout=0.1, downsample_factor=4, offset_scale=4,
+                              offset_groups=None, offset_kernel_size=6).load_state_dict(_sd(g, 'dca'), strict=True)
+
+
+def test_deformable_attention_matches_reference_on_cpu(g):
+    m = hoa.DeformableAttention2D(dim=13, dim_head=8, heads=1, dropout=0.1, downsample_factor=4, offset_scale=4,
+                                  offset_groups=None, offset_kernel_size=6).eval()
+    m.load_state_dict(_sd(g, 'dca'))
+    with torch.no_grad():
+        out = m(torch.from_numpy(g['dca_q']), torch.from_numpy(g['dca_kv']))
+        full = hoa.hoa1(m, torch.from_numpy(g['hoa1_opacity'].astype(np.float32)),
+                        torch.from_numpy(g['hoa1_alpha'].astype(np.float32)), 13, 128, 128)
+    np.testing.assert_allclose(out.numpy(), g['dca_out'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(full[:, :, ::5, ::3].numpy(), g['hoa1_out_slice'], rtol=1e-5, atol=1e-6)
+
+
+def test_cpu_tensors_are_refused(g):
+    from ocrfdet_amd import _lib
+    with pytest.raises(_lib.OcrfHipError):
+        hoa.ObatinOpacityMask()(torch.zeros(1, 8, 4, 4), torch.zeros(1, 1, 4, 4))
+
+
+@pytest.mark.gpu
+def test_opacity_mask_gate_gpu(cuda, g):
+    from oracle import hoa as ohoa
+    m = hoa.ObatinOpacityMask().to(cuda)
+    m.load_state_dict(_sd(g, 'mask'))
+    x, ob = torch.from_numpy(g['mask_in_x']).to(cuda), torch.from_numpy(g['mask_in_opacity']).to(cuda)
+    mask, gated = m.gate(x, ob)
+    np.testing.assert_allclose(mask.cpu().numpy(), g['mask_out'], rtol=1e-4, atol=1e-5)          # reference
+    np.testing.assert_allclose(gated.cpu().numpy(), g['mask_gated'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(m(x, ob).cpu().numpy(), ohoa.opacity_mask(g['mask_in_x'], g['mask_in_opacity'], g, 'mask'),
+                               rtol=1e-4, atol=1e-5)                                             # oracle
+    # full BEV size of the headline config, ragged against the 256-pixel workgroups
+    rng = np.random.default_rng(0)
+    xb = rng.standard_normal((2, 80, 200, 200)).astype(np.float32)
+    obb = rng.standard_normal((2, 1, 200, 200)).astype(np.float32)
+    want = ohoa.opacity_mask(xb, obb, g, 'mask')
+    mask, gated = m.gate(torch.from_numpy(xb).to(cuda), torch.from_numpy(obb).to(cuda))
+    np.testing.assert_allclose(mask.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gated.cpu().numpy(), xb * want, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_height_attention_gpu(cuda, g):
+    for ch in (4, 8, 16):
+        m = hoa.HeightAttention(ch, ch, 1).to(cuda)
+        m.load_state_dict(_sd(g, f'ha{ch}'))
+        x = torch.from_numpy(g[f'ha{ch}_in']).to(cuda)
+        gate = m(x)
+        assert gate.shape == (2, ch, 1, 1)
+        np.testing.assert_allclose(gate.cpu().numpy(), g[f'ha{ch}_out'], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(m.gate_apply(x).cpu().numpy(), g[f'ha{ch}_out'] * g[f'ha{ch}_in'], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_opacity_voxel_to_bev_gpu(cuda, g):
+    m = hoa.OpacityVoxelToBEVConverter(13).to(cuda).eval()
+    m.load_state_dict(_sd(g, 'v2b'))
+    with torch.no_grad():
+        out = m(torch.from_numpy(g['v2b_in']).to(cuda), torch.from_numpy(g['v2b_pos']).to(cuda))
+    np.testing.assert_allclose(out.cpu().numpy(), g['v2b_out'], rtol=1e-4, atol=3e-5)
+
+
+@pytest.mark.gpu
+def test_hoa1_gpu(cuda, g):
+    m = hoa.DeformableAttention2D(dim=13, dim_head=8, heads=1, dropout=0.1, downsample_factor=4, offset_scale=4,
+                                  offset_groups=None, offset_kernel_size=6).to(cuda).eval()
+    m.load_state_dict(_sd(g, 'dca'))
+    with torch.no_grad():
+        full = hoa.hoa1(m, torch.from_numpy(g['hoa1_opacity'].astype(np.float32)).to(cuda),
+                        torch.from_numpy(g['hoa1_alpha'].astype(np.float32)).to(cuda), 13, 128, 128)
+    np.testing.assert_allclose(full[:, :, ::5, ::3].cpu().numpy(), g['hoa1_out_slice'], rtol=1e-4, atol=2e-5)
