@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-DEFAULT_CONFIG = 'cfg1_6cam_256x704_bev128x128x8'
+DEFAULT_CONFIG = 'cfg2_6cam_2frame_bev200x200_render_hoa'
 
 
 def parse():
@@ -37,7 +37,10 @@ def parse():
 
 
 def cpu_baseline(hp, depth, feat, budget_s):
-    """Times the C oracle (oracle/bev_pool_ref.c, OpenMP) on the same step: LSS pool + HT pool."""
+    """Times the C/OpenMP oracle on a bounded sample of the same step: the two pools of the whole
+    step (a few repetitions) and ONE rendered view (the reference-structured rasteriser sorts all
+    tile instances, so a full step of views would take minutes); the step time is assembled as
+    t_pools + views_per_step * t_view."""
     import numpy as np
     import oracle
     oracle.build()
@@ -46,21 +49,44 @@ def cpu_baseline(hp, depth, feat, budget_s):
     for p in (hp.lss, hp.ht):
         plans.append(tuple(t.cpu().numpy() for t in (p.ranks_depth, p.ranks_feat, p.ranks_bev, p.starts, p.lengths)) + (p.bev_shape,))
 
-    def one():
+    def pools():
         for rd, rf, rb, st, ln, shape in plans:
             oracle.bev_pool_v2(d, f, rd, rf, rb, shape, st, ln)     # includes the wrapper's permute
-    one()                                                            # warm-up
+    pools()                                                          # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
-        one()
+        pools()
         n += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or n >= 400:
+        if el >= min(budget_s, 5.0) or n >= 200:
             break
-    return dict(value=hp.bev_voxels_per_step * n / el, unit='BEV voxels/s', cores=oracle.num_threads(),
-                kind='port', ms_per_step=1e3 * el / n,
-                sample=f'{n} full steps (LSS pool + HT pool, same inputs and ranks as the GPU step) '
-                       f'in {el:.1f} s with the C/OpenMP oracle')
+    t_pools = el / n
+    t_view, n_views_timed, rendered = 0.0, 0, None
+    if hp.cfg.render:
+        g = hp.gauss
+        Himg, Wimg = hp.cfg.input_size
+        args = (hp.voxel_xyz[0].reshape(-1, 3).cpu().numpy(), g['rgb'].cpu().numpy(), g['opacity'].cpu().numpy(),
+                g['scales'].cpu().numpy(), g['rotations'].cpu().numpy())
+        t0 = time.perf_counter()
+        while True:
+            v = n_views_timed % len(hp.cams)
+            r = oracle.rasterize_forward(*args, hp.render_cams['vm'][v].cpu().numpy(), hp.render_cams['pm'][v].cpu().numpy(),
+                                         hp.render_cams['tfx'][v], hp.render_cams['tfy'][v], Himg, Wimg,
+                                         np.zeros(3, np.float32))
+            rendered = r['num_rendered']
+            n_views_timed += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s or n_views_timed >= 12:
+                break
+        t_view = el / n_views_timed
+    t_step = t_pools + hp.views_per_step * t_view
+    return dict(value=hp.bev_voxels_per_step / t_step, unit='BEV voxels/s', cores=oracle.num_threads(),
+                kind='port', ms_per_step=1e3 * t_step, ms_pools=1e3 * t_pools, ms_per_view=1e3 * t_view,
+                views_per_sec=(hp.views_per_step / t_step) if hp.views_per_step else 0.0,
+                sample=f'{n} x (LSS pool + HT pool of the whole step, same inputs and ranks as the GPU)'
+                       + (f' and {n_views_timed} rendered view(s) of frame 0 ({rendered} tile instances in the last), '
+                          f'step time assembled as pools + {hp.views_per_step} x view' if hp.cfg.render else '')
+                       + '; HOA (small torch convs) not included; C/OpenMP oracle')
 
 
 def main():
@@ -82,21 +108,23 @@ def main():
     # frames are independent until the channel concat (detectors/ocrfdet.py:274)
     hp = hotpath.HotPath(cfg, dev)
     depth, feat = hp.make_inputs(seed=rank)
-    gathered = None
-    if world > 1:
-        lss0, ht0 = hp.step(depth, feat)
-        both = torch.cat((lss0, ht0), 1)
-        gathered = torch.empty((world,) + tuple(both.shape), device=dev)
+    # N > 1 (weak scaling, frame policy of ocrfdet_amd.sharding): every rank owns cfg.n_frames whole
+    # frames of a (world * n_frames)-frame sequence — frames are independent until the channel
+    # concat (detectors/ocrfdet.py:274) — and ONE RCCL all_gather per step hands every rank the
+    # fused (LSS | HT) BEV of all frames, the operand of that concat.
+    from ocrfdet_amd import sharding
 
     def step():
-        lss, ht = hp.step(depth, feat)
+        out = hp.step(depth, feat)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, torch.cat((lss, ht), 1))
-        return lss, ht
+            fused = torch.cat((out[0], out[-2] if cfg.hoa else out[1]), 1)       # (frames, Z*C + C, Y, X)
+            sharding.gather_frames(fused, world * fused.shape[0])
+        return out
 
     for _ in range(args.warmup):
         step()
-    timer = _lib.KernelTimer(_lib.K_BEV_POOL_FWD, 2 * args.steps)
+    dom_id = _lib.K_RASTER_BLEND if cfg.render else _lib.K_BEV_POOL_FWD
+    timer = _lib.KernelTimer(dom_id, 2 * args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -117,21 +145,31 @@ def main():
     if rank == 0:
         ms = timer.read_ms()
         avg_ms = sum(ms) / max(len(ms), 1)
-        alg_bytes = 0.5 * (hp.lss.algorithmic_bytes(depth.numel(), feat.numel()) +
-                           hp.ht.algorithmic_bytes(depth.numel(), feat.numel()))
+        if cfg.render:
+            # SURVEY 8(d) per-view figure for what one blend launch touches: 8 B rect + 8 B record
+            # per visible Gaussian scanned at least once, 44 B payload per blended record is bounded
+            # by the same count, 20 B per pixel written (colour 12, depth 4, T 4) + 4 B n_contrib
+            H, W = cfg.input_size
+            P = hp.voxel_xyz.shape[1] * hp.voxel_xyz.shape[2]
+            alg_bytes = float(len(hp.cams) * (60 * P + 24 * H * W))
+        else:
+            alg_bytes = 0.5 * (hp.lss.algorithmic_bytes(depth.numel(), feat.numel()) +
+                               hp.ht.algorithmic_bytes(depth.numel(), feat.numel()))
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         voxels = hp.bev_voxels_per_step * world * args.steps
         out = {
             'metric': 'BEV voxels/sec + rendered views/sec, 6-cam 256x704',
             'value': voxels / elapsed, 'unit': 'BEV voxels/s',
-            'rendered_views_per_sec': 0.0,
+            'rendered_views_per_sec': hp.views_per_step * world * args.steps / elapsed,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': cfg.name, 'cams': cfg.n_cams, 'frames_per_gpu': cfg.n_frames,
                        'bev': list(cfg.bev_xyz), 'channels': cfg.channels, 'depth_bins': cfg.D,
-                       'stages': 'lss_pool+ht_pool', 'index_prep': 'cached (accelerate=True semantics)',
-                       'sharding': f'frame-shard x{world}, all_gather of per-frame BEV' if world > 1 else 'none'},
+                       'stages': 'lss_pool+ht_pool' + ('+render' if cfg.render else '') + ('+hoa' if cfg.hoa else ''),
+                       'views_per_step': hp.views_per_step, 'render_camera': getattr(hp, 'render_convention', None),
+                       'index_prep': 'cached (accelerate=True semantics)',
+                       'sharding': f'{world} x {cfg.n_frames} frames (frame policy), one RCCL all_gather of the fused BEV per step' if world > 1 else 'none'},
             'roofline': {'bound': 'hbm', 'kernel': timer.kernel_name, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_us': 1e3 * avg_ms,

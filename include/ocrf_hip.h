@@ -185,6 +185,32 @@ int ocrf_hoa_height_attention(const float *x, int B, int C, int hid, int Y, int 
                               size_t workspace_bytes, ocrf_stream_t stream);
 size_t ocrf_hoa_height_attention_workspace_bytes(int B, int C);
 
+/*
+ * OpacityVoxelToBEVConverter (view_transformer_ocrf.py:463-518) as fused blocks, eval mode.
+ * ocrf_hoa_unet_block = one `conv_block` (depthwise 3x3 + bias -> 1x1 + bias -> BatchNorm folded into
+ * pw_w/pw_b by the caller -> ReLU, :485-491) over the virtual input
+ *   mode 0: src0 (B,C0,H,W)                                   [encoder1, :498]
+ *   mode 1: maxpool2x2(src0 (B,C0,2H,2W))                     [encoder2 / bottleneck, :501,:504]
+ *   mode 2: cat(ConvTranspose2d_k2s2(src0 (B,C0,H/2,W/2); up_w (C0,Cup,2,2), up_b), src1 (B,C1,H,W))
+ *                                                             [decoder2 / decoder1, :507-514]
+ * with gate0 (B,C0) / gate1 (B,C1) (the producers' HeightAttention gates, NULL = none) multiplied in
+ * while reading, `addend` (B,Cout,H,W) added after the ReLU (positional encoding, NULL = none), and
+ * partial_max (B*Cout, ocrf_hoa_unet_tiles(H,W)) receiving per-tile channel maxima (NULL = skip).
+ * Channel counts <= 16.  ocrf_hoa_height_gate_from_tiles turns those maxima into the HeightAttention
+ * gate (B,C) (same w1/w2 layout as ocrf_hoa_height_attention); ocrf_hoa_gated_conv1x1 is the final
+ * `output_conv` (:516) over gate * x: out (B,1,H,W) = bias[0] + sum_c w[c] * gate[b][c] * x[b][c].
+ */
+int ocrf_hoa_unet_block(const float *src0, const float *gate0, int C0, int H0, int W0, int mode,
+                        const float *up_w, const float *up_b, int Cup, const float *src1,
+                        const float *gate1, int C1, const float *dw_w, const float *dw_b,
+                        const float *pw_w, const float *pw_b, int Cout, const float *addend, float *out,
+                        float *partial_max, int B, int H, int W, ocrf_stream_t stream);
+int ocrf_hoa_unet_tiles(int H, int W);
+int ocrf_hoa_height_gate_from_tiles(int B, int C, int hid, int n_tiles, const float *partial_max,
+                                    const float *w1, const float *w2, float *gate, ocrf_stream_t stream);
+int ocrf_hoa_gated_conv1x1(const float *x, const float *gate, int B, int C, int H, int W, const float *w,
+                           const float *bias, float *out, ocrf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Per-kernel device timer (measurement aid for bench.py; not part of the reference's surface)
  * ------------------------------------------------------------------------------------------
@@ -206,7 +232,9 @@ enum {
   OCRF_K_HOA_STATS = 20,         /* hoa_channel_stats_kernel */
   OCRF_K_HOA_MASK_GATE = 21,     /* hoa_mask_gate_kernel */
   OCRF_K_HOA_HEIGHT_MAX = 22,    /* hoa_height_max_kernel */
-  OCRF_K_HOA_HEIGHT_GATE = 23    /* hoa_height_gate_kernel */
+  OCRF_K_HOA_HEIGHT_GATE = 23,   /* hoa_height_gate_kernel / hoa_height_gate_from_tiles_kernel */
+  OCRF_K_HOA_UNET_BLOCK = 24,    /* hoa_unet_block_kernel */
+  OCRF_K_HOA_OUT_CONV = 25       /* hoa_gated_conv1x1_kernel */
 };
 const char *ocrf_kernel_name(int kernel_id);           /* symbol as rocprofv3 prints it */
 int ocrf_timer_create(int capacity, void **timer_out); /* host pointers */

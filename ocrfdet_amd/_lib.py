@@ -80,6 +80,16 @@ def _declare(L):
                                             [c_void_p, c_size_t, c_void_p])
     L.ocrf_hoa_height_attention_workspace_bytes.restype = c_size_t
     L.ocrf_hoa_height_attention_workspace_bytes.argtypes = [c_int, c_int]
+    L.ocrf_hoa_unet_block.restype = c_int
+    L.ocrf_hoa_unet_block.argtypes = ([c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+                                       c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                       c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p])
+    L.ocrf_hoa_unet_tiles.restype = c_int
+    L.ocrf_hoa_unet_tiles.argtypes = [c_int, c_int]
+    L.ocrf_hoa_height_gate_from_tiles.restype = c_int
+    L.ocrf_hoa_height_gate_from_tiles.argtypes = [c_int] * 4 + [c_void_p] * 5
+    L.ocrf_hoa_gated_conv1x1.restype = c_int
+    L.ocrf_hoa_gated_conv1x1.argtypes = [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p] * 4
     L.ocrf_kernel_name.restype = ctypes.c_char_p
     L.ocrf_kernel_name.argtypes = [c_int]
     L.ocrf_timer_create.restype = c_int

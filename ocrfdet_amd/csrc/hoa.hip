@@ -194,3 +194,248 @@ int ocrf_hoa_height_attention(const float* x, int B, int C, int hid, int Y, int 
 }
 
 }  // extern "C"
+
+// =================================================================================================
+// HOA-2: OpacityVoxelToBEVConverter (view_transformer_ocrf.py:463-518) as fused UNet blocks.
+//
+// One kernel = one `conv_block` (depthwise 3x3 -> 1x1 -> BatchNorm(eval) -> ReLU, :485-491) with
+// everything around it folded in:
+//   * input transform: identity | 2x2 max-pool of the producer (:501,504) | ConvTranspose2d(k=2,s=2)
+//     of the producer concatenated with a skip tensor (:507-509, :512-514);
+//   * the HeightAttention gate of each producer (`ca(x) * x`, :500-515) applied while reading it;
+//   * optional addend after ReLU (the positional encoding, :498);
+//   * per-channel partial maxima of the result for the block's own HeightAttention.
+// The virtual input tile (16x16 + halo) is built once in LDS; channel counts are <= 16.
+// The reference runs this as ~60 MIOpen/elementwise launches on (B,<=16,Y,X) tensors.
+// =================================================================================================
+namespace {
+
+constexpr int kUT = 16;                  // tile edge
+constexpr int kUH = kUT + 2;             // with halo
+constexpr int kUMaxC = 16;
+
+struct UnetBlockArgs {
+  const float* src0; const float* gate0; int C0, H0, W0; int mode;   // 0 identity, 1 maxpool2, 2 upconv k2s2
+  const float* up_w; const float* up_b; int Cup;                      // mode 2: (C0,Cup,2,2), (Cup)
+  const float* src1; const float* gate1; int C1;                      // skip tensor (B,C1,H,W) or null
+  const float* dw_w; const float* dw_b;                               // (Cin,3,3), (Cin)
+  const float* pw_w; const float* pw_b; int Cout;                     // BN-folded (Cout,Cin), (Cout)
+  const float* addend;                                                // (B,Cout,H,W) or null
+  float* out; float* partial_max; int H, W, tiles_x, tiles_y;         // partial_max (B*Cout, tiles) or null
+};
+
+__global__ __launch_bounds__(kBlock) void hoa_unet_block_kernel(UnetBlockArgs a) {
+  __shared__ float s_v[kUMaxC][kUH][kUH + 1];
+  __shared__ float s_red[kBlock / 64][kUMaxC];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z;
+  const int ty0 = blockIdx.y * kUT, tx0 = blockIdx.x * kUT;
+  const int Cfirst = (a.mode == 2) ? a.Cup : a.C0;
+  const int Cin = Cfirst + a.C1;
+  const int H = a.H, W = a.W;
+
+  // (1) virtual input tile with halo, zero outside the image (conv padding = 1)
+  for (int i = tid; i < kUH * kUH; i += kBlock) {
+    const int hy = i / kUH, hx = i % kUH;
+    const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+    const bool in = (y >= 0) && (y < H) && (x >= 0) && (x < W);
+    if (a.mode == 2) {
+      float acc[kUMaxC];
+#pragma unroll
+      for (int co = 0; co < kUMaxC; ++co) acc[co] = (co < a.Cup) ? a.up_b[co] : 0.f;
+      if (in) {
+        const int sy = y >> 1, sx = x >> 1, ki = (y & 1) * 2 + (x & 1);
+        for (int ci = 0; ci < a.C0; ++ci) {
+          float v = a.src0[(((long)b * a.C0 + ci) * a.H0 + sy) * a.W0 + sx];
+          if (a.gate0) v *= a.gate0[b * a.C0 + ci];
+#pragma unroll
+          for (int co = 0; co < kUMaxC; ++co)
+            if (co < a.Cup) acc[co] = fmaf(v, a.up_w[(ci * a.Cup + co) * 4 + ki], acc[co]);
+        }
+      }
+#pragma unroll
+      for (int co = 0; co < kUMaxC; ++co)
+        if (co < a.Cup) s_v[co][hy][hx] = in ? acc[co] : 0.f;
+    } else {
+      for (int c = 0; c < a.C0; ++c) {
+        float v = 0.f;
+        if (in) {
+          const float* p = a.src0 + ((long)b * a.C0 + c) * a.H0 * a.W0;
+          if (a.mode == 1) {
+            const float* q = p + (long)(2 * y) * a.W0 + 2 * x;
+            v = fmaxf(fmaxf(q[0], q[1]), fmaxf(q[a.W0], q[a.W0 + 1]));
+          } else {
+            v = p[(long)y * a.W0 + x];
+          }
+          // gates are sigmoids (> 0), so max-pooling before or after the multiply is the same
+          if (a.gate0) v *= a.gate0[b * a.C0 + c];
+        }
+        s_v[c][hy][hx] = v;
+      }
+    }
+    for (int c = 0; c < a.C1; ++c) {
+      float v = 0.f;
+      if (in) {
+        v = a.src1[(((long)b * a.C1 + c) * H + y) * W + x];
+        if (a.gate1) v *= a.gate1[b * a.C1 + c];
+      }
+      s_v[Cfirst + c][hy][hx] = v;
+    }
+  }
+  __syncthreads();
+
+  // (2) depthwise 3x3 -> 1x1 (BN folded) -> ReLU (+ addend), one pixel per thread
+  const int ly = tid / kUT, lx = tid % kUT;
+  const int y = ty0 + ly, x = tx0 + lx;
+  const bool valid = (y < H) && (x < W);
+  float outv[kUMaxC];
+#pragma unroll
+  for (int co = 0; co < kUMaxC; ++co) outv[co] = (co < a.Cout) ? a.pw_b[co] : 0.f;
+  for (int c = 0; c < Cin; ++c) {
+    float d = a.dw_b[c];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) d = fmaf(s_v[c][ly + i][lx + j], a.dw_w[c * 9 + i * 3 + j], d);
+#pragma unroll
+    for (int co = 0; co < kUMaxC; ++co)
+      if (co < a.Cout) outv[co] = fmaf(d, a.pw_w[co * Cin + c], outv[co]);
+  }
+  const long plane = (long)H * W;
+  const long pix = (long)y * W + x;
+#pragma unroll
+  for (int co = 0; co < kUMaxC; ++co) {
+    if (co < a.Cout) {
+      float v = fmaxf(outv[co], 0.f);
+      if (valid) {
+        if (a.addend) v += a.addend[((long)b * a.Cout + co) * plane + pix];
+        a.out[((long)b * a.Cout + co) * plane + pix] = v;
+      } else {
+        v = -INFINITY;
+      }
+      outv[co] = v;
+    }
+  }
+  // (3) per-channel maximum of this tile for the block's HeightAttention
+  if (a.partial_max) {
+#pragma unroll
+    for (int co = 0; co < kUMaxC; ++co) {
+      if (co < a.Cout) {
+        float m = outv[co];
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off));
+        if ((tid & 63) == 0) s_red[tid >> 6][co] = m;
+      }
+    }
+    __syncthreads();
+    if (tid < a.Cout) {
+      float m = s_red[0][tid];
+      for (int w = 1; w < kBlock / 64; ++w) m = fmaxf(m, s_red[w][tid]);
+      const int n_tiles = a.tiles_x * a.tiles_y;
+      a.partial_max[((long)b * a.Cout + tid) * n_tiles + blockIdx.y * a.tiles_x + blockIdx.x] = m;
+    }
+  }
+}
+
+// HeightAttention gate from per-tile maxima (any number of tiles): one workgroup per batch entry.
+__global__ __launch_bounds__(kBlock) void hoa_height_gate_from_tiles_kernel(
+    int C, int hid, int n_tiles, const float* __restrict__ partial, const float* __restrict__ w1,
+    const float* __restrict__ w2, float* __restrict__ gate) {
+  __shared__ float s_max[64];
+  __shared__ float s_hid[64];
+  __shared__ float s_w[kBlock / 64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int q = C / 4;
+  for (int c = 0; c < C; ++c) {
+    float m = -INFINITY;
+    for (int t = tid; t < n_tiles; t += kBlock) m = fmaxf(m, partial[((long)b * C + c) * n_tiles + t]);
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off));
+    if ((tid & 63) == 0) s_w[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < kBlock / 64; ++w) m = fmaxf(m, s_w[w]);
+      s_max[c] = m;
+    }
+    __syncthreads();
+  }
+  if (tid < 4 * hid) {
+    const int g = tid / hid, h = tid % hid;
+    float acc = 0.f;
+    for (int i = 0; i < q; ++i) acc = fmaf(w1[(g * hid + h) * q + i], s_max[g * q + i], acc);
+    s_hid[tid] = fmaxf(acc, 0.f);
+  }
+  __syncthreads();
+  if (tid < C) {
+    const int g = tid / q, o = tid % q;
+    float acc = 0.f;
+    for (int h = 0; h < hid; ++h) acc = fmaf(w2[(g * q + o) * hid + h], s_hid[g * hid + h], acc);
+    gate[(long)b * C + tid] = sigmoidf_(acc);
+  }
+}
+
+// Final 1x1 output conv (:516) over the gated decoder output.
+__global__ __launch_bounds__(kBlock) void hoa_gated_conv1x1_kernel(const float* __restrict__ x,
+                                                                   const float* __restrict__ gate, int C,
+                                                                   long plane, const float* __restrict__ w,
+                                                                   const float* __restrict__ bias,
+                                                                   float* __restrict__ out) {
+  const long pix = (long)blockIdx.x * kBlock + threadIdx.x;
+  const int b = blockIdx.y;
+  if (pix >= plane) return;
+  float acc = bias[0];
+  for (int c = 0; c < C; ++c) acc = fmaf(x[((long)b * C + c) * plane + pix] * gate[b * C + c], w[c], acc);
+  out[(long)b * plane + pix] = acc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ocrf_hoa_unet_block(const float* src0, const float* gate0, int C0, int H0, int W0, int mode,
+                        const float* up_w, const float* up_b, int Cup, const float* src1,
+                        const float* gate1, int C1, const float* dw_w, const float* dw_b,
+                        const float* pw_w, const float* pw_b, int Cout, const float* addend, float* out,
+                        float* partial_max, int B, int H, int W, ocrf_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int Cfirst = (mode == 2) ? Cup : C0;
+  if (!src0 || !dw_w || !dw_b || !pw_w || !pw_b || !out || B <= 0 || H <= 0 || W <= 0 || mode < 0 || mode > 2 ||
+      C0 <= 0 || C0 > kUMaxC || C1 < 0 || Cfirst + C1 > kUMaxC || Cout <= 0 || Cout > kUMaxC ||
+      (mode == 2 && (!up_w || !up_b || Cup <= 0)) || (C1 > 0 && !src1))
+    return (int)hipErrorInvalidValue;
+  if ((mode == 0 && (H0 != H || W0 != W)) || (mode == 1 && (H0 / 2 != H || W0 / 2 != W)) ||
+      (mode == 2 && (H0 * 2 != H || W0 * 2 != W)))
+    return (int)hipErrorInvalidValue;
+  UnetBlockArgs a;
+  a.src0 = src0; a.gate0 = gate0; a.C0 = C0; a.H0 = H0; a.W0 = W0; a.mode = mode;
+  a.up_w = up_w; a.up_b = up_b; a.Cup = Cup; a.src1 = src1; a.gate1 = gate1; a.C1 = C1;
+  a.dw_w = dw_w; a.dw_b = dw_b; a.pw_w = pw_w; a.pw_b = pw_b; a.Cout = Cout; a.addend = addend;
+  a.out = out; a.partial_max = partial_max; a.H = H; a.W = W;
+  a.tiles_x = (W + kUT - 1) / kUT; a.tiles_y = (H + kUT - 1) / kUT;
+  ocrf::launch(OCRF_K_HOA_UNET_BLOCK, hoa_unet_block_kernel, dim3(a.tiles_x, a.tiles_y, B), dim3(kBlock), 0,
+               stream, a);
+  return (int)hipGetLastError();
+}
+
+int ocrf_hoa_unet_tiles(int H, int W) { return ((W + kUT - 1) / kUT) * ((H + kUT - 1) / kUT); }
+
+int ocrf_hoa_height_gate_from_tiles(int B, int C, int hid, int n_tiles, const float* partial_max,
+                                    const float* w1, const float* w2, float* gate, ocrf_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (!partial_max || !w1 || !w2 || !gate || B <= 0 || C <= 0 || (C % 4) || C > 64 || hid <= 0 || 4 * hid > 64 ||
+      n_tiles <= 0)
+    return (int)hipErrorInvalidValue;
+  ocrf::launch(OCRF_K_HOA_HEIGHT_GATE, hoa_height_gate_from_tiles_kernel, dim3(B), dim3(kBlock), 0, stream, C, hid,
+               n_tiles, partial_max, w1, w2, gate);
+  return (int)hipGetLastError();
+}
+
+int ocrf_hoa_gated_conv1x1(const float* x, const float* gate, int B, int C, int H, int W, const float* w,
+                           const float* bias, float* out, ocrf_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (!x || !gate || !w || !bias || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return (int)hipErrorInvalidValue;
+  const long plane = (long)H * W;
+  ocrf::launch(OCRF_K_HOA_OUT_CONV, hoa_gated_conv1x1_kernel, dim3((unsigned)((plane + kBlock - 1) / kBlock), B),
+               dim3(kBlock), 0, stream, x, gate, C, plane, w, bias, out);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

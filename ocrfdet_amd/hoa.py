@@ -51,10 +51,15 @@ class HeightAttention(nn.Module):
         self.tanh = nn.Sigmoid()           # the reference names its sigmoid `tanh` (:445)
 
     def _packed(self):
+        """w1 [4][hid][q], w2 [4][q][hid] for the C ABI; cached until a weight changes."""
         convs = (self.conv1, self.conv2, self.conv3, self.conv4)
-        w1 = torch.stack([c[0].weight.reshape(self.hid, self.q_in) for c in convs]).contiguous().float()
-        w2 = torch.stack([c[2].weight.reshape(self.q_out, self.hid) for c in convs]).contiguous().float()
-        return w1, w2
+        ps = [c[i].weight for c in convs for i in (0, 2)]
+        key = tuple((p._version, p.data_ptr()) for p in ps)
+        if getattr(self, '_pack_key', None) != key:
+            w1 = torch.stack([c[0].weight.detach().reshape(self.hid, self.q_in) for c in convs]).contiguous().float()
+            w2 = torch.stack([c[2].weight.detach().reshape(self.q_out, self.hid) for c in convs]).contiguous().float()
+            self._pack_key, self._pack = key, (w1, w2)
+        return self._pack
 
     def _run(self, x, want_gated):
         _lib.require_cuda(x)
@@ -110,12 +115,77 @@ class OpacityVoxelToBEVConverter(nn.Module):
         return nn.ConvTranspose2d(in_channels, out_channels, kernel_size=2, stride=2)
 
     def forward(self, x, position):
+        if not self.training and x.is_cuda:
+            return self._forward_fused(x, position)
+        # training mode (BatchNorm batch statistics): block by block, gates still in HIP
         enc1 = self.ca1.gate_apply(self.encoder1(x) + position)
         enc2 = self.ca2.gate_apply(self.encoder2(self.pool(enc1)))
         mid = self.ca_bottleneck.gate_apply(self.bottleneck(self.pool(enc2)))
         dec2 = self.ca_dec2.gate_apply(self.decoder2(torch.cat((self.upconv2(mid), enc2), dim=1)))
         dec1 = self.ca_dec1.gate_apply(self.decoder1(torch.cat((self.upconv1(dec2), enc1), dim=1)))
         return self.output_conv(dec1)
+
+    def _folded(self, block):
+        """(dw_w (Cin,9), dw_b, pw_w (Cout,Cin) with BatchNorm folded in, pw_b) of a conv_block;
+        cached until one of the tensors involved changes."""
+        dw, pw, bn = block[0], block[1], block[2]
+        ts = (dw.weight, dw.bias, pw.weight, pw.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        key = tuple((t._version, t.data_ptr()) for t in ts)
+        cache = self.__dict__.setdefault('_fold_cache', {})
+        hit = cache.get(id(block))
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                pw_w = pw.weight.reshape(pw.out_channels, pw.in_channels) * s[:, None]
+                pw_b = (pw.bias - bn.running_mean) * s + bn.bias
+                vals = [t.detach().contiguous().float()
+                        for t in (dw.weight.reshape(dw.in_channels, 9), dw.bias, pw_w, pw_b)]
+            cache[id(block)] = hit = (key, vals)
+        return hit[1]
+
+    def _forward_fused(self, x, position):
+        """Eval-mode forward as 5 fused block kernels + 5 gate kernels + the output conv
+        (csrc/hoa.hip, ocrf_hoa_unet_block): no intermediate pooled / upsampled / concatenated /
+        gated tensor is ever written."""
+        _lib.require_cuda(x, position)
+        x, position = _f32c(x), _f32c(position)
+        B, _, H, W = x.shape
+        dev = x.device
+        L = _lib.lib()
+        st = _lib.stream_ptr(dev)
+
+        def block(src0, gate0, mode, up, src1, gate1, conv, ca, cout, h, w, addend=None):
+            dw_w, dw_b, pw_w, pw_b = self._folded(conv)
+            up_w = up.weight.detach().contiguous().float() if up is not None else None
+            up_b = up.bias.detach().contiguous().float() if up is not None else None
+            cup = up.out_channels if up is not None else 0
+            out = torch.empty(B, cout, h, w, device=dev)
+            n_tiles = L.ocrf_hoa_unet_tiles(h, w)
+            pmax = torch.empty(B * cout, n_tiles, device=dev)
+            _lib.check(L.ocrf_hoa_unet_block(
+                _lib.ptr(src0), _lib.ptr(gate0), src0.shape[1], src0.shape[2], src0.shape[3], mode, _lib.ptr(up_w),
+                _lib.ptr(up_b), cup, _lib.ptr(src1), _lib.ptr(gate1), src1.shape[1] if src1 is not None else 0,
+                _lib.ptr(dw_w), _lib.ptr(dw_b), _lib.ptr(pw_w), _lib.ptr(pw_b), cout, _lib.ptr(addend), _lib.ptr(out),
+                _lib.ptr(pmax), B, h, w, st), 'ocrf_hoa_unet_block')
+            w1, w2 = ca._packed()
+            gate = torch.empty(B, cout, device=dev)
+            _lib.check(L.ocrf_hoa_height_gate_from_tiles(B, cout, ca.hid, n_tiles, _lib.ptr(pmax), _lib.ptr(w1),
+                                                         _lib.ptr(w2), _lib.ptr(gate), st),
+                       'ocrf_hoa_height_gate_from_tiles')
+            return out, gate
+
+        with torch.cuda.device(dev):
+            e1, g1 = block(x, None, 0, None, None, None, self.encoder1, self.ca1, 4, H, W, position)
+            e2, g2 = block(e1, g1, 1, None, None, None, self.encoder2, self.ca2, 8, H // 2, W // 2)
+            bt, gb = block(e2, g2, 1, None, None, None, self.bottleneck, self.ca_bottleneck, 16, H // 4, W // 4)
+            d2, gd2 = block(bt, gb, 2, self.upconv2, e2, g2, self.decoder2, self.ca_dec2, 8, H // 2, W // 2)
+            d1, gd1 = block(d2, gd2, 2, self.upconv1, e1, g1, self.decoder1, self.ca_dec1, 4, H, W)
+            out = torch.empty(B, 1, H, W, device=dev)
+            ow = self.output_conv.weight.detach().reshape(-1).contiguous().float()
+            ob = self.output_conv.bias.detach().contiguous().float()
+            _lib.check(L.ocrf_hoa_gated_conv1x1(_lib.ptr(d1), _lib.ptr(gd1), B, 4, H, W, _lib.ptr(ow), _lib.ptr(ob),
+                                                _lib.ptr(out), st), 'ocrf_hoa_gated_conv1x1')
+        return out
 
 
 class ObatinOpacityMask(nn.Module):          # sic: the reference's spelling

@@ -12,7 +12,7 @@ import math
 import numpy as np
 import torch
 
-from . import bevpool, gaussian_renderer, index_prep, synthetic
+from . import bevpool, gaussian_renderer, hoa, index_prep, synthetic
 from .diff_gaussian_rasterization import rasterize_views
 
 
@@ -78,6 +78,36 @@ class HotPath:
 
         if cfg.render:
             self._prepare_render(r)
+        if cfg.hoa:
+            self._prepare_hoa()
+
+    def _prepare_hoa(self, seed=0):
+        """HOA blocks with seeded random-init weights of the reference architecture
+        (view_transformer_ocrf.py:590-648) and the synthetic NeRF-branch alpha volume they consume."""
+        cfg, dev = self.cfg, self.device
+        X, Y, _ = cfg.bev_xyz
+        torch.manual_seed(seed)
+        self.hoa_mods = dict(
+            dca=hoa.DeformableAttention2D(dim=cfg.num_height, dim_head=8, heads=1, dropout=0.1, downsample_factor=4,
+                                          offset_scale=4, offset_groups=None, offset_kernel_size=6),
+            v2b=hoa.OpacityVoxelToBEVConverter(input_channel=cfg.num_height), mask=hoa.ObatinOpacityMask())
+        for m in self.hoa_mods.values():
+            m.to(dev).eval()
+        g = torch.Generator(device='cpu').manual_seed(seed)
+        self.alpha_lidar = torch.rand(self.batch, cfg.num_height, Y, X, generator=g).to(dev)
+        self.bev_pos1 = (torch.randn(self.batch, 4, Y, X, generator=g) * 0.1).to(dev)
+
+    @torch.no_grad()
+    def hoa_step(self, geom_feat):
+        """HOA-1/2/3 (view_transformer_ocrf.py:1159-1161, 1196-1199): -> (gated BEV, opacity BEV)."""
+        cfg = self.cfg
+        X, Y, _ = cfg.bev_xyz
+        m = self.hoa_mods
+        oa = [hoa.hoa1(m['dca'], self.gauss['opacity'], self.alpha_lidar[b:b + 1], cfg.num_height, Y, X)
+              for b in range(self.batch)]
+        opacity_bev = m['v2b'](torch.cat(oa, 0), self.bev_pos1)
+        _, gated = m['mask'].gate(geom_feat, opacity_bev)
+        return gated, opacity_bev
 
     def _prepare_render(self, r, convention='corrected', seed=0):
         """Cameras + synthetic Gaussian parameters of the OcRF render.
@@ -158,9 +188,14 @@ class HotPath:
         """One pass: LSS BEV (B, Z*C, Y, X) and HT BEV (B, C, Y, X) (view_transformer.py:194,
         view_transformer_ocrf.py:781)."""
         lss, ht = self.pool(self.lss, depth, feat), self.pool(self.ht, depth, feat)
+        out = [lss, ht]
         if self.cfg.render:
-            return lss, ht, self.render()
-        return lss, ht
+            out.append(self.render())
+        if self.cfg.hoa:
+            # stand-in for geom_feat: the HT BEV has its shape (B,C,Y,X); the fusion convs between
+            # the pools and HOA-3 (SURVEY 8a row a27) are MIOpen territory, not part of this path
+            out.extend(self.hoa_step(ht))
+        return tuple(out)
 
     @property
     def bev_voxels_per_step(self):

@@ -87,6 +87,30 @@ def test_opacity_voxel_to_bev_gpu(cuda, g):
 
 
 @pytest.mark.gpu
+def test_opacity_voxel_to_bev_fused_vs_blockwise_and_oracle(cuda, g):
+    """Eval-mode fused path (5 block kernels) == training-style block-by-block path == numpy oracle,
+    at the headline BEV size (200x200: ragged 16x16 tiles, H/4 = 50)."""
+    from oracle import hoa as ohoa
+    m = hoa.OpacityVoxelToBEVConverter(13).to(cuda).eval()
+    m.load_state_dict(_sd(g, 'v2b'))
+    rng = np.random.default_rng(1)
+    x = rng.random((2, 13, 200, 200), dtype=np.float32)
+    pos = (rng.standard_normal((2, 4, 200, 200)) * 0.1).astype(np.float32)
+    xt, pt = torch.from_numpy(x).to(cuda), torch.from_numpy(pos).to(cuda)
+    with torch.no_grad():
+        fused = m(xt, pt)
+        enc1 = m.ca1.gate_apply(m.encoder1(xt) + pt)                       # block-by-block (torch convs)
+        enc2 = m.ca2.gate_apply(m.encoder2(m.pool(enc1)))
+        mid = m.ca_bottleneck.gate_apply(m.bottleneck(m.pool(enc2)))
+        dec2 = m.ca_dec2.gate_apply(m.decoder2(torch.cat((m.upconv2(mid), enc2), dim=1)))
+        dec1 = m.ca_dec1.gate_apply(m.decoder1(torch.cat((m.upconv1(dec2), enc1), dim=1)))
+        blockwise = m.output_conv(dec1)
+    np.testing.assert_allclose(fused.cpu().numpy(), blockwise.cpu().numpy(), rtol=1e-4, atol=3e-5)
+    want = ohoa.opacity_voxel_to_bev(x, pos, g, 'v2b')
+    np.testing.assert_allclose(fused.cpu().numpy(), want, rtol=1e-4, atol=3e-5)
+
+
+@pytest.mark.gpu
 def test_hoa1_gpu(cuda, g):
     m = hoa.DeformableAttention2D(dim=13, dim_head=8, heads=1, dropout=0.1, downsample_factor=4, offset_scale=4,
                                   offset_groups=None, offset_kernel_size=6).to(cuda).eval()
