@@ -211,6 +211,20 @@ int ocrf_hoa_height_gate_from_tiles(int B, int C, int hid, int n_tiles, const fl
 int ocrf_hoa_gated_conv1x1(const float *x, const float *gate, int B, int C, int H, int W, const float *w,
                            const float *bias, float *out, ocrf_stream_t stream);
 
+/*
+ * HOA-1 (view_transformer_ocrf.py:1159-1161): deformable cross attention between the Gaussian
+ * opacity volume and the NeRF-branch alpha volume, eval mode, for the DeformableAttention2D that
+ * OcRFDet instantiates (:639-648: dim 13, heads 1, dim_head 8, offset_groups 1, downsample_factor 4,
+ * offset_kernel_size 6; mmdet3d/ops/cross_attention_2d.py:93-220):
+ *   out (B,13,Y,X) = upsample(att(down(opacity), down(alpha)), (Y,X)) + opacity,
+ * down/up = bilinear align_corners=True to/from (Y/6, X/6).  opacity, alpha: (B,13,Y,X).
+ * weights: ocrf_hoa1_weights_len() floats packed as documented in csrc/hoa.hip (the Python module
+ * packs its state_dict).  att_workspace: B*13*(Y/6)*(X/6) floats.  (Y/6)*(X/6) <= 1600.
+ */
+int ocrf_hoa1_forward(const float *opacity, const float *alpha, const float *weights, int B, int Y, int X,
+                      float offset_scale, float *att_workspace, float *out, ocrf_stream_t stream);
+int ocrf_hoa1_weights_len(void);
+
 /* ------------------------------------------------------------------------------------------
  * Per-kernel device timer (measurement aid for bench.py; not part of the reference's surface)
  * ------------------------------------------------------------------------------------------
@@ -234,7 +248,9 @@ enum {
   OCRF_K_HOA_HEIGHT_MAX = 22,    /* hoa_height_max_kernel */
   OCRF_K_HOA_HEIGHT_GATE = 23,   /* hoa_height_gate_kernel / hoa_height_gate_from_tiles_kernel */
   OCRF_K_HOA_UNET_BLOCK = 24,    /* hoa_unet_block_kernel */
-  OCRF_K_HOA_OUT_CONV = 25       /* hoa_gated_conv1x1_kernel */
+  OCRF_K_HOA_OUT_CONV = 25,      /* hoa_gated_conv1x1_kernel */
+  OCRF_K_HOA1_ATTN = 26,         /* hoa1_attention_kernel */
+  OCRF_K_HOA1_UP = 27            /* hoa1_upsample_residual_kernel */
 };
 const char *ocrf_kernel_name(int kernel_id);           /* symbol as rocprofv3 prints it */
 int ocrf_timer_create(int capacity, void **timer_out); /* host pointers */

@@ -90,6 +90,10 @@ def _declare(L):
     L.ocrf_hoa_height_gate_from_tiles.argtypes = [c_int] * 4 + [c_void_p] * 5
     L.ocrf_hoa_gated_conv1x1.restype = c_int
     L.ocrf_hoa_gated_conv1x1.argtypes = [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p] * 4
+    L.ocrf_hoa1_forward.restype = c_int
+    L.ocrf_hoa1_forward.argtypes = [c_void_p] * 3 + [c_int] * 3 + [c_float] + [c_void_p] * 3
+    L.ocrf_hoa1_weights_len.restype = c_int
+    L.ocrf_hoa1_weights_len.argtypes = []
     L.ocrf_kernel_name.restype = ctypes.c_char_p
     L.ocrf_kernel_name.argtypes = [c_int]
     L.ocrf_timer_create.restype = c_int

@@ -439,3 +439,203 @@ int ocrf_hoa_gated_conv1x1(const float* x, const float* gate, int B, int C, int 
 }
 
 }  // extern "C"
+
+// =================================================================================================
+// HOA-1 (view_transformer_ocrf.py:1159-1161 + mmdet3d/ops/cross_attention_2d.py:142-220), eval mode,
+// for the configuration OcRFDet instantiates (:639-648): dim = 13, heads = 1, dim_head = 8,
+// offset_groups = 1, downsample_factor = 4, offset_kernel_size = 6, CPB dim = 3, depth = 2.
+//   att  = to_out(softmax(q k^T * scale + CPB(grid_q - vgrid)) v)  on the (hq,wq) = (Y/6,X/6) maps
+//   out  = upsample_bilinear(att, (Y,X), align_corners) + opacity
+// Kernel 1: one workgroup per 256 query tokens; every workgroup rebuilds q for the whole (hq,wq)
+// map in LDS (the offset conv needs it) straight from the full-resolution opacity volume, the
+// kv tokens (offsets -> sampling grid -> bilinear-of-bilinear sample of alpha -> k, v), then runs
+// the attention of its tokens with an online softmax.  Kernel 2: upsample + residual.
+// The reference does this with ~50 tiny launches per sample.
+// Packed weights (floats): to_q[8][13] | off_dw[8][36] | off_db[8] | off_pw[2][8] | to_k[8][13] |
+//   to_v[8][13] | to_out[13][8] | to_out_b[13] | cpb0_w[3][2] | cpb0_b[3] | cpb1_w[3][3] | cpb1_b[3]
+//   | cpb2_w[3] | cpb2_b[1]
+// =================================================================================================
+namespace {
+
+constexpr int kHD = 13, kHI = 8, kHMaxTok = 1600, kHMaxKV = 128;
+constexpr int oQ = 0, oDW = oQ + 8 * 13, oDB = oDW + 8 * 36, oPW = oDB + 8, oK = oPW + 16, oV = oK + 104,
+              oO = oV + 104, oOB = oO + 104, oC0W = oOB + 13, oC0B = oC0W + 6, oC1W = oC0B + 3, oC1B = oC1W + 9,
+              oC2W = oC1B + 3, oC2B = oC2W + 3, kHoaWeights = oC2B + 1;
+
+// F.interpolate(..., mode='bilinear', align_corners=True) sample of one channel plane
+__device__ __forceinline__ float bilinear_ac(const float* __restrict__ p, int H, int W, float sy, float sx) {
+  const int y0 = min((int)sy, H - 1), x0 = min((int)sx, W - 1);
+  const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+  const float ly = sy - (float)y0, lx = sx - (float)x0;
+  const float top = p[(long)y0 * W + x0] * (1.f - lx) + p[(long)y0 * W + x1] * lx;
+  const float bot = p[(long)y1 * W + x0] * (1.f - lx) + p[(long)y1 * W + x1] * lx;
+  return top * (1.f - ly) + bot * ly;
+}
+
+__global__ __launch_bounds__(kBlock) void hoa1_attention_kernel(
+    const float* __restrict__ opacity, const float* __restrict__ alpha, const float* __restrict__ wts, int Y, int X,
+    int hq, int wq, int hk, int wk, float offset_scale, float* __restrict__ att) {
+  extern __shared__ float sm[];
+  float* s_w = sm;                                  // kHoaWeights
+  float* s_q = s_w + ((kHoaWeights + 3) & ~3);      // [ntok][8]
+  const int ntok = hq * wq, nkv = hk * wk;
+  float* s_k = s_q + ntok * kHI;                    // [nkv][8]
+  float* s_v = s_k + nkv * kHI;                     // [nkv][8]
+  float* s_g = s_v + nkv * kHI;                     // [nkv][2] normalised sampling grid
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const long plane = (long)Y * X;
+  const float* op = opacity + (long)b * kHD * plane;
+  const float* al = alpha + (long)b * kHD * plane;
+  for (int i = tid; i < kHoaWeights; i += kBlock) s_w[i] = wts[i];
+  __syncthreads();
+  const float ry = hq > 1 ? (float)(Y - 1) / (float)(hq - 1) : 0.f, rx = wq > 1 ? (float)(X - 1) / (float)(wq - 1) : 0.f;
+
+  // q = to_q(downsample(opacity)) for every token (unscaled: the offset net sees it unscaled)
+  for (int t = tid; t < ntok; t += kBlock) {
+    const int ty = t / wq, tx = t % wq;
+    float q[kHI];
+#pragma unroll
+    for (int d = 0; d < kHI; ++d) q[d] = 0.f;
+    for (int c = 0; c < kHD; ++c) {
+      const float v = bilinear_ac(op + c * plane, Y, X, ry * (float)ty, rx * (float)tx);
+#pragma unroll
+      for (int d = 0; d < kHI; ++d) q[d] = fmaf(s_w[oQ + d * kHD + c], v, q[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < kHI; ++d) s_q[t * kHI + d] = q[d];
+  }
+  __syncthreads();
+
+  // kv tokens: offsets (depthwise 6x6 stride 4 pad 1 -> GELU -> 1x1 -> tanh -> * scale), sampling
+  // grid, bilinear sample (zeros padding, align_corners=False) of downsample(alpha), k and v
+  for (int j = tid; j < nkv; j += kBlock) {
+    const int ky = j / wk, kx = j % wk;
+    float g[kHI];
+#pragma unroll
+    for (int d = 0; d < kHI; ++d) {
+      float a = s_w[oDB + d];
+      for (int i = 0; i < 6; ++i) {
+        const int yy = ky * 4 - 1 + i;
+        if (yy < 0 || yy >= hq) continue;
+        for (int jj = 0; jj < 6; ++jj) {
+          const int xx = kx * 4 - 1 + jj;
+          if (xx < 0 || xx >= wq) continue;
+          a = fmaf(s_w[oDW + d * 36 + i * 6 + jj], s_q[(yy * wq + xx) * kHI + d], a);
+        }
+      }
+      g[d] = 0.5f * a * (1.f + erff(a * 0.70710678118654752f));            // nn.GELU (exact)
+    }
+    float ox = 0.f, oy = 0.f;
+#pragma unroll
+    for (int d = 0; d < kHI; ++d) { ox = fmaf(s_w[oPW + d], g[d], ox); oy = fmaf(s_w[oPW + 8 + d], g[d], oy); }
+    const float vx = (float)kx + tanhf(ox) * offset_scale, vy = (float)ky + tanhf(oy) * offset_scale;
+    // normalize_grid as written (cross_attention_2d.py:30-38): channel 0 over (h-1), 1 over (w-1)
+    const float gx = 2.0f * vx / (float)max(hk - 1, 1) - 1.0f, gy = 2.0f * vy / (float)max(wk - 1, 1) - 1.0f;
+    s_g[j * 2] = gx;
+    s_g[j * 2 + 1] = gy;
+    const float fx = ((gx + 1.f) * (float)wq - 1.f) * 0.5f, fy = ((gy + 1.f) * (float)hq - 1.f) * 0.5f;
+    const int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
+    float kv[kHD];
+#pragma unroll
+    for (int c = 0; c < kHD; ++c) kv[c] = 0.f;
+    for (int dy = 0; dy < 2; ++dy)
+      for (int dx = 0; dx < 2; ++dx) {
+        const int xi = x0 + dx, yi = y0 + dy;
+        if (xi < 0 || xi >= wq || yi < 0 || yi >= hq) continue;
+        const float w = (1.f - fabsf(fx - (float)xi)) * (1.f - fabsf(fy - (float)yi));
+        for (int c = 0; c < kHD; ++c)
+          kv[c] = fmaf(bilinear_ac(al + c * plane, Y, X, ry * (float)yi, rx * (float)xi), w, kv[c]);
+      }
+#pragma unroll
+    for (int d = 0; d < kHI; ++d) {
+      float a = 0.f, bb = 0.f;
+      for (int c = 0; c < kHD; ++c) { a = fmaf(s_w[oK + d * kHD + c], kv[c], a); bb = fmaf(s_w[oV + d * kHD + c], kv[c], bb); }
+      s_k[j * kHI + d] = a;
+      s_v[j * kHI + d] = bb;
+    }
+  }
+  __syncthreads();
+
+  // attention of this workgroup's tokens
+  const int t = blockIdx.x * kBlock + tid;
+  if (t >= ntok) return;
+  const int ty = t / wq, tx = t % wq;
+  const float scale = 0.35355339059327373f;               // dim_head ** -0.5
+  float q[kHI];
+#pragma unroll
+  for (int d = 0; d < kHI; ++d) q[d] = s_q[t * kHI + d] * scale;
+  // query grid: create_grid_like(x_kv) normalised with dim=0 -> x over (h-1), y over (w-1)
+  const float qx = 2.0f * (float)tx / (float)max(hq - 1, 1) - 1.0f, qy = 2.0f * (float)ty / (float)max(wq - 1, 1) - 1.0f;
+  float m = -INFINITY, l = 0.f, acc[kHI];
+#pragma unroll
+  for (int d = 0; d < kHI; ++d) acc[d] = 0.f;
+  for (int j = 0; j < nkv; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < kHI; ++d) s = fmaf(q[d], s_k[j * kHI + d], s);
+    // CPB (cross_attention_2d.py:74-89)
+    const float px = qx - s_g[j * 2], py = qy - s_g[j * 2 + 1];
+    const float bx = copysignf(logf(fabsf(px) + 1.f), px) * (px != 0.f), by = copysignf(logf(fabsf(py) + 1.f), py) * (py != 0.f);
+    float h0[3], h1[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) h0[i] = fmaxf(fmaf(s_w[oC0W + i * 2], bx, fmaf(s_w[oC0W + i * 2 + 1], by, s_w[oC0B + i])), 0.f);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      h1[i] = fmaxf(s_w[oC1B + i] + s_w[oC1W + i * 3] * h0[0] + s_w[oC1W + i * 3 + 1] * h0[1] + s_w[oC1W + i * 3 + 2] * h0[2], 0.f);
+    s += s_w[oC2B] + s_w[oC2W] * h1[0] + s_w[oC2W + 1] * h1[1] + s_w[oC2W + 2] * h1[2];
+    const float mn = fmaxf(m, s);
+    const float corr = __expf(m - mn), p = __expf(s - mn);
+    l = l * corr + p;
+#pragma unroll
+    for (int d = 0; d < kHI; ++d) acc[d] = fmaf(p, s_v[j * kHI + d], acc[d] * corr);
+    m = mn;
+  }
+  const float inv = 1.f / l;
+  for (int c = 0; c < kHD; ++c) {
+    float o = s_w[oOB + c];
+#pragma unroll
+    for (int d = 0; d < kHI; ++d) o = fmaf(s_w[oO + c * kHI + d], acc[d] * inv, o);
+    att[((long)b * kHD + c) * ntok + t] = o;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void hoa1_upsample_residual_kernel(const float* __restrict__ att,
+                                                                        const float* __restrict__ opacity, int C,
+                                                                        int Y, int X, int hq, int wq,
+                                                                        float* __restrict__ out) {
+  const long plane = (long)Y * X;
+  const long pix = (long)blockIdx.x * kBlock + threadIdx.x;
+  const long bc = blockIdx.y;
+  if (pix >= plane) return;
+  const int y = (int)(pix / X), x = (int)(pix % X);
+  const float ry = Y > 1 ? (float)(hq - 1) / (float)(Y - 1) : 0.f, rx = X > 1 ? (float)(wq - 1) / (float)(X - 1) : 0.f;
+  out[bc * plane + pix] = bilinear_ac(att + bc * hq * wq, hq, wq, ry * (float)y, rx * (float)x) + opacity[bc * plane + pix];
+}
+
+}  // namespace
+
+extern "C" {
+
+int ocrf_hoa1_weights_len(void) { return kHoaWeights; }
+
+int ocrf_hoa1_forward(const float* opacity, const float* alpha, const float* weights, int B, int Y, int X,
+                      float offset_scale, float* att_workspace, float* out, ocrf_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int hq = Y / 6, wq = X / 6;                      // int(Width / 6), int(Length / 6) (:1159)
+  if (!opacity || !alpha || !weights || !att_workspace || !out || B <= 0 || hq < 6 || wq < 6)
+    return (int)hipErrorInvalidValue;
+  const int hk = (hq + 2 - 6) / 4 + 1, wk = (wq + 2 - 6) / 4 + 1;
+  const int ntok = hq * wq, nkv = hk * wk;
+  if (ntok > kHMaxTok || nkv > kHMaxKV) return (int)hipErrorInvalidValue;
+  const size_t lds = (size_t)(((kHoaWeights + 3) & ~3) + ntok * kHI + 2 * nkv * kHI + 2 * nkv) * sizeof(float);
+  ocrf::launch(OCRF_K_HOA1_ATTN, hoa1_attention_kernel, dim3((ntok + kBlock - 1) / kBlock, B), dim3(kBlock), lds,
+               stream, opacity, alpha, weights, Y, X, hq, wq, hk, wk, offset_scale, att_workspace);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  const long plane = (long)Y * X;
+  ocrf::launch(OCRF_K_HOA1_UP, hoa1_upsample_residual_kernel, dim3((unsigned)((plane + kBlock - 1) / kBlock), B * kHD),
+               dim3(kBlock), 0, stream, static_cast<const float*>(att_workspace), opacity, kHD, Y, X, hq, wq, out);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

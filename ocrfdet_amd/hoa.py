@@ -322,12 +322,48 @@ class DeformableAttention2D(nn.Module):
         return (out, vgrid) if return_vgrid else out
 
 
+def _hoa1_packed(m):
+    """The module's weights in the layout of ``ocrf_hoa1_forward`` (csrc/hoa.hip); cached."""
+    ps = [m.to_q.weight, m.to_offsets[0].weight, m.to_offsets[0].bias, m.to_offsets[2].weight, m.to_k.weight,
+          m.to_v.weight, m.to_out.weight, m.to_out.bias, m.rel_pos_bias.mlp[0][0].weight, m.rel_pos_bias.mlp[0][0].bias,
+          m.rel_pos_bias.mlp[1][0].weight, m.rel_pos_bias.mlp[1][0].bias, m.rel_pos_bias.mlp[2].weight,
+          m.rel_pos_bias.mlp[2].bias]
+    key = tuple((p._version, p.data_ptr()) for p in ps)
+    if getattr(m, '_hoa1_key', None) != key:
+        with torch.no_grad():
+            m._hoa1_pack = torch.cat([p.detach().reshape(-1).float() for p in ps]).contiguous()
+        m._hoa1_key = key
+    return m._hoa1_pack
+
+
+def _hoa1_fusable(m, x):
+    return (x.is_cuda and not m.training and m.heads == 1 and m.offset_groups == 1 and m.downsample_factor == 4
+            and m.to_q.in_channels == 13 and m.to_q.out_channels == 8 and m.to_offsets[0].kernel_size == (6, 6)
+            and len(m.rel_pos_bias.mlp) == 3 and m.rel_pos_bias.mlp[0][0].out_features == 3)
+
+
 def hoa1(defor_cross_attention, opacity, alpha_lidar, heights, Y, X):
-    """view_transformer_ocrf.py:1159-1161: opacity (heights*Y*X, 1) from A_MLP, alpha_lidar
-    (1,heights,Y,X) -> opacity_alpha (1,heights,Y,X)."""
-    o = opacity.view(1, heights, Y, X)
+    """view_transformer_ocrf.py:1159-1161: opacity (B*heights*Y*X, 1) from A_MLP (B = 1 in the
+    reference's per-sample loop), alpha_lidar (B,heights,Y,X) -> opacity_alpha (B,heights,Y,X).
+    Eval mode on the GPU runs the two fused HIP kernels; otherwise the reference's op sequence."""
+    m = defor_cross_attention
+    o = opacity.view(-1, heights, Y, X)
+    if _hoa1_fusable(m, o) and heights == 13:
+        _lib.require_cuda(o, alpha_lidar)
+        o32, a32 = _f32c(o), _f32c(alpha_lidar)
+        B = o32.shape[0]
+        L = _lib.lib()
+        w = _hoa1_packed(m)
+        assert w.numel() == L.ocrf_hoa1_weights_len()
+        att = torch.empty(B, heights, Y // 6, X // 6, device=o.device)
+        out = torch.empty_like(o32)
+        with torch.cuda.device(o.device):
+            _lib.check(L.ocrf_hoa1_forward(_lib.ptr(o32), _lib.ptr(a32), _lib.ptr(w), B, Y, X,
+                                           ctypes.c_float(float(m.to_offsets[4].scale)), _lib.ptr(att), _lib.ptr(out),
+                                           _lib.stream_ptr(o.device)), 'ocrf_hoa1_forward')
+        return out
     size = (int(Y / 6), int(X / 6))
     o_up = F.interpolate(o, size=size, mode='bilinear', align_corners=True)
     a_up = F.interpolate(alpha_lidar, size=size, mode='bilinear', align_corners=True)
-    att = defor_cross_attention(o_up, a_up)
+    att = m(o_up, a_up)
     return F.interpolate(att, size=(Y, X), mode='bilinear', align_corners=True) + o

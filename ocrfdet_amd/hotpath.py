@@ -103,9 +103,10 @@ class HotPath:
         cfg = self.cfg
         X, Y, _ = cfg.bev_xyz
         m = self.hoa_mods
-        oa = [hoa.hoa1(m['dca'], self.gauss['opacity'], self.alpha_lidar[b:b + 1], cfg.num_height, Y, X)
-              for b in range(self.batch)]
-        opacity_bev = m['v2b'](torch.cat(oa, 0), self.bev_pos1)
+        # every frame shares the synthetic opacity volume; the reference loops samples (:1090)
+        opac = self.gauss['opacity'].view(1, cfg.num_height, Y, X).expand(self.batch, -1, -1, -1)
+        oa = hoa.hoa1(m['dca'], opac.reshape(-1, 1), self.alpha_lidar, cfg.num_height, Y, X)
+        opacity_bev = m['v2b'](oa, self.bev_pos1)
         _, gated = m['mask'].gate(geom_feat, opacity_bev)
         return gated, opacity_bev
 

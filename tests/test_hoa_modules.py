@@ -119,3 +119,14 @@ def test_hoa1_gpu(cuda, g):
         full = hoa.hoa1(m, torch.from_numpy(g['hoa1_opacity'].astype(np.float32)).to(cuda),
                         torch.from_numpy(g['hoa1_alpha'].astype(np.float32)).to(cuda), 13, 128, 128)
     np.testing.assert_allclose(full[:, :, ::5, ::3].cpu().numpy(), g['hoa1_out_slice'], rtol=1e-4, atol=2e-5)
+    # fused kernels (eval) == the reference's op sequence (train-mode dispatch, dropout p = 0) at 200x200, B = 2
+    rng = np.random.default_rng(4)
+    op = torch.from_numpy(rng.random((2, 13, 200, 200), dtype=np.float32)).to(cuda)
+    al = torch.from_numpy(rng.random((2, 13, 200, 200), dtype=np.float32)).to(cuda)
+    with torch.no_grad():
+        fused = hoa.hoa1(m, op.reshape(-1, 1), al, 13, 200, 200)
+        m.train()
+        m.dropout.p = 0.0
+        ref = hoa.hoa1(m, op.reshape(-1, 1), al, 13, 200, 200)
+        m.eval()
+    np.testing.assert_allclose(fused.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=2e-5)
