@@ -219,7 +219,7 @@ int ocrf_hoa_gated_conv1x1(const float *x, const float *gate, int B, int C, int 
  *   out (B,13,Y,X) = upsample(att(down(opacity), down(alpha)), (Y,X)) + opacity,
  * down/up = bilinear align_corners=True to/from (Y/6, X/6).  opacity, alpha: (B,13,Y,X).
  * weights: ocrf_hoa1_weights_len() floats packed as documented in csrc/hoa.hip (the Python module
- * packs its state_dict).  att_workspace: B*13*(Y/6)*(X/6) floats.  (Y/6)*(X/6) <= 1600.
+ * packs its state_dict).  att_workspace: B*((13+8)*(Y/6)*(X/6) + 18*128) floats.  (Y/6)*(X/6) <= 1600.
  */
 int ocrf_hoa1_forward(const float *opacity, const float *alpha, const float *weights, int B, int Y, int X,
                       float offset_scale, float *att_workspace, float *out, ocrf_stream_t stream);
@@ -250,7 +250,9 @@ enum {
   OCRF_K_HOA_UNET_BLOCK = 24,    /* hoa_unet_block_kernel */
   OCRF_K_HOA_OUT_CONV = 25,      /* hoa_gated_conv1x1_kernel */
   OCRF_K_HOA1_ATTN = 26,         /* hoa1_attention_kernel */
-  OCRF_K_HOA1_UP = 27            /* hoa1_upsample_residual_kernel */
+  OCRF_K_HOA1_UP = 27,           /* hoa1_upsample_residual_kernel */
+  OCRF_K_HOA1_Q = 28,            /* hoa1_q_kernel */
+  OCRF_K_HOA1_KV = 29            /* hoa1_kv_kernel */
 };
 const char *ocrf_kernel_name(int kernel_id);           /* symbol as rocprofv3 prints it */
 int ocrf_timer_create(int capacity, void **timer_out); /* host pointers */

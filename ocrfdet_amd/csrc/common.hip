@@ -59,6 +59,8 @@ const char* ocrf_kernel_name(int kernel_id) {
     case OCRF_K_HOA_OUT_CONV: return "hoa_gated_conv1x1_kernel";
     case OCRF_K_HOA1_ATTN: return "hoa1_attention_kernel";
     case OCRF_K_HOA1_UP: return "hoa1_upsample_residual_kernel";
+    case OCRF_K_HOA1_Q: return "hoa1_q_kernel";
+    case OCRF_K_HOA1_KV: return "hoa1_kv_kernel";
     default: return "";
   }
 }

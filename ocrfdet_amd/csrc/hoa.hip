@@ -45,38 +45,48 @@ __global__ __launch_bounds__(kBlock) void hoa_channel_stats_kernel(const float* 
 }
 
 // (2) mask = sigmoid(conv_kxk([mean, max]) + opacity_bev); gated = x * mask.
+// One workgroup per 16x16 pixel tile: the two statistic planes (+ halo) and the weights sit in LDS.
+constexpr int kMT = 16;
 __global__ __launch_bounds__(kBlock) void hoa_mask_gate_kernel(
     const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ opacity_bev,
     const float* __restrict__ conv_w, int k, int C, int Y, int X, float* __restrict__ mask,
     float* __restrict__ gated) {
-  extern __shared__ float s_w[];          // 2*k*k conv weights
-  for (int i = threadIdx.x; i < 2 * k * k; i += kBlock) s_w[i] = conv_w[i];
-  __syncthreads();
+  extern __shared__ float s_dyn[];        // 2*k*k weights, then 2 planes of (kMT+k-1)^2
+  const int r = k / 2, tw = kMT + k - 1;
+  float* s_w = s_dyn;
+  float* s_s = s_dyn + 2 * k * k;
   const long plane = (long)Y * X;
-  const long pix = (long)blockIdx.x * kBlock + threadIdx.x;
-  const int b = blockIdx.y;
-  if (pix >= plane) return;
-  const int yy = (int)(pix / X), xx = (int)(pix % X);
-  const int r = k / 2;
-  float acc = 0.f;
-  for (int ch = 0; ch < 2; ++ch) {
-    const float* sp = stats + ((long)b * 2 + ch) * plane;
-    for (int i = 0; i < k; ++i) {
-      const int y2 = yy + i - r;
-      if (y2 < 0 || y2 >= Y) continue;
-      for (int j = 0; j < k; ++j) {
-        const int x2 = xx + j - r;
-        if (x2 < 0 || x2 >= X) continue;
-        acc = fmaf(sp[(long)y2 * X + x2], s_w[(ch * k + i) * k + j], acc);
-      }
-    }
+  const int b = blockIdx.z, ty0 = blockIdx.y * kMT, tx0 = blockIdx.x * kMT;
+  for (int i = threadIdx.x; i < 2 * k * k; i += kBlock) s_w[i] = conv_w[i];
+  for (int i = threadIdx.x; i < 2 * tw * tw; i += kBlock) {
+    const int ch = i / (tw * tw), rem = i % (tw * tw);
+    const int y = ty0 + rem / tw - r, xx = tx0 + rem % tw - r;
+    s_s[i] = (y >= 0 && y < Y && xx >= 0 && xx < X) ? stats[((long)b * 2 + ch) * plane + (long)y * X + xx] : 0.f;
   }
+  __syncthreads();
+  const int ly = threadIdx.x / kMT, lx = threadIdx.x % kMT;
+  const int yy = ty0 + ly, xx = tx0 + lx;
+  if (yy >= Y || xx >= X) return;
+  float acc = 0.f;
+  for (int ch = 0; ch < 2; ++ch)
+    for (int i = 0; i < k; ++i)
+      for (int j = 0; j < k; ++j)
+        acc = fmaf(s_s[(ch * tw + ly + i) * tw + lx + j], s_w[(ch * k + i) * k + j], acc);
+  const long pix = (long)yy * X + xx;
   const float m = sigmoidf_(acc + opacity_bev[(long)b * plane + pix]);
   mask[(long)b * plane + pix] = m;
   if (gated) {
     const float* p = x + (long)b * C * plane + pix;
     float* q = gated + (long)b * C * plane + pix;
-    for (int c = 0; c < C; ++c) q[(long)c * plane] = p[(long)c * plane] * m;
+    int c = 0;
+    for (; c + 8 <= C; c += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(long)(c + u) * plane];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[(long)(c + u) * plane] = v[u] * m;
+    }
+    for (; c < C; ++c) q[(long)c * plane] = p[(long)c * plane] * m;
   }
 }
 
@@ -161,10 +171,10 @@ int ocrf_hoa_opacity_mask_gate(const float* x, const float* stats, const float* 
   if (!x || !stats || !opacity_bev || !conv_w || !mask || k <= 0 || (k & 1) == 0 || k > 15 || B <= 0 ||
       C <= 0 || Y <= 0 || X <= 0)
     return (int)hipErrorInvalidValue;
-  const long plane = (long)Y * X;
-  ocrf::launch(OCRF_K_HOA_MASK_GATE, hoa_mask_gate_kernel, dim3((unsigned)((plane + kBlock - 1) / kBlock), B),
-               dim3(kBlock), (size_t)2 * k * k * sizeof(float), stream, x, stats, opacity_bev, conv_w, k, C, Y,
-               X, mask, gated);
+  const int tw = kMT + k - 1;
+  ocrf::launch(OCRF_K_HOA_MASK_GATE, hoa_mask_gate_kernel, dim3((X + kMT - 1) / kMT, (Y + kMT - 1) / kMT, B),
+               dim3(kBlock), (size_t)(2 * k * k + 2 * tw * tw) * sizeof(float), stream, x, stats, opacity_bev,
+               conv_w, k, C, Y, X, mask, gated);
   return (int)hipGetLastError();
 }
 
@@ -227,7 +237,23 @@ struct UnetBlockArgs {
 __global__ __launch_bounds__(kBlock) void hoa_unet_block_kernel(UnetBlockArgs a) {
   __shared__ float s_v[kUMaxC][kUH][kUH + 1];
   __shared__ float s_red[kBlock / 64][kUMaxC];
+  __shared__ float s_upw[kUMaxC * kUMaxC * 4], s_upb[kUMaxC], s_dww[kUMaxC * 9], s_dwb[kUMaxC],
+      s_pww[kUMaxC * kUMaxC], s_pwb[kUMaxC], s_g0[kUMaxC], s_g1[kUMaxC];
   const int tid = threadIdx.x;
+  {
+    const int Cf = (a.mode == 2) ? a.Cup : a.C0, Ci = Cf + a.C1;
+    if (a.mode == 2) {
+      for (int i = tid; i < a.C0 * a.Cup * 4; i += kBlock) s_upw[i] = a.up_w[i];
+      if (tid < a.Cup) s_upb[tid] = a.up_b[tid];
+    }
+    for (int i = tid; i < Ci * 9; i += kBlock) s_dww[i] = a.dw_w[i];
+    for (int i = tid; i < a.Cout * Ci; i += kBlock) s_pww[i] = a.pw_w[i];
+    if (tid < Ci) s_dwb[tid] = a.dw_b[tid];
+    if (tid < a.Cout) s_pwb[tid] = a.pw_b[tid];
+    if (tid < a.C0) s_g0[tid] = a.gate0 ? a.gate0[blockIdx.z * a.C0 + tid] : 1.f;
+    if (tid < a.C1) s_g1[tid] = a.gate1 ? a.gate1[blockIdx.z * a.C1 + tid] : 1.f;
+  }
+  __syncthreads();
   const int b = blockIdx.z;
   const int ty0 = blockIdx.y * kUT, tx0 = blockIdx.x * kUT;
   const int Cfirst = (a.mode == 2) ? a.Cup : a.C0;
@@ -239,45 +265,54 @@ __global__ __launch_bounds__(kBlock) void hoa_unet_block_kernel(UnetBlockArgs a)
     const int hy = i / kUH, hx = i % kUH;
     const int y = ty0 + hy - 1, x = tx0 + hx - 1;
     const bool in = (y >= 0) && (y < H) && (x >= 0) && (x < W);
+    // all channel loads of a position are issued before any is used (fully unrolled, predicated):
+    // a runtime-bounded loop would pay one L2 latency per channel
+    float sv[kUMaxC];
     if (a.mode == 2) {
+      const int sy = in ? (y >> 1) : 0, sx = in ? (x >> 1) : 0, ki = (y & 1) * 2 + (x & 1);
+#pragma unroll
+      for (int ci = 0; ci < kUMaxC; ++ci)
+        sv[ci] = (in && ci < a.C0) ? a.src0[(((long)b * a.C0 + ci) * a.H0 + sy) * a.W0 + sx] * s_g0[ci] : 0.f;
       float acc[kUMaxC];
 #pragma unroll
-      for (int co = 0; co < kUMaxC; ++co) acc[co] = (co < a.Cup) ? a.up_b[co] : 0.f;
-      if (in) {
-        const int sy = y >> 1, sx = x >> 1, ki = (y & 1) * 2 + (x & 1);
-        for (int ci = 0; ci < a.C0; ++ci) {
-          float v = a.src0[(((long)b * a.C0 + ci) * a.H0 + sy) * a.W0 + sx];
-          if (a.gate0) v *= a.gate0[b * a.C0 + ci];
+      for (int co = 0; co < kUMaxC; ++co) acc[co] = (co < a.Cup) ? s_upb[co] : 0.f;
+#pragma unroll
+      for (int ci = 0; ci < kUMaxC; ++ci) {
+        if (ci < a.C0) {
 #pragma unroll
           for (int co = 0; co < kUMaxC; ++co)
-            if (co < a.Cup) acc[co] = fmaf(v, a.up_w[(ci * a.Cup + co) * 4 + ki], acc[co]);
+            if (co < a.Cup) acc[co] = fmaf(sv[ci], s_upw[(ci * a.Cup + co) * 4 + ki], acc[co]);
         }
       }
 #pragma unroll
       for (int co = 0; co < kUMaxC; ++co)
         if (co < a.Cup) s_v[co][hy][hx] = in ? acc[co] : 0.f;
-    } else {
-      for (int c = 0; c < a.C0; ++c) {
+    } else if (a.mode == 1) {
+#pragma unroll
+      for (int c = 0; c < kUMaxC; ++c) {
         float v = 0.f;
-        if (in) {
-          const float* p = a.src0 + ((long)b * a.C0 + c) * a.H0 * a.W0;
-          if (a.mode == 1) {
-            const float* q = p + (long)(2 * y) * a.W0 + 2 * x;
-            v = fmaxf(fmaxf(q[0], q[1]), fmaxf(q[a.W0], q[a.W0 + 1]));
-          } else {
-            v = p[(long)y * a.W0 + x];
-          }
+        if (in && c < a.C0) {
+          const float* q = a.src0 + ((long)b * a.C0 + c) * a.H0 * a.W0 + (long)(2 * y) * a.W0 + 2 * x;
           // gates are sigmoids (> 0), so max-pooling before or after the multiply is the same
-          if (a.gate0) v *= a.gate0[b * a.C0 + c];
+          v = fmaxf(fmaxf(q[0], q[1]), fmaxf(q[a.W0], q[a.W0 + 1])) * s_g0[c];
         }
-        s_v[c][hy][hx] = v;
+        sv[c] = v;
       }
+#pragma unroll
+      for (int c = 0; c < kUMaxC; ++c)
+        if (c < a.C0) s_v[c][hy][hx] = sv[c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < kUMaxC; ++c)
+        sv[c] = (in && c < a.C0) ? a.src0[((long)b * a.C0 + c) * a.H0 * a.W0 + (long)y * a.W0 + x] * s_g0[c] : 0.f;
+#pragma unroll
+      for (int c = 0; c < kUMaxC; ++c)
+        if (c < a.C0) s_v[c][hy][hx] = sv[c];
     }
     for (int c = 0; c < a.C1; ++c) {
       float v = 0.f;
       if (in) {
-        v = a.src1[(((long)b * a.C1 + c) * H + y) * W + x];
-        if (a.gate1) v *= a.gate1[b * a.C1 + c];
+        v = a.src1[(((long)b * a.C1 + c) * H + y) * W + x] * s_g1[c];
       }
       s_v[Cfirst + c][hy][hx] = v;
     }
@@ -290,16 +325,16 @@ __global__ __launch_bounds__(kBlock) void hoa_unet_block_kernel(UnetBlockArgs a)
   const bool valid = (y < H) && (x < W);
   float outv[kUMaxC];
 #pragma unroll
-  for (int co = 0; co < kUMaxC; ++co) outv[co] = (co < a.Cout) ? a.pw_b[co] : 0.f;
+  for (int co = 0; co < kUMaxC; ++co) outv[co] = (co < a.Cout) ? s_pwb[co] : 0.f;
   for (int c = 0; c < Cin; ++c) {
-    float d = a.dw_b[c];
+    float d = s_dwb[c];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) d = fmaf(s_v[c][ly + i][lx + j], a.dw_w[c * 9 + i * 3 + j], d);
+      for (int j = 0; j < 3; ++j) d = fmaf(s_v[c][ly + i][lx + j], s_dww[c * 9 + i * 3 + j], d);
 #pragma unroll
     for (int co = 0; co < kUMaxC; ++co)
-      if (co < a.Cout) outv[co] = fmaf(d, a.pw_w[co * Cin + c], outv[co]);
+      if (co < a.Cout) outv[co] = fmaf(d, s_pww[co * Cin + c], outv[co]);
   }
   const long plane = (long)H * W;
   const long pix = (long)y * W + x;
@@ -336,27 +371,140 @@ __global__ __launch_bounds__(kBlock) void hoa_unet_block_kernel(UnetBlockArgs a)
   }
 }
 
-// HeightAttention gate from per-tile maxima (any number of tiles): one workgroup per batch entry.
+// Compile-time-shaped variant of hoa_unet_block_kernel for the five blocks of the reference UNet:
+// channel loops unroll completely, so every weight index is a constant and the weights arrive through
+// the scalar cache into SGPRs (no LDS traffic, no per-channel LDS latency chain) — the generic
+// kernel above spends its time waiting on serialized LDS reads inside runtime-bounded loops.
+template <int MODE, int C0, int CUP, int C1, int COUT>
+__global__ __launch_bounds__(kBlock) void hoa_unet_block_fixed_kernel(UnetBlockArgs a) {
+  constexpr int CF = (MODE == 2) ? CUP : C0;
+  constexpr int CIN = CF + C1;
+  __shared__ float s_v[CIN][kUH][kUH + 1];
+  __shared__ float s_red[kBlock / 64][COUT];
+  __shared__ float s_upw[(MODE == 2) ? C0 * CUP * 4 : 1];   // the 2x2 tap is per lane: vector (LDS) reads
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z;
+  const int ty0 = blockIdx.y * kUT, tx0 = blockIdx.x * kUT;
+  const int H = a.H, W = a.W;
+  if (MODE == 2) {
+    for (int i = tid; i < C0 * CUP * 4; i += kBlock) s_upw[i] = a.up_w[i];
+    __syncthreads();
+  }
+
+  for (int i = tid; i < kUH * kUH; i += kBlock) {
+    const int hy = i / kUH, hx = i % kUH;
+    const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+    const bool in = (y >= 0) && (y < H) && (x >= 0) && (x < W);
+    float sv[C0];
+    if (MODE == 2) {
+      const int sy = in ? (y >> 1) : 0, sx = in ? (x >> 1) : 0, ki = (y & 1) * 2 + (x & 1);
+#pragma unroll
+      for (int ci = 0; ci < C0; ++ci) {
+        float v = in ? a.src0[(((long)b * C0 + ci) * a.H0 + sy) * a.W0 + sx] : 0.f;
+        if (a.gate0) v *= a.gate0[b * C0 + ci];
+        sv[ci] = v;
+      }
+#pragma unroll
+      for (int co = 0; co < CUP; ++co) {
+        float acc = a.up_b[co];
+#pragma unroll
+        for (int ci = 0; ci < C0; ++ci) acc = fmaf(sv[ci], s_upw[(ci * CUP + co) * 4 + ki], acc);
+        s_v[co][hy][hx] = in ? acc : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < C0; ++c) {
+        float v = 0.f;
+        if (in) {
+          const float* p = a.src0 + ((long)b * C0 + c) * a.H0 * a.W0;
+          if (MODE == 1) {
+            const float* q = p + (long)(2 * y) * a.W0 + 2 * x;
+            v = fmaxf(fmaxf(q[0], q[1]), fmaxf(q[a.W0], q[a.W0 + 1]));
+          } else {
+            v = p[(long)y * a.W0 + x];
+          }
+          if (a.gate0) v *= a.gate0[b * C0 + c];     // gates > 0: commutes with the max-pool
+        }
+        sv[c] = v;
+      }
+#pragma unroll
+      for (int c = 0; c < C0; ++c) s_v[c][hy][hx] = sv[c];
+    }
+#pragma unroll
+    for (int c = 0; c < C1; ++c) {
+      float v = 0.f;
+      if (in) {
+        v = a.src1[(((long)b * C1 + c) * H + y) * W + x];
+        if (a.gate1) v *= a.gate1[b * C1 + c];
+      }
+      s_v[CF + c][hy][hx] = v;
+    }
+  }
+  __syncthreads();
+
+  const int ly = tid / kUT, lx = tid % kUT;
+  const int y = ty0 + ly, x = tx0 + lx;
+  const bool valid = (y < H) && (x < W);
+  float outv[COUT];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) outv[co] = a.pw_b[co];
+#pragma unroll
+  for (int c = 0; c < CIN; ++c) {
+    float d = a.dw_b[c];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) d = fmaf(s_v[c][ly + i][lx + j], a.dw_w[c * 9 + i * 3 + j], d);
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) outv[co] = fmaf(d, a.pw_w[co * CIN + c], outv[co]);
+  }
+  const long plane = (long)H * W;
+  const long pix = (long)y * W + x;
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) {
+    float v = fmaxf(outv[co], 0.f);
+    if (valid) {
+      if (a.addend) v += a.addend[((long)b * COUT + co) * plane + pix];
+      a.out[((long)b * COUT + co) * plane + pix] = v;
+    } else {
+      v = -INFINITY;
+    }
+    outv[co] = v;
+  }
+  if (a.partial_max) {
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+      float m = outv[co];
+      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off));
+      if ((tid & 63) == 0) s_red[tid >> 6][co] = m;
+    }
+    __syncthreads();
+    if (tid < COUT) {
+      float m = s_red[0][tid];
+      for (int w = 1; w < kBlock / 64; ++w) m = fmaxf(m, s_red[w][tid]);
+      const int n_tiles = a.tiles_x * a.tiles_y;
+      a.partial_max[((long)b * COUT + tid) * n_tiles + blockIdx.y * a.tiles_x + blockIdx.x] = m;
+    }
+  }
+}
+
+// HeightAttention gate from per-tile maxima (any number of tiles): one workgroup per batch entry,
+// one wave per channel for the max (no barrier per channel).
 __global__ __launch_bounds__(kBlock) void hoa_height_gate_from_tiles_kernel(
     int C, int hid, int n_tiles, const float* __restrict__ partial, const float* __restrict__ w1,
     const float* __restrict__ w2, float* __restrict__ gate) {
   __shared__ float s_max[64];
   __shared__ float s_hid[64];
-  __shared__ float s_w[kBlock / 64];
   const int b = blockIdx.x, tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
   const int q = C / 4;
-  for (int c = 0; c < C; ++c) {
+  for (int c = wave; c < C; c += kBlock / 64) {
     float m = -INFINITY;
-    for (int t = tid; t < n_tiles; t += kBlock) m = fmaxf(m, partial[((long)b * C + c) * n_tiles + t]);
+    for (int t = lane; t < n_tiles; t += 64) m = fmaxf(m, partial[((long)b * C + c) * n_tiles + t]);
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off));
-    if ((tid & 63) == 0) s_w[tid >> 6] = m;
-    __syncthreads();
-    if (tid == 0) {
-      for (int w = 1; w < kBlock / 64; ++w) m = fmaxf(m, s_w[w]);
-      s_max[c] = m;
-    }
-    __syncthreads();
+    if (lane == 0) s_max[c] = m;
   }
+  __syncthreads();
   if (tid < 4 * hid) {
     const int g = tid / hid, h = tid % hid;
     float acc = 0.f;
@@ -410,8 +558,20 @@ int ocrf_hoa_unet_block(const float* src0, const float* gate0, int C0, int H0, i
   a.dw_w = dw_w; a.dw_b = dw_b; a.pw_w = pw_w; a.pw_b = pw_b; a.Cout = Cout; a.addend = addend;
   a.out = out; a.partial_max = partial_max; a.H = H; a.W = W;
   a.tiles_x = (W + kUT - 1) / kUT; a.tiles_y = (H + kUT - 1) / kUT;
-  ocrf::launch(OCRF_K_HOA_UNET_BLOCK, hoa_unet_block_kernel, dim3(a.tiles_x, a.tiles_y, B), dim3(kBlock), 0,
-               stream, a);
+  const dim3 grid(a.tiles_x, a.tiles_y, B);
+#define OCRF_UNET_FIXED(M, c0, cup, c1, co)                                                                   \
+  if (mode == M && C0 == c0 && (M != 2 || Cup == cup) && C1 == c1 && Cout == co) {                            \
+    ocrf::launch(OCRF_K_HOA_UNET_BLOCK, hoa_unet_block_fixed_kernel<M, c0, cup, c1, co>, grid, dim3(kBlock), 0, \
+                 stream, a);                                                                                    \
+    return (int)hipGetLastError();                                                                              \
+  }
+  OCRF_UNET_FIXED(0, 13, 0, 0, 4)     // encoder1   (:498)
+  OCRF_UNET_FIXED(1, 4, 0, 0, 8)      // encoder2   (:501)
+  OCRF_UNET_FIXED(1, 8, 0, 0, 16)     // bottleneck (:504)
+  OCRF_UNET_FIXED(2, 16, 8, 8, 8)     // decoder2   (:507-509)
+  OCRF_UNET_FIXED(2, 8, 4, 4, 4)      // decoder1   (:512-514)
+#undef OCRF_UNET_FIXED
+  ocrf::launch(OCRF_K_HOA_UNET_BLOCK, hoa_unet_block_kernel, grid, dim3(kBlock), 0, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -472,110 +632,148 @@ __device__ __forceinline__ float bilinear_ac(const float* __restrict__ p, int H,
   return top * (1.f - ly) + bot * ly;
 }
 
-__global__ __launch_bounds__(kBlock) void hoa1_attention_kernel(
-    const float* __restrict__ opacity, const float* __restrict__ alpha, const float* __restrict__ wts, int Y, int X,
-    int hq, int wq, int hk, int wk, float offset_scale, float* __restrict__ att) {
+// q = to_q(downsample(opacity)) for every token, once per batch entry: qbuf (B, ntok, 8), unscaled.
+__global__ __launch_bounds__(kBlock) void hoa1_q_kernel(const float* __restrict__ opacity,
+                                                        const float* __restrict__ wts, int Y, int X, int hq, int wq,
+                                                        float* __restrict__ qbuf) {
+  __shared__ float s_wq[kHI * kHD];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  if (tid < kHI * kHD) s_wq[tid] = wts[oQ + tid];
+  __syncthreads();
+  const int ntok = hq * wq;
+  const int t = blockIdx.x * kBlock + tid;
+  if (t >= ntok) return;
+  const long plane = (long)Y * X;
+  const float* op = opacity + (long)b * kHD * plane;
+  const float ry = hq > 1 ? (float)(Y - 1) / (float)(hq - 1) : 0.f, rx = wq > 1 ? (float)(X - 1) / (float)(wq - 1) : 0.f;
+  const int ty = t / wq, tx = t % wq;
+  float q[kHI];
+#pragma unroll
+  for (int d = 0; d < kHI; ++d) q[d] = 0.f;
+  for (int c = 0; c < kHD; ++c) {
+    const float v = bilinear_ac(op + c * plane, Y, X, ry * (float)ty, rx * (float)tx);
+#pragma unroll
+    for (int d = 0; d < kHI; ++d) q[d] = fmaf(s_wq[d * kHD + c], v, q[d]);
+  }
+#pragma unroll
+  for (int d = 0; d < kHI; ++d) qbuf[((long)b * ntok + t) * kHI + d] = q[d];
+}
+
+// kv tokens of one batch entry (one workgroup): offsets (depthwise 6x6 stride 4 pad 1 -> GELU ->
+// 1x1 -> tanh -> * scale), sampling grid, bilinear sample (zeros padding, align_corners=False) of
+// downsample(alpha), k and v.  kvbuf (B, nkv, 18) = k[8] | v[8] | grid[2].
+__global__ __launch_bounds__(kBlock) void hoa1_kv_kernel(const float* __restrict__ qbuf,
+                                                         const float* __restrict__ alpha,
+                                                         const float* __restrict__ wts, int Y, int X, int hq, int wq,
+                                                         int hk, int wk, float offset_scale,
+                                                         float* __restrict__ kvbuf) {
   extern __shared__ float sm[];
   float* s_w = sm;                                  // kHoaWeights
   float* s_q = s_w + ((kHoaWeights + 3) & ~3);      // [ntok][8]
   const int ntok = hq * wq, nkv = hk * wk;
-  float* s_k = s_q + ntok * kHI;                    // [nkv][8]
-  float* s_v = s_k + nkv * kHI;                     // [nkv][8]
-  float* s_g = s_v + nkv * kHI;                     // [nkv][2] normalised sampling grid
-  const int tid = threadIdx.x, b = blockIdx.y;
+  float* s_gl = s_q + ntok * kHI;                   // [nkv][8] GELU(offset conv)
+  float* s_f = s_gl + nkv * kHI;                    // [nkv][2] sampling position in the (hq,wq) map
+  float* s_kv = s_f + nkv * 2;                      // [nkv][13] sampled alpha
+  const int tid = threadIdx.x, b = blockIdx.x;
   const long plane = (long)Y * X;
-  const float* op = opacity + (long)b * kHD * plane;
   const float* al = alpha + (long)b * kHD * plane;
+  float* out = kvbuf + (long)b * nkv * 18;
   for (int i = tid; i < kHoaWeights; i += kBlock) s_w[i] = wts[i];
+  for (int i = tid; i < ntok * kHI; i += kBlock) s_q[i] = qbuf[(long)b * ntok * kHI + i];
   __syncthreads();
-  const float ry = hq > 1 ? (float)(Y - 1) / (float)(hq - 1) : 0.f, rx = wq > 1 ? (float)(X - 1) / (float)(wq - 1) : 0.f;
-
-  // q = to_q(downsample(opacity)) for every token (unscaled: the offset net sees it unscaled)
-  for (int t = tid; t < ntok; t += kBlock) {
-    const int ty = t / wq, tx = t % wq;
-    float q[kHI];
-#pragma unroll
-    for (int d = 0; d < kHI; ++d) q[d] = 0.f;
-    for (int c = 0; c < kHD; ++c) {
-      const float v = bilinear_ac(op + c * plane, Y, X, ry * (float)ty, rx * (float)tx);
-#pragma unroll
-      for (int d = 0; d < kHI; ++d) q[d] = fmaf(s_w[oQ + d * kHD + c], v, q[d]);
+  for (int i = tid; i < nkv * kHI; i += kBlock) {          // one (kv token, channel) per thread
+    const int j = i / kHI, d = i % kHI;
+    const int ky = j / wk, kx = j % wk;
+    float a = s_w[oDB + d];
+    for (int u = 0; u < 6; ++u) {
+      const int yy = ky * 4 - 1 + u;
+      if (yy < 0 || yy >= hq) continue;
+      for (int v = 0; v < 6; ++v) {
+        const int xx = kx * 4 - 1 + v;
+        if (xx < 0 || xx >= wq) continue;
+        a = fmaf(s_w[oDW + d * 36 + u * 6 + v], s_q[(yy * wq + xx) * kHI + d], a);
+      }
     }
-#pragma unroll
-    for (int d = 0; d < kHI; ++d) s_q[t * kHI + d] = q[d];
+    s_gl[i] = 0.5f * a * (1.f + erff(a * 0.70710678118654752f));            // nn.GELU (exact)
   }
   __syncthreads();
-
-  // kv tokens: offsets (depthwise 6x6 stride 4 pad 1 -> GELU -> 1x1 -> tanh -> * scale), sampling
-  // grid, bilinear sample (zeros padding, align_corners=False) of downsample(alpha), k and v
   for (int j = tid; j < nkv; j += kBlock) {
     const int ky = j / wk, kx = j % wk;
-    float g[kHI];
-#pragma unroll
-    for (int d = 0; d < kHI; ++d) {
-      float a = s_w[oDB + d];
-      for (int i = 0; i < 6; ++i) {
-        const int yy = ky * 4 - 1 + i;
-        if (yy < 0 || yy >= hq) continue;
-        for (int jj = 0; jj < 6; ++jj) {
-          const int xx = kx * 4 - 1 + jj;
-          if (xx < 0 || xx >= wq) continue;
-          a = fmaf(s_w[oDW + d * 36 + i * 6 + jj], s_q[(yy * wq + xx) * kHI + d], a);
-        }
-      }
-      g[d] = 0.5f * a * (1.f + erff(a * 0.70710678118654752f));            // nn.GELU (exact)
-    }
     float ox = 0.f, oy = 0.f;
 #pragma unroll
-    for (int d = 0; d < kHI; ++d) { ox = fmaf(s_w[oPW + d], g[d], ox); oy = fmaf(s_w[oPW + 8 + d], g[d], oy); }
+    for (int d = 0; d < kHI; ++d) {
+      ox = fmaf(s_w[oPW + d], s_gl[j * kHI + d], ox);
+      oy = fmaf(s_w[oPW + 8 + d], s_gl[j * kHI + d], oy);
+    }
     const float vx = (float)kx + tanhf(ox) * offset_scale, vy = (float)ky + tanhf(oy) * offset_scale;
     // normalize_grid as written (cross_attention_2d.py:30-38): channel 0 over (h-1), 1 over (w-1)
     const float gx = 2.0f * vx / (float)max(hk - 1, 1) - 1.0f, gy = 2.0f * vy / (float)max(wk - 1, 1) - 1.0f;
-    s_g[j * 2] = gx;
-    s_g[j * 2 + 1] = gy;
-    const float fx = ((gx + 1.f) * (float)wq - 1.f) * 0.5f, fy = ((gy + 1.f) * (float)hq - 1.f) * 0.5f;
+    out[j * 18 + 16] = gx;
+    out[j * 18 + 17] = gy;
+    s_f[j * 2] = ((gx + 1.f) * (float)wq - 1.f) * 0.5f;
+    s_f[j * 2 + 1] = ((gy + 1.f) * (float)hq - 1.f) * 0.5f;
+  }
+  __syncthreads();
+  const float ry = hq > 1 ? (float)(Y - 1) / (float)(hq - 1) : 0.f, rx = wq > 1 ? (float)(X - 1) / (float)(wq - 1) : 0.f;
+  for (int i = tid; i < nkv * kHD; i += kBlock) {          // one (kv token, alpha channel) per thread
+    const int j = i / kHD, c = i % kHD;
+    const float fx = s_f[j * 2], fy = s_f[j * 2 + 1];
     const int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
-    float kv[kHD];
-#pragma unroll
-    for (int c = 0; c < kHD; ++c) kv[c] = 0.f;
+    float acc = 0.f;
     for (int dy = 0; dy < 2; ++dy)
       for (int dx = 0; dx < 2; ++dx) {
         const int xi = x0 + dx, yi = y0 + dy;
         if (xi < 0 || xi >= wq || yi < 0 || yi >= hq) continue;
         const float w = (1.f - fabsf(fx - (float)xi)) * (1.f - fabsf(fy - (float)yi));
-        for (int c = 0; c < kHD; ++c)
-          kv[c] = fmaf(bilinear_ac(al + c * plane, Y, X, ry * (float)yi, rx * (float)xi), w, kv[c]);
+        acc = fmaf(bilinear_ac(al + c * plane, Y, X, ry * (float)yi, rx * (float)xi), w, acc);
       }
-#pragma unroll
-    for (int d = 0; d < kHI; ++d) {
-      float a = 0.f, bb = 0.f;
-      for (int c = 0; c < kHD; ++c) { a = fmaf(s_w[oK + d * kHD + c], kv[c], a); bb = fmaf(s_w[oV + d * kHD + c], kv[c], bb); }
-      s_k[j * kHI + d] = a;
-      s_v[j * kHI + d] = bb;
-    }
+    s_kv[i] = acc;
   }
   __syncthreads();
+  for (int i = tid; i < nkv * kHI; i += kBlock) {
+    const int j = i / kHI, d = i % kHI;
+    float a = 0.f, bb = 0.f;
+    for (int c = 0; c < kHD; ++c) {
+      a = fmaf(s_w[oK + d * kHD + c], s_kv[j * kHD + c], a);
+      bb = fmaf(s_w[oV + d * kHD + c], s_kv[j * kHD + c], bb);
+    }
+    out[j * 18 + d] = a;
+    out[j * 18 + 8 + d] = bb;
+  }
+}
 
-  // attention of this workgroup's tokens
-  const int t = blockIdx.x * kBlock + tid;
+// attention: one query token per thread, kv tokens of the batch entry in LDS, online softmax
+__global__ __launch_bounds__(kBlock) void hoa1_attention_kernel(
+    const float* __restrict__ qbuf, const float* __restrict__ kvbuf, const float* __restrict__ wts, int hq, int wq,
+    int nkv, float* __restrict__ att) {
+  extern __shared__ float sm[];
+  float* s_w = sm;                                  // kHoaWeights
+  float* s_kv = s_w + ((kHoaWeights + 3) & ~3);     // [nkv][18]
+  const int tid = threadIdx.x, b = blockIdx.y, nthr = blockDim.x;
+  const int ntok = hq * wq;
+  for (int i = tid; i < kHoaWeights; i += nthr) s_w[i] = wts[i];
+  for (int i = tid; i < nkv * 18; i += nthr) s_kv[i] = kvbuf[(long)b * nkv * 18 + i];
+  __syncthreads();
+  const int t = blockIdx.x * nthr + tid;
   if (t >= ntok) return;
   const int ty = t / wq, tx = t % wq;
   const float scale = 0.35355339059327373f;               // dim_head ** -0.5
   float q[kHI];
 #pragma unroll
-  for (int d = 0; d < kHI; ++d) q[d] = s_q[t * kHI + d] * scale;
+  for (int d = 0; d < kHI; ++d) q[d] = qbuf[((long)b * ntok + t) * kHI + d] * scale;
   // query grid: create_grid_like(x_kv) normalised with dim=0 -> x over (h-1), y over (w-1)
   const float qx = 2.0f * (float)tx / (float)max(hq - 1, 1) - 1.0f, qy = 2.0f * (float)ty / (float)max(wq - 1, 1) - 1.0f;
   float m = -INFINITY, l = 0.f, acc[kHI];
 #pragma unroll
   for (int d = 0; d < kHI; ++d) acc[d] = 0.f;
   for (int j = 0; j < nkv; ++j) {
+    const float* kv = s_kv + j * 18;
     float s = 0.f;
 #pragma unroll
-    for (int d = 0; d < kHI; ++d) s = fmaf(q[d], s_k[j * kHI + d], s);
+    for (int d = 0; d < kHI; ++d) s = fmaf(q[d], kv[d], s);
     // CPB (cross_attention_2d.py:74-89)
-    const float px = qx - s_g[j * 2], py = qy - s_g[j * 2 + 1];
-    const float bx = copysignf(logf(fabsf(px) + 1.f), px) * (px != 0.f), by = copysignf(logf(fabsf(py) + 1.f), py) * (py != 0.f);
+    const float px = qx - kv[16], py = qy - kv[17];
+    const float bx = copysignf(__logf(fabsf(px) + 1.f), px), by = copysignf(__logf(fabsf(py) + 1.f), py);
     float h0[3], h1[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) h0[i] = fmaxf(fmaf(s_w[oC0W + i * 2], bx, fmaf(s_w[oC0W + i * 2 + 1], by, s_w[oC0B + i])), 0.f);
@@ -587,7 +785,7 @@ __global__ __launch_bounds__(kBlock) void hoa1_attention_kernel(
     const float corr = __expf(m - mn), p = __expf(s - mn);
     l = l * corr + p;
 #pragma unroll
-    for (int d = 0; d < kHI; ++d) acc[d] = fmaf(p, s_v[j * kHI + d], acc[d] * corr);
+    for (int d = 0; d < kHI; ++d) acc[d] = fmaf(p, kv[8 + d], acc[d] * corr);
     m = mn;
   }
   const float inv = 1.f / l;
@@ -627,10 +825,22 @@ int ocrf_hoa1_forward(const float* opacity, const float* alpha, const float* wei
   const int hk = (hq + 2 - 6) / 4 + 1, wk = (wq + 2 - 6) / 4 + 1;
   const int ntok = hq * wq, nkv = hk * wk;
   if (ntok > kHMaxTok || nkv > kHMaxKV) return (int)hipErrorInvalidValue;
-  const size_t lds = (size_t)(((kHoaWeights + 3) & ~3) + ntok * kHI + 2 * nkv * kHI + 2 * nkv) * sizeof(float);
-  ocrf::launch(OCRF_K_HOA1_ATTN, hoa1_attention_kernel, dim3((ntok + kBlock - 1) / kBlock, B), dim3(kBlock), lds,
-               stream, opacity, alpha, weights, Y, X, hq, wq, hk, wk, offset_scale, att_workspace);
+  float* qbuf = att_workspace + (size_t)B * kHD * ntok;
+  float* kvbuf = qbuf + (size_t)B * ntok * kHI;
+  ocrf::launch(OCRF_K_HOA1_Q, hoa1_q_kernel, dim3((ntok + kBlock - 1) / kBlock, B), dim3(kBlock), 0, stream, opacity,
+               weights, Y, X, hq, wq, qbuf);
   hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  const size_t lds_kv = (size_t)(((kHoaWeights + 3) & ~3) + ntok * kHI + nkv * (kHI + 2 + kHD)) * sizeof(float);
+  ocrf::launch(OCRF_K_HOA1_KV, hoa1_kv_kernel, dim3(B), dim3(kBlock), lds_kv, stream, static_cast<const float*>(qbuf),
+               alpha, weights, Y, X, hq, wq, hk, wk, offset_scale, kvbuf);
+  e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  const size_t lds_at = (size_t)(((kHoaWeights + 3) & ~3) + nkv * 18) * sizeof(float);
+  ocrf::launch(OCRF_K_HOA1_ATTN, hoa1_attention_kernel, dim3((ntok + 63) / 64, B), dim3(64), lds_at, stream,
+               static_cast<const float*>(qbuf), static_cast<const float*>(kvbuf), weights, hq, wq, nkv,
+               att_workspace);
+  e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   const long plane = (long)Y * X;
   ocrf::launch(OCRF_K_HOA1_UP, hoa1_upsample_residual_kernel, dim3((unsigned)((plane + kBlock - 1) / kBlock), B * kHD),

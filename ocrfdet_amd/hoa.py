@@ -355,7 +355,7 @@ def hoa1(defor_cross_attention, opacity, alpha_lidar, heights, Y, X):
         L = _lib.lib()
         w = _hoa1_packed(m)
         assert w.numel() == L.ocrf_hoa1_weights_len()
-        att = torch.empty(B, heights, Y // 6, X // 6, device=o.device)
+        att = torch.empty(B * ((heights + 8) * (Y // 6) * (X // 6) + 18 * 128), device=o.device)   # att | q | kv
         out = torch.empty_like(o32)
         with torch.cuda.device(o.device):
             _lib.check(L.ocrf_hoa1_forward(_lib.ptr(o32), _lib.ptr(a32), _lib.ptr(w), B, Y, X,
