@@ -138,9 +138,10 @@ int ocrf_bev_pool_v2_grad(int c, int n_intervals, const float *out_grad, const f
  * outputs (caller-allocated, fully written):
  *   out_color (n_views,3,H,W)  out_depth (n_views,H,W)  out_final_T (n_views,H,W) [= 1 - accumulated
  *   opacity]  out_n_contrib (n_views,H,W)  radii (n_views,P)  tiles_touched (n_views,P) or NULL
- *   status (device int, may be NULL; caller zeroes it): bit 0 is set if some tile met more than
- *   3840 Gaussians inside ONE 0.2 %-wide depth bucket, the capacity of the in-LDS exact sort; the
- *   pixels of such a tile were blended in bucket order but possibly not in exact depth order.
+ *   status (device int, may be NULL; caller zeroes it): informational.  Bit 1 (value 2) is set when
+ *   some tile met more than ~3 000 Gaussians inside ONE 0.2 %-wide depth bucket, more than the in-LDS
+ *   sort holds; such a tile is then blended by an exact but slower streaming selection over that
+ *   bucket.  Results are exact either way; bit 0 is never set (reserved).
  * P == 0 zero-fills the outputs like the reference (rasterize_points.cu:68-69).
  * No host synchronisation happens (the reference reads num_rendered back, rasterizer_impl.cu:281).
  */
@@ -242,7 +243,6 @@ enum {
   OCRF_K_RASTER_BLEND = 11,      /* raster_blend_kernel */
   OCRF_K_RASTER_GATHER = 12,     /* raster_scatter_kernel */
   OCRF_K_RASTER_SCAN = 13,       /* raster_bucket_scan_kernel */
-  OCRF_K_RASTER_REDUCE = 14,     /* raster_bucket_reduce_kernel */
   OCRF_K_HOA_STATS = 20,         /* hoa_channel_stats_kernel */
   OCRF_K_HOA_MASK_GATE = 21,     /* hoa_mask_gate_kernel */
   OCRF_K_HOA_HEIGHT_MAX = 22,    /* hoa_height_max_kernel */

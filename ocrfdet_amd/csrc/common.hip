@@ -50,7 +50,6 @@ const char* ocrf_kernel_name(int kernel_id) {
     case OCRF_K_RASTER_BLEND: return "raster_blend_kernel<false>";
     case OCRF_K_RASTER_GATHER: return "raster_scatter_kernel";
     case OCRF_K_RASTER_SCAN: return "raster_bucket_scan_kernel";
-    case OCRF_K_RASTER_REDUCE: return "raster_bucket_reduce_kernel";
     case OCRF_K_HOA_STATS: return "hoa_channel_stats_kernel";
     case OCRF_K_HOA_MASK_GATE: return "hoa_mask_gate_kernel";
     case OCRF_K_HOA_HEIGHT_MAX: return "hoa_height_max_kernel";

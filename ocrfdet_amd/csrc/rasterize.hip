@@ -14,7 +14,8 @@
 //   1. preprocess  — one thread per (view, Gaussian); same arithmetic, fp-contract off so that
 //                    radii / tile rectangles are compiler-independent; visible Gaussians also
 //                    count themselves into a histogram of 8192 depth buckets per view (bucket =
-//                    top 18 bits of the positive depth float: 0.2 % wide);
+//                    top 18 bits of the positive depth float: 0.2 % wide), through an LDS
+//                    histogram per 2048-Gaussian workgroup;
 //   2. bucket scan — exclusive scan of the histogram (one workgroup per view);
 //   3. scatter     — every visible Gaussian drops its (tile rect, depth|id) record into its
 //                    bucket's range: the list is now ordered by bucket, unordered inside one;
@@ -40,7 +41,7 @@ constexpr int kTileX = 16, kTileY = 16;     // cuda_rasterizer/config.h:15-17
 constexpr int kBuckets = 8192;               // depth buckets per view
 constexpr int kBucketShift = 14;             // bucket = (depth bits >> 14) - base: 9 mantissa bits
 constexpr unsigned kBucketBase = 0x3E4CCCCDu >> kBucketShift;   // depth > 0.2f always (auxiliary.h:154)
-constexpr int kCopies = 32;                  // replicated histograms: spreads same-bucket atomics
+constexpr int kChunk = 2048;                 // Gaussians per workgroup in preprocess / scatter
 constexpr int kCapRec = 4096;                // LDS record capacity of the blend kernel
 constexpr int kStage = 256;                  // payload entries staged per blend batch
 constexpr int kScanUnroll = 4;               // rect batches in flight in the scan
@@ -57,27 +58,6 @@ struct __attribute__((aligned(8))) Rect { unsigned short x0, y0, x1, y1; };
 __device__ __forceinline__ int bucket_of(unsigned key) {
   const int b = (int)(key >> kBucketShift) - (int)kBucketBase;
   return min(max(b, 0), kBuckets - 1);
-}
-
-// Lanes of a wave that are adjacent and want the same bucket form a run; the run's first lane
-// does ONE atomic for the whole run (neighbouring Gaussians of a regular grid share a depth
-// bucket for cameras looking across the fast grid axis: 64 same-address atomics become one).
-// Returns the slot base for this lane's run (valid on active lanes) and its rank inside the run.
-__device__ __forceinline__ int run_atomic_add(int* counters, int bucket, bool active, int* rank_out) {
-  const int lane = threadIdx.x & 63;
-  const int key = active ? bucket : -1 - lane;              // inactive lanes never match
-  const int prev = __shfl_up(key, 1);
-  const bool head = (lane == 0) || (prev != key);
-  const unsigned long long heads = __ballot(head);
-  const unsigned long long upto = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-  const int head_lane = 63 - __clzll(upto);
-  const unsigned long long after = heads & ~((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-  const int next_head = after ? (__ffsll((long long)after) - 1) : 64;
-  int base = 0;
-  if (active && head) base = atomicAdd(&counters[bucket], next_head - lane);
-  base = __shfl(base, head_lane);
-  *rank_out = lane - head_lane;
-  return base;
 }
 
 // auxiliary.h:41-44 — the reference evaluates this in double precision (its literals are double)
@@ -97,10 +77,17 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
     const Camera* __restrict__ cams, unsigned* __restrict__ keys, Rect* __restrict__ rects,
     float2* __restrict__ xy, float4* __restrict__ conic_o, int* __restrict__ radii,
     unsigned* __restrict__ tiles_touched, int* __restrict__ hist) {
-  const int idx_raw = blockIdx.x * kBlock + threadIdx.x;
+  // One workgroup = kChunk consecutive Gaussians of one view.  Their depth buckets are counted in
+  // an LDS histogram first and only the non-empty bins go to the global one: scattered global
+  // atomics run at ~20 G/s chip-wide, and a depth slice of a regular grid puts thousands of
+  // Gaussians into ONE bucket.
+  __shared__ int s_hist[kBuckets];
   const int v = blockIdx.y;
-  const bool in_range = idx_raw < P;
-  const int idx = in_range ? idx_raw : P - 1;       // tail lanes recompute the last Gaussian, store nothing
+  for (int i = threadIdx.x; i < kBuckets; i += kBlock) s_hist[i] = 0;
+  __syncthreads();
+  for (int it = 0; it < kChunk / kBlock; ++it) {
+  const int idx = blockIdx.x * kChunk + it * kBlock + threadIdx.x;
+  if (idx >= P) break;
   const long o = (long)v * P + idx;
   const Camera& cam = cams[v];
   const float* vm = cam.view;
@@ -190,7 +177,7 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
       const int y0 = min(gy, max(0, (int)((pixy - (float)rad) / (float)kTileY)));
       const int x1 = min(gx, max(0, (int)((pixx + (float)rad + (float)(kTileX - 1)) / (float)kTileX)));
       const int y1 = min(gy, max(0, (int)((pixy + (float)rad + (float)(kTileY - 1)) / (float)kTileY)));
-      if (in_range && (x1 - x0) * (y1 - y0) != 0) {
+      if ((x1 - x0) * (y1 - y0) != 0) {
         key = __float_as_uint(vz);        // vz > 0.2: the raw bits order like the value
         my_radii = rad;
         touched = (unsigned)((y1 - y0) * (x1 - x0));
@@ -203,51 +190,29 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
       }
     }
   }
-  {
-    int rank;
-    // hist[v][bucket][copy], copy = workgroup index mod kCopies: a depth slice of a regular grid
-    // puts thousands of Gaussians into ONE bucket; same-address atomics serialise in L2
-    (void)run_atomic_add(hist + (long)v * kBuckets * kCopies + (blockIdx.x % kCopies), bucket_of(key) * kCopies,
-                         key != 0xFFFFFFFFu, &rank);
-  }
-  if (!in_range) return;
+  if (key != 0xFFFFFFFFu) atomicAdd(&s_hist[bucket_of(key)], 1);
   keys[o] = key;
   radii[o] = my_radii;
   if (tiles_touched) tiles_touched[o] = touched;
-}
-
-// ---------------------------------------------------------------------------------------------
-// 2a. per bucket: total over the kCopies replicas -> tot[v][b]; the replicas are overwritten by
-//     their exclusive prefix inside the bucket (the scatter cursors).  One thread per bucket.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void raster_bucket_reduce_kernel(int* __restrict__ hist,
-                                                                      int* __restrict__ tot) {
-  const long b = (long)blockIdx.x * kBlock + threadIdx.x;      // over n_views * kBuckets
-  int4* h = reinterpret_cast<int4*>(hist + b * kCopies);
-  int run = 0;
-#pragma unroll
-  for (int q = 0; q < kCopies / 4; ++q) {
-    int4 x = h[q];
-    int4 y;
-    y.x = run; run += x.x;
-    y.y = run; run += x.y;
-    y.z = run; run += x.z;
-    y.w = run; run += x.w;
-    h[q] = y;
+  }   // chunk loop
+  __syncthreads();
+  for (int i = threadIdx.x; i < kBuckets; i += kBlock) {
+    const int c = s_hist[i];
+    if (c) atomicAdd(&hist[v * kBuckets + i], c);
   }
-  tot[b] = run;
 }
 
 // ---------------------------------------------------------------------------------------------
-// 2b. exclusive scan of each view's bucket totals: starts[v][0..kBuckets] (last = visible count).
-//     One workgroup per view, 32 buckets per thread.
+// 2. exclusive scan of each view's histogram: starts[v][0..kBuckets] (last = visible count) and
+//    the scatter cursors reset to the starts.  One workgroup per view, 32 buckets per thread.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void raster_bucket_scan_kernel(const int* __restrict__ tot,
-                                                                    int* __restrict__ starts) {
+__global__ __launch_bounds__(kBlock) void raster_bucket_scan_kernel(const int* __restrict__ hist,
+                                                                    int* __restrict__ starts,
+                                                                    int* __restrict__ cursor) {
   __shared__ int s_sum[kBlock];
   constexpr int per = kBuckets / kBlock;
   const int v = blockIdx.x, tid = threadIdx.x;
-  const int* h = tot + (long)v * kBuckets + tid * per;
+  const int* h = hist + (long)v * kBuckets + tid * per;
   int local[per];
   int sum = 0;
 #pragma unroll
@@ -262,8 +227,9 @@ __global__ __launch_bounds__(kBlock) void raster_bucket_scan_kernel(const int* _
   }
   const int base = s_sum[tid] - sum;
   int* st = starts + (long)v * (kBuckets + 1) + tid * per;
+  int* cu = cursor + (long)v * kBuckets + tid * per;
 #pragma unroll
-  for (int i = 0; i < per; ++i) st[i] = base + local[i];
+  for (int i = 0; i < per; ++i) { st[i] = base + local[i]; cu[i] = base + local[i]; }
   if (tid == kBlock - 1) starts[(long)v * (kBuckets + 1) + kBuckets] = s_sum[tid];
 }
 
@@ -272,21 +238,34 @@ __global__ __launch_bounds__(kBlock) void raster_bucket_scan_kernel(const int* _
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void raster_scatter_kernel(
     int P, const unsigned* __restrict__ keys, const Rect* __restrict__ rects,
-    const int* __restrict__ starts, int* __restrict__ cursor, Rect* __restrict__ b_rect,
-    unsigned long long* __restrict__ b_comp) {
-  const int idx = blockIdx.x * kBlock + threadIdx.x;
-  const int v = blockIdx.y;
-  const long o = (long)v * P + min(idx, P - 1);
-  const unsigned key = idx < P ? keys[o] : 0xFFFFFFFFu;
-  const bool vis = key != 0xFFFFFFFFu;
-  int rank;
-  const int bkt = bucket_of(key);
-  const int slot0 = run_atomic_add(cursor + (long)v * kBuckets * kCopies + (blockIdx.x % kCopies),
-                                   bkt * kCopies, vis, &rank);
-  if (!vis) return;
-  const int slot = starts[(long)v * (kBuckets + 1) + bkt] + slot0 + rank;
-  b_rect[(long)v * P + slot] = rects[o];
-  b_comp[(long)v * P + slot] = ((unsigned long long)key << 32) | (unsigned)idx;
+    int* __restrict__ cursor, Rect* __restrict__ b_rect, unsigned long long* __restrict__ b_comp) {
+  // Same chunking as the preprocess: count in LDS, reserve one global range per non-empty bucket
+  // (ONE returning global atomic per bucket per workgroup), hand out slots with LDS atomics.
+  __shared__ int s_cnt[kBuckets];
+  const int v = blockIdx.y, tid = threadIdx.x;
+  for (int i = tid; i < kBuckets; i += kBlock) s_cnt[i] = 0;
+  __syncthreads();
+  unsigned key[kChunk / kBlock];
+#pragma unroll
+  for (int it = 0; it < kChunk / kBlock; ++it) {
+    const int idx = blockIdx.x * kChunk + it * kBlock + tid;
+    key[it] = idx < P ? keys[(long)v * P + idx] : 0xFFFFFFFFu;
+    if (key[it] != 0xFFFFFFFFu) atomicAdd(&s_cnt[bucket_of(key[it])], 1);
+  }
+  __syncthreads();
+  for (int i = tid; i < kBuckets; i += kBlock) {
+    const int c = s_cnt[i];
+    if (c) s_cnt[i] = atomicAdd(&cursor[v * kBuckets + i], c);      // now: next free slot of bucket i
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < kChunk / kBlock; ++it) {
+    if (key[it] == 0xFFFFFFFFu) continue;
+    const int idx = blockIdx.x * kChunk + it * kBlock + tid;
+    const int slot = atomicAdd(&s_cnt[bucket_of(key[it])], 1);
+    b_rect[(long)v * P + slot] = rects[(long)v * P + idx];
+    b_comp[(long)v * P + slot] = ((unsigned long long)key[it] << 32) | (unsigned)idx;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -405,9 +384,68 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
   float C0 = 0.f, C1 = 0.f, C2 = 0.f;
   float D = depth_mode == 0 ? 15.0f : 0.0f;
 
+  bool all_done = false;
+  // blend rec[0, n) (sorted) front to back, kStage at a time; sets all_done
+  auto blend_records = [&](int n) {
+    for (int s0 = 0; s0 < n && !all_done; s0 += kStage) {
+      const int ns = min(kStage, n - s0);
+      if (tid < ns) {
+        const unsigned long long c = rec[s0 + tid];
+        const unsigned id = (unsigned)(c & 0xFFFFFFFFull);
+        const float2 p = xy[base + id];
+        const float4 co = conic_o[base + id];
+        l_a[tid] = make_float4(p.x, p.y, co.x, co.y);
+        l_b[tid] = make_float4(co.z, co.w, __uint_as_float((unsigned)(c >> 32)), colors[3 * (long)id]);
+        l_c[tid] = make_float2(colors[3 * (long)id + 1], colors[3 * (long)id + 2]);
+      }
+      __syncthreads();
+      // Branch-free per-record update so that the LDS reads of the next records can be issued
+      // ahead (4 records per trip); a wave leaves the batch as soon as its 64 pixels are done.
+      for (int j0 = 0; j0 < ns; j0 += 4) {
+        if (__ballot(!done) == 0ull) break;
+        float4 ra[4], rb[4];
+        float2 rc2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = min(j0 + u, ns - 1);
+          ra[u] = l_a[j];
+          rb[u] = l_b[j];
+          rc2[u] = l_c[j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool live = !done && (j0 + u < ns);
+          contributor += live ? 1u : 0u;
+          const float4 a = ra[u];
+          const float4 b = rb[u];
+          const float dx = a.x - pixf_x, dy = a.y - pixf_y;
+          const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+          const float alpha = fminf(0.99f, b.y * __expf(power));
+          const bool valid = live && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+          const float test_T = T * (1 - alpha);
+          const bool stop = valid && (test_T < 0.0001f);
+          const bool contrib = valid && !stop;
+          const float wgt = contrib ? alpha * T : 0.f;
+          C0 = fmaf(b.w, wgt, C0);
+          C1 = fmaf(rc2[u].x, wgt, C1);
+          C2 = fmaf(rc2[u].y, wgt, C2);
+          if (depth_mode == 0) {
+            D = (contrib && T > 0.5f && test_T < 0.5f) ? b.z : D;
+          } else {
+            D = fmaf(b.z, wgt, D);
+          }
+          T = contrib ? test_T : T;
+          last_contributor = contrib ? contributor : last_contributor;
+          done = done || stop;
+        }
+      }
+      // every pixel saturated -> stop (forward.cu:304-307)
+      all_done = __syncthreads_count(done) == kBlock;
+    }
+  };
+
   int scan = 0;      // next list entry to look at
   int nrec = 0;      // records held in LDS (sorted prefix left over from the previous round)
-  bool all_done = false;
   unsigned long long t_prev = 0, t_acc[6] = {0, 0, 0, 0, 0, 0};
   auto stamp = [&](int slot) {
     if constexpr (STAMP) {
@@ -492,72 +530,75 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
       n_ready = l_ready;
       if (n_ready == 0) {
         if (nrec >= kCapRec - kScanUnroll * kBlock) {
-          // one depth bucket alone overflows the LDS capacity for this tile: flag it (the host
-          // wrapper turns this into an error) and fall through blending in the order held
-          if (tid == 0) atomicOr(status, 1);
-          n_ready = nrec;
+          // ONE depth bucket holds more tile hits than the LDS can sort at once.  Exact streaming
+          // selection over that bucket's range: keep the K smallest (depth bits, id) composites
+          // above `last`, blend them, repeat from `last` until the bucket is exhausted.
+          constexpr int K = kCapRec - kBlock;
+          const int rs = starts[(long)v * (kBuckets + 1) + b_last];
+          const int re = starts[(long)v * (kBuckets + 1) + b_last + 1];
+          unsigned long long last = 0ull;
+          if (tid == 0) atomicOr(status, 2);          // informational: the slow exact path ran
+          while (!all_done) {
+            int cnt = 0;
+            unsigned long long thr = kPad;
+            bool full = false;
+            for (int p0 = rs; p0 < re; p0 += kBlock) {
+              const int i = p0 + tid;
+              unsigned long long comp = 0ull;
+              bool take = false;
+              if (i < re) {
+                const Rect rc = b_rect[base + i];
+                if ((tx >= rc.x0) && (tx < rc.x1) && (ty >= rc.y0) && (ty < rc.y1)) {
+                  comp = b_comp[base + i];
+                  take = comp > last && comp < thr;
+                }
+              }
+              const unsigned long long m = __ballot(take);
+              const int rank = __popcll(m & ((1ull << lane) - 1ull));
+              if (lane == 0) l_wtot[wave] = __popcll(m);
+              __syncthreads();
+              int off = cnt, tot = 0;
+#pragma unroll
+              for (int w = 0; w < kBlock / 64; ++w) {
+                const int c = l_wtot[w];
+                if (w < wave) off += c;
+                tot += c;
+              }
+              if (take) rec[off + rank] = comp;
+              cnt += tot;
+              __syncthreads();
+              if (cnt > K) {                           // merge: keep the K smallest seen so far
+                for (int q = cnt + tid; q < kCapRec; q += kBlock) rec[q] = kPad;
+                __syncthreads();
+                bitonic_sort_lds(rec, kCapRec, tid);
+                cnt = K;
+                thr = rec[K - 1];
+                full = true;
+                __syncthreads();
+              }
+            }
+            if (cnt == 0) break;
+            int m2 = kBlock;
+            while (m2 < cnt) m2 <<= 1;
+            for (int q = cnt + tid; q < m2; q += kBlock) rec[q] = kPad;
+            __syncthreads();
+            bitonic_sort_lds(rec, m2, tid);
+            last = rec[cnt - 1];
+            __syncthreads();
+            blend_records(cnt);
+            if (!full) break;                          // everything above `last` fitted: bucket done
+          }
+          scan = re;
+          nrec = 0;
+          if (all_done) break;
+          continue;
         } else {
           continue;      // keep scanning: the only bucket held is still open
         }
       }
     }
     stamp(2);
-    // ---- blend the final records front to back, kStage at a time ----
-    for (int s0 = 0; s0 < n_ready && !all_done; s0 += kStage) {
-      const int ns = min(kStage, n_ready - s0);
-      if (tid < ns) {
-        const unsigned long long c = rec[s0 + tid];
-        const unsigned id = (unsigned)(c & 0xFFFFFFFFull);
-        const float2 p = xy[base + id];
-        const float4 co = conic_o[base + id];
-        l_a[tid] = make_float4(p.x, p.y, co.x, co.y);
-        l_b[tid] = make_float4(co.z, co.w, __uint_as_float((unsigned)(c >> 32)), colors[3 * (long)id]);
-        l_c[tid] = make_float2(colors[3 * (long)id + 1], colors[3 * (long)id + 2]);
-      }
-      __syncthreads();
-      // Branch-free per-record update so that the LDS reads of the next records can be issued
-      // ahead (4 records per trip); a wave leaves the batch as soon as its 64 pixels are done.
-      for (int j0 = 0; j0 < ns; j0 += 4) {
-        if (__ballot(!done) == 0ull) break;
-        float4 ra[4], rb[4];
-        float2 rc2[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int j = min(j0 + u, ns - 1);
-          ra[u] = l_a[j];
-          rb[u] = l_b[j];
-          rc2[u] = l_c[j];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const bool live = !done && (j0 + u < ns);
-          contributor += live ? 1u : 0u;
-          const float4 a = ra[u];
-          const float4 b = rb[u];
-          const float dx = a.x - pixf_x, dy = a.y - pixf_y;
-          const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-          const float alpha = fminf(0.99f, b.y * __expf(power));
-          const bool valid = live && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-          const float test_T = T * (1 - alpha);
-          const bool stop = valid && (test_T < 0.0001f);
-          const bool contrib = valid && !stop;
-          const float wgt = contrib ? alpha * T : 0.f;
-          C0 = fmaf(b.w, wgt, C0);
-          C1 = fmaf(rc2[u].x, wgt, C1);
-          C2 = fmaf(rc2[u].y, wgt, C2);
-          if (depth_mode == 0) {
-            D = (contrib && T > 0.5f && test_T < 0.5f) ? b.z : D;
-          } else {
-            D = fmaf(b.z, wgt, D);
-          }
-          T = contrib ? test_T : T;
-          last_contributor = contrib ? contributor : last_contributor;
-          done = done || stop;
-        }
-      }
-      // every pixel saturated -> stop (forward.cu:304-307)
-      all_done = __syncthreads_count(done) == kBlock;
-    }
+    blend_records(n_ready);
     stamp(3);
     if (all_done || (at_end && n_ready == nrec)) break;
     // ---- carry the records of the open bucket to the front (still sorted) ----
@@ -609,9 +650,9 @@ inline void raster_layout(int P, int n_views, RasterWs* ws) {
   ws->conic_o = take(n * sizeof(float4));
   ws->b_rect = take(n * sizeof(Rect));
   ws->b_comp = take(n * 8);
-  ws->hist = take((size_t)n_views * kBuckets * kCopies * sizeof(int));   // becomes the cursors
+  ws->hist = take((size_t)n_views * kBuckets * sizeof(int));
   ws->starts = take((size_t)n_views * (kBuckets + 1) * sizeof(int));
-  ws->cursor = take((size_t)n_views * kBuckets * sizeof(int));            // bucket totals
+  ws->cursor = take((size_t)n_views * kBuckets * sizeof(int));
   ws->status = take(256);
   ws->total = off;
 }
@@ -672,26 +713,21 @@ int ocrf_rasterize_forward(int P, int n_views, int H, int W, const float* means3
   int* st = status ? status : reinterpret_cast<int*>(base + ws.status);
   const Camera* cams = reinterpret_cast<const Camera*>(cameras);
 
-  hipError_t e = hipMemsetAsync(hist, 0, (size_t)n_views * kBuckets * kCopies * sizeof(int), stream);
+  hipError_t e = hipMemsetAsync(hist, 0, (size_t)n_views * kBuckets * sizeof(int), stream);
   if (e != hipSuccess) return (int)e;
-  const dim3 pgrid((P + kBlock - 1) / kBlock, n_views);
+  const dim3 pgrid((P + kChunk - 1) / kChunk, n_views);
   ocrf::launch(OCRF_K_RASTER_PREPROCESS, raster_preprocess_kernel, pgrid, dim3(kBlock), 0, stream, P,
                W, H, gx, gy, means3D, opacities, scales, scale_modifier, rotations, cov3D_precomp,
                cams, keys, rects, xy, conic_o, radii, tiles_touched, hist);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  int* tot = cursor;
-  ocrf::launch(OCRF_K_RASTER_REDUCE, raster_bucket_reduce_kernel,
-               dim3((unsigned)((size_t)n_views * kBuckets / kBlock)), dim3(kBlock), 0, stream, hist, tot);
-  e = hipGetLastError();
-  if (e != hipSuccess) return (int)e;
   ocrf::launch(OCRF_K_RASTER_SCAN, raster_bucket_scan_kernel, dim3(n_views), dim3(kBlock), 0, stream,
-               static_cast<const int*>(tot), starts);
+               static_cast<const int*>(hist), starts, cursor);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   ocrf::launch(OCRF_K_RASTER_GATHER, raster_scatter_kernel, pgrid, dim3(kBlock), 0, stream, P,
-               static_cast<const unsigned*>(keys), static_cast<const Rect*>(rects),
-               static_cast<const int*>(starts), hist, b_rect, b_comp);
+               static_cast<const unsigned*>(keys), static_cast<const Rect*>(rects), cursor, b_rect,
+               b_comp);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   const size_t lds = (size_t)kCapRec * 8 + (size_t)kStage * (16 + 16 + 8);

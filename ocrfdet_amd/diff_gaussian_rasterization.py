@@ -103,7 +103,7 @@ def rasterize_views(means3D, colors, opacities, scales, rotations, viewmatrices,
             _lib.ptr(status), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_ptr(dev)), 'ocrf_rasterize_forward')
     if tt is not None:
         out['tiles_touched'] = tt
-    out['status'] = status     # device int; bit 0 = a depth bucket overflowed the exact LDS sort
+    out['status'] = status     # device int, informational: 2 = the exact streaming path ran for some tile
     return out
 
 
