@@ -156,6 +156,15 @@ def main():
             alg_bytes = 0.5 * (hp.lss.algorithmic_bytes(depth.numel(), feat.numel()) +
                                hp.ht.algorithmic_bytes(depth.numel(), feat.numel()))
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE in separate runs of this same command, gfx950 x2 fetch correction);
+        # bench.py cannot run the profiler on itself, so this is the last committed measurement
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')
+        if args.config == DEFAULT_CONFIG and os.path.exists(pmc):
+            rec = json.load(open(pmc)).get(timer.kernel_name.split('<')[0])
+            if rec:
+                traffic, traffic_src = rec['hbm_bytes_corrected'], 'profiles/r1_pmc_traffic.json'
         voxels = hp.bev_voxels_per_step * world * args.steps
         out = {
             'metric': 'BEV voxels/sec + rendered views/sec, 6-cam 256x704',
@@ -171,7 +180,7 @@ def main():
                        'index_prep': 'cached (accelerate=True semantics)',
                        'sharding': f'{world} x {cfg.n_frames} frames (frame policy), one RCCL all_gather of the fused BEV per step' if world > 1 else 'none'},
             'roofline': {'bound': 'hbm', 'kernel': timer.kernel_name, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_us': 1e3 * avg_ms,
                          'launches_timed': len(ms)},
         }
