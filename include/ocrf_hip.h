@@ -155,6 +155,31 @@ int ocrf_rasterize_forward(int P, int n_views, int H, int W, const float *means3
 
 size_t ocrf_rasterize_workspace_bytes(int P, int n_views);
 
+/*
+ * Backward of the colour output of ocrf_rasterize_forward (the w-depth fork has no depth backward,
+ * diff-gaussian-rasterization-w-depth/README.md:13).  Replaces RasterizeGaussiansBackwardCUDA
+ * (rasterize_points.cu:117-196 -> rasterizer_impl.cu:338-434 -> cuda_rasterizer/backward.cu) for
+ * colours precomputed and covariance from (scales, rotations); gradients are summed over the views.
+ *   fwd_color / fwd_final_T / fwd_n_contrib: the forward's outputs for the same inputs
+ *   dL_dcolor (n_views,3,H,W)
+ * outputs (fully written): dL_dmeans3D (P,3)  dL_dcolors (P,3)  dL_dopacity (P)  dL_dscales (P,3)
+ *   dL_drotations (P,4) [w.r.t. the un-normalised quaternion, like the reference]
+ *   dL_dmeans2D (n_views,P,3) or NULL [NDC-space screen gradient, z = 0; the reference returns it
+ *   for densification statistics]
+ * Float atomics are used per (tile, Gaussian): results vary in the last bits run to run, like the
+ * reference's (backward.cu:509-541).  Reference quirk kept: a clamped t.x / t.y is treated as a
+ * constant (x_grad_mul / y_grad_mul, backward.cu:174-175).
+ */
+int ocrf_rasterize_backward(int P, int n_views, int H, int W, const float *means3D, const float *colors,
+                            const float *opacities, const float *scales, float scale_modifier,
+                            const float *rotations, const float *cameras, const float *bg,
+                            const float *fwd_color, const float *fwd_final_T, const uint32_t *fwd_n_contrib,
+                            const float *dL_dcolor, float *dL_dmeans3D, float *dL_dcolors,
+                            float *dL_dopacity, float *dL_dscales, float *dL_drotations,
+                            float *dL_dmeans2D, void *workspace, size_t workspace_bytes,
+                            ocrf_stream_t stream);
+size_t ocrf_rasterize_backward_workspace_bytes(int P, int n_views);
+
 /* ------------------------------------------------------------------------------------------
  * Height-aware Opacity-based Attention (HOA) reductions
  * ------------------------------------------------------------------------------------------
@@ -243,6 +268,8 @@ enum {
   OCRF_K_RASTER_BLEND = 11,      /* raster_blend_kernel */
   OCRF_K_RASTER_GATHER = 12,     /* raster_scatter_kernel */
   OCRF_K_RASTER_SCAN = 13,       /* raster_bucket_scan_kernel */
+  OCRF_K_RASTER_BLEND_BWD = 15,  /* raster_blend_kernel<false, true> */
+  OCRF_K_RASTER_PRE_BWD = 16,    /* raster_preprocess_backward_kernel */
   OCRF_K_HOA_STATS = 20,         /* hoa_channel_stats_kernel */
   OCRF_K_HOA_MASK_GATE = 21,     /* hoa_mask_gate_kernel */
   OCRF_K_HOA_HEIGHT_MAX = 22,    /* hoa_height_max_kernel */

@@ -69,6 +69,11 @@ def _declare(L):
     L.ocrf_rasterize_forward.restype = c_int
     L.ocrf_rasterize_forward.argtypes = ([c_int] * 4 + [c_void_p] * 4 + [c_float] + [c_void_p] * 4 +
                                          [c_int] + [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p])
+    L.ocrf_rasterize_backward.restype = c_int
+    L.ocrf_rasterize_backward.argtypes = ([c_int] * 4 + [c_void_p] * 4 + [c_float] + [c_void_p] * 13 +
+                                          [c_void_p, c_size_t, c_void_p])
+    L.ocrf_rasterize_backward_workspace_bytes.restype = c_size_t
+    L.ocrf_rasterize_backward_workspace_bytes.argtypes = [c_int, c_int]
     L.ocrf_rasterize_workspace_bytes.restype = c_size_t
     L.ocrf_rasterize_workspace_bytes.argtypes = [c_int, c_int]
     L.ocrf_hoa_channel_stats.restype = c_int
@@ -149,6 +154,7 @@ workspace = Workspace()
 
 K_BEV_POOL_FWD, K_BEV_POOL_FIXUP, K_BEV_POOL_INTERVAL, K_BEV_POOL_GRAD, K_BEV_POOL_NCHW = 1, 2, 3, 4, 5
 K_RASTER_PREPROCESS, K_RASTER_BLEND, K_RASTER_GATHER = 10, 11, 12
+K_RASTER_SCAN, K_RASTER_BLEND_BWD, K_RASTER_PRE_BWD = 13, 15, 16
 K_HOA_STATS, K_HOA_MASK_GATE, K_HOA_HEIGHT_MAX, K_HOA_HEIGHT_GATE = 20, 21, 22, 23
 
 

@@ -352,7 +352,22 @@ __device__ __forceinline__ void bitonic_sort_lds(unsigned long long* rec, int n_
   }
 }
 
-template <bool STAMP>
+// Backward mode (BWD): the same traversal, front to back, of exactly the same per-tile sequence;
+// each pixel stops at the contributor index the forward recorded (n_contrib) and evaluates
+//   dL/dalpha_i = sum_ch dL/dC_ch * (c_i T_i - (S_ch - prefix_ch(i)) / (1 - alpha_i)) - T_final/(1-alpha_i) * (bg . dL/dC)
+// with S = C_out - T_final * bg the colour the forward accumulated — algebraically the reference's
+// back-to-front recurrence (backward.cu:470-517) without needing the list reversed.  The nine
+// per-Gaussian partial derivatives are summed over the wave with shuffles, over the workgroup in
+// LDS, and leave as nine float atomics per (tile, record).
+struct BwdArgs {
+  const float* dL_dcolor;      // (V,3,H,W)
+  const float* fwd_color;      // (V,3,H,W) forward output
+  const float* fwd_final_T;    // (V,H,W)
+  const unsigned* fwd_n_contrib;
+  float* acc;                  // (V,P,9): mean2D x,y | conic x,y,z | opacity | colour r,g,b
+};
+
+template <bool STAMP, bool BWD>
 __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
     unsigned long long* __restrict__ stamps,
     int P, int W, int H, int depth_mode, const int* __restrict__ starts,
@@ -360,11 +375,13 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
     const float2* __restrict__ xy, const float4* __restrict__ conic_o,
     const float* __restrict__ colors, const float* __restrict__ bg, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_final_T,
-    unsigned* __restrict__ out_n_contrib, int* __restrict__ status) {
+    unsigned* __restrict__ out_n_contrib, int* __restrict__ status, BwdArgs bw) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long rec[];
   float4* l_a = reinterpret_cast<float4*>(rec + kCapRec);
   float4* l_b = l_a + kStage;
   float2* l_c = reinterpret_cast<float2*>(l_b + kStage);
+  unsigned* l_id = reinterpret_cast<unsigned*>(l_c + kStage);     // BWD only
+  float* l_g = reinterpret_cast<float*>(l_id + kStage);           // BWD only: [kStage][9]
   __shared__ int l_wtot[kScanUnroll * (kBlock / 64)];
   __shared__ int l_ready;
 
@@ -383,6 +400,25 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
   unsigned contributor = 0, last_contributor = 0;
   float C0 = 0.f, C1 = 0.f, C2 = 0.f;
   float D = depth_mode == 0 ? 15.0f : 0.0f;
+  // backward-only per-pixel state
+  float dL0 = 0.f, dL1 = 0.f, dL2 = 0.f, S0 = 0.f, S1 = 0.f, S2 = 0.f, Tfin = 0.f, bgdot = 0.f;
+  unsigned n_last = 0;
+  if constexpr (BWD) {
+    if (inside) {
+      const long npix = (long)W * H;
+      const long pix = (long)pyi * W + pxi;
+      dL0 = bw.dL_dcolor[(v * 3 + 0) * npix + pix];
+      dL1 = bw.dL_dcolor[(v * 3 + 1) * npix + pix];
+      dL2 = bw.dL_dcolor[(v * 3 + 2) * npix + pix];
+      Tfin = bw.fwd_final_T[v * npix + pix];
+      S0 = bw.fwd_color[(v * 3 + 0) * npix + pix] - Tfin * bg[0];
+      S1 = bw.fwd_color[(v * 3 + 1) * npix + pix] - Tfin * bg[1];
+      S2 = bw.fwd_color[(v * 3 + 2) * npix + pix] - Tfin * bg[2];
+      bgdot = bg[0] * dL0 + bg[1] * dL1 + bg[2] * dL2;
+      n_last = bw.fwd_n_contrib[v * npix + pix];
+    }
+    done = done || (n_last == 0);
+  }
 
   bool all_done = false;
   // blend rec[0, n) (sorted) front to back, kStage at a time; sets all_done
@@ -397,6 +433,11 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
         l_a[tid] = make_float4(p.x, p.y, co.x, co.y);
         l_b[tid] = make_float4(co.z, co.w, __uint_as_float((unsigned)(c >> 32)), colors[3 * (long)id]);
         l_c[tid] = make_float2(colors[3 * (long)id + 1], colors[3 * (long)id + 2]);
+        if constexpr (BWD) {
+          l_id[tid] = id;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) l_g[tid * 9 + k] = 0.f;
+        }
       }
       __syncthreads();
       // Branch-free per-record update so that the LDS reads of the next records can be issued
@@ -420,9 +461,44 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
           const float4 b = rb[u];
           const float dx = a.x - pixf_x, dy = a.y - pixf_y;
           const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-          const float alpha = fminf(0.99f, b.y * __expf(power));
+          const float G = __expf(power);
+          const float alpha = fminf(0.99f, b.y * G);
           const bool valid = live && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
           const float test_T = T * (1 - alpha);
+          if constexpr (BWD) {
+            const bool contrib = valid && (contributor <= n_last);
+            const float wgt = contrib ? alpha * T : 0.f;
+            C0 = fmaf(b.w, wgt, C0);                       // prefix including this record
+            C1 = fmaf(rc2[u].x, wgt, C1);
+            C2 = fmaf(rc2[u].y, wgt, C2);
+            const float inv1ma = 1.f / (1.f - alpha);
+            float dL_dalpha = dL0 * (b.w * T - (S0 - C0) * inv1ma) + dL1 * (rc2[u].x * T - (S1 - C1) * inv1ma) +
+                              dL2 * (rc2[u].y * T - (S2 - C2) * inv1ma) - Tfin * inv1ma * bgdot;
+            dL_dalpha = contrib ? dL_dalpha : 0.f;
+            const float dL_dG = b.y * dL_dalpha;
+            const float gdx = G * dx, gdy = G * dy;
+            float g[9];
+            g[0] = dL_dG * (-gdx * a.z - gdy * a.w) * (0.5f * (float)W);
+            g[1] = dL_dG * (-gdy * b.x - gdx * a.w) * (0.5f * (float)H);
+            g[2] = -0.5f * gdx * dx * dL_dG;
+            g[3] = -0.5f * gdx * dy * dL_dG;
+            g[4] = -0.5f * gdy * dy * dL_dG;
+            g[5] = G * dL_dalpha;
+            g[6] = wgt * dL0;
+            g[7] = wgt * dL1;
+            g[8] = wgt * dL2;
+            if (__ballot(contrib) != 0ull) {
+#pragma unroll
+              for (int k = 0; k < 9; ++k) {
+                float r = g[k];
+                for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off);
+                if (lane == 0) atomicAdd(&l_g[(j0 + u) * 9 + k], r);
+              }
+            }
+            T = contrib ? test_T : T;
+            done = done || (live && contributor >= n_last);
+            continue;
+          }
           const bool stop = valid && (test_T < 0.0001f);
           const bool contrib = valid && !stop;
           const float wgt = contrib ? alpha * T : 0.f;
@@ -441,6 +517,17 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
       }
       // every pixel saturated -> stop (forward.cu:304-307)
       all_done = __syncthreads_count(done) == kBlock;
+      if constexpr (BWD) {
+        if (tid < ns) {
+          float* dst = bw.acc + (base + l_id[tid]) * 9;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) {
+            const float r = l_g[tid * 9 + k];
+            if (r != 0.f) atomicAdd(&dst[k], r);
+          }
+        }
+        __syncthreads();
+      }
     }
   };
 
@@ -622,7 +709,7 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
     }
   }
 
-  if (inside) {
+  if (!BWD && inside) {
     const long npix = (long)W * H;
     const long pix = (long)pyi * W + pxi;
     out_final_T[v * npix + pix] = T;
@@ -634,10 +721,151 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Backward of the per-Gaussian stages (backward.cu:144-276 computeCov2DCUDA, :346-396 preprocessCUDA,
+// :278-342 computeCov3D): one thread per Gaussian, views summed in ascending order (deterministic).
+// acc (V,P,9) comes from the backward blend: mean2D x,y | conic x,y,z | opacity | colour r,g,b.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void raster_preprocess_backward_kernel(
+    int P, int n_views, int W, int H, const float* __restrict__ means3D, const float* __restrict__ scales,
+    float scale_modifier, const float* __restrict__ rotations, const Camera* __restrict__ cams,
+    const int* __restrict__ radii, const float* __restrict__ acc, float* __restrict__ dL_dmeans3D,
+    float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales,
+    float* __restrict__ dL_drotations, float* __restrict__ dL_dmeans2D) {
+  const int idx = blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= P) return;
+  const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
+  const float sv[3] = {scale_modifier * scales[3 * idx], scale_modifier * scales[3 * idx + 1],
+                       scale_modifier * scales[3 * idx + 2]};
+  const float r = rotations[4 * idx], x = rotations[4 * idx + 1], y = rotations[4 * idx + 2], z = rotations[4 * idx + 3];
+  const float Rm[3][3] = {
+      {1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+      {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+      {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
+  float Mk[3][3];                                   // M[k][i] = s_k R[i][k]
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Mk[k][i] = sv[k] * Rm[i][k];
+  float V3[3][3];                                   // Sigma = M^T M
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) V3[i][j] = Mk[0][i] * Mk[0][j] + Mk[1][i] * Mk[1][j] + Mk[2][i] * Mk[2][j];
+
+  float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float dcol[3] = {0.f, 0.f, 0.f}, dop = 0.f;
+  for (int v = 0; v < n_views; ++v) {
+    const float* a9 = acc + ((long)v * P + idx) * 9;
+    dop += a9[5];
+    dcol[0] += a9[6]; dcol[1] += a9[7]; dcol[2] += a9[8];
+    if (dL_dmeans2D) {
+      dL_dmeans2D[((long)v * P + idx) * 3 + 0] = a9[0];
+      dL_dmeans2D[((long)v * P + idx) * 3 + 1] = a9[1];
+      dL_dmeans2D[((long)v * P + idx) * 3 + 2] = 0.f;
+    }
+    if (!(radii[(long)v * P + idx] > 0)) continue;
+    const Camera& cam = cams[v];
+    const float* vm = cam.view;
+    const float* pm = cam.proj;
+    const float dcx = a9[2], dcy = a9[3], dcz = a9[4];
+    float t0 = vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12];
+    float t1 = vm[1] * mx + vm[5] * my + vm[9] * mz + vm[13];
+    const float t2 = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
+    const float limx = 1.3f * cam.tanfovx, limy = 1.3f * cam.tanfovy;
+    const float txtz = t0 / t2, tytz = t1 / t2;
+    t0 = fminf(limx, fmaxf(-limx, txtz)) * t2;
+    t1 = fminf(limy, fmaxf(-limy, tytz)) * t2;
+    const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+    const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+    const float h_x = cam.focal_x, h_y = cam.focal_y;
+    const float j00 = h_x / t2, j02 = -(h_x * t0) / (t2 * t2);
+    const float j11 = h_y / t2, j12 = -(h_y * t1) / (t2 * t2);
+    float Tm[2][3], TV[2][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      Tm[0][c] = j00 * vm[4 * c + 0] + j02 * vm[4 * c + 2];
+      Tm[1][c] = j11 * vm[4 * c + 1] + j12 * vm[4 * c + 2];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) TV[i][c] = Tm[i][0] * V3[0][c] + Tm[i][1] * V3[1][c] + Tm[i][2] * V3[2][c];
+    const float a = (TV[0][0] * Tm[0][0] + TV[0][1] * Tm[0][1] + TV[0][2] * Tm[0][2]) + 0.3f;
+    const float b = TV[0][0] * Tm[1][0] + TV[0][1] * Tm[1][1] + TV[0][2] * Tm[1][2];
+    const float c2 = (TV[1][0] * Tm[1][0] + TV[1][1] * Tm[1][1] + TV[1][2] * Tm[1][2]) + 0.3f;
+    const float denom = a * c2 - b * b;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+    if (denom2inv != 0.f) {
+      dL_da = denom2inv * (-c2 * c2 * dcx + 2 * b * c2 * dcy + (denom - a * c2) * dcz);
+      dL_dc = denom2inv * (-a * a * dcz + 2 * a * b * dcy + (denom - a * c2) * dcx);
+      dL_db = denom2inv * 2 * (b * c2 * dcx - (denom + 2 * b * b) * dcy + a * b * dcz);
+      dcov[0] += Tm[0][0] * Tm[0][0] * dL_da + Tm[0][0] * Tm[1][0] * dL_db + Tm[1][0] * Tm[1][0] * dL_dc;
+      dcov[3] += Tm[0][1] * Tm[0][1] * dL_da + Tm[0][1] * Tm[1][1] * dL_db + Tm[1][1] * Tm[1][1] * dL_dc;
+      dcov[5] += Tm[0][2] * Tm[0][2] * dL_da + Tm[0][2] * Tm[1][2] * dL_db + Tm[1][2] * Tm[1][2] * dL_dc;
+      dcov[1] += 2 * Tm[0][0] * Tm[0][1] * dL_da + (Tm[0][0] * Tm[1][1] + Tm[0][1] * Tm[1][0]) * dL_db + 2 * Tm[1][0] * Tm[1][1] * dL_dc;
+      dcov[2] += 2 * Tm[0][0] * Tm[0][2] * dL_da + (Tm[0][0] * Tm[1][2] + Tm[0][2] * Tm[1][0]) * dL_db + 2 * Tm[1][0] * Tm[1][2] * dL_dc;
+      dcov[4] += 2 * Tm[0][2] * Tm[0][1] * dL_da + (Tm[0][1] * Tm[1][2] + Tm[0][2] * Tm[1][1]) * dL_db + 2 * Tm[1][1] * Tm[1][2] * dL_dc;
+    }
+    float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float dT0 = 2 * TV[0][c] * dL_da + TV[1][c] * dL_db;
+      const float dT1 = 2 * TV[1][c] * dL_dc + TV[0][c] * dL_db;
+      dJ00 += vm[4 * c + 0] * dT0;
+      dJ02 += vm[4 * c + 2] * dT0;
+      dJ11 += vm[4 * c + 1] * dT1;
+      dJ12 += vm[4 * c + 2] * dT1;
+    }
+    const float tz = 1.f / t2, tz2 = tz * tz, tz3 = tz2 * tz;
+    const float dtx = x_grad_mul * -h_x * tz2 * dJ02;
+    const float dty = y_grad_mul * -h_y * tz2 * dJ12;
+    const float dtz = -h_x * tz2 * dJ00 - h_y * tz2 * dJ11 + (2 * h_x * t0) * tz3 * dJ02 + (2 * h_y * t1) * tz3 * dJ12;
+    dmean[0] += vm[0] * dtx + vm[1] * dty + vm[2] * dtz;
+    dmean[1] += vm[4] * dtx + vm[5] * dty + vm[6] * dtz;
+    dmean[2] += vm[8] * dtx + vm[9] * dty + vm[10] * dtz;
+    // screen-space mean -> 3D mean through the full projection (backward.cu:365-383)
+    const float hw = pm[3] * mx + pm[7] * my + pm[11] * mz + pm[15];
+    const float m_w = 1.0f / (hw + 0.0000001f);
+    const float mul1 = (pm[0] * mx + pm[4] * my + pm[8] * mz + pm[12]) * m_w * m_w;
+    const float mul2 = (pm[1] * mx + pm[5] * my + pm[9] * mz + pm[13]) * m_w * m_w;
+    const float g2x = a9[0], g2y = a9[1];
+    dmean[0] += (pm[0] * m_w - pm[3] * mul1) * g2x + (pm[1] * m_w - pm[3] * mul2) * g2y;
+    dmean[1] += (pm[4] * m_w - pm[7] * mul1) * g2x + (pm[5] * m_w - pm[7] * mul2) * g2y;
+    dmean[2] += (pm[8] * m_w - pm[11] * mul1) * g2x + (pm[9] * m_w - pm[11] * mul2) * g2y;
+  }
+  dL_dopacity[idx] = dop;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    dL_dcolors[3 * idx + i] = dcol[i];
+    dL_dmeans3D[3 * idx + i] = dmean[i];
+  }
+  // Sigma = M^T M -> scales and (un-normalised) quaternion (backward.cu:278-342)
+  const float dS[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]}, {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
+                          {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+  float dM[3][3], Q[3][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dM[k][i] = 2.0f * (Mk[k][0] * dS[0][i] + Mk[k][1] * dS[1][i] + Mk[k][2] * dS[2][i]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) dL_dscales[3 * idx + k] = Rm[0][k] * dM[k][0] + Rm[1][k] * dM[k][1] + Rm[2][k] * dM[k][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Q[i][k] = sv[k] * dM[k][i];
+  dL_drotations[4 * idx + 0] = 2 * z * (Q[1][0] - Q[0][1]) + 2 * y * (Q[0][2] - Q[2][0]) + 2 * x * (Q[2][1] - Q[1][2]);
+  dL_drotations[4 * idx + 1] = 2 * y * (Q[0][1] + Q[1][0]) + 2 * z * (Q[0][2] + Q[2][0]) + 2 * r * (Q[2][1] - Q[1][2]) - 4 * x * (Q[2][2] + Q[1][1]);
+  dL_drotations[4 * idx + 2] = 2 * x * (Q[0][1] + Q[1][0]) + 2 * r * (Q[0][2] - Q[2][0]) + 2 * z * (Q[2][1] + Q[1][2]) - 4 * y * (Q[2][2] + Q[0][0]);
+  dL_drotations[4 * idx + 3] = 2 * r * (Q[1][0] - Q[0][1]) + 2 * x * (Q[0][2] + Q[2][0]) + 2 * y * (Q[2][1] + Q[1][2]) - 4 * z * (Q[1][1] + Q[0][0]);
+}
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct RasterWs {
-  size_t keys, rects, xy, conic_o, b_rect, b_comp, hist, starts, cursor, status, total;
+  size_t keys, rects, xy, conic_o, b_rect, b_comp, hist, starts, cursor, status, total, acc, radii, bwd_total;
 };
 
 inline void raster_layout(int P, int n_views, RasterWs* ws) {
@@ -655,6 +883,9 @@ inline void raster_layout(int P, int n_views, RasterWs* ws) {
   ws->cursor = take((size_t)n_views * kBuckets * sizeof(int));
   ws->status = take(256);
   ws->total = off;
+  ws->acc = take(n * 9 * sizeof(float));          // backward only
+  ws->radii = take(n * sizeof(int));
+  ws->bwd_total = off;
 }
 
 }  // namespace
@@ -732,18 +963,89 @@ int ocrf_rasterize_forward(int P, int n_views, int H, int W, const float* means3
   if (e != hipSuccess) return (int)e;
   const size_t lds = (size_t)kCapRec * 8 + (size_t)kStage * (16 + 16 + 8);
   if (g_stamps) {
-    hipLaunchKernelGGL(raster_blend_kernel<true>, dim3(gx, gy, n_views), dim3(kBlock), lds, stream,
+    hipLaunchKernelGGL((raster_blend_kernel<true, false>), dim3(gx, gy, n_views), dim3(kBlock), lds, stream,
                        g_stamps, P, W, H, depth_mode, static_cast<const int*>(starts),
                        static_cast<const Rect*>(b_rect), static_cast<const unsigned long long*>(b_comp),
                        static_cast<const float2*>(xy), static_cast<const float4*>(conic_o), colors, bg,
-                       out_color, out_depth, out_final_T, out_n_contrib, st);
+                       out_color, out_depth, out_final_T, out_n_contrib, st, BwdArgs{});
     return (int)hipGetLastError();
   }
-  ocrf::launch(OCRF_K_RASTER_BLEND, raster_blend_kernel<false>, dim3(gx, gy, n_views), dim3(kBlock), lds,
+  ocrf::launch(OCRF_K_RASTER_BLEND, raster_blend_kernel<false, false>, dim3(gx, gy, n_views), dim3(kBlock), lds,
                stream, (unsigned long long*)nullptr, P, W, H, depth_mode, static_cast<const int*>(starts),
                static_cast<const Rect*>(b_rect), static_cast<const unsigned long long*>(b_comp),
                static_cast<const float2*>(xy), static_cast<const float4*>(conic_o), colors, bg,
-               out_color, out_depth, out_final_T, out_n_contrib, st);
+               out_color, out_depth, out_final_T, out_n_contrib, st, BwdArgs{});
+  return (int)hipGetLastError();
+}
+
+size_t ocrf_rasterize_backward_workspace_bytes(int P, int n_views) {
+  if (P <= 0 || n_views <= 0) return 0;
+  RasterWs ws;
+  raster_layout(P, n_views, &ws);
+  return ws.bwd_total;
+}
+
+int ocrf_rasterize_backward(int P, int n_views, int H, int W, const float* means3D, const float* colors,
+                            const float* opacities, const float* scales, float scale_modifier,
+                            const float* rotations, const float* cameras, const float* bg,
+                            const float* fwd_color, const float* fwd_final_T, const uint32_t* fwd_n_contrib,
+                            const float* dL_dcolor, float* dL_dmeans3D, float* dL_dcolors,
+                            float* dL_dopacity, float* dL_dscales, float* dL_drotations,
+                            float* dL_dmeans2D, void* workspace, size_t workspace_bytes,
+                            ocrf_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (P <= 0 || n_views <= 0 || H <= 0 || W <= 0 || !means3D || !colors || !opacities || !scales || !rotations ||
+      !cameras || !bg || !fwd_color || !fwd_final_T || !fwd_n_contrib || !dL_dcolor || !dL_dmeans3D || !dL_dcolors ||
+      !dL_dopacity || !dL_dscales || !dL_drotations)
+    return (int)hipErrorInvalidValue;
+  const int gx = (W + kTileX - 1) / kTileX, gy = (H + kTileY - 1) / kTileY;
+  if (gx > 65535 || gy > 65535) return (int)hipErrorInvalidValue;
+  RasterWs ws;
+  raster_layout(P, n_views, &ws);
+  if (!workspace || workspace_bytes < ws.bwd_total) return (int)hipErrorInvalidValue;
+  char* base = static_cast<char*>(workspace);
+  auto* keys = reinterpret_cast<unsigned*>(base + ws.keys);
+  auto* rects = reinterpret_cast<Rect*>(base + ws.rects);
+  auto* xy = reinterpret_cast<float2*>(base + ws.xy);
+  auto* conic_o = reinterpret_cast<float4*>(base + ws.conic_o);
+  auto* b_rect = reinterpret_cast<Rect*>(base + ws.b_rect);
+  auto* b_comp = reinterpret_cast<unsigned long long*>(base + ws.b_comp);
+  auto* hist = reinterpret_cast<int*>(base + ws.hist);
+  auto* starts = reinterpret_cast<int*>(base + ws.starts);
+  auto* cursor = reinterpret_cast<int*>(base + ws.cursor);
+  int* st = reinterpret_cast<int*>(base + ws.status);
+  auto* acc = reinterpret_cast<float*>(base + ws.acc);
+  auto* radii = reinterpret_cast<int*>(base + ws.radii);
+  const Camera* cams = reinterpret_cast<const Camera*>(cameras);
+  // rebuild the bucket-ordered lists exactly as the forward did (same kernels, same inputs)
+  hipError_t e = hipMemsetAsync(hist, 0, (size_t)n_views * kBuckets * sizeof(int), stream);
+  if (e == hipSuccess) e = hipMemsetAsync(acc, 0, (size_t)n_views * P * 9 * sizeof(float), stream);
+  if (e != hipSuccess) return (int)e;
+  const dim3 pgrid((P + kChunk - 1) / kChunk, n_views);
+  hipLaunchKernelGGL(raster_preprocess_kernel, pgrid, dim3(kBlock), 0, stream, P, W, H, gx, gy, means3D, opacities,
+                     scales, scale_modifier, rotations, (const float*)nullptr, cams, keys, rects, xy, conic_o, radii,
+                     (unsigned*)nullptr, hist);
+  hipLaunchKernelGGL(raster_bucket_scan_kernel, dim3(n_views), dim3(kBlock), 0, stream, static_cast<const int*>(hist),
+                     starts, cursor);
+  hipLaunchKernelGGL(raster_scatter_kernel, pgrid, dim3(kBlock), 0, stream, P, static_cast<const unsigned*>(keys),
+                     static_cast<const Rect*>(rects), cursor, b_rect, b_comp);
+  e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  BwdArgs bw;
+  bw.dL_dcolor = dL_dcolor; bw.fwd_color = fwd_color; bw.fwd_final_T = fwd_final_T;
+  bw.fwd_n_contrib = fwd_n_contrib; bw.acc = acc;
+  const size_t lds = (size_t)kCapRec * 8 + (size_t)kStage * (16 + 16 + 8 + 4 + 36);
+  ocrf::launch(OCRF_K_RASTER_BLEND_BWD, raster_blend_kernel<false, true>, dim3(gx, gy, n_views), dim3(kBlock), lds,
+               stream, (unsigned long long*)nullptr, P, W, H, 0, static_cast<const int*>(starts),
+               static_cast<const Rect*>(b_rect), static_cast<const unsigned long long*>(b_comp),
+               static_cast<const float2*>(xy), static_cast<const float4*>(conic_o), colors, bg, (float*)nullptr,
+               (float*)nullptr, (float*)nullptr, (unsigned*)nullptr, st, bw);
+  e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  ocrf::launch(OCRF_K_RASTER_PRE_BWD, raster_preprocess_backward_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock),
+               0, stream, P, n_views, W, H, means3D, scales, scale_modifier, rotations, cams,
+               static_cast<const int*>(radii), static_cast<const float*>(acc), dL_dmeans3D, dL_dcolors, dL_dopacity,
+               dL_dscales, dL_drotations, dL_dmeans2D);
   return (int)hipGetLastError();
 }
 

@@ -19,9 +19,12 @@ depth (1,H,W))``
 Beyond the reference: ``rasterize_views`` renders a batch of cameras over one Gaussian set in a
 single launch sequence and also returns ``final_T`` (1 - accumulated opacity) and ``n_contrib``.
 
-Compute: ``csrc/rasterize.hip`` through the C ABI (``ocrf_rasterize_forward``).  Forward only in
-this round: the backward raises.  SH colours are outside the path OcRFDet
-uses (``shs=None`` at the call site) and raise ``NotImplementedError``.
+Compute: ``csrc/rasterize.hip`` through the C ABI (``ocrf_rasterize_forward`` /
+``ocrf_rasterize_backward``).  The backward covers what the fork's does — the colour output w.r.t.
+means3D, means2D (screen-space, for densification statistics), colours, opacities, scales, rotations;
+depth has no backward in the fork either (diff-gaussian-rasterization-w-depth/README.md:13).
+``cov3D_precomp`` is forward-only here.  SH colours are outside the path OcRFDet uses (``shs=None``
+at the call site) and raise ``NotImplementedError``.
 """
 import ctypes
 from typing import NamedTuple
@@ -31,7 +34,8 @@ import torch.nn as nn
 
 from . import _lib
 
-__all__ = ['GaussianRasterizationSettings', 'GaussianRasterizer', 'rasterize_gaussians', 'rasterize_views']
+__all__ = ['GaussianRasterizationSettings', 'GaussianRasterizer', 'rasterize_gaussians', 'rasterize_views',
+           'rasterize_views_backward', 'rasterize_views_autograd']
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -53,6 +57,62 @@ def _f32c(t):
     return t.detach().contiguous().float()
 
 
+def _pack_cameras(viewmatrices, projmatrices, tanfovx, tanfovy, H, W, dev):
+    """(V,36) float rows: view16 | proj16 | tanfovx | tanfovy | focal_x | focal_y."""
+    vm = _f32c(viewmatrices).reshape(-1, 16)
+    pm = _f32c(projmatrices).reshape(-1, 16)
+    V = vm.size(0)
+    tfx = torch.as_tensor(tanfovx, dtype=torch.float64).reshape(-1).expand(V) if not torch.is_tensor(tanfovx) \
+        else tanfovx.detach().double().reshape(-1).cpu().expand(V)
+    tfy = torch.as_tensor(tanfovy, dtype=torch.float64).reshape(-1).expand(V) if not torch.is_tensor(tanfovy) \
+        else tanfovy.detach().double().reshape(-1).cpu().expand(V)
+    # focal = size / (2 * tan) evaluated in float32 like rasterizer_impl.cu:222-223
+    tf = torch.stack((tfx, tfy), 1).float()
+    focal = torch.stack((torch.tensor(float(W)) / (2.0 * tf[:, 0]), torch.tensor(float(H)) / (2.0 * tf[:, 1])), 1)
+    return torch.cat((vm, pm, tf.to(dev), focal.float().to(dev)), 1).contiguous()
+
+
+def rasterize_views_backward(grad_color, fwd, means3D, colors, opacities, scales, rotations, viewmatrices,
+                             projmatrices, tanfovx, tanfovy, image_height, image_width, bg, scale_modifier=1.0,
+                             want_means2D=False):
+    """Backward of ``rasterize_views``' colour output, summed over the views.  ``fwd`` is the dict
+    ``rasterize_views`` returned for the same inputs.  Returns a dict ``means3D`` (P,3), ``colors``
+    (P,3), ``opacities`` (P,1), ``scales`` (P,3), ``rotations`` (P,4) [, ``means2D`` (V,P,3)]."""
+    _lib.require_cuda(means3D, colors, opacities, scales, rotations, grad_color)
+    dev = means3D.device
+    P = means3D.size(0)
+    H, W = int(image_height), int(image_width)
+    cams = _pack_cameras(viewmatrices, projmatrices, tanfovx, tanfovy, H, W, dev)
+    V = cams.size(0)
+    g = _f32c(grad_color).reshape(V, 3, H, W)
+    means3D, colors, opac = _f32c(means3D), _f32c(colors), _f32c(opacities).reshape(-1)
+    sc, rot, bg = _f32c(scales), _f32c(rotations), _f32c(bg).reshape(3)
+    fc, ft, fn = fwd['color'].contiguous(), fwd['final_T'].contiguous(), fwd['n_contrib'].contiguous()
+    if tuple(fc.shape) != (V, 3, H, W) or tuple(ft.shape) != (V, H, W) or tuple(fn.shape) != (V, H, W):
+        raise RuntimeError('rasterize_views_backward: forward outputs do not match the view batch')
+    out = dict(means3D=torch.empty(P, 3, device=dev), colors=torch.empty(P, 3, device=dev),
+               opacities=torch.empty(P, 1, device=dev), scales=torch.empty(P, 3, device=dev),
+               rotations=torch.empty(P, 4, device=dev))
+    m2d = torch.empty(V, P, 3, device=dev) if want_means2D else None
+    if P == 0:
+        if m2d is not None:
+            out['means2D'] = m2d
+        return out
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        need = L.ocrf_rasterize_backward_workspace_bytes(P, V)
+        ws = _lib.workspace.get(dev, need, 'raster')
+        _lib.check(L.ocrf_rasterize_backward(
+            P, V, H, W, _lib.ptr(means3D), _lib.ptr(colors), _lib.ptr(opac), _lib.ptr(sc),
+            ctypes.c_float(scale_modifier), _lib.ptr(rot), _lib.ptr(cams), _lib.ptr(bg), _lib.ptr(fc), _lib.ptr(ft),
+            _lib.ptr(fn), _lib.ptr(g), _lib.ptr(out['means3D']), _lib.ptr(out['colors']), _lib.ptr(out['opacities']),
+            _lib.ptr(out['scales']), _lib.ptr(out['rotations']), _lib.ptr(m2d), _lib.ptr(ws),
+            ctypes.c_size_t(ws.numel()), _lib.stream_ptr(dev)), 'ocrf_rasterize_backward')
+    if m2d is not None:
+        out['means2D'] = m2d
+    return out
+
+
 def rasterize_views(means3D, colors, opacities, scales, rotations, viewmatrices, projmatrices,
                     tanfovx, tanfovy, image_height, image_width, bg, scale_modifier=1.0,
                     cov3D_precomp=None, depth_mode='median', want_tiles_touched=False):
@@ -67,18 +127,9 @@ def rasterize_views(means3D, colors, opacities, scales, rotations, viewmatrices,
         raise RuntimeError('means3D must have dimensions (num_points, 3)')     # rasterize_points.cu:57-59
     dev = means3D.device
     P = means3D.size(0)
-    vm = _f32c(viewmatrices).reshape(-1, 16)
-    pm = _f32c(projmatrices).reshape(-1, 16)
-    V = vm.size(0)
     H, W = int(image_height), int(image_width)
-    tfx = torch.as_tensor(tanfovx, dtype=torch.float64).reshape(-1).expand(V) if not torch.is_tensor(tanfovx) \
-        else tanfovx.detach().double().reshape(-1).cpu().expand(V)
-    tfy = torch.as_tensor(tanfovy, dtype=torch.float64).reshape(-1).expand(V) if not torch.is_tensor(tanfovy) \
-        else tanfovy.detach().double().reshape(-1).cpu().expand(V)
-    # focal = size / (2 * tan) evaluated in float32 like rasterizer_impl.cu:222-223
-    tf = torch.stack((tfx, tfy), 1).float()
-    focal = torch.stack((torch.tensor(float(W)) / (2.0 * tf[:, 0]), torch.tensor(float(H)) / (2.0 * tf[:, 1])), 1)
-    cams = torch.cat((vm, pm, tf.to(dev), focal.float().to(dev)), 1).contiguous()        # (V,36)
+    cams = _pack_cameras(viewmatrices, projmatrices, tanfovx, tanfovy, H, W, dev)         # (V,36)
+    V = cams.size(0)
     means3D, colors, opac = _f32c(means3D), _f32c(colors), _f32c(opacities).reshape(-1)
     if cov3D_precomp is not None and cov3D_precomp.numel() > 0:
         cov, sc, rot = _f32c(cov3D_precomp), None, None
@@ -122,13 +173,56 @@ class _RasterizeGaussians(torch.autograd.Function):
                               cov3Ds_precomp if cov3Ds_precomp is not None and cov3Ds_precomp.numel() else None)
         color, radii, depth = out['color'][0], out['radii'][0], out['depth'][0]
         ctx.mark_non_differentiable(radii, depth)
+        ctx.raster_settings = rs
+        ctx.has_cov = cov3Ds_precomp is not None and cov3Ds_precomp.numel() > 0
+        ctx.fwd = {k: out[k] for k in ('color', 'final_T', 'n_contrib')}
+        if not ctx.has_cov:
+            ctx.save_for_backward(means3D, colors_precomp, opacities, scales, rotations)
         return color, radii, depth
 
     @staticmethod
     def backward(ctx, grad_color, _r, _d):
-        raise NotImplementedError(
-            'ocrfdet_amd rasteriser: backward not built yet (SURVEY.md section 8(f) rank 1); the '
-            'w-depth fork has no depth backward either (diff-gaussian-rasterization-w-depth/README.md:13)')
+        """Gradient tuple in the reference's order (diff_gaussian_rasterization/__init__.py:96-149):
+        means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings."""
+        if ctx.has_cov:
+            raise NotImplementedError('ocrfdet_amd rasteriser: backward with cov3D_precomp is not built '
+                                      '(OcRFDet passes scales and rotations)')
+        rs = ctx.raster_settings
+        means3D, colors, opacities, scales, rotations = ctx.saved_tensors
+        g = rasterize_views_backward(grad_color.unsqueeze(0), ctx.fwd, means3D, colors, opacities, scales, rotations,
+                                     rs.viewmatrix.reshape(1, 4, 4), rs.projmatrix.reshape(1, 4, 4),
+                                     float(rs.tanfovx), float(rs.tanfovy), rs.image_height, rs.image_width, rs.bg,
+                                     float(rs.scale_modifier), want_means2D=True)
+        return (g['means3D'], g['means2D'][0], None, g['colors'], g['opacities'].reshape(opacities.shape),
+                g['scales'], g['rotations'], None, None)
+
+
+class _RasterizeViews(torch.autograd.Function):
+    """Differentiable batched render: colour (V,3,H,W) w.r.t. the Gaussian parameters, gradients
+    summed over the views in one backward launch sequence."""
+
+    @staticmethod
+    def forward(ctx, means3D, colors, opacities, scales, rotations, cam):
+        out = rasterize_views(means3D, colors, opacities, scales, rotations, *cam)
+        ctx.cam = cam
+        ctx.fwd = {k: out[k] for k in ('color', 'final_T', 'n_contrib')}
+        ctx.save_for_backward(means3D, colors, opacities, scales, rotations)
+        ctx.mark_non_differentiable(out['depth'], out['radii'], out['final_T'])
+        return out['color'], out['depth'], out['final_T'], out['radii']
+
+    @staticmethod
+    def backward(ctx, grad_color, _d, _t, _r):
+        means3D, colors, opacities, scales, rotations = ctx.saved_tensors
+        g = rasterize_views_backward(grad_color, ctx.fwd, means3D, colors, opacities, scales, rotations, *ctx.cam)
+        return g['means3D'], g['colors'], g['opacities'].reshape(opacities.shape), g['scales'], g['rotations'], None
+
+
+def rasterize_views_autograd(means3D, colors, opacities, scales, rotations, viewmatrices, projmatrices, tanfovx,
+                             tanfovy, image_height, image_width, bg, scale_modifier=1.0):
+    """``rasterize_views`` with autograd through the colour output: returns (color (V,3,H,W),
+    depth (V,1,H,W), final_T (V,H,W), radii (V,P))."""
+    cam = (viewmatrices, projmatrices, tanfovx, tanfovy, image_height, image_width, bg, scale_modifier)
+    return _RasterizeViews.apply(means3D, colors, opacities, scales, rotations, cam)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,

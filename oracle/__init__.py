@@ -154,3 +154,33 @@ def rasterize_forward(means3D, colors_precomp, opacities, scales, rotations, vie
         raise MemoryError("oracle_rasterize_forward: allocation failed")
     out["num_rendered"] = int(R)
     return out
+
+
+def rasterize_backward(grad_color, means3D, colors_precomp, opacities, scales, rotations, viewmatrix,
+                       projmatrix, tanfovx, tanfovy, image_height, image_width, bg, scale_modifier=1.0):
+    """Backward of the colour output of ``rasterize_forward`` w.r.t. means3D, colours, opacities,
+    scales, rotations (rasterize_points.cu:117-196 -> rasterizer_impl.cu:338-434 ->
+    cuda_rasterizer/backward.cu).  ``grad_color`` is (3,H,W).  Returns a dict with
+    ``means3D`` (P,3), ``means2D`` (P,3), ``colors`` (P,3), ``opacities`` (P,1), ``scales`` (P,3),
+    ``rotations`` (P,4), ``cov3D`` (P,6)."""
+    means3D, colors, opac = _f32(means3D), _f32(colors_precomp), _f32(opacities).reshape(-1)
+    scales, rots = _f32(scales), _f32(rotations)
+    vm, pm, bg = _f32(viewmatrix).reshape(16), _f32(projmatrix).reshape(16), _f32(bg).reshape(3)
+    g = _f32(grad_color)
+    P = means3D.shape[0]
+    H, W = int(image_height), int(image_width)
+    assert g.shape == (3, H, W)
+    out = dict(means2D=np.zeros((P, 3), np.float32), colors=np.zeros((P, 3), np.float32),
+               opacities=np.zeros((P, 1), np.float32), means3D=np.zeros((P, 3), np.float32),
+               cov3D=np.zeros((P, 6), np.float32), scales=np.zeros((P, 3), np.float32),
+               rotations=np.zeros((P, 4), np.float32))
+    L = lib()
+    L.oracle_rasterize_backward.restype = ctypes.c_long
+    R = L.oracle_rasterize_backward(
+        ctypes.c_int(P), _p(bg), ctypes.c_int(W), ctypes.c_int(H), _p(means3D), _p(colors), _p(opac), _p(scales),
+        ctypes.c_float(scale_modifier), _p(rots), _p(vm), _p(pm), ctypes.c_float(tanfovx), ctypes.c_float(tanfovy),
+        _p(g), _p(out['means2D']), _p(out['colors']), _p(out['opacities']), _p(out['means3D']), _p(out['cov3D']),
+        _p(out['scales']), _p(out['rotations']))
+    if R < 0:
+        raise MemoryError('oracle_rasterize_backward: allocation failed')
+    return out

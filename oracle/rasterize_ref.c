@@ -149,14 +149,17 @@ static uint32_t getHigherMsb(uint32_t n)
  *  defined where radii>0, exactly as in the reference, but are zero-initialised here).
  * Returns num_rendered (R), or -1 on allocation failure.
  */
-long oracle_rasterize_forward(int P, const float *background, int W, int H, const float *means3D,
-                              const float *colors_precomp, const float *opacities,
-                              const float *scales, float scale_modifier, const float *rotations,
-                              const float *viewmatrix, const float *projmatrix, float tan_fovx,
-                              float tan_fovy, int depth_mode, float *out_color, float *out_depth,
-                              float *out_final_T, uint32_t *out_n_contrib, int *radii,
-                              float *means2D, float *depths, float *conic_opacity,
-                              uint32_t *tiles_touched)
+/* Sorted tile lists kept by the forward for the backward (NULL = do not keep). */
+typedef struct { kv_t *kv; uint32_t *ranges; long R; float *cov3D; } keep_t;
+
+static long forward_impl(int P, const float *background, int W, int H, const float *means3D,
+                         const float *colors_precomp, const float *opacities,
+                         const float *scales, float scale_modifier, const float *rotations,
+                         const float *viewmatrix, const float *projmatrix, float tan_fovx,
+                         float tan_fovy, int depth_mode, float *out_color, float *out_depth,
+                         float *out_final_T, uint32_t *out_n_contrib, int *radii,
+                         float *means2D, float *depths, float *conic_opacity,
+                         uint32_t *tiles_touched, keep_t *keep)
 {
     const float focal_y = (float)H / (2.0f * tan_fovy); /* rasterizer_impl.cu:222-223 */
     const float focal_x = (float)W / (2.0f * tan_fovx);
@@ -186,7 +189,8 @@ long oracle_rasterize_forward(int P, const float *background, int W, int H, cons
         transformPoint4x4(p_orig, projmatrix, p_hom);
         const float p_w = 1.0f / (p_hom[3] + 0.0000001f);
         const float p_proj[2] = {p_hom[0] * p_w, p_hom[1] * p_w};
-        float cov3D[6];
+        float cov3D_local[6];
+        float *cov3D = keep ? keep->cov3D + 6 * (size_t)idx : cov3D_local;
         computeCov3D(scales + 3 * (size_t)idx, scale_modifier, rotations + 4 * (size_t)idx, cov3D);
         float cov[3];
         computeCov2D(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, viewmatrix, cov);
@@ -307,7 +311,240 @@ long oracle_rasterize_forward(int P, const float *background, int W, int H, cons
                 out_depth[pix_id] = D;
             }
     }
-    free(ranges);
-    free(kv);
+    if (keep) { keep->kv = kv; keep->ranges = ranges; keep->R = R; }
+    else { free(ranges); free(kv); }
+    return R;
+}
+
+long oracle_rasterize_forward(int P, const float *background, int W, int H, const float *means3D,
+                              const float *colors_precomp, const float *opacities,
+                              const float *scales, float scale_modifier, const float *rotations,
+                              const float *viewmatrix, const float *projmatrix, float tan_fovx,
+                              float tan_fovy, int depth_mode, float *out_color, float *out_depth,
+                              float *out_final_T, uint32_t *out_n_contrib, int *radii,
+                              float *means2D, float *depths, float *conic_opacity,
+                              uint32_t *tiles_touched)
+{
+    return forward_impl(P, background, W, H, means3D, colors_precomp, opacities, scales, scale_modifier,
+                        rotations, viewmatrix, projmatrix, tan_fovx, tan_fovy, depth_mode, out_color,
+                        out_depth, out_final_T, out_n_contrib, radii, means2D, depths, conic_opacity,
+                        tiles_touched, NULL);
+}
+
+/*
+ * Backward of the colour output (the w-depth fork has no depth backward, README:13), restating
+ * cuda_rasterizer/backward.cu: renderCUDA :399-557 (back-to-front per pixel, the reference's
+ * atomicAdds become sequential double-precision sums here), computeCov2DCUDA :144-276,
+ * preprocessCUDA :346-396 with computeCov3D :278-342; host glue rasterizer_impl.cu:338-434,
+ * rasterize_points.cu:117-196.  The forward is re-run to obtain the sorted tile lists.
+ * Outputs (caller-allocated): dL_dmeans2D (P,3) [z unused, = 0], dL_dcolors (P,3), dL_dopacity (P),
+ * dL_dmeans3D (P,3), dL_dcov3D (P,6), dL_dscales (P,3), dL_drotations (P,4).
+ */
+long oracle_rasterize_backward(int P, const float *background, int W, int H, const float *means3D,
+                               const float *colors, const float *opacities, const float *scales,
+                               float scale_modifier, const float *rotations, const float *viewmatrix,
+                               const float *projmatrix, float tan_fovx, float tan_fovy,
+                               const float *dL_dpixels, float *dL_dmeans2D, float *dL_dcolors,
+                               float *dL_dopacity, float *dL_dmeans3D, float *dL_dcov3D,
+                               float *dL_dscales, float *dL_drotations)
+{
+    const long npix = (long)W * H;
+    memset(dL_dmeans2D, 0, sizeof(float) * 3 * (size_t)P);
+    memset(dL_dcolors, 0, sizeof(float) * 3 * (size_t)P);
+    memset(dL_dopacity, 0, sizeof(float) * (size_t)P);
+    memset(dL_dmeans3D, 0, sizeof(float) * 3 * (size_t)P);
+    memset(dL_dcov3D, 0, sizeof(float) * 6 * (size_t)P);
+    memset(dL_dscales, 0, sizeof(float) * 3 * (size_t)P);
+    memset(dL_drotations, 0, sizeof(float) * 4 * (size_t)P);
+    if (P == 0) return 0;
+    float *out_color = malloc(sizeof(float) * 3 * npix), *out_depth = malloc(sizeof(float) * npix);
+    float *final_T = malloc(sizeof(float) * npix);
+    uint32_t *n_contrib = malloc(sizeof(uint32_t) * npix), *touched = malloc(sizeof(uint32_t) * (size_t)P);
+    int *radii = malloc(sizeof(int) * (size_t)P);
+    float *means2D = malloc(sizeof(float) * 2 * (size_t)P), *depths = malloc(sizeof(float) * (size_t)P);
+    float *conic_o = malloc(sizeof(float) * 4 * (size_t)P);
+    keep_t keep = {0};
+    keep.cov3D = calloc((size_t)P * 6, sizeof(float));
+    const long R = forward_impl(P, background, W, H, means3D, colors, opacities, scales, scale_modifier, rotations,
+                                viewmatrix, projmatrix, tan_fovx, tan_fovy, 0, out_color, out_depth, final_T,
+                                n_contrib, radii, means2D, depths, conic_o, touched, &keep);
+    if (R < 0) return -1;
+    const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+    /* per-Gaussian double accumulators: mean2D (2), conic (3: x, y, w), opacity, colour (3) */
+    double *acc = calloc((size_t)P * 9, sizeof(double));
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;                       /* :452-453 */
+    /* ---- renderCUDA backward, :399-557 (tiles serial: accumulators are shared) ---- */
+    for (int tile = 0; tile < gx * gy; tile++) {
+        const int ty = tile / gx, tx = tile % gx;
+        const uint32_t r0 = keep.ranges[2 * tile], r1 = keep.ranges[2 * tile + 1];
+        for (int ly = 0; ly < BLOCK_Y; ly++)
+            for (int lx = 0; lx < BLOCK_X; lx++) {
+                const int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+                if (px >= W || py >= H) continue;
+                const long pix_id = (long)W * py + px;
+                const float T_final = final_T[pix_id];
+                float T = T_final;
+                const uint32_t last_contributor = n_contrib[pix_id];
+                float accum_rec[3] = {0, 0, 0}, last_color[3] = {0, 0, 0}, last_alpha = 0.f;
+                const float dL_dpixel[3] = {dL_dpixels[pix_id], dL_dpixels[npix + pix_id], dL_dpixels[2 * npix + pix_id]};
+                uint32_t contributor = r1 - r0;
+                for (long k = (long)r1 - 1; k >= (long)r0; k--) {               /* back to front */
+                    contributor--;
+                    if (contributor >= last_contributor) continue;
+                    const uint32_t id = keep.kv[k].val;
+                    const float dx = means2D[2 * (size_t)id] - (float)px, dy = means2D[2 * (size_t)id + 1] - (float)py;
+                    const float *co = conic_o + 4 * (size_t)id;
+                    const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    if (power > 0.0f) continue;
+                    const float G = expf(power);
+                    const float alpha = fminf_(0.99f, co[3] * G);
+                    if (alpha < 1.0f / 255.0f) continue;
+                    T = T / (1.f - alpha);
+                    const float dchannel_dcolor = alpha * T;
+                    float dL_dalpha = 0.0f;
+                    for (int ch = 0; ch < 3; ch++) {
+                        const float c = colors[(size_t)id * 3 + ch];
+                        accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+                        last_color[ch] = c;
+                        dL_dalpha += (c - accum_rec[ch]) * dL_dpixel[ch];
+                        acc[(size_t)id * 9 + 6 + ch] += (double)(dchannel_dcolor * dL_dpixel[ch]);
+                    }
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    float bg_dot = 0;
+                    for (int i = 0; i < 3; i++) bg_dot += background[i] * dL_dpixel[i];
+                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                    const float dL_dG = co[3] * dL_dalpha;
+                    const float gdx = G * dx, gdy = G * dy;
+                    const float dG_ddelx = -gdx * co[0] - gdy * co[1];
+                    const float dG_ddely = -gdy * co[2] - gdx * co[1];
+                    acc[(size_t)id * 9 + 0] += (double)(dL_dG * dG_ddelx * ddelx_dx);
+                    acc[(size_t)id * 9 + 1] += (double)(dL_dG * dG_ddely * ddely_dy);
+                    acc[(size_t)id * 9 + 2] += (double)(-0.5f * gdx * dx * dL_dG);
+                    acc[(size_t)id * 9 + 3] += (double)(-0.5f * gdx * dy * dL_dG);
+                    acc[(size_t)id * 9 + 4] += (double)(-0.5f * gdy * dy * dL_dG);
+                    acc[(size_t)id * 9 + 5] += (double)(G * dL_dalpha);
+                }
+            }
+    }
+    const float h_x = (float)W / (2.0f * tan_fovx), h_y = (float)H / (2.0f * tan_fovy);
+#pragma omp parallel for schedule(static)
+    for (int idx = 0; idx < P; idx++) {
+        const double *a9 = acc + (size_t)idx * 9;
+        dL_dmeans2D[3 * (size_t)idx] = (float)a9[0];
+        dL_dmeans2D[3 * (size_t)idx + 1] = (float)a9[1];
+        dL_dopacity[idx] = (float)a9[5];
+        for (int ch = 0; ch < 3; ch++) dL_dcolors[3 * (size_t)idx + ch] = (float)a9[6 + ch];
+        if (!(radii[idx] > 0)) continue;
+        /* ---- computeCov2DCUDA, :144-276 ---- */
+        const float *cov3D = keep.cov3D + 6 * (size_t)idx;
+        const float *mean = means3D + 3 * (size_t)idx;
+        const float dcx = (float)a9[2], dcy = (float)a9[3], dcz = (float)a9[4];
+        float t[3];
+        transformPoint4x3(mean, viewmatrix, t);
+        const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+        const float txtz = t[0] / t[2], tytz = t[1] / t[2];
+        t[0] = fminf_(limx, fmaxf_(-limx, txtz)) * t[2];
+        t[1] = fminf_(limy, fmaxf_(-limy, tytz)) * t[2];
+        const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+        const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+        /* Tm = J * Rv (2x3 non-zero rows), Rv[i][j] = viewmatrix[4*j+i]; glm's T[c][r] == Tm[r][c] */
+        const float j00 = h_x / t[2], j02 = -(h_x * t[0]) / (t[2] * t[2]);
+        const float j11 = h_y / t[2], j12 = -(h_y * t[1]) / (t[2] * t[2]);
+        float Tm[2][3];
+        for (int c = 0; c < 3; c++) {
+            const float r0v = viewmatrix[4 * c + 0], r1v = viewmatrix[4 * c + 1], r2v = viewmatrix[4 * c + 2];
+            Tm[0][c] = j00 * r0v + j02 * r2v;
+            Tm[1][c] = j11 * r1v + j12 * r2v;
+        }
+        const float V[3][3] = {{cov3D[0], cov3D[1], cov3D[2]}, {cov3D[1], cov3D[3], cov3D[4]}, {cov3D[2], cov3D[4], cov3D[5]}};
+        float TV[2][3];
+        for (int i = 0; i < 2; i++)
+            for (int c = 0; c < 3; c++) TV[i][c] = Tm[i][0] * V[0][c] + Tm[i][1] * V[1][c] + Tm[i][2] * V[2][c];
+        const float a = (TV[0][0] * Tm[0][0] + TV[0][1] * Tm[0][1] + TV[0][2] * Tm[0][2]) + 0.3f;
+        const float b = TV[0][0] * Tm[1][0] + TV[0][1] * Tm[1][1] + TV[0][2] * Tm[1][2];
+        const float c2 = (TV[1][0] * Tm[1][0] + TV[1][1] * Tm[1][1] + TV[1][2] * Tm[1][2]) + 0.3f;
+        const float denom = a * c2 - b * b;
+        float dL_da = 0, dL_db = 0, dL_dc = 0;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        float *dcov = dL_dcov3D + 6 * (size_t)idx;
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-c2 * c2 * dcx + 2 * b * c2 * dcy + (denom - a * c2) * dcz);
+            dL_dc = denom2inv * (-a * a * dcz + 2 * a * b * dcy + (denom - a * c2) * dcx);
+            dL_db = denom2inv * 2 * (b * c2 * dcx - (denom + 2 * b * b) * dcy + a * b * dcz);
+            /* cov2D = Tm V Tm^T: d/dV_ij (:219-229; off-diagonal entries appear twice) */
+            dcov[0] = Tm[0][0] * Tm[0][0] * dL_da + Tm[0][0] * Tm[1][0] * dL_db + Tm[1][0] * Tm[1][0] * dL_dc;
+            dcov[3] = Tm[0][1] * Tm[0][1] * dL_da + Tm[0][1] * Tm[1][1] * dL_db + Tm[1][1] * Tm[1][1] * dL_dc;
+            dcov[5] = Tm[0][2] * Tm[0][2] * dL_da + Tm[0][2] * Tm[1][2] * dL_db + Tm[1][2] * Tm[1][2] * dL_dc;
+            dcov[1] = 2 * Tm[0][0] * Tm[0][1] * dL_da + (Tm[0][0] * Tm[1][1] + Tm[0][1] * Tm[1][0]) * dL_db + 2 * Tm[1][0] * Tm[1][1] * dL_dc;
+            dcov[2] = 2 * Tm[0][0] * Tm[0][2] * dL_da + (Tm[0][0] * Tm[1][2] + Tm[0][2] * Tm[1][0]) * dL_db + 2 * Tm[1][0] * Tm[1][2] * dL_dc;
+            dcov[4] = 2 * Tm[0][2] * Tm[0][1] * dL_da + (Tm[0][1] * Tm[1][2] + Tm[0][2] * Tm[1][1]) * dL_db + 2 * Tm[1][1] * Tm[1][2] * dL_dc;
+        }
+        /* d/dTm (:238-249): row 0 <- 2 (Tm0 V) dL_da + (Tm1 V) dL_db ; row 1 <- 2 (Tm1 V) dL_dc + (Tm0 V) dL_db */
+        float dT[2][3];
+        for (int c = 0; c < 3; c++) {
+            dT[0][c] = 2 * TV[0][c] * dL_da + TV[1][c] * dL_db;
+            dT[1][c] = 2 * TV[1][c] * dL_dc + TV[0][c] * dL_db;
+        }
+        /* Tm = J Rv -> dJ (:253-256) */
+        float dJ00 = 0, dJ02 = 0, dJ11 = 0, dJ12 = 0;
+        for (int c = 0; c < 3; c++) {
+            dJ00 += viewmatrix[4 * c + 0] * dT[0][c];
+            dJ02 += viewmatrix[4 * c + 2] * dT[0][c];
+            dJ11 += viewmatrix[4 * c + 1] * dT[1][c];
+            dJ12 += viewmatrix[4 * c + 2] * dT[1][c];
+        }
+        const float tz = 1.f / t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+        const float dL_dtx = x_grad_mul * -h_x * tz2 * dJ02;
+        const float dL_dty = y_grad_mul * -h_y * tz2 * dJ12;
+        const float dL_dtz = -h_x * tz2 * dJ00 - h_y * tz2 * dJ11 + (2 * h_x * t[0]) * tz3 * dJ02 + (2 * h_y * t[1]) * tz3 * dJ12;
+        /* transformVec4x3Transpose (auxiliary.h:88-96) */
+        float dmean[3] = {viewmatrix[0] * dL_dtx + viewmatrix[1] * dL_dty + viewmatrix[2] * dL_dtz,
+                          viewmatrix[4] * dL_dtx + viewmatrix[5] * dL_dty + viewmatrix[6] * dL_dtz,
+                          viewmatrix[8] * dL_dtx + viewmatrix[9] * dL_dty + viewmatrix[10] * dL_dtz};
+        /* ---- preprocessCUDA backward, :365-383: 2D mean -> 3D mean through the projection ---- */
+        float m_hom[4];
+        transformPoint4x4(mean, projmatrix, m_hom);
+        const float m_w = 1.0f / (m_hom[3] + 0.0000001f);
+        const float mul1 = (projmatrix[0] * mean[0] + projmatrix[4] * mean[1] + projmatrix[8] * mean[2] + projmatrix[12]) * m_w * m_w;
+        const float mul2 = (projmatrix[1] * mean[0] + projmatrix[5] * mean[1] + projmatrix[9] * mean[2] + projmatrix[13]) * m_w * m_w;
+        const float g2x = dL_dmeans2D[3 * (size_t)idx], g2y = dL_dmeans2D[3 * (size_t)idx + 1];
+        dmean[0] += (projmatrix[0] * m_w - projmatrix[3] * mul1) * g2x + (projmatrix[1] * m_w - projmatrix[3] * mul2) * g2y;
+        dmean[1] += (projmatrix[4] * m_w - projmatrix[7] * mul1) * g2x + (projmatrix[5] * m_w - projmatrix[7] * mul2) * g2y;
+        dmean[2] += (projmatrix[8] * m_w - projmatrix[11] * mul1) * g2x + (projmatrix[9] * m_w - projmatrix[11] * mul2) * g2y;
+        for (int i = 0; i < 3; i++) dL_dmeans3D[3 * (size_t)idx + i] = dmean[i];
+        /* ---- computeCov3D backward, :278-342: Sigma = M^T M, M[k][i] = s_k R[i][k] ---- */
+        const float sx = scale_modifier * scales[3 * (size_t)idx], sy = scale_modifier * scales[3 * (size_t)idx + 1],
+                    sz = scale_modifier * scales[3 * (size_t)idx + 2];
+        const float sv[3] = {sx, sy, sz};
+        const float r = rotations[4 * (size_t)idx], x = rotations[4 * (size_t)idx + 1], y = rotations[4 * (size_t)idx + 2],
+                    z = rotations[4 * (size_t)idx + 3];
+        const float Rm[3][3] = {
+            {1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+            {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+            {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
+        const float dS[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]}, {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
+                                {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+        /* dL/dM[k][i] = 2 sum_j M[k][j] dS[j][i]; with M[k][j] = s_k R[j][k] */
+        float dM[3][3];
+        for (int k = 0; k < 3; k++)
+            for (int i = 0; i < 3; i++)
+                dM[k][i] = 2.0f * (sv[k] * Rm[0][k] * dS[0][i] + sv[k] * Rm[1][k] * dS[1][i] + sv[k] * Rm[2][k] * dS[2][i]);
+        /* d/ds_k = sum_i R[i][k] dM[k][i]  (scale_modifier is not applied to the gradient, :318-321) */
+        for (int k = 0; k < 3; k++)
+            dL_dscales[3 * (size_t)idx + k] = Rm[0][k] * dM[k][0] + Rm[1][k] * dM[k][1] + Rm[2][k] * dM[k][2];
+        /* dL/dR[i][k] = s_k dM[k][i]  =: Q[i][k]; then the quaternion derivative of R (:327-331) */
+        float Q[3][3];
+        for (int i = 0; i < 3; i++)
+            for (int k = 0; k < 3; k++) Q[i][k] = sv[k] * dM[k][i];
+        float *dq = dL_drotations + 4 * (size_t)idx;
+        dq[0] = 2 * z * (Q[1][0] - Q[0][1]) + 2 * y * (Q[0][2] - Q[2][0]) + 2 * x * (Q[2][1] - Q[1][2]);
+        dq[1] = 2 * y * (Q[0][1] + Q[1][0]) + 2 * z * (Q[0][2] + Q[2][0]) + 2 * r * (Q[2][1] - Q[1][2]) - 4 * x * (Q[2][2] + Q[1][1]);
+        dq[2] = 2 * x * (Q[0][1] + Q[1][0]) + 2 * r * (Q[0][2] - Q[2][0]) + 2 * z * (Q[2][1] + Q[1][2]) - 4 * y * (Q[2][2] + Q[0][0]);
+        dq[3] = 2 * r * (Q[1][0] - Q[0][1]) + 2 * x * (Q[0][2] + Q[2][0]) + 2 * y * (Q[2][1] + Q[1][2]) - 4 * z * (Q[1][1] + Q[0][0]);
+    }
+    free(acc); free(keep.kv); free(keep.ranges); free(keep.cov3D);
+    free(out_color); free(out_depth); free(final_T); free(n_contrib); free(touched); free(radii);
+    free(means2D); free(depths); free(conic_o);
     return R;
 }
