@@ -352,13 +352,27 @@ __device__ __forceinline__ void bitonic_sort_lds(unsigned long long* rec, int n_
   }
 }
 
+// DPP lane permutations inside a 16-lane row (VALU-rate, no LDS): used by the backward reduction.
+constexpr int kDppQuadXor1 = 0xB1;     // quad_perm:[1,0,3,2]
+constexpr int kDppQuadXor2 = 0x4E;     // quad_perm:[2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;  // row_half_mirror: lane i <-> 7-i within 8
+constexpr int kDppRowMirror = 0x140;   // row_mirror: lane i <-> 15-i
+constexpr int kDppRowRor8 = 0x128;     // row_ror:8: lane i <- lane (i+8)%16
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+
 // Backward mode (BWD): the same traversal, front to back, of exactly the same per-tile sequence;
 // each pixel stops at the contributor index the forward recorded (n_contrib) and evaluates
 //   dL/dalpha_i = sum_ch dL/dC_ch * (c_i T_i - (S_ch - prefix_ch(i)) / (1 - alpha_i)) - T_final/(1-alpha_i) * (bg . dL/dC)
 // with S = C_out - T_final * bg the colour the forward accumulated — algebraically the reference's
 // back-to-front recurrence (backward.cu:470-517) without needing the list reversed.  The nine
-// per-Gaussian partial derivatives are summed over the wave with shuffles, over the workgroup in
-// LDS, and leave as nine float atomics per (tile, record).
+// per-Gaussian partial derivatives are summed over each 16-lane row with DPP, over the workgroup
+// in LDS, and leave as nine float atomics per (tile, record).
+#ifndef OCRF_EXP
+#define OCRF_EXP 0
+#endif
 struct BwdArgs {
   const float* dL_dcolor;      // (V,3,H,W)
   const float* fwd_color;      // (V,3,H,W) forward output
@@ -471,7 +485,7 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
             C0 = fmaf(b.w, wgt, C0);                       // prefix including this record
             C1 = fmaf(rc2[u].x, wgt, C1);
             C2 = fmaf(rc2[u].y, wgt, C2);
-            const float inv1ma = 1.f / (1.f - alpha);
+            const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);     // alpha <= 0.99; 1 ulp
             float dL_dalpha = dL0 * (b.w * T - (S0 - C0) * inv1ma) + dL1 * (rc2[u].x * T - (S1 - C1) * inv1ma) +
                               dL2 * (rc2[u].y * T - (S2 - C2) * inv1ma) - Tfin * inv1ma * bgdot;
             dL_dalpha = contrib ? dL_dalpha : 0.f;
@@ -487,13 +501,39 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
             g[6] = wgt * dL0;
             g[7] = wgt * dL1;
             g[8] = wgt * dL2;
+#if OCRF_EXP & 2
+            if (g[0]+g[1]+g[2]+g[3]+g[4]+g[5]+g[6]+g[7]+g[8] == 12345.f) l_g[0] = 1.f;
+            if (false) {
+#else
             if (__ballot(contrib) != 0ull) {
+#endif
+              // Transposed reduction on the VALU (DPP), no LDS traffic: each halving step keeps half
+              // of the values per lane, so 8 values cost 4+2+1 pair-sums instead of 8 x 6; lane l
+              // ends with value (l & 7) summed over its 16-lane row, and the four rows meet in LDS.
+              float h[4], q[2];
 #pragma unroll
-              for (int k = 0; k < 9; ++k) {
-                float r = g[k];
-                for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off);
-                if (lane == 0) atomicAdd(&l_g[(j0 + u) * 9 + k], r);
+              for (int i = 0; i < 4; ++i) {
+                const float lo = g[i] + dpp_mov<kDppHalfMirror>(g[i]);
+                const float hi = g[i + 4] + dpp_mov<kDppHalfMirror>(g[i + 4]);
+                h[i] = (lane & 4) ? hi : lo;
               }
+#pragma unroll
+              for (int i = 0; i < 2; ++i) {
+                const float lo = h[i] + dpp_mov<kDppQuadXor2>(h[i]);
+                const float hi = h[i + 2] + dpp_mov<kDppQuadXor2>(h[i + 2]);
+                q[i] = (lane & 2) ? hi : lo;
+              }
+              const float lo = q[0] + dpp_mov<kDppQuadXor1>(q[0]);
+              const float hi = q[1] + dpp_mov<kDppQuadXor1>(q[1]);
+              float r = (lane & 1) ? hi : lo;
+              r += dpp_mov<kDppRowRor8>(r);
+              float e = g[8];
+              e += dpp_mov<kDppQuadXor1>(e);
+              e += dpp_mov<kDppQuadXor2>(e);
+              e += dpp_mov<kDppHalfMirror>(e);
+              e += dpp_mov<kDppRowMirror>(e);
+              const int l16 = lane & 15;
+              if (l16 < 9) atomicAdd(&l_g[(j0 + u) * 9 + l16], l16 == 8 ? e : r);
             }
             T = contrib ? test_T : T;
             done = done || (live && contributor >= n_last);
@@ -523,7 +563,11 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
 #pragma unroll
           for (int k = 0; k < 9; ++k) {
             const float r = l_g[tid * 9 + k];
+#if OCRF_EXP & 1
+            if (r == 12345.f) atomicAdd(&dst[k], r);
+#else
             if (r != 0.f) atomicAdd(&dst[k], r);
+#endif
           }
         }
         __syncthreads();

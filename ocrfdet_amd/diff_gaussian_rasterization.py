@@ -34,7 +34,7 @@ import torch.nn as nn
 
 from . import _lib
 
-__all__ = ['GaussianRasterizationSettings', 'GaussianRasterizer', 'rasterize_gaussians', 'rasterize_views',
+__all__ = ['GaussianRasterizationSettings', 'GaussianRasterizer', 'rasterize_gaussians', 'rasterize_views', 'pack_cameras',
            'rasterize_views_backward', 'rasterize_views_autograd']
 
 
@@ -57,8 +57,10 @@ def _f32c(t):
     return t.detach().contiguous().float()
 
 
-def _pack_cameras(viewmatrices, projmatrices, tanfovx, tanfovy, H, W, dev):
-    """(V,36) float rows: view16 | proj16 | tanfovx | tanfovy | focal_x | focal_y."""
+def pack_cameras(viewmatrices, projmatrices, tanfovx, tanfovy, H, W, dev):
+    """(V,36) float rows: view16 | proj16 | tanfovx | tanfovy | focal_x | focal_y — the camera block of
+    the C ABI.  Costs a few small host->device copies: callers with a fixed rig build it once and pass it
+    as ``packed_cameras=``."""
     vm = _f32c(viewmatrices).reshape(-1, 16)
     pm = _f32c(projmatrices).reshape(-1, 16)
     V = vm.size(0)
@@ -74,7 +76,7 @@ def _pack_cameras(viewmatrices, projmatrices, tanfovx, tanfovy, H, W, dev):
 
 def rasterize_views_backward(grad_color, fwd, means3D, colors, opacities, scales, rotations, viewmatrices,
                              projmatrices, tanfovx, tanfovy, image_height, image_width, bg, scale_modifier=1.0,
-                             want_means2D=False):
+                             want_means2D=False, packed_cameras=None):
     """Backward of ``rasterize_views``' colour output, summed over the views.  ``fwd`` is the dict
     ``rasterize_views`` returned for the same inputs.  Returns a dict ``means3D`` (P,3), ``colors``
     (P,3), ``opacities`` (P,1), ``scales`` (P,3), ``rotations`` (P,4) [, ``means2D`` (V,P,3)]."""
@@ -82,7 +84,8 @@ def rasterize_views_backward(grad_color, fwd, means3D, colors, opacities, scales
     dev = means3D.device
     P = means3D.size(0)
     H, W = int(image_height), int(image_width)
-    cams = _pack_cameras(viewmatrices, projmatrices, tanfovx, tanfovy, H, W, dev)
+    cams = packed_cameras if packed_cameras is not None else \
+        pack_cameras(viewmatrices, projmatrices, tanfovx, tanfovy, H, W, dev)
     V = cams.size(0)
     g = _f32c(grad_color).reshape(V, 3, H, W)
     means3D, colors, opac = _f32c(means3D), _f32c(colors), _f32c(opacities).reshape(-1)
@@ -115,20 +118,22 @@ def rasterize_views_backward(grad_color, fwd, means3D, colors, opacities, scales
 
 def rasterize_views(means3D, colors, opacities, scales, rotations, viewmatrices, projmatrices,
                     tanfovx, tanfovy, image_height, image_width, bg, scale_modifier=1.0,
-                    cov3D_precomp=None, depth_mode='median', want_tiles_touched=False):
+                    cov3D_precomp=None, depth_mode='median', want_tiles_touched=False, packed_cameras=None):
     """Render ``V`` cameras over the same ``P`` Gaussians.
 
     ``viewmatrices`` / ``projmatrices``: (V,4,4) transposed matrices as the reference passes them;
     ``tanfovx`` / ``tanfovy``: length-V sequences (or scalars).  Returns a dict of fresh tensors:
     ``color`` (V,3,H,W), ``depth`` (V,1,H,W), ``final_T`` (V,H,W), ``n_contrib`` (V,H,W) int32,
     ``radii`` (V,P) int32 [, ``tiles_touched`` (V,P) int32]."""
-    _lib.require_cuda(means3D, colors, opacities, viewmatrices, projmatrices, bg)
+    _lib.require_cuda(means3D, colors, opacities, bg)
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError('means3D must have dimensions (num_points, 3)')     # rasterize_points.cu:57-59
     dev = means3D.device
     P = means3D.size(0)
     H, W = int(image_height), int(image_width)
-    cams = _pack_cameras(viewmatrices, projmatrices, tanfovx, tanfovy, H, W, dev)         # (V,36)
+    cams = packed_cameras if packed_cameras is not None else \
+        pack_cameras(viewmatrices, projmatrices, tanfovx, tanfovy, H, W, dev)              # (V,36)
+    _lib.require_cuda(cams)
     V = cams.size(0)
     means3D, colors, opac = _f32c(means3D), _f32c(colors), _f32c(opacities).reshape(-1)
     if cov3D_precomp is not None and cov3D_precomp.numel() > 0:

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import bevpool, gaussian_renderer, hoa, index_prep, synthetic
-from .diff_gaussian_rasterization import rasterize_views
+from .diff_gaussian_rasterization import pack_cameras, rasterize_views
 
 
 class PoolPlan:
@@ -136,6 +136,8 @@ class HotPath:
             vms.append(cam['world_view_transform']), pms.append(cam['full_proj_transform'])
             tfx.append(math.tan(float(cam['FovX']) * 0.5)), tfy.append(math.tan(float(cam['FovY']) * 0.5))
         self.render_cams = dict(vm=torch.stack(vms).to(dev), pm=torch.stack(pms).to(dev), tfx=tfx, tfy=tfy)
+        # the rig is fixed: pack the C ABI's camera block once instead of on every render call
+        self.render_cams['packed'] = pack_cameras(self.render_cams['vm'], self.render_cams['pm'], tfx, tfy, H, W, dev)
         P = self.voxel_xyz.shape[1] * self.voxel_xyz.shape[2]
         rng = np.random.default_rng(seed)
         q = rng.standard_normal((P, 4)).astype(np.float32)
@@ -156,7 +158,8 @@ class HotPath:
         for b in range(self.batch):
             xyz = self.voxel_xyz[b].reshape(-1, 3)
             outs.append(rasterize_views(xyz, g['rgb'], g['opacity'], g['scales'], g['rotations'], rc['vm'],
-                                        rc['pm'], rc['tfx'], rc['tfy'], H, W, self.bg))
+                                        rc['pm'], rc['tfx'], rc['tfy'], H, W, self.bg,
+                                        packed_cameras=rc['packed']))
         return outs
 
     @property
