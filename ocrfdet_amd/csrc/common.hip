@@ -47,8 +47,8 @@ const char* ocrf_kernel_name(int kernel_id) {
     case OCRF_K_BEV_POOL_GRAD: return "bev_pool_grad_vec_kernel";
     case OCRF_K_BEV_POOL_NCHW: return "bev_pool_rows_to_nchw_kernel";
     case OCRF_K_RASTER_PREPROCESS: return "raster_preprocess_kernel";
-    case OCRF_K_RASTER_BLEND: return "raster_blend_kernel<false, false>";
-    case OCRF_K_RASTER_BLEND_BWD: return "raster_blend_kernel<false, true>";
+    case OCRF_K_RASTER_BLEND: return "raster_blend_kernel<false, false, *>";
+    case OCRF_K_RASTER_BLEND_BWD: return "raster_blend_kernel<false, true, true>";
     case OCRF_K_RASTER_PRE_BWD: return "raster_preprocess_backward_kernel";
     case OCRF_K_RASTER_GATHER: return "raster_scatter_kernel";
     case OCRF_K_RASTER_SCAN: return "raster_bucket_scan_kernel";

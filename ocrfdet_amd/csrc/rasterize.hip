@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void raster_scatter_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // 4. blend (forward.cu:261-374 + w-depth README:5-11).
-// Dynamic LDS: u64 rec[kCapRec]; float4 l_a[kStage], l_b[kStage]; float2 l_c[kStage].
+// Dynamic LDS: u64 rec[kCapRec]; float4 l_a[kStage], l_b[kStage], l_c[kStage].
 // ---------------------------------------------------------------------------------------------
 // Bitonic sort of 256*R u64 records held in LDS, R consecutive records per thread in registers:
 // exchange distances below R are register moves, below 64*R wave shuffles, and only the last
@@ -370,9 +370,6 @@ __device__ __forceinline__ float dpp_mov(float x) {
 // back-to-front recurrence (backward.cu:470-517) without needing the list reversed.  The nine
 // per-Gaussian partial derivatives are summed over each 16-lane row with DPP, over the workgroup
 // in LDS, and leave as nine float atomics per (tile, record).
-#ifndef OCRF_EXP
-#define OCRF_EXP 0
-#endif
 struct BwdArgs {
   const float* dL_dcolor;      // (V,3,H,W)
   const float* fwd_color;      // (V,3,H,W) forward output
@@ -381,57 +378,84 @@ struct BwdArgs {
   float* acc;                  // (V,P,9): mean2D x,y | conic x,y,z | opacity | colour r,g,b
 };
 
-template <bool STAMP, bool BWD>
+typedef float f2 __attribute__((ext_vector_type(2)));   // maps to v_pk_{mul,add,fma}_f32 on gfx950
+
+__device__ __forceinline__ f2 splat(float x) { return f2{x, x}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// One workgroup = one PAIR of vertically adjacent 16x16 tiles (tile rows 2*by and 2*by+1) of one
+// view; thread (lx, ly) owns pixel (lx, ly) of both tiles — same x, y 16 apart.  The two pixels
+// share dx and the dx-only part of the exponent and run as the two halves of packed fp32 ops; the
+// per-record LDS reads, the scan and the sort are shared by both tiles.  Each tile still sees
+// exactly its own list: a record carries two coverage bits (rect covers tile A / tile B), a pixel
+// ignores records that do not cover its tile, and the contributor index of each tile is a scalar
+// counter of its covered records.
+template <bool STAMP, bool BWD, bool MEDIAN>
 __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
     unsigned long long* __restrict__ stamps,
-    int P, int W, int H, int depth_mode, const int* __restrict__ starts,
+    int P, int W, int H, int gy, const int* __restrict__ starts, const Rect* __restrict__ rects,
     const Rect* __restrict__ b_rect, const unsigned long long* __restrict__ b_comp,
     const float2* __restrict__ xy, const float4* __restrict__ conic_o,
     const float* __restrict__ colors, const float* __restrict__ bg, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_final_T,
     unsigned* __restrict__ out_n_contrib, int* __restrict__ status, BwdArgs bw) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long rec[];
-  float4* l_a = reinterpret_cast<float4*>(rec + kCapRec);
-  float4* l_b = l_a + kStage;
-  float2* l_c = reinterpret_cast<float2*>(l_b + kStage);
+  float4* l_a = reinterpret_cast<float4*>(rec + kCapRec);          // x, y, conic.x, conic.y
+  float4* l_b = l_a + kStage;                                      // conic.z, opacity, depth, r
+  float4* l_c = l_b + kStage;                                      // g, b, coverage bits, -
   unsigned* l_id = reinterpret_cast<unsigned*>(l_c + kStage);     // BWD only
   float* l_g = reinterpret_cast<float*>(l_id + kStage);           // BWD only: [kStage][9]
   __shared__ int l_wtot[kScanUnroll * (kBlock / 64)];
   __shared__ int l_ready;
 
   const int tid = threadIdx.x;
-  const int tx = blockIdx.x, ty = blockIdx.y, v = blockIdx.z;
+  const int tx = blockIdx.x, v = blockIdx.z;
+  const int tyA = 2 * blockIdx.y, tyB = tyA + 1;      // tyB == gy: the pair has no second tile
   const int lx = tid % kTileX, ly = tid / kTileX;
-  const int pxi = tx * kTileX + lx, pyi = ty * kTileY + ly;
-  const bool inside = pxi < W && pyi < H;
-  const float pixf_x = (float)pxi, pixf_y = (float)pyi;
+  const int pxi = tx * kTileX + lx, pyA = tyA * kTileY + ly, pyB = tyB * kTileY + ly;
+  const bool insideA = pxi < W && pyA < H;
+  const bool insideB = tyB < gy && pxi < W && pyB < H;
+  const float pixf_x = (float)pxi;
+  const f2 pixf_y = f2{(float)pyA, (float)pyB};
   const long base = (long)v * P;
   const int nv = starts[(long)v * (kBuckets + 1) + kBuckets];
   const int wave = tid / 64, lane = tid % 64;
 
-  bool done = !inside;
-  float T = 1.0f;
-  unsigned contributor = 0, last_contributor = 0;
-  float C0 = 0.f, C1 = 0.f, C2 = 0.f;
-  float D = depth_mode == 0 ? 15.0f : 0.0f;
+  bool doneA = !insideA, doneB = !insideB;
+  f2 T = splat(1.0f);
+  int jA = 0, jB = 0;                                  // wave-uniform: covered records so far
+  unsigned lastA = 0, lastB = 0;
+  f2 C0 = splat(0.f), C1 = splat(0.f), C2 = splat(0.f);
+  f2 D = splat(MEDIAN ? 15.0f : 0.0f);
   // backward-only per-pixel state
-  float dL0 = 0.f, dL1 = 0.f, dL2 = 0.f, S0 = 0.f, S1 = 0.f, S2 = 0.f, Tfin = 0.f, bgdot = 0.f;
-  unsigned n_last = 0;
+  f2 dL0 = splat(0.f), dL1 = splat(0.f), dL2 = splat(0.f), S0 = splat(0.f), S1 = splat(0.f), S2 = splat(0.f);
+  f2 Tfin = splat(0.f), bgdot = splat(0.f);
+  int n_lastA = 0, n_lastB = 0;
   if constexpr (BWD) {
-    if (inside) {
-      const long npix = (long)W * H;
-      const long pix = (long)pyi * W + pxi;
-      dL0 = bw.dL_dcolor[(v * 3 + 0) * npix + pix];
-      dL1 = bw.dL_dcolor[(v * 3 + 1) * npix + pix];
-      dL2 = bw.dL_dcolor[(v * 3 + 2) * npix + pix];
-      Tfin = bw.fwd_final_T[v * npix + pix];
-      S0 = bw.fwd_color[(v * 3 + 0) * npix + pix] - Tfin * bg[0];
-      S1 = bw.fwd_color[(v * 3 + 1) * npix + pix] - Tfin * bg[1];
-      S2 = bw.fwd_color[(v * 3 + 2) * npix + pix] - Tfin * bg[2];
-      bgdot = bg[0] * dL0 + bg[1] * dL1 + bg[2] * dL2;
-      n_last = bw.fwd_n_contrib[v * npix + pix];
-    }
-    done = done || (n_last == 0);
+    const long npix = (long)W * H;
+    struct PixelBwd { float d0, d1, d2, s0, s1, s2, tf, bd; int nl; };
+    auto load = [&](bool inside, int py) {
+      PixelBwd q = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0};
+      if (!inside) return q;
+      const long pix = (long)py * W + pxi;
+      q.d0 = bw.dL_dcolor[(v * 3 + 0) * npix + pix];
+      q.d1 = bw.dL_dcolor[(v * 3 + 1) * npix + pix];
+      q.d2 = bw.dL_dcolor[(v * 3 + 2) * npix + pix];
+      q.tf = bw.fwd_final_T[v * npix + pix];
+      q.s0 = bw.fwd_color[(v * 3 + 0) * npix + pix] - q.tf * bg[0];
+      q.s1 = bw.fwd_color[(v * 3 + 1) * npix + pix] - q.tf * bg[1];
+      q.s2 = bw.fwd_color[(v * 3 + 2) * npix + pix] - q.tf * bg[2];
+      q.bd = bg[0] * q.d0 + bg[1] * q.d1 + bg[2] * q.d2;
+      q.nl = (int)bw.fwd_n_contrib[v * npix + pix];
+      return q;
+    };
+    const PixelBwd qa = load(insideA, pyA), qb = load(insideB, pyB);
+    dL0 = f2{qa.d0, qb.d0}; dL1 = f2{qa.d1, qb.d1}; dL2 = f2{qa.d2, qb.d2};
+    S0 = f2{qa.s0, qb.s0}; S1 = f2{qa.s1, qb.s1}; S2 = f2{qa.s2, qb.s2};
+    Tfin = f2{qa.tf, qb.tf}; bgdot = f2{qa.bd, qb.bd};
+    n_lastA = qa.nl; n_lastB = qb.nl;
+    doneA = doneA || (n_lastA == 0);
+    doneB = doneB || (n_lastB == 0);
   }
 
   bool all_done = false;
@@ -444,9 +468,11 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
         const unsigned id = (unsigned)(c & 0xFFFFFFFFull);
         const float2 p = xy[base + id];
         const float4 co = conic_o[base + id];
+        const Rect rc = rects[base + id];
+        const unsigned cov = ((tyA >= rc.y0 && tyA < rc.y1) ? 1u : 0u) | ((tyB >= rc.y0 && tyB < rc.y1) ? 2u : 0u);
         l_a[tid] = make_float4(p.x, p.y, co.x, co.y);
         l_b[tid] = make_float4(co.z, co.w, __uint_as_float((unsigned)(c >> 32)), colors[3 * (long)id]);
-        l_c[tid] = make_float2(colors[3 * (long)id + 1], colors[3 * (long)id + 2]);
+        l_c[tid] = make_float4(colors[3 * (long)id + 1], colors[3 * (long)id + 2], __uint_as_float(cov), 0.f);
         if constexpr (BWD) {
           l_id[tid] = id;
 #pragma unroll
@@ -455,58 +481,79 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
       }
       __syncthreads();
       // Branch-free per-record update so that the LDS reads of the next records can be issued
-      // ahead (4 records per trip); a wave leaves the batch as soon as its 64 pixels are done.
+      // ahead (4 records per trip); a wave leaves the batch as soon as its 128 pixels are done.
       for (int j0 = 0; j0 < ns; j0 += 4) {
-        if (__ballot(!done) == 0ull) break;
-        float4 ra[4], rb[4];
-        float2 rc2[4];
+        if (__ballot(!(doneA && doneB)) == 0ull) break;
+        float4 ra[4], rb[4], rc4[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int j = min(j0 + u, ns - 1);
           ra[u] = l_a[j];
           rb[u] = l_b[j];
-          rc2[u] = l_c[j];
+          rc4[u] = l_c[j];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const bool live = !done && (j0 + u < ns);
-          contributor += live ? 1u : 0u;
           const float4 a = ra[u];
           const float4 b = rb[u];
-          const float dx = a.x - pixf_x, dy = a.y - pixf_y;
-          const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-          const float G = __expf(power);
-          const float alpha = fminf(0.99f, b.y * G);
-          const bool valid = live && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-          const float test_T = T * (1 - alpha);
+          const float cg = rc4[u].x, cb = rc4[u].y;
+          const unsigned cov = __builtin_amdgcn_readfirstlane(__float_as_uint(rc4[u].z));
+          const bool in = (j0 + u) < ns;
+          const bool covA = in && (cov & 1u), covB = in && (cov & 2u);
+          jA += covA ? 1 : 0;
+          jB += covB ? 1 : 0;
+          const bool liveA = covA && !doneA, liveB = covB && !doneB;
+          // power = -0.5 (cxx dx dx + czz dy dy) - cxy dx dy, in the reference's order (forward.cu:320-323)
+          const float dx = a.x - pixf_x;
+          const float qx = (a.z * dx) * dx;
+          const float bx = a.w * dx;
+          const f2 dy = splat(a.y) - pixf_y;
+          const f2 qy = (splat(b.x) * dy) * dy;
+          const f2 power = splat(-0.5f) * (splat(qx) + qy) - splat(bx) * dy;
+          f2 G;
+          G.x = __expf(power.x);
+          G.y = __expf(power.y);
+          f2 alpha = splat(b.y) * G;
+          alpha.x = fminf(0.99f, alpha.x);
+          alpha.y = fminf(0.99f, alpha.y);
+          const bool validA = liveA && !(power.x > 0.0f) && !(alpha.x < 1.0f / 255.0f);
+          const bool validB = liveB && !(power.y > 0.0f) && !(alpha.y < 1.0f / 255.0f);
+          const f2 test_T = T * (splat(1.0f) - alpha);
+          const f2 aT = alpha * T;
           if constexpr (BWD) {
-            const bool contrib = valid && (contributor <= n_last);
-            const float wgt = contrib ? alpha * T : 0.f;
-            C0 = fmaf(b.w, wgt, C0);                       // prefix including this record
-            C1 = fmaf(rc2[u].x, wgt, C1);
-            C2 = fmaf(rc2[u].y, wgt, C2);
-            const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);     // alpha <= 0.99; 1 ulp
-            float dL_dalpha = dL0 * (b.w * T - (S0 - C0) * inv1ma) + dL1 * (rc2[u].x * T - (S1 - C1) * inv1ma) +
-                              dL2 * (rc2[u].y * T - (S2 - C2) * inv1ma) - Tfin * inv1ma * bgdot;
-            dL_dalpha = contrib ? dL_dalpha : 0.f;
-            const float dL_dG = b.y * dL_dalpha;
-            const float gdx = G * dx, gdy = G * dy;
+            const bool contribA = validA && (jA <= n_lastA), contribB = validB && (jB <= n_lastB);
+            f2 wgt;
+            wgt.x = contribA ? aT.x : 0.f;
+            wgt.y = contribB ? aT.y : 0.f;
+            C0 = fma2(splat(b.w), wgt, C0);                // prefix including this record
+            C1 = fma2(splat(cg), wgt, C1);
+            C2 = fma2(splat(cb), wgt, C2);
+            const f2 om = splat(1.0f) - alpha;             // alpha <= 0.99
+            f2 inv;
+            inv.x = __builtin_amdgcn_rcpf(om.x);
+            inv.y = __builtin_amdgcn_rcpf(om.y);
+            f2 dLda = dL0 * (splat(b.w) * T - (S0 - C0) * inv) + dL1 * (splat(cg) * T - (S1 - C1) * inv) +
+                      dL2 * (splat(cb) * T - (S2 - C2) * inv) - Tfin * inv * bgdot;
+            dLda.x = contribA ? dLda.x : 0.f;
+            dLda.y = contribB ? dLda.y : 0.f;
+            const f2 dG = splat(b.y) * dLda;
+            const f2 gdx = G * splat(dx), gdy = G * dy;
+            const f2 m0 = dG * (-gdx * splat(a.z) - gdy * splat(a.w));
+            const f2 m1 = dG * (-gdy * splat(b.x) - gdx * splat(a.w));
+            const f2 k2 = gdx * splat(dx) * dG, k3 = gdx * dy * dG, k4 = gdy * dy * dG;
+            const f2 k5 = G * dLda;
+            const f2 k6 = wgt * dL0, k7 = wgt * dL1, k8 = wgt * dL2;
             float g[9];
-            g[0] = dL_dG * (-gdx * a.z - gdy * a.w) * (0.5f * (float)W);
-            g[1] = dL_dG * (-gdy * b.x - gdx * a.w) * (0.5f * (float)H);
-            g[2] = -0.5f * gdx * dx * dL_dG;
-            g[3] = -0.5f * gdx * dy * dL_dG;
-            g[4] = -0.5f * gdy * dy * dL_dG;
-            g[5] = G * dL_dalpha;
-            g[6] = wgt * dL0;
-            g[7] = wgt * dL1;
-            g[8] = wgt * dL2;
-#if OCRF_EXP & 2
-            if (g[0]+g[1]+g[2]+g[3]+g[4]+g[5]+g[6]+g[7]+g[8] == 12345.f) l_g[0] = 1.f;
-            if (false) {
-#else
-            if (__ballot(contrib) != 0ull) {
-#endif
+            g[0] = (m0.x + m0.y) * (0.5f * (float)W);
+            g[1] = (m1.x + m1.y) * (0.5f * (float)H);
+            g[2] = -0.5f * (k2.x + k2.y);
+            g[3] = -0.5f * (k3.x + k3.y);
+            g[4] = -0.5f * (k4.x + k4.y);
+            g[5] = k5.x + k5.y;
+            g[6] = k6.x + k6.y;
+            g[7] = k7.x + k7.y;
+            g[8] = k8.x + k8.y;
+            if (__ballot(contribA || contribB) != 0ull) {
               // Transposed reduction on the VALU (DPP), no LDS traffic: each halving step keeps half
               // of the values per lane, so 8 values cost 4+2+1 pair-sums instead of 8 x 6; lane l
               // ends with value (l & 7) summed over its 16-lane row, and the four rows meet in LDS.
@@ -535,45 +582,55 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
               const int l16 = lane & 15;
               if (l16 < 9) atomicAdd(&l_g[(j0 + u) * 9 + l16], l16 == 8 ? e : r);
             }
-            T = contrib ? test_T : T;
-            done = done || (live && contributor >= n_last);
+            T.x = contribA ? test_T.x : T.x;
+            T.y = contribB ? test_T.y : T.y;
+            doneA = doneA || (liveA && jA >= n_lastA);
+            doneB = doneB || (liveB && jB >= n_lastB);
             continue;
           }
-          const bool stop = valid && (test_T < 0.0001f);
-          const bool contrib = valid && !stop;
-          const float wgt = contrib ? alpha * T : 0.f;
-          C0 = fmaf(b.w, wgt, C0);
-          C1 = fmaf(rc2[u].x, wgt, C1);
-          C2 = fmaf(rc2[u].y, wgt, C2);
-          if (depth_mode == 0) {
-            D = (contrib && T > 0.5f && test_T < 0.5f) ? b.z : D;
+          const bool stopA = validA && (test_T.x < 0.0001f), stopB = validB && (test_T.y < 0.0001f);
+          const bool contribA = validA != stopA, contribB = validB != stopB;     // stop implies valid
+          f2 wgt;
+          wgt.x = contribA ? aT.x : 0.f;
+          wgt.y = contribB ? aT.y : 0.f;
+          C0 = fma2(splat(b.w), wgt, C0);
+          C1 = fma2(splat(cg), wgt, C1);
+          C2 = fma2(splat(cb), wgt, C2);
+          if constexpr (MEDIAN) {
+            // '&' on purpose: no short-circuit regions, two compares + scalar mask ops per pixel
+            const bool medA = contribA & (T.x > 0.5f) & (test_T.x < 0.5f);
+            const bool medB = contribB & (T.y > 0.5f) & (test_T.y < 0.5f);
+            D.x = medA ? b.z : D.x;
+            D.y = medB ? b.z : D.y;
           } else {
-            D = fmaf(b.z, wgt, D);
+            D = fma2(splat(b.z), wgt, D);
           }
-          T = contrib ? test_T : T;
-          last_contributor = contrib ? contributor : last_contributor;
-          done = done || stop;
+          T.x = contribA ? test_T.x : T.x;
+          T.y = contribB ? test_T.y : T.y;
+          lastA = contribA ? (unsigned)jA : lastA;
+          lastB = contribB ? (unsigned)jB : lastB;
+          doneA = doneA || stopA;
+          doneB = doneB || stopB;
         }
       }
       // every pixel saturated -> stop (forward.cu:304-307)
-      all_done = __syncthreads_count(done) == kBlock;
+      all_done = __syncthreads_count(doneA && doneB) == kBlock;
       if constexpr (BWD) {
         if (tid < ns) {
           float* dst = bw.acc + (base + l_id[tid]) * 9;
 #pragma unroll
           for (int k = 0; k < 9; ++k) {
             const float r = l_g[tid * 9 + k];
-#if OCRF_EXP & 1
-            if (r == 12345.f) atomicAdd(&dst[k], r);
-#else
             if (r != 0.f) atomicAdd(&dst[k], r);
-#endif
           }
         }
         __syncthreads();
       }
     }
   };
+
+  // does the record's tile rectangle cover one of the two tiles of this workgroup?
+  auto covers = [&](const Rect rc) { return (tx >= rc.x0) && (tx < rc.x1) && (tyA < rc.y1) && (tyB >= rc.y0); };
 
   int scan = 0;      // next list entry to look at
   int nrec = 0;      // records held in LDS (sorted prefix left over from the previous round)
@@ -587,7 +644,7 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
   };
   stamp(-1);
   while (!all_done) {
-    // ---- scan: keep the records whose rect covers this tile, until ~2 batches are held ----
+    // ---- scan: keep the records whose rect covers this tile pair, until ~2 batches are held ----
     // stop once ~half a batch of new records is in: nrec then lands in (128, 384] on the first
     // round, so the sort pads to 256 or 512.  kScanUnroll batches of 256 rects are in flight at
     // once (the scan is latency-bound: one dependent global load per batch otherwise).
@@ -600,10 +657,7 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
       for (int u = 0; u < kScanUnroll; ++u) {
         const int i = scan + u * kBlock + tid;
         hit[u] = false;
-        if (u < n_u && i < nv) {
-          const Rect rc = b_rect[base + i];
-          hit[u] = (tx >= rc.x0) && (tx < rc.x1) && (ty >= rc.y0) && (ty < rc.y1);
-        }
+        if (u < n_u && i < nv) hit[u] = covers(b_rect[base + i]);
       }
       int rank[kScanUnroll];
 #pragma unroll
@@ -678,8 +732,7 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
               unsigned long long comp = 0ull;
               bool take = false;
               if (i < re) {
-                const Rect rc = b_rect[base + i];
-                if ((tx >= rc.x0) && (tx < rc.x1) && (ty >= rc.y0) && (ty < rc.y1)) {
+                if (covers(b_rect[base + i])) {
                   comp = b_comp[base + i];
                   take = comp > last && comp < thr;
                 }
@@ -749,19 +802,24 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
       const long w = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
       for (int k = 0; k < 5; ++k) stamps[w * 8 + k] = t_acc[k];
       stamps[w * 8 + 5] = (unsigned long long)scan;
-      stamps[w * 8 + 6] = (unsigned long long)contributor;
+      stamps[w * 8 + 6] = (unsigned long long)max(jA, jB);
     }
   }
 
-  if (!BWD && inside) {
+  if constexpr (!BWD) {
     const long npix = (long)W * H;
-    const long pix = (long)pyi * W + pxi;
-    out_final_T[v * npix + pix] = T;
-    out_n_contrib[v * npix + pix] = last_contributor;
-    out_color[(v * 3 + 0) * npix + pix] = C0 + T * bg[0];
-    out_color[(v * 3 + 1) * npix + pix] = C1 + T * bg[1];
-    out_color[(v * 3 + 2) * npix + pix] = C2 + T * bg[2];
-    out_depth[v * npix + pix] = D;
+    auto store = [&](bool inside, int py, float t, unsigned last, float c0, float c1, float c2, float d) {
+      if (!inside) return;
+      const long pix = (long)py * W + pxi;
+      out_final_T[v * npix + pix] = t;
+      out_n_contrib[v * npix + pix] = last;
+      out_color[(v * 3 + 0) * npix + pix] = c0 + t * bg[0];
+      out_color[(v * 3 + 1) * npix + pix] = c1 + t * bg[1];
+      out_color[(v * 3 + 2) * npix + pix] = c2 + t * bg[2];
+      out_depth[v * npix + pix] = d;
+    };
+    store(insideA, pyA, T.x, lastA, C0.x, C1.x, C2.x, D.x);
+    store(insideB, pyB, T.y, lastB, C0.y, C1.y, C2.y, D.y);
   }
 }
 
@@ -1005,20 +1063,30 @@ int ocrf_rasterize_forward(int P, int n_views, int H, int W, const float* means3
                b_comp);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  const size_t lds = (size_t)kCapRec * 8 + (size_t)kStage * (16 + 16 + 8);
+  const size_t lds = (size_t)kCapRec * 8 + (size_t)kStage * (16 + 16 + 16);
+  const dim3 bgrid(gx, (gy + 1) / 2, n_views);        // one workgroup per vertical pair of tiles
   if (g_stamps) {
-    hipLaunchKernelGGL((raster_blend_kernel<true, false>), dim3(gx, gy, n_views), dim3(kBlock), lds, stream,
-                       g_stamps, P, W, H, depth_mode, static_cast<const int*>(starts),
+    hipLaunchKernelGGL((raster_blend_kernel<true, false, true>), bgrid, dim3(kBlock), lds, stream,
+                       g_stamps, P, W, H, gy, static_cast<const int*>(starts), static_cast<const Rect*>(rects),
                        static_cast<const Rect*>(b_rect), static_cast<const unsigned long long*>(b_comp),
                        static_cast<const float2*>(xy), static_cast<const float4*>(conic_o), colors, bg,
                        out_color, out_depth, out_final_T, out_n_contrib, st, BwdArgs{});
     return (int)hipGetLastError();
   }
-  ocrf::launch(OCRF_K_RASTER_BLEND, raster_blend_kernel<false, false>, dim3(gx, gy, n_views), dim3(kBlock), lds,
-               stream, (unsigned long long*)nullptr, P, W, H, depth_mode, static_cast<const int*>(starts),
-               static_cast<const Rect*>(b_rect), static_cast<const unsigned long long*>(b_comp),
-               static_cast<const float2*>(xy), static_cast<const float4*>(conic_o), colors, bg,
-               out_color, out_depth, out_final_T, out_n_contrib, st, BwdArgs{});
+  if (depth_mode == 0)
+    ocrf::launch(OCRF_K_RASTER_BLEND, raster_blend_kernel<false, false, true>, bgrid, dim3(kBlock), lds,
+                 stream, (unsigned long long*)nullptr, P, W, H, gy, static_cast<const int*>(starts),
+                 static_cast<const Rect*>(rects), static_cast<const Rect*>(b_rect),
+                 static_cast<const unsigned long long*>(b_comp), static_cast<const float2*>(xy),
+                 static_cast<const float4*>(conic_o), colors, bg, out_color, out_depth, out_final_T,
+                 out_n_contrib, st, BwdArgs{});
+  else
+    ocrf::launch(OCRF_K_RASTER_BLEND, raster_blend_kernel<false, false, false>, bgrid, dim3(kBlock), lds,
+                 stream, (unsigned long long*)nullptr, P, W, H, gy, static_cast<const int*>(starts),
+                 static_cast<const Rect*>(rects), static_cast<const Rect*>(b_rect),
+                 static_cast<const unsigned long long*>(b_comp), static_cast<const float2*>(xy),
+                 static_cast<const float4*>(conic_o), colors, bg, out_color, out_depth, out_final_T,
+                 out_n_contrib, st, BwdArgs{});
   return (int)hipGetLastError();
 }
 
@@ -1078,10 +1146,11 @@ int ocrf_rasterize_backward(int P, int n_views, int H, int W, const float* means
   BwdArgs bw;
   bw.dL_dcolor = dL_dcolor; bw.fwd_color = fwd_color; bw.fwd_final_T = fwd_final_T;
   bw.fwd_n_contrib = fwd_n_contrib; bw.acc = acc;
-  const size_t lds = (size_t)kCapRec * 8 + (size_t)kStage * (16 + 16 + 8 + 4 + 36);
-  ocrf::launch(OCRF_K_RASTER_BLEND_BWD, raster_blend_kernel<false, true>, dim3(gx, gy, n_views), dim3(kBlock), lds,
-               stream, (unsigned long long*)nullptr, P, W, H, 0, static_cast<const int*>(starts),
-               static_cast<const Rect*>(b_rect), static_cast<const unsigned long long*>(b_comp),
+  const size_t lds = (size_t)kCapRec * 8 + (size_t)kStage * (16 + 16 + 16 + 4 + 36);
+  ocrf::launch(OCRF_K_RASTER_BLEND_BWD, raster_blend_kernel<false, true, true>, dim3(gx, (gy + 1) / 2, n_views),
+               dim3(kBlock), lds, stream, (unsigned long long*)nullptr, P, W, H, gy, static_cast<const int*>(starts),
+               static_cast<const Rect*>(rects), static_cast<const Rect*>(b_rect),
+               static_cast<const unsigned long long*>(b_comp),
                static_cast<const float2*>(xy), static_cast<const float4*>(conic_o), colors, bg, (float*)nullptr,
                (float*)nullptr, (float*)nullptr, (unsigned*)nullptr, st, bw);
   e = hipGetLastError();

@@ -6,7 +6,7 @@ dev = torch.device('cuda:0')
 hp = hotpath.HotPath(cfg, dev)
 r = synthetic.rig(cfg.n_cams, cfg.input_size, hp.batch)
 L = _lib.lib()
-ntile = 44 * 16 * 6
+ntile = 44 * 8 * 6      # one workgroup per vertical pair of 16x16 tiles
 for conv in ('reference', 'corrected'):
     hp._prepare_render(r, conv)
     hp.render(); torch.cuda.synchronize()
