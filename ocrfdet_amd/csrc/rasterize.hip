@@ -616,12 +616,14 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
       // every pixel saturated -> stop (forward.cu:304-307)
       all_done = __syncthreads_count(doneA && doneB) == kBlock;
       if constexpr (BWD) {
-        if (tid < ns) {
-          float* dst = bw.acc + (base + l_id[tid]) * 9;
-#pragma unroll
-          for (int k = 0; k < 9; ++k) {
-            const float r = l_g[tid * 9 + k];
-            if (r != 0.f) atomicAdd(&dst[k], r);
+        // Float atomics execute at the memory side as 64-B requests: the rate is set by the
+        // number of requests, not of adds.  16 lanes per record (9 active) keep a record's 36
+        // contiguous bytes in 1-2 requests; one lane per record would issue 9.
+        for (int r0 = 0; r0 < ns; r0 += kBlock / 16) {
+          const int r = r0 + tid / 16, k = tid % 16;
+          if (r < ns && k < 9) {
+            const float val = l_g[r * 9 + k];
+            if (val != 0.f) atomicAdd(&bw.acc[(base + l_id[r]) * 9 + k], val);
           }
         }
         __syncthreads();
