@@ -33,6 +33,9 @@ def parse():
     ap.add_argument('--config', default=DEFAULT_CONFIG)
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU-baseline sample budget')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--index-prep', choices=('cached', 'per_step'), default='cached',
+                    help="'per_step': rank vectors recomputed by the HIP index preparation inside every step "
+                         "(the reference with accelerate=False); 'cached': once per calibration (accelerate=True)")
     return ap.parse_args()
 
 
@@ -106,7 +109,7 @@ def main():
     cfg = synthetic.CONFIGS[args.config]
     # weak scaling: every rank owns cfg.n_frames frames of a (world * n_frames)-frame sequence;
     # frames are independent until the channel concat (detectors/ocrfdet.py:274)
-    hp = hotpath.HotPath(cfg, dev)
+    hp = hotpath.HotPath(cfg, dev, index_prep_mode=args.index_prep)
     depth, feat = hp.make_inputs(seed=rank)
     # N > 1 (weak scaling, frame policy of ocrfdet_amd.sharding): every rank owns cfg.n_frames whole
     # frames of a (world * n_frames)-frame sequence — frames are independent until the channel
@@ -152,6 +155,9 @@ def main():
             H, W = cfg.input_size
             P = hp.voxel_xyz.shape[1] * hp.voxel_xyz.shape[2]
             alg_bytes = float(len(hp.cams) * (60 * P + 24 * H * W))
+            # the blend is VALU-bound: pixel.record evaluations per launch, counted as the
+            # contributor index each pixel stopped at (a lower bound of what the kernel evaluates)
+            evals = float(hp.render()[0]['n_contrib'].sum().item())
         else:
             alg_bytes = 0.5 * (hp.lss.algorithmic_bytes(depth.numel(), feat.numel()) +
                                hp.ht.algorithmic_bytes(depth.numel(), feat.numel()))
@@ -177,13 +183,20 @@ def main():
                        'bev': list(cfg.bev_xyz), 'channels': cfg.channels, 'depth_bins': cfg.D,
                        'stages': 'lss_pool+ht_pool' + ('+render' if cfg.render else '') + ('+hoa' if cfg.hoa else ''),
                        'views_per_step': hp.views_per_step, 'render_camera': getattr(hp, 'render_convention', None),
-                       'index_prep': 'cached (accelerate=True semantics)',
+                       'index_prep': 'cached (accelerate=True semantics)' if args.index_prep == 'cached' else
+                                     'per step, HIP (accelerate=False semantics)',
                        'sharding': f'{world} x {cfg.n_frames} frames (frame policy), one RCCL all_gather of the fused BEV per step' if world > 1 else 'none'},
             'roofline': {'bound': 'hbm', 'kernel': timer.kernel_name, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_us': 1e3 * avg_ms,
                          'launches_timed': len(ms)},
         }
+        if cfg.render and avg_ms > 0:
+            lane_slots = 256 * 4 * 16 * 2.4e9          # CUs x SIMDs x lanes x clock (MI355X_MICROARCH.md)
+            out['roofline']['valu'] = {
+                'pixel_records_per_launch': evals, 'pixel_records_per_sec': evals / (avg_ms * 1e-3),
+                'issue_slots_per_pixel_record': 26.5,    # ISA count of the inner loop, DESIGN 4.3
+                'frac_of_valu_issue_peak': evals * 26.5 / (avg_ms * 1e-3) / lane_slots}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(hp, depth, feat, args.cpu_seconds)
             out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']

@@ -96,6 +96,16 @@ int ocrf_bev_pool_v2_nchw(int c, int n_intervals, int n_points, const float *dep
                           int layout, void *workspace, size_t workspace_bytes,
                           ocrf_stream_t stream);
 
+/* Same, for rank vectors whose lengths were produced on the device (ocrf_lss_prepare /
+ * ocrf_ht_prepare): the vectors are passed at their capacities and `counts` (device, int32) holds
+ * [n_points, n_intervals]; the launch is sized for the capacities and workgroups past the real
+ * end retire at once, so nothing between index preparation and pooling reads the device.
+ * Workspace: ocrf_bev_pool_v2_nchw_workspace_bytes(c, cap_intervals, cap_points, n_voxels). */
+int ocrf_bev_pool_v2_nchw_dyn(int c, int cap_intervals, int cap_points, const int *counts,
+                              const float *depth, const float *feat, const int *ranks_depth,
+                              const int *ranks_feat, const int *ranks_bev, const int *interval_starts,
+                              const int *interval_lengths, float *out, int B, int Z, int Y, int X,
+                              int layout, void *workspace, size_t workspace_bytes, ocrf_stream_t stream);
 size_t ocrf_bev_pool_v2_nchw_workspace_bytes(int c, int n_intervals, int n_points, long n_voxels);
 
 /*
@@ -179,6 +189,46 @@ int ocrf_rasterize_backward(int P, int n_views, int H, int W, const float *means
                             float *dL_dmeans2D, void *workspace, size_t workspace_bytes,
                             ocrf_stream_t stream);
 size_t ocrf_rasterize_backward_workspace_bytes(int P, int n_views);
+
+/* ------------------------------------------------------------------------------------------
+ * Index preparation of the two poolings on the device (csrc/index_prep.hip).
+ *
+ * ocrf_lss_prepare replaces get_lidar_coor + voxel_pooling_prepare_v2
+ * (mmdet3d/models/necks/view_transformer.py:108-147,197-255) for one batch of B samples x N cameras:
+ *   frustum   (D,H,W,3) device   the create_frustum template (:77-106), (u, v, depth) per cell
+ *   cams      (B*N,33)  device   per camera-frame, row-major 3x3s:
+ *                                inv(post_rots) 9 | rots . inv(cam2imgs) 9 | post_trans 3 | trans 3 | bda 9
+ *                                (the tiny per-camera algebra stays with the caller: the same torch
+ *                                calls the reference makes at :128-146)
+ *   grid_lower_host / grid_interval_host   3 floats each in HOST memory (create_grid_infos, :59-75)
+ *   gx, gy, gz                    grid size (X, Y, Z)
+ * outputs (device, int32; capacities: B*N*D*H*W for the three rank vectors, min(that, B*Z*Y*X) for
+ * the interval vectors): ranks_bev / ranks_depth / ranks_feat sorted by voxel, ascending point
+ * index inside a voxel (stable, where the reference's argsort is not); interval_starts /
+ * interval_lengths; counts[0] = Np (kept points), counts[1] = Nv (intervals) — device ints, so that
+ * the call itself never synchronises.  Bit-exact against the reference's vectors.
+ *
+ * ocrf_ht_prepare replaces get_sampling_point + fast_sample_prepare
+ * (mmdet3d/models/necks/view_transformer_ocrf.py:687-740,785-852):
+ *   ref_points (Z,n_pillars,3) device   get_reference_points_3d template (:651-673), normalised
+ *   cams       (B*N,24) device          lidar2img 3x4 | img_aug 3x4 per camera-frame (get_projection, :675-685)
+ *   pc_range_host  6 floats in HOST memory; w_in / h_in: network input size; depth0 / depth1:
+ *   grid_config['depth'][0:2]; Wf, Hf, D: feature-map size and depth bins
+ * outputs as above with ranks_bev = b*n_pillars + pillar; inside a pillar the order is (camera,
+ * height) ascending = the reference's flattening order under a stable sort.
+ */
+int ocrf_lss_prepare(int B, int N, int D, int H, int W, const float *frustum, const float *cams,
+                     const float *grid_lower_host, const float *grid_interval_host, int gx, int gy, int gz,
+                     int *ranks_bev, int *ranks_depth, int *ranks_feat, int *interval_starts,
+                     int *interval_lengths, int *counts, void *workspace, size_t workspace_bytes,
+                     ocrf_stream_t stream);
+size_t ocrf_lss_prepare_workspace_bytes(int B, int N, int D, int H, int W, int gx, int gy, int gz);
+int ocrf_ht_prepare(int B, int N, int Z, int n_pillars, int Wf, int Hf, int D, const float *ref_points,
+                    const float *cams, const float *pc_range_host, float w_in, float h_in, float depth0,
+                    float depth1, int *ranks_bev, int *ranks_depth, int *ranks_feat, int *interval_starts,
+                    int *interval_lengths, int *counts, void *workspace, size_t workspace_bytes,
+                    ocrf_stream_t stream);
+size_t ocrf_ht_prepare_workspace_bytes(int B, int n_pillars);
 
 /* ------------------------------------------------------------------------------------------
  * Height-aware Opacity-based Attention (HOA) reductions
@@ -279,7 +329,15 @@ enum {
   OCRF_K_HOA1_ATTN = 26,         /* hoa1_attention_kernel */
   OCRF_K_HOA1_UP = 27,           /* hoa1_upsample_residual_kernel */
   OCRF_K_HOA1_Q = 28,            /* hoa1_q_kernel */
-  OCRF_K_HOA1_KV = 29            /* hoa1_kv_kernel */
+  OCRF_K_HOA1_KV = 29,           /* hoa1_kv_kernel */
+  OCRF_K_LSS_KEYS = 40,          /* lss_keys_kernel */
+  OCRF_K_RADIX_HIST = 41,        /* radix_hist_kernel */
+  OCRF_K_SCAN = 42,              /* scan_apply_kernel<T> */
+  OCRF_K_RADIX_SCATTER = 43,     /* radix_scatter_kernel<*> */
+  OCRF_K_LSS_BOUNDS = 44,        /* lower_bound_kernel */
+  OCRF_K_LSS_EMIT = 45,          /* lss_emit_ranks_kernel */
+  OCRF_K_HT_COUNT = 46,          /* ht_pillar_kernel<false> */
+  OCRF_K_HT_EMIT = 47            /* ht_pillar_kernel<true> */
 };
 const char *ocrf_kernel_name(int kernel_id);           /* symbol as rocprofv3 prints it */
 int ocrf_timer_create(int capacity, void **timer_out); /* host pointers */

@@ -60,6 +60,9 @@ def _declare(L):
     L.ocrf_bev_pool_v2_nchw.restype = c_int
     L.ocrf_bev_pool_v2_nchw.argtypes = ([c_int, c_int, c_int] + [c_void_p] * 8 + [c_int] * 5 +
                                         [c_void_p, c_size_t, c_void_p])
+    L.ocrf_bev_pool_v2_nchw_dyn.restype = c_int
+    L.ocrf_bev_pool_v2_nchw_dyn.argtypes = ([c_int, c_int, c_int] + [c_void_p] * 9 + [c_int] * 5 +
+                                            [c_void_p, c_size_t, c_void_p])
     L.ocrf_bev_pool_v2_nchw_workspace_bytes.restype = c_size_t
     L.ocrf_bev_pool_v2_nchw_workspace_bytes.argtypes = [c_int, c_int, c_int, ctypes.c_long]
     L.ocrf_bev_pool_v2_check_intervals.restype = c_int
@@ -69,6 +72,16 @@ def _declare(L):
     L.ocrf_rasterize_forward.restype = c_int
     L.ocrf_rasterize_forward.argtypes = ([c_int] * 4 + [c_void_p] * 4 + [c_float] + [c_void_p] * 4 +
                                          [c_int] + [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p])
+    L.ocrf_lss_prepare.restype = c_int
+    L.ocrf_lss_prepare.argtypes = ([c_int] * 5 + [c_void_p] * 4 + [c_int] * 3 + [c_void_p] * 6 +
+                                   [c_void_p, c_size_t, c_void_p])
+    L.ocrf_lss_prepare_workspace_bytes.restype = c_size_t
+    L.ocrf_lss_prepare_workspace_bytes.argtypes = [c_int] * 8
+    L.ocrf_ht_prepare.restype = c_int
+    L.ocrf_ht_prepare.argtypes = ([c_int] * 7 + [c_void_p] * 3 + [c_float] * 4 + [c_void_p] * 6 +
+                                  [c_void_p, c_size_t, c_void_p])
+    L.ocrf_ht_prepare_workspace_bytes.restype = c_size_t
+    L.ocrf_ht_prepare_workspace_bytes.argtypes = [c_int, c_int]
     L.ocrf_rasterize_backward.restype = c_int
     L.ocrf_rasterize_backward.argtypes = ([c_int] * 4 + [c_void_p] * 4 + [c_float] + [c_void_p] * 13 +
                                           [c_void_p, c_size_t, c_void_p])
@@ -155,6 +168,7 @@ workspace = Workspace()
 K_BEV_POOL_FWD, K_BEV_POOL_FIXUP, K_BEV_POOL_INTERVAL, K_BEV_POOL_GRAD, K_BEV_POOL_NCHW = 1, 2, 3, 4, 5
 K_RASTER_PREPROCESS, K_RASTER_BLEND, K_RASTER_GATHER = 10, 11, 12
 K_RASTER_SCAN, K_RASTER_BLEND_BWD, K_RASTER_PRE_BWD = 13, 15, 16
+K_LSS_KEYS, K_RADIX_HIST, K_SCAN, K_RADIX_SCATTER, K_LSS_BOUNDS, K_LSS_EMIT, K_HT_COUNT, K_HT_EMIT = range(40, 48)
 K_HOA_STATS, K_HOA_MASK_GATE, K_HOA_HEIGHT_MAX, K_HOA_HEIGHT_GATE = 20, 21, 22, 23
 
 

@@ -24,7 +24,7 @@ import torch
 
 from . import _lib
 
-__all__ = ['bev_pool_v2', 'bev_pool_v2_collapsed', 'TRTBEVPoolv2', 'QuickCumsumCuda',
+__all__ = ['bev_pool_v2_device_counts', 'bev_pool_v2', 'bev_pool_v2_collapsed', 'TRTBEVPoolv2', 'QuickCumsumCuda',
            'bev_pool_v2_ext', 'runs_of']
 
 
@@ -212,6 +212,36 @@ def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev,
     pooled = QuickCumsumCuda.apply(depth, feat, ranks_depth, ranks_feat, ranks_bev,
                                    bev_feat_shape, interval_starts, interval_lengths)
     return pooled.permute(0, 4, 1, 2, 3).contiguous()        # (B,Z,Y,X,C) -> (B,C,Z,Y,X)
+
+
+@torch.no_grad()
+def bev_pool_v2_device_counts(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape,
+                              interval_starts, interval_lengths, counts, layout=1):
+    """Forward-only pooling on rank vectors whose lengths live on the device: the five vectors are
+    passed at their CAPACITY (as ``index_prep.*_hip(sync=False)`` returns them) together with
+    ``counts`` = int32 device tensor [n_points, n_intervals], so that nothing between the index
+    preparation and the pooling reads the device.  ``layout`` as in ``_FusedPool``."""
+    B, Z, Y, X, C = (int(v) for v in bev_feat_shape)
+    if not _fusable(C):
+        raise _lib.OcrfHipError(f'bev_pool_v2_device_counts needs C % 4 == 0 and C <= 256, got {C}')
+    d32, f32 = depth.float().contiguous(), feat.float().contiguous()
+    _lib.require_cuda(d32, f32, ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths, counts)
+    for t in (ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths, counts):
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise _lib.OcrfHipError('rank / interval / count vectors must be contiguous int32')
+    cap_pts, cap_iv = ranks_depth.numel(), interval_starts.numel()
+    dev = d32.device
+    out = torch.empty((B, C, Z, Y, X) if layout == 0 else (B, Z * C, Y, X), dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        need = L.ocrf_bev_pool_v2_nchw_workspace_bytes(C, cap_iv, cap_pts, B * Z * Y * X)
+        scratch = _lib.workspace.get(dev, need, 'bev_pool_nchw')
+        _lib.check(L.ocrf_bev_pool_v2_nchw_dyn(
+            C, cap_iv, cap_pts, _lib.ptr(counts), _lib.ptr(d32), _lib.ptr(f32), _lib.ptr(ranks_depth),
+            _lib.ptr(ranks_feat), _lib.ptr(ranks_bev), _lib.ptr(interval_starts), _lib.ptr(interval_lengths),
+            _lib.ptr(out), B, Z, Y, X, int(layout), _lib.ptr(scratch), ctypes.c_size_t(scratch.numel()),
+            _lib.stream_ptr(dev)), 'ocrf_bev_pool_v2_nchw_dyn')
+    return out
 
 
 def bev_pool_v2_collapsed(depth, feat, ranks_depth, ranks_feat, ranks_bev,

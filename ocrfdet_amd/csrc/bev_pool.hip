@@ -99,7 +99,7 @@ __device__ __forceinline__ void load_batch(Batch& q, int l0, const int* s_rf, co
 template <bool STAMP, int kSub>
 __global__ __launch_bounds__(kBlock) void bev_pool_fwd_chunked_kernel(
     unsigned long long* __restrict__ stamps,
-    int c4, int gpw, int n_intervals, int n_points, int compact_rows,
+    int c4, int gpw, int n_intervals, int n_points, const int* __restrict__ counts, int compact_rows,
     const float* __restrict__ depth, const float4* __restrict__ feat4,
     const int* __restrict__ ranks_depth, const int* __restrict__ ranks_feat,
     const int* __restrict__ ranks_bev, const int* __restrict__ interval_starts,
@@ -118,6 +118,16 @@ __global__ __launch_bounds__(kBlock) void bev_pool_fwd_chunked_kernel(
   float4* s_part = reinterpret_cast<float4*>(s_meta + 4 * gpb);   // [2*gpb][c4]
 
   const int bs = blockIdx.x * BP;             // first point of this block
+  if (counts) {
+    // sizes produced on the device (ocrf_lss_prepare / ocrf_ht_prepare): the launch was sized for
+    // the capacities, workgroups past the real end leave a neutral record for the fix-up and go
+    n_points = counts[0];
+    n_intervals = counts[1];
+    if (bs >= n_points) {
+      if (tid == 0) bmeta[blockIdx.x] = make_int4(0, 0, 0, 0);
+      return;
+    }
+  }
   const int be = min(bs + BP, n_points);      // one past its last point
   auto stamp = [&](int slot) {
     if constexpr (STAMP) {
@@ -516,7 +526,7 @@ inline FwdGeom fwd_geom(int c, int n_points) {
 }
 
 // Shared by the scatter (reference contract) and compact-row (NCHW epilogue) forms.
-int launch_fwd(int c, int n_intervals, int n_points, int compact_rows, const float* depth,
+int launch_fwd(int c, int n_intervals, int n_points, const int* counts, int compact_rows, const float* depth,
                const float* feat, const int* ranks_depth, const int* ranks_feat,
                const int* ranks_bev, const int* interval_starts, const int* interval_lengths,
                float* dst, void* workspace, int* row_of_vox, hipStream_t stream) {
@@ -527,7 +537,7 @@ int launch_fwd(int c, int n_intervals, int n_points, int compact_rows, const flo
                              : bev_pool_fwd_chunked_kernel<false, 32>;
   ocrf::launch(OCRF_K_BEV_POOL_FWD, kern, dim3(g.n_blocks),
                dim3(kBlock), g.lds, stream, (unsigned long long*)nullptr, g.c4, g.gpw, n_intervals,
-               n_points, compact_rows, depth,
+               n_points, counts, compact_rows, depth,
                reinterpret_cast<const float4*>(feat), ranks_depth, ranks_feat, ranks_bev,
                interval_starts, interval_lengths, reinterpret_cast<float4*>(dst), part, bmeta,
                row_of_vox);
@@ -562,7 +572,7 @@ int ocrf_diag_bev_pool_v2_stamps(int c, int n_intervals, int n_points, const flo
   auto kern = (g_sub == 64) ? bev_pool_fwd_chunked_kernel<true, 64>
                              : bev_pool_fwd_chunked_kernel<true, 32>;
   hipLaunchKernelGGL(kern, dim3(g.n_blocks), dim3(kBlock), g.lds,
-                     stream, stamps, g.c4, g.gpw, n_intervals, n_points, 0, depth,
+                     stream, stamps, g.c4, g.gpw, n_intervals, n_points, (const int*)nullptr, 0, depth,
                      reinterpret_cast<const float4*>(feat), ranks_depth, ranks_feat, ranks_bev,
                      interval_starts, interval_lengths, reinterpret_cast<float4*>(out), part, bmeta,
                      (int*)nullptr);
@@ -596,7 +606,7 @@ int ocrf_bev_pool_v2(int c, int n_intervals, int n_points, const float* depth, c
   const size_t need = ocrf_bev_pool_v2_workspace_bytes(c, n_points);
   if (!workspace || workspace_bytes < need || !aligned16(workspace))
     return (int)hipErrorInvalidValue;
-  return launch_fwd(c, n_intervals, n_points, 0, depth, feat, ranks_depth, ranks_feat, ranks_bev,
+  return launch_fwd(c, n_intervals, n_points, nullptr, 0, depth, feat, ranks_depth, ranks_feat, ranks_bev,
                     interval_starts, interval_lengths, out, workspace, nullptr, stream);
 }
 
@@ -619,13 +629,12 @@ size_t ocrf_bev_pool_v2_nchw_workspace_bytes(int c, int n_intervals, int n_point
   return nchw_geom(c, n_intervals, n_points, n_voxels).total;
 }
 
-int ocrf_bev_pool_v2_nchw(int c, int n_intervals, int n_points, const float* depth,
-                          const float* feat, const int* ranks_depth, const int* ranks_feat,
-                          const int* ranks_bev, const int* interval_starts,
-                          const int* interval_lengths, float* out, int B, int Z, int Y, int X,
-                          int layout, void* workspace, size_t workspace_bytes,
-                          ocrf_stream_t stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
+namespace {
+int nchw_impl(int c, int n_intervals, int n_points, const int* counts, const float* depth,
+              const float* feat, const int* ranks_depth, const int* ranks_feat,
+              const int* ranks_bev, const int* interval_starts,
+              const int* interval_lengths, float* out, int B, int Z, int Y, int X,
+              int layout, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!vec_ok(c) || n_intervals < 0 || n_points < 0 || B <= 0 || Z <= 0 || Y <= 0 || X <= 0 ||
       (layout != 0 && layout != 1) || !out)
     return (int)hipErrorInvalidValue;
@@ -643,7 +652,7 @@ int ocrf_bev_pool_v2_nchw(int c, int n_intervals, int n_points, const float* dep
     if (!depth || !feat || !ranks_depth || !ranks_feat || !ranks_bev || !interval_starts ||
         !interval_lengths)
       return (int)hipErrorInvalidValue;
-    const int rc = launch_fwd(c, n_intervals, n_points, 1, depth, feat, ranks_depth, ranks_feat,
+    const int rc = launch_fwd(c, n_intervals, n_points, counts, 1, depth, feat, ranks_depth, ranks_feat,
                               ranks_bev, interval_starts, interval_lengths, rows, workspace,
                               row_of_vox, stream);
     if (rc != 0) return rc;
@@ -656,6 +665,30 @@ int ocrf_bev_pool_v2_nchw(int c, int n_intervals, int n_points, const float* dep
                dim3(kBlock), lds, stream, c4, B, Z, Y, X, tiles_x, layout,
                reinterpret_cast<const float4*>(rows), static_cast<const int*>(row_of_vox), out);
   return (int)hipGetLastError();
+}
+}  // namespace
+
+int ocrf_bev_pool_v2_nchw(int c, int n_intervals, int n_points, const float* depth,
+                          const float* feat, const int* ranks_depth, const int* ranks_feat,
+                          const int* ranks_bev, const int* interval_starts,
+                          const int* interval_lengths, float* out, int B, int Z, int Y, int X,
+                          int layout, void* workspace, size_t workspace_bytes,
+                          ocrf_stream_t stream_) {
+  return nchw_impl(c, n_intervals, n_points, nullptr, depth, feat, ranks_depth, ranks_feat, ranks_bev,
+                   interval_starts, interval_lengths, out, B, Z, Y, X, layout, workspace, workspace_bytes,
+                   static_cast<hipStream_t>(stream_));
+}
+
+int ocrf_bev_pool_v2_nchw_dyn(int c, int cap_intervals, int cap_points, const int* counts,
+                              const float* depth, const float* feat, const int* ranks_depth,
+                              const int* ranks_feat, const int* ranks_bev, const int* interval_starts,
+                              const int* interval_lengths, float* out, int B, int Z, int Y, int X,
+                              int layout, void* workspace, size_t workspace_bytes,
+                              ocrf_stream_t stream_) {
+  if (!counts || cap_intervals <= 0 || cap_points <= 0) return (int)hipErrorInvalidValue;
+  return nchw_impl(c, cap_intervals, cap_points, counts, depth, feat, ranks_depth, ranks_feat, ranks_bev,
+                   interval_starts, interval_lengths, out, B, Z, Y, X, layout, workspace, workspace_bytes,
+                   static_cast<hipStream_t>(stream_));
 }
 
 int ocrf_bev_pool_v2_check_intervals(int n_intervals, int n_points, const int* interval_starts,

@@ -62,6 +62,14 @@ const char* ocrf_kernel_name(int kernel_id) {
     case OCRF_K_HOA1_UP: return "hoa1_upsample_residual_kernel";
     case OCRF_K_HOA1_Q: return "hoa1_q_kernel";
     case OCRF_K_HOA1_KV: return "hoa1_kv_kernel";
+    case OCRF_K_LSS_KEYS: return "lss_keys_kernel";
+    case OCRF_K_RADIX_HIST: return "radix_hist_kernel";
+    case OCRF_K_SCAN: return "scan_apply_kernel<*>";
+    case OCRF_K_RADIX_SCATTER: return "radix_scatter_kernel<*>";
+    case OCRF_K_LSS_BOUNDS: return "lower_bound_kernel";
+    case OCRF_K_LSS_EMIT: return "lss_emit_ranks_kernel";
+    case OCRF_K_HT_COUNT: return "ht_pillar_kernel<false>";
+    case OCRF_K_HT_EMIT: return "ht_pillar_kernel<true>";
     default: return "";
   }
 }

@@ -1,0 +1,573 @@
+// Index preparation of the two bev_pool_v2 calls on the device.
+//
+// LSS branch: frustum template -> ego frame -> voxel id per point -> points grouped by voxel
+//   (mmdet3d/models/necks/view_transformer.py:108-147 get_lidar_coor, :197-255
+//   voxel_pooling_prepare_v2).
+// HT branch: pillar sample points -> every camera -> image cell per (camera, height, pillar)
+//   (mmdet3d/models/necks/view_transformer_ocrf.py:687-740 get_sampling_point, :785-852
+//   fast_sample_prepare).
+//
+// The reference spends ~20 elementwise passes, a boolean compaction and an argsort per branch and
+// forward.  Here one kernel evaluates the per-point arithmetic — written as the same separate
+// float32 multiplies and adds, k ascending, fp-contract off, IEEE division, so the voxel indices
+// are bit-exact against vectors dumped from the reference — and
+//   * LSS: the points are ordered by voxel with an LSD radix sort written for this key shape
+//     (keys are voxel ids: 17-20 bits -> 2 passes of 9 bits up to 262 144 voxels, 3 beyond; stable,
+//     so the order inside an interval is ascending point index — deterministic where the
+//     reference's argsort is not); interval starts / lengths come from one binary search per voxel;
+//   * HT: the key is the pillar itself and a pillar's candidates are its (camera, height) pairs, so
+//     no sort is needed at all: a group of lanes per pillar (one per camera) counts, one scan over
+//     the pillars, emit in (camera, height) order.
+// Tiny per-camera algebra (3x3 inverses and products) stays on the host, as the same torch calls the
+// reference makes; the kernels take the resulting per-camera blocks.
+#include <hip/hip_runtime.h>
+
+#include "launch.h"
+#include "ocrf_hip.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kItems = 8;                     // keys per thread and radix pass
+constexpr int kChunk = kBlock * kItems;       // 2048 keys per workgroup
+constexpr int kRadixBits = 9;
+constexpr int kBins = 1 << kRadixBits;        // 512
+constexpr int kScanBlock = 1024;          // the one-workgroup scan of the per-chunk sums
+
+struct LssCam {       // 33 floats per camera-frame, see ocrf_hip.h
+  float inv_post[9], combine[9], post_trans[3], trans[3], bda[9];
+};
+
+struct HtCam {        // 24 floats per camera-frame
+  float l2i[12], aug[12];
+};
+
+// float -> int64 like x86 cvttss2si / CUDA: NaN and out-of-range give a value that fails the
+// in-grid test (torch .long() on the reference's devices), never cell 0.
+__device__ __forceinline__ long long trunc_ll(float x) {
+  if (!(fabsf(x) < 9.0e18f)) return (long long)0x8000000000000000ull;
+  return (long long)x;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LSS: voxel key per frustum point.  key = b*Z*Y*X + cz*Y*X + cy*X + cx, or n_vox_total if the
+// point falls outside the grid.  One workgroup = 1024 consecutive points (mostly one camera).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void lss_keys_kernel(
+    int n_pts, int N, int DHW, const float* __restrict__ frustum, const LssCam* __restrict__ cams,
+    float lx, float ly, float lz, float ix, float iy, float iz, int gx, int gy, int gz,
+    unsigned n_vox_total, unsigned* __restrict__ keys) {
+  const int p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n_pts) return;
+  const int cam = p / DHW;                 // b*N + n
+  const int cell_i = p - cam * DHW;        // (d*H + h)*W + w
+  const LssCam& c = cams[cam];
+  // frustum - post_trans, inv(post_rots) (view_transformer.py:130-133)
+  const float fx = frustum[3 * cell_i] - c.post_trans[0];
+  const float fy = frustum[3 * cell_i + 1] - c.post_trans[1];
+  const float fz = frustum[3 * cell_i + 2] - c.post_trans[2];
+  float x = c.inv_post[0] * fx + c.inv_post[1] * fy + c.inv_post[2] * fz;
+  float y = c.inv_post[3] * fx + c.inv_post[4] * fy + c.inv_post[5] * fz;
+  float z = c.inv_post[6] * fx + c.inv_post[7] * fy + c.inv_post[8] * fz;
+  x = x * z;                                // un-project by depth (:138-139)
+  y = y * z;
+  float x2 = c.combine[0] * x + c.combine[1] * y + c.combine[2] * z;
+  float y2 = c.combine[3] * x + c.combine[4] * y + c.combine[5] * z;
+  float z2 = c.combine[6] * x + c.combine[7] * y + c.combine[8] * z;
+  x2 = x2 + c.trans[0];
+  y2 = y2 + c.trans[1];
+  z2 = z2 + c.trans[2];
+  const float ex = c.bda[0] * x2 + c.bda[1] * y2 + c.bda[2] * z2;
+  const float ey = c.bda[3] * x2 + c.bda[4] * y2 + c.bda[5] * z2;
+  const float ez = c.bda[6] * x2 + c.bda[7] * y2 + c.bda[8] * z2;
+  // ((coor - lower) / interval).long(): truncation toward zero BEFORE the range test (:220-230)
+  const long long cx = trunc_ll((ex - lx) / ix);
+  const long long cy = trunc_ll((ey - ly) / iy);
+  const long long cz = trunc_ll((ez - lz) / iz);
+  unsigned key = n_vox_total;
+  if (cx >= 0 && cx < gx && cy >= 0 && cy < gy && cz >= 0 && cz < gz) {
+    const int b = cam / N;
+    key = (unsigned)(((long long)b * gz + cz) * gy * gx + cy * gx + cx);
+  }
+  keys[p] = key;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LSD radix sort, one 9-bit digit per pass: histogram -> exclusive scan of the [digit][workgroup]
+// table -> stable scatter.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void radix_hist_kernel(const unsigned* __restrict__ keys, int n, int shift,
+                                                            int n_wg, int* __restrict__ table) {
+  __shared__ int s_hist[kBins];
+  for (int i = threadIdx.x; i < kBins; i += kBlock) s_hist[i] = 0;
+  __syncthreads();
+  const int base = blockIdx.x * kChunk;
+#pragma unroll
+  for (int it = 0; it < kItems; ++it) {
+    const int i = base + it * kBlock + threadIdx.x;
+    if (i < n) atomicAdd(&s_hist[(keys[i] >> shift) & (kBins - 1)], 1);
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < kBins; d += kBlock) table[(long)d * n_wg + blockIdx.x] = s_hist[d];
+}
+
+// Exclusive scan of n values in place, three launches: per-workgroup sums (2048 values each) ->
+// scan of the sums by one workgroup -> rescan of every chunk with its offset.  Each thread owns 8
+// consecutive values, so a wave touches 2 KB of contiguous memory per load.
+template <typename T>
+__device__ __forceinline__ T block_exclusive(T v, T* s_wave, T* block_total) {
+  // exclusive prefix of v over the 256 threads of the workgroup
+  const int lane = threadIdx.x % 64, wave = threadIdx.x / 64;
+  T inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const T o = __shfl_up(inc, off);
+    if (lane >= off) inc += o;
+  }
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  T base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) {
+    const T c = s_wave[w];
+    if (w < wave) base += c;
+    tot += c;
+  }
+  if (block_total) *block_total = tot;
+  return base + inc - v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scan_reduce_kernel(const T* __restrict__ data, long n, T* __restrict__ partial) {
+  __shared__ T s_wave[kBlock / 64];
+  const long base = (long)blockIdx.x * kChunk + (long)threadIdx.x * kItems;
+  T sum = 0;
+#pragma unroll
+  for (int i = 0; i < kItems; ++i)
+    if (base + i < n) sum += data[base + i];
+  T tot;
+  block_exclusive<T>(sum, s_wave, &tot);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kScanBlock) void scan_top_kernel(T* __restrict__ partial, int nb, T* __restrict__ total) {
+  __shared__ T s_sum[kScanBlock];
+  const int tid = threadIdx.x;
+  const int per = (nb + kScanBlock - 1) / kScanBlock;
+  const int lo = min(tid * per, nb), hi = min(lo + per, nb);
+  T sum = 0;
+  for (int i = lo; i < hi; ++i) sum += partial[i];
+  s_sum[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < kScanBlock; off <<= 1) {      // Hillis-Steele inclusive scan
+    const T add = tid >= off ? s_sum[tid - off] : (T)0;
+    __syncthreads();
+    s_sum[tid] += add;
+    __syncthreads();
+  }
+  T run = s_sum[tid] - sum;
+  for (int i = lo; i < hi; ++i) {
+    const T v = partial[i];
+    partial[i] = run;
+    run += v;
+  }
+  if (total && tid == kScanBlock - 1) *total = s_sum[tid];
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scan_apply_kernel(T* __restrict__ data, long n, const T* __restrict__ partial) {
+  __shared__ T s_wave[kBlock / 64];
+  const long base = (long)blockIdx.x * kChunk + (long)threadIdx.x * kItems;
+  T v[kItems];
+  T sum = 0;
+#pragma unroll
+  for (int i = 0; i < kItems; ++i) {
+    v[i] = base + i < n ? data[base + i] : (T)0;
+    sum += v[i];
+  }
+  T run = partial[blockIdx.x] + block_exclusive<T>(sum, s_wave, (T*)nullptr);
+#pragma unroll
+  for (int i = 0; i < kItems; ++i) {
+    if (base + i < n) data[base + i] = run;
+    run += v[i];
+  }
+}
+
+// host side: scratch must hold ceil(n / 2048) values of T
+template <typename T>
+inline void scan_exclusive(T* data, long n, T* total, T* scratch, hipStream_t stream) {
+  const int nb = (int)((n + kChunk - 1) / kChunk);
+  hipLaunchKernelGGL(scan_reduce_kernel<T>, dim3(nb), dim3(kBlock), 0, stream, static_cast<const T*>(data), n, scratch);
+  hipLaunchKernelGGL(scan_top_kernel<T>, dim3(1), dim3(kScanBlock), 0, stream, scratch, nb, total);
+  ocrf::launch(OCRF_K_SCAN, scan_apply_kernel<T>, dim3(nb), dim3(kBlock), 0, stream, data, n, static_cast<const T*>(scratch));
+}
+
+// Stable scatter of one pass.  A wave owns 512 consecutive keys of the workgroup's chunk and walks
+// them 64 at a time in order; the rank of a key among equal digits of its step is a ballot match,
+// running per-digit positions live in LDS (LDS operations of one wave execute in order).
+template <bool IMPLICIT_VALS>
+__global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
+    const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in, int n, int shift, int n_wg,
+    const int* __restrict__ table, unsigned* __restrict__ keys_out, int* __restrict__ vals_out) {
+  __shared__ int s_pos[kBlock / 64][kBins];
+  const int tid = threadIdx.x, wave = tid / 64, lane = tid % 64;
+  for (int i = tid; i < (kBlock / 64) * kBins; i += kBlock) (&s_pos[0][0])[i] = 0;
+  __syncthreads();
+  const int wbase = blockIdx.x * kChunk + wave * (kChunk / (kBlock / 64));
+  unsigned key[kItems];
+  bool ok[kItems];
+#pragma unroll
+  for (int s = 0; s < kItems; ++s) {
+    const int i = wbase + s * 64 + lane;
+    ok[s] = i < n;
+    key[s] = ok[s] ? keys_in[i] : 0u;
+    if (ok[s]) atomicAdd(&s_pos[wave][(key[s] >> shift) & (kBins - 1)], 1);
+  }
+  __syncthreads();
+  // per digit: global base of this workgroup, then the waves in order
+  for (int d = tid; d < kBins; d += kBlock) {
+    int run = table[(long)d * n_wg + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) {
+      const int c = s_pos[w][d];
+      s_pos[w][d] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < kItems; ++s) {
+    const int digit = (int)((key[s] >> shift) & (kBins - 1));
+    unsigned long long same = __ballot(ok[s]);
+#pragma unroll
+    for (int b = 0; b < kRadixBits; ++b) {
+      const unsigned long long m = __ballot((digit >> b) & 1);
+      same &= ((digit >> b) & 1) ? m : ~m;
+    }
+    if (ok[s]) {
+      const int rank = __popcll(same & ((1ull << lane) - 1ull));
+      const int pos = s_pos[wave][digit] + rank;
+      const int i = wbase + s * 64 + lane;
+      keys_out[pos] = key[s];
+      vals_out[pos] = IMPLICIT_VALS ? i : vals_in[i];
+      if (rank == 0) s_pos[wave][digit] = pos + __popcll(same);      // leader advances the digit
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// S[v] = first sorted position with key >= v, for v in [0, n_vox_total]; S[n_vox_total] = Np.
+__global__ __launch_bounds__(kBlock) void lower_bound_kernel(const unsigned* __restrict__ sorted, int n,
+                                                             unsigned n_vox_total, int* __restrict__ S) {
+  const unsigned v = blockIdx.x * kBlock + threadIdx.x;
+  if (v > n_vox_total) return;
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (sorted[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  S[v] = lo;
+}
+
+// flags[v] = voxel v holds points; scanned in place afterwards
+__global__ __launch_bounds__(kBlock) void nonempty_flags_kernel(const int* __restrict__ S, unsigned n_vox_total,
+                                                                int* __restrict__ flags) {
+  const unsigned v = blockIdx.x * kBlock + threadIdx.x;
+  if (v < n_vox_total) flags[v] = S[v + 1] > S[v] ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void lss_emit_intervals_kernel(const int* __restrict__ S, const int* __restrict__ idx,
+                                                                    unsigned n_vox_total, int* __restrict__ starts,
+                                                                    int* __restrict__ lengths, const int* __restrict__ n_iv,
+                                                                    int* __restrict__ counts) {
+  const unsigned v = blockIdx.x * kBlock + threadIdx.x;
+  if (v == 0) {
+    counts[0] = S[n_vox_total];
+    counts[1] = *n_iv;
+  }
+  if (v >= n_vox_total) return;
+  const int len = S[v + 1] - S[v];
+  if (len > 0) {
+    starts[idx[v]] = S[v];
+    lengths[idx[v]] = len;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void lss_emit_ranks_kernel(const unsigned* __restrict__ sorted_keys,
+                                                                const int* __restrict__ sorted_pts, const int* __restrict__ S,
+                                                                unsigned n_vox_total, int DHW, int HW,
+                                                                int* __restrict__ ranks_bev, int* __restrict__ ranks_depth,
+                                                                int* __restrict__ ranks_feat) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= S[n_vox_total]) return;
+  const int p = sorted_pts[i];
+  ranks_bev[i] = (int)sorted_keys[i];
+  ranks_depth[i] = p;                                   // the point's own flat index (:232-236)
+  ranks_feat[i] = (p / DHW) * HW + p % HW;              // (b*N + n)*H*W + h*W + w
+}
+
+// ---------------------------------------------------------------------------------------------
+// HT: one lane group per (b, pillar), one lane per camera; candidates in (camera, height) order.
+// ---------------------------------------------------------------------------------------------
+struct HtParams {
+  int B, N, Z, Nq, Wf, Hf, D;
+  float sx, ox, sy, oy, sz, oz;      // pc_range scale / offset (view_transformer_ocrf.py:690-692)
+  float w_in, h_in, d0, dspan;       // image size, depth_range[0], depth_range[1]-depth_range[0]
+};
+
+// G = lanes per pillar (power of two >= N, <= 64): lane g of a group handles camera g of the pillar
+// and its Z heights; the group's lanes meet through shuffles (count of the pillar, prefix over its
+// cameras), so the output order inside a pillar is (camera, height) ascending.
+template <bool EMIT>
+__global__ __launch_bounds__(kBlock) void ht_pillar_kernel(HtParams q, int G, const float* __restrict__ ref /*(Z,Nq,3) normalised*/,
+                                                           const HtCam* __restrict__ cams,
+                                                           long long* __restrict__ cnt_flag /*count: out; emit: scanned*/,
+                                                           int* __restrict__ ranks_bev, int* __restrict__ ranks_depth,
+                                                           int* __restrict__ ranks_feat, int* __restrict__ starts,
+                                                           int* __restrict__ lengths) {
+  const long gtid = (long)blockIdx.x * kBlock + threadIdx.x;
+  const int t = (int)(gtid / G);                 // b*Nq + pillar
+  const int n = (int)(gtid % G);                 // camera
+  const bool active = t < q.B * q.Nq && n < q.N;
+  const int tt = min(t, q.B * q.Nq - 1);
+  const int b = tt / q.Nq, pil = tt - b * q.Nq;
+  const float eps = 1e-5f;
+  const HtCam& c = cams[b * q.N + min(n, q.N - 1)];
+  // pass 1 over the heights: validity bits; the cells are recomputed for the valid ones below, once
+  // the lane knows its offset inside the pillar
+  unsigned valid = 0;
+  for (int z = 0; z < q.Z; ++z) {
+    const float* r = ref + ((long)z * q.Nq + pil) * 3;
+    const float x = r[0] * q.sx + q.ox;
+    const float y = r[1] * q.sy + q.oy;
+    const float zz = r[2] * q.sz + q.oz;
+    // lidar2img rows, then perspective divide and the image augmentation (:700-722)
+    const float cx = c.l2i[0] * x + c.l2i[1] * y + c.l2i[2] * zz + c.l2i[3] * 1.0f;
+    const float cy = c.l2i[4] * x + c.l2i[5] * y + c.l2i[6] * zz + c.l2i[7] * 1.0f;
+    const float cz = c.l2i[8] * x + c.l2i[9] * y + c.l2i[10] * zz + c.l2i[11] * 1.0f;
+    bool m = cz > eps;
+    const float den = fmaxf(cz, eps);
+    const float u0 = cx / den, v0 = cy / den;
+    float u = c.aug[0] * u0 + c.aug[1] * v0 + c.aug[2] * cz + c.aug[3] * 1.0f;
+    float v = c.aug[4] * u0 + c.aug[5] * v0 + c.aug[6] * cz + c.aug[7] * 1.0f;
+    u = u / q.w_in;
+    v = v / q.h_in;
+    const float d = (cz - q.d0) / q.dspan;
+    m = m && (u > 0.0f) && (u < 1.0f) && (v > 0.0f) && (v < 1.0f) && (d > 0.0f) && (d < 1.0f);
+    if (!(m && active)) continue;
+    valid |= 1u << z;
+  }
+  const int cnt = __popc(valid);
+  // inclusive prefix of cnt over the G lanes of the group, and the group's total
+  int inc = cnt;
+  for (int off = 1; off < G; off <<= 1) {
+    const int o = __shfl_up(inc, off, G);
+    if (n >= off) inc += o;
+  }
+  const int total = __shfl(inc, G - 1, G);
+  if (!EMIT) {
+    if (n == 0 && t < q.B * q.Nq) cnt_flag[t] = ((long long)total << 32) | (total > 0 ? 1ll : 0ll);   // two prefix sums, one scan
+    return;
+  }
+  if (t >= q.B * q.Nq) return;
+  const long long cf = cnt_flag[t];
+  const int out0 = (int)(cf >> 32);
+  if (n == 0 && total > 0) {
+    const int k = (int)(cf & 0xFFFFFFFFll);
+    starts[k] = out0;
+    lengths[k] = total;
+  }
+  if (cnt == 0) return;
+  int out = out0 + inc - cnt;
+  for (int z = 0; z < q.Z; ++z) {
+    if (!((valid >> z) & 1u)) continue;
+    const float* r = ref + ((long)z * q.Nq + pil) * 3;
+    const float x = r[0] * q.sx + q.ox;
+    const float y = r[1] * q.sy + q.oy;
+    const float zz = r[2] * q.sz + q.oz;
+    const float cx = c.l2i[0] * x + c.l2i[1] * y + c.l2i[2] * zz + c.l2i[3] * 1.0f;
+    const float cy = c.l2i[4] * x + c.l2i[5] * y + c.l2i[6] * zz + c.l2i[7] * 1.0f;
+    const float cz = c.l2i[8] * x + c.l2i[9] * y + c.l2i[10] * zz + c.l2i[11] * 1.0f;
+    const float den = fmaxf(cz, eps);
+    const float u0 = cx / den, v0 = cy / den;
+    float u = c.aug[0] * u0 + c.aug[1] * v0 + c.aug[2] * cz + c.aug[3] * 1.0f;
+    float v = c.aug[4] * u0 + c.aug[5] * v0 + c.aug[6] * cz + c.aug[7] * 1.0f;
+    u = u / q.w_in;
+    v = v / q.h_in;
+    const float d = (cz - q.d0) / q.dspan;
+    // (coor * (W,H,D)).round().long(), clamped to the map (:806-813); rintf = half-to-even
+    long long iw = (long long)rintf(u * (float)q.Wf);
+    long long ih = (long long)rintf(v * (float)q.Hf);
+    long long id = (long long)rintf(d * (float)q.D);
+    iw = min(max(iw, 0ll), (long long)q.Wf - 1);
+    ih = min(max(ih, 0ll), (long long)q.Hf - 1);
+    id = min(max(id, 0ll), (long long)q.D - 1);
+    const long long cam = (long long)b * q.N + n;
+    const long long hw = (long long)q.Wf * q.Hf;
+    long long rd = cam * (q.D * hw) + id * hw + ih * q.Wf + iw;
+    long long rf = cam * hw + ih * q.Wf + iw;
+    rd = min(max(rd, 0ll), (long long)q.B * q.N * q.D * hw - 1);
+    rf = min(max(rf, 0ll), (long long)q.B * q.N * hw - 1);
+    ranks_bev[out] = t;                     // b*Nq + pillar
+    ranks_depth[out] = (int)rd;
+    ranks_feat[out] = (int)rf;
+    ++out;
+  }
+}
+
+__global__ void ht_counts_kernel(const long long* __restrict__ total, int* __restrict__ counts) {
+  counts[0] = (int)(*total >> 32);
+  counts[1] = (int)(*total & 0xFFFFFFFFll);
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+inline int radix_passes(unsigned n_vox_total) {
+  int bits = 1;
+  while (bits < 32 && (1ull << bits) <= (unsigned long long)n_vox_total) ++bits;
+  return (bits + kRadixBits - 1) / kRadixBits;
+}
+
+struct LssWs {
+  size_t keys_a, keys_b, vals_a, vals_b, table, S, flags, total, scratch, bytes;
+};
+
+inline void lss_layout(long n_pts, unsigned n_vox_total, LssWs* w) {
+  size_t off = 0;
+  auto take = [&](size_t b) { size_t o = off; off += align_up(b, 256); return o; };
+  const long n_wg = (n_pts + kChunk - 1) / kChunk;
+  w->keys_a = take((size_t)n_pts * 4);
+  w->keys_b = take((size_t)n_pts * 4);
+  w->vals_a = take((size_t)n_pts * 4);
+  w->vals_b = take((size_t)n_pts * 4);
+  w->table = take((size_t)kBins * n_wg * 4);
+  w->S = take(((size_t)n_vox_total + 1) * 4);
+  w->flags = take(((size_t)n_vox_total + 1) * 4);
+  w->total = take(256);
+  const size_t longest = (size_t)kBins * n_wg > (size_t)n_vox_total ? (size_t)kBins * n_wg : (size_t)n_vox_total;
+  w->scratch = take(((longest + kChunk - 1) / kChunk + 1) * 4);
+  w->bytes = off;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ocrf_lss_prepare_workspace_bytes(int B, int N, int D, int H, int W, int gx, int gy, int gz) {
+  if (B <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0 || gx <= 0 || gy <= 0 || gz <= 0) return 0;
+  LssWs w;
+  lss_layout((long)B * N * D * H * W, (unsigned)((long)B * gz * gy * gx), &w);
+  return w.bytes;
+}
+
+int ocrf_lss_prepare(int B, int N, int D, int H, int W, const float* frustum, const float* cams,
+                     const float* grid_lower, const float* grid_interval, int gx, int gy, int gz,
+                     int* ranks_bev, int* ranks_depth, int* ranks_feat, int* interval_starts,
+                     int* interval_lengths, int* counts, void* workspace, size_t workspace_bytes,
+                     ocrf_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (B <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0 || gx <= 0 || gy <= 0 || gz <= 0 || !frustum || !cams ||
+      !grid_lower || !grid_interval || !ranks_bev || !ranks_depth || !ranks_feat || !interval_starts ||
+      !interval_lengths || !counts)
+    return (int)hipErrorInvalidValue;
+  const long n_pts_l = (long)B * N * D * H * W;
+  const long n_vox_l = (long)B * gz * gy * gx;
+  if (n_pts_l >= (1l << 31) - kChunk || n_vox_l >= (1l << 31) - 1) return (int)hipErrorInvalidValue;
+  const int n_pts = (int)n_pts_l;
+  const unsigned n_vox_total = (unsigned)n_vox_l;
+  LssWs w;
+  lss_layout(n_pts, n_vox_total, &w);
+  if (!workspace || workspace_bytes < w.bytes) return (int)hipErrorInvalidValue;
+  char* base = static_cast<char*>(workspace);
+  unsigned* keys[2] = {reinterpret_cast<unsigned*>(base + w.keys_a), reinterpret_cast<unsigned*>(base + w.keys_b)};
+  int* vals[2] = {reinterpret_cast<int*>(base + w.vals_a), reinterpret_cast<int*>(base + w.vals_b)};
+  int* table = reinterpret_cast<int*>(base + w.table);
+  int* S = reinterpret_cast<int*>(base + w.S);
+  int* flags = reinterpret_cast<int*>(base + w.flags);
+  int* total = reinterpret_cast<int*>(base + w.total);
+  int* scratch = reinterpret_cast<int*>(base + w.scratch);
+  const int n_wg = (n_pts + kChunk - 1) / kChunk;
+  // the grid constants are read on the host side of the ABI (6 floats); they are host memory
+  const float lx = grid_lower[0], ly = grid_lower[1], lz = grid_lower[2];
+  const float ix = grid_interval[0], iy = grid_interval[1], iz = grid_interval[2];
+
+  ocrf::launch(OCRF_K_LSS_KEYS, lss_keys_kernel, dim3((n_pts + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, n_pts, N,
+               D * H * W, frustum, reinterpret_cast<const LssCam*>(cams), lx, ly, lz, ix, iy, iz, gx, gy, gz, n_vox_total,
+               keys[0]);
+  const int passes = radix_passes(n_vox_total);
+  int cur = 0;
+  for (int pass = 0; pass < passes; ++pass) {
+    const int shift = pass * kRadixBits;
+    ocrf::launch(OCRF_K_RADIX_HIST, radix_hist_kernel, dim3(n_wg), dim3(kBlock), 0, stream,
+                 static_cast<const unsigned*>(keys[cur]), n_pts, shift, n_wg, table);
+    scan_exclusive<int>(table, (long)kBins * n_wg, (int*)nullptr, scratch, stream);
+    if (pass == 0)
+      ocrf::launch(OCRF_K_RADIX_SCATTER, radix_scatter_kernel<true>, dim3(n_wg), dim3(kBlock), 0, stream,
+                   static_cast<const unsigned*>(keys[cur]), static_cast<const int*>(nullptr), n_pts, shift, n_wg,
+                   static_cast<const int*>(table), keys[cur ^ 1], vals[cur ^ 1]);
+    else
+      ocrf::launch(OCRF_K_RADIX_SCATTER, radix_scatter_kernel<false>, dim3(n_wg), dim3(kBlock), 0, stream,
+                   static_cast<const unsigned*>(keys[cur]), static_cast<const int*>(vals[cur]), n_pts, shift, n_wg,
+                   static_cast<const int*>(table), keys[cur ^ 1], vals[cur ^ 1]);
+    cur ^= 1;
+  }
+  const int vgrid = (int)((n_vox_total + 1 + kBlock - 1) / kBlock);
+  ocrf::launch(OCRF_K_LSS_BOUNDS, lower_bound_kernel, dim3(vgrid), dim3(kBlock), 0, stream,
+               static_cast<const unsigned*>(keys[cur]), n_pts, n_vox_total, S);
+  hipLaunchKernelGGL(nonempty_flags_kernel, dim3(vgrid), dim3(kBlock), 0, stream, static_cast<const int*>(S), n_vox_total,
+                     flags);
+  scan_exclusive<int>(flags, (long)n_vox_total, total, scratch, stream);
+  hipLaunchKernelGGL(lss_emit_intervals_kernel, dim3(vgrid), dim3(kBlock), 0, stream, static_cast<const int*>(S),
+                     static_cast<const int*>(flags), n_vox_total, interval_starts, interval_lengths,
+                     static_cast<const int*>(total), counts);
+  ocrf::launch(OCRF_K_LSS_EMIT, lss_emit_ranks_kernel, dim3((n_pts + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
+               static_cast<const unsigned*>(keys[cur]), static_cast<const int*>(vals[cur]), static_cast<const int*>(S),
+               n_vox_total, D * H * W, H * W, ranks_bev, ranks_depth, ranks_feat);
+  return (int)hipGetLastError();
+}
+
+size_t ocrf_ht_prepare_workspace_bytes(int B, int n_pillars) {
+  if (B <= 0 || n_pillars <= 0) return 0;
+  const size_t n = (size_t)B * n_pillars;
+  return align_up(n * 8, 256) + 256 + align_up(((n + kChunk - 1) / kChunk + 1) * 8, 256);
+}
+
+int ocrf_ht_prepare(int B, int N, int Z, int n_pillars, int Wf, int Hf, int D, const float* ref_points,
+                    const float* cams, const float* pc_range, float w_in, float h_in, float depth0,
+                    float depth1, int* ranks_bev, int* ranks_depth, int* ranks_feat, int* interval_starts,
+                    int* interval_lengths, int* counts, void* workspace, size_t workspace_bytes,
+                    ocrf_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (B <= 0 || N <= 0 || N > 64 || Z <= 0 || Z > 32 || n_pillars <= 0 || Wf <= 0 || Hf <= 0 || D <= 0 || !ref_points || !cams ||
+      !pc_range || !ranks_bev || !ranks_depth || !ranks_feat || !interval_starts || !interval_lengths || !counts)
+    return (int)hipErrorInvalidValue;
+  if ((long)B * N * Z * n_pillars >= (1l << 31) - 1 || (long)B * N * D * Wf * Hf >= (1l << 31) - 1)
+    return (int)hipErrorInvalidValue;
+  const size_t need = ocrf_ht_prepare_workspace_bytes(B, n_pillars);
+  if (!workspace || workspace_bytes < need) return (int)hipErrorInvalidValue;
+  long long* cnt_flag = static_cast<long long*>(workspace);
+  long long* total = reinterpret_cast<long long*>(static_cast<char*>(workspace) + align_up((size_t)B * n_pillars * 8, 256));
+  long long* scratch = total + 32;
+  HtParams q;
+  q.B = B; q.N = N; q.Z = Z; q.Nq = n_pillars; q.Wf = Wf; q.Hf = Hf; q.D = D;
+  // scale / offset as float32 scalars of double differences: what `tensor * python_float` does
+  q.sx = (float)((double)pc_range[3] - (double)pc_range[0]); q.ox = pc_range[0];
+  q.sy = (float)((double)pc_range[4] - (double)pc_range[1]); q.oy = pc_range[1];
+  q.sz = (float)((double)pc_range[5] - (double)pc_range[2]); q.oz = pc_range[2];
+  q.w_in = w_in; q.h_in = h_in; q.d0 = depth0; q.dspan = (float)((double)depth1 - (double)depth0);
+  int G = 1;
+  while (G < N) G <<= 1;                      // lanes per pillar
+  const int grid = (int)(((long)B * n_pillars * G + kBlock - 1) / kBlock);
+  ocrf::launch(OCRF_K_HT_COUNT, ht_pillar_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, q, G, ref_points,
+               reinterpret_cast<const HtCam*>(cams), cnt_flag, (int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)nullptr,
+               (int*)nullptr);
+  scan_exclusive<long long>(cnt_flag, (long)B * n_pillars, total, scratch, stream);
+  ocrf::launch(OCRF_K_HT_EMIT, ht_pillar_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, q, G, ref_points,
+               reinterpret_cast<const HtCam*>(cams), cnt_flag, ranks_bev, ranks_depth, ranks_feat, interval_starts,
+               interval_lengths);
+  hipLaunchKernelGGL(ht_counts_kernel, dim3(1), dim3(1), 0, stream, static_cast<const long long*>(total), counts);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

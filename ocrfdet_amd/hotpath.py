@@ -41,11 +41,16 @@ class PoolPlan:
 
 
 class HotPath:
-    def __init__(self, cfg, device, cams=None):
-        """``cams``: optional list of camera indices this instance owns (camera sharding)."""
+    def __init__(self, cfg, device, cams=None, index_prep_mode='cached'):
+        """``cams``: optional list of camera indices this instance owns (camera sharding).
+        ``index_prep_mode``: 'cached' — rank vectors computed once per calibration, the reference's
+        ``accelerate=True`` intent; 'per_step' — recomputed inside every ``step()`` by the HIP index
+        preparation (csrc/index_prep.hip), what the reference does with ``accelerate=False``."""
         self.cfg, self.device = cfg, torch.device(device)
         self.cams = list(range(cfg.n_cams)) if cams is None else list(cams)
         self.batch = cfg.batch * cfg.n_frames                  # frames ride along as batch entries
+        assert index_prep_mode in ('cached', 'per_step')
+        self.index_prep_mode = index_prep_mode
         self._prepare()
 
     def _prepare(self):
@@ -75,6 +80,14 @@ class HotPath:
         self.voxel_xyz = ref                                    # metric voxel centres (B, Zh, Y*X, 3)
         self.ht = PoolPlan(*self._or_empty(index_prep.fast_sample_prepare(coor, mask, Wf, Hf, cfg.D)),
                            (self.batch, 1, Y, X, C))
+        # inputs of the per-step HIP preparation: init-time templates on the device, calibration on
+        # the host (its 3x3 algebra is a handful of tiny torch calls per step, like the reference's)
+        self._calib_host = [a.cpu() for a in args]
+        self._frustum_dev = frustum.to(dev).contiguous()
+        self._ref_template = index_prep.get_reference_points_3d(Y, X, bs=1, num_points_in_pillar=cfg.num_height,
+                                                                device='cpu')[0].to(dev).contiguous()
+        self._grid = (lower, interval, size)
+        self._lss_bufs, self._ht_bufs = index_prep._RankBuffers(), index_prep._RankBuffers()
 
         if cfg.render:
             self._prepare_render(r)
@@ -188,10 +201,38 @@ class HotPath:
         return bevpool.bev_pool_v2_collapsed(depth, feat, plan.ranks_depth, plan.ranks_feat,
                                              plan.ranks_bev, plan.bev_shape, plan.starts, plan.lengths)
 
+    def prepare_indices_hip(self, sync=True):
+        """Rank vectors of both poolings from the calibration, on the device (view_transformer.py:108-147,
+        197-255; view_transformer_ocrf.py:675-740,785-852): tiny per-camera algebra on the host, one
+        small upload each, then csrc/index_prep.hip.  -> (lss PoolPlan, ht PoolPlan)."""
+        cfg, dev = self.cfg, self.device
+        X, Y, Z = cfg.bev_xyz
+        Hf, Wf = cfg.feat_hw
+        args = self._calib_host
+        B, N = args[1].shape[:2]
+        lss_block = index_prep.lss_camera_block(*args).to(dev, non_blocking=True)
+        lidar2img, img_aug, _, _ = index_prep.get_projection(*args)
+        ht_block = index_prep.ht_camera_block(lidar2img, img_aug).to(dev, non_blocking=True)
+        lss = index_prep.voxel_pooling_prepare_v2_hip(self._frustum_dev, lss_block, B, N, *self._grid,
+                                                      buffers=self._lss_bufs, sync=False)
+        ht = index_prep.fast_sample_prepare_hip(self._ref_template, ht_block, B, N, list(cfg.pc_range), cfg.input_size,
+                                                cfg.grid['depth'], Wf, Hf, cfg.D, buffers=self._ht_bufs, sync=False)
+        if not sync:
+            return lss, ht                                      # ((five capacity vectors), counts) each
+        counts = torch.stack((lss[1], ht[1])).cpu()           # ONE device->host read for both (4 ints)
+        return (PoolPlan(*self._or_empty(index_prep._trim(lss[0], counts[0])), (self.batch, Z, Y, X, cfg.channels)),
+                PoolPlan(*self._or_empty(index_prep._trim(ht[0], counts[1])), (self.batch, 1, Y, X, cfg.channels)))
+
     def step(self, depth, feat):
         """One pass: LSS BEV (B, Z*C, Y, X) and HT BEV (B, C, Y, X) (view_transformer.py:194,
         view_transformer_ocrf.py:781)."""
-        lss, ht = self.pool(self.lss, depth, feat), self.pool(self.ht, depth, feat)
+        if self.index_prep_mode == 'per_step':
+            # ranks stay on the device, their lengths too: no host read anywhere in the step
+            (lv, lc), (hv, hc) = self.prepare_indices_hip(sync=False)
+            lss = bevpool.bev_pool_v2_device_counts(depth, feat, lv[1], lv[2], lv[0], self.lss.bev_shape, lv[3], lv[4], lc)
+            ht = bevpool.bev_pool_v2_device_counts(depth, feat, hv[1], hv[2], hv[0], self.ht.bev_shape, hv[3], hv[4], hc)
+        else:
+            lss, ht = self.pool(self.lss, depth, feat), self.pool(self.ht, depth, feat)
         out = [lss, ht]
         if self.cfg.render:
             out.append(self.render())

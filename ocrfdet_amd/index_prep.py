@@ -15,14 +15,25 @@ Split of work (DESIGN.md "index preparation"):
     what makes the voxel indices bit-exact against vectors dumped from the reference
     (tests/test_index_prep.py), on the CPU and on the GPU alike.
 
-The functions are device-agnostic torch code (plumbing); the sort is ``torch.sort(stable=True)``
-where the reference's ``argsort`` is unstable, so the order inside an interval is deterministic
-here and unspecified there.
+The functions above the "HIP" section are device-agnostic torch code (plumbing); the sort is
+``torch.sort(stable=True)`` where the reference's ``argsort`` is unstable, so the order inside an
+interval is deterministic here and unspecified there.
+
+HIP section (``voxel_pooling_prepare_v2_hip``, ``fast_sample_prepare_hip``): the same two
+preparations as fused device kernels (csrc/index_prep.hip, C ABI ``ocrf_lss_prepare`` /
+``ocrf_ht_prepare``) — per-point arithmetic, an LSD radix sort shaped for voxel-id keys (LSS) or no
+sort at all (HT), intervals — a dozen launches instead of ~40 torch passes and two argsorts, with
+identical outputs (tests/test_index_prep_gpu.py).
 """
+import ctypes
+
 import torch
 
+from . import _lib
+
 __all__ = ['create_frustum', 'get_lidar_coor', 'voxel_pooling_prepare_v2', 'get_reference_points_3d',
-           'get_projection', 'get_sampling_point', 'fast_sample_prepare', 'grid_infos']
+           'get_projection', 'get_sampling_point', 'fast_sample_prepare', 'grid_infos',
+           'lss_camera_block', 'ht_camera_block', 'voxel_pooling_prepare_v2_hip', 'fast_sample_prepare_hip']
 
 
 def grid_infos(grid_config):
@@ -196,3 +207,101 @@ def fast_sample_prepare(coor, mask, W, H, D):
     starts, lengths = _runs(ranks_bev)
     return (ranks_bev.int().contiguous(), ranks_depth[order].int().contiguous(),
             ranks_feat[order].int().contiguous(), starts, lengths)
+
+
+# ----------------------------------------------------------------------------------------------
+# HIP
+# ----------------------------------------------------------------------------------------------
+def lss_camera_block(rots, trans, cam2imgs, post_rots, post_trans, bda):
+    """(B*N, 33) float32: inv(post_rots) | rots.inv(cam2imgs) | post_trans | trans | bda per
+    camera-frame — the tiny algebra of get_lidar_coor (view_transformer.py:128-146), made with the
+    same torch calls on whatever device the calibration lives on."""
+    B, N = trans.shape[:2]
+    inv_post = torch.inverse(post_rots).reshape(B * N, 9)
+    combine = rots.matmul(torch.inverse(cam2imgs)).reshape(B * N, 9)
+    bda_n = bda.view(B, 1, 9).expand(B, N, 9).reshape(B * N, 9)
+    return torch.cat((inv_post, combine, post_trans.reshape(B * N, 3), trans.reshape(B * N, 3), bda_n), 1).float().contiguous()
+
+
+def ht_camera_block(lidar2img, img_aug):
+    """(B*N, 24) float32: lidar2img 3x4 | img_aug 3x4 per camera-frame (get_projection)."""
+    B, N = lidar2img.shape[:2]
+    return torch.cat((lidar2img.reshape(B * N, 12), img_aug.reshape(B * N, 12)), 1).float().contiguous()
+
+
+class _RankBuffers:
+    """Grow-only output buffers of one preparation (rank vectors at their capacity)."""
+
+    def __init__(self):
+        self.cap_pts = self.cap_iv = 0
+
+    def get(self, dev, n_pts, n_iv):
+        if n_pts > self.cap_pts or n_iv > self.cap_iv or self.bufs[0].device != dev:
+            self.cap_pts, self.cap_iv = max(n_pts, self.cap_pts), max(n_iv, self.cap_iv)
+            self.bufs = [torch.empty(self.cap_pts, dtype=torch.int32, device=dev) for _ in range(3)] + \
+                        [torch.empty(self.cap_iv, dtype=torch.int32, device=dev) for _ in range(2)] + \
+                        [torch.zeros(2, dtype=torch.int32, device=dev)]
+        return self.bufs
+
+
+def _trim(bufs, counts_host):
+    n_p, n_v = int(counts_host[0]), int(counts_host[1])
+    if n_p == 0:
+        return None, None, None, None, None
+    return bufs[0][:n_p], bufs[1][:n_p], bufs[2][:n_p], bufs[3][:n_v], bufs[4][:n_v]
+
+
+def voxel_pooling_prepare_v2_hip(frustum, cam_block, B, N, grid_lower_bound, grid_interval, grid_size,
+                                 buffers=None, sync=True):
+    """HIP ``get_lidar_coor`` + ``voxel_pooling_prepare_v2`` (view_transformer.py:108-147,197-255).
+
+    ``frustum`` (D,H,W,3) and ``cam_block`` (B*N,33, ``lss_camera_block``) on the device; the grid
+    tensors are the host tensors of ``grid_infos``.  Returns ranks_bev, ranks_depth, ranks_feat,
+    interval_starts, interval_lengths (int32 views of ``buffers``, or five ``None``); with
+    ``sync=False`` returns ``(buffers, counts)`` untrimmed and does not read the device."""
+    _lib.require_cuda(frustum, cam_block)
+    dev = frustum.device
+    D, H, W, _ = frustum.shape
+    gx, gy, gz = (int(v) for v in grid_size.tolist())
+    lower = grid_lower_bound.detach().float().cpu().contiguous()
+    interval = grid_interval.detach().float().cpu().contiguous()
+    n_pts = B * N * D * H * W
+    bufs = (buffers if buffers is not None else _RankBuffers()).get(dev, n_pts, min(n_pts, B * gz * gy * gx))
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        need = L.ocrf_lss_prepare_workspace_bytes(B, N, D, H, W, gx, gy, gz)
+        ws = _lib.workspace.get(dev, need, 'index_prep')
+        _lib.check(L.ocrf_lss_prepare(
+            B, N, D, H, W, _lib.ptr(frustum.contiguous()), _lib.ptr(cam_block), ctypes.c_void_p(lower.data_ptr()),
+            ctypes.c_void_p(interval.data_ptr()), gx, gy, gz, *[_lib.ptr(b) for b in bufs], _lib.ptr(ws),
+            ctypes.c_size_t(ws.numel()), _lib.stream_ptr(dev)), 'ocrf_lss_prepare')
+    if not sync:
+        return bufs[:5], bufs[5]
+    return _trim(bufs, bufs[5].cpu())
+
+
+def fast_sample_prepare_hip(ref_template, cam_block, B, N, pc_range, image_shapes, depth_range, W, H, D,
+                            buffers=None, sync=True):
+    """HIP ``get_sampling_point`` + ``fast_sample_prepare`` (view_transformer_ocrf.py:687-740,785-852).
+
+    ``ref_template`` (Z,Nq,3): one sample of ``get_reference_points_3d`` (normalised, NOT yet scaled
+    to metres); ``cam_block`` (B*N,24) from ``ht_camera_block``; ``image_shapes`` = (H_in, W_in);
+    ``W``/``H``/``D``: feature-map size and depth bins.  Returns like ``voxel_pooling_prepare_v2_hip``."""
+    _lib.require_cuda(ref_template, cam_block)
+    dev = ref_template.device
+    Z, Nq, _ = ref_template.shape
+    pc = torch.tensor([float(v) for v in pc_range], dtype=torch.float32)
+    n_pts = B * N * Z * Nq
+    bufs = (buffers if buffers is not None else _RankBuffers()).get(dev, n_pts, B * Nq)
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        need = L.ocrf_ht_prepare_workspace_bytes(B, Nq)
+        ws = _lib.workspace.get(dev, need, 'index_prep')
+        _lib.check(L.ocrf_ht_prepare(
+            B, N, Z, Nq, int(W), int(H), int(D), _lib.ptr(ref_template.contiguous()), _lib.ptr(cam_block),
+            ctypes.c_void_p(pc.data_ptr()), ctypes.c_float(image_shapes[1]), ctypes.c_float(image_shapes[0]),
+            ctypes.c_float(depth_range[0]), ctypes.c_float(depth_range[1]), *[_lib.ptr(b) for b in bufs], _lib.ptr(ws),
+            ctypes.c_size_t(ws.numel()), _lib.stream_ptr(dev)), 'ocrf_ht_prepare')
+    if not sync:
+        return bufs[:5], bufs[5]
+    return _trim(bufs, bufs[5].cpu())
