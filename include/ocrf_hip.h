@@ -336,8 +336,8 @@ enum {
   OCRF_K_RADIX_SCATTER = 43,     /* radix_scatter_kernel<*> */
   OCRF_K_LSS_BOUNDS = 44,        /* lower_bound_kernel */
   OCRF_K_LSS_EMIT = 45,          /* lss_emit_ranks_kernel */
-  OCRF_K_HT_COUNT = 46,          /* ht_pillar_kernel<false> */
-  OCRF_K_HT_EMIT = 47            /* ht_pillar_kernel<true> */
+  OCRF_K_HT_COUNT = 46,          /* ht_valid_kernel */
+  OCRF_K_HT_EMIT = 47            /* ht_emit_kernel */
 };
 const char *ocrf_kernel_name(int kernel_id);           /* symbol as rocprofv3 prints it */
 int ocrf_timer_create(int capacity, void **timer_out); /* host pointers */

@@ -68,8 +68,8 @@ const char* ocrf_kernel_name(int kernel_id) {
     case OCRF_K_RADIX_SCATTER: return "radix_scatter_kernel<*>";
     case OCRF_K_LSS_BOUNDS: return "lower_bound_kernel";
     case OCRF_K_LSS_EMIT: return "lss_emit_ranks_kernel";
-    case OCRF_K_HT_COUNT: return "ht_pillar_kernel<false>";
-    case OCRF_K_HT_EMIT: return "ht_pillar_kernel<true>";
+    case OCRF_K_HT_COUNT: return "ht_valid_kernel";
+    case OCRF_K_HT_EMIT: return "ht_emit_kernel";
     default: return "";
   }
 }

@@ -16,8 +16,8 @@
 //     so the order inside an interval is ascending point index — deterministic where the
 //     reference's argsort is not); interval starts / lengths come from one binary search per voxel;
 //   * HT: the key is the pillar itself and a pillar's candidates are its (camera, height) pairs, so
-//     no sort is needed at all: a group of lanes per pillar (one per camera) counts, one scan over
-//     the pillars, emit in (camera, height) order.
+//     no sort is needed at all: validity bits per (camera, pillar), totals per pillar, one scan
+//     over the pillars, emit in (camera, height) order.
 // Tiny per-camera algebra (3x3 inverses and products) stays on the host, as the same torch calls the
 // reference makes; the kernels take the resulting per-camera blocks.
 #include <hip/hip_runtime.h>
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(kBlock) void lss_emit_ranks_kernel(const unsigned* 
 }
 
 // ---------------------------------------------------------------------------------------------
-// HT: one lane group per (b, pillar), one lane per camera; candidates in (camera, height) order.
+// HT: one thread per (camera-frame, pillar); candidates in (camera, height) order.
 // ---------------------------------------------------------------------------------------------
 struct HtParams {
   int B, N, Z, Nq, Wf, Hf, D;
@@ -316,86 +316,92 @@ struct HtParams {
   float w_in, h_in, d0, dspan;       // image size, depth_range[0], depth_range[1]-depth_range[0]
 };
 
-// G = lanes per pillar (power of two >= N, <= 64): lane g of a group handles camera g of the pillar
-// and its Z heights; the group's lanes meet through shuffles (count of the pillar, prefix over its
-// cameras), so the output order inside a pillar is (camera, height) ascending.
-template <bool EMIT>
-__global__ __launch_bounds__(kBlock) void ht_pillar_kernel(HtParams q, int G, const float* __restrict__ ref /*(Z,Nq,3) normalised*/,
-                                                           const HtCam* __restrict__ cams,
-                                                           long long* __restrict__ cnt_flag /*count: out; emit: scanned*/,
-                                                           int* __restrict__ ranks_bev, int* __restrict__ ranks_depth,
-                                                           int* __restrict__ ranks_feat, int* __restrict__ starts,
-                                                           int* __restrict__ lengths) {
-  const long gtid = (long)blockIdx.x * kBlock + threadIdx.x;
-  const int t = (int)(gtid / G);                 // b*Nq + pillar
-  const int n = (int)(gtid % G);                 // camera
-  const bool active = t < q.B * q.Nq && n < q.N;
-  const int tt = min(t, q.B * q.Nq - 1);
-  const int b = tt / q.Nq, pil = tt - b * q.Nq;
+// Lanes run over consecutive pillars of ONE camera-frame (blockIdx.y), so the reads of the pillar
+// template are coalesced and the cheap rejections (behind the camera, out of depth range) are
+// wave-coherent: a wave of pillars the camera does not see retires after a few instructions.
+// The tests are evaluated cheapest first; the mask is their conjunction, the order is free.
+__device__ __forceinline__ bool ht_project(const HtParams& q, const HtCam& c, float x, float y, float zz,
+                                           float* u_out, float* v_out, float* d_out) {
   const float eps = 1e-5f;
-  const HtCam& c = cams[b * q.N + min(n, q.N - 1)];
-  // pass 1 over the heights: validity bits; the cells are recomputed for the valid ones below, once
-  // the lane knows its offset inside the pillar
+  // lidar2img rows (the x, y products first, k ascending as in the reference), perspective divide,
+  // image augmentation, normalisation (view_transformer_ocrf.py:700-735)
+  const float cz = c.l2i[8] * x + c.l2i[9] * y + c.l2i[10] * zz + c.l2i[11] * 1.0f;
+  if (!(cz > eps)) return false;
+  const float d = (cz - q.d0) / q.dspan;
+  if (!((d > 0.0f) && (d < 1.0f))) return false;
+  const float cx = c.l2i[0] * x + c.l2i[1] * y + c.l2i[2] * zz + c.l2i[3] * 1.0f;
+  const float cy = c.l2i[4] * x + c.l2i[5] * y + c.l2i[6] * zz + c.l2i[7] * 1.0f;
+  const float den = fmaxf(cz, eps);
+  const float u0 = cx / den, v0 = cy / den;
+  float u = c.aug[0] * u0 + c.aug[1] * v0 + c.aug[2] * cz + c.aug[3] * 1.0f;
+  float v = c.aug[4] * u0 + c.aug[5] * v0 + c.aug[6] * cz + c.aug[7] * 1.0f;
+  u = u / q.w_in;
+  v = v / q.h_in;
+  *u_out = u; *v_out = v; *d_out = d;
+  return (u > 0.0f) && (u < 1.0f) && (v > 0.0f) && (v < 1.0f);
+}
+
+// valid_bits[cam][pillar]: bit z = sample (cam, z, pillar) passes the mask
+__global__ __launch_bounds__(kBlock) void ht_valid_kernel(HtParams q, const float* __restrict__ ref /*(Z,Nq,3) normalised*/,
+                                                          const HtCam* __restrict__ cams, unsigned* __restrict__ valid_bits) {
+  const int pil = blockIdx.x * kBlock + threadIdx.x;
+  const int cam = blockIdx.y;                  // b*N + n
+  if (pil >= q.Nq) return;
+  const HtCam& c = cams[cam];
   unsigned valid = 0;
   for (int z = 0; z < q.Z; ++z) {
     const float* r = ref + ((long)z * q.Nq + pil) * 3;
-    const float x = r[0] * q.sx + q.ox;
-    const float y = r[1] * q.sy + q.oy;
-    const float zz = r[2] * q.sz + q.oz;
-    // lidar2img rows, then perspective divide and the image augmentation (:700-722)
-    const float cx = c.l2i[0] * x + c.l2i[1] * y + c.l2i[2] * zz + c.l2i[3] * 1.0f;
-    const float cy = c.l2i[4] * x + c.l2i[5] * y + c.l2i[6] * zz + c.l2i[7] * 1.0f;
-    const float cz = c.l2i[8] * x + c.l2i[9] * y + c.l2i[10] * zz + c.l2i[11] * 1.0f;
-    bool m = cz > eps;
-    const float den = fmaxf(cz, eps);
-    const float u0 = cx / den, v0 = cy / den;
-    float u = c.aug[0] * u0 + c.aug[1] * v0 + c.aug[2] * cz + c.aug[3] * 1.0f;
-    float v = c.aug[4] * u0 + c.aug[5] * v0 + c.aug[6] * cz + c.aug[7] * 1.0f;
-    u = u / q.w_in;
-    v = v / q.h_in;
-    const float d = (cz - q.d0) / q.dspan;
-    m = m && (u > 0.0f) && (u < 1.0f) && (v > 0.0f) && (v < 1.0f) && (d > 0.0f) && (d < 1.0f);
-    if (!(m && active)) continue;
-    valid |= 1u << z;
+    float u, v, d;
+    if (ht_project(q, c, r[0] * q.sx + q.ox, r[1] * q.sy + q.oy, r[2] * q.sz + q.oz, &u, &v, &d)) valid |= 1u << z;
   }
-  const int cnt = __popc(valid);
-  // inclusive prefix of cnt over the G lanes of the group, and the group's total
-  int inc = cnt;
-  for (int off = 1; off < G; off <<= 1) {
-    const int o = __shfl_up(inc, off, G);
-    if (n >= off) inc += o;
-  }
-  const int total = __shfl(inc, G - 1, G);
-  if (!EMIT) {
-    if (n == 0 && t < q.B * q.Nq) cnt_flag[t] = ((long long)total << 32) | (total > 0 ? 1ll : 0ll);   // two prefix sums, one scan
-    return;
-  }
+  valid_bits[(long)cam * q.Nq + pil] = valid;
+}
+
+// per (b, pillar): number of kept samples over its cameras, packed with the non-empty flag so that
+// ONE scan gives both prefix sums
+__global__ __launch_bounds__(kBlock) void ht_pillar_totals_kernel(HtParams q, const unsigned* __restrict__ valid_bits,
+                                                                  long long* __restrict__ cnt_flag) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= q.B * q.Nq) return;
+  const int b = t / q.Nq, pil = t - b * q.Nq;
+  int total = 0;
+  for (int n = 0; n < q.N; ++n) total += __popc(valid_bits[((long)b * q.N + n) * q.Nq + pil]);
+  cnt_flag[t] = ((long long)total << 32) | (total > 0 ? 1ll : 0ll);
+}
+
+// emit in (camera, height) order inside a pillar = the reference's flattening order under a stable sort
+__global__ __launch_bounds__(kBlock) void ht_emit_kernel(HtParams q, const float* __restrict__ ref, const HtCam* __restrict__ cams,
+                                                         const unsigned* __restrict__ valid_bits,
+                                                         const long long* __restrict__ cnt_flag /*scanned*/,
+                                                         int* __restrict__ ranks_bev, int* __restrict__ ranks_depth,
+                                                         int* __restrict__ ranks_feat, int* __restrict__ starts,
+                                                         int* __restrict__ lengths) {
+  const int pil = blockIdx.x * kBlock + threadIdx.x;
+  const int cam = blockIdx.y;
+  if (pil >= q.Nq) return;
+  const int b = cam / q.N, n = cam - b * q.N;
+  const int t = b * q.Nq + pil;
+  const unsigned valid = valid_bits[(long)cam * q.Nq + pil];
+  if (n != 0 && valid == 0) return;
   const long long cf = cnt_flag[t];
-  const int out0 = (int)(cf >> 32);
-  if (n == 0 && total > 0) {
-    const int k = (int)(cf & 0xFFFFFFFFll);
-    starts[k] = out0;
-    lengths[k] = total;
+  int out = (int)(cf >> 32);
+  if (n == 0) {
+    int total = 0;
+    for (int m = 0; m < q.N; ++m) total += __popc(valid_bits[((long)b * q.N + m) * q.Nq + pil]);
+    if (total > 0) {
+      const int k = (int)(cf & 0xFFFFFFFFll);
+      starts[k] = out;
+      lengths[k] = total;
+    }
+    if (valid == 0) return;
   }
-  if (cnt == 0) return;
-  int out = out0 + inc - cnt;
+  for (int m = 0; m < n; ++m) out += __popc(valid_bits[((long)b * q.N + m) * q.Nq + pil]);
+  const HtCam& c = cams[cam];
   for (int z = 0; z < q.Z; ++z) {
     if (!((valid >> z) & 1u)) continue;
     const float* r = ref + ((long)z * q.Nq + pil) * 3;
-    const float x = r[0] * q.sx + q.ox;
-    const float y = r[1] * q.sy + q.oy;
-    const float zz = r[2] * q.sz + q.oz;
-    const float cx = c.l2i[0] * x + c.l2i[1] * y + c.l2i[2] * zz + c.l2i[3] * 1.0f;
-    const float cy = c.l2i[4] * x + c.l2i[5] * y + c.l2i[6] * zz + c.l2i[7] * 1.0f;
-    const float cz = c.l2i[8] * x + c.l2i[9] * y + c.l2i[10] * zz + c.l2i[11] * 1.0f;
-    const float den = fmaxf(cz, eps);
-    const float u0 = cx / den, v0 = cy / den;
-    float u = c.aug[0] * u0 + c.aug[1] * v0 + c.aug[2] * cz + c.aug[3] * 1.0f;
-    float v = c.aug[4] * u0 + c.aug[5] * v0 + c.aug[6] * cz + c.aug[7] * 1.0f;
-    u = u / q.w_in;
-    v = v / q.h_in;
-    const float d = (cz - q.d0) / q.dspan;
+    float u, v, d;
+    ht_project(q, c, r[0] * q.sx + q.ox, r[1] * q.sy + q.oy, r[2] * q.sz + q.oz, &u, &v, &d);
     // (coor * (W,H,D)).round().long(), clamped to the map (:806-813); rintf = half-to-even
     long long iw = (long long)rintf(u * (float)q.Wf);
     long long ih = (long long)rintf(v * (float)q.Hf);
@@ -403,10 +409,9 @@ __global__ __launch_bounds__(kBlock) void ht_pillar_kernel(HtParams q, int G, co
     iw = min(max(iw, 0ll), (long long)q.Wf - 1);
     ih = min(max(ih, 0ll), (long long)q.Hf - 1);
     id = min(max(id, 0ll), (long long)q.D - 1);
-    const long long cam = (long long)b * q.N + n;
     const long long hw = (long long)q.Wf * q.Hf;
-    long long rd = cam * (q.D * hw) + id * hw + ih * q.Wf + iw;
-    long long rf = cam * hw + ih * q.Wf + iw;
+    long long rd = (long long)cam * (q.D * hw) + id * hw + ih * q.Wf + iw;
+    long long rf = (long long)cam * hw + ih * q.Wf + iw;
     rd = min(max(rd, 0ll), (long long)q.B * q.N * q.D * hw - 1);
     rf = min(max(rf, 0ll), (long long)q.B * q.N * hw - 1);
     ranks_bev[out] = t;                     // b*Nq + pillar
@@ -530,7 +535,7 @@ int ocrf_lss_prepare(int B, int N, int D, int H, int W, const float* frustum, co
 size_t ocrf_ht_prepare_workspace_bytes(int B, int n_pillars) {
   if (B <= 0 || n_pillars <= 0) return 0;
   const size_t n = (size_t)B * n_pillars;
-  return align_up(n * 8, 256) + 256 + align_up(((n + kChunk - 1) / kChunk + 1) * 8, 256);
+  return align_up(n * 8, 256) + 256 + align_up(((n + kChunk - 1) / kChunk + 1) * 8, 256) + align_up(n * 64 * 4, 256);   // valid bits: up to 64 cameras
 }
 
 int ocrf_ht_prepare(int B, int N, int Z, int n_pillars, int Wf, int Hf, int D, const float* ref_points,
@@ -539,7 +544,7 @@ int ocrf_ht_prepare(int B, int N, int Z, int n_pillars, int Wf, int Hf, int D, c
                     int* interval_lengths, int* counts, void* workspace, size_t workspace_bytes,
                     ocrf_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (B <= 0 || N <= 0 || N > 64 || Z <= 0 || Z > 32 || n_pillars <= 0 || Wf <= 0 || Hf <= 0 || D <= 0 || !ref_points || !cams ||
+  if (B <= 0 || N <= 0 || N > 64 || Z <= 0 || Z > 32 || B * N > 65535 || n_pillars <= 0 || Wf <= 0 || Hf <= 0 || D <= 0 || !ref_points || !cams ||
       !pc_range || !ranks_bev || !ranks_depth || !ranks_feat || !interval_starts || !interval_lengths || !counts)
     return (int)hipErrorInvalidValue;
   if ((long)B * N * Z * n_pillars >= (1l << 31) - 1 || (long)B * N * D * Wf * Hf >= (1l << 31) - 1)
@@ -549,6 +554,8 @@ int ocrf_ht_prepare(int B, int N, int Z, int n_pillars, int Wf, int Hf, int D, c
   long long* cnt_flag = static_cast<long long*>(workspace);
   long long* total = reinterpret_cast<long long*>(static_cast<char*>(workspace) + align_up((size_t)B * n_pillars * 8, 256));
   long long* scratch = total + 32;
+  unsigned* valid_bits = reinterpret_cast<unsigned*>(
+      reinterpret_cast<char*>(scratch) + align_up((((size_t)B * n_pillars + kChunk - 1) / kChunk + 1) * 8, 256));
   HtParams q;
   q.B = B; q.N = N; q.Z = Z; q.Nq = n_pillars; q.Wf = Wf; q.Hf = Hf; q.D = D;
   // scale / offset as float32 scalars of double differences: what `tensor * python_float` does
@@ -556,16 +563,16 @@ int ocrf_ht_prepare(int B, int N, int Z, int n_pillars, int Wf, int Hf, int D, c
   q.sy = (float)((double)pc_range[4] - (double)pc_range[1]); q.oy = pc_range[1];
   q.sz = (float)((double)pc_range[5] - (double)pc_range[2]); q.oz = pc_range[2];
   q.w_in = w_in; q.h_in = h_in; q.d0 = depth0; q.dspan = (float)((double)depth1 - (double)depth0);
-  int G = 1;
-  while (G < N) G <<= 1;                      // lanes per pillar
-  const int grid = (int)(((long)B * n_pillars * G + kBlock - 1) / kBlock);
-  ocrf::launch(OCRF_K_HT_COUNT, ht_pillar_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, q, G, ref_points,
-               reinterpret_cast<const HtCam*>(cams), cnt_flag, (int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)nullptr,
-               (int*)nullptr);
+  const dim3 cgrid((n_pillars + kBlock - 1) / kBlock, B * N);
+  const int pgrid = (B * n_pillars + kBlock - 1) / kBlock;
+  const HtCam* hc = reinterpret_cast<const HtCam*>(cams);
+  ocrf::launch(OCRF_K_HT_COUNT, ht_valid_kernel, cgrid, dim3(kBlock), 0, stream, q, ref_points, hc, valid_bits);
+  hipLaunchKernelGGL(ht_pillar_totals_kernel, dim3(pgrid), dim3(kBlock), 0, stream, q,
+                     static_cast<const unsigned*>(valid_bits), cnt_flag);
   scan_exclusive<long long>(cnt_flag, (long)B * n_pillars, total, scratch, stream);
-  ocrf::launch(OCRF_K_HT_EMIT, ht_pillar_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, q, G, ref_points,
-               reinterpret_cast<const HtCam*>(cams), cnt_flag, ranks_bev, ranks_depth, ranks_feat, interval_starts,
-               interval_lengths);
+  ocrf::launch(OCRF_K_HT_EMIT, ht_emit_kernel, cgrid, dim3(kBlock), 0, stream, q, ref_points, hc,
+               static_cast<const unsigned*>(valid_bits), static_cast<const long long*>(cnt_flag), ranks_bev, ranks_depth,
+               ranks_feat, interval_starts, interval_lengths);
   hipLaunchKernelGGL(ht_counts_kernel, dim3(1), dim3(1), 0, stream, static_cast<const long long*>(total), counts);
   return (int)hipGetLastError();
 }
