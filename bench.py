@@ -9,6 +9,17 @@ synthetic input (seeded) that is already resident in HBM.  Rank 
 line; `value` = BEV voxels written per second by the whole job (both pools executed per voxel
 grid), with `roofline` for the dominant kernel (HIP-event timed inside the timed region) and
 `cpu_baseline` (the C oracle on this box's host cores, rank 0, N=1 only).
+
+N > 1 (`--shard`):
+  samples (default) — every rank owns whole samples (6 cameras x n_frames each), the layout of the
+      reference's own multi-GPU runs (tools/dist_test.sh -> MMDistributedDataParallel, one process
+      per GPU).  The hot path has no exchange step in this layout, so there is no data-path
+      collective; weak scaling.
+  frames  — every rank owns n_frames frames of ONE (world x n_frames)-frame sequence and one RCCL
+      all_gather per step hands every rank the fused BEV of all frames (the operand of the channel
+      concat, detectors/ocrfdet.py:274); weak scaling.
+  cameras — ONE sample, cameras split over min(world, n_cams) ranks (BASELINE.json configs[3]), one
+      RCCL all_reduce(sum) of the partial fused BEV per step, HOA replicated; strong scaling.
 """
 import argparse
 import json
@@ -33,6 +44,8 @@ def parse():
     ap.add_argument('--config', default=DEFAULT_CONFIG)
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU-baseline sample budget')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--shard', choices=('samples', 'frames', 'cameras'), default='samples')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL); gloo only for plumbing tests')
     ap.add_argument('--index-prep', choices=('cached', 'per_step'), default='cached',
                     help="'per_step': rank vectors recomputed by the HIP index preparation inside every step "
                          "(the reference with accelerate=False); 'cached': once per calibration (accelerate=True)")
@@ -97,29 +110,51 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    single_dev = os.environ.get('OCRF_BENCH_SINGLE_DEVICE') == '1'      # plumbing test: all ranks on cuda:0 (gloo)
+    if single_dev:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(args.backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
-    from ocrfdet_amd import _lib, hotpath, synthetic
+    from ocrfdet_amd import _lib, hotpath, sharding, synthetic
     _lib.lib()                      # raises if libocrf_hip.so is missing — no fallback
     cfg = synthetic.CONFIGS[args.config]
-    # weak scaling: every rank owns cfg.n_frames frames of a (world * n_frames)-frame sequence;
-    # frames are independent until the channel concat (detectors/ocrfdet.py:274)
-    hp = hotpath.HotPath(cfg, dev, index_prep_mode=args.index_prep)
-    depth, feat = hp.make_inputs(seed=rank)
-    # N > 1 (weak scaling, frame policy of ocrfdet_amd.sharding): every rank owns cfg.n_frames whole
-    # frames of a (world * n_frames)-frame sequence — frames are independent until the channel
-    # concat (detectors/ocrfdet.py:274) — and ONE RCCL all_gather per step hands every rank the
-    # fused (LSS | HT) BEV of all frames, the operand of that concat.
-    from ocrfdet_amd import sharding
+    shard = args.shard if world > 1 else 'none'
+    active = True
+    if shard == 'cameras':
+        # strong scaling of ONE sample: rank r < n_cams owns cameras r, r + world', ... (world' active ranks)
+        n_active = min(world, cfg.n_cams)
+        active = rank < n_active
+        my_cams = list(range(rank, cfg.n_cams, n_active)) if active else [0]
+        hp = hotpath.HotPath(cfg, dev, cams=my_cams, index_prep_mode=args.index_prep)
+    else:
+        hp = hotpath.HotPath(cfg, dev, index_prep_mode=args.index_prep)
+    depth, feat = hp.make_inputs(seed=0 if shard == 'cameras' else rank)
+    X, Y, Z = cfg.bev_xyz
 
     def step():
+        if shard == 'cameras':
+            # pools (+ render of the owned cameras) -> partial fused BEV -> ONE all_reduce -> HOA everywhere
+            if active:
+                lss, ht = hp.pool_step(depth, feat)
+                fused = torch.cat((lss, ht), 1)
+                if cfg.render:
+                    hp.render()
+            else:
+                fused = torch.zeros(hp.batch, (Z + 1) * cfg.channels, Y, X, device=dev)
+            sharding.reduce_partial_bev(fused)
+            if cfg.hoa:
+                hp.hoa_step(fused[:, Z * cfg.channels:])
+            return fused
         out = hp.step(depth, feat)
-        if world > 1:
+        if shard == 'frames':
             fused = torch.cat((out[0], out[-2] if cfg.hoa else out[1]), 1)       # (frames, Z*C + C, Y, X)
             sharding.gather_frames(fused, world * fused.shape[0])
         return out
@@ -171,13 +206,16 @@ def main():
             rec = json.load(open(pmc)).get(timer.kernel_name.split('<')[0])
             if rec:
                 traffic, traffic_src = rec['hbm_bytes_corrected'], 'profiles/r1_pmc_traffic.json'
-        voxels = hp.bev_voxels_per_step * world * args.steps
+        strong = shard == 'cameras'
+        voxels = hp.bev_voxels_per_step * (1 if strong else world) * args.steps
         out = {
             'metric': 'BEV voxels/sec + rendered views/sec, 6-cam 256x704',
             'value': voxels / elapsed, 'unit': 'BEV voxels/s',
-            'rendered_views_per_sec': hp.views_per_step * world * args.steps / elapsed,
+            'rendered_views_per_sec': (cfg.batch * cfg.n_frames * cfg.n_cams if cfg.render else 0) *
+                                      (1 if strong else world) * args.steps / elapsed,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+            'scaling': 'strong' if strong else 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': cfg.name, 'cams': cfg.n_cams, 'frames_per_gpu': cfg.n_frames,
                        'bev': list(cfg.bev_xyz), 'channels': cfg.channels, 'depth_bins': cfg.D,
@@ -185,7 +223,10 @@ def main():
                        'views_per_step': hp.views_per_step, 'render_camera': getattr(hp, 'render_convention', None),
                        'index_prep': 'cached (accelerate=True semantics)' if args.index_prep == 'cached' else
                                      'per step, HIP (accelerate=False semantics)',
-                       'sharding': f'{world} x {cfg.n_frames} frames (frame policy), one RCCL all_gather of the fused BEV per step' if world > 1 else 'none'},
+                       'sharding': {'none': 'none',
+                                    'samples': f'{world} ranks x 1 sample (6 cams x {cfg.n_frames} frames) each, no data-path collective',
+                                    'frames': f'{world} x {cfg.n_frames} frames of one sequence, one RCCL all_gather of the fused BEV per step',
+                                    'cameras': f'1 sample, cameras over {min(world, cfg.n_cams)} of {world} ranks, one RCCL all_reduce of the fused BEV per step'}[shard]},
             'roofline': {'bound': 'hbm', 'kernel': timer.kernel_name, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_us': 1e3 * avg_ms,

@@ -223,16 +223,20 @@ class HotPath:
         return (PoolPlan(*self._or_empty(index_prep._trim(lss[0], counts[0])), (self.batch, Z, Y, X, cfg.channels)),
                 PoolPlan(*self._or_empty(index_prep._trim(ht[0], counts[1])), (self.batch, 1, Y, X, cfg.channels)))
 
-    def step(self, depth, feat):
-        """One pass: LSS BEV (B, Z*C, Y, X) and HT BEV (B, C, Y, X) (view_transformer.py:194,
-        view_transformer_ocrf.py:781)."""
+    def pool_step(self, depth, feat):
+        """Both poolings (index preparation first in 'per_step' mode): LSS BEV (B, Z*C, Y, X) and
+        HT BEV (B, C, Y, X) (view_transformer.py:194, view_transformer_ocrf.py:781)."""
         if self.index_prep_mode == 'per_step':
             # ranks stay on the device, their lengths too: no host read anywhere in the step
             (lv, lc), (hv, hc) = self.prepare_indices_hip(sync=False)
             lss = bevpool.bev_pool_v2_device_counts(depth, feat, lv[1], lv[2], lv[0], self.lss.bev_shape, lv[3], lv[4], lc)
             ht = bevpool.bev_pool_v2_device_counts(depth, feat, hv[1], hv[2], hv[0], self.ht.bev_shape, hv[3], hv[4], hc)
-        else:
-            lss, ht = self.pool(self.lss, depth, feat), self.pool(self.ht, depth, feat)
+            return lss, ht
+        return self.pool(self.lss, depth, feat), self.pool(self.ht, depth, feat)
+
+    def step(self, depth, feat):
+        """One pass of the hot path: pools (+ render + HOA where the configuration has them)."""
+        lss, ht = self.pool_step(depth, feat)
         out = [lss, ht]
         if self.cfg.render:
             out.append(self.render())

@@ -1,6 +1,11 @@
 """Multi-GPU sharding of the hot path: one process per GPU, ``torch.distributed`` (backend
 ``nccl`` = RCCL over xGMI on MI355X; ``gloo`` in the CPU tests).
 
+``bench.py --gpus N`` defaults to the layout of the reference's own multi-GPU runs
+(tools/dist_test.sh -> MMDistributedDataParallel): every rank owns whole SAMPLES; the hot path has
+no exchange step in that layout and nothing in this module is called.  The policies below split ONE
+sample (or one multi-frame sequence) over ranks, which does need an exchange.
+
 The unit of work is one camera-frame.  ``bev_pool`` is a sum over (camera, depth, pixel)
 contributions per voxel (mmdet3d/ops/bev_pool_v2/src/bev_pool_cuda.cu:39-43) and frames are
 independent until the channel concat (mmdet3d/models/detectors/ocrfdet.py:274), so:
