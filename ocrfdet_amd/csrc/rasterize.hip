@@ -71,23 +71,37 @@ __device__ __forceinline__ float ndc2pix(float v, int S) {
 //    xy, conic_opacity.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
-    int P, int W, int H, int gx, int gy, const float* __restrict__ means3D,
+    int P, int n_views, int n_chunks, int W, int H, int gx, int gy, const float* __restrict__ means3D,
     const float* __restrict__ opacities, const float* __restrict__ scales, float scale_modifier,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
-    const Camera* __restrict__ cams, unsigned* __restrict__ keys, Rect* __restrict__ rects,
-    float2* __restrict__ xy, float4* __restrict__ conic_o, int* __restrict__ radii,
-    unsigned* __restrict__ tiles_touched, int* __restrict__ hist) {
+    const Camera* __restrict__ cams, uint4* __restrict__ vis_rec, int* __restrict__ vis_count,
+    Rect* __restrict__ rects, float2* __restrict__ xy, float4* __restrict__ conic_o,
+    int* __restrict__ radii, unsigned* __restrict__ tiles_touched, int* __restrict__ hist) {
   // One workgroup = kChunk consecutive Gaussians of one view.  Their depth buckets are counted in
   // an LDS histogram first and only the non-empty bins go to the global one: scattered global
   // atomics run at ~20 G/s chip-wide, and a depth slice of a regular grid puts thousands of
   // Gaussians into ONE bucket.
+  // Workgroup -> (chunk, view), XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so
+  // ids L and L+8 share an L2; the V views of a chunk get ids 8 apart and run back to back on one
+  // XCD, which reads the chunk's 90 KB of Gaussian parameters from HBM once instead of V times.
   __shared__ int s_hist[kBuckets];
-  const int v = blockIdx.y;
+  __shared__ int s_wsum[kBlock / 64];
+  __shared__ int s_base;
+  const int L = blockIdx.x;
+  const int kq = L >> 3;
+  const int chunk = (kq / n_views) * 8 + (L & 7);
+  const int v = kq % n_views;
+  if (chunk >= n_chunks) return;
   for (int i = threadIdx.x; i < kBuckets; i += kBlock) s_hist[i] = 0;
   __syncthreads();
+  unsigned key_of[kChunk / kBlock];
+  Rect rect_of[kChunk / kBlock];
+#pragma unroll
   for (int it = 0; it < kChunk / kBlock; ++it) {
-  const int idx = blockIdx.x * kChunk + it * kBlock + threadIdx.x;
-  if (idx >= P) break;
+  const int idx = chunk * kChunk + it * kBlock + threadIdx.x;
+  key_of[it] = 0xFFFFFFFFu;
+  rect_of[it] = Rect{0, 0, 0, 0};
+  if (idx >= P) continue;
   const long o = (long)v * P + idx;
   const Camera& cam = cams[v];
   const float* vm = cam.view;
@@ -138,8 +152,8 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
       c3[3] = S[1][1]; c3[4] = S[1][2]; c3[5] = S[2][2];
     }
 
-    // computeCov2D (forward.cu:74-113)
     const float limx = 1.3f * cam.tanfovx, limy = 1.3f * cam.tanfovy;
+    // computeCov2D (forward.cu:74-113)
     const float txtz = vx / vz, tytz = vy / vz;
     const float tx = fminf(limx, fmaxf(-limx, txtz)) * vz;
     const float ty = fminf(limy, fmaxf(-limy, tytz)) * vz;
@@ -185,17 +199,49 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
         rc.x0 = (unsigned short)x0; rc.y0 = (unsigned short)y0;
         rc.x1 = (unsigned short)x1; rc.y1 = (unsigned short)y1;
         rects[o] = rc;
+        rect_of[it] = rc;
         xy[o] = make_float2(pixx, pixy);
         conic_o[o] = make_float4(con_x, con_y, con_z, opacities[idx]);
       }
     }
   }
   if (key != 0xFFFFFFFFu) atomicAdd(&s_hist[bucket_of(key)], 1);
-  keys[o] = key;
+  key_of[it] = key;
   radii[o] = my_radii;
   if (tiles_touched) tiles_touched[o] = touched;
   }   // chunk loop
+  // compact (depth bits, id, rect) records of the visible Gaussians: one returning global atomic
+  // per workgroup reserves the range; the order is arbitrary (the scatter re-buckets, the blend sorts)
+  int mine = 0;
+#pragma unroll
+  for (int it = 0; it < kChunk / kBlock; ++it) mine += key_of[it] != 0xFFFFFFFFu;
+  const int lane = threadIdx.x % 64, wave = threadIdx.x / 64;
+  int inc = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o2 = __shfl_up(inc, off);
+    if (lane >= off) inc += o2;
+  }
+  if (lane == 63) s_wsum[wave] = inc;
   __syncthreads();
+  int before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) {
+    if (w < wave) before += s_wsum[w];
+    total += s_wsum[w];
+  }
+  if (threadIdx.x == 0) s_base = total ? atomicAdd(&vis_count[v], total) : 0;
+  __syncthreads();
+  int pos = s_base + before + inc - mine;
+#pragma unroll
+  for (int it = 0; it < kChunk / kBlock; ++it) {
+    if (key_of[it] == 0xFFFFFFFFu) continue;
+    const unsigned idx = (unsigned)(chunk * kChunk + it * kBlock + threadIdx.x);
+    const Rect rc = rect_of[it];
+    vis_rec[(long)v * P + pos] = make_uint4(key_of[it], idx, (unsigned)rc.x0 | ((unsigned)rc.y0 << 16),
+                                            (unsigned)rc.x1 | ((unsigned)rc.y1 << 16));
+    ++pos;
+  }
   for (int i = threadIdx.x; i < kBuckets; i += kBlock) {
     const int c = s_hist[i];
     if (c) atomicAdd(&hist[v * kBuckets + i], c);
@@ -237,34 +283,45 @@ __global__ __launch_bounds__(kBlock) void raster_bucket_scan_kernel(const int* _
 // 3. scatter the visible Gaussians into bucket order: b_rect, b_comp = (depth bits << 32) | id.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void raster_scatter_kernel(
-    int P, const unsigned* __restrict__ keys, const Rect* __restrict__ rects,
+    int P, const uint4* __restrict__ vis_rec, const int* __restrict__ vis_count,
     int* __restrict__ cursor, Rect* __restrict__ b_rect, unsigned long long* __restrict__ b_comp) {
-  // Same chunking as the preprocess: count in LDS, reserve one global range per non-empty bucket
-  // (ONE returning global atomic per bucket per workgroup), hand out slots with LDS atomics.
+  // Walks the compact visible records of one view (the launch is sized for P; workgroups past the
+  // view's count retire at once): count in LDS, reserve one global range per non-empty bucket (ONE
+  // returning global atomic per bucket per workgroup), hand out slots with LDS atomics.
   __shared__ int s_cnt[kBuckets];
   const int v = blockIdx.y, tid = threadIdx.x;
+  const int n = vis_count[v];
+  if ((int)blockIdx.x * kChunk >= n) return;
   for (int i = tid; i < kBuckets; i += kBlock) s_cnt[i] = 0;
   __syncthreads();
-  unsigned key[kChunk / kBlock];
+  uint4 rec[kChunk / kBlock];
 #pragma unroll
   for (int it = 0; it < kChunk / kBlock; ++it) {
-    const int idx = blockIdx.x * kChunk + it * kBlock + tid;
-    key[it] = idx < P ? keys[(long)v * P + idx] : 0xFFFFFFFFu;
-    if (key[it] != 0xFFFFFFFFu) atomicAdd(&s_cnt[bucket_of(key[it])], 1);
+    const int i = blockIdx.x * kChunk + it * kBlock + tid;
+    rec[it] = i < n ? vis_rec[(long)v * P + i] : make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+    if (rec[it].x != 0xFFFFFFFFu) atomicAdd(&s_cnt[bucket_of(rec[it].x)], 1);
   }
   __syncthreads();
-  for (int i = tid; i < kBuckets; i += kBlock) {
-    const int c = s_cnt[i];
-    if (c) s_cnt[i] = atomicAdd(&cursor[v * kBuckets + i], c);      // now: next free slot of bucket i
-  }
+  // all of a thread's returning atomics are issued before any result is consumed: their latency
+  // (~2 us each) overlaps instead of adding up
+  int cnt[kBuckets / kBlock], slot0[kBuckets / kBlock];
+#pragma unroll
+  for (int k = 0; k < kBuckets / kBlock; ++k) cnt[k] = s_cnt[k * kBlock + tid];
+#pragma unroll
+  for (int k = 0; k < kBuckets / kBlock; ++k)
+    slot0[k] = cnt[k] ? atomicAdd(&cursor[v * kBuckets + k * kBlock + tid], cnt[k]) : 0;
+#pragma unroll
+  for (int k = 0; k < kBuckets / kBlock; ++k) s_cnt[k * kBlock + tid] = slot0[k];      // next free slot of the bucket
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < kChunk / kBlock; ++it) {
-    if (key[it] == 0xFFFFFFFFu) continue;
-    const int idx = blockIdx.x * kChunk + it * kBlock + tid;
-    const int slot = atomicAdd(&s_cnt[bucket_of(key[it])], 1);
-    b_rect[(long)v * P + slot] = rects[(long)v * P + idx];
-    b_comp[(long)v * P + slot] = ((unsigned long long)key[it] << 32) | (unsigned)idx;
+    if (rec[it].x == 0xFFFFFFFFu) continue;
+    const int slot = atomicAdd(&s_cnt[bucket_of(rec[it].x)], 1);
+    Rect rc;
+    rc.x0 = (unsigned short)(rec[it].z & 0xFFFFu); rc.y0 = (unsigned short)(rec[it].z >> 16);
+    rc.x1 = (unsigned short)(rec[it].w & 0xFFFFu); rc.y1 = (unsigned short)(rec[it].w >> 16);
+    b_rect[(long)v * P + slot] = rc;
+    b_comp[(long)v * P + slot] = ((unsigned long long)rec[it].x << 32) | rec[it].y;
   }
 }
 
@@ -969,20 +1026,20 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_backward_kernel(
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct RasterWs {
-  size_t keys, rects, xy, conic_o, b_rect, b_comp, hist, starts, cursor, status, total, acc, radii, bwd_total;
+  size_t vis_rec, rects, xy, conic_o, b_rect, b_comp, hist, starts, cursor, status, total, acc, radii, bwd_total;
 };
 
 inline void raster_layout(int P, int n_views, RasterWs* ws) {
   const size_t n = (size_t)P * n_views;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
-  ws->keys = take(n * 4);
+  ws->vis_rec = take(n * sizeof(uint4));
   ws->rects = take(n * sizeof(Rect));
   ws->xy = take(n * sizeof(float2));
   ws->conic_o = take(n * sizeof(float4));
   ws->b_rect = take(n * sizeof(Rect));
   ws->b_comp = take(n * 8);
-  ws->hist = take((size_t)n_views * kBuckets * sizeof(int));
+  ws->hist = take((size_t)n_views * (kBuckets + 1) * sizeof(int));      // + the per-view visible counts
   ws->starts = take((size_t)n_views * (kBuckets + 1) * sizeof(int));
   ws->cursor = take((size_t)n_views * kBuckets * sizeof(int));
   ws->status = take(256);
@@ -1036,7 +1093,7 @@ int ocrf_rasterize_forward(int P, int n_views, int H, int W, const float* means3
   raster_layout(P, n_views, &ws);
   if (!workspace || workspace_bytes < ws.total) return (int)hipErrorInvalidValue;
   char* base = static_cast<char*>(workspace);
-  auto* keys = reinterpret_cast<unsigned*>(base + ws.keys);
+  auto* vis_rec = reinterpret_cast<uint4*>(base + ws.vis_rec);
   auto* rects = reinterpret_cast<Rect*>(base + ws.rects);
   auto* xy = reinterpret_cast<float2*>(base + ws.xy);
   auto* conic_o = reinterpret_cast<float4*>(base + ws.conic_o);
@@ -1048,12 +1105,15 @@ int ocrf_rasterize_forward(int P, int n_views, int H, int W, const float* means3
   int* st = status ? status : reinterpret_cast<int*>(base + ws.status);
   const Camera* cams = reinterpret_cast<const Camera*>(cameras);
 
-  hipError_t e = hipMemsetAsync(hist, 0, (size_t)n_views * kBuckets * sizeof(int), stream);
+  int* vis_count = hist + (size_t)n_views * kBuckets;
+  hipError_t e = hipMemsetAsync(hist, 0, (size_t)n_views * (kBuckets + 1) * sizeof(int), stream);
   if (e != hipSuccess) return (int)e;
-  const dim3 pgrid((P + kChunk - 1) / kChunk, n_views);
-  ocrf::launch(OCRF_K_RASTER_PREPROCESS, raster_preprocess_kernel, pgrid, dim3(kBlock), 0, stream, P,
-               W, H, gx, gy, means3D, opacities, scales, scale_modifier, rotations, cov3D_precomp,
-               cams, keys, rects, xy, conic_o, radii, tiles_touched, hist);
+  const int n_chunks = (P + kChunk - 1) / kChunk;
+  const dim3 pgrid(n_chunks, n_views);
+  const dim3 xgrid((unsigned)((n_chunks + 7) / 8 * 8 * n_views));      // (chunk, view) pairs, XCD-aware order
+  ocrf::launch(OCRF_K_RASTER_PREPROCESS, raster_preprocess_kernel, xgrid, dim3(kBlock), 0, stream, P, n_views,
+               n_chunks, W, H, gx, gy, means3D, opacities, scales, scale_modifier, rotations, cov3D_precomp,
+               cams, vis_rec, vis_count, rects, xy, conic_o, radii, tiles_touched, hist);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   ocrf::launch(OCRF_K_RASTER_SCAN, raster_bucket_scan_kernel, dim3(n_views), dim3(kBlock), 0, stream,
@@ -1061,8 +1121,7 @@ int ocrf_rasterize_forward(int P, int n_views, int H, int W, const float* means3
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   ocrf::launch(OCRF_K_RASTER_GATHER, raster_scatter_kernel, pgrid, dim3(kBlock), 0, stream, P,
-               static_cast<const unsigned*>(keys), static_cast<const Rect*>(rects), cursor, b_rect,
-               b_comp);
+               static_cast<const uint4*>(vis_rec), static_cast<const int*>(vis_count), cursor, b_rect, b_comp);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   const size_t lds = (size_t)kCapRec * 8 + (size_t)kStage * (16 + 16 + 16);
@@ -1118,7 +1177,7 @@ int ocrf_rasterize_backward(int P, int n_views, int H, int W, const float* means
   raster_layout(P, n_views, &ws);
   if (!workspace || workspace_bytes < ws.bwd_total) return (int)hipErrorInvalidValue;
   char* base = static_cast<char*>(workspace);
-  auto* keys = reinterpret_cast<unsigned*>(base + ws.keys);
+  auto* vis_rec = reinterpret_cast<uint4*>(base + ws.vis_rec);
   auto* rects = reinterpret_cast<Rect*>(base + ws.rects);
   auto* xy = reinterpret_cast<float2*>(base + ws.xy);
   auto* conic_o = reinterpret_cast<float4*>(base + ws.conic_o);
@@ -1132,17 +1191,20 @@ int ocrf_rasterize_backward(int P, int n_views, int H, int W, const float* means
   auto* radii = reinterpret_cast<int*>(base + ws.radii);
   const Camera* cams = reinterpret_cast<const Camera*>(cameras);
   // rebuild the bucket-ordered lists exactly as the forward did (same kernels, same inputs)
-  hipError_t e = hipMemsetAsync(hist, 0, (size_t)n_views * kBuckets * sizeof(int), stream);
+  int* vis_count = hist + (size_t)n_views * kBuckets;
+  hipError_t e = hipMemsetAsync(hist, 0, (size_t)n_views * (kBuckets + 1) * sizeof(int), stream);
   if (e == hipSuccess) e = hipMemsetAsync(acc, 0, (size_t)n_views * P * 9 * sizeof(float), stream);
   if (e != hipSuccess) return (int)e;
-  const dim3 pgrid((P + kChunk - 1) / kChunk, n_views);
-  hipLaunchKernelGGL(raster_preprocess_kernel, pgrid, dim3(kBlock), 0, stream, P, W, H, gx, gy, means3D, opacities,
-                     scales, scale_modifier, rotations, (const float*)nullptr, cams, keys, rects, xy, conic_o, radii,
-                     (unsigned*)nullptr, hist);
+  const int n_chunks = (P + kChunk - 1) / kChunk;
+  const dim3 pgrid(n_chunks, n_views);
+  const dim3 xgrid((unsigned)((n_chunks + 7) / 8 * 8 * n_views));
+  hipLaunchKernelGGL(raster_preprocess_kernel, xgrid, dim3(kBlock), 0, stream, P, n_views, n_chunks, W, H, gx, gy,
+                     means3D, opacities, scales, scale_modifier, rotations, (const float*)nullptr, cams, vis_rec,
+                     vis_count, rects, xy, conic_o, radii, (unsigned*)nullptr, hist);
   hipLaunchKernelGGL(raster_bucket_scan_kernel, dim3(n_views), dim3(kBlock), 0, stream, static_cast<const int*>(hist),
                      starts, cursor);
-  hipLaunchKernelGGL(raster_scatter_kernel, pgrid, dim3(kBlock), 0, stream, P, static_cast<const unsigned*>(keys),
-                     static_cast<const Rect*>(rects), cursor, b_rect, b_comp);
+  hipLaunchKernelGGL(raster_scatter_kernel, pgrid, dim3(kBlock), 0, stream, P, static_cast<const uint4*>(vis_rec),
+                     static_cast<const int*>(vis_count), cursor, b_rect, b_comp);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   BwdArgs bw;
