@@ -29,11 +29,15 @@ __global__ __launch_bounds__(kBlock) void hoa_channel_stats_kernel(const float* 
   const float* p = x + (long)b * C * plane + pix;
   float sum = 0.f, mx = -INFINITY;
   int c = 0;
-  for (; c + 4 <= C; c += 4) {
-    const float v0 = p[(long)c * plane], v1 = p[(long)(c + 1) * plane], v2 = p[(long)(c + 2) * plane],
-                v3 = p[(long)(c + 3) * plane];
-    sum += v0; sum += v1; sum += v2; sum += v3;         // channel order, like torch.mean's sum
-    mx = fmaxf(fmaxf(mx, fmaxf(v0, v1)), fmaxf(v2, v3));
+  for (; c + 16 <= C; c += 16) {            // 16 plane reads in flight per lane (few workgroups: depth, not occupancy)
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = p[(long)(c + u) * plane];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      sum += v[u];                              // channel order, like torch.mean's sum
+      mx = fmaxf(mx, v[u]);
+    }
   }
   for (; c < C; ++c) {
     const float v = p[(long)c * plane];
@@ -45,46 +49,49 @@ __global__ __launch_bounds__(kBlock) void hoa_channel_stats_kernel(const float* 
 }
 
 // (2) mask = sigmoid(conv_kxk([mean, max]) + opacity_bev); gated = x * mask.
-// One workgroup per 16x16 pixel tile: the two statistic planes (+ halo) and the weights sit in LDS.
-constexpr int kMT = 16;
+// One workgroup per 64x4 pixel tile (a wave = one 256-B row segment of every channel plane: whole
+// cache lines; 16-wide tiles fetched every line twice): the two statistic planes (+ halo) and the
+// weights sit in LDS.
+constexpr int kMTX = 64, kMTY = 4;
 __global__ __launch_bounds__(kBlock) void hoa_mask_gate_kernel(
     const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ opacity_bev,
     const float* __restrict__ conv_w, int k, int C, int Y, int X, float* __restrict__ mask,
     float* __restrict__ gated) {
-  extern __shared__ float s_dyn[];        // 2*k*k weights, then 2 planes of (kMT+k-1)^2
-  const int r = k / 2, tw = kMT + k - 1;
+  extern __shared__ float s_dyn[];        // 2*k*k weights, then 2 planes of (kMTY+k-1) x (kMTX+k-1)
+  const int r = k / 2, tw = kMTX + k - 1, th = kMTY + k - 1;
   float* s_w = s_dyn;
   float* s_s = s_dyn + 2 * k * k;
   const long plane = (long)Y * X;
-  const int b = blockIdx.z, ty0 = blockIdx.y * kMT, tx0 = blockIdx.x * kMT;
+  const int b = blockIdx.z, ty0 = blockIdx.y * kMTY, tx0 = blockIdx.x * kMTX;
   for (int i = threadIdx.x; i < 2 * k * k; i += kBlock) s_w[i] = conv_w[i];
-  for (int i = threadIdx.x; i < 2 * tw * tw; i += kBlock) {
-    const int ch = i / (tw * tw), rem = i % (tw * tw);
+  for (int i = threadIdx.x; i < 2 * tw * th; i += kBlock) {
+    const int ch = i / (tw * th), rem = i % (tw * th);
     const int y = ty0 + rem / tw - r, xx = tx0 + rem % tw - r;
     s_s[i] = (y >= 0 && y < Y && xx >= 0 && xx < X) ? stats[((long)b * 2 + ch) * plane + (long)y * X + xx] : 0.f;
   }
   __syncthreads();
-  const int ly = threadIdx.x / kMT, lx = threadIdx.x % kMT;
+  const int ly = threadIdx.x / kMTX, lx = threadIdx.x % kMTX;
   const int yy = ty0 + ly, xx = tx0 + lx;
   if (yy >= Y || xx >= X) return;
   float acc = 0.f;
   for (int ch = 0; ch < 2; ++ch)
     for (int i = 0; i < k; ++i)
       for (int j = 0; j < k; ++j)
-        acc = fmaf(s_s[(ch * tw + ly + i) * tw + lx + j], s_w[(ch * k + i) * k + j], acc);
+        acc = fmaf(s_s[(ch * th + ly + i) * tw + lx + j], s_w[(ch * k + i) * k + j], acc);
   const long pix = (long)yy * X + xx;
   const float m = sigmoidf_(acc + opacity_bev[(long)b * plane + pix]);
   mask[(long)b * plane + pix] = m;
   if (gated) {
     const float* p = x + (long)b * C * plane + pix;
     float* q = gated + (long)b * C * plane + pix;
+    // 16 plane reads in flight per lane
     int c = 0;
-    for (; c + 8 <= C; c += 8) {
-      float v[8];
+    for (; c + 16 <= C; c += 16) {
+      float v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = p[(long)(c + u) * plane];
+      for (int u = 0; u < 16; ++u) v[u] = p[(long)(c + u) * plane];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) q[(long)(c + u) * plane] = v[u] * m;
+      for (int u = 0; u < 16; ++u) q[(long)(c + u) * plane] = v[u] * m;
     }
     for (; c < C; ++c) q[(long)c * plane] = p[(long)c * plane] * m;
   }
@@ -171,9 +178,9 @@ int ocrf_hoa_opacity_mask_gate(const float* x, const float* stats, const float* 
   if (!x || !stats || !opacity_bev || !conv_w || !mask || k <= 0 || (k & 1) == 0 || k > 15 || B <= 0 ||
       C <= 0 || Y <= 0 || X <= 0)
     return (int)hipErrorInvalidValue;
-  const int tw = kMT + k - 1;
-  ocrf::launch(OCRF_K_HOA_MASK_GATE, hoa_mask_gate_kernel, dim3((X + kMT - 1) / kMT, (Y + kMT - 1) / kMT, B),
-               dim3(kBlock), (size_t)(2 * k * k + 2 * tw * tw) * sizeof(float), stream, x, stats, opacity_bev,
+  const int tw = kMTX + k - 1, th = kMTY + k - 1;
+  ocrf::launch(OCRF_K_HOA_MASK_GATE, hoa_mask_gate_kernel, dim3((X + kMTX - 1) / kMTX, (Y + kMTY - 1) / kMTY, B),
+               dim3(kBlock), (size_t)(2 * k * k + 2 * tw * th) * sizeof(float), stream, x, stats, opacity_bev,
                conv_w, k, C, Y, X, mask, gated);
   return (int)hipGetLastError();
 }
