@@ -283,6 +283,116 @@ def color_golden():
                 sparse=sparse.numpy().astype(np.uint8))
 
 
+CORE_CFG = dict(name='core_small_6cam_64x176_bev48x48', input_size=(64, 176),
+                grid=dict(x=[-19.2, 19.2, 0.8], y=[-19.2, 19.2, 0.8], z=[-5.0, 3.0, 8.0], depth=[1.0, 60.0, 0.5]),
+                pc_range=(-19.2, -19.2, -5.0, 19.2, 19.2, 3.0))
+
+
+def core_inputs(cfg, batch, seed=11):
+    """The 12-entry ``img_inputs`` list of ``OcRFViewTransformerFull.forward``
+    (view_transformer_ocrf.py:1319-1321, :1042) and a stand-in for the DepthNet output, all seeded.
+    Shared with tests/helpers.py so the GPU box rebuilds identical inputs."""
+    r = synthetic.rig(6, cfg.input_size, batch)
+    Hf, Wf = cfg.feat_hw
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(batch, 6, 256, Hf, Wf, generator=g).half().float()     # stored as float16 in the fixture
+    raw = torch.randint(0, 256, (batch, 6, 3, *cfg.input_size), generator=g).float()
+    inp = [x] + [T(r[k]) for k in ('rots', 'trans', 'intrins', 'post_rots', 'post_trans', 'bda')]
+    inp += [torch.zeros(batch, 6, 27), raw.clone(), raw, raw.clone(), T(r['c2w'])]
+    pre = torch.randn(batch * 6, cfg.D + 2 + cfg.channels, Hf, Wf, generator=g)
+    pre[:, :cfg.D] *= 3
+    return inp, pre
+
+
+def core_golden():
+    """The whole neck: ``OcRFViewTransformerFull.forward`` -> ``view_transform_core``
+    (view_transformer_ocrf.py:1319-1334, 1040-1201) on a small 6-camera configuration, in eval mode,
+    seeded weights.  The DepthNet (a CNN outside the path) is replaced by a fixed tensor; the CUDA
+    rasteriser, which cannot run here, by the build's C oracle (so the rendered images pin the glue
+    around ``render``, not the rasteriser arithmetic)."""
+    import math
+    import torch.nn as nn
+    import oracle
+    cfg = synthetic.PathConfig(**CORE_CFG)
+    B = 2
+    torch.manual_seed(7)
+    random.seed(3)
+    vt.build_conv_layer = lambda cfg=None, *a, **k: nn.Identity()       # DCN of the (unused) DepthNet
+    m = vto.OcRFViewTransformerFull(
+        pc_range=list(cfg.pc_range), bev_h=48, bev_w=48, num_height=13, grid_config=cfg.grid,
+        input_size=cfg.input_size, downsample=16, in_channels=256, out_channels=80, accelerate=False)
+    # non-trivial BatchNorm statistics and HOA-style perturbed weights so that eval mode is exercised
+    for mod in m.modules():
+        if isinstance(mod, (nn.BatchNorm2d, nn.BatchNorm3d)):
+            mod.running_mean.normal_(0, 0.2), mod.running_var.uniform_(0.5, 1.5)
+            mod.weight.data.uniform_(0.5, 1.5), mod.bias.data.normal_(0, 0.2)
+    m.LinearWeightedImage.w.data.fill_(0.35), m.LinearWeightedDepth.w.data.fill_(0.6)
+    for head in (m.img_feat_resize1, m.img_feat_resize2, m.D_MLP_nerf, m.C_MLP_nerf):      # keep the ReLUs alive
+        head.fc1.bias.data.uniform_(0.2, 0.8), head.fc2.bias.data.uniform_(0.1, 0.6)
+    m.eval()
+    inp, pre = core_inputs(cfg, B)
+
+    class _DN(nn.Module):
+        def forward(self, x_, mlp, sm):
+            return pre
+    state = {k: v.detach().numpy().copy() for k, v in m.state_dict().items() if not k.startswith('depth_net.')}
+    m.depth_net = _DN()
+    cap = {}
+
+    def render_stub(data, idx, xyz, rgb, rot, sc, op, bg_color):
+        o = oracle.rasterize_forward(xyz.numpy(), rgb.numpy(), op.numpy(), sc.numpy(), rot.numpy(),
+                                     data['world_view_transform'].numpy(), data['full_proj_transform'].numpy(),
+                                     math.tan(data['FovX'] * 0.5), math.tan(data['FovY'] * 0.5), data['height'],
+                                     data['width'], np.array(bg_color, np.float32))
+        n = len([k for k in cap if k.startswith('gauss_rgb')])
+        cap[f'gauss_xyz{n}'], cap[f'gauss_rgb{n}'], cap[f'gauss_rot{n}'] = xyz.numpy(), rgb.numpy(), rot.numpy()
+        cap[f'gauss_scales{n}'], cap[f'gauss_opacity{n}'] = sc.numpy(), op.numpy()
+        cap[f'cam_world_view{n}'] = data['world_view_transform'].numpy()
+        cap[f'cam_full_proj{n}'] = data['full_proj_transform'].numpy()
+        cap[f'cam_fov{n}'] = np.array([float(data['FovX']), float(data['FovY'])])
+        cap[f'num_rendered{n}'] = np.int64(o['num_rendered'])
+        return T(o['color']), T(o['depth'])
+    vto.render = render_stub
+    gpm = du.getProjectionMatrix          # numpy>=2: see camera_golden
+    du.getProjectionMatrix = lambda znear, zfar, K, h, w: gpm(znear, zfar, K.astype(np.float64), h, w)
+    ref3d = m.get_reference_points_3d
+    m.get_reference_points_3d = lambda *a, **k: ref3d(*a, **{**k, 'device': 'cpu'})
+
+    def tap(name, fn, pick=lambda o: o):
+        def wrapped(*a, **k):
+            o = fn(*a, **k)
+            cap.setdefault(name, []).append(pick(o).detach().numpy().copy())
+            return o
+        return wrapped
+    m.get_lss_bev_feat = tap('lss_feat', m.get_lss_bev_feat)
+    m.get_ht_bev_feat = tap('ht_feat', m.get_ht_bev_feat, lambda o: o[0])
+    m.retain_valid_pixels = tap('sparse', m.retain_valid_pixels)
+    m.color_voxels = tap('avg', m.color_voxels, lambda o: o[1])
+    m.fuser.register_forward_hook(lambda mod, i, o: cap.setdefault('channel_feat', []).append(o.numpy().copy()))
+    m.defor_cross_attention.register_forward_hook(
+        lambda mod, i, o: (cap.setdefault('opacity_up', []).append(i[0].numpy().copy()),
+                           cap.setdefault('alpha_up', []).append(i[1].numpy().copy())) and None)
+    with torch.no_grad():
+        bev, depth, (bev_mask, sem), lst = m(inp)
+    du.getProjectionMatrix = gpm
+    out = {f'state.{k}': v for k, v in state.items()}
+    out.update(batch=np.int64(B), pre=pre.numpy(), x=inp[0].numpy().astype(np.float16),
+               raw=inp[9].numpy().astype(np.uint8),
+               bev_feat=bev.numpy(), depth=depth.numpy(), bev_mask_logit=bev_mask.numpy(), semantic=sem.numpy(),
+               render_imgs=lst[0].numpy(), gt_images=lst[1].numpy(), render_G=lst[2].numpy(), render_N=lst[3].numpy(),
+               opacity_alpha_view=lst[4].numpy(), cam_idx_list=np.array(lst[5], np.int64),
+               render_depth=lst[6].numpy(), render_depth_G=lst[7].numpy(), render_depth_N=lst[8].numpy(),
+               lss_feat=cap['lss_feat'][0], ht_feat=cap['ht_feat'][0], channel_feat=cap['channel_feat'][0],
+               colored_avg=cap['avg'][0],                     # first color_voxels call: RGB; then one alpha call per sample
+               alpha_lidar=np.concatenate(cap['avg'][1:], 0),
+               opacity_up=np.concatenate(cap['opacity_up'], 0), alpha_up=np.concatenate(cap['alpha_up'], 0),
+               sparse_sel=np.stack([cap['sparse'][0][b, c] for b, c in enumerate(lst[5])]).astype(np.uint8))
+    for k, v in cap.items():
+        if k.startswith(('gauss_', 'cam_', 'num_rendered')):
+            out[k] = v[::5] if k.startswith('gauss_') else v   # every 5th Gaussian keeps the file small
+    return out
+
+
 def main():
     random.seed(0)
     torch.manual_seed(0)
@@ -305,6 +415,7 @@ def main():
     save('hoa.npz', hoa_golden())
     save('heads.npz', heads_golden())
     save('color_cfg0.npz', color_golden())
+    save('core_small.npz', core_golden())
 
 
 if __name__ == '__main__':

@@ -80,3 +80,31 @@ def random_gaussians(rng, n, z_range=(1.0, 30.0), xy_extent=12.0, scale=(0.05, 0
     opac = rng.uniform(0.05, 0.95, (n, 1)).astype(np.float32)
     rgb = rng.uniform(0, 1, (n, 3)).astype(np.float32)
     return xyz, rgb, opac, scales, q
+
+
+CORE_CFG = dict(name='core_small_6cam_64x176_bev48x48', input_size=(64, 176),
+                grid=dict(x=[-19.2, 19.2, 0.8], y=[-19.2, 19.2, 0.8], z=[-5.0, 3.0, 8.0], depth=[1.0, 60.0, 0.5]),
+                pc_range=(-19.2, -19.2, -5.0, 19.2, 19.2, 3.0))
+
+
+def core_fixture():
+    """tests/golden/core_small.npz (reference ``OcRFViewTransformerFull.forward`` in eval mode on a
+    small 6-camera configuration) -> (cfg, golden dict, state dict of numpy arrays)."""
+    import os
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'core_small.npz')))
+    state = {k[len('state.'):]: v for k, v in g.items() if k.startswith('state.')}
+    return synthetic.PathConfig(**CORE_CFG), g, state
+
+
+def core_geometry(cfg, batch):
+    """Pillar projections of the HT branch for the core fixture, from the numpy oracle:
+    voxel centres (B,Zh,Q,3), pixel coordinates (B,N,Zh,Q,2), mask (B,N,Zh,Q,1)."""
+    r = synthetic.rig(cfg.n_cams, cfg.input_size, batch)
+    X, Y, _ = cfg.bev_xyz
+    ref = ip.get_reference_points_3d(Y, X, bs=batch, num_points_in_pillar=cfg.num_height)
+    l2i, aug = ip.get_projection(r['rots'], r['trans'], r['intrins'], r['post_rots'], r['post_trans'], r['bda'])
+    coor, mask, extra = ip.get_sampling_point(ref, cfg.pc_range, cfg.grid['depth'], l2i, aug, cfg.input_size)
+    pix = coor[..., :2].copy()
+    pix[..., 0] *= np.float32(cfg.input_size[1])
+    pix[..., 1] *= np.float32(cfg.input_size[0])
+    return extra, pix, mask, r
