@@ -302,6 +302,80 @@ int ocrf_hoa1_forward(const float *opacity, const float *alpha, const float *wei
 int ocrf_hoa1_weights_len(void);
 
 /* ------------------------------------------------------------------------------------------
+ * Neck glue between the poolings, the render and HOA (eval mode; csrc/neck.hip)
+ * ------------------------------------------------------------------------------------------ */
+
+/*
+ * OcRFViewTransformerFull.forward's pre-filter (view_transformer_ocrf.py:1323-1331) fused with the
+ * channels-last permute the poolings need (:875, :901).  x (BN, D+2+C, HW) = DepthNet output:
+ *   depth         (BN,D,HW)  softmax over the D depth logits (returned to the caller, :1334)
+ *   filter_depth  (BN,D,HW)  depth, zeroed where depth < depth_threshold (= depth_threshold/D of the ctor)
+ *   semantic      (BN,2,HW)  softmax over the 2 semantic logits
+ *   feat_channels_last (BN,HW,C)  tran_feat * (semantic[:,1] >= semantic_threshold), i.e. the
+ *                 (B,N,H,W,C) operand of bev_pool_v2
+ * 64*(C+1)*4 bytes of LDS must fit (C <= 230).
+ */
+int ocrf_prefilter(const float *x, int BN, int D, int C, int HW, float depth_threshold,
+                   float semantic_threshold, float *depth, float *filter_depth, float *semantic,
+                   float *feat_channels_last, ocrf_stream_t stream);
+
+/*
+ * lidar_points_to_image_values + color_voxels' avg_color (view_transformer_ocrf.py:924-959):
+ *   avg[b][q][c] = sum_{n: mask[b][n][q]} bilinear(imgs[b][n][c], pix[b][n][q]) / max(1, #valid n)
+ * imgs (B,N,C,Hi,Wi) with C in {1,3}; pix (B,N,ZQ,2) PIXEL coordinates (x,y) — normalised as
+ * (p/(size-1))*2-1 and sampled like F.grid_sample(bilinear, zeros, align_corners=True), :929-936;
+ * mask (B,N,ZQ) bytes (torch.bool); avg (B,ZQ,C).  Hi/Wi are the extents the reference's view of the
+ * image claims: for the alpha volume it passes the (H,W) stack viewed as (W,H) (:1123).
+ */
+int ocrf_pillar_sample_mean(const float *imgs, const float *pix, const unsigned char *mask, float *avg,
+                            int B, int N, int C, int Hi, int Wi, int ZQ, ocrf_stream_t stream);
+
+/*
+ * retain_valid_pixels (view_transformer_ocrf.py:1004-1024): out = 255 except pixels
+ * (clamp(trunc(pix.x)), clamp(trunc(pix.y))) of valid projections, which keep imgs' value.
+ * imgs (B,N,C,H,W); cam_sel == NULL: every camera, out (B,N,C,H,W); cam_sel (B) int32 device
+ * pointer: only camera cam_sel[b] of sample b (the one the caller consumes, :1104), out (B,C,H,W).
+ */
+int ocrf_retain_valid_pixels(const float *imgs, const float *pix, const unsigned char *mask,
+                             const int *cam_sel, float *out, int B, int N, int C, int H, int W, int ZQ,
+                             ocrf_stream_t stream);
+
+/*
+ * VoxelFeatureExtractor (view_transformer_ocrf.py:520-531, call :1051; Conv3d(1->Zh,k=1) +
+ * BatchNorm3d folded by the caller into lift_a/lift_b + ReLU) fused with the four Gaussian heads
+ * (:272-320, calls :1130-1133).  bev (B,C,YX) is the HT BEV feature, rgb_avg (B,Zh,YX,3) the
+ * sampled voxel colour in 0..255 (divided by 255 inside, :1071).  Gaussian g = (b, h, q):
+ *   f[c] = relu(lift_a[h]*bev[b][c][q] + lift_b[h]);  opacity (B,Zh*YX,1) = sigmoid(A_MLP(f)),
+ *   scales (.,3) = softplus(S_MLP(f)), rotations (.,4) = normalize(R_MLP(f)), color (.,3) =
+ *   sigmoid(C_MLP([f, rgb/255])).
+ * params: ocrf_gauss_heads_params_len(C, Zh) floats packed as documented in csrc/neck.hip.
+ * rotations must be 16-byte aligned.
+ */
+int ocrf_gauss_heads(const float *bev, const float *rgb_avg, const float *params, int B, int C, int Zh,
+                     int YX, float *opacity, float *scales, float *rotations, float *color,
+                     ocrf_stream_t stream);
+int ocrf_gauss_heads_params_len(int C, int Zh);
+
+/*
+ * NeRF branch (view_transformer_ocrf.py:1094-1121) from z (M,32,h2,w2) = ResizeNetwork.conv2's
+ * output (:546); the caller composes upsample2 (k2 s2) -> upsample3 (k4 s4) -> first Linear of each
+ * consumer into per-sub-position maps (64 positions of the 8x8 up-sampling cell):
+ *   ocrf_nerf_alpha:  alpha (M,8*h2,8*w2) = 1 - exp(-softplus(w_sigma[:,pos] . z + c_sigma[pos]))
+ *                     (sigma = Softplus(Linear(Linear(.))), :605, :1099-1102)
+ *   ocrf_nerf_render: for sample b and camera cam_sel[b] (int32 device vector), with sparse_rgb
+ *                     (B,3,H,W) from ocrf_retain_valid_pixels: render_image_n (B,3,H,W) =
+ *                     alpha * relu(img_feat_resize1) * softmax(C_MLP_nerf), render_depth_n (B,1,H,W) =
+ *                     alpha * relu(img_feat_resize2)   (T == 1 and the depth weight == 1, :1108-1117).
+ * params of ocrf_nerf_render: ocrf_nerf_render_params_len() floats, layout in csrc/neck.hip.
+ */
+int ocrf_nerf_alpha(const float *z, const float *w_sigma, const float *c_sigma, float *alpha, int M,
+                    int h2, int w2, ocrf_stream_t stream);
+int ocrf_nerf_render(const float *z, const int *cam_sel, const float *alpha, const float *sparse_rgb,
+                     const float *params, int B, int N, int h2, int w2, float *render_image_n,
+                     float *render_depth_n, ocrf_stream_t stream);
+int ocrf_nerf_render_params_len(void);
+
+/* ------------------------------------------------------------------------------------------
  * Per-kernel device timer (measurement aid for bench.py; not part of the reference's surface)
  * ------------------------------------------------------------------------------------------
  * While a timer is armed for kernel id K, every launch of K inside the library is bracketed by
@@ -337,7 +411,13 @@ enum {
   OCRF_K_LSS_BOUNDS = 44,        /* lower_bound_kernel */
   OCRF_K_LSS_EMIT = 45,          /* lss_emit_ranks_kernel */
   OCRF_K_HT_COUNT = 46,          /* ht_valid_kernel */
-  OCRF_K_HT_EMIT = 47            /* ht_emit_kernel */
+  OCRF_K_HT_EMIT = 47,           /* ht_emit_kernel */
+  OCRF_K_NECK_PREFILTER = 60,    /* neck_prefilter_kernel */
+  OCRF_K_NECK_SAMPLE = 61,       /* neck_pillar_sample_mean_kernel<C> */
+  OCRF_K_NECK_RETAIN = 62,       /* neck_fill_kernel + neck_retain_scatter_kernel */
+  OCRF_K_NECK_HEADS = 63,        /* neck_gauss_heads_kernel */
+  OCRF_K_NECK_NERF_ALPHA = 64,   /* neck_nerf_alpha_kernel */
+  OCRF_K_NECK_NERF_RENDER = 65   /* neck_nerf_render_kernel */
 };
 const char *ocrf_kernel_name(int kernel_id);           /* symbol as rocprofv3 prints it */
 int ocrf_timer_create(int capacity, void **timer_out); /* host pointers */

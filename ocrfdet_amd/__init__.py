@@ -9,7 +9,9 @@ Drop-in mirrors of the reference's Python surface for that path (and nothing els
   diff_gaussian_rasterization (w-depth fork)      ocrfdet_amd.diff_gaussian_rasterization
   ...MVSGaussian.lib.gaussian_renderer.render     ocrfdet_amd.gaussian_renderer.render
   HOA blocks of view_transformer_ocrf.py          ocrfdet_amd.hoa
-  index preparation of view_transformer(_ocrf)    ocrfdet_amd.view_transformer
+  index preparation of view_transformer(_ocrf)    ocrfdet_amd.index_prep
+  ...necks.view_transformer_ocrf                  ocrfdet_amd.view_transformer_ocrf (OcRFViewTransformerFull
+                                                  and its sub-modules; kernels: ocrfdet_amd.neck_ops)
   ==============================================  =================================================
 
 Every op calls the C ABI of ``csrc/libocrf_hip.so`` (``include/ocrf_hip.h``) through ctypes with

@@ -112,6 +112,22 @@ def _declare(L):
     L.ocrf_hoa1_forward.argtypes = [c_void_p] * 3 + [c_int] * 3 + [c_float] + [c_void_p] * 3
     L.ocrf_hoa1_weights_len.restype = c_int
     L.ocrf_hoa1_weights_len.argtypes = []
+    L.ocrf_prefilter.restype = c_int
+    L.ocrf_prefilter.argtypes = [c_void_p] + [c_int] * 4 + [c_float] * 2 + [c_void_p] * 5
+    L.ocrf_pillar_sample_mean.restype = c_int
+    L.ocrf_pillar_sample_mean.argtypes = [c_void_p] * 4 + [c_int] * 6 + [c_void_p]
+    L.ocrf_retain_valid_pixels.restype = c_int
+    L.ocrf_retain_valid_pixels.argtypes = [c_void_p] * 5 + [c_int] * 6 + [c_void_p]
+    L.ocrf_gauss_heads.restype = c_int
+    L.ocrf_gauss_heads.argtypes = [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 5
+    L.ocrf_gauss_heads_params_len.restype = c_int
+    L.ocrf_gauss_heads_params_len.argtypes = [c_int, c_int]
+    L.ocrf_nerf_alpha.restype = c_int
+    L.ocrf_nerf_alpha.argtypes = [c_void_p] * 4 + [c_int] * 3 + [c_void_p]
+    L.ocrf_nerf_render.restype = c_int
+    L.ocrf_nerf_render.argtypes = [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 3
+    L.ocrf_nerf_render_params_len.restype = c_int
+    L.ocrf_nerf_render_params_len.argtypes = []
     L.ocrf_kernel_name.restype = ctypes.c_char_p
     L.ocrf_kernel_name.argtypes = [c_int]
     L.ocrf_timer_create.restype = c_int

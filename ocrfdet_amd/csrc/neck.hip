@@ -1,0 +1,421 @@
+// The stages of OcRFViewTransformerFull.view_transform_core that sit between the two poolings, the
+// render and HOA, eval mode, fused for MI355X:
+//
+//   ocrf_prefilter            depth / semantic softmax + thresholds, feature written channels-last
+//                             (view_transformer_ocrf.py:1323-1331 + the permute of :875/:901)
+//   ocrf_pillar_sample_mean   lidar_points_to_image_values + color_voxels (:924-971): masked
+//                             bilinear taps of every camera averaged per pillar point
+//   ocrf_retain_valid_pixels  retain_valid_pixels (:1004-1024) without the B*6*13 Python loop
+//   ocrf_gauss_heads          VoxelFeatureExtractor (:520-531) + the four Gaussian heads
+//                             (:272-320, :1130-1133): the (B,13,Y,X,80) voxel feature never exists
+//   ocrf_nerf_alpha/_render   the NeRF branch (:1094-1121).  ResizeNetwork (:534-554) has no
+//                             non-linearity, and every consumer of its 80-channel full-resolution
+//                             output starts with a Linear, so upsample2 -> upsample3 -> Linear is
+//                             composed by the caller into one 32 -> (8x8 positions) map per
+//                             consumer: the 6 x (80,H,W) feature images are never materialised.
+//
+// All arithmetic is fp32 with -ffp-contract=off; divisions and exp/log are the IEEE / ocml ones.
+#include <hip/hip_runtime.h>
+
+#include "launch.h"
+#include "ocrf_hip.h"
+
+namespace {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float softplusf(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+// ------------------------------------------------------------------------------------------
+// prefilter: one workgroup = 64 consecutive pixels of one image x 4 depth slices.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void neck_prefilter_kernel(
+    const float* __restrict__ x, int D, int C, int HW, float depth_thr, float sem_thr,
+    float* __restrict__ depth, float* __restrict__ filter_depth, float* __restrict__ semantic,
+    float* __restrict__ feat_cl) {
+  __shared__ float red[4][kWave];
+  __shared__ float keep[kWave];
+  extern __shared__ float tile[];            // [64][C + 1] transposition buffer
+  const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int bn = blockIdx.y, p0 = blockIdx.x * kWave, p = p0 + lane;
+  const bool live = p < HW;
+  const float* xi = x + (size_t)bn * (D + 2 + C) * HW;
+  float m = -INFINITY;
+  for (int d = sl; d < D; d += 4)
+    if (live) m = fmaxf(m, xi[(size_t)d * HW + p]);
+  red[sl][lane] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0][lane], red[1][lane]), fmaxf(red[2][lane], red[3][lane]));
+  __syncthreads();
+  float s = 0.0f;
+  for (int d = sl; d < D; d += 4)
+    if (live) s += expf(xi[(size_t)d * HW + p] - m);
+  red[sl][lane] = s;
+  __syncthreads();
+  s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  for (int d = sl; d < D; d += 4) {
+    if (!live) break;
+    const float v = expf(xi[(size_t)d * HW + p] - m) / s;
+    const size_t o = ((size_t)bn * D + d) * HW + p;
+    depth[o] = v;
+    filter_depth[o] = v < depth_thr ? 0.0f : v;
+  }
+  if (sl == 0) {
+    float k = 0.0f;
+    if (live) {
+      const float a = xi[(size_t)D * HW + p], b = xi[(size_t)(D + 1) * HW + p];
+      const float mm = fmaxf(a, b), ea = expf(a - mm), eb = expf(b - mm), den = ea + eb;
+      const float s0 = ea / den, s1 = eb / den;
+      semantic[((size_t)bn * 2 + 0) * HW + p] = s0;
+      semantic[((size_t)bn * 2 + 1) * HW + p] = s1;
+      k = s1 >= sem_thr ? 1.0f : 0.0f;
+    }
+    keep[lane] = k;
+  }
+  __syncthreads();
+  // feature: read (c, pixel) coalesced along pixels, write the (pixel, c) tile as one contiguous run
+  const int stride = C + 1;
+  for (int c = sl; c < C; c += 4)
+    tile[lane * stride + c] = live ? xi[(size_t)(D + 2 + c) * HW + p] * keep[lane] : 0.0f;
+  __syncthreads();
+  const int npx = min(kWave, HW - p0);
+  float* dst = feat_cl + ((size_t)bn * HW + p0) * C;
+  for (int i = threadIdx.x; i < npx * C; i += 256) dst[i] = tile[(i / C) * stride + (i % C)];
+}
+
+// ------------------------------------------------------------------------------------------
+// bilinear tap exactly as F.grid_sample(align_corners=True, padding zeros) evaluates it after the
+// reference's own normalisation (view_transformer_ocrf.py:929-931)
+// ------------------------------------------------------------------------------------------
+struct Tap {
+  int x0, y0;
+  float w[4];       // nw, ne, sw, se (0 for out-of-range corners)
+  bool in[4];
+};
+
+__device__ __forceinline__ Tap make_tap(float px, float py, int H, int W) {
+  const float wm = (float)(W - 1), hm = (float)(H - 1);
+  const float xn = (px / wm) * 2.0f - 1.0f, yn = (py / hm) * 2.0f - 1.0f;
+  const float ix = ((xn + 1.0f) / 2.0f) * wm, iy = ((yn + 1.0f) / 2.0f) * hm;
+  const float fx = floorf(ix), fy = floorf(iy);
+  const float x1 = fx + 1.0f, y1 = fy + 1.0f;
+  Tap t;
+  t.w[0] = (x1 - ix) * (y1 - iy);
+  t.w[1] = (ix - fx) * (y1 - iy);
+  t.w[2] = (x1 - ix) * (iy - fy);
+  t.w[3] = (ix - fx) * (iy - fy);
+  // the float -> int conversion saturates, so far-away (or non-finite) coordinates stay out of range
+  const bool fin = fabsf(ix) < 1e9f && fabsf(iy) < 1e9f;
+  t.x0 = fin ? (int)fx : -4;
+  t.y0 = fin ? (int)fy : -4;
+  const bool xin0 = t.x0 >= 0 && t.x0 < W, xin1 = t.x0 + 1 >= 0 && t.x0 + 1 < W;
+  const bool yin0 = t.y0 >= 0 && t.y0 < H, yin1 = t.y0 + 1 >= 0 && t.y0 + 1 < H;
+  t.in[0] = xin0 && yin0;
+  t.in[1] = xin1 && yin0;
+  t.in[2] = xin0 && yin1;
+  t.in[3] = xin1 && yin1;
+  return t;
+}
+
+__device__ __forceinline__ float tap_channel(const float* __restrict__ img, const Tap& t, int W) {
+  const float* r0 = img + (size_t)t.y0 * W + t.x0;
+  float acc = 0.0f;
+  if (t.in[0]) acc += r0[0] * t.w[0];
+  if (t.in[1]) acc += r0[1] * t.w[1];
+  if (t.in[2]) acc += r0[W] * t.w[2];
+  if (t.in[3]) acc += r0[W + 1] * t.w[3];
+  return acc;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void neck_pillar_sample_mean_kernel(
+    const float* __restrict__ imgs, const float2* __restrict__ pix, const unsigned char* __restrict__ mask,
+    float* __restrict__ avg, int N, int Hi, int Wi, int ZQ) {
+  const int q = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (q >= ZQ) return;
+  float acc[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) acc[c] = 0.0f;
+  int cnt = 0;
+  for (int n = 0; n < N; ++n) {
+    const size_t pi = ((size_t)b * N + n) * ZQ + q;
+    if (!mask[pi]) continue;
+    ++cnt;
+    const float2 uv = pix[pi];
+    const Tap t = make_tap(uv.x, uv.y, Hi, Wi);
+    const float* img = imgs + ((size_t)b * N + n) * C * Hi * Wi;
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] += tap_channel(img + (size_t)c * Hi * Wi, t, Wi);
+  }
+  const float den = cnt ? (float)cnt : 1.0f;
+  float* o = avg + ((size_t)b * ZQ + q) * C;
+#pragma unroll
+  for (int c = 0; c < C; ++c) o[c] = acc[c] / den;
+}
+
+// ------------------------------------------------------------------------------------------
+// retain_valid_pixels: 255-fill, then every valid projection copies its pixel (all writers of a
+// pixel write the same value)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void neck_fill_kernel(float4* __restrict__ out, size_t n4, float* __restrict__ tail,
+                                                        int ntail, float v) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) out[i] = make_float4(v, v, v, v);
+  if (i < (size_t)ntail) tail[i] = v;
+}
+
+__global__ __launch_bounds__(256) void neck_retain_scatter_kernel(
+    const float* __restrict__ imgs, const float2* __restrict__ pix, const unsigned char* __restrict__ mask,
+    const int* __restrict__ cam_sel, float* __restrict__ out, int N, int C, int H, int W, int ZQ) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.z;
+  const int n = cam_sel ? cam_sel[b] : (int)blockIdx.y;
+  if (q >= ZQ || n < 0 || n >= N) return;
+  const size_t pi = ((size_t)b * N + n) * ZQ + q;
+  if (!mask[pi]) return;
+  const float2 uv = pix[pi];
+  if (uv.x == -1.0f) return;                       // the reference's sentinel test (:1017)
+  const int hi = max(W, H) - 1;
+  // .long() truncates toward zero; clamp to [0, max(W,H)-1] as the reference does (:1018), then to
+  // the image for memory safety (the reference would raise an index error there)
+  int xi = (int)uv.x, yi = (int)uv.y;
+  xi = min(max(xi, 0), min(hi, W - 1));
+  yi = min(max(yi, 0), min(hi, H - 1));
+  const float* src = imgs + ((size_t)b * N + n) * C * H * W + (size_t)yi * W + xi;
+  float* dst = out + (cam_sel ? (size_t)b : ((size_t)b * N + n)) * C * H * W + (size_t)yi * W + xi;
+  for (int c = 0; c < C; ++c) dst[(size_t)c * H * W] = src[(size_t)c * H * W];
+}
+
+// ------------------------------------------------------------------------------------------
+// Gaussian heads.  One thread = one (height, pillar); the 16 hidden units of the four heads are
+// accumulated while the C channels of the pillar stream by (lanes = consecutive pillars: coalesced
+// reads of the NCHW BEV; weights are wave-uniform scalar loads).
+// params: lift_a[Zh] lift_b[Zh] | W1[16][C] (S,R,A,Col: 4 rows each) | W1rgb[4][3] | b1[16] |
+//         S: W2[3][4] b2[3] | R: W2[4][4] b2[4] | A: W2[1][4] b2[1] | Col: W2[3][4] b2[3]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void neck_gauss_heads_kernel(
+    const float* __restrict__ bev, const float* __restrict__ rgb_avg, const float* __restrict__ prm, int C, int Zh, int YX,
+    float* __restrict__ opacity, float* __restrict__ scales, float* __restrict__ rot, float* __restrict__ color) {
+  const int q = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y, b = blockIdx.z;
+  if (q >= YX) return;
+  const float la = prm[h], lb = prm[Zh + h];
+  const float* W1 = prm + 2 * Zh;
+  const float* W1rgb = W1 + 16 * C;
+  const float* b1 = W1rgb + 12;
+  const float* S2 = b1 + 16;
+  const float* R2 = S2 + 15;
+  const float* A2 = R2 + 20;
+  const float* C2 = A2 + 5;
+  float hid[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) hid[k] = 0.0f;
+  const float* bp = bev + (size_t)b * C * YX + q;
+  for (int c = 0; c < C; ++c) {
+    const float f = fmaxf(la * bp[(size_t)c * YX] + lb, 0.0f);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) hid[k] = fmaf(W1[k * C + c], f, hid[k]);
+  }
+  const size_t g = ((size_t)b * Zh + h) * YX + q;
+  const float* rp = rgb_avg + g * 3;
+  const float r01[3] = {rp[0] / 255.0f, rp[1] / 255.0f, rp[2] / 255.0f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    for (int j = 0; j < 3; ++j) hid[12 + k] = fmaf(W1rgb[k * 3 + j], r01[j], hid[12 + k]);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) hid[k] = fmaxf(hid[k] + b1[k], 0.0f);
+  // scales: softplus
+  for (int o = 0; o < 3; ++o) {
+    float v = S2[12 + o];
+    for (int k = 0; k < 4; ++k) v = fmaf(S2[o * 4 + k], hid[k], v);
+    scales[g * 3 + o] = softplusf(v);
+  }
+  // rotation: L2-normalised (F.normalize eps 1e-12)
+  float r[4], nn = 0.0f;
+  for (int o = 0; o < 4; ++o) {
+    float v = R2[16 + o];
+    for (int k = 0; k < 4; ++k) v = fmaf(R2[o * 4 + k], hid[4 + k], v);
+    r[o] = v;
+    nn = fmaf(v, v, nn);
+  }
+  const float den = fmaxf(sqrtf(nn), 1e-12f);
+  *reinterpret_cast<float4*>(rot + g * 4) = make_float4(r[0] / den, r[1] / den, r[2] / den, r[3] / den);
+  // opacity
+  {
+    float v = A2[4];
+    for (int k = 0; k < 4; ++k) v = fmaf(A2[k], hid[8 + k], v);
+    opacity[g] = sigmoidf(v);
+  }
+  for (int o = 0; o < 3; ++o) {
+    float v = C2[12 + o];
+    for (int k = 0; k < 4; ++k) v = fmaf(C2[o * 4 + k], hid[12 + k], v);
+    color[g * 3 + o] = sigmoidf(v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// NeRF branch.  z (M,32,h2,w2) is the output of ResizeNetwork.conv2; an output pixel (y, x) of the
+// 8x up-sampled image reads z[:, y/8, x/8] and the composed map of its sub-position (y%8, x%8).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void neck_nerf_alpha_kernel(
+    const float* __restrict__ z, const float* __restrict__ Wm /*[32][64]*/, const float* __restrict__ cm /*[64]*/,
+    float* __restrict__ alpha, int h2, int w2) {
+  const int Wo = 8 * w2;
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, m = blockIdx.z;
+  if (x >= Wo) return;
+  const int pos = (y & 7) * 8 + (x & 7);
+  const float* zp = z + ((size_t)m * 32 * h2 + (y >> 3)) * w2 + (x >> 3);
+  float v = cm[pos];
+#pragma unroll 8
+  for (int ci = 0; ci < 32; ++ci) v = fmaf(zp[(size_t)ci * h2 * w2], Wm[ci * 64 + pos], v);
+  alpha[((size_t)m * 8 * h2 + y) * Wo + x] = 1.0f - expf(-softplusf(v));
+}
+
+// prm: W12[12][32][64] | c12[12][64] | W1rgb[12][3] | Cn: W2[3][4] b2[3] | R1: W2[3][4] b2[3] | R2: W2[1][4] b2[1]
+// hidden order: C_MLP_nerf (0-3), img_feat_resize1 (4-7), img_feat_resize2 (8-11).  The depth weight is a
+// softmax over a size-1 axis (:1108), i.e. 1, so D_MLP_nerf never reaches an output and is not evaluated.
+__global__ __launch_bounds__(256) void neck_nerf_render_kernel(
+    const float* __restrict__ z, const int* __restrict__ cam_sel, const float* __restrict__ alpha,
+    const float* __restrict__ sparse_rgb, const float* __restrict__ prm, int N, int h2, int w2,
+    float* __restrict__ img_n, float* __restrict__ dep_n) {
+  const int Wo = 8 * w2, Ho = 8 * h2;
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  if (x >= Wo) return;
+  const int cs = cam_sel[b];
+  if (cs < 0 || cs >= N) return;
+  const int m = b * N + cs;
+  const int pos = (y & 7) * 8 + (x & 7);
+  const float* zp = z + ((size_t)m * 32 * h2 + (y >> 3)) * w2 + (x >> 3);
+  const float* W12 = prm;
+  const float* c12 = W12 + 12 * 32 * 64;
+  const float* W1rgb = c12 + 12 * 64;
+  const float* Cn = W1rgb + 36;
+  const float* R1 = Cn + 15;
+  const float* R2 = R1 + 15;
+  float hid[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) hid[k] = c12[k * 64 + pos];
+  for (int ci = 0; ci < 32; ++ci) {
+    const float zv = zp[(size_t)ci * h2 * w2];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) hid[k] = fmaf(zv, W12[(k * 32 + ci) * 64 + pos], hid[k]);
+  }
+  const size_t pix = (size_t)y * Wo + x, plane = (size_t)Ho * Wo;
+  const float* sp = sparse_rgb + (size_t)b * 3 * plane + pix;
+  const float r01[3] = {sp[0] / 255.0f, sp[plane] / 255.0f, sp[2 * plane] / 255.0f};
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    float v = hid[k];
+    for (int j = 0; j < 3; ++j) v = fmaf(W1rgb[k * 3 + j], r01[j], v);
+    hid[k] = fmaxf(v, 0.0f);
+  }
+  float cw[3], rad[3];
+  for (int o = 0; o < 3; ++o) {
+    float v = Cn[12 + o], u = R1[12 + o];
+    for (int k = 0; k < 4; ++k) {
+      v = fmaf(Cn[o * 4 + k], hid[k], v);
+      u = fmaf(R1[o * 4 + k], hid[4 + k], u);
+    }
+    cw[o] = sigmoidf(v);
+    rad[o] = fmaxf(u, 0.0f);
+  }
+  const float mx = fmaxf(cw[0], fmaxf(cw[1], cw[2]));
+  const float e0 = expf(cw[0] - mx), e1 = expf(cw[1] - mx), e2 = expf(cw[2] - mx), es = e0 + e1 + e2;
+  float d = R2[4];
+  for (int k = 0; k < 4; ++k) d = fmaf(R2[k], hid[8 + k], d);
+  d = fmaxf(d, 0.0f);
+  const float a = alpha[(size_t)m * plane + pix];
+  float* io = img_n + (size_t)b * 3 * plane + pix;
+  io[0] = a * (rad[0] * (e0 / es));
+  io[plane] = a * (rad[1] * (e1 / es));
+  io[2 * plane] = a * (rad[2] * (e2 / es));
+  dep_n[(size_t)b * plane + pix] = a * d;
+}
+
+inline int last_error() { return (int)hipGetLastError(); }
+
+}  // namespace
+
+extern "C" {
+
+int ocrf_prefilter(const float* x, int BN, int D, int C, int HW, float depth_threshold, float semantic_threshold,
+                   float* depth, float* filter_depth, float* semantic, float* feat_channels_last,
+                   ocrf_stream_t stream) {
+  if (BN <= 0 || D <= 0 || C <= 0 || HW <= 0) return (int)hipErrorInvalidValue;
+  if (!x || !depth || !filter_depth || !semantic || !feat_channels_last) return (int)hipErrorInvalidValue;
+  const size_t lds = (size_t)kWave * (C + 1) * sizeof(float);
+  if (lds > 60000) return (int)hipErrorInvalidValue;
+  ocrf::launch(OCRF_K_NECK_PREFILTER, neck_prefilter_kernel, dim3((HW + kWave - 1) / kWave, BN), dim3(256), lds,
+               (hipStream_t)stream, x, D, C, HW, depth_threshold, semantic_threshold, depth, filter_depth, semantic,
+               feat_channels_last);
+  return last_error();
+}
+
+int ocrf_pillar_sample_mean(const float* imgs, const float* pix, const unsigned char* mask, float* avg, int B, int N,
+                            int C, int Hi, int Wi, int ZQ, ocrf_stream_t stream) {
+  if (B <= 0 || N <= 0 || Hi < 2 || Wi < 2 || ZQ <= 0 || !imgs || !pix || !mask || !avg)
+    return (int)hipErrorInvalidValue;
+  const dim3 grid((ZQ + 255) / 256, B), block(256);
+  const float2* p2 = reinterpret_cast<const float2*>(pix);
+  if (C == 1)
+    ocrf::launch(OCRF_K_NECK_SAMPLE, neck_pillar_sample_mean_kernel<1>, grid, block, 0, (hipStream_t)stream, imgs, p2,
+                 mask, avg, N, Hi, Wi, ZQ);
+  else if (C == 3)
+    ocrf::launch(OCRF_K_NECK_SAMPLE, neck_pillar_sample_mean_kernel<3>, grid, block, 0, (hipStream_t)stream, imgs, p2,
+                 mask, avg, N, Hi, Wi, ZQ);
+  else
+    return (int)hipErrorInvalidValue;
+  return last_error();
+}
+
+int ocrf_retain_valid_pixels(const float* imgs, const float* pix, const unsigned char* mask, const int* cam_sel,
+                             float* out, int B, int N, int C, int H, int W, int ZQ, ocrf_stream_t stream) {
+  if (B <= 0 || N <= 0 || C <= 0 || H <= 0 || W <= 0 || ZQ <= 0 || !imgs || !pix || !mask || !out)
+    return (int)hipErrorInvalidValue;
+  const size_t total = (size_t)B * (cam_sel ? 1 : N) * C * H * W;
+  const size_t n4 = (reinterpret_cast<uintptr_t>(out) & 15) ? 0 : total / 4;
+  const int ntail = (int)(total - 4 * n4 > 0x7fffffff ? 0 : total - 4 * n4);
+  if (total - 4 * n4 > 0x7fffffff) return (int)hipErrorInvalidValue;   // misaligned giant buffer: not supported
+  const size_t nthreads = n4 > (size_t)ntail ? n4 : (size_t)ntail;
+  ocrf::launch(OCRF_K_NECK_RETAIN, neck_fill_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0,
+               (hipStream_t)stream, reinterpret_cast<float4*>(out), n4, out + 4 * n4, ntail, 255.0f);
+  ocrf::launch(OCRF_K_NECK_RETAIN, neck_retain_scatter_kernel, dim3((ZQ + 255) / 256, cam_sel ? 1 : N, B), dim3(256),
+               0, (hipStream_t)stream, imgs, reinterpret_cast<const float2*>(pix), mask, cam_sel, out, N, C, H, W, ZQ);
+  return last_error();
+}
+
+int ocrf_gauss_heads_params_len(int C, int Zh) { return 2 * Zh + 16 * C + 12 + 16 + 15 + 20 + 5 + 15; }
+
+int ocrf_gauss_heads(const float* bev, const float* rgb_avg, const float* params, int B, int C, int Zh, int YX,
+                     float* opacity, float* scales, float* rotations, float* color, ocrf_stream_t stream) {
+  if (B <= 0 || C <= 0 || Zh <= 0 || YX <= 0 || !bev || !rgb_avg || !params || !opacity || !scales || !rotations ||
+      !color)
+    return (int)hipErrorInvalidValue;
+  if (reinterpret_cast<uintptr_t>(rotations) & 15) return (int)hipErrorInvalidValue;
+  ocrf::launch(OCRF_K_NECK_HEADS, neck_gauss_heads_kernel, dim3((YX + 255) / 256, Zh, B), dim3(256), 0,
+               (hipStream_t)stream, bev, rgb_avg, params, C, Zh, YX, opacity, scales, rotations, color);
+  return last_error();
+}
+
+int ocrf_nerf_alpha(const float* z, const float* w_sigma, const float* c_sigma, float* alpha, int M, int h2, int w2,
+                    ocrf_stream_t stream) {
+  if (M <= 0 || h2 <= 0 || w2 <= 0 || !z || !w_sigma || !c_sigma || !alpha) return (int)hipErrorInvalidValue;
+  ocrf::launch(OCRF_K_NECK_NERF_ALPHA, neck_nerf_alpha_kernel, dim3((8 * w2 + 255) / 256, 8 * h2, M), dim3(256), 0,
+               (hipStream_t)stream, z, w_sigma, c_sigma, alpha, h2, w2);
+  return last_error();
+}
+
+int ocrf_nerf_render_params_len(void) { return 12 * 32 * 64 + 12 * 64 + 36 + 15 + 15 + 5; }
+
+int ocrf_nerf_render(const float* z, const int* cam_sel, const float* alpha, const float* sparse_rgb,
+                     const float* params, int B, int N, int h2, int w2, float* render_image_n, float* render_depth_n,
+                     ocrf_stream_t stream) {
+  if (B <= 0 || N <= 0 || h2 <= 0 || w2 <= 0 || !z || !cam_sel || !alpha || !sparse_rgb || !params ||
+      !render_image_n || !render_depth_n)
+    return (int)hipErrorInvalidValue;
+  ocrf::launch(OCRF_K_NECK_NERF_RENDER, neck_nerf_render_kernel, dim3((8 * w2 + 255) / 256, 8 * h2, B), dim3(256), 0,
+               (hipStream_t)stream, z, cam_sel, alpha, sparse_rgb, params, N, h2, w2, render_image_n, render_depth_n);
+  return last_error();
+}
+
+}  // extern "C"

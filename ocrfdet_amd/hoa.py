@@ -28,7 +28,7 @@ from torch import nn
 from . import _lib
 
 __all__ = ['HeightAttention', 'OpacityVoxelToBEVConverter', 'ObatinOpacityMask', 'DeformableAttention2D',
-           'CPB', 'hoa1']
+           'CPB', 'hoa1', 'spatial_gate']
 
 
 def _f32c(t):
@@ -188,6 +188,28 @@ class OpacityVoxelToBEVConverter(nn.Module):
         return out
 
 
+def spatial_gate(weight, x, addend, want_gated):
+    """mask = sigmoid(conv_kxk([mean_c(x), max_c(x)]; weight (1,2,k,k)) + addend (B,1,Y,X)) and,
+    optionally, x * mask — the shared form of ObatinOpacityMask (view_transformer_ocrf.py:230-242,
+    :1197-1199) and BEVGeomAttention (:215-228, :1190), as two HIP kernels (csrc/hoa.hip)."""
+    _lib.require_cuda(x, addend)
+    B, C, Y, X = x.shape
+    x, ob = _f32c(x), _f32c(addend)
+    w = _f32c(weight)
+    k = w.shape[-1]
+    stats = torch.empty(B, 2, Y, X, device=x.device)
+    mask = torch.empty(B, 1, Y, X, device=x.device)
+    gated = torch.empty_like(x) if want_gated else None
+    L = _lib.lib()
+    with torch.cuda.device(x.device):
+        st = _lib.stream_ptr(x.device)
+        _lib.check(L.ocrf_hoa_channel_stats(_lib.ptr(x), B, C, Y, X, _lib.ptr(stats), st), 'ocrf_hoa_channel_stats')
+        _lib.check(L.ocrf_hoa_opacity_mask_gate(_lib.ptr(x), _lib.ptr(stats), _lib.ptr(ob), _lib.ptr(w), k, B, C,
+                                                Y, X, _lib.ptr(mask), _lib.ptr(gated), st),
+                   'ocrf_hoa_opacity_mask_gate')
+    return mask, gated
+
+
 class ObatinOpacityMask(nn.Module):          # sic: the reference's spelling
     def __init__(self, kernel_size=7):
         super().__init__()
@@ -195,22 +217,7 @@ class ObatinOpacityMask(nn.Module):          # sic: the reference's spelling
         self.sigmoid = nn.Sigmoid()
 
     def _run(self, x, opacity_bev, want_gated):
-        _lib.require_cuda(x, opacity_bev)
-        B, C, Y, X = x.shape
-        x, ob = _f32c(x), _f32c(opacity_bev)
-        w = _f32c(self.conv.weight)
-        k = w.shape[-1]
-        stats = torch.empty(B, 2, Y, X, device=x.device)
-        mask = torch.empty(B, 1, Y, X, device=x.device)
-        gated = torch.empty_like(x) if want_gated else None
-        L = _lib.lib()
-        with torch.cuda.device(x.device):
-            st = _lib.stream_ptr(x.device)
-            _lib.check(L.ocrf_hoa_channel_stats(_lib.ptr(x), B, C, Y, X, _lib.ptr(stats), st), 'ocrf_hoa_channel_stats')
-            _lib.check(L.ocrf_hoa_opacity_mask_gate(_lib.ptr(x), _lib.ptr(stats), _lib.ptr(ob), _lib.ptr(w), k, B, C,
-                                                    Y, X, _lib.ptr(mask), _lib.ptr(gated), st),
-                       'ocrf_hoa_opacity_mask_gate')
-        return mask, gated
+        return spatial_gate(self.conv.weight, x, opacity_bev, want_gated)
 
     def forward(self, x, opacity_bev):
         return self._run(x, opacity_bev, False)[0]

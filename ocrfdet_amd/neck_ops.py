@@ -1,0 +1,205 @@
+"""Python boundary of ``csrc/neck.hip``: the stages of ``view_transform_core`` between the poolings,
+the render and HOA, eval mode.
+
+Each function takes / returns CUDA tensors, calls the C ABI (``include/ocrf_hip.h``) on torch's
+current stream and raises ``OcrfHipError`` on CPU tensors — there is no fallback.  The ``pack_*`` /
+``compose_*`` helpers turn the reference's ``state_dict`` layout into the flat parameter blocks the
+kernels read; they are pure torch and run anywhere.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+__all__ = ['prefilter', 'pillar_sample_mean', 'retain_valid_pixels', 'gauss_heads', 'pack_gauss_head_params',
+           'compose_nerf_maps', 'nerf_alpha', 'nerf_render']
+
+
+def _f32c(t):
+    return t.contiguous().float()
+
+
+def prefilter(x, D, C, depth_threshold, semantic_threshold):
+    """view_transformer_ocrf.py:1323-1331.  x (BN, D+2+C, H, W) ->
+    depth (BN,D,H,W), filter_depth (BN,D,H,W), semantic (BN,2,H,W), filter_feat channels-last
+    (BN,H,W,C) (the operand the poolings permute to, :875/:901)."""
+    _lib.require_cuda(x)
+    x = _f32c(x)
+    BN, ch, H, W = x.shape
+    if ch < D + 2 + C:
+        raise ValueError(f'prefilter: {ch} channels < D + 2 + C = {D + 2 + C}')
+    if ch != D + 2 + C:
+        x = x[:, :D + 2 + C].contiguous()
+    dev = x.device
+    depth = torch.empty(BN, D, H, W, device=dev)
+    fdepth = torch.empty_like(depth)
+    sem = torch.empty(BN, 2, H, W, device=dev)
+    feat = torch.empty(BN, H, W, C, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().ocrf_prefilter(_lib.ptr(x), BN, D, C, H * W, ctypes.c_float(depth_threshold),
+                                             ctypes.c_float(semantic_threshold), _lib.ptr(depth), _lib.ptr(fdepth),
+                                             _lib.ptr(sem), _lib.ptr(feat), _lib.stream_ptr(dev)), 'ocrf_prefilter')
+    return depth, fdepth, sem, feat
+
+
+def _mask_bytes(mask, shape):
+    m = mask.reshape(shape)
+    if m.dtype != torch.bool and m.dtype != torch.uint8:
+        m = m != 0
+    return m.contiguous().view(torch.uint8) if m.dtype == torch.bool else m.contiguous()
+
+
+def pillar_sample_mean(imgs, pix, mask, view_hw=None):
+    """``lidar_points_to_image_values`` + ``color_voxels``'s ``avg_color``
+    (view_transformer_ocrf.py:924-959).  imgs (B,N,C,H,W), pix (B,N,Zh,Q,2) pixel coordinates, mask
+    (B,N,Zh,Q[,1]) -> (B,Zh,Q,C).  ``view_hw``: the (H,W) the caller's *view* of the image memory
+    claims, for the reference's swapped view of the alpha volume (:1123)."""
+    _lib.require_cuda(imgs, pix, mask)
+    B, N, C, H, W = imgs.shape
+    if view_hw is not None:
+        if view_hw[0] * view_hw[1] != H * W:
+            raise ValueError('view_hw must cover the same memory as the image')
+        H, W = int(view_hw[0]), int(view_hw[1])
+    Zh, Q = pix.shape[2], pix.shape[3]
+    imgs, pix = _f32c(imgs), _f32c(pix)
+    m = _mask_bytes(mask, (B, N, Zh * Q))
+    avg = torch.empty(B, Zh, Q, C, device=imgs.device)
+    with torch.cuda.device(imgs.device):
+        _lib.check(_lib.lib().ocrf_pillar_sample_mean(_lib.ptr(imgs), _lib.ptr(pix), _lib.ptr(m), _lib.ptr(avg), B, N, C,
+                                                      H, W, Zh * Q, _lib.stream_ptr(imgs.device)),
+                   'ocrf_pillar_sample_mean')
+    return avg
+
+
+def retain_valid_pixels(image_matrix, pseudo_point_cloud, mask, cam_sel=None):
+    """``retain_valid_pixels`` (view_transformer_ocrf.py:1004-1024).  image_matrix (B,N,C,H,W),
+    pseudo_point_cloud (B,N,Zh,...,2) pixel coordinates, mask (B,N,Zh,...[,1]).
+    ``cam_sel`` None -> (B,N,C,H,W) like the reference; an int32 device vector (B) -> only camera
+    ``cam_sel[b]`` of each sample, (B,C,H,W) (the reference consumes just that one, :1104)."""
+    _lib.require_cuda(image_matrix, pseudo_point_cloud, mask)
+    B, N, C, H, W = image_matrix.shape
+    imgs = _f32c(image_matrix)
+    pix = _f32c(pseudo_point_cloud).reshape(B, N, -1, 2)
+    ZQ = pix.shape[2]
+    m = _mask_bytes(mask, (B, N, ZQ))
+    dev = imgs.device
+    if cam_sel is not None:
+        _lib.require_cuda(cam_sel)
+        cam_sel = cam_sel.to(torch.int32).contiguous()
+        out = torch.empty(B, C, H, W, device=dev)
+    else:
+        out = torch.empty(B, N, C, H, W, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().ocrf_retain_valid_pixels(_lib.ptr(imgs), _lib.ptr(pix), _lib.ptr(m), _lib.ptr(cam_sel),
+                                                       _lib.ptr(out), B, N, C, H, W, ZQ, _lib.stream_ptr(dev)),
+                   'ocrf_retain_valid_pixels')
+    return out
+
+
+def pack_gauss_head_params(vfe, s_mlp, r_mlp, a_mlp, c_mlp):
+    """Flat parameter block of ``ocrf_gauss_heads`` (layout: csrc/neck.hip) from the reference's
+    modules: ``VoxelFeatureExtractor`` with its BatchNorm3d folded (eval statistics) and the four
+    heads' ``fc1`` / ``fc2``."""
+    conv, bn = vfe.conv[0], vfe.conv[1]
+    with torch.no_grad():
+        s = (bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps))
+        a = conv.weight.double().reshape(-1) * s
+        b = (conv.bias.double() - bn.running_mean.double()) * s + bn.bias.double()
+        C = s_mlp.fc1.in_features
+        w1 = torch.cat((s_mlp.fc1.weight, r_mlp.fc1.weight, a_mlp.fc1.weight, c_mlp.fc1.weight[:, :C]), 0)
+        b1 = torch.cat((s_mlp.fc1.bias, r_mlp.fc1.bias, a_mlp.fc1.bias, c_mlp.fc1.bias))
+        parts = [a.float(), b.float(), w1.reshape(-1), c_mlp.fc1.weight[:, C:].reshape(-1), b1]
+        for m in (s_mlp, r_mlp, a_mlp, c_mlp):
+            parts += [m.fc2.weight.reshape(-1), m.fc2.bias]
+        return torch.cat([p.detach().float().reshape(-1) for p in parts]).contiguous()
+
+
+def gauss_heads(bev, rgb_avg, params, num_height):
+    """VoxelFeatureExtractor + S/R/A/C_MLP (view_transformer_ocrf.py:1051, :1130-1133) without the
+    (B,13,Y,X,80) voxel feature.  bev (B,C,Y,X), rgb_avg (B,Zh,Y*X,3) in 0..255 ->
+    opacity (B,P,1), scales (B,P,3), rotations (B,P,4), color (B,P,3), P = Zh*Y*X."""
+    _lib.require_cuda(bev, rgb_avg, params)
+    B, C, Y, X = bev.shape
+    bev, rgb_avg = _f32c(bev), _f32c(rgb_avg)
+    L = _lib.lib()
+    if params.numel() != L.ocrf_gauss_heads_params_len(C, num_height):
+        raise ValueError('gauss_heads: parameter block does not match (C, num_height)')
+    P = num_height * Y * X
+    dev = bev.device
+    op, sc = torch.empty(B, P, 1, device=dev), torch.empty(B, P, 3, device=dev)
+    rot, col = torch.empty(B, P, 4, device=dev), torch.empty(B, P, 3, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.ocrf_gauss_heads(_lib.ptr(bev), _lib.ptr(rgb_avg), _lib.ptr(params), B, C, num_height, Y * X,
+                                      _lib.ptr(op), _lib.ptr(sc), _lib.ptr(rot), _lib.ptr(col), _lib.stream_ptr(dev)),
+                   'ocrf_gauss_heads')
+    return op, sc, rot, col
+
+
+def compose_nerf_maps(resize, sigma, c_mlp_nerf, img_feat_resize1, img_feat_resize2):
+    """ResizeNetwork has no non-linearity (view_transformer_ocrf.py:534-554), so for every consumer
+    whose first layer is a Linear ``L`` (weights w (k,80), bias c (k)):
+        L(upsample3(upsample2(z)))[y, x] = z[:, y//8, x//8] . M[:, pos] + const[pos],  pos = (y%8)*8 + x%8
+    with M (k,32,64).  Composed in float64.  -> (w_sigma (32,64), c_sigma (64),
+    render parameter block of ``ocrf_nerf_render``) as float32 tensors on the modules' device."""
+    with torch.no_grad():
+        W2, b2 = resize.upsample2.weight.double(), resize.upsample2.bias.double()      # (32,80,2,2), (80)
+        W3, b3 = resize.upsample3.weight.double(), resize.upsample3.bias.double()      # (80,80,4,4), (80)
+
+        def compose(w, c):
+            """w (k,80), c (k) -> M (k,32,8,8) flattened to (k,32,64), const (k,64)."""
+            t = torch.einsum('ofrs,kf->kors', W3, w)                 # (k, 80 mid channels, 4, 4)
+            M = torch.einsum('iopq,kors->kiprqs', W2, t)             # y%8 = 4p + r, x%8 = 4q + s
+            const = torch.einsum('o,kors->krs', b2, t) + (w @ b3 + c)[:, None, None]    # (k,4,4)
+            const = const[:, None, :, None, :].expand(-1, 2, -1, 2, -1)                 # (k,p,r,q,s)
+            k = w.shape[0]
+            return M.reshape(k, 32, 64), const.reshape(k, 64)
+        ws = sigma[1].weight.double() @ sigma[0].weight.double()                         # (1,80)
+        cs = sigma[1].weight.double() @ sigma[0].bias.double() + sigma[1].bias.double()
+        Ms, consts = compose(ws, cs)
+        heads = (c_mlp_nerf, img_feat_resize1, img_feat_resize2)
+        w1 = torch.cat([h.fc1.weight.double()[:, :80] for h in heads], 0)               # (12,80)
+        b1 = torch.cat([h.fc1.bias.double() for h in heads])
+        M12, c12 = compose(w1, b1)
+        rgb = torch.cat([h.fc1.weight.double()[:, 80:] for h in heads], 0)              # (12,3)
+        parts = [M12, c12, rgb]
+        for h in heads:
+            parts += [h.fc2.weight.double(), h.fc2.bias.double()]
+        block = torch.cat([p.reshape(-1) for p in parts]).float().contiguous()
+        return Ms[0].float().contiguous(), consts[0].float().contiguous(), block
+
+
+def nerf_alpha(z, w_sigma, c_sigma):
+    """alpha = 1 - exp(-softplus(sigma(feat))) for every camera image (view_transformer_ocrf.py:
+    1096-1102) from z (M,32,h2,w2) = ResizeNetwork.conv2's output.  -> (M, 8*h2, 8*w2)."""
+    _lib.require_cuda(z, w_sigma, c_sigma)
+    z = _f32c(z)
+    M, ci, h2, w2 = z.shape
+    if ci != 32 or w_sigma.numel() != 32 * 64 or c_sigma.numel() != 64:
+        raise ValueError('nerf_alpha: z must have 32 channels and the maps 32x64 / 64 entries')
+    alpha = torch.empty(M, 8 * h2, 8 * w2, device=z.device)
+    with torch.cuda.device(z.device):
+        _lib.check(_lib.lib().ocrf_nerf_alpha(_lib.ptr(z), _lib.ptr(w_sigma), _lib.ptr(c_sigma), _lib.ptr(alpha), M,
+                                              h2, w2, _lib.stream_ptr(z.device)), 'ocrf_nerf_alpha')
+    return alpha
+
+
+def nerf_render(z, cam_sel, alpha, sparse_rgb, params, n_cams):
+    """NeRF-branch image / depth of the selected camera of each sample (view_transformer_ocrf.py:
+    1104-1121).  z (B*N,32,h2,w2), cam_sel (B) int32, alpha (B*N,H,W), sparse_rgb (B,3,H,W) in
+    0..255 -> render_image_N (B,3,H,W), render_depth_N (B,1,H,W)."""
+    _lib.require_cuda(z, cam_sel, alpha, sparse_rgb, params)
+    z, alpha, sparse_rgb = _f32c(z), _f32c(alpha), _f32c(sparse_rgb)
+    M, _, h2, w2 = z.shape
+    B = M // n_cams
+    L = _lib.lib()
+    if params.numel() != L.ocrf_nerf_render_params_len() or tuple(sparse_rgb.shape) != (B, 3, 8 * h2, 8 * w2):
+        raise ValueError('nerf_render: parameter block or sparse_rgb shape mismatch')
+    cam_sel = cam_sel.to(torch.int32).contiguous()
+    img = torch.empty(B, 3, 8 * h2, 8 * w2, device=z.device)
+    dep = torch.empty(B, 1, 8 * h2, 8 * w2, device=z.device)
+    with torch.cuda.device(z.device):
+        _lib.check(L.ocrf_nerf_render(_lib.ptr(z), _lib.ptr(cam_sel), _lib.ptr(alpha), _lib.ptr(sparse_rgb),
+                                      _lib.ptr(params), B, n_cams, h2, w2, _lib.ptr(img), _lib.ptr(dep),
+                                      _lib.stream_ptr(z.device)), 'ocrf_nerf_render')
+    return img, dep

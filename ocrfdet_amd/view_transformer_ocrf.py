@@ -1,0 +1,615 @@
+"""``OcRFViewTransformerFull`` — the reference's neck (mmdet3d/models/necks/view_transformer_ocrf.py:
+577-648 ctor, :1040-1201 ``view_transform_core``, :1319-1334 ``forward``) with the same constructor
+keywords, sub-module attribute names and ``state_dict`` keys (the config addresses ``S_MLP``, ``R_MLP``,
+``A_MLP``, ``C_MLP``, ``C_MLP_nerf``, ``D_MLP_nerf``, ``sigma``, ``img_feat_resize1/2`` by name,
+configs/ocrfdet/ocrfdet.py:259-337), assembled MI355X-first:
+
+  eval mode (inference; everything below runs as HIP kernels behind include/ocrf_hip.h unless noted)
+    pre-filter + channels-last feature ............ ocrf_prefilter
+    rank vectors of both poolings ................. ocrf_lss_prepare / ocrf_ht_prepare (cached when
+                                                    ``accelerate=True``)
+    LSS pool, HT pool ............................. ocrf_bev_pool_v2_nchw
+    voxel colours, alpha volume ................... ocrf_pillar_sample_mean
+    sparse ground-truth image ..................... ocrf_retain_valid_pixels (selected camera only)
+    voxel lift + 4 Gaussian heads ................. ocrf_gauss_heads (no (B,13,Y,X,80) tensor)
+    NeRF branch ................................... 3 small MIOpen convolutions batched over all
+                                                    cameras, then ocrf_nerf_alpha / ocrf_nerf_render on
+                                                    composed maps (no (80,H,W) feature images)
+    Gaussian render ............................... ocrf_rasterize_forward
+    HOA-1 / HOA-2 / HOA-3, geometry attention ..... ocrf_hoa1_forward, ocrf_hoa_unet_block, ...,
+                                                    ocrf_hoa_opacity_mask_gate
+    DualFeatFusion / ProbNet convolutions ......... PyTorch-ROCm (MIOpen), SURVEY 8a row a27
+  training mode: the reference's op sequence as differentiable torch ops around the differentiable
+    HIP ops (bev_pool_v2 and the rasteriser have HIP backwards).
+
+``depth_net`` (a CNN outside the path, view_transformer.py:463-630) is injected: pass
+``depth_net=module``; when the reference's mmdet3d is importable its ``DepthNet`` is built from
+``depthnet_cfg`` exactly as the reference does (:588-589).
+"""
+import math
+import random
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import bevpool, gaussian_renderer, hoa, index_prep, neck_ops
+
+__all__ = ['OcRFViewTransformerFull', 'MS_CAM', 'ChannelAttention', 'SpatialAttention', 'ResCBAMBlock', 'ProbNet',
+           'DualFeatFusion', 'BEVGeomAttention', 'ScaleFactorMLP', 'RotationFactorMLP', 'OpacityFactorMLP',
+           'ColorFactorMLPGaussian', 'ColorFactorMLPNerf', 'DepthFactorMLPNerf', 'ImgFeatResize1', 'ImgFeatResize2',
+           'VoxelFeatureExtractor', 'ResizeNetwork', 'LinearWeightedImage', 'LinearWeightedDepth',
+           'LearnedPositionalEncoding', 'DiceLoss']
+
+
+# ------------------------------------------------------------------------------------------------
+# small building blocks (structure fixed by the reference's state_dict; :36-228, :272-380, :520-575)
+# ------------------------------------------------------------------------------------------------
+def _conv_bn(cin, cout, k=1, relu=False):
+    layers = [nn.Conv2d(cin, cout, kernel_size=k, stride=1, padding=k // 2), nn.BatchNorm2d(cout)]
+    return layers + [nn.ReLU(inplace=True)] if relu else layers
+
+
+class MS_CAM(nn.Module):
+    """Multi-scale channel attention (:36-66)."""
+
+    def __init__(self, input_channel=64, output_channel=64, r=4):
+        super().__init__()
+        mid = int(input_channel // r)
+        self.local_att = nn.Sequential(*_conv_bn(input_channel, mid, relu=True), *_conv_bn(mid, output_channel))
+        self.global_att = nn.Sequential(nn.AdaptiveAvgPool2d(1), *_conv_bn(input_channel, mid, relu=True),
+                                        *_conv_bn(mid, output_channel))
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, x):
+        return self.sigmoid(self.local_att(x) + self.global_att(x))
+
+
+class ChannelAttention(nn.Module):
+    def __init__(self, input_channel, output_channel, ratio=16):
+        super().__init__()
+        self.avg_pool, self.max_pool = nn.AdaptiveAvgPool2d(1), nn.AdaptiveMaxPool2d(1)
+        self.fc = nn.Sequential(nn.Conv2d(input_channel, input_channel // ratio, 1, bias=False), nn.ReLU(),
+                                nn.Conv2d(input_channel // ratio, output_channel, 1, bias=False))
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, x):
+        return self.sigmoid(self.fc(self.avg_pool(x)) + self.fc(self.max_pool(x)))
+
+
+def _spatial_logits(x, conv):
+    return conv(torch.cat((x.mean(1, keepdim=True), x.amax(1, keepdim=True)), 1))
+
+
+class SpatialAttention(nn.Module):
+    def __init__(self, kernel_size=7):
+        super().__init__()
+        self.conv1 = nn.Conv2d(2, 1, kernel_size, padding=kernel_size // 2, bias=False)
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, x):
+        return self.sigmoid(_spatial_logits(x, self.conv1))
+
+
+class ResCBAMBlock(nn.Module):
+    """:100-137.  Note the reference feeds ``conv2`` with ``inplanes`` channels (== planes here)."""
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.ca, self.sa = ChannelAttention(planes, planes), SpatialAttention()
+        self.downsample, self.stride = downsample, stride
+
+    def forward(self, x):
+        out = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
+        out = self.ca(out) * out
+        if out.is_cuda and not torch.is_grad_enabled():
+            out = hoa.spatial_gate(self.sa.conv1.weight, out, torch.zeros_like(out[:, :1]), True)[1]
+        else:
+            out = self.sa(out) * out
+        res = x if self.downsample is None else self.downsample(x)
+        return self.relu(out + res)
+
+
+class DiceLoss(nn.Module):
+    def __init__(self, use_sigmoid=True, loss_weight=1.):
+        super().__init__()
+        self.use_sigmoid, self.loss_weight = use_sigmoid, loss_weight
+
+    def forward(self, inputs, targets, smooth=1e-5):
+        p = (torch.sigmoid(inputs) if self.use_sigmoid else inputs).reshape(-1)
+        t = targets.reshape(-1)
+        dice = (2. * (p * t).sum() + smooth) / (p.sum() + t.sum() + smooth)
+        return self.loss_weight * (1 - dice)
+
+
+class ProbNet(nn.Module):
+    """BEV foreground-probability head (:139-201); the losses keep their buffers so checkpoints load."""
+
+    def __init__(self, in_channels=512, scale_factor=1, with_centerness=False, loss_weight=6.0, bev_size=None):
+        super().__init__()
+        self.loss_weight, self.loss_weight_opacity = loss_weight, 6.0
+        mid = in_channels // 2
+        self.base_conv = nn.Sequential(*_conv_bn(in_channels, mid, k=3, relu=True))
+        self.prob_conv = nn.Sequential(ResCBAMBlock(mid, mid))
+        self.mask_net = nn.Conv2d(mid, 1, kernel_size=1, padding=0, stride=1)
+        self.with_centerness = with_centerness
+        if with_centerness:
+            n = bev_size[0]
+            g = torch.stack(torch.meshgrid(torch.arange(n), torch.arange(n), indexing='ij'), -1)
+            g = (g - n // 2) / (n // 2)
+            self.centerness = ((g[..., 0] ** 2 + g[..., 1] ** 2) / 2).sqrt() + 1       # plain attribute (:167)
+        self.dice_loss = DiceLoss(use_sigmoid=True, loss_weight=self.loss_weight)
+        self.dice_loss_opacity = DiceLoss(use_sigmoid=True, loss_weight=self.loss_weight_opacity)
+        self.ce_loss = nn.BCEWithLogitsLoss(pos_weight=torch.tensor([2.13]))
+
+    def forward(self, input):
+        return self.mask_net(self.prob_conv(self.base_conv(input)))
+
+
+class DualFeatFusion(nn.Module):
+    def __init__(self, input_channel, output_channel):
+        super().__init__()
+        self.ca = MS_CAM(input_channel, output_channel)
+
+    def forward(self, x1, x2):
+        cf = self.ca(torch.cat((x1, x2), 1))
+        return cf * x1 + (1 - cf) * x2
+
+
+class BEVGeomAttention(nn.Module):
+    def __init__(self, kernel_size=7):
+        super().__init__()
+        self.conv1 = nn.Conv2d(2, 1, kernel_size, padding=kernel_size // 2, bias=False)
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, x, bev_prob):
+        if x.is_cuda and not torch.is_grad_enabled():
+            return hoa.spatial_gate(self.conv1.weight, x, bev_prob, False)[0]
+        return self.sigmoid(_spatial_logits(x, self.conv1) + bev_prob)
+
+    def gate(self, x, bev_prob):
+        """-> x * forward(x, bev_prob) (:1190) in two HBM passes."""
+        if x.is_cuda and not torch.is_grad_enabled():
+            return hoa.spatial_gate(self.conv1.weight, x, bev_prob, True)[1]
+        return self.forward(x, bev_prob) * x
+
+
+class _Head(nn.Module):
+    """fc1 -> ReLU -> fc2 -> ``act``; ``extra`` widens fc1's input by the sampled RGB (:272-380)."""
+    extra = 0
+
+    def __init__(self, input_dim, hidden_dim, output_dim):
+        super().__init__()
+        self.fc1 = nn.Linear(input_dim + self.extra, hidden_dim)
+        self.fc2 = nn.Linear(hidden_dim, output_dim)
+
+    def act(self, x):
+        return x
+
+    def forward(self, x):
+        return self.act(self.fc2(torch.relu(self.fc1(x))))
+
+
+class ScaleFactorMLP(_Head):
+    def __init__(self, input_dim, hidden_dim, output_dim):
+        super().__init__(input_dim, hidden_dim, output_dim)
+        self.softplus = nn.Softplus()
+
+    def act(self, x):
+        return self.softplus(x)
+
+
+class RotationFactorMLP(_Head):
+    def act(self, x):
+        return F.normalize(x, dim=-1)
+
+
+class OpacityFactorMLP(_Head):
+    def __init__(self, input_dim, hidden_dim, output_dim):
+        super().__init__(input_dim, hidden_dim, output_dim)
+        self.sigmoid = nn.Sigmoid()
+
+    def act(self, x):
+        return self.sigmoid(x)
+
+
+class ColorFactorMLPGaussian(OpacityFactorMLP):
+    extra = 3
+
+
+class ColorFactorMLPNerf(OpacityFactorMLP):
+    extra = 3
+
+
+class DepthFactorMLPNerf(_Head):
+    extra = 3
+
+    def act(self, x):
+        return torch.relu(x)
+
+
+class ImgFeatResize1(DepthFactorMLPNerf):
+    pass
+
+
+class ImgFeatResize2(DepthFactorMLPNerf):
+    pass
+
+
+class VoxelFeatureExtractor(nn.Module):
+    def __init__(self, in_planes=1, out_planes=13):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv3d(in_planes, out_planes, kernel_size=1), nn.BatchNorm3d(out_planes),
+                                  nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class ResizeNetwork(nn.Module):
+    """256 -> output_channel, x16 up-sampling, purely linear (:534-554)."""
+
+    def __init__(self, output_channel):
+        super().__init__()
+        self.conv1 = nn.Conv2d(256, 128, kernel_size=3, padding=1)
+        self.upsample1 = nn.ConvTranspose2d(128, 64, kernel_size=2, stride=2)
+        self.conv2 = nn.Conv2d(64, 32, kernel_size=3, padding=1)
+        self.upsample2 = nn.ConvTranspose2d(32, output_channel, kernel_size=2, stride=2)
+        self.upsample3 = nn.ConvTranspose2d(output_channel, output_channel, kernel_size=4, stride=4)
+
+    def stem(self, x):
+        """Everything up to conv2's output — what the composed NeRF kernels consume."""
+        return self.conv2(self.upsample1(self.conv1(x)))
+
+    def forward(self, x):
+        return self.upsample3(self.upsample2(self.stem(x)))
+
+
+class _LinearWeighted(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = nn.Parameter(torch.tensor(0.5))
+
+    def forward(self, a1, a2):
+        return self.w * a1 + (1 - self.w) * a2
+
+
+class LinearWeightedImage(_LinearWeighted):
+    pass
+
+
+class LinearWeightedDepth(_LinearWeighted):
+    pass
+
+
+class LearnedPositionalEncoding(nn.Module):
+    """mmdet 2.x ``LearnedPositionalEncoding`` (not in the reference tree; imported at :12):
+    ``forward(mask (B,H,W)) -> (B, 2*num_feats, H, W)`` = cat(col_embed(x) over rows, row_embed(y)
+    over columns)."""
+
+    def __init__(self, num_feats, row_num_embed=50, col_num_embed=50):
+        super().__init__()
+        self.row_embed = nn.Embedding(row_num_embed, num_feats)
+        self.col_embed = nn.Embedding(col_num_embed, num_feats)
+        self.num_feats, self.row_num_embed, self.col_num_embed = num_feats, row_num_embed, col_num_embed
+        nn.init.uniform_(self.row_embed.weight)
+        nn.init.uniform_(self.col_embed.weight)
+
+    def forward(self, mask):
+        h, w = mask.shape[-2:]
+        xe = self.col_embed(torch.arange(w, device=mask.device))
+        ye = self.row_embed(torch.arange(h, device=mask.device))
+        pos = torch.cat((xe.unsqueeze(0).expand(h, -1, -1), ye.unsqueeze(1).expand(-1, w, -1)), -1)
+        return pos.permute(2, 0, 1).unsqueeze(0).repeat(mask.shape[0], 1, 1, 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# the neck
+# ------------------------------------------------------------------------------------------------
+class _Geometry:
+    """Everything ``view_transform_core`` derives from the calibration alone: both rank-vector sets,
+    voxel centres, pillar projections and their validity (view_transformer.py:108-147,197-255;
+    view_transformer_ocrf.py:651-740,785-852)."""
+    __slots__ = ('lss', 'ht', 'voxel', 'pix', 'mask', 'calib')
+
+
+class OcRFViewTransformerFull(nn.Module):
+    def __init__(self, pc_range, bev_h=128, bev_w=128, num_height=13, collapse_z=True, loss_semantic_weight=25,
+                 depth_threshold=1, semantic_threshold=0.25, depthnet_cfg=dict(), grid_config=None, input_size=None,
+                 downsample=16, in_channels=512, out_channels=64, accelerate=False, loss_depth_weight=3.0,
+                 depth_net=None):
+        super().__init__()
+        if grid_config is None or input_size is None:
+            raise TypeError('grid_config and input_size are required (view_transformer.py:36-44)')
+        # LSSViewTransformer (view_transformer.py:36-76)
+        self.grid_config, self.downsample, self.input_size = grid_config, downsample, input_size
+        self.grid_lower_bound, self.grid_interval, self.grid_size = index_prep.grid_infos(grid_config)
+        self.frustum = index_prep.create_frustum(grid_config['depth'], input_size, downsample)
+        self.D = self.frustum.shape[0]
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.accelerate, self.initial_flag = accelerate, True
+        self.loss_depth_weight = loss_depth_weight
+        # :581-589
+        self.loss_semantic_weight = loss_semantic_weight
+        self.depth_threshold = depth_threshold / self.D
+        self.semantic_threshold = semantic_threshold
+        self.pc_range, self.bev_h, self.bev_w = pc_range, bev_h, bev_w
+        self.num_height, self.collapse_z = num_height, collapse_z
+        self.depth_net = depth_net if depth_net is not None else self._reference_depth_net(depthnet_cfg)
+        self.fuser = DualFeatFusion(2 * out_channels, out_channels)
+        self.geom_att = BEVGeomAttention()
+        self.ObatinOpacityMask = hoa.ObatinOpacityMask()
+        self.prob = ProbNet(in_channels=out_channels, with_centerness=True, bev_size=(bev_h, bev_w))
+        self.positional_encoding = LearnedPositionalEncoding(out_channels // 2, bev_h, bev_w)
+        self.positional_encoding1 = LearnedPositionalEncoding(8 // 4, bev_h, bev_w)
+        # NeRF branch (:598-610)
+        dim, hidden = 80, 4
+        self.image_feat_resize = ResizeNetwork(dim)
+        self.sigma = nn.Sequential(nn.Linear(dim, hidden), nn.Linear(hidden, 1), nn.Softplus())
+        self.C_MLP_nerf = ColorFactorMLPNerf(dim, hidden, 3)
+        self.D_MLP_nerf = DepthFactorMLPNerf(dim, hidden, 1)
+        self.img_feat_resize1 = ImgFeatResize1(dim, hidden, 3)
+        self.img_feat_resize2 = ImgFeatResize2(dim, hidden, 1)
+        # Gaussian heads (:612-623)
+        self.S_MLP = ScaleFactorMLP(dim, hidden, 3)
+        self.R_MLP = RotationFactorMLP(dim, hidden, 4)
+        self.A_MLP = OpacityFactorMLP(dim, hidden, 1)
+        self.C_MLP = ColorFactorMLPGaussian(dim, hidden, 3)
+        self.OpacityVoxelToBEV = hoa.OpacityVoxelToBEVConverter(input_channel=13)
+        self.color_crit = nn.MSELoss(reduction='mean')
+        self.zfar, self.znear, self.trans, self.scale = 999.9, 0.01, [0.0, 0.0, 0.0], 1.0
+        self.ObtainVoxelFeature = VoxelFeatureExtractor()
+        self.LinearWeightedImage, self.LinearWeightedDepth = LinearWeightedImage(), LinearWeightedDepth()
+        self.defor_cross_attention = hoa.DeformableAttention2D(
+            dim=13, dim_head=8, heads=1, dropout=0.1, downsample_factor=4, offset_scale=4, offset_groups=None,
+            offset_kernel_size=6)
+        self._geo = None
+        self._rank_bufs = (index_prep._RankBuffers(), index_prep._RankBuffers())
+        self._packs = {}
+
+    def _reference_depth_net(self, cfg):
+        try:
+            from mmdet3d.models.necks.view_transformer import DepthNet
+        except Exception:
+            return None           # forward() then raises; view_transform_core() does not need it
+        return DepthNet(self.in_channels, self.in_channels, self.out_channels, self.D + 2, **cfg)
+
+    # -------------------------------------------------------------------------------- geometry
+    def pre_compute(self, input):
+        """``accelerate=True``: the geometry of the first call is kept (:854-866; the reference's own
+        version of this path does not survive ``get_ht_bev_feat``)."""
+        if self.initial_flag or self._geo is None:
+            self._geo = self._geometry(input)
+            self.initial_flag = False
+
+    def _geometry(self, input):
+        x = input[0]
+        dev = x.device
+        B, N, _, Hf, Wf = x.shape
+        # the per-camera 3x3 algebra stays on the host, as the same torch calls the reference makes
+        # (a handful of (B,N,3,3) tensors; the reference moves them to the host itself, :1086-1088)
+        calib = [t.detach().float().cpu() for t in input[1:7]]
+        geo = _Geometry()
+        geo.calib = calib
+        gx, gy, gz = (int(v) for v in self.grid_size.tolist())
+        lss_block = index_prep.lss_camera_block(*calib).to(dev)
+        lidar2img, img_aug, _, _ = index_prep.get_projection(*calib)
+        ht_block = index_prep.ht_camera_block(lidar2img, img_aug).to(dev)
+        frustum = self.frustum.to(dev)
+        tmpl = index_prep.get_reference_points_3d(self.bev_h, self.bev_w, bs=1, num_points_in_pillar=self.num_height,
+                                                  device='cpu')[0].to(dev)
+        geo.lss = index_prep.voxel_pooling_prepare_v2_hip(frustum, lss_block, B, N, self.grid_lower_bound,
+                                                          self.grid_interval, self.grid_size,
+                                                          buffers=None if self.accelerate else self._rank_bufs[0])
+        geo.ht = index_prep.fast_sample_prepare_hip(tmpl, ht_block, B, N, list(self.pc_range), self.input_size,
+                                                    self.grid_config['depth'], Wf, Hf, self.D,
+                                                    buffers=None if self.accelerate else self._rank_bufs[1])
+        ref = tmpl[None].repeat(B, 1, 1, 1)
+        coor, mask, _ = index_prep.get_sampling_point(ref, list(self.pc_range), self.grid_config['depth'],
+                                                      lidar2img.to(dev), img_aug.to(dev), self.input_size)
+        geo.voxel = ref                                             # scaled to metres in place (:690-692)
+        pix = coor[..., :2].clone()
+        pix[..., 0] *= self.input_size[1]                           # :1065-1066
+        pix[..., 1] *= self.input_size[0]
+        geo.pix, geo.mask = pix.contiguous(), mask.squeeze(-1).contiguous()
+        return geo
+
+    def _camera(self, geo, input, bs, cam_idx):
+        """Camera of the render call (:1135-1152), quirks included: unscaled intrinsics with the
+        network-input viewport, ``c2w`` fed where a world->view transform is expected."""
+        K = geo.calib[2][bs, cam_idx]
+        c2w = input[11][bs, cam_idx].detach().float().cpu()
+        cam = gaussian_renderer.camera_from_calibration(K.numpy(), c2w.numpy(), self.input_size[0], self.input_size[1],
+                                                        znear=self.znear, zfar=self.zfar)
+        for k in ('world_view_transform', 'full_proj_transform', 'camera_center'):    # the FoV scalars stay on the host
+            cam[k] = cam[k].to(input[0].device)
+        return cam
+
+    # -------------------------------------------------------------------------------- packs
+    def _pack(self, name, params, build):
+        key = tuple((p._version, p.data_ptr()) for p in params)
+        hit = self._packs.get(name)
+        if hit is None or hit[0] != key:
+            self._packs[name] = (key, build())
+        return self._packs[name][1]
+
+    def _head_params(self):
+        mods = (self.ObtainVoxelFeature, self.S_MLP, self.R_MLP, self.A_MLP, self.C_MLP)
+        ps = [p for m in mods for p in list(m.parameters()) + list(m.buffers())]
+        return self._pack('heads', ps, lambda: neck_ops.pack_gauss_head_params(*mods))
+
+    def _nerf_params(self):
+        mods = (self.image_feat_resize, self.sigma, self.C_MLP_nerf, self.img_feat_resize1, self.img_feat_resize2)
+        ps = [p for m in mods for p in m.parameters()]
+        return self._pack('nerf', ps, lambda: neck_ops.compose_nerf_maps(*mods))
+
+    # -------------------------------------------------------------------------------- pooling
+    def _pool(self, ranks, depth, feat_cl, bev_shape):
+        if ranks[0] is None:
+            B, Z, Y, X, C = bev_shape
+            return torch.zeros(B, Z * C, Y, X, device=depth.device)
+        rb, rd, rf, st, ln = ranks
+        return bevpool.bev_pool_v2_collapsed(depth, feat_cl, rd, rf, rb, bev_shape, st, ln)
+
+    def get_lss_bev_feat(self, geo, depth, feat_cl):
+        gx, gy, gz = (int(v) for v in self.grid_size.tolist())
+        return self._pool(geo.lss, depth, feat_cl, (depth.shape[0], gz, gy, gx, feat_cl.shape[-1]))
+
+    def get_ht_bev_feat(self, geo, depth, feat_cl):
+        return self._pool(geo.ht, depth, feat_cl, (depth.shape[0], 1, self.bev_h, self.bev_w, feat_cl.shape[-1]))
+
+    # -------------------------------------------------------------------------------- core
+    def view_transform(self, input, depth, tran_feat, feat_channels_last=None):
+        if self.accelerate:
+            self.pre_compute(input)
+        return self.view_transform_core(input, depth, tran_feat, feat_channels_last)
+
+    def view_transform_core(self, input, depth, tran_feat, feat_channels_last=None, cam_idx_list=None):
+        """Same inputs / outputs as the reference (:1040-1201).  ``feat_channels_last`` (B*N,H,W,C),
+        when the caller already has it (``forward`` does), skips the permute of :875/:901;
+        ``cam_idx_list`` overrides the random camera choice of :1081 (tests)."""
+        x = input[0]
+        B, N, _, Hf, Wf = x.shape
+        imgs_wo_norm, dtype = input[9], x.dtype
+        C, Zh, Y, X = self.out_channels, self.num_height, self.bev_h, self.bev_w
+        H, W = self.input_size
+        fused = not (self.training and torch.is_grad_enabled())
+        geo = self._geo if (self.accelerate and self._geo is not None) else self._geometry(input)
+        depth5 = depth.reshape(B, N, self.D, Hf, Wf).float()
+        if feat_channels_last is None:
+            feat_channels_last = tran_feat.reshape(B, N, C, Hf, Wf).permute(0, 1, 3, 4, 2)
+        feat_cl = feat_channels_last.reshape(B, N, Hf, Wf, C).float().contiguous()
+        lss_feat = self.get_lss_bev_feat(geo, depth5, feat_cl)
+        ht_feat = self.get_ht_bev_feat(geo, depth5, feat_cl)
+
+        if cam_idx_list is None:
+            cam_idx_list = [random.randint(0, 5) for _ in range(B)]
+        cam_sel = torch.tensor(cam_idx_list, dtype=torch.int32, device=x.device)
+        voxel_coor = geo.voxel.reshape(B, Zh * Y * X, 3)
+        if fused:
+            avg_rgb = neck_ops.pillar_sample_mean(imgs_wo_norm, geo.pix, geo.mask)                 # (B,Zh,YX,3)
+            sparse = neck_ops.retain_valid_pixels(imgs_wo_norm, geo.pix, geo.mask, cam_sel)        # (B,3,H,W)
+            w_s, c_s, nerf_block = self._nerf_params()
+            z = self.image_feat_resize.stem(x.reshape(B * N, -1, Hf, Wf).float())
+            alpha = neck_ops.nerf_alpha(z, w_s, c_s)                                                # (B*N,H,W)
+            render_N, render_depth_N = neck_ops.nerf_render(z, cam_sel, alpha, sparse, nerf_block, N)
+            # the reference views the (6,H,W,1) stack as (1,6,1,W,H) before sampling it (:1123)
+            alpha_lidar = neck_ops.pillar_sample_mean(alpha.view(B, N, 1, H, W), geo.pix, geo.mask, view_hw=(W, H))
+            alpha_lidar = alpha_lidar.view(B, Zh, Y, X)
+            opacity, scaling, rotation, color = neck_ops.gauss_heads(ht_feat, avg_rgb, self._head_params(), Zh)
+        else:
+            (opacity, scaling, rotation, color, sparse, alpha_lidar, render_N,
+             render_depth_N) = self._neck_torch(input, geo, ht_feat, cam_idx_list)
+
+        render_G, render_depth_G = [], []
+        for bs in range(B):
+            cam = self._camera(geo, input, bs, cam_idx_list[bs])
+            img, dep = gaussian_renderer.render(cam, cam_idx_list[bs], voxel_coor[bs], color[bs], rotation[bs],
+                                                scaling[bs], opacity[bs], bg_color=[0, 0, 0])
+            render_G.append(img.unsqueeze(0)), render_depth_G.append(dep.unsqueeze(0))
+        render_image_G_all, render_depth_G_all = torch.cat(render_G), torch.cat(render_depth_G)
+        render_image = self.LinearWeightedImage(render_image_G_all, render_N)
+        render_depth = self.LinearWeightedDepth(render_depth_G_all, render_depth_N)
+        gt_images = imgs_wo_norm[torch.arange(B, device=x.device), cam_sel.long()] / 255.0
+
+        # HOA-1 for the whole batch (the reference loops samples, :1159-1161)
+        opacity_alpha = hoa.hoa1(self.defor_cross_attention, opacity.reshape(-1, 1), alpha_lidar, Zh, Y, X)
+
+        channel_feat = self.fuser(lss_feat, ht_feat)
+        zeros = torch.zeros((B, Y, X), device=x.device).to(dtype)
+        bev_mask_logit = self.prob(self.positional_encoding(zeros).to(dtype) + channel_feat)
+        geom_feat = self.geom_att.gate(channel_feat, bev_mask_logit)
+        opacity_alpha_view = self.OpacityVoxelToBEV(opacity_alpha, self.positional_encoding1(zeros).to(dtype))
+        if fused:
+            geom_feat = self.ObatinOpacityMask.gate(geom_feat, opacity_alpha_view)[1]
+        else:
+            m = torch.sigmoid(_spatial_logits(geom_feat, self.ObatinOpacityMask.conv) + opacity_alpha_view)
+            geom_feat = geom_feat * m
+        return geom_feat, depth, bev_mask_logit, [render_image, gt_images, render_image_G_all, render_N,
+                                                  opacity_alpha_view, cam_idx_list, render_depth, render_depth_G_all,
+                                                  render_depth_N]
+
+    def _neck_torch(self, input, geo, ht_feat, cam_idx_list):
+        """Training mode: the reference's op sequence (:1051-1133) as differentiable torch ops."""
+        x, imgs_wo_norm = input[0], input[9]
+        B, N, _, Hf, Wf = x.shape
+        Zh, Y, X = self.num_height, self.bev_h, self.bev_w
+        H, W = self.input_size
+        mask5 = geo.mask.unsqueeze(-1)
+
+        def sample(imgs, h, w):
+            c = imgs.shape[2]
+            g = geo.pix.clone()
+            g[..., 0] = (g[..., 0] / (w - 1)) * 2 - 1
+            g[..., 1] = (g[..., 1] / (h - 1)) * 2 - 1
+            v = F.grid_sample(imgs.reshape(B * N, c, h, w).float(), g.view(B * N, 1, Zh * Y * X, 2), align_corners=True)
+            v = v.view(B, N, c, Zh, Y * X).permute(0, 1, 3, 4, 2) * mask5.float()
+            cnt = mask5.sum(1).float().clamp(min=1)
+            return v.sum(1) / cnt
+        avg_rgb = sample(imgs_wo_norm, H, W)
+        # retain_valid_pixels for the selected cameras, vectorised (:1004-1024)
+        sel = torch.tensor(cam_idx_list, device=x.device)
+        ar = torch.arange(B, device=x.device)
+        pix_s, mask_s = geo.pix[ar, sel].reshape(B, -1, 2), geo.mask[ar, sel].reshape(B, -1)
+        imgs_s = imgs_wo_norm[ar, sel].float()
+        keep = torch.zeros(B, H * W, dtype=torch.bool, device=x.device)
+        hi = max(W, H) - 1
+        xi = pix_s[..., 0].long().clamp(0, min(hi, W - 1))
+        yi = pix_s[..., 1].long().clamp(0, min(hi, H - 1))
+        keep.scatter_(1, (yi * W + xi) * mask_s.long(), mask_s)          # masked-out points all hit pixel 0 with False
+        keep[:, 0] = ((yi * W + xi == 0) & mask_s).any(1)
+        sparse = torch.where(keep.view(B, 1, H, W), imgs_s, torch.full_like(imgs_s, 255.0))
+        feat = self.image_feat_resize(x.reshape(B * N, -1, Hf, Wf).float())                  # (B*N,80,H,W)
+        f = feat.permute(0, 2, 3, 1)
+        alpha = 1. - torch.exp(-self.sigma(f))                                               # (B*N,H,W,1)
+        alpha_lidar = sample(alpha.reshape(B, N, 1, W, H), W, H).view(B, Zh, Y, X)
+        fs = f.view(B, N, H, W, -1)[ar, sel]
+        xin = torch.cat((fs, sparse.permute(0, 2, 3, 1) / 255.0), -1)
+        radiance = self.img_feat_resize1(xin) * F.softmax(self.C_MLP_nerf(xin), dim=-1)
+        radiance1 = self.img_feat_resize2(xin) * F.softmax(self.D_MLP_nerf(xin), dim=-1)
+        a_sel = alpha.view(B, N, H, W, 1)[ar, sel]
+        render_N = (a_sel * radiance).permute(0, 3, 1, 2)
+        render_depth_N = (a_sel * radiance1).permute(0, 3, 1, 2)
+        voxel_feat = self.ObtainVoxelFeature(ht_feat.permute(0, 2, 3, 1).unsqueeze(1)).reshape(B, Zh * Y * X, -1)
+        rgb01 = avg_rgb.reshape(B, Zh * Y * X, 3) / 255.0
+        return (self.A_MLP(voxel_feat), self.S_MLP(voxel_feat), self.R_MLP(voxel_feat),
+                self.C_MLP(torch.cat((voxel_feat, rgb01), -1)), sparse, alpha_lidar, render_N, render_depth_N)
+
+    # -------------------------------------------------------------------------------- forward
+    def forward(self, input, stereo_metas=None):
+        """:1319-1334.  ``input``: the 12-entry ``img_inputs`` list."""
+        if self.depth_net is None:
+            raise RuntimeError('OcRFViewTransformerFull.forward needs a depth_net (pass depth_net=... or install '
+                               'the reference mmdet3d); view_transform_core() runs without it')
+        x, mlp_input = input[0], input[7]
+        B, N, C, H, W = x.shape
+        y = self.depth_net(x.view(B * N, C, H, W), mlp_input, stereo_metas)
+        if y.is_cuda and not (self.training and torch.is_grad_enabled()):
+            depth, filter_depth, semantic, feat_cl = neck_ops.prefilter(y, self.D, self.out_channels,
+                                                                        self.depth_threshold, self.semantic_threshold)
+            bev_feat, _, bev_mask, extras = self.view_transform(input, filter_depth, None, feat_cl)
+        else:
+            depth = y[:, :self.D].softmax(dim=1)
+            semantic = y[:, self.D:self.D + 2].softmax(dim=1)
+            tran_feat = y[:, self.D + 2:self.D + 2 + self.out_channels]
+            filter_depth = torch.where(depth < self.depth_threshold, torch.zeros_like(depth), depth)
+            filter_feat = (semantic[:, 1:2] >= self.semantic_threshold) * tran_feat
+            bev_feat, _, bev_mask, extras = self.view_transform(input, filter_depth, filter_feat)
+        return bev_feat, depth, (bev_mask, semantic), extras
+
+    def get_mlp_input(self, rot, tran, intrin, post_rot, post_tran, bda):
+        """27 camera-aware scalars per view for the DepthNet's SE layers (view_transformer.py:696-722)."""
+        B, N = rot.shape[:2]
+        bda = bda.view(B, 1, 3, 3).repeat(1, N, 1, 1)
+        v = torch.stack([intrin[:, :, 0, 0], intrin[:, :, 1, 1], intrin[:, :, 0, 2], intrin[:, :, 1, 2],
+                         post_rot[:, :, 0, 0], post_rot[:, :, 0, 1], post_tran[:, :, 0], post_rot[:, :, 1, 0],
+                         post_rot[:, :, 1, 1], post_tran[:, :, 1], bda[:, :, 0, 0], bda[:, :, 0, 1], bda[:, :, 1, 0],
+                         bda[:, :, 1, 1], bda[:, :, 2, 2]], dim=-1)
+        s2e = torch.cat([rot, tran.reshape(B, N, 3, 1)], dim=-1).reshape(B, N, -1)
+        return torch.cat([v, s2e], dim=-1)

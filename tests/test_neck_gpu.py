@@ -1,0 +1,230 @@
+"""GPU parity of csrc/neck.hip and of the assembled ``OcRFViewTransformerFull`` against the oracle and
+the vectors dumped from the reference's own forward (tests/golden/core_small.npz).  Tolerances: 1e-4
+on network outputs (BASELINE.json north_star), exact on masks / integer decisions."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import core as oc
+from oracle.hoa import conv2d, conv_transpose2d_k2s2
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def core():
+    from ocrfdet_amd import view_transformer_ocrf as vto
+    cfg, g, state = helpers.core_fixture()
+    pre = torch.from_numpy(g['pre']).cuda()
+
+    class DepthNetStub(torch.nn.Module):
+        def forward(self, x, mlp_input, stereo_metas=None):
+            return pre
+    m = vto.OcRFViewTransformerFull(
+        pc_range=list(cfg.pc_range), bev_h=48, bev_w=48, num_height=13, grid_config=cfg.grid,
+        input_size=cfg.input_size, downsample=16, in_channels=256, out_channels=80, depth_net=DepthNetStub())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    m.cuda().eval()
+    B = int(g['batch'])
+    voxel, pix, mask, rig = helpers.core_geometry(cfg, B)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()      # noqa: E731
+    raw = t(g['raw'].astype(np.float32))
+    inp = [t(g['x'].astype(np.float32))] + [t(rig[k]) for k in ('rots', 'trans', 'intrins', 'post_rots', 'post_trans', 'bda')]
+    inp += [torch.zeros(B, 6, 27).cuda(), raw.clone(), raw, raw.clone(), t(rig['c2w'])]
+    return dict(cfg=cfg, g=g, p=state, m=m, B=B, voxel=voxel, pix=pix, mask=mask, inp=inp, t=t)
+
+
+def close(got, want, tol, what):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else got
+    err = float(np.abs(got.astype(np.float64) - np.asarray(want, np.float64)).max())
+    assert err <= tol, f'{what}: max|err| {err:.3e} > {tol}'
+
+
+def test_prefilter(core):
+    from ocrfdet_amd import neck_ops
+    cfg, g = core['cfg'], core['g']
+    thr = 1.0 / cfg.D
+    depth, fdepth, sem, feat = neck_ops.prefilter(core['t'](g['pre']), cfg.D, cfg.channels, thr, 0.25)
+    want_d, want_fd, want_s, want_f = oc.prefilter(g['pre'], cfg.D, cfg.channels, thr, 0.25)
+    close(depth, g['depth'], 1e-6, 'depth vs reference'), close(sem, g['semantic'], 1e-6, 'semantic vs reference')
+    d = depth.cpu().numpy()
+    fd = fdepth.cpu().numpy()
+    assert ((fd == 0) | (fd == d)).all()
+    flips = (fd != want_fd) & (np.abs(want_d - np.float32(thr)) > 1e-6)       # only ties at the threshold may differ
+    assert not flips.any()
+    s1 = sem.cpu().numpy()[:, 1]
+    keep = (s1 >= np.float32(0.25))[:, None]
+    tf = g['pre'][:, cfg.D + 2:]
+    assert np.array_equal(feat.cpu().numpy(), np.ascontiguousarray((keep * tf).transpose(0, 2, 3, 1)))
+    sure = np.abs(want_s[:, 1] - 0.25) > 1e-6
+    assert np.array_equal((feat.cpu().numpy() != 0).any(-1)[sure], (want_f != 0).any(1)[sure])
+
+
+def test_prefilter_ragged_width(core):
+    """HW not a multiple of the 64-pixel tile, C not a multiple of 4."""
+    from ocrfdet_amd import neck_ops
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((3, 7 + 2 + 9, 5, 15)).astype(np.float32)
+    depth, fdepth, sem, feat = neck_ops.prefilter(torch.from_numpy(x).cuda(), 7, 9, 0.1, 0.4)
+    wd, wfd, ws, wf = oc.prefilter(x, 7, 9, 0.1, 0.4)
+    close(depth, wd, 1e-6, 'depth'), close(sem, ws, 1e-6, 'semantic')
+    ok = (np.abs(wd - 0.1) > 1e-6)
+    assert np.array_equal(fdepth.cpu().numpy()[ok], wfd[ok])
+    sure = np.abs(ws[:, 1] - 0.4) > 1e-6
+    assert np.array_equal(feat.cpu().numpy()[sure], wf.transpose(0, 2, 3, 1)[sure])
+
+
+def test_pillar_sample_mean(core):
+    from ocrfdet_amd import neck_ops
+    g, t = core['g'], core['t']
+    raw = g['raw'].astype(np.float32)
+    got = neck_ops.pillar_sample_mean(t(raw), t(core['pix']), t(core['mask']))
+    want = oc.color_voxels_avg(oc.lidar_points_to_image_values(core['pix'], raw, core['mask']), core['mask'])
+    close(got, want, 2e-4, 'avg colour vs oracle (0..255 scale)')
+    close(got / 255.0, g['colored_avg'] / 255.0, 2e-4, 'avg colour vs reference (0..1 scale)')
+    # empty mask -> zeros; single channel with the swapped view
+    none = np.zeros_like(core['mask'])
+    assert float(neck_ops.pillar_sample_mean(t(raw), t(core['pix']), t(none)).abs().max()) == 0.0
+    H, W = core['cfg'].input_size
+    a = np.random.default_rng(1).random((core['B'], 6, 1, H, W), dtype=np.float32)
+    got = neck_ops.pillar_sample_mean(t(a), t(core['pix']), t(core['mask']), view_hw=(W, H))
+    want = oc.color_voxels_avg(oc.lidar_points_to_image_values(core['pix'], a.reshape(core['B'], 6, 1, W, H), core['mask']),
+                               core['mask'])
+    close(got, want, 1e-5, 'swapped-view alpha sampling')
+
+
+def test_retain_valid_pixels(core):
+    from ocrfdet_amd import neck_ops
+    g, t = core['g'], core['t']
+    raw = g['raw'].astype(np.float32)
+    want = oc.retain_valid_pixels(raw, core['pix'], core['mask'])
+    got = neck_ops.retain_valid_pixels(t(raw), t(core['pix']), t(core['mask']))
+    assert np.array_equal(got.cpu().numpy(), want)
+    cams = g['cam_idx_list'].astype(np.int32)
+    sel = neck_ops.retain_valid_pixels(t(raw), t(core['pix']), t(core['mask']), torch.from_numpy(cams).cuda())
+    for b, c in enumerate(cams):
+        assert np.array_equal(sel[b].cpu().numpy(), want[b, c])
+        assert np.array_equal(sel[b].cpu().numpy().astype(np.uint8), g['sparse_sel'][b])
+
+
+def test_gauss_heads(core):
+    from ocrfdet_amd import neck_ops
+    cfg, g, p, m, t = core['cfg'], core['g'], core['p'], core['m'], core['t']
+    op, sc, rot, col = neck_ops.gauss_heads(t(g['ht_feat']), t(g['colored_avg']), m._head_params(), cfg.num_height)
+    lift = oc.voxel_lift(g['ht_feat'], p)
+    for b in range(core['B']):
+        want = oc.gauss_heads(lift[b].reshape(-1, cfg.channels), g['colored_avg'][b].reshape(-1, 3) / np.float32(255.0), p)
+        for got, ref, name in zip((op, sc, rot, col), want, ('opacity', 'scales', 'rotations', 'colour')):
+            close(got[b], ref, 2e-6, name + ' vs oracle')
+        close(op[b, ::5], g[f'gauss_opacity{b}'], 1e-5, 'opacity vs reference')
+        close(sc[b, ::5], g[f'gauss_scales{b}'], 1e-5, 'scales vs reference')
+        close(rot[b, ::5], g[f'gauss_rot{b}'], 1e-5, 'rotations vs reference')
+        close(col[b, ::5], g[f'gauss_rgb{b}'], 1e-5, 'colour vs reference')
+
+
+def test_nerf_branch(core):
+    from ocrfdet_amd import neck_ops
+    cfg, g, p, m, t = core['cfg'], core['g'], core['p'], core['m'], core['t']
+    B = core['B']
+    H, W = cfg.input_size
+    x = g['x'].astype(np.float32)
+    w_s, c_s, block = m._nerf_params()
+    with torch.no_grad():
+        z = m.image_feat_resize.stem(t(x).reshape(B * 6, 256, *cfg.feat_hw))
+    zr = np.stack([conv2d(conv_transpose2d_k2s2(conv2d(x[b], p['image_feat_resize.conv1.weight'], p['image_feat_resize.conv1.bias'], padding=1),
+                                                p['image_feat_resize.upsample1.weight'], p['image_feat_resize.upsample1.bias']),
+                          p['image_feat_resize.conv2.weight'], p['image_feat_resize.conv2.bias'], padding=1) for b in range(B)])
+    close(z, zr.reshape(B * 6, 32, *z.shape[2:]), 1e-4, 'ResizeNetwork stem (MIOpen) vs oracle')
+    alpha = neck_ops.nerf_alpha(z, w_s, c_s)
+    cams = torch.from_numpy(g['cam_idx_list'].astype(np.int32)).cuda()
+    sparse = t(g['sparse_sel'].astype(np.float32))
+    img_n, dep_n = neck_ops.nerf_render(z, cams, alpha, sparse, block, 6)
+    close(img_n, g['render_N'], 1e-5, 'render_N vs reference'), close(dep_n, g['render_depth_N'], 1e-5, 'render_depth_N vs reference')
+    for b in range(B):
+        feat = oc.resize_network(x[b], p)
+        close(alpha.view(B, 6, H, W)[b], oc.nerf_alpha(feat, p), 1e-5, 'alpha vs oracle')
+    a_l = neck_ops.pillar_sample_mean(alpha.view(B, 6, 1, H, W), t(core['pix']), t(core['mask']), view_hw=(W, H))
+    close(a_l, g['alpha_lidar'], 1e-4, 'alpha_lidar vs reference')
+
+
+def _check_outputs(core, out, tol=1e-4):
+    g = core['g']
+    bev, depth, (bev_mask, sem), lst = out
+    close(depth, g['depth'], 1e-6, 'depth'), close(sem, g['semantic'], 1e-6, 'semantic')
+    close(bev_mask, g['bev_mask_logit'], tol, 'bev_mask_logit')
+    close(lst[4], g['opacity_alpha_view'], tol, 'opacity_alpha_view')
+    close(bev, g['bev_feat'], tol, 'bev_feat')
+    assert list(lst[5]) == [int(c) for c in g['cam_idx_list']]
+    close(lst[1], g['gt_images'], 1e-6, 'gt_images')
+    close(lst[3], g['render_N'], 1e-5, 'render_N'), close(lst[8], g['render_depth_N'], 1e-5, 'render_depth_N')
+    # the reference-side render was the C oracle (the CUDA rasteriser cannot run in the build container)
+    for name, got, want in (('render_G', lst[2], g['render_G']), ('render_depth_G', lst[7], g['render_depth_G']),
+                            ('render_imgs', lst[0], g['render_imgs']), ('render_depth', lst[6], g['render_depth'])):
+        d = np.abs(got.detach().cpu().numpy() - want)
+        assert (d > tol).mean() < 1e-3 and d.max() < 5e-2, f'{name}: {d.max():.3e}, {(d > tol).mean():.2e} of pixels off'
+
+
+def test_module_forward_vs_reference(core):
+    m, g = core['m'], core['g']
+    cams = [int(c) for c in g['cam_idx_list']]
+    with torch.no_grad():
+        x = core['inp'][0]
+        B, N, C, H, W = x.shape
+        y = m.depth_net(x.view(B * N, C, H, W), core['inp'][7], None)
+        from ocrfdet_amd import neck_ops
+        depth, fdepth, sem, feat_cl = neck_ops.prefilter(y, m.D, m.out_channels, m.depth_threshold, m.semantic_threshold)
+        bev, _, bev_mask, lst = m.view_transform_core(core['inp'], fdepth, None, feat_cl, cam_idx_list=cams)
+    _check_outputs(core, (bev, depth, (bev_mask, sem), lst))
+
+
+def test_module_forward_entry_point_and_accelerate(core):
+    """``forward`` end to end with Python's RNG seeded like the fixture's generator, then the cached
+    (``accelerate=True``) geometry gives the same result."""
+    import random
+    m = core['m']
+    random.seed(3)
+    with torch.no_grad():
+        out = m(core['inp'])
+    _check_outputs(core, out)
+    m.accelerate, m.initial_flag = True, True
+    try:
+        random.seed(3)
+        with torch.no_grad():
+            m(core['inp'])
+            random.seed(3)
+            out2 = m(core['inp'])
+        assert torch.equal(out[0], out2[0]) and torch.equal(out[3][4], out2[3][4])
+    finally:
+        m.accelerate, m._geo = False, None
+
+
+def test_training_path_matches_fused_path(core):
+    """The differentiable torch formulation used in training mode (BatchNorm / dropout kept in eval
+    so both paths see the same statistics) agrees with the fused kernels, and gradients reach the
+    heads through the rasteriser's and the pooling's HIP backwards."""
+    m, g = core['m'], core['g']
+    cams = [int(c) for c in g['cam_idx_list']]
+    cfg = core['cfg']
+    pre = torch.from_numpy(g['pre']).cuda()
+    depth = pre[:, :cfg.D].softmax(1)
+    feat = pre[:, cfg.D + 2:].clone().requires_grad_(True)
+    m.training = True               # top level only: sub-modules stay in eval mode
+    try:
+        bev, _, bev_mask, lst = m.view_transform_core(core['inp'], depth, feat, cam_idx_list=cams)
+        (lst[0].sum() + bev.sum() + lst[4].sum()).backward()
+    finally:
+        m.training = False
+    assert feat.grad is not None and torch.isfinite(feat.grad).all() and float(feat.grad.abs().sum()) > 0
+    for name in ('S_MLP', 'R_MLP', 'A_MLP', 'C_MLP', 'sigma', 'img_feat_resize1'):
+        gr = getattr(m, name)
+        gr = (gr.fc1 if hasattr(gr, 'fc1') else gr[0]).weight.grad
+        assert gr is not None and torch.isfinite(gr).all(), name
+    m.zero_grad()
+    with torch.no_grad():
+        bev2, _, bev_mask2, lst2 = m.view_transform_core(core['inp'], depth, feat.detach(), cam_idx_list=cams)
+    close(bev, bev2.cpu().numpy(), 1e-4, 'bev_feat train vs fused')
+    close(bev_mask, bev_mask2.cpu().numpy(), 1e-4, 'bev_mask train vs fused')
+    close(lst[4], lst2[4].cpu().numpy(), 1e-4, 'opacity view train vs fused')
+    close(lst[3], lst2[3].cpu().numpy(), 1e-5, 'render_N train vs fused')
+    close(lst[8], lst2[8].cpu().numpy(), 1e-5, 'render_depth_N train vs fused')

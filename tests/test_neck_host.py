@@ -1,0 +1,112 @@
+"""Host logic of the neck stages (no GPU): the parameter packing of ``ocrf_gauss_heads`` and the
+composition of ResizeNetwork's transposed convolutions into per-sub-position maps
+(``neck_ops.compose_nerf_maps``) are evaluated in numpy exactly as csrc/neck.hip reads them and
+compared with the literal restatement in oracle/core.py on the reference fixture."""
+import numpy as np
+import pytest
+import torch
+
+from ocrfdet_amd import neck_ops
+from ocrfdet_amd import view_transformer_ocrf as vto
+from oracle import core as oc
+from tests import helpers
+
+
+@pytest.fixture(scope='module')
+def core():
+    cfg, g, state = helpers.core_fixture()
+    m = vto.OcRFViewTransformerFull(
+        pc_range=list(cfg.pc_range), bev_h=48, bev_w=48, num_height=13, grid_config=cfg.grid,
+        input_size=cfg.input_size, downsample=16, in_channels=256, out_channels=80)
+    missing, unexpected = m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=False)
+    assert not unexpected and all(k.startswith('depth_net.') for k in missing)
+    m.eval()
+    return cfg, g, state, m
+
+
+def test_state_dict_keys_match_reference(core):
+    _, _, state, m = core
+    own = {k for k in m.state_dict() if not k.startswith('depth_net.')}
+    assert own == set(state), (sorted(own - set(state))[:5], sorted(set(state) - own)[:5])
+    for k, v in m.state_dict().items():
+        if k in state:
+            assert tuple(v.shape) == state[k].shape, k
+
+
+def test_config_referenced_attribute_names(core):
+    m = core[3]
+    # configs/ocrfdet/ocrfdet.py:259-337 addresses these by name (lr multipliers / hooks)
+    for name in ('S_MLP', 'R_MLP', 'A_MLP', 'C_MLP', 'C_MLP_nerf', 'D_MLP_nerf', 'sigma', 'img_feat_resize1',
+                 'img_feat_resize2', 'image_feat_resize', 'OpacityVoxelToBEV', 'ObatinOpacityMask',
+                 'defor_cross_attention', 'ObtainVoxelFeature', 'LinearWeightedImage', 'LinearWeightedDepth', 'fuser',
+                 'geom_att', 'prob', 'positional_encoding', 'positional_encoding1'):
+        assert hasattr(m, name), name
+
+
+def test_gauss_head_packing(core):
+    cfg, g, p, m = core
+    prm = neck_ops.pack_gauss_head_params(m.ObtainVoxelFeature, m.S_MLP, m.R_MLP, m.A_MLP, m.C_MLP).numpy().astype(np.float64)
+    C, Zh = cfg.channels, cfg.num_height
+    assert prm.size == 2 * Zh + 16 * C + 12 + 16 + 15 + 20 + 5 + 15
+    la, lb = prm[:Zh], prm[Zh:2 * Zh]
+    o = 2 * Zh
+    W1 = prm[o:o + 16 * C].reshape(16, C)
+    W1rgb = prm[o + 16 * C:o + 16 * C + 12].reshape(4, 3)
+    b1 = prm[o + 16 * C + 12:o + 16 * C + 28]
+    rest = prm[o + 16 * C + 28:]
+    S2, R2, A2, C2 = rest[:15], rest[15:35], rest[35:40], rest[40:55]
+    bev = g['ht_feat'][0].reshape(C, -1).astype(np.float64)              # (C, YX)
+    rgb = (g['colored_avg'][0] / np.float32(255.0)).astype(np.float64)   # (Zh, YX, 3)
+    lift = oc.voxel_lift(g['ht_feat'][:1], p)[0].reshape(Zh, -1, C)
+    want = oc.gauss_heads(lift.reshape(-1, C), rgb.reshape(-1, 3).astype(np.float32), p)
+    f = np.maximum(la[:, None, None] * bev.T[None] + lb[:, None, None], 0)           # (Zh, YX, C)
+    hid = f @ W1.T
+    hid[..., 12:] += rgb @ W1rgb.T
+    hid = np.maximum(hid + b1, 0).reshape(-1, 16)
+    sc = np.log1p(np.exp(hid[:, 0:4] @ S2[:12].reshape(3, 4).T + S2[12:]))
+    r = hid[:, 4:8] @ R2[:16].reshape(4, 4).T + R2[16:]
+    r /= np.maximum(np.linalg.norm(r, axis=1, keepdims=True), 1e-12)
+    op = 1 / (1 + np.exp(-(hid[:, 8:12] @ A2[:4].reshape(1, 4).T + A2[4:])))
+    col = 1 / (1 + np.exp(-(hid[:, 12:16] @ C2[:12].reshape(3, 4).T + C2[12:])))
+    for got, ref in zip((op, sc, r, col), want):
+        assert np.abs(got - ref).max() < 2e-6
+
+
+def test_composed_nerf_maps(core):
+    cfg, g, p, m = core
+    w_s, c_s, block = neck_ops.compose_nerf_maps(m.image_feat_resize, m.sigma, m.C_MLP_nerf, m.img_feat_resize1,
+                                                 m.img_feat_resize2)
+    w_s, c_s, block = (t.numpy().astype(np.float64) for t in (w_s, c_s, block))
+    assert block.size == 12 * 32 * 64 + 12 * 64 + 36 + 15 + 15 + 5
+    x = g['x'][0].astype(np.float32)                                     # (6,256,h,w)
+    # z = conv2(upsample1(conv1(x))) (view_transformer_ocrf.py:543-546), literal numpy
+    from oracle.hoa import conv2d, conv_transpose2d_k2s2
+    z = conv2d(x, p['image_feat_resize.conv1.weight'], p['image_feat_resize.conv1.bias'], padding=1)
+    z = conv_transpose2d_k2s2(z, p['image_feat_resize.upsample1.weight'], p['image_feat_resize.upsample1.bias'])
+    z = conv2d(z, p['image_feat_resize.conv2.weight'], p['image_feat_resize.conv2.bias'], padding=1).astype(np.float64)
+    feat = oc.resize_network(x, p)                                        # literal (6,80,H,W)
+    H, W = cfg.input_size
+    ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
+    pos = (ys % 8) * 8 + xs % 8
+    zz = z[:, :, ys // 8, xs // 8]                                        # (6,32,H,W)
+    lin = np.einsum('mchw,chw->mhw', zz, w_s[:, pos]) + c_s[pos]
+    alpha = 1 - np.exp(-np.log1p(np.exp(lin)))
+    assert np.abs(alpha - oc.nerf_alpha(feat, p)).max() < 2e-6
+    # the 12 hidden pre-activations of the selected camera
+    cam = int(g['cam_idx_list'][0])
+    M12 = block[:12 * 32 * 64].reshape(12, 32, 64)
+    c12 = block[12 * 32 * 64:12 * 32 * 64 + 12 * 64].reshape(12, 64)
+    hid = np.einsum('chw,kchw->khw', zz[cam], M12[:, :, pos]) + c12[:, pos]
+    f = feat[cam].transpose(1, 2, 0).astype(np.float64)
+    for i, name in enumerate(('C_MLP_nerf', 'img_feat_resize1', 'img_feat_resize2')):
+        w = p[name + '.fc1.weight'].astype(np.float64)
+        want = f @ w[:, :80].T + p[name + '.fc1.bias']
+        assert np.abs(hid[4 * i:4 * i + 4].transpose(1, 2, 0) - want).max() < 5e-6, name
+
+
+def test_ops_refuse_cpu_tensors():
+    from ocrfdet_amd._lib import OcrfHipError
+    with pytest.raises(OcrfHipError):
+        neck_ops.prefilter(torch.zeros(1, 10, 2, 2), 4, 4, 0.1, 0.25)
+    with pytest.raises(OcrfHipError):
+        neck_ops.pillar_sample_mean(torch.zeros(1, 1, 3, 4, 4), torch.zeros(1, 1, 2, 3, 2), torch.ones(1, 1, 2, 3, 1, dtype=torch.bool))
