@@ -198,8 +198,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                                      rs.viewmatrix.reshape(1, 4, 4), rs.projmatrix.reshape(1, 4, 4),
                                      float(rs.tanfovx), float(rs.tanfovy), rs.image_height, rs.image_width, rs.bg,
                                      float(rs.scale_modifier), want_means2D=True)
-        return (g['means3D'], g['means2D'][0], None, g['colors'], g['opacities'].reshape(opacities.shape),
-                g['scales'], g['rotations'], None, None)
+        grads = (g['means3D'], g['means2D'][0], None, g['colors'], g['opacities'].reshape(opacities.shape),
+                 g['scales'], g['rotations'], None, None)
+        # inputs that were not tensors needing a gradient (means2D=None from render()) must get None
+        return tuple(v if need else None for v, need in zip(grads, ctx.needs_input_grad))
 
 
 class _RasterizeViews(torch.autograd.Function):

@@ -51,7 +51,7 @@ def test_prefilter(core):
     d = depth.cpu().numpy()
     fd = fdepth.cpu().numpy()
     assert ((fd == 0) | (fd == d)).all()
-    flips = (fd != want_fd) & (np.abs(want_d - np.float32(thr)) > 1e-6)       # only ties at the threshold may differ
+    flips = ((fd == 0) != (want_fd == 0)) & (np.abs(want_d - np.float32(thr)) > 1e-6)   # only ties at the threshold may differ
     assert not flips.any()
     s1 = sem.cpu().numpy()[:, 1]
     keep = (s1 >= np.float32(0.25))[:, None]
@@ -70,9 +70,10 @@ def test_prefilter_ragged_width(core):
     wd, wfd, ws, wf = oc.prefilter(x, 7, 9, 0.1, 0.4)
     close(depth, wd, 1e-6, 'depth'), close(sem, ws, 1e-6, 'semantic')
     ok = (np.abs(wd - 0.1) > 1e-6)
-    assert np.array_equal(fdepth.cpu().numpy()[ok], wfd[ok])
+    assert np.array_equal(fdepth.cpu().numpy()[ok] == 0, wfd[ok] == 0)
+    close(fdepth.cpu().numpy()[ok], wfd[ok], 1e-6, 'filter_depth')
     sure = np.abs(ws[:, 1] - 0.4) > 1e-6
-    assert np.array_equal(feat.cpu().numpy()[sure], wf.transpose(0, 2, 3, 1)[sure])
+    assert np.array_equal(feat.cpu().numpy()[sure], np.ascontiguousarray(wf.transpose(0, 2, 3, 1))[sure])
 
 
 def test_pillar_sample_mean(core):
