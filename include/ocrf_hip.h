@@ -301,6 +301,18 @@ int ocrf_hoa1_forward(const float *opacity, const float *alpha, const float *wei
                       float offset_scale, float *att_workspace, float *out, ocrf_stream_t stream);
 int ocrf_hoa1_weights_len(void);
 
+/*
+ * Pillar projections consumed by the colour / alpha sampling and retain_valid_pixels
+ * (view_transformer_ocrf.py:1057-1066 from get_sampling_point :687-740), same inputs as
+ * ocrf_ht_prepare (pc_range: 6 floats in HOST memory):
+ *   pix   (B,N,Z,n_pillars,2)  (u_norm*w_in, v_norm*h_in) of every sample, masked ones included
+ *   mask  (B,N,Z,n_pillars)    bytes, the get_sampling_point mask
+ *   voxel (B,Z,n_pillars,3)    metric voxel centres (the in-place scaled reference points, :690-692); may be NULL
+ */
+int ocrf_ht_project(int B, int N, int Z, int n_pillars, const float *ref_points, const float *cams,
+                    const float *pc_range, float w_in, float h_in, float depth0, float depth1,
+                    float *pix, unsigned char *mask, float *voxel, ocrf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Neck glue between the poolings, the render and HOA (eval mode; csrc/neck.hip)
  * ------------------------------------------------------------------------------------------ */
@@ -313,7 +325,7 @@ int ocrf_hoa1_weights_len(void);
  *   semantic      (BN,2,HW)  softmax over the 2 semantic logits
  *   feat_channels_last (BN,HW,C)  tran_feat * (semantic[:,1] >= semantic_threshold), i.e. the
  *                 (B,N,H,W,C) operand of bev_pool_v2
- * 64*(C+1)*4 bytes of LDS must fit (C <= 230).
+ * 64*(C+1)*4 bytes of LDS must fit (C <= 230); D <= 512.
  */
 int ocrf_prefilter(const float *x, int BN, int D, int C, int HW, float depth_threshold,
                    float semantic_threshold, float *depth, float *filter_depth, float *semantic,
@@ -349,7 +361,7 @@ int ocrf_retain_valid_pixels(const float *imgs, const float *pix, const unsigned
  *   scales (.,3) = softplus(S_MLP(f)), rotations (.,4) = normalize(R_MLP(f)), color (.,3) =
  *   sigmoid(C_MLP([f, rgb/255])).
  * params: ocrf_gauss_heads_params_len(C, Zh) floats packed as documented in csrc/neck.hip.
- * rotations must be 16-byte aligned.
+ * rotations must be 16-byte aligned, params 8-byte aligned; Zh in {1,2,4,6,8,13} (register tile).
  */
 int ocrf_gauss_heads(const float *bev, const float *rgb_avg, const float *params, int B, int C, int Zh,
                      int YX, float *opacity, float *scales, float *rotations, float *color,
@@ -412,6 +424,7 @@ enum {
   OCRF_K_LSS_EMIT = 45,          /* lss_emit_ranks_kernel */
   OCRF_K_HT_COUNT = 46,          /* ht_valid_kernel */
   OCRF_K_HT_EMIT = 47,           /* ht_emit_kernel */
+  OCRF_K_HT_PROJECT = 48,        /* ht_project_kernel */
   OCRF_K_NECK_PREFILTER = 60,    /* neck_prefilter_kernel */
   OCRF_K_NECK_SAMPLE = 61,       /* neck_pillar_sample_mean_kernel<C> */
   OCRF_K_NECK_RETAIN = 62,       /* neck_fill_kernel + neck_retain_scatter_kernel */

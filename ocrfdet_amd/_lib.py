@@ -112,6 +112,8 @@ def _declare(L):
     L.ocrf_hoa1_forward.argtypes = [c_void_p] * 3 + [c_int] * 3 + [c_float] + [c_void_p] * 3
     L.ocrf_hoa1_weights_len.restype = c_int
     L.ocrf_hoa1_weights_len.argtypes = []
+    L.ocrf_ht_project.restype = c_int
+    L.ocrf_ht_project.argtypes = [c_int] * 4 + [c_void_p] * 3 + [c_float] * 4 + [c_void_p] * 4
     L.ocrf_prefilter.restype = c_int
     L.ocrf_prefilter.argtypes = [c_void_p] + [c_int] * 4 + [c_float] * 2 + [c_void_p] * 5
     L.ocrf_pillar_sample_mean.restype = c_int

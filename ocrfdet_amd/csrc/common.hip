@@ -70,6 +70,7 @@ const char* ocrf_kernel_name(int kernel_id) {
     case OCRF_K_LSS_EMIT: return "lss_emit_ranks_kernel";
     case OCRF_K_HT_COUNT: return "ht_valid_kernel";
     case OCRF_K_HT_EMIT: return "ht_emit_kernel";
+    case OCRF_K_HT_PROJECT: return "ht_project_kernel";
     case OCRF_K_NECK_PREFILTER: return "neck_prefilter_kernel";
     case OCRF_K_NECK_SAMPLE: return "neck_pillar_sample_mean_kernel<*>";
     case OCRF_K_NECK_RETAIN: return "neck_retain_scatter_kernel";

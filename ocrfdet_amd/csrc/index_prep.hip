@@ -357,6 +357,42 @@ __global__ __launch_bounds__(kBlock) void ht_valid_kernel(HtParams q, const floa
   valid_bits[(long)cam * q.Nq + pil] = valid;
 }
 
+// Pillar projections for the colour / alpha sampling and retain_valid_pixels (view_transformer_ocrf.py:
+// 1057-1066): pixel coordinates (u_norm * W_in, v_norm * H_in) and the validity mask of EVERY
+// (camera, height, pillar) sample, plus the metric voxel centres — the same arithmetic as ht_project,
+// without the early exits (the reference materialises the coordinates of masked samples too).
+__global__ __launch_bounds__(kBlock) void ht_project_kernel(HtParams q, const float* __restrict__ ref, const HtCam* __restrict__ cams,
+                                                            float2* __restrict__ pix, unsigned char* __restrict__ mask,
+                                                            float* __restrict__ voxel) {
+  const int pil = blockIdx.x * kBlock + threadIdx.x;
+  const int cam = blockIdx.y;                  // b*N + n
+  if (pil >= q.Nq) return;
+  const HtCam& c = cams[cam];
+  const float eps = 1e-5f;
+  for (int z = 0; z < q.Z; ++z) {
+    const float* r = ref + ((long)z * q.Nq + pil) * 3;
+    const float x = r[0] * q.sx + q.ox, y = r[1] * q.sy + q.oy, zz = r[2] * q.sz + q.oz;
+    const float cx = c.l2i[0] * x + c.l2i[1] * y + c.l2i[2] * zz + c.l2i[3] * 1.0f;
+    const float cy = c.l2i[4] * x + c.l2i[5] * y + c.l2i[6] * zz + c.l2i[7] * 1.0f;
+    const float cz = c.l2i[8] * x + c.l2i[9] * y + c.l2i[10] * zz + c.l2i[11] * 1.0f;
+    const float den = fmaxf(cz, eps);
+    const float u0 = cx / den, v0 = cy / den;
+    float u = c.aug[0] * u0 + c.aug[1] * v0 + c.aug[2] * cz + c.aug[3] * 1.0f;
+    float v = c.aug[4] * u0 + c.aug[5] * v0 + c.aug[6] * cz + c.aug[7] * 1.0f;
+    u = u / q.w_in;
+    v = v / q.h_in;
+    const float d = (cz - q.d0) / q.dspan;
+    const bool ok = (cz > eps) && (u > 0.0f) && (u < 1.0f) && (v > 0.0f) && (v < 1.0f) && (d > 0.0f) && (d < 1.0f);
+    const long o = ((long)cam * q.Z + z) * q.Nq + pil;
+    pix[o] = make_float2(u * q.w_in, v * q.h_in);
+    mask[o] = ok ? 1 : 0;
+    if (voxel && cam % q.N == 0) {
+      float* vo = voxel + (((long)(cam / q.N) * q.Z + z) * q.Nq + pil) * 3;
+      vo[0] = x; vo[1] = y; vo[2] = zz;
+    }
+  }
+}
+
 // per (b, pillar): number of kept samples over its cameras, packed with the non-empty flag so that
 // ONE scan gives both prefix sums
 __global__ __launch_bounds__(kBlock) void ht_pillar_totals_kernel(HtParams q, const unsigned* __restrict__ valid_bits,
@@ -529,6 +565,23 @@ int ocrf_lss_prepare(int B, int N, int D, int H, int W, const float* frustum, co
   ocrf::launch(OCRF_K_LSS_EMIT, lss_emit_ranks_kernel, dim3((n_pts + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
                static_cast<const unsigned*>(keys[cur]), static_cast<const int*>(vals[cur]), static_cast<const int*>(S),
                n_vox_total, D * H * W, H * W, ranks_bev, ranks_depth, ranks_feat);
+  return (int)hipGetLastError();
+}
+
+int ocrf_ht_project(int B, int N, int Z, int n_pillars, const float* ref_points, const float* cams,
+                    const float* pc_range, float w_in, float h_in, float depth0, float depth1, float* pix,
+                    unsigned char* mask, float* voxel, ocrf_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (B <= 0 || N <= 0 || Z <= 0 || B * N > 65535 || n_pillars <= 0 || !ref_points || !cams || !pc_range || !pix || !mask)
+    return (int)hipErrorInvalidValue;
+  HtParams q;
+  q.B = B; q.N = N; q.Z = Z; q.Nq = n_pillars; q.Wf = 0; q.Hf = 0; q.D = 0;
+  q.sx = (float)((double)pc_range[3] - (double)pc_range[0]); q.ox = pc_range[0];
+  q.sy = (float)((double)pc_range[4] - (double)pc_range[1]); q.oy = pc_range[1];
+  q.sz = (float)((double)pc_range[5] - (double)pc_range[2]); q.oz = pc_range[2];
+  q.w_in = w_in; q.h_in = h_in; q.d0 = depth0; q.dspan = (float)((double)depth1 - (double)depth0);
+  ocrf::launch(OCRF_K_HT_PROJECT, ht_project_kernel, dim3((n_pillars + kBlock - 1) / kBlock, B * N), dim3(kBlock), 0, stream,
+               q, ref_points, reinterpret_cast<const HtCam*>(cams), reinterpret_cast<float2*>(pix), mask, voxel);
   return (int)hipGetLastError();
 }
 

@@ -30,6 +30,7 @@ __device__ __forceinline__ float softplusf(float x) { return x > 20.0f ? x : log
 // ------------------------------------------------------------------------------------------
 // prefilter: one workgroup = 64 consecutive pixels of one image x 4 depth slices.
 // ------------------------------------------------------------------------------------------
+template <int PER>   // depth logits per thread (D <= 4*PER): loaded once, all in flight together
 __global__ __launch_bounds__(256) void neck_prefilter_kernel(
     const float* __restrict__ x, int D, int C, int HW, float depth_thr, float sem_thr,
     float* __restrict__ depth, float* __restrict__ filter_depth, float* __restrict__ semantic,
@@ -41,25 +42,38 @@ __global__ __launch_bounds__(256) void neck_prefilter_kernel(
   const int bn = blockIdx.y, p0 = blockIdx.x * kWave, p = p0 + lane;
   const bool live = p < HW;
   const float* xi = x + (size_t)bn * (D + 2 + C) * HW;
+  float v[PER];
   float m = -INFINITY;
-  for (int d = sl; d < D; d += 4)
-    if (live) m = fmaxf(m, xi[(size_t)d * HW + p]);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int d = sl + 4 * i;
+    v[i] = (live && d < D) ? xi[(size_t)d * HW + p] : -INFINITY;
+  }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) m = fmaxf(m, v[i]);
   red[sl][lane] = m;
   __syncthreads();
   m = fmaxf(fmaxf(red[0][lane], red[1][lane]), fmaxf(red[2][lane], red[3][lane]));
   __syncthreads();
   float s = 0.0f;
-  for (int d = sl; d < D; d += 4)
-    if (live) s += expf(xi[(size_t)d * HW + p] - m);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int d = sl + 4 * i;
+    v[i] = (live && d < D) ? expf(v[i] - m) : 0.0f;
+    s += v[i];
+  }
   red[sl][lane] = s;
   __syncthreads();
   s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-  for (int d = sl; d < D; d += 4) {
-    if (!live) break;
-    const float v = expf(xi[(size_t)d * HW + p] - m) / s;
-    const size_t o = ((size_t)bn * D + d) * HW + p;
-    depth[o] = v;
-    filter_depth[o] = v < depth_thr ? 0.0f : v;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int d = sl + 4 * i;
+    if (live && d < D) {
+      const float pr = v[i] / s;
+      const size_t o = ((size_t)bn * D + d) * HW + p;
+      depth[o] = pr;
+      filter_depth[o] = pr < depth_thr ? 0.0f : pr;
+    }
   }
   if (sl == 0) {
     float k = 0.0f;
@@ -188,68 +202,94 @@ __global__ __launch_bounds__(256) void neck_retain_scatter_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Gaussian heads.  One thread = one (height, pillar); the 16 hidden units of the four heads are
-// accumulated while the C channels of the pillar stream by (lanes = consecutive pillars: coalesced
-// reads of the NCHW BEV; weights are wave-uniform scalar loads).
-// params: lift_a[Zh] lift_b[Zh] | W1[16][C] (S,R,A,Col: 4 rows each) | W1rgb[4][3] | b1[16] |
+// Gaussian heads.  One thread = one pillar, ALL heights: a channel of the NCHW BEV is read once
+// (lanes = consecutive pillars: coalesced), its 16 first-layer weights arrive as ONE wave-uniform
+// 64-byte scalar load (W1 is stored channel-major for that), and the 16 hidden units of every height
+// are accumulated as 8 packed pairs (v_pk_fma_f32).  ZH heights x 16 accumulators live in registers.
+// params: lift_a[Zh] lift_b[Zh] | W1t[C][16] (columns S,R,A,Col: 4 each) | W1rgb[4][3] | b1[16] |
 //         S: W2[3][4] b2[3] | R: W2[4][4] b2[4] | A: W2[1][4] b2[1] | Col: W2[3][4] b2[3]
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void neck_gauss_heads_kernel(
-    const float* __restrict__ bev, const float* __restrict__ rgb_avg, const float* __restrict__ prm, int C, int Zh, int YX,
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int ZH>
+__global__ __launch_bounds__(64) void neck_gauss_heads_kernel(
+    const float* __restrict__ bev, const float* __restrict__ rgb_avg, const float* __restrict__ prm, int C, int YX,
     float* __restrict__ opacity, float* __restrict__ scales, float* __restrict__ rot, float* __restrict__ color) {
-  const int q = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int q = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
   if (q >= YX) return;
-  const float la = prm[h], lb = prm[Zh + h];
-  const float* W1 = prm + 2 * Zh;
-  const float* W1rgb = W1 + 16 * C;
+  const float* la = prm;
+  const float* lb = prm + ZH;
+  const f32x2* W1t = reinterpret_cast<const f32x2*>(prm + 2 * ZH);
+  const float* W1rgb = prm + 2 * ZH + 16 * C;
   const float* b1 = W1rgb + 12;
   const float* S2 = b1 + 16;
   const float* R2 = S2 + 15;
   const float* A2 = R2 + 20;
   const float* C2 = A2 + 5;
-  float hid[16];
+  f32x2 hid[ZH][8];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) hid[k] = 0.0f;
+  for (int h = 0; h < ZH; ++h)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) hid[h][k] = f32x2{0.0f, 0.0f};
   const float* bp = bev + (size_t)b * C * YX + q;
-  for (int c = 0; c < C; ++c) {
-    const float f = fmaxf(la * bp[(size_t)c * YX] + lb, 0.0f);
+  // 8 channel reads in flight per lane: with one or two waves per SIMD nothing else hides the latency
+  constexpr int kAhead = 8;
+  for (int c0 = 0; c0 < C; c0 += kAhead) {
+    float vv[kAhead];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) hid[k] = fmaf(W1[k * C + c], f, hid[k]);
-  }
-  const size_t g = ((size_t)b * Zh + h) * YX + q;
-  const float* rp = rgb_avg + g * 3;
-  const float r01[3] = {rp[0] / 255.0f, rp[1] / 255.0f, rp[2] / 255.0f};
+    for (int j = 0; j < kAhead; ++j) vv[j] = (c0 + j < C) ? bp[(size_t)(c0 + j) * YX] : 0.0f;
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
-    for (int j = 0; j < 3; ++j) hid[12 + k] = fmaf(W1rgb[k * 3 + j], r01[j], hid[12 + k]);
+    for (int j = 0; j < kAhead; ++j) {
+      if (c0 + j >= C) break;
+      f32x2 w[8];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) hid[k] = fmaxf(hid[k] + b1[k], 0.0f);
-  // scales: softplus
-  for (int o = 0; o < 3; ++o) {
-    float v = S2[12 + o];
-    for (int k = 0; k < 4; ++k) v = fmaf(S2[o * 4 + k], hid[k], v);
-    scales[g * 3 + o] = softplusf(v);
+      for (int k = 0; k < 8; ++k) w[k] = W1t[(c0 + j) * 8 + k];
+#pragma unroll
+      for (int h = 0; h < ZH; ++h) {
+        const float f = fmaxf(fmaf(la[h], vv[j], lb[h]), 0.0f);
+        const f32x2 ff = {f, f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) hid[h][k] = __builtin_elementwise_fma(w[k], ff, hid[h][k]);
+      }
+    }
   }
-  // rotation: L2-normalised (F.normalize eps 1e-12)
-  float r[4], nn = 0.0f;
-  for (int o = 0; o < 4; ++o) {
-    float v = R2[16 + o];
-    for (int k = 0; k < 4; ++k) v = fmaf(R2[o * 4 + k], hid[4 + k], v);
-    r[o] = v;
-    nn = fmaf(v, v, nn);
-  }
-  const float den = fmaxf(sqrtf(nn), 1e-12f);
-  *reinterpret_cast<float4*>(rot + g * 4) = make_float4(r[0] / den, r[1] / den, r[2] / den, r[3] / den);
-  // opacity
-  {
-    float v = A2[4];
-    for (int k = 0; k < 4; ++k) v = fmaf(A2[k], hid[8 + k], v);
-    opacity[g] = sigmoidf(v);
-  }
-  for (int o = 0; o < 3; ++o) {
-    float v = C2[12 + o];
-    for (int k = 0; k < 4; ++k) v = fmaf(C2[o * 4 + k], hid[12 + k], v);
-    color[g * 3 + o] = sigmoidf(v);
+#pragma unroll
+  for (int h = 0; h < ZH; ++h) {
+    const size_t g = ((size_t)b * ZH + h) * YX + q;
+    const float* rp = rgb_avg + g * 3;
+    const float r01[3] = {rp[0] / 255.0f, rp[1] / 255.0f, rp[2] / 255.0f};
+    float hv[16];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { hv[2 * k] = hid[h][k].x; hv[2 * k + 1] = hid[h][k].y; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      for (int j = 0; j < 3; ++j) hv[12 + k] = fmaf(W1rgb[k * 3 + j], r01[j], hv[12 + k]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) hv[k] = fmaxf(hv[k] + b1[k], 0.0f);
+    for (int o = 0; o < 3; ++o) {                    // scales: softplus
+      float v = S2[12 + o];
+      for (int k = 0; k < 4; ++k) v = fmaf(S2[o * 4 + k], hv[k], v);
+      scales[g * 3 + o] = softplusf(v);
+    }
+    float r[4], nn = 0.0f;                           // rotation: L2-normalised (F.normalize eps 1e-12)
+    for (int o = 0; o < 4; ++o) {
+      float v = R2[16 + o];
+      for (int k = 0; k < 4; ++k) v = fmaf(R2[o * 4 + k], hv[4 + k], v);
+      r[o] = v;
+      nn = fmaf(v, v, nn);
+    }
+    const float den = fmaxf(sqrtf(nn), 1e-12f);
+    *reinterpret_cast<float4*>(rot + g * 4) = make_float4(r[0] / den, r[1] / den, r[2] / den, r[3] / den);
+    {
+      float v = A2[4];
+      for (int k = 0; k < 4; ++k) v = fmaf(A2[k], hv[8 + k], v);
+      opacity[g] = sigmoidf(v);
+    }
+    for (int o = 0; o < 3; ++o) {
+      float v = C2[12 + o];
+      for (int k = 0; k < 4; ++k) v = fmaf(C2[o * 4 + k], hv[12 + k], v);
+      color[g * 3 + o] = sigmoidf(v);
+    }
   }
 }
 
@@ -345,9 +385,18 @@ int ocrf_prefilter(const float* x, int BN, int D, int C, int HW, float depth_thr
   if (!x || !depth || !filter_depth || !semantic || !feat_channels_last) return (int)hipErrorInvalidValue;
   const size_t lds = (size_t)kWave * (C + 1) * sizeof(float);
   if (lds > 60000) return (int)hipErrorInvalidValue;
-  ocrf::launch(OCRF_K_NECK_PREFILTER, neck_prefilter_kernel, dim3((HW + kWave - 1) / kWave, BN), dim3(256), lds,
-               (hipStream_t)stream, x, D, C, HW, depth_threshold, semantic_threshold, depth, filter_depth, semantic,
-               feat_channels_last);
+  const dim3 grid((HW + kWave - 1) / kWave, BN), block(256);
+  if (D <= 32)
+    ocrf::launch(OCRF_K_NECK_PREFILTER, neck_prefilter_kernel<8>, grid, block, lds, (hipStream_t)stream, x, D, C, HW,
+                 depth_threshold, semantic_threshold, depth, filter_depth, semantic, feat_channels_last);
+  else if (D <= 128)
+    ocrf::launch(OCRF_K_NECK_PREFILTER, neck_prefilter_kernel<32>, grid, block, lds, (hipStream_t)stream, x, D, C, HW,
+                 depth_threshold, semantic_threshold, depth, filter_depth, semantic, feat_channels_last);
+  else if (D <= 512)
+    ocrf::launch(OCRF_K_NECK_PREFILTER, neck_prefilter_kernel<128>, grid, block, lds, (hipStream_t)stream, x, D, C, HW,
+                 depth_threshold, semantic_threshold, depth, filter_depth, semantic, feat_channels_last);
+  else
+    return (int)hipErrorInvalidValue;
   return last_error();
 }
 
@@ -392,8 +441,23 @@ int ocrf_gauss_heads(const float* bev, const float* rgb_avg, const float* params
       !color)
     return (int)hipErrorInvalidValue;
   if (reinterpret_cast<uintptr_t>(rotations) & 15) return (int)hipErrorInvalidValue;
-  ocrf::launch(OCRF_K_NECK_HEADS, neck_gauss_heads_kernel, dim3((YX + 255) / 256, Zh, B), dim3(256), 0,
-               (hipStream_t)stream, bev, rgb_avg, params, C, Zh, YX, opacity, scales, rotations, color);
+  if ((reinterpret_cast<uintptr_t>(params) + 2 * Zh * sizeof(float)) & 7) return (int)hipErrorInvalidValue;
+  const dim3 grid((YX + 63) / 64, B), block(64);
+  switch (Zh) {       // heights are a compile-time constant of the register tile; the reference uses 13 (:578)
+#define OCRF_HEADS_CASE(Z)                                                                                        \
+  case Z:                                                                                                         \
+    ocrf::launch(OCRF_K_NECK_HEADS, neck_gauss_heads_kernel<Z>, grid, block, 0, (hipStream_t)stream, bev, rgb_avg, \
+                 params, C, YX, opacity, scales, rotations, color);                                               \
+    break;
+    OCRF_HEADS_CASE(13)
+    OCRF_HEADS_CASE(8)
+    OCRF_HEADS_CASE(6)
+    OCRF_HEADS_CASE(4)
+    OCRF_HEADS_CASE(2)
+    OCRF_HEADS_CASE(1)
+#undef OCRF_HEADS_CASE
+    default: return (int)hipErrorInvalidValue;
+  }
   return last_error();
 }
 

@@ -305,3 +305,23 @@ def fast_sample_prepare_hip(ref_template, cam_block, B, N, pc_range, image_shape
     if not sync:
         return bufs[:5], bufs[5]
     return _trim(bufs, bufs[5].cpu())
+
+
+def ht_project_hip(ref_template, cam_block, B, N, pc_range, image_shapes, depth_range):
+    """HIP ``get_sampling_point`` outputs that the colour sampling needs (view_transformer_ocrf.py:
+    687-740, 1057-1066): -> pix (B,N,Z,Nq,2) pixel coordinates, mask (B,N,Z,Nq) bool, voxel
+    (B,Z,Nq,3) metric centres.  Inputs as ``fast_sample_prepare_hip``."""
+    _lib.require_cuda(ref_template, cam_block)
+    dev = ref_template.device
+    Z, Nq, _ = ref_template.shape
+    pc = torch.tensor([float(v) for v in pc_range], dtype=torch.float32)
+    pix = torch.empty(B, N, Z, Nq, 2, device=dev)
+    mask = torch.empty(B, N, Z, Nq, dtype=torch.bool, device=dev)
+    voxel = torch.empty(B, Z, Nq, 3, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().ocrf_ht_project(
+            B, N, Z, Nq, _lib.ptr(ref_template.contiguous()), _lib.ptr(cam_block), ctypes.c_void_p(pc.data_ptr()),
+            ctypes.c_float(image_shapes[1]), ctypes.c_float(image_shapes[0]), ctypes.c_float(depth_range[0]),
+            ctypes.c_float(depth_range[1]), _lib.ptr(pix), _lib.ptr(mask), _lib.ptr(voxel), _lib.stream_ptr(dev)),
+            'ocrf_ht_project')
+    return pix, mask, voxel

@@ -109,7 +109,8 @@ def pack_gauss_head_params(vfe, s_mlp, r_mlp, a_mlp, c_mlp):
         C = s_mlp.fc1.in_features
         w1 = torch.cat((s_mlp.fc1.weight, r_mlp.fc1.weight, a_mlp.fc1.weight, c_mlp.fc1.weight[:, :C]), 0)
         b1 = torch.cat((s_mlp.fc1.bias, r_mlp.fc1.bias, a_mlp.fc1.bias, c_mlp.fc1.bias))
-        parts = [a.float(), b.float(), w1.reshape(-1), c_mlp.fc1.weight[:, C:].reshape(-1), b1]
+        # first layer stored channel-major (C,16): one 64-byte scalar load per channel in the kernel
+        parts = [a.float(), b.float(), w1.t().reshape(-1), c_mlp.fc1.weight[:, C:].reshape(-1), b1]
         for m in (s_mlp, r_mlp, a_mlp, c_mlp):
             parts += [m.fc2.weight.reshape(-1), m.fc2.bias]
         return torch.cat([p.detach().float().reshape(-1) for p in parts]).contiguous()

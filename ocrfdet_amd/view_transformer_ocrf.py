@@ -52,7 +52,9 @@ def _conv_bn(cin, cout, k=1, relu=False):
 
 
 class MS_CAM(nn.Module):
-    """Multi-scale channel attention (:36-66)."""
+    """Multi-scale channel attention (:36-66).  The pooling modules are kept for the Sequential's
+    indices (state_dict keys); the reductions themselves are ``mean`` / ``amax`` — PyTorch's
+    adaptive-pool kernels run one thread per output element, 3.4 ms per call on a 200x200 map."""
 
     def __init__(self, input_channel=64, output_channel=64, r=4):
         super().__init__()
@@ -63,7 +65,10 @@ class MS_CAM(nn.Module):
         self.sigmoid = nn.Sigmoid()
 
     def forward(self, x):
-        return self.sigmoid(self.local_att(x) + self.global_att(x))
+        g = x.mean((2, 3), keepdim=True)
+        for layer in list(self.global_att)[1:]:
+            g = layer(g)
+        return self.sigmoid(self.local_att(x) + g)
 
 
 class ChannelAttention(nn.Module):
@@ -75,7 +80,7 @@ class ChannelAttention(nn.Module):
         self.sigmoid = nn.Sigmoid()
 
     def forward(self, x):
-        return self.sigmoid(self.fc(self.avg_pool(x)) + self.fc(self.max_pool(x)))
+        return self.sigmoid(self.fc(x.mean((2, 3), keepdim=True)) + self.fc(x.amax((2, 3), keepdim=True)))
 
 
 def _spatial_logits(x, conv):
@@ -369,7 +374,7 @@ class OcRFViewTransformerFull(nn.Module):
         self.defor_cross_attention = hoa.DeformableAttention2D(
             dim=13, dim_head=8, heads=1, dropout=0.1, downsample_factor=4, offset_scale=4, offset_groups=None,
             offset_kernel_size=6)
-        self._geo = None
+        self._geo, self._tmpl = None, None
         self._rank_bufs = (index_prep._RankBuffers(), index_prep._RankBuffers())
         self._packs = {}
 
@@ -385,10 +390,21 @@ class OcRFViewTransformerFull(nn.Module):
         """``accelerate=True``: the geometry of the first call is kept (:854-866; the reference's own
         version of this path does not survive ``get_ht_bev_feat``)."""
         if self.initial_flag or self._geo is None:
-            self._geo = self._geometry(input)
+            self._geo = self._geometry(input)          # trimmed ranks: usable by both the fused and the autograd pooling
             self.initial_flag = False
 
-    def _geometry(self, input):
+    def _templates(self, dev):
+        """Calibration-independent templates on the device (frustum :77-106, normalised pillar grid
+        :651-673), built once."""
+        if self._tmpl is None or self._tmpl[0].device != dev:
+            ref = index_prep.get_reference_points_3d(self.bev_h, self.bev_w, bs=1, num_points_in_pillar=self.num_height,
+                                                     device='cpu')[0]
+            self._tmpl = (self.frustum.to(dev).contiguous(), ref.to(dev).contiguous())
+        return self._tmpl
+
+    def _geometry(self, input, sync=True):
+        """``sync=False`` (eval mode): the rank vectors stay at their capacity with their lengths on the
+        device — nothing between the calibration and the pooled BEV reads the device."""
         x = input[0]
         dev = x.device
         B, N, _, Hf, Wf = x.shape
@@ -401,23 +417,16 @@ class OcRFViewTransformerFull(nn.Module):
         lss_block = index_prep.lss_camera_block(*calib).to(dev)
         lidar2img, img_aug, _, _ = index_prep.get_projection(*calib)
         ht_block = index_prep.ht_camera_block(lidar2img, img_aug).to(dev)
-        frustum = self.frustum.to(dev)
-        tmpl = index_prep.get_reference_points_3d(self.bev_h, self.bev_w, bs=1, num_points_in_pillar=self.num_height,
-                                                  device='cpu')[0].to(dev)
+        frustum, tmpl = self._templates(dev)
         geo.lss = index_prep.voxel_pooling_prepare_v2_hip(frustum, lss_block, B, N, self.grid_lower_bound,
                                                           self.grid_interval, self.grid_size,
-                                                          buffers=None if self.accelerate else self._rank_bufs[0])
+                                                          buffers=None if self.accelerate else self._rank_bufs[0],
+                                                          sync=sync)
         geo.ht = index_prep.fast_sample_prepare_hip(tmpl, ht_block, B, N, list(self.pc_range), self.input_size,
                                                     self.grid_config['depth'], Wf, Hf, self.D,
-                                                    buffers=None if self.accelerate else self._rank_bufs[1])
-        ref = tmpl[None].repeat(B, 1, 1, 1)
-        coor, mask, _ = index_prep.get_sampling_point(ref, list(self.pc_range), self.grid_config['depth'],
-                                                      lidar2img.to(dev), img_aug.to(dev), self.input_size)
-        geo.voxel = ref                                             # scaled to metres in place (:690-692)
-        pix = coor[..., :2].clone()
-        pix[..., 0] *= self.input_size[1]                           # :1065-1066
-        pix[..., 1] *= self.input_size[0]
-        geo.pix, geo.mask = pix.contiguous(), mask.squeeze(-1).contiguous()
+                                                    buffers=None if self.accelerate else self._rank_bufs[1], sync=sync)
+        geo.pix, geo.mask, geo.voxel = index_prep.ht_project_hip(tmpl, ht_block, B, N, list(self.pc_range),
+                                                                 self.input_size, self.grid_config['depth'])
         return geo
 
     def _camera(self, geo, input, bs, cam_idx):
@@ -451,6 +460,9 @@ class OcRFViewTransformerFull(nn.Module):
 
     # -------------------------------------------------------------------------------- pooling
     def _pool(self, ranks, depth, feat_cl, bev_shape):
+        if len(ranks) == 2:                       # ((five capacity vectors), device counts): forward only
+            (rb, rd, rf, st, ln), counts = ranks
+            return bevpool.bev_pool_v2_device_counts(depth, feat_cl, rd, rf, rb, bev_shape, st, ln, counts)
         if ranks[0] is None:
             B, Z, Y, X, C = bev_shape
             return torch.zeros(B, Z * C, Y, X, device=depth.device)
@@ -480,7 +492,7 @@ class OcRFViewTransformerFull(nn.Module):
         C, Zh, Y, X = self.out_channels, self.num_height, self.bev_h, self.bev_w
         H, W = self.input_size
         fused = not (self.training and torch.is_grad_enabled())
-        geo = self._geo if (self.accelerate and self._geo is not None) else self._geometry(input)
+        geo = self._geo if (self.accelerate and self._geo is not None) else self._geometry(input, sync=not fused)
         depth5 = depth.reshape(B, N, self.D, Hf, Wf).float()
         if feat_channels_last is None:
             feat_channels_last = tran_feat.reshape(B, N, C, Hf, Wf).permute(0, 1, 3, 4, 2)

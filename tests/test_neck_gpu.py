@@ -195,7 +195,9 @@ def test_module_forward_entry_point_and_accelerate(core):
             m(core['inp'])
             random.seed(3)
             out2 = m(core['inp'])
-        assert torch.equal(out[0], out2[0]) and torch.equal(out[3][4], out2[3][4])
+        # MIOpen may pick another convolution algorithm on a later call: compare to 1e-5, not bitwise
+        close(out2[0], out[0].cpu().numpy(), 1e-5, 'bev_feat with cached geometry')
+        close(out2[3][4], out[3][4].cpu().numpy(), 1e-5, 'opacity view with cached geometry')
     finally:
         m.accelerate, m._geo = False, None
 
@@ -229,3 +231,34 @@ def test_training_path_matches_fused_path(core):
     close(lst[4], lst2[4].cpu().numpy(), 1e-4, 'opacity view train vs fused')
     close(lst[3], lst2[3].cpu().numpy(), 1e-5, 'render_N train vs fused')
     close(lst[8], lst2[8].cpu().numpy(), 1e-5, 'render_depth_N train vs fused')
+
+
+def test_ht_project_bit_exact(core):
+    """ocrf_ht_project vs the numpy oracle of get_sampling_point (itself pinned bit-exactly to the
+    reference's vectors): mask identical, pixel coordinates of valid samples bit-identical."""
+    from ocrfdet_amd import index_prep
+    from oracle import index_prep as oip
+    from ocrfdet_amd import synthetic
+    cfg, B = core['cfg'], core['B']
+    X, Y, _ = cfg.bev_xyz
+    r = synthetic.rig(cfg.n_cams, cfg.input_size, B)
+    calib = [torch.from_numpy(r[k]) for k in ('rots', 'trans', 'intrins', 'post_rots', 'post_trans', 'bda')]
+    l2i, aug, _, _ = index_prep.get_projection(*calib)
+    block = index_prep.ht_camera_block(l2i, aug).cuda()
+    tmpl = index_prep.get_reference_points_3d(Y, X, bs=1, num_points_in_pillar=cfg.num_height, device='cpu')[0].cuda()
+    pix, mask, voxel = index_prep.ht_project_hip(tmpl, block, B, cfg.n_cams, list(cfg.pc_range), cfg.input_size,
+                                                 cfg.grid['depth'])
+    # torch formulation with the SAME lidar2img / img_aug (the 3x3 inverses are LAPACK's on both sides)
+    ref = tmpl.cpu()[None].repeat(B, 1, 1, 1)
+    coor, tmask, _ = index_prep.get_sampling_point(ref, list(cfg.pc_range), cfg.grid['depth'], l2i, aug, cfg.input_size)
+    want_pix = coor[..., :2].clone()
+    want_pix[..., 0] *= cfg.input_size[1]
+    want_pix[..., 1] *= cfg.input_size[0]
+    m = tmask.squeeze(-1)
+    assert torch.equal(mask.cpu(), m)
+    assert torch.equal(pix.cpu()[m], want_pix[m])
+    assert torch.equal(voxel.cpu(), ref)
+    # and the numpy oracle's mask (pinned to the reference's sha256 in tests/test_index_prep.py)
+    assert np.array_equal(mask.cpu().numpy(), core['mask'][..., 0])
+    ok = core['mask'][..., 0]
+    assert np.abs(pix.cpu().numpy()[ok] - core['pix'][ok]).max() < 1e-4

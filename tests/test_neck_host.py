@@ -50,7 +50,7 @@ def test_gauss_head_packing(core):
     assert prm.size == 2 * Zh + 16 * C + 12 + 16 + 15 + 20 + 5 + 15
     la, lb = prm[:Zh], prm[Zh:2 * Zh]
     o = 2 * Zh
-    W1 = prm[o:o + 16 * C].reshape(16, C)
+    W1 = prm[o:o + 16 * C].reshape(C, 16).T                               # stored channel-major
     W1rgb = prm[o + 16 * C:o + 16 * C + 12].reshape(4, 3)
     b1 = prm[o + 16 * C + 12:o + 16 * C + 28]
     rest = prm[o + 16 * C + 28:]
