@@ -46,6 +46,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--shard', choices=('samples', 'frames', 'cameras'), default='samples')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL); gloo only for plumbing tests')
+    ap.add_argument('--scope', choices=('hotpath', 'neck'), default='hotpath',
+                    help="'hotpath': pools (+ one rendered view per camera + HOA) — the headline step; 'neck': the whole "
+                         "OcRFViewTransformerFull.view_transform (one rendered view per sample, like the reference)")
     ap.add_argument('--index-prep', choices=('cached', 'per_step'), default='cached',
                     help="'per_step': rank vectors recomputed by the HIP index preparation inside every step "
                          "(the reference with accelerate=False); 'cached': once per calibration (accelerate=True)")
@@ -105,6 +108,65 @@ def cpu_baseline(hp, depth, feat, budget_s):
                        + '; HOA (small torch convs) not included; C/OpenMP oracle')
 
 
+def bench_neck(args, cfg, dev, world, rank):
+    """--scope neck: one step = pre-filter + the whole view_transform of B = n_frames samples per rank
+    (whole samples per rank, no data-path collective).  Roofline: the LSS/HT pooling kernel."""
+    import torch.distributed as dist
+    from ocrfdet_amd import _lib, hotpath
+    neck = hotpath.NeckPath(cfg, dev, accelerate=args.index_prep == 'cached', seed=rank)
+    for _ in range(args.warmup):
+        neck.step()
+    timer = _lib.KernelTimer(_lib.K_BEV_POOL_FWD, 2 * args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    timer.arm()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        neck.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    timer.disarm()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        ms = timer.read_ms()
+        avg_ms = sum(ms) / max(len(ms), 1)
+        m, geo = neck.module, neck.module._geo
+        d_numel = neck.batch * cfg.n_cams * cfg.D * cfg.feat_hw[0] * cfg.feat_hw[1]
+        f_numel = neck.batch * cfg.n_cams * cfg.channels * cfg.feat_hw[0] * cfg.feat_hw[1]
+        alg = None
+        if geo is not None and len(geo.lss) == 5 and geo.lss[0] is not None:
+            X, Y, Z = cfg.bev_xyz
+            per = [4 * (d_numel + f_numel + 3 * r[0].numel() + 2 * r[3].numel() + neck.batch * z * Y * X * cfg.channels)
+                   for r, z in ((geo.lss, Z), (geo.ht, 1))]
+            alg = 0.5 * sum(per)
+        achieved = alg / (avg_ms * 1e-3) / 1e9 if alg and avg_ms > 0 else None
+        out = {'metric': 'BEV voxels/sec + rendered views/sec, 6-cam 256x704',
+               'value': neck.bev_voxels_per_step * world * args.steps / elapsed, 'unit': 'BEV voxels/s',
+               'rendered_views_per_sec': neck.views_per_step * world * args.steps / elapsed,
+               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': cfg.name + ' / whole neck', 'cams': cfg.n_cams, 'frames_per_gpu': cfg.n_frames,
+                          'bev': list(cfg.bev_xyz), 'channels': cfg.channels, 'depth_bins': cfg.D,
+                          'stages': 'prefilter+lss_pool+ht_pool+colour/alpha sampling+gauss heads+nerf branch+render+hoa+bev fusion',
+                          'views_per_step': neck.views_per_step, 'render_camera': 'reference',
+                          'index_prep': 'cached (accelerate=True)' if args.index_prep == 'cached' else 'per step, HIP (accelerate=False)',
+                          'sharding': 'none' if world == 1 else f'{world} ranks x whole samples, no data-path collective'},
+               'roofline': {'bound': 'hbm', 'kernel': timer.kernel_name, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                            'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS if achieved else None, 'traffic': None,
+                            'algorithmic_bytes_per_launch': alg, 'avg_launch_us': 1e3 * avg_ms, 'launches_timed': len(ms)},
+               'cpu_baseline': None}
+        print(json.dumps(out), flush=True)
+    timer.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -128,6 +190,8 @@ def main():
     cfg = synthetic.CONFIGS[args.config]
     shard = args.shard if world > 1 else 'none'
     active = True
+    if args.scope == 'neck':
+        return bench_neck(args, cfg, dev, world, rank)
     if shard == 'cameras':
         # strong scaling of ONE sample: rank r < n_cams owns cameras r, r + world', ... (world' active ranks)
         n_active = min(world, cfg.n_cams)

@@ -250,3 +250,49 @@ class HotPath:
     def bev_voxels_per_step(self):
         X, Y, Z = self.cfg.bev_xyz
         return self.batch * Z * Y * X
+
+
+class NeckPath:
+    """The whole neck as one step: pre-filter + ``OcRFViewTransformerFull.view_transform`` (both
+    poolings, colour / alpha sampling, Gaussian heads, NeRF branch, one rendered view per sample, HOA,
+    BEV fusion) with random-init weights of the reference architecture on the synthetic rig — what
+    ``bench.py --scope neck`` and ``tools/time_neck.py`` drive.  Frames ride along as batch entries."""
+
+    def __init__(self, cfg, device, accelerate=True, seed=0):
+        from . import neck_ops
+        from . import view_transformer_ocrf as vto
+        self.cfg, self.device, self._ops = cfg, torch.device(device), neck_ops
+        self.batch = cfg.batch * cfg.n_frames
+        X, Y, _ = cfg.bev_xyz
+        torch.manual_seed(seed)
+        self.module = vto.OcRFViewTransformerFull(
+            pc_range=list(cfg.pc_range), bev_h=Y, bev_w=X, num_height=cfg.num_height, grid_config=cfg.grid,
+            input_size=cfg.input_size, downsample=cfg.downsample, in_channels=256, out_channels=cfg.channels,
+            accelerate=accelerate).to(self.device).eval()
+        r = synthetic.rig(cfg.n_cams, cfg.input_size, self.batch)
+        Hf, Wf = cfg.feat_hw
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(self.batch, cfg.n_cams, 256, Hf, Wf, generator=g)
+        raw = torch.randint(0, 256, (self.batch, cfg.n_cams, 3, *cfg.input_size), generator=g).float()
+        inp = [x] + [torch.from_numpy(r[k]) for k in ('rots', 'trans', 'intrins', 'post_rots', 'post_trans', 'bda')]
+        inp += [torch.zeros(self.batch, cfg.n_cams, 27), raw, raw, raw, torch.from_numpy(r['c2w'])]
+        self.inputs = [t.to(self.device) for t in inp]
+        pre = torch.randn(self.batch * cfg.n_cams, cfg.D + 2 + cfg.channels, Hf, Wf, generator=g)
+        pre[:, :cfg.D] *= 3                                       # stand-in for the DepthNet output
+        self.depthnet_out = pre.to(self.device)
+
+    @torch.no_grad()
+    def step(self):
+        m = self.module
+        depth, fdepth, sem, feat_cl = self._ops.prefilter(self.depthnet_out, m.D, m.out_channels, m.depth_threshold,
+                                                          m.semantic_threshold)
+        return m.view_transform(self.inputs, fdepth, None, feat_cl)
+
+    @property
+    def bev_voxels_per_step(self):
+        X, Y, Z = self.cfg.bev_xyz
+        return self.batch * Z * Y * X
+
+    @property
+    def views_per_step(self):
+        return self.batch                                         # one random camera per sample (:1081)

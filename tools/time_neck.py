@@ -13,31 +13,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ocrfdet_amd import neck_ops, synthetic  # noqa: E402
-from ocrfdet_amd import view_transformer_ocrf as vto  # noqa: E402
-
-
-def build(cfg, dev, accelerate, seed=0):
-    torch.manual_seed(seed)
-    X, Y, _ = cfg.bev_xyz
-    m = vto.OcRFViewTransformerFull(pc_range=list(cfg.pc_range), bev_h=Y, bev_w=X, num_height=cfg.num_height,
-                                    grid_config=cfg.grid, input_size=cfg.input_size, downsample=cfg.downsample,
-                                    in_channels=256, out_channels=cfg.channels, accelerate=accelerate)
-    return m.to(dev).eval()
-
-
-def inputs(cfg, dev, seed=0):
-    B = cfg.batch * cfg.n_frames
-    r = synthetic.rig(cfg.n_cams, cfg.input_size, B)
-    Hf, Wf = cfg.feat_hw
-    g = torch.Generator().manual_seed(seed)
-    x = torch.randn(B, cfg.n_cams, 256, Hf, Wf, generator=g)
-    raw = torch.randint(0, 256, (B, cfg.n_cams, 3, *cfg.input_size), generator=g).float()
-    inp = [x] + [torch.from_numpy(r[k]) for k in ('rots', 'trans', 'intrins', 'post_rots', 'post_trans', 'bda')]
-    inp += [torch.zeros(B, cfg.n_cams, 27), raw, raw, raw, torch.from_numpy(r['c2w'])]
-    pre = torch.randn(B * cfg.n_cams, cfg.D + 2 + cfg.channels, Hf, Wf, generator=g)
-    pre[:, :cfg.D] *= 3
-    return [t.to(dev) for t in inp], pre.to(dev)
+from ocrfdet_amd import hotpath, synthetic  # noqa: E402
 
 
 def main():
@@ -49,13 +25,8 @@ def main():
     a = ap.parse_args()
     cfg = synthetic.CONFIGS[a.config]
     dev = torch.device('cuda:0')
-    m = build(cfg, dev, a.accelerate)
-    inp, pre = inputs(cfg, dev)
-    B = inp[0].shape[0]
-
-    def step():
-        depth, fdepth, sem, feat_cl = neck_ops.prefilter(pre, m.D, m.out_channels, m.depth_threshold, m.semantic_threshold)
-        return m.view_transform(inp, fdepth, None, feat_cl)
+    neck = hotpath.NeckPath(cfg, dev, accelerate=a.accelerate)
+    B, step = neck.batch, neck.step
     random.seed(0)
     with torch.no_grad():
         for _ in range(5):
