@@ -288,6 +288,42 @@ class NeckPath:
                                                           m.semantic_threshold)
         return m.view_transform(self.inputs, fdepth, None, feat_cl)
 
+    # ---- the same step as ONE hipGraph launch (cached geometry only) -------------------------------
+    def capture(self, warmup=3):
+        """Capture ``step`` into a hipGraph.  The only per-step host decision — the random camera of each
+        sample (view_transformer_ocrf.py:1081) — lives in two small static device tensors that
+        ``step_graphed`` refreshes before every replay."""
+        m = self.module
+        if not m.accelerate:
+            raise RuntimeError('graph capture needs accelerate=True (geometry cached across steps)')
+        self.step()                                               # geometry, packs, workspaces, MIOpen algorithms
+        self._cams = m.stage_cameras(m._geo, [0] * self.batch, self.device)
+
+        def body():
+            depth, fdepth, sem, feat_cl = self._ops.prefilter(self.depthnet_out, m.D, m.out_channels, m.depth_threshold,
+                                                              m.semantic_threshold)
+            return m.view_transform(self.inputs, fdepth, None, feat_cl, cameras=self._cams)
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):
+                body()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self._graph):
+            self._static_out = body()
+        return self
+
+    def step_graphed(self, cam_idx_list=None):
+        """-> the same tuple as ``step`` (static tensors, overwritten by the next replay)."""
+        import random
+        if cam_idx_list is None:
+            cam_idx_list = [random.randint(0, 5) for _ in range(self.batch)]
+        self.module.stage_cameras(self.module._geo, cam_idx_list, self.device, out=self._cams)
+        self._graph.replay()
+        return self._static_out
+
     @property
     def bev_voxels_per_step(self):
         X, Y, Z = self.cfg.bev_xyz

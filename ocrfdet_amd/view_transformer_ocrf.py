@@ -35,6 +35,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import bevpool, gaussian_renderer, hoa, index_prep, neck_ops
+from .diff_gaussian_rasterization import pack_cameras, rasterize_views
 
 __all__ = ['OcRFViewTransformerFull', 'MS_CAM', 'ChannelAttention', 'SpatialAttention', 'ResCBAMBlock', 'ProbNet',
            'DualFeatFusion', 'BEVGeomAttention', 'ScaleFactorMLP', 'RotationFactorMLP', 'OpacityFactorMLP',
@@ -321,7 +322,7 @@ class _Geometry:
     """Everything ``view_transform_core`` derives from the calibration alone: both rank-vector sets,
     voxel centres, pillar projections and their validity (view_transformer.py:108-147,197-255;
     view_transformer_ocrf.py:651-740,785-852)."""
-    __slots__ = ('lss', 'ht', 'voxel', 'pix', 'mask', 'calib')
+    __slots__ = ('lss', 'ht', 'voxel', 'pix', 'mask', 'calib', 'c2w', 'cam_rows')
 
 
 class OcRFViewTransformerFull(nn.Module):
@@ -374,7 +375,7 @@ class OcRFViewTransformerFull(nn.Module):
         self.defor_cross_attention = hoa.DeformableAttention2D(
             dim=13, dim_head=8, heads=1, dropout=0.1, downsample_factor=4, offset_scale=4, offset_groups=None,
             offset_kernel_size=6)
-        self._geo, self._tmpl = None, None
+        self._geo, self._tmpl, self._bg = None, None, None
         self._rank_bufs = (index_prep._RankBuffers(), index_prep._RankBuffers())
         self._packs = {}
 
@@ -412,7 +413,7 @@ class OcRFViewTransformerFull(nn.Module):
         # (a handful of (B,N,3,3) tensors; the reference moves them to the host itself, :1086-1088)
         calib = [t.detach().float().cpu() for t in input[1:7]]
         geo = _Geometry()
-        geo.calib = calib
+        geo.calib, geo.c2w, geo.cam_rows = calib, input[11].detach().float().cpu(), {}
         gx, gy, gz = (int(v) for v in self.grid_size.tolist())
         lss_block = index_prep.lss_camera_block(*calib).to(dev)
         lidar2img, img_aug, _, _ = index_prep.get_projection(*calib)
@@ -429,16 +430,34 @@ class OcRFViewTransformerFull(nn.Module):
                                                                  self.input_size, self.grid_config['depth'])
         return geo
 
-    def _camera(self, geo, input, bs, cam_idx):
-        """Camera of the render call (:1135-1152), quirks included: unscaled intrinsics with the
-        network-input viewport, ``c2w`` fed where a world->view transform is expected."""
-        K = geo.calib[2][bs, cam_idx]
-        c2w = input[11][bs, cam_idx].detach().float().cpu()
-        cam = gaussian_renderer.camera_from_calibration(K.numpy(), c2w.numpy(), self.input_size[0], self.input_size[1],
-                                                        znear=self.znear, zfar=self.zfar)
-        for k in ('world_view_transform', 'full_proj_transform', 'camera_center'):    # the FoV scalars stay on the host
-            cam[k] = cam[k].to(input[0].device)
-        return cam
+    def _camera(self, geo, bs, cam_idx):
+        """``data`` dict of the render call (:1135-1152), quirks included: unscaled intrinsics with the
+        network-input viewport, ``c2w`` fed where a world->view transform is expected.  Host tensors."""
+        return gaussian_renderer.camera_from_calibration(geo.calib[2][bs, cam_idx].numpy(), geo.c2w[bs, cam_idx].numpy(),
+                                                         self.input_size[0], self.input_size[1], znear=self.znear,
+                                                         zfar=self.zfar)
+
+    def stage_cameras(self, geo, cam_idx_list, device, out=None):
+        """Everything the device needs to know about the random camera choice (:1081): ``cam_sel``
+        (B) int32 and the rasteriser's packed camera rows (B,36).  The rows are cached per (sample,
+        camera) for the lifetime of ``geo``; with ``out`` (a dict from an earlier call) the values are
+        copied into its tensors in place — the static inputs of a captured graph."""
+        rows = []
+        for bs, c in enumerate(cam_idx_list):
+            if (bs, c) not in geo.cam_rows:
+                cam = self._camera(geo, bs, c)
+                geo.cam_rows[(bs, c)] = pack_cameras(cam['world_view_transform'][None], cam['full_proj_transform'][None],
+                                                     math.tan(float(cam['FovX']) * 0.5), math.tan(float(cam['FovY']) * 0.5),
+                                                     self.input_size[0], self.input_size[1], 'cpu')
+            rows.append(geo.cam_rows[(bs, c)])
+        packed = torch.cat(rows, 0)
+        sel = torch.tensor(list(cam_idx_list), dtype=torch.int32)
+        if out is None:
+            return dict(cam_sel=sel.to(device), packed=packed.to(device), cam_idx_list=list(cam_idx_list))
+        out['cam_sel'].copy_(sel, non_blocking=True)
+        out['packed'].copy_(packed, non_blocking=True)
+        out['cam_idx_list'] = list(cam_idx_list)
+        return out
 
     # -------------------------------------------------------------------------------- packs
     def _pack(self, name, params, build):
@@ -477,15 +496,17 @@ class OcRFViewTransformerFull(nn.Module):
         return self._pool(geo.ht, depth, feat_cl, (depth.shape[0], 1, self.bev_h, self.bev_w, feat_cl.shape[-1]))
 
     # -------------------------------------------------------------------------------- core
-    def view_transform(self, input, depth, tran_feat, feat_channels_last=None):
+    def view_transform(self, input, depth, tran_feat, feat_channels_last=None, cameras=None):
         if self.accelerate:
             self.pre_compute(input)
-        return self.view_transform_core(input, depth, tran_feat, feat_channels_last)
+        return self.view_transform_core(input, depth, tran_feat, feat_channels_last, cameras=cameras)
 
-    def view_transform_core(self, input, depth, tran_feat, feat_channels_last=None, cam_idx_list=None):
+    def view_transform_core(self, input, depth, tran_feat, feat_channels_last=None, cam_idx_list=None, cameras=None):
         """Same inputs / outputs as the reference (:1040-1201).  ``feat_channels_last`` (B*N,H,W,C),
         when the caller already has it (``forward`` does), skips the permute of :875/:901;
-        ``cam_idx_list`` overrides the random camera choice of :1081 (tests)."""
+        ``cam_idx_list`` overrides the random camera choice of :1081 (tests); ``cameras`` is a dict from
+        ``stage_cameras`` (choice already made and staged on the device: nothing in the call then touches
+        the host, so the whole call can be captured in a hipGraph)."""
         x = input[0]
         B, N, _, Hf, Wf = x.shape
         imgs_wo_norm, dtype = input[9], x.dtype
@@ -500,9 +521,11 @@ class OcRFViewTransformerFull(nn.Module):
         lss_feat = self.get_lss_bev_feat(geo, depth5, feat_cl)
         ht_feat = self.get_ht_bev_feat(geo, depth5, feat_cl)
 
-        if cam_idx_list is None:
-            cam_idx_list = [random.randint(0, 5) for _ in range(B)]
-        cam_sel = torch.tensor(cam_idx_list, dtype=torch.int32, device=x.device)
+        if cameras is None:
+            if cam_idx_list is None:
+                cam_idx_list = [random.randint(0, 5) for _ in range(B)]
+            cameras = self.stage_cameras(geo, cam_idx_list, x.device)
+        cam_idx_list, cam_sel = cameras['cam_idx_list'], cameras['cam_sel']
         voxel_coor = geo.voxel.reshape(B, Zh * Y * X, 3)
         if fused:
             avg_rgb = neck_ops.pillar_sample_mean(imgs_wo_norm, geo.pix, geo.mask)                 # (B,Zh,YX,3)
@@ -521,9 +544,17 @@ class OcRFViewTransformerFull(nn.Module):
 
         render_G, render_depth_G = [], []
         for bs in range(B):
-            cam = self._camera(geo, input, bs, cam_idx_list[bs])
-            img, dep = gaussian_renderer.render(cam, cam_idx_list[bs], voxel_coor[bs], color[bs], rotation[bs],
-                                                scaling[bs], opacity[bs], bg_color=[0, 0, 0])
+            if fused:          # the staged camera row straight into the C ABI: no per-call camera packing
+                if self._bg is None or self._bg.device != x.device:
+                    self._bg = torch.zeros(3, device=x.device)
+                o = rasterize_views(voxel_coor[bs], color[bs], opacity[bs], scaling[bs], rotation[bs], None, None, None,
+                                    None, H, W, self._bg, packed_cameras=cameras['packed'][bs:bs + 1])
+                img, dep = o['color'][0], o['depth'][0]
+            else:
+                cam = self._camera(geo, bs, cam_idx_list[bs])
+                cam = {k: (v.to(x.device) if torch.is_tensor(v) and v.dim() else v) for k, v in cam.items()}
+                img, dep = gaussian_renderer.render(cam, cam_idx_list[bs], voxel_coor[bs], color[bs], rotation[bs],
+                                                    scaling[bs], opacity[bs], bg_color=[0, 0, 0])
             render_G.append(img.unsqueeze(0)), render_depth_G.append(dep.unsqueeze(0))
         render_image_G_all, render_depth_G_all = torch.cat(render_G), torch.cat(render_depth_G)
         render_image = self.LinearWeightedImage(render_image_G_all, render_N)

@@ -40,6 +40,18 @@ def main():
     X, Y, Z = cfg.bev_xyz
     print(f'{cfg.name}: B={B} accelerate={a.accelerate}: {ms:.3f} ms per neck forward '
           f'({B * Z * Y * X / ms * 1e3:.3e} BEV voxels/s, {B / ms * 1e3:.1f} rendered views/s)')
+    if a.accelerate:
+        neck.capture()
+        for _ in range(5):
+            neck.step_graphed()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.iters):
+            neck.step_graphed()
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / a.iters
+        print(f'{cfg.name}: B={B} as ONE hipGraph: {ms:.3f} ms per neck forward '
+              f'({B * Z * Y * X / ms * 1e3:.3e} BEV voxels/s, {B / ms * 1e3:.1f} rendered views/s)')
     if a.stages:
         import torch.autograd.profiler as prof
         with torch.no_grad(), prof.profile(use_device='cuda') as p:
