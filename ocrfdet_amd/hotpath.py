@@ -293,9 +293,15 @@ class NeckPath:
         """Capture ``step`` into a hipGraph.  The only per-step host decision — the random camera of each
         sample (view_transformer_ocrf.py:1081) — lives in two small static device tensors that
         ``step_graphed`` refreshes before every replay."""
+        import os
         m = self.module
         if not m.accelerate:
             raise RuntimeError('graph capture needs accelerate=True (geometry cached across steps)')
+        if os.environ.get('OCRF_EXPERIMENTAL_GRAPH') != '1':
+            # OPEN ISSUE (DESIGN.md section 7): every stage captures and replays alone at cfg2, and the
+            # whole step does at the 48x48 test size, but the whole step at cfg2 ended in a GPU memory
+            # fault on replay.  Until the cause is found the capture is opt-in and not used by bench.py.
+            raise RuntimeError('NeckPath.capture is experimental: set OCRF_EXPERIMENTAL_GRAPH=1 to use it')
         self.step()                                               # geometry, packs, workspaces, MIOpen algorithms
         self._cams = m.stage_cameras(m._geo, [0] * self.batch, self.device)
 
@@ -322,7 +328,8 @@ class NeckPath:
             cam_idx_list = [random.randint(0, 5) for _ in range(self.batch)]
         self.module.stage_cameras(self.module._geo, cam_idx_list, self.device, out=self._cams)
         self._graph.replay()
-        return self._static_out
+        o = self._static_out
+        return (o[0], o[1], o[2], list(o[3][:5]) + [list(cam_idx_list)] + list(o[3][6:]))
 
     @property
     def bev_voxels_per_step(self):

@@ -454,8 +454,24 @@ class OcRFViewTransformerFull(nn.Module):
         sel = torch.tensor(list(cam_idx_list), dtype=torch.int32)
         if out is None:
             return dict(cam_sel=sel.to(device), packed=packed.to(device), cam_idx_list=list(cam_idx_list))
-        out['cam_sel'].copy_(sel, non_blocking=True)
-        out['packed'].copy_(packed, non_blocking=True)
+        # static device tensors of a captured graph: refresh through PINNED host slots (an asynchronous
+        # copy out of a pageable temporary may still be reading it after the temporary is gone), each
+        # slot guarded by an event so that it is not rewritten while its copy is in flight
+        ring = out.setdefault('_ring', [])
+        if not ring:
+            for _ in range(4):
+                ring.append([torch.empty_like(sel).pin_memory(), torch.empty_like(packed).pin_memory(), None])
+            out['_slot'] = 0
+        slot = ring[out['_slot']]
+        out['_slot'] = (out['_slot'] + 1) % len(ring)
+        if slot[2] is not None:
+            slot[2].synchronize()
+        slot[0].copy_(sel)
+        slot[1].copy_(packed)
+        out['cam_sel'].copy_(slot[0], non_blocking=True)
+        out['packed'].copy_(slot[1], non_blocking=True)
+        slot[2] = torch.cuda.Event()
+        slot[2].record(torch.cuda.current_stream(device))
         out['cam_idx_list'] = list(cam_idx_list)
         return out
 
