@@ -46,6 +46,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--shard', choices=('samples', 'frames', 'cameras'), default='samples')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL); gloo only for plumbing tests')
+    ap.add_argument('--no-overlap', action='store_true',
+                    help='run the per-frame renders on the main stream instead of beside the pools + HOA on their own HIP streams')
     ap.add_argument('--scope', choices=('hotpath', 'neck'), default='hotpath',
                     help="'hotpath': pools (+ one rendered view per camera + HOA) — the headline step; 'neck': the whole "
                          "OcRFViewTransformerFull.view_transform (one rendered view per sample, like the reference)")
@@ -197,9 +199,9 @@ def main():
         n_active = min(world, cfg.n_cams)
         active = rank < n_active
         my_cams = list(range(rank, cfg.n_cams, n_active)) if active else [0]
-        hp = hotpath.HotPath(cfg, dev, cams=my_cams, index_prep_mode=args.index_prep)
+        hp = hotpath.HotPath(cfg, dev, cams=my_cams, index_prep_mode=args.index_prep, overlap=not args.no_overlap)
     else:
-        hp = hotpath.HotPath(cfg, dev, index_prep_mode=args.index_prep)
+        hp = hotpath.HotPath(cfg, dev, index_prep_mode=args.index_prep, overlap=not args.no_overlap)
     depth, feat = hp.make_inputs(seed=0 if shard == 'cameras' else rank)
     X, Y, Z = cfg.bev_xyz
 
@@ -285,6 +287,8 @@ def main():
                        'bev': list(cfg.bev_xyz), 'channels': cfg.channels, 'depth_bins': cfg.D,
                        'stages': 'lss_pool+ht_pool' + ('+render' if cfg.render else '') + ('+hoa' if cfg.hoa else ''),
                        'views_per_step': hp.views_per_step, 'render_camera': getattr(hp, 'render_convention', None),
+                       'streams': ('main: pools + HOA; one HIP stream per frame: render' if hp.overlap and cfg.render
+                                   else 'single stream'),
                        'index_prep': 'cached (accelerate=True semantics)' if args.index_prep == 'cached' else
                                      'per step, HIP (accelerate=False semantics)',
                        'sharding': {'none': 'none',

@@ -122,6 +122,44 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
     const float p_w = 1.0f / (hw + 0.0000001f);
     const float projx = hx * p_w, projy = hy * p_w;
 
+    // computeCov2D's Jacobian rows first (forward.cu:83-98): they are needed anyway and give a
+    // conservative screen-space radius, so a Gaussian whose rect is certainly empty leaves before
+    // the covariance / conic / double-precision part (~2/3 of the work).  Exactness: the reference
+    // gives such a Gaussian radii = 0, tiles_touched = 0 and no key (forward.cu:236-238), which is
+    // what the early exit leaves; the bound only ever over-estimates the radius:
+    //   lambda_max(A Sigma A^T + 0.3 I) <= 0.3 + |A|_F^2 |Sigma|_2,  Sigma = R diag(s^2) R^T,
+    //   R = (1 - |q|^2) I + |q|^2 Rot(q/|q|)  =>  |R|_2 <= |1 - |q|^2| + |q|^2.
+    const float limx = 1.3f * cam.tanfovx, limy = 1.3f * cam.tanfovy;
+    const float txtz = vx / vz, tytz = vy / vz;
+    const float tx = fminf(limx, fmaxf(-limx, txtz)) * vz;
+    const float ty = fminf(limy, fmaxf(-limy, tytz)) * vz;
+    const float j00 = cam.focal_x / vz, j02 = -(cam.focal_x * tx) / (vz * vz);
+    const float j11 = cam.focal_y / vz, j12 = -(cam.focal_y * ty) / (vz * vz);
+    float A[2][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float r0 = vm[4 * c + 0], r1 = vm[4 * c + 1], r2 = vm[4 * c + 2];
+      A[0][c] = j00 * r0 + j02 * r2;
+      A[1][c] = j11 * r1 + j12 * r2;
+    }
+    bool surely_empty = false;
+    if (!cov3D_precomp) {
+      const float s0 = scale_modifier * scales[3 * idx], s1 = scale_modifier * scales[3 * idx + 1],
+                  s2 = scale_modifier * scales[3 * idx + 2];
+      const float smax = fmaxf(fabsf(s0), fmaxf(fabsf(s1), fabsf(s2)));
+      const float qr = rotations[4 * idx], qx = rotations[4 * idx + 1], qy = rotations[4 * idx + 2],
+                  qz = rotations[4 * idx + 3];
+      const float qq = qr * qr + qx * qx + qy * qy + qz * qz;
+      const float rn = (fabsf(1.f - qq) + qq) * smax;
+      const float af = A[0][0] * A[0][0] + A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][0] * A[1][0] +
+                       A[1][1] * A[1][1] + A[1][2] * A[1][2];
+      const float rb = 3.f * sqrtf(0.3f + af * rn * rn) * 1.001f + 3.f;      // >= the reference's radius + 2 px
+      const float fxp = ((projx + 1.f) * (float)W - 1.f) * 0.5f, fyp = ((projy + 1.f) * (float)H - 1.f) * 0.5f;
+      // rect empty <=> x1 <= x0 or y1 <= y0 (auxiliary.h:46-56); NaNs compare false and take the full path
+      surely_empty = (fxp + rb < 0.f) || (fxp - rb > (float)(kTileX * gx) + 1.f) || (fyp + rb < 0.f) ||
+                     (fyp - rb > (float)(kTileY * gy) + 1.f);
+    }
+    if (!surely_empty) {
     float c3[6];
     if (cov3D_precomp) {
 #pragma unroll
@@ -152,20 +190,7 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
       c3[3] = S[1][1]; c3[4] = S[1][2]; c3[5] = S[2][2];
     }
 
-    const float limx = 1.3f * cam.tanfovx, limy = 1.3f * cam.tanfovy;
-    // computeCov2D (forward.cu:74-113)
-    const float txtz = vx / vz, tytz = vy / vz;
-    const float tx = fminf(limx, fmaxf(-limx, txtz)) * vz;
-    const float ty = fminf(limy, fmaxf(-limy, tytz)) * vz;
-    const float j00 = cam.focal_x / vz, j02 = -(cam.focal_x * tx) / (vz * vz);
-    const float j11 = cam.focal_y / vz, j12 = -(cam.focal_y * ty) / (vz * vz);
-    float A[2][3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float r0 = vm[4 * c + 0], r1 = vm[4 * c + 1], r2 = vm[4 * c + 2];
-      A[0][c] = j00 * r0 + j02 * r2;
-      A[1][c] = j11 * r1 + j12 * r2;
-    }
+    // computeCov2D (forward.cu:74-113), A from above
     const float V[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
     float Bm[2][3];
 #pragma unroll
@@ -204,6 +229,7 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
         conic_o[o] = make_float4(con_x, con_y, con_z, opacities[idx]);
       }
     }
+    }   // !surely_empty
   }
   if (key != 0xFFFFFFFFu) atomicAdd(&s_hist[bucket_of(key)], 1);
   key_of[it] = key;
@@ -254,10 +280,12 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void raster_bucket_scan_kernel(const int* __restrict__ hist,
                                                                     int* __restrict__ starts,
-                                                                    int* __restrict__ cursor) {
+                                                                    int* __restrict__ cursor,
+                                                                    int* __restrict__ status) {
   __shared__ int s_sum[kBlock];
   constexpr int per = kBuckets / kBlock;
   const int v = blockIdx.x, tid = threadIdx.x;
+  if (status && v == 0 && tid == 0) *status = 0;      // the blend ORs its bits in afterwards: no memset launch
   const int* h = hist + (long)v * kBuckets + tid * per;
   int local[per];
   int sum = 0;
@@ -1117,7 +1145,7 @@ int ocrf_rasterize_forward(int P, int n_views, int H, int W, const float* means3
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   ocrf::launch(OCRF_K_RASTER_SCAN, raster_bucket_scan_kernel, dim3(n_views), dim3(kBlock), 0, stream,
-               static_cast<const int*>(hist), starts, cursor);
+               static_cast<const int*>(hist), starts, cursor, st);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   ocrf::launch(OCRF_K_RASTER_GATHER, raster_scatter_kernel, pgrid, dim3(kBlock), 0, stream, P,
@@ -1202,7 +1230,7 @@ int ocrf_rasterize_backward(int P, int n_views, int H, int W, const float* means
                      means3D, opacities, scales, scale_modifier, rotations, (const float*)nullptr, cams, vis_rec,
                      vis_count, rects, xy, conic_o, radii, (unsigned*)nullptr, hist);
   hipLaunchKernelGGL(raster_bucket_scan_kernel, dim3(n_views), dim3(kBlock), 0, stream, static_cast<const int*>(hist),
-                     starts, cursor);
+                     starts, cursor, st);
   hipLaunchKernelGGL(raster_scatter_kernel, pgrid, dim3(kBlock), 0, stream, P, static_cast<const uint4*>(vis_rec),
                      static_cast<const int*>(vis_count), cursor, b_rect, b_comp);
   e = hipGetLastError();

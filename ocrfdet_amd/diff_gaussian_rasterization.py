@@ -118,13 +118,15 @@ def rasterize_views_backward(grad_color, fwd, means3D, colors, opacities, scales
 
 def rasterize_views(means3D, colors, opacities, scales, rotations, viewmatrices, projmatrices,
                     tanfovx, tanfovy, image_height, image_width, bg, scale_modifier=1.0,
-                    cov3D_precomp=None, depth_mode='median', want_tiles_touched=False, packed_cameras=None):
+                    cov3D_precomp=None, depth_mode='median', want_tiles_touched=False, packed_cameras=None,
+                    workspace_tag='raster'):
     """Render ``V`` cameras over the same ``P`` Gaussians.
 
     ``viewmatrices`` / ``projmatrices``: (V,4,4) transposed matrices as the reference passes them;
     ``tanfovx`` / ``tanfovy``: length-V sequences (or scalars).  Returns a dict of fresh tensors:
     ``color`` (V,3,H,W), ``depth`` (V,1,H,W), ``final_T`` (V,H,W), ``n_contrib`` (V,H,W) int32,
-    ``radii`` (V,P) int32 [, ``tiles_touched`` (V,P) int32]."""
+    ``radii`` (V,P) int32 [, ``tiles_touched`` (V,P) int32].  Calls that may run concurrently on
+    different streams must use different ``workspace_tag``s (the scratch buffer is per tag)."""
     _lib.require_cuda(means3D, colors, opacities, bg)
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError('means3D must have dimensions (num_points, 3)')     # rasterize_points.cu:57-59
@@ -146,11 +148,11 @@ def rasterize_views(means3D, colors, opacities, scales, rotations, viewmatrices,
                n_contrib=torch.empty(V, H, W, dtype=torch.int32, device=dev),
                radii=torch.empty(V, max(P, 0), dtype=torch.int32, device=dev))
     tt = torch.empty(V, P, dtype=torch.int32, device=dev) if want_tiles_touched else None
-    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    status = torch.empty(1, dtype=torch.int32, device=dev)      # zeroed on the device by the bucket scan kernel
     L = _lib.lib()
     with torch.cuda.device(dev):
         need = L.ocrf_rasterize_workspace_bytes(P, V)
-        ws = _lib.workspace.get(dev, need, 'raster')
+        ws = _lib.workspace.get(dev, need, workspace_tag)
         _lib.check(L.ocrf_rasterize_forward(
             P, V, H, W, _lib.ptr(means3D), _lib.ptr(colors), _lib.ptr(opac), _lib.ptr(sc),
             ctypes.c_float(scale_modifier), _lib.ptr(rot), _lib.ptr(cov), _lib.ptr(cams), _lib.ptr(bg),

@@ -143,48 +143,84 @@ class OpacityVoxelToBEVConverter(nn.Module):
             cache[id(block)] = hit = (key, vals)
         return hit[1]
 
+    def _plan(self, B, H, W, dev):
+        """Everything of the fused forward that does not depend on the input values, built once per
+        (shape, device, weight version): folded / packed weights, the intermediate buffers and the
+        ctypes argument lists of the 11 launches.  The per-call host work is then one version check,
+        one allocation (the result) and the launches themselves (the block-by-block Python of the
+        first version cost ~0.3 ms per call, more than the kernels)."""
+        tensors = self.__dict__.get('_plan_tensors')
+        if tensors is None:
+            tensors = self.__dict__['_plan_tensors'] = list(self.parameters()) + list(self.buffers())
+        key = (B, H, W, dev, tuple(t._version for t in tensors), tuple(t.data_ptr() for t in tensors))
+        plan = self.__dict__.get('_plan_cache')
+        if plan is not None and plan['key'] == key:
+            return plan
+        L = _lib.lib()
+        keep, calls = [], []                      # keep: tensors the pointers below refer to
+
+        def dev_f32(t):
+            t = t.detach().contiguous().float()
+            keep.append(t)
+            return t
+
+        def block(src0, gate0, mode, up, src1, gate1, conv, ca, cout, h, w, addend_slot=False):
+            dw_w, dw_b, pw_w, pw_b = (dev_f32(t) for t in self._folded(conv))
+            up_w = dev_f32(up.weight) if up is not None else None
+            up_b = dev_f32(up.bias) if up is not None else None
+            cup = up.out_channels if up is not None else 0
+            out = torch.empty(B, cout, h, w, device=dev)
+            n_tiles = L.ocrf_hoa_unet_tiles(h, w)
+            pmax = torch.empty(B * cout, n_tiles, device=dev)
+            gate = torch.empty(B, cout, device=dev)
+            w1, w2 = (dev_f32(t) for t in ca._packed())
+            keep.extend((out, pmax, gate))
+            c0 = src0.shape[1] if src0 is not None else self.encoder1[0].in_channels
+            h0, w0 = (src0.shape[2], src0.shape[3]) if src0 is not None else (H, W)
+            args = [_lib.ptr(src0), _lib.ptr(gate0), c0, h0, w0, mode, _lib.ptr(up_w), _lib.ptr(up_b), cup,
+                    _lib.ptr(src1), _lib.ptr(gate1), src1.shape[1] if src1 is not None else 0, _lib.ptr(dw_w),
+                    _lib.ptr(dw_b), _lib.ptr(pw_w), _lib.ptr(pw_b), cout, _lib.ptr(None), _lib.ptr(out), _lib.ptr(pmax),
+                    B, h, w]
+            calls.append(('block', args, addend_slot))
+            calls.append(('gate', [B, cout, ca.hid, n_tiles, _lib.ptr(pmax), _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(gate)]))
+            return out, gate
+        with torch.no_grad():
+            e1, g1 = block(None, None, 0, None, None, None, self.encoder1, self.ca1, 4, H, W, addend_slot=True)
+            e2, g2 = block(e1, g1, 1, None, None, None, self.encoder2, self.ca2, 8, H // 2, W // 2)
+            bt, gb = block(e2, g2, 1, None, None, None, self.bottleneck, self.ca_bottleneck, 16, H // 4, W // 4)
+            d2, gd2 = block(bt, gb, 2, self.upconv2, e2, g2, self.decoder2, self.ca_dec2, 8, H // 2, W // 2)
+            d1, gd1 = block(d2, gd2, 2, self.upconv1, e1, g1, self.decoder1, self.ca_dec1, 4, H, W)
+            ow, ob = dev_f32(self.output_conv.weight.reshape(-1)), dev_f32(self.output_conv.bias)
+        plan = dict(key=key, keep=keep, calls=calls,
+                    out_args=[_lib.ptr(d1), _lib.ptr(gd1), B, 4, H, W, _lib.ptr(ow), _lib.ptr(ob)])
+        self.__dict__['_plan_cache'] = plan
+        return plan
+
     def _forward_fused(self, x, position):
         """Eval-mode forward as 5 fused block kernels + 5 gate kernels + the output conv
         (csrc/hoa.hip, ocrf_hoa_unet_block): no intermediate pooled / upsampled / concatenated /
-        gated tensor is ever written."""
+        gated tensor is ever written.  The intermediates live in per-module buffers (``_plan``): one
+        forward at a time per module instance (calls on one stream are ordered; do not run the same
+        instance on two streams at once)."""
         _lib.require_cuda(x, position)
         x, position = _f32c(x), _f32c(position)
         B, _, H, W = x.shape
         dev = x.device
         L = _lib.lib()
-        st = _lib.stream_ptr(dev)
-
-        def block(src0, gate0, mode, up, src1, gate1, conv, ca, cout, h, w, addend=None):
-            dw_w, dw_b, pw_w, pw_b = self._folded(conv)
-            up_w = up.weight.detach().contiguous().float() if up is not None else None
-            up_b = up.bias.detach().contiguous().float() if up is not None else None
-            cup = up.out_channels if up is not None else 0
-            out = torch.empty(B, cout, h, w, device=dev)
-            n_tiles = L.ocrf_hoa_unet_tiles(h, w)
-            pmax = torch.empty(B * cout, n_tiles, device=dev)
-            _lib.check(L.ocrf_hoa_unet_block(
-                _lib.ptr(src0), _lib.ptr(gate0), src0.shape[1], src0.shape[2], src0.shape[3], mode, _lib.ptr(up_w),
-                _lib.ptr(up_b), cup, _lib.ptr(src1), _lib.ptr(gate1), src1.shape[1] if src1 is not None else 0,
-                _lib.ptr(dw_w), _lib.ptr(dw_b), _lib.ptr(pw_w), _lib.ptr(pw_b), cout, _lib.ptr(addend), _lib.ptr(out),
-                _lib.ptr(pmax), B, h, w, st), 'ocrf_hoa_unet_block')
-            w1, w2 = ca._packed()
-            gate = torch.empty(B, cout, device=dev)
-            _lib.check(L.ocrf_hoa_height_gate_from_tiles(B, cout, ca.hid, n_tiles, _lib.ptr(pmax), _lib.ptr(w1),
-                                                         _lib.ptr(w2), _lib.ptr(gate), st),
-                       'ocrf_hoa_height_gate_from_tiles')
-            return out, gate
-
+        plan = self._plan(B, H, W, dev)
+        out = torch.empty(B, 1, H, W, device=dev)
         with torch.cuda.device(dev):
-            e1, g1 = block(x, None, 0, None, None, None, self.encoder1, self.ca1, 4, H, W, position)
-            e2, g2 = block(e1, g1, 1, None, None, None, self.encoder2, self.ca2, 8, H // 2, W // 2)
-            bt, gb = block(e2, g2, 1, None, None, None, self.bottleneck, self.ca_bottleneck, 16, H // 4, W // 4)
-            d2, gd2 = block(bt, gb, 2, self.upconv2, e2, g2, self.decoder2, self.ca_dec2, 8, H // 2, W // 2)
-            d1, gd1 = block(d2, gd2, 2, self.upconv1, e1, g1, self.decoder1, self.ca_dec1, 4, H, W)
-            out = torch.empty(B, 1, H, W, device=dev)
-            ow = self.output_conv.weight.detach().reshape(-1).contiguous().float()
-            ob = self.output_conv.bias.detach().contiguous().float()
-            _lib.check(L.ocrf_hoa_gated_conv1x1(_lib.ptr(d1), _lib.ptr(gd1), B, 4, H, W, _lib.ptr(ow), _lib.ptr(ob),
-                                                _lib.ptr(out), st), 'ocrf_hoa_gated_conv1x1')
+            st = _lib.stream_ptr(dev)
+            for call in plan['calls']:
+                if call[0] == 'block':
+                    args = call[1]
+                    if call[2]:                   # the first block reads the caller's tensors
+                        args = list(args)
+                        args[0], args[17] = _lib.ptr(x), _lib.ptr(position)
+                    _lib.check(L.ocrf_hoa_unet_block(*args, st), 'ocrf_hoa_unet_block')
+                else:
+                    _lib.check(L.ocrf_hoa_height_gate_from_tiles(*call[1], st), 'ocrf_hoa_height_gate_from_tiles')
+            _lib.check(L.ocrf_hoa_gated_conv1x1(*plan['out_args'], _lib.ptr(out), st), 'ocrf_hoa_gated_conv1x1')
         return out
 
 

@@ -41,7 +41,7 @@ class PoolPlan:
 
 
 class HotPath:
-    def __init__(self, cfg, device, cams=None, index_prep_mode='cached'):
+    def __init__(self, cfg, device, cams=None, index_prep_mode='cached', overlap=True):
         """``cams``: optional list of camera indices this instance owns (camera sharding).
         ``index_prep_mode``: 'cached' — rank vectors computed once per calibration, the reference's
         ``accelerate=True`` intent; 'per_step' — recomputed inside every ``step()`` by the HIP index
@@ -51,6 +51,11 @@ class HotPath:
         self.batch = cfg.batch * cfg.n_frames                  # frames ride along as batch entries
         assert index_prep_mode in ('cached', 'per_step')
         self.index_prep_mode = index_prep_mode
+        # the renders of the frames are independent of the poolings and of each other: with ``overlap``
+        # every frame renders on its own HIP stream beside the pools + HOA of the main stream (the
+        # blend is VALU-bound with a ragged tail, the pools are latency / L2-bound: they interleave)
+        self.overlap = bool(overlap) and self.device.type == 'cuda'
+        self._side = []
         self._prepare()
 
     def _prepare(self):
@@ -163,16 +168,23 @@ class HotPath:
         self.bg = torch.zeros(3, device=dev)
         self.render_convention = convention
 
-    def render(self):
-        """All owned cameras of every frame: list (one per frame) of dicts from rasterize_views."""
+    def render(self, streams=None):
+        """All owned cameras of every frame: list (one per frame) of dicts from rasterize_views.
+        ``streams``: one HIP stream per frame (each with its own scratch buffer); the caller joins them."""
         cfg, rc, g = self.cfg, self.render_cams, self.gauss
         H, W = cfg.input_size
         outs = []
         for b in range(self.batch):
             xyz = self.voxel_xyz[b].reshape(-1, 3)
-            outs.append(rasterize_views(xyz, g['rgb'], g['opacity'], g['scales'], g['rotations'], rc['vm'],
-                                        rc['pm'], rc['tfx'], rc['tfy'], H, W, self.bg,
-                                        packed_cameras=rc['packed']))
+            if streams is None:
+                outs.append(rasterize_views(xyz, g['rgb'], g['opacity'], g['scales'], g['rotations'], rc['vm'],
+                                            rc['pm'], rc['tfx'], rc['tfy'], H, W, self.bg,
+                                            packed_cameras=rc['packed']))
+            else:
+                with torch.cuda.stream(streams[b]):
+                    outs.append(rasterize_views(xyz, g['rgb'], g['opacity'], g['scales'], g['rotations'], rc['vm'],
+                                                rc['pm'], rc['tfx'], rc['tfy'], H, W, self.bg,
+                                                packed_cameras=rc['packed'], workspace_tag=f'raster{b}'))
         return outs
 
     @property
@@ -236,14 +248,27 @@ class HotPath:
 
     def step(self, depth, feat):
         """One pass of the hot path: pools (+ render + HOA where the configuration has them)."""
+        fork = self.overlap and self.cfg.render
+        if fork:
+            cur = torch.cuda.current_stream(self.device)
+            while len(self._side) < self.batch:
+                self._side.append(torch.cuda.Stream(self.device))
+            for s in self._side[:self.batch]:
+                s.wait_stream(cur)                    # inputs (and last step's consumers) are ordered before
+            rendered = self.render(self._side)
         lss, ht = self.pool_step(depth, feat)
         out = [lss, ht]
-        if self.cfg.render:
+        if fork:
+            out.append(rendered)
+        elif self.cfg.render:
             out.append(self.render())
         if self.cfg.hoa:
             # stand-in for geom_feat: the HT BEV has its shape (B,C,Y,X); the fusion convs between
             # the pools and HOA-3 (SURVEY 8a row a27) are MIOpen territory, not part of this path
             out.extend(self.hoa_step(ht))
+        if fork:
+            for s in self._side[:self.batch]:
+                cur.wait_stream(s)                    # join: everything the step returns is ordered on `cur`
         return tuple(out)
 
     @property
