@@ -246,6 +246,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the same kernel alone on the device (renders on the main stream): with the stages overlapped on
+    # several HIP streams the in-region duration above includes the time the kernel shares the CUs
+    iso_ms = None
+    if hp.overlap and cfg.render and shard != 'cameras':
+        hp.overlap = False
+        iso = _lib.KernelTimer(dom_id, 64)
+        torch.cuda.synchronize()
+        iso.arm()
+        for _ in range(min(16, args.steps)):
+            step()
+        torch.cuda.synchronize()
+        iso.disarm()
+        v = iso.read_ms()
+        iso_ms = sum(v) / max(len(v), 1)
+        iso.close()
+        hp.overlap = True
     if rank == 0:
         ms = timer.read_ms()
         avg_ms = sum(ms) / max(len(ms), 1)
@@ -298,14 +314,19 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': timer.kernel_name, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_us': 1e3 * avg_ms,
-                         'launches_timed': len(ms)},
+                         'launches_timed': len(ms),
+                         'isolated': ({'avg_launch_us': 1e3 * iso_ms, 'achieved': alg_bytes / (iso_ms * 1e-3) / 1e9,
+                                       'frac': alg_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       'note': 'same kernel, stages not overlapped (after the timed region)'}
+                                      if iso_ms else None)},
         }
         if cfg.render and avg_ms > 0:
             lane_slots = 256 * 4 * 16 * 2.4e9          # CUs x SIMDs x lanes x clock (MI355X_MICROARCH.md)
             out['roofline']['valu'] = {
                 'pixel_records_per_launch': evals, 'pixel_records_per_sec': evals / (avg_ms * 1e-3),
                 'issue_slots_per_pixel_record': 26.5,    # ISA count of the inner loop, DESIGN 4.3
-                'frac_of_valu_issue_peak': evals * 26.5 / (avg_ms * 1e-3) / lane_slots}
+                'frac_of_valu_issue_peak': evals * 26.5 / (avg_ms * 1e-3) / lane_slots,
+                'frac_of_valu_issue_peak_isolated': (evals * 26.5 / (iso_ms * 1e-3) / lane_slots) if iso_ms else None}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(hp, depth, feat, args.cpu_seconds)
             out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']

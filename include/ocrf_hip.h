@@ -325,7 +325,7 @@ int ocrf_ht_project(int B, int N, int Z, int n_pillars, const float *ref_points,
  *   semantic      (BN,2,HW)  softmax over the 2 semantic logits
  *   feat_channels_last (BN,HW,C)  tran_feat * (semantic[:,1] >= semantic_threshold), i.e. the
  *                 (B,N,H,W,C) operand of bev_pool_v2
- * 64*(C+1)*4 bytes of LDS must fit (C <= 230); D <= 512.
+ * D <= 512.
  */
 int ocrf_prefilter(const float *x, int BN, int D, int C, int HW, float depth_threshold,
                    float semantic_threshold, float *depth, float *filter_depth, float *semantic,

@@ -22,52 +22,56 @@
 
 namespace {
 
-constexpr int kWave = 64;
-
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float softplusf(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 
 // ------------------------------------------------------------------------------------------
-// prefilter: one workgroup = 64 consecutive pixels of one image x 4 depth slices.
+// prefilter: one workgroup = PXW consecutive pixels of one image x (256 / PXW) depth slices.  The map
+// is small (12 images x 704 pixels at the reference shape), so the tile is narrow (16 pixels: 528
+// workgroups) to give every CU work; each thread loads its <= PER depth logits ONCE, all in flight.
 // ------------------------------------------------------------------------------------------
-template <int PER>   // depth logits per thread (D <= 4*PER): loaded once, all in flight together
+template <int PXW, int PER>
 __global__ __launch_bounds__(256) void neck_prefilter_kernel(
     const float* __restrict__ x, int D, int C, int HW, float depth_thr, float sem_thr,
     float* __restrict__ depth, float* __restrict__ filter_depth, float* __restrict__ semantic,
     float* __restrict__ feat_cl) {
-  __shared__ float red[4][kWave];
-  __shared__ float keep[kWave];
-  extern __shared__ float tile[];            // [64][C + 1] transposition buffer
-  const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int bn = blockIdx.y, p0 = blockIdx.x * kWave, p = p0 + lane;
+  constexpr int NSL = 256 / PXW;
+  __shared__ float red[NSL][PXW];
+  __shared__ float keep[PXW];
+  extern __shared__ float tile[];            // [PXW][C + 1] transposition buffer
+  const int lane = threadIdx.x % PXW, sl = threadIdx.x / PXW;
+  const int bn = blockIdx.y, p0 = blockIdx.x * PXW, p = p0 + lane;
   const bool live = p < HW;
   const float* xi = x + (size_t)bn * (D + 2 + C) * HW;
   float v[PER];
   float m = -INFINITY;
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    const int d = sl + 4 * i;
+    const int d = sl + NSL * i;
     v[i] = (live && d < D) ? xi[(size_t)d * HW + p] : -INFINITY;
   }
 #pragma unroll
   for (int i = 0; i < PER; ++i) m = fmaxf(m, v[i]);
   red[sl][lane] = m;
   __syncthreads();
-  m = fmaxf(fmaxf(red[0][lane], red[1][lane]), fmaxf(red[2][lane], red[3][lane]));
+#pragma unroll
+  for (int k = 0; k < NSL; ++k) m = fmaxf(m, red[k][lane]);
   __syncthreads();
   float s = 0.0f;
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    const int d = sl + 4 * i;
+    const int d = sl + NSL * i;
     v[i] = (live && d < D) ? expf(v[i] - m) : 0.0f;
     s += v[i];
   }
   red[sl][lane] = s;
   __syncthreads();
-  s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NSL; ++k) s += red[k][lane];        // same order in every slice: one value per pixel
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    const int d = sl + 4 * i;
+    const int d = sl + NSL * i;
     if (live && d < D) {
       const float pr = v[i] / s;
       const size_t o = ((size_t)bn * D + d) * HW + p;
@@ -90,10 +94,10 @@ __global__ __launch_bounds__(256) void neck_prefilter_kernel(
   __syncthreads();
   // feature: read (c, pixel) coalesced along pixels, write the (pixel, c) tile as one contiguous run
   const int stride = C + 1;
-  for (int c = sl; c < C; c += 4)
+  for (int c = sl; c < C; c += NSL)
     tile[lane * stride + c] = live ? xi[(size_t)(D + 2 + c) * HW + p] * keep[lane] : 0.0f;
   __syncthreads();
-  const int npx = min(kWave, HW - p0);
+  const int npx = min(PXW, HW - p0);
   float* dst = feat_cl + ((size_t)bn * HW + p0) * C;
   for (int i = threadIdx.x; i < npx * C; i += 256) dst[i] = tile[(i / C) * stride + (i % C)];
 }
@@ -152,15 +156,24 @@ __global__ __launch_bounds__(256) void neck_pillar_sample_mean_kernel(
 #pragma unroll
   for (int c = 0; c < C; ++c) acc[c] = 0.0f;
   int cnt = 0;
-  for (int n = 0; n < N; ++n) {
-    const size_t pi = ((size_t)b * N + n) * ZQ + q;
-    if (!mask[pi]) continue;
-    ++cnt;
-    const float2 uv = pix[pi];
-    const Tap t = make_tap(uv.x, uv.y, Hi, Wi);
-    const float* img = imgs + ((size_t)b * N + n) * C * Hi * Wi;
+  // cameras in batches of 8: every mask byte of the batch first, then the coordinates of the valid
+  // ones, then their taps — three rounds of independent loads instead of a dependent chain per camera
+  for (int n0 = 0; n0 < N; n0 += 8) {
+    unsigned char m[8];
+    float2 uv[8];
 #pragma unroll
-    for (int c = 0; c < C; ++c) acc[c] += tap_channel(img + (size_t)c * Hi * Wi, t, Wi);
+    for (int j = 0; j < 8; ++j) m[j] = (n0 + j < N) ? mask[((size_t)b * N + n0 + j) * ZQ + q] : 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) uv[j] = m[j] ? pix[((size_t)b * N + n0 + j) * ZQ + q] : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (!m[j]) continue;
+      ++cnt;
+      const Tap t = make_tap(uv[j].x, uv[j].y, Hi, Wi);
+      const float* img = imgs + ((size_t)b * N + n0 + j) * C * Hi * Wi;
+#pragma unroll
+      for (int c = 0; c < C; ++c) acc[c] += tap_channel(img + (size_t)c * Hi * Wi, t, Wi);
+    }
   }
   const float den = cnt ? (float)cnt : 1.0f;
   float* o = avg + ((size_t)b * ZQ + q) * C;
@@ -202,23 +215,30 @@ __global__ __launch_bounds__(256) void neck_retain_scatter_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Gaussian heads.  One thread = one pillar, ALL heights: a channel of the NCHW BEV is read once
-// (lanes = consecutive pillars: coalesced), its 16 first-layer weights arrive as ONE wave-uniform
-// 64-byte scalar load (W1 is stored channel-major for that), and the 16 hidden units of every height
-// are accumulated as 8 packed pairs (v_pk_fma_f32).  ZH heights x 16 accumulators live in registers.
+// Gaussian heads.  One thread = one pillar x a group of HG heights: a channel of the NCHW BEV is read
+// once per group (lanes = consecutive pillars: coalesced), its 16 first-layer weights arrive as ONE
+// wave-uniform 64-byte scalar load (W1 is stored channel-major for that), and the 16 hidden units of
+// every height of the group are accumulated as 8 packed pairs (v_pk_fma_f32).  HG x 16 accumulators
+// live in registers; two groups (7 + 6 of the 13 heights) give 2 500 waves at 200x200 instead of
+// 1 250 — with one wave per SIMD and a quarter of the SIMDs holding two, the finer grain is what
+// shortens the critical path.
 // params: lift_a[Zh] lift_b[Zh] | W1t[C][16] (columns S,R,A,Col: 4 each) | W1rgb[4][3] | b1[16] |
 //         S: W2[3][4] b2[3] | R: W2[4][4] b2[4] | A: W2[1][4] b2[1] | Col: W2[3][4] b2[3]
 // ------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int ZH>
+template <int ZH, int HG>
 __global__ __launch_bounds__(64) void neck_gauss_heads_kernel(
     const float* __restrict__ bev, const float* __restrict__ rgb_avg, const float* __restrict__ prm, int C, int YX,
     float* __restrict__ opacity, float* __restrict__ scales, float* __restrict__ rot, float* __restrict__ color) {
-  const int q = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
-  if (q >= YX) return;
-  const float* la = prm;
-  const float* lb = prm + ZH;
+  constexpr int kGroups = (ZH + HG - 1) / HG;
+  const int q = min(blockIdx.x * 64 + (int)threadIdx.x, YX - 1), b = blockIdx.y / kGroups, h0 = (blockIdx.y % kGroups) * HG;
+  float la[HG], lb[HG];      // lanes past the end redo the last pillar and store nothing
+#pragma unroll
+  for (int h = 0; h < HG; ++h) {        // the last group may be short: its spare slots repeat the last height
+    la[h] = prm[min(h0 + h, ZH - 1)];
+    lb[h] = prm[ZH + min(h0 + h, ZH - 1)];
+  }
   const f32x2* W1t = reinterpret_cast<const f32x2*>(prm + 2 * ZH);
   const float* W1rgb = prm + 2 * ZH + 16 * C;
   const float* b1 = W1rgb + 12;
@@ -226,9 +246,9 @@ __global__ __launch_bounds__(64) void neck_gauss_heads_kernel(
   const float* R2 = S2 + 15;
   const float* A2 = R2 + 20;
   const float* C2 = A2 + 5;
-  f32x2 hid[ZH][8];
+  f32x2 hid[HG][8];
 #pragma unroll
-  for (int h = 0; h < ZH; ++h)
+  for (int h = 0; h < HG; ++h)
 #pragma unroll
     for (int k = 0; k < 8; ++k) hid[h][k] = f32x2{0.0f, 0.0f};
   const float* bp = bev + (size_t)b * C * YX + q;
@@ -245,7 +265,7 @@ __global__ __launch_bounds__(64) void neck_gauss_heads_kernel(
 #pragma unroll
       for (int k = 0; k < 8; ++k) w[k] = W1t[(c0 + j) * 8 + k];
 #pragma unroll
-      for (int h = 0; h < ZH; ++h) {
+      for (int h = 0; h < HG; ++h) {
         const float f = fmaxf(fmaf(la[h], vv[j], lb[h]), 0.0f);
         const f32x2 ff = {f, f};
 #pragma unroll
@@ -253,11 +273,22 @@ __global__ __launch_bounds__(64) void neck_gauss_heads_kernel(
       }
     }
   }
+  // epilogue.  The 3-float rows of rgb / scales / colour go through an LDS transposition (one wave =
+  // 64 consecutive Gaussians = 768 contiguous bytes per array): per-lane 12-byte-stride accesses cost
+  // three partial-line transactions per cache line.
+  __shared__ float stg[2][64 * 3];
+  const int lane = threadIdx.x;
+  const int q0 = blockIdx.x * 64, nq = min(64, YX - q0);
 #pragma unroll
-  for (int h = 0; h < ZH; ++h) {
-    const size_t g = ((size_t)b * ZH + h) * YX + q;
-    const float* rp = rgb_avg + g * 3;
-    const float r01[3] = {rp[0] / 255.0f, rp[1] / 255.0f, rp[2] / 255.0f};
+  for (int h = 0; h < HG; ++h) {
+    if (h0 + h >= ZH) break;
+    const size_t g0 = ((size_t)b * ZH + h0 + h) * YX + q0, g = g0 + lane;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (lane + 64 * k < nq * 3) stg[0][lane + 64 * k] = rgb_avg[g0 * 3 + lane + 64 * k];
+    __syncthreads();
+    const float r01[3] = {stg[0][lane * 3] / 255.0f, stg[0][lane * 3 + 1] / 255.0f, stg[0][lane * 3 + 2] / 255.0f};
     float hv[16];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { hv[2 * k] = hid[h][k].x; hv[2 * k + 1] = hid[h][k].y; }
@@ -266,11 +297,24 @@ __global__ __launch_bounds__(64) void neck_gauss_heads_kernel(
       for (int j = 0; j < 3; ++j) hv[12 + k] = fmaf(W1rgb[k * 3 + j], r01[j], hv[12 + k]);
 #pragma unroll
     for (int k = 0; k < 16; ++k) hv[k] = fmaxf(hv[k] + b1[k], 0.0f);
+    __syncthreads();
     for (int o = 0; o < 3; ++o) {                    // scales: softplus
       float v = S2[12 + o];
       for (int k = 0; k < 4; ++k) v = fmaf(S2[o * 4 + k], hv[k], v);
-      scales[g * 3 + o] = softplusf(v);
+      stg[0][lane * 3 + o] = softplusf(v);
     }
+    for (int o = 0; o < 3; ++o) {                    // colour: sigmoid
+      float v = C2[12 + o];
+      for (int k = 0; k < 4; ++k) v = fmaf(C2[o * 4 + k], hv[12 + k], v);
+      stg[1][lane * 3 + o] = sigmoidf(v);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (lane + 64 * k < nq * 3) {
+        scales[g0 * 3 + lane + 64 * k] = stg[0][lane + 64 * k];
+        color[g0 * 3 + lane + 64 * k] = stg[1][lane + 64 * k];
+      }
     float r[4], nn = 0.0f;                           // rotation: L2-normalised (F.normalize eps 1e-12)
     for (int o = 0; o < 4; ++o) {
       float v = R2[16 + o];
@@ -279,16 +323,11 @@ __global__ __launch_bounds__(64) void neck_gauss_heads_kernel(
       nn = fmaf(v, v, nn);
     }
     const float den = fmaxf(sqrtf(nn), 1e-12f);
-    *reinterpret_cast<float4*>(rot + g * 4) = make_float4(r[0] / den, r[1] / den, r[2] / den, r[3] / den);
-    {
-      float v = A2[4];
-      for (int k = 0; k < 4; ++k) v = fmaf(A2[k], hv[8 + k], v);
+    float v = A2[4];
+    for (int k = 0; k < 4; ++k) v = fmaf(A2[k], hv[8 + k], v);
+    if (lane < nq) {
+      *reinterpret_cast<float4*>(rot + g * 4) = make_float4(r[0] / den, r[1] / den, r[2] / den, r[3] / den);
       opacity[g] = sigmoidf(v);
-    }
-    for (int o = 0; o < 3; ++o) {
-      float v = C2[12 + o];
-      for (int k = 0; k < 4; ++k) v = fmaf(C2[o * 4 + k], hv[12 + k], v);
-      color[g * 3 + o] = sigmoidf(v);
     }
   }
 }
@@ -383,18 +422,19 @@ int ocrf_prefilter(const float* x, int BN, int D, int C, int HW, float depth_thr
                    ocrf_stream_t stream) {
   if (BN <= 0 || D <= 0 || C <= 0 || HW <= 0) return (int)hipErrorInvalidValue;
   if (!x || !depth || !filter_depth || !semantic || !feat_channels_last) return (int)hipErrorInvalidValue;
-  const size_t lds = (size_t)kWave * (C + 1) * sizeof(float);
+  constexpr int kPx = 16;                     // pixels per workgroup
+  const size_t lds = (size_t)kPx * (C + 1) * sizeof(float);
   if (lds > 60000) return (int)hipErrorInvalidValue;
-  const dim3 grid((HW + kWave - 1) / kWave, BN), block(256);
+  const dim3 grid((HW + kPx - 1) / kPx, BN), block(256);
   if (D <= 32)
-    ocrf::launch(OCRF_K_NECK_PREFILTER, neck_prefilter_kernel<8>, grid, block, lds, (hipStream_t)stream, x, D, C, HW,
-                 depth_threshold, semantic_threshold, depth, filter_depth, semantic, feat_channels_last);
+    ocrf::launch(OCRF_K_NECK_PREFILTER, neck_prefilter_kernel<kPx, 2>, grid, block, lds, (hipStream_t)stream, x, D, C,
+                 HW, depth_threshold, semantic_threshold, depth, filter_depth, semantic, feat_channels_last);
   else if (D <= 128)
-    ocrf::launch(OCRF_K_NECK_PREFILTER, neck_prefilter_kernel<32>, grid, block, lds, (hipStream_t)stream, x, D, C, HW,
-                 depth_threshold, semantic_threshold, depth, filter_depth, semantic, feat_channels_last);
+    ocrf::launch(OCRF_K_NECK_PREFILTER, neck_prefilter_kernel<kPx, 8>, grid, block, lds, (hipStream_t)stream, x, D, C,
+                 HW, depth_threshold, semantic_threshold, depth, filter_depth, semantic, feat_channels_last);
   else if (D <= 512)
-    ocrf::launch(OCRF_K_NECK_PREFILTER, neck_prefilter_kernel<128>, grid, block, lds, (hipStream_t)stream, x, D, C, HW,
-                 depth_threshold, semantic_threshold, depth, filter_depth, semantic, feat_channels_last);
+    ocrf::launch(OCRF_K_NECK_PREFILTER, neck_prefilter_kernel<kPx, 32>, grid, block, lds, (hipStream_t)stream, x, D, C,
+                 HW, depth_threshold, semantic_threshold, depth, filter_depth, semantic, feat_channels_last);
   else
     return (int)hipErrorInvalidValue;
   return last_error();
@@ -442,19 +482,19 @@ int ocrf_gauss_heads(const float* bev, const float* rgb_avg, const float* params
     return (int)hipErrorInvalidValue;
   if (reinterpret_cast<uintptr_t>(rotations) & 15) return (int)hipErrorInvalidValue;
   if ((reinterpret_cast<uintptr_t>(params) + 2 * Zh * sizeof(float)) & 7) return (int)hipErrorInvalidValue;
-  const dim3 grid((YX + 63) / 64, B), block(64);
+  const dim3 block(64);
   switch (Zh) {       // heights are a compile-time constant of the register tile; the reference uses 13 (:578)
-#define OCRF_HEADS_CASE(Z)                                                                                        \
-  case Z:                                                                                                         \
-    ocrf::launch(OCRF_K_NECK_HEADS, neck_gauss_heads_kernel<Z>, grid, block, 0, (hipStream_t)stream, bev, rgb_avg, \
-                 params, C, YX, opacity, scales, rotations, color);                                               \
+#define OCRF_HEADS_CASE(Z, G)                                                                                    \
+  case Z:                                                                                                        \
+    ocrf::launch(OCRF_K_NECK_HEADS, neck_gauss_heads_kernel<Z, G>, dim3((YX + 63) / 64, B * ((Z + G - 1) / G)),   \
+                 block, 0, (hipStream_t)stream, bev, rgb_avg, params, C, YX, opacity, scales, rotations, color); \
     break;
-    OCRF_HEADS_CASE(13)
-    OCRF_HEADS_CASE(8)
-    OCRF_HEADS_CASE(6)
-    OCRF_HEADS_CASE(4)
-    OCRF_HEADS_CASE(2)
-    OCRF_HEADS_CASE(1)
+    OCRF_HEADS_CASE(13, 7)
+    OCRF_HEADS_CASE(8, 4)
+    OCRF_HEADS_CASE(6, 3)
+    OCRF_HEADS_CASE(4, 4)
+    OCRF_HEADS_CASE(2, 2)
+    OCRF_HEADS_CASE(1, 1)
 #undef OCRF_HEADS_CASE
     default: return (int)hipErrorInvalidValue;
   }

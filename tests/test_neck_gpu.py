@@ -262,3 +262,18 @@ def test_ht_project_bit_exact(core):
     assert np.array_equal(mask.cpu().numpy(), core['mask'][..., 0])
     ok = core['mask'][..., 0]
     assert np.abs(pix.cpu().numpy()[ok] - core['pix'][ok]).max() < 1e-4
+
+
+def test_gauss_heads_ragged_plane(core):
+    """Y*X not a multiple of the 64-pillar wave tile: against the module's own torch layers."""
+    from ocrfdet_amd import neck_ops
+    m, cfg = core['m'], core['cfg']
+    g = torch.Generator().manual_seed(3)
+    bev = torch.randn(2, cfg.channels, 10, 7, generator=g).cuda()
+    rgb = (torch.rand(2, cfg.num_height, 70, 3, generator=g) * 255).cuda()
+    op, sc, rot, col = neck_ops.gauss_heads(bev, rgb, m._head_params(), cfg.num_height)
+    with torch.no_grad():
+        vf = m.ObtainVoxelFeature(bev.permute(0, 2, 3, 1).unsqueeze(1)).reshape(2, cfg.num_height * 70, -1)
+        want = (m.A_MLP(vf), m.S_MLP(vf), m.R_MLP(vf), m.C_MLP(torch.cat((vf, rgb.reshape(2, -1, 3) / 255.0), -1)))
+    for got, ref, name in zip((op, sc, rot, col), want, ('opacity', 'scales', 'rotations', 'colour')):
+        close(got, ref.cpu().numpy(), 1e-5, name)
