@@ -387,6 +387,17 @@ int ocrf_nerf_render(const float *z, const int *cam_sel, const float *alpha, con
                      float *render_depth_n, ocrf_stream_t stream);
 int ocrf_nerf_render_params_len(void);
 
+/*
+ * DualFeatFusion.forward (view_transformer_ocrf.py:203-213; MS_CAM :36-66), eval mode, one pass:
+ *   out = cf * x1 + (1 - cf) * x2,  cf = sigmoid(local_att([x1; x2]) + global_vec[b]),
+ *   local_att = Conv1x1(2C->M) + BN + ReLU + Conv1x1(M->C) + BN with both BatchNorms folded by the
+ *   caller into params = W1t[2C][M] | b1[M] | W2[C][M] | b2[C]; global_vec (B,C) is MS_CAM's
+ *   global_att branch of the pooled map (a (B,2C) vector through two tiny layers: the caller's).
+ * x1, x2, out: (B,C,YX).  (C, M) in {(80, 40), (64, 32)}; params 8-byte aligned.
+ */
+int ocrf_dual_feat_fusion(const float *x1, const float *x2, const float *params, const float *global_vec,
+                          float *out, int B, int C, int M, int YX, ocrf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Per-kernel device timer (measurement aid for bench.py; not part of the reference's surface)
  * ------------------------------------------------------------------------------------------
@@ -430,7 +441,8 @@ enum {
   OCRF_K_NECK_RETAIN = 62,       /* neck_fill_kernel + neck_retain_scatter_kernel */
   OCRF_K_NECK_HEADS = 63,        /* neck_gauss_heads_kernel */
   OCRF_K_NECK_NERF_ALPHA = 64,   /* neck_nerf_alpha_kernel */
-  OCRF_K_NECK_NERF_RENDER = 65   /* neck_nerf_render_kernel */
+  OCRF_K_NECK_NERF_RENDER = 65,  /* neck_nerf_render_kernel */
+  OCRF_K_NECK_FUSION = 66        /* neck_dual_fusion_kernel<C, M> */
 };
 const char *ocrf_kernel_name(int kernel_id);           /* symbol as rocprofv3 prints it */
 int ocrf_timer_create(int capacity, void **timer_out); /* host pointers */

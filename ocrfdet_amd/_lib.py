@@ -130,6 +130,8 @@ def _declare(L):
     L.ocrf_nerf_render.argtypes = [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 3
     L.ocrf_nerf_render_params_len.restype = c_int
     L.ocrf_nerf_render_params_len.argtypes = []
+    L.ocrf_dual_feat_fusion.restype = c_int
+    L.ocrf_dual_feat_fusion.argtypes = [c_void_p] * 5 + [c_int] * 4 + [c_void_p]
     L.ocrf_kernel_name.restype = ctypes.c_char_p
     L.ocrf_kernel_name.argtypes = [c_int]
     L.ocrf_timer_create.restype = c_int

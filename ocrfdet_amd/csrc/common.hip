@@ -77,6 +77,7 @@ const char* ocrf_kernel_name(int kernel_id) {
     case OCRF_K_NECK_HEADS: return "neck_gauss_heads_kernel";
     case OCRF_K_NECK_NERF_ALPHA: return "neck_nerf_alpha_kernel";
     case OCRF_K_NECK_NERF_RENDER: return "neck_nerf_render_kernel";
+    case OCRF_K_NECK_FUSION: return "neck_dual_fusion_kernel<*>";
     default: return "";
   }
 }

@@ -411,6 +411,88 @@ __global__ __launch_bounds__(256) void neck_nerf_render_kernel(
   dep_n[(size_t)b * plane + pix] = a * d;
 }
 
+// ------------------------------------------------------------------------------------------
+// DualFeatFusion (view_transformer_ocrf.py:203-213 with MS_CAM :36-66), eval mode: per pixel
+//   h = relu(W1 [x1; x2] + b1)   (2C -> M, BatchNorm folded by the caller)
+//   l = W2 h + b2                (M -> C, BatchNorm folded)
+//   cf = sigmoid(l + g[b])       g = the global-attention branch of the pooled map, (B,C)
+//   out = cf * x1 + (1 - cf) * x2
+// Lanes = consecutive pixels (every plane read / write is coalesced), the weights are wave-uniform
+// scalar loads, both layers accumulate in packed pairs (v_pk_fma_f32).  Replaces the
+// reference's cat + 2 GEMMs + 2 BatchNorm + ReLU + 7 elementwise passes over (B,C..2C,Y,X).
+// prm: W1t[2C][M] | b1[M] | W2[C][M] | b2[C]
+// ------------------------------------------------------------------------------------------
+template <int C, int M>
+__global__ __launch_bounds__(256) void neck_dual_fusion_kernel(
+    const float* __restrict__ x1, const float* __restrict__ x2, const float* __restrict__ prm,
+    const float* __restrict__ gvec, float* __restrict__ out, int YX) {
+  // workgroup = 64 pixels x 4 waves; wave g owns hidden units [g*M/4, (g+1)*M/4) in the first layer
+  // and output channels [g*C/4, (g+1)*C/4) in the second, the hidden vector crosses through LDS.
+  // (One wave per 64 pixels left ~1 wave per SIMD, each streaming all 38 KB of weights through the
+  // 16 KB scalar cache: 120 us.  Four waves per tile quarter both the serial chain and the weights
+  // a wave touches.)
+  constexpr int MQ = M / 4, CQ = C / 4;
+  static_assert(M % 8 == 0 && C % 16 == 0, "quarter sizes must be even / a multiple of the read-ahead");
+  __shared__ float s_h[M][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int q = blockIdx.x * 64 + lane, b = blockIdx.y;
+  const bool live = q < YX;
+  const int qc = live ? q : YX - 1;
+  const float* b1 = prm + 2 * C * M;
+  const float* W2 = b1 + M;
+  const float* b2 = W2 + C * M;
+  const float* p1 = x1 + (size_t)b * C * YX + qc;
+  const float* p2 = x2 + (size_t)b * C * YX + qc;
+  f32x2 h[MQ / 2];
+#pragma unroll
+  for (int m = 0; m < MQ / 2; ++m) h[m] = f32x2{b1[grp * MQ + 2 * m], b1[grp * MQ + 2 * m + 1]};
+  constexpr int kAhead = 8;                  // plane reads in flight per lane
+  for (int half = 0; half < 2; ++half) {
+    const float* p = half ? p2 : p1;
+    for (int c0 = 0; c0 < C; c0 += kAhead) {
+      float vv[kAhead];
+#pragma unroll
+      for (int j = 0; j < kAhead; ++j) vv[j] = p[(size_t)(c0 + j) * YX];
+#pragma unroll
+      for (int j = 0; j < kAhead; ++j) {
+        const f32x2 v = {vv[j], vv[j]};
+        const f32x2* w = reinterpret_cast<const f32x2*>(prm + (size_t)(half * C + c0 + j) * M + grp * MQ);
+#pragma unroll
+        for (int m = 0; m < MQ / 2; ++m) h[m] = __builtin_elementwise_fma(w[m], v, h[m]);
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MQ / 2; ++m) {
+    s_h[grp * MQ + 2 * m][lane] = fmaxf(h[m].x, 0.0f);
+    s_h[grp * MQ + 2 * m + 1][lane] = fmaxf(h[m].y, 0.0f);
+  }
+  __syncthreads();
+  f32x2 hh[M / 2];
+#pragma unroll
+  for (int m = 0; m < M / 2; ++m) hh[m] = f32x2{s_h[2 * m][lane], s_h[2 * m + 1][lane]};
+  float* po = out + (size_t)b * C * YX + qc;
+  for (int c0 = grp * CQ; c0 < (grp + 1) * CQ; c0 += kAhead / 2) {
+    float va[kAhead / 2], vb[kAhead / 2];
+#pragma unroll
+    for (int j = 0; j < kAhead / 2; ++j) {
+      va[j] = p1[(size_t)(c0 + j) * YX];
+      vb[j] = p2[(size_t)(c0 + j) * YX];
+    }
+#pragma unroll
+    for (int j = 0; j < kAhead / 2; ++j) {
+      const int c = c0 + j;
+      f32x2 acc = {b2[c] + gvec[b * C + c], 0.0f};
+      const f32x2* w = reinterpret_cast<const f32x2*>(W2 + (size_t)c * M);
+#pragma unroll
+      for (int m = 0; m < M / 2; ++m) acc = __builtin_elementwise_fma(w[m], hh[m], acc);
+      const float cf = sigmoidf(acc.x + acc.y);
+      const float o = cf * va[j] + (1.0f - cf) * vb[j];
+      if (live) po[(size_t)c * YX] = o;
+    }
+  }
+}
+
 inline int last_error() { return (int)hipGetLastError(); }
 
 }  // namespace
@@ -519,6 +601,21 @@ int ocrf_nerf_render(const float* z, const int* cam_sel, const float* alpha, con
     return (int)hipErrorInvalidValue;
   ocrf::launch(OCRF_K_NECK_NERF_RENDER, neck_nerf_render_kernel, dim3((8 * w2 + 255) / 256, 8 * h2, B), dim3(256), 0,
                (hipStream_t)stream, z, cam_sel, alpha, sparse_rgb, params, N, h2, w2, render_image_n, render_depth_n);
+  return last_error();
+}
+
+int ocrf_dual_feat_fusion(const float* x1, const float* x2, const float* params, const float* global_vec, float* out,
+                          int B, int C, int M, int YX, ocrf_stream_t stream) {
+  if (B <= 0 || YX <= 0 || !x1 || !x2 || !params || !global_vec || !out) return (int)hipErrorInvalidValue;
+  if (reinterpret_cast<uintptr_t>(params) & 7) return (int)hipErrorInvalidValue;
+  if (C == 80 && M == 40)        // the reference's numC_Trans = 80 (configs/ocrfdet/ocrfdet.py:41)
+    ocrf::launch(OCRF_K_NECK_FUSION, neck_dual_fusion_kernel<80, 40>, dim3((YX + 63) / 64, B), dim3(256), 0,
+                 (hipStream_t)stream, x1, x2, params, global_vec, out, YX);
+  else if (C == 64 && M == 32)   // LSSViewTransformer's default out_channels
+    ocrf::launch(OCRF_K_NECK_FUSION, neck_dual_fusion_kernel<64, 32>, dim3((YX + 63) / 64, B), dim3(256), 0,
+                 (hipStream_t)stream, x1, x2, params, global_vec, out, YX);
+  else
+    return (int)hipErrorInvalidValue;
   return last_error();
 }
 

@@ -13,7 +13,7 @@ import torch
 from . import _lib
 
 __all__ = ['prefilter', 'pillar_sample_mean', 'retain_valid_pixels', 'gauss_heads', 'pack_gauss_head_params',
-           'compose_nerf_maps', 'nerf_alpha', 'nerf_render']
+           'compose_nerf_maps', 'nerf_alpha', 'nerf_render', 'pack_fusion_params', 'dual_feat_fusion']
 
 
 def _f32c(t):
@@ -204,3 +204,37 @@ def nerf_render(z, cam_sel, alpha, sparse_rgb, params, n_cams):
                                       _lib.ptr(params), B, n_cams, h2, w2, _lib.ptr(img), _lib.ptr(dep),
                                       _lib.stream_ptr(z.device)), 'ocrf_nerf_render')
     return img, dep
+
+
+def _fold_conv_bn(conv, bn):
+    """1x1 conv + eval BatchNorm -> (W (out,in), b (out)) in float64."""
+    s = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+    w = conv.weight.double().reshape(conv.out_channels, conv.in_channels) * s[:, None]
+    b = (conv.bias.double() - bn.running_mean.double()) * s + bn.bias.double()
+    return w, b
+
+
+def pack_fusion_params(ms_cam):
+    """Parameter block of ``ocrf_dual_feat_fusion`` from an ``MS_CAM``'s ``local_att`` (conv, bn, relu,
+    conv, bn; view_transformer_ocrf.py:42-48): W1t[2C][M] | b1[M] | W2[C][M] | b2[C]."""
+    with torch.no_grad():
+        la = ms_cam.local_att
+        w1, b1 = _fold_conv_bn(la[0], la[1])          # (M, 2C)
+        w2, b2 = _fold_conv_bn(la[3], la[4])          # (C, M)
+        return torch.cat((w1.t().reshape(-1), b1, w2.reshape(-1), b2)).float().contiguous()
+
+
+def dual_feat_fusion(x1, x2, params, global_vec, hidden):
+    """``DualFeatFusion.forward`` (view_transformer_ocrf.py:203-213), eval mode, in one pass.
+    x1, x2 (B,C,Y,X); ``global_vec`` (B,C) = MS_CAM's global branch; -> (B,C,Y,X)."""
+    _lib.require_cuda(x1, x2, params, global_vec)
+    B, C, Y, X = x1.shape
+    x1, x2, gv = _f32c(x1), _f32c(x2), _f32c(global_vec).reshape(B, C)
+    if params.numel() != 2 * C * hidden + hidden + C * hidden + C:
+        raise ValueError('dual_feat_fusion: parameter block does not match (C, hidden)')
+    out = torch.empty_like(x1)
+    with torch.cuda.device(x1.device):
+        _lib.check(_lib.lib().ocrf_dual_feat_fusion(_lib.ptr(x1), _lib.ptr(x2), _lib.ptr(params), _lib.ptr(gv),
+                                                    _lib.ptr(out), B, C, hidden, Y * X, _lib.stream_ptr(x1.device)),
+                   'ocrf_dual_feat_fusion')
+    return out

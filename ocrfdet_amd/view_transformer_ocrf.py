@@ -159,11 +159,31 @@ class ProbNet(nn.Module):
 
 
 class DualFeatFusion(nn.Module):
+    """:203-213.  Eval mode on the GPU: one HIP pass (``ocrf_dual_feat_fusion``) instead of cat + two
+    1x1 convolutions + two BatchNorms + ReLU + seven elementwise passes over the BEV."""
+
     def __init__(self, input_channel, output_channel):
         super().__init__()
         self.ca = MS_CAM(input_channel, output_channel)
 
+    def _fusable(self, x1):
+        la = self.ca.local_att
+        c, m = la[3].out_channels, la[0].out_channels
+        return (x1.is_cuda and not self.training and not torch.is_grad_enabled() and la[0].in_channels == 2 * c
+                and (c, m) in ((80, 40), (64, 32)))
+
     def forward(self, x1, x2):
+        if self._fusable(x1):
+            ca = self.ca
+            ts = [p for p in ca.local_att.parameters()] + [b for b in ca.local_att.buffers()]
+            key = tuple((t._version, t.data_ptr()) for t in ts)
+            if self.__dict__.get('_pack_key') != key:
+                self.__dict__['_pack'] = neck_ops.pack_fusion_params(ca)
+                self.__dict__['_pack_key'] = key
+            g = torch.cat((x1.mean((2, 3), keepdim=True), x2.mean((2, 3), keepdim=True)), 1)
+            for layer in list(ca.global_att)[1:]:
+                g = layer(g)
+            return neck_ops.dual_feat_fusion(x1, x2, self.__dict__['_pack'], g, ca.local_att[0].out_channels)
         cf = self.ca(torch.cat((x1, x2), 1))
         return cf * x1 + (1 - cf) * x2
 

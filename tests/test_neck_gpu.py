@@ -277,3 +277,20 @@ def test_gauss_heads_ragged_plane(core):
         want = (m.A_MLP(vf), m.S_MLP(vf), m.R_MLP(vf), m.C_MLP(torch.cat((vf, rgb.reshape(2, -1, 3) / 255.0), -1)))
     for got, ref, name in zip((op, sc, rot, col), want, ('opacity', 'scales', 'rotations', 'colour')):
         close(got, ref.cpu().numpy(), 1e-5, name)
+
+
+def test_dual_feat_fusion(core):
+    """ocrf_dual_feat_fusion vs the numpy oracle, the reference fixture and the module's torch path
+    (also a ragged plane)."""
+    g, p, m, t = core['g'], core['p'], core['m'], core['t']
+    with torch.no_grad():
+        got = m.fuser(t(g['lss_feat']), t(g['ht_feat']))
+    close(got, g['channel_feat'], 1e-5, 'fuser vs reference')
+    close(got, oc.dual_feat_fusion(g['lss_feat'], g['ht_feat'], p), 1e-5, 'fuser vs oracle')
+    gen = torch.Generator().manual_seed(9)
+    a, b = torch.randn(3, 80, 9, 13, generator=gen).cuda(), torch.randn(3, 80, 9, 13, generator=gen).cuda()
+    with torch.no_grad():
+        fused = m.fuser(a, b)
+        cf = m.fuser.ca(torch.cat((a, b), 1))
+        want = cf * a + (1 - cf) * b
+    close(fused, want.cpu().numpy(), 1e-5, 'fuser ragged vs torch ops')
