@@ -14,7 +14,9 @@
 //                             composed by the caller into one 32 -> (8x8 positions) map per
 //                             consumer: the 6 x (80,H,W) feature images are never materialised.
 //
-// All arithmetic is fp32 with -ffp-contract=off; divisions and exp/log are the IEEE / ocml ones.
+// All arithmetic is fp32 with -ffp-contract=off.  The pre-filter's softmax and the sampling taps use
+// IEEE division / ocml expf (their results feed threshold tests and index-like decisions); the MLP
+// activations use the hardware transcendentals (see sigmoidf / softplusf).
 #include <hip/hip_runtime.h>
 
 #include "launch.h"
@@ -22,8 +24,12 @@
 
 namespace {
 
-__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float softplusf(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+// Activations on the hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp each): the
+// ocml expf / log1pf / IEEE-division sequences were as expensive as the whole first layer of the heads
+// kernel.  Absolute error <= ~1e-6 on outputs of O(1), two orders below the 1e-4 parity bar.
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoidf(float x) { return rcp_fast(1.0f + __expf(-x)); }
+__device__ __forceinline__ float softplusf(float x) { return x > 20.0f ? x : __logf(1.0f + __expf(x)); }
 
 // ------------------------------------------------------------------------------------------
 // prefilter: one workgroup = PXW consecutive pixels of one image x (256 / PXW) depth slices.  The map
@@ -288,7 +294,8 @@ __global__ __launch_bounds__(64) void neck_gauss_heads_kernel(
     for (int k = 0; k < 3; ++k)
       if (lane + 64 * k < nq * 3) stg[0][lane + 64 * k] = rgb_avg[g0 * 3 + lane + 64 * k];
     __syncthreads();
-    const float r01[3] = {stg[0][lane * 3] / 255.0f, stg[0][lane * 3 + 1] / 255.0f, stg[0][lane * 3 + 2] / 255.0f};
+    constexpr float k255 = 1.0f / 255.0f;
+    const float r01[3] = {stg[0][lane * 3] * k255, stg[0][lane * 3 + 1] * k255, stg[0][lane * 3 + 2] * k255};
     float hv[16];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { hv[2 * k] = hid[h][k].x; hv[2 * k + 1] = hid[h][k].y; }
@@ -322,11 +329,11 @@ __global__ __launch_bounds__(64) void neck_gauss_heads_kernel(
       r[o] = v;
       nn = fmaf(v, v, nn);
     }
-    const float den = fmaxf(sqrtf(nn), 1e-12f);
+    const float inv = rcp_fast(fmaxf(sqrtf(nn), 1e-12f));
     float v = A2[4];
     for (int k = 0; k < 4; ++k) v = fmaf(A2[k], hv[8 + k], v);
     if (lane < nq) {
-      *reinterpret_cast<float4*>(rot + g * 4) = make_float4(r[0] / den, r[1] / den, r[2] / den, r[3] / den);
+      *reinterpret_cast<float4*>(rot + g * 4) = make_float4(r[0] * inv, r[1] * inv, r[2] * inv, r[3] * inv);
       opacity[g] = sigmoidf(v);
     }
   }
@@ -347,7 +354,7 @@ __global__ __launch_bounds__(256) void neck_nerf_alpha_kernel(
   float v = cm[pos];
 #pragma unroll 8
   for (int ci = 0; ci < 32; ++ci) v = fmaf(zp[(size_t)ci * h2 * w2], Wm[ci * 64 + pos], v);
-  alpha[((size_t)m * 8 * h2 + y) * Wo + x] = 1.0f - expf(-softplusf(v));
+  alpha[((size_t)m * 8 * h2 + y) * Wo + x] = 1.0f - __expf(-softplusf(v));
 }
 
 // prm: W12[12][32][64] | c12[12][64] | W1rgb[12][3] | Cn: W2[3][4] b2[3] | R1: W2[3][4] b2[3] | R2: W2[1][4] b2[1]
@@ -381,7 +388,8 @@ __global__ __launch_bounds__(256) void neck_nerf_render_kernel(
   }
   const size_t pix = (size_t)y * Wo + x, plane = (size_t)Ho * Wo;
   const float* sp = sparse_rgb + (size_t)b * 3 * plane + pix;
-  const float r01[3] = {sp[0] / 255.0f, sp[plane] / 255.0f, sp[2 * plane] / 255.0f};
+  constexpr float k255 = 1.0f / 255.0f;
+  const float r01[3] = {sp[0] * k255, sp[plane] * k255, sp[2 * plane] * k255};
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
     float v = hid[k];
@@ -399,15 +407,15 @@ __global__ __launch_bounds__(256) void neck_nerf_render_kernel(
     rad[o] = fmaxf(u, 0.0f);
   }
   const float mx = fmaxf(cw[0], fmaxf(cw[1], cw[2]));
-  const float e0 = expf(cw[0] - mx), e1 = expf(cw[1] - mx), e2 = expf(cw[2] - mx), es = e0 + e1 + e2;
+  const float e0 = __expf(cw[0] - mx), e1 = __expf(cw[1] - mx), e2 = __expf(cw[2] - mx), ies = rcp_fast(e0 + e1 + e2);
   float d = R2[4];
   for (int k = 0; k < 4; ++k) d = fmaf(R2[k], hid[8 + k], d);
   d = fmaxf(d, 0.0f);
   const float a = alpha[(size_t)m * plane + pix];
   float* io = img_n + (size_t)b * 3 * plane + pix;
-  io[0] = a * (rad[0] * (e0 / es));
-  io[plane] = a * (rad[1] * (e1 / es));
-  io[2 * plane] = a * (rad[2] * (e2 / es));
+  io[0] = a * (rad[0] * (e0 * ies));
+  io[plane] = a * (rad[1] * (e1 * ies));
+  io[2 * plane] = a * (rad[2] * (e2 * ies));
   dep_n[(size_t)b * plane + pix] = a * d;
 }
 
@@ -434,7 +442,8 @@ __global__ __launch_bounds__(256) void neck_dual_fusion_kernel(
   constexpr int MQ = M / 4, CQ = C / 4;
   static_assert(M % 8 == 0 && C % 16 == 0, "quarter sizes must be even / a multiple of the read-ahead");
   __shared__ float s_h[M][64];
-  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  // the wave index is wave-uniform, but only readfirstlane tells the compiler so (scalar weight loads)
+  const int lane = threadIdx.x & 63, grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int q = blockIdx.x * 64 + lane, b = blockIdx.y;
   const bool live = q < YX;
   const int qc = live ? q : YX - 1;

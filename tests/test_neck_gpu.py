@@ -117,7 +117,7 @@ def test_gauss_heads(core):
     for b in range(core['B']):
         want = oc.gauss_heads(lift[b].reshape(-1, cfg.channels), g['colored_avg'][b].reshape(-1, 3) / np.float32(255.0), p)
         for got, ref, name in zip((op, sc, rot, col), want, ('opacity', 'scales', 'rotations', 'colour')):
-            close(got[b], ref, 2e-6, name + ' vs oracle')
+            close(got[b], ref, 5e-6, name + ' vs oracle')       # hardware exp / log / rcp in the activations
         close(op[b, ::5], g[f'gauss_opacity{b}'], 1e-5, 'opacity vs reference')
         close(sc[b, ::5], g[f'gauss_scales{b}'], 1e-5, 'scales vs reference')
         close(rot[b, ::5], g[f'gauss_rot{b}'], 1e-5, 'rotations vs reference')
