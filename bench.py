@@ -47,7 +47,7 @@ def parse():
     ap.add_argument('--shard', choices=('samples', 'frames', 'cameras'), default='samples')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL); gloo only for plumbing tests')
     ap.add_argument('--no-overlap', action='store_true',
-                    help='run the per-frame renders on the main stream instead of beside the pools + HOA on their own HIP streams')
+                    help='run the renders on the main stream instead of beside the pools + HOA on a side HIP stream')
     ap.add_argument('--scope', choices=('hotpath', 'neck'), default='hotpath',
                     help="'hotpath': pools (+ one rendered view per camera + HOA) — the headline step; 'neck': the whole "
                          "OcRFViewTransformerFull.view_transform (one rendered view per sample, like the reference)")
@@ -303,7 +303,7 @@ def main():
                        'bev': list(cfg.bev_xyz), 'channels': cfg.channels, 'depth_bins': cfg.D,
                        'stages': 'lss_pool+ht_pool' + ('+render' if cfg.render else '') + ('+hoa' if cfg.hoa else ''),
                        'views_per_step': hp.views_per_step, 'render_camera': getattr(hp, 'render_convention', None),
-                       'streams': ('main: pools + HOA; one HIP stream per frame: render' if hp.overlap and cfg.render
+                       'streams': ('main: pools + HOA; side HIP stream: renders' if hp.overlap and cfg.render
                                    else 'single stream'),
                        'index_prep': 'cached (accelerate=True semantics)' if args.index_prep == 'cached' else
                                      'per step, HIP (accelerate=False semantics)',

@@ -51,9 +51,10 @@ class HotPath:
         self.batch = cfg.batch * cfg.n_frames                  # frames ride along as batch entries
         assert index_prep_mode in ('cached', 'per_step')
         self.index_prep_mode = index_prep_mode
-        # the renders of the frames are independent of the poolings and of each other: with ``overlap``
-        # every frame renders on its own HIP stream beside the pools + HOA of the main stream (the
-        # blend is VALU-bound with a ragged tail, the pools are latency / L2-bound: they interleave)
+        # the renders are independent of the poolings: with ``overlap`` they run on ONE side HIP stream
+        # beside the pools + HOA of the main stream (the blend is VALU-bound with a ragged tail, the pools
+        # and the small HOA kernels are latency / L2-bound: they interleave).  One stream per frame was
+        # worse: two blends at once slow each other more than the overlap returns (0.66 vs 0.60 ms)
         self.overlap = bool(overlap) and self.device.type == 'cuda'
         self._side = []
         self._prepare()
@@ -170,7 +171,8 @@ class HotPath:
 
     def render(self, streams=None):
         """All owned cameras of every frame: list (one per frame) of dicts from rasterize_views.
-        ``streams``: one HIP stream per frame (each with its own scratch buffer); the caller joins them."""
+        ``streams``: a HIP stream per frame (frames on different streams get their own scratch buffer);
+        the caller joins them."""
         cfg, rc, g = self.cfg, self.render_cams, self.gauss
         H, W = cfg.input_size
         outs = []
@@ -184,7 +186,8 @@ class HotPath:
                 with torch.cuda.stream(streams[b]):
                     outs.append(rasterize_views(xyz, g['rgb'], g['opacity'], g['scales'], g['rotations'], rc['vm'],
                                                 rc['pm'], rc['tfx'], rc['tfy'], H, W, self.bg,
-                                                packed_cameras=rc['packed'], workspace_tag=f'raster{b}'))
+                                                packed_cameras=rc['packed'],
+                                                workspace_tag=f'raster{streams.index(streams[b])}'))
         return outs
 
     @property
@@ -251,11 +254,11 @@ class HotPath:
         fork = self.overlap and self.cfg.render
         if fork:
             cur = torch.cuda.current_stream(self.device)
-            while len(self._side) < self.batch:
+            if not self._side:
                 self._side.append(torch.cuda.Stream(self.device))
-            for s in self._side[:self.batch]:
-                s.wait_stream(cur)                    # inputs (and last step's consumers) are ordered before
-            rendered = self.render(self._side)
+            side = self._side[0]
+            side.wait_stream(cur)                     # inputs (and last step's consumers) are ordered before
+            rendered = self.render([side] * self.batch)
         lss, ht = self.pool_step(depth, feat)
         out = [lss, ht]
         if fork:
@@ -267,8 +270,7 @@ class HotPath:
             # the pools and HOA-3 are MIOpen territory, not part of this path
             out.extend(self.hoa_step(ht))
         if fork:
-            for s in self._side[:self.batch]:
-                cur.wait_stream(s)                    # join: everything the step returns is ordered on `cur`
+            cur.wait_stream(side)                     # join: everything the step returns is ordered on `cur`
         return tuple(out)
 
     @property
