@@ -163,6 +163,21 @@ int ocrf_rasterize_forward(int P, int n_views, int H, int W, const float *means3
                            uint32_t *tiles_touched, int *status, void *workspace,
                            size_t workspace_bytes, ocrf_stream_t stream);
 
+/*
+ * The same forward over n_sets Gaussian sets of P Gaussians each in ONE set of launches: the arrays
+ * are (n_sets, P, .), `cameras` holds n_sets * views_per_set rows and view v renders set
+ * v / views_per_set (the per-sample loop of view_transformer_ocrf.py:1090-1153 — every sample has its
+ * own Gaussian parameters and one camera — or the frames of a multi-frame batch).  Outputs are indexed
+ * by view as above; workspace as for n_sets * views_per_set views.
+ */
+int ocrf_rasterize_forward_sets(int P, int n_sets, int views_per_set, int H, int W, const float *means3D,
+                                const float *colors, const float *opacities, const float *scales,
+                                float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                                const float *cameras, const float *bg, int depth_mode, float *out_color,
+                                float *out_depth, float *out_final_T, uint32_t *out_n_contrib, int *radii,
+                                uint32_t *tiles_touched, int *status, void *workspace,
+                                size_t workspace_bytes, ocrf_stream_t stream);
+
 size_t ocrf_rasterize_workspace_bytes(int P, int n_views);
 
 /*

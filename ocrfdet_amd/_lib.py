@@ -72,6 +72,9 @@ def _declare(L):
     L.ocrf_rasterize_forward.restype = c_int
     L.ocrf_rasterize_forward.argtypes = ([c_int] * 4 + [c_void_p] * 4 + [c_float] + [c_void_p] * 4 +
                                          [c_int] + [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p])
+    L.ocrf_rasterize_forward_sets.restype = c_int
+    L.ocrf_rasterize_forward_sets.argtypes = ([c_int] * 5 + [c_void_p] * 4 + [c_float] + [c_void_p] * 4 +
+                                              [c_int] + [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p])
     L.ocrf_lss_prepare.restype = c_int
     L.ocrf_lss_prepare.argtypes = ([c_int] * 5 + [c_void_p] * 4 + [c_int] * 3 + [c_void_p] * 6 +
                                    [c_void_p, c_size_t, c_void_p])

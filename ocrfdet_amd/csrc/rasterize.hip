@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
     const Camera* __restrict__ cams, uint4* __restrict__ vis_rec, int* __restrict__ vis_count,
     Rect* __restrict__ rects, float2* __restrict__ xy, float4* __restrict__ conic_o,
-    int* __restrict__ radii, unsigned* __restrict__ tiles_touched, int* __restrict__ hist) {
+    int* __restrict__ radii, unsigned* __restrict__ tiles_touched, int* __restrict__ hist, int vps) {
   // One workgroup = kChunk consecutive Gaussians of one view.  Their depth buckets are counted in
   // an LDS histogram first and only the non-empty bins go to the global one: scattered global
   // atomics run at ~20 G/s chip-wide, and a depth slice of a regular grid puts thousands of
@@ -103,6 +103,7 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
   rect_of[it] = Rect{0, 0, 0, 0};
   if (idx >= P) continue;
   const long o = (long)v * P + idx;
+  const long gi = (long)(v / vps) * P + idx;      // Gaussian sets: view v renders set v / views_per_set
   const Camera& cam = cams[v];
   const float* vm = cam.view;
   const float* pm = cam.proj;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
   int my_radii = 0;
   unsigned touched = 0;
 
-  const float px = means3D[3 * idx], py = means3D[3 * idx + 1], pz = means3D[3 * idx + 2];
+  const float px = means3D[3 * gi], py = means3D[3 * gi + 1], pz = means3D[3 * gi + 2];
   // transformPoint4x3 (auxiliary.h:58-66)
   const float vx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
   const float vy = vm[1] * px + vm[5] * py + vm[9] * pz + vm[13];
@@ -144,11 +145,11 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
     }
     bool surely_empty = false;
     if (!cov3D_precomp) {
-      const float s0 = scale_modifier * scales[3 * idx], s1 = scale_modifier * scales[3 * idx + 1],
-                  s2 = scale_modifier * scales[3 * idx + 2];
+      const float s0 = scale_modifier * scales[3 * gi], s1 = scale_modifier * scales[3 * gi + 1],
+                  s2 = scale_modifier * scales[3 * gi + 2];
       const float smax = fmaxf(fabsf(s0), fmaxf(fabsf(s1), fabsf(s2)));
-      const float qr = rotations[4 * idx], qx = rotations[4 * idx + 1], qy = rotations[4 * idx + 2],
-                  qz = rotations[4 * idx + 3];
+      const float qr = rotations[4 * gi], qx = rotations[4 * gi + 1], qy = rotations[4 * gi + 2],
+                  qz = rotations[4 * gi + 3];
       const float qq = qr * qr + qx * qx + qy * qy + qz * qz;
       const float rn = (fabsf(1.f - qq) + qq) * smax;
       const float af = A[0][0] * A[0][0] + A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][0] * A[1][0] +
@@ -163,13 +164,13 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
     float c3[6];
     if (cov3D_precomp) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) c3[i] = cov3D_precomp[6 * (long)idx + i];
+      for (int i = 0; i < 6; ++i) c3[i] = cov3D_precomp[6 * gi + i];
     } else {
       // computeCov3D (forward.cu:118-152): Sigma = R diag(s^2) R^T, quaternion not normalised
-      const float sx = scale_modifier * scales[3 * idx], sy = scale_modifier * scales[3 * idx + 1],
-                  sz = scale_modifier * scales[3 * idx + 2];
-      const float r = rotations[4 * idx], x = rotations[4 * idx + 1], y = rotations[4 * idx + 2],
-                  z = rotations[4 * idx + 3];
+      const float sx = scale_modifier * scales[3 * gi], sy = scale_modifier * scales[3 * gi + 1],
+                  sz = scale_modifier * scales[3 * gi + 2];
+      const float r = rotations[4 * gi], x = rotations[4 * gi + 1], y = rotations[4 * gi + 2],
+                  z = rotations[4 * gi + 3];
       const float R[3][3] = {
           {1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
           {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
         rects[o] = rc;
         rect_of[it] = rc;
         xy[o] = make_float2(pixx, pixy);
-        conic_o[o] = make_float4(con_x, con_y, con_z, opacities[idx]);
+        conic_o[o] = make_float4(con_x, con_y, con_z, opacities[gi]);
       }
     }
     }   // !surely_empty
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
     const float2* __restrict__ xy, const float4* __restrict__ conic_o,
     const float* __restrict__ colors, const float* __restrict__ bg, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_final_T,
-    unsigned* __restrict__ out_n_contrib, int* __restrict__ status, BwdArgs bw) {
+    unsigned* __restrict__ out_n_contrib, int* __restrict__ status, BwdArgs bw, int vps) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long rec[];
   float4* l_a = reinterpret_cast<float4*>(rec + kCapRec);          // x, y, conic.x, conic.y
   float4* l_b = l_a + kStage;                                      // conic.z, opacity, depth, r
@@ -556,8 +557,9 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
         const Rect rc = rects[base + id];
         const unsigned cov = ((tyA >= rc.y0 && tyA < rc.y1) ? 1u : 0u) | ((tyB >= rc.y0 && tyB < rc.y1) ? 2u : 0u);
         l_a[tid] = make_float4(p.x, p.y, co.x, co.y);
-        l_b[tid] = make_float4(co.z, co.w, __uint_as_float((unsigned)(c >> 32)), colors[3 * (long)id]);
-        l_c[tid] = make_float4(colors[3 * (long)id + 1], colors[3 * (long)id + 2], __uint_as_float(cov), 0.f);
+        const float* col = colors + 3 * ((long)(v / vps) * P + id);     // the view's Gaussian set
+        l_b[tid] = make_float4(co.z, co.w, __uint_as_float((unsigned)(c >> 32)), col[0]);
+        l_c[tid] = make_float4(col[1], col[2], __uint_as_float(cov), 0.f);
         if constexpr (BWD) {
           l_id[tid] = id;
 #pragma unroll
@@ -1094,13 +1096,15 @@ size_t ocrf_rasterize_workspace_bytes(int P, int n_views) {
   return ws.total;
 }
 
-int ocrf_rasterize_forward(int P, int n_views, int H, int W, const float* means3D,
+int ocrf_rasterize_forward_sets(int P, int n_sets, int views_per_set, int H, int W, const float* means3D,
                            const float* colors, const float* opacities, const float* scales,
                            float scale_modifier, const float* rotations, const float* cov3D_precomp,
                            const float* cameras, const float* bg, int depth_mode, float* out_color,
                            float* out_depth, float* out_final_T, uint32_t* out_n_contrib, int* radii,
                            uint32_t* tiles_touched, int* status, void* workspace,
                            size_t workspace_bytes, ocrf_stream_t stream_) {
+  if (n_sets <= 0 || views_per_set <= 0) return (int)hipErrorInvalidValue;
+  const int n_views = n_sets * views_per_set;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (P < 0 || n_views <= 0 || H <= 0 || W <= 0 || (depth_mode != 0 && depth_mode != 1) ||
       !out_color || !out_depth || !out_final_T || !out_n_contrib || !bg || !cameras)
@@ -1141,7 +1145,7 @@ int ocrf_rasterize_forward(int P, int n_views, int H, int W, const float* means3
   const dim3 xgrid((unsigned)((n_chunks + 7) / 8 * 8 * n_views));      // (chunk, view) pairs, XCD-aware order
   ocrf::launch(OCRF_K_RASTER_PREPROCESS, raster_preprocess_kernel, xgrid, dim3(kBlock), 0, stream, P, n_views,
                n_chunks, W, H, gx, gy, means3D, opacities, scales, scale_modifier, rotations, cov3D_precomp,
-               cams, vis_rec, vis_count, rects, xy, conic_o, radii, tiles_touched, hist);
+               cams, vis_rec, vis_count, rects, xy, conic_o, radii, tiles_touched, hist, views_per_set);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   ocrf::launch(OCRF_K_RASTER_SCAN, raster_bucket_scan_kernel, dim3(n_views), dim3(kBlock), 0, stream,
@@ -1159,7 +1163,7 @@ int ocrf_rasterize_forward(int P, int n_views, int H, int W, const float* means3
                        g_stamps, P, W, H, gy, static_cast<const int*>(starts), static_cast<const Rect*>(rects),
                        static_cast<const Rect*>(b_rect), static_cast<const unsigned long long*>(b_comp),
                        static_cast<const float2*>(xy), static_cast<const float4*>(conic_o), colors, bg,
-                       out_color, out_depth, out_final_T, out_n_contrib, st, BwdArgs{});
+                       out_color, out_depth, out_final_T, out_n_contrib, st, BwdArgs{}, views_per_set);
     return (int)hipGetLastError();
   }
   if (depth_mode == 0)
@@ -1168,15 +1172,27 @@ int ocrf_rasterize_forward(int P, int n_views, int H, int W, const float* means3
                  static_cast<const Rect*>(rects), static_cast<const Rect*>(b_rect),
                  static_cast<const unsigned long long*>(b_comp), static_cast<const float2*>(xy),
                  static_cast<const float4*>(conic_o), colors, bg, out_color, out_depth, out_final_T,
-                 out_n_contrib, st, BwdArgs{});
+                 out_n_contrib, st, BwdArgs{}, views_per_set);
   else
     ocrf::launch(OCRF_K_RASTER_BLEND, raster_blend_kernel<false, false, false>, bgrid, dim3(kBlock), lds,
                  stream, (unsigned long long*)nullptr, P, W, H, gy, static_cast<const int*>(starts),
                  static_cast<const Rect*>(rects), static_cast<const Rect*>(b_rect),
                  static_cast<const unsigned long long*>(b_comp), static_cast<const float2*>(xy),
                  static_cast<const float4*>(conic_o), colors, bg, out_color, out_depth, out_final_T,
-                 out_n_contrib, st, BwdArgs{});
+                 out_n_contrib, st, BwdArgs{}, views_per_set);
   return (int)hipGetLastError();
+}
+
+int ocrf_rasterize_forward(int P, int n_views, int H, int W, const float* means3D,
+                           const float* colors, const float* opacities, const float* scales,
+                           float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                           const float* cameras, const float* bg, int depth_mode, float* out_color,
+                           float* out_depth, float* out_final_T, uint32_t* out_n_contrib, int* radii,
+                           uint32_t* tiles_touched, int* status, void* workspace,
+                           size_t workspace_bytes, ocrf_stream_t stream_) {
+  return ocrf_rasterize_forward_sets(P, 1, n_views, H, W, means3D, colors, opacities, scales, scale_modifier, rotations,
+                                     cov3D_precomp, cameras, bg, depth_mode, out_color, out_depth, out_final_T,
+                                     out_n_contrib, radii, tiles_touched, status, workspace, workspace_bytes, stream_);
 }
 
 size_t ocrf_rasterize_backward_workspace_bytes(int P, int n_views) {
@@ -1228,7 +1244,7 @@ int ocrf_rasterize_backward(int P, int n_views, int H, int W, const float* means
   const dim3 xgrid((unsigned)((n_chunks + 7) / 8 * 8 * n_views));
   hipLaunchKernelGGL(raster_preprocess_kernel, xgrid, dim3(kBlock), 0, stream, P, n_views, n_chunks, W, H, gx, gy,
                      means3D, opacities, scales, scale_modifier, rotations, (const float*)nullptr, cams, vis_rec,
-                     vis_count, rects, xy, conic_o, radii, (unsigned*)nullptr, hist);
+                     vis_count, rects, xy, conic_o, radii, (unsigned*)nullptr, hist, n_views);
   hipLaunchKernelGGL(raster_bucket_scan_kernel, dim3(n_views), dim3(kBlock), 0, stream, static_cast<const int*>(hist),
                      starts, cursor, st);
   hipLaunchKernelGGL(raster_scatter_kernel, pgrid, dim3(kBlock), 0, stream, P, static_cast<const uint4*>(vis_rec),
@@ -1244,7 +1260,7 @@ int ocrf_rasterize_backward(int P, int n_views, int H, int W, const float* means
                static_cast<const Rect*>(rects), static_cast<const Rect*>(b_rect),
                static_cast<const unsigned long long*>(b_comp),
                static_cast<const float2*>(xy), static_cast<const float4*>(conic_o), colors, bg, (float*)nullptr,
-               (float*)nullptr, (float*)nullptr, (unsigned*)nullptr, st, bw);
+               (float*)nullptr, (float*)nullptr, (unsigned*)nullptr, st, bw, n_views);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   ocrf::launch(OCRF_K_RASTER_PRE_BWD, raster_preprocess_backward_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock),

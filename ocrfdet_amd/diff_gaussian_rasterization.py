@@ -165,6 +165,41 @@ def rasterize_views(means3D, colors, opacities, scales, rotations, viewmatrices,
     return out
 
 
+def rasterize_sets(means3D, colors, opacities, scales, rotations, packed_cameras, image_height, image_width, bg,
+                   scale_modifier=1.0, depth_mode='median', workspace_tag='raster'):
+    """``S`` Gaussian sets x ``V`` views each in one set of launches (C ABI ``ocrf_rasterize_forward_sets``):
+    means3D (S,P,3), colors (S,P,3), opacities (S,P[,1]), scales (S,P,3), rotations (S,P,4),
+    ``packed_cameras`` (S*V,36) from ``pack_cameras`` (view v renders set v // V).  Forward only.
+    -> dict like ``rasterize_views`` with a leading S*V view axis."""
+    _lib.require_cuda(means3D, colors, opacities, scales, rotations, packed_cameras, bg)
+    if means3D.dim() != 3 or means3D.size(2) != 3:
+        raise RuntimeError('means3D must have dimensions (num_sets, num_points, 3)')
+    dev = means3D.device
+    S, P = means3D.size(0), means3D.size(1)
+    NV = packed_cameras.size(0)
+    if NV % S:
+        raise RuntimeError('packed_cameras rows must be a multiple of the number of sets')
+    H, W = int(image_height), int(image_width)
+    means3D, colors, opac = _f32c(means3D), _f32c(colors), _f32c(opacities).reshape(S, P)
+    sc, rot, bg, cams = _f32c(scales), _f32c(rotations), _f32c(bg).reshape(3), _f32c(packed_cameras)
+    out = dict(color=torch.empty(NV, 3, H, W, device=dev), depth=torch.empty(NV, 1, H, W, device=dev),
+               final_T=torch.empty(NV, H, W, device=dev), n_contrib=torch.empty(NV, H, W, dtype=torch.int32, device=dev),
+               radii=torch.empty(NV, P, dtype=torch.int32, device=dev))
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        need = L.ocrf_rasterize_workspace_bytes(P, NV)
+        ws = _lib.workspace.get(dev, need, workspace_tag)
+        _lib.check(L.ocrf_rasterize_forward_sets(
+            P, S, NV // S, H, W, _lib.ptr(means3D), _lib.ptr(colors), _lib.ptr(opac), _lib.ptr(sc),
+            ctypes.c_float(scale_modifier), _lib.ptr(rot), _lib.ptr(None), _lib.ptr(cams), _lib.ptr(bg),
+            {'median': 0, 'mean': 1}[depth_mode], _lib.ptr(out['color']), _lib.ptr(out['depth']), _lib.ptr(out['final_T']),
+            _lib.ptr(out['n_contrib']), _lib.ptr(out['radii']), _lib.ptr(None), _lib.ptr(status), _lib.ptr(ws),
+            ctypes.c_size_t(ws.numel()), _lib.stream_ptr(dev)), 'ocrf_rasterize_forward_sets')
+    out['status'] = status
+    return out
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,

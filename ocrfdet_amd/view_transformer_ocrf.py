@@ -35,7 +35,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import bevpool, gaussian_renderer, hoa, index_prep, neck_ops
-from .diff_gaussian_rasterization import pack_cameras, rasterize_views
+from .diff_gaussian_rasterization import pack_cameras, rasterize_sets
 
 __all__ = ['OcRFViewTransformerFull', 'MS_CAM', 'ChannelAttention', 'SpatialAttention', 'ResCBAMBlock', 'ProbNet',
            'DualFeatFusion', 'BEVGeomAttention', 'ScaleFactorMLP', 'RotationFactorMLP', 'OpacityFactorMLP',
@@ -578,21 +578,22 @@ class OcRFViewTransformerFull(nn.Module):
             (opacity, scaling, rotation, color, sparse, alpha_lidar, render_N,
              render_depth_N) = self._neck_torch(input, geo, ht_feat, cam_idx_list)
 
-        render_G, render_depth_G = [], []
-        for bs in range(B):
-            if fused:          # the staged camera row straight into the C ABI: no per-call camera packing
-                if self._bg is None or self._bg.device != x.device:
-                    self._bg = torch.zeros(3, device=x.device)
-                o = rasterize_views(voxel_coor[bs], color[bs], opacity[bs], scaling[bs], rotation[bs], None, None, None,
-                                    None, H, W, self._bg, packed_cameras=cameras['packed'][bs:bs + 1])
-                img, dep = o['color'][0], o['depth'][0]
-            else:
+        if fused:
+            # every sample is a Gaussian set with one camera: ONE rasteriser call for the batch, fed with
+            # the staged camera rows (the reference loops samples, :1090-1153)
+            if self._bg is None or self._bg.device != x.device:
+                self._bg = torch.zeros(3, device=x.device)
+            o = rasterize_sets(voxel_coor, color, opacity, scaling, rotation, cameras['packed'], H, W, self._bg)
+            render_image_G_all, render_depth_G_all = o['color'], o['depth']
+        else:
+            render_G, render_depth_G = [], []
+            for bs in range(B):
                 cam = self._camera(geo, bs, cam_idx_list[bs])
                 cam = {k: (v.to(x.device) if torch.is_tensor(v) and v.dim() else v) for k, v in cam.items()}
                 img, dep = gaussian_renderer.render(cam, cam_idx_list[bs], voxel_coor[bs], color[bs], rotation[bs],
                                                     scaling[bs], opacity[bs], bg_color=[0, 0, 0])
-            render_G.append(img.unsqueeze(0)), render_depth_G.append(dep.unsqueeze(0))
-        render_image_G_all, render_depth_G_all = torch.cat(render_G), torch.cat(render_depth_G)
+                render_G.append(img.unsqueeze(0)), render_depth_G.append(dep.unsqueeze(0))
+            render_image_G_all, render_depth_G_all = torch.cat(render_G), torch.cat(render_depth_G)
         render_image = self.LinearWeightedImage(render_image_G_all, render_N)
         render_depth = self.LinearWeightedDepth(render_depth_G_all, render_depth_N)
         gt_images = imgs_wo_norm[torch.arange(B, device=x.device), cam_sel.long()] / 255.0

@@ -171,3 +171,27 @@ def test_argument_errors_and_empty(cuda):
                                colors_precomp=torch.zeros(0, 3, device=cuda), scales=torch.zeros(0, 3, device=cuda),
                                rotations=torch.zeros(0, 4, device=cuda))
     assert color.shape == (3, 8, 8) and float(color.abs().sum()) == 0 and radii.numel() == 0
+
+
+def test_gaussian_sets_match_per_set_calls(cuda):
+    """ocrf_rasterize_forward_sets: S sets x V views in one call == S separate calls, bit for bit."""
+    import torch
+    from ocrfdet_amd.diff_gaussian_rasterization import pack_cameras, rasterize_sets, rasterize_views
+    rng = np.random.default_rng(11)
+    S, V, P, H, W = 3, 2, 3000, 80, 112
+    sets = [helpers.random_gaussians(rng, P) for _ in range(S)]
+    cams = []
+    for v in range(V):
+        vm, pm, tfx, tfy = helpers.simple_camera(W, H, cam_pos=(0.5 * v, 0.0, -1.0 * v))
+        cams.append((vm, pm, tfx, tfy))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)   # noqa: E731
+    packed = pack_cameras(t(np.stack([c[0] for c in cams])), t(np.stack([c[1] for c in cams])),
+                          [c[2] for c in cams], [c[3] for c in cams], H, W, cuda)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=cuda)
+    st = [t(np.stack([s[i] for s in sets])) for i in range(5)]             # xyz, rgb, opac, scales, q
+    got = rasterize_sets(st[0], st[1], st[2], st[3], st[4], packed.repeat(S, 1), H, W, bg)
+    for s in range(S):
+        want = rasterize_views(st[0][s], st[1][s], st[2][s], st[3][s], st[4][s], None, None, None, None, H, W, bg,
+                               packed_cameras=packed)
+        for k in ('color', 'depth', 'final_T', 'n_contrib', 'radii'):
+            assert torch.equal(got[k][s * V:(s + 1) * V], want[k]), (s, k)
