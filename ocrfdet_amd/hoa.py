@@ -78,11 +78,28 @@ class HeightAttention(nn.Module):
                 _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_ptr(x.device)), 'ocrf_hoa_height_attention')
         return gate.view(B, C, 1, 1), gated
 
+    def _needs_grad(self, x):
+        """The HIP kernels are forward-only: whenever autograd is recording something that reaches this
+        module, the reference's op sequence runs as differentiable torch ops instead."""
+        return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+
+    def _forward_torch(self, x):
+        q = self.q_in
+        outs = [conv(x[:, i * q:(i + 1) * q].amax((2, 3), keepdim=True))
+                for i, conv in enumerate((self.conv1, self.conv2, self.conv3, self.conv4))]
+        return self.tanh(torch.cat(outs, dim=1))
+
     def forward(self, x):
+        _lib.require_cuda(x)               # GPU only, also for the differentiable formulation
+        if self._needs_grad(x):
+            return self._forward_torch(x)
         return self._run(x, False)[0]
 
     def gate_apply(self, x):
         """``self(x) * x`` in one pass (view_transformer_ocrf.py:499-514)."""
+        _lib.require_cuda(x)
+        if self._needs_grad(x):
+            return self._forward_torch(x) * x
         return self._run(x, True)[1]
 
 
@@ -115,7 +132,8 @@ class OpacityVoxelToBEVConverter(nn.Module):
         return nn.ConvTranspose2d(in_channels, out_channels, kernel_size=2, stride=2)
 
     def forward(self, x, position):
-        if not self.training and x.is_cuda:
+        if not self.training and x.is_cuda and not (torch.is_grad_enabled() and (
+                x.requires_grad or any(p.requires_grad for p in self.parameters()))):
             return self._forward_fused(x, position)
         # training mode (BatchNorm batch statistics): block by block, gates still in HIP
         enc1 = self.ca1.gate_apply(self.encoder1(x) + position)
@@ -253,6 +271,12 @@ class ObatinOpacityMask(nn.Module):          # sic: the reference's spelling
         self.sigmoid = nn.Sigmoid()
 
     def _run(self, x, opacity_bev, want_gated):
+        _lib.require_cuda(x, opacity_bev)
+        if torch.is_grad_enabled() and (x.requires_grad or opacity_bev.requires_grad or self.conv.weight.requires_grad):
+            # forward-only HIP kernels: under autograd the reference's ops (:236-242), differentiable
+            stats = torch.cat((x.mean(1, keepdim=True), x.amax(1, keepdim=True)), 1)
+            mask = self.sigmoid(self.conv(stats) + opacity_bev)
+            return mask, (x * mask if want_gated else None)
         return spatial_gate(self.conv.weight, x, opacity_bev, want_gated)
 
     def forward(self, x, opacity_bev):
@@ -380,7 +404,8 @@ def _hoa1_packed(m):
 
 
 def _hoa1_fusable(m, x):
-    return (x.is_cuda and not m.training and m.heads == 1 and m.offset_groups == 1 and m.downsample_factor == 4
+    return (x.is_cuda and not m.training and not (torch.is_grad_enabled() and (x.requires_grad or any(
+        p.requires_grad for p in m.parameters()))) and m.heads == 1 and m.offset_groups == 1 and m.downsample_factor == 4
             and m.to_q.in_channels == 13 and m.to_q.out_channels == 8 and m.to_offsets[0].kernel_size == (6, 6)
             and len(m.rel_pos_bias.mlp) == 3 and m.rel_pos_bias.mlp[0][0].out_features == 3)
 

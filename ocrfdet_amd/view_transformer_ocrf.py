@@ -399,6 +399,11 @@ class OcRFViewTransformerFull(nn.Module):
         self._rank_bufs = (index_prep._RankBuffers(), index_prep._RankBuffers())
         self._packs = {}
 
+    def _recording(self, *tensors):
+        if not torch.is_grad_enabled():
+            return False
+        return any(t is not None and t.requires_grad for t in tensors) or any(p.requires_grad for p in self.parameters())
+
     def _reference_depth_net(self, cfg):
         try:
             from mmdet3d.models.necks.view_transformer import DepthNet
@@ -548,7 +553,9 @@ class OcRFViewTransformerFull(nn.Module):
         imgs_wo_norm, dtype = input[9], x.dtype
         C, Zh, Y, X = self.out_channels, self.num_height, self.bev_h, self.bev_w
         H, W = self.input_size
-        fused = not (self.training and torch.is_grad_enabled())
+        # fused HIP kernels are forward-only and fold the BatchNorm running statistics: eval mode with
+        # nothing recorded by autograd; anything else takes the differentiable torch formulation
+        fused = not self.training and not self._recording(depth, tran_feat, feat_channels_last)
         geo = self._geo if (self.accelerate and self._geo is not None) else self._geometry(input, sync=not fused)
         depth5 = depth.reshape(B, N, self.D, Hf, Wf).float()
         if feat_channels_last is None:
@@ -670,7 +677,7 @@ class OcRFViewTransformerFull(nn.Module):
         x, mlp_input = input[0], input[7]
         B, N, C, H, W = x.shape
         y = self.depth_net(x.view(B * N, C, H, W), mlp_input, stereo_metas)
-        if y.is_cuda and not (self.training and torch.is_grad_enabled()):
+        if y.is_cuda and not self.training and not self._recording(y):
             depth, filter_depth, semantic, feat_cl = neck_ops.prefilter(y, self.D, self.out_channels,
                                                                         self.depth_threshold, self.semantic_threshold)
             bev_feat, _, bev_mask, extras = self.view_transform(input, filter_depth, None, feat_cl)

@@ -50,17 +50,20 @@ def test_opacity_mask_gate_gpu(cuda, g):
     m = hoa.ObatinOpacityMask().to(cuda)
     m.load_state_dict(_sd(g, 'mask'))
     x, ob = torch.from_numpy(g['mask_in_x']).to(cuda), torch.from_numpy(g['mask_in_opacity']).to(cuda)
-    mask, gated = m.gate(x, ob)
+    with torch.no_grad():                                                                         # the HIP kernels
+        mask, gated = m.gate(x, ob)
+        plain = m(x, ob)
     np.testing.assert_allclose(mask.cpu().numpy(), g['mask_out'], rtol=1e-4, atol=1e-5)          # reference
     np.testing.assert_allclose(gated.cpu().numpy(), g['mask_gated'], rtol=1e-4, atol=1e-5)
-    np.testing.assert_allclose(m(x, ob).cpu().numpy(), ohoa.opacity_mask(g['mask_in_x'], g['mask_in_opacity'], g, 'mask'),
+    np.testing.assert_allclose(plain.cpu().numpy(), ohoa.opacity_mask(g['mask_in_x'], g['mask_in_opacity'], g, 'mask'),
                                rtol=1e-4, atol=1e-5)                                             # oracle
     # full BEV size of the headline config, ragged against the 256-pixel workgroups
     rng = np.random.default_rng(0)
     xb = rng.standard_normal((2, 80, 200, 200)).astype(np.float32)
     obb = rng.standard_normal((2, 1, 200, 200)).astype(np.float32)
     want = ohoa.opacity_mask(xb, obb, g, 'mask')
-    mask, gated = m.gate(torch.from_numpy(xb).to(cuda), torch.from_numpy(obb).to(cuda))
+    with torch.no_grad():
+        mask, gated = m.gate(torch.from_numpy(xb).to(cuda), torch.from_numpy(obb).to(cuda))
     np.testing.assert_allclose(mask.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(gated.cpu().numpy(), xb * want, rtol=1e-4, atol=1e-5)
 
@@ -71,10 +74,11 @@ def test_height_attention_gpu(cuda, g):
         m = hoa.HeightAttention(ch, ch, 1).to(cuda)
         m.load_state_dict(_sd(g, f'ha{ch}'))
         x = torch.from_numpy(g[f'ha{ch}_in']).to(cuda)
-        gate = m(x)
+        with torch.no_grad():
+            gate, gated = m(x), m.gate_apply(x)
         assert gate.shape == (2, ch, 1, 1)
         np.testing.assert_allclose(gate.cpu().numpy(), g[f'ha{ch}_out'], rtol=1e-4, atol=1e-6)
-        np.testing.assert_allclose(m.gate_apply(x).cpu().numpy(), g[f'ha{ch}_out'] * g[f'ha{ch}_in'], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(gated.cpu().numpy(), g[f'ha{ch}_out'] * g[f'ha{ch}_in'], rtol=1e-4, atol=1e-6)
 
 
 @pytest.mark.gpu
@@ -130,3 +134,38 @@ def test_hoa1_gpu(cuda, g):
         ref = hoa.hoa1(m, op.reshape(-1, 1), al, 13, 200, 200)
         m.eval()
     np.testing.assert_allclose(fused.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_hoa_modules_keep_gradients_under_autograd():
+    """The HIP kernels are forward-only: with autograd recording, every HOA module must fall back to
+    differentiable torch ops (a silent gradient cut would break training as a drop-in) and agree with
+    its fused forward."""
+    import torch
+    from ocrfdet_amd import hoa
+    torch.manual_seed(0)
+    dev = torch.device('cuda:0')
+    ha = hoa.HeightAttention(8, 8, 1).to(dev)
+    x = torch.randn(2, 8, 12, 10, device=dev, requires_grad=True)
+    y = ha.gate_apply(x)
+    y.sum().backward()
+    assert x.grad is not None and ha.conv1[0].weight.grad is not None and float(x.grad.abs().sum()) > 0
+    with torch.no_grad():
+        assert torch.allclose(ha.gate_apply(x), y, atol=1e-6)
+    om = hoa.ObatinOpacityMask().to(dev)
+    f = torch.randn(2, 16, 12, 10, device=dev, requires_grad=True)
+    ob = torch.randn(2, 1, 12, 10, device=dev, requires_grad=True)
+    mask, gated = om.gate(f, ob)
+    gated.sum().backward()
+    assert f.grad is not None and ob.grad is not None and om.conv.weight.grad is not None
+    with torch.no_grad():
+        m2, g2 = om.gate(f, ob)
+    assert torch.allclose(m2, mask, atol=1e-6) and torch.allclose(g2, gated, atol=1e-5)
+    v2b = hoa.OpacityVoxelToBEVConverter(13).to(dev).eval()
+    xin = torch.randn(1, 13, 16, 16, device=dev, requires_grad=True)
+    pos = torch.randn(1, 4, 16, 16, device=dev)
+    out = v2b(xin, pos)
+    out.sum().backward()
+    assert xin.grad is not None and float(xin.grad.abs().sum()) > 0
+    with torch.no_grad():
+        assert torch.allclose(v2b(xin, pos), out, atol=1e-5)
