@@ -77,6 +77,11 @@ def grid_sample_bilinear(img, px, py):
     (C,H,W) at pixel coordinates produced exactly as :929-931 + ATen's un-normalisation do:
     ``xn = (px/(W-1))*2-1`` then ``ix = ((xn+1)/2)*(W-1)``, all float32."""
     C, H, W = img.shape
+    with np.errstate(invalid='ignore', over='ignore'):      # non-finite coordinates take the zero-padding path
+        return _grid_sample_bilinear(img, px, py, C, H, W)
+
+
+def _grid_sample_bilinear(img, px, py, C, H, W):
     xn = (px.astype(f32) / f32(W - 1)) * f32(2) - f32(1)
     yn = (py.astype(f32) / f32(H - 1)) * f32(2) - f32(1)
     ix = ((xn + f32(1)) / f32(2)) * f32(W - 1)

@@ -294,3 +294,64 @@ def test_dual_feat_fusion(core):
         cf = m.fuser.ca(torch.cat((a, b), 1))
         want = cf * a + (1 - cf) * b
     close(fused, want.cpu().numpy(), 1e-5, 'fuser ragged vs torch ops')
+
+
+@pytest.mark.parametrize('zh', [1, 2, 4, 6, 8, 13])
+def test_gauss_heads_every_supported_height_count(zh):
+    """Every register-tile instantiation of ocrf_gauss_heads (heights per pillar) against torch layers."""
+    from ocrfdet_amd import neck_ops
+    from ocrfdet_amd import view_transformer_ocrf as vto
+    torch.manual_seed(zh)
+    dev = torch.device('cuda:0')
+    vfe = vto.VoxelFeatureExtractor(1, zh).to(dev).eval()
+    bn = vfe.conv[1]
+    bn.running_mean.normal_(0, 0.2), bn.running_var.uniform_(0.5, 1.5)
+    heads = [cls(80, 4, o).to(dev) for cls, o in ((vto.ScaleFactorMLP, 3), (vto.RotationFactorMLP, 4),
+                                                   (vto.OpacityFactorMLP, 1), (vto.ColorFactorMLPGaussian, 3))]
+    bev = torch.randn(1, 80, 5, 27, device=dev)
+    rgb = torch.rand(1, zh, 135, 3, device=dev) * 255
+    prm = neck_ops.pack_gauss_head_params(vfe, *heads)
+    op, sc, rot, col = neck_ops.gauss_heads(bev, rgb, prm, zh)
+    with torch.no_grad():
+        vf = vfe(bev.permute(0, 2, 3, 1).unsqueeze(1)).reshape(1, zh * 135, -1)
+        want = (heads[2](vf), heads[0](vf), heads[1](vf), heads[3](torch.cat((vf, rgb.reshape(1, -1, 3) / 255.0), -1)))
+    for got, ref, name in zip((op, sc, rot, col), want, ('opacity', 'scales', 'rotations', 'colour')):
+        close(got, ref.cpu().numpy(), 1e-5, f'{name} (Zh={zh})')
+
+
+@pytest.mark.parametrize('D', [5, 40, 200])
+def test_prefilter_every_depth_tile(D):
+    """The three register-tile sizes of the pre-filter (D <= 32, <= 128, <= 512), 1-pixel-wide map."""
+    from ocrfdet_amd import neck_ops
+    rng = np.random.default_rng(D)
+    x = (rng.standard_normal((2, D + 2 + 12, 3, 1)) * 2).astype(np.float32)
+    depth, fdepth, sem, feat = neck_ops.prefilter(torch.from_numpy(x).cuda(), D, 12, 1.0 / D, 0.3)
+    wd, wfd, ws, wf = oc.prefilter(x, D, 12, 1.0 / D, 0.3)
+    close(depth, wd, 1e-6, 'depth'), close(sem, ws, 1e-6, 'semantic')
+    ok = np.abs(wd - np.float32(1.0 / D)) > 1e-6
+    assert np.array_equal(fdepth.cpu().numpy()[ok] == 0, wfd[ok] == 0)
+    sure = np.abs(ws[:, 1] - 0.3) > 1e-6
+    assert np.array_equal(feat.cpu().numpy()[sure], np.ascontiguousarray(wf.transpose(0, 2, 3, 1))[sure])
+
+
+def test_sampling_and_retain_edge_cases():
+    """One camera, coordinates far outside / non-finite, nothing valid, every point valid."""
+    from ocrfdet_amd import neck_ops
+    rng = np.random.default_rng(2)
+    B, N, Zh, Q, H, W = 2, 1, 3, 50, 9, 14
+    imgs = rng.uniform(0, 255, (B, N, 3, H, W)).astype(np.float32)
+    pix = np.stack([rng.uniform(-3, W + 3, (B, N, Zh, Q)), rng.uniform(-3, H + 3, (B, N, Zh, Q))], -1).astype(np.float32)
+    pix[0, 0, 0, 0] = (np.inf, 2.0)
+    pix[0, 0, 0, 1] = (np.nan, np.nan)
+    pix[0, 0, 0, 2] = (1e30, -1e30)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()      # noqa: E731
+    for mask in (np.ones((B, N, Zh, Q, 1), bool), np.zeros((B, N, Zh, Q, 1), bool), rng.random((B, N, Zh, Q, 1)) < 0.5):
+        got = neck_ops.pillar_sample_mean(t(imgs), t(pix), t(mask)).cpu().numpy()
+        want = oc.color_voxels_avg(oc.lidar_points_to_image_values(pix, imgs, mask), mask)
+        fin = np.isfinite(want)
+        assert np.isfinite(got).all() or not fin.all()
+        np.testing.assert_allclose(got[fin], want[fin], atol=2e-4)
+        inside = mask.copy()
+        inside[..., 0] &= (pix[..., 0] >= 0) & (pix[..., 0] < W) & (pix[..., 1] >= 0) & (pix[..., 1] < H)
+        r_got = neck_ops.retain_valid_pixels(t(imgs), t(pix), t(inside)).cpu().numpy()
+        assert np.array_equal(r_got, oc.retain_valid_pixels(imgs, pix, inside))
