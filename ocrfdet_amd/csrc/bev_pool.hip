@@ -83,17 +83,21 @@ __global__ __launch_bounds__(kBlock) void bev_pool_interval_kernel(
 // code: 1 | (local interval index << 2) = last point of a whole interval -> store to its dst
 // row; 2 = last point of a head piece -> keep in a register; tail pieces are the leftover.
 // ---------------------------------------------------------------------------------------------
+// Row gathers in flight per lane: 2 x kBatch (double-buffered).  8 + 8 cost 202 VGPRs = 2 waves per SIMD =
+// 2 workgroups per CU, and the latency-type phases around the loop (staging, interval search, combine:
+// 57 % of a workgroup's cycles) found nothing to overlap with; 4 + 4 fit 4 waves per SIMD.
+constexpr int kBatch = 4;
 struct Batch {
-  float4 v[8];
-  int2 wc[8];
+  float4 v[kBatch];
+  int2 wc[kBatch];
 };
 
 __device__ __forceinline__ void load_batch(Batch& q, int l0, const int* s_rf, const int2* s_wc,
                                            const float4* __restrict__ feat4, int c4, int lg) {
 #pragma unroll
-  for (int k = 0; k < 8; ++k) q.v[k] = feat4[(long)s_rf[l0 + k] * c4 + lg];
+  for (int k = 0; k < kBatch; ++k) q.v[k] = feat4[(long)s_rf[l0 + k] * c4 + lg];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) q.wc[k] = s_wc[l0 + k];
+  for (int k = 0; k < kBatch; ++k) q.wc[k] = s_wc[l0 + k];
 }
 
 template <bool STAMP, int kSub>
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(kBlock) void bev_pool_fwd_chunked_kernel(
     float4 head_acc = acc;
     auto consume = [&](const Batch& q, int l0) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < kBatch; ++k) {
         const int2 wc = q.wc[k];
         acc = fma4(q.v[k], __int_as_float(wc.x), acc);
         const int code = wc.y;
@@ -251,12 +255,12 @@ __global__ __launch_bounds__(kBlock) void bev_pool_fwd_chunked_kernel(
     Batch A, B;
     const int l0 = gb * kSub;
     load_batch(A, l0, s_rf, s_wc, feat4, c4, lg);
-#pragma unroll
-    for (int b = 0; b < kSub / 8; b += 2) {
-      load_batch(B, l0 + 8 * (b + 1), s_rf, s_wc, feat4, c4, lg);
-      consume(A, l0 + 8 * b);
-      if (b + 2 < kSub / 8) load_batch(A, l0 + 8 * (b + 2), s_rf, s_wc, feat4, c4, lg);
-      consume(B, l0 + 8 * (b + 1));
+#pragma nounroll      // unrolled, the scheduler hoists every gather to the top: 202 VGPRs, 2 waves per SIMD
+    for (int b = 0; b < kSub / kBatch; b += 2) {
+      load_batch(B, l0 + kBatch * (b + 1), s_rf, s_wc, feat4, c4, lg);
+      consume(A, l0 + kBatch * b);
+      if (b + 2 < kSub / kBatch) load_batch(A, l0 + kBatch * (b + 2), s_rf, s_wc, feat4, c4, lg);
+      consume(B, l0 + kBatch * (b + 1));
     }
     s_part[(2 * gb) * c4 + lg] = head_acc;       // head piece (meaningful iff s_meta says so)
     s_part[(2 * gb + 1) * c4 + lg] = acc;        // tail piece: what the last interval left
