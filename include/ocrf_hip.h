@@ -149,7 +149,7 @@ int ocrf_bev_pool_v2_grad(int c, int n_intervals, const float *out_grad, const f
  *   out_color (n_views,3,H,W)  out_depth (n_views,H,W)  out_final_T (n_views,H,W) [= 1 - accumulated
  *   opacity]  out_n_contrib (n_views,H,W)  radii (n_views,P)  tiles_touched (n_views,P) or NULL
  *   status (device int, may be NULL; written by the call): informational.  Bit 1 (value 2) is set when
- *   some tile met more than ~3 000 Gaussians inside ONE 0.2 %-wide depth bucket, more than the in-LDS
+ *   some tile met more than ~1 000 Gaussians inside ONE 0.2 %-wide depth bucket, more than the in-LDS
  *   sort holds; such a tile is then blended by an exact but slower streaming selection over that
  *   bucket.  Results are exact either way; bit 0 is never set (reserved).
  * P == 0 zero-fills the outputs like the reference (rasterize_points.cu:68-69).

@@ -42,7 +42,7 @@ constexpr int kBuckets = 8192;               // depth buckets per view
 constexpr int kBucketShift = 14;             // bucket = (depth bits >> 14) - base: 9 mantissa bits
 constexpr unsigned kBucketBase = 0x3E4CCCCDu >> kBucketShift;   // depth > 0.2f always (auxiliary.h:154)
 constexpr int kChunk = 2048;                 // Gaussians per workgroup in preprocess / scatter
-constexpr int kCapRec = 4096;                // LDS record capacity of the blend kernel
+constexpr int kCapRec = 2048;                // LDS record capacity of the blend kernel (28 KB with the stage: 4 workgroups per CU)
 constexpr int kStage = 256;                  // payload entries staged per blend batch
 constexpr int kScanUnroll = 4;               // rect batches in flight in the scan
 constexpr unsigned long long kPad = ~0ull;
