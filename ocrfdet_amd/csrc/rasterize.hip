@@ -84,7 +84,11 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
   // Workgroup -> (chunk, view), XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so
   // ids L and L+8 share an L2; the V views of a chunk get ids 8 apart and run back to back on one
   // XCD, which reads the chunk's 90 KB of Gaussian parameters from HBM once instead of V times.
-  __shared__ int s_hist[kBuckets];
+  // two 16-bit counters per word (a workgroup counts at most kChunk = 2048 Gaussians: no carry):
+  // 16 KB instead of 32 KB of LDS, so the 92-VGPR limit (5 workgroups per CU), not the LDS (4), sets
+  // the occupancy
+  static_assert(kChunk < 65536, "16-bit bucket counters");
+  __shared__ unsigned s_hist[kBuckets / 2];
   __shared__ int s_wsum[kBlock / 64];
   __shared__ int s_base;
   const int L = blockIdx.x;
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
   const int chunk = (kq / n_views) * 8 + (L & 7);
   const int v = kq % n_views;
   if (chunk >= n_chunks) return;
-  for (int i = threadIdx.x; i < kBuckets; i += kBlock) s_hist[i] = 0;
+  for (int i = threadIdx.x; i < kBuckets / 2; i += kBlock) s_hist[i] = 0;
   __syncthreads();
   unsigned key_of[kChunk / kBlock];
   Rect rect_of[kChunk / kBlock];
@@ -232,7 +236,10 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
     }
     }   // !surely_empty
   }
-  if (key != 0xFFFFFFFFu) atomicAdd(&s_hist[bucket_of(key)], 1);
+  if (key != 0xFFFFFFFFu) {
+    const int bk = bucket_of(key);
+    atomicAdd(&s_hist[bk >> 1], (bk & 1) ? 0x10000u : 1u);
+  }
   key_of[it] = key;
   radii[o] = my_radii;
   if (tiles_touched) tiles_touched[o] = touched;
@@ -269,9 +276,10 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
                                             (unsigned)rc.x1 | ((unsigned)rc.y1 << 16));
     ++pos;
   }
-  for (int i = threadIdx.x; i < kBuckets; i += kBlock) {
-    const int c = s_hist[i];
-    if (c) atomicAdd(&hist[v * kBuckets + i], c);
+  for (int i = threadIdx.x; i < kBuckets / 2; i += kBlock) {
+    const unsigned c = s_hist[i];
+    if (c & 0xFFFFu) atomicAdd(&hist[v * kBuckets + 2 * i], (int)(c & 0xFFFFu));
+    if (c >> 16) atomicAdd(&hist[v * kBuckets + 2 * i + 1], (int)(c >> 16));
   }
 }
 
