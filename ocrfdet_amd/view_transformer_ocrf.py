@@ -29,7 +29,6 @@ configs/ocrfdet/ocrfdet.py:259-337), assembled MI355X-first:
 import math
 import random
 
-import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import nn

@@ -1,5 +1,5 @@
 """Diagnostic: cProfile of the host side of one neck step (launch-bound at small batch)."""
-import cProfile, pstats, sys, os, torch, random
+import cProfile, pstats, sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ocrfdet_amd import hotpath, synthetic
 cfg = synthetic.CONFIGS['cfg2_6cam_2frame_bev200x200_render_hoa']
