@@ -355,3 +355,42 @@ def test_sampling_and_retain_edge_cases():
         inside[..., 0] &= (pix[..., 0] >= 0) & (pix[..., 0] < W) & (pix[..., 1] >= 0) & (pix[..., 1] < H)
         r_got = neck_ops.retain_valid_pixels(t(imgs), t(pix), t(inside)).cpu().numpy()
         assert np.array_equal(r_got, oc.retain_valid_pixels(imgs, pix, inside))
+
+
+def test_full_size_neck_fused_vs_torch_formulation():
+    """BASELINE configs[2] size (6 cams x 2 frames, 256x704, BEV 200x200, 520 000 Gaussians per sample):
+    the fused HIP neck against the reference's op sequence run as plain torch ops on the same GPU
+    (materialising the (B,13,Y,X,80) voxel feature and the 12 x (80,256,704) NeRF feature images), with
+    random-init weights of the reference architecture.  Tolerance 1e-4 (north_star)."""
+    from ocrfdet_amd import hotpath, synthetic
+    cfg = synthetic.CONFIGS['cfg2_6cam_2frame_bev200x200_render_hoa']
+    neck = hotpath.NeckPath(cfg, torch.device('cuda:0'), accelerate=True)
+    m = neck.module
+    cams = [2, 5]
+    with torch.no_grad():
+        d, fd, s, fcl = neck._ops.prefilter(neck.depthnet_out, m.D, m.out_channels, m.depth_threshold, m.semantic_threshold)
+        want_d = neck.depthnet_out[:, :m.D].softmax(1)
+        close(d, want_d.cpu().numpy(), 1e-6, 'depth softmax at full size')
+        m.pre_compute(neck.inputs)
+        fused = m.view_transform_core(neck.inputs, fd, None, fcl, cam_idx_list=cams)
+        m.training = True                        # top level only: the torch formulation, BatchNorm still in eval
+        try:
+            tran = fcl.permute(0, 3, 1, 2).contiguous()
+            plain = m.view_transform_core(neck.inputs, fd, tran, None, cam_idx_list=cams)
+        finally:
+            m.training = False
+    close(fused[0], plain[0].cpu().numpy(), 1e-4, 'bev_feat')
+    close(fused[2], plain[2].cpu().numpy(), 1e-4, 'bev_mask_logit')
+    names = ['render_imgs', 'gt_images', 'render_G', 'render_N', 'opacity_alpha_view', None, 'render_depth',
+             'render_depth_G', 'render_depth_N']
+    for i, name in enumerate(names):
+        if name is None:
+            continue
+        a, b = fused[3][i], plain[3][i]
+        dlt = (a - b).abs()
+        if name in ('render_imgs', 'render_G', 'render_depth', 'render_depth_G'):
+            # the rasteriser blends ~100 Gaussians per pixel: parameters that differ by 1e-6 can move a
+            # pixel's early-termination point; allow a vanishing share of such pixels
+            assert float((dlt > 1e-4).float().mean()) < 1e-3 and float(dlt.max()) < 5e-2, name
+        else:
+            assert float(dlt.max()) <= 1e-4, f'{name}: {float(dlt.max()):.3e}'
