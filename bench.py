@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL); gloo only for plumbing tests')
     ap.add_argument('--no-overlap', action='store_true',
                     help='run the renders on the main stream instead of beside the pools + HOA on a side HIP stream')
+    ap.add_argument('--no-graph', action='store_true',
+                    help="--scope neck: issue the step kernel by kernel instead of replaying it as one hipGraph")
     ap.add_argument('--scope', choices=('hotpath', 'neck'), default='hotpath',
                     help="'hotpath': pools (+ one rendered view per camera + HOA) — the headline step; 'neck': the whole "
                          "OcRFViewTransformerFull.view_transform (one rendered view per sample, like the reference)")
@@ -116,20 +118,35 @@ def bench_neck(args, cfg, dev, world, rank):
     import torch.distributed as dist
     from ocrfdet_amd import _lib, hotpath
     neck = hotpath.NeckPath(cfg, dev, accelerate=args.index_prep == 'cached', seed=rank)
+    graphed = args.index_prep == 'cached' and not args.no_graph
     for _ in range(args.warmup):
         neck.step()
-    timer = _lib.KernelTimer(_lib.K_BEV_POOL_FWD, 2 * args.steps)
+    step = neck.step
+    if graphed:
+        # the whole step as ONE hipGraph launch; the random camera of each sample is staged into static
+        # device tensors before every replay (hotpath.NeckPath.capture)
+        neck.capture()
+        step = neck.step_graphed
+        for _ in range(3):
+            step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    timer.arm()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        neck.step()
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    # kernel events cannot bracket launches inside a graph replay: the pooling kernel is timed over a
+    # short eager run of the same step right after the timed region
+    timer = _lib.KernelTimer(_lib.K_BEV_POOL_FWD, 64)
+    torch.cuda.synchronize()
+    timer.arm()
+    for _ in range(min(16, args.steps)):
+        neck.step()
+    torch.cuda.synchronize()
     timer.disarm()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -157,6 +174,7 @@ def bench_neck(args, cfg, dev, world, rank):
                           'bev': list(cfg.bev_xyz), 'channels': cfg.channels, 'depth_bins': cfg.D,
                           'stages': 'prefilter+lss_pool+ht_pool+colour/alpha sampling+gauss heads+nerf branch+render+hoa+bev fusion',
                           'views_per_step': neck.views_per_step, 'render_camera': 'reference',
+                          'launch': 'one hipGraph replay per step' if graphed else 'eager (kernel by kernel)',
                           'index_prep': 'cached (accelerate=True)' if args.index_prep == 'cached' else 'per step, HIP (accelerate=False)',
                           'sharding': 'none' if world == 1 else f'{world} ranks x whole samples, no data-path collective'},
                'roofline': {'bound': 'hbm', 'kernel': timer.kernel_name, 'achieved': achieved, 'peak': HBM_PEAK_GBS,

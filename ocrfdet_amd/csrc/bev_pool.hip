@@ -650,7 +650,7 @@ int nchw_impl(int c, int n_intervals, int n_points, const int* counts, const flo
   char* ws = static_cast<char*>(workspace);
   float* rows = reinterpret_cast<float*>(ws + g.rows_off);
   int* row_of_vox = reinterpret_cast<int*>(ws + g.map_off);
-  hipError_t err = hipMemsetAsync(row_of_vox, 0, (size_t)n_vox * sizeof(int), stream);
+  hipError_t err = ocrf::zero_async(row_of_vox, (size_t)n_vox * sizeof(int), stream);
   if (err != hipSuccess) return (int)err;
   if (n_intervals > 0 && n_points > 0) {
     if (!depth || !feat || !ranks_depth || !ranks_feat || !ranks_bev || !interval_starts ||
@@ -700,7 +700,7 @@ int ocrf_bev_pool_v2_check_intervals(int n_intervals, int n_points, const int* i
                                      ocrf_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (n_intervals < 0 || n_points < 0 || !flag) return (int)hipErrorInvalidValue;
-  hipError_t err = hipMemsetAsync(flag, 0, sizeof(int), stream);
+  hipError_t err = ocrf::zero_async(flag, sizeof(int), stream);
   if (err != hipSuccess || n_intervals == 0) return (int)err;
   if (!interval_starts || !interval_lengths) return (int)hipErrorInvalidValue;
   const unsigned grid = (unsigned)((n_intervals + kBlock - 1) / kBlock);

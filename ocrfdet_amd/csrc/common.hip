@@ -20,7 +20,24 @@ Timer* g_armed = nullptr;
 
 }  // namespace
 
+namespace {
+
+__global__ void zero_words_kernel(unsigned* __restrict__ dst, size_t n_words) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_words) dst[i] = 0u;
+}
+
+}  // namespace
+
 namespace ocrf {
+
+hipError_t zero_async(void* dst, size_t bytes, hipStream_t stream) {
+  const size_t n = bytes / 4;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                     static_cast<unsigned*>(dst), n);
+  return hipGetLastError();
+}
 
 bool timer_next(int kernel_id, hipEvent_t* start, hipEvent_t* stop) {
   if (!g_armed) return false;   // fast path: no lock when no timer is armed

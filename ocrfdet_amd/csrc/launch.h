@@ -23,4 +23,11 @@ inline void launch(int kernel_id, F kernel, dim3 grid, dim3 block, size_t lds, h
   }
 }
 
+// Zero-fill of `bytes` (a multiple of 4, dst 4-byte aligned) as an ordinary kernel instead of
+// hipMemsetAsync: in a captured hipGraph the memset becomes a memset NODE, and replaying a graph that
+// holds memset nodes after ANY intervening hipMemcpyAsync on the stream ended in GPU memory faults on
+// ROCm 7.2 / gfx950 (found by bisecting a captured neck step: kernel-only graphs survive the same
+// sequence).  A kernel is also cheaper than the memset path for these sizes (32-320 KB).
+hipError_t zero_async(void* dst, size_t bytes, hipStream_t stream);
+
 }  // namespace ocrf

@@ -1119,10 +1119,10 @@ int ocrf_rasterize_forward_sets(int P, int n_sets, int views_per_set, int H, int
     return (int)hipErrorInvalidValue;
   const size_t npix = (size_t)H * W * n_views;
   if (P == 0) {   // rasterize_points.cu:68-69: zero-filled outputs, nothing launched
-    hipError_t e = hipMemsetAsync(out_color, 0, npix * 3 * sizeof(float), stream);
-    if (e == hipSuccess) e = hipMemsetAsync(out_depth, 0, npix * sizeof(float), stream);
-    if (e == hipSuccess) e = hipMemsetAsync(out_final_T, 0, npix * sizeof(float), stream);
-    if (e == hipSuccess) e = hipMemsetAsync(out_n_contrib, 0, npix * sizeof(uint32_t), stream);
+    hipError_t e = ocrf::zero_async(out_color, npix * 3 * sizeof(float), stream);
+    if (e == hipSuccess) e = ocrf::zero_async(out_depth, npix * sizeof(float), stream);
+    if (e == hipSuccess) e = ocrf::zero_async(out_final_T, npix * sizeof(float), stream);
+    if (e == hipSuccess) e = ocrf::zero_async(out_n_contrib, npix * sizeof(uint32_t), stream);
     return (int)e;
   }
   if (!means3D || !colors || !opacities || !radii || (!cov3D_precomp && (!scales || !rotations)))
@@ -1146,7 +1146,7 @@ int ocrf_rasterize_forward_sets(int P, int n_sets, int views_per_set, int H, int
   const Camera* cams = reinterpret_cast<const Camera*>(cameras);
 
   int* vis_count = hist + (size_t)n_views * kBuckets;
-  hipError_t e = hipMemsetAsync(hist, 0, (size_t)n_views * (kBuckets + 1) * sizeof(int), stream);
+  hipError_t e = ocrf::zero_async(hist, (size_t)n_views * (kBuckets + 1) * sizeof(int), stream);
   if (e != hipSuccess) return (int)e;
   const int n_chunks = (P + kChunk - 1) / kChunk;
   const dim3 pgrid(n_chunks, n_views);
@@ -1244,8 +1244,8 @@ int ocrf_rasterize_backward(int P, int n_views, int H, int W, const float* means
   const Camera* cams = reinterpret_cast<const Camera*>(cameras);
   // rebuild the bucket-ordered lists exactly as the forward did (same kernels, same inputs)
   int* vis_count = hist + (size_t)n_views * kBuckets;
-  hipError_t e = hipMemsetAsync(hist, 0, (size_t)n_views * (kBuckets + 1) * sizeof(int), stream);
-  if (e == hipSuccess) e = hipMemsetAsync(acc, 0, (size_t)n_views * P * 9 * sizeof(float), stream);
+  hipError_t e = ocrf::zero_async(hist, (size_t)n_views * (kBuckets + 1) * sizeof(int), stream);
+  if (e == hipSuccess) e = ocrf::zero_async(acc, (size_t)n_views * P * 9 * sizeof(float), stream);
   if (e != hipSuccess) return (int)e;
   const int n_chunks = (P + kChunk - 1) / kChunk;
   const dim3 pgrid(n_chunks, n_views);

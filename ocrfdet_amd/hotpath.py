@@ -322,15 +322,9 @@ class NeckPath:
         """Capture ``step`` into a hipGraph.  The only per-step host decision — the random camera of each
         sample (view_transformer_ocrf.py:1081) — lives in two small static device tensors that
         ``step_graphed`` refreshes before every replay."""
-        import os
         m = self.module
         if not m.accelerate:
             raise RuntimeError('graph capture needs accelerate=True (geometry cached across steps)')
-        if os.environ.get('OCRF_EXPERIMENTAL_GRAPH') != '1':
-            # OPEN ISSUE (DESIGN.md section 7): every stage captures and replays alone at cfg2, and the
-            # whole step does at the 48x48 test size, but the whole step at cfg2 ended in a GPU memory
-            # fault on replay.  Until the cause is found the capture is opt-in and not used by bench.py.
-            raise RuntimeError('NeckPath.capture is experimental: set OCRF_EXPERIMENTAL_GRAPH=1 to use it')
         self.step()                                               # geometry, packs, workspaces, MIOpen algorithms
         self._cams = m.stage_cameras(m._geo, [0] * self.batch, self.device)
 

@@ -83,6 +83,20 @@ class ChannelAttention(nn.Module):
         return self.sigmoid(self.fc(x.mean((2, 3), keepdim=True)) + self.fc(x.amax((2, 3), keepdim=True)))
 
 
+_ZEROS = {}
+
+
+def _zeros(shape, like):
+    """A persistent all-zero tensor per (shape, device, dtype): read-only operand of fused kernels.  Not
+    ``torch.zeros`` per call: that is a memset, and memset NODES make a captured hipGraph of the step
+    fault on replay after any intervening copy (csrc/launch.h, zero_async)."""
+    key = (tuple(shape), like.device, like.dtype)
+    t = _ZEROS.get(key)
+    if t is None:
+        t = _ZEROS[key] = torch.zeros(shape, device=like.device, dtype=like.dtype)
+    return t
+
+
 def _spatial_logits(x, conv):
     return conv(torch.cat((x.mean(1, keepdim=True), x.amax(1, keepdim=True)), 1))
 
@@ -114,7 +128,7 @@ class ResCBAMBlock(nn.Module):
         out = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
         out = self.ca(out) * out
         if out.is_cuda and not torch.is_grad_enabled():
-            out = hoa.spatial_gate(self.sa.conv1.weight, out, torch.zeros_like(out[:, :1]), True)[1]
+            out = hoa.spatial_gate(self.sa.conv1.weight, out, _zeros((out.shape[0], 1) + out.shape[2:], out), True)[1]
         else:
             out = self.sa(out) * out
         res = x if self.downsample is None else self.downsample(x)
@@ -608,7 +622,7 @@ class OcRFViewTransformerFull(nn.Module):
         opacity_alpha = hoa.hoa1(self.defor_cross_attention, opacity.reshape(-1, 1), alpha_lidar, Zh, Y, X)
 
         channel_feat = self.fuser(lss_feat, ht_feat)
-        zeros = torch.zeros((B, Y, X), device=x.device).to(dtype)
+        zeros = _zeros((B, Y, X), x)            # positional encodings only read its shape / device
         bev_mask_logit = self.prob(self.positional_encoding(zeros).to(dtype) + channel_feat)
         geom_feat = self.geom_att.gate(channel_feat, bev_mask_logit)
         opacity_alpha_view = self.OpacityVoxelToBEV(opacity_alpha, self.positional_encoding1(zeros).to(dtype))

@@ -394,3 +394,28 @@ def test_full_size_neck_fused_vs_torch_formulation():
             assert float((dlt > 1e-4).float().mean()) < 1e-3 and float(dlt.max()) < 5e-2, name
         else:
             assert float(dlt.max()) <= 1e-4, f'{name}: {float(dlt.max()):.3e}'
+
+
+def test_graph_captured_step_matches_eager():
+    """hotpath.NeckPath: the whole neck step replayed as one hipGraph equals the eager step for the
+    same camera choice, follows a changed camera choice through the static camera buffers, and
+    survives many restaged replays (the library launches no memset inside a step: csrc/launch.h)."""
+    import random
+    from ocrfdet_amd import hotpath, synthetic
+    cfg = synthetic.PathConfig(**{**helpers.CORE_CFG, 'n_frames': 2})
+    neck = hotpath.NeckPath(cfg, torch.device('cuda:0'), accelerate=True)
+    m = neck.module
+    neck.capture()
+    for cams in ([1, 4], [5, 0]):
+        out_g = neck.step_graphed(cams)
+        bev_g, view_g, img_g = out_g[0].clone(), out_g[3][4].clone(), out_g[3][0].clone()
+        with torch.no_grad():
+            d, fd, s, fcl = neck._ops.prefilter(neck.depthnet_out, m.D, m.out_channels, m.depth_threshold, m.semantic_threshold)
+            out_e = m.view_transform_core(neck.inputs, fd, None, fcl, cam_idx_list=cams)
+        close(bev_g, out_e[0].cpu().numpy(), 1e-5, 'bev_feat graph vs eager')
+        close(view_g, out_e[3][4].cpu().numpy(), 1e-5, 'opacity view graph vs eager')
+        close(img_g, out_e[3][0].cpu().numpy(), 1e-5, 'render graph vs eager')
+        assert out_g[3][5] == cams
+    for _ in range(40):
+        neck.step_graphed([random.randint(0, 5), random.randint(0, 5)])
+    torch.cuda.synchronize()

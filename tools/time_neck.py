@@ -40,7 +40,7 @@ def main():
     X, Y, Z = cfg.bev_xyz
     print(f'{cfg.name}: B={B} accelerate={a.accelerate}: {ms:.3f} ms per neck forward '
           f'({B * Z * Y * X / ms * 1e3:.3e} BEV voxels/s, {B / ms * 1e3:.1f} rendered views/s)')
-    if a.accelerate and os.environ.get('OCRF_EXPERIMENTAL_GRAPH') == '1':
+    if a.accelerate:
         neck.capture()
         for _ in range(5):
             neck.step_graphed()
