@@ -419,3 +419,27 @@ def test_graph_captured_step_matches_eager():
     for _ in range(40):
         neck.step_graphed([random.randint(0, 5), random.randint(0, 5)])
     torch.cuda.synchronize()
+
+
+def test_full_training_mode_forward_backward(core):
+    """``module.train()`` for real (BatchNorm batch statistics, dropout in the deformable attention):
+    forward + backward through the whole neck on the GPU; every trainable parameter of the path gets a
+    finite gradient (a drop-in has to train, not only infer)."""
+    import copy
+    m = copy.deepcopy(core['m'])
+    m.train()
+    cfg, g = core['cfg'], core['g']
+    pre = torch.from_numpy(g['pre']).cuda()
+    depth = pre[:, :cfg.D].softmax(1).requires_grad_(True)
+    feat = pre[:, cfg.D + 2:].clone().requires_grad_(True)
+    torch.manual_seed(0)
+    bev, _, logit, lst = m.view_transform_core(core['inp'], depth, feat, cam_idx_list=[1, 4])
+    loss = bev.square().mean() + logit.square().mean() + lst[0].mean() + lst[6].mean() + lst[4].square().mean()
+    loss.backward()
+    assert torch.isfinite(loss)
+    assert depth.grad is not None and feat.grad is not None
+    assert torch.isfinite(depth.grad).all() and torch.isfinite(feat.grad).all()
+    missing = [n for n, p in m.named_parameters()
+               if p.requires_grad and not n.startswith(('depth_net.', 'D_MLP_nerf.', 'prob.ce_loss'))
+               and (p.grad is None or not torch.isfinite(p.grad).all())]
+    assert not missing, f'no / non-finite gradient for {missing[:8]}'
