@@ -343,18 +343,37 @@ __global__ __launch_bounds__(64) void neck_gauss_heads_kernel(
 // NeRF branch.  z (M,32,h2,w2) is the output of ResizeNetwork.conv2; an output pixel (y, x) of the
 // 8x up-sampled image reads z[:, y/8, x/8] and the composed map of its sub-position (y%8, x%8).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void neck_nerf_alpha_kernel(
+// One thread = 8 horizontally consecutive output pixels (one coarse pixel j, one sub-row a): the 32
+// channels of z[:, i, j] are read once for the 8 pixels, and since the sub-row is uniform over the
+// workgroup (blockIdx.y = output row) the 32 x 8 weights are wave-uniform scalar loads.  4 loads and
+// 16 packed FMAs per pixel instead of 64 loads and 32 FMAs; the 8 results leave as two float4 stores.
+__global__ __launch_bounds__(64) void neck_nerf_alpha_kernel(
     const float* __restrict__ z, const float* __restrict__ Wm /*[32][64]*/, const float* __restrict__ cm /*[64]*/,
     float* __restrict__ alpha, int h2, int w2) {
-  const int Wo = 8 * w2;
-  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, m = blockIdx.z;
-  if (x >= Wo) return;
-  const int pos = (y & 7) * 8 + (x & 7);
-  const float* zp = z + ((size_t)m * 32 * h2 + (y >> 3)) * w2 + (x >> 3);
-  float v = cm[pos];
+  const int j = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y, m = blockIdx.z;
+  if (j >= w2) return;
+  const int a = y & 7;
+  const float* zp = z + ((size_t)m * 32 * h2 + (y >> 3)) * w2 + j;
+  const f32x2* wrow = reinterpret_cast<const f32x2*>(Wm + a * 8);
+  f32x2 acc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc[k] = f32x2{cm[a * 8 + 2 * k], cm[a * 8 + 2 * k + 1]};
 #pragma unroll 8
-  for (int ci = 0; ci < 32; ++ci) v = fmaf(zp[(size_t)ci * h2 * w2], Wm[ci * 64 + pos], v);
-  alpha[((size_t)m * 8 * h2 + y) * Wo + x] = 1.0f - __expf(-softplusf(v));
+  for (int ci = 0; ci < 32; ++ci) {
+    const float zv = zp[(size_t)ci * h2 * w2];
+    const f32x2 zz = {zv, zv};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = __builtin_elementwise_fma(wrow[ci * 32 + k], zz, acc[k]);
+  }
+  float o[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    o[2 * k] = 1.0f - __expf(-softplusf(acc[k].x));
+    o[2 * k + 1] = 1.0f - __expf(-softplusf(acc[k].y));
+  }
+  float4* dst = reinterpret_cast<float4*>(alpha + ((size_t)m * 8 * h2 + y) * (8 * w2) + 8 * j);
+  dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+  dst[1] = make_float4(o[4], o[5], o[6], o[7]);
 }
 
 // prm: W12[12][32][64] | c12[12][64] | W1rgb[12][3] | Cn: W2[3][4] b2[3] | R1: W2[3][4] b2[3] | R2: W2[1][4] b2[1]
@@ -595,7 +614,8 @@ int ocrf_gauss_heads(const float* bev, const float* rgb_avg, const float* params
 int ocrf_nerf_alpha(const float* z, const float* w_sigma, const float* c_sigma, float* alpha, int M, int h2, int w2,
                     ocrf_stream_t stream) {
   if (M <= 0 || h2 <= 0 || w2 <= 0 || !z || !w_sigma || !c_sigma || !alpha) return (int)hipErrorInvalidValue;
-  ocrf::launch(OCRF_K_NECK_NERF_ALPHA, neck_nerf_alpha_kernel, dim3((8 * w2 + 255) / 256, 8 * h2, M), dim3(256), 0,
+  if ((reinterpret_cast<uintptr_t>(alpha) & 15) || (reinterpret_cast<uintptr_t>(w_sigma) & 7)) return (int)hipErrorInvalidValue;
+  ocrf::launch(OCRF_K_NECK_NERF_ALPHA, neck_nerf_alpha_kernel, dim3((w2 + 63) / 64, 8 * h2, M), dim3(64), 0,
                (hipStream_t)stream, z, w_sigma, c_sigma, alpha, h2, w2);
   return last_error();
 }

@@ -35,6 +35,18 @@ def _f32c(t):
     return t.contiguous().float()
 
 
+class _LaunchCache(dict):
+    """Per-module cache of launch plans (ctypes pointers into the module's own buffers).  It is not
+    part of the module's state: ``copy.deepcopy(model)`` / pickling (EMA hooks, checkpointing of whole
+    modules) get an empty cache and rebuild it on the next forward."""
+
+    def __deepcopy__(self, memo):
+        return _LaunchCache()
+
+    def __reduce__(self):
+        return (_LaunchCache, ())
+
+
 class HeightAttention(nn.Module):
     def __init__(self, input_channel, output_channel, ratio=16):
         super().__init__()
@@ -167,11 +179,14 @@ class OpacityVoxelToBEVConverter(nn.Module):
         ctypes argument lists of the 11 launches.  The per-call host work is then one version check,
         one allocation (the result) and the launches themselves (the block-by-block Python of the
         first version cost ~0.3 ms per call, more than the kernels)."""
-        tensors = self.__dict__.get('_plan_tensors')
+        cache = self.__dict__.get('_plan_cache')
+        if cache is None:
+            cache = self.__dict__['_plan_cache'] = _LaunchCache()
+        tensors = cache.get('tensors')
         if tensors is None:
-            tensors = self.__dict__['_plan_tensors'] = list(self.parameters()) + list(self.buffers())
+            tensors = cache['tensors'] = list(self.parameters()) + list(self.buffers())
         key = (B, H, W, dev, tuple(t._version for t in tensors), tuple(t.data_ptr() for t in tensors))
-        plan = self.__dict__.get('_plan_cache')
+        plan = cache.get('plan')
         if plan is not None and plan['key'] == key:
             return plan
         L = _lib.lib()
@@ -211,7 +226,7 @@ class OpacityVoxelToBEVConverter(nn.Module):
             ow, ob = dev_f32(self.output_conv.weight.reshape(-1)), dev_f32(self.output_conv.bias)
         plan = dict(key=key, keep=keep, calls=calls,
                     out_args=[_lib.ptr(d1), _lib.ptr(gd1), B, 4, H, W, _lib.ptr(ow), _lib.ptr(ob)])
-        self.__dict__['_plan_cache'] = plan
+        cache['plan'] = plan
         return plan
 
     def _forward_fused(self, x, position):

@@ -426,7 +426,7 @@ def test_full_training_mode_forward_backward(core):
     forward + backward through the whole neck on the GPU; every trainable parameter of the path gets a
     finite gradient (a drop-in has to train, not only infer)."""
     import copy
-    m = copy.deepcopy(core['m'])
+    m = copy.deepcopy(core['m'])            # also: a module that has run its fused path must stay deep-copyable
     m.train()
     cfg, g = core['cfg'], core['g']
     pre = torch.from_numpy(g['pre']).cuda()
