@@ -110,3 +110,17 @@ def test_ops_refuse_cpu_tensors():
         neck_ops.prefilter(torch.zeros(1, 10, 2, 2), 4, 4, 0.1, 0.25)
     with pytest.raises(OcrfHipError):
         neck_ops.pillar_sample_mean(torch.zeros(1, 1, 3, 4, 4), torch.zeros(1, 1, 2, 3, 2), torch.ones(1, 1, 2, 3, 1, dtype=torch.bool))
+
+
+def test_module_is_deepcopyable_and_picklable(core):
+    """EMA hooks and checkpointing of whole modules deep-copy / pickle the neck."""
+    import copy
+    import io
+    m = core[3]
+    m2 = copy.deepcopy(m)
+    assert set(m2.state_dict()) == set(m.state_dict())
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m3 = torch.load(buf, weights_only=False)
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m3.state_dict().values()))
