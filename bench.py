@@ -179,7 +179,9 @@ def bench_neck(args, cfg, dev, world, rank):
                           'sharding': 'none' if world == 1 else f'{world} ranks x whole samples, no data-path collective'},
                'roofline': {'bound': 'hbm', 'kernel': timer.kernel_name, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                             'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS if achieved else None, 'traffic': None,
-                            'algorithmic_bytes_per_launch': alg, 'avg_launch_us': 1e3 * avg_ms, 'launches_timed': len(ms)},
+                            'algorithmic_bytes_per_launch': alg, 'avg_launch_us': 1e3 * avg_ms, 'launches_timed': len(ms),
+                            'note': 'kernel timed over an eager run of the same step right after the timed region '
+                                    '(HIP events cannot bracket a launch inside a graph replay)'},
                'cpu_baseline': None}
         print(json.dumps(out), flush=True)
     timer.close()
