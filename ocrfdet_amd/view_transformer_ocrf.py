@@ -26,6 +26,7 @@ configs/ocrfdet/ocrfdet.py:259-337), assembled MI355X-first:
 ``depth_net=module``; when the reference's mmdet3d is importable its ``DepthNet`` is built from
 ``depthnet_cfg`` exactly as the reference does (:588-589).
 """
+import contextlib
 import math
 import random
 
@@ -409,6 +410,9 @@ class OcRFViewTransformerFull(nn.Module):
             dim=13, dim_head=8, heads=1, dropout=0.1, downsample_factor=4, offset_scale=4, offset_groups=None,
             offset_kernel_size=6)
         self._geo, self._tmpl, self._bg = None, None, None
+        # eval-mode strands on side HIP streams (see _core_fused); off by default: a caller that runs the
+        # module under its own stream discipline should opt in
+        self.parallel_branches, self._transient = False, hoa._LaunchCache()     # streams: not module state
         self._rank_bufs = (index_prep._RankBuffers(), index_prep._RankBuffers())
         self._packs = {}
 
@@ -574,9 +578,6 @@ class OcRFViewTransformerFull(nn.Module):
         if feat_channels_last is None:
             feat_channels_last = tran_feat.reshape(B, N, C, Hf, Wf).permute(0, 1, 3, 4, 2)
         feat_cl = feat_channels_last.reshape(B, N, Hf, Wf, C).float().contiguous()
-        lss_feat = self.get_lss_bev_feat(geo, depth5, feat_cl)
-        ht_feat = self.get_ht_bev_feat(geo, depth5, feat_cl)
-
         if cameras is None:
             if cam_idx_list is None:
                 cam_idx_list = [random.randint(0, 5) for _ in range(B)]
@@ -584,36 +585,19 @@ class OcRFViewTransformerFull(nn.Module):
         cam_idx_list, cam_sel = cameras['cam_idx_list'], cameras['cam_sel']
         voxel_coor = geo.voxel.reshape(B, Zh * Y * X, 3)
         if fused:
-            avg_rgb = neck_ops.pillar_sample_mean(imgs_wo_norm, geo.pix, geo.mask)                 # (B,Zh,YX,3)
-            sparse = neck_ops.retain_valid_pixels(imgs_wo_norm, geo.pix, geo.mask, cam_sel)        # (B,3,H,W)
-            w_s, c_s, nerf_block = self._nerf_params()
-            z = self.image_feat_resize.stem(x.reshape(B * N, -1, Hf, Wf).float())
-            alpha = neck_ops.nerf_alpha(z, w_s, c_s)                                                # (B*N,H,W)
-            render_N, render_depth_N = neck_ops.nerf_render(z, cam_sel, alpha, sparse, nerf_block, N)
-            # the reference views the (6,H,W,1) stack as (1,6,1,W,H) before sampling it (:1123)
-            alpha_lidar = neck_ops.pillar_sample_mean(alpha.view(B, N, 1, H, W), geo.pix, geo.mask, view_hw=(W, H))
-            alpha_lidar = alpha_lidar.view(B, Zh, Y, X)
-            opacity, scaling, rotation, color = neck_ops.gauss_heads(ht_feat, avg_rgb, self._head_params(), Zh)
-        else:
-            (opacity, scaling, rotation, color, sparse, alpha_lidar, render_N,
-             render_depth_N) = self._neck_torch(input, geo, ht_feat, cam_idx_list)
-
-        if fused:
-            # every sample is a Gaussian set with one camera: ONE rasteriser call for the batch, fed with
-            # the staged camera rows (the reference loops samples, :1090-1153)
-            if self._bg is None or self._bg.device != x.device:
-                self._bg = torch.zeros(3, device=x.device)
-            o = rasterize_sets(voxel_coor, color, opacity, scaling, rotation, cameras['packed'], H, W, self._bg)
-            render_image_G_all, render_depth_G_all = o['color'], o['depth']
-        else:
-            render_G, render_depth_G = [], []
-            for bs in range(B):
-                cam = self._camera(geo, bs, cam_idx_list[bs])
-                cam = {k: (v.to(x.device) if torch.is_tensor(v) and v.dim() else v) for k, v in cam.items()}
-                img, dep = gaussian_renderer.render(cam, cam_idx_list[bs], voxel_coor[bs], color[bs], rotation[bs],
-                                                    scaling[bs], opacity[bs], bg_color=[0, 0, 0])
-                render_G.append(img.unsqueeze(0)), render_depth_G.append(dep.unsqueeze(0))
-            render_image_G_all, render_depth_G_all = torch.cat(render_G), torch.cat(render_depth_G)
+            return self._core_fused(input, geo, depth, depth5, feat_cl, cameras, voxel_coor)
+        lss_feat = self.get_lss_bev_feat(geo, depth5, feat_cl)
+        ht_feat = self.get_ht_bev_feat(geo, depth5, feat_cl)
+        (opacity, scaling, rotation, color, sparse, alpha_lidar, render_N,
+         render_depth_N) = self._neck_torch(input, geo, ht_feat, cam_idx_list)
+        render_G, render_depth_G = [], []
+        for bs in range(B):
+            cam = self._camera(geo, bs, cam_idx_list[bs])
+            cam = {k: (v.to(x.device) if torch.is_tensor(v) and v.dim() else v) for k, v in cam.items()}
+            img, dep = gaussian_renderer.render(cam, cam_idx_list[bs], voxel_coor[bs], color[bs], rotation[bs],
+                                                scaling[bs], opacity[bs], bg_color=[0, 0, 0])
+            render_G.append(img.unsqueeze(0)), render_depth_G.append(dep.unsqueeze(0))
+        render_image_G_all, render_depth_G_all = torch.cat(render_G), torch.cat(render_depth_G)
         render_image = self.LinearWeightedImage(render_image_G_all, render_N)
         render_depth = self.LinearWeightedDepth(render_depth_G_all, render_depth_N)
         gt_images = imgs_wo_norm[torch.arange(B, device=x.device), cam_sel.long()] / 255.0
@@ -626,11 +610,82 @@ class OcRFViewTransformerFull(nn.Module):
         bev_mask_logit = self.prob(self.positional_encoding(zeros).to(dtype) + channel_feat)
         geom_feat = self.geom_att.gate(channel_feat, bev_mask_logit)
         opacity_alpha_view = self.OpacityVoxelToBEV(opacity_alpha, self.positional_encoding1(zeros).to(dtype))
-        if fused:
-            geom_feat = self.ObatinOpacityMask.gate(geom_feat, opacity_alpha_view)[1]
-        else:
-            m = torch.sigmoid(_spatial_logits(geom_feat, self.ObatinOpacityMask.conv) + opacity_alpha_view)
-            geom_feat = geom_feat * m
+        m = torch.sigmoid(_spatial_logits(geom_feat, self.ObatinOpacityMask.conv) + opacity_alpha_view)
+        geom_feat = geom_feat * m
+        return geom_feat, depth, bev_mask_logit, [render_image, gt_images, render_image_G_all, render_N,
+                                                  opacity_alpha_view, cam_idx_list, render_depth, render_depth_G_all,
+                                                  render_depth_N]
+
+    def _core_fused(self, input, geo, depth, depth5, feat_cl, cameras, voxel_coor):
+        """Eval-mode ``view_transform_core`` on the HIP kernels.  The step has three independent strands
+        until HOA joins them — (A) poolings -> Gaussian heads -> render, (B) colour sampling + NeRF branch
+        (needs only the images and the calibration), (C) BEV fusion -> ProbNet -> geometry attention (needs
+        only the pooled BEVs).  With ``parallel_branches`` B and C run on two side HIP streams (captured as
+        parallel branches of the graph): the many small kernels of C and the MIOpen convolutions of B fill
+        the gaps of A instead of queueing behind it."""
+        x, imgs_wo_norm = input[0], input[9]
+        dev, dtype = x.device, x.dtype
+        B, N, _, Hf, Wf = x.shape
+        Zh, Y, X = self.num_height, self.bev_h, self.bev_w
+        H, W = self.input_size
+        cam_idx_list, cam_sel = cameras['cam_idx_list'], cameras['cam_sel']
+        par = self.parallel_branches
+        cur = torch.cuda.current_stream(dev)
+        if par:
+            streams = self._transient.get('streams')
+            if streams is None or streams[0].device != dev:
+                streams = self._transient['streams'] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+            sB, sC = streams
+            sB.wait_stream(cur)                    # inputs ready; last call's consumers of our buffers done
+            sC.wait_stream(cur)
+        on = (lambda s: torch.cuda.stream(s)) if par else (lambda s: contextlib.nullcontext())
+        # ---- strand B
+        with on(sB if par else None):
+            avg_rgb = neck_ops.pillar_sample_mean(imgs_wo_norm, geo.pix, geo.mask)                 # (B,Zh,YX,3)
+            if par:
+                rgb_ready = torch.cuda.Event()
+                rgb_ready.record(sB)
+            sparse = neck_ops.retain_valid_pixels(imgs_wo_norm, geo.pix, geo.mask, cam_sel)        # (B,3,H,W)
+            w_s, c_s, nerf_block = self._nerf_params()
+            z = self.image_feat_resize.stem(x.reshape(B * N, -1, Hf, Wf).float())
+            alpha = neck_ops.nerf_alpha(z, w_s, c_s)                                                # (B*N,H,W)
+            render_N, render_depth_N = neck_ops.nerf_render(z, cam_sel, alpha, sparse, nerf_block, N)
+            # the reference views the (6,H,W,1) stack as (1,6,1,W,H) before sampling it (:1123)
+            alpha_lidar = neck_ops.pillar_sample_mean(alpha.view(B, N, 1, H, W), geo.pix, geo.mask, view_hw=(W, H))
+            alpha_lidar = alpha_lidar.view(B, Zh, Y, X)
+            gt_images = imgs_wo_norm[torch.arange(B, device=dev), cam_sel.long()] / 255.0
+        # ---- strand A, first half
+        lss_feat = self.get_lss_bev_feat(geo, depth5, feat_cl)
+        ht_feat = self.get_ht_bev_feat(geo, depth5, feat_cl)
+        # ---- strand C
+        if par:
+            sC.wait_stream(cur)
+        with on(sC if par else None):
+            channel_feat = self.fuser(lss_feat, ht_feat)
+            zeros = _zeros((B, Y, X), x)            # positional encodings only read its shape / device
+            bev_mask_logit = self.prob(self.positional_encoding(zeros).to(dtype) + channel_feat)
+            geom_feat = self.geom_att.gate(channel_feat, bev_mask_logit)
+            pos1 = self.positional_encoding1(zeros).to(dtype)
+        # ---- strand A, second half
+        if par:
+            cur.wait_event(rgb_ready)
+        opacity, scaling, rotation, color = neck_ops.gauss_heads(ht_feat, avg_rgb, self._head_params(), Zh)
+        # every sample is a Gaussian set with one camera: ONE rasteriser call for the batch, fed with the
+        # staged camera rows (the reference loops samples, :1090-1153)
+        if self._bg is None or self._bg.device != dev:
+            self._bg = torch.zeros(3, device=dev)
+        o = rasterize_sets(voxel_coor, color, opacity, scaling, rotation, cameras['packed'], H, W, self._bg)
+        render_image_G_all, render_depth_G_all = o['color'], o['depth']
+        if par:
+            cur.wait_stream(sB)
+        render_image = self.LinearWeightedImage(render_image_G_all, render_N)
+        render_depth = self.LinearWeightedDepth(render_depth_G_all, render_depth_N)
+        # HOA-1 for the whole batch (the reference loops samples, :1159-1161), HOA-2
+        opacity_alpha = hoa.hoa1(self.defor_cross_attention, opacity.reshape(-1, 1), alpha_lidar, Zh, Y, X)
+        if par:
+            cur.wait_stream(sC)
+        opacity_alpha_view = self.OpacityVoxelToBEV(opacity_alpha, pos1)
+        geom_feat = self.ObatinOpacityMask.gate(geom_feat, opacity_alpha_view)[1]                   # HOA-3
         return geom_feat, depth, bev_mask_logit, [render_image, gt_images, render_image_G_all, render_N,
                                                   opacity_alpha_view, cam_idx_list, render_depth, render_depth_G_all,
                                                   render_depth_N]

@@ -443,3 +443,27 @@ def test_full_training_mode_forward_backward(core):
                if p.requires_grad and not n.startswith(('depth_net.', 'D_MLP_nerf.', 'prob.ce_loss'))
                and (p.grad is None or not torch.isfinite(p.grad).all())]
     assert not missing, f'no / non-finite gradient for {missing[:8]}'
+
+
+def test_parallel_branches_match_single_stream(core):
+    """The three strands of the fused step on side HIP streams give the single-stream result, call
+    after call (buffers of one call are recycled by the next)."""
+    m, g = core['m'], core['g']
+    cams = [int(c) for c in g['cam_idx_list']]
+    from ocrfdet_amd import neck_ops
+    with torch.no_grad():
+        y = m.depth_net(None, None, None)
+        depth, fdepth, sem, feat_cl = neck_ops.prefilter(y, m.D, m.out_channels, m.depth_threshold, m.semantic_threshold)
+        ref = m.view_transform_core(core['inp'], fdepth, None, feat_cl, cam_idx_list=cams)
+        m.parallel_branches = True
+        try:
+            for _ in range(4):
+                out = m.view_transform_core(core['inp'], fdepth, None, feat_cl, cam_idx_list=cams)
+                torch.cuda.synchronize()
+                close(out[0], ref[0].cpu().numpy(), 1e-5, 'bev_feat')
+                close(out[2], ref[2].cpu().numpy(), 1e-5, 'bev_mask_logit')
+                for i in (0, 1, 2, 3, 4, 6, 7, 8):
+                    close(out[3][i], ref[3][i].cpu().numpy(), 1e-5, f'extras[{i}]')
+        finally:
+            m.parallel_branches = False
+    _check_outputs(core, (out[0], depth, (out[2], sem), out[3]))
