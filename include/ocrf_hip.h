@@ -85,7 +85,7 @@ size_t ocrf_bev_pool_v2_workspace_bytes(int c, int n_points);
  *   layout 1: out[b][z*C + c][y][x]   == torch.cat(bev_feat.unbind(dim=2), 1), what
  *                                        voxel_pooling_v2 / fast_sampling return
  *                                        (view_transformer.py:194, view_transformer_ocrf.py:781).
- * (B,Z,Y,X) is the reference's bev_feat_shape without C.  Needs C % 4 == 0, 32 <= C <= 256 and
+ * (B,Z,Y,X) is the reference's bev_feat_shape without C (B*Z*Y*X < 2^29).  Needs C % 4 == 0, 32 <= C <= 256 and
  * the interval precondition of ocrf_bev_pool_v2; ranks_bev values must be < B*Z*Y*X.
  * workspace >= ocrf_bev_pool_v2_nchw_workspace_bytes(c, n_intervals, n_points, B*Z*Y*X).
  */
@@ -95,6 +95,25 @@ int ocrf_bev_pool_v2_nchw(int c, int n_intervals, int n_points, const float *dep
                           const int *interval_lengths, float *out, int B, int Z, int Y, int X,
                           int layout, void *workspace, size_t workspace_bytes,
                           ocrf_stream_t stream);
+
+/*
+ * Plans for rank vectors that stay the same across calls (static calibration: the reference's
+ * `accelerate=True`, pre_compute at view_transformer.py:257-262 / view_transformer_ocrf.py:854-866).
+ * ocrf_bev_pool_plan_build runs the rank-only part of the pooling once — the interval search, the
+ * piece marking, the voxel -> row map — and keeps it in `plan` (device memory, caller-owned,
+ * >= ocrf_bev_pool_plan_bytes(c, n_points, B*Z*Y*X) bytes, 16-byte aligned);
+ * ocrf_bev_pool_v2_nchw_planned is ocrf_bev_pool_v2_nchw for exactly those rank vectors (same c,
+ * n_intervals, n_points, grid) reading the plan instead: same results bit for bit, ~1/3 less kernel
+ * time.  ranks_bev / interval_* are not needed again after the build.  B*Z*Y*X < 2^29.
+ */
+size_t ocrf_bev_pool_plan_bytes(int c, int n_points, long n_voxels);
+int ocrf_bev_pool_plan_build(int c, int n_intervals, int n_points, const int *ranks_bev,
+                             const int *interval_starts, const int *interval_lengths, long n_voxels,
+                             void *plan, size_t plan_bytes, ocrf_stream_t stream);
+int ocrf_bev_pool_v2_nchw_planned(int c, int n_intervals, int n_points, const float *depth,
+                                  const float *feat, const int *ranks_depth, const int *ranks_feat,
+                                  const void *plan, float *out, int B, int Z, int Y, int X, int layout,
+                                  void *workspace, size_t workspace_bytes, ocrf_stream_t stream);
 
 /* Same, for rank vectors whose lengths were produced on the device (ocrf_lss_prepare /
  * ocrf_ht_prepare): the vectors are passed at their capacities and `counts` (device, int32) holds

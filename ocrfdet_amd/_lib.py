@@ -65,6 +65,13 @@ def _declare(L):
                                             [c_void_p, c_size_t, c_void_p])
     L.ocrf_bev_pool_v2_nchw_workspace_bytes.restype = c_size_t
     L.ocrf_bev_pool_v2_nchw_workspace_bytes.argtypes = [c_int, c_int, c_int, ctypes.c_long]
+    L.ocrf_bev_pool_plan_bytes.restype = c_size_t
+    L.ocrf_bev_pool_plan_bytes.argtypes = [c_int, c_int, ctypes.c_long]
+    L.ocrf_bev_pool_plan_build.restype = c_int
+    L.ocrf_bev_pool_plan_build.argtypes = [c_int] * 3 + [c_void_p] * 3 + [ctypes.c_long, c_void_p, c_size_t, c_void_p]
+    L.ocrf_bev_pool_v2_nchw_planned.restype = c_int
+    L.ocrf_bev_pool_v2_nchw_planned.argtypes = ([c_int] * 3 + [c_void_p] * 6 + [c_int] * 5 +
+                                                [c_void_p, c_size_t, c_void_p])
     L.ocrf_bev_pool_v2_check_intervals.restype = c_int
     L.ocrf_bev_pool_v2_check_intervals.argtypes = [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
     L.ocrf_bev_pool_v2_grad.restype = c_int

@@ -244,6 +244,54 @@ def bev_pool_v2_device_counts(depth, feat, ranks_depth, ranks_feat, ranks_bev, b
     return out
 
 
+class DevicePoolPlan:
+    """The rank-only part of one pooling, built once for rank vectors that are cached across calls
+    (C ABI ``ocrf_bev_pool_plan_build``): interval search, piece marking and the voxel -> row map.
+    ``bev_pool_v2_planned`` then needs only depth, feat, ranks_depth and ranks_feat.  Forward only."""
+
+    def __init__(self, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts, interval_lengths):
+        _lib.require_cuda(ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths)
+        B, Z, Y, X, C = (int(v) for v in bev_feat_shape)
+        if not _fusable(C):
+            raise _lib.OcrfHipError(f'pool plans need C % 4 == 0 and C <= 256, got {C}')
+        self.shape = (B, Z, Y, X, C)
+        self.ranks_depth = ranks_depth.int().contiguous()
+        self.ranks_feat = ranks_feat.int().contiguous()
+        rb, st, ln = ranks_bev.int().contiguous(), interval_starts.int().contiguous(), interval_lengths.int().contiguous()
+        self.n_points, self.n_intervals = self.ranks_depth.numel(), st.numel()
+        dev = rb.device
+        L = _lib.lib()
+        self.plan = torch.empty(L.ocrf_bev_pool_plan_bytes(C, self.n_points, ctypes.c_long(B * Z * Y * X)), dtype=torch.uint8,
+                                device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.ocrf_bev_pool_plan_build(C, self.n_intervals, self.n_points, _lib.ptr(rb), _lib.ptr(st), _lib.ptr(ln),
+                                                  ctypes.c_long(B * Z * Y * X), _lib.ptr(self.plan),
+                                                  ctypes.c_size_t(self.plan.numel()), _lib.stream_ptr(dev)),
+                       'ocrf_bev_pool_plan_build')
+
+
+@torch.no_grad()
+def bev_pool_v2_planned(depth, feat, plan, layout=1):
+    """``bev_pool_v2_collapsed`` (layout 1: (B, Z*C, Y, X)) or ``bev_pool_v2`` (layout 0: (B,C,Z,Y,X)) for the
+    rank vectors a ``DevicePoolPlan`` was built from; bit-identical results."""
+    B, Z, Y, X, C = plan.shape
+    d32, f32 = depth.float().contiguous(), feat.float().contiguous()
+    _lib.require_cuda(d32, f32)
+    if f32.size(-1) != C:
+        raise _lib.OcrfHipError(f'feat has {f32.size(-1)} channels, the plan was built for {C}')
+    dev = d32.device
+    out = torch.empty((B, C, Z, Y, X) if layout == 0 else (B, Z * C, Y, X), dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        need = L.ocrf_bev_pool_v2_nchw_workspace_bytes(C, plan.n_intervals, plan.n_points, B * Z * Y * X)
+        scratch = _lib.workspace.get(dev, need, 'bev_pool_nchw')
+        _lib.check(L.ocrf_bev_pool_v2_nchw_planned(
+            C, plan.n_intervals, plan.n_points, _lib.ptr(d32), _lib.ptr(f32), _lib.ptr(plan.ranks_depth),
+            _lib.ptr(plan.ranks_feat), _lib.ptr(plan.plan), _lib.ptr(out), B, Z, Y, X, int(layout), _lib.ptr(scratch),
+            ctypes.c_size_t(scratch.numel()), _lib.stream_ptr(dev)), 'ocrf_bev_pool_v2_nchw_planned')
+    return out
+
+
 def bev_pool_v2_collapsed(depth, feat, ranks_depth, ranks_feat, ranks_bev,
                           bev_feat_shape, interval_starts, interval_lengths):
     """``torch.cat(bev_pool_v2(...).unbind(dim=2), 1)`` -> (B, Z*C, Y, X), the tensor

@@ -100,7 +100,15 @@ __device__ __forceinline__ void load_batch(Batch& q, int l0, const int* s_rf, co
   for (int k = 0; k < kBatch; ++k) q.wc[k] = s_wc[l0 + k];
 }
 
-template <bool STAMP, int kSub>
+// MODE 0: everything from the rank vectors, every call.
+// MODE 1: BUILD a plan — run the rank-only phases (2)-(3c) once and keep their result: per point an
+//         emit code (bit 31 = the point lies in no interval: weight 0), per sub-chunk the piece table;
+//         nothing is pooled.
+// MODE 2: PLANNED — (1') stage depth weights + rf + the plan's codes and piece table, then (4), (5).
+//         For rank vectors that are cached across calls (``accelerate``): the interval search, interval
+//         staging and marking phases (35 % of a workgroup's cycles) are gone and the workgroup needs
+//         half the LDS.
+template <bool STAMP, int kSub, int MODE>
 __global__ __launch_bounds__(kBlock) void bev_pool_fwd_chunked_kernel(
     unsigned long long* __restrict__ stamps,
     int c4, int gpw, int n_intervals, int n_points, const int* __restrict__ counts, int compact_rows,
@@ -108,17 +116,18 @@ __global__ __launch_bounds__(kBlock) void bev_pool_fwd_chunked_kernel(
     const int* __restrict__ ranks_depth, const int* __restrict__ ranks_feat,
     const int* __restrict__ ranks_bev, const int* __restrict__ interval_starts,
     const int* __restrict__ interval_lengths, float4* __restrict__ dst, float4* __restrict__ part,
-    int4* __restrict__ bmeta, int* __restrict__ row_of_vox) {
+    int4* __restrict__ bmeta, int* __restrict__ row_of_vox, int* __restrict__ plan_codes,
+    int* __restrict__ plan_meta) {
   extern __shared__ __attribute__((aligned(16))) int smem[];
   const int tid = threadIdx.x;
   const int gpb = gpw * (kBlock / kWave);
   const int BP = gpb * kSub;
   int2* s_wc = reinterpret_cast<int2*>(smem);              // {float bits of depth weight, code}
   int* s_rf = smem + 2 * BP;
-  int* s_st = s_rf + BP;
+  int* s_st = s_rf + BP;                                   // MODE 2 keeps none of s_st / s_ln / s_row
   int* s_ln = s_st + BP + kBlock;
   int* s_row = s_ln + BP + kBlock;
-  int* s_meta = s_row + BP + kBlock;                       // [gpb][4]: head, tail, tail_j, -
+  int* s_meta = (MODE == 2) ? (s_rf + BP) : (s_row + BP + kBlock);   // [gpb][4]: head, tail, tail row, tail runs past the block
   float4* s_part = reinterpret_cast<float4*>(s_meta + 4 * gpb);   // [2*gpb][c4]
 
   const int bs = blockIdx.x * BP;             // first point of this block
@@ -143,15 +152,28 @@ __global__ __launch_bounds__(kBlock) void bev_pool_fwd_chunked_kernel(
   // (1) stage the block's points (coalesced index reads, one depth gather per point).
   for (int i = tid; i < BP; i += kBlock) {
     float w = 0.f;
-    int rf = 0;
+    int rf = 0, code = 0;
     if (bs + i < be) {
-      w = depth[ranks_depth[bs + i]];
-      rf = ranks_feat[bs + i];
+      if constexpr (MODE == 1) {
+        w = 1.f;                                   // only "zeroed or not" matters when building
+      } else {
+        w = depth[ranks_depth[bs + i]];
+        rf = ranks_feat[bs + i];
+      }
+      if constexpr (MODE == 2) {
+        code = plan_codes[bs + i];
+        if (code < 0) { w = 0.f; code &= 0x7fffffff; }
+      }
     }
-    s_wc[i] = make_int2(__float_as_int(w), 0);
+    s_wc[i] = make_int2(__float_as_int(w), code);
     s_rf[i] = rf;
   }
-  if (tid < 4 * gpb) s_meta[tid] = 0;
+  if constexpr (MODE == 2) {
+    if (tid < 4 * gpb) s_meta[tid] = plan_meta[(long)blockIdx.x * 4 * gpb + tid];
+  } else {
+    if (tid < 4 * gpb) s_meta[tid] = 0;
+  }
+  if constexpr (MODE != 2) {
 
   // (2) cooperative 256-ary search: k_lo = last interval with start <= bs (0 if none).
   int lo = 0, hi = n_intervals;
@@ -221,6 +243,30 @@ __global__ __launch_bounds__(kBlock) void bev_pool_fwd_chunked_kernel(
     }
   }
   __syncthreads();
+  // (3c) fold the rows into the codes and the piece table, so that (4) and (5) need neither s_row nor
+  // s_st / s_ln (and a plan can stand in for all of (2)-(3c))
+  for (int i = tid; i < BP; i += kBlock) {
+    const int code = s_wc[i].y;
+    if (code & 1) s_wc[i].y = 1 | (s_row[code >> 2] << 2);
+  }
+  for (int g = tid; g < gpb; g += kBlock) {
+    if (s_meta[4 * g + 1]) {
+      const int t = s_meta[4 * g + 2];
+      s_meta[4 * g + 2] = s_row[t];
+      s_meta[4 * g + 3] = (s_st[t] + s_ln[t] > be) ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  if constexpr (MODE == 1) {
+    for (int i = tid; i < BP; i += kBlock)
+      if (bs + i < be) plan_codes[bs + i] = s_wc[i].y | (s_wc[i].x == 0 ? (int)0x80000000 : 0);
+    if (tid < 4 * gpb) plan_meta[(long)blockIdx.x * 4 * gpb + tid] = s_meta[tid];
+    return;
+  }
+  }   // MODE != 2
+  else {
+    __syncthreads();
+  }
 
   // (4) one lane group per sub-chunk, branch-free accumulate with marked emits.
   const int wave = tid / kWave, lane = tid % kWave;
@@ -240,7 +286,7 @@ __global__ __launch_bounds__(kBlock) void bev_pool_fwd_chunked_kernel(
         const int code = wc.y;
         // the only memory operation in the loop is this global store: an LDS store here would
         // make hipcc merge both into one flat store, whose wait drains the gathers in flight
-        if (code & 1) dst[(long)s_row[code >> 2] * c4 + lg] = acc;
+        if (code & 1) dst[(long)(code >> 2) * c4 + lg] = acc;
         const bool is_head = code == 2;
         head_acc.x = is_head ? acc.x : head_acc.x;
         head_acc.y = is_head ? acc.y : head_acc.y;
@@ -282,8 +328,8 @@ __global__ __launch_bounds__(kBlock) void bev_pool_fwd_chunked_kernel(
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       if (h == 1) break;
     }
-    const int row = s_row[tail_j];
-    if (s_st[tail_j] + s_ln[tail_j] > be) {         // runs past the block: leave a block tail
+    const int row = tail_j;                          // (3c): the tail interval's row
+    if (s_meta[4 * gb + 3]) {                        // runs past the block: leave a block tail
       part[(long)(2 * blockIdx.x + 1) * c4 + lg] = acc;
       if (lg == 0) { bmeta[blockIdx.x].y = 1; bmeta[blockIdx.x].z = row; }
     } else {
@@ -312,10 +358,7 @@ __global__ __launch_bounds__(kBlock) void bev_pool_fwd_chunked_kernel(
       // or, when there is none, this lane
       bool open = false;
       for (int g2 = 0; g2 < n_gb; ++g2) {
-        if (s_meta[4 * g2 + 1]) {
-          const int tj = s_meta[4 * g2 + 2];
-          open = open || (s_st[tj] + s_ln[tj] > be);
-        }
+        open = open || (s_meta[4 * g2 + 1] && s_meta[4 * g2 + 3]);
       }
       if (!open) bmeta[blockIdx.x].y = 0;
     }
@@ -530,23 +573,35 @@ inline FwdGeom fwd_geom(int c, int n_points) {
 }
 
 // Shared by the scatter (reference contract) and compact-row (NCHW epilogue) forms.
+// mode 0: from the ranks; 1: build `plan_codes` / `plan_meta` (+ row_of_vox) only; 2: pooled from the plan
 int launch_fwd(int c, int n_intervals, int n_points, const int* counts, int compact_rows, const float* depth,
                const float* feat, const int* ranks_depth, const int* ranks_feat,
                const int* ranks_bev, const int* interval_starts, const int* interval_lengths,
-               float* dst, void* workspace, int* row_of_vox, hipStream_t stream) {
+               float* dst, void* workspace, int* row_of_vox, hipStream_t stream, int mode = 0,
+               int* plan_codes = nullptr, int* plan_meta = nullptr) {
   const FwdGeom g = fwd_geom(c, n_points);
   float4* part = static_cast<float4*>(workspace);
-  int4* bmeta = reinterpret_cast<int4*>(static_cast<char*>(workspace) + g.part_bytes);
-  auto kern = (g_sub == 64) ? bev_pool_fwd_chunked_kernel<false, 64>
-                             : bev_pool_fwd_chunked_kernel<false, 32>;
+  int4* bmeta = workspace ? reinterpret_cast<int4*>(static_cast<char*>(workspace) + g.part_bytes) : nullptr;
+  using K = decltype(&bev_pool_fwd_chunked_kernel<false, 32, 0>);
+  K kern;
+  size_t lds = g.lds;
+  if (mode == 1) {
+    kern = (g_sub == 64) ? bev_pool_fwd_chunked_kernel<false, 64, 1> : bev_pool_fwd_chunked_kernel<false, 32, 1>;
+  } else if (mode == 2) {
+    kern = (g_sub == 64) ? bev_pool_fwd_chunked_kernel<false, 64, 2> : bev_pool_fwd_chunked_kernel<false, 32, 2>;
+    lds = (size_t)(3 * g.BP + 4 * g.gpb) * sizeof(int) + (size_t)2 * g.gpb * g.c4 * sizeof(float4);
+  } else {
+    kern = (g_sub == 64) ? bev_pool_fwd_chunked_kernel<false, 64, 0> : bev_pool_fwd_chunked_kernel<false, 32, 0>;
+  }
   ocrf::launch(OCRF_K_BEV_POOL_FWD, kern, dim3(g.n_blocks),
-               dim3(kBlock), g.lds, stream, (unsigned long long*)nullptr, g.c4, g.gpw, n_intervals,
+               dim3(kBlock), lds, stream, (unsigned long long*)nullptr, g.c4, g.gpw, n_intervals,
                n_points, counts, compact_rows, depth,
                reinterpret_cast<const float4*>(feat), ranks_depth, ranks_feat, ranks_bev,
                interval_starts, interval_lengths, reinterpret_cast<float4*>(dst), part, bmeta,
-               row_of_vox);
+               row_of_vox, plan_codes, plan_meta);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
+  if (mode == 1) return 0;
   const unsigned grid2 = (unsigned)((g.n_blocks + g.gpb - 1) / g.gpb);
   ocrf::launch(OCRF_K_BEV_POOL_FIXUP, bev_pool_fwd_fixup_kernel, dim3(grid2), dim3(kBlock), 0, stream,
                g.c4, g.gpw, g.n_blocks, reinterpret_cast<float4*>(dst),
@@ -573,13 +628,13 @@ int ocrf_diag_bev_pool_v2_stamps(int c, int n_intervals, int n_points, const flo
   const FwdGeom g = fwd_geom(c, n_points);
   float4* part = static_cast<float4*>(workspace);
   int4* bmeta = reinterpret_cast<int4*>(static_cast<char*>(workspace) + g.part_bytes);
-  auto kern = (g_sub == 64) ? bev_pool_fwd_chunked_kernel<true, 64>
-                             : bev_pool_fwd_chunked_kernel<true, 32>;
+  auto kern = (g_sub == 64) ? bev_pool_fwd_chunked_kernel<true, 64, 0>
+                             : bev_pool_fwd_chunked_kernel<true, 32, 0>;
   hipLaunchKernelGGL(kern, dim3(g.n_blocks), dim3(kBlock), g.lds,
                      stream, stamps, g.c4, g.gpw, n_intervals, n_points, (const int*)nullptr, 0, depth,
                      reinterpret_cast<const float4*>(feat), ranks_depth, ranks_feat, ranks_bev,
                      interval_starts, interval_lengths, reinterpret_cast<float4*>(out), part, bmeta,
-                     (int*)nullptr);
+                     (int*)nullptr, (int*)nullptr, (int*)nullptr);
   return (int)hipGetLastError();
 }
 
@@ -643,7 +698,7 @@ int nchw_impl(int c, int n_intervals, int n_points, const int* counts, const flo
       (layout != 0 && layout != 1) || !out)
     return (int)hipErrorInvalidValue;
   const long n_vox = (long)B * Z * Y * X;
-  if (n_vox > 0x7fffffffL) return (int)hipErrorInvalidValue;
+  if (n_vox > 0x1fffffffL) return (int)hipErrorInvalidValue;      // row ids travel in 29 bits of the emit codes
   const NchwGeom g = nchw_geom(c, n_intervals, n_points, n_vox);
   if (!workspace || workspace_bytes < g.total || !aligned16(workspace) || !aligned16(feat))
     return (int)hipErrorInvalidValue;
@@ -693,6 +748,78 @@ int ocrf_bev_pool_v2_nchw_dyn(int c, int cap_intervals, int cap_points, const in
   return nchw_impl(c, cap_intervals, cap_points, counts, depth, feat, ranks_depth, ranks_feat, ranks_bev,
                    interval_starts, interval_lengths, out, B, Z, Y, X, layout, workspace, workspace_bytes,
                    static_cast<hipStream_t>(stream_));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Plans: for rank vectors that stay the same across calls (static calibration, ``accelerate``)
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct PlanGeom {
+  size_t codes_off, meta_off, map_off, total;
+};
+inline PlanGeom plan_geom(int c, int n_points, long n_vox) {
+  const FwdGeom f = fwd_geom(c, n_points);
+  PlanGeom g;
+  g.codes_off = 0;
+  g.meta_off = align_up((size_t)f.n_blocks * f.BP * sizeof(int), 256);
+  g.map_off = g.meta_off + align_up((size_t)f.n_blocks * 4 * f.gpb * sizeof(int), 256);
+  g.total = g.map_off + align_up((size_t)n_vox * sizeof(int), 256);
+  return g;
+}
+}  // namespace
+
+size_t ocrf_bev_pool_plan_bytes(int c, int n_points, long n_voxels) {
+  if (!vec_ok(c) || n_points <= 0 || n_voxels <= 0) return 0;
+  return plan_geom(c, n_points, n_voxels).total;
+}
+
+int ocrf_bev_pool_plan_build(int c, int n_intervals, int n_points, const int* ranks_bev,
+                             const int* interval_starts, const int* interval_lengths, long n_voxels,
+                             void* plan, size_t plan_bytes, ocrf_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (!vec_ok(c) || n_intervals <= 0 || n_points <= 0 || n_voxels <= 0 || n_voxels > 0x1fffffffL || !ranks_bev ||
+      !interval_starts || !interval_lengths || !plan)
+    return (int)hipErrorInvalidValue;
+  const PlanGeom g = plan_geom(c, n_points, n_voxels);
+  if (plan_bytes < g.total || !aligned16(plan)) return (int)hipErrorInvalidValue;
+  char* p = static_cast<char*>(plan);
+  int* row_of_vox = reinterpret_cast<int*>(p + g.map_off);
+  hipError_t err = ocrf::zero_async(row_of_vox, (size_t)n_voxels * sizeof(int), stream);
+  if (err != hipSuccess) return (int)err;
+  return launch_fwd(c, n_intervals, n_points, nullptr, 1, nullptr, nullptr, nullptr, nullptr, ranks_bev, interval_starts,
+                    interval_lengths, nullptr, nullptr, row_of_vox, stream, 1, reinterpret_cast<int*>(p + g.codes_off),
+                    reinterpret_cast<int*>(p + g.meta_off));
+}
+
+int ocrf_bev_pool_v2_nchw_planned(int c, int n_intervals, int n_points, const float* depth, const float* feat,
+                                  const int* ranks_depth, const int* ranks_feat, const void* plan, float* out,
+                                  int B, int Z, int Y, int X, int layout, void* workspace,
+                                  size_t workspace_bytes, ocrf_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (!vec_ok(c) || n_intervals <= 0 || n_points <= 0 || B <= 0 || Z <= 0 || Y <= 0 || X <= 0 ||
+      (layout != 0 && layout != 1) || !out || !plan || !depth || !feat || !ranks_depth || !ranks_feat)
+    return (int)hipErrorInvalidValue;
+  const long n_vox = (long)B * Z * Y * X;
+  if (n_vox > 0x1fffffffL) return (int)hipErrorInvalidValue;
+  const NchwGeom g = nchw_geom(c, n_intervals, n_points, n_vox);
+  if (!workspace || workspace_bytes < g.total || !aligned16(workspace) || !aligned16(feat) || !aligned16(plan))
+    return (int)hipErrorInvalidValue;
+  const PlanGeom pg = plan_geom(c, n_points, n_vox);
+  char* ws = static_cast<char*>(workspace);
+  float* rows = reinterpret_cast<float*>(ws + g.rows_off);
+  char* p = const_cast<char*>(static_cast<const char*>(plan));
+  const int rc = launch_fwd(c, n_intervals, n_points, nullptr, 1, depth, feat, ranks_depth, ranks_feat, nullptr, nullptr,
+                            nullptr, rows, workspace, nullptr, stream, 2, reinterpret_cast<int*>(p + pg.codes_off),
+                            reinterpret_cast<int*>(p + pg.meta_off));
+  if (rc != 0) return rc;
+  const int c4 = c / 4;
+  const int tiles_x = (X + kTile - 1) / kTile;
+  const long n_tiles = (long)B * Z * Y * tiles_x;
+  const size_t lds = (size_t)kTile * (c + 1) * sizeof(float) + kTile * sizeof(int);
+  ocrf::launch(OCRF_K_BEV_POOL_NCHW, bev_pool_rows_to_nchw_kernel, dim3((unsigned)n_tiles), dim3(kBlock), lds, stream,
+               c4, B, Z, Y, X, tiles_x, layout, reinterpret_cast<const float4*>(rows),
+               reinterpret_cast<const int*>(p + pg.map_off), out);
+  return (int)hipGetLastError();
 }
 
 int ocrf_bev_pool_v2_check_intervals(int n_intervals, int n_points, const int* interval_starts,

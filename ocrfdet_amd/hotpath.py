@@ -23,6 +23,7 @@ class PoolPlan:
         self.ranks_bev, self.ranks_depth, self.ranks_feat = ranks_bev, ranks_depth, ranks_feat
         self.starts, self.lengths = starts, lengths
         self.bev_shape = tuple(int(v) for v in bev_shape)      # (B, Z, Y, X, C)
+        self.device_plan = None                                # bevpool.DevicePoolPlan, built on first use
 
     @property
     def n_points(self):
@@ -214,9 +215,15 @@ class HotPath:
         return depth.to(self.device), feat.to(self.device)
 
     def pool(self, plan, depth, feat):
-        """-> (B, Z*C, Y, X): pooled BEV with Z collapsed into channels (view_transformer.py:194)."""
-        return bevpool.bev_pool_v2_collapsed(depth, feat, plan.ranks_depth, plan.ranks_feat,
-                                             plan.ranks_bev, plan.bev_shape, plan.starts, plan.lengths)
+        """-> (B, Z*C, Y, X): pooled BEV with Z collapsed into channels (view_transformer.py:194).  The
+        rank vectors are cached, so the rank-only half of the pooling is too (bevpool.DevicePoolPlan)."""
+        if plan.n_points == 0:
+            return bevpool.bev_pool_v2_collapsed(depth, feat, plan.ranks_depth, plan.ranks_feat,
+                                                 plan.ranks_bev, plan.bev_shape, plan.starts, plan.lengths)
+        if plan.device_plan is None:
+            plan.device_plan = bevpool.DevicePoolPlan(plan.ranks_depth, plan.ranks_feat, plan.ranks_bev, plan.bev_shape,
+                                                      plan.starts, plan.lengths)
+        return bevpool.bev_pool_v2_planned(depth, feat, plan.device_plan)
 
     def prepare_indices_hip(self, sync=True):
         """Rank vectors of both poolings from the calibration, on the device (view_transformer.py:108-147,

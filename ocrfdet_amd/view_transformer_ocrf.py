@@ -356,7 +356,7 @@ class _Geometry:
     """Everything ``view_transform_core`` derives from the calibration alone: both rank-vector sets,
     voxel centres, pillar projections and their validity (view_transformer.py:108-147,197-255;
     view_transformer_ocrf.py:651-740,785-852)."""
-    __slots__ = ('lss', 'ht', 'voxel', 'pix', 'mask', 'calib', 'c2w', 'cam_rows')
+    __slots__ = ('lss', 'ht', 'voxel', 'pix', 'mask', 'calib', 'c2w', 'cam_rows', 'plans')
 
 
 class OcRFViewTransformerFull(nn.Module):
@@ -455,7 +455,7 @@ class OcRFViewTransformerFull(nn.Module):
         # (a handful of (B,N,3,3) tensors; the reference moves them to the host itself, :1086-1088)
         calib = [t.detach().float().cpu() for t in input[1:7]]
         geo = _Geometry()
-        geo.calib, geo.c2w, geo.cam_rows = calib, input[11].detach().float().cpu(), {}
+        geo.calib, geo.c2w, geo.cam_rows, geo.plans = calib, input[11].detach().float().cpu(), {}, {}
         gx, gy, gz = (int(v) for v in self.grid_size.tolist())
         lss_block = index_prep.lss_camera_block(*calib).to(dev)
         lidar2img, img_aug, _, _ = index_prep.get_projection(*calib)
@@ -546,12 +546,24 @@ class OcRFViewTransformerFull(nn.Module):
         rb, rd, rf, st, ln = ranks
         return bevpool.bev_pool_v2_collapsed(depth, feat_cl, rd, rf, rb, bev_shape, st, ln)
 
+    def _pool_cached(self, geo, which, ranks, depth, feat_cl, bev_shape):
+        """Cached geometry + forward-only call: the rank-only half of the pooling is cached as well."""
+        if (geo is self._geo and len(ranks) == 5 and ranks[0] is not None and not torch.is_grad_enabled()
+                and bevpool._fusable(bev_shape[-1])):
+            plan = geo.plans.get(which)
+            if plan is None or plan.shape != tuple(bev_shape):
+                rb, rd, rf, st, ln = ranks
+                plan = geo.plans[which] = bevpool.DevicePoolPlan(rd, rf, rb, bev_shape, st, ln)
+            return bevpool.bev_pool_v2_planned(depth, feat_cl, plan)
+        return self._pool(ranks, depth, feat_cl, bev_shape)
+
     def get_lss_bev_feat(self, geo, depth, feat_cl):
         gx, gy, gz = (int(v) for v in self.grid_size.tolist())
-        return self._pool(geo.lss, depth, feat_cl, (depth.shape[0], gz, gy, gx, feat_cl.shape[-1]))
+        return self._pool_cached(geo, 'lss', geo.lss, depth, feat_cl, (depth.shape[0], gz, gy, gx, feat_cl.shape[-1]))
 
     def get_ht_bev_feat(self, geo, depth, feat_cl):
-        return self._pool(geo.ht, depth, feat_cl, (depth.shape[0], 1, self.bev_h, self.bev_w, feat_cl.shape[-1]))
+        return self._pool_cached(geo, 'ht', geo.ht, depth, feat_cl,
+                                 (depth.shape[0], 1, self.bev_h, self.bev_w, feat_cl.shape[-1]))
 
     # -------------------------------------------------------------------------------- core
     def view_transform(self, input, depth, tran_feat, feat_channels_last=None, cameras=None):

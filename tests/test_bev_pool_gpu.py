@@ -221,3 +221,39 @@ def test_layouts_agree_with_reference_wrapper_ops(cuda, oracle_lib):
     want = oracle_lib.bev_pool_v2(dep.reshape(1, 1, -1, 1, 1), fe.reshape(1, 1, 1, -1, c), rd2, rf2, rb2, shape2, st2, ln2)
     got = _run(cuda, dep.reshape(1, 1, -1, 1, 1), fe.reshape(1, 1, 1, -1, c), rd2, rf2, rb2, shape2, st2, ln2)
     np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['skewed', 'uniform', 'one_interval', 'gaps', 'cfg2'])
+def test_planned_pool_is_bit_identical(cuda, case):
+    """bevpool.DevicePoolPlan + bev_pool_v2_planned (rank-only phases built once) == the unplanned
+    kernel, bit for bit, in both output layouts, call after call."""
+    import torch
+    from ocrfdet_amd import bevpool, synthetic
+    rng = np.random.default_rng(7)
+    C = 80
+    if case == 'cfg2':
+        cfg = synthetic.CONFIGS['cfg2_6cam_2frame_bev200x200_render_hoa']
+        rb, rd, rf, st, ln = helpers.ht_ranks(cfg)
+        depth, feat = helpers.pool_inputs(cfg)
+        X, Y, _ = cfg.bev_xyz
+        shape = (cfg.batch, 1, Y, X, C)
+        depth, feat = depth.reshape(-1), feat.reshape(-1, C)
+    else:
+        n_vox = {'one_interval': 1}.get(case, 900)
+        n_pts = 20000
+        depth, feat, rd, rf, rb, st, ln = helpers.random_pool_problem(rng, n_pts, n_vox, C, skew=(case == 'skewed'))
+        if case == 'gaps':                      # drop every third interval: uncovered points in between
+            keep = np.ones(len(st), bool)
+            keep[::3] = False
+            st, ln = st[keep], ln[keep]
+        shape = (1, 1, 30, 30, C) if n_vox > 1 else (1, 1, 1, 1, C)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)   # noqa: E731
+    d, f = t(depth), t(feat)
+    args = (t(rd), t(rf), t(rb), shape, t(st), t(ln))
+    plan = bevpool.DevicePoolPlan(*args)
+    for layout in (1, 0):
+        want = (bevpool.bev_pool_v2_collapsed(d, f, *args) if layout == 1 else bevpool.bev_pool_v2(d, f, *args))
+        for _ in range(2):
+            got = bevpool.bev_pool_v2_planned(d, f, plan, layout=layout)
+            assert torch.equal(got, want), (case, layout)
