@@ -329,44 +329,19 @@ class NeckPath:
 
     # ---- the same step as ONE hipGraph launch (cached geometry only) -------------------------------
     def capture(self, warmup=3):
-        """Capture ``step`` into a hipGraph.  The only per-step host decision — the random camera of each
-        sample (view_transformer_ocrf.py:1081) — lives in two small static device tensors that
-        ``step_graphed`` refreshes before every replay."""
-        m = self.module
-        if not m.accelerate:
-            raise RuntimeError('graph capture needs accelerate=True (geometry cached across steps)')
-        self.step()                                               # geometry, packs, workspaces, MIOpen algorithms
-        self._cams = m.stage_cameras(m._geo, [0] * self.batch, self.device)
-
-        def body():
-            depth, fdepth, sem, feat_cl = self._ops.prefilter(self.depthnet_out, m.D, m.out_channels, m.depth_threshold,
-                                                              m.semantic_threshold)
-            return m.view_transform(self.inputs, fdepth, None, feat_cl, cameras=self._cams)
-        m.parallel_branches = self._graph_parallel
-        try:
-            side = torch.cuda.Stream(self.device)
-            side.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(side), torch.no_grad():
-                for _ in range(warmup):
-                    body()
-            torch.cuda.current_stream(self.device).wait_stream(side)
-            torch.cuda.synchronize(self.device)
-            self._graph = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(self._graph):
-                self._static_out = body()
-        finally:
-            m.parallel_branches = False
+        """Capture ``step`` into a hipGraph (view_transformer_ocrf.GraphedNeck).  The only per-step host
+        decision — the random camera of each sample (view_transformer_ocrf.py:1081) — lives in two small
+        static device tensors that ``step_graphed`` refreshes before every replay."""
+        from .view_transformer_ocrf import GraphedNeck
+        self._graphed = GraphedNeck(self.module, self.inputs, self.depthnet_out, warmup=warmup,
+                                    parallel_branches=self._graph_parallel)
         return self
 
     def step_graphed(self, cam_idx_list=None):
-        """-> the same tuple as ``step`` (static tensors, overwritten by the next replay)."""
-        import random
-        if cam_idx_list is None:
-            cam_idx_list = [random.randint(0, 5) for _ in range(self.batch)]
-        self.module.stage_cameras(self.module._geo, cam_idx_list, self.device, out=self._cams)
-        self._graph.replay()
-        o = self._static_out
-        return (o[0], o[1], o[2], list(o[3][:5]) + [list(cam_idx_list)] + list(o[3][6:]))
+        """-> (bev_feat, depth, bev_mask_logit, extras) like ``step`` (static tensors, overwritten by the next
+        replay)."""
+        bev, depth, (bev_mask, _sem), extras = self._graphed.replay(cam_idx_list)
+        return bev, depth, bev_mask, extras
 
     @property
     def bev_voxels_per_step(self):

@@ -467,3 +467,36 @@ def test_parallel_branches_match_single_stream(core):
         finally:
             m.parallel_branches = False
     _check_outputs(core, (out[0], depth, (out[2], sem), out[3]))
+
+
+def test_graphed_neck_follows_new_inputs(core):
+    """view_transformer_ocrf.GraphedNeck: new image features / raw images / DepthNet outputs are copied
+    into the graph's static buffers; the replay matches the module's eager forward on them."""
+    import copy
+    from ocrfdet_amd import neck_ops
+    from ocrfdet_amd.view_transformer_ocrf import GraphedNeck
+    m = copy.deepcopy(core['m'])
+    m.accelerate, m.initial_flag = True, True
+    g = core['g']
+    pre = torch.from_numpy(g['pre']).cuda()
+    neck = GraphedNeck(m, core['inp'], pre)
+    gen = torch.Generator().manual_seed(5)
+    for trial in range(2):
+        inp = list(core['inp'])
+        inp[0] = torch.randn(inp[0].shape, generator=gen).cuda()
+        raw = torch.randint(0, 256, inp[9].shape, generator=gen).float().cuda()
+        inp[8], inp[9], inp[10] = raw.clone(), raw, raw.clone()
+        y = (torch.randn(pre.shape, generator=gen) * 2).cuda()
+        cams = [trial, 5 - trial]
+        bev, depth, (bev_mask, sem), ex = neck(inp, y, cams)
+        got = [bev.clone(), depth.clone(), bev_mask.clone(), ex[4].clone(), ex[0].clone(), ex[3].clone()]
+        with torch.no_grad():
+            d, fd, s, fcl = neck_ops.prefilter(y, m.D, m.out_channels, m.depth_threshold, m.semantic_threshold)
+            want = m.view_transform_core(inp, fd, None, fcl, cam_idx_list=cams)
+        close(got[0], want[0].cpu().numpy(), 1e-5, 'bev_feat')
+        close(got[1], d.cpu().numpy(), 1e-6, 'depth')
+        close(got[2], want[2].cpu().numpy(), 1e-5, 'bev_mask_logit')
+        close(got[3], want[3][4].cpu().numpy(), 1e-5, 'opacity view')
+        close(got[4], want[3][0].cpu().numpy(), 1e-5, 'render_imgs')
+        close(got[5], want[3][3].cpu().numpy(), 1e-5, 'render_N')
+        assert ex[5] == cams
