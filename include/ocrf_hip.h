@@ -479,6 +479,10 @@ enum {
   OCRF_K_NECK_FUSION = 66        /* neck_dual_fusion_kernel<C, M> */
 };
 const char *ocrf_kernel_name(int kernel_id);           /* symbol as rocprofv3 prints it */
+/* Diagnostic: a one-thread kernel that stores the device's constant-rate clock (wall_clock64, 100 MHz)
+ * into *slot (device) when the stream reaches it — timelines inside a hipGraph replay, where host
+ * events cannot be placed and the profiler's per-kernel signals perturb the overlap. */
+int ocrf_diag_stamp(unsigned long long *slot, void *stream);
 int ocrf_timer_create(int capacity, void **timer_out); /* host pointers */
 int ocrf_timer_arm(void *timer, int kernel_id);
 int ocrf_timer_read(void *timer, float *ms_out /* host */, int capacity, int *count_out /* host */);

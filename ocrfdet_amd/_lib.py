@@ -142,6 +142,8 @@ def _declare(L):
     L.ocrf_nerf_render_params_len.argtypes = []
     L.ocrf_dual_feat_fusion.restype = c_int
     L.ocrf_dual_feat_fusion.argtypes = [c_void_p] * 5 + [c_int] * 4 + [c_void_p]
+    L.ocrf_diag_stamp.restype = c_int
+    L.ocrf_diag_stamp.argtypes = [c_void_p, c_void_p]
     L.ocrf_kernel_name.restype = ctypes.c_char_p
     L.ocrf_kernel_name.argtypes = [c_int]
     L.ocrf_timer_create.restype = c_int
@@ -174,6 +176,14 @@ def require_cuda(*tensors):
 
 def ptr(t):
     return ctypes.c_void_p(t.data_ptr() if t is not None and t.numel() > 0 else 0)
+
+
+def diag_stamp(stamps, index):
+    """Diagnostic: store the device clock (100 MHz) into ``stamps[index]`` (int64, cuda) when torch's current
+    stream reaches this point — works inside a captured graph (``ocrf_diag_stamp``)."""
+    require_cuda(stamps)
+    check(lib().ocrf_diag_stamp(ctypes.c_void_p(stamps.data_ptr() + 8 * index), stream_ptr(stamps.device)),
+          'ocrf_diag_stamp')
 
 
 class Workspace:

@@ -27,6 +27,8 @@ __global__ void zero_words_kernel(unsigned* __restrict__ dst, size_t n_words) {
   if (i < n_words) dst[i] = 0u;
 }
 
+__global__ void diag_stamp_kernel(unsigned long long* __restrict__ slot) { *slot = wall_clock64(); }
+
 }  // namespace
 
 namespace ocrf {
@@ -55,6 +57,11 @@ bool timer_next(int kernel_id, hipEvent_t* start, hipEvent_t* stop) {
 extern "C" {
 
 const char* ocrf_version(void) { return "ocrf_hip 0.1 gfx950"; }
+
+int ocrf_diag_stamp(unsigned long long* slot, void* stream) {
+  hipLaunchKernelGGL(diag_stamp_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), slot);
+  return (int)hipGetLastError();
+}
 
 const char* ocrf_kernel_name(int kernel_id) {
   switch (kernel_id) {

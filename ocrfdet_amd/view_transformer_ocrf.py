@@ -34,7 +34,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import bevpool, gaussian_renderer, hoa, index_prep, neck_ops
+from . import _lib, bevpool, gaussian_renderer, hoa, index_prep, neck_ops
 from .diff_gaussian_rasterization import pack_cameras, rasterize_sets
 
 __all__ = ['OcRFViewTransformerFull', 'GraphedNeck', 'MS_CAM', 'ChannelAttention', 'SpatialAttention', 'ResCBAMBlock', 'ProbNet',
@@ -535,6 +535,13 @@ class OcRFViewTransformerFull(nn.Module):
         ps = [p for m in mods for p in m.parameters()]
         return self._pack('nerf', ps, lambda: neck_ops.compose_nerf_maps(*mods))
 
+    def _pos(self, name, batch, like):
+        """Eval-mode positional-encoding maps are constants of the weights: built once per (weights, batch)
+        instead of arange + 2 embeddings + cat + an 80-channel strided ``repeat`` per forward."""
+        enc = getattr(self, name)
+        return self._pack((name, batch, like.dtype), list(enc.parameters()),
+                          lambda: enc(_zeros((batch, self.bev_h, self.bev_w), like)).to(like.dtype).contiguous())
+
     # -------------------------------------------------------------------------------- pooling
     def _pool(self, ranks, depth, feat_cl, bev_shape):
         if len(ranks) == 2:                       # ((five capacity vectors), device counts): forward only
@@ -649,11 +656,14 @@ class OcRFViewTransformerFull(nn.Module):
                 streams = self._transient['streams'] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
             sB, sC = streams
             sB.wait_stream(cur)                    # inputs ready; last call's consumers of our buffers done
-            sC.wait_stream(cur)
         on = (lambda s: torch.cuda.stream(s)) if par else (lambda s: contextlib.nullcontext())
+        stamps = self._transient.get('stamps')     # diagnostic timeline (tools/timeline_neck.py)
+        mark = (lambda i: _lib.diag_stamp(stamps, i)) if stamps is not None else (lambda i: None)
+        mark(0)
         # ---- strand B
         with on(sB if par else None):
             avg_rgb = neck_ops.pillar_sample_mean(imgs_wo_norm, geo.pix, geo.mask)                 # (B,Zh,YX,3)
+            mark(1)
             if par:
                 rgb_ready = torch.cuda.Event()
                 rgb_ready.record(sB)
@@ -666,38 +676,50 @@ class OcRFViewTransformerFull(nn.Module):
             alpha_lidar = neck_ops.pillar_sample_mean(alpha.view(B, N, 1, H, W), geo.pix, geo.mask, view_hw=(W, H))
             alpha_lidar = alpha_lidar.view(B, Zh, Y, X)
             gt_images = imgs_wo_norm[torch.arange(B, device=dev), cam_sel.long()] / 255.0
-        # ---- strand A, first half
+            mark(2)
+        # ---- strand A, first half.  The wait for B's colours sits in FRONT of the poolings although only the
+        # heads need them: ROCm 7.2's graph executor serialises the two branches forked after a node (C, A)
+        # when one of them starts with a second, cross-branch dependency (tools/diag_graph_parallel.py:
+        # 8.2 instead of 5 kernel times); with the dependency ahead of the fork they overlap.
+        if par:
+            cur.wait_event(rgb_ready)
         lss_feat = self.get_lss_bev_feat(geo, depth5, feat_cl)
         ht_feat = self.get_ht_bev_feat(geo, depth5, feat_cl)
+        mark(3)
         # ---- strand C
         if par:
             sC.wait_stream(cur)
         with on(sC if par else None):
             channel_feat = self.fuser(lss_feat, ht_feat)
-            zeros = _zeros((B, Y, X), x)            # positional encodings only read its shape / device
-            bev_mask_logit = self.prob(self.positional_encoding(zeros).to(dtype) + channel_feat)
+            mark(4)
+            bev_mask_logit = self.prob(self._pos('positional_encoding', B, x) + channel_feat)
+            mark(5)
             geom_feat = self.geom_att.gate(channel_feat, bev_mask_logit)
-            pos1 = self.positional_encoding1(zeros).to(dtype)
+            mark(6)
         # ---- strand A, second half
-        if par:
-            cur.wait_event(rgb_ready)
         opacity, scaling, rotation, color = neck_ops.gauss_heads(ht_feat, avg_rgb, self._head_params(), Zh)
+        mark(7)
         # every sample is a Gaussian set with one camera: ONE rasteriser call for the batch, fed with the
         # staged camera rows (the reference loops samples, :1090-1153)
         if self._bg is None or self._bg.device != dev:
             self._bg = torch.zeros(3, device=dev)
         o = rasterize_sets(voxel_coor, color, opacity, scaling, rotation, cameras['packed'], H, W, self._bg)
         render_image_G_all, render_depth_G_all = o['color'], o['depth']
+        mark(8)
         if par:
             cur.wait_stream(sB)
         render_image = self.LinearWeightedImage(render_image_G_all, render_N)
         render_depth = self.LinearWeightedDepth(render_depth_G_all, render_depth_N)
+        mark(9)
         # HOA-1 for the whole batch (the reference loops samples, :1159-1161), HOA-2
         opacity_alpha = hoa.hoa1(self.defor_cross_attention, opacity.reshape(-1, 1), alpha_lidar, Zh, Y, X)
+        mark(10)
+        opacity_alpha_view = self.OpacityVoxelToBEV(opacity_alpha, self._pos('positional_encoding1', B, x))
+        mark(11)
         if par:
             cur.wait_stream(sC)
-        opacity_alpha_view = self.OpacityVoxelToBEV(opacity_alpha, pos1)
         geom_feat = self.ObatinOpacityMask.gate(geom_feat, opacity_alpha_view)[1]                   # HOA-3
+        mark(12)
         return geom_feat, depth, bev_mask_logit, [render_image, gt_images, render_image_G_all, render_N,
                                                   opacity_alpha_view, cam_idx_list, render_depth, render_depth_G_all,
                                                   render_depth_N]

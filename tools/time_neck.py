@@ -54,11 +54,12 @@ def main():
               f'({B * Z * Y * X / ms * 1e3:.3e} BEV voxels/s, {B / ms * 1e3:.1f} rendered views/s)')
     if a.stages:
         import torch.autograd.profiler as prof
-        with torch.no_grad(), prof.profile(use_device='cuda') as p:
+        with torch.no_grad(), prof.profile(use_device='cuda', record_shapes=True) as p:
             for _ in range(5):
                 step()
             torch.cuda.synchronize()
-        print(p.key_averages().table(sort_by='device_time_total', row_limit=40, max_name_column_width=70))
+        print(p.key_averages(group_by_input_shape=True).table(sort_by='device_time_total', row_limit=60, max_name_column_width=50,
+                                                            max_shapes_column_width=90))
 
 
 if __name__ == '__main__':
