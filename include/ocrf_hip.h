@@ -432,6 +432,35 @@ int ocrf_nerf_render_params_len(void);
 int ocrf_dual_feat_fusion(const float *x1, const float *x2, const float *params, const float *global_vec,
                           float *out, int B, int C, int M, int YX, ocrf_stream_t stream);
 
+/*
+ * CBAM / ProbNet tail (view_transformer_ocrf.py:68-137 ChannelAttention, SpatialAttention, ResCBAMBlock;
+ * :139-201 ProbNet; MS_CAM.global_att :50-58), eval mode.  The 3x3 convolutions stay with MIOpen; these four
+ * entry points replace the ~30 elementwise / reduction launches between them.
+ *
+ * ocrf_plane_bias_act_stats: one pass over y (B,C,YX), in place when write != 0: y += bias[c] (bias may be
+ *   NULL; BatchNorm folded by the caller), ReLU when relu != 0; when psum != NULL also S partial sums and
+ *   maxima of the result per plane -> psum / pmax [(b*out_C + c_off + c)*S + s] (two inputs can fill one
+ *   (B, out_C, S) block: MS_CAM pools cat(x1, x2)).  y 16-byte aligned.
+ * ocrf_channel_mlp: v_mean = sum_s psum * inv_n, v_max = max_s pmax;
+ *   out[b][n] = act(W2.relu(W1.v_mean + b1) + b2 [+ W2.relu(W1.v_max + b1) + b2]), act = sigmoid or identity;
+ *   W1 (M,K), W2 (N,M) row-major, b1 / b2 may be NULL; K <= 256, M <= 64.
+ * ocrf_scaled_channel_stats: stats (B,2,YX) = mean_c, max_c of scale[b][c] * x[b][c] (SpatialAttention's input
+ *   of the channel-gated map, which is never materialised).
+ * ocrf_cbam_tail: m = sigmoid(conv_kxk(stats)); o_c = relu(m * (scale_c * y_c) + res_c);
+ *   logit (B,YX) = sum_c wm_c * o_c + bm (ProbNet.mask_net); block_out (B,C,YX) receives o when not NULL.
+ */
+int ocrf_plane_bias_act_stats(float *y, const float *bias, int B, int C, int YX, int relu, int write, int S,
+                              int out_C, int c_off, float *psum, float *pmax, ocrf_stream_t stream);
+int ocrf_channel_mlp(const float *psum, const float *pmax, int B, int K, int S, float inv_n, const float *W1,
+                     const float *b1, const float *W2, const float *b2, int M, int N, int use_max, int do_sigmoid,
+                     float *out, ocrf_stream_t stream);
+int ocrf_scaled_channel_stats(const float *x, const float *scale, int B, int C, int YX, float *stats,
+                              ocrf_stream_t stream);
+int ocrf_cbam_tail(const float *y, const float *scale, const float *stats, const float *conv_w, int k,
+                   const float *res, const float *wm, float bm, int B, int C, int Y, int X, float *logit,
+                   float *block_out, ocrf_stream_t stream);
+
+
 /* ------------------------------------------------------------------------------------------
  * Per-kernel device timer (measurement aid for bench.py; not part of the reference's surface)
  * ------------------------------------------------------------------------------------------
@@ -476,7 +505,11 @@ enum {
   OCRF_K_NECK_HEADS = 63,        /* neck_gauss_heads_kernel */
   OCRF_K_NECK_NERF_ALPHA = 64,   /* neck_nerf_alpha_kernel */
   OCRF_K_NECK_NERF_RENDER = 65,  /* neck_nerf_render_kernel */
-  OCRF_K_NECK_FUSION = 66        /* neck_dual_fusion_kernel<C, M> */
+  OCRF_K_NECK_FUSION = 66,       /* neck_dual_fusion_kernel<C, M> */
+  OCRF_K_NECK_PLANE_PASS = 67,   /* neck_plane_pass_kernel<WRITE, RELU, STATS> */
+  OCRF_K_NECK_CHANNEL_MLP = 68,  /* neck_channel_mlp_kernel */
+  OCRF_K_NECK_SCALED_STATS = 69, /* neck_scaled_channel_stats_kernel */
+  OCRF_K_NECK_CBAM_TAIL = 70     /* neck_cbam_tail_kernel */
 };
 const char *ocrf_kernel_name(int kernel_id);           /* symbol as rocprofv3 prints it */
 /* Diagnostic: a one-thread kernel that stores the device's constant-rate clock (wall_clock64, 100 MHz)

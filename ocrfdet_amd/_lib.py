@@ -142,6 +142,14 @@ def _declare(L):
     L.ocrf_nerf_render_params_len.argtypes = []
     L.ocrf_dual_feat_fusion.restype = c_int
     L.ocrf_dual_feat_fusion.argtypes = [c_void_p] * 5 + [c_int] * 4 + [c_void_p]
+    L.ocrf_plane_bias_act_stats.restype = c_int
+    L.ocrf_plane_bias_act_stats.argtypes = [c_void_p] * 2 + [c_int] * 8 + [c_void_p] * 3
+    L.ocrf_channel_mlp.restype = c_int
+    L.ocrf_channel_mlp.argtypes = [c_void_p] * 2 + [c_int] * 3 + [c_float] + [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 2
+    L.ocrf_scaled_channel_stats.restype = c_int
+    L.ocrf_scaled_channel_stats.argtypes = [c_void_p] * 2 + [c_int] * 3 + [c_void_p] * 2
+    L.ocrf_cbam_tail.restype = c_int
+    L.ocrf_cbam_tail.argtypes = [c_void_p] * 4 + [c_int] + [c_void_p] * 2 + [c_float] + [c_int] * 4 + [c_void_p] * 3
     L.ocrf_diag_stamp.restype = c_int
     L.ocrf_diag_stamp.argtypes = [c_void_p, c_void_p]
     L.ocrf_kernel_name.restype = ctypes.c_char_p

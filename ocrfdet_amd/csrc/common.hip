@@ -102,6 +102,10 @@ const char* ocrf_kernel_name(int kernel_id) {
     case OCRF_K_NECK_NERF_ALPHA: return "neck_nerf_alpha_kernel";
     case OCRF_K_NECK_NERF_RENDER: return "neck_nerf_render_kernel";
     case OCRF_K_NECK_FUSION: return "neck_dual_fusion_kernel<*>";
+    case OCRF_K_NECK_PLANE_PASS: return "neck_plane_pass_kernel<*>";
+    case OCRF_K_NECK_CHANNEL_MLP: return "neck_channel_mlp_kernel";
+    case OCRF_K_NECK_SCALED_STATS: return "neck_scaled_channel_stats_kernel";
+    case OCRF_K_NECK_CBAM_TAIL: return "neck_cbam_tail_kernel";
     default: return "";
   }
 }

@@ -521,6 +521,201 @@ __global__ __launch_bounds__(256) void neck_dual_fusion_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// CBAM / ProbNet tail (view_transformer_ocrf.py:68-137 ChannelAttention / SpatialAttention /
+// ResCBAMBlock, :139-201 ProbNet; MS_CAM's global branch :50-58).  The convolutions themselves
+// stay with MIOpen; everything between them is here: ~30 elementwise / reduction launches of the
+// torch graph become 6.
+// ---------------------------------------------------------------------------------------------
+// One pass over every (b, c) plane: y += bias[c] (BatchNorm folded by the caller), optional ReLU,
+// written back in place (WRITE), and / or partial sum + max of the result per plane chunk (STATS):
+// grid (S, B*C); partials land at [(b * out_C + c_off + c) * S + chunk].
+template <bool WRITE, bool RELU, bool STATS>
+__global__ __launch_bounds__(256) void neck_plane_pass_kernel(float* __restrict__ y, const float* __restrict__ bias,
+                                                              int C, long plane, int S, int out_C, int c_off,
+                                                              float* __restrict__ psum, float* __restrict__ pmax) {
+  __shared__ float s_sum[4], s_max[4];
+  const long bc = blockIdx.y;
+  const int b = (int)(bc / C), c = (int)(bc % C);
+  const long chunk = (((plane + S - 1) / S) + 3) & ~3L;
+  const long lo = (long)blockIdx.x * chunk, hi = min(lo + chunk, plane);
+  float* p = y + bc * plane;
+  const float bv = bias ? bias[c] : 0.f;
+  float sum = 0.f, mx = -INFINITY;
+  if ((plane & 3) == 0) {
+    for (long i = lo + 4 * (long)threadIdx.x; i < hi; i += 4 * 256) {
+      float4 v = *reinterpret_cast<const float4*>(p + i);
+      v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+      if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (WRITE) *reinterpret_cast<float4*>(p + i) = v;
+      if (STATS) {
+        sum += (v.x + v.y) + (v.z + v.w);
+        mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+      }
+    }
+  } else {
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
+      float v = p[i] + bv;
+      if (RELU) v = fmaxf(v, 0.f);
+      if (WRITE) p[i] = v;
+      if (STATS) { sum += v; mx = fmaxf(mx, v); }
+    }
+  }
+  if (STATS) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      sum += __shfl_down(sum, off);
+      mx = fmaxf(mx, __shfl_down(mx, off));
+    }
+    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = sum; s_max[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const long o = ((long)b * out_C + c_off + c) * S + blockIdx.x;
+      psum[o] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+      pmax[o] = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    }
+  }
+}
+
+// The pooled vector(s) through a two-layer MLP, one workgroup per sample:
+//   v_mean[k] = sum_s psum[b][k][s] * inv_n,  v_max[k] = max_s pmax[b][k][s]
+//   out[b][n] = act( W2 . relu(W1 . v_mean + b1) + b2  [+ W2 . relu(W1 . v_max + b1) + b2] )
+// ChannelAttention: fc(avg) + fc(max) -> sigmoid (no biases); MS_CAM.global_att: mean only, BatchNorms
+// folded into (W1, b1), (W2, b2), no activation.   K <= 256, M <= 64.
+__global__ __launch_bounds__(256) void neck_channel_mlp_kernel(const float* __restrict__ psum,
+                                                               const float* __restrict__ pmax, int K, int S,
+                                                               float inv_n, const float* __restrict__ W1,
+                                                               const float* __restrict__ b1,
+                                                               const float* __restrict__ W2,
+                                                               const float* __restrict__ b2, int M, int N,
+                                                               int use_max, int do_sigmoid, float* __restrict__ out) {
+  __shared__ float s_in[2][256];
+  __shared__ float s_h[2][64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < K) {
+    float sum = 0.f, mx = -INFINITY;
+    for (int s2 = 0; s2 < S; ++s2) {
+      sum += psum[((long)b * K + tid) * S + s2];
+      if (use_max) mx = fmaxf(mx, pmax[((long)b * K + tid) * S + s2]);
+    }
+    s_in[0][tid] = sum * inv_n;
+    s_in[1][tid] = mx;
+  }
+  __syncthreads();
+  const int nv = use_max ? 2 : 1;
+  for (int h = tid; h < nv * M; h += 256) {
+    const int which = h / M, m = h % M;
+    float a = b1 ? b1[m] : 0.f;
+    for (int k = 0; k < K; ++k) a = fmaf(W1[m * K + k], s_in[which][k], a);
+    s_h[which][m] = fmaxf(a, 0.f);
+  }
+  __syncthreads();
+  for (int n = tid; n < N; n += 256) {
+    float a = b2 ? b2[n] : 0.f;
+    for (int m = 0; m < M; ++m) a = fmaf(W2[n * M + m], s_h[0][m], a);
+    if (use_max) {
+      float a2 = b2 ? b2[n] : 0.f;
+      for (int m = 0; m < M; ++m) a2 = fmaf(W2[n * M + m], s_h[1][m], a2);
+      a += a2;
+    }
+    out[(long)b * N + n] = do_sigmoid ? 1.0f / (1.0f + __expf(-a)) : a;
+  }
+}
+
+// SpatialAttention's input statistics of the channel-gated map: mean and max over c of scale[b][c] * x[b][c]
+// (the gated map itself is never written).  One thread per pixel, 8 plane reads in flight.
+__global__ __launch_bounds__(256) void neck_scaled_channel_stats_kernel(const float* __restrict__ x,
+                                                                        const float* __restrict__ scale, int C,
+                                                                        long plane, float* __restrict__ stats) {
+  const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (pix >= plane) return;
+  const float* p = x + (long)b * C * plane + pix;
+  const float* sc = scale + (long)b * C;
+  float sum = 0.f, mx = -INFINITY;
+  int c = 0;
+  for (; c + 8 <= C; c += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(long)(c + u) * plane];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float w = sc[c + u] * v[u];
+      sum += w;
+      mx = fmaxf(mx, w);
+    }
+  }
+  for (; c < C; ++c) {
+    const float w = sc[c] * p[(long)c * plane];
+    sum += w;
+    mx = fmaxf(mx, w);
+  }
+  stats[((long)b * 2 + 0) * plane + pix] = sum / (float)C;
+  stats[((long)b * 2 + 1) * plane + pix] = mx;
+}
+
+// ResCBAMBlock's tail + ProbNet.mask_net in one read of the block's conv output y and residual res:
+//   m = sigmoid(conv_kxk(stats))                       SpatialAttention   (:68-81)
+//   o_c = relu(m * (scale_c * y_c) + res_c)            ca * out, sa * out, += residual, ReLU (:128-136)
+//   logit = sum_c wm_c * o_c + bm                      mask_net 1x1       (:160,172)
+// 64x4 pixel tiles (whole 256-B row segments per wave), statistic planes + halo in LDS.
+constexpr int kCTX = 64, kCTY = 4;
+__global__ __launch_bounds__(256) void neck_cbam_tail_kernel(const float* __restrict__ y,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ stats,
+                                                             const float* __restrict__ conv_w, int k,
+                                                             const float* __restrict__ res,
+                                                             const float* __restrict__ wm, float bm, int C, int Y,
+                                                             int X, float* __restrict__ logit,
+                                                             float* __restrict__ block_out) {
+  extern __shared__ float s_dyn[];
+  const int r = k / 2, tw = kCTX + k - 1, th = kCTY + k - 1;
+  float* s_w = s_dyn;
+  float* s_s = s_dyn + 2 * k * k;
+  const long plane = (long)Y * X;
+  const int b = blockIdx.z, ty0 = blockIdx.y * kCTY, tx0 = blockIdx.x * kCTX;
+  for (int i = threadIdx.x; i < 2 * k * k; i += 256) s_w[i] = conv_w[i];
+  for (int i = threadIdx.x; i < 2 * tw * th; i += 256) {
+    const int ch = i / (tw * th), rem = i % (tw * th);
+    const int yy = ty0 + rem / tw - r, xx = tx0 + rem % tw - r;
+    s_s[i] = (yy >= 0 && yy < Y && xx >= 0 && xx < X) ? stats[((long)b * 2 + ch) * plane + (long)yy * X + xx] : 0.f;
+  }
+  __syncthreads();
+  const int ly = threadIdx.x / kCTX, lx = threadIdx.x % kCTX;
+  const int yy = ty0 + ly, xx = tx0 + lx;
+  if (yy >= Y || xx >= X) return;
+  float acc = 0.f;
+  for (int ch = 0; ch < 2; ++ch)
+    for (int i = 0; i < k; ++i)
+      for (int j = 0; j < k; ++j)
+        acc = fmaf(s_s[(ch * th + ly + i) * tw + lx + j], s_w[(ch * k + i) * k + j], acc);
+  const float m = 1.0f / (1.0f + __expf(-acc));
+  const long pix = (long)yy * X + xx;
+  const float* py = y + (long)b * C * plane + pix;
+  const float* pr = res + (long)b * C * plane + pix;
+  const float* sc = scale + (long)b * C;
+  float* po = block_out ? block_out + (long)b * C * plane + pix : nullptr;
+  float lg = 0.f;
+  int c = 0;
+  for (; c + 8 <= C; c += 8) {
+    float v[8], q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { v[u] = py[(long)(c + u) * plane]; q[u] = pr[(long)(c + u) * plane]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float o = fmaxf(m * (sc[c + u] * v[u]) + q[u], 0.f);
+      if (po) po[(long)(c + u) * plane] = o;
+      lg = fmaf(wm[c + u], o, lg);
+    }
+  }
+  for (; c < C; ++c) {
+    const float o = fmaxf(m * (sc[c] * py[(long)c * plane]) + pr[(long)c * plane], 0.f);
+    if (po) po[(long)c * plane] = o;
+    lg = fmaf(wm[c], o, lg);
+  }
+  logit[(long)b * plane + pix] = lg + bm;
+}
+
 inline int last_error() { return (int)hipGetLastError(); }
 
 }  // namespace
@@ -645,6 +840,61 @@ int ocrf_dual_feat_fusion(const float* x1, const float* x2, const float* params,
                  (hipStream_t)stream, x1, x2, params, global_vec, out, YX);
   else
     return (int)hipErrorInvalidValue;
+  return last_error();
+}
+
+int ocrf_plane_bias_act_stats(float* y, const float* bias, int B, int C, int YX, int relu, int write, int S,
+                              int out_C, int c_off, float* psum, float* pmax, ocrf_stream_t stream) {
+  if (!y || B <= 0 || C <= 0 || YX <= 0 || S <= 0 || S > 65535) return (int)hipErrorInvalidValue;
+  const bool stats = psum != nullptr;
+  if (stats && (!pmax || out_C < c_off + C || c_off < 0)) return (int)hipErrorInvalidValue;
+  if (!stats && !write) return (int)hipErrorInvalidValue;
+  if (reinterpret_cast<uintptr_t>(y) & 15) return (int)hipErrorInvalidValue;
+  const dim3 grid(S, (unsigned)(B * C)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const long plane = YX;
+#define OCRF_PLANE_PASS(W, R, T)                                                                                  \
+  ocrf::launch(OCRF_K_NECK_PLANE_PASS, neck_plane_pass_kernel<W, R, T>, grid, block, 0, st, y, bias, C, plane, S, \
+               out_C, c_off, psum, pmax)
+  if (write && relu && stats) OCRF_PLANE_PASS(true, true, true);
+  else if (write && relu) OCRF_PLANE_PASS(true, true, false);
+  else if (write && stats) OCRF_PLANE_PASS(true, false, true);
+  else if (write) OCRF_PLANE_PASS(true, false, false);
+  else if (relu) OCRF_PLANE_PASS(false, true, true);
+  else OCRF_PLANE_PASS(false, false, true);
+#undef OCRF_PLANE_PASS
+  return last_error();
+}
+
+int ocrf_channel_mlp(const float* psum, const float* pmax, int B, int K, int S, float inv_n, const float* W1,
+                     const float* b1, const float* W2, const float* b2, int M, int N, int use_max, int do_sigmoid,
+                     float* out, ocrf_stream_t stream) {
+  if (!psum || !W1 || !W2 || !out || B <= 0 || K <= 0 || K > 256 || M <= 0 || M > 64 || N <= 0 || S <= 0 ||
+      (use_max && !pmax))
+    return (int)hipErrorInvalidValue;
+  ocrf::launch(OCRF_K_NECK_CHANNEL_MLP, neck_channel_mlp_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, psum,
+               pmax, K, S, inv_n, W1, b1, W2, b2, M, N, use_max, do_sigmoid, out);
+  return last_error();
+}
+
+int ocrf_scaled_channel_stats(const float* x, const float* scale, int B, int C, int YX, float* stats,
+                              ocrf_stream_t stream) {
+  if (!x || !scale || !stats || B <= 0 || C <= 0 || YX <= 0) return (int)hipErrorInvalidValue;
+  ocrf::launch(OCRF_K_NECK_SCALED_STATS, neck_scaled_channel_stats_kernel, dim3((YX + 255) / 256, B), dim3(256), 0,
+               (hipStream_t)stream, x, scale, C, (long)YX, stats);
+  return last_error();
+}
+
+int ocrf_cbam_tail(const float* y, const float* scale, const float* stats, const float* conv_w, int k,
+                   const float* res, const float* wm, float bm, int B, int C, int Y, int X, float* logit,
+                   float* block_out, ocrf_stream_t stream) {
+  if (!y || !scale || !stats || !conv_w || !res || !wm || !logit || k <= 0 || (k & 1) == 0 || k > 15 || B <= 0 ||
+      C <= 0 || Y <= 0 || X <= 0)
+    return (int)hipErrorInvalidValue;
+  const int tw = kCTX + k - 1, th = kCTY + k - 1;
+  ocrf::launch(OCRF_K_NECK_CBAM_TAIL, neck_cbam_tail_kernel, dim3((X + kCTX - 1) / kCTX, (Y + kCTY - 1) / kCTY, B),
+               dim3(256), (size_t)(2 * k * k + 2 * tw * th) * sizeof(float), (hipStream_t)stream, y, scale, stats,
+               conv_w, k, res, wm, bm, C, Y, X, logit, block_out);
   return last_error();
 }
 

@@ -13,7 +13,9 @@ import torch
 from . import _lib
 
 __all__ = ['prefilter', 'pillar_sample_mean', 'retain_valid_pixels', 'gauss_heads', 'pack_gauss_head_params',
-           'compose_nerf_maps', 'nerf_alpha', 'nerf_render', 'pack_fusion_params', 'dual_feat_fusion']
+           'compose_nerf_maps', 'nerf_alpha', 'nerf_render', 'pack_fusion_params', 'dual_feat_fusion',
+           'plane_bias_act_stats', 'channel_mlp', 'scaled_channel_stats', 'cbam_tail', 'pack_global_att',
+           'pack_probnet', 'probnet_forward', 'global_att_vector']
 
 
 def _f32c(t):
@@ -214,6 +216,15 @@ def _fold_conv_bn(conv, bn):
     return w, b
 
 
+def _fold_conv_bn_kxk(conv, bn):
+    """k x k conv (bias optional) + eval BatchNorm -> (W (out,in,k,k) f32, b (out) f32), folded in float64."""
+    s = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+    w = conv.weight.double() * s[:, None, None, None]
+    cb = conv.bias.double() if conv.bias is not None else torch.zeros_like(s)
+    b = (cb - bn.running_mean.double()) * s + bn.bias.double()
+    return w.float().contiguous(), b.float().contiguous()
+
+
 def pack_fusion_params(ms_cam):
     """Parameter block of ``ocrf_dual_feat_fusion`` from an ``MS_CAM``'s ``local_att`` (conv, bn, relu,
     conv, bn; view_transformer_ocrf.py:42-48): W1t[2C][M] | b1[M] | W2[C][M] | b2[C]."""
@@ -238,3 +249,125 @@ def dual_feat_fusion(x1, x2, params, global_vec, hidden):
                                                     _lib.ptr(out), B, C, hidden, Y * X, _lib.stream_ptr(x1.device)),
                    'ocrf_dual_feat_fusion')
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# CBAM / ProbNet tail (ocrf_plane_bias_act_stats, ocrf_channel_mlp, ocrf_scaled_channel_stats, ocrf_cbam_tail)
+# ------------------------------------------------------------------------------------------------
+_SPLITS = 8
+
+
+def plane_bias_act_stats(y, bias=None, relu=False, write=True, stats=None, c_off=0):
+    """In place on y (B,C,Y,X): ``y += bias[c]`` then ReLU (``write``); with ``stats=(psum, pmax)`` (each
+    (B, out_C, S)) also the S partial sums / maxima of every plane at channel offset ``c_off``."""
+    _lib.require_cuda(y)
+    if not (y.is_contiguous() and y.dtype == torch.float32):
+        raise ValueError('plane_bias_act_stats works in place on a contiguous float32 tensor')
+    B, C, Y, X = y.shape
+    psum, pmax = stats if stats is not None else (None, None)
+    out_C, S = (psum.shape[1], psum.shape[2]) if psum is not None else (C, _SPLITS)
+    with torch.cuda.device(y.device):
+        _lib.check(_lib.lib().ocrf_plane_bias_act_stats(_lib.ptr(y), _lib.ptr(bias), B, C, Y * X, int(relu), int(write),
+                                                        S, out_C, c_off, _lib.ptr(psum), _lib.ptr(pmax),
+                                                        _lib.stream_ptr(y.device)), 'ocrf_plane_bias_act_stats')
+    return y
+
+
+def channel_mlp(psum, pmax, inv_n, w1, b1, w2, b2, use_max, sigmoid):
+    """Pooled vectors (from the partials) through W2.relu(W1.v + b1) + b2, summed over the mean and max vectors
+    when ``use_max``; -> (B, N)."""
+    _lib.require_cuda(psum, w1, w2)
+    B, K, S = psum.shape
+    M, N = w1.shape[0], w2.shape[0]
+    out = torch.empty(B, N, device=psum.device)
+    with torch.cuda.device(psum.device):
+        _lib.check(_lib.lib().ocrf_channel_mlp(_lib.ptr(psum), _lib.ptr(pmax), B, K, S, ctypes.c_float(inv_n),
+                                               _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2), M, N,
+                                               int(use_max), int(sigmoid), _lib.ptr(out),
+                                               _lib.stream_ptr(psum.device)), 'ocrf_channel_mlp')
+    return out
+
+
+def scaled_channel_stats(x, scale):
+    """(B,2,Y,X): mean and max over channels of ``scale[b,c] * x[b,c]``."""
+    _lib.require_cuda(x, scale)
+    B, C, Y, X = x.shape
+    stats = torch.empty(B, 2, Y, X, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().ocrf_scaled_channel_stats(_lib.ptr(x), _lib.ptr(scale), B, C, Y * X, _lib.ptr(stats),
+                                                        _lib.stream_ptr(x.device)), 'ocrf_scaled_channel_stats')
+    return stats
+
+
+def cbam_tail(y, scale, stats, sa_weight, res, wm, bm, want_block_out=False):
+    """ResCBAMBlock's tail + a 1x1 head: -> logit (B,1,Y,X) [, block output (B,C,Y,X)]."""
+    _lib.require_cuda(y, scale, stats, sa_weight, res, wm)
+    B, C, Y, X = y.shape
+    k = sa_weight.shape[-1]
+    logit = torch.empty(B, 1, Y, X, device=y.device)
+    block = torch.empty_like(y) if want_block_out else None
+    with torch.cuda.device(y.device):
+        _lib.check(_lib.lib().ocrf_cbam_tail(_lib.ptr(y), _lib.ptr(scale), _lib.ptr(stats), _lib.ptr(sa_weight), k,
+                                             _lib.ptr(res), _lib.ptr(wm), ctypes.c_float(bm), B, C, Y, X,
+                                             _lib.ptr(logit), _lib.ptr(block), _lib.stream_ptr(y.device)),
+                   'ocrf_cbam_tail')
+    return (logit, block) if want_block_out else logit
+
+
+def pack_global_att(ms_cam):
+    """MS_CAM.global_att (pool, conv, bn, relu, conv, bn; :50-58) with both BatchNorms folded."""
+    with torch.no_grad():
+        ga = ms_cam.global_att
+        w1, b1 = _fold_conv_bn(ga[1], ga[2])
+        w2, b2 = _fold_conv_bn(ga[4], ga[5])
+        return tuple(t.float().contiguous() for t in (w1, b1, w2, b2))
+
+
+def global_att_vector(x1, x2, packed):
+    """MS_CAM's global branch of cat(x1, x2): (B, C) — one read of each input + one tiny launch instead of
+    two means, a cat, two 1x1 convolutions with bias, two BatchNorms and a ReLU."""
+    _lib.require_cuda(x1, x2)
+    B, C, Y, X = x1.shape
+    x1, x2 = _f32c(x1), _f32c(x2)
+    psum = torch.empty(B, 2 * C, _SPLITS, device=x1.device)
+    pmax = torch.empty_like(psum)
+    plane_bias_act_stats(x1, write=False, stats=(psum, pmax), c_off=0)
+    plane_bias_act_stats(x2, write=False, stats=(psum, pmax), c_off=C)
+    w1, b1, w2, b2 = packed
+    return channel_mlp(psum, None, 1.0 / (Y * X), w1, b1, w2, b2, use_max=False, sigmoid=False)
+
+
+def pack_probnet(prob):
+    """Everything ``probnet_forward`` needs from a ``ProbNet`` (:139-201) whose ``prob_conv`` is one
+    ``ResCBAMBlock`` without downsample: the three 3x3 convolutions with their BatchNorms folded, the
+    channel-attention MLP, the spatial-attention kernel and the 1x1 mask head."""
+    with torch.no_grad():
+        blk = prob.prob_conv[0]
+        w0, b0 = _fold_conv_bn_kxk(prob.base_conv[0], prob.base_conv[1])
+        w1, b1 = _fold_conv_bn_kxk(blk.conv1, blk.bn1)
+        w2, b2 = _fold_conv_bn_kxk(blk.conv2, blk.bn2)
+        fc = blk.ca.fc
+        return {'w0': w0, 'b0': b0, 'w1': w1, 'b1': b1, 'w2': w2, 'b2': b2,
+                'ca1': fc[0].weight.float().reshape(fc[0].out_channels, -1).contiguous(),
+                'ca2': fc[2].weight.float().reshape(fc[2].out_channels, -1).contiguous(),
+                'sa': blk.sa.conv1.weight.float().reshape(-1).contiguous(), 'k': blk.sa.conv1.kernel_size[0],
+                'wm': prob.mask_net.weight.float().reshape(-1).contiguous(), 'bm': float(prob.mask_net.bias.item())}
+
+
+def probnet_forward(x, pk):
+    """``ProbNet.forward`` (:171-172 of the module here; reference :195-201), eval mode: three MIOpen
+    convolutions + six HIP launches."""
+    import torch.nn.functional as F
+    _lib.require_cuda(x)
+    B, _, Y, X = x.shape
+    y0 = plane_bias_act_stats(F.conv2d(_f32c(x), pk['w0'], None, padding=1).contiguous(), pk['b0'], relu=True)
+    y1 = plane_bias_act_stats(F.conv2d(y0, pk['w1'], None, padding=1).contiguous(), pk['b1'], relu=True)
+    y2 = F.conv2d(y1, pk['w2'], None, padding=1).contiguous()
+    C = y2.shape[1]
+    psum = torch.empty(B, C, _SPLITS, device=x.device)
+    pmax = torch.empty_like(psum)
+    plane_bias_act_stats(y2, pk['b2'], relu=False, stats=(psum, pmax))
+    scale = channel_mlp(psum, pmax, 1.0 / (Y * X), pk['ca1'], None, pk['ca2'], None, use_max=True, sigmoid=True)
+    stats = scaled_channel_stats(y2, scale)
+    sa = pk['sa'].view(1, 2, pk['k'], pk['k'])
+    return cbam_tail(y2, scale, stats, sa, y0, pk['wm'], pk['bm'])

@@ -168,7 +168,21 @@ class ProbNet(nn.Module):
         self.dice_loss_opacity = DiceLoss(use_sigmoid=True, loss_weight=self.loss_weight_opacity)
         self.ce_loss = nn.BCEWithLogitsLoss(pos_weight=torch.tensor([2.13]))
 
+    def _fusable(self, x):
+        blk = self.prob_conv[0]
+        return (x.is_cuda and not self.training and not torch.is_grad_enabled() and len(self.prob_conv) == 1
+                and blk.downsample is None and blk.stride == 1 and self.mask_net.out_channels == 1)
+
     def forward(self, input):
+        if self._fusable(input):
+            # eval on the GPU: MIOpen's three convolutions with the BatchNorms folded + six HIP launches
+            # (neck_ops.probnet_forward) instead of ~33 launches
+            ts = [t for t in list(self.parameters()) + list(self.buffers()) if t.is_floating_point()]
+            key = tuple((t._version, t.data_ptr()) for t in ts)
+            if self.__dict__.get('_pack_key') != key:
+                self.__dict__['_pack'] = neck_ops.pack_probnet(self)
+                self.__dict__['_pack_key'] = key
+            return neck_ops.probnet_forward(input, self.__dict__['_pack'])
         return self.mask_net(self.prob_conv(self.base_conv(input)))
 
 
@@ -190,14 +204,14 @@ class DualFeatFusion(nn.Module):
         if self._fusable(x1):
             ca = self.ca
             ts = [p for p in ca.local_att.parameters()] + [b for b in ca.local_att.buffers()]
+            ts += [p for p in ca.global_att.parameters()] + [b for b in ca.global_att.buffers()]
             key = tuple((t._version, t.data_ptr()) for t in ts)
             if self.__dict__.get('_pack_key') != key:
-                self.__dict__['_pack'] = neck_ops.pack_fusion_params(ca)
+                self.__dict__['_pack'] = (neck_ops.pack_fusion_params(ca), neck_ops.pack_global_att(ca))
                 self.__dict__['_pack_key'] = key
-            g = torch.cat((x1.mean((2, 3), keepdim=True), x2.mean((2, 3), keepdim=True)), 1)
-            for layer in list(ca.global_att)[1:]:
-                g = layer(g)
-            return neck_ops.dual_feat_fusion(x1, x2, self.__dict__['_pack'], g, ca.local_att[0].out_channels)
+            local, glob = self.__dict__['_pack']
+            g = neck_ops.global_att_vector(x1, x2, glob)
+            return neck_ops.dual_feat_fusion(x1, x2, local, g, ca.local_att[0].out_channels)
         cf = self.ca(torch.cat((x1, x2), 1))
         return cf * x1 + (1 - cf) * x2
 
@@ -317,6 +331,8 @@ class _LinearWeighted(nn.Module):
         self.w = nn.Parameter(torch.tensor(0.5))
 
     def forward(self, a1, a2):
+        if a1.is_cuda and not torch.is_grad_enabled():
+            return torch.lerp(a2, a1, self.w)       # a2 + w (a1 - a2): one launch instead of four
         return self.w * a1 + (1 - self.w) * a2
 
 
@@ -696,7 +712,9 @@ class OcRFViewTransformerFull(nn.Module):
             mark(5)
             geom_feat = self.geom_att.gate(channel_feat, bev_mask_logit)
             mark(6)
-        # ---- strand A, second half
+        # ---- strand A, second half.  (Forking again behind the heads — render + weighted images beside
+        # HOA-1/2 — needs B joined in front of the heads to keep single-parent branches, and that wait costs
+        # more than the overlap returns: 0.84 vs 0.80 ms, tools/ab_neck_graph.py.)
         opacity, scaling, rotation, color = neck_ops.gauss_heads(ht_feat, avg_rgb, self._head_params(), Zh)
         mark(7)
         # every sample is a Gaussian set with one camera: ONE rasteriser call for the batch, fed with the

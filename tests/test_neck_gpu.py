@@ -296,6 +296,58 @@ def test_dual_feat_fusion(core):
     close(fused, want.cpu().numpy(), 1e-5, 'fuser ragged vs torch ops')
 
 
+@pytest.mark.parametrize('shape', [(2, 50, 70), (1, 33, 35), (3, 8, 130)])
+def test_probnet_fused_matches_torch_layers(shape):
+    """ProbNet in eval mode (three MIOpen convolutions with folded BatchNorms + ocrf_plane_bias_act_stats /
+    ocrf_channel_mlp / ocrf_scaled_channel_stats / ocrf_cbam_tail) against the same module's torch layers
+    (taken with autograd enabled); planes that are not multiples of the 64x4 tile or of 4 floats."""
+    from ocrfdet_amd import view_transformer_ocrf as vto
+    B, Y, X = shape
+    torch.manual_seed(B * 100 + Y)
+    dev = torch.device('cuda:0')
+    prob = vto.ProbNet(in_channels=80).to(dev).eval()
+    for mod in prob.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.3), mod.running_var.uniform_(0.5, 1.5)
+            mod.weight.data.uniform_(0.5, 1.5), mod.bias.data.normal_(0, 0.2)
+    x = torch.randn(B, 80, Y, X, device=dev)
+    with torch.no_grad():
+        got = prob(x)
+    with torch.enable_grad():
+        want = prob(x).detach()
+    assert got.shape == want.shape == (B, 1, Y, X)
+    close(got, want.cpu().numpy(), 2e-5 * float(want.abs().max()) + 2e-5, 'ProbNet fused vs torch layers')
+    # a parameter update must invalidate the folded pack
+    with torch.no_grad():
+        prob.mask_net.bias.add_(0.5)
+        got2 = prob(x)
+    close(got2, (want + 0.5).cpu().numpy(), 2e-5 * float(want.abs().max()) + 2e-5, 'ProbNet after a parameter update')
+
+
+def test_global_att_vector_matches_torch_layers():
+    """MS_CAM's global branch (ocrf_plane_bias_act_stats in statistics-only mode + ocrf_channel_mlp) vs the layers."""
+    from ocrfdet_amd import neck_ops
+    from ocrfdet_amd import view_transformer_ocrf as vto
+    torch.manual_seed(5)
+    dev = torch.device('cuda:0')
+    fuser = vto.DualFeatFusion(160, 80).to(dev).eval()
+    for mod in fuser.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.3), mod.running_var.uniform_(0.5, 1.5)
+    a, b = torch.randn(2, 80, 21, 37, device=dev), torch.randn(2, 80, 21, 37, device=dev) + 0.3
+    with torch.no_grad():
+        g = neck_ops.global_att_vector(a, b, neck_ops.pack_global_att(fuser.ca))
+        want = torch.cat((a, b), 1).mean((2, 3), keepdim=True)
+        for layer in list(fuser.ca.global_att)[1:]:
+            want = layer(want)
+    close(g, want.reshape(2, 80).cpu().numpy(), 1e-5, 'global_att vector')
+    with torch.no_grad():
+        fused = fuser(a, b)
+    with torch.enable_grad():
+        ref = fuser(a, b).detach()
+    close(fused, ref.cpu().numpy(), 1e-5, 'DualFeatFusion fused vs torch layers')
+
+
 @pytest.mark.parametrize('zh', [1, 2, 4, 6, 8, 13])
 def test_gauss_heads_every_supported_height_count(zh):
     """Every register-tile instantiation of ocrf_gauss_heads (heights per pillar) against torch layers."""
