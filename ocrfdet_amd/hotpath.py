@@ -334,7 +334,8 @@ class NeckPath:
         static device tensors that ``step_graphed`` refreshes before every replay."""
         from .view_transformer_ocrf import GraphedNeck
         self._graphed = GraphedNeck(self.module, self.inputs, self.depthnet_out, warmup=warmup,
-                                    parallel_branches=self._graph_parallel)
+                                    parallel_branches=self._graph_parallel,
+                                    capture_stream=getattr(self, '_capture_stream', None))
         return self
 
     def step_graphed(self, cam_idx_list=None):

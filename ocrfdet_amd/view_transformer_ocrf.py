@@ -837,7 +837,8 @@ class GraphedNeck:
     the graph (``_core_fused``).  Outputs are static tensors, overwritten by the next call.  Eval mode,
     forward only."""
 
-    def __init__(self, module, example_input, example_depthnet_out, warmup=3, parallel_branches=True):
+    def __init__(self, module, example_input, example_depthnet_out, warmup=3, parallel_branches=True,
+                 capture_stream=None):
         if not module.accelerate:
             raise RuntimeError('GraphedNeck needs accelerate=True (geometry cached across calls)')
         if module.training:
@@ -861,7 +862,7 @@ class GraphedNeck:
                 torch.cuda.current_stream(dev).wait_stream(side)
                 torch.cuda.synchronize(dev)
                 self._graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._graph):
+                with torch.cuda.graph(self._graph, stream=capture_stream):
                     self._static_out = self._body(self._cams)
             finally:
                 m.parallel_branches = False

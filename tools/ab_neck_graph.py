@@ -18,7 +18,9 @@ def main():
     dev = torch.device('cuda:0')
     necks = {}
     # edit the variants here: (label, function that configures the NeckPath before capture)
-    variants = (('parallel strands', lambda n: None), ('one strand', lambda n: setattr(n, '_graph_parallel', False)))
+    variants = (('parallel strands', lambda n: None),
+                ('main strand captured on a high-priority stream',
+                 lambda n: setattr(n, '_capture_stream', torch.cuda.Stream(dev, priority=-1))))
     for name, setup in variants:
         n = hotpath.NeckPath(cfg, dev, accelerate=True)
         setup(n)
