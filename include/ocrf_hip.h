@@ -283,6 +283,22 @@ int ocrf_hoa_opacity_mask_gate(const float *x, const float *stats, const float *
                                float *gated, ocrf_stream_t stream);
 
 /*
+ * Depthwise 3x3 convolution, padding 1, stride 1 (the first layer of OpacityVoxelToBEVConverter.conv_block,
+ * view_transformer_ocrf.py:483-489) for the TRAINING path, where MIOpen's depthwise backward-weight costs
+ * milliseconds on these 4..16-channel maps:
+ *   ocrf_hoa_dw3x3:        y[b][c] = conv3x3(x[b][c], w[c] (9 floats)) + bias[c]   (bias may be NULL); also the
+ *                          input gradient when called with dy and the flipped weights
+ *   ocrf_hoa_dw3x3_wgrad:  partial[(b*C + c) * n_bands + band][10]: per 16-row band the nine sums
+ *                          dy[y][x] * x[y+i-1][x+j-1] and the sum of dy; n_bands = ocrf_hoa_dw3x3_wgrad_bands(Y);
+ *                          the caller adds the bands and samples (fixed order: deterministic).
+ */
+int ocrf_hoa_dw3x3(const float *x, const float *w, const float *bias, int B, int C, int Y, int X, float *y,
+                   ocrf_stream_t stream);
+int ocrf_hoa_dw3x3_wgrad_bands(int Y);
+int ocrf_hoa_dw3x3_wgrad(const float *x, const float *dy, int B, int C, int Y, int X, float *partial,
+                         ocrf_stream_t stream);
+
+/*
  * HeightAttention.forward (view_transformer_ocrf.py:447-461) and its use `ca(x) * x`
  * (:499-514): the C channels are four height quarters of q = C/4 channels; per quarter g
  *   gate[b][g*q + o] = sigmoid( sum_h w2[g][o][h] * relu( sum_i w1[g][h][i] * max_{y,x} x[b][g*q+i] ) )
@@ -490,6 +506,8 @@ enum {
   OCRF_K_HOA1_UP = 27,           /* hoa1_upsample_residual_kernel */
   OCRF_K_HOA1_Q = 28,            /* hoa1_q_kernel */
   OCRF_K_HOA1_KV = 29,           /* hoa1_kv_kernel */
+  OCRF_K_HOA_DW3X3 = 30,         /* hoa_dw3x3_kernel */
+  OCRF_K_HOA_DW3X3_WGRAD = 31,   /* hoa_dw3x3_wgrad_kernel */
   OCRF_K_LSS_KEYS = 40,          /* lss_keys_kernel */
   OCRF_K_RADIX_HIST = 41,        /* radix_hist_kernel */
   OCRF_K_SCAN = 42,              /* scan_apply_kernel<T> */

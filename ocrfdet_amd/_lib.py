@@ -150,6 +150,12 @@ def _declare(L):
     L.ocrf_scaled_channel_stats.argtypes = [c_void_p] * 2 + [c_int] * 3 + [c_void_p] * 2
     L.ocrf_cbam_tail.restype = c_int
     L.ocrf_cbam_tail.argtypes = [c_void_p] * 4 + [c_int] + [c_void_p] * 2 + [c_float] + [c_int] * 4 + [c_void_p] * 3
+    L.ocrf_hoa_dw3x3.restype = c_int
+    L.ocrf_hoa_dw3x3.argtypes = [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 2
+    L.ocrf_hoa_dw3x3_wgrad_bands.restype = c_int
+    L.ocrf_hoa_dw3x3_wgrad_bands.argtypes = [c_int]
+    L.ocrf_hoa_dw3x3_wgrad.restype = c_int
+    L.ocrf_hoa_dw3x3_wgrad.argtypes = [c_void_p] * 2 + [c_int] * 4 + [c_void_p] * 2
     L.ocrf_diag_stamp.restype = c_int
     L.ocrf_diag_stamp.argtypes = [c_void_p, c_void_p]
     L.ocrf_kernel_name.restype = ctypes.c_char_p

@@ -86,6 +86,8 @@ const char* ocrf_kernel_name(int kernel_id) {
     case OCRF_K_HOA1_UP: return "hoa1_upsample_residual_kernel";
     case OCRF_K_HOA1_Q: return "hoa1_q_kernel";
     case OCRF_K_HOA1_KV: return "hoa1_kv_kernel";
+    case OCRF_K_HOA_DW3X3: return "hoa_dw3x3_kernel";
+    case OCRF_K_HOA_DW3X3_WGRAD: return "hoa_dw3x3_wgrad_kernel";
     case OCRF_K_LSS_KEYS: return "lss_keys_kernel";
     case OCRF_K_RADIX_HIST: return "radix_hist_kernel";
     case OCRF_K_SCAN: return "scan_apply_kernel<*>";

@@ -158,9 +158,98 @@ __global__ __launch_bounds__(kBlock) void hoa_height_gate_kernel(
   for (int c = 0; c < C; ++c) o[(long)c * plane] = p[(long)c * plane] * s_gate[c];
 }
 
+// Depthwise 3x3 convolution (padding 1, stride 1) for the TRAINING path of HOA-2's UNet blocks
+// (view_transformer_ocrf.py:483-489 conv_block's first layer): MIOpen's depthwise backward-weight runs
+// 2-10 ms per call on these 4..16-channel maps (26 ms of an 84 ms neck forward + backward at 200x200).
+// One kernel serves the forward and the input gradient (the caller passes the flipped weights, no bias);
+// the weight / bias gradient is a band-wise partial reduction the caller sums (deterministic).
+constexpr int kDwBand = 16;
+__global__ __launch_bounds__(kBlock) void hoa_dw3x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, int C, int Y, int X,
+                                                           float* __restrict__ y) {
+  const int bc = blockIdx.z, c = bc % C;
+  const int xx = blockIdx.x * 64 + (threadIdx.x & 63), yy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (xx >= X || yy >= Y) return;
+  const float* p = x + (long)bc * Y * X;
+  float acc = bias ? bias[c] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int sy = yy + i - 1;
+    if (sy < 0 || sy >= Y) continue;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int sx = xx + j - 1;
+      if (sx < 0 || sx >= X) continue;
+      acc = fmaf(w[c * 9 + i * 3 + j], p[(long)sy * X + sx], acc);
+    }
+  }
+  y[(long)bc * Y * X + (long)yy * X + xx] = acc;
+}
+
+// partial[(bc * n_bands + band) * 10 + t]: t < 9 -> sum over the band of dy[y][x] * x[y+i-1][x+j-1], t = 9 -> sum dy
+__global__ __launch_bounds__(kBlock) void hoa_dw3x3_wgrad_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ dy, int Y, int X,
+                                                                 float* __restrict__ partial) {
+  __shared__ float s_acc[kBlock / 64][10];
+  const int bc = blockIdx.y, band = blockIdx.x;
+  const float* px = x + (long)bc * Y * X;
+  const float* pg = dy + (long)bc * Y * X;
+  const int y0 = band * kDwBand, y1 = min(y0 + kDwBand, Y);
+  float acc[10];
+#pragma unroll
+  for (int t = 0; t < 10; ++t) acc[t] = 0.f;
+  for (int idx = threadIdx.x; idx < (y1 - y0) * X; idx += kBlock) {
+    const int yy = y0 + idx / X, xx = idx % X;
+    const float g = pg[(long)yy * X + xx];
+    acc[9] += g;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int sy = yy + i - 1;
+      if (sy < 0 || sy >= Y) continue;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int sx = xx + j - 1;
+        if (sx < 0 || sx >= X) continue;
+        acc[i * 3 + j] = fmaf(g, px[(long)sy * X + sx], acc[i * 3 + j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 10; ++t) {
+    float v = acc[t];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0) s_acc[threadIdx.x >> 6][t] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 10) {
+    float v = 0.f;
+    for (int wv = 0; wv < kBlock / 64; ++wv) v += s_acc[wv][threadIdx.x];
+    partial[((long)bc * gridDim.x + band) * 10 + threadIdx.x] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int ocrf_hoa_dw3x3(const float* x, const float* w, const float* bias, int B, int C, int Y, int X, float* y,
+                   ocrf_stream_t stream_) {
+  if (!x || !w || !y || B <= 0 || C <= 0 || Y <= 0 || X <= 0 || (long)B * C > 65535) return (int)hipErrorInvalidValue;
+  ocrf::launch(OCRF_K_HOA_DW3X3, hoa_dw3x3_kernel, dim3((X + 63) / 64, (Y + 3) / 4, B * C), dim3(kBlock), 0,
+               static_cast<hipStream_t>(stream_), x, w, bias, C, Y, X, y);
+  return (int)hipGetLastError();
+}
+
+int ocrf_hoa_dw3x3_wgrad_bands(int Y) { return (Y + kDwBand - 1) / kDwBand; }
+
+int ocrf_hoa_dw3x3_wgrad(const float* x, const float* dy, int B, int C, int Y, int X, float* partial,
+                         ocrf_stream_t stream_) {
+  if (!x || !dy || !partial || B <= 0 || C <= 0 || Y <= 0 || X <= 0 || (long)B * C > 65535)
+    return (int)hipErrorInvalidValue;
+  ocrf::launch(OCRF_K_HOA_DW3X3_WGRAD, hoa_dw3x3_wgrad_kernel, dim3(ocrf_hoa_dw3x3_wgrad_bands(Y), B * C),
+               dim3(kBlock), 0, static_cast<hipStream_t>(stream_), x, dy, Y, X, partial);
+  return (int)hipGetLastError();
+}
 
 int ocrf_hoa_channel_stats(const float* x, int B, int C, int Y, int X, float* stats, ocrf_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);

@@ -115,6 +115,57 @@ class HeightAttention(nn.Module):
         return self._run(x, True)[1]
 
 
+def _dw3x3(x, w9, bias):
+    B, C, Y, X = x.shape
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().ocrf_hoa_dw3x3(_lib.ptr(x), _lib.ptr(w9), _lib.ptr(bias), B, C, Y, X, _lib.ptr(y),
+                                             _lib.stream_ptr(x.device)), 'ocrf_hoa_dw3x3')
+    return y
+
+
+class _DepthwiseConv3x3(torch.autograd.Function):
+    """Depthwise 3x3 convolution (padding 1) with HIP forward and backward (``ocrf_hoa_dw3x3``,
+    ``ocrf_hoa_dw3x3_wgrad``): the training path of HOA-2's UNet blocks.  MIOpen's depthwise backward-weight
+    takes 2-10 ms per call on these 4..16-channel BEV maps; the weight gradient here is a band-wise partial
+    reduction summed in a fixed order (deterministic)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _lib.require_cuda(x, weight)
+        x = _f32c(x)
+        C = x.shape[1]
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return _dw3x3(x, _f32c(weight.detach()).reshape(C, 9), _f32c(bias.detach()) if bias is not None else None)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        B, C, Y, X = x.shape
+        gy = _f32c(gy)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _dw3x3(gy, _f32c(weight.detach().flip(2, 3)).reshape(C, 9), None)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            L = _lib.lib()
+            nb = L.ocrf_hoa_dw3x3_wgrad_bands(Y)
+            partial = torch.empty(B, C, nb, 10, device=x.device)
+            with torch.cuda.device(x.device):
+                _lib.check(L.ocrf_hoa_dw3x3_wgrad(_lib.ptr(x), _lib.ptr(gy), B, C, Y, X, _lib.ptr(partial),
+                                                  _lib.stream_ptr(x.device)), 'ocrf_hoa_dw3x3_wgrad')
+            sums = partial.sum((0, 2))                                   # (C, 10)
+            gw = sums[:, :9].reshape(C, 1, 3, 3).to(weight.dtype)
+            gb = sums[:, 9] if ctx.has_bias else None
+        return gx, gw, gb
+
+
+def _is_dw3x3(conv):
+    return (isinstance(conv, nn.Conv2d) and conv.kernel_size == (3, 3) and conv.padding == (1, 1)
+            and conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.padding_mode == 'zeros'
+            and conv.groups == conv.in_channels == conv.out_channels)
+
+
 class OpacityVoxelToBEVConverter(nn.Module):
     def __init__(self, input_channel=13):
         super().__init__()
@@ -147,13 +198,25 @@ class OpacityVoxelToBEVConverter(nn.Module):
         if not self.training and x.is_cuda and not (torch.is_grad_enabled() and (
                 x.requires_grad or any(p.requires_grad for p in self.parameters()))):
             return self._forward_fused(x, position)
-        # training mode (BatchNorm batch statistics): block by block, gates still in HIP
-        enc1 = self.ca1.gate_apply(self.encoder1(x) + position)
-        enc2 = self.ca2.gate_apply(self.encoder2(self.pool(enc1)))
-        mid = self.ca_bottleneck.gate_apply(self.bottleneck(self.pool(enc2)))
-        dec2 = self.ca_dec2.gate_apply(self.decoder2(torch.cat((self.upconv2(mid), enc2), dim=1)))
-        dec1 = self.ca_dec1.gate_apply(self.decoder1(torch.cat((self.upconv1(dec2), enc1), dim=1)))
+        # training mode (BatchNorm batch statistics): block by block; the depthwise layers (forward and
+        # backward) and the gates run in HIP, the 1x1 layers / BatchNorm / pooling are torch ops
+        blk = self._block
+        enc1 = self.ca1.gate_apply(blk(self.encoder1, x) + position)
+        enc2 = self.ca2.gate_apply(blk(self.encoder2, self.pool(enc1)))
+        mid = self.ca_bottleneck.gate_apply(blk(self.bottleneck, self.pool(enc2)))
+        dec2 = self.ca_dec2.gate_apply(blk(self.decoder2, torch.cat((self.upconv2(mid), enc2), dim=1)))
+        dec1 = self.ca_dec1.gate_apply(blk(self.decoder1, torch.cat((self.upconv1(dec2), enc1), dim=1)))
         return self.output_conv(dec1)
+
+    @staticmethod
+    def _block(block, x):
+        dw = block[0]
+        if x.is_cuda and _is_dw3x3(dw):
+            x = _DepthwiseConv3x3.apply(x, dw.weight, dw.bias)
+            for layer in list(block)[1:]:
+                x = layer(x)
+            return x
+        return block(x)
 
     def _folded(self, block):
         """(dw_w (Cin,9), dw_b, pw_w (Cout,Cin) with BatchNorm folded in, pw_b) of a conv_block;

@@ -234,6 +234,43 @@ class BEVGeomAttention(nn.Module):
         return self.forward(x, bev_prob) * x
 
 
+class _TallLinear(torch.autograd.Function):
+    """``F.linear`` whose weight gradient is a split-K batched GEMM.  The heads run on 10^6 rows with 4..83
+    columns; hipBLASLt computes ``dW = dY^T X`` (K = rows) as ONE tall reduction at 1-5 ms per layer (20 ms of an
+    84 ms neck forward + backward).  Chunks of 4096 rows through ``bmm`` + a sum are ~30x faster."""
+    CHUNK = 4096
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = g.matmul(weight)
+        g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
+        if ctx.needs_input_grad[1]:
+            r = _TallLinear.CHUNK
+            n = g2.shape[0] // r
+            gw = torch.bmm(g2[:n * r].view(n, r, -1).transpose(1, 2), x2[:n * r].view(n, r, -1)).sum(0)
+            if n * r < g2.shape[0]:
+                gw = gw + g2[n * r:].t().mm(x2[n * r:])
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g2.sum(0)
+        return gx, gw, gb
+
+
+def _linear(lin, x):
+    """``lin(x)`` for an ``nn.Linear``; many-row inputs under autograd take the split-K weight gradient."""
+    if x.is_cuda and torch.is_grad_enabled() and x.numel() // x.shape[-1] >= 8 * _TallLinear.CHUNK:
+        return _TallLinear.apply(x, lin.weight, lin.bias)
+    return lin(x)
+
+
 class _Head(nn.Module):
     """fc1 -> ReLU -> fc2 -> ``act``; ``extra`` widens fc1's input by the sampled RGB (:272-380)."""
     extra = 0
@@ -247,7 +284,7 @@ class _Head(nn.Module):
         return x
 
     def forward(self, x):
-        return self.act(self.fc2(torch.relu(self.fc1(x))))
+        return self.act(_linear(self.fc2, torch.relu(_linear(self.fc1, x))))
 
 
 class ScaleFactorMLP(_Head):
@@ -774,7 +811,7 @@ class OcRFViewTransformerFull(nn.Module):
         sparse = torch.where(keep.view(B, 1, H, W), imgs_s, torch.full_like(imgs_s, 255.0))
         feat = self.image_feat_resize(x.reshape(B * N, -1, Hf, Wf).float())                  # (B*N,80,H,W)
         f = feat.permute(0, 2, 3, 1)
-        alpha = 1. - torch.exp(-self.sigma(f))                                               # (B*N,H,W,1)
+        alpha = 1. - torch.exp(-self.sigma[2](_linear(self.sigma[1], _linear(self.sigma[0], f))))      # (B*N,H,W,1)
         alpha_lidar = sample(alpha.reshape(B, N, 1, W, H), W, H).view(B, Zh, Y, X)
         fs = f.view(B, N, H, W, -1)[ar, sel]
         xin = torch.cat((fs, sparse.permute(0, 2, 3, 1) / 255.0), -1)

@@ -169,3 +169,34 @@ def test_hoa_modules_keep_gradients_under_autograd():
     assert xin.grad is not None and float(xin.grad.abs().sum()) > 0
     with torch.no_grad():
         assert torch.allclose(v2b(xin, pos), out, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(2, 13, 50, 70), (1, 4, 17, 5), (3, 16, 33, 129)])
+def test_depthwise_conv3x3_forward_and_backward(shape):
+    """ocrf_hoa_dw3x3 / ocrf_hoa_dw3x3_wgrad (the training path of the UNet blocks) against F.conv2d's own
+    forward and autograd gradients; ragged planes (not multiples of the 64x4 tile / 16-row band)."""
+    import torch.nn.functional as F
+    B, C, Y, X = shape
+    torch.manual_seed(C)
+    dev = torch.device('cuda:0')
+    conv = torch.nn.Conv2d(C, C, 3, padding=1, groups=C).to(dev)
+    x = torch.randn(B, C, Y, X, device=dev, requires_grad=True)
+    gy = torch.randn(B, C, Y, X, device=dev)
+    want = F.conv2d(x, conv.weight, conv.bias, padding=1, groups=C)
+    gx_w, gw_w, gb_w = torch.autograd.grad(want, (x, conv.weight, conv.bias), gy)
+    got = hoa._DepthwiseConv3x3.apply(x, conv.weight, conv.bias)
+    gx, gw, gb = torch.autograd.grad(got, (x, conv.weight, conv.bias), gy)
+    assert torch.allclose(got, want, atol=1e-5)
+    assert torch.allclose(gx, gx_w, atol=1e-5)
+    assert torch.allclose(gw, gw_w, atol=2e-4 * float(gw_w.abs().max()) + 1e-4), float((gw - gw_w).abs().max())
+    assert torch.allclose(gb, gb_w, atol=2e-4 * float(gb_w.abs().max()) + 1e-4)
+    # the block wrapper takes this path and matches the plain Sequential, training-mode BatchNorm included
+    v2b = hoa.OpacityVoxelToBEVConverter(13).to(dev).train()
+    xin = torch.randn(2, 13, 16, 24, device=dev, requires_grad=True)
+    a = v2b._block(v2b.encoder1, xin)
+    b = v2b.encoder1(xin)
+    assert torch.allclose(a, b, atol=1e-5)
+    ga, = torch.autograd.grad(a.square().sum(), xin)
+    gb2, = torch.autograd.grad(b.square().sum(), xin)
+    assert torch.allclose(ga, gb2, atol=1e-4)

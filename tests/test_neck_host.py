@@ -124,3 +124,26 @@ def test_module_is_deepcopyable_and_picklable(core):
     buf.seek(0)
     m3 = torch.load(buf, weights_only=False)
     assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m3.state_dict().values()))
+
+
+def test_tall_linear_split_k_gradients():
+    """``_TallLinear`` (split-K weight gradient of the heads' Linear layers): same outputs and gradients as
+    ``nn.Linear`` in float64, row count not a multiple of the chunk, bias present / absent."""
+    import torch
+    from ocrfdet_amd import view_transformer_ocrf as vto
+    torch.manual_seed(0)
+    old = vto._TallLinear.CHUNK
+    vto._TallLinear.CHUNK = 512
+    try:
+        for bias in (True, False):
+            lin = torch.nn.Linear(7, 3, bias=bias).double()
+            x = torch.randn(2, 1333, 7, dtype=torch.double, requires_grad=True)
+            y = vto._TallLinear.apply(x, lin.weight, lin.bias)
+            params = [x, lin.weight] + ([lin.bias] if bias else [])
+            got = torch.autograd.grad(y.square().sum(), params)
+            want = torch.autograd.grad(lin(x).square().sum(), params)
+            assert torch.equal(y, lin(x))
+            for a, b in zip(got, want):
+                assert torch.allclose(a, b, rtol=1e-12, atol=1e-12)
+    finally:
+        vto._TallLinear.CHUNK = old

@@ -1,0 +1,63 @@
+"""Diagnostic: the neck in TRAINING mode at a bench configuration — forward + backward of
+``view_transform_core`` (per-forward index preparation, differentiable torch ops around the HIP
+bev_pool_v2 / rasteriser forward + backward kernels), wall time per iteration and the top device ops.
+
+    python tools/time_neck_train.py [config] [--iters N] [--profile]
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ocrfdet_amd import hotpath, synthetic  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('config', nargs='?', default='cfg2_6cam_2frame_bev200x200_render_hoa')
+    ap.add_argument('--iters', type=int, default=10)
+    ap.add_argument('--profile', action='store_true')
+    a = ap.parse_args()
+    cfg = synthetic.CONFIGS[a.config]
+    dev = torch.device('cuda:0')
+    neck = hotpath.NeckPath(cfg, dev, accelerate=False)
+    m = neck.module.train()
+    pre = neck.depthnet_out
+    depth0 = pre[:, :cfg.D].softmax(1)
+    feat0 = pre[:, cfg.D + 2:cfg.D + 2 + cfg.channels].clone()
+
+    def it():
+        depth = depth0.clone().requires_grad_(True)
+        feat = feat0.clone().requires_grad_(True)
+        bev, _, logit, lst = m.view_transform_core(neck.inputs, depth, feat)
+        loss = bev.square().mean() + logit.square().mean() + lst[0].mean() + lst[6].mean() + lst[4].square().mean()
+        loss.backward()
+        m.zero_grad(set_to_none=True)
+        return loss
+
+    for _ in range(3):
+        it()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.iters):
+        it()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / a.iters
+    print(f'{cfg.name}: B={neck.batch} training forward + backward: {ms:.2f} ms per iteration')
+    if a.profile:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as p:
+            for _ in range(3):
+                it()
+            torch.cuda.synchronize()
+        rows = [e for e in p.key_averages(group_by_input_shape=True) if e.device_time_total > 0 and e.key.startswith('aten::')]
+        rows.sort(key=lambda e: -e.device_time_total)
+        for e in rows[:40]:
+            print(f'{e.device_time_total / 3e3:9.2f} ms/iter  n={e.count // 3:4d}  {e.key:38s} {str(e.input_shapes)[:150]}')
+
+
+if __name__ == '__main__':
+    main()
