@@ -147,3 +147,26 @@ def test_tall_linear_split_k_gradients():
                 assert torch.allclose(a, b, rtol=1e-12, atol=1e-12)
     finally:
         vto._TallLinear.CHUNK = old
+
+
+def test_voxel_lift_closed_form_matches_layers():
+    """``VoxelFeatureExtractor._lift`` (Conv3d(1->Zh, k=1) + BatchNorm3d + ReLU as one broadcast multiply-add)
+    against the three layers in float64: outputs, every gradient and the running statistics, training and eval."""
+    import copy
+    import torch
+    from ocrfdet_amd import view_transformer_ocrf as vto
+    torch.manual_seed(0)
+    m = vto.VoxelFeatureExtractor(1, 13).double()
+    m.conv[1].weight.data.uniform_(0.5, 1.5), m.conv[1].bias.data.normal_()
+    ref = copy.deepcopy(m)
+    x = torch.randn(2, 1, 5, 6, 8, dtype=torch.double, requires_grad=True)
+    for train in (True, True, False):
+        m.train(train), ref.train(train)
+        a, b = m._lift(x), ref.conv(x)
+        assert torch.allclose(a, b, rtol=0, atol=1e-12)
+        ga = torch.autograd.grad(a.square().sum(), [x] + list(m.parameters()))
+        gb = torch.autograd.grad(b.square().sum(), [x] + list(ref.parameters()))
+        for p, q in zip(ga, gb):
+            assert torch.allclose(p, q, rtol=0, atol=1e-8)
+        for k in ('running_mean', 'running_var', 'num_batches_tracked'):
+            assert torch.allclose(getattr(m.conv[1], k).double(), getattr(ref.conv[1], k).double(), rtol=0, atol=1e-12), k

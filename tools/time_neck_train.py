@@ -20,6 +20,7 @@ def main():
     ap.add_argument('config', nargs='?', default='cfg2_6cam_2frame_bev200x200_render_hoa')
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--profile', action='store_true')
+    ap.add_argument('--host', action='store_true', help='cProfile of the host side')
     a = ap.parse_args()
     cfg = synthetic.CONFIGS[a.config]
     dev = torch.device('cuda:0')
@@ -47,12 +48,26 @@ def main():
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / a.iters
     print(f'{cfg.name}: B={neck.batch} training forward + backward: {ms:.2f} ms per iteration')
+    if a.host:
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(5):
+            it()
+        torch.cuda.synchronize()
+        pr.disable()
+        pstats.Stats(pr).sort_stats('cumulative').print_stats(60)
     if a.profile:
         from torch.profiler import ProfilerActivity, profile
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as p:
             for _ in range(3):
                 it()
             torch.cuda.synchronize()
+        ka = p.key_averages()
+        print(f'device time {sum(e.self_device_time_total for e in ka) / 3e3:.2f} ms/iter, host (self CPU) {sum(e.self_cpu_time_total for e in ka) / 3e3:.2f} ms/iter')
+        for e in sorted(ka, key=lambda e: -e.self_device_time_total)[:25]:
+            print(f'  {e.self_device_time_total / 3e3:8.3f} ms/iter  n={e.count // 3:4d}  {e.key[:120]}')
         rows = [e for e in p.key_averages(group_by_input_shape=True) if e.device_time_total > 0 and e.key.startswith('aten::')]
         rows.sort(key=lambda e: -e.device_time_total)
         for e in rows[:40]:
