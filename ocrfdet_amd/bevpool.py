@@ -25,7 +25,7 @@ import torch
 from . import _lib
 
 __all__ = ['bev_pool_v2_device_counts', 'bev_pool_v2', 'bev_pool_v2_collapsed', 'TRTBEVPoolv2', 'QuickCumsumCuda',
-           'bev_pool_v2_ext', 'runs_of']
+           'bev_pool_v2_ext', 'runs_of', 'dense_runs']
 
 
 def _want(t, dtype, name):
@@ -40,6 +40,16 @@ def runs_of(sorted_ranks):
     _, counts = torch.unique_consecutive(sorted_ranks, return_counts=True)
     ends = torch.cumsum(counts, 0)
     return (ends - counts).int(), counts.int()
+
+
+def dense_runs(sorted_ranks, n_values):
+    """(starts, lengths) int32 of the run of EVERY value 0..n_values-1 in a sorted 1-D tensor (length 0 where
+    a value is absent).  Same runs as ``runs_of`` plus empty ones, but of a size the host knows: no
+    device -> host read (``unique_consecutive`` has to return its count), so the backward of ``bev_pool_v2``
+    does not stall the autograd thread.  The gradient kernels skip empty runs."""
+    edges = torch.searchsorted(sorted_ranks, torch.arange(n_values + 1, device=sorted_ranks.device,
+                                                          dtype=sorted_ranks.dtype))
+    return edges[:-1].int(), (edges[1:] - edges[:-1]).int()
 
 
 class _ExtensionAPI:
@@ -134,7 +144,7 @@ class QuickCumsumCuda(torch.autograd.Function):
         # regroup the point list by feature pixel (bev_pool.py:47-57); stable so that runs of
         # equal ranks_feat keep their forward order
         rf_sorted, perm = torch.sort(rf, stable=True)
-        starts_bp, lengths_bp = runs_of(rf_sorted)
+        starts_bp, lengths_bp = dense_runs(rf_sorted, f32.numel() // f32.size(-1))
         g_depth = torch.zeros_like(d32)
         g_feat = torch.zeros_like(f32)
         bev_pool_v2_ext.bev_pool_v2_backward(
@@ -194,7 +204,7 @@ class _FusedPool(torch.autograd.Function):
         else:
             g = grad_out.view(B, Z, C, Y, X).permute(0, 1, 3, 4, 2)
         rf_sorted, perm = torch.sort(rf, stable=True)
-        starts_bp, lengths_bp = runs_of(rf_sorted)
+        starts_bp, lengths_bp = dense_runs(rf_sorted, f32.numel() // f32.size(-1))
         g_depth = torch.zeros_like(d32)
         g_feat = torch.zeros_like(f32)
         bev_pool_v2_ext.bev_pool_v2_backward(

@@ -519,6 +519,7 @@ __global__ __launch_bounds__(kBlock) void bev_pool_grad_scalar_kernel(
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_intervals) return;
   const int start = interval_starts[idx], len = interval_lengths[idx];
+  if (len <= 0) return;                       // empty runs (dense per-pixel run tables) touch nothing
   for (int i = 0; i < len; ++i) {
     const float* og = out_grad + (long)ranks_bev[start + i] * c;
     const float* f = feat + (long)ranks_feat[start + i] * c;
