@@ -262,10 +262,57 @@ def main():
     t = timed(capture(v10))
     print(f'v10 three chains of 40 short kernels: {t:.3f} ms  (x{t / base * 20:.1f} short kernels; ideal 42, serial 122)')
 
+    def v11():     # two chains that exchange one event each way in the middle (no fork node at all)
+        cur = torch.cuda.current_stream()
+        sB = streams[0]
+        x.add_(1)
+        sB.wait_stream(cur)
+        with torch.cuda.stream(sB):
+            spins(2)
+            ev_b = torch.cuda.Event()
+            ev_b.record(sB)
+        spins(2)
+        ev_h = torch.cuda.Event()
+        ev_h.record(cur)
+        with torch.cuda.stream(sB):
+            sB.wait_event(ev_h)
+            spins(3)
+        cur.wait_event(ev_b)
+        spins(3)
+        cur.wait_stream(sB)
+        x.add_(1)
+
+    def v12():     # v11 plus a third chain C forked after the first node of cur (the neck's strand C)
+        cur = torch.cuda.current_stream()
+        sB, sC = streams[0], streams[1]
+        x.add_(1)
+        sB.wait_stream(cur)
+        with torch.cuda.stream(sB):
+            spins(2)
+            ev_b = torch.cuda.Event()
+            ev_b.record(sB)
+        spins(1)
+        sC.wait_stream(cur)
+        with torch.cuda.stream(sC):
+            spins(5)
+        spins(1)
+        ev_h = torch.cuda.Event()
+        ev_h.record(cur)
+        with torch.cuda.stream(sB):
+            sB.wait_event(ev_h)
+            spins(3)
+        cur.wait_event(ev_b)
+        spins(3)
+        cur.wait_stream(sB)
+        cur.wait_stream(sC)
+        x.add_(1)
+
     for name, fn, ideal, serial in (('v7 event wait before P, mid join', v7, 8, 16), ('v8 B1 before the fork, mid join', v8, 8, 16),
                                     ('v9 B1 before the fork, joins at the end', v9, 10, 16),('v1 nested fork + B, no cross edge', v1, 5, 12), ('v3 cross edge only', v3, 4, 8),
                                     ('v4 nested fork alone', v4, 5, 8), ('v5 A2 on its own stream', v5, 5, 12),
-                                    ('v6 C forked at root, waits P by event', v6, 5, 12)):
+                                    ('v6 C forked at root, waits P by event', v6, 5, 12),
+                                    ('v11 two chains crossing in the middle', v11, 5, 10),
+                                    ('v12 = v11 + a third chain forked after the first node', v12, 6, 15)):
         t = timed(capture(fn))
         print(f'{name}: {t:.3f} ms  (x{t / base * 4:.2f} spins; ideal {ideal}, serial {serial})')
 
