@@ -495,6 +495,7 @@ class OcRFViewTransformerFull(nn.Module):
         # eval-mode strands on side HIP streams (see _core_fused); off by default: a caller that runs the
         # module under its own stream discipline should opt in
         self.parallel_branches, self._transient = False, hoa._LaunchCache()     # streams: not module state
+        self.fork_c_after = 'heads'
         self._rank_bufs = (index_prep._RankBuffers(), index_prep._RankBuffers())
         self._packs = {}
 
@@ -768,21 +769,30 @@ class OcRFViewTransformerFull(nn.Module):
         lss_feat = self.get_lss_bev_feat(geo, depth5, feat_cl)
         ht_feat = self.get_ht_bev_feat(geo, depth5, feat_cl)
         mark(3)
-        # ---- strand C
-        if par:
-            sC.wait_stream(cur)
-        with on(sC if par else None):
-            channel_feat = self.fuser(lss_feat, ht_feat)
-            mark(4)
-            bev_mask_logit = self.prob(self._pos('positional_encoding', B, x) + channel_feat)
-            mark(5)
-            geom_feat = self.geom_att.gate(channel_feat, bev_mask_logit)
-            mark(6)
+        def strand_c():
+            if par:
+                sC.wait_stream(cur)
+            with on(sC if par else None):
+                channel_feat = self.fuser(lss_feat, ht_feat)
+                mark(4)
+                logit = self.prob(self._pos('positional_encoding', B, x) + channel_feat)
+                mark(5)
+                gated = self.geom_att.gate(channel_feat, logit)
+                mark(6)
+            return logit, gated
+        # Where strand C is forked: C needs only the poolings, but beside MIOpen's convolutions of C the big
+        # kernels of this strand are starved (heads 64 us alone, 355 us there; the render 88 -> 310 us) and
+        # everything behind them waits, so they go first (tools/ab_neck_graph.py).
+        fork_at = self.fork_c_after
+        if fork_at == 'pools':
+            bev_mask_logit, geom_feat = strand_c()
+        opacity, scaling, rotation, color = neck_ops.gauss_heads(ht_feat, avg_rgb, self._head_params(), Zh)
+        mark(7)
+        if fork_at == 'heads':
+            bev_mask_logit, geom_feat = strand_c()
         # ---- strand A, second half.  (Forking again behind the heads — render + weighted images beside
         # HOA-1/2 — needs B joined in front of the heads to keep single-parent branches, and that wait costs
         # more than the overlap returns: 0.84 vs 0.80 ms, tools/ab_neck_graph.py.)
-        opacity, scaling, rotation, color = neck_ops.gauss_heads(ht_feat, avg_rgb, self._head_params(), Zh)
-        mark(7)
         # every sample is a Gaussian set with one camera: ONE rasteriser call for the batch, fed with the
         # staged camera rows (the reference loops samples, :1090-1153)
         if self._bg is None or self._bg.device != dev:
@@ -790,6 +800,8 @@ class OcRFViewTransformerFull(nn.Module):
         o = rasterize_sets(voxel_coor, color, opacity, scaling, rotation, cameras['packed'], H, W, self._bg)
         render_image_G_all, render_depth_G_all = o['color'], o['depth']
         mark(8)
+        if fork_at == 'render':
+            bev_mask_logit, geom_feat = strand_c()
         if par:
             cur.wait_stream(sB)
         render_image = self.LinearWeightedImage(render_image_G_all, render_N)

@@ -18,9 +18,8 @@ def main():
     dev = torch.device('cuda:0')
     necks = {}
     # edit the variants here: (label, function that configures the NeckPath before capture)
-    variants = (('parallel strands', lambda n: None),
-                ('main strand captured on a high-priority stream',
-                 lambda n: setattr(n, '_capture_stream', torch.cuda.Stream(dev, priority=-1))))
+    variants = tuple((f'C forked after the {w}', (lambda w: lambda n: setattr(n.module, 'fork_c_after', w))(w))
+                     for w in ('pools', 'heads', 'render'))
     for name, setup in variants:
         n = hotpath.NeckPath(cfg, dev, accelerate=True)
         setup(n)

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ocrfdet_amd import hotpath, synthetic  # noqa: E402
 
 NAMES = ['core start (cur)', 'B: colours sampled', 'B: end (NeRF branch, alpha volume, gt)', 'A: both pools done',
-         'C: fusion done', 'C: ProbNet done', 'C: geometry gate done', 'A: heads done', 'A: render done',
+         'C: fusion done', 'C: ProbNet done', 'C: geometry gate done', 'A: heads done (before C is forked)', 'A: render done',
          'A: joined B, weighted images', 'A: HOA-1 done', 'A: HOA-2 done', 'end (joined C, HOA-3)']
 
 
