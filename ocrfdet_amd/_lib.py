@@ -4,6 +4,7 @@ There is no CPU or PyTorch fallback anywhere in ``ocrfdet_amd``: if the library 
 the ops raise.  ``build()`` compiles it in-tree with hipcc for gfx950 (cross-compiles without a
 GPU); the built ``.so`` is git-ignored but travels with the source tree.
 """
+import contextlib
 import ctypes
 import os
 import subprocess
@@ -175,9 +176,27 @@ def check(err, what):
         raise OcrfHipError(f"{what} failed with hipError_t {err}")
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream_ptr(device=None):
     """hipStream_t of torch's current stream on ``device`` as an integer for ctypes."""
+    if _raw_stream is not None:
+        idx = device.index if isinstance(device, torch.device) else device
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device() if idx is None else idx))
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+_NO_SWITCH = contextlib.nullcontext()
+
+
+def on_device(device):
+    """``torch.cuda.device(device)`` when the current device differs, else a no-op: the context manager costs
+    ~10 us per call, more than the launch it guards (the reference's OptionalCUDAGuard, bev_pool.cpp:42)."""
+    idx = device.index if isinstance(device, torch.device) else device
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_SWITCH
+    return torch.cuda.device(idx)
 
 
 def require_cuda(*tensors):

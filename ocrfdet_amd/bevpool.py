@@ -73,7 +73,7 @@ class _ExtensionAPI:
             raise _lib.OcrfHipError('rank / interval vectors disagree in length')
         L = _lib.lib()
         dev = depth.device
-        with torch.cuda.device(dev):                  # OptionalCUDAGuard, bev_pool.cpp:42
+        with _lib.on_device(dev):                  # OptionalCUDAGuard, bev_pool.cpp:42
             stream = _lib.stream_ptr(dev)
             if os.environ.get('OCRF_CHECK_INTERVALS', '0') == '1':
                 flag = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -108,7 +108,7 @@ class _ExtensionAPI:
         channels = out_grad.size(4)                   # `c = _out_grad.size(4)`, bev_pool.cpp:86
         L = _lib.lib()
         dev = out_grad.device
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(L.ocrf_bev_pool_v2_grad(
                 channels, interval_lengths.size(0), _lib.ptr(out_grad), _lib.ptr(depth),
                 _lib.ptr(feat), _lib.ptr(ranks_depth), _lib.ptr(ranks_feat), _lib.ptr(ranks_bev),
@@ -183,7 +183,7 @@ class _FusedPool(torch.autograd.Function):
         out = torch.empty((B, C, Z, Y, X) if layout == 0 else (B, Z * C, Y, X),
                           dtype=torch.float32, device=dev)
         L = _lib.lib()
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             need = L.ocrf_bev_pool_v2_nchw_workspace_bytes(C, n_iv, n_pts, B * Z * Y * X)
             scratch = _lib.workspace.get(dev, need, 'bev_pool_nchw')
             _lib.check(L.ocrf_bev_pool_v2_nchw(
@@ -243,7 +243,7 @@ def bev_pool_v2_device_counts(depth, feat, ranks_depth, ranks_feat, ranks_bev, b
     dev = d32.device
     out = torch.empty((B, C, Z, Y, X) if layout == 0 else (B, Z * C, Y, X), dtype=torch.float32, device=dev)
     L = _lib.lib()
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         need = L.ocrf_bev_pool_v2_nchw_workspace_bytes(C, cap_iv, cap_pts, B * Z * Y * X)
         scratch = _lib.workspace.get(dev, need, 'bev_pool_nchw')
         _lib.check(L.ocrf_bev_pool_v2_nchw_dyn(
@@ -273,7 +273,7 @@ class DevicePoolPlan:
         L = _lib.lib()
         self.plan = torch.empty(L.ocrf_bev_pool_plan_bytes(C, self.n_points, ctypes.c_long(B * Z * Y * X)), dtype=torch.uint8,
                                 device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(L.ocrf_bev_pool_plan_build(C, self.n_intervals, self.n_points, _lib.ptr(rb), _lib.ptr(st), _lib.ptr(ln),
                                                   ctypes.c_long(B * Z * Y * X), _lib.ptr(self.plan),
                                                   ctypes.c_size_t(self.plan.numel()), _lib.stream_ptr(dev)),
@@ -292,7 +292,7 @@ def bev_pool_v2_planned(depth, feat, plan, layout=1):
     dev = d32.device
     out = torch.empty((B, C, Z, Y, X) if layout == 0 else (B, Z * C, Y, X), dtype=torch.float32, device=dev)
     L = _lib.lib()
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         need = L.ocrf_bev_pool_v2_nchw_workspace_bytes(C, plan.n_intervals, plan.n_points, B * Z * Y * X)
         scratch = _lib.workspace.get(dev, need, 'bev_pool_nchw')
         _lib.check(L.ocrf_bev_pool_v2_nchw_planned(

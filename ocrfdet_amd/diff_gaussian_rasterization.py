@@ -102,7 +102,7 @@ def rasterize_views_backward(grad_color, fwd, means3D, colors, opacities, scales
             out['means2D'] = m2d
         return out
     L = _lib.lib()
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         need = L.ocrf_rasterize_backward_workspace_bytes(P, V)
         ws = _lib.workspace.get(dev, need, 'raster')
         _lib.check(L.ocrf_rasterize_backward(
@@ -150,7 +150,7 @@ def rasterize_views(means3D, colors, opacities, scales, rotations, viewmatrices,
     tt = torch.empty(V, P, dtype=torch.int32, device=dev) if want_tiles_touched else None
     status = torch.empty(1, dtype=torch.int32, device=dev)      # zeroed on the device by the bucket scan kernel
     L = _lib.lib()
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         need = L.ocrf_rasterize_workspace_bytes(P, V)
         ws = _lib.workspace.get(dev, need, workspace_tag)
         _lib.check(L.ocrf_rasterize_forward(
@@ -187,7 +187,7 @@ def rasterize_sets(means3D, colors, opacities, scales, rotations, packed_cameras
                radii=torch.empty(NV, P, dtype=torch.int32, device=dev))
     status = torch.empty(1, dtype=torch.int32, device=dev)
     L = _lib.lib()
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         need = L.ocrf_rasterize_workspace_bytes(P, NV)
         ws = _lib.workspace.get(dev, need, workspace_tag)
         _lib.check(L.ocrf_rasterize_forward_sets(

@@ -83,7 +83,7 @@ class HeightAttention(nn.Module):
         gate = torch.empty(B, C, device=x.device)
         gated = torch.empty_like(x) if want_gated else None
         L = _lib.lib()
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             ws = _lib.workspace.get(x.device, L.ocrf_hoa_height_attention_workspace_bytes(B, C), 'hoa')
             _lib.check(L.ocrf_hoa_height_attention(
                 _lib.ptr(x), B, C, self.hid, Y, X, _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(gate), _lib.ptr(gated),
@@ -118,7 +118,7 @@ class HeightAttention(nn.Module):
 def _dw3x3(x, w9, bias):
     B, C, Y, X = x.shape
     y = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         _lib.check(_lib.lib().ocrf_hoa_dw3x3(_lib.ptr(x), _lib.ptr(w9), _lib.ptr(bias), B, C, Y, X, _lib.ptr(y),
                                              _lib.stream_ptr(x.device)), 'ocrf_hoa_dw3x3')
     return y
@@ -151,7 +151,7 @@ class _DepthwiseConv3x3(torch.autograd.Function):
             L = _lib.lib()
             nb = L.ocrf_hoa_dw3x3_wgrad_bands(Y)
             partial = torch.empty(B, C, nb, 10, device=x.device)
-            with torch.cuda.device(x.device):
+            with _lib.on_device(x.device):
                 _lib.check(L.ocrf_hoa_dw3x3_wgrad(_lib.ptr(x), _lib.ptr(gy), B, C, Y, X, _lib.ptr(partial),
                                                   _lib.stream_ptr(x.device)), 'ocrf_hoa_dw3x3_wgrad')
             sums = partial.sum((0, 2))                                   # (C, 10)
@@ -305,7 +305,7 @@ class OpacityVoxelToBEVConverter(nn.Module):
         L = _lib.lib()
         plan = self._plan(B, H, W, dev)
         out = torch.empty(B, 1, H, W, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             st = _lib.stream_ptr(dev)
             for call in plan['calls']:
                 if call[0] == 'block':
@@ -333,7 +333,7 @@ def spatial_gate(weight, x, addend, want_gated):
     mask = torch.empty(B, 1, Y, X, device=x.device)
     gated = torch.empty_like(x) if want_gated else None
     L = _lib.lib()
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         st = _lib.stream_ptr(x.device)
         _lib.check(L.ocrf_hoa_channel_stats(_lib.ptr(x), B, C, Y, X, _lib.ptr(stats), st), 'ocrf_hoa_channel_stats')
         _lib.check(L.ocrf_hoa_opacity_mask_gate(_lib.ptr(x), _lib.ptr(stats), _lib.ptr(ob), _lib.ptr(w), k, B, C,
@@ -503,7 +503,7 @@ def hoa1(defor_cross_attention, opacity, alpha_lidar, heights, Y, X):
         assert w.numel() == L.ocrf_hoa1_weights_len()
         att = torch.empty(B * ((heights + 8) * (Y // 6) * (X // 6) + 18 * 128), device=o.device)   # att | q | kv
         out = torch.empty_like(o32)
-        with torch.cuda.device(o.device):
+        with _lib.on_device(o.device):
             _lib.check(L.ocrf_hoa1_forward(_lib.ptr(o32), _lib.ptr(a32), _lib.ptr(w), B, Y, X,
                                            ctypes.c_float(float(m.to_offsets[4].scale)), _lib.ptr(att), _lib.ptr(out),
                                            _lib.stream_ptr(o.device)), 'ocrf_hoa1_forward')

@@ -268,7 +268,7 @@ def voxel_pooling_prepare_v2_hip(frustum, cam_block, B, N, grid_lower_bound, gri
     n_pts = B * N * D * H * W
     bufs = (buffers if buffers is not None else _RankBuffers()).get(dev, n_pts, min(n_pts, B * gz * gy * gx))
     L = _lib.lib()
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         need = L.ocrf_lss_prepare_workspace_bytes(B, N, D, H, W, gx, gy, gz)
         ws = _lib.workspace.get(dev, need, 'index_prep')
         _lib.check(L.ocrf_lss_prepare(
@@ -294,7 +294,7 @@ def fast_sample_prepare_hip(ref_template, cam_block, B, N, pc_range, image_shape
     n_pts = B * N * Z * Nq
     bufs = (buffers if buffers is not None else _RankBuffers()).get(dev, n_pts, B * Nq)
     L = _lib.lib()
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         need = L.ocrf_ht_prepare_workspace_bytes(B, Nq)
         ws = _lib.workspace.get(dev, need, 'index_prep')
         _lib.check(L.ocrf_ht_prepare(
@@ -318,7 +318,7 @@ def ht_project_hip(ref_template, cam_block, B, N, pc_range, image_shapes, depth_
     pix = torch.empty(B, N, Z, Nq, 2, device=dev)
     mask = torch.empty(B, N, Z, Nq, dtype=torch.bool, device=dev)
     voxel = torch.empty(B, Z, Nq, 3, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(_lib.lib().ocrf_ht_project(
             B, N, Z, Nq, _lib.ptr(ref_template.contiguous()), _lib.ptr(cam_block), ctypes.c_void_p(pc.data_ptr()),
             ctypes.c_float(image_shapes[1]), ctypes.c_float(image_shapes[0]), ctypes.c_float(depth_range[0]),

@@ -38,7 +38,7 @@ def prefilter(x, D, C, depth_threshold, semantic_threshold):
     fdepth = torch.empty_like(depth)
     sem = torch.empty(BN, 2, H, W, device=dev)
     feat = torch.empty(BN, H, W, C, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(_lib.lib().ocrf_prefilter(_lib.ptr(x), BN, D, C, H * W, ctypes.c_float(depth_threshold),
                                              ctypes.c_float(semantic_threshold), _lib.ptr(depth), _lib.ptr(fdepth),
                                              _lib.ptr(sem), _lib.ptr(feat), _lib.stream_ptr(dev)), 'ocrf_prefilter')
@@ -67,7 +67,7 @@ def pillar_sample_mean(imgs, pix, mask, view_hw=None):
     imgs, pix = _f32c(imgs), _f32c(pix)
     m = _mask_bytes(mask, (B, N, Zh * Q))
     avg = torch.empty(B, Zh, Q, C, device=imgs.device)
-    with torch.cuda.device(imgs.device):
+    with _lib.on_device(imgs.device):
         _lib.check(_lib.lib().ocrf_pillar_sample_mean(_lib.ptr(imgs), _lib.ptr(pix), _lib.ptr(m), _lib.ptr(avg), B, N, C,
                                                       H, W, Zh * Q, _lib.stream_ptr(imgs.device)),
                    'ocrf_pillar_sample_mean')
@@ -92,7 +92,7 @@ def retain_valid_pixels(image_matrix, pseudo_point_cloud, mask, cam_sel=None):
         out = torch.empty(B, C, H, W, device=dev)
     else:
         out = torch.empty(B, N, C, H, W, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(_lib.lib().ocrf_retain_valid_pixels(_lib.ptr(imgs), _lib.ptr(pix), _lib.ptr(m), _lib.ptr(cam_sel),
                                                        _lib.ptr(out), B, N, C, H, W, ZQ, _lib.stream_ptr(dev)),
                    'ocrf_retain_valid_pixels')
@@ -132,7 +132,7 @@ def gauss_heads(bev, rgb_avg, params, num_height):
     dev = bev.device
     op, sc = torch.empty(B, P, 1, device=dev), torch.empty(B, P, 3, device=dev)
     rot, col = torch.empty(B, P, 4, device=dev), torch.empty(B, P, 3, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(L.ocrf_gauss_heads(_lib.ptr(bev), _lib.ptr(rgb_avg), _lib.ptr(params), B, C, num_height, Y * X,
                                       _lib.ptr(op), _lib.ptr(sc), _lib.ptr(rot), _lib.ptr(col), _lib.stream_ptr(dev)),
                    'ocrf_gauss_heads')
@@ -181,7 +181,7 @@ def nerf_alpha(z, w_sigma, c_sigma):
     if ci != 32 or w_sigma.numel() != 32 * 64 or c_sigma.numel() != 64:
         raise ValueError('nerf_alpha: z must have 32 channels and the maps 32x64 / 64 entries')
     alpha = torch.empty(M, 8 * h2, 8 * w2, device=z.device)
-    with torch.cuda.device(z.device):
+    with _lib.on_device(z.device):
         _lib.check(_lib.lib().ocrf_nerf_alpha(_lib.ptr(z), _lib.ptr(w_sigma), _lib.ptr(c_sigma), _lib.ptr(alpha), M,
                                               h2, w2, _lib.stream_ptr(z.device)), 'ocrf_nerf_alpha')
     return alpha
@@ -201,7 +201,7 @@ def nerf_render(z, cam_sel, alpha, sparse_rgb, params, n_cams):
     cam_sel = cam_sel.to(torch.int32).contiguous()
     img = torch.empty(B, 3, 8 * h2, 8 * w2, device=z.device)
     dep = torch.empty(B, 1, 8 * h2, 8 * w2, device=z.device)
-    with torch.cuda.device(z.device):
+    with _lib.on_device(z.device):
         _lib.check(L.ocrf_nerf_render(_lib.ptr(z), _lib.ptr(cam_sel), _lib.ptr(alpha), _lib.ptr(sparse_rgb),
                                       _lib.ptr(params), B, n_cams, h2, w2, _lib.ptr(img), _lib.ptr(dep),
                                       _lib.stream_ptr(z.device)), 'ocrf_nerf_render')
@@ -244,7 +244,7 @@ def dual_feat_fusion(x1, x2, params, global_vec, hidden):
     if params.numel() != 2 * C * hidden + hidden + C * hidden + C:
         raise ValueError('dual_feat_fusion: parameter block does not match (C, hidden)')
     out = torch.empty_like(x1)
-    with torch.cuda.device(x1.device):
+    with _lib.on_device(x1.device):
         _lib.check(_lib.lib().ocrf_dual_feat_fusion(_lib.ptr(x1), _lib.ptr(x2), _lib.ptr(params), _lib.ptr(gv),
                                                     _lib.ptr(out), B, C, hidden, Y * X, _lib.stream_ptr(x1.device)),
                    'ocrf_dual_feat_fusion')
@@ -266,7 +266,7 @@ def plane_bias_act_stats(y, bias=None, relu=False, write=True, stats=None, c_off
     B, C, Y, X = y.shape
     psum, pmax = stats if stats is not None else (None, None)
     out_C, S = (psum.shape[1], psum.shape[2]) if psum is not None else (C, _SPLITS)
-    with torch.cuda.device(y.device):
+    with _lib.on_device(y.device):
         _lib.check(_lib.lib().ocrf_plane_bias_act_stats(_lib.ptr(y), _lib.ptr(bias), B, C, Y * X, int(relu), int(write),
                                                         S, out_C, c_off, _lib.ptr(psum), _lib.ptr(pmax),
                                                         _lib.stream_ptr(y.device)), 'ocrf_plane_bias_act_stats')
@@ -280,7 +280,7 @@ def channel_mlp(psum, pmax, inv_n, w1, b1, w2, b2, use_max, sigmoid):
     B, K, S = psum.shape
     M, N = w1.shape[0], w2.shape[0]
     out = torch.empty(B, N, device=psum.device)
-    with torch.cuda.device(psum.device):
+    with _lib.on_device(psum.device):
         _lib.check(_lib.lib().ocrf_channel_mlp(_lib.ptr(psum), _lib.ptr(pmax), B, K, S, ctypes.c_float(inv_n),
                                                _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2), M, N,
                                                int(use_max), int(sigmoid), _lib.ptr(out),
@@ -293,7 +293,7 @@ def scaled_channel_stats(x, scale):
     _lib.require_cuda(x, scale)
     B, C, Y, X = x.shape
     stats = torch.empty(B, 2, Y, X, device=x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         _lib.check(_lib.lib().ocrf_scaled_channel_stats(_lib.ptr(x), _lib.ptr(scale), B, C, Y * X, _lib.ptr(stats),
                                                         _lib.stream_ptr(x.device)), 'ocrf_scaled_channel_stats')
     return stats
@@ -306,7 +306,7 @@ def cbam_tail(y, scale, stats, sa_weight, res, wm, bm, want_block_out=False):
     k = sa_weight.shape[-1]
     logit = torch.empty(B, 1, Y, X, device=y.device)
     block = torch.empty_like(y) if want_block_out else None
-    with torch.cuda.device(y.device):
+    with _lib.on_device(y.device):
         _lib.check(_lib.lib().ocrf_cbam_tail(_lib.ptr(y), _lib.ptr(scale), _lib.ptr(stats), _lib.ptr(sa_weight), k,
                                              _lib.ptr(res), _lib.ptr(wm), ctypes.c_float(bm), B, C, Y, X,
                                              _lib.ptr(logit), _lib.ptr(block), _lib.stream_ptr(y.device)),

@@ -84,6 +84,26 @@ class ChannelAttention(nn.Module):
         return self.sigmoid(self.fc(x.mean((2, 3), keepdim=True)) + self.fc(x.amax((2, 3), keepdim=True)))
 
 
+def _tensors_of(owner, name, modules, buffers=True):
+    """The parameter (+ buffer) tensors of ``modules`` as a list cached on ``owner``: enumerating them through
+    ``Module.parameters()`` costs ~0.1 ms per call, a third of the host time of an eager forward.  The weight-pack
+    caches key on these tensors' versions / addresses, which ``load_state_dict``, optimizer steps and ``.to()``
+    all change while the tensor OBJECTS stay; ``OcRFViewTransformerFull`` drops the lists on ``_apply`` /
+    ``load_state_dict`` / ``train`` anyway.  Assigning a NEW ``nn.Parameter`` to a sub-module needs
+    ``invalidate_packs()``."""
+    cache = owner.__dict__.setdefault('_tensor_lists', {})
+    lst = cache.get(name)
+    if lst is None:
+        lst = cache[name] = [t for m in modules
+                             for t in list(m.parameters()) + (list(m.buffers()) if buffers else [])]
+    return lst
+
+
+def _drop_tensor_lists(root):
+    for m in root.modules():
+        m.__dict__.pop('_tensor_lists', None)
+
+
 _ZEROS = {}
 
 
@@ -177,7 +197,7 @@ class ProbNet(nn.Module):
         if self._fusable(input):
             # eval on the GPU: MIOpen's three convolutions with the BatchNorms folded + six HIP launches
             # (neck_ops.probnet_forward) instead of ~33 launches
-            ts = [t for t in list(self.parameters()) + list(self.buffers()) if t.is_floating_point()]
+            ts = _tensors_of(self, 'prob', (self,))
             key = tuple((t._version, t.data_ptr()) for t in ts)
             if self.__dict__.get('_pack_key') != key:
                 self.__dict__['_pack'] = neck_ops.pack_probnet(self)
@@ -203,8 +223,7 @@ class DualFeatFusion(nn.Module):
     def forward(self, x1, x2):
         if self._fusable(x1):
             ca = self.ca
-            ts = [p for p in ca.local_att.parameters()] + [b for b in ca.local_att.buffers()]
-            ts += [p for p in ca.global_att.parameters()] + [b for b in ca.global_att.buffers()]
+            ts = _tensors_of(self, 'fuser', (ca.local_att, ca.global_att))
             key = tuple((t._version, t.data_ptr()) for t in ts)
             if self.__dict__.get('_pack_key') != key:
                 self.__dict__['_pack'] = (neck_ops.pack_fusion_params(ca), neck_ops.pack_global_att(ca))
@@ -502,7 +521,8 @@ class OcRFViewTransformerFull(nn.Module):
     def _recording(self, *tensors):
         if not torch.is_grad_enabled():
             return False
-        return any(t is not None and t.requires_grad for t in tensors) or any(p.requires_grad for p in self.parameters())
+        return (any(t is not None and t.requires_grad for t in tensors)
+                or any(p.requires_grad for p in _tensors_of(self, 'all', (self,), buffers=False)))
 
     def _reference_depth_net(self, cfg):
         try:
@@ -601,6 +621,24 @@ class OcRFViewTransformerFull(nn.Module):
         return out
 
     # -------------------------------------------------------------------------------- packs
+    def invalidate_packs(self):
+        """Forget the cached tensor lists and weight packs (needed only after assigning a NEW Parameter object to a
+        sub-module; value updates, ``load_state_dict``, ``.to()`` and ``train()`` are tracked)."""
+        _drop_tensor_lists(self)
+        self._packs.clear()
+
+    def _apply(self, fn, *args, **kwargs):
+        _drop_tensor_lists(self)
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        _drop_tensor_lists(self)
+        return super().load_state_dict(*args, **kwargs)
+
+    def train(self, mode=True):
+        _drop_tensor_lists(self)
+        return super().train(mode)
+
     def _pack(self, name, params, build):
         key = tuple((p._version, p.data_ptr()) for p in params)
         hit = self._packs.get(name)
@@ -610,19 +648,18 @@ class OcRFViewTransformerFull(nn.Module):
 
     def _head_params(self):
         mods = (self.ObtainVoxelFeature, self.S_MLP, self.R_MLP, self.A_MLP, self.C_MLP)
-        ps = [p for m in mods for p in list(m.parameters()) + list(m.buffers())]
-        return self._pack('heads', ps, lambda: neck_ops.pack_gauss_head_params(*mods))
+        return self._pack('heads', _tensors_of(self, 'heads', mods), lambda: neck_ops.pack_gauss_head_params(*mods))
 
     def _nerf_params(self):
         mods = (self.image_feat_resize, self.sigma, self.C_MLP_nerf, self.img_feat_resize1, self.img_feat_resize2)
-        ps = [p for m in mods for p in m.parameters()]
-        return self._pack('nerf', ps, lambda: neck_ops.compose_nerf_maps(*mods))
+        return self._pack('nerf', _tensors_of(self, 'nerf', mods, buffers=False),
+                          lambda: neck_ops.compose_nerf_maps(*mods))
 
     def _pos(self, name, batch, like):
         """Eval-mode positional-encoding maps are constants of the weights: built once per (weights, batch)
         instead of arange + 2 embeddings + cat + an 80-channel strided ``repeat`` per forward."""
         enc = getattr(self, name)
-        return self._pack((name, batch, like.dtype), list(enc.parameters()),
+        return self._pack((name, batch, like.dtype), _tensors_of(self, name, (enc,), buffers=False),
                           lambda: enc(_zeros((batch, self.bev_h, self.bev_w), like)).to(like.dtype).contiguous())
 
     # -------------------------------------------------------------------------------- pooling
