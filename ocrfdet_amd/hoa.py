@@ -131,6 +131,7 @@ class _DepthwiseConv3x3(torch.autograd.Function):
     reduction summed in a fixed order (deterministic)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, x, weight, bias):
         _lib.require_cuda(x, weight)
         x = _f32c(x)
@@ -140,6 +141,7 @@ class _DepthwiseConv3x3(torch.autograd.Function):
         return _dw3x3(x, _f32c(weight.detach()).reshape(C, 9), _f32c(bias.detach()) if bias is not None else None)
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         B, C, Y, X = x.shape

@@ -260,12 +260,14 @@ class _TallLinear(torch.autograd.Function):
     CHUNK = 4096
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda')
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return F.linear(x, weight, bias)
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         gx = gw = gb = None
