@@ -552,3 +552,43 @@ def test_graphed_neck_follows_new_inputs(core):
         close(got[4], want[3][0].cpu().numpy(), 1e-5, 'render_imgs')
         close(got[5], want[3][3].cpu().numpy(), 1e-5, 'render_N')
         assert ex[5] == cams
+
+
+def test_cbam_entry_points_edge_cases_and_argument_errors():
+    """Tiny planes (fewer elements than one chunk / one tile), K at the channel_mlp limit, and the C entry points'
+    refusal of malformed calls (hipErrorInvalidValue = 1 instead of a launch)."""
+    import ctypes
+    from ocrfdet_amd import _lib, neck_ops
+    dev = torch.device('cuda:0')
+    torch.manual_seed(3)
+    # 1 x 3 plane: every chunk but the first is empty
+    y = torch.randn(2, 5, 1, 3, device=dev)
+    bias = torch.randn(5, device=dev)
+    psum, pmax = torch.empty(2, 5, 8, device=dev), torch.empty(2, 5, 8, device=dev)
+    want = torch.relu(y + bias.view(1, 5, 1, 1))
+    neck_ops.plane_bias_act_stats(y, bias, relu=True, stats=(psum, pmax))
+    assert torch.equal(y, want)
+    assert torch.allclose(psum.sum(2), want.sum((2, 3)), atol=1e-6) and torch.equal(pmax.amax(2), want.amax((2, 3)))
+    # channel_mlp at K = 256, M = 64 against torch
+    B, K, M, N, S = 3, 256, 64, 70, 4
+    ps, pm = torch.randn(B, K, S, device=dev), torch.randn(B, K, S, device=dev)
+    w1, b1 = torch.randn(M, K, device=dev) / 16, torch.randn(M, device=dev)
+    w2, b2 = torch.randn(N, M, device=dev) / 8, torch.randn(N, device=dev)
+    got = neck_ops.channel_mlp(ps, pm, 0.25, w1, b1, w2, b2, use_max=True, sigmoid=True)
+    f = lambda v: torch.relu(v @ w1.t() + b1) @ w2.t() + b2
+    ref = torch.sigmoid(f(ps.sum(2) * 0.25) + f(pm.amax(2)))
+    close(got, ref.cpu().numpy(), 2e-5, 'channel_mlp at the size limits')
+    L, st = _lib.lib(), _lib.stream_ptr(dev)
+    p = _lib.ptr
+    assert L.ocrf_channel_mlp(p(ps), p(pm), B, 257, S, ctypes.c_float(1.0), p(w1), p(b1), p(w2), p(b2), M, N, 1, 1,
+                              p(got), st) == 1                                    # K over the LDS budget
+    assert L.ocrf_channel_mlp(p(ps), None, B, K, S, ctypes.c_float(1.0), p(w1), p(b1), p(w2), p(b2), M, N, 1, 1,
+                              p(got), st) == 1                                    # use_max without maxima
+    assert L.ocrf_plane_bias_act_stats(p(y), p(bias), 2, 5, 3, 1, 0, 8, 5, 0, None, None, st) == 1   # nothing to do
+    assert L.ocrf_plane_bias_act_stats(p(y), p(bias), 2, 5, 3, 1, 1, 8, 4, 0, p(psum), p(pmax), st) == 1  # out_C < C
+    x = torch.randn(1, 4, 2, 2, device=dev)
+    sc, stt, w = torch.ones(1, 4, device=dev), torch.zeros(1, 2, 2, 2, device=dev), torch.zeros(2 * 16, device=dev)
+    lg = torch.empty(1, 1, 2, 2, device=dev)
+    assert L.ocrf_cbam_tail(p(x), p(sc), p(stt), p(w), 4, p(x), p(sc), ctypes.c_float(0.0), 1, 4, 2, 2, p(lg), None,
+                            st) == 1                                              # even kernel size
+    torch.cuda.synchronize()
