@@ -770,15 +770,20 @@ __global__ __launch_bounds__(kBlock) void hoa1_kv_kernel(const float* __restrict
   float* s_gl = s_q + ntok * kHI;                   // [nkv][8] GELU(offset conv)
   float* s_f = s_gl + nkv * kHI;                    // [nkv][2] sampling position in the (hq,wq) map
   float* s_kv = s_f + nkv * 2;                      // [nkv][13] sampled alpha
-  const int tid = threadIdx.x, b = blockIdx.x;
+  // grid (G, B): workgroup g of a sample owns kv tokens [j0, j1) — the phases are latency chains (36-tap
+  // LDS convolution, 16 dependent global taps per sampled value), so B workgroups left the chip idle for 20 us
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int per = (hk * wk + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int j0 = blockIdx.x * per, j1 = min(j0 + per, hk * wk), nj = j1 - j0;
+  if (nj <= 0) return;
   const long plane = (long)Y * X;
   const float* al = alpha + (long)b * kHD * plane;
   float* out = kvbuf + (long)b * nkv * 18;
   for (int i = tid; i < kHoaWeights; i += kBlock) s_w[i] = wts[i];
   for (int i = tid; i < ntok * kHI; i += kBlock) s_q[i] = qbuf[(long)b * ntok * kHI + i];
   __syncthreads();
-  for (int i = tid; i < nkv * kHI; i += kBlock) {          // one (kv token, channel) per thread
-    const int j = i / kHI, d = i % kHI;
+  for (int i = tid; i < nj * kHI; i += kBlock) {           // one (kv token, channel) per thread
+    const int j = j0 + i / kHI, d = i % kHI;
     const int ky = j / wk, kx = j % wk;
     float a = s_w[oDB + d];
     for (int u = 0; u < 6; ++u) {
@@ -790,10 +795,10 @@ __global__ __launch_bounds__(kBlock) void hoa1_kv_kernel(const float* __restrict
         a = fmaf(s_w[oDW + d * 36 + u * 6 + v], s_q[(yy * wq + xx) * kHI + d], a);
       }
     }
-    s_gl[i] = 0.5f * a * (1.f + erff(a * 0.70710678118654752f));            // nn.GELU (exact)
+    s_gl[j * kHI + d] = 0.5f * a * (1.f + erff(a * 0.70710678118654752f));            // nn.GELU (exact)
   }
   __syncthreads();
-  for (int j = tid; j < nkv; j += kBlock) {
+  for (int j = j0 + tid; j < j1; j += kBlock) {
     const int ky = j / wk, kx = j % wk;
     float ox = 0.f, oy = 0.f;
 #pragma unroll
@@ -811,8 +816,8 @@ __global__ __launch_bounds__(kBlock) void hoa1_kv_kernel(const float* __restrict
   }
   __syncthreads();
   const float ry = hq > 1 ? (float)(Y - 1) / (float)(hq - 1) : 0.f, rx = wq > 1 ? (float)(X - 1) / (float)(wq - 1) : 0.f;
-  for (int i = tid; i < nkv * kHD; i += kBlock) {          // one (kv token, alpha channel) per thread
-    const int j = i / kHD, c = i % kHD;
+  for (int i = tid; i < nj * kHD; i += kBlock) {           // one (kv token, alpha channel) per thread
+    const int j = j0 + i / kHD, c = i % kHD;
     const float fx = s_f[j * 2], fy = s_f[j * 2 + 1];
     const int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
     float acc = 0.f;
@@ -823,11 +828,11 @@ __global__ __launch_bounds__(kBlock) void hoa1_kv_kernel(const float* __restrict
         const float w = (1.f - fabsf(fx - (float)xi)) * (1.f - fabsf(fy - (float)yi));
         acc = fmaf(bilinear_ac(al + c * plane, Y, X, ry * (float)yi, rx * (float)xi), w, acc);
       }
-    s_kv[i] = acc;
+    s_kv[j * kHD + c] = acc;
   }
   __syncthreads();
-  for (int i = tid; i < nkv * kHI; i += kBlock) {
-    const int j = i / kHI, d = i % kHI;
+  for (int i = tid; i < nj * kHI; i += kBlock) {
+    const int j = j0 + i / kHI, d = i % kHI;
     float a = 0.f, bb = 0.f;
     for (int c = 0; c < kHD; ++c) {
       a = fmaf(s_w[oK + d * kHD + c], s_kv[j * kHD + c], a);
@@ -839,6 +844,7 @@ __global__ __launch_bounds__(kBlock) void hoa1_kv_kernel(const float* __restrict
 }
 
 // attention: one query token per thread, kv tokens of the batch entry in LDS, online softmax
+constexpr int kAttSplit = 4;      // lanes per query token: each takes every 4th kv token, merged by shuffles
 __global__ __launch_bounds__(kBlock) void hoa1_attention_kernel(
     const float* __restrict__ qbuf, const float* __restrict__ kvbuf, const float* __restrict__ wts, int hq, int wq,
     int nkv, float* __restrict__ att) {
@@ -850,8 +856,11 @@ __global__ __launch_bounds__(kBlock) void hoa1_attention_kernel(
   for (int i = tid; i < kHoaWeights; i += nthr) s_w[i] = wts[i];
   for (int i = tid; i < nkv * 18; i += nthr) s_kv[i] = kvbuf[(long)b * nkv * 18 + i];
   __syncthreads();
-  const int t = blockIdx.x * nthr + tid;
-  if (t >= ntok) return;
+  // one query token per kAttSplit adjacent lanes (a query's 64 key / value tokens in sequence on one lane kept
+  // 36 single-wave workgroups busy for 24 us); lanes past the last token compute on a clamped one and store nothing
+  const int tq = (blockIdx.x * nthr + tid) / kAttSplit, part = tid % kAttSplit;
+  const bool valid = tq < ntok;
+  const int t = min(tq, ntok - 1);
   const int ty = t / wq, tx = t % wq;
   const float scale = 0.35355339059327373f;               // dim_head ** -0.5
   float q[kHI];
@@ -862,7 +871,7 @@ __global__ __launch_bounds__(kBlock) void hoa1_attention_kernel(
   float m = -INFINITY, l = 0.f, acc[kHI];
 #pragma unroll
   for (int d = 0; d < kHI; ++d) acc[d] = 0.f;
-  for (int j = 0; j < nkv; ++j) {
+  for (int j = part; j < nkv; j += kAttSplit) {
     const float* kv = s_kv + j * 18;
     float s = 0.f;
 #pragma unroll
@@ -884,8 +893,20 @@ __global__ __launch_bounds__(kBlock) void hoa1_attention_kernel(
     for (int d = 0; d < kHI; ++d) acc[d] = fmaf(p, kv[8 + d], acc[d] * corr);
     m = mn;
   }
+  // merge the kAttSplit partial softmax states (fixed butterfly: deterministic)
+#pragma unroll
+  for (int off = 1; off < kAttSplit; off <<= 1) {
+    const float mo = __shfl_xor(m, off), lo = __shfl_xor(l, off);
+    const float mn = fmaxf(m, mo);
+    const float c1 = (m == -INFINITY) ? 0.f : __expf(m - mn), c2 = (mo == -INFINITY) ? 0.f : __expf(mo - mn);
+    l = l * c1 + lo * c2;
+#pragma unroll
+    for (int d = 0; d < kHI; ++d) acc[d] = acc[d] * c1 + __shfl_xor(acc[d], off) * c2;
+    m = mn;
+  }
+  if (!valid) return;
   const float inv = 1.f / l;
-  for (int c = 0; c < kHD; ++c) {
+  for (int c = part; c < kHD; c += kAttSplit) {          // the output projection's channels are shared out too
     float o = s_w[oOB + c];
 #pragma unroll
     for (int d = 0; d < kHI; ++d) o = fmaf(s_w[oO + c * kHI + d], acc[d] * inv, o);
@@ -928,12 +949,12 @@ int ocrf_hoa1_forward(const float* opacity, const float* alpha, const float* wei
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   const size_t lds_kv = (size_t)(((kHoaWeights + 3) & ~3) + ntok * kHI + nkv * (kHI + 2 + kHD)) * sizeof(float);
-  ocrf::launch(OCRF_K_HOA1_KV, hoa1_kv_kernel, dim3(B), dim3(kBlock), lds_kv, stream, static_cast<const float*>(qbuf),
+  ocrf::launch(OCRF_K_HOA1_KV, hoa1_kv_kernel, dim3(min(nkv, 8), B), dim3(kBlock), lds_kv, stream, static_cast<const float*>(qbuf),
                alpha, weights, Y, X, hq, wq, hk, wk, offset_scale, kvbuf);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   const size_t lds_at = (size_t)(((kHoaWeights + 3) & ~3) + nkv * 18) * sizeof(float);
-  ocrf::launch(OCRF_K_HOA1_ATTN, hoa1_attention_kernel, dim3((ntok + 63) / 64, B), dim3(64), lds_at, stream,
+  ocrf::launch(OCRF_K_HOA1_ATTN, hoa1_attention_kernel, dim3((ntok * kAttSplit + 63) / 64, B), dim3(64), lds_at, stream,
                static_cast<const float*>(qbuf), static_cast<const float*>(kvbuf), weights, hq, wq, nkv,
                att_workspace);
   e = hipGetLastError();
