@@ -53,6 +53,9 @@ def parse():
     ap.add_argument('--scope', choices=('hotpath', 'neck'), default='hotpath',
                     help="'hotpath': pools (+ one rendered view per camera + HOA) — the headline step; 'neck': the whole "
                          "OcRFViewTransformerFull.view_transform (one rendered view per sample, like the reference)")
+    ap.add_argument('--host-calibration', action='store_true',
+                    help="--scope neck --index-prep per_step: hand the calibration tensors over as HOST tensors (the "
+                         "dataloader's copies) — the forward then has no device -> host read-back at all")
     ap.add_argument('--index-prep', choices=('cached', 'per_step'), default='cached',
                     help="'per_step': rank vectors recomputed by the HIP index preparation inside every step "
                          "(the reference with accelerate=False); 'cached': once per calibration (accelerate=True)")
@@ -117,7 +120,8 @@ def bench_neck(args, cfg, dev, world, rank):
     (whole samples per rank, no data-path collective).  Roofline: the LSS/HT pooling kernel."""
     import torch.distributed as dist
     from ocrfdet_amd import _lib, hotpath
-    neck = hotpath.NeckPath(cfg, dev, accelerate=args.index_prep == 'cached', seed=rank)
+    neck = hotpath.NeckPath(cfg, dev, accelerate=args.index_prep == 'cached', seed=rank,
+                            host_calibration=args.host_calibration)
     graphed = args.index_prep == 'cached' and not args.no_graph
     for _ in range(args.warmup):
         neck.step()
@@ -175,7 +179,9 @@ def bench_neck(args, cfg, dev, world, rank):
                           'stages': 'prefilter+lss_pool+ht_pool+colour/alpha sampling+gauss heads+nerf branch+render+hoa+bev fusion',
                           'views_per_step': neck.views_per_step, 'render_camera': 'reference',
                           'launch': 'one hipGraph replay per step' if graphed else 'eager (kernel by kernel)',
-                          'index_prep': 'cached (accelerate=True)' if args.index_prep == 'cached' else 'per step, HIP (accelerate=False)',
+                          'index_prep': 'cached (accelerate=True)' if args.index_prep == 'cached' else
+                          'per step, HIP (accelerate=False); calibration ' +
+                          ('handed over as host tensors' if args.host_calibration else 'read back from the device (one packed copy)'),
                           'sharding': 'none' if world == 1 else f'{world} ranks x whole samples, no data-path collective'},
                'roofline': {'bound': 'hbm', 'kernel': timer.kernel_name, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                             'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS if achieved else None, 'traffic': None,

@@ -294,7 +294,7 @@ class NeckPath:
     BEV fusion) with random-init weights of the reference architecture on the synthetic rig — what
     ``bench.py --scope neck`` and ``tools/time_neck.py`` drive.  Frames ride along as batch entries."""
 
-    def __init__(self, cfg, device, accelerate=True, seed=0, parallel_branches=True):
+    def __init__(self, cfg, device, accelerate=True, seed=0, parallel_branches=True, host_calibration=False):
         from . import neck_ops
         from . import view_transformer_ocrf as vto
         self.cfg, self.device, self._ops = cfg, torch.device(device), neck_ops
@@ -315,7 +315,10 @@ class NeckPath:
         raw = torch.randint(0, 256, (self.batch, cfg.n_cams, 3, *cfg.input_size), generator=g).float()
         inp = [x] + [torch.from_numpy(r[k]) for k in ('rots', 'trans', 'intrins', 'post_rots', 'post_trans', 'bda')]
         inp += [torch.zeros(self.batch, cfg.n_cams, 27), raw, raw, raw, torch.from_numpy(r['c2w'])]
-        self.inputs = [t.to(self.device) for t in inp]
+        # host_calibration: the six calibration tensors and c2w stay host tensors (what the dataloader produced);
+        # the module then needs no device -> host read-back per forward (OcRFViewTransformerFull._to_host)
+        keep = {1, 2, 3, 4, 5, 6, 11} if host_calibration else set()
+        self.inputs = [t if i in keep else t.to(self.device) for i, t in enumerate(inp)]
         pre = torch.randn(self.batch * cfg.n_cams, cfg.D + 2 + cfg.channels, Hf, Wf, generator=g)
         pre[:, :cfg.D] *= 3                                       # stand-in for the DepthNet output
         self.depthnet_out = pre.to(self.device)

@@ -558,9 +558,10 @@ class OcRFViewTransformerFull(nn.Module):
         B, N, _, Hf, Wf = x.shape
         # the per-camera 3x3 algebra stays on the host, as the same torch calls the reference makes
         # (a handful of (B,N,3,3) tensors; the reference moves them to the host itself, :1086-1088)
-        calib = [t.detach().float().cpu() for t in input[1:7]]
+        host = self._to_host(list(input[1:7]) + [input[11]])
+        calib = host[:6]
         geo = _Geometry()
-        geo.calib, geo.c2w, geo.cam_rows, geo.plans = calib, input[11].detach().float().cpu(), {}, {}
+        geo.calib, geo.c2w, geo.cam_rows, geo.plans = calib, host[6], {}, {}
         gx, gy, gz = (int(v) for v in self.grid_size.tolist())
         lss_block = index_prep.lss_camera_block(*calib).to(dev)
         lidar2img, img_aug, _, _ = index_prep.get_projection(*calib)
@@ -576,6 +577,20 @@ class OcRFViewTransformerFull(nn.Module):
         geo.pix, geo.mask, geo.voxel = index_prep.ht_project_hip(tmpl, ht_block, B, N, list(self.pc_range),
                                                                  self.input_size, self.grid_config['depth'])
         return geo
+
+    @staticmethod
+    def _to_host(tensors):
+        """float32 host copies of the calibration tensors.  Device tensors leave in ONE packed read-back (the
+        reference reads them one by one, :1086-1088; each read is a device synchronisation); host tensors pass
+        through untouched — a caller that still has the dataloader's host copies can hand those in and the
+        forward does not synchronise at all."""
+        ts = [t.detach().float() for t in tensors]
+        on_dev = [t for t in ts if t.is_cuda]
+        if len(on_dev) > 1:
+            flat = torch.cat([t.reshape(-1) for t in on_dev]).cpu()
+            parts = iter(flat.split([t.numel() for t in on_dev]))
+            return [next(parts).view(t.shape) if t.is_cuda else t for t in ts]
+        return [t.cpu() for t in ts]
 
     def _camera(self, geo, bs, cam_idx):
         """``data`` dict of the render call (:1135-1152), quirks included: unscaled intrinsics with the
