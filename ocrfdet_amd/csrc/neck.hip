@@ -845,7 +845,7 @@ int ocrf_dual_feat_fusion(const float* x1, const float* x2, const float* params,
 
 int ocrf_plane_bias_act_stats(float* y, const float* bias, int B, int C, int YX, int relu, int write, int S,
                               int out_C, int c_off, float* psum, float* pmax, ocrf_stream_t stream) {
-  if (!y || B <= 0 || C <= 0 || YX <= 0 || S <= 0 || S > 65535) return (int)hipErrorInvalidValue;
+  if (!y || B <= 0 || C <= 0 || YX <= 0 || S <= 0 || S > 65535 || (long)B * C > 65535) return (int)hipErrorInvalidValue;
   const bool stats = psum != nullptr;
   if (stats && (!pmax || out_C < c_off + C || c_off < 0)) return (int)hipErrorInvalidValue;
   if (!stats && !write) return (int)hipErrorInvalidValue;
