@@ -195,3 +195,40 @@ def test_gaussian_sets_match_per_set_calls(cuda):
                                packed_cameras=packed)
         for k in ('color', 'depth', 'final_T', 'n_contrib', 'radii'):
             assert torch.equal(got[k][s * V:(s + 1) * V], want[k]), (s, k)
+
+
+def test_full_size_properties_of_the_bench_scene(cuda):
+    """BASELINE configs[2] at full size (520 000 Gaussians, 6 views of 256x704 — more than the C oracle renders in
+    test time): properties that hold bit for bit whatever the size.  (1) with a zero background the colour is
+    linear in the Gaussians' colours, and a factor of two is exact in binary floating point: image(2 c) == 2
+    image(c), depth / final_T / n_contrib / radii unchanged; (2) a view's image does not depend on which other
+    views share the launch or on their order; (3) two launches of the same inputs agree bitwise."""
+    from ocrfdet_amd import hotpath
+    cfg = synthetic.CONFIGS['cfg2_6cam_2frame_bev200x200_render_hoa']
+    hp = hotpath.HotPath(cfg, cuda)
+    g, rc = hp.gauss, hp.render_cams
+    H, W = cfg.input_size
+    xyz = hp.voxel_xyz[0].reshape(-1, 3)
+    assert xyz.shape[0] == 13 * 200 * 200
+    zero = torch.zeros(3, device=cuda)
+
+    def run(rgb, packed):
+        return dgr.rasterize_views(xyz, rgb, g['opacity'], g['scales'], g['rotations'], None, None, None, None, H, W,
+                                   zero, packed_cameras=packed)
+    a = run(g['rgb'], rc['packed'])
+    b = run(g['rgb'], rc['packed'])
+    for k in ('color', 'depth', 'final_T', 'n_contrib', 'radii'):
+        assert torch.equal(a[k], b[k]), f'{k} differs between two identical launches'
+    assert int(a['status'].item()) & 1 == 0
+    assert float(a['final_T'].min()) < 0.5 and float(a['color'].max()) > 0.0          # the scene is not empty
+    c = run(g['rgb'] * 2.0, rc['packed'])
+    assert torch.equal(c['color'], a['color'] * 2.0)
+    for k in ('depth', 'final_T', 'n_contrib', 'radii'):
+        assert torch.equal(c[k], a[k]), k
+    perm = torch.tensor([4, 2, 5, 0, 3, 1], device=cuda)
+    d = run(g['rgb'], rc['packed'][perm].contiguous())
+    for k in ('color', 'depth', 'final_T', 'n_contrib', 'radii'):
+        assert torch.equal(d[k], a[k][perm]), f'{k} depends on the order of the views'
+    e = run(g['rgb'], rc['packed'][3:4].contiguous())
+    for k in ('color', 'depth', 'final_T', 'n_contrib', 'radii'):
+        assert torch.equal(e[k][0], a[k][3]), f'{k} depends on the other views of the launch'
