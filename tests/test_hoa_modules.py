@@ -200,3 +200,36 @@ def test_depthwise_conv3x3_forward_and_backward(shape):
     ga, = torch.autograd.grad(a.square().sum(), xin)
     gb2, = torch.autograd.grad(b.square().sum(), xin)
     assert torch.allclose(ga, gb2, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_full_size_hoa_is_per_sample_and_reproducible(cuda):
+    """HOA-1 / HOA-2 / HOA-3 at the headline BEV size (B = 2, 13 x 200 x 200; 80 x 200 x 200): size-independent
+    properties, bit for bit — a sample's result does not depend on the other samples of the batch (the fused
+    kernels run the whole batch in one launch where the reference loops), two runs agree, and HOA-3's gated output
+    is exactly x * mask."""
+    torch.manual_seed(0)
+    B, Zh, Y, X = 2, 13, 200, 200
+    dca = hoa.DeformableAttention2D(dim=13, dim_head=8, heads=1, dropout=0.1, downsample_factor=4, offset_scale=4,
+                                    offset_groups=None, offset_kernel_size=6).to(cuda).eval()
+    v2b = hoa.OpacityVoxelToBEVConverter(13).to(cuda).eval()
+    om = hoa.ObatinOpacityMask().to(cuda).eval()
+    opacity = torch.rand(B * Zh * Y * X, 1, device=cuda)
+    alpha = torch.rand(B, Zh, Y, X, device=cuda)
+    pos = torch.randn(B, 4, Y, X, device=cuda)
+    feat = torch.randn(B, 80, Y, X, device=cuda)
+    with torch.no_grad():
+        oa = hoa.hoa1(dca, opacity, alpha, Zh, Y, X)
+        view = v2b(oa, pos)
+        mask, gated = om.gate(feat, view)
+        assert torch.equal(hoa.hoa1(dca, opacity, alpha, Zh, Y, X), oa) and torch.equal(v2b(oa, pos), view)
+        assert torch.equal(gated, feat * mask)
+        assert torch.isfinite(oa).all() and torch.isfinite(view).all() and float(mask.min()) >= 0 and float(mask.max()) <= 1
+        n = Zh * Y * X
+        for b in range(B):
+            oa_b = hoa.hoa1(dca, opacity[b * n:(b + 1) * n], alpha[b:b + 1], Zh, Y, X)
+            assert torch.equal(oa_b, oa[b:b + 1]), 'HOA-1 depends on the rest of the batch'
+            view_b = v2b(oa_b, pos[b:b + 1])
+            assert torch.equal(view_b, view[b:b + 1]), 'HOA-2 depends on the rest of the batch'
+            mb, gb = om.gate(feat[b:b + 1], view_b)
+            assert torch.equal(mb, mask[b:b + 1]) and torch.equal(gb, gated[b:b + 1])
