@@ -300,7 +300,7 @@ def main():
             alg_bytes = float(len(hp.cams) * (60 * P + 24 * H * W))
             # the blend is VALU-bound: pixel.record evaluations per launch, counted as the
             # contributor index each pixel stopped at (a lower bound of what the kernel evaluates)
-            evals = float(hp.render()[0]['n_contrib'].sum().item())
+            evals = float(hp.render(want_n_contrib=True)[0]['n_contrib'].sum().item())
         else:
             alg_bytes = 0.5 * (hp.lss.algorithmic_bytes(depth.numel(), feat.numel()) +
                                hp.ht.algorithmic_bytes(depth.numel(), feat.numel()))

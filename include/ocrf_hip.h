@@ -166,7 +166,8 @@ int ocrf_bev_pool_v2_grad(int c, int n_intervals, const float *out_grad, const f
  *                             1 = mean depth (the fork's commented-out alternative)
  * outputs (caller-allocated, fully written):
  *   out_color (n_views,3,H,W)  out_depth (n_views,H,W)  out_final_T (n_views,H,W) [= 1 - accumulated
- *   opacity]  out_n_contrib (n_views,H,W)  radii (n_views,P)  tiles_touched (n_views,P) or NULL
+ *   opacity]  out_n_contrib (n_views,H,W) or NULL (inference: only the backward reads it; NULL drops its
+ *   tracking from the blend)  radii (n_views,P)  tiles_touched (n_views,P) or NULL
  *   status (device int, may be NULL; written by the call): informational.  Bit 1 (value 2) is set when
  *   some tile met more than ~1 000 Gaussians inside ONE 0.2 %-wide depth bucket, more than the in-LDS
  *   sort holds; such a tile is then blended by an exact but slower streaming selection over that

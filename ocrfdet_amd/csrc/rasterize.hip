@@ -484,7 +484,7 @@ __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementw
 // exactly its own list: a record carries two coverage bits (rect covers tile A / tile B), a pixel
 // ignores records that do not cover its tile, and the contributor index of each tile is a scalar
 // counter of its covered records.
-template <bool STAMP, bool BWD, bool MEDIAN>
+template <bool STAMP, bool BWD, bool MEDIAN, bool CONTRIB = true>
 __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
     unsigned long long* __restrict__ stamps,
     int P, int W, int H, int gy, const int* __restrict__ starts, const Rect* __restrict__ rects,
@@ -564,9 +564,12 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
         const float4 co = conic_o[base + id];
         const Rect rc = rects[base + id];
         const unsigned cov = ((tyA >= rc.y0 && tyA < rc.y1) ? 1u : 0u) | ((tyB >= rc.y0 && tyB < rc.y1) ? 2u : 0u);
-        l_a[tid] = make_float4(p.x, p.y, co.x, co.y);
+        // forward: the conic's diagonal is staged as -0.5 * c (exact: a power of two commutes with every
+        // rounding of (c dx) dx and of the sum), which removes the -0.5 multiply from the per-record chain
+        const float hs = BWD ? 1.0f : -0.5f;
+        l_a[tid] = make_float4(p.x, p.y, hs * co.x, co.y);
         const float* col = colors + 3 * ((long)(v / vps) * P + id);     // the view's Gaussian set
-        l_b[tid] = make_float4(co.z, co.w, __uint_as_float((unsigned)(c >> 32)), col[0]);
+        l_b[tid] = make_float4(hs * co.z, co.w, __uint_as_float((unsigned)(c >> 32)), col[0]);
         l_c[tid] = make_float4(col[1], col[2], __uint_as_float(cov), 0.f);
         if constexpr (BWD) {
           l_id[tid] = id;
@@ -604,7 +607,9 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
           const float bx = a.w * dx;
           const f2 dy = splat(a.y) - pixf_y;
           const f2 qy = (splat(b.x) * dy) * dy;
-          const f2 power = splat(-0.5f) * (splat(qx) + qy) - splat(bx) * dy;
+          f2 power;
+          if constexpr (BWD) power = splat(-0.5f) * (splat(qx) + qy) - splat(bx) * dy;
+          else power = (splat(qx) + qy) - splat(bx) * dy;          // qx, qy carry the -0.5 (staging above)
           f2 G;
           G.x = __expf(power.x);
           G.y = __expf(power.y);
@@ -702,8 +707,10 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
           }
           T.x = contribA ? test_T.x : T.x;
           T.y = contribB ? test_T.y : T.y;
-          lastA = contribA ? (unsigned)jA : lastA;
-          lastB = contribB ? (unsigned)jB : lastB;
+          if constexpr (CONTRIB) {
+            lastA = contribA ? (unsigned)jA : lastA;
+            lastB = contribB ? (unsigned)jB : lastB;
+          }
           doneA = doneA || stopA;
           doneB = doneB || stopB;
         }
@@ -909,7 +916,7 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
       if (!inside) return;
       const long pix = (long)py * W + pxi;
       out_final_T[v * npix + pix] = t;
-      out_n_contrib[v * npix + pix] = last;
+      if constexpr (CONTRIB) out_n_contrib[v * npix + pix] = last;
       out_color[(v * 3 + 0) * npix + pix] = c0 + t * bg[0];
       out_color[(v * 3 + 1) * npix + pix] = c1 + t * bg[1];
       out_color[(v * 3 + 2) * npix + pix] = c2 + t * bg[2];
@@ -1115,14 +1122,14 @@ int ocrf_rasterize_forward_sets(int P, int n_sets, int views_per_set, int H, int
   const int n_views = n_sets * views_per_set;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (P < 0 || n_views <= 0 || H <= 0 || W <= 0 || (depth_mode != 0 && depth_mode != 1) ||
-      !out_color || !out_depth || !out_final_T || !out_n_contrib || !bg || !cameras)
+      !out_color || !out_depth || !out_final_T || !bg || !cameras)
     return (int)hipErrorInvalidValue;
   const size_t npix = (size_t)H * W * n_views;
   if (P == 0) {   // rasterize_points.cu:68-69: zero-filled outputs, nothing launched
     hipError_t e = ocrf::zero_async(out_color, npix * 3 * sizeof(float), stream);
     if (e == hipSuccess) e = ocrf::zero_async(out_depth, npix * sizeof(float), stream);
     if (e == hipSuccess) e = ocrf::zero_async(out_final_T, npix * sizeof(float), stream);
-    if (e == hipSuccess) e = ocrf::zero_async(out_n_contrib, npix * sizeof(uint32_t), stream);
+    if (e == hipSuccess && out_n_contrib) e = ocrf::zero_async(out_n_contrib, npix * sizeof(uint32_t), stream);
     return (int)e;
   }
   if (!means3D || !colors || !opacities || !radii || (!cov3D_precomp && (!scales || !rotations)))
@@ -1174,20 +1181,18 @@ int ocrf_rasterize_forward_sets(int P, int n_sets, int views_per_set, int H, int
                        out_color, out_depth, out_final_T, out_n_contrib, st, BwdArgs{}, views_per_set);
     return (int)hipGetLastError();
   }
-  if (depth_mode == 0)
-    ocrf::launch(OCRF_K_RASTER_BLEND, raster_blend_kernel<false, false, true>, bgrid, dim3(kBlock), lds,
-                 stream, (unsigned long long*)nullptr, P, W, H, gy, static_cast<const int*>(starts),
-                 static_cast<const Rect*>(rects), static_cast<const Rect*>(b_rect),
-                 static_cast<const unsigned long long*>(b_comp), static_cast<const float2*>(xy),
-                 static_cast<const float4*>(conic_o), colors, bg, out_color, out_depth, out_final_T,
-                 out_n_contrib, st, BwdArgs{}, views_per_set);
-  else
-    ocrf::launch(OCRF_K_RASTER_BLEND, raster_blend_kernel<false, false, false>, bgrid, dim3(kBlock), lds,
-                 stream, (unsigned long long*)nullptr, P, W, H, gy, static_cast<const int*>(starts),
-                 static_cast<const Rect*>(rects), static_cast<const Rect*>(b_rect),
-                 static_cast<const unsigned long long*>(b_comp), static_cast<const float2*>(xy),
-                 static_cast<const float4*>(conic_o), colors, bg, out_color, out_depth, out_final_T,
-                 out_n_contrib, st, BwdArgs{}, views_per_set);
+#define OCRF_BLEND(MED, CON)                                                                                     \
+  ocrf::launch(OCRF_K_RASTER_BLEND, raster_blend_kernel<false, false, MED, CON>, bgrid, dim3(kBlock), lds, stream, \
+               (unsigned long long*)nullptr, P, W, H, gy, static_cast<const int*>(starts),                          \
+               static_cast<const Rect*>(rects), static_cast<const Rect*>(b_rect),                                   \
+               static_cast<const unsigned long long*>(b_comp), static_cast<const float2*>(xy),                      \
+               static_cast<const float4*>(conic_o), colors, bg, out_color, out_depth, out_final_T, out_n_contrib,    \
+               st, BwdArgs{}, views_per_set)
+  if (depth_mode == 0 && out_n_contrib) OCRF_BLEND(true, true);
+  else if (depth_mode == 0) OCRF_BLEND(true, false);
+  else if (out_n_contrib) OCRF_BLEND(false, true);
+  else OCRF_BLEND(false, false);
+#undef OCRF_BLEND
   return (int)hipGetLastError();
 }
 

@@ -119,14 +119,16 @@ def rasterize_views_backward(grad_color, fwd, means3D, colors, opacities, scales
 def rasterize_views(means3D, colors, opacities, scales, rotations, viewmatrices, projmatrices,
                     tanfovx, tanfovy, image_height, image_width, bg, scale_modifier=1.0,
                     cov3D_precomp=None, depth_mode='median', want_tiles_touched=False, packed_cameras=None,
-                    workspace_tag='raster'):
+                    workspace_tag='raster', want_n_contrib=True):
     """Render ``V`` cameras over the same ``P`` Gaussians.
 
     ``viewmatrices`` / ``projmatrices``: (V,4,4) transposed matrices as the reference passes them;
     ``tanfovx`` / ``tanfovy``: length-V sequences (or scalars).  Returns a dict of fresh tensors:
     ``color`` (V,3,H,W), ``depth`` (V,1,H,W), ``final_T`` (V,H,W), ``n_contrib`` (V,H,W) int32,
     ``radii`` (V,P) int32 [, ``tiles_touched`` (V,P) int32].  Calls that may run concurrently on
-    different streams must use different ``workspace_tag``s (the scratch buffer is per tag)."""
+    different streams must use different ``workspace_tag``s (the scratch buffer is per tag).
+    ``want_n_contrib=False`` (inference: only the backward reads the per-pixel contributor index) drops
+    ``n_contrib`` and the two selects per pixel-record that track it."""
     _lib.require_cuda(means3D, colors, opacities, bg)
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError('means3D must have dimensions (num_points, 3)')     # rasterize_points.cu:57-59
@@ -145,8 +147,9 @@ def rasterize_views(means3D, colors, opacities, scales, rotations, viewmatrices,
     bg = _f32c(bg).reshape(3)
     out = dict(color=torch.empty(V, 3, H, W, device=dev), depth=torch.empty(V, 1, H, W, device=dev),
                final_T=torch.empty(V, H, W, device=dev),
-               n_contrib=torch.empty(V, H, W, dtype=torch.int32, device=dev),
                radii=torch.empty(V, max(P, 0), dtype=torch.int32, device=dev))
+    if want_n_contrib:
+        out['n_contrib'] = torch.empty(V, H, W, dtype=torch.int32, device=dev)
     tt = torch.empty(V, P, dtype=torch.int32, device=dev) if want_tiles_touched else None
     status = torch.empty(1, dtype=torch.int32, device=dev)      # zeroed on the device by the bucket scan kernel
     L = _lib.lib()
@@ -157,7 +160,7 @@ def rasterize_views(means3D, colors, opacities, scales, rotations, viewmatrices,
             P, V, H, W, _lib.ptr(means3D), _lib.ptr(colors), _lib.ptr(opac), _lib.ptr(sc),
             ctypes.c_float(scale_modifier), _lib.ptr(rot), _lib.ptr(cov), _lib.ptr(cams), _lib.ptr(bg),
             {'median': 0, 'mean': 1}[depth_mode], _lib.ptr(out['color']), _lib.ptr(out['depth']),
-            _lib.ptr(out['final_T']), _lib.ptr(out['n_contrib']), _lib.ptr(out['radii']), _lib.ptr(tt),
+            _lib.ptr(out['final_T']), _lib.ptr(out.get('n_contrib')), _lib.ptr(out['radii']), _lib.ptr(tt),
             _lib.ptr(status), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_ptr(dev)), 'ocrf_rasterize_forward')
     if tt is not None:
         out['tiles_touched'] = tt
@@ -166,10 +169,11 @@ def rasterize_views(means3D, colors, opacities, scales, rotations, viewmatrices,
 
 
 def rasterize_sets(means3D, colors, opacities, scales, rotations, packed_cameras, image_height, image_width, bg,
-                   scale_modifier=1.0, depth_mode='median', workspace_tag='raster'):
+                   scale_modifier=1.0, depth_mode='median', workspace_tag='raster', want_n_contrib=False):
     """``S`` Gaussian sets x ``V`` views each in one set of launches (C ABI ``ocrf_rasterize_forward_sets``):
     means3D (S,P,3), colors (S,P,3), opacities (S,P[,1]), scales (S,P,3), rotations (S,P,4),
-    ``packed_cameras`` (S*V,36) from ``pack_cameras`` (view v renders set v // V).  Forward only.
+    ``packed_cameras`` (S*V,36) from ``pack_cameras`` (view v renders set v // V).  Forward only, so the
+    contributor index is not tracked unless ``want_n_contrib``.
     -> dict like ``rasterize_views`` with a leading S*V view axis."""
     _lib.require_cuda(means3D, colors, opacities, scales, rotations, packed_cameras, bg)
     if means3D.dim() != 3 or means3D.size(2) != 3:
@@ -183,8 +187,9 @@ def rasterize_sets(means3D, colors, opacities, scales, rotations, packed_cameras
     means3D, colors, opac = _f32c(means3D), _f32c(colors), _f32c(opacities).reshape(S, P)
     sc, rot, bg, cams = _f32c(scales), _f32c(rotations), _f32c(bg).reshape(3), _f32c(packed_cameras)
     out = dict(color=torch.empty(NV, 3, H, W, device=dev), depth=torch.empty(NV, 1, H, W, device=dev),
-               final_T=torch.empty(NV, H, W, device=dev), n_contrib=torch.empty(NV, H, W, dtype=torch.int32, device=dev),
-               radii=torch.empty(NV, P, dtype=torch.int32, device=dev))
+               final_T=torch.empty(NV, H, W, device=dev), radii=torch.empty(NV, P, dtype=torch.int32, device=dev))
+    if want_n_contrib:
+        out['n_contrib'] = torch.empty(NV, H, W, dtype=torch.int32, device=dev)
     status = torch.empty(1, dtype=torch.int32, device=dev)
     L = _lib.lib()
     with _lib.on_device(dev):
@@ -194,7 +199,7 @@ def rasterize_sets(means3D, colors, opacities, scales, rotations, packed_cameras
             P, S, NV // S, H, W, _lib.ptr(means3D), _lib.ptr(colors), _lib.ptr(opac), _lib.ptr(sc),
             ctypes.c_float(scale_modifier), _lib.ptr(rot), _lib.ptr(None), _lib.ptr(cams), _lib.ptr(bg),
             {'median': 0, 'mean': 1}[depth_mode], _lib.ptr(out['color']), _lib.ptr(out['depth']), _lib.ptr(out['final_T']),
-            _lib.ptr(out['n_contrib']), _lib.ptr(out['radii']), _lib.ptr(None), _lib.ptr(status), _lib.ptr(ws),
+            _lib.ptr(out.get('n_contrib')), _lib.ptr(out['radii']), _lib.ptr(None), _lib.ptr(status), _lib.ptr(ws),
             ctypes.c_size_t(ws.numel()), _lib.stream_ptr(dev)), 'ocrf_rasterize_forward_sets')
     out['status'] = status
     return out

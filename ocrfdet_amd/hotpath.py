@@ -170,12 +170,13 @@ class HotPath:
         self.bg = torch.zeros(3, device=dev)
         self.render_convention = convention
 
-    def render(self, streams=None):
+    def render(self, streams=None, want_n_contrib=False):
         """All owned cameras of every frame: list (one per frame) of dicts from rasterize_views.
         ``streams``: a HIP stream per frame (frames on different streams get their own scratch buffer);
         the caller joins them.  One call per frame on purpose: a single 12-view call
         (``rasterize_sets``) is 7 % faster alone but 17 % slower beside the main stream's kernels — a
-        4 224-workgroup blend leaves them no room to interleave."""
+        4 224-workgroup blend leaves them no room to interleave.  The step is inference: the per-pixel contributor
+        index (read only by the backward) is not tracked unless ``want_n_contrib``."""
         cfg, rc, g = self.cfg, self.render_cams, self.gauss
         H, W = cfg.input_size
         outs = []
@@ -184,12 +185,12 @@ class HotPath:
             if streams is None:
                 outs.append(rasterize_views(xyz, g['rgb'], g['opacity'], g['scales'], g['rotations'], rc['vm'],
                                             rc['pm'], rc['tfx'], rc['tfy'], H, W, self.bg,
-                                            packed_cameras=rc['packed']))
+                                            packed_cameras=rc['packed'], want_n_contrib=want_n_contrib))
             else:
                 with torch.cuda.stream(streams[b]):
                     outs.append(rasterize_views(xyz, g['rgb'], g['opacity'], g['scales'], g['rotations'], rc['vm'],
                                                 rc['pm'], rc['tfx'], rc['tfy'], H, W, self.bg,
-                                                packed_cameras=rc['packed'],
+                                                packed_cameras=rc['packed'], want_n_contrib=want_n_contrib,
                                                 workspace_tag=f'raster{streams.index(streams[b])}'))
         return outs
 

@@ -189,7 +189,7 @@ def test_gaussian_sets_match_per_set_calls(cuda):
                           [c[2] for c in cams], [c[3] for c in cams], H, W, cuda)
     bg = torch.tensor([0.1, 0.2, 0.3], device=cuda)
     st = [t(np.stack([s[i] for s in sets])) for i in range(5)]             # xyz, rgb, opac, scales, q
-    got = rasterize_sets(st[0], st[1], st[2], st[3], st[4], packed.repeat(S, 1), H, W, bg)
+    got = rasterize_sets(st[0], st[1], st[2], st[3], st[4], packed.repeat(S, 1), H, W, bg, want_n_contrib=True)
     for s in range(S):
         want = rasterize_views(st[0][s], st[1][s], st[2][s], st[3][s], st[4][s], None, None, None, None, H, W, bg,
                                packed_cameras=packed)
@@ -232,3 +232,9 @@ def test_full_size_properties_of_the_bench_scene(cuda):
     e = run(g['rgb'], rc['packed'][3:4].contiguous())
     for k in ('color', 'depth', 'final_T', 'n_contrib', 'radii'):
         assert torch.equal(e[k][0], a[k][3]), f'{k} depends on the other views of the launch'
+    # (4) the inference variant that does not track the contributor index renders the same images
+    f = dgr.rasterize_views(xyz, g['rgb'], g['opacity'], g['scales'], g['rotations'], None, None, None, None, H, W, zero,
+                            packed_cameras=rc['packed'], want_n_contrib=False)
+    assert 'n_contrib' not in f
+    for k in ('color', 'depth', 'final_T', 'radii'):
+        assert torch.equal(f[k], a[k]), k
