@@ -350,9 +350,9 @@ def main():
             lane_slots = 256 * 4 * 16 * 2.4e9          # CUs x SIMDs x lanes x clock (MI355X_MICROARCH.md)
             out['roofline']['valu'] = {
                 'pixel_records_per_launch': evals, 'pixel_records_per_sec': evals / (avg_ms * 1e-3),
-                'issue_slots_per_pixel_record': 26.5,    # ISA count of the inner loop, DESIGN 4.3
-                'frac_of_valu_issue_peak': evals * 26.5 / (avg_ms * 1e-3) / lane_slots,
-                'frac_of_valu_issue_peak_isolated': (evals * 26.5 / (iso_ms * 1e-3) / lane_slots) if iso_ms else None}
+                'issue_slots_per_pixel_record': 23.9,    # ISA count of the inner loop, DESIGN 4.3
+                'frac_of_valu_issue_peak': evals * 23.9 / (avg_ms * 1e-3) / lane_slots,
+                'frac_of_valu_issue_peak_isolated': (evals * 23.9 / (iso_ms * 1e-3) / lane_slots) if iso_ms else None}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(hp, depth, feat, args.cpu_seconds)
             out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']

@@ -610,9 +610,11 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
           f2 power;
           if constexpr (BWD) power = splat(-0.5f) * (splat(qx) + qy) - splat(bx) * dy;
           else power = (splat(qx) + qy) - splat(bx) * dy;          // qx, qy carry the -0.5 (staging above)
+          // __expf(x) is v_exp_f32(log2(e) x): the two multiplies go as one packed op
+          const f2 p2 = power * splat(1.44269504088896340736f);
           f2 G;
-          G.x = __expf(power.x);
-          G.y = __expf(power.y);
+          G.x = __builtin_amdgcn_exp2f(p2.x);
+          G.y = __builtin_amdgcn_exp2f(p2.y);
           f2 alpha = splat(b.y) * G;
           alpha.x = fminf(0.99f, alpha.x);
           alpha.y = fminf(0.99f, alpha.y);
@@ -754,8 +756,10 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
     // once (the scan is latency-bound: one dependent global load per batch otherwise).
     const int target = min(nrec + kBlock / 2 + 1, kCapRec - kScanUnroll * kBlock);
     while (scan < nv && nrec < target) {
-      // dense scenes fill a round from the first 256 entries: look at one batch first, then four
-      const int n_u = (scan == 0) ? 1 : kScanUnroll;
+      // dense scenes fill a round from the first 256-512 entries: look at one batch at a time twice (four at
+      // once after a sparse first batch overshoots into a 512-record sort of which ~120 records are consumed),
+      // then four
+      const int n_u = (scan < 2 * kBlock) ? 1 : kScanUnroll;
       bool hit[kScanUnroll];
 #pragma unroll
       for (int u = 0; u < kScanUnroll; ++u) {
@@ -1173,12 +1177,16 @@ int ocrf_rasterize_forward_sets(int P, int n_sets, int views_per_set, int H, int
   if (e != hipSuccess) return (int)e;
   const size_t lds = (size_t)kCapRec * 8 + (size_t)kStage * (16 + 16 + 16);
   const dim3 bgrid(gx, (gy + 1) / 2, n_views);        // one workgroup per vertical pair of tiles
-  if (g_stamps) {
-    hipLaunchKernelGGL((raster_blend_kernel<true, false, true>), bgrid, dim3(kBlock), lds, stream,
-                       g_stamps, P, W, H, gy, static_cast<const int*>(starts), static_cast<const Rect*>(rects),
-                       static_cast<const Rect*>(b_rect), static_cast<const unsigned long long*>(b_comp),
-                       static_cast<const float2*>(xy), static_cast<const float4*>(conic_o), colors, bg,
-                       out_color, out_depth, out_final_T, out_n_contrib, st, BwdArgs{}, views_per_set);
+  if (g_stamps) {      // diagnostic build of the same kernel (median depth), with or without the contributor index
+#define OCRF_BLEND_STAMPED(CON)                                                                                     \
+  hipLaunchKernelGGL((raster_blend_kernel<true, false, true, CON>), bgrid, dim3(kBlock), lds, stream, g_stamps, P, \
+                     W, H, gy, static_cast<const int*>(starts), static_cast<const Rect*>(rects),                    \
+                     static_cast<const Rect*>(b_rect), static_cast<const unsigned long long*>(b_comp),              \
+                     static_cast<const float2*>(xy), static_cast<const float4*>(conic_o), colors, bg, out_color,    \
+                     out_depth, out_final_T, out_n_contrib, st, BwdArgs{}, views_per_set)
+    if (out_n_contrib) OCRF_BLEND_STAMPED(true);
+    else OCRF_BLEND_STAMPED(false);
+#undef OCRF_BLEND_STAMPED
     return (int)hipGetLastError();
   }
 #define OCRF_BLEND(MED, CON)                                                                                     \

@@ -19,3 +19,6 @@ for conv in ('reference', 'corrected'):
     st = buf.cpu().numpy().reshape(ntile, 8)
     print(conv, 'per-tile cycles mean [scan, sort, ready, blend, carry]:', st[:, :5].mean(0).round(0), 'total mean', st[:, :5].sum(1).mean(),
           'max', st[:, :5].sum(1).max(), 'entries scanned mean/max', st[:, 5].mean(), st[:, 5].max(), 'records consumed mean/max', st[:, 6].mean(), st[:, 6].max())
+    tot = st[:, :5].sum(1).reshape(6, 8, 44)
+    print(conv, 'mean total cycles per tile-pair row (top -> bottom):', tot.mean((0, 2)).round(0))
+    print(conv, 'mean total cycles per view:', tot.mean((1, 2)).round(0))
