@@ -41,7 +41,8 @@ constexpr int kTileX = 16, kTileY = 16;     // cuda_rasterizer/config.h:15-17
 constexpr int kBuckets = 8192;               // depth buckets per view
 constexpr int kBucketShift = 14;             // bucket = (depth bits >> 14) - base: 9 mantissa bits
 constexpr unsigned kBucketBase = 0x3E4CCCCDu >> kBucketShift;   // depth > 0.2f always (auxiliary.h:154)
-constexpr int kChunk = 2048;                 // Gaussians per workgroup in preprocess / scatter
+constexpr int kChunk = 2048;                 // compact records per workgroup in the scatter
+constexpr int kPreChunk = 1024;              // Gaussians per workgroup in the preprocess
 constexpr int kCapRec = 2048;                // LDS record capacity of the blend kernel (28 KB with the stage: 4 workgroups per CU)
 constexpr int kStage = 256;                  // payload entries staged per blend batch
 constexpr int kScanUnroll = 4;               // rect batches in flight in the scan
@@ -77,17 +78,17 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
     const Camera* __restrict__ cams, uint4* __restrict__ vis_rec, int* __restrict__ vis_count,
     Rect* __restrict__ rects, float2* __restrict__ xy, float4* __restrict__ conic_o,
     int* __restrict__ radii, unsigned* __restrict__ tiles_touched, int* __restrict__ hist, int vps) {
-  // One workgroup = kChunk consecutive Gaussians of one view.  Their depth buckets are counted in
+  // One workgroup = kPreChunk consecutive Gaussians of one view.  Their depth buckets are counted in
   // an LDS histogram first and only the non-empty bins go to the global one: scattered global
   // atomics run at ~20 G/s chip-wide, and a depth slice of a regular grid puts thousands of
   // Gaussians into ONE bucket.
   // Workgroup -> (chunk, view), XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so
   // ids L and L+8 share an L2; the V views of a chunk get ids 8 apart and run back to back on one
   // XCD, which reads the chunk's 90 KB of Gaussian parameters from HBM once instead of V times.
-  // two 16-bit counters per word (a workgroup counts at most kChunk = 2048 Gaussians: no carry):
+  // two 16-bit counters per word (a workgroup counts at most kPreChunk Gaussians: no carry):
   // 16 KB instead of 32 KB of LDS, so the 92-VGPR limit (5 workgroups per CU), not the LDS (4), sets
   // the occupancy
-  static_assert(kChunk < 65536, "16-bit bucket counters");
+  static_assert(kPreChunk < 65536, "16-bit bucket counters");
   __shared__ unsigned s_hist[kBuckets / 2];
   __shared__ int s_wsum[kBlock / 64];
   __shared__ int s_base;
@@ -98,11 +99,11 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
   if (chunk >= n_chunks) return;
   for (int i = threadIdx.x; i < kBuckets / 2; i += kBlock) s_hist[i] = 0;
   __syncthreads();
-  unsigned key_of[kChunk / kBlock];
-  Rect rect_of[kChunk / kBlock];
+  unsigned key_of[kPreChunk / kBlock];
+  Rect rect_of[kPreChunk / kBlock];
 #pragma unroll
-  for (int it = 0; it < kChunk / kBlock; ++it) {
-  const int idx = chunk * kChunk + it * kBlock + threadIdx.x;
+  for (int it = 0; it < kPreChunk / kBlock; ++it) {
+  const int idx = chunk * kPreChunk + it * kBlock + threadIdx.x;
   key_of[it] = 0xFFFFFFFFu;
   rect_of[it] = Rect{0, 0, 0, 0};
   if (idx >= P) continue;
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
   // per workgroup reserves the range; the order is arbitrary (the scatter re-buckets, the blend sorts)
   int mine = 0;
 #pragma unroll
-  for (int it = 0; it < kChunk / kBlock; ++it) mine += key_of[it] != 0xFFFFFFFFu;
+  for (int it = 0; it < kPreChunk / kBlock; ++it) mine += key_of[it] != 0xFFFFFFFFu;
   const int lane = threadIdx.x % 64, wave = threadIdx.x / 64;
   int inc = mine;
 #pragma unroll
@@ -268,9 +269,9 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
   __syncthreads();
   int pos = s_base + before + inc - mine;
 #pragma unroll
-  for (int it = 0; it < kChunk / kBlock; ++it) {
+  for (int it = 0; it < kPreChunk / kBlock; ++it) {
     if (key_of[it] == 0xFFFFFFFFu) continue;
-    const unsigned idx = (unsigned)(chunk * kChunk + it * kBlock + threadIdx.x);
+    const unsigned idx = (unsigned)(chunk * kPreChunk + it * kBlock + threadIdx.x);
     const Rect rc = rect_of[it];
     vis_rec[(long)v * P + pos] = make_uint4(key_of[it], idx, (unsigned)rc.x0 | ((unsigned)rc.y0 << 16),
                                             (unsigned)rc.x1 | ((unsigned)rc.y1 << 16));
@@ -1159,11 +1160,11 @@ int ocrf_rasterize_forward_sets(int P, int n_sets, int views_per_set, int H, int
   int* vis_count = hist + (size_t)n_views * kBuckets;
   hipError_t e = ocrf::zero_async(hist, (size_t)n_views * (kBuckets + 1) * sizeof(int), stream);
   if (e != hipSuccess) return (int)e;
-  const int n_chunks = (P + kChunk - 1) / kChunk;
+  const int n_chunks = (P + kChunk - 1) / kChunk, n_pre = (P + kPreChunk - 1) / kPreChunk;
   const dim3 pgrid(n_chunks, n_views);
-  const dim3 xgrid((unsigned)((n_chunks + 7) / 8 * 8 * n_views));      // (chunk, view) pairs, XCD-aware order
+  const dim3 xgrid((unsigned)((n_pre + 7) / 8 * 8 * n_views));         // (chunk, view) pairs, XCD-aware order
   ocrf::launch(OCRF_K_RASTER_PREPROCESS, raster_preprocess_kernel, xgrid, dim3(kBlock), 0, stream, P, n_views,
-               n_chunks, W, H, gx, gy, means3D, opacities, scales, scale_modifier, rotations, cov3D_precomp,
+               n_pre, W, H, gx, gy, means3D, opacities, scales, scale_modifier, rotations, cov3D_precomp,
                cams, vis_rec, vis_count, rects, xy, conic_o, radii, tiles_touched, hist, views_per_set);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
@@ -1260,10 +1261,10 @@ int ocrf_rasterize_backward(int P, int n_views, int H, int W, const float* means
   hipError_t e = ocrf::zero_async(hist, (size_t)n_views * (kBuckets + 1) * sizeof(int), stream);
   if (e == hipSuccess) e = ocrf::zero_async(acc, (size_t)n_views * P * 9 * sizeof(float), stream);
   if (e != hipSuccess) return (int)e;
-  const int n_chunks = (P + kChunk - 1) / kChunk;
+  const int n_chunks = (P + kChunk - 1) / kChunk, n_pre = (P + kPreChunk - 1) / kPreChunk;
   const dim3 pgrid(n_chunks, n_views);
-  const dim3 xgrid((unsigned)((n_chunks + 7) / 8 * 8 * n_views));
-  hipLaunchKernelGGL(raster_preprocess_kernel, xgrid, dim3(kBlock), 0, stream, P, n_views, n_chunks, W, H, gx, gy,
+  const dim3 xgrid((unsigned)((n_pre + 7) / 8 * 8 * n_views));
+  hipLaunchKernelGGL(raster_preprocess_kernel, xgrid, dim3(kBlock), 0, stream, P, n_views, n_pre, W, H, gx, gy,
                      means3D, opacities, scales, scale_modifier, rotations, (const float*)nullptr, cams, vis_rec,
                      vis_count, rects, xy, conic_o, radii, (unsigned*)nullptr, hist, n_views);
   hipLaunchKernelGGL(raster_bucket_scan_kernel, dim3(n_views), dim3(kBlock), 0, stream, static_cast<const int*>(hist),
