@@ -217,12 +217,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                               rs.viewmatrix.reshape(1, 4, 4), rs.projmatrix.reshape(1, 4, 4),
                               float(rs.tanfovx), float(rs.tanfovy), rs.image_height, rs.image_width,
                               rs.bg, float(rs.scale_modifier),
-                              cov3Ds_precomp if cov3Ds_precomp is not None and cov3Ds_precomp.numel() else None)
+                              cov3Ds_precomp if cov3Ds_precomp is not None and cov3Ds_precomp.numel() else None,
+                              want_n_contrib=any(ctx.needs_input_grad))      # only the backward reads it
         color, radii, depth = out['color'][0], out['radii'][0], out['depth'][0]
         ctx.mark_non_differentiable(radii, depth)
         ctx.raster_settings = rs
         ctx.has_cov = cov3Ds_precomp is not None and cov3Ds_precomp.numel() > 0
-        ctx.fwd = {k: out[k] for k in ('color', 'final_T', 'n_contrib')}
+        ctx.fwd = {k: out.get(k) for k in ('color', 'final_T', 'n_contrib')}
         if not ctx.has_cov:
             ctx.save_for_backward(means3D, colors_precomp, opacities, scales, rotations)
         return color, radii, depth
