@@ -5,7 +5,7 @@ Drop-in mirrors of the reference's Python surface for that path (and nothing els
   ==============================================  =================================================
   reference import                                here
   ==============================================  =================================================
-  mmdet3d.ops.bev_pool_v2.bev_pool                ocrfdet_amd.bev_pool
+  mmdet3d.ops.bev_pool_v2.bev_pool                ocrfdet_amd.bevpool
   diff_gaussian_rasterization (w-depth fork)      ocrfdet_amd.diff_gaussian_rasterization
   ...MVSGaussian.lib.gaussian_renderer.render     ocrfdet_amd.gaussian_renderer.render
   HOA blocks of view_transformer_ocrf.py          ocrfdet_amd.hoa

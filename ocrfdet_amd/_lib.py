@@ -220,19 +220,46 @@ def diag_stamp(stamps, index):
 
 
 class Workspace:
-    """Per-device grow-only scratch buffer (a torch uint8 tensor), so that steady-state calls
-    allocate nothing.  Stream-ordered reuse is safe because every user runs on the current stream."""
+    """Per-device grow-only scratch buffers (torch uint8 tensors, one per tag), so that steady-state calls
+    allocate nothing.  Reuse is stream-ordered: a tag is meant for one stream at a time (the side streams of
+    ``HotPath`` / ``_core_fused`` use tags of their own).
+
+    Two hazards of replacing a buffer when a larger request arrives are handled here:
+    * a captured hipGraph has the raw pointers of the buffers it used baked in — ``hold(device)`` returns
+      strong references to every buffer of the device; whoever owns a graph keeps that object for the
+      graph's lifetime (``GraphedNeck``), so a later, larger eager request gets a NEW buffer while the
+      graph keeps replaying on its own, still allocated one;
+    * the caching allocator may hand a freed block to the next allocation on the allocating stream while
+      another stream that used the buffer is still running — every stream that asked for the tag is
+      recorded on the old buffer (``Tensor.record_stream``) before it is dropped."""
 
     def __init__(self):
         self._bufs = {}
+        self._users = {}                       # key -> raw hipStream_t values that asked for the tag
 
     def get(self, device, nbytes, tag="default"):
-        key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        key = (idx, tag)
         buf = self._bufs.get(key)
+        if _raw_stream is not None:
+            users = self._users.get(key)
+            if users is None:
+                users = self._users[key] = set()
+            users.add(_raw_stream(idx))
         if buf is None or buf.numel() < nbytes:
+            if buf is not None:
+                for raw in self._users.get(key, ()):
+                    if raw:                    # 0 = the legacy default stream, the allocator's own
+                        buf.record_stream(torch.cuda.ExternalStream(raw, device=buf.device))
+                self._users[key] = {_raw_stream(idx)} if _raw_stream is not None else set()
             buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
             self._bufs[key] = buf
         return buf
+
+    def hold(self, device):
+        """Strong references to every scratch buffer of ``device`` as of now (see the class docstring)."""
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        return [b for (d, _), b in self._bufs.items() if d == idx]
 
 
 workspace = Workspace()

@@ -223,9 +223,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.mark_non_differentiable(radii, depth)
         ctx.raster_settings = rs
         ctx.has_cov = cov3Ds_precomp is not None and cov3Ds_precomp.numel() > 0
-        ctx.fwd = {k: out.get(k) for k in ('color', 'final_T', 'n_contrib')}
         if not ctx.has_cov:
-            ctx.save_for_backward(means3D, colors_precomp, opacities, scales, rotations)
+            # the forward's outputs are saved through autograd (not as plain attributes): the backward
+            # rebuilds S = C_out - T_final * bg from them, so an in-place edit of the rendered image
+            # (clamp_, mul_) must raise instead of silently changing the gradients
+            ctx.save_for_backward(means3D, colors_precomp, opacities, scales, rotations, color, out['final_T'],
+                                  out.get('n_contrib'))
         return color, radii, depth
 
     @staticmethod
@@ -236,8 +239,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             raise NotImplementedError('ocrfdet_amd rasteriser: backward with cov3D_precomp is not built '
                                       '(OcRFDet passes scales and rotations)')
         rs = ctx.raster_settings
-        means3D, colors, opacities, scales, rotations = ctx.saved_tensors
-        g = rasterize_views_backward(grad_color.unsqueeze(0), ctx.fwd, means3D, colors, opacities, scales, rotations,
+        means3D, colors, opacities, scales, rotations, fwd_color, fwd_T, fwd_n = ctx.saved_tensors
+        fwd = dict(color=fwd_color.unsqueeze(0), final_T=fwd_T, n_contrib=fwd_n)
+        g = rasterize_views_backward(grad_color.unsqueeze(0), fwd, means3D, colors, opacities, scales, rotations,
                                      rs.viewmatrix.reshape(1, 4, 4), rs.projmatrix.reshape(1, 4, 4),
                                      float(rs.tanfovx), float(rs.tanfovy), rs.image_height, rs.image_width, rs.bg,
                                      float(rs.scale_modifier), want_means2D=True)
@@ -255,15 +259,15 @@ class _RasterizeViews(torch.autograd.Function):
     def forward(ctx, means3D, colors, opacities, scales, rotations, cam):
         out = rasterize_views(means3D, colors, opacities, scales, rotations, *cam)
         ctx.cam = cam
-        ctx.fwd = {k: out[k] for k in ('color', 'final_T', 'n_contrib')}
-        ctx.save_for_backward(means3D, colors, opacities, scales, rotations)
+        ctx.save_for_backward(means3D, colors, opacities, scales, rotations, out['color'], out['final_T'], out['n_contrib'])
         ctx.mark_non_differentiable(out['depth'], out['radii'], out['final_T'])
         return out['color'], out['depth'], out['final_T'], out['radii']
 
     @staticmethod
     def backward(ctx, grad_color, _d, _t, _r):
-        means3D, colors, opacities, scales, rotations = ctx.saved_tensors
-        g = rasterize_views_backward(grad_color, ctx.fwd, means3D, colors, opacities, scales, rotations, *ctx.cam)
+        means3D, colors, opacities, scales, rotations, fwd_color, fwd_T, fwd_n = ctx.saved_tensors
+        fwd = dict(color=fwd_color, final_T=fwd_T, n_contrib=fwd_n)
+        g = rasterize_views_backward(grad_color, fwd, means3D, colors, opacities, scales, rotations, *ctx.cam)
         return g['means3D'], g['colors'], g['opacities'].reshape(opacities.shape), g['scales'], g['rotations'], None
 
 

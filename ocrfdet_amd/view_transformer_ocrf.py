@@ -363,7 +363,8 @@ class VoxelFeatureExtractor(nn.Module):
     def forward(self, x):
         conv, bn = self.conv[0], self.conv[1]
         if (x.is_cuda and x.dim() == 5 and x.shape[1] == 1 and conv.in_channels == 1 and conv.kernel_size == (1, 1, 1)
-                and bn.affine and bn.track_running_stats):
+                and type(bn) is nn.BatchNorm3d and bn.affine and bn.track_running_stats):
+            # (a converted nn.SyncBatchNorm needs cross-rank statistics: it takes the layer path below)
             return self._lift(x)
         return self.conv(x)
 
@@ -552,7 +553,11 @@ class OcRFViewTransformerFull(nn.Module):
 
     def _geometry(self, input, sync=True):
         """``sync=False`` (eval mode): the rank vectors stay at their capacity with their lengths on the
-        device — nothing between the calibration and the pooled BEV reads the device."""
+        device — nothing between the calibration and the pooled BEV reads the device.  Only that forward-only
+        path writes into the module's persistent rank buffers: with ``sync=True`` the ranks reach autograd
+        Functions that save them for the backward (``QuickCumsumCuda`` / ``_FusedPool``; ``.int().contiguous()``
+        is a no-op on them), and a later forward of the same module before that backward (adjacent frame,
+        second view, eval hook) must not overwrite what was saved — those calls get fresh tensors."""
         x = input[0]
         dev = x.device
         B, N, _, Hf, Wf = x.shape
@@ -569,11 +574,11 @@ class OcRFViewTransformerFull(nn.Module):
         frustum, tmpl = self._templates(dev)
         geo.lss = index_prep.voxel_pooling_prepare_v2_hip(frustum, lss_block, B, N, self.grid_lower_bound,
                                                           self.grid_interval, self.grid_size,
-                                                          buffers=None if self.accelerate else self._rank_bufs[0],
+                                                          buffers=None if (self.accelerate or sync) else self._rank_bufs[0],
                                                           sync=sync)
         geo.ht = index_prep.fast_sample_prepare_hip(tmpl, ht_block, B, N, list(self.pc_range), self.input_size,
                                                     self.grid_config['depth'], Wf, Hf, self.D,
-                                                    buffers=None if self.accelerate else self._rank_bufs[1], sync=sync)
+                                                    buffers=None if (self.accelerate or sync) else self._rank_bufs[1], sync=sync)
         geo.pix, geo.mask, geo.voxel = index_prep.ht_project_hip(tmpl, ht_block, B, N, list(self.pc_range),
                                                                  self.input_size, self.grid_config['depth'])
         return geo
@@ -1013,6 +1018,9 @@ class GraphedNeck:
                 self._graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._graph, stream=capture_stream):
                     self._static_out = self._body(self._cams)
+                # the graph has the raw pointers of the library's scratch buffers baked in: keep those
+                # buffers alive for the graph's lifetime, whatever later eager calls make of their tags
+                self._scratch = _lib.workspace.hold(dev)
             finally:
                 m.parallel_branches = False
 

@@ -45,7 +45,8 @@ def test_kat_forward_backward(cuda):
 
 
 @pytest.mark.parametrize('cfg_name', ['cfg0_1cam_128x352_bev64x64x4', 'ref_6cam_256x704_bev128x128x1',
-                                      'cfg1_6cam_256x704_bev128x128x8'])
+                                      'cfg1_6cam_256x704_bev128x128x8',
+                                      'cfg2_6cam_2frame_bev200x200_render_hoa'])
 @pytest.mark.parametrize('branch', ['lss', 'ht'])
 def test_parity_reference_shapes(cuda, oracle_lib, cfg_name, branch):
     cfg = synthetic.CONFIGS[cfg_name]
@@ -193,6 +194,57 @@ def test_backward_parity(cuda, oracle_lib):
     out.backward(_dev(og, cuda))
     np.testing.assert_allclose(d.grad.cpu().numpy(), want_d, rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(f.grad.cpu().numpy(), want_f, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('cfg_name', ['cfg0_1cam_128x352_bev64x64x4', 'ref_6cam_256x704_bev128x128x1'])
+def test_backward_ht_ranks_repeated_depth_cells(cuda, oracle_lib, cfg_name):
+    """HT ranks: several pillar samples round to the same (camera, d, h, w) depth cell, so ``ranks_depth``
+    repeats.  The reference stores ``depth_grad[ranks_depth[p]] = ...`` without accumulation
+    (bev_pool_cuda.cu:103-104): a repeated cell ends with ONE contributor's value.  A depth cell fixes its
+    feature pixel, so all of a cell's contributors lie in one ranks_feat run, i.e. in ONE reference thread,
+    and the last of them in that run's order wins; the reference's order inside a run comes from an unstable
+    argsort (bev_pool.py:47), so any contributor is a legal winner.  Here the sort is stable and a run is walked
+    in order by one lane group: the winner is the LAST contributor in forward list order — deterministic, and
+    the same as the C oracle's (which also sorts stably).  feat_grad is a sum and has no such freedom."""
+    cfg = synthetic.CONFIGS[cfg_name]
+    depth, feat = helpers.pool_inputs(cfg)
+    rb, rd, rf, st, ln = helpers.ht_ranks(cfg)
+    uniq, cnt = np.unique(rd, return_counts=True)
+    assert (cnt > 1).sum() > 100, 'the HT ranks of this configuration should repeat depth cells'
+    X, Y, _ = cfg.bev_xyz
+    shape = (cfg.batch, 1, Y, X, cfg.channels)
+    rng = np.random.default_rng(9)
+    og = rng.standard_normal(shape).astype(np.float32)
+    want_d, want_f = oracle_lib.bev_pool_v2_backward(og, depth, feat, rd, rf, rb)
+    grads = []
+    for _ in range(3):
+        d = _dev(depth, cuda).requires_grad_()
+        f = _dev(feat, cuda).requires_grad_()
+        out = bevpool.QuickCumsumCuda.apply(d, f, _dev(rd, cuda), _dev(rf, cuda), _dev(rb, cuda), shape,
+                                            _dev(st, cuda), _dev(ln, cuda))
+        out.backward(_dev(og, cuda))
+        grads.append((d.grad.cpu().numpy(), f.grad.cpu().numpy()))
+    gd, gf = grads[0]
+    np.testing.assert_allclose(gf, want_f, rtol=1e-4, atol=1e-4)
+    # (1) every cell holds the value of one of its contributors (the reference's contract) ...
+    per_point = np.einsum('pc,pc->p', og.reshape(-1, cfg.channels)[rb].astype(np.float64),
+                          feat.reshape(-1, cfg.channels)[rf].astype(np.float64))
+    flat = gd.reshape(-1)
+    err = np.abs(flat[rd] - per_point)                      # distance of the cell's value to each contributor
+    best = np.full(depth.size, np.inf)
+    np.minimum.at(best, rd, err)
+    assert best[uniq].max() <= 1e-4
+    untouched = np.ones(depth.size, bool)
+    untouched[rd] = False
+    assert not flat[untouched].any()
+    # (2) ... namely the last one in list order, like the oracle, and the same on every run
+    np.testing.assert_allclose(gd, want_d, rtol=1e-4, atol=1e-4)
+    last = np.zeros(depth.size, np.int64)
+    last[rd] = np.arange(rd.size)                           # numpy fancy assignment: last write wins
+    np.testing.assert_allclose(flat[uniq], per_point[last[uniq]], rtol=1e-4, atol=1e-4)
+    for gd2, gf2 in grads[1:]:
+        np.testing.assert_array_equal(gd, gd2)
+        np.testing.assert_array_equal(gf, gf2)
 
 
 def test_layouts_agree_with_reference_wrapper_ops(cuda, oracle_lib):

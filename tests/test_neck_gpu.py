@@ -233,6 +233,41 @@ def test_training_path_matches_fused_path(core):
     close(lst[8], lst2[8].cpu().numpy(), 1e-5, 'render_depth_N train vs fused')
 
 
+def test_second_forward_does_not_disturb_saved_ranks(core):
+    """A forward of the same module BEFORE the backward of an earlier one (adjacent frame, second view, eval
+    hook) must not change that backward: the rank vectors an autograd Function saved may not alias the
+    module's persistent rank buffers (which only the forward-only sync=False path may use)."""
+    m, g = core['m'], core['g']
+    cams = [int(c) for c in g['cam_idx_list']]
+    cfg = core['cfg']
+    pre = torch.from_numpy(g['pre']).cuda()
+    depth = pre[:, :cfg.D].softmax(1)
+
+    def run(disturb):
+        feat = pre[:, cfg.D + 2:].clone().requires_grad_(True)
+        m.training = True
+        try:
+            bev, _, _, _ = m.view_transform_core(core['inp'], depth, feat, cam_idx_list=cams)
+            if disturb:
+                # another calibration (cameras rolled by one): different rank vectors of different lengths
+                inp2 = list(core['inp'])
+                for i in (1, 2, 3, 4, 5, 11):
+                    inp2[i] = torch.roll(inp2[i], 1, 1) * (1.0 if i != 2 else 1.1)
+                with torch.no_grad():
+                    m.view_transform_core(inp2, depth, feat.detach(), cam_idx_list=cams)
+                m.training = False
+                with torch.no_grad():                      # and an eval forward, which does use the buffers
+                    m.view_transform_core(inp2, depth, feat.detach(), cam_idx_list=cams)
+            bev.sum().backward()
+        finally:
+            m.training = False
+        m.zero_grad()
+        return feat.grad.clone()
+
+    a, b = run(False), run(True)
+    torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+
+
 def test_ht_project_bit_exact(core):
     """ocrf_ht_project vs the numpy oracle of get_sampling_point (itself pinned bit-exactly to the
     reference's vectors): mask identical, pixel coordinates of valid samples bit-identical."""
