@@ -38,7 +38,7 @@ const char *ocrf_version(void);
  *   out[ranks_bev[starts[k]]*c + ch] = sum_i depth[ranks_depth[starts[k]+i]] * feat[ranks_feat[starts[k]+i]*c + ch]
  * (assignment, accumulated in list order); launches on the legacy default stream; any interval
  * layout is accepted (one lane group per interval).  No error is reported (the reference
- * reports none) — use ocrf_bev_pool_v2 for an error code, a stream and the load-balanced kernel.
+ * reports none) — use ocrf_bev_pool_v2 for an error code, a stream and the tiled kernel.
  */
 void bev_pool_v2(int c, int n_intervals, const float *depth, const float *feat,
                  const int *ranks_depth, const int *ranks_feat, const int *ranks_bev,
@@ -57,37 +57,40 @@ void bev_pool_v2_grad(int c, int n_intervals, const float *out_grad, const float
                       const int *interval_lengths, float *depth_grad, float *feat_grad);
 
 /*
- * Load-balanced forward.  Same arithmetic contract as bev_pool_v2 with these additions:
+ * Tiled forward (one output-stationary pass: csrc/bev_pool.hip).  Same arithmetic contract as bev_pool_v2 —
+ * `out` is (B,Z,Y,X,C) = (n_voxels, C) rows — with these additions / differences:
  *   n_points        length of the three rank vectors (the reference passes it implicitly as
  *                   tensor sizes, bev_pool.cpp:30-57);
- *   workspace       scratch of at least ocrf_bev_pool_v2_workspace_bytes(c, n_points) bytes
- *                   (may be NULL when that is 0); contents are don't-care on entry and exit;
+ *   n_voxels        rows of `out` (B*Z*Y*X, < 2^30); EVERY row is written (empty voxels as 0), so `out`
+ *                   needs no pre-zeroing (pre-zeroed, as the reference's caller does, is fine too);
+ *   workspace       scratch of at least ocrf_bev_pool_v2_workspace_bytes(c, n_points, n_voxels) bytes,
+ *                   16-byte aligned; contents are don't-care on entry and exit;
  *   stream          hipStream_t.
- * Precondition (always true for the reference's producers, view_transformer.py:240-255,
- * view_transformer_ocrf.py:837-852): interval_starts is ascending and intervals do not overlap
- * (gaps are allowed: points outside every interval are ignored).  Check it with
- * ocrf_bev_pool_v2_check_intervals when in doubt; bev_pool_v2 above accepts anything.
- * Results are bitwise reproducible run to run (no float atomics).
+ * ANY interval layout is accepted, like the reference's kernel: unsorted, overlapping, empty intervals, gaps
+ * (points outside every interval are ignored).  Two intervals that name the same voxel race in the reference
+ * (two threads assign the same row); here one of them wins as well.  Channel counts outside C % 4 == 0,
+ * 32 <= C <= 256 take the reference's own thread mapping (then `out` must be pre-zeroed).
+ * Results are bitwise reproducible run to run (no float atomics); a voxel whose points lie inside one 32-point
+ * sub-chunk of its tile's point list is summed in exactly the reference's order.
  */
-int ocrf_bev_pool_v2(int c, int n_intervals, int n_points, const float *depth, const float *feat,
+int ocrf_bev_pool_v2(int c, int n_intervals, int n_points, long n_voxels, const float *depth, const float *feat,
                      const int *ranks_depth, const int *ranks_feat, const int *ranks_bev,
                      const int *interval_starts, const int *interval_lengths, float *out,
                      void *workspace, size_t workspace_bytes, ocrf_stream_t stream);
 
-size_t ocrf_bev_pool_v2_workspace_bytes(int c, int n_points);
+size_t ocrf_bev_pool_v2_workspace_bytes(int c, int n_points, long n_voxels);
 
 /*
- * Fused forward: ocrf_bev_pool_v2 + the layout passes the reference runs after it.  Writes EVERY
- * element of `out` (empty voxels as 0), so `out` needs no pre-zeroing, directly in channel-major
- * order:
+ * Fused forward: the same pass writing the layout the reference reaches with its passes AFTER the op, directly:
  *   layout 0: out[b][c][z][y][x]      == bev_pool_v2(...) of the reference, i.e. the op's
  *                                        permute(0,4,1,2,3).contiguous() (bev_pool.py:91);
  *   layout 1: out[b][z*C + c][y][x]   == torch.cat(bev_feat.unbind(dim=2), 1), what
  *                                        voxel_pooling_v2 / fast_sampling return
  *                                        (view_transformer.py:194, view_transformer_ocrf.py:781).
- * (B,Z,Y,X) is the reference's bev_feat_shape without C (B*Z*Y*X < 2^29).  Needs C % 4 == 0, 32 <= C <= 256 and
- * the interval precondition of ocrf_bev_pool_v2; ranks_bev values must be < B*Z*Y*X.
- * workspace >= ocrf_bev_pool_v2_nchw_workspace_bytes(c, n_intervals, n_points, B*Z*Y*X).
+ * Every element of `out` is written exactly once (64 voxels x C channels per workgroup, 256-byte runs per
+ * channel).  (B,Z,Y,X) is the reference's bev_feat_shape without C (B*Z*Y*X < 2^30).  Needs C % 4 == 0,
+ * 32 <= C <= 256; ranks_bev values outside [0, B*Z*Y*X) are ignored.
+ * workspace >= ocrf_bev_pool_v2_nchw_workspace_bytes(c, n_intervals, n_points, B, Z, Y, X).
  */
 int ocrf_bev_pool_v2_nchw(int c, int n_intervals, int n_points, const float *depth,
                           const float *feat, const int *ranks_depth, const int *ranks_feat,
@@ -99,37 +102,39 @@ int ocrf_bev_pool_v2_nchw(int c, int n_intervals, int n_points, const float *dep
 /*
  * Plans for rank vectors that stay the same across calls (static calibration: the reference's
  * `accelerate=True`, pre_compute at view_transformer.py:257-262 / view_transformer_ocrf.py:854-866).
- * ocrf_bev_pool_plan_build runs the rank-only part of the pooling once — the interval search, the
- * piece marking, the voxel -> row map — and keeps it in `plan` (device memory, caller-owned,
- * >= ocrf_bev_pool_plan_bytes(c, n_points, B*Z*Y*X) bytes, 16-byte aligned);
- * ocrf_bev_pool_v2_nchw_planned is ocrf_bev_pool_v2_nchw for exactly those rank vectors (same c,
- * n_intervals, n_points, grid) reading the plan instead: same results bit for bit, ~1/3 less kernel
- * time.  ranks_bev / interval_* are not needed again after the build.  B*Z*Y*X < 2^29.
+ * ocrf_bev_pool_plan_build runs the rank-only part of the pooling once — the dense voxel table, the list of
+ * work units (tiles and slices of heavy tiles), their split over the XCDs — and keeps it in `plan` (device
+ * memory, caller-owned, >= ocrf_bev_pool_plan_bytes(c, n_points, B, Z, Y, X) bytes, 16-byte aligned);
+ * ocrf_bev_pool_v2_nchw_planned is ocrf_bev_pool_v2_nchw for exactly those rank vectors (same c, n_points,
+ * grid) as ONE launch: same results bit for bit.  ranks_bev / interval_* are not needed again after the build.
+ * The plan holds the arrival counters of the cut tiles (left at zero by every call), so a plan serves one
+ * stream at a time.  workspace >= ocrf_bev_pool_planned_workspace_bytes(c, n_points).
  */
-size_t ocrf_bev_pool_plan_bytes(int c, int n_points, long n_voxels);
+size_t ocrf_bev_pool_plan_bytes(int c, int n_points, int B, int Z, int Y, int X);
 int ocrf_bev_pool_plan_build(int c, int n_intervals, int n_points, const int *ranks_bev,
-                             const int *interval_starts, const int *interval_lengths, long n_voxels,
+                             const int *interval_starts, const int *interval_lengths, int B, int Z, int Y, int X,
                              void *plan, size_t plan_bytes, ocrf_stream_t stream);
-int ocrf_bev_pool_v2_nchw_planned(int c, int n_intervals, int n_points, const float *depth,
-                                  const float *feat, const int *ranks_depth, const int *ranks_feat,
-                                  const void *plan, float *out, int B, int Z, int Y, int X, int layout,
-                                  void *workspace, size_t workspace_bytes, ocrf_stream_t stream);
+size_t ocrf_bev_pool_planned_workspace_bytes(int c, int n_points);
+int ocrf_bev_pool_v2_nchw_planned(int c, int n_points, const float *depth, const float *feat,
+                                  const int *ranks_depth, const int *ranks_feat, void *plan, float *out,
+                                  int B, int Z, int Y, int X, int layout, void *workspace,
+                                  size_t workspace_bytes, ocrf_stream_t stream);
 
 /* Same, for rank vectors whose lengths were produced on the device (ocrf_lss_prepare /
  * ocrf_ht_prepare): the vectors are passed at their capacities and `counts` (device, int32) holds
- * [n_points, n_intervals]; the launch is sized for the capacities and workgroups past the real
+ * [n_points, n_intervals]; the launches are sized for the capacities and workgroups past the real
  * end retire at once, so nothing between index preparation and pooling reads the device.
- * Workspace: ocrf_bev_pool_v2_nchw_workspace_bytes(c, cap_intervals, cap_points, n_voxels). */
+ * Workspace: ocrf_bev_pool_v2_nchw_workspace_bytes(c, cap_intervals, cap_points, B, Z, Y, X). */
 int ocrf_bev_pool_v2_nchw_dyn(int c, int cap_intervals, int cap_points, const int *counts,
                               const float *depth, const float *feat, const int *ranks_depth,
                               const int *ranks_feat, const int *ranks_bev, const int *interval_starts,
                               const int *interval_lengths, float *out, int B, int Z, int Y, int X,
                               int layout, void *workspace, size_t workspace_bytes, ocrf_stream_t stream);
-size_t ocrf_bev_pool_v2_nchw_workspace_bytes(int c, int n_intervals, int n_points, long n_voxels);
+size_t ocrf_bev_pool_v2_nchw_workspace_bytes(int c, int n_intervals, int n_points, int B, int Z, int Y, int X);
 
 /*
- * Writes *flag (device int) = 0 if interval_starts/lengths satisfy the precondition of
- * ocrf_bev_pool_v2 for n_points points, else a non-zero bit mask
+ * Writes *flag (device int) = 0 if interval_starts/lengths are the ascending, non-overlapping cover the
+ * reference's producers build (view_transformer.py:240-255) for n_points points, else a non-zero bit mask
  * (1: not ascending / overlapping, 2: interval exceeds n_points, 4: negative start or length).
  */
 int ocrf_bev_pool_v2_check_intervals(int n_intervals, int n_points, const int *interval_starts,
@@ -484,13 +489,14 @@ int ocrf_cbam_tail(const float *y, const float *scale, const float *stats, const
  * While a timer is armed for kernel id K, every launch of K inside the library is bracketed by
  * a hipEvent pair recorded on the launch stream (hipExtLaunchKernelGGL), up to `capacity`
  * launches.  ocrf_timer_read waits for the recorded pairs and returns their elapsed
- * milliseconds.  Arming with timer == NULL disarms.  Host-side only; one armed timer at a time. */
+ * milliseconds.  Several timers (for different kernel ids) may be armed at once; arming with
+ * timer == NULL disarms all of them.  Host-side only. */
 enum {
-  OCRF_K_BEV_POOL_FWD = 1,      /* bev_pool_fwd_chunked_kernel */
-  OCRF_K_BEV_POOL_FIXUP = 2,    /* bev_pool_fwd_fixup_kernel */
+  OCRF_K_BEV_POOL_FWD = 1,      /* bev_pool_tile_kernel */
+  OCRF_K_BEV_POOL_FIXUP = 2,    /* (retired) */
   OCRF_K_BEV_POOL_INTERVAL = 3, /* bev_pool_interval_kernel */
   OCRF_K_BEV_POOL_GRAD = 4,     /* bev_pool_grad_vec_kernel */
-  OCRF_K_BEV_POOL_NCHW = 5,     /* bev_pool_rows_to_nchw_kernel */
+  OCRF_K_BEV_POOL_NCHW = 5,     /* (retired: the tile kernel writes the final layout itself) */
   OCRF_K_RASTER_PREPROCESS = 10, /* raster_preprocess_kernel */
   OCRF_K_RASTER_BLEND = 11,      /* raster_blend_kernel */
   OCRF_K_RASTER_GATHER = 12,     /* raster_scatter_kernel */
@@ -539,6 +545,19 @@ int ocrf_timer_create(int capacity, void **timer_out); /* host pointers */
 int ocrf_timer_arm(void *timer, int kernel_id);
 int ocrf_timer_read(void *timer, float *ms_out /* host */, int capacity, int *count_out /* host */);
 int ocrf_timer_destroy(void *timer);
+
+/* Diagnostics of the pooling kernel (A/B timing of variants in one process; never on the product path).
+ * ocrf_tune_set: key 0 = rounds of the point walk per slice of a heavy tile (1..64; default 4), key 1 = deal
+ * workgroups to XCDs in contiguous unit ranges (default 1), key 2 = cap on the workgroups of the launch (0 = one per
+ * unit), key 3 = voxels per tile (32 | 64; default 64).  Plans and workspaces are sized for the values in
+ * force when they were built.  ocrf_diag_bev_pool_stamps: the planned pooling with s_memtime accumulated per
+ * phase and unit into stamps[ocrf_bev_pool_max_units(...)][8] = {table + zero-fill, staging, gather, combine,
+ * write-out, points of the unit, -, -}. */
+int ocrf_tune_set(int key, int value);
+int ocrf_bev_pool_max_units(int c, int n_points, int B, int Z, int Y, int X);
+int ocrf_diag_bev_pool_stamps(int c, int n_points, const float *depth, const float *feat, const int *ranks_depth,
+                              const int *ranks_feat, void *plan, float *out, int B, int Z, int Y, int X, int layout,
+                              void *workspace, unsigned long long *stamps, ocrf_stream_t stream);
 
 #ifdef __cplusplus
 }

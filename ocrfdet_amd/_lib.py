@@ -54,10 +54,11 @@ def _declare(L):
     L.bev_pool_v2.argtypes = [c_int, c_int] + [c_void_p] * 8
     L.bev_pool_v2_grad.restype = None
     L.bev_pool_v2_grad.argtypes = [c_int, c_int] + [c_void_p] * 10
+    c_long = ctypes.c_long
     L.ocrf_bev_pool_v2.restype = c_int
-    L.ocrf_bev_pool_v2.argtypes = [c_int, c_int, c_int] + [c_void_p] * 8 + [c_void_p, c_size_t, c_void_p]
+    L.ocrf_bev_pool_v2.argtypes = [c_int, c_int, c_int, c_long] + [c_void_p] * 8 + [c_void_p, c_size_t, c_void_p]
     L.ocrf_bev_pool_v2_workspace_bytes.restype = c_size_t
-    L.ocrf_bev_pool_v2_workspace_bytes.argtypes = [c_int, c_int]
+    L.ocrf_bev_pool_v2_workspace_bytes.argtypes = [c_int, c_int, c_long]
     L.ocrf_bev_pool_v2_nchw.restype = c_int
     L.ocrf_bev_pool_v2_nchw.argtypes = ([c_int, c_int, c_int] + [c_void_p] * 8 + [c_int] * 5 +
                                         [c_void_p, c_size_t, c_void_p])
@@ -65,14 +66,22 @@ def _declare(L):
     L.ocrf_bev_pool_v2_nchw_dyn.argtypes = ([c_int, c_int, c_int] + [c_void_p] * 9 + [c_int] * 5 +
                                             [c_void_p, c_size_t, c_void_p])
     L.ocrf_bev_pool_v2_nchw_workspace_bytes.restype = c_size_t
-    L.ocrf_bev_pool_v2_nchw_workspace_bytes.argtypes = [c_int, c_int, c_int, ctypes.c_long]
+    L.ocrf_bev_pool_v2_nchw_workspace_bytes.argtypes = [c_int] * 7
     L.ocrf_bev_pool_plan_bytes.restype = c_size_t
-    L.ocrf_bev_pool_plan_bytes.argtypes = [c_int, c_int, ctypes.c_long]
+    L.ocrf_bev_pool_plan_bytes.argtypes = [c_int] * 6
     L.ocrf_bev_pool_plan_build.restype = c_int
-    L.ocrf_bev_pool_plan_build.argtypes = [c_int] * 3 + [c_void_p] * 3 + [ctypes.c_long, c_void_p, c_size_t, c_void_p]
+    L.ocrf_bev_pool_plan_build.argtypes = [c_int] * 3 + [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_size_t, c_void_p]
+    L.ocrf_bev_pool_planned_workspace_bytes.restype = c_size_t
+    L.ocrf_bev_pool_planned_workspace_bytes.argtypes = [c_int, c_int]
     L.ocrf_bev_pool_v2_nchw_planned.restype = c_int
-    L.ocrf_bev_pool_v2_nchw_planned.argtypes = ([c_int] * 3 + [c_void_p] * 6 + [c_int] * 5 +
+    L.ocrf_bev_pool_v2_nchw_planned.argtypes = ([c_int] * 2 + [c_void_p] * 6 + [c_int] * 5 +
                                                 [c_void_p, c_size_t, c_void_p])
+    L.ocrf_tune_set.restype = c_int
+    L.ocrf_tune_set.argtypes = [c_int, c_int]
+    L.ocrf_bev_pool_max_units.restype = c_int
+    L.ocrf_bev_pool_max_units.argtypes = [c_int] * 6
+    L.ocrf_diag_bev_pool_stamps.restype = c_int
+    L.ocrf_diag_bev_pool_stamps.argtypes = [c_int] * 2 + [c_void_p] * 6 + [c_int] * 5 + [c_void_p] * 3
     L.ocrf_bev_pool_v2_check_intervals.restype = c_int
     L.ocrf_bev_pool_v2_check_intervals.argtypes = [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
     L.ocrf_bev_pool_v2_grad.restype = c_int

@@ -85,10 +85,11 @@ class _ExtensionAPI:
                     raise _lib.OcrfHipError(
                         f'intervals are not an ascending non-overlapping cover (flag={bad}); the '
                         'C entry point bev_pool_v2() accepts arbitrary layouts')
-            need = L.ocrf_bev_pool_v2_workspace_bytes(channels, n_pts)
+            n_vox = out.numel() // max(channels, 1)
+            need = L.ocrf_bev_pool_v2_workspace_bytes(channels, n_pts, n_vox)
             scratch = _lib.workspace.get(dev, need, 'bev_pool')
             _lib.check(L.ocrf_bev_pool_v2(
-                channels, n_iv, n_pts, _lib.ptr(depth), _lib.ptr(feat), _lib.ptr(ranks_depth),
+                channels, n_iv, n_pts, n_vox, _lib.ptr(depth), _lib.ptr(feat), _lib.ptr(ranks_depth),
                 _lib.ptr(ranks_feat), _lib.ptr(ranks_bev), _lib.ptr(interval_starts),
                 _lib.ptr(interval_lengths), _lib.ptr(out), _lib.ptr(scratch),
                 ctypes.c_size_t(scratch.numel()), stream), 'ocrf_bev_pool_v2')
@@ -184,7 +185,7 @@ class _FusedPool(torch.autograd.Function):
                           dtype=torch.float32, device=dev)
         L = _lib.lib()
         with _lib.on_device(dev):
-            need = L.ocrf_bev_pool_v2_nchw_workspace_bytes(C, n_iv, n_pts, B * Z * Y * X)
+            need = L.ocrf_bev_pool_v2_nchw_workspace_bytes(C, n_iv, n_pts, B, Z, Y, X)
             scratch = _lib.workspace.get(dev, need, 'bev_pool_nchw')
             _lib.check(L.ocrf_bev_pool_v2_nchw(
                 C, n_iv, n_pts, _lib.ptr(d32), _lib.ptr(f32), _lib.ptr(rd), _lib.ptr(rf),
@@ -244,7 +245,7 @@ def bev_pool_v2_device_counts(depth, feat, ranks_depth, ranks_feat, ranks_bev, b
     out = torch.empty((B, C, Z, Y, X) if layout == 0 else (B, Z * C, Y, X), dtype=torch.float32, device=dev)
     L = _lib.lib()
     with _lib.on_device(dev):
-        need = L.ocrf_bev_pool_v2_nchw_workspace_bytes(C, cap_iv, cap_pts, B * Z * Y * X)
+        need = L.ocrf_bev_pool_v2_nchw_workspace_bytes(C, cap_iv, cap_pts, B, Z, Y, X)
         scratch = _lib.workspace.get(dev, need, 'bev_pool_nchw')
         _lib.check(L.ocrf_bev_pool_v2_nchw_dyn(
             C, cap_iv, cap_pts, _lib.ptr(counts), _lib.ptr(d32), _lib.ptr(f32), _lib.ptr(ranks_depth),
@@ -256,8 +257,10 @@ def bev_pool_v2_device_counts(depth, feat, ranks_depth, ranks_feat, ranks_bev, b
 
 class DevicePoolPlan:
     """The rank-only part of one pooling, built once for rank vectors that are cached across calls
-    (C ABI ``ocrf_bev_pool_plan_build``): interval search, piece marking and the voxel -> row map.
-    ``bev_pool_v2_planned`` then needs only depth, feat, ranks_depth and ranks_feat.  Forward only."""
+    (C ABI ``ocrf_bev_pool_plan_build``): the dense voxel table, the list of work units (tiles, and slices
+    of heavy tiles) and their split over the XCDs.  ``bev_pool_v2_planned`` is then ONE launch that needs
+    only depth, feat, ranks_depth and ranks_feat.  Forward only; a plan serves one stream at a time (it
+    holds the arrival counters of the cut tiles)."""
 
     def __init__(self, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts, interval_lengths):
         _lib.require_cuda(ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths)
@@ -271,11 +274,10 @@ class DevicePoolPlan:
         self.n_points, self.n_intervals = self.ranks_depth.numel(), st.numel()
         dev = rb.device
         L = _lib.lib()
-        self.plan = torch.empty(L.ocrf_bev_pool_plan_bytes(C, self.n_points, ctypes.c_long(B * Z * Y * X)), dtype=torch.uint8,
-                                device=dev)
+        self.plan = torch.empty(L.ocrf_bev_pool_plan_bytes(C, self.n_points, B, Z, Y, X), dtype=torch.uint8, device=dev)
         with _lib.on_device(dev):
             _lib.check(L.ocrf_bev_pool_plan_build(C, self.n_intervals, self.n_points, _lib.ptr(rb), _lib.ptr(st), _lib.ptr(ln),
-                                                  ctypes.c_long(B * Z * Y * X), _lib.ptr(self.plan),
+                                                  B, Z, Y, X, _lib.ptr(self.plan),
                                                   ctypes.c_size_t(self.plan.numel()), _lib.stream_ptr(dev)),
                        'ocrf_bev_pool_plan_build')
 
@@ -293,10 +295,10 @@ def bev_pool_v2_planned(depth, feat, plan, layout=1):
     out = torch.empty((B, C, Z, Y, X) if layout == 0 else (B, Z * C, Y, X), dtype=torch.float32, device=dev)
     L = _lib.lib()
     with _lib.on_device(dev):
-        need = L.ocrf_bev_pool_v2_nchw_workspace_bytes(C, plan.n_intervals, plan.n_points, B * Z * Y * X)
+        need = L.ocrf_bev_pool_planned_workspace_bytes(C, plan.n_points)
         scratch = _lib.workspace.get(dev, need, 'bev_pool_nchw')
         _lib.check(L.ocrf_bev_pool_v2_nchw_planned(
-            C, plan.n_intervals, plan.n_points, _lib.ptr(d32), _lib.ptr(f32), _lib.ptr(plan.ranks_depth),
+            C, plan.n_points, _lib.ptr(d32), _lib.ptr(f32), _lib.ptr(plan.ranks_depth),
             _lib.ptr(plan.ranks_feat), _lib.ptr(plan.plan), _lib.ptr(out), B, Z, Y, X, int(layout), _lib.ptr(scratch),
             ctypes.c_size_t(scratch.numel()), _lib.stream_ptr(dev)), 'ocrf_bev_pool_v2_nchw_planned')
     return out

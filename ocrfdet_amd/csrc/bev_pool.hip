@@ -1,20 +1,32 @@
 // BEVPoolv2 voxel pooling for MI355X (gfx950) — forward + backward.
 //
 // Replaces mmdet3d/ops/bev_pool_v2/src/bev_pool_cuda.cu (reference: one thread per
-// (interval, channel) looping the whole interval; interval lengths at the reference shape run
-// from 1 to 5 216 with mean 51, so that kernel is bound by its longest thread).
+// (interval, channel) looping the whole interval — interval lengths at the reference shape run
+// from 1 to 5 216 with mean 51, so that kernel is bound by its longest thread — followed by a
+// zero-fill, a strided permute copy (bev_pool.py:91) and a cat (view_transformer.py:194)).
 //
-// Design (see DESIGN.md "bev_pool_v2"):
-//   * the POINT list, not the interval list, is cut into equal sub-chunks of S points; one lane
-//     group (C/4 lanes, one float4 of channels per lane -> a feat row is one coalesced 16 B/lane
-//     read) sums one sub-chunk, so every wave does the same work whatever the interval skew;
-//   * a workgroup finds the intervals that overlap its points with a cooperative 256-ary search
-//     on interval_starts and stages them, and the rank triples of its points, in LDS;
-//   * an interval that lies inside one sub-chunk is summed in list order and stored directly;
-//     an interval cut by a sub-chunk border leaves per-sub-chunk partial rows in a workspace and
-//     a second, tiny kernel adds them in ascending sub-chunk order — no float atomics, results
-//     are bitwise reproducible;
-//   * the arithmetic is fp32 fmaf, like the reference's contracted `psum += f*d`.
+// Design (DESIGN.md "bev_pool_v2"): ONE output-stationary pass.
+//   * The unit of work is a TILE of 64 consecutive voxels of one (b, z) plane: its pooled rows are
+//     built in LDS and leave the chip exactly once, already in the layout the caller asked for
+//     (channel-major runs of 64 floats = 256 B per channel, or channel-last rows), zeros included.
+//     There is no row buffer, no second pass and no pre-zeroing of the output.
+//   * A dense voxel table (start, length per voxel) built from the interval list replaces every
+//     search: a tile reads its 64 entries with one coalesced load.  Any interval layout is legal
+//     (unsorted, overlapping, empty, gaps) exactly as for the reference's kernel.
+//   * Load balance: tile point counts are as skewed as the interval lengths (at the headline shape
+//     1 % of the tiles hold 16 % of the points), so a tile with more than Q points is cut into
+//     SLICES of Q points that run as separate workgroups; a slice leaves a partial tile (slab) and
+//     the LAST slice to arrive (agent-scope release / ticket / acquire) adds the slabs in ascending
+//     slice order and writes the tile.  The order is fixed whoever arrives last: no float atomics,
+//     results are bitwise reproducible.
+//   * Inside a workgroup the tile's points are walked in rounds of BP = 12 x 32 points (C = 80):
+//     one lane group (C/4 lanes, a float4 of channels per lane -> a feat row is one coalesced
+//     16 B/lane read) per 32-point sub-chunk, branch-free `acc = fma(row, w, acc)` with marked
+//     emits; a voxel that lies inside one sub-chunk is summed in exactly the reference's order
+//     (bit-exact), pieces of voxels cut by sub-chunk borders are added in ascending order.
+//   * Workgroups are dealt to the 8 XCDs in contiguous, cost-balanced unit ranges, so that the
+//     tiles of one BEV region — which gather the same feat rows and depth cells — share one L2.
+//   * fp32 fmaf, like the reference's contracted `psum += f*d`.
 #include <hip/hip_runtime.h>
 
 #include "launch.h"
@@ -24,8 +36,13 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
-constexpr int kSubDefault = 32;  // S: points per lane group (tunable: ocrf_tune_set(0, 32|64))
-int g_sub = kSubDefault;
+constexpr int kTVmax = 64;       // voxels per tile: 64 or 32 (g_tv)
+int g_tv = 64;                   // ocrf_tune_set(3, 32|64)
+constexpr int kSub = 32;         // points per lane group per round
+constexpr int kUnitCost = 192;   // fixed cost of a unit in point equivalents (table read, zero-fill, tile write)
+int g_rounds = 4;                // rounds per slice: Q = g_rounds * BP points (ocrf_tune_set(0, 1..64))
+int g_xcd = 1;                   // XCD-contiguous unit ranges (ocrf_tune_set(1, 0|1))
+int g_grid = 0;                  // workgroups of the pooling launch: 0 = one per unit, else this many (ocrf_tune_set(2, n))
 
 __device__ __forceinline__ float4 fma4(float4 f, float d, float4 a) {
   a.x = fmaf(f.x, d, a.x);
@@ -34,10 +51,14 @@ __device__ __forceinline__ float4 fma4(float4 f, float d, float4 a) {
   a.w = fmaf(f.w, d, a.w);
   return a;
 }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Compatibility kernel: one thread per (interval, channel), exactly the reference's mapping
-// (bev_pool_cuda.cu:21-48).  Accepts any interval layout.
+// (bev_pool_cuda.cu:21-48).  Behind the exact-signature entry point and for channel counts the
+// tile kernel does not take (C % 4 != 0, C < 32, C > 256).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void bev_pool_interval_kernel(
     int c, int n_intervals, const float* __restrict__ depth, const float* __restrict__ feat,
@@ -60,393 +81,471 @@ __global__ __launch_bounds__(kBlock) void bev_pool_interval_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Load-balanced forward, pass 1.
-//   c4  = C/4 lanes per group, gpw = 64/c4 groups per wave, gpb = 4*gpw groups per block,
-//   BP  = gpb*kSub points per block.
-//   dst = row-addressed float4 output: row r, lane lg -> dst[r*c4 + lg].  The row of interval j
-//         is ranks_bev[start_j] (scatter into the (B,Z,Y,X,C) tensor, the reference's contract)
-//         or, with compact_rows, the interval's own index (dense [n_intervals][C] table that the
-//         NCHW epilogue consumes).
-//   part = workspace rows [2*n_blocks][c4] float4: 2b = block head partial, 2b+1 = tail partial.
-//   bmeta = workspace [n_blocks] int4 {head: 0 none / 1 ends in this block / 2 runs through,
-//                                      tail: 0/1, tail_row, 0}.
-// Phases: (1) stage per-point {depth weight, code} and the feat row index in LDS; (2) 256-ary
-// cooperative search for the first interval of the block; (3) stage the block's intervals;
-// (3b) one thread per interval marks the LAST point of each of its pieces (a piece = interval
-// /\ sub-chunk) with an emit code, zeroes the weight of points outside every interval and fills
-// the per-sub-chunk head/tail table; (4) each lane group walks its kSub points branch-free —
-// acc = fma(feat_row, w, acc); on a marked point it emits acc and restarts — with the row gathers
-// of the next 8 points in flight while 8 are consumed; (5) pieces of intervals cut by sub-chunk
-// borders are combined through LDS in ascending order, pieces cut by BLOCK borders go to `part`.
-// Dynamic LDS: int2 s_wc[BP] {w bits, code}; int s_rf[BP] s_st[BP+256] s_ln[BP+256]
-//              s_row[BP+256] s_meta[4*gpb]; float4 s_part[2*gpb][c4].
-// code: 1 | (local interval index << 2) = last point of a whole interval -> store to its dst
-// row; 2 = last point of a head piece -> keep in a register; tail pieces are the leftover.
+// Preparation (rank-only; cached in a plan when the rank vectors are):
+//   prep block = Header | tab int2[n_vox] | tile_cnt int[n_tiles] | arrive int[n_tiles] |
+//                tinfo int2[n_tiles] | units 2 x int4[max_units] {tile, j0, j1, slice} {slices, first slab, -, -}
+//   (A) zero tab + tile_cnt + arrive; (B) interval k -> tab[ranks_bev[start_k]] = (start_k, len_k),
+//   tile_cnt[tile] += len_k; (C) one workgroup turns the tile counts into the unit list.
 // ---------------------------------------------------------------------------------------------
-// Row gathers in flight per lane: 2 x kBatch (double-buffered).  8 + 8 cost 202 VGPRs = 2 waves per SIMD =
-// 2 workgroups per CU, and the latency-type phases around the loop (staging, interval search, combine:
-// 57 % of a workgroup's cycles) found nothing to overlap with; 4 + 4 fit 4 waves per SIMD.
+struct Header {
+  int n_units;
+  int xs[9];        // unit range of XCD x: [xs[x], xs[x+1])
+  int status;       // bit 0: the unit list was clamped (more units than the workspace was sized for)
+  int pad[5];
+};
+static_assert(sizeof(Header) == 64, "Header is one 64-byte line");
+
+struct Geometry {    // of the voxel space and its tiling
+  int planes, YX, tpp, n_tiles;   // tpp = tiles per plane
+  long n_vox;
+};
+inline Geometry make_geometry(long planes, long YX) {
+  Geometry g;
+  g.planes = (int)planes;
+  g.YX = (int)YX;
+  g.tpp = (int)((YX + g_tv - 1) / g_tv);
+  g.n_tiles = (int)(planes * g.tpp);
+  g.n_vox = planes * YX;
+  return g;
+}
+
+__global__ __launch_bounds__(kBlock) void bev_pool_table_kernel(
+    int n_intervals, int n_points, const int* __restrict__ counts, int YX, int tpp, int tv, long n_vox,
+    const int* __restrict__ ranks_bev, const int* __restrict__ interval_starts,
+    const int* __restrict__ interval_lengths, int2* __restrict__ tab, int* __restrict__ tile_cnt) {
+  if (counts) { n_points = counts[0]; n_intervals = counts[1]; }
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= n_intervals) return;
+  const int s = interval_starts[k];
+  int l = interval_lengths[k];
+  if (s < 0 || s >= n_points || l <= 0) return;      // an empty interval pools to 0: the table's default
+  l = min(l, n_points - s);
+  const int vox = ranks_bev[s];
+  if (vox < 0 || vox >= n_vox) return;
+  tab[vox] = make_int2(s, l);
+  atomicAdd(&tile_cnt[(vox / YX) * tpp + (vox % YX) / tv], l);
+}
+
+// exclusive scan of one int per thread over a 1024-thread workgroup; returns the total in `total`
+__device__ __forceinline__ int block_scan_1024(int v, int* s_w, int& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(inc, off);
+    if (lane >= off) inc += o;
+  }
+  __syncthreads();                 // s_w may still be read by the previous call
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int w = 0; w < 16; ++w) {
+    const int c = s_w[w];
+    if (w < wave) base += c;
+    tot += c;
+  }
+  total = tot;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(1024) void bev_pool_units_kernel(
+    int n_tiles, int Q, int max_units, const int* __restrict__ tile_cnt, Header* __restrict__ hdr,
+    int2* __restrict__ tinfo, int4* __restrict__ units) {
+  __shared__ int s_w[16];
+  __shared__ int s_x[9];
+  const int tid = threadIdx.x;
+  // pass 1: total cost
+  long cost_total = 0;
+  {
+    int part = 0;                                    // per-thread partial in units of 64 points (no overflow)
+    for (int t = tid; t < n_tiles; t += 1024) {
+      const int cnt = tile_cnt[t];
+      const int ns = max(1, (cnt + Q - 1) / Q);
+      part += (cnt + ns * kUnitCost + 63) >> 6;
+    }
+    int tot;
+    (void)block_scan_1024(part, s_w, tot);
+    cost_total = tot;
+  }
+  if (tid < 9) s_x[tid] = (tid == 0) ? 0 : -1;
+  __syncthreads();
+  int unit_base = 0, slab_base = 0;
+  long cost_base = 0;
+  for (int t0 = 0; t0 < n_tiles; t0 += 1024) {
+    const int t = t0 + tid;
+    const int cnt = (t < n_tiles) ? tile_cnt[t] : 0;
+    int ns = (t < n_tiles) ? max(1, (cnt + Q - 1) / Q) : 0;
+    const int cost = (t < n_tiles) ? ((cnt + ns * kUnitCost + 63) >> 6) : 0;
+    int tot_u, tot_s, tot_c;
+    const int ub = unit_base + block_scan_1024(ns, s_w, tot_u);
+    const int sb = slab_base + block_scan_1024(ns > 1 ? ns : 0, s_w, tot_s);
+    const long cb = cost_base + block_scan_1024(cost, s_w, tot_c);
+    if (t < n_tiles) {
+      if (ub + ns > max_units) {                     // clamp (only inconsistent tile counts get here)
+        ns = max(0, max_units - ub);
+        atomicOr(&hdr->status, 1);
+      }
+      tinfo[t] = make_int2(ns, ns > 1 ? sb : -1);
+      for (int s = 0; s < ns; ++s) {
+        units[2 * (ub + s)] = make_int4(t, s * Q, min(cnt, (s + 1) * Q), s);
+        units[2 * (ub + s) + 1] = make_int4(ns, ns > 1 ? sb : -1, 0, 0);
+      }
+      // XCD x starts at the first tile whose cost prefix reaches x/8 of the total
+      for (int x = 1; x < 8; ++x) {
+        const long thr = (cost_total * x + 7) / 8;
+        if (cb < thr && cb + cost >= thr) s_x[x] = ub + ns;
+      }
+    }
+    unit_base += tot_u;
+    slab_base += tot_s;
+    cost_base += tot_c;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int n_units = min(unit_base, max_units);
+    int prev = 0;
+    for (int x = 1; x < 8; ++x) {                    // unset (zero-cost) boundaries inherit; keep monotone
+      int v = s_x[x];
+      if (v < prev) v = prev;
+      if (v > n_units) v = n_units;
+      s_x[x] = v;
+      prev = v;
+    }
+    hdr->n_units = n_units;
+    hdr->xs[0] = 0;
+    for (int x = 1; x < 8; ++x) hdr->xs[x] = s_x[x];
+    hdr->xs[8] = n_units;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The pooling kernel.
+//   c4 = C/4 lanes per lane group, gpw = 64/c4 groups per wave, gpb = 4*gpw groups per workgroup,
+//   BP = gpb*kSub points per round, ldq = tile row pitch in float4 (odd: conflict-free b128 column reads).
+// Per unit (tile, slice [j0, j1) of the tile's flattened point list):
+//   (1) table entries of the 64 voxels -> s_start, exclusive prefix of the lengths -> s_pre; zero the tile;
+//   per round of BP points:
+//   (2) stage: flattened index j -> (voxel slot v by binary search in s_pre, point p) -> depth weight,
+//       feat row, emit code; per sub-chunk the piece table s_meta {head, tail, tail voxel, head voxel};
+//       code: 1 | (v << 2) = last point of a voxel that lies inside this sub-chunk -> store the row;
+//             2 = last point of a HEAD piece (the voxel began in an earlier sub-chunk) -> keep in a register;
+//       a TAIL piece (the voxel goes on in the next sub-chunk) is whatever is left in the accumulator.
+//       head: 0 none / 1 the head voxel ends in this sub-chunk / 2 it runs through;
+//   (3) each lane group walks its kSub points branch-free with 4 + 4 row gathers in flight per lane;
+//   (4) pieces are combined in ascending order through LDS: the owner of a tail adds the heads that follow,
+//       tile[v] += sum (the tile is zero at the start, a voxel that crosses a ROUND border is continued by
+//       the next round's sub-chunk 0 — rounds are separated by barriers, so the order stays ascending);
+//   (5) whole tile: the rows leave in the caller's layout.  Slice of a cut tile: the rows leave as a slab,
+//       then release -> ticket; the last arriver acquires, adds the slabs in slice order and writes the tile.
+// ---------------------------------------------------------------------------------------------
 constexpr int kBatch = 4;
 struct Batch {
   float4 v[kBatch];
   int2 wc[kBatch];
 };
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// feat rows are gathered through a buffer descriptor: a 32-bit byte offset per lane (row offset staged in LDS +
+// 16 * lane-in-group) instead of a 64-bit address multiply-add per load
 __device__ __forceinline__ void load_batch(Batch& q, int l0, const int* s_rf, const int2* s_wc,
-                                           const float4* __restrict__ feat4, int c4, int lg) {
+                                           const __amdgpu_buffer_rsrc_t& feat_rsrc, int lg16) {
 #pragma unroll
-  for (int k = 0; k < kBatch; ++k) q.v[k] = feat4[(long)s_rf[l0 + k] * c4 + lg];
+  for (int k = 0; k < kBatch; ++k) {
+    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, s_rf[l0 + k] + lg16, 0, 0);
+    q.v[k] = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+  }
 #pragma unroll
   for (int k = 0; k < kBatch; ++k) q.wc[k] = s_wc[l0 + k];
 }
 
-// MODE 0: everything from the rank vectors, every call.
-// MODE 1: BUILD a plan — run the rank-only phases (2)-(3c) once and keep their result: per point an
-//         emit code (bit 31 = the point lies in no interval: weight 0), per sub-chunk the piece table;
-//         nothing is pooled.
-// MODE 2: PLANNED — (1') stage depth weights + rf + the plan's codes and piece table, then (4), (5).
-//         For rank vectors that are cached across calls (``accelerate``): the interval search, interval
-//         staging and marking phases (35 % of a workgroup's cycles) are gone and the workgroup needs
-//         half the LDS.
-template <bool STAMP, int kSub, int MODE>
-__global__ __launch_bounds__(kBlock) void bev_pool_fwd_chunked_kernel(
-    unsigned long long* __restrict__ stamps,
-    int c4, int gpw, int n_intervals, int n_points, const int* __restrict__ counts, int compact_rows,
-    const float* __restrict__ depth, const float4* __restrict__ feat4,
-    const int* __restrict__ ranks_depth, const int* __restrict__ ranks_feat,
-    const int* __restrict__ ranks_bev, const int* __restrict__ interval_starts,
-    const int* __restrict__ interval_lengths, float4* __restrict__ dst, float4* __restrict__ part,
-    int4* __restrict__ bmeta, int* __restrict__ row_of_vox, int* __restrict__ plan_codes,
-    int* __restrict__ plan_meta) {
+struct TileArgs {
+  int c4, gpw, ldq;
+  int YX, tpp, Z, layout;        // layout 0: (B,C,Z,Y,X)  1: (B,Z*C,Y,X)  2: rows (n_vox, C)
+  int n_points;
+  const int* counts;             // device [n_points, n_intervals] or null
+  const Header* hdr;
+  const int2* tab;
+  const int4* units;
+  int* arrive;
+  const float* depth;
+  const float4* feat4;
+  const int* ranks_depth;
+  const int* ranks_feat;
+  float* out;
+  float4* slabs;
+  int xcd;
+};
+
+template <bool STAMP, int kTV>
+__global__ __launch_bounds__(kBlock, 4) void bev_pool_tile_kernel(TileArgs a, unsigned long long* __restrict__ stamps) {
   extern __shared__ __attribute__((aligned(16))) int smem[];
   const int tid = threadIdx.x;
+  const int c4 = a.c4, gpw = a.gpw, ldq = a.ldq;
   const int gpb = gpw * (kBlock / kWave);
   const int BP = gpb * kSub;
-  int2* s_wc = reinterpret_cast<int2*>(smem);              // {float bits of depth weight, code}
-  int* s_rf = smem + 2 * BP;
-  int* s_st = s_rf + BP;                                   // MODE 2 keeps none of s_st / s_ln / s_row
-  int* s_ln = s_st + BP + kBlock;
-  int* s_row = s_ln + BP + kBlock;
-  int* s_meta = (MODE == 2) ? (s_rf + BP) : (s_row + BP + kBlock);   // [gpb][4]: head, tail, tail row, tail runs past the block
-  float4* s_part = reinterpret_cast<float4*>(s_meta + 4 * gpb);   // [2*gpb][c4]
+  float4* tile = reinterpret_cast<float4*>(smem);                  // [kTV][ldq]
+  float4* s_part = tile + kTV * ldq;                               // [gpb][c4] head pieces
+  int2* s_wc = reinterpret_cast<int2*>(s_part + gpb * c4);         // [BP] {weight bits, code}
+  int* s_rf = reinterpret_cast<int*>(s_wc + BP);                   // [BP]
+  int* s_meta = s_rf + BP;                                         // [gpb][4]
+  int* s_start = s_meta + 4 * gpb;                                 // [kTV]
+  int* s_pre = s_start + kTV;                                      // [kTV + 1]
+  int* s_flag = s_pre + kTV + 1;
 
-  const int bs = blockIdx.x * BP;             // first point of this block
-  if (counts) {
-    // sizes produced on the device (ocrf_lss_prepare / ocrf_ht_prepare): the launch was sized for
-    // the capacities, workgroups past the real end leave a neutral record for the fix-up and go
-    n_points = counts[0];
-    n_intervals = counts[1];
-    if (bs >= n_points) {
-      if (tid == 0) bmeta[blockIdx.x] = make_int4(0, 0, 0, 0);
-      return;
-    }
-  }
-  const int be = min(bs + BP, n_points);      // one past its last point
-  auto stamp = [&](int slot) {
-    if constexpr (STAMP) {
-      if (tid == 0) stamps[(long)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memtime();
-    }
-  };
-  stamp(0);
-
-  // (1) stage the block's points (coalesced index reads, one depth gather per point).
-  for (int i = tid; i < BP; i += kBlock) {
-    float w = 0.f;
-    int rf = 0, code = 0;
-    if (bs + i < be) {
-      if constexpr (MODE == 1) {
-        w = 1.f;                                   // only "zeroed or not" matters when building
-      } else {
-        w = depth[ranks_depth[bs + i]];
-        rf = ranks_feat[bs + i];
-      }
-      if constexpr (MODE == 2) {
-        code = plan_codes[bs + i];
-        if (code < 0) { w = 0.f; code &= 0x7fffffff; }
-      }
-    }
-    s_wc[i] = make_int2(__float_as_int(w), code);
-    s_rf[i] = rf;
-  }
-  if constexpr (MODE == 2) {
-    if (tid < 4 * gpb) s_meta[tid] = plan_meta[(long)blockIdx.x * 4 * gpb + tid];
-  } else {
-    if (tid < 4 * gpb) s_meta[tid] = 0;
-  }
-  if constexpr (MODE != 2) {
-
-  // (2) cooperative 256-ary search: k_lo = last interval with start <= bs (0 if none).
-  int lo = 0, hi = n_intervals;
-  while (hi - lo > 1) {
-    const int span = hi - lo;
-    const int stride = (span + kBlock - 1) / kBlock;
-    const int idx = lo + tid * stride;
-    const bool ok = (idx < hi) && (interval_starts[idx] <= bs);
-    const int cnt = __syncthreads_count(ok);
-    if (cnt == 0) { hi = lo + 1; break; }
-    const int nlo = lo + (cnt - 1) * stride;
-    hi = min(nlo + stride, hi);
-    lo = nlo;
-  }
-  const int k_lo = lo;
-  stamp(1);
-
-  // (3) stage the intervals that can overlap [bs, be): at most BP+1 of them (lengths >= 1).
-  const int ni_max = min(BP + 1, n_intervals - k_lo);
-  int n_loaded = 0;
-  for (int base = 0; base < ni_max; base += kBlock) {
-    const int t = base + tid;
-    if (t < ni_max) {
-      const int st = interval_starts[k_lo + t];
-      s_st[t] = st;
-      s_ln[t] = interval_lengths[k_lo + t];
-      const int vox = ranks_bev[st];
-      s_row[t] = compact_rows ? (k_lo + t) : vox;
-      // the block in which an interval starts publishes voxel -> row (+1; 0 = empty voxel)
-      if (compact_rows && st >= bs && st < be) row_of_vox[vox] = k_lo + t + 1;
-    }
-    __syncthreads();
-    n_loaded = min(base + kBlock, ni_max);
-    if (s_st[n_loaded - 1] >= be) break;   // uniform: everything after starts past the block
-  }
-  __syncthreads();
-  stamp(2);
-
-  // (3b) mark piece ends, zero the weights of uncovered points, fill the sub-chunk table.
-  const bool exhausted = (k_lo + n_loaded >= n_intervals);
-  for (int t = tid; t < n_loaded; t += kBlock) {
-    const int is = s_st[t];
-    const int ie = is + s_ln[t];
-    if (t == 0) {
-      for (int q = bs; q < min(is, be); ++q) s_wc[q - bs].x = 0;          // before the first interval
-    }
-    const int nis = (t + 1 < n_loaded) ? s_st[t + 1] : (exhausted ? 0x7fffffff : be);
-    for (int q = max(ie, bs); q < min(nis, be); ++q) s_wc[q - bs].x = 0;   // gap after this one
-    const int plo = max(is, bs), phi = min(ie, be);
-    if (plo >= phi) continue;
-    const int g0 = (plo - bs) / kSub, g1 = (phi - 1 - bs) / kSub;
-    for (int g = g0; g <= g1; ++g) {
-      const int sg = bs + g * kSub;
-      const int eg = min(sg + kSub, be);
-      const int pb = min(ie, eg);                  // one past the piece's last point
-      const bool before = is < sg, after = ie > eg;
-      // whole interval -> 1, head piece -> 2; a tail piece is whatever is left in the
-      // accumulator when the sub-chunk ends, so it needs no mark
-      if (!before && !after) s_wc[pb - 1 - bs].y = 1 | (t << 2);
-      else if (before) s_wc[pb - 1 - bs].y = 2;
-      if (before) {
-        s_meta[4 * g + 0] = after ? 2 : 1;
-      } else if (after) {
-        s_meta[4 * g + 1] = 1;
-        s_meta[4 * g + 2] = t;
-      }
-    }
-  }
-  __syncthreads();
-  // (3c) fold the rows into the codes and the piece table, so that (4) and (5) need neither s_row nor
-  // s_st / s_ln (and a plan can stand in for all of (2)-(3c))
-  for (int i = tid; i < BP; i += kBlock) {
-    const int code = s_wc[i].y;
-    if (code & 1) s_wc[i].y = 1 | (s_row[code >> 2] << 2);
-  }
-  for (int g = tid; g < gpb; g += kBlock) {
-    if (s_meta[4 * g + 1]) {
-      const int t = s_meta[4 * g + 2];
-      s_meta[4 * g + 2] = s_row[t];
-      s_meta[4 * g + 3] = (s_st[t] + s_ln[t] > be) ? 1 : 0;
-    }
-  }
-  __syncthreads();
-  if constexpr (MODE == 1) {
-    for (int i = tid; i < BP; i += kBlock)
-      if (bs + i < be) plan_codes[bs + i] = s_wc[i].y | (s_wc[i].x == 0 ? (int)0x80000000 : 0);
-    if (tid < 4 * gpb) plan_meta[(long)blockIdx.x * 4 * gpb + tid] = s_meta[tid];
-    return;
-  }
-  }   // MODE != 2
-  else {
-    __syncthreads();
-  }
-
-  // (4) one lane group per sub-chunk, branch-free accumulate with marked emits.
   const int wave = tid / kWave, lane = tid % kWave;
   const int gi = lane / c4, lg = lane % c4;
   const int gb = wave * gpw + gi;
-  const int s = bs + gb * kSub;
-  const bool active = (gi < gpw) && (s < be);
+  const int n_points = a.counts ? a.counts[0] : a.n_points;
+  // whole 4 GB window from the feat base: row offsets are 32-bit byte offsets (the host checks nothing larger is needed)
+  const __amdgpu_buffer_rsrc_t feat_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.feat4), 0, 0x7fffffff, 0x00020000);
+  const int lg16 = lg * 16;
+  const int row_bytes = c4 * 16;
 
-  if (active) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 head_acc = acc;
-    auto consume = [&](const Batch& q, int l0) {
-#pragma unroll
-      for (int k = 0; k < kBatch; ++k) {
-        const int2 wc = q.wc[k];
-        acc = fma4(q.v[k], __int_as_float(wc.x), acc);
-        const int code = wc.y;
-        // the only memory operation in the loop is this global store: an LDS store here would
-        // make hipcc merge both into one flat store, whose wait drains the gathers in flight
-        if (code & 1) dst[(long)(code >> 2) * c4 + lg] = acc;
-        const bool is_head = code == 2;
-        head_acc.x = is_head ? acc.x : head_acc.x;
-        head_acc.y = is_head ? acc.y : head_acc.y;
-        head_acc.z = is_head ? acc.z : head_acc.z;
-        head_acc.w = is_head ? acc.w : head_acc.w;
-        acc.x = code ? 0.f : acc.x;
-        acc.y = code ? 0.f : acc.y;
-        acc.z = code ? 0.f : acc.z;
-        acc.w = code ? 0.f : acc.w;
+  // units of this workgroup: a strided walk over the unit range of "its" XCD (blocks b and b + 8 share one)
+  int u, u_end, u_step;
+  if (a.xcd) {
+    const int x = blockIdx.x & 7;
+    u = a.hdr->xs[x] + (blockIdx.x >> 3);
+    u_end = a.hdr->xs[x + 1];
+    u_step = gridDim.x >> 3;
+  } else {
+    u = blockIdx.x;
+    u_end = a.hdr->n_units;
+    u_step = gridDim.x;
+  }
+  unsigned long long t_prev = 0, t_acc[6] = {0, 0, 0, 0, 0, 0};
+  auto stamp = [&](int slot) {
+    if constexpr (STAMP) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      if (slot >= 0) t_acc[slot] += t - t_prev;
+      t_prev = t;
+    }
+  };
+
+  for (; u < u_end; u += u_step) {
+    stamp(-1);
+    const int4 unit = a.units[2 * u];
+    const int4 uinfo = a.units[2 * u + 1];           // {slices of the tile, first slab}: no dependent read later
+    const int tileid = unit.x;
+    const int plane = tileid / a.tpp, kt = tileid % a.tpp;
+    const int v0 = kt * kTV;
+    const int nv = min(kTV, a.YX - v0);
+    const long vox0 = (long)plane * a.YX + v0;
+
+    // (1) the tile's voxel table; zero the tile
+    if (tid < kTV) {
+      int2 e = make_int2(0, 0);
+      if (tid < nv) e = a.tab[vox0 + tid];
+      if (e.x < 0 || e.x >= n_points) e = make_int2(0, 0);
+      e.y = max(0, min(e.y, n_points - e.x));
+      s_start[tid] = e.x;
+      int inc = e.y;
+      for (int off = 1; off < kTV; off <<= 1) {
+        const int o = __shfl_up(inc, off);
+        if (tid >= off) inc += o;
       }
-    };
-    Batch A, B;
-    const int l0 = gb * kSub;
-    load_batch(A, l0, s_rf, s_wc, feat4, c4, lg);
-#pragma nounroll      // unrolled, the scheduler hoists every gather to the top: 202 VGPRs, 2 waves per SIMD
-    for (int b = 0; b < kSub / kBatch; b += 2) {
-      load_batch(B, l0 + kBatch * (b + 1), s_rf, s_wc, feat4, c4, lg);
-      consume(A, l0 + kBatch * b);
-      if (b + 2 < kSub / kBatch) load_batch(A, l0 + kBatch * (b + 2), s_rf, s_wc, feat4, c4, lg);
-      consume(B, l0 + kBatch * (b + 1));
+      s_pre[tid + 1] = inc;
+      if (tid == 0) s_pre[0] = 0;
     }
-    s_part[(2 * gb) * c4 + lg] = head_acc;       // head piece (meaningful iff s_meta says so)
-    s_part[(2 * gb + 1) * c4 + lg] = acc;        // tail piece: what the last interval left
-  }
-  stamp(3);
-  __syncthreads();
-  stamp(4);
+    for (int i = tid; i < kTV * ldq; i += kBlock) tile[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const int j0 = unit.y, j1 = min(unit.z, s_pre[kTV]);
+    stamp(0);
 
-  // (5) combine the pieces of intervals cut by sub-chunk borders, in ascending sub-chunk order.
-  if (!active) return;
-  const int n_gb = (be - bs + kSub - 1) / kSub;    // sub-chunks in use in this block
-  const int head = s_meta[4 * gb + 0], tail = s_meta[4 * gb + 1], tail_j = s_meta[4 * gb + 2];
-  if (tail) {
-    float4 acc = s_part[(2 * gb + 1) * c4 + lg];
-    for (int g2 = gb + 1; g2 < n_gb; ++g2) {
-      const int h = s_meta[4 * g2];
-      if (h == 0) break;
-      const float4 v = s_part[(2 * g2) * c4 + lg];
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-      if (h == 1) break;
-    }
-    const int row = tail_j;                          // (3c): the tail interval's row
-    if (s_meta[4 * gb + 3]) {                        // runs past the block: leave a block tail
-      part[(long)(2 * blockIdx.x + 1) * c4 + lg] = acc;
-      if (lg == 0) { bmeta[blockIdx.x].y = 1; bmeta[blockIdx.x].z = row; }
-    } else {
-      dst[(long)row * c4 + lg] = acc;
-    }
-  }
-  if (gb == 0) {
-    int btype = 0;
-    if (head) {
-      float4 acc = s_part[lg];
-      btype = head;
-      if (head == 2) {
-        for (int g2 = 1; g2 < n_gb; ++g2) {
-          const int h = s_meta[4 * g2];
-          if (h == 0) { btype = 1; break; }
-          const float4 v = s_part[(2 * g2) * c4 + lg];
-          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-          if (h == 1) { btype = 1; break; }
+    for (int jr = j0; jr < j1; jr += BP) {
+      const int je = min(jr + BP, j1);
+      // (2) stage the round
+#pragma unroll 1
+      for (int i = tid; i < BP; i += kBlock) {
+        const int j = jr + i;
+        const int g = i / kSub;
+        const int sc0 = jr + g * kSub;
+        const int sc_end = min(sc0 + kSub, je);
+        const int jc = min(j, je - 1);
+        int v = 0;
+#pragma unroll
+        for (int step = kTV / 2; step >= 1; step >>= 1)
+          if (s_pre[v + step] <= jc) v += step;
+        const int pv = s_pre[v], pn = s_pre[v + 1];
+        const int p = s_start[v] + (jc - pv);
+        const int rf = a.ranks_feat[p];
+        float w = 0.f;
+        int code = 0;
+        if (j < je) {
+          w = a.depth[a.ranks_depth[p]];
+          const bool lastv = (j + 1 == pn), end_sc = (j + 1 == sc_end), here = pv >= sc0;
+          if (lastv && here) code = 1 | (v << 2);
+          else if ((lastv || end_sc) && !here) code = 2;
+          if (end_sc) {                                    // last point of its sub-chunk: the tail entry
+            s_meta[4 * g + 1] = (here && pn > sc_end) ? 1 : 0;
+            s_meta[4 * g + 2] = v;
+          }
+        }
+        // padding points repeat the round's last row with weight 0 (no foreign row is touched)
+        s_wc[i] = make_int2(__float_as_int(w), code);
+        s_rf[i] = rf * row_bytes;
+        if (i % kSub == 0) {                               // first point of its sub-chunk: the head entry
+          int head = 0;
+          if (sc0 < je) head = (pv < sc0) ? ((pn > sc_end) ? 2 : 1) : 0;
+          else s_meta[4 * g + 1] = 0;
+          s_meta[4 * g + 0] = head;
+          s_meta[4 * g + 3] = v;
         }
       }
-      part[(long)(2 * blockIdx.x) * c4 + lg] = acc;
-    }
-    if (lg == 0) {
-      bmeta[blockIdx.x].x = btype;
-      // exactly one writer of the tail flag: the owner of an interval running past `be` (above)
-      // or, when there is none, this lane
-      bool open = false;
-      for (int g2 = 0; g2 < n_gb; ++g2) {
-        open = open || (s_meta[4 * g2 + 1] && s_meta[4 * g2 + 3]);
+      __syncthreads();
+      stamp(1);
+
+      // (3) one lane group per sub-chunk
+      const bool active = (gi < gpw) && (jr + gb * kSub < je);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 head_acc = acc;
+      if (active) {
+        auto consume = [&](const Batch& q) {
+#pragma unroll
+          for (int k = 0; k < kBatch; ++k) {
+            const int2 wc = q.wc[k];
+            acc = fma4(q.v[k], __int_as_float(wc.x), acc);
+            const int code = wc.y;
+            // emits are rare (one per voxel and lane group): a skipped branch costs less than the selects
+            if (code) {
+              // ONE kind of store in the loop (LDS) and a register select for the head piece: an `else` here makes
+              // hipcc spill head_acc and merge both sides into a flat_store, whose vmcnt(0) drains the gathers
+              if (code & 1) tile[(code >> 2) * ldq + lg] = acc;
+              const bool is_head = (code & 1) == 0;
+              head_acc.x = is_head ? acc.x : head_acc.x;
+              head_acc.y = is_head ? acc.y : head_acc.y;
+              head_acc.z = is_head ? acc.z : head_acc.z;
+              head_acc.w = is_head ? acc.w : head_acc.w;
+              acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+          }
+        };
+        Batch A, B;
+        const int l0 = gb * kSub;
+        load_batch(A, l0, s_rf, s_wc, feat_rsrc, lg16);
+#pragma nounroll      // unrolled, the scheduler hoists every gather to the top: > 200 VGPRs, 2 waves per SIMD
+        for (int b = 0; b < kSub / kBatch; b += 2) {
+          load_batch(B, l0 + kBatch * (b + 1), s_rf, s_wc, feat_rsrc, lg16);
+          consume(A);
+          if (b + 2 < kSub / kBatch) load_batch(A, l0 + kBatch * (b + 2), s_rf, s_wc, feat_rsrc, lg16);
+          consume(B);
+        }
+        s_part[gb * c4 + lg] = head_acc;             // head piece (meaningful iff s_meta says so)
       }
-      if (!open) bmeta[blockIdx.x].y = 0;
+      __syncthreads();
+      stamp(2);
+
+      // (4) pieces of voxels cut by sub-chunk borders, ascending; a tail piece (what the last voxel of the
+      // sub-chunk left in `acc`) never leaves its owner's registers
+      if (active) {
+        const int n_gb = (je - jr + kSub - 1) / kSub;
+        if (s_meta[4 * gb + 1]) {
+          for (int g2 = gb + 1; g2 < n_gb; ++g2) {
+            const int h = s_meta[4 * g2];
+            if (h == 0) break;
+            acc = add4(acc, s_part[g2 * c4 + lg]);
+            if (h == 1) break;
+          }
+          float4* dst = tile + s_meta[4 * gb + 2] * ldq + lg;
+          *dst = add4(*dst, acc);
+        }
+        if (gb == 0 && s_meta[0]) {
+          if (s_meta[0] == 2) {
+            for (int g2 = 1; g2 < n_gb; ++g2) {
+              const int h = s_meta[4 * g2];
+              if (h == 0) break;
+              head_acc = add4(head_acc, s_part[g2 * c4 + lg]);
+              if (h == 1) break;
+            }
+          }
+          float4* dst = tile + s_meta[3] * ldq + lg;
+          *dst = add4(*dst, head_acc);
+        }
+      }
+      __syncthreads();
+      stamp(3);
     }
-  }
-  stamp(5);
-}
 
-// Pass 2: the block in which an interval cut by block borders starts owns it.
-__global__ __launch_bounds__(kBlock) void bev_pool_fwd_fixup_kernel(
-    int c4, int gpw, int n_blocks, float4* __restrict__ dst, const float4* __restrict__ part,
-    const int4* __restrict__ bmeta) {
-  const int tid = threadIdx.x;
-  const int wave = tid / kWave, lane = tid % kWave;
-  const int gi = lane / c4, lg = lane % c4;
-  if (gi >= gpw) return;
-  const int b = (blockIdx.x * (kBlock / kWave) + wave) * gpw + gi;
-  if (b >= n_blocks) return;
-  const int4 m = bmeta[b];
-  if (!m.y) return;
-  float4 acc = part[(long)(2 * b + 1) * c4 + lg];
-  for (int j = b + 1; j < n_blocks; ++j) {
-    const int h = bmeta[j].x;
-    if (h == 0) break;
-    const float4 v = part[(long)(2 * j) * c4 + lg];
-    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    if (h == 1) break;
-  }
-  dst[(long)m.z * c4 + lg] = acc;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Epilogue of the fused forward: dense channel-major output from the compact row table.
-// One workgroup per tile of kTile consecutive x of one (b, z, y) row: the rows of the non-empty
-// voxels go through LDS ([kTile][C+1] floats) and every channel leaves as one contiguous run of
-// kTile floats, zeros included — the output is written exactly once, never pre-zeroed, and the
-// reference's permute(0,4,1,2,3).contiguous() (bev_pool.py:91) and cat(unbind(2),1)
-// (view_transformer.py:194) passes disappear.
-//   layout 0: out[((b*C + c)*Z + z)*Y*X + y*X + x]      (B,C,Z,Y,X)
-//   layout 1: out[((b*Z + z)*C + c)*Y*X + y*X + x]      (B,Z*C,Y,X)
-// ---------------------------------------------------------------------------------------------
-constexpr int kTile = 64;
-
-__global__ __launch_bounds__(kBlock) void bev_pool_rows_to_nchw_kernel(
-    int c4, int B, int Z, int Y, int X, int tiles_x, int layout, const float4* __restrict__ rows,
-    const int* __restrict__ row_of_vox, float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float s_tile[];
-  const int C = 4 * c4;
-  const int ld = C + 1;
-  int* s_rowid = reinterpret_cast<int*>(s_tile + kTile * ld);
-  const int tid = threadIdx.x;
-  long t = blockIdx.x;
-  const int tx = (int)(t % tiles_x); t /= tiles_x;
-  const int y = (int)(t % Y); t /= Y;
-  const int z = (int)(t % Z);
-  const int b = (int)(t / Z);
-  const int x0 = tx * kTile;
-  const int nx = min(kTile, X - x0);
-  const long vox0 = (((long)b * Z + z) * Y + y) * X + x0;
-  int any = 0;
-  if (tid < kTile) {
-    const int r = (tid < nx) ? row_of_vox[vox0 + tid] : 0;
-    s_rowid[tid] = r;
-    any = r != 0;
-  }
-  const int n_any = __syncthreads_count(any);
-  const long plane = (long)Y * X;
-  const long base0 = (layout == 0) ? ((long)b * C * Z + z) * plane : (((long)b * Z + z) * C) * plane;
-  const long cstride = (layout == 0) ? (long)Z * plane : plane;
-  const long rowoff = (long)y * X + x0;
-  if (n_any == 0) {
-    for (int i = tid; i < C * kTile; i += kBlock) {
-      const int ch = i / kTile, xx = i % kTile;
-      if (xx < nx) out[base0 + ch * cstride + rowoff + xx] = 0.f;
+    // (5) the tile leaves the chip
+    const int2 ti = make_int2(uinfo.x, uinfo.y);
+    bool write_tile = true;
+    if (ti.x > 1) {
+      // the slab leaves WRITE-THROUGH (sc1 stores: the bytes are in memory once the wave's vmcnt drains, no L2
+      // write-back fence needed — cdna_hip_programming.md 'In-launch split-K reduction'), then the ticket
+      float4* slab = a.slabs + (long)(ti.y + unit.w) * kTV * c4;
+      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(slab, 0, kTV * c4 * (int)sizeof(float4), 0x00020000);
+      if (gi < gpw) {
+        for (int v = gb; v < nv; v += gpb) {
+          const float4 x = tile[v * ldq + lg];
+          typedef unsigned u4 __attribute__((ext_vector_type(4)));
+          const u4 bits = {__float_as_uint(x.x), __float_as_uint(x.y), __float_as_uint(x.z), __float_as_uint(x.w)};
+          __builtin_amdgcn_raw_buffer_store_b128(bits, rsrc, (v * c4 + lg) * (int)sizeof(float4), 0, 16);   // aux 16 = sc1
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        const int old = __hip_atomic_fetch_add(&a.arrive[tileid], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_flag = (old == ti.x - 1) ? 1 : 0;
+      }
+      __syncthreads();
+      write_tile = *s_flag != 0;
+      if (write_tile) {
+        if (tid == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          // the ticket counter is back at 0 for the next call (plans keep it across calls)
+          __hip_atomic_store(&a.arrive[tileid], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const float4* s0 = a.slabs + (long)ti.y * kTV * c4;
+        if (gi < gpw) {
+          for (int v = gb; v < nv; v += gpb) {
+            const float4* sp = s0 + v * c4 + lg;
+            float4 acc = *sp;
+            for (int s = 1; s < ti.x; ++s) acc = add4(acc, sp[(long)s * kTV * c4]);
+            tile[v * ldq + lg] = acc;
+          }
+        }
+        __syncthreads();
+      }
     }
-    return;
-  }
-  // gather rows (c4 lanes per row, float4 each) into the padded tile
-  for (int i = tid; i < kTile * c4; i += kBlock) {
-    const int v = i / c4, q = i % c4;
-    const int r = s_rowid[v];
-    const float4 val = r ? rows[(long)(r - 1) * c4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
-    float* d = s_tile + v * ld + 4 * q;
-    d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
-  }
-  __syncthreads();
-  for (int i = tid; i < C * kTile; i += kBlock) {
-    const int ch = i / kTile, xx = i % kTile;
-    if (xx < nx) out[base0 + ch * cstride + rowoff + xx] = s_tile[xx * ld + ch];
+    if (write_tile) {
+      if (a.layout == 2) {
+        float4* o = reinterpret_cast<float4*>(a.out) + vox0 * c4;
+        if (gi < gpw)
+          for (int v = gb; v < nv; v += gpb) o[v * c4 + lg] = tile[v * ldq + lg];
+      } else {
+        const int C = 4 * c4;
+        const long plane_sz = (long)a.YX;
+        const int b = plane / a.Z, z = plane % a.Z;
+        const long base0 = (a.layout == 0) ? (((long)b * C * a.Z + z) * plane_sz) : ((long)plane * C * plane_sz);
+        const long cstride = (a.layout == 0) ? (long)a.Z * plane_sz : plane_sz;
+        // a wave instruction writes 64 / kTV channel runs of kTV floats (256 or 2 x 128 contiguous bytes)
+        constexpr int kRuns = kWave / kTV;
+        const int vl = lane % kTV, sub = lane / kTV;
+        float* o = a.out + base0 + v0 + vl;
+        if (vl < nv) {
+          for (int q = wave * kRuns + sub; q < c4; q += (kBlock / kWave) * kRuns) {
+            const float4 x = tile[vl * ldq + q];
+            float* oc = o + (long)(4 * q) * cstride;
+            oc[0] = x.x;
+            oc[cstride] = x.y;
+            oc[2 * cstride] = x.z;
+            oc[3 * cstride] = x.w;
+          }
+        }
+      }
+    }
+    stamp(4);
+    __syncthreads();            // the next unit reuses the LDS
+    if constexpr (STAMP) {
+      if (tid == 0) {
+        unsigned long long* s = stamps + (long)u * 8;
+        for (int k = 0; k < 5; ++k) s[k] = t_acc[k];
+        s[5] = (unsigned long long)(j1 - j0);
+        for (int k = 0; k < 5; ++k) t_acc[k] = 0;
+      }
+    }
   }
 }
 
@@ -539,6 +638,110 @@ inline bool vec_ok(int c) { return c >= 32 && c <= 256 && (c % 4) == 0; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// ---- host-side geometry of the prep block, the slabs and one launch ------------------------------
+struct PoolGeom {
+  int c4, gpw, gpb, BP, ldq, Q;
+  size_t lds;
+};
+inline PoolGeom pool_geom(int c) {
+  PoolGeom g;
+  g.c4 = c / 4;
+  g.gpw = kWave / g.c4;
+  g.gpb = g.gpw * (kBlock / kWave);
+  g.BP = g.gpb * kSub;
+  g.ldq = g.c4 | 1;                 // odd pitch in float4: b128 column reads are conflict-free
+  g.Q = g_rounds * g.BP;
+  g.lds = (size_t)(g_tv * g.ldq + g.gpb * g.c4) * sizeof(float4) + (size_t)g.BP * (sizeof(int2) + sizeof(int)) +
+          (size_t)(4 * g.gpb + g_tv + g_tv + 1 + 1) * sizeof(int);
+  g.lds = align_up(g.lds, 16);
+  return g;
+}
+inline int max_units_of(const Geometry& vg, const PoolGeom& pg, long n_points) {
+  return (int)(vg.n_tiles + n_points / pg.Q + 8);
+}
+struct PrepLayout {
+  size_t tab_off, cnt_off, arrive_off, tinfo_off, units_off, total;
+  size_t zero_bytes;       // tab + tile_cnt + arrive are contiguous and zeroed together
+  int max_units;
+};
+inline PrepLayout prep_layout(const Geometry& vg, const PoolGeom& pg, long n_points) {
+  PrepLayout L;
+  L.max_units = max_units_of(vg, pg, n_points);
+  L.tab_off = sizeof(Header);
+  L.cnt_off = L.tab_off + align_up((size_t)vg.n_vox * sizeof(int2), 16);
+  L.arrive_off = L.cnt_off + align_up((size_t)vg.n_tiles * sizeof(int), 16);
+  const size_t zero_end = L.arrive_off + align_up((size_t)vg.n_tiles * sizeof(int), 16);
+  L.zero_bytes = zero_end - L.tab_off;
+  L.tinfo_off = zero_end;
+  L.units_off = L.tinfo_off + align_up((size_t)vg.n_tiles * sizeof(int2), 16);
+  L.total = align_up(L.units_off + (size_t)L.max_units * 2 * sizeof(int4), 256);
+  return L;
+}
+// slabs: every slice of a cut tile; cut tiles hold more than Q points each, so at most 2 n_points / Q slices
+inline size_t slab_bytes_of(int c, const PoolGeom& pg, long n_points) {
+  return align_up((size_t)(2 * (n_points / pg.Q) + 2) * kTVmax * c * sizeof(float), 256);
+}
+
+int launch_prep(int c, int n_intervals, int n_points, const int* counts, const Geometry& vg, const int* ranks_bev,
+                const int* interval_starts, const int* interval_lengths, void* prep, hipStream_t stream) {
+  const PoolGeom pg = pool_geom(c);
+  const PrepLayout L = prep_layout(vg, pg, n_points);
+  char* p = static_cast<char*>(prep);
+  Header* hdr = reinterpret_cast<Header*>(p);
+  // header + table + counters in one zero-fill (they are contiguous)
+  hipError_t err = ocrf::zero_async(p, sizeof(Header) + L.zero_bytes, stream);
+  if (err != hipSuccess) return (int)err;
+  if (n_intervals > 0 && n_points > 0) {
+    hipLaunchKernelGGL(bev_pool_table_kernel, dim3((unsigned)((n_intervals + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       stream, n_intervals, n_points, counts, vg.YX, vg.tpp, g_tv, vg.n_vox, ranks_bev, interval_starts,
+                       interval_lengths, reinterpret_cast<int2*>(p + L.tab_off), reinterpret_cast<int*>(p + L.cnt_off));
+    err = hipGetLastError();
+    if (err != hipSuccess) return (int)err;
+  }
+  hipLaunchKernelGGL(bev_pool_units_kernel, dim3(1), dim3(1024), 0, stream, vg.n_tiles, pg.Q, L.max_units,
+                     reinterpret_cast<const int*>(p + L.cnt_off), hdr, reinterpret_cast<int2*>(p + L.tinfo_off),
+                     reinterpret_cast<int4*>(p + L.units_off));
+  return (int)hipGetLastError();
+}
+
+int launch_tiles(int c, int n_points, const int* counts, const Geometry& vg, int Z, int layout, const float* depth,
+                 const float* feat, const int* ranks_depth, const int* ranks_feat, const void* prep, float* out,
+                 void* slabs, hipStream_t stream, unsigned long long* stamps = nullptr) {
+  const PoolGeom pg = pool_geom(c);
+  const PrepLayout L = prep_layout(vg, pg, n_points);
+  const char* p = static_cast<const char*>(prep);
+  TileArgs a;
+  a.c4 = pg.c4; a.gpw = pg.gpw; a.ldq = pg.ldq;
+  a.YX = vg.YX; a.tpp = vg.tpp; a.Z = Z; a.layout = layout;
+  a.n_points = n_points;
+  a.counts = counts;
+  a.hdr = reinterpret_cast<const Header*>(p);
+  a.tab = reinterpret_cast<const int2*>(p + L.tab_off);
+  a.units = reinterpret_cast<const int4*>(p + L.units_off);
+  a.arrive = reinterpret_cast<int*>(const_cast<char*>(p) + L.arrive_off);
+  a.depth = depth;
+  a.feat4 = reinterpret_cast<const float4*>(feat);
+  a.ranks_depth = ranks_depth;
+  a.ranks_feat = ranks_feat;
+  a.out = out;
+  a.slabs = static_cast<float4*>(slabs);
+  a.xcd = g_xcd;
+  // one workgroup per unit of the longest XCD range in the common case; a workgroup walks on (stride grid / 8)
+  // when a range is longer, so any split of the units over the XCDs is covered
+  int per_xcd = (L.max_units + 7) / 8;
+  per_xcd += per_xcd / 4;
+  if (g_grid > 0) per_xcd = min(per_xcd, max(1, g_grid / 8));
+  const unsigned grid = (unsigned)(8 * per_xcd);
+  if (stamps) {
+    auto k = (g_tv == 32) ? bev_pool_tile_kernel<true, 32> : bev_pool_tile_kernel<true, 64>;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), pg.lds, stream, a, stamps);
+  } else {
+    auto k = (g_tv == 32) ? bev_pool_tile_kernel<false, 32> : bev_pool_tile_kernel<false, 64>;
+    ocrf::launch(OCRF_K_BEV_POOL_FWD, k, dim3(grid), dim3(kBlock), pg.lds, stream, a, (unsigned long long*)nullptr);
+  }
+  return (int)hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" {
@@ -554,108 +757,35 @@ void bev_pool_v2(int c, int n_intervals, const float* depth, const float* feat,
                      interval_lengths, out);
 }
 
-namespace {
-struct FwdGeom {
-  int c4, gpw, gpb, BP, n_blocks;
-  size_t lds, part_bytes, total_bytes;
-};
-inline FwdGeom fwd_geom(int c, int n_points) {
-  FwdGeom g;
-  const int kSub = g_sub;
-  g.c4 = c / 4;
-  g.gpw = kWave / g.c4;
-  g.gpb = g.gpw * (kBlock / kWave);
-  g.BP = g.gpb * kSub;
-  g.n_blocks = (n_points + g.BP - 1) / g.BP;
-  g.lds = (size_t)(6 * g.BP + 3 * kBlock + 4 * g.gpb) * sizeof(int) + (size_t)2 * g.gpb * g.c4 * sizeof(float4);
-  g.part_bytes = align_up((size_t)g.n_blocks * 2 * c * sizeof(float), 256);
-  g.total_bytes = g.part_bytes + (size_t)g.n_blocks * sizeof(int4);
-  return g;
-}
-
-// Shared by the scatter (reference contract) and compact-row (NCHW epilogue) forms.
-// mode 0: from the ranks; 1: build `plan_codes` / `plan_meta` (+ row_of_vox) only; 2: pooled from the plan
-int launch_fwd(int c, int n_intervals, int n_points, const int* counts, int compact_rows, const float* depth,
-               const float* feat, const int* ranks_depth, const int* ranks_feat,
-               const int* ranks_bev, const int* interval_starts, const int* interval_lengths,
-               float* dst, void* workspace, int* row_of_vox, hipStream_t stream, int mode = 0,
-               int* plan_codes = nullptr, int* plan_meta = nullptr) {
-  const FwdGeom g = fwd_geom(c, n_points);
-  float4* part = static_cast<float4*>(workspace);
-  int4* bmeta = workspace ? reinterpret_cast<int4*>(static_cast<char*>(workspace) + g.part_bytes) : nullptr;
-  using K = decltype(&bev_pool_fwd_chunked_kernel<false, 32, 0>);
-  K kern;
-  size_t lds = g.lds;
-  if (mode == 1) {
-    kern = (g_sub == 64) ? bev_pool_fwd_chunked_kernel<false, 64, 1> : bev_pool_fwd_chunked_kernel<false, 32, 1>;
-  } else if (mode == 2) {
-    kern = (g_sub == 64) ? bev_pool_fwd_chunked_kernel<false, 64, 2> : bev_pool_fwd_chunked_kernel<false, 32, 2>;
-    lds = (size_t)(3 * g.BP + 4 * g.gpb) * sizeof(int) + (size_t)2 * g.gpb * g.c4 * sizeof(float4);
-  } else {
-    kern = (g_sub == 64) ? bev_pool_fwd_chunked_kernel<false, 64, 0> : bev_pool_fwd_chunked_kernel<false, 32, 0>;
-  }
-  ocrf::launch(OCRF_K_BEV_POOL_FWD, kern, dim3(g.n_blocks),
-               dim3(kBlock), lds, stream, (unsigned long long*)nullptr, g.c4, g.gpw, n_intervals,
-               n_points, counts, compact_rows, depth,
-               reinterpret_cast<const float4*>(feat), ranks_depth, ranks_feat, ranks_bev,
-               interval_starts, interval_lengths, reinterpret_cast<float4*>(dst), part, bmeta,
-               row_of_vox, plan_codes, plan_meta);
-  hipError_t err = hipGetLastError();
-  if (err != hipSuccess) return (int)err;
-  if (mode == 1) return 0;
-  const unsigned grid2 = (unsigned)((g.n_blocks + g.gpb - 1) / g.gpb);
-  ocrf::launch(OCRF_K_BEV_POOL_FIXUP, bev_pool_fwd_fixup_kernel, dim3(grid2), dim3(kBlock), 0, stream,
-               g.c4, g.gpw, g.n_blocks, reinterpret_cast<float4*>(dst),
-               static_cast<const float4*>(part), static_cast<const int4*>(bmeta));
-  return (int)hipGetLastError();
-}
-}  // namespace
-
-// Diagnostic knob (A/B timing of kernel variants in one process): key 0 = points per lane group.
+// Diagnostic knobs (A/B timing of kernel variants in one process): key 0 = rounds per slice (1..64),
+// key 1 = XCD-contiguous unit ranges on / off.  Plans and workspaces are sized for the value in force when
+// they were built: change a knob only between independent runs.
 int ocrf_tune_set(int key, int value) {
-  if (key == 0 && (value == 32 || value == 64)) { g_sub = value; return 0; }
+  if (key == 0 && value >= 1 && value <= 64) { g_rounds = value; return 0; }
+  if (key == 1 && (value == 0 || value == 1)) { g_xcd = value; return 0; }
+  if (key == 2 && value >= 0) { g_grid = value; return 0; }
+  if (key == 3 && (value == 32 || value == 64)) { g_tv = value; return 0; }
   return (int)hipErrorInvalidValue;
 }
 
-// Diagnostic build of pass 1 that records s_memtime at six phase boundaries per workgroup into
-// stamps[n_blocks][8] (never used by the product path; see DESIGN.md "In-kernel stamps").
-int ocrf_diag_bev_pool_v2_stamps(int c, int n_intervals, int n_points, const float* depth,
-                                 const float* feat, const int* ranks_depth, const int* ranks_feat,
-                                 const int* ranks_bev, const int* interval_starts,
-                                 const int* interval_lengths, float* out, void* workspace,
-                                 unsigned long long* stamps, ocrf_stream_t stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (!vec_ok(c) || n_points <= 0) return (int)hipErrorInvalidValue;
-  const FwdGeom g = fwd_geom(c, n_points);
-  float4* part = static_cast<float4*>(workspace);
-  int4* bmeta = reinterpret_cast<int4*>(static_cast<char*>(workspace) + g.part_bytes);
-  auto kern = (g_sub == 64) ? bev_pool_fwd_chunked_kernel<true, 64, 0>
-                             : bev_pool_fwd_chunked_kernel<true, 32, 0>;
-  hipLaunchKernelGGL(kern, dim3(g.n_blocks), dim3(kBlock), g.lds,
-                     stream, stamps, g.c4, g.gpw, n_intervals, n_points, (const int*)nullptr, 0, depth,
-                     reinterpret_cast<const float4*>(feat), ranks_depth, ranks_feat, ranks_bev,
-                     interval_starts, interval_lengths, reinterpret_cast<float4*>(out), part, bmeta,
-                     (int*)nullptr, (int*)nullptr, (int*)nullptr);
-  return (int)hipGetLastError();
+size_t ocrf_bev_pool_v2_workspace_bytes(int c, int n_points, long n_voxels) {
+  if (!vec_ok(c) || n_points < 0 || n_voxels <= 0) return 0;
+  const PoolGeom pg = pool_geom(c);
+  return prep_layout(make_geometry(1, n_voxels), pg, n_points).total + slab_bytes_of(c, pg, n_points);
 }
 
-size_t ocrf_bev_pool_v2_workspace_bytes(int c, int n_points) {
-  if (!vec_ok(c) || n_points <= 0) return 0;
-  return fwd_geom(c, n_points).total_bytes;
-}
-
-int ocrf_bev_pool_v2(int c, int n_intervals, int n_points, const float* depth, const float* feat,
+int ocrf_bev_pool_v2(int c, int n_intervals, int n_points, long n_voxels, const float* depth, const float* feat,
                      const int* ranks_depth, const int* ranks_feat, const int* ranks_bev,
                      const int* interval_starts, const int* interval_lengths, float* out,
                      void* workspace, size_t workspace_bytes, ocrf_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (c <= 0 || n_intervals < 0 || n_points < 0) return (int)hipErrorInvalidValue;
-  if (n_intervals == 0 || n_points == 0) return 0;
-  if (!depth || !feat || !ranks_depth || !ranks_feat || !ranks_bev || !interval_starts ||
-      !interval_lengths || !out)
+  if (c <= 0 || n_intervals < 0 || n_points < 0 || n_voxels <= 0 || !out) return (int)hipErrorInvalidValue;
+  if (n_intervals > 0 && n_points > 0 &&
+      (!depth || !feat || !ranks_depth || !ranks_feat || !ranks_bev || !interval_starts || !interval_lengths))
     return (int)hipErrorInvalidValue;
   if (!vec_ok(c) || !aligned16(feat) || !aligned16(out)) {
-    // scalar mapping of the reference; correct for every C and alignment
+    // scalar mapping of the reference; correct for every C and alignment (out pre-zeroed by the caller)
+    if (n_intervals == 0 || n_points == 0) return 0;
     const long total = (long)n_intervals * c;
     const unsigned grid = (unsigned)((total + kBlock - 1) / kBlock);
     ocrf::launch(OCRF_K_BEV_POOL_INTERVAL, bev_pool_interval_kernel, dim3(grid), dim3(kBlock), 0,
@@ -663,30 +793,23 @@ int ocrf_bev_pool_v2(int c, int n_intervals, int n_points, const float* depth, c
                  interval_starts, interval_lengths, out);
     return (int)hipGetLastError();
   }
-  const size_t need = ocrf_bev_pool_v2_workspace_bytes(c, n_points);
-  if (!workspace || workspace_bytes < need || !aligned16(workspace))
-    return (int)hipErrorInvalidValue;
-  return launch_fwd(c, n_intervals, n_points, nullptr, 0, depth, feat, ranks_depth, ranks_feat, ranks_bev,
-                    interval_starts, interval_lengths, out, workspace, nullptr, stream);
+  if (n_voxels > 0x3fffffffL) return (int)hipErrorInvalidValue;
+  const size_t need = ocrf_bev_pool_v2_workspace_bytes(c, n_points, n_voxels);
+  if (!workspace || workspace_bytes < need || !aligned16(workspace)) return (int)hipErrorInvalidValue;
+  const Geometry vg = make_geometry(1, n_voxels);
+  const PoolGeom pg = pool_geom(c);
+  const size_t prep_bytes = prep_layout(vg, pg, n_points).total;
+  int rc = launch_prep(c, n_intervals, n_points, nullptr, vg, ranks_bev, interval_starts, interval_lengths, workspace,
+                       stream);
+  if (rc != 0) return rc;
+  return launch_tiles(c, n_points, nullptr, vg, 1, 2, depth, feat, ranks_depth, ranks_feat, workspace, out,
+                      static_cast<char*>(workspace) + prep_bytes, stream);
 }
 
-namespace {
-struct NchwGeom {
-  size_t fwd_bytes, rows_off, map_off, total;
-};
-inline NchwGeom nchw_geom(int c, int n_intervals, int n_points, long n_voxels) {
-  NchwGeom g;
-  g.fwd_bytes = n_points > 0 ? align_up(fwd_geom(c, n_points).total_bytes, 256) : 0;
-  g.rows_off = g.fwd_bytes;
-  g.map_off = g.rows_off + align_up((size_t)n_intervals * c * sizeof(float), 256);
-  g.total = g.map_off + align_up((size_t)n_voxels * sizeof(int), 256);
-  return g;
-}
-}  // namespace
-
-size_t ocrf_bev_pool_v2_nchw_workspace_bytes(int c, int n_intervals, int n_points, long n_voxels) {
-  if (!vec_ok(c) || n_intervals < 0 || n_points < 0 || n_voxels <= 0) return 0;
-  return nchw_geom(c, n_intervals, n_points, n_voxels).total;
+size_t ocrf_bev_pool_v2_nchw_workspace_bytes(int c, int n_intervals, int n_points, int B, int Z, int Y, int X) {
+  if (!vec_ok(c) || n_intervals < 0 || n_points < 0 || B <= 0 || Z <= 0 || Y <= 0 || X <= 0) return 0;
+  const PoolGeom pg = pool_geom(c);
+  return prep_layout(make_geometry((long)B * Z, (long)Y * X), pg, n_points).total + slab_bytes_of(c, pg, n_points);
 }
 
 namespace {
@@ -698,33 +821,19 @@ int nchw_impl(int c, int n_intervals, int n_points, const int* counts, const flo
   if (!vec_ok(c) || n_intervals < 0 || n_points < 0 || B <= 0 || Z <= 0 || Y <= 0 || X <= 0 ||
       (layout != 0 && layout != 1) || !out)
     return (int)hipErrorInvalidValue;
-  const long n_vox = (long)B * Z * Y * X;
-  if (n_vox > 0x1fffffffL) return (int)hipErrorInvalidValue;      // row ids travel in 29 bits of the emit codes
-  const NchwGeom g = nchw_geom(c, n_intervals, n_points, n_vox);
-  if (!workspace || workspace_bytes < g.total || !aligned16(workspace) || !aligned16(feat))
+  const Geometry vg = make_geometry((long)B * Z, (long)Y * X);
+  if (vg.n_vox > 0x3fffffffL) return (int)hipErrorInvalidValue;
+  const size_t need = ocrf_bev_pool_v2_nchw_workspace_bytes(c, n_intervals, n_points, B, Z, Y, X);
+  if (!workspace || workspace_bytes < need || !aligned16(workspace) || !aligned16(feat)) return (int)hipErrorInvalidValue;
+  if (n_intervals > 0 && n_points > 0 &&
+      (!depth || !feat || !ranks_depth || !ranks_feat || !ranks_bev || !interval_starts || !interval_lengths))
     return (int)hipErrorInvalidValue;
-  char* ws = static_cast<char*>(workspace);
-  float* rows = reinterpret_cast<float*>(ws + g.rows_off);
-  int* row_of_vox = reinterpret_cast<int*>(ws + g.map_off);
-  hipError_t err = ocrf::zero_async(row_of_vox, (size_t)n_vox * sizeof(int), stream);
-  if (err != hipSuccess) return (int)err;
-  if (n_intervals > 0 && n_points > 0) {
-    if (!depth || !feat || !ranks_depth || !ranks_feat || !ranks_bev || !interval_starts ||
-        !interval_lengths)
-      return (int)hipErrorInvalidValue;
-    const int rc = launch_fwd(c, n_intervals, n_points, counts, 1, depth, feat, ranks_depth, ranks_feat,
-                              ranks_bev, interval_starts, interval_lengths, rows, workspace,
-                              row_of_vox, stream);
-    if (rc != 0) return rc;
-  }
-  const int c4 = c / 4;
-  const int tiles_x = (X + kTile - 1) / kTile;
-  const long n_tiles = (long)B * Z * Y * tiles_x;
-  const size_t lds = (size_t)kTile * (c + 1) * sizeof(float) + kTile * sizeof(int);
-  ocrf::launch(OCRF_K_BEV_POOL_NCHW, bev_pool_rows_to_nchw_kernel, dim3((unsigned)n_tiles),
-               dim3(kBlock), lds, stream, c4, B, Z, Y, X, tiles_x, layout,
-               reinterpret_cast<const float4*>(rows), static_cast<const int*>(row_of_vox), out);
-  return (int)hipGetLastError();
+  const size_t prep_bytes = prep_layout(vg, pool_geom(c), n_points).total;
+  int rc = launch_prep(c, n_intervals, n_points, counts, vg, ranks_bev, interval_starts, interval_lengths, workspace,
+                       stream);
+  if (rc != 0) return rc;
+  return launch_tiles(c, n_points, counts, vg, Z, layout, depth, feat, ranks_depth, ranks_feat, workspace, out,
+                      static_cast<char*>(workspace) + prep_bytes, stream);
 }
 }  // namespace
 
@@ -752,75 +861,62 @@ int ocrf_bev_pool_v2_nchw_dyn(int c, int cap_intervals, int cap_points, const in
 }
 
 // ---------------------------------------------------------------------------------------------
-// Plans: for rank vectors that stay the same across calls (static calibration, ``accelerate``)
+// Plans: for rank vectors that stay the same across calls (static calibration, ``accelerate``) the whole
+// preparation — voxel table, unit list, XCD ranges — is kept; a call is then ONE launch.
 // ---------------------------------------------------------------------------------------------
-namespace {
-struct PlanGeom {
-  size_t codes_off, meta_off, map_off, total;
-};
-inline PlanGeom plan_geom(int c, int n_points, long n_vox) {
-  const FwdGeom f = fwd_geom(c, n_points);
-  PlanGeom g;
-  g.codes_off = 0;
-  g.meta_off = align_up((size_t)f.n_blocks * f.BP * sizeof(int), 256);
-  g.map_off = g.meta_off + align_up((size_t)f.n_blocks * 4 * f.gpb * sizeof(int), 256);
-  g.total = g.map_off + align_up((size_t)n_vox * sizeof(int), 256);
-  return g;
-}
-}  // namespace
-
-size_t ocrf_bev_pool_plan_bytes(int c, int n_points, long n_voxels) {
-  if (!vec_ok(c) || n_points <= 0 || n_voxels <= 0) return 0;
-  return plan_geom(c, n_points, n_voxels).total;
+size_t ocrf_bev_pool_plan_bytes(int c, int n_points, int B, int Z, int Y, int X) {
+  if (!vec_ok(c) || n_points <= 0 || B <= 0 || Z <= 0 || Y <= 0 || X <= 0) return 0;
+  return prep_layout(make_geometry((long)B * Z, (long)Y * X), pool_geom(c), n_points).total;
 }
 
 int ocrf_bev_pool_plan_build(int c, int n_intervals, int n_points, const int* ranks_bev,
-                             const int* interval_starts, const int* interval_lengths, long n_voxels,
+                             const int* interval_starts, const int* interval_lengths, int B, int Z, int Y, int X,
                              void* plan, size_t plan_bytes, ocrf_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (!vec_ok(c) || n_intervals <= 0 || n_points <= 0 || n_voxels <= 0 || n_voxels > 0x1fffffffL || !ranks_bev ||
+  if (!vec_ok(c) || n_intervals <= 0 || n_points <= 0 || B <= 0 || Z <= 0 || Y <= 0 || X <= 0 || !ranks_bev ||
       !interval_starts || !interval_lengths || !plan)
     return (int)hipErrorInvalidValue;
-  const PlanGeom g = plan_geom(c, n_points, n_voxels);
-  if (plan_bytes < g.total || !aligned16(plan)) return (int)hipErrorInvalidValue;
-  char* p = static_cast<char*>(plan);
-  int* row_of_vox = reinterpret_cast<int*>(p + g.map_off);
-  hipError_t err = ocrf::zero_async(row_of_vox, (size_t)n_voxels * sizeof(int), stream);
-  if (err != hipSuccess) return (int)err;
-  return launch_fwd(c, n_intervals, n_points, nullptr, 1, nullptr, nullptr, nullptr, nullptr, ranks_bev, interval_starts,
-                    interval_lengths, nullptr, nullptr, row_of_vox, stream, 1, reinterpret_cast<int*>(p + g.codes_off),
-                    reinterpret_cast<int*>(p + g.meta_off));
+  const Geometry vg = make_geometry((long)B * Z, (long)Y * X);
+  if (vg.n_vox > 0x3fffffffL) return (int)hipErrorInvalidValue;
+  if (plan_bytes < ocrf_bev_pool_plan_bytes(c, n_points, B, Z, Y, X) || !aligned16(plan)) return (int)hipErrorInvalidValue;
+  return launch_prep(c, n_intervals, n_points, nullptr, vg, ranks_bev, interval_starts, interval_lengths, plan, stream);
 }
 
-int ocrf_bev_pool_v2_nchw_planned(int c, int n_intervals, int n_points, const float* depth, const float* feat,
-                                  const int* ranks_depth, const int* ranks_feat, const void* plan, float* out,
+size_t ocrf_bev_pool_planned_workspace_bytes(int c, int n_points) {
+  if (!vec_ok(c) || n_points <= 0) return 0;
+  return slab_bytes_of(c, pool_geom(c), n_points);
+}
+
+int ocrf_bev_pool_v2_nchw_planned(int c, int n_points, const float* depth, const float* feat,
+                                  const int* ranks_depth, const int* ranks_feat, void* plan, float* out,
                                   int B, int Z, int Y, int X, int layout, void* workspace,
                                   size_t workspace_bytes, ocrf_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (!vec_ok(c) || n_intervals <= 0 || n_points <= 0 || B <= 0 || Z <= 0 || Y <= 0 || X <= 0 ||
+  if (!vec_ok(c) || n_points <= 0 || B <= 0 || Z <= 0 || Y <= 0 || X <= 0 ||
       (layout != 0 && layout != 1) || !out || !plan || !depth || !feat || !ranks_depth || !ranks_feat)
     return (int)hipErrorInvalidValue;
-  const long n_vox = (long)B * Z * Y * X;
-  if (n_vox > 0x1fffffffL) return (int)hipErrorInvalidValue;
-  const NchwGeom g = nchw_geom(c, n_intervals, n_points, n_vox);
-  if (!workspace || workspace_bytes < g.total || !aligned16(workspace) || !aligned16(feat) || !aligned16(plan))
+  const Geometry vg = make_geometry((long)B * Z, (long)Y * X);
+  if (vg.n_vox > 0x3fffffffL) return (int)hipErrorInvalidValue;
+  if (!workspace || workspace_bytes < ocrf_bev_pool_planned_workspace_bytes(c, n_points) || !aligned16(workspace) ||
+      !aligned16(feat) || !aligned16(plan))
     return (int)hipErrorInvalidValue;
-  const PlanGeom pg = plan_geom(c, n_points, n_vox);
-  char* ws = static_cast<char*>(workspace);
-  float* rows = reinterpret_cast<float*>(ws + g.rows_off);
-  char* p = const_cast<char*>(static_cast<const char*>(plan));
-  const int rc = launch_fwd(c, n_intervals, n_points, nullptr, 1, depth, feat, ranks_depth, ranks_feat, nullptr, nullptr,
-                            nullptr, rows, workspace, nullptr, stream, 2, reinterpret_cast<int*>(p + pg.codes_off),
-                            reinterpret_cast<int*>(p + pg.meta_off));
-  if (rc != 0) return rc;
-  const int c4 = c / 4;
-  const int tiles_x = (X + kTile - 1) / kTile;
-  const long n_tiles = (long)B * Z * Y * tiles_x;
-  const size_t lds = (size_t)kTile * (c + 1) * sizeof(float) + kTile * sizeof(int);
-  ocrf::launch(OCRF_K_BEV_POOL_NCHW, bev_pool_rows_to_nchw_kernel, dim3((unsigned)n_tiles), dim3(kBlock), lds, stream,
-               c4, B, Z, Y, X, tiles_x, layout, reinterpret_cast<const float4*>(rows),
-               reinterpret_cast<const int*>(p + pg.map_off), out);
-  return (int)hipGetLastError();
+  return launch_tiles(c, n_points, nullptr, vg, Z, layout, depth, feat, ranks_depth, ranks_feat, plan, out, workspace,
+                      stream);
+}
+
+// Diagnostic build of the pooling kernel that accumulates s_memtime per phase and unit into stamps[max_units][8]
+// = {table + zero, staging, gather, combine, write-out, points} (never used by the product path).
+int ocrf_diag_bev_pool_stamps(int c, int n_points, const float* depth, const float* feat, const int* ranks_depth,
+                              const int* ranks_feat, void* plan, float* out, int B, int Z, int Y, int X, int layout,
+                              void* workspace, unsigned long long* stamps, ocrf_stream_t stream_) {
+  if (!vec_ok(c) || n_points <= 0 || !plan || !stamps) return (int)hipErrorInvalidValue;
+  const Geometry vg = make_geometry((long)B * Z, (long)Y * X);
+  return launch_tiles(c, n_points, nullptr, vg, Z, layout, depth, feat, ranks_depth, ranks_feat, plan, out, workspace,
+                      static_cast<hipStream_t>(stream_), stamps);
+}
+int ocrf_bev_pool_max_units(int c, int n_points, int B, int Z, int Y, int X) {
+  if (!vec_ok(c)) return 0;
+  return max_units_of(make_geometry((long)B * Z, (long)Y * X), pool_geom(c), n_points);
 }
 
 int ocrf_bev_pool_v2_check_intervals(int n_intervals, int n_points, const int* interval_starts,

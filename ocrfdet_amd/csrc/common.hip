@@ -16,7 +16,8 @@ struct Timer {
 };
 
 std::mutex g_mu;
-Timer* g_armed = nullptr;
+std::vector<Timer*> g_armed;              // armed timers (a few at most: one per kernel id of interest)
+volatile int g_n_armed = 0;               // fast-path test without the lock
 
 }  // namespace
 
@@ -42,14 +43,16 @@ hipError_t zero_async(void* dst, size_t bytes, hipStream_t stream) {
 }
 
 bool timer_next(int kernel_id, hipEvent_t* start, hipEvent_t* stop) {
-  if (!g_armed) return false;   // fast path: no lock when no timer is armed
+  if (!g_n_armed) return false;   // fast path: no lock when no timer is armed
   std::lock_guard<std::mutex> lk(g_mu);
-  Timer* t = g_armed;
-  if (!t || t->kernel_id != kernel_id || t->used >= (int)t->start.size()) return false;
-  *start = t->start[t->used];
-  *stop = t->stop[t->used];
-  ++t->used;
-  return true;
+  for (Timer* t : g_armed) {
+    if (t->kernel_id != kernel_id || t->used >= (int)t->start.size()) continue;
+    *start = t->start[t->used];
+    *stop = t->stop[t->used];
+    ++t->used;
+    return true;
+  }
+  return false;
 }
 
 }  // namespace ocrf
@@ -65,11 +68,9 @@ int ocrf_diag_stamp(unsigned long long* slot, void* stream) {
 
 const char* ocrf_kernel_name(int kernel_id) {
   switch (kernel_id) {
-    case OCRF_K_BEV_POOL_FWD: return "bev_pool_fwd_chunked_kernel<false>";
-    case OCRF_K_BEV_POOL_FIXUP: return "bev_pool_fwd_fixup_kernel";
+    case OCRF_K_BEV_POOL_FWD: return "bev_pool_tile_kernel<false>";
     case OCRF_K_BEV_POOL_INTERVAL: return "bev_pool_interval_kernel";
     case OCRF_K_BEV_POOL_GRAD: return "bev_pool_grad_vec_kernel";
-    case OCRF_K_BEV_POOL_NCHW: return "bev_pool_rows_to_nchw_kernel";
     case OCRF_K_RASTER_PREPROCESS: return "raster_preprocess_kernel";
     case OCRF_K_RASTER_BLEND: return "raster_blend_kernel<false, false, *>";
     case OCRF_K_RASTER_BLEND_BWD: return "raster_blend_kernel<false, true, true>";
@@ -129,8 +130,16 @@ int ocrf_timer_create(int capacity, void** timer_out) {
 int ocrf_timer_arm(void* timer, int kernel_id) {
   std::lock_guard<std::mutex> lk(g_mu);
   Timer* t = static_cast<Timer*>(timer);
-  if (t) { t->kernel_id = kernel_id; t->used = 0; }
-  g_armed = t;
+  if (!t) {
+    g_armed.clear();
+  } else {
+    t->kernel_id = kernel_id;
+    t->used = 0;
+    bool present = false;
+    for (Timer* q : g_armed) present = present || (q == t);
+    if (!present) g_armed.push_back(t);
+  }
+  g_n_armed = (int)g_armed.size();
   return 0;
 }
 
@@ -157,7 +166,9 @@ int ocrf_timer_destroy(void* timer) {
   if (!t) return 0;
   {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_armed == t) g_armed = nullptr;
+    for (size_t i = 0; i < g_armed.size(); ++i)
+      if (g_armed[i] == t) { g_armed.erase(g_armed.begin() + i); break; }
+    g_n_armed = (int)g_armed.size();
   }
   for (auto e : t->start) (void)hipEventDestroy(e);
   for (auto e : t->stop) (void)hipEventDestroy(e);

@@ -37,11 +37,15 @@ def test_code_object_is_gfx950_only():
 
 def test_workspace_query_is_host_only():
     lib = _lib.lib()
-    assert lib.ocrf_bev_pool_v2_workspace_bytes(80, 0) == 0
-    n = lib.ocrf_bev_pool_v2_workspace_bytes(80, 447232)
-    blocks = (447232 + 383) // 384                  # 12 lane groups x 32 points per workgroup at C=80
-    assert n >= blocks * 2 * 80 * 4 + blocks * 16
-    assert lib.ocrf_bev_pool_v2_workspace_bytes(3, 1000) == 0     # scalar path needs none
+    n_vox = 128 * 128
+    n = lib.ocrf_bev_pool_v2_workspace_bytes(80, 447232, n_vox)
+    tiles = n_vox // 64                             # 64 voxels per tile; 12 lane groups x 32 points per round at C=80
+    # dense voxel table + per-tile counters / info + a unit per tile and per slice of a heavy tile
+    assert n >= n_vox * 8 + tiles * 16 + (tiles + 447232 // 1536) * 16
+    assert lib.ocrf_bev_pool_v2_workspace_bytes(3, 1000, 100) == 0     # scalar path needs none
+    assert lib.ocrf_bev_pool_v2_nchw_workspace_bytes(80, 8774, 447232, 1, 1, 128, 128) >= n - 4096
+    assert lib.ocrf_bev_pool_plan_bytes(80, 447232, 1, 1, 128, 128) > 0
+    assert lib.ocrf_bev_pool_planned_workspace_bytes(80, 447232) > 0
 
 
 def test_ops_refuse_cpu_tensors():
