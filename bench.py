@@ -11,15 +11,15 @@ grid), with `roofline` for the dominant kernel (HIP-event timed inside the timed
 `cpu_baseline` (the C oracle on this box's host cores, rank 0, N=1 only).
 
 N > 1 (`--shard`):
-  samples (default) — every rank owns whole samples (6 cameras x n_frames each), the layout of the
-      reference's own multi-GPU runs (tools/dist_test.sh -> MMDistributedDataParallel, one process
-      per GPU).  The hot path has no exchange step in this layout, so there is no data-path
-      collective; weak scaling.
-  frames  — every rank owns n_frames frames of ONE (world x n_frames)-frame sequence and one RCCL
-      all_gather per step hands every rank the fused BEV of all frames (the operand of the channel
-      concat, detectors/ocrfdet.py:274); weak scaling.
-  cameras — ONE sample, cameras split over min(world, n_cams) ranks (BASELINE.json configs[3]), one
-      RCCL all_reduce(sum) of the partial fused BEV per step, HOA replicated; strong scaling.
+  camera_frames (default) — BASELINE.json north_star: the camera-frames of ONE sample over ALL ranks
+      (ocrfdet_amd.sharding.CameraFramePlan: whole frames per rank while world <= n_frames, else a group of
+      world / n_frames ranks per frame with the frame's cameras dealt over it); partial fused BEVs are summed by
+      a reduce_scatter inside each frame group and ONE world all_gather leaves the fused grid everywhere, both
+      asynchronous beside the renders and HOA-1/2; HOA-3 replicated.  Strong scaling (the sample is fixed).
+      The same line carries `samples_layout`: every rank a whole sample (the reference's DDP layout, no
+      data-path collective), weak scaling, timed right after.
+  samples — only that weak-scaling layout;  frames — one (world x n_frames)-frame sequence, one all_gather;
+  cameras — round 1's layout: cameras over min(world, n_cams) ranks, one dense all_reduce.
 """
 import argparse
 import json
@@ -33,6 +33,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3        # ibid.: peak FP32 (vector) = 256 CU x 4 SIMD-32 x 32 lanes x 2 flop x 2.4 GHz
+N_SIMD, CLOCK_HZ = 256 * 4, 2.4e9
+VALU_CYCLES_PER_INST = 2.0      # ibid.: a wave64 VALU op issues over 2 cycles on a SIMD-32
+BLEND_FLOPS_PER_PIXEL_RECORD = 20.0      # blend flops ~= 20 x sum_tiles len x 256
+PMC_FILE = os.path.join('profiles', 'r2_pmc_mean.csv')     # rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh)
 DEFAULT_CONFIG = 'cfg2_6cam_2frame_bev200x200_render_hoa'
 
 
@@ -44,7 +49,7 @@ def parse():
     ap.add_argument('--config', default=DEFAULT_CONFIG)
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU-baseline sample budget')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--shard', choices=('samples', 'frames', 'cameras'), default='samples')
+    ap.add_argument('--shard', choices=('camera_frames', 'samples', 'frames', 'cameras'), default='camera_frames')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL); gloo only for plumbing tests')
     ap.add_argument('--no-overlap', action='store_true',
                     help='run the renders on the main stream instead of beside the pools + HOA on a side HIP stream')
@@ -56,6 +61,7 @@ def parse():
     ap.add_argument('--host-calibration', action='store_true',
                     help="--scope neck --index-prep per_step: hand the calibration tensors over as HOST tensors (the "
                          "dataloader's copies) — the forward then has no device -> host read-back at all")
+    ap.add_argument('--no-per-step', action='store_true', help='skip the second timed loop with the index preparation inside the step')
     ap.add_argument('--index-prep', choices=('cached', 'per_step'), default='cached',
                     help="'per_step': rank vectors recomputed by the HIP index preparation inside every step "
                          "(the reference with accelerate=False); 'cached': once per calibration (accelerate=True)")
@@ -107,6 +113,8 @@ def cpu_baseline(hp, depth, feat, budget_s):
         t_view = el / n_views_timed
     t_step = t_pools + hp.views_per_step * t_view
     return dict(value=hp.bev_voxels_per_step / t_step, unit='BEV voxels/s', cores=oracle.num_threads(),
+                cores_note='OpenMP threads of the pooling and of the per-Gaussian / per-tile loops; the '
+                           'reference-structured sort of all tile instances inside a view is ONE thread (qsort)',
                 kind='port', ms_per_step=1e3 * t_step, ms_pools=1e3 * t_pools, ms_per_view=1e3 * t_view,
                 views_per_sec=(hp.views_per_step / t_step) if hp.views_per_step else 0.0,
                 sample=f'{n} x (LSS pool + HT pool of the whole step, same inputs and ranks as the GPU)'
@@ -195,6 +203,47 @@ def bench_neck(args, cfg, dev, world, rank):
         dist.destroy_process_group()
 
 
+def pmc_counters(kernel_prefix):
+    """Mean per launch of every counter rocprofv3 collected for one kernel (profiles/r2_pmc_mean.csv, written by
+    tools/collect_profiles.sh from separate --pmc passes of this command with --no-overlap): {counter: mean}."""
+    path = os.path.join(ROOT, PMC_FILE)
+    out = {}
+    if not os.path.exists(path):
+        return out
+    import csv
+    for r in csv.DictReader(open(path)):
+        if r['kernel'].startswith(kernel_prefix) and int(r['launches']) > 4:     # skip the one-off variants
+            out[r['counter']] = float(r['mean'])
+    return out
+
+
+def hbm_traffic(c):
+    """HBM bytes per launch from the PMC passes: FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE counts half of a wide
+    coalesced read stream on gfx950 (MI355X_MICROARCH.md, HBM) — doubled."""
+    if 'FETCH_SIZE' not in c or 'WRITE_SIZE' not in c:
+        return None
+    return (2.0 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024.0
+
+
+def timed(step, steps, world, dev):
+    import torch.distributed as dist
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -217,148 +266,206 @@ def main():
     _lib.lib()                      # raises if libocrf_hip.so is missing — no fallback
     cfg = synthetic.CONFIGS[args.config]
     shard = args.shard if world > 1 else 'none'
-    active = True
     if args.scope == 'neck':
         return bench_neck(args, cfg, dev, world, rank)
+    X, Y, Z = cfg.bev_xyz
+    active = True
+    sp = None
+    if shard == 'camera_frames':
+        sp = hotpath.ShardedHotPath(cfg, dev, rank, world, index_prep_mode=args.index_prep)
+        sp_inputs = sp.make_inputs(seed=0)
     if shard == 'cameras':
-        # strong scaling of ONE sample: rank r < n_cams owns cameras r, r + world', ... (world' active ranks)
+        # round 1's layout: rank r < n_cams owns cameras r, r + world', ... (world' active ranks)
         n_active = min(world, cfg.n_cams)
         active = rank < n_active
         my_cams = list(range(rank, cfg.n_cams, n_active)) if active else [0]
         hp = hotpath.HotPath(cfg, dev, cams=my_cams, index_prep_mode=args.index_prep, overlap=not args.no_overlap)
     else:
+        # whole-sample instance: the N = 1 step, the 'samples' / 'frames' layouts, and every layout's kernel figures
         hp = hotpath.HotPath(cfg, dev, index_prep_mode=args.index_prep, overlap=not args.no_overlap)
-    depth, feat = hp.make_inputs(seed=0 if shard == 'cameras' else rank)
-    X, Y, Z = cfg.bev_xyz
+    depth, feat = hp.make_inputs(seed=0 if shard in ('cameras', 'camera_frames') else rank)
 
-    def step():
-        if shard == 'cameras':
-            # pools (+ render of the owned cameras) -> partial fused BEV -> ONE all_reduce -> HOA everywhere
-            if active:
-                lss, ht = hp.pool_step(depth, feat)
-                fused = torch.cat((lss, ht), 1)
-                if cfg.render:
-                    hp.render()
-            else:
-                fused = torch.zeros(hp.batch, (Z + 1) * cfg.channels, Y, X, device=dev)
-            sharding.reduce_partial_bev(fused)
-            if cfg.hoa:
-                hp.hoa_step(fused[:, Z * cfg.channels:])
-            return fused
+    def step_whole():
         out = hp.step(depth, feat)
         if shard == 'frames':
             fused = torch.cat((out[0], out[-2] if cfg.hoa else out[1]), 1)       # (frames, Z*C + C, Y, X)
             sharding.gather_frames(fused, world * fused.shape[0])
         return out
 
+    def step_cameras():
+        # pools (+ render of the owned cameras) -> partial fused BEV -> ONE all_reduce -> HOA everywhere
+        if active:
+            lss, ht = hp.pool_step(depth, feat)
+            fused = torch.cat((lss, ht), 1)
+            if cfg.render:
+                hp.render()
+        else:
+            fused = torch.zeros(hp.batch, (Z + 1) * cfg.channels, Y, X, device=dev)
+        sharding.reduce_partial_bev(fused)
+        if cfg.hoa:
+            hp.hoa_step(fused[:, Z * cfg.channels:])
+        return fused
+
+    step = {'camera_frames': (lambda: sp.step(sp_inputs)), 'cameras': step_cameras}.get(shard, step_whole)
     for _ in range(args.warmup):
         step()
-    dom_id = _lib.K_RASTER_BLEND if cfg.render else _lib.K_BEV_POOL_FWD
-    timer = _lib.KernelTimer(dom_id, 2 * args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    timer.arm()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    timer.disarm()
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # device duration of the kernels of interest, HIP events on their launch stream inside the timed region
+    t_blend = _lib.KernelTimer(_lib.K_RASTER_BLEND, 2 * args.steps + 8) if cfg.render else None
+    t_pool = _lib.KernelTimer(_lib.K_BEV_POOL_FWD, 2 * (cfg.batch * cfg.n_frames if sp else 1) * args.steps + 8)
+    for t in (t_blend, t_pool):
+        if t is not None:
+            t.arm()
+    elapsed = timed(step, args.steps, world, dev)
+    _lib.KernelTimer.disarm_all()
 
-    # the same kernel alone on the device (renders on the main stream): with the stages overlapped on
-    # several HIP streams the in-region duration above includes the time the kernel shares the CUs
-    iso_ms = None
-    if hp.overlap and cfg.render and shard != 'cameras':
+    strong = shard in ('cameras', 'camera_frames')
+    # ---- the same kernels alone on the device (renders on the main stream) ------------------------------------
+    iso_blend = iso_pool = None
+    if shard in ('none', 'samples', 'frames'):
+        was = hp.overlap
         hp.overlap = False
-        iso = _lib.KernelTimer(dom_id, 64)
+        ib = _lib.KernelTimer(_lib.K_RASTER_BLEND, 64) if cfg.render else None
+        ip = _lib.KernelTimer(_lib.K_BEV_POOL_FWD, 64)
+        for t in (ib, ip):
+            if t is not None:
+                t.arm()
         torch.cuda.synchronize()
-        iso.arm()
         for _ in range(min(16, args.steps)):
-            step()
+            hp.step(depth, feat)
         torch.cuda.synchronize()
-        iso.disarm()
-        v = iso.read_ms()
-        iso_ms = sum(v) / max(len(v), 1)
-        iso.close()
-        hp.overlap = True
+        _lib.KernelTimer.disarm_all()
+        iso_blend = ib.mean_ms() if ib is not None else None
+        iso_pool = ip.mean_ms()
+        for t in (ib, ip):
+            if t is not None:
+                t.close()
+        hp.overlap = was
+    # ---- the step with the index preparation inside (the reference with accelerate=False) ---------------------
+    per_step_ms = None
+    if shard in ('none', 'samples') and args.index_prep == 'cached' and not args.no_per_step:
+        hp2 = hotpath.HotPath(cfg, dev, index_prep_mode='per_step', overlap=not args.no_overlap)
+        n2 = max(5, min(args.steps, 50))
+        for _ in range(3):
+            hp2.step(depth, feat)
+        per_step_ms = 1e3 * timed(lambda: hp2.step(depth, feat), n2, world, dev) / n2
+        del hp2
+    # ---- weak-scaling secondary of the sharded default: every rank a whole sample ---------------------------
+    samples_layout = None
+    if shard == 'camera_frames':
+        d2, f2 = hp.make_inputs(seed=rank)
+        for _ in range(min(args.warmup, 5)):
+            hp.step(d2, f2)
+        e2 = timed(lambda: hp.step(d2, f2), args.steps, world, dev)
+        samples_layout = {'value': hp.bev_voxels_per_step * world * args.steps / e2, 'unit': 'BEV voxels/s',
+                          'rendered_views_per_sec': hp.views_per_step * world * args.steps / e2,
+                          'ms_per_step': 1e3 * e2 / args.steps, 'scaling': 'weak',
+                          'sharding': f'{world} ranks x 1 sample (6 cams x {cfg.n_frames} frames) each, no data-path collective'}
+
     if rank == 0:
-        ms = timer.read_ms()
-        avg_ms = sum(ms) / max(len(ms), 1)
+        blend_ms = t_blend.mean_ms() if t_blend is not None else None
+        pool_ms = t_pool.mean_ms()
+        d_numel, f_numel = depth.numel(), feat.numel()
+        pool_alg = 0.5 * (hp.lss.algorithmic_bytes(d_numel, f_numel) + hp.ht.algorithmic_bytes(d_numel, f_numel))
+        pool_c = pmc_counters('bev_pool_tile_kernel')
+        pools = {'kernel': t_pool.kernel_name, 'bound': 'hbm',
+                 'launches_per_pool': 1, 'avg_launch_us': 1e3 * pool_ms if pool_ms else None,
+                 'launches_timed': t_pool.count(),
+                 'algorithmic_bytes_per_launch': pool_alg,
+                 'algorithmic_bytes_formula': '4*(B*N*D*H*W + B*N*H*W*C + 3*Np + 2*Nv + B*Z*Y*X*C), mean of the LSS and HT pool (SURVEY 8d)',
+                 'achieved': pool_alg / (pool_ms * 1e-3) / 1e9 if pool_ms else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                 'frac': pool_alg / (pool_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pool_ms else None,
+                 'traffic': hbm_traffic(pool_c), 'traffic_source': PMC_FILE if pool_c else None,
+                 'isolated_avg_launch_us': 1e3 * iso_pool if iso_pool else None,
+                 'isolated_frac': pool_alg / (iso_pool * 1e-3) / 1e9 / HBM_PEAK_GBS if iso_pool else None}
+        if sp is not None:
+            pools['note'] = ('camera-sharded pools: each launch pools this rank\'s cameras of one frame into a full-size '
+                             'partial grid; algorithmic bytes are those of the whole-sample pools, for reference only')
         if cfg.render:
-            # SURVEY 8(d) per-view figure for what one blend launch touches: 8 B rect + 8 B record
-            # per visible Gaussian scanned at least once, 44 B payload per blended record is bounded
-            # by the same count, 20 B per pixel written (colour 12, depth 4, T 4) + 4 B n_contrib
-            H, W = cfg.input_size
-            P = hp.voxel_xyz.shape[1] * hp.voxel_xyz.shape[2]
-            alg_bytes = float(len(hp.cams) * (60 * P + 24 * H * W))
-            # the blend is VALU-bound: pixel.record evaluations per launch, counted as the
-            # contributor index each pixel stopped at (a lower bound of what the kernel evaluates)
-            evals = float(hp.render(want_n_contrib=True)[0]['n_contrib'].sum().item())
+            # the blend is VALU-bound: flops = 20 per pixel.record, pixel.records counted as the
+            # contributor index every pixel stopped at (a lower bound of what the kernel evaluates)
+            evals = float(sum(int(o['n_contrib'].sum().item()) for o in hp.render(want_n_contrib=True))) / hp.batch
+            c = pmc_counters('raster_blend_kernel<false, false, true, false>')
+            cycles = blend_ms * 1e-3 * CLOCK_HZ
+            tfl = BLEND_FLOPS_PER_PIXEL_RECORD * evals / (blend_ms * 1e-3) / 1e12
+            traffic = hbm_traffic(c)
+            roofline = {
+                'bound': 'valu', 'kernel': t_blend.kernel_name,
+                'achieved': tfl, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tfl / FP32_PEAK_TFLOPS,
+                'flops_per_pixel_record': BLEND_FLOPS_PER_PIXEL_RECORD, 'pixel_records_per_launch': evals,
+                'avg_launch_us': 1e3 * blend_ms, 'launches_timed': t_blend.count(),
+                'traffic': traffic, 'traffic_source': PMC_FILE if traffic else None,
+                'hbm': ({'bytes_per_launch_pmc': traffic, 'achieved_GBs': traffic / (blend_ms * 1e-3) / 1e9,
+                         'frac_of_peak': traffic / (blend_ms * 1e-3) / 1e9 / HBM_PEAK_GBS} if traffic else None),
+                'isolated': ({'avg_launch_us': 1e3 * iso_blend,
+                              'achieved': BLEND_FLOPS_PER_PIXEL_RECORD * evals / (iso_blend * 1e-3) / 1e12,
+                              'frac': BLEND_FLOPS_PER_PIXEL_RECORD * evals / (iso_blend * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                              'note': 'same kernel, stages not overlapped (after the timed region)'} if iso_blend else None)}
+            if c.get('SQ_INSTS_VALU'):
+                # counters are per launch of the --no-overlap run -> priced against the isolated duration
+                cyc = (iso_blend or blend_ms) * 1e-3 * CLOCK_HZ
+                roofline['valu'] = {
+                    'source': PMC_FILE, 'SQ_INSTS_VALU': c['SQ_INSTS_VALU'], 'SQ_INSTS_SALU': c.get('SQ_INSTS_SALU'),
+                    'SQ_ACTIVE_INST_VALU_quadcycles': c.get('SQ_ACTIVE_INST_VALU'),
+                    'valu_insts_per_pixel_record_pair': c['SQ_INSTS_VALU'] * 64 / (evals / 2) if evals else None,
+                    'issue_frac': c['SQ_INSTS_VALU'] * VALU_CYCLES_PER_INST / (N_SIMD * cyc),
+                    'busy_frac': (4.0 * c['SQ_ACTIVE_INST_VALU'] / (N_SIMD * cyc)) if c.get('SQ_ACTIVE_INST_VALU') else None,
+                    'salu_per_valu': (c['SQ_INSTS_SALU'] / c['SQ_INSTS_VALU']) if c.get('SQ_INSTS_SALU') else None,
+                    'note': 'issue_frac = wave64 VALU instructions x 2 cycles (SIMD-32) / (1024 SIMDs x kernel cycles at '
+                            '2.4 GHz); busy_frac = SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / the same denominator'}
+            del cycles
         else:
-            alg_bytes = 0.5 * (hp.lss.algorithmic_bytes(depth.numel(), feat.numel()) +
-                               hp.ht.algorithmic_bytes(depth.numel(), feat.numel()))
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc
-        # FETCH_SIZE / WRITE_SIZE in separate runs of this same command, gfx950 x2 fetch correction);
-        # bench.py cannot run the profiler on itself, so this is the last committed measurement
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')
-        if args.config == DEFAULT_CONFIG and os.path.exists(pmc):
-            rec = json.load(open(pmc)).get(timer.kernel_name.split('<')[0])
-            if rec:
-                traffic, traffic_src = rec['hbm_bytes_corrected'], 'profiles/r1_pmc_traffic.json'
-        strong = shard == 'cameras'
+            roofline = dict(pools)
         voxels = hp.bev_voxels_per_step * (1 if strong else world) * args.steps
+        views = (cfg.batch * cfg.n_frames * cfg.n_cams if cfg.render else 0) * (1 if strong else world) * args.steps
+        if shard == 'camera_frames':
+            ex = sp.exchange
+            sharding_desc = {
+                'layout': sp.plan.describe(), 'rccl_ranks': world, 'idle_ranks': sp.plan.idle_ranks,
+                'collectives_per_step': (['reduce_scatter(sum) of the partial fused grid inside each frame group']
+                                         if ex.partial else []) + ['all_gather of the finished plane blocks over the world'],
+                'bytes_received_per_rank_reduce_scatter': ex.bytes_reduce_scatter,
+                'bytes_received_per_rank_all_gather': ex.bytes_all_gather,
+                'in_place_all_gather': bool(ex.direct), 'overlap': 'collectives asynchronous beside the renders (side HIP '
+                'stream) and HOA-1/2; HOA-3 gate replicated on the gathered grid'}
+        else:
+            sharding_desc = {'none': 'none',
+                             'samples': f'{world} ranks x 1 sample (6 cams x {cfg.n_frames} frames) each, no data-path collective',
+                             'frames': f'{world} x {cfg.n_frames} frames of one sequence, one RCCL all_gather of the fused BEV per step',
+                             'cameras': f'1 sample, cameras over {min(world, cfg.n_cams)} of {world} ranks, one RCCL all_reduce of the fused BEV per step'}[shard]
         out = {
             'metric': 'BEV voxels/sec + rendered views/sec, 6-cam 256x704',
             'value': voxels / elapsed, 'unit': 'BEV voxels/s',
-            'rendered_views_per_sec': (cfg.batch * cfg.n_frames * cfg.n_cams if cfg.render else 0) *
-                                      (1 if strong else world) * args.steps / elapsed,
+            'rendered_views_per_sec': views / elapsed,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+            'ms_per_step': 1e3 * elapsed / args.steps, 'per_step_ms': per_step_ms, 'higher_is_better': True,
             'scaling': 'strong' if strong else 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': cfg.name, 'cams': cfg.n_cams, 'frames_per_gpu': cfg.n_frames,
                        'bev': list(cfg.bev_xyz), 'channels': cfg.channels, 'depth_bins': cfg.D,
                        'stages': 'lss_pool+ht_pool' + ('+render' if cfg.render else '') + ('+hoa' if cfg.hoa else ''),
-                       'views_per_step': hp.views_per_step, 'render_camera': getattr(hp, 'render_convention', None),
+                       'views_per_step': hp.views_per_step if sp is None else cfg.batch * cfg.n_frames * cfg.n_cams,
+                       'render_camera': getattr(hp, 'render_convention', None),
                        'streams': ('main: pools + HOA; side HIP stream: renders' if hp.overlap and cfg.render
                                    else 'single stream'),
-                       'index_prep': 'cached (accelerate=True semantics)' if args.index_prep == 'cached' else
-                                     'per step, HIP (accelerate=False semantics)',
-                       'sharding': {'none': 'none',
-                                    'samples': f'{world} ranks x 1 sample (6 cams x {cfg.n_frames} frames) each, no data-path collective',
-                                    'frames': f'{world} x {cfg.n_frames} frames of one sequence, one RCCL all_gather of the fused BEV per step',
-                                    'cameras': f'1 sample, cameras over {min(world, cfg.n_cams)} of {world} ranks, one RCCL all_reduce of the fused BEV per step'}[shard]},
-            'roofline': {'bound': 'hbm', 'kernel': timer.kernel_name, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
-                         'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_us': 1e3 * avg_ms,
-                         'launches_timed': len(ms),
-                         'isolated': ({'avg_launch_us': 1e3 * iso_ms, 'achieved': alg_bytes / (iso_ms * 1e-3) / 1e9,
-                                       'frac': alg_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                       'note': 'same kernel, stages not overlapped (after the timed region)'}
-                                      if iso_ms else None)},
+                       'index_prep': 'cached (accelerate=True semantics); per_step_ms = the same step with the HIP index '
+                                     'preparation inside (accelerate=False semantics, the reference\'s working mode)'
+                                     if args.index_prep == 'cached' else 'per step, HIP (accelerate=False semantics)',
+                       'sharding': sharding_desc},
+            'roofline': roofline,
         }
-        if cfg.render and avg_ms > 0:
-            lane_slots = 256 * 4 * 16 * 2.4e9          # CUs x SIMDs x lanes x clock (MI355X_MICROARCH.md)
-            out['roofline']['valu'] = {
-                'pixel_records_per_launch': evals, 'pixel_records_per_sec': evals / (avg_ms * 1e-3),
-                'issue_slots_per_pixel_record': 23.9,    # ISA count of the inner loop, DESIGN 4.3
-                'frac_of_valu_issue_peak': evals * 23.9 / (avg_ms * 1e-3) / lane_slots,
-                'frac_of_valu_issue_peak_isolated': (evals * 23.9 / (iso_ms * 1e-3) / lane_slots) if iso_ms else None}
+        if cfg.render:
+            out['pools'] = pools
+        if samples_layout is not None:
+            out['samples_layout'] = samples_layout
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(hp, depth, feat, args.cpu_seconds)
             out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
         print(json.dumps(out), flush=True)
-    timer.close()
+    for t in (t_blend, t_pool):
+        if t is not None:
+            t.close()
     if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

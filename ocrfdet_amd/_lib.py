@@ -295,10 +295,23 @@ class KernelTimer:
         return lib().ocrf_kernel_name(self.kernel_id).decode()
 
     def arm(self):
+        """Several timers (different kernel ids) may be armed at once."""
         check(lib().ocrf_timer_arm(self._h, self.kernel_id), 'ocrf_timer_arm')
 
     def disarm(self):
         check(lib().ocrf_timer_arm(None, 0), 'ocrf_timer_arm')
+
+    @staticmethod
+    def disarm_all():
+        check(lib().ocrf_timer_arm(None, 0), 'ocrf_timer_arm')
+
+    def mean_ms(self):
+        v = self.read_ms()
+        self._count = len(v)
+        return sum(v) / len(v) if v else None
+
+    def count(self):
+        return getattr(self, '_count', 0)
 
     def read_ms(self):
         buf = (ctypes.c_float * self.capacity)()

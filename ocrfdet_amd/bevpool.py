@@ -283,16 +283,21 @@ class DevicePoolPlan:
 
 
 @torch.no_grad()
-def bev_pool_v2_planned(depth, feat, plan, layout=1):
+def bev_pool_v2_planned(depth, feat, plan, layout=1, out=None):
     """``bev_pool_v2_collapsed`` (layout 1: (B, Z*C, Y, X)) or ``bev_pool_v2`` (layout 0: (B,C,Z,Y,X)) for the
-    rank vectors a ``DevicePoolPlan`` was built from; bit-identical results."""
+    rank vectors a ``DevicePoolPlan`` was built from; bit-identical results.  ``out``: optional contiguous fp32
+    tensor of that many elements to write into (e.g. a slice of a fused multi-frame buffer)."""
     B, Z, Y, X, C = plan.shape
     d32, f32 = depth.float().contiguous(), feat.float().contiguous()
     _lib.require_cuda(d32, f32)
     if f32.size(-1) != C:
         raise _lib.OcrfHipError(f'feat has {f32.size(-1)} channels, the plan was built for {C}')
     dev = d32.device
-    out = torch.empty((B, C, Z, Y, X) if layout == 0 else (B, Z * C, Y, X), dtype=torch.float32, device=dev)
+    shape = (B, C, Z, Y, X) if layout == 0 else (B, Z * C, Y, X)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=dev)
+    elif out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != B * C * Z * Y * X or out.device != dev:
+        raise _lib.OcrfHipError('out must be a contiguous fp32 tensor of B*C*Z*Y*X elements on the inputs\' device')
     L = _lib.lib()
     with _lib.on_device(dev):
         need = L.ocrf_bev_pool_planned_workspace_bytes(C, plan.n_points)

@@ -150,70 +150,73 @@ __device__ __forceinline__ int block_scan_1024(int v, int* s_w, int& total) {
 __global__ __launch_bounds__(1024) void bev_pool_units_kernel(
     int n_tiles, int Q, int max_units, const int* __restrict__ tile_cnt, Header* __restrict__ hdr,
     int2* __restrict__ tinfo, int4* __restrict__ units) {
+  // Unit list: XCD x owns units [xs[x], xs[x+1]) = a contiguous range of tiles (cost-balanced: the tiles of one
+  // BEV region gather the same feat rows and share that XCD's L2); inside a range the slices of cut tiles come
+  // FIRST — they are the longest units, started last they would be the tail of the launch — then the whole
+  // tiles.  The order inside a class is whatever the slot atomics give: results do not depend on it.
   __shared__ int s_w[16];
-  __shared__ int s_x[9];
+  __shared__ int s_split[8], s_whole[8], s_cur_split[8], s_cur_whole[8], s_base[9];
   const int tid = threadIdx.x;
-  // pass 1: total cost
+  auto slices_of = [&](int cnt) { return max(1, (cnt + Q - 1) / Q); };
+  auto cost_of = [&](int cnt, int ns) { return (cnt + ns * kUnitCost + 63) >> 6; };   // in units of 64 points
   long cost_total = 0;
   {
-    int part = 0;                                    // per-thread partial in units of 64 points (no overflow)
+    int part = 0;
     for (int t = tid; t < n_tiles; t += 1024) {
       const int cnt = tile_cnt[t];
-      const int ns = max(1, (cnt + Q - 1) / Q);
-      part += (cnt + ns * kUnitCost + 63) >> 6;
+      part += cost_of(cnt, slices_of(cnt));
     }
     int tot;
     (void)block_scan_1024(part, s_w, tot);
-    cost_total = tot;
+    cost_total = max(tot, 1);
   }
-  if (tid < 9) s_x[tid] = (tid == 0) ? 0 : -1;
+  if (tid < 8) s_split[tid] = s_whole[tid] = s_cur_split[tid] = s_cur_whole[tid] = 0;
   __syncthreads();
-  int unit_base = 0, slab_base = 0;
+  // pass 2: XCD of every tile (by its exclusive cost prefix), units per XCD and class; slab bases
+  int slab_base = 0;
   long cost_base = 0;
   for (int t0 = 0; t0 < n_tiles; t0 += 1024) {
     const int t = t0 + tid;
     const int cnt = (t < n_tiles) ? tile_cnt[t] : 0;
-    int ns = (t < n_tiles) ? max(1, (cnt + Q - 1) / Q) : 0;
-    const int cost = (t < n_tiles) ? ((cnt + ns * kUnitCost + 63) >> 6) : 0;
-    int tot_u, tot_s, tot_c;
-    const int ub = unit_base + block_scan_1024(ns, s_w, tot_u);
+    const int ns = (t < n_tiles) ? slices_of(cnt) : 0;
+    const int cost = (t < n_tiles) ? cost_of(cnt, ns) : 0;
+    int tot_s, tot_c;
     const int sb = slab_base + block_scan_1024(ns > 1 ? ns : 0, s_w, tot_s);
     const long cb = cost_base + block_scan_1024(cost, s_w, tot_c);
     if (t < n_tiles) {
-      if (ub + ns > max_units) {                     // clamp (only inconsistent tile counts get here)
-        ns = max(0, max_units - ub);
-        atomicOr(&hdr->status, 1);
-      }
-      tinfo[t] = make_int2(ns, ns > 1 ? sb : -1);
-      for (int s = 0; s < ns; ++s) {
-        units[2 * (ub + s)] = make_int4(t, s * Q, min(cnt, (s + 1) * Q), s);
-        units[2 * (ub + s) + 1] = make_int4(ns, ns > 1 ? sb : -1, 0, 0);
-      }
-      // XCD x starts at the first tile whose cost prefix reaches x/8 of the total
-      for (int x = 1; x < 8; ++x) {
-        const long thr = (cost_total * x + 7) / 8;
-        if (cb < thr && cb + cost >= thr) s_x[x] = ub + ns;
-      }
+      const int x = (int)min(7L, cb * 8 / cost_total);
+      tinfo[t] = make_int2(ns > 1 ? sb : -1, x);
+      if (ns > 1) atomicAdd(&s_split[x], ns);
+      else atomicAdd(&s_whole[x], 1);
     }
-    unit_base += tot_u;
     slab_base += tot_s;
     cost_base += tot_c;
   }
   __syncthreads();
   if (tid == 0) {
-    const int n_units = min(unit_base, max_units);
-    int prev = 0;
-    for (int x = 1; x < 8; ++x) {                    // unset (zero-cost) boundaries inherit; keep monotone
-      int v = s_x[x];
-      if (v < prev) v = prev;
-      if (v > n_units) v = n_units;
-      s_x[x] = v;
-      prev = v;
+    int b = 0;
+    for (int x = 0; x < 8; ++x) { s_base[x] = b; b += s_split[x] + s_whole[x]; }
+    s_base[8] = b;
+  }
+  __syncthreads();
+  const int n_all = s_base[8];
+  // pass 3: hand out the slots
+  for (int t = tid; t < n_tiles; t += 1024) {
+    const int cnt = tile_cnt[t];
+    const int ns = slices_of(cnt);
+    const int2 ti = tinfo[t];
+    const int x = ti.y;
+    const int slot = (ns > 1) ? s_base[x] + atomicAdd(&s_cur_split[x], ns)
+                              : s_base[x] + s_split[x] + atomicAdd(&s_cur_whole[x], 1);
+    for (int s = 0; s < ns; ++s) {
+      if (slot + s >= max_units) { atomicOr(&hdr->status, 1); break; }   // only inconsistent tile counts get here
+      units[2 * (slot + s)] = make_int4(t, s * Q, min(cnt, (s + 1) * Q), s);
+      units[2 * (slot + s) + 1] = make_int4(ns, ti.x, 0, 0);
     }
-    hdr->n_units = n_units;
-    hdr->xs[0] = 0;
-    for (int x = 1; x < 8; ++x) hdr->xs[x] = s_x[x];
-    hdr->xs[8] = n_units;
+  }
+  if (tid == 0) {
+    hdr->n_units = min(n_all, max_units);
+    for (int x = 0; x <= 8; ++x) hdr->xs[x] = min(s_base[x], max_units);
   }
 }
 

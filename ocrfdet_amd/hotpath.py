@@ -118,16 +118,23 @@ class HotPath:
         self.bev_pos1 = (torch.randn(self.batch, 4, Y, X, generator=g) * 0.1).to(dev)
 
     @torch.no_grad()
-    def hoa_step(self, geom_feat):
-        """HOA-1/2/3 (view_transformer_ocrf.py:1159-1161, 1196-1199): -> (gated BEV, opacity BEV)."""
+    def hoa_opacity_bev(self):
+        """HOA-1/2 (view_transformer_ocrf.py:1159-1161, 1196): opacity BEV (B,1,Y,X).  Independent of the pooled
+        BEV (it reads the Gaussian opacities and the NeRF-branch alpha volume)."""
         cfg = self.cfg
         X, Y, _ = cfg.bev_xyz
         m = self.hoa_mods
         # every frame shares the synthetic opacity volume; the reference loops samples (:1090)
         opac = self.gauss['opacity'].view(1, cfg.num_height, Y, X).expand(self.batch, -1, -1, -1)
         oa = hoa.hoa1(m['dca'], opac.reshape(-1, 1), self.alpha_lidar, cfg.num_height, Y, X)
-        opacity_bev = m['v2b'](oa, self.bev_pos1)
-        _, gated = m['mask'].gate(geom_feat, opacity_bev)
+        return m['v2b'](oa, self.bev_pos1)
+
+    @torch.no_grad()
+    def hoa_step(self, geom_feat, opacity_bev=None):
+        """HOA-1/2/3 (view_transformer_ocrf.py:1159-1161, 1196-1199): -> (gated BEV, opacity BEV)."""
+        if opacity_bev is None:
+            opacity_bev = self.hoa_opacity_bev()
+        _, gated = self.hoa_mods['mask'].gate(geom_feat, opacity_bev)
         return gated, opacity_bev
 
     def _prepare_render(self, r, convention='corrected', seed=0):
@@ -215,16 +222,20 @@ class HotPath:
         feat = feat.permute(0, 1, 3, 4, 2).contiguous()
         return depth.to(self.device), feat.to(self.device)
 
-    def pool(self, plan, depth, feat):
+    def pool(self, plan, depth, feat, out=None):
         """-> (B, Z*C, Y, X): pooled BEV with Z collapsed into channels (view_transformer.py:194).  The
-        rank vectors are cached, so the rank-only half of the pooling is too (bevpool.DevicePoolPlan)."""
+        rank vectors are cached, so the rank-only half of the pooling is too (bevpool.DevicePoolPlan).
+        ``out``: contiguous fp32 tensor to write into (a slice of a fused buffer)."""
         if plan.n_points == 0:
-            return bevpool.bev_pool_v2_collapsed(depth, feat, plan.ranks_depth, plan.ranks_feat,
-                                                 plan.ranks_bev, plan.bev_shape, plan.starts, plan.lengths)
+            res = bevpool.bev_pool_v2_collapsed(depth, feat, plan.ranks_depth, plan.ranks_feat,
+                                                plan.ranks_bev, plan.bev_shape, plan.starts, plan.lengths)
+            if out is not None:
+                out.view_as(res).copy_(res)
+            return res
         if plan.device_plan is None:
             plan.device_plan = bevpool.DevicePoolPlan(plan.ranks_depth, plan.ranks_feat, plan.ranks_bev, plan.bev_shape,
                                                       plan.starts, plan.lengths)
-        return bevpool.bev_pool_v2_planned(depth, feat, plan.device_plan)
+        return bevpool.bev_pool_v2_planned(depth, feat, plan.device_plan, out=out)
 
     def prepare_indices_hip(self, sync=True):
         """Rank vectors of both poolings from the calibration, on the device (view_transformer.py:108-147,
@@ -287,6 +298,83 @@ class HotPath:
     def bev_voxels_per_step(self):
         X, Y, Z = self.cfg.bev_xyz
         return self.batch * Z * Y * X
+
+
+class ShardedHotPath:
+    """The hot path of ONE sample with its camera-frames sharded over the ranks of a ``torch.distributed`` job
+    (``sharding.CameraFramePlan``; BASELINE.json north_star, configs[3] / [4]): this rank pools and renders only
+    the camera-frames it owns, the partial fused BEVs are summed inside each frame's group (reduce_scatter over
+    plane blocks) and ONE world all_gather leaves the complete fused grid ``(n_frames, Z*C + C, Y, X)`` on every
+    rank; HOA runs replicated on it.  The collectives are asynchronous: the renders (side HIP stream) and HOA-1/2
+    (which do not read the pooled BEV) run beside them.  With ``world == 1`` it is ``HotPath`` with the same fused
+    output buffer."""
+
+    def __init__(self, cfg, device, rank, world, index_prep_mode='cached'):
+        from . import sharding
+        self.cfg, self.device, self.rank, self.world = cfg, torch.device(device), rank, world
+        X, Y, Z = cfg.bev_xyz
+        C = cfg.channels
+        self.n_frames = cfg.batch * cfg.n_frames
+        self.planes_lss = Z * C
+        self.plan = sharding.CameraFramePlan(cfg.n_cams, self.n_frames, world, (Z + 1) * C)
+        self.exchange = sharding.BevExchange(self.plan, rank, self.device, (Y, X))
+        one = synthetic.PathConfig(**{**cfg.__dict__, 'batch': 1, 'n_frames': 1, 'hoa': False})
+        self.subs = {f: HotPath(one, self.device, cams=self.plan.cams_of(rank, f), index_prep_mode=index_prep_mode,
+                                overlap=False) for f in self.plan.frames_of(rank)}
+        # HOA (replicated) needs the Gaussian opacities / alpha volume of every frame, not this rank's cameras
+        self.base = HotPath(synthetic.PathConfig(**{**cfg.__dict__, 'render': cfg.render or cfg.hoa}), self.device,
+                            cams=[0], index_prep_mode='cached', overlap=False) if cfg.hoa else None
+        self._side = torch.cuda.Stream(self.device) if self.device.type == 'cuda' and cfg.render else None
+
+    def make_inputs(self, seed=0):
+        """Per owned frame: depth (1, n_owned_cams, D, H, W), feat (1, n_owned_cams, H, W, C) — the same values
+        the unsharded ``HotPath.make_inputs(seed)`` holds for those camera-frames."""
+        cfg = self.cfg
+        full = synthetic.PathConfig(**{**cfg.__dict__, 'batch': self.n_frames})
+        depth, feat = synthetic.depth_and_feat(full, seed)
+        Hf, Wf = cfg.feat_hw
+        depth = depth.view(self.n_frames, cfg.n_cams, cfg.D, Hf, Wf)
+        feat = feat.view(self.n_frames, cfg.n_cams, cfg.channels, Hf, Wf).permute(0, 1, 3, 4, 2)
+        out = {}
+        for f, sub in self.subs.items():
+            out[f] = (depth[f:f + 1, sub.cams].contiguous().to(self.device), feat[f:f + 1, sub.cams].contiguous().to(self.device))
+        return out
+
+    @property
+    def views_per_step(self):
+        return sum(len(s.cams) for s in self.subs.values()) if self.cfg.render else 0
+
+    def step(self, inputs):
+        """-> (fused BEV (n_frames, Z*C + C, Y, X) complete on every rank, rendered list, gated, opacity_bev)."""
+        cfg = self.cfg
+        ex = self.exchange
+        cur = torch.cuda.current_stream(self.device) if self._side is not None else None
+        rendered = []
+        if self._side is not None:
+            self._side.wait_stream(cur)
+            for f, sub in self.subs.items():
+                rendered.append(sub.render([self._side]))
+        for f, sub in self.subs.items():
+            depth, feat = inputs[f]
+            tgt = ex.pool_target(f)
+            sub.pool(sub.lss, depth, feat, out=tgt[:self.planes_lss])
+            sub.pool(sub.ht, depth, feat, out=tgt[self.planes_lss:])
+        works = ex.start()
+        opacity_bev = self.base.hoa_opacity_bev() if self.base is not None else None
+        full = ex.finish(works)
+        gated = None
+        if self.base is not None:
+            # per frame: a frame's HT planes are contiguous inside the fused grid, the batch of them is not
+            gated = [self.base.hoa_step(full[f:f + 1, self.planes_lss:], opacity_bev[f:f + 1])[0]
+                     for f in range(self.n_frames)]
+        if self._side is not None:
+            cur.wait_stream(self._side)
+        return full, rendered, gated, opacity_bev
+
+    @property
+    def bev_voxels_per_step(self):
+        X, Y, Z = self.cfg.bev_xyz
+        return self.n_frames * Z * Y * X
 
 
 class NeckPath:

@@ -25,6 +25,33 @@ def test_unit_assignment_is_a_partition():
     assert sharding.assign_units(6, 1, 6, 'camera') == [[(0, n)] for n in range(6)]     # 1 camera per GPU
 
 
+def test_camera_frame_plan_is_a_partition_over_all_ranks():
+    """BASELINE.json north_star / configs[3]: the camera-frames of one sample over ALL ranks; 12 camera-frames
+    (6 cams x 2 frames) over 8 ranks leave no rank idle."""
+    P = 160
+    for n_cams, n_frames, world in [(6, 2, 1), (6, 2, 2), (6, 2, 4), (6, 2, 8), (6, 8, 8), (6, 1, 6), (6, 16, 8),
+                                    (6, 2, 3), (6, 8, 4), (6, 2, 12), (4, 2, 4)]:
+        plan = sharding.CameraFramePlan(n_cams, n_frames, world, P)
+        flat = sorted(u for r in plan.units for u in r)
+        assert flat == [(f, c) for f in range(n_frames) for c in range(n_cams)], (n_cams, n_frames, world)
+        assert not plan.idle_ranks, (n_cams, n_frames, world)
+        covered = {}
+        for f, p0, n, r in plan.block_owner:
+            assert r in plan.group_of_frame[f]
+            for q in range(p0, p0 + n):
+                covered[(f, q)] = covered.get((f, q), 0) + 1
+        assert len(covered) == n_frames * P and set(covered.values()) == {1}
+        for f, ranks in enumerate(plan.group_of_frame):
+            # exactly the ranks that own a camera of the frame
+            assert sorted(ranks) == sorted({r for r in range(world) if plan.cams_of(r, f)})
+        if world > n_frames and world % n_frames == 0:
+            assert max(len(u) for u in plan.units) - min(len(u) for u in plan.units) <= 1
+    plan = sharding.CameraFramePlan(6, 2, 8, P)
+    assert [len(u) for u in plan.units] == [2, 2, 1, 1, 2, 2, 1, 1]
+    assert plan.group_of_frame == [[0, 1, 2, 3], [4, 5, 6, 7]]
+    assert sharding.CameraFramePlan(6, 1, 8, P).idle_ranks == [6, 7]      # 6 camera-frames cannot feed 8 ranks
+
+
 def _pool_cams(cfg, cams, seed):
     """Partial LSS BEV (C,Y,X) of one frame from a subset of cameras, via the oracle."""
     import oracle
@@ -70,6 +97,54 @@ def _worker(rank, world, port, q):
         raise
     finally:
         dist.destroy_process_group()
+
+
+def _worker_cf(rank, world, port, q, n_frames):
+    """CameraFramePlan + BevExchange on CPU tensors over gloo; per-rank partial pools from the oracle."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), OMP_NUM_THREADS='2')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        n_cams = 4
+        cfg = synthetic.PathConfig(**{**synthetic.CONFIGS['cfg0_1cam_128x352_bev64x64x4'].__dict__, 'n_cams': n_cams,
+                                      'n_frames': n_frames})
+        X, Y, Z = cfg.bev_xyz
+        P = cfg.channels * Z
+        plan = sharding.CameraFramePlan(n_cams, n_frames, world, P)
+        ex = sharding.BevExchange(plan, rank, 'cpu', (Y, X))
+        errs = []
+        for it in range(2):                                        # twice: buffers are reused across steps
+            for f in plan.frames_of(rank):
+                ex.pool_target(f).copy_(torch.from_numpy(_pool_cams(cfg, plan.cams_of(rank, f), seed=f + 10 * it)))
+            full = ex.finish(ex.start())
+            want = [torch.from_numpy(_pool_cams(cfg, list(range(n_cams)), seed=f + 10 * it)) for f in range(n_frames)]
+            errs.append(max(float((full[f] - want[f]).abs().max()) for f in range(n_frames)))
+        q.put((rank, max(errs), tuple(full.shape), plan.describe()))
+    except Exception as e:      # report instead of leaving the parent to time out
+        q.put((rank, repr(e), None, None))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('world,n_frames', [(2, 2), (2, 1), (4, 2)])
+def test_camera_frame_exchange_gloo_matches_single_process(world, n_frames):
+    """world 2 x 2 frames: whole frames per rank, only the world all_gather; world 2 x 1 frame: the frame's
+    cameras split over both ranks (reduce step, then gather); world 4 x 2 frames: two groups of two."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 23000 + (os.getpid() * 7 + world * 13 + n_frames) % 4000
+    procs = [ctx.Process(target=_worker_cf, args=(r, world, port, q, n_frames)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=480) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, err, shape, desc in res:
+        assert not isinstance(err, str), f'rank {rank} failed: {err}'
+        assert err <= 1e-4, f'rank {rank}: sharded fused BEV differs by {err} ({desc})'
+        assert shape[0] == n_frames
 
 
 @pytest.mark.timeout(300)
