@@ -12,7 +12,8 @@ import subprocess
 import torch
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-_SO = os.path.join(_CSRC, "libocrf_hip.so")
+# OCRF_HIP_SO: another build of the same library (A/B of kernel versions in diagnostics); default: the in-tree one
+_SO = os.environ.get("OCRF_HIP_SO") or os.path.join(_CSRC, "libocrf_hip.so")
 _LIB = None
 
 

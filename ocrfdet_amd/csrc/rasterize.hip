@@ -516,8 +516,13 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
   const int nv = starts[(long)v * (kBuckets + 1) + kBuckets];
   const int wave = tid / 64, lane = tid % 64;
 
-  bool doneA = !insideA, doneB = !insideB;
+  bool doneA = !insideA, doneB = !insideB;      // backward only; the forward keeps "stopped" in the sign of T
   f2 T = splat(1.0f);
+  if constexpr (!BWD) {
+    // forward: T < 0 <=> the pixel has stopped (or lies outside the image); |T| is its final transmittance
+    T.x = insideA ? 1.0f : -1.0f;
+    T.y = insideB ? 1.0f : -1.0f;
+  }
   int jA = 0, jB = 0;                                  // wave-uniform: covered records so far
   unsigned lastA = 0, lastB = 0;
   f2 C0 = splat(0.f), C1 = splat(0.f), C2 = splat(0.f);
@@ -565,20 +570,106 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
         const float4 co = conic_o[base + id];
         const Rect rc = rects[base + id];
         const unsigned cov = ((tyA >= rc.y0 && tyA < rc.y1) ? 1u : 0u) | ((tyB >= rc.y0 && tyB < rc.y1) ? 2u : 0u);
-        // forward: the conic's diagonal is staged as -0.5 * c (exact: a power of two commutes with every
-        // rounding of (c dx) dx and of the sum), which removes the -0.5 multiply from the per-record chain
-        const float hs = BWD ? 1.0f : -0.5f;
-        l_a[tid] = make_float4(p.x, p.y, hs * co.x, co.y);
         const float* col = colors + 3 * ((long)(v / vps) * P + id);     // the view's Gaussian set
-        l_b[tid] = make_float4(hs * co.z, co.w, __uint_as_float((unsigned)(c >> 32)), col[0]);
-        l_c[tid] = make_float4(col[1], col[2], __uint_as_float(cov), 0.f);
         if constexpr (BWD) {
+          l_a[tid] = make_float4(p.x, p.y, co.x, co.y);
+          l_b[tid] = make_float4(co.z, co.w, __uint_as_float((unsigned)(c >> 32)), col[0]);
+          l_c[tid] = make_float4(col[1], col[2], __uint_as_float(cov), 0.f);
           l_id[tid] = id;
 #pragma unroll
           for (int k = 0; k < 9; ++k) l_g[tid * 9 + k] = 0.f;
+        } else {
+          // forward: the conic's diagonal is staged as -0.5 * c (exact: a power of two commutes with every
+          // rounding of (c dx) dx and of the sum), which removes the -0.5 multiply from the per-record chain;
+          // a record that does not cover one of the two tiles is staged with opacity 0 FOR THAT TILE: its alpha
+          // is 0 there, below the 1/255 cut, so the pixel loop needs no coverage test at all
+          l_a[tid] = make_float4(p.x, p.y, -0.5f * co.x, co.y);
+          l_b[tid] = make_float4((cov & 1u) ? co.w : 0.f, (cov & 2u) ? co.w : 0.f, -0.5f * co.z, col[0]);
+          l_c[tid] = make_float4(col[1], col[2], __uint_as_float((unsigned)(c >> 32)), __uint_as_float(cov));
         }
+      } else if (!BWD && tid < ((ns + 3) & ~3)) {
+        // pad the batch to a multiple of four records with no-ops (opacity 0): the loop reads 4 per trip
+        l_a[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        l_b[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        l_c[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
       __syncthreads();
+      if constexpr (!BWD) {
+        // Forward: a per-record update with NO mask algebra.  Every decision of forward.cu:320-352 is ONE compare
+        // that feeds ONE select (v_cmp -> v_cndmask), the rest is packed arithmetic on the two pixels:
+        //   * coverage is in the staged per-tile opacities (above);
+        //   * alpha is zeroed where the reference skips the Gaussian (power > 0, alpha < 1/255): then
+        //     test_T = T * 1 = T and the weight alpha * T = 0 exactly — "not valid" needs no predicate;
+        //   * a live pixel has T >= 1e-4 (else it would have stopped), so test_T < 1e-4 alone means "stop"
+        //     (forward.cu:340-344: this Gaussian is not blended); a stopped pixel keeps -|T|: its test_T <= 0
+        //     "stops" again, which changes nothing;
+        //   * median depth: T > 0.5 and test_T < 0.5 can only hold for a blended Gaussian (alpha <= 0.99).
+        // Same arithmetic, same order and therefore the same bits as the mask formulation it replaces
+        // (tools/render_hash.py); 4 records per trip, wave-level early exit.
+        const int ns4 = (ns + 3) & ~3;
+        for (int j0 = 0; j0 < ns4; j0 += 4) {
+          if (__ballot(fmaxf(T.x, T.y) > 0.f) == 0ull) break;
+          float4 ra[4], rb[4], rc4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            ra[u] = l_a[j0 + u];
+            rb[u] = l_b[j0 + u];
+            rc4[u] = l_c[j0 + u];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float4 a = ra[u];
+            const float4 b = rb[u];
+            const float cg = rc4[u].x, cb = rc4[u].y, dep = rc4[u].z;
+            // power = -0.5 (cxx dx dx + czz dy dy) - cxy dx dy, in the reference's order (forward.cu:320-323)
+            const float dx = a.x - pixf_x;
+            const float qx = (a.z * dx) * dx;
+            const float bx = a.w * dx;
+            const f2 dy = splat(a.y) - pixf_y;
+            const f2 qy = (splat(b.z) * dy) * dy;
+            const f2 power = (splat(qx) + qy) - splat(bx) * dy;          // qx, qy carry the -0.5 (staging)
+            const f2 p2 = power * splat(1.44269504088896340736f);       // __expf(x) = v_exp_f32(log2(e) x)
+            f2 G;
+            G.x = __builtin_amdgcn_exp2f(p2.x);
+            G.y = __builtin_amdgcn_exp2f(p2.y);
+            f2 alpha = f2{b.x, b.y} * G;
+            alpha.x = fminf(0.99f, alpha.x);
+            alpha.y = fminf(0.99f, alpha.y);
+            alpha.x = (power.x > 0.0f) ? 0.f : alpha.x;
+            alpha.y = (power.y > 0.0f) ? 0.f : alpha.y;
+            alpha.x = (alpha.x < 1.0f / 255.0f) ? 0.f : alpha.x;
+            alpha.y = (alpha.y < 1.0f / 255.0f) ? 0.f : alpha.y;
+            const f2 test_T = T * (splat(1.0f) - alpha);
+            const f2 aT = alpha * T;
+            const bool stopA = test_T.x < 0.0001f, stopB = test_T.y < 0.0001f;
+            f2 wgt;
+            wgt.x = stopA ? 0.f : aT.x;
+            wgt.y = stopB ? 0.f : aT.y;
+            C0 = fma2(splat(b.w), wgt, C0);
+            C1 = fma2(splat(cg), wgt, C1);
+            C2 = fma2(splat(cb), wgt, C2);
+            if constexpr (MEDIAN) {
+              const float mA = (T.x > 0.5f) ? test_T.x : 1.0f;
+              const float mB = (T.y > 0.5f) ? test_T.y : 1.0f;
+              D.x = (mA < 0.5f) ? dep : D.x;
+              D.y = (mB < 0.5f) ? dep : D.y;
+            } else {
+              D = fma2(splat(dep), wgt, D);
+            }
+            if constexpr (CONTRIB) {
+              const unsigned cov = __builtin_amdgcn_readfirstlane(__float_as_uint(rc4[u].w));
+              jA += (int)(cov & 1u);
+              jB += (int)((cov >> 1) & 1u);
+              lastA = (wgt.x > 0.f) ? (unsigned)jA : lastA;       // alpha T > 0 <=> this Gaussian was blended
+              lastB = (wgt.y > 0.f) ? (unsigned)jB : lastB;
+            }
+            T.x = stopA ? -fabsf(T.x) : test_T.x;
+            T.y = stopB ? -fabsf(T.y) : test_T.y;
+          }
+        }
+        doneA = T.x < 0.f;
+        doneB = T.y < 0.f;
+      } else {
       // Branch-free per-record update so that the LDS reads of the next records can be issued
       // ahead (4 records per trip); a wave leaves the batch as soon as its 128 pixels are done.
       for (int j0 = 0; j0 < ns; j0 += 4) {
@@ -689,34 +780,9 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
             T.y = contribB ? test_T.y : T.y;
             doneA = doneA || (liveA && jA >= n_lastA);
             doneB = doneB || (liveB && jB >= n_lastB);
-            continue;
           }
-          const bool stopA = validA && (test_T.x < 0.0001f), stopB = validB && (test_T.y < 0.0001f);
-          const bool contribA = validA != stopA, contribB = validB != stopB;     // stop implies valid
-          f2 wgt;
-          wgt.x = contribA ? aT.x : 0.f;
-          wgt.y = contribB ? aT.y : 0.f;
-          C0 = fma2(splat(b.w), wgt, C0);
-          C1 = fma2(splat(cg), wgt, C1);
-          C2 = fma2(splat(cb), wgt, C2);
-          if constexpr (MEDIAN) {
-            // '&' on purpose: no short-circuit regions, two compares + scalar mask ops per pixel
-            const bool medA = contribA & (T.x > 0.5f) & (test_T.x < 0.5f);
-            const bool medB = contribB & (T.y > 0.5f) & (test_T.y < 0.5f);
-            D.x = medA ? b.z : D.x;
-            D.y = medB ? b.z : D.y;
-          } else {
-            D = fma2(splat(b.z), wgt, D);
-          }
-          T.x = contribA ? test_T.x : T.x;
-          T.y = contribB ? test_T.y : T.y;
-          if constexpr (CONTRIB) {
-            lastA = contribA ? (unsigned)jA : lastA;
-            lastB = contribB ? (unsigned)jB : lastB;
-          }
-          doneA = doneA || stopA;
-          doneB = doneB || stopB;
         }
+      }
       }
       // every pixel saturated -> stop (forward.cu:304-307)
       all_done = __syncthreads_count(doneA && doneB) == kBlock;
@@ -927,8 +993,8 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
       out_color[(v * 3 + 2) * npix + pix] = c2 + t * bg[2];
       out_depth[v * npix + pix] = d;
     };
-    store(insideA, pyA, T.x, lastA, C0.x, C1.x, C2.x, D.x);
-    store(insideB, pyB, T.y, lastB, C0.y, C1.y, C2.y, D.y);
+    store(insideA, pyA, fabsf(T.x), lastA, C0.x, C1.x, C2.x, D.x);
+    store(insideB, pyB, fabsf(T.y), lastB, C0.y, C1.y, C2.y, D.y);
   }
 }
 

@@ -195,12 +195,30 @@ class BevExchange:
         else:
             self.send = torch.zeros(self.slot, self.Y, self.X, **kw)
             self.recv = torch.empty(W * self.slot, self.Y, self.X, **kw)
+        if self.direct and self.active and not self._in_place_gather_works():
+            self.direct = False                  # staged gather: one extra copy of the grid, always valid
+            self.send = torch.zeros(self.slot, self.Y, self.X, **kw)
+            self.recv = torch.empty(W * self.slot, self.Y, self.X, **kw)
         self.partial = {f: torch.empty(P, self.Y, self.X, **kw) for f in plan.frames_of(rank)
                         if len(plan.group_of_frame[f]) > 1}
         esz = self.full.element_size()
         self.bytes_reduce_scatter = sum((len(plan.group_of_frame[f]) - 1) * (P // len(plan.group_of_frame[f])) *
                                         self.Y * self.X * esz for f in self.partial)
         self.bytes_all_gather = (W - 1) * self.slot * self.Y * self.X * esz if W > 1 else 0
+
+    def _in_place_gather_works(self):
+        """One trial of the in-place all_gather (send block = this rank's slice of the receive buffer, the form NCCL /
+        RCCL document as in-place) with known values, at construction; every rank reaches the same verdict."""
+        try:
+            self.send.fill_(float(self.rank + 1))
+            dist.all_gather_into_tensor(self.recv, self.send)
+            got = self.recv.view(self.plan.world, -1)[:, 0].float().cpu()
+            ok = bool(torch.equal(got, torch.arange(1, self.plan.world + 1, dtype=torch.float32)))
+        except Exception:
+            ok = False
+        flag = torch.tensor([1 if ok else 0], device=self.device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
 
     def _send_block(self, f):
         off = 0

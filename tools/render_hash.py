@@ -11,7 +11,9 @@ from ocrfdet_amd import hotpath, synthetic  # noqa: E402
 
 cfg = synthetic.CONFIGS['cfg2_6cam_2frame_bev200x200_render_hoa']
 hp = hotpath.HotPath(cfg, torch.device('cuda:0'))
-out = hp.render(want_n_contrib=True)[0]
-torch.cuda.synchronize()
-for k in ('color', 'depth', 'final_T', 'n_contrib', 'radii'):
-    print(k, hashlib.sha1(out[k].cpu().numpy().tobytes()).hexdigest())
+for want in (True, False):              # the training-forward variant (tracks n_contrib) and the inference variant
+    out = hp.render(want_n_contrib=want)[0]
+    torch.cuda.synchronize()
+    for k in ('color', 'depth', 'final_T', 'n_contrib', 'radii'):
+        if k in out and out[k] is not None:
+            print('n_contrib' if want else 'inference', k, hashlib.sha1(out[k].cpu().numpy().tobytes()).hexdigest())
