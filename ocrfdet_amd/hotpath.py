@@ -67,34 +67,34 @@ class HotPath:
         g = {k: torch.from_numpy(r[k][:, sel] if r[k].ndim >= 3 and k != 'bda' else r[k]).to(dev)
              for k in ('rots', 'trans', 'intrins', 'post_rots', 'post_trans', 'bda', 'c2w')}
         self.geom = g
-        args = [g[k] for k in ('rots', 'trans', 'intrins', 'post_rots', 'post_trans', 'bda')]
         X, Y, Z = cfg.bev_xyz
         Hf, Wf = cfg.feat_hw
         C = cfg.channels
-        # LSS branch (view_transformer.py:108-147,197-255)
+        # Rank vectors of both branches from the HIP index preparation (csrc/index_prep.hip), which is pinned
+        # bit-exactly to the reference's vectors at every configuration (tests/test_index_prep_gpu.py).  The same
+        # formulas as torch ops ON THE GPU are not: torch's elementwise GPU kernels contract multiply-adds, and at
+        # 512x1408 three pillar samples land on the other side of a .round() (view_transformer_ocrf.py:810).
+        # The tiny per-camera 3x3 algebra runs on the host, as the same torch calls the reference makes.
+        self._calib_host = [torch.from_numpy(r[k][:, sel] if k != 'bda' else r[k]) for k in
+                            ('rots', 'trans', 'intrins', 'post_rots', 'post_trans', 'bda')]
         frustum = index_prep.create_frustum(cfg.grid['depth'], cfg.input_size, cfg.downsample)
-        coor = index_prep.get_lidar_coor(frustum, *args)
-        lower, interval, size = index_prep.grid_infos(cfg.grid)
-        self.lss = PoolPlan(*self._or_empty(index_prep.voxel_pooling_prepare_v2(coor, lower, interval, size)),
-                            (self.batch, Z, Y, X, C))
-        del coor
-        # HT branch (view_transformer_ocrf.py:651-852)
-        lidar2img, img_aug, _, _ = index_prep.get_projection(*args)
-        ref = index_prep.get_reference_points_3d(Y, X, bs=self.batch, num_points_in_pillar=cfg.num_height,
-                                                 device=dev)
-        coor, mask, _ = index_prep.get_sampling_point(ref, list(cfg.pc_range), cfg.grid['depth'],
-                                                      lidar2img, img_aug, cfg.input_size)
-        self.voxel_xyz = ref                                    # metric voxel centres (B, Zh, Y*X, 3)
-        self.ht = PoolPlan(*self._or_empty(index_prep.fast_sample_prepare(coor, mask, Wf, Hf, cfg.D)),
-                           (self.batch, 1, Y, X, C))
-        # inputs of the per-step HIP preparation: init-time templates on the device, calibration on
-        # the host (its 3x3 algebra is a handful of tiny torch calls per step, like the reference's)
-        self._calib_host = [a.cpu() for a in args]
         self._frustum_dev = frustum.to(dev).contiguous()
         self._ref_template = index_prep.get_reference_points_3d(Y, X, bs=1, num_points_in_pillar=cfg.num_height,
                                                                 device='cpu')[0].to(dev).contiguous()
-        self._grid = (lower, interval, size)
+        self._grid = index_prep.grid_infos(cfg.grid)
         self._lss_bufs, self._ht_bufs = index_prep._RankBuffers(), index_prep._RankBuffers()
+        self.lss, self.ht = self.prepare_indices_hip(sync=True)
+        # cached plans must not alias the grow-only buffers the per-step preparation writes into
+        for plan in (self.lss, self.ht):
+            for name in ('ranks_bev', 'ranks_depth', 'ranks_feat', 'starts', 'lengths'):
+                setattr(plan, name, getattr(plan, name).clone())
+        # metric voxel centres (B, Zh, Y*X, 3): the Gaussian means of the render (ocrf_ht_project, bit-exact vs the
+        # oracle of get_sampling_point's in-place scaling, view_transformer_ocrf.py:690-692)
+        lidar2img, img_aug, _, _ = index_prep.get_projection(*self._calib_host)
+        ht_block = index_prep.ht_camera_block(lidar2img, img_aug).to(dev)
+        _, _, voxel = index_prep.ht_project_hip(self._ref_template, ht_block, self.batch, len(sel), list(cfg.pc_range),
+                                                cfg.input_size, cfg.grid['depth'])
+        self.voxel_xyz = voxel
 
         if cfg.render:
             self._prepare_render(r)

@@ -406,8 +406,16 @@ def main():
 
     save('lss_cfg0.npz', lss_golden(cfgs['cfg0_1cam_128x352_bev64x64x4'], full=True))
     save('ht_cfg0.npz', ht_golden(cfgs['cfg0_1cam_128x352_bev64x64x4'], full=True))
-    for key in ('ref_6cam_256x704_bev128x128x1', 'cfg1_6cam_256x704_bev128x128x8',
-                'cfg2_6cam_2frame_bev200x200_render_hoa'):
+    keys = ('ref_6cam_256x704_bev128x128x1', 'cfg1_6cam_256x704_bev128x128x8',
+            'cfg2_6cam_2frame_bev200x200_render_hoa', 'cfg4_6cam_8frame_512x1408_bev200x200')
+    if len(sys.argv) > 1:                   # python make_golden.py cfg4 ...: only the rank fixtures of these configs
+        for key in keys:
+            tag = key.split('_')[0]
+            if tag in sys.argv[1:]:
+                save(f'lss_{tag}.npz', lss_golden(cfgs[key], full=False))
+                save(f'ht_{tag}.npz', ht_golden(cfgs[key], full=False))
+        return
+    for key in keys:
         tag = key.split('_')[0]
         save(f'lss_{tag}.npz', lss_golden(cfgs[key], full=False))
         save(f'ht_{tag}.npz', ht_golden(cfgs[key], full=False))

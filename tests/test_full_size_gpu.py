@@ -1,0 +1,94 @@
+"""GPU: the full-size configurations of BASELINE.json that the small parity tests do not reach —
+configs[2] (6 cams 256x704, 200x200 BEV: 520 000 Gaussians) under BOTH render-camera conventions (the
+reference's own set-up, view_transformer_ocrf.py:1135-1152, and the corrected one the bench times) and
+configs[4] (512x1408 input: 32x88 feature map, 88x32 tile grid, 8 frames) — against the C oracle where it
+finishes in seconds, through size-independent properties elsewhere."""
+import numpy as np
+import pytest
+import torch
+
+from ocrfdet_amd import hotpath, synthetic
+from tests import helpers
+from tests.test_rasterize_gpu import _compare
+
+pytestmark = pytest.mark.gpu
+CFG2 = 'cfg2_6cam_2frame_bev200x200_render_hoa'
+CFG4 = 'cfg4_6cam_8frame_512x1408_bev200x200'
+
+
+def _one_frame(key):
+    return synthetic.PathConfig(**{**synthetic.CONFIGS[key].__dict__, 'n_frames': 1, 'hoa': False})
+
+
+def _render_vs_oracle(hp, oracle_lib, views, max_outlier_frac=2e-4):
+    g, rc = hp.gauss, hp.render_cams
+    H, W = hp.cfg.input_size
+    xyz = hp.voxel_xyz[0].reshape(-1, 3)
+    got = hp.render(want_n_contrib=True)[0]
+    torch.cuda.synchronize()
+    assert int(got['status'].item()) & 1 == 0
+    rendered = []
+    for v in views:
+        want = oracle_lib.rasterize_forward(xyz.cpu().numpy(), g['rgb'].cpu().numpy(), g['opacity'].cpu().numpy(),
+                                            g['scales'].cpu().numpy(), g['rotations'].cpu().numpy(),
+                                            rc['vm'][v].cpu().numpy(), rc['pm'][v].cpu().numpy(), rc['tfx'][v], rc['tfy'][v],
+                                            H, W, np.zeros(3, np.float32))
+        one = {k: got[k][v:v + 1].cpu().numpy() for k in ('color', 'depth', 'final_T', 'n_contrib', 'radii')}
+        one['tiles_touched'] = want['tiles_touched'][None]        # not returned by the batched call: radii pin the rects
+        _compare(want, one, H, W, max_outlier_frac)
+        rendered.append(want['num_rendered'])
+    return rendered
+
+
+@pytest.mark.parametrize('convention', ['reference', 'corrected'])
+def test_cfg2_render_both_camera_conventions(cuda, oracle_lib, convention):
+    hp = hotpath.HotPath(_one_frame(CFG2), cuda)
+    r = synthetic.rig(hp.cfg.n_cams, hp.cfg.input_size, hp.batch)
+    hp._prepare_render(r, convention=convention)
+    n = _render_vs_oracle(hp, oracle_lib, views=(1, 4))
+    # the reference's unscaled intrinsics give a narrow field of view: few tile instances; corrected: millions
+    assert (max(n) < 3_000_000) if convention == 'reference' else (min(n) > 1_000_000)
+
+
+def test_cfg4_rank_triples_pools_and_render_at_512x1408(cuda, oracle_lib):
+    cfg = _one_frame(CFG4)
+    assert cfg.feat_hw == (32, 88)
+    hp = hotpath.HotPath(cfg, cuda)
+    depth, feat = hp.make_inputs(seed=2)
+    lss, ht, rendered = hp.step(depth, feat)[:3]
+    torch.cuda.synchronize()
+    X, Y, Z = cfg.bev_xyz
+    # pools against the C oracle (LSS: 2 M points)
+    d, f = depth.cpu().numpy(), feat.cpu().numpy()
+    for name, plan, got in (('lss', hp.lss, lss), ('ht', hp.ht, ht)):
+        want = oracle_lib.bev_pool_v2(d, f, plan.ranks_depth.cpu().numpy(), plan.ranks_feat.cpu().numpy(),
+                                      plan.ranks_bev.cpu().numpy(), plan.bev_shape, plan.starts.cpu().numpy(),
+                                      plan.lengths.cpu().numpy())
+        want = np.concatenate([want[:, :, z] for z in range(want.shape[2])], 1)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4, err_msg=name)
+    # the per-step HIP index preparation at this shape gives the same pooled BEVs bit for bit
+    hp2 = hotpath.HotPath(synthetic.PathConfig(**{**cfg.__dict__, 'render': False}), cuda, index_prep_mode='per_step')
+    lss2, ht2 = hp2.step(depth, feat)[:2]
+    assert torch.equal(lss2, lss) and torch.equal(ht2, ht)
+    # render: 88 x 32 tiles, one view against the oracle
+    H, W = cfg.input_size
+    assert rendered[0]['color'].shape == (6, 3, H, W)
+    _render_vs_oracle(hp, oracle_lib, views=(0,))
+
+
+def test_cfg4_eight_frames_step_properties(cuda):
+    """The whole configs[4] step (8 frames x 6 cams, 48 rendered views): finite, frames agree with a one-frame
+    run (frames ride along as batch entries; the synthetic rig is the same for every frame)."""
+    cfg = synthetic.PathConfig(**{**synthetic.CONFIGS[CFG4].__dict__, 'hoa': False})
+    hp = hotpath.HotPath(cfg, cuda)
+    depth, feat = hp.make_inputs(seed=4)
+    lss, ht, rendered = hp.step(depth, feat)[:3]
+    torch.cuda.synchronize()
+    assert lss.shape[0] == 8 and len(rendered) == 8
+    assert torch.isfinite(lss).all() and torch.isfinite(ht).all()
+    one = hotpath.HotPath(_one_frame(CFG4), cuda)
+    l1, h1 = one.step(depth[3:4].contiguous(), feat[3:4].contiguous())[:2]
+    assert torch.equal(l1[0], lss[3]) and torch.equal(h1[0], ht[3])
+    for o in rendered:
+        assert torch.isfinite(o['color']).all() and float(o['final_T'].min()) >= 0.0
+        assert torch.equal(o['color'], rendered[0]['color'])            # same Gaussians, same cameras

@@ -13,7 +13,8 @@ from ocrfdet_amd import index_prep as pip_
 from ocrfdet_amd import synthetic
 
 CASES = [('cfg0', 'cfg0_1cam_128x352_bev64x64x4', True), ('ref', 'ref_6cam_256x704_bev128x128x1', False),
-         ('cfg1', 'cfg1_6cam_256x704_bev128x128x8', False), ('cfg2', 'cfg2_6cam_2frame_bev200x200_render_hoa', False)]
+         ('cfg1', 'cfg1_6cam_256x704_bev128x128x8', False), ('cfg2', 'cfg2_6cam_2frame_bev200x200_render_hoa', False),
+         ('cfg4', 'cfg4_6cam_8frame_512x1408_bev200x200', False)]      # BASELINE configs[4]: 512x1408 -> 32x88 features
 
 
 def sha(a):

@@ -16,7 +16,8 @@ from ocrfdet_amd import synthetic
 pytestmark = pytest.mark.gpu
 
 CASES = [('cfg0', 'cfg0_1cam_128x352_bev64x64x4'), ('ref', 'ref_6cam_256x704_bev128x128x1'),
-         ('cfg1', 'cfg1_6cam_256x704_bev128x128x8'), ('cfg2', 'cfg2_6cam_2frame_bev200x200_render_hoa')]
+         ('cfg1', 'cfg1_6cam_256x704_bev128x128x8'), ('cfg2', 'cfg2_6cam_2frame_bev200x200_render_hoa'),
+         ('cfg4', 'cfg4_6cam_8frame_512x1408_bev200x200')]       # BASELINE configs[4]: 512x1408 -> 32x88 features
 
 
 def sha(a):
