@@ -2,8 +2,9 @@
 under profiles/ (the raw numbers bench.py's `roofline` block is recomputed from):
 
   kernel_stats_serial.csv / kernel_stats_overlap.csv   rocprofv3 --stats per kernel (calls, total, mean, min, max; ns)
-  pmc_raw.csv     one row per (dispatch, counter) of THIS library's kernels, straight from rocprofv3's
-                  counter_collection.csv (torch / MIOpen / rocprim kernels dropped, argument lists cut off)
+  pmc_raw.csv     rows of rocprofv3's counter_collection.csv (dispatch, counter, value) for THIS library's kernels
+                  (torch / MIOpen / rocprim kernels dropped, argument lists cut off), the first RAW_KEEP dispatches
+                  of every (kernel, counter) — the means below are over ALL dispatches
   pmc_mean.csv    mean / min / max per (kernel, counter) + launches
 
     python tools/pmc_reduce.py gpurun_out/prof_<tag>
@@ -14,6 +15,7 @@ import glob
 import os
 import sys
 
+RAW_KEEP = 8
 OURS = ('raster_', 'bev_pool', 'hoa', 'neck_', 'lss_', 'ht_', 'radix_', 'scan_', 'lower_bound', 'zero_words', 'geom_',
         'camera_')
 
@@ -64,6 +66,8 @@ def main():
                     k = short(r['Kernel_Name'])
                     v = float(r['Counter_Value'])
                     acc[(k, r['Counter_Name'])].append(v)
+                    if len(acc[(k, r['Counter_Name'])]) > RAW_KEEP:
+                        continue
                     w.writerow([os.path.basename(d), r.get('Dispatch_Id', ''), k, r.get('Grid_Size', ''),
                                 r.get('Workgroup_Size', ''), r.get('LDS_Block_Size', ''), r.get('VGPR_Count', ''),
                                 r.get('SGPR_Count', ''), r['Counter_Name'], r['Counter_Value']])
