@@ -328,7 +328,56 @@ struct UnetBlockArgs {
   const float* pw_w; const float* pw_b; int Cout;                     // BN-folded (Cout,Cin), (Cout)
   const float* addend;                                                // (B,Cout,H,W) or null
   float* out; float* partial_max; int H, W, tiles_x, tiles_y;         // partial_max (B*Cout, tiles) or null
+  // gate of src0 / src1 computed IN this kernel from the producer's per-tile channel maxima (pm != null; else the
+  // gate0 / gate1 vectors above, else 1): HeightAttention = sigmoid(w2 relu(w1 maxpool)) per channel quarter
+  const float* pm0; const float* g0w1; const float* g0w2; int g0hid, g0tiles;
+  const float* pm1; const float* g1w1; const float* g1w2; int g1hid, g1tiles;
 };
+
+// HeightAttention gate of one batch entry from per-tile maxima, by the whole workgroup, into s_gate[C]
+// (view_transformer_ocrf.py:421-461: global max-pool per channel, per quarter q -> hid -> q, sigmoid).  Every
+// consumer workgroup redoes this tiny reduction (C <= 16 channels x <= a few hundred tiles from L2) instead of
+// waiting for a separate launch between every two blocks of the UNet.  Contains barriers: call uniformly.
+__device__ __forceinline__ void gate_from_tiles_dev(int b, int C, int hid, int n_tiles, const float* __restrict__ partial,
+                                                     const float* __restrict__ w1, const float* __restrict__ w2,
+                                                     float* s_gate, float* s_max, float* s_hid) {
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int q = C / 4;
+  for (int c = wave; c < C; c += kBlock / 64) {
+    float m = -INFINITY;
+    for (int t = lane; t < n_tiles; t += 64) m = fmaxf(m, partial[((long)b * C + c) * n_tiles + t]);
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off));
+    if (lane == 0) s_max[c] = m;
+  }
+  __syncthreads();
+  if (tid < 4 * hid) {
+    const int g = tid / hid, h = tid % hid;
+    float acc = 0.f;
+    for (int i = 0; i < q; ++i) acc = fmaf(w1[(g * hid + h) * q + i], s_max[g * q + i], acc);
+    s_hid[tid] = fmaxf(acc, 0.f);
+  }
+  __syncthreads();
+  if (tid < C) {
+    const int g = tid / q, o = tid % q;
+    float acc = 0.f;
+    for (int h = 0; h < hid; ++h) acc = fmaf(w2[(g * q + o) * hid + h], s_hid[g * hid + h], acc);
+    s_gate[tid] = sigmoidf_(acc);
+  }
+  __syncthreads();
+}
+
+// s_gate[C] = the gate the kernel multiplies a source with: from tiles, from a vector, or 1
+__device__ __forceinline__ void load_gate_dev(int b, int C, const float* gate_vec, const float* pm, const float* w1,
+                                              const float* w2, int hid, int n_tiles, float* s_gate, float* s_max,
+                                              float* s_hid) {
+  if (pm) {
+    gate_from_tiles_dev(b, C, hid, n_tiles, pm, w1, w2, s_gate, s_max, s_hid);
+  } else {
+    if ((int)threadIdx.x < C) s_gate[threadIdx.x] = gate_vec ? gate_vec[b * C + threadIdx.x] : 1.f;
+    __syncthreads();
+  }
+}
 
 __global__ __launch_bounds__(kBlock) void hoa_unet_block_kernel(UnetBlockArgs a) {
   __shared__ float s_v[kUMaxC][kUH][kUH + 1];
@@ -346,10 +395,13 @@ __global__ __launch_bounds__(kBlock) void hoa_unet_block_kernel(UnetBlockArgs a)
     for (int i = tid; i < a.Cout * Ci; i += kBlock) s_pww[i] = a.pw_w[i];
     if (tid < Ci) s_dwb[tid] = a.dw_b[tid];
     if (tid < a.Cout) s_pwb[tid] = a.pw_b[tid];
-    if (tid < a.C0) s_g0[tid] = a.gate0 ? a.gate0[blockIdx.z * a.C0 + tid] : 1.f;
-    if (tid < a.C1) s_g1[tid] = a.gate1 ? a.gate1[blockIdx.z * a.C1 + tid] : 1.f;
   }
   __syncthreads();
+  {
+    __shared__ float s_gm[64], s_gh[64];
+    load_gate_dev(blockIdx.z, a.C0, a.gate0, a.pm0, a.g0w1, a.g0w2, a.g0hid, a.g0tiles, s_g0, s_gm, s_gh);
+    if (a.C1 > 0) load_gate_dev(blockIdx.z, a.C1, a.gate1, a.pm1, a.g1w1, a.g1w2, a.g1hid, a.g1tiles, s_g1, s_gm, s_gh);
+  }
   const int b = blockIdx.z;
   const int ty0 = blockIdx.y * kUT, tx0 = blockIdx.x * kUT;
   const int Cfirst = (a.mode == 2) ? a.Cup : a.C0;
@@ -478,14 +530,16 @@ __global__ __launch_bounds__(kBlock) void hoa_unet_block_fixed_kernel(UnetBlockA
   __shared__ float s_v[CIN][kUH][kUH + 1];
   __shared__ float s_red[kBlock / 64][COUT];
   __shared__ float s_upw[(MODE == 2) ? C0 * CUP * 4 : 1];   // the 2x2 tap is per lane: vector (LDS) reads
+  __shared__ float s_g0[C0], s_g1[C1 > 0 ? C1 : 1], s_gm[64], s_gh[64];
   const int tid = threadIdx.x;
   const int b = blockIdx.z;
   const int ty0 = blockIdx.y * kUT, tx0 = blockIdx.x * kUT;
   const int H = a.H, W = a.W;
   if (MODE == 2) {
     for (int i = tid; i < C0 * CUP * 4; i += kBlock) s_upw[i] = a.up_w[i];
-    __syncthreads();
   }
+  load_gate_dev(b, C0, a.gate0, a.pm0, a.g0w1, a.g0w2, a.g0hid, a.g0tiles, s_g0, s_gm, s_gh);
+  if (C1 > 0) load_gate_dev(b, C1, a.gate1, a.pm1, a.g1w1, a.g1w2, a.g1hid, a.g1tiles, s_g1, s_gm, s_gh);
 
   for (int i = tid; i < kUH * kUH; i += kBlock) {
     const int hy = i / kUH, hx = i % kUH;
@@ -497,7 +551,7 @@ __global__ __launch_bounds__(kBlock) void hoa_unet_block_fixed_kernel(UnetBlockA
 #pragma unroll
       for (int ci = 0; ci < C0; ++ci) {
         float v = in ? a.src0[(((long)b * C0 + ci) * a.H0 + sy) * a.W0 + sx] : 0.f;
-        if (a.gate0) v *= a.gate0[b * C0 + ci];
+        v *= s_g0[ci];
         sv[ci] = v;
       }
 #pragma unroll
@@ -519,7 +573,7 @@ __global__ __launch_bounds__(kBlock) void hoa_unet_block_fixed_kernel(UnetBlockA
           } else {
             v = p[(long)y * a.W0 + x];
           }
-          if (a.gate0) v *= a.gate0[b * C0 + c];     // gates > 0: commutes with the max-pool
+          v *= s_g0[c];                              // gates > 0: commutes with the max-pool
         }
         sv[c] = v;
       }
@@ -531,7 +585,7 @@ __global__ __launch_bounds__(kBlock) void hoa_unet_block_fixed_kernel(UnetBlockA
       float v = 0.f;
       if (in) {
         v = a.src1[(((long)b * C1 + c) * H + y) * W + x];
-        if (a.gate1) v *= a.gate1[b * C1 + c];
+        v *= s_g1[c];
       }
       s_v[CF + c][hy][hx] = v;
     }
@@ -616,19 +670,25 @@ __global__ __launch_bounds__(kBlock) void hoa_height_gate_from_tiles_kernel(
   }
 }
 
-// Final 1x1 output conv (:516) over the gated decoder output.
+// Final 1x1 output conv (:516) over the gated decoder output; the gate as a vector or from per-tile maxima.
 __global__ __launch_bounds__(kBlock) void hoa_gated_conv1x1_kernel(const float* __restrict__ x,
                                                                    const float* __restrict__ gate, int C,
                                                                    long plane, const float* __restrict__ w,
                                                                    const float* __restrict__ bias,
-                                                                   float* __restrict__ out) {
-  const long pix = (long)blockIdx.x * kBlock + threadIdx.x;
+                                                                   float* __restrict__ out, const float* pm,
+                                                                   const float* gw1, const float* gw2, int ghid,
+                                                                   int gtiles) {
+  __shared__ float s_g[64], s_gm[64], s_gh[64];
   const int b = blockIdx.y;
+  load_gate_dev(b, C, gate, pm, gw1, gw2, ghid, gtiles, s_g, s_gm, s_gh);
+  const long pix = (long)blockIdx.x * kBlock + threadIdx.x;
   if (pix >= plane) return;
   float acc = bias[0];
-  for (int c = 0; c < C; ++c) acc = fmaf(x[((long)b * C + c) * plane + pix] * gate[b * C + c], w[c], acc);
+  for (int c = 0; c < C; ++c) acc = fmaf(x[((long)b * C + c) * plane + pix] * s_g[c], w[c], acc);
   out[(long)b * plane + pix] = acc;
 }
+
+int launch_unet_block(const UnetBlockArgs& a, int B, hipStream_t stream);
 
 }  // namespace
 
@@ -654,6 +714,16 @@ int ocrf_hoa_unet_block(const float* src0, const float* gate0, int C0, int H0, i
   a.dw_w = dw_w; a.dw_b = dw_b; a.pw_w = pw_w; a.pw_b = pw_b; a.Cout = Cout; a.addend = addend;
   a.out = out; a.partial_max = partial_max; a.H = H; a.W = W;
   a.tiles_x = (W + kUT - 1) / kUT; a.tiles_y = (H + kUT - 1) / kUT;
+  a.pm0 = a.g0w1 = a.g0w2 = a.pm1 = a.g1w1 = a.g1w2 = nullptr;
+  a.g0hid = a.g0tiles = a.g1hid = a.g1tiles = 0;
+  return launch_unet_block(a, B, stream);
+}
+
+}  // extern "C"
+
+namespace {
+int launch_unet_block(const UnetBlockArgs& a, int B, hipStream_t stream) {
+  const int mode = a.mode, C0 = a.C0, Cup = a.Cup, C1 = a.C1, Cout = a.Cout;
   const dim3 grid(a.tiles_x, a.tiles_y, B);
 #define OCRF_UNET_FIXED(M, c0, cup, c1, co)                                                                   \
   if (mode == M && C0 == c0 && (M != 2 || Cup == cup) && C1 == c1 && Cout == co) {                            \
@@ -668,6 +738,115 @@ int ocrf_hoa_unet_block(const float* src0, const float* gate0, int C0, int H0, i
   OCRF_UNET_FIXED(2, 8, 4, 4, 4)      // decoder1   (:512-514)
 #undef OCRF_UNET_FIXED
   ocrf::launch(OCRF_K_HOA_UNET_BLOCK, hoa_unet_block_kernel, grid, dim3(kBlock), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
+// packed weights of the whole converter (floats), in this order
+struct V2bOffsets {
+  int dw_w[5], dw_b[5], pw_w[5], pw_b[5], g_w1[5], g_w2[5], up_w[2], up_b[2], out_w, out_b, total;
+};
+constexpr int kV2bCin[5] = {13, 4, 8, 16, 8}, kV2bCout[5] = {4, 8, 16, 8, 4};     // e1, e2, bottleneck, d2, d1
+inline V2bOffsets v2b_offsets() {
+  V2bOffsets o;
+  int p = 0;
+  for (int k = 0; k < 5; ++k) {
+    const int ci = kV2bCin[k], co = kV2bCout[k], q = co / 4;
+    o.dw_w[k] = p; p += ci * 9;
+    o.dw_b[k] = p; p += ci;
+    o.pw_w[k] = p; p += co * ci;
+    o.pw_b[k] = p; p += co;
+    o.g_w1[k] = p; p += 4 * q * q;       // HeightAttention(co, co, ratio = 1): hid = q
+    o.g_w2[k] = p; p += 4 * q * q;
+  }
+  o.up_w[0] = p; p += 16 * 8 * 4;  o.up_b[0] = p; p += 8;      // upconv2
+  o.up_w[1] = p; p += 8 * 4 * 4;   o.up_b[1] = p; p += 4;      // upconv1
+  o.out_w = p; p += 4;
+  o.out_b = p; p += 1;
+  o.total = p;
+  return o;
+}
+}  // namespace
+
+extern "C" {
+
+int ocrf_hoa_v2b_weights_len(void) { return v2b_offsets().total; }
+
+size_t ocrf_hoa_v2b_workspace_bytes(int B, int H, int W) {
+  if (B <= 0 || H < 4 || W < 4 || (H % 4) || (W % 4)) return 0;
+  size_t n = 0;
+  const int hs[5] = {H, H / 2, H / 4, H / 2, H}, wsz[5] = {W, W / 2, W / 4, W / 2, W};
+  for (int k = 0; k < 5; ++k) {
+    const size_t tiles = (size_t)((wsz[k] + kUT - 1) / kUT) * ((hs[k] + kUT - 1) / kUT);
+    n += (size_t)B * kV2bCout[k] * hs[k] * wsz[k] + (size_t)B * kV2bCout[k] * tiles;
+  }
+  return (n * sizeof(float) + 255) / 256 * 256;
+}
+
+// The whole OpacityVoxelToBEVConverter.forward (view_transformer_ocrf.py:497-518) of the architecture OcRFDet
+// instantiates (13 -> 4 -> 8 -> 16 -> 8 -> 4 -> 1, ratio-1 HeightAttention gates) as SIX launches in one call:
+// five conv blocks, each computing its producers' channel gates in its own prologue from the per-tile maxima they
+// left, and the gated output conv.  x (B,13,H,W), position (B,4,H,W), out (B,1,H,W); H, W multiples of 4.
+int ocrf_hoa_v2b_forward(const float* x, const float* position, const float* weights, int B, int H, int W,
+                         void* workspace, size_t workspace_bytes, float* out, ocrf_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (!x || !position || !weights || !out || !workspace || B <= 0 || H < 4 || W < 4 || (H % 4) || (W % 4) ||
+      workspace_bytes < ocrf_hoa_v2b_workspace_bytes(B, H, W))
+    return (int)hipErrorInvalidValue;
+  const V2bOffsets o = v2b_offsets();
+  const int hs[5] = {H, H / 2, H / 4, H / 2, H}, wsz[5] = {W, W / 2, W / 4, W / 2, W};
+  float* act[5];
+  float* pm[5];
+  int tiles[5];
+  float* p = static_cast<float*>(workspace);
+  for (int k = 0; k < 5; ++k) {
+    tiles[k] = ((wsz[k] + kUT - 1) / kUT) * ((hs[k] + kUT - 1) / kUT);
+    act[k] = p; p += (size_t)B * kV2bCout[k] * hs[k] * wsz[k];
+    pm[k] = p; p += (size_t)B * kV2bCout[k] * tiles[k];
+  }
+  // block k: source 0 (producer index, mode, up-conv index or -1), skip source (producer index or -1)
+  const int src0[5] = {-1, 0, 1, 2, 3}, mode[5] = {0, 1, 1, 2, 2}, up[5] = {-1, -1, -1, 0, 1}, skip[5] = {-1, -1, -1, 1, 0};
+  for (int k = 0; k < 5; ++k) {
+    UnetBlockArgs a;
+    const int s0 = src0[k];
+    a.src0 = s0 < 0 ? x : act[s0];
+    a.gate0 = nullptr;
+    a.C0 = kV2bCin[k] - (skip[k] >= 0 ? kV2bCout[skip[k]] : 0);
+    if (mode[k] == 2) a.C0 = kV2bCout[s0];
+    a.H0 = s0 < 0 ? H : hs[s0];
+    a.W0 = s0 < 0 ? W : wsz[s0];
+    a.mode = mode[k];
+    a.up_w = up[k] >= 0 ? weights + o.up_w[up[k]] : nullptr;
+    a.up_b = up[k] >= 0 ? weights + o.up_b[up[k]] : nullptr;
+    a.Cup = up[k] >= 0 ? kV2bCout[k] : 0;
+    a.src1 = skip[k] >= 0 ? act[skip[k]] : nullptr;
+    a.gate1 = nullptr;
+    a.C1 = skip[k] >= 0 ? kV2bCout[skip[k]] : 0;
+    a.dw_w = weights + o.dw_w[k]; a.dw_b = weights + o.dw_b[k];
+    a.pw_w = weights + o.pw_w[k]; a.pw_b = weights + o.pw_b[k];
+    a.Cout = kV2bCout[k];
+    a.addend = k == 0 ? position : nullptr;
+    a.out = act[k]; a.partial_max = pm[k];
+    a.H = hs[k]; a.W = wsz[k];
+    a.tiles_x = (wsz[k] + kUT - 1) / kUT; a.tiles_y = (hs[k] + kUT - 1) / kUT;
+    a.pm0 = s0 < 0 ? nullptr : pm[s0];
+    a.g0w1 = s0 < 0 ? nullptr : weights + o.g_w1[s0];
+    a.g0w2 = s0 < 0 ? nullptr : weights + o.g_w2[s0];
+    a.g0hid = s0 < 0 ? 0 : kV2bCout[s0] / 4;
+    a.g0tiles = s0 < 0 ? 0 : tiles[s0];
+    const int s1 = skip[k];
+    a.pm1 = s1 < 0 ? nullptr : pm[s1];
+    a.g1w1 = s1 < 0 ? nullptr : weights + o.g_w1[s1];
+    a.g1w2 = s1 < 0 ? nullptr : weights + o.g_w2[s1];
+    a.g1hid = s1 < 0 ? 0 : kV2bCout[s1] / 4;
+    a.g1tiles = s1 < 0 ? 0 : tiles[s1];
+    const int rc = launch_unet_block(a, B, stream);
+    if (rc != 0) return rc;
+  }
+  const long plane = (long)H * W;
+  ocrf::launch(OCRF_K_HOA_OUT_CONV, hoa_gated_conv1x1_kernel, dim3((unsigned)((plane + kBlock - 1) / kBlock), B),
+               dim3(kBlock), 0, stream, static_cast<const float*>(act[4]), (const float*)nullptr, 4, plane,
+               weights + o.out_w, weights + o.out_b, out, static_cast<const float*>(pm[4]), weights + o.g_w1[4],
+               weights + o.g_w2[4], 1, tiles[4]);
   return (int)hipGetLastError();
 }
 
@@ -690,7 +869,8 @@ int ocrf_hoa_gated_conv1x1(const float* x, const float* gate, int B, int C, int 
   if (!x || !gate || !w || !bias || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return (int)hipErrorInvalidValue;
   const long plane = (long)H * W;
   ocrf::launch(OCRF_K_HOA_OUT_CONV, hoa_gated_conv1x1_kernel, dim3((unsigned)((plane + kBlock - 1) / kBlock), B),
-               dim3(kBlock), 0, stream, x, gate, C, plane, w, bias, out);
+               dim3(kBlock), 0, stream, x, gate, C, plane, w, bias, out, (const float*)nullptr, (const float*)nullptr,
+               (const float*)nullptr, 0, 0);
   return (int)hipGetLastError();
 }
 

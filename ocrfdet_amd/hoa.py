@@ -294,14 +294,62 @@ class OpacityVoxelToBEVConverter(nn.Module):
         cache['plan'] = plan
         return plan
 
+    def _packed_v2b(self):
+        """All weights of the converter as ONE float vector in the order ``ocrf_hoa_v2b_forward`` reads them
+        (csrc/hoa.hip ``v2b_offsets``): per block (encoder1, encoder2, bottleneck, decoder2, decoder1) the folded
+        depthwise / pointwise weights and that block's HeightAttention w1, w2; the two up-convolutions; the output
+        conv.  Cached until a parameter or buffer changes."""
+        cache = self.__dict__.get('_plan_cache')
+        if cache is None:
+            cache = self.__dict__['_plan_cache'] = _LaunchCache()
+        tensors = cache.get('tensors')
+        if tensors is None:
+            tensors = cache['tensors'] = list(self.parameters()) + list(self.buffers())
+        key = (tuple(t._version for t in tensors), tuple(t.data_ptr() for t in tensors))
+        hit = cache.get('packed')
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        parts = []
+        with torch.no_grad():
+            for blk, ca in ((self.encoder1, self.ca1), (self.encoder2, self.ca2), (self.bottleneck, self.ca_bottleneck),
+                            (self.decoder2, self.ca_dec2), (self.decoder1, self.ca_dec1)):
+                parts.extend(t.reshape(-1) for t in self._folded(blk))
+                parts.extend(t.reshape(-1) for t in ca._packed())
+            for up in (self.upconv2, self.upconv1):
+                parts.extend((up.weight.detach().float().reshape(-1), up.bias.detach().float().reshape(-1)))
+            parts.extend((self.output_conv.weight.detach().float().reshape(-1), self.output_conv.bias.detach().float().reshape(-1)))
+            packed = torch.cat([t.float() for t in parts]).contiguous()
+        assert packed.numel() == _lib.lib().ocrf_hoa_v2b_weights_len()
+        cache['packed'] = (key, packed)
+        return packed
+
+    def _is_reference_architecture(self):
+        e1 = self.encoder1[0]
+        return (e1.in_channels == 13 and self.ca1.hid == self.ca1.q_in == 1 and self.ca_bottleneck.hid == 4)
+
     def _forward_fused(self, x, position):
-        """Eval-mode forward as 5 fused block kernels + 5 gate kernels + the output conv
-        (csrc/hoa.hip, ocrf_hoa_unet_block): no intermediate pooled / upsampled / concatenated /
-        gated tensor is ever written.  The intermediates live in per-module buffers (``_plan``): one
-        forward at a time per module instance (calls on one stream are ordered; do not run the same
-        instance on two streams at once)."""
+        """Eval-mode forward as ONE C call of six launches (csrc/hoa.hip, ``ocrf_hoa_v2b_forward``): five fused
+        block kernels, each computing the HeightAttention gates of its producers in its own prologue, and the gated
+        output conv; no intermediate pooled / upsampled / concatenated / gated tensor is ever written.  The
+        intermediates live in the library's 'hoa_v2b' scratch buffer: one forward at a time per stream."""
         _lib.require_cuda(x, position)
         x, position = _f32c(x), _f32c(position)
+        B, _, H, W = x.shape
+        dev = x.device
+        L = _lib.lib()
+        if self._is_reference_architecture() and H % 4 == 0 and W % 4 == 0:
+            w = self._packed_v2b()
+            out = torch.empty(B, 1, H, W, device=dev)
+            with _lib.on_device(dev):
+                ws = _lib.workspace.get(dev, L.ocrf_hoa_v2b_workspace_bytes(B, H, W), 'hoa_v2b')
+                _lib.check(L.ocrf_hoa_v2b_forward(_lib.ptr(x), _lib.ptr(position), _lib.ptr(w), B, H, W, _lib.ptr(ws),
+                                                  ctypes.c_size_t(ws.numel()), _lib.ptr(out), _lib.stream_ptr(dev)),
+                           'ocrf_hoa_v2b_forward')
+            return out
+        return self._forward_blocks(x, position)
+
+    def _forward_blocks(self, x, position):
+        """Any other channel configuration: block by block (5 block kernels + 5 gate kernels + the output conv)."""
         B, _, H, W = x.shape
         dev = x.device
         L = _lib.lib()

@@ -115,6 +115,7 @@ class HotPath:
             m.to(dev).eval()
         g = torch.Generator(device='cpu').manual_seed(seed)
         self.alpha_lidar = torch.rand(self.batch, cfg.num_height, Y, X, generator=g).to(dev)
+        self._opac_flat = None
         self.bev_pos1 = (torch.randn(self.batch, 4, Y, X, generator=g) * 0.1).to(dev)
 
     @torch.no_grad()
@@ -124,9 +125,11 @@ class HotPath:
         cfg = self.cfg
         X, Y, _ = cfg.bev_xyz
         m = self.hoa_mods
-        # every frame shares the synthetic opacity volume; the reference loops samples (:1090)
-        opac = self.gauss['opacity'].view(1, cfg.num_height, Y, X).expand(self.batch, -1, -1, -1)
-        oa = hoa.hoa1(m['dca'], opac.reshape(-1, 1), self.alpha_lidar, cfg.num_height, Y, X)
+        # every frame shares the synthetic opacity volume; the reference loops samples (:1090).  The (B*P, 1)
+        # layout A_MLP hands over (:1130) is an INPUT of this stage: laid out once, not per step
+        if self._opac_flat is None:
+            self._opac_flat = self.gauss['opacity'].view(1, cfg.num_height, Y, X).expand(self.batch, -1, -1, -1).reshape(-1, 1).contiguous()
+        oa = hoa.hoa1(m['dca'], self._opac_flat, self.alpha_lidar, cfg.num_height, Y, X)
         return m['v2b'](oa, self.bev_pos1)
 
     @torch.no_grad()

@@ -112,6 +112,12 @@ def test_opacity_voxel_to_bev_fused_vs_blockwise_and_oracle(cuda, g):
     np.testing.assert_allclose(fused.cpu().numpy(), blockwise.cpu().numpy(), rtol=1e-4, atol=3e-5)
     want = ohoa.opacity_voxel_to_bev(x, pos, g, 'v2b')
     np.testing.assert_allclose(fused.cpu().numpy(), want, rtol=1e-4, atol=3e-5)
+    # the one-call form (six launches, gates computed in the consumers' prologues) == the eleven-launch form (a
+    # gate kernel between every two blocks), bit for bit: same reductions, same arithmetic
+    with torch.no_grad():
+        eleven = m._forward_blocks(xt, pt)
+        again = m(xt, pt)
+    assert torch.equal(fused, eleven) and torch.equal(fused, again)
 
 
 @pytest.mark.gpu

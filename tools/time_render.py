@@ -10,12 +10,12 @@ hp = hotpath.HotPath(cfg, dev)
 r = synthetic.rig(cfg.n_cams, cfg.input_size, hp.batch)
 for conv in ('reference', 'corrected'):
     hp._prepare_render(r, conv)
-    outs = hp.render(); torch.cuda.synchronize()
+    outs = hp.render(want_n_contrib=True); torch.cuda.synchronize()
     o = outs[0]
     nv = [(o['radii'][v] > 0).sum().item() for v in range(o['radii'].shape[0])]
     print(conv, 'visible per view', nv, 'mean final_T', o['final_T'].mean().item(), 'max n_contrib', o['n_contrib'].max().item(),
           'mean n_contrib', o['n_contrib'].float().mean().item())
-    for kid, kname in ((_lib.K_RASTER_PREPROCESS, 'preprocess'), (_lib.K_RASTER_GATHER, 'gather'), (_lib.K_RASTER_BLEND, 'blend')):
+    for kid, kname in ((_lib.K_RASTER_PREPROCESS, 'preprocess'), (_lib.K_RASTER_SCAN, 'scan'), (_lib.K_RASTER_GATHER, 'gather'), (_lib.K_RASTER_BLEND, 'blend')):
         t = _lib.KernelTimer(kid, 40); torch.cuda.synchronize(); t.arm()
         for _ in range(10): hp.render()
         torch.cuda.synchronize(); t.disarm(); ms = t.read_ms(); t.close()
