@@ -115,15 +115,35 @@ __global__ __launch_bounds__(kBlock) void bev_pool_table_kernel(
     const int* __restrict__ interval_lengths, int2* __restrict__ tab, int* __restrict__ tile_cnt) {
   if (counts) { n_points = counts[0]; n_intervals = counts[1]; }
   const int k = blockIdx.x * kBlock + threadIdx.x;
-  if (k >= n_intervals) return;
-  const int s = interval_starts[k];
-  int l = interval_lengths[k];
-  if (s < 0 || s >= n_points || l <= 0) return;      // an empty interval pools to 0: the table's default
-  l = min(l, n_points - s);
-  const int vox = ranks_bev[s];
-  if (vox < 0 || vox >= n_vox) return;
-  tab[vox] = make_int2(s, l);
-  atomicAdd(&tile_cnt[(vox / YX) * tpp + (vox % YX) / tv], l);
+  int tile = -1, l = 0;
+  if (k < n_intervals) {
+    const int s = interval_starts[k];
+    l = interval_lengths[k];
+    if (s >= 0 && s < n_points && l > 0) {            // an empty interval pools to 0: the table's default
+      l = min(l, n_points - s);
+      const int vox = ranks_bev[s];
+      if (vox >= 0 && vox < n_vox) {
+        tab[vox] = make_int2(s, l);
+        tile = (vox / YX) * tpp + (vox % YX) / tv;
+      }
+    }
+  }
+  if (tile < 0) l = 0;
+  // one atomic per RUN of equal tiles inside the wave (the producers emit intervals in voxel order, so a wave
+  // holds a handful of runs): 64 same-address atomics per wave serialise at the L2
+  const int lane = threadIdx.x & 63;
+  const int prev = __shfl_up(tile, 1);
+  const bool head = (lane == 0) || (tile != prev);
+  int inc = l;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(inc, off);
+    if (lane >= off) inc += o;
+  }
+  const unsigned long long heads = __ballot(head);
+  const unsigned long long later = heads & ~((2ull << lane) - 1ull);      // heads after this lane
+  const int end_lane = later ? (__ffsll((long long)later) - 2) : 63;       // last lane of this lane's run
+  const int run_total = __shfl(inc, end_lane) - (inc - l);
+  if (head && tile >= 0 && run_total > 0) atomicAdd(&tile_cnt[tile], run_total);
 }
 
 // exclusive scan of one int per thread over a 1024-thread workgroup; returns the total in `total`

@@ -49,51 +49,142 @@ __global__ __launch_bounds__(kBlock) void hoa_channel_stats_kernel(const float* 
 }
 
 // (2) mask = sigmoid(conv_kxk([mean, max]) + opacity_bev); gated = x * mask.
-// One workgroup per 64x4 pixel tile (a wave = one 256-B row segment of every channel plane: whole
-// cache lines; 16-wide tiles fetched every line twice): the two statistic planes (+ halo) and the
-// weights sit in LDS.
-constexpr int kMTX = 64, kMTY = 4;
+// One workgroup = 256 * VEC CONSECUTIVE pixels of the flattened (Y*X) plane (whole runs of every channel plane
+// whatever X is: a 64-wide 2-D tile left a quarter of the workgroups 8 pixels wide at X = 200) and ONE GROUP of
+// the channels (grid.z = batch x groups; every group recomputes the 2 x k x k taps of its pixels from the
+// statistic rows staged in LDS, group 0 writes the mask).  VEC = 4 (X % 4 == 0): a thread owns 4 adjacent pixels
+// of one row — 16-byte loads and stores of x / gated, and the k-wide windows of adjacent pixels share their reads.
+// KT = k when it is known at compile time (7, the only size OcRFDet uses: the tap loops unroll and their LDS reads
+// pipeline instead of paying one LDS latency per tap), 0 = runtime k.
+template <int VEC, int KT>
 __global__ __launch_bounds__(kBlock) void hoa_mask_gate_kernel(
     const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ opacity_bev,
-    const float* __restrict__ conv_w, int k, int C, int Y, int X, float* __restrict__ mask,
-    float* __restrict__ gated) {
-  extern __shared__ float s_dyn[];        // 2*k*k weights, then 2 planes of (kMTY+k-1) x (kMTX+k-1)
-  const int r = k / 2, tw = kMTX + k - 1, th = kMTY + k - 1;
+    const float* __restrict__ conv_w, int k_rt, int C, int Y, int X, int groups, int n_rows,
+    float* __restrict__ mask, float* __restrict__ gated) {
+  const int k = KT ? KT : k_rt;
+  extern __shared__ float s_dyn[];        // 2*k*k weights, then 2 planes of n_rows x (X + k - 1), zero padded
+  const int r = k / 2, tw = X + k - 1;
   float* s_w = s_dyn;
   float* s_s = s_dyn + 2 * k * k;
   const long plane = (long)Y * X;
-  const int b = blockIdx.z, ty0 = blockIdx.y * kMTY, tx0 = blockIdx.x * kMTX;
+  const int b = blockIdx.z / groups, g = blockIdx.z % groups;
+  const long p0 = (long)blockIdx.x * kBlock * VEC;
+  const int row0 = (int)(p0 / X) - r;                      // first staged row (may be negative: zeros)
   for (int i = threadIdx.x; i < 2 * k * k; i += kBlock) s_w[i] = conv_w[i];
-  for (int i = threadIdx.x; i < 2 * tw * th; i += kBlock) {
-    const int ch = i / (tw * th), rem = i % (tw * th);
-    const int y = ty0 + rem / tw - r, xx = tx0 + rem % tw - r;
-    s_s[i] = (y >= 0 && y < Y && xx >= 0 && xx < X) ? stats[((long)b * 2 + ch) * plane + (long)y * X + xx] : 0.f;
+  // the first batch of this thread's x values is on its way while the mask is computed
+  const long pix_e = p0 + (long)threadIdx.x * VEC;
+  const int cpg_e = (C + groups - 1) / groups;
+  const int c0_e = g * cpg_e, c1_e = min(C, c0_e + cpg_e);
+  float4 first[5];
+  const bool pre = (VEC == 4) && gated && pix_e < plane && c0_e + 5 <= c1_e;
+  if constexpr (VEC == 4) {
+    if (pre) {
+      const float* pe = x + (long)b * C * plane + pix_e;
+#pragma unroll
+      for (int u = 0; u < 5; ++u) first[u] = *reinterpret_cast<const float4*>(pe + (long)(c0_e + u) * plane);
+    }
+  }
+  // the statistic rows: all of a thread's loads are issued before any is stored
+  const int n_stage = 2 * n_rows * tw;
+  for (int i0 = 0; i0 < n_stage; i0 += 8 * kBlock) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * kBlock + threadIdx.x;
+      const int ch = i / (n_rows * tw), rem = i % (n_rows * tw);
+      const int y = row0 + rem / tw, xx = rem % tw - r;
+      v[u] = (i < n_stage && y >= 0 && y < Y && xx >= 0 && xx < X)
+                 ? stats[((long)b * 2 + ch) * plane + (long)y * X + xx] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * kBlock + threadIdx.x;
+      if (i < n_stage) s_s[i] = v[u];
+    }
   }
   __syncthreads();
-  const int ly = threadIdx.x / kMTX, lx = threadIdx.x % kMTX;
-  const int yy = ty0 + ly, xx = tx0 + lx;
-  if (yy >= Y || xx >= X) return;
-  float acc = 0.f;
-  for (int ch = 0; ch < 2; ++ch)
-    for (int i = 0; i < k; ++i)
-      for (int j = 0; j < k; ++j)
-        acc = fmaf(s_s[(ch * th + ly + i) * tw + lx + j], s_w[(ch * k + i) * k + j], acc);
-  const long pix = (long)yy * X + xx;
-  const float m = sigmoidf_(acc + opacity_bev[(long)b * plane + pix]);
-  mask[(long)b * plane + pix] = m;
+  const long pix = p0 + (long)threadIdx.x * VEC;
+  if (pix >= plane) return;
+  const int yy = (int)(pix / X), xx = (int)(pix % X);
+  const int ly = yy - row0 - r;                            // staged row of (yy - r) is ly
+  float acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  if constexpr (KT > 0) {
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+#pragma unroll
+      for (int i = 0; i < KT; ++i) {
+        const float* row = s_s + (ch * n_rows + ly + i) * tw + xx;
+        const float* wr = s_w + (ch * KT + i) * KT;
+        float win[KT + VEC - 1];                          // the k-wide windows of adjacent pixels overlap
+#pragma unroll
+        for (int j = 0; j < KT + VEC - 1; ++j) win[j] = row[j];
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+          const float w = wr[j];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[e] = fmaf(win[j + e], w, acc[e]);
+        }
+      }
+    }
+  } else {
+    for (int ch = 0; ch < 2; ++ch)
+      for (int i = 0; i < k; ++i) {
+        const float* row = s_s + (ch * n_rows + ly + i) * tw + xx;
+        const float* wr = s_w + (ch * k + i) * k;
+        for (int j = 0; j < k; ++j) {
+          const float w = wr[j];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[e] = fmaf(row[j + e], w, acc[e]);
+        }
+      }
+  }
+  float m[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) m[e] = sigmoidf_(acc[e] + opacity_bev[(long)b * plane + pix + e]);
+  if (g == 0) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) mask[(long)b * plane + pix + e] = m[e];
+  }
   if (gated) {
+    const int cpg = (C + groups - 1) / groups;
+    const int c0 = g * cpg, c1 = min(C, c0 + cpg);
     const float* p = x + (long)b * C * plane + pix;
     float* q = gated + (long)b * C * plane + pix;
-    // 16 plane reads in flight per lane
-    int c = 0;
-    for (; c + 16 <= C; c += 16) {
-      float v[16];
+    if constexpr (VEC == 4) {
+      int c = c0;
+      if (pre) {
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = p[(long)(c + u) * plane];
+        for (int u = 0; u < 5; ++u)
+          *reinterpret_cast<float4*>(q + (long)(c + u) * plane) =
+              make_float4(first[u].x * m[0], first[u].y * m[1], first[u].z * m[2], first[u].w * m[3]);
+        c += 5;
+      }
+      for (; c + 5 <= c1; c += 5) {                        // 5 x 16 B in flight per lane
+        float4 v[5];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) q[(long)(c + u) * plane] = v[u] * m;
+        for (int u = 0; u < 5; ++u) v[u] = *reinterpret_cast<const float4*>(p + (long)(c + u) * plane);
+#pragma unroll
+        for (int u = 0; u < 5; ++u)
+          *reinterpret_cast<float4*>(q + (long)(c + u) * plane) =
+              make_float4(v[u].x * m[0], v[u].y * m[1], v[u].z * m[2], v[u].w * m[3]);
+      }
+      for (; c < c1; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (long)c * plane);
+        *reinterpret_cast<float4*>(q + (long)c * plane) = make_float4(v.x * m[0], v.y * m[1], v.z * m[2], v.w * m[3]);
+      }
+    } else {
+      int c = c0;
+      for (; c + 10 <= c1; c += 10) {                      // 10 plane reads in flight per lane
+        float v[10];
+#pragma unroll
+        for (int u = 0; u < 10; ++u) v[u] = p[(long)(c + u) * plane];
+#pragma unroll
+        for (int u = 0; u < 10; ++u) q[(long)(c + u) * plane] = v[u] * m[0];
+      }
+      for (; c < c1; ++c) q[(long)c * plane] = p[(long)c * plane] * m[0];
     }
-    for (; c < C; ++c) q[(long)c * plane] = p[(long)c * plane] * m;
   }
 }
 
@@ -267,10 +358,24 @@ int ocrf_hoa_opacity_mask_gate(const float* x, const float* stats, const float* 
   if (!x || !stats || !opacity_bev || !conv_w || !mask || k <= 0 || (k & 1) == 0 || k > 15 || B <= 0 ||
       C <= 0 || Y <= 0 || X <= 0)
     return (int)hipErrorInvalidValue;
-  const int tw = kMTX + k - 1, th = kMTY + k - 1;
-  ocrf::launch(OCRF_K_HOA_MASK_GATE, hoa_mask_gate_kernel, dim3((X + kMTX - 1) / kMTX, (Y + kMTY - 1) / kMTY, B),
-               dim3(kBlock), (size_t)(2 * k * k + 2 * tw * th) * sizeof(float), stream, x, stats, opacity_bev,
-               conv_w, k, C, Y, X, mask, gated);
+  const long plane = (long)Y * X;
+  const bool vec4 = (X % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gated)) & 15u) == 0 &&
+                    (X + 6) * 14 * 2 * 4 <= 60 * 1024;
+  const int per_wg = kBlock * (vec4 ? 4 : 1);
+  // rows a run of per_wg consecutive pixels can touch (it may start mid-row) plus the k - 1 halo rows
+  const int n_rows = (per_wg + X - 2) / X + 1 + (k - 1);
+  const size_t lds = (size_t)(2 * k * k + 2 * n_rows * (X + k - 1)) * sizeof(float);
+  if (lds > 64 * 1024) return (int)hipErrorInvalidValue;             // X beyond ~1 000: not a BEV plane
+  const int groups = gated ? ((C >= 40) ? 4 : (C >= 16 ? 2 : 1)) : 1;
+  const dim3 grid((unsigned)((plane + per_wg - 1) / per_wg), 1, (unsigned)(B * groups));
+#define OCRF_MASK_GATE(V, K)                                                                                       \
+  ocrf::launch(OCRF_K_HOA_MASK_GATE, hoa_mask_gate_kernel<V, K>, grid, dim3(kBlock), lds, stream, x, stats, opacity_bev, \
+               conv_w, k, C, Y, X, groups, n_rows, mask, gated)
+  if (vec4 && k == 7) OCRF_MASK_GATE(4, 7);
+  else if (vec4) OCRF_MASK_GATE(4, 0);
+  else if (k == 7) OCRF_MASK_GATE(1, 7);
+  else OCRF_MASK_GATE(1, 0);
+#undef OCRF_MASK_GATE
   return (int)hipGetLastError();
 }
 
