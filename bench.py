@@ -58,6 +58,9 @@ def parse():
     ap.add_argument('--scope', choices=('hotpath', 'neck'), default='hotpath',
                     help="'hotpath': pools (+ one rendered view per camera + HOA) — the headline step; 'neck': the whole "
                          "OcRFViewTransformerFull.view_transform (one rendered view per sample, like the reference)")
+    ap.add_argument('--device-geometry', action='store_true',
+                    help="--scope neck --index-prep per_step: per-forward calibration algebra on the GPU (ocrf_geometry_blocks): "
+                         "no device read-back, no synchronisation in the forward")
     ap.add_argument('--host-calibration', action='store_true',
                     help="--scope neck --index-prep per_step: hand the calibration tensors over as HOST tensors (the "
                          "dataloader's copies) — the forward then has no device -> host read-back at all")
@@ -130,6 +133,7 @@ def bench_neck(args, cfg, dev, world, rank):
     from ocrfdet_amd import _lib, hotpath
     neck = hotpath.NeckPath(cfg, dev, accelerate=args.index_prep == 'cached', seed=rank,
                             host_calibration=args.host_calibration)
+    neck.module.device_geometry = bool(args.device_geometry)
     graphed = args.index_prep == 'cached' and not args.no_graph
     for _ in range(args.warmup):
         neck.step()
@@ -189,7 +193,8 @@ def bench_neck(args, cfg, dev, world, rank):
                           'launch': 'one hipGraph replay per step' if graphed else 'eager (kernel by kernel)',
                           'index_prep': 'cached (accelerate=True)' if args.index_prep == 'cached' else
                           'per step, HIP (accelerate=False); calibration ' +
-                          ('handed over as host tensors' if args.host_calibration else 'read back from the device (one packed copy)'),
+                          ('algebra on the device (ocrf_geometry_blocks), no read-back' if args.device_geometry else
+                           'handed over as host tensors' if args.host_calibration else 'read back from the device (one packed copy)'),
                           'sharding': 'none' if world == 1 else f'{world} ranks x whole samples, no data-path collective'},
                'roofline': {'bound': 'hbm', 'kernel': timer.kernel_name, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                             'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS if achieved else None, 'traffic': None,

@@ -270,6 +270,24 @@ int ocrf_ht_prepare(int B, int N, int Z, int n_pillars, int Wf, int Hf, int D, c
                     ocrf_stream_t stream);
 size_t ocrf_ht_prepare_workspace_bytes(int B, int n_pillars);
 
+/*
+ * Per-forward calibration algebra on the device (the host glue of view_transformer.py:128-146,
+ * view_transformer_ocrf.py:675-685 and :1135-1152 with data_utils.py:703-733): from the seven calibration
+ * tensors of the reference's input tuple, where they already live, to the camera blocks the kernels above take —
+ *   lss_block   (B*N,33)  inv(post_rots) | rots inv(intrins) | post_trans | trans | bda      (ocrf_lss_prepare)
+ *   ht_block    (B*N,24)  lidar2img 3x4 | img_aug 3x4                        (ocrf_ht_prepare / ocrf_ht_project)
+ *   camera_rows (B*N,36)  the `cameras` rows of ocrf_rasterize_forward for every camera-frame, built as the
+ *                         reference builds its render camera (quirks included); needs c2w (B*N,4,4)
+ * (any of the three may be NULL).  3x3 inverses and products are evaluated in double precision and rounded to
+ * float once, so the values agree with the reference's float32 LAPACK / matmul chain to ~1 ulp, not bit for bit:
+ * a pillar sample or frustum point that sits within that distance of a cell border can land in the neighbouring
+ * cell (as it can between the reference's own CPU and CUDA runs).  No host read, no synchronisation.
+ */
+int ocrf_geometry_blocks(int B, int N, const float *rots, const float *trans, const float *intrins,
+                         const float *post_rots, const float *post_trans, const float *bda, const float *c2w,
+                         int H_in, int W_in, float znear, float zfar, float *lss_block, float *ht_block,
+                         float *camera_rows, ocrf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Height-aware Opacity-based Attention (HOA) reductions
  * ------------------------------------------------------------------------------------------

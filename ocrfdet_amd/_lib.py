@@ -101,6 +101,8 @@ def _declare(L):
     L.ocrf_ht_prepare.restype = c_int
     L.ocrf_ht_prepare.argtypes = ([c_int] * 7 + [c_void_p] * 3 + [c_float] * 4 + [c_void_p] * 6 +
                                   [c_void_p, c_size_t, c_void_p])
+    L.ocrf_geometry_blocks.restype = c_int
+    L.ocrf_geometry_blocks.argtypes = [c_int, c_int] + [c_void_p] * 7 + [c_int, c_int, c_float, c_float] + [c_void_p] * 4
     L.ocrf_ht_prepare_workspace_bytes.restype = c_size_t
     L.ocrf_ht_prepare_workspace_bytes.argtypes = [c_int, c_int]
     L.ocrf_rasterize_backward.restype = c_int

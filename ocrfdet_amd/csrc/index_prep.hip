@@ -585,6 +585,140 @@ int ocrf_ht_project(int B, int N, int Z, int n_pillars, const float* ref_points,
   return (int)hipGetLastError();
 }
 
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Per-forward calibration algebra on the device: the B*N tiny matrices of get_lidar_coor
+// (view_transformer.py:128-146), get_projection (view_transformer_ocrf.py:675-685) and the render camera
+// (view_transformer_ocrf.py:1135-1152 with data_utils.py:703-733) from the calibration tensors where they
+// already are.  One thread per camera-frame; 3x3 inverses by cofactors in double precision, every product in
+// double, ONE rounding to float at the end (the reference's host path rounds after every float32 LAPACK /
+// matmul step; a CUDA run of the reference rounds differently again: the values agree to ~1 ulp).
+//   lss (B*N,33): inv(post_rots) | rots inv(K) | post_trans | trans | bda
+//   ht  (B*N,24): lidar2img = [K inv(rots) inv(bda) | -K inv(rots) trans] | img_aug = [post_rots | post_trans]
+//   cam (B*N,36): world_view^T | full_proj^T | tanfovx | tanfovy | focal_x | focal_y, the reference's quirks
+//                 kept: intrinsics as given with the network-input viewport, c2w's R and t fed where a
+//                 world->view rotation / translation are expected (getWorld2View2 inverts twice: identity).
+// ---------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ void inv3(const double* m, double* o) {
+  const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+  const double A = e * i - f * h, B = f * g - d * i, C = d * h - e * g;
+  const double det = a * A + b * B + c * C;
+  const double r = 1.0 / det;
+  o[0] = A * r; o[1] = (c * h - b * i) * r; o[2] = (b * f - c * e) * r;
+  o[3] = B * r; o[4] = (a * i - c * g) * r; o[5] = (c * d - a * f) * r;
+  o[6] = C * r; o[7] = (b * g - a * h) * r; o[8] = (a * e - b * d) * r;
+}
+__device__ __forceinline__ void mul3(const double* x, const double* y, double* o) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[3 * r + c] = x[3 * r] * y[c] + x[3 * r + 1] * y[3 + c] + x[3 * r + 2] * y[6 + c];
+}
+
+__global__ __launch_bounds__(64) void geom_blocks_kernel(
+    int B, int N, const float* __restrict__ rots, const float* __restrict__ trans, const float* __restrict__ intrins,
+    const float* __restrict__ post_rots, const float* __restrict__ post_trans, const float* __restrict__ bda,
+    const float* __restrict__ c2w, int H_in, int W_in, float znear, float zfar, float* __restrict__ lss,
+    float* __restrict__ ht, float* __restrict__ cam) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= B * N) return;
+  const int b = i / N;
+  double R[9], K[9], Pr[9], Bd[9], t[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    R[k] = rots[9 * i + k]; K[k] = intrins[9 * i + k]; Pr[k] = post_rots[9 * i + k]; Bd[k] = bda[9 * b + k];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) t[k] = trans[3 * i + k];
+  double iPr[9], iK[9], iR[9], iB[9], comb[9], kr[9], l2r[9];
+  inv3(Pr, iPr); inv3(K, iK); inv3(R, iR); inv3(Bd, iB);
+  mul3(R, iK, comb);
+  mul3(K, iR, kr);
+  mul3(kr, iB, l2r);
+  if (lss) {
+    float* o = lss + 33 * i;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { o[k] = (float)iPr[k]; o[9 + k] = (float)comb[k]; o[24 + k] = bda[9 * b + k]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o[18 + k] = post_trans[3 * i + k]; o[21 + k] = trans[3 * i + k]; }
+  }
+  if (ht) {
+    float* o = ht + 24 * i;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { o[4 * r + c] = (float)l2r[3 * r + c]; o[12 + 4 * r + c] = post_rots[9 * i + 3 * r + c]; }
+      o[4 * r + 3] = (float)(-(kr[3 * r] * t[0] + kr[3 * r + 1] * t[1] + kr[3 * r + 2] * t[2]));
+      o[12 + 4 * r + 3] = post_trans[3 * i + r];
+    }
+  }
+  if (cam && c2w) {
+    const float* M = c2w + 16 * i;
+    float* o = cam + 36 * i;
+    // world_view_transform = [[R^T, t], [0, 1]]^T with R = c2w[:3,:3], t = c2w[:3,3] (row-major, transposed)
+    float wv[16];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) wv[4 * r + c] = M[4 * r + c];
+      wv[4 * r + 3] = 0.f;
+      wv[12 + r] = M[4 * r + 3];
+    }
+    wv[15] = 1.f;
+    // getProjectionMatrix (data_utils.py:716-733) in double on the float32 intrinsics, stored transposed
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5], zn = znear, zf = zfar, w = W_in, h = H_in;
+    const double nfx = zn / fx, nfy = zn / fy;
+    const double left = -(w - cx) * nfx, right = cx * nfx, bottom = (cy - h) * nfy, top = cy * nfy;
+    float P[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) P[k] = 0.f;
+    P[0] = (float)(2.0 * zn / (right - left));           // P[0][0]
+    P[5] = (float)(2.0 * zn / (top - bottom));           // P[1][1]
+    P[8] = (float)((right + left) / (right - left));     // P^T[2][0] = P[0][2]
+    P[9] = (float)((top + bottom) / (top - bottom));     // P^T[2][1] = P[1][2]
+    P[11] = 1.f;                                          // P^T[2][3] = P[3][2]
+    P[10] = (float)(zf / (zf - zn));                      // P[2][2]
+    P[14] = (float)(-(zf * zn) / (zf - zn));              // P^T[3][2] = P[2][3]
+    // full_proj_transform = world_view^T-stored @ projection^T-stored, float32 like the reference's bmm
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = fmaf(wv[4 * r + k], P[4 * k + c], acc);
+        o[16 + 4 * r + c] = acc;
+      }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) o[k] = wv[k];
+    // FoV from the intrinsics as given (:1143-1146): fov = 2 atan(size / (2 f)) in float32, tan(fov / 2) in double
+    const float fovx = 2.f * atanf((float)W_in / (2.f * (float)fx));
+    const float fovy = 2.f * atanf((float)H_in / (2.f * (float)fy));
+    const float tfx = (float)tan(0.5 * (double)fovx), tfy = (float)tan(0.5 * (double)fovy);
+    o[32] = tfx; o[33] = tfy;
+    o[34] = (float)W_in / (2.0f * tfx);
+    o[35] = (float)H_in / (2.0f * tfy);
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int ocrf_geometry_blocks(int B, int N, const float* rots, const float* trans, const float* intrins,
+                         const float* post_rots, const float* post_trans, const float* bda, const float* c2w,
+                         int H_in, int W_in, float znear, float zfar, float* lss_block, float* ht_block,
+                         float* camera_rows, ocrf_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (B <= 0 || N <= 0 || !rots || !trans || !intrins || !post_rots || !post_trans || !bda || H_in <= 0 || W_in <= 0 ||
+      (camera_rows && !c2w))
+    return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(geom_blocks_kernel, dim3((unsigned)((B * N + 63) / 64)), dim3(64), 0, stream, B, N, rots, trans,
+                     intrins, post_rots, post_trans, bda, c2w, H_in, W_in, znear, zfar, lss_block, ht_block, camera_rows);
+  return (int)hipGetLastError();
+}
+
 size_t ocrf_ht_prepare_workspace_bytes(int B, int n_pillars) {
   if (B <= 0 || n_pillars <= 0) return 0;
   const size_t n = (size_t)B * n_pillars;

@@ -307,6 +307,28 @@ def fast_sample_prepare_hip(ref_template, cam_block, B, N, pc_range, image_shape
     return _trim(bufs, bufs[5].cpu())
 
 
+def geometry_blocks_hip(rots, trans, intrins, post_rots, post_trans, bda, c2w, image_shapes, znear=0.01, zfar=999.9):
+    """The per-forward calibration algebra on the device (C ABI ``ocrf_geometry_blocks``): from the calibration
+    tensors of the input tuple (all on the GPU) to ``lss_camera_block`` (B*N,33), ``ht_camera_block`` (B*N,24) and
+    the rasteriser's camera rows (B,N,36) of every camera-frame — no host read, no synchronisation.  Values agree
+    with the host formulation (``lss_camera_block`` / ``get_projection`` / ``camera_from_calibration``) to ~1 ulp,
+    not bit for bit (double-precision cofactor inverses rounded once vs the float32 LAPACK chain)."""
+    ts = [t.detach().float().contiguous() for t in (rots, trans, intrins, post_rots, post_trans, bda)]
+    _lib.require_cuda(*ts)
+    dev = ts[0].device
+    B, N = ts[1].shape[:2]
+    c2w_d = c2w.detach().float().contiguous().to(dev) if c2w is not None else None
+    lss = torch.empty(B * N, 33, device=dev)
+    ht = torch.empty(B * N, 24, device=dev)
+    cam = torch.empty(B, N, 36, device=dev) if c2w_d is not None else None
+    with _lib.on_device(dev):
+        _lib.check(_lib.lib().ocrf_geometry_blocks(
+            B, N, *[_lib.ptr(t) for t in ts], _lib.ptr(c2w_d), int(image_shapes[0]), int(image_shapes[1]),
+            ctypes.c_float(znear), ctypes.c_float(zfar), _lib.ptr(lss), _lib.ptr(ht), _lib.ptr(cam),
+            _lib.stream_ptr(dev)), 'ocrf_geometry_blocks')
+    return lss, ht, cam
+
+
 def ht_project_hip(ref_template, cam_block, B, N, pc_range, image_shapes, depth_range):
     """HIP ``get_sampling_point`` outputs that the colour sampling needs (view_transformer_ocrf.py:
     687-740, 1057-1066): -> pix (B,N,Z,Nq,2) pixel coordinates, mask (B,N,Z,Nq) bool, voxel

@@ -460,7 +460,7 @@ class _Geometry:
     """Everything ``view_transform_core`` derives from the calibration alone: both rank-vector sets,
     voxel centres, pillar projections and their validity (view_transformer.py:108-147,197-255;
     view_transformer_ocrf.py:651-740,785-852)."""
-    __slots__ = ('lss', 'ht', 'voxel', 'pix', 'mask', 'calib', 'c2w', 'cam_rows', 'plans')
+    __slots__ = ('lss', 'ht', 'voxel', 'pix', 'mask', 'calib', 'c2w', 'cam_rows', 'plans', 'cam_rows_dev')
 
 
 class OcRFViewTransformerFull(nn.Module):
@@ -514,6 +514,10 @@ class OcRFViewTransformerFull(nn.Module):
             dim=13, dim_head=8, heads=1, dropout=0.1, downsample_factor=4, offset_scale=4, offset_groups=None,
             offset_kernel_size=6)
         self._geo, self._tmpl, self._bg = None, None, None
+        # forward-only mode: per-forward calibration algebra on the GPU (ocrf_geometry_blocks) when the calibration
+        # tensors arrive there — no device read-back, no synchronisation in the forward (see ``_geometry``)
+        self.device_geometry = False
+        self._pin_ring = None
         # eval-mode strands on side HIP streams (see _core_fused); off by default: a caller that runs the
         # module under its own stream discipline should opt in
         self.parallel_branches, self._transient = False, hoa._LaunchCache()     # streams: not module state
@@ -561,16 +565,26 @@ class OcRFViewTransformerFull(nn.Module):
         x = input[0]
         dev = x.device
         B, N, _, Hf, Wf = x.shape
-        # the per-camera 3x3 algebra stays on the host, as the same torch calls the reference makes
-        # (a handful of (B,N,3,3) tensors; the reference moves them to the host itself, :1086-1088)
-        host = self._to_host(list(input[1:7]) + [input[11]])
-        calib = host[:6]
         geo = _Geometry()
-        geo.calib, geo.c2w, geo.cam_rows, geo.plans = calib, host[6], {}, {}
+        geo.cam_rows, geo.plans, geo.cam_rows_dev = {}, {}, None
+        on_dev = all(torch.is_tensor(t) and t.is_cuda for t in list(input[1:7]) + [input[11]])
+        if getattr(self, 'device_geometry', False) and not sync and on_dev:
+            # forward-only path with the calibration already on the GPU: the tiny per-camera algebra runs there
+            # too (ocrf_geometry_blocks) — nothing in the forward reads the device or waits for it.  ~1 ulp from
+            # the host formulation below, which stays the default (and the one the rank fixtures pin bit for bit)
+            lss_block, ht_block, geo.cam_rows_dev = index_prep.geometry_blocks_hip(
+                *input[1:7], input[11], self.input_size, self.znear, self.zfar)
+            geo.calib = geo.c2w = None
+        else:
+            # the per-camera 3x3 algebra on the host, as the same torch calls the reference makes
+            # (a handful of (B,N,3,3) tensors; the reference moves them to the host itself, :1086-1088)
+            host = self._to_host(list(input[1:7]) + [input[11]])
+            calib = host[:6]
+            geo.calib, geo.c2w = calib, host[6]
+            lss_block = index_prep.lss_camera_block(*calib).to(dev)
+            lidar2img, img_aug, _, _ = index_prep.get_projection(*calib)
+            ht_block = index_prep.ht_camera_block(lidar2img, img_aug).to(dev)
         gx, gy, gz = (int(v) for v in self.grid_size.tolist())
-        lss_block = index_prep.lss_camera_block(*calib).to(dev)
-        lidar2img, img_aug, _, _ = index_prep.get_projection(*calib)
-        ht_block = index_prep.ht_camera_block(lidar2img, img_aug).to(dev)
         frustum, tmpl = self._templates(dev)
         geo.lss = index_prep.voxel_pooling_prepare_v2_hip(frustum, lss_block, B, N, self.grid_lower_bound,
                                                           self.grid_interval, self.grid_size,
@@ -609,6 +623,16 @@ class OcRFViewTransformerFull(nn.Module):
         (B) int32 and the rasteriser's packed camera rows (B,36).  The rows are cached per (sample,
         camera) for the lifetime of ``geo``; with ``out`` (a dict from an earlier call) the values are
         copied into its tensors in place — the static inputs of a captured graph."""
+        if getattr(geo, 'cam_rows_dev', None) is not None:
+            # device geometry: the rows of every camera-frame are already on the GPU; pick the chosen ones there
+            sel_d = self._small_h2d(torch.tensor(list(cam_idx_list), dtype=torch.int32), device)
+            packed = geo.cam_rows_dev[torch.arange(len(cam_idx_list), device=device), sel_d.long()].contiguous()
+            if out is None:
+                return dict(cam_sel=sel_d, packed=packed, cam_idx_list=list(cam_idx_list))
+            out['cam_sel'].copy_(sel_d)
+            out['packed'].copy_(packed)
+            out['cam_idx_list'] = list(cam_idx_list)
+            return out
         rows = []
         for bs, c in enumerate(cam_idx_list):
             if (bs, c) not in geo.cam_rows:
@@ -640,6 +664,24 @@ class OcRFViewTransformerFull(nn.Module):
         slot[2] = torch.cuda.Event()
         slot[2].record(torch.cuda.current_stream(device))
         out['cam_idx_list'] = list(cam_idx_list)
+        return out
+
+    def _small_h2d(self, host_tensor, device):
+        """A few host integers to the device without a hidden wait: through a ring of PINNED slots (an asynchronous
+        copy out of pageable memory blocks the host until the stream reaches it), each guarded by an event."""
+        if self._pin_ring is None:
+            self._pin_ring = dict(slots=[[torch.empty(64, dtype=torch.int32).pin_memory(), None] for _ in range(8)], i=0)
+        ring = self._pin_ring
+        slot = ring['slots'][ring['i']]
+        ring['i'] = (ring['i'] + 1) % len(ring['slots'])
+        if slot[1] is not None:
+            slot[1].synchronize()
+        n = host_tensor.numel()
+        slot[0][:n].copy_(host_tensor.reshape(-1))
+        out = torch.empty(n, dtype=torch.int32, device=device)
+        out.copy_(slot[0][:n], non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream(device))
         return out
 
     # -------------------------------------------------------------------------------- packs
