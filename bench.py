@@ -346,7 +346,7 @@ def main():
                 t.close()
         hp.overlap = was
     # ---- the step with the index preparation inside (the reference with accelerate=False) ---------------------
-    per_step_ms = None
+    per_step_ms = per_step_devgeom_ms = None
     if shard in ('none', 'samples') and args.index_prep == 'cached' and not args.no_per_step:
         hp2 = hotpath.HotPath(cfg, dev, index_prep_mode='per_step', overlap=not args.no_overlap)
         n2 = max(5, min(args.steps, 50))
@@ -354,6 +354,11 @@ def main():
             hp2.step(depth, feat)
         per_step_ms = 1e3 * timed(lambda: hp2.step(depth, feat), n2, world, dev) / n2
         del hp2
+        hp3 = hotpath.HotPath(cfg, dev, index_prep_mode='per_step', overlap=not args.no_overlap, device_geometry=True)
+        for _ in range(3):
+            hp3.step(depth, feat)
+        per_step_devgeom_ms = 1e3 * timed(lambda: hp3.step(depth, feat), n2, world, dev) / n2
+        del hp3
     # ---- weak-scaling secondary of the sharded default: every rank a whole sample ---------------------------
     samples_layout = None
     if shard == 'camera_frames':
@@ -442,7 +447,8 @@ def main():
             'value': voxels / elapsed, 'unit': 'BEV voxels/s',
             'rendered_views_per_sec': views / elapsed,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * elapsed / args.steps, 'per_step_ms': per_step_ms, 'higher_is_better': True,
+            'ms_per_step': 1e3 * elapsed / args.steps, 'per_step_ms': per_step_ms,
+            'per_step_device_geometry_ms': per_step_devgeom_ms, 'higher_is_better': True,
             'scaling': 'strong' if strong else 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': cfg.name, 'cams': cfg.n_cams, 'frames_per_gpu': cfg.n_frames,
@@ -453,7 +459,9 @@ def main():
                        'streams': ('main: pools + HOA; side HIP stream: renders' if hp.overlap and cfg.render
                                    else 'single stream'),
                        'index_prep': 'cached (accelerate=True semantics); per_step_ms = the same step with the HIP index '
-                                     'preparation inside (accelerate=False semantics, the reference\'s working mode)'
+                                     'preparation inside (accelerate=False semantics, the reference\'s working mode), calibration '
+                                     'algebra on the host as the reference\'s own torch calls (rank vectors bit-exact); '
+                                     'per_step_device_geometry_ms = the same with that algebra on the GPU too'
                                      if args.index_prep == 'cached' else 'per step, HIP (accelerate=False semantics)',
                        'sharding': sharding_desc},
             'roofline': roofline,

@@ -42,7 +42,7 @@ class PoolPlan:
 
 
 class HotPath:
-    def __init__(self, cfg, device, cams=None, index_prep_mode='cached', overlap=True):
+    def __init__(self, cfg, device, cams=None, index_prep_mode='cached', overlap=True, device_geometry=False):
         """``cams``: optional list of camera indices this instance owns (camera sharding).
         ``index_prep_mode``: 'cached' — rank vectors computed once per calibration, the reference's
         ``accelerate=True`` intent; 'per_step' — recomputed inside every ``step()`` by the HIP index
@@ -52,6 +52,9 @@ class HotPath:
         self.batch = cfg.batch * cfg.n_frames                  # frames ride along as batch entries
         assert index_prep_mode in ('cached', 'per_step')
         self.index_prep_mode = index_prep_mode
+        # per-step mode only: the per-camera calibration algebra on the GPU too (ocrf_geometry_blocks; ~1 ulp from
+        # the host formulation, so a 1e-5 fraction of border points may change cell) instead of on the host
+        self.device_geometry = bool(device_geometry)
         # the renders are independent of the poolings: with ``overlap`` they run on ONE side HIP stream
         # beside the pools + HOA of the main stream (the blend is VALU-bound with a ragged tail, the pools
         # and the small HOA kernels are latency / L2-bound: they interleave).  One stream per frame was
@@ -83,7 +86,8 @@ class HotPath:
                                                                 device='cpu')[0].to(dev).contiguous()
         self._grid = index_prep.grid_infos(cfg.grid)
         self._lss_bufs, self._ht_bufs = index_prep._RankBuffers(), index_prep._RankBuffers()
-        self.lss, self.ht = self.prepare_indices_hip(sync=True)
+        self.lss, self.ht = self.prepare_indices_hip(sync=True)       # (host algebra: `_calib_dev` does not exist yet)
+        self._calib_dev = [t.to(dev) for t in self._calib_host]
         # cached plans must not alias the grow-only buffers the per-step preparation writes into
         for plan in (self.lss, self.ht):
             for name in ('ranks_bev', 'ranks_depth', 'ranks_feat', 'starts', 'lengths'):
@@ -249,9 +253,12 @@ class HotPath:
         Hf, Wf = cfg.feat_hw
         args = self._calib_host
         B, N = args[1].shape[:2]
-        lss_block = index_prep.lss_camera_block(*args).to(dev, non_blocking=True)
-        lidar2img, img_aug, _, _ = index_prep.get_projection(*args)
-        ht_block = index_prep.ht_camera_block(lidar2img, img_aug).to(dev, non_blocking=True)
+        if self.device_geometry and hasattr(self, '_calib_dev'):
+            lss_block, ht_block, _ = index_prep.geometry_blocks_hip(*self._calib_dev, None, cfg.input_size)
+        else:
+            lss_block = index_prep.lss_camera_block(*args).to(dev, non_blocking=True)
+            lidar2img, img_aug, _, _ = index_prep.get_projection(*args)
+            ht_block = index_prep.ht_camera_block(lidar2img, img_aug).to(dev, non_blocking=True)
         lss = index_prep.voxel_pooling_prepare_v2_hip(self._frustum_dev, lss_block, B, N, *self._grid,
                                                       buffers=self._lss_bufs, sync=False)
         ht = index_prep.fast_sample_prepare_hip(self._ref_template, ht_block, B, N, list(cfg.pc_range), cfg.input_size,
