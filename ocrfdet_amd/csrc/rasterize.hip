@@ -496,8 +496,8 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
     unsigned* __restrict__ out_n_contrib, int* __restrict__ status, BwdArgs bw, int vps) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long rec[];
   float4* l_a = reinterpret_cast<float4*>(rec + kCapRec);          // x, y, conic.x, conic.y
-  float4* l_b = l_a + kStage;                                      // conic.z, opacity, depth, r
-  float4* l_c = l_b + kStage;                                      // g, b, coverage bits, -
+  float4* l_b = l_a + kStage;                                      // BWD: conic.z, opacity, depth, r; fwd: see staging
+  float4* l_c = l_b + kStage;                                      // BWD: g, b, coverage bits, -
   unsigned* l_id = reinterpret_cast<unsigned*>(l_c + kStage);     // BWD only
   float* l_g = reinterpret_cast<float*>(l_id + kStage);           // BWD only: [kStage][9]
   __shared__ int l_wtot[kScanUnroll * (kBlock / 64)];
@@ -583,8 +583,10 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
           // rounding of (c dx) dx and of the sum), which removes the -0.5 multiply from the per-record chain;
           // a record that does not cover one of the two tiles is staged with opacity 0 FOR THAT TILE: its alpha
           // is 0 there, below the 1/255 cut, so the pixel loop needs no coverage test at all
-          l_a[tid] = make_float4(p.x, p.y, -0.5f * co.x, co.y);
-          l_b[tid] = make_float4((cov & 1u) ? co.w : 0.f, (cov & 2u) ? co.w : 0.f, -0.5f * co.z, col[0]);
+          // slot order: values that are broadcast into packed ops sit in slots 0-2 of a 16-byte read (hipcc copies a
+          // broadcast operand out of slot 3, one v_mov per record), per-record scalars (cxx, cxy, depth) in slot 3
+          l_a[tid] = make_float4(p.x, p.y, -0.5f * co.z, -0.5f * co.x);
+          l_b[tid] = make_float4((cov & 1u) ? co.w : 0.f, (cov & 2u) ? co.w : 0.f, col[0], co.y);
           l_c[tid] = make_float4(col[1], col[2], __uint_as_float((unsigned)(c >> 32)), __uint_as_float(cov));
         }
       } else if (!BWD && tid < ((ns + 3) & ~3)) {
@@ -607,8 +609,10 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
         // Same arithmetic, same order and therefore the same bits as the mask formulation it replaces
         // (tools/render_hash.py); 4 records per trip, wave-level early exit.
         const int ns4 = (ns + 3) & ~3;
+        f2 h = T - splat(0.5f);
         for (int j0 = 0; j0 < ns4; j0 += 4) {
-          if (__ballot(fmaxf(T.x, T.y) > 0.f) == 0ull) break;
+          // live <=> sign bit of T clear (T is never +-0: a live T is >= 1e-4, a stopped one is -|T|)
+          if (__ballot((__float_as_int(T.x) & __float_as_int(T.y)) >= 0) == 0ull) break;
           float4 ra[4], rb[4], rc4[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
@@ -620,13 +624,13 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
           for (int u = 0; u < 4; ++u) {
             const float4 a = ra[u];
             const float4 b = rb[u];
-            const float cg = rc4[u].x, cb = rc4[u].y, dep = rc4[u].z;
+            const float cr = b.z, cg = rc4[u].x, cb = rc4[u].y, dep = rc4[u].z;
             // power = -0.5 (cxx dx dx + czz dy dy) - cxy dx dy, in the reference's order (forward.cu:320-323)
             const float dx = a.x - pixf_x;
-            const float qx = (a.z * dx) * dx;
-            const float bx = a.w * dx;
+            const float qx = (a.w * dx) * dx;
+            const float bx = b.w * dx;
             const f2 dy = splat(a.y) - pixf_y;
-            const f2 qy = (splat(b.z) * dy) * dy;
+            const f2 qy = (splat(a.z) * dy) * dy;
             const f2 power = (splat(qx) + qy) - splat(bx) * dy;          // qx, qy carry the -0.5 (staging)
             const f2 p2 = power * splat(1.44269504088896340736f);       // __expf(x) = v_exp_f32(log2(e) x)
             f2 G;
@@ -635,24 +639,27 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
             f2 alpha = f2{b.x, b.y} * G;
             alpha.x = fminf(0.99f, alpha.x);
             alpha.y = fminf(0.99f, alpha.y);
-            alpha.x = (power.x > 0.0f) ? 0.f : alpha.x;
-            alpha.y = (power.y > 0.0f) ? 0.f : alpha.y;
-            alpha.x = (alpha.x < 1.0f / 255.0f) ? 0.f : alpha.x;
-            alpha.y = (alpha.y < 1.0f / 255.0f) ? 0.f : alpha.y;
+            // the two "skip this Gaussian" tests share one select: two compares, one 64-bit scalar OR, one v_cndmask
+            alpha.x = ((power.x > 0.0f) | (alpha.x < 1.0f / 255.0f)) ? 0.f : alpha.x;
+            alpha.y = ((power.y > 0.0f) | (alpha.y < 1.0f / 255.0f)) ? 0.f : alpha.y;
             const f2 test_T = T * (splat(1.0f) - alpha);
             const f2 aT = alpha * T;
             const bool stopA = test_T.x < 0.0001f, stopB = test_T.y < 0.0001f;
             f2 wgt;
             wgt.x = stopA ? 0.f : aT.x;
             wgt.y = stopB ? 0.f : aT.y;
-            C0 = fma2(splat(b.w), wgt, C0);
+            C0 = fma2(splat(cr), wgt, C0);
             C1 = fma2(splat(cg), wgt, C1);
             C2 = fma2(splat(cb), wgt, C2);
             if constexpr (MEDIAN) {
-              const float mA = (T.x > 0.5f) ? test_T.x : 1.0f;
-              const float mB = (T.y > 0.5f) ? test_T.y : 1.0f;
-              D.x = (mA < 0.5f) ? dep : D.x;
-              D.y = (mB < 0.5f) ? dep : D.y;
+              // T > 0.5 and test_T < 0.5  <=>  (T - 0.5)(test_T - 0.5) < 0: T never rises, a stopped pixel's -|T| and its
+              // test_T are both below 0.5, and a non-zero |x - 0.5| is >= 2^-25, so the product cannot underflow.  h is
+              // carried: the next record's T is this record's test_T unless the pixel stops, and then both are < 0.5.
+              const f2 h2 = test_T - splat(0.5f);
+              const f2 cross = h * h2;
+              D.x = (cross.x < 0.f) ? dep : D.x;
+              D.y = (cross.y < 0.f) ? dep : D.y;
+              h = h2;
             } else {
               D = fma2(splat(dep), wgt, D);
             }
