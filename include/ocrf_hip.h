@@ -382,6 +382,8 @@ int ocrf_hoa_gated_conv1x1(const float *x, const float *gate, int B, int C, int 
  * down/up = bilinear align_corners=True to/from (Y/6, X/6).  opacity, alpha: (B,13,Y,X).
  * weights: ocrf_hoa1_weights_len() floats packed as documented in csrc/hoa.hip (the Python module
  * packs its state_dict).  att_workspace: B*((13+8)*(Y/6)*(X/6) + 18*128) floats.  (Y/6)*(X/6) <= 1600.
+ * Two kernel launches: the key / value tokens (one workgroup per group of kv tokens rebuilds the rows of q its
+ * offset convolution reads), then attention + output projection + upsample + residual per 16x16 output tile.
  */
 int ocrf_hoa1_forward(const float *opacity, const float *alpha, const float *weights, int B, int Y, int X,
                       float offset_scale, float *att_workspace, float *out, ocrf_stream_t stream);
@@ -539,9 +541,9 @@ enum {
   OCRF_K_HOA_HEIGHT_GATE = 23,   /* hoa_height_gate_kernel / hoa_height_gate_from_tiles_kernel */
   OCRF_K_HOA_UNET_BLOCK = 24,    /* hoa_unet_block_kernel */
   OCRF_K_HOA_OUT_CONV = 25,      /* hoa_gated_conv1x1_kernel */
-  OCRF_K_HOA1_ATTN = 26,         /* hoa1_attention_kernel */
-  OCRF_K_HOA1_UP = 27,           /* hoa1_upsample_residual_kernel */
-  OCRF_K_HOA1_Q = 28,            /* hoa1_q_kernel */
+  OCRF_K_HOA1_ATTN = 26,         /* hoa1_attention_upsample_kernel */
+  OCRF_K_HOA1_UP = 27,           /* unused since round 2 (fused into OCRF_K_HOA1_ATTN) */
+  OCRF_K_HOA1_Q = 28,            /* unused since round 2 (q is rebuilt by its consumers) */
   OCRF_K_HOA1_KV = 29,           /* hoa1_kv_kernel */
   OCRF_K_HOA_DW3X3 = 30,         /* hoa_dw3x3_kernel */
   OCRF_K_HOA_DW3X3_WGRAD = 31,   /* hoa_dw3x3_wgrad_kernel */

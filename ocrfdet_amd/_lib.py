@@ -288,6 +288,7 @@ K_RASTER_PREPROCESS, K_RASTER_BLEND, K_RASTER_GATHER = 10, 11, 12
 K_RASTER_SCAN, K_RASTER_BLEND_BWD, K_RASTER_PRE_BWD = 13, 15, 16
 K_LSS_KEYS, K_RADIX_HIST, K_SCAN, K_RADIX_SCATTER, K_LSS_BOUNDS, K_LSS_EMIT, K_HT_COUNT, K_HT_EMIT = range(40, 48)
 K_HOA_STATS, K_HOA_MASK_GATE, K_HOA_HEIGHT_MAX, K_HOA_HEIGHT_GATE = 20, 21, 22, 23
+K_HOA_UNET_BLOCK, K_HOA_OUT_CONV, K_HOA1_ATTN, K_HOA1_KV = 24, 25, 26, 29
 
 
 class KernelTimer:

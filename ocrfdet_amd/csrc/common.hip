@@ -83,9 +83,9 @@ const char* ocrf_kernel_name(int kernel_id) {
     case OCRF_K_HOA_HEIGHT_GATE: return "hoa_height_gate_kernel";
     case OCRF_K_HOA_UNET_BLOCK: return "hoa_unet_block_kernel";
     case OCRF_K_HOA_OUT_CONV: return "hoa_gated_conv1x1_kernel";
-    case OCRF_K_HOA1_ATTN: return "hoa1_attention_kernel";
-    case OCRF_K_HOA1_UP: return "hoa1_upsample_residual_kernel";
-    case OCRF_K_HOA1_Q: return "hoa1_q_kernel";
+    case OCRF_K_HOA1_ATTN: return "hoa1_attention_upsample_kernel";
+    case OCRF_K_HOA1_UP: return "(unused)";
+    case OCRF_K_HOA1_Q: return "(unused)";
     case OCRF_K_HOA1_KV: return "hoa1_kv_kernel";
     case OCRF_K_HOA_DW3X3: return "hoa_dw3x3_kernel";
     case OCRF_K_HOA_DW3X3_WGRAD: return "hoa_dw3x3_wgrad_kernel";

@@ -1013,46 +1013,19 @@ __device__ __forceinline__ float bilinear_ac(const float* __restrict__ p, int H,
   return top * (1.f - ly) + bot * ly;
 }
 
-// q = to_q(downsample(opacity)) for every token, once per batch entry: qbuf (B, ntok, 8), unscaled.
-__global__ __launch_bounds__(kBlock) void hoa1_q_kernel(const float* __restrict__ opacity,
-                                                        const float* __restrict__ wts, int Y, int X, int hq, int wq,
-                                                        float* __restrict__ qbuf) {
-  __shared__ float s_wq[kHI * kHD];
-  const int tid = threadIdx.x, b = blockIdx.y;
-  if (tid < kHI * kHD) s_wq[tid] = wts[oQ + tid];
-  __syncthreads();
-  const int ntok = hq * wq;
-  const int t = blockIdx.x * kBlock + tid;
-  if (t >= ntok) return;
-  const long plane = (long)Y * X;
-  const float* op = opacity + (long)b * kHD * plane;
-  const float ry = hq > 1 ? (float)(Y - 1) / (float)(hq - 1) : 0.f, rx = wq > 1 ? (float)(X - 1) / (float)(wq - 1) : 0.f;
-  const int ty = t / wq, tx = t % wq;
-  float q[kHI];
-#pragma unroll
-  for (int d = 0; d < kHI; ++d) q[d] = 0.f;
-  for (int c = 0; c < kHD; ++c) {
-    const float v = bilinear_ac(op + c * plane, Y, X, ry * (float)ty, rx * (float)tx);
-#pragma unroll
-    for (int d = 0; d < kHI; ++d) q[d] = fmaf(s_wq[d * kHD + c], v, q[d]);
-  }
-#pragma unroll
-  for (int d = 0; d < kHI; ++d) qbuf[((long)b * ntok + t) * kHI + d] = q[d];
-}
-
 // kv tokens of one batch entry (one workgroup): offsets (depthwise 6x6 stride 4 pad 1 -> GELU ->
 // 1x1 -> tanh -> * scale), sampling grid, bilinear sample (zeros padding, align_corners=False) of
 // downsample(alpha), k and v.  kvbuf (B, nkv, 18) = k[8] | v[8] | grid[2].
-__global__ __launch_bounds__(kBlock) void hoa1_kv_kernel(const float* __restrict__ qbuf,
+__global__ __launch_bounds__(kBlock) void hoa1_kv_kernel(const float* __restrict__ opacity,
                                                          const float* __restrict__ alpha,
                                                          const float* __restrict__ wts, int Y, int X, int hq, int wq,
-                                                         int hk, int wk, float offset_scale,
+                                                         int hk, int wk, float offset_scale, int q_rows_cap,
                                                          float* __restrict__ kvbuf) {
   extern __shared__ float sm[];
   float* s_w = sm;                                  // kHoaWeights
-  float* s_q = s_w + ((kHoaWeights + 3) & ~3);      // [ntok][8]
-  const int ntok = hq * wq, nkv = hk * wk;
-  float* s_gl = s_q + ntok * kHI;                   // [nkv][8] GELU(offset conv)
+  float* s_q = s_w + ((kHoaWeights + 3) & ~3);      // [rows of the q map this workgroup's offset conv reads][wq][8]
+  const int nkv = hk * wk;
+  float* s_gl = s_q + q_rows_cap * wq * kHI;        // [nkv][8] GELU(offset conv)
   float* s_f = s_gl + nkv * kHI;                    // [nkv][2] sampling position in the (hq,wq) map
   float* s_kv = s_f + nkv * 2;                      // [nkv][13] sampled alpha
   // grid (G, B): workgroup g of a sample owns kv tokens [j0, j1) — the phases are latency chains (36-tap
@@ -1065,19 +1038,53 @@ __global__ __launch_bounds__(kBlock) void hoa1_kv_kernel(const float* __restrict
   const float* al = alpha + (long)b * kHD * plane;
   float* out = kvbuf + (long)b * nkv * 18;
   for (int i = tid; i < kHoaWeights; i += kBlock) s_w[i] = wts[i];
-  for (int i = tid; i < ntok * kHI; i += kBlock) s_q[i] = qbuf[(long)b * ntok * kHI + i];
+  // the 6x6 stride-4 offset conv of kv rows [j0 / wk, (j1 - 1) / wk] reads q rows [4 ky - 1, 4 ky + 4]: q is rebuilt
+  // here for exactly those rows (no q launch, no q buffer); 6 of 33 rows for one kv row at BEV 200 x 200.  The
+  // taps of the first batch of tokens are in flight together with the weights (one memory round trip, not two).
+  const int qy_lo = max(0, (j0 / wk) * 4 - 1), qy_hi = min(hq - 1, ((j1 - 1) / wk) * 4 + 4);
+  const float* op = opacity + (long)b * kHD * plane;
+  const float ry = hq > 1 ? (float)(Y - 1) / (float)(hq - 1) : 0.f, rx = wq > 1 ? (float)(X - 1) / (float)(wq - 1) : 0.f;
+  const int nq = (qy_hi - qy_lo + 1) * wq;
+  for (int i0 = 0; i0 < nq; i0 += kBlock) {
+    const int i = i0 + tid;
+    float tok[kHD];
+    if (i < nq) {
+#pragma unroll
+      for (int c = 0; c < kHD; ++c)
+        tok[c] = bilinear_ac(op + c * plane, Y, X, ry * (float)(qy_lo + i / wq), rx * (float)(i % wq));
+    }
+    if (i0 == 0) __syncthreads();          // weights
+    if (i < nq) {
+      float q[kHI];
+#pragma unroll
+      for (int d = 0; d < kHI; ++d) q[d] = 0.f;
+#pragma unroll
+      for (int c = 0; c < kHD; ++c) {
+#pragma unroll
+        for (int d = 0; d < kHI; ++d) q[d] = fmaf(s_w[oQ + d * kHD + c], tok[c], q[d]);
+      }
+#pragma unroll
+      for (int d = 0; d < kHI; ++d) s_q[i * kHI + d] = q[d];
+    }
+  }
   __syncthreads();
   for (int i = tid; i < nj * kHI; i += kBlock) {           // one (kv token, channel) per thread
     const int j = j0 + i / kHI, d = i % kHI;
     const int ky = j / wk, kx = j % wk;
     float a = s_w[oDB + d];
+    // zero padding: a tap outside the map is read at a clamped position with weight 0 (a + 0 = a), which keeps the
+    // 36 LDS reads independent of the bounds tests and in flight together
+#pragma unroll
     for (int u = 0; u < 6; ++u) {
       const int yy = ky * 4 - 1 + u;
-      if (yy < 0 || yy >= hq) continue;
+      const bool yin = yy >= 0 && yy < hq;
+      const int yc = min(max(yy, qy_lo), qy_hi) - qy_lo;
+#pragma unroll
       for (int v = 0; v < 6; ++v) {
         const int xx = kx * 4 - 1 + v;
-        if (xx < 0 || xx >= wq) continue;
-        a = fmaf(s_w[oDW + d * 36 + u * 6 + v], s_q[(yy * wq + xx) * kHI + d], a);
+        const bool in = yin && xx >= 0 && xx < wq;
+        const float w = in ? s_w[oDW + d * 36 + u * 6 + v] : 0.f;
+        a = fmaf(w, s_q[(yc * wq + min(max(xx, 0), wq - 1)) * kHI + d], a);
       }
     }
     s_gl[j * kHI + d] = 0.5f * a * (1.f + erff(a * 0.70710678118654752f));            // nn.GELU (exact)
@@ -1100,19 +1107,23 @@ __global__ __launch_bounds__(kBlock) void hoa1_kv_kernel(const float* __restrict
     s_f[j * 2 + 1] = ((gy + 1.f) * (float)hq - 1.f) * 0.5f;
   }
   __syncthreads();
-  const float ry = hq > 1 ? (float)(Y - 1) / (float)(hq - 1) : 0.f, rx = wq > 1 ? (float)(X - 1) / (float)(wq - 1) : 0.f;
   for (int i = tid; i < nj * kHD; i += kBlock) {           // one (kv token, alpha channel) per thread
     const int j = j0 + i / kHD, c = i % kHD;
     const float fx = s_f[j * 2], fy = s_f[j * 2 + 1];
     const int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
+    // zeros padding: a tap outside the map is read at a clamped position with weight 0 (the sum is unchanged:
+    // the volumes are finite), so that the 16 loads of the four taps are independent
+    float val[4], wt[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
+      const bool in = xi >= 0 && xi < wq && yi >= 0 && yi < hq;
+      wt[t] = in ? (1.f - fabsf(fx - (float)xi)) * (1.f - fabsf(fy - (float)yi)) : 0.f;
+      val[t] = bilinear_ac(al + c * plane, Y, X, ry * (float)min(max(yi, 0), hq - 1), rx * (float)min(max(xi, 0), wq - 1));
+    }
     float acc = 0.f;
-    for (int dy = 0; dy < 2; ++dy)
-      for (int dx = 0; dx < 2; ++dx) {
-        const int xi = x0 + dx, yi = y0 + dy;
-        if (xi < 0 || xi >= wq || yi < 0 || yi >= hq) continue;
-        const float w = (1.f - fabsf(fx - (float)xi)) * (1.f - fabsf(fy - (float)yi));
-        acc = fmaf(bilinear_ac(al + c * plane, Y, X, ry * (float)yi, rx * (float)xi), w, acc);
-      }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = fmaf(val[t], wt[t], acc);
     s_kv[j * kHD + c] = acc;
   }
   __syncthreads();
@@ -1128,88 +1139,139 @@ __global__ __launch_bounds__(kBlock) void hoa1_kv_kernel(const float* __restrict
   }
 }
 
-// attention: one query token per thread, kv tokens of the batch entry in LDS, online softmax
-constexpr int kAttSplit = 4;      // lanes per query token: each takes every 4th kv token, merged by shuffles
-__global__ __launch_bounds__(kBlock) void hoa1_attention_kernel(
-    const float* __restrict__ qbuf, const float* __restrict__ kvbuf, const float* __restrict__ wts, int hq, int wq,
-    int nkv, float* __restrict__ att) {
+// attention + to_out + bilinear upsample + residual of one 16x16 output tile.  The tile's pixels interpolate between
+// at most kTT x kTT tokens of the (hq, wq) attention map ((hq - 1) / (Y - 1) < 1/6: 15 pixels span < 2.5 tokens); the
+// workgroup rebuilds q for those tokens from the opacity volume, runs their attention over the sample's kv tokens
+// (LDS, online softmax, kAttSplit lanes per token merged by a fixed DPP butterfly) and keeps the 13 output channels
+// in LDS for the interpolation: no q / attention buffers and no separate upsample launch.  Tokens shared by
+// neighbouring tiles are recomputed (a token's attention is ~6 k flops).  The kernel is a latency chain on a chip
+// it cannot fill (338 workgroups at 2 x 200 x 200), so every global load — the token's 52 bilinear taps, the pixel's
+// 13 residual values, weights and kv tokens — is issued before the first barrier.
+constexpr int kAttSplit = 8, kTP = 16, kTT = 5;
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppMirror8 = 0x141;   // quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror
+template <int CTRL>
+__device__ __forceinline__ float hoa_dpp(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+
+__global__ __launch_bounds__(kBlock) void hoa1_attention_upsample_kernel(
+    const float* __restrict__ opacity, const float* __restrict__ kvbuf, const float* __restrict__ wts, int Y, int X,
+    int hq, int wq, int nkv, float* __restrict__ out) {
   extern __shared__ float sm[];
   float* s_w = sm;                                  // kHoaWeights
   float* s_kv = s_w + ((kHoaWeights + 3) & ~3);     // [nkv][18]
-  const int tid = threadIdx.x, b = blockIdx.y, nthr = blockDim.x;
-  const int ntok = hq * wq;
-  for (int i = tid; i < kHoaWeights; i += nthr) s_w[i] = wts[i];
-  for (int i = tid; i < nkv * 18; i += nthr) s_kv[i] = kvbuf[(long)b * nkv * 18 + i];
-  __syncthreads();
-  // one query token per kAttSplit adjacent lanes (a query's 64 key / value tokens in sequence on one lane kept
-  // 36 single-wave workgroups busy for 24 us); lanes past the last token compute on a clamped one and store nothing
-  const int tq = (blockIdx.x * nthr + tid) / kAttSplit, part = tid % kAttSplit;
-  const bool valid = tq < ntok;
-  const int t = min(tq, ntok - 1);
-  const int ty = t / wq, tx = t % wq;
-  const float scale = 0.35355339059327373f;               // dim_head ** -0.5
-  float q[kHI];
-#pragma unroll
-  for (int d = 0; d < kHI; ++d) q[d] = qbuf[((long)b * ntok + t) * kHI + d] * scale;
-  // query grid: create_grid_like(x_kv) normalised with dim=0 -> x over (h-1), y over (w-1)
-  const float qx = 2.0f * (float)tx / (float)max(hq - 1, 1) - 1.0f, qy = 2.0f * (float)ty / (float)max(wq - 1, 1) - 1.0f;
-  float m = -INFINITY, l = 0.f, acc[kHI];
-#pragma unroll
-  for (int d = 0; d < kHI; ++d) acc[d] = 0.f;
-  for (int j = part; j < nkv; j += kAttSplit) {
-    const float* kv = s_kv + j * 18;
-    float s = 0.f;
-#pragma unroll
-    for (int d = 0; d < kHI; ++d) s = fmaf(q[d], kv[d], s);
-    // CPB (cross_attention_2d.py:74-89)
-    const float px = qx - kv[16], py = qy - kv[17];
-    const float bx = copysignf(__logf(fabsf(px) + 1.f), px), by = copysignf(__logf(fabsf(py) + 1.f), py);
-    float h0[3], h1[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) h0[i] = fmaxf(fmaf(s_w[oC0W + i * 2], bx, fmaf(s_w[oC0W + i * 2 + 1], by, s_w[oC0B + i])), 0.f);
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-      h1[i] = fmaxf(s_w[oC1B + i] + s_w[oC1W + i * 3] * h0[0] + s_w[oC1W + i * 3 + 1] * h0[1] + s_w[oC1W + i * 3 + 2] * h0[2], 0.f);
-    s += s_w[oC2B] + s_w[oC2W] * h1[0] + s_w[oC2W + 1] * h1[1] + s_w[oC2W + 2] * h1[2];
-    const float mn = fmaxf(m, s);
-    const float corr = __expf(m - mn), p = __expf(s - mn);
-    l = l * corr + p;
-#pragma unroll
-    for (int d = 0; d < kHI; ++d) acc[d] = fmaf(p, kv[8 + d], acc[d] * corr);
-    m = mn;
-  }
-  // merge the kAttSplit partial softmax states (fixed butterfly: deterministic)
-#pragma unroll
-  for (int off = 1; off < kAttSplit; off <<= 1) {
-    const float mo = __shfl_xor(m, off), lo = __shfl_xor(l, off);
-    const float mn = fmaxf(m, mo);
-    const float c1 = (m == -INFINITY) ? 0.f : __expf(m - mn), c2 = (mo == -INFINITY) ? 0.f : __expf(mo - mn);
-    l = l * c1 + lo * c2;
-#pragma unroll
-    for (int d = 0; d < kHI; ++d) acc[d] = acc[d] * c1 + __shfl_xor(acc[d], off) * c2;
-    m = mn;
-  }
-  if (!valid) return;
-  const float inv = 1.f / l;
-  for (int c = part; c < kHD; c += kAttSplit) {          // the output projection's channels are shared out too
-    float o = s_w[oOB + c];
-#pragma unroll
-    for (int d = 0; d < kHI; ++d) o = fmaf(s_w[oO + c * kHI + d], acc[d] * inv, o);
-    att[((long)b * kHD + c) * ntok + t] = o;
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void hoa1_upsample_residual_kernel(const float* __restrict__ att,
-                                                                        const float* __restrict__ opacity, int C,
-                                                                        int Y, int X, int hq, int wq,
-                                                                        float* __restrict__ out) {
+  __shared__ float s_att[kTT * kTT * kHD];
+  const int tid = threadIdx.x, b = blockIdx.z;
   const long plane = (long)Y * X;
-  const long pix = (long)blockIdx.x * kBlock + threadIdx.x;
-  const long bc = blockIdx.y;
-  if (pix >= plane) return;
-  const int y = (int)(pix / X), x = (int)(pix % X);
-  const float ry = Y > 1 ? (float)(hq - 1) / (float)(Y - 1) : 0.f, rx = X > 1 ? (float)(wq - 1) / (float)(X - 1) : 0.f;
-  out[bc * plane + pix] = bilinear_ac(att + bc * hq * wq, hq, wq, ry * (float)y, rx * (float)x) + opacity[bc * plane + pix];
+  const float* op = opacity + (long)b * kHD * plane;
+  // token window of the tile: the bilinear_ac taps of its first and last pixel
+  const float dy = Y > 1 ? (float)(hq - 1) / (float)(Y - 1) : 0.f, dx = X > 1 ? (float)(wq - 1) / (float)(X - 1) : 0.f;
+  const int py0 = blockIdx.y * kTP, px0 = blockIdx.x * kTP;
+  const int py1 = min(py0 + kTP, Y) - 1, px1 = min(px0 + kTP, X) - 1;
+  const int ty0 = min((int)(dy * (float)py0), hq - 1), tx0 = min((int)(dx * (float)px0), wq - 1);
+  const int ty1 = min(min((int)(dy * (float)py1), hq - 1) + 1, hq - 1), tx1 = min(min((int)(dx * (float)px1), wq - 1) + 1, wq - 1);
+  const int nty = ty1 - ty0 + 1, ntx = tx1 - tx0 + 1;       // <= kTT each
+  const int tl = tid / kAttSplit, part = tid % kAttSplit;
+  const bool has = tl < nty * ntx;
+  const int lt = has ? tl : 0;                               // idle lanes of a live wave run token 0
+  const int ty = ty0 + lt / ntx, tx = tx0 + lt % ntx;
+  const float ry = hq > 1 ? (float)(Y - 1) / (float)(hq - 1) : 0.f, rx = wq > 1 ? (float)(X - 1) / (float)(wq - 1) : 0.f;
+  // ---- all global loads ----
+  float tok[kHD];
+#pragma unroll
+  for (int c = 0; c < kHD; ++c) tok[c] = 0.f;
+  if (tl < kTT * kTT) {
+#pragma unroll
+    for (int c = 0; c < kHD; ++c) tok[c] = bilinear_ac(op + c * plane, Y, X, ry * (float)ty, rx * (float)tx);
+  }
+  const int y = py0 + tid / kTP, x = px0 + tid % kTP;
+  const bool inside = y < Y && x < X;
+  const long pix = (long)min(y, Y - 1) * X + min(x, X - 1);
+  float res[kHD];
+#pragma unroll
+  for (int c = 0; c < kHD; ++c) res[c] = op[c * plane + pix];
+  for (int i = tid; i < kHoaWeights; i += kBlock) s_w[i] = wts[i];
+  for (int i = tid; i < nkv * 18; i += kBlock) s_kv[i] = kvbuf[(long)b * nkv * 18 + i];
+  __syncthreads();
+  // ---- attention of the window's tokens: kAttSplit adjacent lanes per token ----
+  if (tl < kTT * kTT) {          // wave-uniform up to the last wave
+    const float scale = 0.35355339059327373f;               // dim_head ** -0.5
+    float q[kHI];
+#pragma unroll
+    for (int d = 0; d < kHI; ++d) q[d] = 0.f;
+#pragma unroll
+    for (int c = 0; c < kHD; ++c) {
+#pragma unroll
+      for (int d = 0; d < kHI; ++d) q[d] = fmaf(s_w[oQ + d * kHD + c], tok[c], q[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < kHI; ++d) q[d] *= scale;
+    // query grid: create_grid_like(x_kv) normalised with dim=0 -> x over (h-1), y over (w-1)
+    const float qx = 2.0f * (float)tx / (float)max(hq - 1, 1) - 1.0f, qy = 2.0f * (float)ty / (float)max(wq - 1, 1) - 1.0f;
+    float m = -INFINITY, l = 0.f, acc[kHI];
+#pragma unroll
+    for (int d = 0; d < kHI; ++d) acc[d] = 0.f;
+#pragma unroll 2
+    for (int j = part; j < nkv; j += kAttSplit) {
+      const float* kv = s_kv + j * 18;
+      float sc = 0.f;
+#pragma unroll
+      for (int d = 0; d < kHI; ++d) sc = fmaf(q[d], kv[d], sc);
+      // CPB (cross_attention_2d.py:74-89)
+      const float px = qx - kv[16], py = qy - kv[17];
+      const float bx = copysignf(__logf(fabsf(px) + 1.f), px), by = copysignf(__logf(fabsf(py) + 1.f), py);
+      float h0[3], h1[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) h0[i] = fmaxf(fmaf(s_w[oC0W + i * 2], bx, fmaf(s_w[oC0W + i * 2 + 1], by, s_w[oC0B + i])), 0.f);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        h1[i] = fmaxf(s_w[oC1B + i] + s_w[oC1W + i * 3] * h0[0] + s_w[oC1W + i * 3 + 1] * h0[1] + s_w[oC1W + i * 3 + 2] * h0[2], 0.f);
+      sc += s_w[oC2B] + s_w[oC2W] * h1[0] + s_w[oC2W + 1] * h1[1] + s_w[oC2W + 2] * h1[2];
+      const float mn = fmaxf(m, sc);
+      const float corr = __expf(m - mn), p = __expf(sc - mn);
+      l = l * corr + p;
+#pragma unroll
+      for (int d = 0; d < kHI; ++d) acc[d] = fmaf(p, kv[8 + d], acc[d] * corr);
+      m = mn;
+    }
+    // merge the kAttSplit partial softmax states: fixed butterfly over the 8 lanes (lane ^ 1, lane ^ 2, 7 - lane)
+    auto merge = [&](auto perm) {
+      const float mo = perm(m), lo = perm(l);
+      const float mn = fmaxf(m, mo);
+      const float c1 = (m == -INFINITY) ? 0.f : __expf(m - mn), c2 = (mo == -INFINITY) ? 0.f : __expf(mo - mn);
+      l = l * c1 + lo * c2;
+#pragma unroll
+      for (int d = 0; d < kHI; ++d) acc[d] = acc[d] * c1 + perm(acc[d]) * c2;
+      m = mn;
+    };
+    merge([](float v) { return hoa_dpp<kDppXor1>(v); });
+    merge([](float v) { return hoa_dpp<kDppXor2>(v); });
+    merge([](float v) { return hoa_dpp<kDppMirror8>(v); });
+    if (has) {
+      const float inv = 1.f / l;
+      for (int c = part; c < kHD; c += kAttSplit) {          // the output projection's channels are shared out too
+        float o = s_w[oOB + c];
+#pragma unroll
+        for (int d = 0; d < kHI; ++d) o = fmaf(s_w[oO + c * kHI + d], acc[d] * inv, o);
+        s_att[lt * kHD + c] = o;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- upsample (bilinear, align_corners) + residual: one pixel per thread, 13 channels ----
+  if (!inside) return;
+  const float sy = dy * (float)y, sx = dx * (float)x;
+  const int y0 = min((int)sy, hq - 1), x0 = min((int)sx, wq - 1);
+  const int y1 = min(y0 + 1, hq - 1), x1 = min(x0 + 1, wq - 1);
+  const float ly = sy - (float)y0, lx = sx - (float)x0;
+  const int i00 = ((y0 - ty0) * ntx + (x0 - tx0)) * kHD, i01 = ((y0 - ty0) * ntx + (x1 - tx0)) * kHD;
+  const int i10 = ((y1 - ty0) * ntx + (x0 - tx0)) * kHD, i11 = ((y1 - ty0) * ntx + (x1 - tx0)) * kHD;
+#pragma unroll
+  for (int c = 0; c < kHD; ++c) {
+    const float top = s_att[i00 + c] * (1.f - lx) + s_att[i01 + c] * lx;
+    const float bot = s_att[i10 + c] * (1.f - lx) + s_att[i11 + c] * lx;
+    out[((long)b * kHD + c) * plane + pix] = (top * (1.f - ly) + bot * ly) + res[c];
+  }
 }
 
 }  // namespace
@@ -1227,26 +1289,19 @@ int ocrf_hoa1_forward(const float* opacity, const float* alpha, const float* wei
   const int hk = (hq + 2 - 6) / 4 + 1, wk = (wq + 2 - 6) / 4 + 1;
   const int ntok = hq * wq, nkv = hk * wk;
   if (ntok > kHMaxTok || nkv > kHMaxKV) return (int)hipErrorInvalidValue;
-  float* qbuf = att_workspace + (size_t)B * kHD * ntok;
-  float* kvbuf = qbuf + (size_t)B * ntok * kHI;
-  ocrf::launch(OCRF_K_HOA1_Q, hoa1_q_kernel, dim3((ntok + kBlock - 1) / kBlock, B), dim3(kBlock), 0, stream, opacity,
-               weights, Y, X, hq, wq, qbuf);
+  // (the workspace keeps round 1's layout att | q | kv; only the kv part is used now)
+  float* kvbuf = att_workspace + (size_t)B * kHD * ntok + (size_t)B * ntok * kHI;
+  const int n_kv_wg = min(nkv, 8);
+  const int per = (nkv + n_kv_wg - 1) / n_kv_wg;
+  const int q_rows = min(hq, ((per + wk - 1) / wk + 1) * 4 + 6);       // upper bound of a workgroup's q-row window
+  const size_t lds_kv = (size_t)(((kHoaWeights + 3) & ~3) + q_rows * wq * kHI + nkv * (kHI + 2 + kHD)) * sizeof(float);
+  ocrf::launch(OCRF_K_HOA1_KV, hoa1_kv_kernel, dim3(n_kv_wg, B), dim3(kBlock), lds_kv, stream, opacity, alpha, weights,
+               Y, X, hq, wq, hk, wk, offset_scale, q_rows, kvbuf);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  const size_t lds_kv = (size_t)(((kHoaWeights + 3) & ~3) + ntok * kHI + nkv * (kHI + 2 + kHD)) * sizeof(float);
-  ocrf::launch(OCRF_K_HOA1_KV, hoa1_kv_kernel, dim3(min(nkv, 8), B), dim3(kBlock), lds_kv, stream, static_cast<const float*>(qbuf),
-               alpha, weights, Y, X, hq, wq, hk, wk, offset_scale, kvbuf);
-  e = hipGetLastError();
-  if (e != hipSuccess) return (int)e;
   const size_t lds_at = (size_t)(((kHoaWeights + 3) & ~3) + nkv * 18) * sizeof(float);
-  ocrf::launch(OCRF_K_HOA1_ATTN, hoa1_attention_kernel, dim3((ntok * kAttSplit + 63) / 64, B), dim3(64), lds_at, stream,
-               static_cast<const float*>(qbuf), static_cast<const float*>(kvbuf), weights, hq, wq, nkv,
-               att_workspace);
-  e = hipGetLastError();
-  if (e != hipSuccess) return (int)e;
-  const long plane = (long)Y * X;
-  ocrf::launch(OCRF_K_HOA1_UP, hoa1_upsample_residual_kernel, dim3((unsigned)((plane + kBlock - 1) / kBlock), B * kHD),
-               dim3(kBlock), 0, stream, static_cast<const float*>(att_workspace), opacity, kHD, Y, X, hq, wq, out);
+  ocrf::launch(OCRF_K_HOA1_ATTN, hoa1_attention_upsample_kernel, dim3((X + kTP - 1) / kTP, (Y + kTP - 1) / kTP, B),
+               dim3(kBlock), lds_at, stream, opacity, static_cast<const float*>(kvbuf), weights, Y, X, hq, wq, nkv, out);
   return (int)hipGetLastError();
 }
 
