@@ -228,6 +228,15 @@ int ocrf_rasterize_backward(int P, int n_views, int H, int W, const float *means
                             float *dL_dopacity, float *dL_dscales, float *dL_drotations,
                             float *dL_dmeans2D, void *workspace, size_t workspace_bytes,
                             ocrf_stream_t stream);
+/* The same with the 3-D covariance handed over (cov3D_precomp (P,6): xx xy xz yy yz zz, as the forward takes it):
+ * the reference stops at dL/dcov3D then (backward.cu:346-396 without computeCov3D's backward, :598-613):
+ * dL_dcov3D (P,6), fully written, off-diagonal entries carry both symmetric halves (backward.cu:251-260). */
+int ocrf_rasterize_backward_cov3d(int P, int n_views, int H, int W, const float *means3D, const float *colors,
+                                  const float *opacities, const float *cov3D_precomp, const float *cameras,
+                                  const float *bg, const float *fwd_color, const float *fwd_final_T,
+                                  const uint32_t *fwd_n_contrib, const float *dL_dcolor, float *dL_dmeans3D,
+                                  float *dL_dcolors, float *dL_dopacity, float *dL_dcov3D, float *dL_dmeans2D,
+                                  void *workspace, size_t workspace_bytes, ocrf_stream_t stream);
 size_t ocrf_rasterize_backward_workspace_bytes(int P, int n_views);
 
 /* ------------------------------------------------------------------------------------------

@@ -108,6 +108,8 @@ def _declare(L):
     L.ocrf_rasterize_backward.restype = c_int
     L.ocrf_rasterize_backward.argtypes = ([c_int] * 4 + [c_void_p] * 4 + [c_float] + [c_void_p] * 13 +
                                           [c_void_p, c_size_t, c_void_p])
+    L.ocrf_rasterize_backward_cov3d.restype = c_int
+    L.ocrf_rasterize_backward_cov3d.argtypes = [c_int] * 4 + [c_void_p] * 16 + [c_size_t, c_void_p]
     L.ocrf_rasterize_backward_workspace_bytes.restype = c_size_t
     L.ocrf_rasterize_backward_workspace_bytes.argtypes = [c_int, c_int]
     L.ocrf_rasterize_workspace_bytes.restype = c_size_t

@@ -1013,16 +1013,22 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void raster_preprocess_backward_kernel(
     int P, int n_views, int W, int H, const float* __restrict__ means3D, const float* __restrict__ scales,
-    float scale_modifier, const float* __restrict__ rotations, const Camera* __restrict__ cams,
+    float scale_modifier, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
+    const Camera* __restrict__ cams,
     const int* __restrict__ radii, const float* __restrict__ acc, float* __restrict__ dL_dmeans3D,
     float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales,
-    float* __restrict__ dL_drotations, float* __restrict__ dL_dmeans2D) {
+    float* __restrict__ dL_drotations, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dmeans2D) {
   const int idx = blockIdx.x * kBlock + threadIdx.x;
   if (idx >= P) return;
   const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
-  const float sv[3] = {scale_modifier * scales[3 * idx], scale_modifier * scales[3 * idx + 1],
-                       scale_modifier * scales[3 * idx + 2]};
-  const float r = rotations[4 * idx], x = rotations[4 * idx + 1], y = rotations[4 * idx + 2], z = rotations[4 * idx + 3];
+  // covariance handed over (backward.cu:346-396 stops at dL/dcov3D then) or built from scale and rotation
+  const bool precomp = cov3D_precomp != nullptr;
+  float sv[3] = {0.f, 0.f, 0.f}, r = 1.f, x = 0.f, y = 0.f, z = 0.f;
+  if (!precomp) {
+    sv[0] = scale_modifier * scales[3 * idx]; sv[1] = scale_modifier * scales[3 * idx + 1];
+    sv[2] = scale_modifier * scales[3 * idx + 2];
+    r = rotations[4 * idx]; x = rotations[4 * idx + 1]; y = rotations[4 * idx + 2]; z = rotations[4 * idx + 3];
+  }
   const float Rm[3][3] = {
       {1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
       {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
@@ -1037,6 +1043,11 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_backward_kernel(
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) V3[i][j] = Mk[0][i] * Mk[0][j] + Mk[1][i] * Mk[1][j] + Mk[2][i] * Mk[2][j];
+  if (precomp) {
+    const float* c6 = cov3D_precomp + 6 * (long)idx;       // xx xy xz yy yz zz (forward.cu:118-121)
+    V3[0][0] = c6[0]; V3[0][1] = V3[1][0] = c6[1]; V3[0][2] = V3[2][0] = c6[2];
+    V3[1][1] = c6[3]; V3[1][2] = V3[2][1] = c6[4]; V3[2][2] = c6[5];
+  }
 
   float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float dcol[3] = {0.f, 0.f, 0.f}, dop = 0.f;
@@ -1125,6 +1136,11 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_backward_kernel(
   for (int i = 0; i < 3; ++i) {
     dL_dcolors[3 * idx + i] = dcol[i];
     dL_dmeans3D[3 * idx + i] = dmean[i];
+  }
+  if (precomp) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dL_dcov3D[6 * (long)idx + i] = dcov[i];
+    return;
   }
   // Sigma = M^T M -> scales and (un-normalised) quaternion (backward.cu:278-342)
   const float dS[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]}, {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
@@ -1297,18 +1313,19 @@ size_t ocrf_rasterize_backward_workspace_bytes(int P, int n_views) {
   return ws.bwd_total;
 }
 
-int ocrf_rasterize_backward(int P, int n_views, int H, int W, const float* means3D, const float* colors,
-                            const float* opacities, const float* scales, float scale_modifier,
-                            const float* rotations, const float* cameras, const float* bg,
-                            const float* fwd_color, const float* fwd_final_T, const uint32_t* fwd_n_contrib,
-                            const float* dL_dcolor, float* dL_dmeans3D, float* dL_dcolors,
-                            float* dL_dopacity, float* dL_dscales, float* dL_drotations,
-                            float* dL_dmeans2D, void* workspace, size_t workspace_bytes,
-                            ocrf_stream_t stream_) {
+static int rasterize_backward_impl(int P, int n_views, int H, int W, const float* means3D, const float* colors,
+                                   const float* opacities, const float* scales, float scale_modifier,
+                                   const float* rotations, const float* cov3D_precomp, const float* cameras,
+                                   const float* bg, const float* fwd_color, const float* fwd_final_T,
+                                   const uint32_t* fwd_n_contrib, const float* dL_dcolor, float* dL_dmeans3D,
+                                   float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations,
+                                   float* dL_dcov3D, float* dL_dmeans2D, void* workspace, size_t workspace_bytes,
+                                   ocrf_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (P <= 0 || n_views <= 0 || H <= 0 || W <= 0 || !means3D || !colors || !opacities || !scales || !rotations ||
-      !cameras || !bg || !fwd_color || !fwd_final_T || !fwd_n_contrib || !dL_dcolor || !dL_dmeans3D || !dL_dcolors ||
-      !dL_dopacity || !dL_dscales || !dL_drotations)
+  if (P <= 0 || n_views <= 0 || H <= 0 || W <= 0 || !means3D || !colors || !opacities || !cameras || !bg ||
+      !fwd_color || !fwd_final_T || !fwd_n_contrib || !dL_dcolor || !dL_dmeans3D || !dL_dcolors || !dL_dopacity)
+    return (int)hipErrorInvalidValue;
+  if (cov3D_precomp ? !dL_dcov3D : (!scales || !rotations || !dL_dscales || !dL_drotations))
     return (int)hipErrorInvalidValue;
   const int gx = (W + kTileX - 1) / kTileX, gy = (H + kTileY - 1) / kTileY;
   if (gx > 65535 || gy > 65535) return (int)hipErrorInvalidValue;
@@ -1338,7 +1355,7 @@ int ocrf_rasterize_backward(int P, int n_views, int H, int W, const float* means
   const dim3 pgrid(n_chunks, n_views);
   const dim3 xgrid((unsigned)((n_pre + 7) / 8 * 8 * n_views));
   hipLaunchKernelGGL(raster_preprocess_kernel, xgrid, dim3(kBlock), 0, stream, P, n_views, n_pre, W, H, gx, gy,
-                     means3D, opacities, scales, scale_modifier, rotations, (const float*)nullptr, cams, vis_rec,
+                     means3D, opacities, scales, scale_modifier, rotations, cov3D_precomp, cams, vis_rec,
                      vis_count, rects, xy, conic_o, radii, (unsigned*)nullptr, hist, n_views);
   hipLaunchKernelGGL(raster_bucket_scan_kernel, dim3(n_views), dim3(kBlock), 0, stream, static_cast<const int*>(hist),
                      starts, cursor, st);
@@ -1359,10 +1376,38 @@ int ocrf_rasterize_backward(int P, int n_views, int H, int W, const float* means
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   ocrf::launch(OCRF_K_RASTER_PRE_BWD, raster_preprocess_backward_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock),
-               0, stream, P, n_views, W, H, means3D, scales, scale_modifier, rotations, cams,
+               0, stream, P, n_views, W, H, means3D, scales, scale_modifier, rotations, cov3D_precomp, cams,
                static_cast<const int*>(radii), static_cast<const float*>(acc), dL_dmeans3D, dL_dcolors, dL_dopacity,
-               dL_dscales, dL_drotations, dL_dmeans2D);
+               dL_dscales, dL_drotations, dL_dcov3D, dL_dmeans2D);
   return (int)hipGetLastError();
+}
+
+int ocrf_rasterize_backward(int P, int n_views, int H, int W, const float* means3D, const float* colors,
+                            const float* opacities, const float* scales, float scale_modifier,
+                            const float* rotations, const float* cameras, const float* bg,
+                            const float* fwd_color, const float* fwd_final_T, const uint32_t* fwd_n_contrib,
+                            const float* dL_dcolor, float* dL_dmeans3D, float* dL_dcolors,
+                            float* dL_dopacity, float* dL_dscales, float* dL_drotations,
+                            float* dL_dmeans2D, void* workspace, size_t workspace_bytes,
+                            ocrf_stream_t stream) {
+  if (!scales || !rotations) return (int)hipErrorInvalidValue;
+  return rasterize_backward_impl(P, n_views, H, W, means3D, colors, opacities, scales, scale_modifier, rotations,
+                                 nullptr, cameras, bg, fwd_color, fwd_final_T, fwd_n_contrib, dL_dcolor, dL_dmeans3D,
+                                 dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, nullptr, dL_dmeans2D, workspace,
+                                 workspace_bytes, stream);
+}
+
+int ocrf_rasterize_backward_cov3d(int P, int n_views, int H, int W, const float* means3D, const float* colors,
+                                  const float* opacities, const float* cov3D_precomp, const float* cameras,
+                                  const float* bg, const float* fwd_color, const float* fwd_final_T,
+                                  const uint32_t* fwd_n_contrib, const float* dL_dcolor, float* dL_dmeans3D,
+                                  float* dL_dcolors, float* dL_dopacity, float* dL_dcov3D, float* dL_dmeans2D,
+                                  void* workspace, size_t workspace_bytes, ocrf_stream_t stream) {
+  if (!cov3D_precomp) return (int)hipErrorInvalidValue;
+  return rasterize_backward_impl(P, n_views, H, W, means3D, colors, opacities, nullptr, 1.0f, nullptr, cov3D_precomp,
+                                 cameras, bg, fwd_color, fwd_final_T, fwd_n_contrib, dL_dcolor, dL_dmeans3D, dL_dcolors,
+                                 dL_dopacity, nullptr, nullptr, dL_dcov3D, dL_dmeans2D, workspace, workspace_bytes,
+                                 stream);
 }
 
 }  // extern "C"

@@ -23,7 +23,7 @@ Compute: ``csrc/rasterize.hip`` through the C ABI (``ocrf_rasterize_forward`` /
 ``ocrf_rasterize_backward``).  The backward covers what the fork's does — the colour output w.r.t.
 means3D, means2D (screen-space, for densification statistics), colours, opacities, scales, rotations;
 depth has no backward in the fork either (diff-gaussian-rasterization-w-depth/README.md:13).
-``cov3D_precomp`` is forward-only here.  SH colours are outside the path OcRFDet uses (``shs=None``
+``cov3D_precomp`` has its own backward (gradient w.r.t. the six covariance entries).  SH colours are outside the path OcRFDet uses (``shs=None``
 at the call site) and raise ``NotImplementedError``.
 """
 import ctypes
@@ -76,10 +76,15 @@ def pack_cameras(viewmatrices, projmatrices, tanfovx, tanfovy, H, W, dev):
 
 def rasterize_views_backward(grad_color, fwd, means3D, colors, opacities, scales, rotations, viewmatrices,
                              projmatrices, tanfovx, tanfovy, image_height, image_width, bg, scale_modifier=1.0,
-                             want_means2D=False, packed_cameras=None):
+                             want_means2D=False, packed_cameras=None, cov3D_precomp=None):
     """Backward of ``rasterize_views``' colour output, summed over the views.  ``fwd`` is the dict
     ``rasterize_views`` returned for the same inputs.  Returns a dict ``means3D`` (P,3), ``colors``
-    (P,3), ``opacities`` (P,1), ``scales`` (P,3), ``rotations`` (P,4) [, ``means2D`` (V,P,3)]."""
+    (P,3), ``opacities`` (P,1), ``scales`` (P,3), ``rotations`` (P,4) [, ``means2D`` (V,P,3)]; with
+    ``cov3D_precomp`` (P,6) (``scales`` / ``rotations`` None) ``cov3D`` (P,6) instead of the last two
+    (backward.cu:346-396 without computeCov3D's backward)."""
+    if cov3D_precomp is not None:
+        return _backward_cov3d(grad_color, fwd, means3D, colors, opacities, cov3D_precomp, viewmatrices, projmatrices,
+                               tanfovx, tanfovy, image_height, image_width, bg, want_means2D, packed_cameras)
     _lib.require_cuda(means3D, colors, opacities, scales, rotations, grad_color)
     dev = means3D.device
     P = means3D.size(0)
@@ -205,6 +210,38 @@ def rasterize_sets(means3D, colors, opacities, scales, rotations, packed_cameras
     return out
 
 
+def _backward_cov3d(grad_color, fwd, means3D, colors, opacities, cov3D, viewmatrices, projmatrices, tanfovx, tanfovy,
+                    image_height, image_width, bg, want_means2D, packed_cameras):
+    _lib.require_cuda(means3D, colors, opacities, cov3D, grad_color)
+    dev = means3D.device
+    P = means3D.size(0)
+    H, W = int(image_height), int(image_width)
+    cams = packed_cameras if packed_cameras is not None else \
+        pack_cameras(viewmatrices, projmatrices, tanfovx, tanfovy, H, W, dev)
+    V = cams.size(0)
+    g = _f32c(grad_color).reshape(V, 3, H, W)
+    means3D, colors, opac = _f32c(means3D), _f32c(colors), _f32c(opacities).reshape(-1)
+    cov, bg = _f32c(cov3D).reshape(P, 6), _f32c(bg).reshape(3)
+    fc, ft, fn = fwd['color'].contiguous(), fwd['final_T'].contiguous(), fwd['n_contrib'].contiguous()
+    if tuple(fc.shape) != (V, 3, H, W) or tuple(ft.shape) != (V, H, W) or tuple(fn.shape) != (V, H, W):
+        raise RuntimeError('rasterize_views_backward: forward outputs do not match the view batch')
+    out = dict(means3D=torch.empty(P, 3, device=dev), colors=torch.empty(P, 3, device=dev),
+               opacities=torch.empty(P, 1, device=dev), cov3D=torch.empty(P, 6, device=dev))
+    m2d = torch.empty(V, P, 3, device=dev) if want_means2D else None
+    if P:
+        L = _lib.lib()
+        with _lib.on_device(dev):
+            ws = _lib.workspace.get(dev, L.ocrf_rasterize_backward_workspace_bytes(P, V), 'raster')
+            _lib.check(L.ocrf_rasterize_backward_cov3d(
+                P, V, H, W, _lib.ptr(means3D), _lib.ptr(colors), _lib.ptr(opac), _lib.ptr(cov), _lib.ptr(cams),
+                _lib.ptr(bg), _lib.ptr(fc), _lib.ptr(ft), _lib.ptr(fn), _lib.ptr(g), _lib.ptr(out['means3D']),
+                _lib.ptr(out['colors']), _lib.ptr(out['opacities']), _lib.ptr(out['cov3D']), _lib.ptr(m2d),
+                _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_ptr(dev)), 'ocrf_rasterize_backward_cov3d')
+    if m2d is not None:
+        out['means2D'] = m2d
+    return out
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
@@ -223,10 +260,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.mark_non_differentiable(radii, depth)
         ctx.raster_settings = rs
         ctx.has_cov = cov3Ds_precomp is not None and cov3Ds_precomp.numel() > 0
-        if not ctx.has_cov:
-            # the forward's outputs are saved through autograd (not as plain attributes): the backward
-            # rebuilds S = C_out - T_final * bg from them, so an in-place edit of the rendered image
-            # (clamp_, mul_) must raise instead of silently changing the gradients
+        # the forward's outputs are saved through autograd (not as plain attributes): the backward
+        # rebuilds S = C_out - T_final * bg from them, so an in-place edit of the rendered image
+        # (clamp_, mul_) must raise instead of silently changing the gradients
+        if ctx.has_cov:
+            ctx.save_for_backward(means3D, colors_precomp, opacities, cov3Ds_precomp, color, out['final_T'],
+                                  out.get('n_contrib'))
+        else:
             ctx.save_for_backward(means3D, colors_precomp, opacities, scales, rotations, color, out['final_T'],
                                   out.get('n_contrib'))
         return color, radii, depth
@@ -235,10 +275,17 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_color, _r, _d):
         """Gradient tuple in the reference's order (diff_gaussian_rasterization/__init__.py:96-149):
         means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings."""
-        if ctx.has_cov:
-            raise NotImplementedError('ocrfdet_amd rasteriser: backward with cov3D_precomp is not built '
-                                      '(OcRFDet passes scales and rotations)')
         rs = ctx.raster_settings
+        if ctx.has_cov:
+            means3D, colors, opacities, cov, fwd_color, fwd_T, fwd_n = ctx.saved_tensors
+            fwd = dict(color=fwd_color.unsqueeze(0), final_T=fwd_T, n_contrib=fwd_n)
+            g = rasterize_views_backward(grad_color.unsqueeze(0), fwd, means3D, colors, opacities, None, None,
+                                         rs.viewmatrix.reshape(1, 4, 4), rs.projmatrix.reshape(1, 4, 4),
+                                         float(rs.tanfovx), float(rs.tanfovy), rs.image_height, rs.image_width, rs.bg,
+                                         want_means2D=True, cov3D_precomp=cov)
+            grads = (g['means3D'], g['means2D'][0], None, g['colors'], g['opacities'].reshape(opacities.shape),
+                     None, None, g['cov3D'].reshape(cov.shape), None)
+            return tuple(v if need else None for v, need in zip(grads, ctx.needs_input_grad))
         means3D, colors, opacities, scales, rotations, fwd_color, fwd_T, fwd_n = ctx.saved_tensors
         fwd = dict(color=fwd_color.unsqueeze(0), final_T=fwd_T, n_contrib=fwd_n)
         g = rasterize_views_backward(grad_color.unsqueeze(0), fwd, means3D, colors, opacities, scales, rotations,

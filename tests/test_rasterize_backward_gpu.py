@@ -113,3 +113,50 @@ def test_backward_of_empty_view_is_zero(cuda):
                                                   torch.zeros(3, device=cuda))
     color.sum().backward()
     assert float(m3.grad.abs().max()) == 0.0 and float(c.grad.abs().max()) == 0.0
+
+
+def _cov3d_of(sc, rot):
+    """computeCov3D (forward.cu:118-121 layout xx xy xz yy yz zz) in float32, Sigma = (S R)^T (S R)."""
+    r, x, y, z = (rot[:, i].astype(np.float32) for i in range(4))
+    one, two = np.float32(1), np.float32(2)
+    R = np.stack([np.stack([one - two * (y * y + z * z), two * (x * y - r * z), two * (x * z + r * y)], 1),
+                  np.stack([two * (x * y + r * z), one - two * (x * x + z * z), two * (y * z - r * x)], 1),
+                  np.stack([two * (x * z - r * y), two * (y * z + r * x), one - two * (x * x + y * y)], 1)], 1)   # (P,3,3)
+    M = sc[:, :, None].astype(np.float32) * np.transpose(R, (0, 2, 1))     # M[k][i] = s_k R[i][k]
+    S = np.einsum('pki,pkj->pij', M, M).astype(np.float32)
+    return np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize('n,seed,tol', [(12, 3, 1e-4), (2000, 7, 2e-3)])
+def test_backward_with_cov3d_precomp(cuda, oracle_lib, n, seed, tol):
+    """cov3D_precomp path (backward.cu:346-396 stops at dL/dcov3D): the oracle returns dL/dcov3D of the same scene
+    built from (scales, rotations); the HIP op gets the covariance itself and must return that gradient, and the
+    same gradients for everything upstream of the covariance."""
+    rng = np.random.default_rng(seed)
+    W, H = 112, 64
+    view, full, tfx, tfy = helpers.simple_camera(W, H)
+    xyz, rgb, opac, sc, rot = helpers.random_gaussians(rng, n)
+    rot = (rot / np.linalg.norm(rot, axis=1, keepdims=True)).astype(np.float32)
+    bg = np.float32([0.2, 0.1, 0.3])
+    gcol = rng.standard_normal((3, H, W)).astype(np.float32)
+    want = oracle_lib.rasterize_backward(gcol, xyz, rgb, opac, sc, rot, view, full, tfx, tfy, H, W, bg)
+    settings = dgr.GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=tfx, tanfovy=tfy, bg=_t(bg, cuda), scale_modifier=1.0,
+        viewmatrix=_t(view, cuda), projmatrix=_t(full, cuda), sh_degree=0, campos=torch.zeros(3, device=cuda),
+        prefiltered=False)
+    m3, m2 = _t(xyz, cuda, True), torch.zeros(n, 3, device=cuda, requires_grad=True)
+    c, o, cov = _t(rgb, cuda, True), _t(opac, cuda, True), _t(_cov3d_of(sc, rot), cuda, True)
+    color, radii, depth = dgr.GaussianRasterizer(settings)(m3, m2, o, colors_precomp=c, cov3D_precomp=cov)
+    (color * _t(gcol, cuda)).sum().backward()
+    torch.cuda.synchronize()
+    _check(c.grad.cpu().numpy(), want['colors'], 'dL_dcolors', tol)
+    _check(o.grad.cpu().numpy(), want['opacities'], 'dL_dopacity', tol)
+    _check(m2.grad.cpu().numpy(), want['means2D'], 'dL_dmeans2D', tol)
+    _check(m3.grad.cpu().numpy(), want['means3D'], 'dL_dmeans3D', tol)
+    _check(cov.grad.cpu().numpy(), want['cov3D'], 'dL_dcov3D', tol)
+    # and the two forward paths render the same image
+    s, r = _t(sc, cuda), _t(rot, cuda)
+    with torch.no_grad():
+        color2, _, _ = dgr.GaussianRasterizer(settings)(_t(xyz, cuda), None, _t(opac, cuda), colors_precomp=_t(rgb, cuda),
+                                                        scales=s, rotations=r)
+    assert float((color2 - color.detach()).abs().max()) <= 1e-4
