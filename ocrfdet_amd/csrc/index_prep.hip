@@ -18,6 +18,8 @@
 //   * HT: the key is the pillar itself and a pillar's candidates are its (camera, height) pairs, so
 //     no sort is needed at all: validity bits per (camera, pillar), totals per pillar, one scan
 //     over the pillars, emit in (camera, height) order.
+// Every prefix sum is a single launch (decoupled look-back over ticket-ordered tiles): 18 launches per LSS
+// preparation became 10, 7 per HT preparation 5.
 // Tiny per-camera algebra (3x3 inverses and products) stays on the host, as the same torch calls the
 // reference makes; the kernels take the resulting per-camera blocks.
 #include <hip/hip_runtime.h>
@@ -32,7 +34,6 @@ constexpr int kItems = 8;                     // keys per thread and radix pass
 constexpr int kChunk = kBlock * kItems;       // 2048 keys per workgroup
 constexpr int kRadixBits = 9;
 constexpr int kBins = 1 << kRadixBits;        // 512
-constexpr int kScanBlock = 1024;          // the one-workgroup scan of the per-chunk sums
 
 struct LssCam {       // 33 floats per camera-frame, see ocrf_hip.h
   float inv_post[9], combine[9], post_trans[3], trans[3], bda[9];
@@ -111,9 +112,8 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const unsigned* __re
   for (int d = threadIdx.x; d < kBins; d += kBlock) table[(long)d * n_wg + blockIdx.x] = s_hist[d];
 }
 
-// Exclusive scan of n values in place, three launches: per-workgroup sums (2048 values each) ->
-// scan of the sums by one workgroup -> rescan of every chunk with its offset.  Each thread owns 8
-// consecutive values, so a wave touches 2 KB of contiguous memory per load.
+// exclusive prefix of v over the 256 threads of the workgroup (each thread of a scan owns 8 consecutive
+// values, so a wave touches 2 KB of contiguous memory per load)
 template <typename T>
 __device__ __forceinline__ T block_exclusive(T v, T* s_wave, T* block_total) {
   // exclusive prefix of v over the 256 threads of the workgroup
@@ -137,48 +137,101 @@ __device__ __forceinline__ T block_exclusive(T v, T* s_wave, T* block_total) {
   return base + inc - v;
 }
 
-template <typename T>
-__global__ __launch_bounds__(kBlock) void scan_reduce_kernel(const T* __restrict__ data, long n, T* __restrict__ partial) {
-  __shared__ T s_wave[kBlock / 64];
-  const long base = (long)blockIdx.x * kChunk + (long)threadIdx.x * kItems;
-  T sum = 0;
-#pragma unroll
-  for (int i = 0; i < kItems; ++i)
-    if (base + i < n) sum += data[base + i];
-  T tot;
-  block_exclusive<T>(sum, s_wave, &tot);
-  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+// ---------------------------------------------------------------------------------------------
+// Single-launch prefix sums: decoupled look-back over TICKET-ordered tiles.  state[0] is the ticket
+// counter, state[1 + t] the 64-bit word of tile t: bits 63:62 = 0 nothing yet | 1 the tile's own sum |
+// 2 its inclusive prefix, bits 61:0 the value — one word, written and read with agent-scope atomics,
+// so a reader never sees a value without its status.  A workgroup takes the next ticket before it
+// does anything else: the tiles it may wait for hold smaller tickets, i.e. are already running —
+// every wave reaches its exit whatever the scheduling order.  `state` must be zero before the launch.
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned long long kLbValue = (1ull << 62) - 1;
+
+__device__ __forceinline__ void lb_publish(unsigned long long* state, int tile, unsigned status, unsigned long long v) {
+  __hip_atomic_store(state + 1 + tile, ((unsigned long long)status << 62) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <typename T>
-__global__ __launch_bounds__(kScanBlock) void scan_top_kernel(T* __restrict__ partial, int nb, T* __restrict__ total) {
-  __shared__ T s_sum[kScanBlock];
-  const int tid = threadIdx.x;
-  const int per = (nb + kScanBlock - 1) / kScanBlock;
-  const int lo = min(tid * per, nb), hi = min(lo + per, nb);
-  T sum = 0;
-  for (int i = lo; i < hi; ++i) sum += partial[i];
-  s_sum[tid] = sum;
+// ticket of this workgroup (uniform); contains a barrier
+__device__ __forceinline__ int lb_ticket(unsigned long long* state, int* s_tile) {
+  if (threadIdx.x == 0) *s_tile = (int)atomicAdd(reinterpret_cast<unsigned*>(state), 1u);
   __syncthreads();
-  for (int off = 1; off < kScanBlock; off <<= 1) {      // Hillis-Steele inclusive scan
-    const T add = tid >= off ? s_sum[tid - off] : (T)0;
-    __syncthreads();
-    s_sum[tid] += add;
-    __syncthreads();
-  }
-  T run = s_sum[tid] - sum;
-  for (int i = lo; i < hi; ++i) {
-    const T v = partial[i];
-    partial[i] = run;
-    run += v;
-  }
-  if (total && tid == kScanBlock - 1) *total = s_sum[tid];
+  return __builtin_amdgcn_readfirstlane(*s_tile);      // known-uniform: what depends on it stays in SGPRs
 }
 
+template <int NW = kBlock / 64>
+struct LbShared {
+  unsigned long long inc[NW], none[NW], sum[NW], run;
+};
+
+// exclusive prefix of this tile given its own sum `tot` (uniform).  All 64 NW threads call; contains barriers.
+// The look-back reads 64 NW predecessors per round (thread i reads tile hi - i): an agent-scope load is a
+// round trip to memory, and while every tile still holds only its own sum a tile t needs ~t / (2 kBlock) rounds.
+template <int NW>
+__device__ __forceinline__ unsigned long long lb_tile_prefix(unsigned long long* state, int tile, unsigned long long tot,
+                                                             LbShared<NW>* sh) {
+  constexpr int kThreads = NW * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) {
+    lb_publish(state, tile, tile == 0 ? 2u : 1u, tot);
+    sh->run = 0;
+  }
+  int hi = tile - 1;
+  while (hi >= 0) {                                   // uniform: hi, and the decisions below, are the same everywhere
+    const int j = hi - tid;
+    const unsigned long long w = j >= 0 ? __hip_atomic_load(state + 1 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                        : (2ull << 62);                 // before tile 0: inclusive prefix 0
+    const unsigned status = (unsigned)(w >> 62);
+    const unsigned long long inc = __ballot(status == 2), none = __ballot(status == 0);
+    if (lane == 0) { sh->inc[wave] = inc; sh->none[wave] = none; }
+    __syncthreads();
+    // nearest predecessor with a full prefix, as a thread index; everything nearer must at least hold its sum
+    int first = kThreads;
+    bool wait = false;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      if (first < kThreads) break;
+      const unsigned long long i = sh->inc[k], n = sh->none[k];
+      const int f = i ? __ffsll((long long)i) - 1 : 64;
+      const unsigned long long need = f >= 63 ? ~0ull : ((2ull << f) - 1ull);
+      wait = wait || (n & need) != 0;
+      if (f < 64) first = k * 64 + f;
+    }
+    __syncthreads();                                  // sh->inc / none are rewritten by the next round
+    if (wait) {
+      __builtin_amdgcn_s_sleep(2);
+      continue;                                       // something nearer than `first` is unpublished: read again
+    }
+    unsigned long long v = tid <= first ? (w & kLbValue) : 0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) sh->sum[wave] = v;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long r = sh->run;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) r += sh->sum[k];
+      sh->run = r;
+    }
+    if (first < kThreads) break;
+    hi -= kThreads;
+  }
+  __syncthreads();
+  const unsigned long long prefix = sh->run;
+  if (tid == 0 && tile > 0) lb_publish(state, tile, 2u, prefix + tot);
+  return prefix;
+}
+
+inline size_t lb_state_bytes(long n_tiles) { return ((size_t)n_tiles + 1) * 8; }
+
+// in-place exclusive scan of n non-negative values (sums < 2^62), one launch of ceil(n / kChunk) workgroups
 template <typename T>
-__global__ __launch_bounds__(kBlock) void scan_apply_kernel(T* __restrict__ data, long n, const T* __restrict__ partial) {
+__global__ __launch_bounds__(kBlock) void scan_lookback_kernel(T* __restrict__ data, long n, T* __restrict__ total,
+                                                               unsigned long long* __restrict__ state) {
   __shared__ T s_wave[kBlock / 64];
-  const long base = (long)blockIdx.x * kChunk + (long)threadIdx.x * kItems;
+  __shared__ int s_tile;
+  __shared__ LbShared<> s_lb;
+  const int tile = lb_ticket(state, &s_tile);
+  const long base = (long)tile * kChunk + (long)threadIdx.x * kItems;
   T v[kItems];
   T sum = 0;
 #pragma unroll
@@ -186,21 +239,22 @@ __global__ __launch_bounds__(kBlock) void scan_apply_kernel(T* __restrict__ data
     v[i] = base + i < n ? data[base + i] : (T)0;
     sum += v[i];
   }
-  T run = partial[blockIdx.x] + block_exclusive<T>(sum, s_wave, (T*)nullptr);
+  T tot;
+  const T local = block_exclusive<T>(sum, s_wave, &tot);
+  const unsigned long long prefix = lb_tile_prefix(state, tile, (unsigned long long)tot, &s_lb);
+  T run = (T)prefix + local;
 #pragma unroll
   for (int i = 0; i < kItems; ++i) {
     if (base + i < n) data[base + i] = run;
     run += v[i];
   }
+  if (total && tile == (int)gridDim.x - 1 && threadIdx.x == 0) *total = (T)prefix + tot;
 }
 
-// host side: scratch must hold ceil(n / 2048) values of T
 template <typename T>
-inline void scan_exclusive(T* data, long n, T* total, T* scratch, hipStream_t stream) {
+inline void scan_exclusive_lookback(T* data, long n, T* total, unsigned long long* zeroed_state, hipStream_t stream) {
   const int nb = (int)((n + kChunk - 1) / kChunk);
-  hipLaunchKernelGGL(scan_reduce_kernel<T>, dim3(nb), dim3(kBlock), 0, stream, static_cast<const T*>(data), n, scratch);
-  hipLaunchKernelGGL(scan_top_kernel<T>, dim3(1), dim3(kScanBlock), 0, stream, scratch, nb, total);
-  ocrf::launch(OCRF_K_SCAN, scan_apply_kernel<T>, dim3(nb), dim3(kBlock), 0, stream, data, n, static_cast<const T*>(scratch));
+  ocrf::launch(OCRF_K_SCAN, scan_lookback_kernel<T>, dim3(nb), dim3(kBlock), 0, stream, data, n, total, zeroed_state);
 }
 
 // Stable scatter of one pass.  A wave owns 512 consecutive keys of the workgroup's chunk and walks
@@ -257,50 +311,52 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
   }
 }
 
-// S[v] = first sorted position with key >= v, for v in [0, n_vox_total]; S[n_vox_total] = Np.
-__global__ __launch_bounds__(kBlock) void lower_bound_kernel(const unsigned* __restrict__ sorted, int n,
-                                                             unsigned n_vox_total, int* __restrict__ S) {
-  const unsigned v = blockIdx.x * kBlock + threadIdx.x;
-  if (v > n_vox_total) return;
-  int lo = 0, hi = n;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (sorted[mid] < v) lo = mid + 1; else hi = mid;
-  }
-  S[v] = lo;
-}
-
-// flags[v] = voxel v holds points; scanned in place afterwards
-__global__ __launch_bounds__(kBlock) void nonempty_flags_kernel(const int* __restrict__ S, unsigned n_vox_total,
-                                                                int* __restrict__ flags) {
-  const unsigned v = blockIdx.x * kBlock + threadIdx.x;
-  if (v < n_vox_total) flags[v] = S[v + 1] > S[v] ? 1 : 0;
-}
-
-__global__ __launch_bounds__(kBlock) void lss_emit_intervals_kernel(const int* __restrict__ S, const int* __restrict__ idx,
-                                                                    unsigned n_vox_total, int* __restrict__ starts,
-                                                                    int* __restrict__ lengths, const int* __restrict__ n_iv,
-                                                                    int* __restrict__ counts) {
-  const unsigned v = blockIdx.x * kBlock + threadIdx.x;
-  if (v == 0) {
-    counts[0] = S[n_vox_total];
-    counts[1] = *n_iv;
-  }
-  if (v >= n_vox_total) return;
-  const int len = S[v + 1] - S[v];
+// lower bounds, non-empty flags, their prefix sum and the interval vectors in ONE launch (one voxel per thread,
+// look-back over the tiles): starts[k] / lengths[k] of the k-th non-empty voxel, counts = {points, intervals}.
+__global__ __launch_bounds__(kBlock) void lss_intervals_kernel(const unsigned* __restrict__ sorted, int n,
+                                                               unsigned n_vox_total, int* __restrict__ starts,
+                                                               int* __restrict__ lengths, int* __restrict__ counts,
+                                                               unsigned long long* __restrict__ state) {
+  __shared__ int s_lo[kBlock + 1];
+  __shared__ int s_wave[kBlock / 64];
+  __shared__ int s_tile;
+  __shared__ LbShared<> s_lb;
+  const int tile = lb_ticket(state, &s_tile);
+  const unsigned v = (unsigned)tile * kBlock + threadIdx.x;
+  auto lower_bound = [&](unsigned key) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (sorted[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  s_lo[threadIdx.x] = lower_bound(min(v, n_vox_total));
+  if (threadIdx.x == kBlock - 1) s_lo[kBlock] = lower_bound(min(v + 1, n_vox_total));
+  __syncthreads();
+  const int lo = s_lo[threadIdx.x];
+  const int len = v < n_vox_total ? s_lo[threadIdx.x + 1] - lo : 0;
+  int tot;
+  const int local = block_exclusive<int>(len > 0 ? 1 : 0, s_wave, &tot);
+  const unsigned long long prefix = lb_tile_prefix(state, tile, (unsigned long long)tot, &s_lb);
   if (len > 0) {
-    starts[idx[v]] = S[v];
-    lengths[idx[v]] = len;
+    const int k = (int)prefix + local;
+    starts[k] = lo;
+    lengths[k] = len;
+  }
+  if (tile == (int)gridDim.x - 1 && threadIdx.x == 0) {
+    counts[0] = lower_bound(n_vox_total);          // keys of dropped points are >= n_vox_total
+    counts[1] = (int)prefix + tot;
   }
 }
 
 __global__ __launch_bounds__(kBlock) void lss_emit_ranks_kernel(const unsigned* __restrict__ sorted_keys,
-                                                                const int* __restrict__ sorted_pts, const int* __restrict__ S,
-                                                                unsigned n_vox_total, int DHW, int HW,
+                                                                const int* __restrict__ sorted_pts,
+                                                                const int* __restrict__ counts, int DHW, int HW,
                                                                 int* __restrict__ ranks_bev, int* __restrict__ ranks_depth,
                                                                 int* __restrict__ ranks_feat) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= S[n_vox_total]) return;
+  if (i >= counts[0]) return;
   const int p = sorted_pts[i];
   ranks_bev[i] = (int)sorted_keys[i];
   ranks_depth[i] = p;                                   // the point's own flat index (:232-236)
@@ -343,9 +399,12 @@ __device__ __forceinline__ bool ht_project(const HtParams& q, const HtCam& c, fl
 
 // valid_bits[cam][pillar]: bit z = sample (cam, z, pillar) passes the mask
 __global__ __launch_bounds__(kBlock) void ht_valid_kernel(HtParams q, const float* __restrict__ ref /*(Z,Nq,3) normalised*/,
-                                                          const HtCam* __restrict__ cams, unsigned* __restrict__ valid_bits) {
+                                                          const HtCam* __restrict__ cams, unsigned* __restrict__ valid_bits,
+                                                          unsigned long long* __restrict__ scan_state, int scan_state_words) {
   const int pil = blockIdx.x * kBlock + threadIdx.x;
   const int cam = blockIdx.y;                  // b*N + n
+  if (blockIdx.x == 0 && cam == 0)             // the look-back state of the scan two launches later
+    for (int i = threadIdx.x; i < scan_state_words; i += kBlock) scan_state[i] = 0ull;
   if (pil >= q.Nq) return;
   const HtCam& c = cams[cam];
   unsigned valid = 0;
@@ -402,7 +461,7 @@ __global__ __launch_bounds__(kBlock) void ht_pillar_totals_kernel(HtParams q, co
   const int b = t / q.Nq, pil = t - b * q.Nq;
   int total = 0;
   for (int n = 0; n < q.N; ++n) total += __popc(valid_bits[((long)b * q.N + n) * q.Nq + pil]);
-  cnt_flag[t] = ((long long)total << 32) | (total > 0 ? 1ll : 0ll);
+  cnt_flag[t] = ((long long)total << 31) | (total > 0 ? 1ll : 0ll);      // both sums stay below 2^31: one 62-bit value
 }
 
 // emit in (camera, height) order inside a pillar = the reference's flattening order under a stable sort
@@ -420,12 +479,12 @@ __global__ __launch_bounds__(kBlock) void ht_emit_kernel(HtParams q, const float
   const unsigned valid = valid_bits[(long)cam * q.Nq + pil];
   if (n != 0 && valid == 0) return;
   const long long cf = cnt_flag[t];
-  int out = (int)(cf >> 32);
+  int out = (int)(cf >> 31);
   if (n == 0) {
     int total = 0;
     for (int m = 0; m < q.N; ++m) total += __popc(valid_bits[((long)b * q.N + m) * q.Nq + pil]);
     if (total > 0) {
-      const int k = (int)(cf & 0xFFFFFFFFll);
+      const int k = (int)(cf & 0x7FFFFFFFll);
       starts[k] = out;
       lengths[k] = total;
     }
@@ -458,8 +517,8 @@ __global__ __launch_bounds__(kBlock) void ht_emit_kernel(HtParams q, const float
 }
 
 __global__ void ht_counts_kernel(const long long* __restrict__ total, int* __restrict__ counts) {
-  counts[0] = (int)(*total >> 32);
-  counts[1] = (int)(*total & 0xFFFFFFFFll);
+  counts[0] = (int)(*total >> 31);
+  counts[1] = (int)(*total & 0x7FFFFFFFll);
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -471,7 +530,8 @@ inline int radix_passes(unsigned n_vox_total) {
 }
 
 struct LssWs {
-  size_t keys_a, keys_b, vals_a, vals_b, table, S, flags, total, scratch, bytes;
+  size_t keys_a, keys_b, vals_a, vals_b, table, state, state_bytes, bytes;
+  long state_tiles_table, state_tiles_iv;
 };
 
 inline void lss_layout(long n_pts, unsigned n_vox_total, LssWs* w) {
@@ -483,11 +543,11 @@ inline void lss_layout(long n_pts, unsigned n_vox_total, LssWs* w) {
   w->vals_a = take((size_t)n_pts * 4);
   w->vals_b = take((size_t)n_pts * 4);
   w->table = take((size_t)kBins * n_wg * 4);
-  w->S = take(((size_t)n_vox_total + 1) * 4);
-  w->flags = take(((size_t)n_vox_total + 1) * 4);
-  w->total = take(256);
-  const size_t longest = (size_t)kBins * n_wg > (size_t)n_vox_total ? (size_t)kBins * n_wg : (size_t)n_vox_total;
-  w->scratch = take(((longest + kChunk - 1) / kChunk + 1) * 4);
+  // look-back states: one per radix pass (<= 4) + the interval kernel, zero-filled by ONE launch per call
+  w->state_tiles_table = ((long)kBins * n_wg + kChunk - 1) / kChunk;
+  w->state_tiles_iv = ((long)n_vox_total + 1 + kBlock - 1) / kBlock;
+  w->state = take(4 * lb_state_bytes(w->state_tiles_table) + lb_state_bytes(w->state_tiles_iv));
+  w->state_bytes = off - w->state;
   w->bytes = off;
 }
 
@@ -524,25 +584,26 @@ int ocrf_lss_prepare(int B, int N, int D, int H, int W, const float* frustum, co
   unsigned* keys[2] = {reinterpret_cast<unsigned*>(base + w.keys_a), reinterpret_cast<unsigned*>(base + w.keys_b)};
   int* vals[2] = {reinterpret_cast<int*>(base + w.vals_a), reinterpret_cast<int*>(base + w.vals_b)};
   int* table = reinterpret_cast<int*>(base + w.table);
-  int* S = reinterpret_cast<int*>(base + w.S);
-  int* flags = reinterpret_cast<int*>(base + w.flags);
-  int* total = reinterpret_cast<int*>(base + w.total);
-  int* scratch = reinterpret_cast<int*>(base + w.scratch);
   const int n_wg = (n_pts + kChunk - 1) / kChunk;
   // the grid constants are read on the host side of the ABI (6 floats); they are host memory
   const float lx = grid_lower[0], ly = grid_lower[1], lz = grid_lower[2];
   const float ix = grid_interval[0], iy = grid_interval[1], iz = grid_interval[2];
 
+  auto* state = reinterpret_cast<unsigned long long*>(base + w.state);
+  const size_t st_words = lb_state_bytes(w.state_tiles_table) / 8;
+  hipError_t ze = ocrf::zero_async(state, w.state_bytes, stream);
+  if (ze != hipSuccess) return (int)ze;
   ocrf::launch(OCRF_K_LSS_KEYS, lss_keys_kernel, dim3((n_pts + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, n_pts, N,
                D * H * W, frustum, reinterpret_cast<const LssCam*>(cams), lx, ly, lz, ix, iy, iz, gx, gy, gz, n_vox_total,
                keys[0]);
   const int passes = radix_passes(n_vox_total);
+  if (passes > 4) return (int)hipErrorInvalidValue;
   int cur = 0;
   for (int pass = 0; pass < passes; ++pass) {
     const int shift = pass * kRadixBits;
     ocrf::launch(OCRF_K_RADIX_HIST, radix_hist_kernel, dim3(n_wg), dim3(kBlock), 0, stream,
                  static_cast<const unsigned*>(keys[cur]), n_pts, shift, n_wg, table);
-    scan_exclusive<int>(table, (long)kBins * n_wg, (int*)nullptr, scratch, stream);
+    scan_exclusive_lookback(table, (long)kBins * n_wg, (int*)nullptr, state + pass * st_words, stream);
     if (pass == 0)
       ocrf::launch(OCRF_K_RADIX_SCATTER, radix_scatter_kernel<true>, dim3(n_wg), dim3(kBlock), 0, stream,
                    static_cast<const unsigned*>(keys[cur]), static_cast<const int*>(nullptr), n_pts, shift, n_wg,
@@ -554,17 +615,12 @@ int ocrf_lss_prepare(int B, int N, int D, int H, int W, const float* frustum, co
     cur ^= 1;
   }
   const int vgrid = (int)((n_vox_total + 1 + kBlock - 1) / kBlock);
-  ocrf::launch(OCRF_K_LSS_BOUNDS, lower_bound_kernel, dim3(vgrid), dim3(kBlock), 0, stream,
-               static_cast<const unsigned*>(keys[cur]), n_pts, n_vox_total, S);
-  hipLaunchKernelGGL(nonempty_flags_kernel, dim3(vgrid), dim3(kBlock), 0, stream, static_cast<const int*>(S), n_vox_total,
-                     flags);
-  scan_exclusive<int>(flags, (long)n_vox_total, total, scratch, stream);
-  hipLaunchKernelGGL(lss_emit_intervals_kernel, dim3(vgrid), dim3(kBlock), 0, stream, static_cast<const int*>(S),
-                     static_cast<const int*>(flags), n_vox_total, interval_starts, interval_lengths,
-                     static_cast<const int*>(total), counts);
+  ocrf::launch(OCRF_K_LSS_BOUNDS, lss_intervals_kernel, dim3(vgrid), dim3(kBlock), 0, stream,
+               static_cast<const unsigned*>(keys[cur]), n_pts, n_vox_total, interval_starts, interval_lengths, counts,
+               state + 4 * st_words);
   ocrf::launch(OCRF_K_LSS_EMIT, lss_emit_ranks_kernel, dim3((n_pts + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
-               static_cast<const unsigned*>(keys[cur]), static_cast<const int*>(vals[cur]), static_cast<const int*>(S),
-               n_vox_total, D * H * W, H * W, ranks_bev, ranks_depth, ranks_feat);
+               static_cast<const unsigned*>(keys[cur]), static_cast<const int*>(vals[cur]), static_cast<const int*>(counts),
+               D * H * W, H * W, ranks_bev, ranks_depth, ranks_feat);
   return (int)hipGetLastError();
 }
 
@@ -753,10 +809,14 @@ int ocrf_ht_prepare(int B, int N, int Z, int n_pillars, int Wf, int Hf, int D, c
   const dim3 cgrid((n_pillars + kBlock - 1) / kBlock, B * N);
   const int pgrid = (B * n_pillars + kBlock - 1) / kBlock;
   const HtCam* hc = reinterpret_cast<const HtCam*>(cams);
-  ocrf::launch(OCRF_K_HT_COUNT, ht_valid_kernel, cgrid, dim3(kBlock), 0, stream, q, ref_points, hc, valid_bits);
+  // scratch holds the look-back state of the scan: (tiles + 1) words, zero-filled by the first kernel
+  auto* state = reinterpret_cast<unsigned long long*>(scratch);
+  const int state_words = (int)(((long)B * n_pillars + kChunk - 1) / kChunk + 1);
+  ocrf::launch(OCRF_K_HT_COUNT, ht_valid_kernel, cgrid, dim3(kBlock), 0, stream, q, ref_points, hc, valid_bits, state,
+               state_words);
   hipLaunchKernelGGL(ht_pillar_totals_kernel, dim3(pgrid), dim3(kBlock), 0, stream, q,
                      static_cast<const unsigned*>(valid_bits), cnt_flag);
-  scan_exclusive<long long>(cnt_flag, (long)B * n_pillars, total, scratch, stream);
+  scan_exclusive_lookback<long long>(cnt_flag, (long)B * n_pillars, total, state, stream);
   ocrf::launch(OCRF_K_HT_EMIT, ht_emit_kernel, cgrid, dim3(kBlock), 0, stream, q, ref_points, hc,
                static_cast<const unsigned*>(valid_bits), static_cast<const long long*>(cnt_flag), ranks_bev, ranks_depth,
                ranks_feat, interval_starts, interval_lengths);
