@@ -147,13 +147,13 @@ def bench_neck(args, cfg, dev, world, rank):
             step()
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=CONTROL)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=CONTROL)
     elapsed = time.perf_counter() - t0
     # kernel events cannot bracket launches inside a graph replay: the pooling kernel is timed over a
     # short eager run of the same step right after the timed region
@@ -165,8 +165,8 @@ def bench_neck(args, cfg, dev, world, rank):
     torch.cuda.synchronize()
     timer.disarm()
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=CONTROL)
         elapsed = float(t.item())
     if rank == 0:
         ms = timer.read_ms()
@@ -205,7 +205,10 @@ def bench_neck(args, cfg, dev, world, rank):
         print(json.dumps(out), flush=True)
     timer.close()
     if world > 1:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:       # noqa: BLE001
+            pass
 
 
 def pmc_counters(kernel_prefix):
@@ -230,21 +233,36 @@ def hbm_traffic(c):
     return (2.0 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024.0
 
 
+CONTROL = None      # gloo group of all ranks: barriers, the max-over-ranks of the clock, agreement on errors
+
+
+def agree(ok, world):
+    """True iff every rank says ok (control plane, CPU): a rank that caught an exception must not leave the
+    others inside a collective."""
+    if world == 1:
+        return bool(ok)
+    import torch.distributed as dist
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=CONTROL)
+    return bool(t.item())
+
+
 def timed(step, steps, world, dev):
+    """steps x step() bracketed by a barrier + torch.cuda.synchronize() on both sides; the MAX over ranks."""
     import torch.distributed as dist
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=CONTROL)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=CONTROL)
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=CONTROL)
         elapsed = float(t.item())
     return elapsed
 
@@ -260,10 +278,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        import datetime
         if args.backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank),
+                                    timeout=datetime.timedelta(seconds=300))
         else:
             dist.init_process_group(args.backend)
+        global CONTROL
+        CONTROL = dist.new_group(backend='gloo')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
@@ -276,9 +298,21 @@ def main():
     X, Y, Z = cfg.bev_xyz
     active = True
     sp = None
+    shard_error = None
     if shard == 'camera_frames':
-        sp = hotpath.ShardedHotPath(cfg, dev, rank, world, index_prep_mode=args.index_prep)
-        sp_inputs = sp.make_inputs(seed=0)
+        # the exchange has only ever run over gloo on the build box (one GPU): if RCCL refuses any part of it, every
+        # rank falls back to the samples layout TOGETHER and the line says so, instead of one rank dying in a collective
+        try:
+            sp = hotpath.ShardedHotPath(cfg, dev, rank, world, index_prep_mode=args.index_prep)
+            sp_inputs = sp.make_inputs(seed=0)
+            for _ in range(2):
+                sp.step(sp_inputs)
+            torch.cuda.synchronize()
+        except Exception as e:       # noqa: BLE001
+            shard_error = f'{type(e).__name__}: {e}'[:300]
+        if not agree(shard_error is None, world):
+            shard_error = shard_error or 'another rank failed in the camera-frame exchange'
+            sp, shard = None, 'samples'
     if shard == 'cameras':
         # round 1's layout: rank r < n_cams owns cameras r, r + world', ... (world' active ranks)
         n_active = min(world, cfg.n_cams)
@@ -449,6 +483,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'per_step_ms': per_step_ms,
             'per_step_device_geometry_ms': per_step_devgeom_ms, 'higher_is_better': True,
+            **({'sharding_fallback': 'camera_frames -> samples: ' + shard_error} if shard_error else {}),
             'scaling': 'strong' if strong else 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': cfg.name, 'cams': cfg.n_cams, 'frames_per_gpu': cfg.n_frames,
@@ -479,7 +514,10 @@ def main():
             t.close()
     if world > 1:
         import torch.distributed as dist
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:       # noqa: BLE001  (a communicator that failed above may refuse to shut down cleanly)
+            pass
 
 
 if __name__ == '__main__':
