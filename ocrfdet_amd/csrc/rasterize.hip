@@ -587,7 +587,14 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
           // broadcast operand out of slot 3, one v_mov per record), per-record scalars (cxx, cxy, depth) in slot 3
           l_a[tid] = make_float4(p.x, p.y, -0.5f * co.z, -0.5f * co.x);
           l_b[tid] = make_float4((cov & 1u) ? co.w : 0.f, (cov & 2u) ? co.w : 0.f, col[0], co.y);
-          l_c[tid] = make_float4(col[1], col[2], __uint_as_float((unsigned)(c >> 32)), __uint_as_float(cov));
+          // slot w: the power below which this record's alpha is under 1/255 for BOTH tiles whatever the pixel
+          // (alpha = o exp(power) < 1/255  <=  power < ln(1 / (255 o)); 1 % margin for v_exp_f32 and the
+          // log2(e) multiply) with the two coverage bits in its lowest mantissa bits.  o <= 0 gives +inf (never
+          // above 1/255), a NaN opacity gives NaN (the test below fails: evaluated in full).
+          const float omax = (cov == 3u) ? co.w : ((cov != 0u) ? co.w : 0.f);
+          const float thr = (omax > 0.f) ? (__logf(1.0f / (255.0f * omax)) - 0.01f) : ((omax <= 0.f) ? INFINITY : omax);
+          l_c[tid] = make_float4(col[1], col[2], __uint_as_float((unsigned)(c >> 32)),
+                                 __uint_as_float((__float_as_uint(thr) & ~3u) | cov));
         }
       } else if (!BWD && tid < ((ns + 3) & ~3)) {
         // pad the batch to a multiple of four records with no-ops (opacity 0): the loop reads 4 per trip
@@ -632,6 +639,19 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
             const f2 dy = splat(a.y) - pixf_y;
             const f2 qy = (splat(a.z) * dy) * dy;
             const f2 power = (splat(qx) + qy) - splat(bx) * dy;          // qx, qy carry the -0.5 (staging)
+            // Wave-uniform skip: if no pixel of the wave can reach alpha >= 1/255 on this record, everything below
+            // leaves the state as it is (alpha = 0: weight 0, test_T = T, no median crossing) — about a third of a
+            // tile pair's records lie in the corners of their 3-sigma square or beyond the wave's rows.  A NaN
+            // power fails the test and is evaluated in full, like the reference (min(0.99, NaN) = 0.99).
+            const float thr = rc4[u].w;
+            if (__ballot(!((power.x <= thr) & (power.y <= thr))) == 0ull) {
+              if constexpr (CONTRIB) {
+                const unsigned cov = __builtin_amdgcn_readfirstlane(__float_as_uint(rc4[u].w));
+                jA += (int)(cov & 1u);
+                jB += (int)((cov >> 1) & 1u);
+              }
+              continue;
+            }
             const f2 p2 = power * splat(1.44269504088896340736f);       // __expf(x) = v_exp_f32(log2(e) x)
             f2 G;
             G.x = __builtin_amdgcn_exp2f(p2.x);
