@@ -134,7 +134,8 @@ def bench_neck(args, cfg, dev, world, rank):
     neck = hotpath.NeckPath(cfg, dev, accelerate=args.index_prep == 'cached', seed=rank,
                             host_calibration=args.host_calibration)
     neck.module.device_geometry = bool(args.device_geometry)
-    graphed = args.index_prep == 'cached' and not args.no_graph
+    # one hipGraph replay per step: cached geometry, or the per-forward geometry inside the graph (device geometry)
+    graphed = (args.index_prep == 'cached' or args.device_geometry) and not args.no_graph
     for _ in range(args.warmup):
         neck.step()
     step = neck.step

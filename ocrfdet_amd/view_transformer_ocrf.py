@@ -786,6 +786,10 @@ class OcRFViewTransformerFull(nn.Module):
                 cam_idx_list = [random.randint(0, 5) for _ in range(B)]
             cameras = self.stage_cameras(geo, cam_idx_list, x.device)
         cam_idx_list, cam_sel = cameras['cam_idx_list'], cameras['cam_sel']
+        if cameras.get('packed') is None:
+            # only the choice was staged (a captured per-forward-geometry graph): the rasteriser's rows of the chosen
+            # cameras are picked on the device from the rows ocrf_geometry_blocks made for every camera-frame
+            cameras = dict(cameras, packed=geo.cam_rows_dev[torch.arange(B, device=x.device), cam_sel.long()].contiguous())
         voxel_coor = geo.voxel.reshape(B, Zh * Y * X, 3)
         if fused:
             return self._core_fused(input, geo, depth, depth5, feat_cl, cameras, voxel_coor)
@@ -1020,7 +1024,11 @@ class OcRFViewTransformerFull(nn.Module):
 
 class GraphedNeck:
     """``OcRFViewTransformerFull`` inference (pre-filter + ``view_transform``) as ONE hipGraph launch per
-    call, for a static calibration (``accelerate=True``) and fixed shapes:
+    call for fixed shapes — with a static calibration (``accelerate=True``: the geometry is cached outside the
+    graph) or, with ``module.device_geometry`` and the calibration tensors on the GPU, with the per-forward geometry
+    INSIDE the graph (``accelerate=False``, the reference's working mode: calibration algebra, both index
+    preparations and everything after them replay as one launch; the calibration values are copied into the
+    graph's static inputs on every call):
 
         neck = GraphedNeck(module, example_input, example_depthnet_out)   # captures
         bev_feat, depth, (bev_mask, semantic), extras = neck(input, depthnet_out)
@@ -1035,8 +1043,12 @@ class GraphedNeck:
 
     def __init__(self, module, example_input, example_depthnet_out, warmup=3, parallel_branches=True,
                  capture_stream=None):
-        if not module.accelerate:
-            raise RuntimeError('GraphedNeck needs accelerate=True (geometry cached across calls)')
+        calib_on_dev = all(torch.is_tensor(example_input[i]) and example_input[i].is_cuda for i in (1, 2, 3, 4, 5, 6, 11))
+        self.per_forward_geometry = not module.accelerate
+        if self.per_forward_geometry and not (getattr(module, 'device_geometry', False) and calib_on_dev):
+            raise RuntimeError('GraphedNeck needs accelerate=True (geometry cached across calls), or '
+                               'module.device_geometry = True with the calibration tensors on the GPU (geometry inside '
+                               'the graph): the host formulation of the calibration algebra cannot be captured')
         if module.training:
             raise RuntimeError('GraphedNeck is inference only: call module.eval() first')
         self.module = m = module
@@ -1047,7 +1059,12 @@ class GraphedNeck:
         self.batch = self.inputs[0].shape[0]
         with torch.no_grad():
             self._body(None)                       # geometry, packs, workspaces, MIOpen algorithms
-            self._cams = m.stage_cameras(m._geo, [0] * self.batch, dev)
+            if self.per_forward_geometry:
+                # only the camera choice is staged; the rows follow from the in-graph geometry
+                self._cams = dict(cam_sel=torch.zeros(self.batch, dtype=torch.int32, device=dev), packed=None,
+                                  cam_idx_list=[0] * self.batch)
+            else:
+                self._cams = m.stage_cameras(m._geo, [0] * self.batch, dev)
             m.parallel_branches = parallel_branches
             try:
                 side = torch.cuda.Stream(dev)
@@ -1077,13 +1094,19 @@ class GraphedNeck:
         """Replay on the values already in the static buffers (``self.inputs``, ``self.depthnet_out``)."""
         if cam_idx_list is None:
             cam_idx_list = [random.randint(0, 5) for _ in range(self.batch)]
-        self.module.stage_cameras(self.module._geo, cam_idx_list, self.device, out=self._cams)
+        if self.per_forward_geometry:
+            self._cams['cam_sel'].copy_(self.module._small_h2d(torch.tensor(list(cam_idx_list), dtype=torch.int32),
+                                                               self.device))
+            self._cams['cam_idx_list'] = list(cam_idx_list)
+        else:
+            self.module.stage_cameras(self.module._geo, cam_idx_list, self.device, out=self._cams)
         self._graph.replay()
         bev, depth, masks, ex = self._static_out
         return bev, depth, masks, list(ex[:5]) + [list(cam_idx_list)] + list(ex[6:])
 
     def __call__(self, input, depthnet_out, cam_idx_list=None):
-        for i in (0, 8, 9, 10):                    # image features and the three raw-image variants
+        # image features and the three raw-image variants; with the geometry inside the graph also the calibration
+        for i in (0, 8, 9, 10) + ((1, 2, 3, 4, 5, 6, 11) if self.per_forward_geometry else ()):
             if torch.is_tensor(input[i]) and input[i] is not self.inputs[i]:
                 self.inputs[i].copy_(input[i], non_blocking=True)
         if depthnet_out is not self.depthnet_out:

@@ -124,3 +124,36 @@ def test_forward_with_device_geometry_does_not_synchronise(cuda):
         d = (a - b).abs()
         frac = float((d > 1e-4).float().mean())
         assert frac <= 2e-3, f'{what}: {frac:.2e} of the elements differ by more than 1e-4'
+
+
+def test_graph_with_the_geometry_inside_follows_the_calibration(cuda):
+    """GraphedNeck on an ``accelerate=False`` module with ``device_geometry``: calibration algebra, both index
+    preparations and the rest of the forward replay as ONE hipGraph launch, and the replay follows the calibration
+    VALUES of each call (copied into the graph's static inputs) — equal to the eager per-forward path bit for bit."""
+    from ocrfdet_amd import hotpath
+    cfg = synthetic.CONFIGS['ref_6cam_256x704_bev128x128x1']
+    neck = hotpath.NeckPath(cfg, cuda, accelerate=False)
+    neck.module.device_geometry = True
+    with torch.no_grad():
+        neck.step()                                   # allocations, packs, MIOpen algorithms
+        neck.capture()
+        cams = [2] * neck.batch
+        base = [t.clone() if torch.is_tensor(t) else t for t in neck.inputs]
+        for trial in range(2):
+            inp = [t.clone() if torch.is_tensor(t) else t for t in base]
+            if trial == 1:                            # another rig pose: yaw the ego frame, move the cameras
+                a = 0.07
+                R = torch.tensor([[math.cos(a), -math.sin(a), 0], [math.sin(a), math.cos(a), 0], [0, 0, 1.0]], device=cuda)
+                inp[6] = (R @ inp[6]).contiguous()
+                inp[2] = inp[2] + 0.05
+            m = neck.module
+            depth, fdepth, sem, feat_cl = neck._ops.prefilter(neck.depthnet_out, m.D, m.out_channels, m.depth_threshold,
+                                                              m.semantic_threshold)
+            want = m.view_transform_core(inp, fdepth, None, feat_cl, cam_idx_list=cams)
+            got = neck._graphed(inp, neck.depthnet_out, cam_idx_list=cams)
+            torch.cuda.synchronize()
+            assert torch.equal(got[0], want[0]), f'trial {trial}: BEV feature differs'
+            assert torch.equal(got[3][0], want[3][0]), f'trial {trial}: rendered image differs'
+            if trial == 1:
+                assert not torch.equal(got[0], first), 'the replay ignored the new calibration'
+            first = got[0].clone()
