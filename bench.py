@@ -116,8 +116,8 @@ def cpu_baseline(hp, depth, feat, budget_s):
         t_view = el / n_views_timed
     t_step = t_pools + hp.views_per_step * t_view
     return dict(value=hp.bev_voxels_per_step / t_step, unit='BEV voxels/s', cores=oracle.num_threads(),
-                cores_note='OpenMP threads of the pooling and of the per-Gaussian / per-tile loops; the '
-                           'reference-structured sort of all tile instances inside a view is ONE thread (qsort)',
+                cores_note='OpenMP threads of the pooling, of the per-Gaussian / per-tile loops and of the per-tile '
+                           'sorts of the tile instances (bucketed by tile first; the histogram pass is one thread)',
                 kind='port', ms_per_step=1e3 * t_step, ms_pools=1e3 * t_pools, ms_per_view=1e3 * t_view,
                 views_per_sec=(hp.views_per_step / t_step) if hp.views_per_step else 0.0,
                 sample=f'{n} x (LSS pool + HT pool of the whole step, same inputs and ranks as the GPU)'

@@ -251,7 +251,32 @@ static long forward_impl(int P, const float *background, int W, int H, const flo
     const int bit = (int)getHigherMsb((uint32_t)(gx * gy));
     const uint64_t mask = (32 + bit >= 64) ? ~0ull : ((1ull << (32 + bit)) - 1ull);
     for (long i = 0; i < R; i++) kv[i].key &= mask; /* radix sort only looks at these bits */
-    qsort(kv, (size_t)R, sizeof(kv_t), kv_cmp);
+    /* the same total order (key, then position: cub's radix sort is stable) as one qsort over all R pairs, on all
+     * cores: bucket by the tile word, then sort every tile's pairs by (depth bits, position) independently */
+    {
+        const size_t nb = (size_t)1 << (bit < 31 ? bit : 31);
+        uint32_t *start = (uint32_t *)calloc(nb + 1, sizeof(uint32_t));
+        uint32_t *cursor = (uint32_t *)malloc(nb * sizeof(uint32_t));
+        kv_t *tmp = (kv_t *)malloc(sizeof(kv_t) * (size_t)(R > 0 ? R : 1));
+        if (!start || !cursor || !tmp) { free(start); free(cursor); free(tmp); free(kv); return -1; }
+        for (long i = 0; i < R; i++) start[(kv[i].key >> 32) + 1]++;
+        for (size_t b = 0; b < nb; b++) start[b + 1] += start[b];
+        memcpy(cursor, start, nb * sizeof(uint32_t));
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < R; i++) {
+            uint32_t at;
+            uint32_t *c = &cursor[kv[i].key >> 32];
+#pragma omp atomic capture
+            at = (*c)++;
+            tmp[at] = kv[i];
+        }
+#pragma omp parallel for schedule(dynamic, 1)
+        for (long b = 0; b < (long)nb; b++)
+            if (start[b + 1] - start[b] > 1) qsort(tmp + start[b], start[b + 1] - start[b], sizeof(kv_t), kv_cmp);
+        free(kv);
+        kv = tmp;
+        free(start); free(cursor);
+    }
 
     /* ---- identifyTileRanges, rasterizer_impl.cu:116-138 (ranges zero-initialised :310) ---- */
     const int ntiles = gx * gy;
