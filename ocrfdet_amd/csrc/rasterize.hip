@@ -43,7 +43,7 @@ constexpr int kBucketShift = 14;             // bucket = (depth bits >> 14) - ba
 constexpr unsigned kBucketBase = 0x3E4CCCCDu >> kBucketShift;   // depth > 0.2f always (auxiliary.h:154)
 constexpr int kChunk = 2048;                 // compact records per workgroup in the scatter
 constexpr int kPreChunk = 1024;              // Gaussians per workgroup in the preprocess
-constexpr int kCapRec = 2048;                // LDS record capacity of the blend kernel (28 KB with the stage: 4 workgroups per CU)
+constexpr int kCapRec = 2048;                // LDS record capacity of the blend kernel (28 KB with the stage: 5 workgroups per CU)
 constexpr int kStage = 256;                  // payload entries staged per blend batch
 constexpr int kScanUnroll = 4;               // rect batches in flight in the scan
 constexpr unsigned long long kPad = ~0ull;
@@ -614,21 +614,23 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
         //     "stops" again, which changes nothing;
         //   * median depth: T > 0.5 and test_T < 0.5 can only hold for a blended Gaussian (alpha <= 0.99).
         // Same arithmetic, same order and therefore the same bits as the mask formulation it replaces
-        // (tools/render_hash.py); 4 records per trip, wave-level early exit.
+        // (tools/render_hash.py); 2 records per trip (87 VGPRs: 5 workgroups per CU; 4 per trip needs 111 = 4
+        // workgroups and is 2 % slower), wave-level early exit.
         const int ns4 = (ns + 3) & ~3;
         f2 h = T - splat(0.5f);
-        for (int j0 = 0; j0 < ns4; j0 += 4) {
+        constexpr int kTrip = 2;
+        for (int j0 = 0; j0 < ns4; j0 += kTrip) {
           // live <=> sign bit of T clear (T is never +-0: a live T is >= 1e-4, a stopped one is -|T|)
           if (__ballot((__float_as_int(T.x) & __float_as_int(T.y)) >= 0) == 0ull) break;
-          float4 ra[4], rb[4], rc4[4];
+          float4 ra[kTrip], rb[kTrip], rc4[kTrip];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < kTrip; ++u) {
             ra[u] = l_a[j0 + u];
             rb[u] = l_b[j0 + u];
             rc4[u] = l_c[j0 + u];
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < kTrip; ++u) {
             const float4 a = ra[u];
             const float4 b = rb[u];
             const float cr = b.z, cg = rc4[u].x, cb = rc4[u].y, dep = rc4[u].z;
