@@ -643,22 +643,50 @@ __global__ __launch_bounds__(kBlock) void hoa_unet_block_fixed_kernel(UnetBlockA
   if (MODE == 2) {
     for (int i = tid; i < C0 * CUP * 4; i += kBlock) s_upw[i] = a.up_w[i];
   }
+  // The raw values of this thread's (at most two) halo pixels are requested BEFORE the producers' gates are rebuilt
+  // from their per-tile maxima: both are global round trips and a block is a latency chain (16-338 workgroups).
+  constexpr int kIt = (kUH * kUH + kBlock - 1) / kBlock;
+  float raw0[kIt][C0], raw1[kIt][C1 > 0 ? C1 : 1];
+#pragma unroll
+  for (int it = 0; it < kIt; ++it) {
+    const int i = tid + it * kBlock;
+    const int hy = i / kUH, hx = i % kUH;
+    const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+    const bool in = (i < kUH * kUH) && (y >= 0) && (y < H) && (x >= 0) && (x < W);
+#pragma unroll
+    for (int c = 0; c < C0; ++c) {
+      float v = 0.f;
+      if (in) {
+        const float* p = a.src0 + ((long)b * C0 + c) * a.H0 * a.W0;
+        if (MODE == 2) {
+          v = p[(long)(y >> 1) * a.W0 + (x >> 1)];
+        } else if (MODE == 1) {
+          const float* q = p + (long)(2 * y) * a.W0 + 2 * x;
+          v = fmaxf(fmaxf(q[0], q[1]), fmaxf(q[a.W0], q[a.W0 + 1]));
+        } else {
+          v = p[(long)y * a.W0 + x];
+        }
+      }
+      raw0[it][c] = v;
+    }
+#pragma unroll
+    for (int c = 0; c < C1; ++c) raw1[it][c] = in ? a.src1[(((long)b * C1 + c) * H + y) * W + x] : 0.f;
+  }
   load_gate_dev(b, C0, a.gate0, a.pm0, a.g0w1, a.g0w2, a.g0hid, a.g0tiles, s_g0, s_gm, s_gh);
   if (C1 > 0) load_gate_dev(b, C1, a.gate1, a.pm1, a.g1w1, a.g1w2, a.g1hid, a.g1tiles, s_g1, s_gm, s_gh);
 
-  for (int i = tid; i < kUH * kUH; i += kBlock) {
+#pragma unroll
+  for (int it = 0; it < kIt; ++it) {
+    const int i = tid + it * kBlock;
+    if (i >= kUH * kUH) continue;
     const int hy = i / kUH, hx = i % kUH;
     const int y = ty0 + hy - 1, x = tx0 + hx - 1;
     const bool in = (y >= 0) && (y < H) && (x >= 0) && (x < W);
-    float sv[C0];
     if (MODE == 2) {
-      const int sy = in ? (y >> 1) : 0, sx = in ? (x >> 1) : 0, ki = (y & 1) * 2 + (x & 1);
+      const int ki = (y & 1) * 2 + (x & 1);
+      float sv[C0];
 #pragma unroll
-      for (int ci = 0; ci < C0; ++ci) {
-        float v = in ? a.src0[(((long)b * C0 + ci) * a.H0 + sy) * a.W0 + sx] : 0.f;
-        v *= s_g0[ci];
-        sv[ci] = v;
-      }
+      for (int ci = 0; ci < C0; ++ci) sv[ci] = raw0[it][ci] * s_g0[ci];
 #pragma unroll
       for (int co = 0; co < CUP; ++co) {
         float acc = a.up_b[co];
@@ -668,32 +696,10 @@ __global__ __launch_bounds__(kBlock) void hoa_unet_block_fixed_kernel(UnetBlockA
       }
     } else {
 #pragma unroll
-      for (int c = 0; c < C0; ++c) {
-        float v = 0.f;
-        if (in) {
-          const float* p = a.src0 + ((long)b * C0 + c) * a.H0 * a.W0;
-          if (MODE == 1) {
-            const float* q = p + (long)(2 * y) * a.W0 + 2 * x;
-            v = fmaxf(fmaxf(q[0], q[1]), fmaxf(q[a.W0], q[a.W0 + 1]));
-          } else {
-            v = p[(long)y * a.W0 + x];
-          }
-          v *= s_g0[c];                              // gates > 0: commutes with the max-pool
-        }
-        sv[c] = v;
-      }
-#pragma unroll
-      for (int c = 0; c < C0; ++c) s_v[c][hy][hx] = sv[c];
+      for (int c = 0; c < C0; ++c) s_v[c][hy][hx] = in ? raw0[it][c] * s_g0[c] : 0.f;      // gates > 0: commute with the max-pool
     }
 #pragma unroll
-    for (int c = 0; c < C1; ++c) {
-      float v = 0.f;
-      if (in) {
-        v = a.src1[(((long)b * C1 + c) * H + y) * W + x];
-        v *= s_g1[c];
-      }
-      s_v[CF + c][hy][hx] = v;
-    }
+    for (int c = 0; c < C1; ++c) s_v[CF + c][hy][hx] = in ? raw1[it][c] * s_g1[c] : 0.f;
   }
   __syncthreads();
 
