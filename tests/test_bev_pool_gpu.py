@@ -268,6 +268,28 @@ def test_backward_parity(cuda, oracle_lib):
     np.testing.assert_allclose(f.grad.cpu().numpy(), want_f, rtol=1e-4, atol=1e-4)
 
 
+def test_backward_parity_full_size_through_the_fused_op(cuda, oracle_lib):
+    """cfg2 (6 cams x 2 frames, BEV 200 x 200, 852 k points): the gradients of the drop-in ``bev_pool_v2`` (fused
+    forward writing (B,C,Z,Y,X) directly, HIP backward) against the C oracle's backward on the same ranks."""
+    cfg = synthetic.CONFIGS['cfg2_6cam_2frame_bev200x200_render_hoa']
+    depth, feat = helpers.pool_inputs(cfg)
+    rb, rd, rf, st, ln = helpers.lss_ranks(cfg)
+    X, Y, Z = cfg.bev_xyz
+    B = depth.shape[0]
+    shape = (B, Z, Y, X, cfg.channels)
+    rng = np.random.default_rng(11)
+    og = rng.standard_normal(shape).astype(np.float32)                      # gradient in the op's (B,Z,Y,X,C) frame
+    want_d, want_f = oracle_lib.bev_pool_v2_backward(og, depth, feat, rd, rf, rb)
+    d = _dev(depth, cuda).requires_grad_()
+    f = _dev(feat, cuda).requires_grad_()
+    out = bevpool.bev_pool_v2(d, f, _dev(rd, cuda), _dev(rf, cuda), _dev(rb, cuda), shape, _dev(st, cuda), _dev(ln, cuda))
+    assert tuple(out.shape) == (B, cfg.channels, Z, Y, X)
+    out.backward(_dev(og, cuda).permute(0, 4, 1, 2, 3).contiguous())       # the same gradient in (B,C,Z,Y,X)
+    scale_d, scale_f = float(np.abs(want_d).max()), float(np.abs(want_f).max())
+    assert float(np.abs(d.grad.cpu().numpy() - want_d).max()) <= 1e-4 * max(scale_d, 1.0)
+    assert float(np.abs(f.grad.cpu().numpy() - want_f).max()) <= 1e-4 * max(scale_f, 1.0)
+
+
 @pytest.mark.parametrize('cfg_name', ['cfg0_1cam_128x352_bev64x64x4', 'ref_6cam_256x704_bev128x128x1'])
 def test_backward_ht_ranks_repeated_depth_cells(cuda, oracle_lib, cfg_name):
     """HT ranks: several pillar samples round to the same (camera, d, h, w) depth cell, so ``ranks_depth``
