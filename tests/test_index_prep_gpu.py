@@ -134,3 +134,47 @@ def test_per_step_path_without_host_reads_equals_cached_path(cuda, key):
     torch.cuda.synchronize()
     for g, w in zip(got, want):
         assert torch.equal(g, w)
+
+
+SWEEP = [  # (B, N, input H, W, BEV Y, X, z cells, heights): one-tile grids, ragged tiles, several scan tiles, empty cameras
+    (1, 1, 32, 48, 4, 4, 1, 5), (1, 2, 64, 96, 9, 17, 2, 6), (2, 3, 64, 176, 33, 31, 1, 13), (3, 1, 128, 160, 64, 64, 4, 7),
+    (1, 6, 96, 128, 130, 70, 1, 13), (2, 2, 48, 64, 257, 3, 1, 8)]
+
+
+@pytest.mark.parametrize('B,N,H,W,Y,X,Zc,Zh', SWEEP)
+def test_prepare_hip_equals_the_torch_formulation_on_a_shape_sweep(cuda, B, N, H, W, Y, X, Zc, Zh):
+    """Edge sizes of the single-launch prefix sums and of the interval kernel (fewer voxels than a workgroup, ragged last
+    tiles, several look-back tiles, cameras that see nothing, samples with no points): rank vectors and intervals of
+    both preparations, element for element, against the CPU torch formulation the reference's vectors pin."""
+    rng = np.random.default_rng(B * 1000 + N * 100 + Y)
+    r = synthetic.rig(N, (H, W), B)
+    r['trans'] = (r['trans'] + rng.uniform(-0.3, 0.3, r['trans'].shape)).astype(np.float32)
+    args = [torch.from_numpy(r[k]) for k in ('rots', 'trans', 'intrins', 'post_rots', 'post_trans', 'bda')]
+    half_x, half_y = 0.4 * X, 0.4 * Y
+    grid = dict(x=[-half_x, half_x, 0.8], y=[-half_y, half_y, 0.8], z=[-5.0, 3.0, 8.0 / Zc], depth=[1.0, 45.0, 1.0])
+    pc_range = [-half_x, -half_y, -5.0, half_x, half_y, 3.0]
+    frustum = pip_.create_frustum(grid['depth'], (H, W), 16)
+    lower, interval, size = pip_.grid_infos(grid)
+    D = frustum.shape[0]
+    Hf, Wf = H // 16, W // 16
+    block = pip_.lss_camera_block(*args)
+    got = pip_.voxel_pooling_prepare_v2_hip(frustum.to(cuda), block.to(cuda), B, N, lower, interval, size)
+    coor = pip_.get_lidar_coor(frustum, *args)
+    want = pip_.voxel_pooling_prepare_v2(coor, lower, interval, size)
+    for name, g_, w_ in zip(('ranks_bev', 'ranks_depth', 'ranks_feat', 'starts', 'lengths'), got, want):
+        if w_ is None:
+            assert g_ is None or g_.numel() == 0, f'lss {name}: expected nothing'
+        else:
+            np.testing.assert_array_equal(g_.cpu().numpy(), w_.numpy(), err_msg=f'lss {name}')
+    lidar2img, img_aug, _, _ = pip_.get_projection(*args)
+    template = pip_.get_reference_points_3d(Y, X, bs=1, num_points_in_pillar=Zh, device='cpu')[0]
+    got = pip_.fast_sample_prepare_hip(template.to(cuda), pip_.ht_camera_block(lidar2img, img_aug).to(cuda), B, N, pc_range,
+                                       (H, W), grid['depth'], Wf, Hf, D)
+    ref = pip_.get_reference_points_3d(Y, X, bs=B, num_points_in_pillar=Zh, device='cpu')
+    c, m, _ = pip_.get_sampling_point(ref, pc_range, grid['depth'], lidar2img, img_aug, (H, W))
+    want = pip_.fast_sample_prepare(c, m, Wf, Hf, D)
+    for name, g_, w_ in zip(('ranks_bev', 'ranks_depth', 'ranks_feat', 'starts', 'lengths'), got, want):
+        if w_ is None:
+            assert g_ is None or g_.numel() == 0, f'ht {name}: expected nothing'
+        else:
+            np.testing.assert_array_equal(g_.cpu().numpy(), w_.numpy(), err_msg=f'ht {name}')
