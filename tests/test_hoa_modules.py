@@ -143,6 +143,27 @@ def test_hoa1_gpu(cuda, g):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('B,Y,X', [(1, 36, 36), (1, 48, 132), (3, 100, 60), (2, 128, 200), (1, 236, 44)])
+def test_hoa1_fused_kernels_on_other_map_sizes(cuda, g, B, Y, X):
+    """The two-launch HOA-1 (kv tokens with rebuilt q rows; attention + upsample per 16x16 output tile with a window of
+    at most 5 x 5 tokens) against the reference's op sequence on maps that are not square, not multiples of the tile,
+    the smallest legal size (Y/6 = 6 tokens) and a single-column kv grid."""
+    m = hoa.DeformableAttention2D(dim=13, dim_head=8, heads=1, dropout=0.1, downsample_factor=4, offset_scale=4,
+                                  offset_groups=None, offset_kernel_size=6).to(cuda).eval()
+    m.load_state_dict(_sd(g, 'dca'))
+    rng = np.random.default_rng(Y * 1000 + X)
+    op = torch.from_numpy(rng.random((B, 13, Y, X), dtype=np.float32)).to(cuda)
+    al = torch.from_numpy(rng.random((B, 13, Y, X), dtype=np.float32)).to(cuda)
+    with torch.no_grad():
+        fused = hoa.hoa1(m, op.reshape(-1, 1), al, 13, Y, X)
+        m.train()
+        m.dropout.p = 0.0
+        ref = hoa.hoa1(m, op.reshape(-1, 1), al, 13, Y, X)
+        m.eval()
+    np.testing.assert_allclose(fused.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.gpu
 def test_hoa_modules_keep_gradients_under_autograd():
     """The HIP kernels are forward-only: with autograd recording, every HOA module must fall back to
     differentiable torch ops (a silent gradient cut would break training as a drop-in) and agree with
