@@ -238,3 +238,24 @@ def test_full_size_properties_of_the_bench_scene(cuda):
     assert 'n_contrib' not in f
     for k in ('color', 'depth', 'final_T', 'radii'):
         assert torch.equal(f[k], a[k]), k
+
+
+def test_opacity_edge_values(cuda, oracle_lib):
+    """Opacities at the edges of what the per-record skip threshold of the blend assumes: exactly 0, far below and
+    right around the 1/255 alpha cut, 1, and above 1 (the op accepts any float; alpha is then clamped at 0.99) — both
+    kernel variants (with and without the contributor index) against the oracle."""
+    rng = np.random.default_rng(12)
+    n = 6000
+    W, H = 176, 96
+    view, full, tfx, tfy = helpers.simple_camera(W, H)
+    xyz, rgb, opac, sc, rot = helpers.random_gaussians(rng, n)
+    edge = np.float32([0.0, 1e-6, 1e-3, 1.0 / 255.0 * 0.999, 1.0 / 255.0, 1.0 / 255.0 * 1.001, 0.01, 1.0, 1.5, 3.0])
+    opac = edge[rng.integers(0, edge.size, n)].reshape(n, 1).astype(np.float32)
+    want, got = _both(oracle_lib, cuda, xyz, rgb, opac, sc, rot, view, full, tfx, tfy, H, W, bg=(0.05, 0.1, 0.15))
+    _compare(want, got, H, W)
+    inf = dgr.rasterize_views(_t(xyz, cuda), _t(rgb, cuda), _t(opac, cuda), _t(sc, cuda), _t(rot, cuda),
+                              _t(view, cuda).view(1, 4, 4), _t(full, cuda).view(1, 4, 4), [tfx], [tfy], H, W,
+                              _t(np.float32((0.05, 0.1, 0.15)), cuda), want_n_contrib=False)
+    torch.cuda.synchronize()
+    for k in ('color', 'depth', 'final_T'):                 # the inference variant: bit-identical to the other one
+        np.testing.assert_array_equal(inf[k].cpu().numpy(), got[k])
