@@ -513,19 +513,21 @@ __global__ __launch_bounds__(kBlock, 5) void bev_pool_tile_kernel(TileArgs a, un
       __syncthreads();
       write_tile = *s_flag != 0;
       if (write_tile) {
-        if (tid == 0) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          // the ticket counter is back at 0 for the next call (plans keep it across calls)
-          __hip_atomic_store(&a.arrive[tileid], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const float4* s0 = a.slabs + (long)ti.y * kTV * c4;
+        // the ticket counter is back at 0 for the next call (plans keep it across calls)
+        if (tid == 0) __hip_atomic_store(&a.arrive[tileid], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // The slabs are read with system-scope loads (sc0 sc1: served past this XCD's L2, where the other slices'
+        // write-through stores are) instead of an agent-scope acquire fence: the fence is a buffer_inv that throws
+        // away the L2 contents every other workgroup of the XCD is gathering feat rows from.
+        float4* s0 = a.slabs + (long)ti.y * kTV * c4;
+        const auto srs = __builtin_amdgcn_make_buffer_rsrc(s0, 0, ti.x * kTV * c4 * (int)sizeof(float4), 0x00020000);
         if (gi < gpw) {
           for (int v = gb; v < nv; v += gpb) {
-            const float4* sp = s0 + v * c4 + lg;
-            float4 acc = *sp;
-            for (int s = 1; s < ti.x; ++s) acc = add4(acc, sp[(long)s * kTV * c4]);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int s = 0; s < ti.x; ++s) {
+              const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(srs, ((s * kTV + v) * c4 + lg) * (int)sizeof(float4), 0, 17);
+              const float4 x = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+              acc = s == 0 ? x : add4(acc, x);
+            }
             tile[v * ldq + lg] = acc;
           }
         }
