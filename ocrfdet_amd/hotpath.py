@@ -41,6 +41,19 @@ class PoolPlan:
         return 4 * (depth_numel + feat_numel + 3 * self.n_points + 2 * self.n_intervals + out)
 
 
+_STREAMS = {}
+
+
+def shared_stream(device, role):
+    """One side HIP stream per (device, role) for the whole process: every HotPath reuses the same two streams
+    ('render', 'prep') instead of creating its own — the streams of a process share a few hardware queues in creation
+    order, and which queue a stream lands on decides whether it really runs beside the main stream."""
+    key = (torch.device(device).index or 0, role)
+    if key not in _STREAMS:
+        _STREAMS[key] = torch.cuda.Stream(device)
+    return _STREAMS[key]
+
+
 class HotPath:
     def __init__(self, cfg, device, cams=None, index_prep_mode='cached', overlap=True, device_geometry=False):
         """``cams``: optional list of camera indices this instance owns (camera sharding).
@@ -61,6 +74,7 @@ class HotPath:
         # worse: two blends at once slow each other more than the overlap returns (0.66 vs 0.60 ms)
         self.overlap = bool(overlap) and self.device.type == 'cuda'
         self._side = []
+        self._prep_stream = None
         self._prepare()
 
     def _prepare(self):
@@ -269,12 +283,13 @@ class HotPath:
         return (PoolPlan(*self._or_empty(index_prep._trim(lss[0], counts[0])), (self.batch, Z, Y, X, cfg.channels)),
                 PoolPlan(*self._or_empty(index_prep._trim(ht[0], counts[1])), (self.batch, 1, Y, X, cfg.channels)))
 
-    def pool_step(self, depth, feat):
+    def pool_step(self, depth, feat, prepared=None):
         """Both poolings (index preparation first in 'per_step' mode): LSS BEV (B, Z*C, Y, X) and
-        HT BEV (B, C, Y, X) (view_transformer.py:194, view_transformer_ocrf.py:781)."""
+        HT BEV (B, C, Y, X) (view_transformer.py:194, view_transformer_ocrf.py:781).  ``prepared``: what
+        ``prepare_indices_hip(sync=False)`` returned, if the caller already issued it."""
         if self.index_prep_mode == 'per_step':
             # ranks stay on the device, their lengths too: no host read anywhere in the step
-            (lv, lc), (hv, hc) = self.prepare_indices_hip(sync=False)
+            (lv, lc), (hv, hc) = prepared if prepared is not None else self.prepare_indices_hip(sync=False)
             lss = bevpool.bev_pool_v2_device_counts(depth, feat, lv[1], lv[2], lv[0], self.lss.bev_shape, lv[3], lv[4], lc)
             ht = bevpool.bev_pool_v2_device_counts(depth, feat, hv[1], hv[2], hv[0], self.ht.bev_shape, hv[3], hv[4], hc)
             return lss, ht
@@ -286,15 +301,30 @@ class HotPath:
         if fork:
             cur = torch.cuda.current_stream(self.device)
             if not self._side:
-                self._side.append(torch.cuda.Stream(self.device))
+                self._side.append(shared_stream(self.device, 'render'))
             side = self._side[0]
             side.wait_stream(cur)                     # inputs (and last step's consumers) are ordered before
             rendered = self.render([side] * self.batch)
         # HOA-1/2 do not read the pooled BEV and are latency chains of small kernels: issued FIRST, they run in the
         # shadow of the render stream's chip-filling preprocess instead of the poolings competing with it
         # (cfg2 step 0.402 -> 0.388 ms; on a stream of their own: 0.41-0.47 ms)
+        prepared = None
+        if (self.index_prep_mode == 'per_step' and self.cfg.hoa and self.overlap and self.device_geometry
+                and hasattr(self, '_calib_dev')):
+            # the index preparation (~ 20 launches, 0.17 ms) needs nothing HOA-1/2 produce: on a stream of its own
+            # beside them; the poolings wait for it.  Only with the calibration algebra on the device: the host
+            # formulation uploads its blocks from pageable memory, and that copy would make the host wait for the
+            # previous step at the top of this one
+            cur0 = torch.cuda.current_stream(self.device)
+            if self._prep_stream is None:
+                self._prep_stream = shared_stream(self.device, 'prep')
+            self._prep_stream.wait_stream(cur0)
+            with torch.cuda.stream(self._prep_stream):
+                prepared = self.prepare_indices_hip(sync=False)
         ob = self.hoa_opacity_bev() if self.cfg.hoa else None
-        lss, ht = self.pool_step(depth, feat)
+        if prepared is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._prep_stream)
+        lss, ht = self.pool_step(depth, feat, prepared)
         out = [lss, ht]
         if fork:
             out.append(rendered)
@@ -338,7 +368,7 @@ class ShardedHotPath:
         # HOA (replicated) needs the Gaussian opacities / alpha volume of every frame, not this rank's cameras
         self.base = HotPath(synthetic.PathConfig(**{**cfg.__dict__, 'render': cfg.render or cfg.hoa}), self.device,
                             cams=[0], index_prep_mode='cached', overlap=False) if cfg.hoa else None
-        self._side = torch.cuda.Stream(self.device) if self.device.type == 'cuda' and cfg.render else None
+        self._side = shared_stream(self.device, 'render') if self.device.type == 'cuda' and cfg.render else None
 
     def make_inputs(self, seed=0):
         """Per owned frame: depth (1, n_owned_cams, D, H, W), feat (1, n_owned_cams, H, W, C) — the same values
