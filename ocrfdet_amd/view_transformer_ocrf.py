@@ -460,7 +460,7 @@ class _Geometry:
     """Everything ``view_transform_core`` derives from the calibration alone: both rank-vector sets,
     voxel centres, pillar projections and their validity (view_transformer.py:108-147,197-255;
     view_transformer_ocrf.py:651-740,785-852)."""
-    __slots__ = ('lss', 'ht', 'voxel', 'pix', 'mask', 'calib', 'c2w', 'cam_rows', 'plans', 'cam_rows_dev')
+    __slots__ = ('lss', 'ht', 'voxel', 'pix', 'mask', 'calib', 'c2w', 'cam_rows', 'plans', 'cam_rows_dev', 'rank_vectors')
 
 
 class OcRFViewTransformerFull(nn.Module):
@@ -555,7 +555,7 @@ class OcRFViewTransformerFull(nn.Module):
             self._tmpl = (self.frustum.to(dev).contiguous(), ref.to(dev).contiguous())
         return self._tmpl
 
-    def _geometry(self, input, sync=True):
+    def _geometry(self, input, sync=True, lazy_ranks=False):
         """``sync=False`` (eval mode): the rank vectors stay at their capacity with their lengths on the
         device — nothing between the calibration and the pooled BEV reads the device.  Only that forward-only
         path writes into the module's persistent rank buffers: with ``sync=True`` the ranks reach autograd
@@ -586,15 +586,26 @@ class OcRFViewTransformerFull(nn.Module):
             ht_block = index_prep.ht_camera_block(lidar2img, img_aug).to(dev)
         gx, gy, gz = (int(v) for v in self.grid_size.tolist())
         frustum, tmpl = self._templates(dev)
-        geo.lss = index_prep.voxel_pooling_prepare_v2_hip(frustum, lss_block, B, N, self.grid_lower_bound,
+
+        def rank_vectors():
+            lss = index_prep.voxel_pooling_prepare_v2_hip(frustum, lss_block, B, N, self.grid_lower_bound,
                                                           self.grid_interval, self.grid_size,
                                                           buffers=None if (self.accelerate or sync) else self._rank_bufs[0],
                                                           sync=sync)
-        geo.ht = index_prep.fast_sample_prepare_hip(tmpl, ht_block, B, N, list(self.pc_range), self.input_size,
+            ht = index_prep.fast_sample_prepare_hip(tmpl, ht_block, B, N, list(self.pc_range), self.input_size,
                                                     self.grid_config['depth'], Wf, Hf, self.D,
                                                     buffers=None if (self.accelerate or sync) else self._rank_bufs[1], sync=sync)
+            return lss, ht
         geo.pix, geo.mask, geo.voxel = index_prep.ht_project_hip(tmpl, ht_block, B, N, list(self.pc_range),
                                                                  self.input_size, self.grid_config['depth'])
+        if lazy_ranks:
+            # per-forward geometry on the fused path: the ~20 launches of the two index preparations are issued by
+            # _core_fused on the poolings' own strand, AFTER the colour / NeRF strand (which needs only the projections
+            # above) has been forked — beside it instead of in front of everything
+            geo.lss = geo.ht = None
+            geo.rank_vectors = rank_vectors
+        else:
+            geo.lss, geo.ht = rank_vectors()
         return geo
 
     @staticmethod
@@ -776,7 +787,8 @@ class OcRFViewTransformerFull(nn.Module):
         # fused HIP kernels are forward-only and fold the BatchNorm running statistics: eval mode with
         # nothing recorded by autograd; anything else takes the differentiable torch formulation
         fused = not self.training and not self._recording(depth, tran_feat, feat_channels_last)
-        geo = self._geo if (self.accelerate and self._geo is not None) else self._geometry(input, sync=not fused)
+        geo = self._geo if (self.accelerate and self._geo is not None) else \
+            self._geometry(input, sync=not fused, lazy_ranks=fused and not self.accelerate)
         depth5 = depth.reshape(B, N, self.D, Hf, Wf).float()
         if feat_channels_last is None:
             feat_channels_last = tran_feat.reshape(B, N, C, Hf, Wf).permute(0, 1, 3, 4, 2)
@@ -869,6 +881,8 @@ class OcRFViewTransformerFull(nn.Module):
         # heads need them: ROCm 7.2's graph executor serialises the two branches forked after a node (C, A)
         # when one of them starts with a second, cross-branch dependency (tools/diag_graph_parallel.py:
         # 8.2 instead of 5 kernel times); with the dependency ahead of the fork they overlap.
+        if geo.lss is None:
+            geo.lss, geo.ht = geo.rank_vectors()      # per-forward geometry: beside strand B (see _geometry)
         if par:
             cur.wait_event(rgb_ready)
         lss_feat = self.get_lss_bev_feat(geo, depth5, feat_cl)
