@@ -265,6 +265,9 @@ size_t ocrf_rasterize_backward_workspace_bytes(int P, int n_views);
  *   grid_config['depth'][0:2]; Wf, Hf, D: feature-map size and depth bins
  * outputs as above with ranks_bev = b*n_pillars + pillar; inside a pillar the order is (camera,
  * height) ascending = the reference's flattening order under a stable sort.
+  * The workspace holds the look-back states of the single-launch prefix sums: one call at a time per workspace
+ * (two calls that share it on different streams overwrite each other's states; a wave that waits ~a second for a
+ * predecessor traps instead of spinning for ever).
  */
 int ocrf_lss_prepare(int B, int N, int D, int H, int W, const float *frustum, const float *cams,
                      const float *grid_lower_host, const float *grid_interval_host, int gx, int gy, int gz,

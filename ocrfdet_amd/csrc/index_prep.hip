@@ -176,6 +176,7 @@ __device__ __forceinline__ unsigned long long lb_tile_prefix(unsigned long long*
     sh->run = 0;
   }
   int hi = tile - 1;
+  int spins = 0;
   while (hi >= 0) {                                   // uniform: hi, and the decisions below, are the same everywhere
     const int j = hi - tid;
     const unsigned long long w = j >= 0 ? __hip_atomic_load(state + 1 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -198,6 +199,10 @@ __device__ __forceinline__ unsigned long long lb_tile_prefix(unsigned long long*
     }
     __syncthreads();                                  // sh->inc / none are rewritten by the next round
     if (wait) {
+      // Every tile this one waits for holds a smaller ticket and is running, so the wait ends within microseconds —
+      // unless the state words are being overwritten, e.g. by a second call sharing this scratch on another stream.
+      // A wave must not spin on a shared GPU for ever: after ~a second the kernel traps (the launch fails loudly).
+      if (++spins > (1 << 20)) __builtin_trap();
       __builtin_amdgcn_s_sleep(2);
       continue;                                       // something nearer than `first` is unpublished: read again
     }

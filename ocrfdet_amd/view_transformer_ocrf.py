@@ -587,14 +587,18 @@ class OcRFViewTransformerFull(nn.Module):
         gx, gy, gz = (int(v) for v in self.grid_size.tolist())
         frustum, tmpl = self._templates(dev)
 
-        def rank_vectors():
-            lss = index_prep.voxel_pooling_prepare_v2_hip(frustum, lss_block, B, N, self.grid_lower_bound,
-                                                          self.grid_interval, self.grid_size,
-                                                          buffers=None if (self.accelerate or sync) else self._rank_bufs[0],
-                                                          sync=sync)
-            ht = index_prep.fast_sample_prepare_hip(tmpl, ht_block, B, N, list(self.pc_range), self.input_size,
-                                                    self.grid_config['depth'], Wf, Hf, self.D,
-                                                    buffers=None if (self.accelerate or sync) else self._rank_bufs[1], sync=sync)
+        def rank_vectors(which=None):
+            lss = ht = None
+            if which in (None, 'lss'):
+                lss = index_prep.voxel_pooling_prepare_v2_hip(frustum, lss_block, B, N, self.grid_lower_bound,
+                                                              self.grid_interval, self.grid_size,
+                                                              buffers=None if (self.accelerate or sync) else self._rank_bufs[0],
+                                                              sync=sync)
+            if which in (None, 'ht'):
+                ht = index_prep.fast_sample_prepare_hip(tmpl, ht_block, B, N, list(self.pc_range), self.input_size,
+                                                        self.grid_config['depth'], Wf, Hf, self.D,
+                                                        buffers=None if (self.accelerate or sync) else self._rank_bufs[1],
+                                                        sync=sync)
             return lss, ht
         geo.pix, geo.mask, geo.voxel = index_prep.ht_project_hip(tmpl, ht_block, B, N, list(self.pc_range),
                                                                  self.input_size, self.grid_config['depth'])
@@ -882,7 +886,9 @@ class OcRFViewTransformerFull(nn.Module):
         # when one of them starts with a second, cross-branch dependency (tools/diag_graph_parallel.py:
         # 8.2 instead of 5 kernel times); with the dependency ahead of the fork they overlap.
         if geo.lss is None:
-            geo.lss, geo.ht = geo.rank_vectors()      # per-forward geometry: beside strand B (see _geometry)
+            # per-forward geometry: beside strand B (see _geometry).  The two preparations stay on ONE stream: they
+            # share the 'index_prep' scratch (and its look-back states)
+            geo.lss, geo.ht = geo.rank_vectors()
         if par:
             cur.wait_event(rgb_ready)
         lss_feat = self.get_lss_bev_feat(geo, depth5, feat_cl)
