@@ -14,8 +14,9 @@ def step(mode):
         r = hp.render([sides[0]] * hp.batch)
     else:
         r = hp.render(sides)
+    ob = hp.hoa_opacity_bev()          # the product's order: HOA-1/2 first
     lss, ht = hp.pool_step(depth, feat)
-    out = hp.hoa_step(ht)
+    out = hp.hoa_step(ht, ob)
     for s in sides: cur.wait_stream(s)
     return r, lss, out
 def timeit(fn, n=200):
