@@ -262,12 +262,17 @@ class DevicePoolPlan:
     only depth, feat, ranks_depth and ranks_feat.  Forward only; a plan serves one stream at a time (it
     holds the arrival counters of the cut tiles)."""
 
+    _count = 0
+
     def __init__(self, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts, interval_lengths):
         _lib.require_cuda(ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths)
         B, Z, Y, X, C = (int(v) for v in bev_feat_shape)
         if not _fusable(C):
             raise _lib.OcrfHipError(f'pool plans need C % 4 == 0 and C <= 256, got {C}')
         self.shape = (B, Z, Y, X, C)
+        # the slabs of cut tiles live in the scratch: a plan of its own scratch can run beside another plan's launch
+        DevicePoolPlan._count += 1
+        self.scratch_tag = f'bev_pool_plan{DevicePoolPlan._count}'
         self.ranks_depth = ranks_depth.int().contiguous()
         self.ranks_feat = ranks_feat.int().contiguous()
         rb, st, ln = ranks_bev.int().contiguous(), interval_starts.int().contiguous(), interval_lengths.int().contiguous()
@@ -301,7 +306,7 @@ def bev_pool_v2_planned(depth, feat, plan, layout=1, out=None):
     L = _lib.lib()
     with _lib.on_device(dev):
         need = L.ocrf_bev_pool_planned_workspace_bytes(C, plan.n_points)
-        scratch = _lib.workspace.get(dev, need, 'bev_pool_nchw')
+        scratch = _lib.workspace.get(dev, need, plan.scratch_tag)
         _lib.check(L.ocrf_bev_pool_v2_nchw_planned(
             C, plan.n_points, _lib.ptr(d32), _lib.ptr(f32), _lib.ptr(plan.ranks_depth),
             _lib.ptr(plan.ranks_feat), _lib.ptr(plan.plan), _lib.ptr(out), B, Z, Y, X, int(layout), _lib.ptr(scratch),
