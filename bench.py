@@ -65,6 +65,12 @@ def parse():
                     help="--scope neck --index-prep per_step: hand the calibration tensors over as HOST tensors (the "
                          "dataloader's copies) — the forward then has no device -> host read-back at all")
     ap.add_argument('--no-per-step', action='store_true', help='skip the second timed loop with the index preparation inside the step')
+    ap.add_argument('--render-mode', choices=('planned', 'per_call'), default='planned',
+                    help="'planned': the render's calibration-only front end (near-plane / frustum cull, depth order, projected "
+                         "centres) cached per frame like the rank vectors (static render plan); 'per_call': recomputed every render")
+    ap.add_argument('--render-guard', choices=('host', 'device'), default='host',
+                    help="planned renders: 'host' = the plan's extent bound is verified by one status read after the timed region; "
+                         "'device' = the per-call pipeline is armed behind every planned render on the GPU")
     ap.add_argument('--index-prep', choices=('cached', 'per_step'), default='cached',
                     help="'per_step': rank vectors recomputed by the HIP index preparation inside every step "
                          "(the reference with accelerate=False); 'cached': once per calibration (accelerate=True)")
@@ -297,6 +303,9 @@ def main():
     if args.scope == 'neck':
         return bench_neck(args, cfg, dev, world, rank)
     X, Y, Z = cfg.bev_xyz
+    rkw = dict(render_mode=args.render_mode, render_guard=args.render_guard)
+    planned = cfg.render and args.render_mode == 'planned'
+    k_blend = _lib.K_RASTER_BLEND_SORTED if planned else _lib.K_RASTER_BLEND
     active = True
     sp = None
     shard_error = None
@@ -304,7 +313,7 @@ def main():
         # the exchange has only ever run over gloo on the build box (one GPU): if RCCL refuses any part of it, every
         # rank falls back to the samples layout TOGETHER and the line says so, instead of one rank dying in a collective
         try:
-            sp = hotpath.ShardedHotPath(cfg, dev, rank, world, index_prep_mode=args.index_prep)
+            sp = hotpath.ShardedHotPath(cfg, dev, rank, world, index_prep_mode=args.index_prep, **rkw)
             sp_inputs = sp.make_inputs(seed=0)
             for _ in range(2):
                 sp.step(sp_inputs)
@@ -319,10 +328,10 @@ def main():
         n_active = min(world, cfg.n_cams)
         active = rank < n_active
         my_cams = list(range(rank, cfg.n_cams, n_active)) if active else [0]
-        hp = hotpath.HotPath(cfg, dev, cams=my_cams, index_prep_mode=args.index_prep, overlap=not args.no_overlap)
+        hp = hotpath.HotPath(cfg, dev, cams=my_cams, index_prep_mode=args.index_prep, overlap=not args.no_overlap, **rkw)
     else:
         # whole-sample instance: the N = 1 step, the 'samples' / 'frames' layouts, and every layout's kernel figures
-        hp = hotpath.HotPath(cfg, dev, index_prep_mode=args.index_prep, overlap=not args.no_overlap)
+        hp = hotpath.HotPath(cfg, dev, index_prep_mode=args.index_prep, overlap=not args.no_overlap, **rkw)
     depth, feat = hp.make_inputs(seed=0 if shard in ('cameras', 'camera_frames') else rank)
 
     def step_whole():
@@ -350,13 +359,18 @@ def main():
     for _ in range(args.warmup):
         step()
     # device duration of the kernels of interest, HIP events on their launch stream inside the timed region
-    t_blend = _lib.KernelTimer(_lib.K_RASTER_BLEND, 2 * args.steps + 8) if cfg.render else None
+    t_blend = _lib.KernelTimer(k_blend, 2 * args.steps + 8) if cfg.render else None
     t_pool = _lib.KernelTimer(_lib.K_BEV_POOL_FWD, 2 * (cfg.batch * cfg.n_frames if sp else 1) * args.steps + 8)
     for t in (t_blend, t_pool):
         if t is not None:
             t.arm()
     elapsed = timed(step, args.steps, world, dev)
     _lib.KernelTimer.disarm_all()
+    # planned renders with the host guard: ONE status read per plan verifies every render of the warm-up and the timed
+    # region (raises if a Gaussian left the plans' extent bound: those renders would not be valid)
+    hp.check_render_plans()
+    for sub in (sp.subs.values() if sp is not None else ()):
+        sub.check_render_plans()
 
     strong = shard in ('cameras', 'camera_frames')
     # ---- the same kernels alone on the device (renders on the main stream) ------------------------------------
@@ -364,7 +378,7 @@ def main():
     if shard in ('none', 'samples', 'frames'):
         was = hp.overlap
         hp.overlap = False
-        ib = _lib.KernelTimer(_lib.K_RASTER_BLEND, 64) if cfg.render else None
+        ib = _lib.KernelTimer(k_blend, 64) if cfg.render else None
         ip = _lib.KernelTimer(_lib.K_BEV_POOL_FWD, 64)
         for t in (ib, ip):
             if t is not None:
@@ -383,13 +397,13 @@ def main():
     # ---- the step with the index preparation inside (the reference with accelerate=False) ---------------------
     per_step_ms = per_step_devgeom_ms = None
     if shard in ('none', 'samples') and args.index_prep == 'cached' and not args.no_per_step:
-        hp2 = hotpath.HotPath(cfg, dev, index_prep_mode='per_step', overlap=not args.no_overlap)
+        hp2 = hotpath.HotPath(cfg, dev, index_prep_mode='per_step', overlap=not args.no_overlap, **rkw)
         n2 = max(5, min(args.steps, 50))
         for _ in range(3):
             hp2.step(depth, feat)
         per_step_ms = 1e3 * timed(lambda: hp2.step(depth, feat), n2, world, dev) / n2
         del hp2
-        hp3 = hotpath.HotPath(cfg, dev, index_prep_mode='per_step', overlap=not args.no_overlap, device_geometry=True)
+        hp3 = hotpath.HotPath(cfg, dev, index_prep_mode='per_step', overlap=not args.no_overlap, device_geometry=True, **rkw)
         for _ in range(3):
             hp3.step(depth, feat)
         per_step_devgeom_ms = 1e3 * timed(lambda: hp3.step(depth, feat), n2, world, dev) / n2
@@ -429,7 +443,7 @@ def main():
             # the blend is VALU-bound: flops = 20 per pixel.record, pixel.records counted as the
             # contributor index every pixel stopped at (a lower bound of what the kernel evaluates)
             evals = float(sum(int(o['n_contrib'].sum().item()) for o in hp.render(want_n_contrib=True))) / hp.batch
-            c = pmc_counters('raster_blend_kernel<false, false, true, false>')
+            c = pmc_counters('raster_blend_sorted_kernel' if planned else 'raster_blend_kernel<false, false, true, false>')
             cycles = blend_ms * 1e-3 * CLOCK_HZ
             tfl = BLEND_FLOPS_PER_PIXEL_RECORD * evals / (blend_ms * 1e-3) / 1e12
             traffic = hbm_traffic(c)
@@ -492,6 +506,13 @@ def main():
                        'stages': 'lss_pool+ht_pool' + ('+render' if cfg.render else '') + ('+hoa' if cfg.hoa else ''),
                        'views_per_step': hp.views_per_step if sp is None else cfg.batch * cfg.n_frames * cfg.n_cams,
                        'render_camera': getattr(hp, 'render_convention', None),
+                       'render_front_end': (None if not cfg.render else
+                                            ('static render plan per frame (cull, depth order, projected centres cached per calibration '
+                                             'like the rank vectors; Gaussian means = the fixed voxel grid); extent bound '
+                                             + ('verified by one status read after the timed region' if args.render_guard == 'host'
+                                                else 'guarded on the device (per-call pipeline armed behind every render)'))
+                                            if planned else 'per call (preprocess + depth-bucket scatter every render)'),
+                       'frames': 'each frame its own ego pose and Gaussian parameters (synthetic.ego_motion)',
                        'streams': ('main: pools + HOA; side HIP stream: renders' if hp.overlap and cfg.render
                                    else 'single stream'),
                        'index_prep': 'cached (accelerate=True semantics); per_step_ms = the same step with the HIP index '

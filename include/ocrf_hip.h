@@ -206,6 +206,62 @@ int ocrf_rasterize_forward_sets(int P, int n_sets, int views_per_set, int H, int
 size_t ocrf_rasterize_workspace_bytes(int P, int n_views);
 
 /*
+ * Static render plans (csrc/raster_plan.hip).  In OcRFDet the Gaussian means are the fixed voxel grid
+ * (view_transformer_ocrf.py:651-673,690-692) and the cameras are fixed per calibration; what depends on
+ * (mean, camera) alone — the near-plane cull and view-space depth (auxiliary.h:139-164), the projected centre and
+ * the Jacobian of computeCov2D (forward.cu:83-98,196-199), hence the whole (depth bits, id) blend order the
+ * reference obtains by sorting every step (rasterizer_impl.cu:226-267) — is computed ONCE:
+ *
+ *   1. ocrf_raster_plan_classify  per view (n_views <= 32): sort key of every Gaussian (depth bits, or "never
+ *      visible": behind the near plane, or outside the frame for every world-space extent <= extent_bound), stable
+ *      radix sort; leaves the sorted ids in `workspace` (>= ocrf_raster_plan_build_workspace_bytes(P, n_views)) and
+ *      the kept counts in kept_counts (device, n_views ints).  The caller reads the counts (its one
+ *      synchronisation), then
+ *   2. ocrf_raster_plan_fill      (same workspace) writes the plan (device, >= ocrf_raster_plan_bytes(P, n_views,
+ *      total_kept) bytes, 256-byte aligned): header, cameras; per view the kept records in blend order (id, depth
+ *      bits, pixel centre); per Gaussian the views that keep it and, per (Gaussian, view), the record's place in
+ *      that order with the rows of J W (forward.cu:83-98).  total_kept = sum of the counts, max_kept = their
+ *      maximum.
+ *
+ * extent_bound bounds scale_modifier * max_k |s_k| * |R(q)|_2 (|R(q)|_2 = |1 - |q|^2| + |q|^2: 1 for a normalised
+ * quaternion) of every Gaussian the plan will be rendered with; a plan stays valid for ANY parameters within it.
+ *
+ *   3. ocrf_rasterize_planned     one render = two launches: one thread per Gaussian builds its 3D covariance once
+ *      and drops conic / tile rect at its place in every rendered view's list; then the blend of the sorted lists.
+ *      n_items views are rendered; item z renders plan view item_view[z] (device ints; NULL = z, then n_items /
+ *      n_sets must equal the plan's view count) with Gaussian set z / (n_items / n_sets) of the (n_sets, P, .)
+ *      parameter arrays; the items of one set name distinct views.  Outputs as
+ *      ocrf_rasterize_forward, indexed by item; colour / depth / final_T are bit-identical to it.  radii
+ *      (n_items, P) or NULL.  workspace >= ocrf_rasterize_planned_workspace_bytes(total_kept, n_sets).
+ *      status (device int, NOT written unless something is wrong: zero it once): bit 2 (value 4) = some Gaussian
+ *      exceeded extent_bound this call, bit 3 (value 8) = bad item_view / unusable plan.
+ *      guard = 0: with bit 2 set the outputs of that call are not valid (the caller re-renders with
+ *      ocrf_rasterize_forward or rebuilds the plan with a larger bound).
+ *      guard = 1: the per-call pipeline of ocrf_rasterize_forward is enqueued behind the planned one, armed by the
+ *      extent check: all of its kernels retire at once when the bound holds, and render the call instead when it
+ *      does not — exact results either way, no host involvement (hipGraph-capturable), at the price of five
+ *      near-empty launches.  Needs means3D, radii and chain_workspace >= ocrf_rasterize_workspace_bytes(P, n_items).
+ * Forward only (no n_contrib): training renders through ocrf_rasterize_forward / _backward.
+ */
+size_t ocrf_raster_plan_build_workspace_bytes(int P, int n_views);
+int ocrf_raster_plan_classify(int P, int n_views, int H, int W, const float *means3D, const float *cameras,
+                              float extent_bound, int *kept_counts, void *workspace, size_t workspace_bytes,
+                              ocrf_stream_t stream);
+size_t ocrf_raster_plan_bytes(int P, int n_views, long total_kept);
+int ocrf_raster_plan_fill(int P, int n_views, int H, int W, const float *means3D, const float *cameras,
+                          float extent_bound, const int *kept_counts, long total_kept, int max_kept,
+                          void *workspace, size_t workspace_bytes, void *plan, size_t plan_bytes,
+                          ocrf_stream_t stream);
+size_t ocrf_rasterize_planned_workspace_bytes(long total_kept, int n_sets);
+int ocrf_rasterize_planned(const void *plan, size_t plan_bytes, int P, int n_plan_views, long total_kept,
+                           int H, int W, int n_sets, int n_items, const int *item_view,
+                           const float *colors, const float *opacities, const float *scales, float scale_modifier,
+                           const float *rotations, const float *bg, int depth_mode, float *out_color,
+                           float *out_depth, float *out_final_T, int *radii, int *status, void *workspace,
+                           size_t workspace_bytes, int guard, const float *means3D, void *chain_workspace,
+                           size_t chain_workspace_bytes, ocrf_stream_t stream);
+
+/*
  * Backward of the colour output of ocrf_rasterize_forward (the w-depth fork has no depth backward,
  * diff-gaussian-rasterization-w-depth/README.md:13).  Replaces RasterizeGaussiansBackwardCUDA
  * (rasterize_points.cu:117-196 -> rasterizer_impl.cu:338-434 -> cuda_rasterizer/backward.cu) for
@@ -547,6 +603,8 @@ enum {
   OCRF_K_RASTER_SCAN = 13,       /* raster_bucket_scan_kernel */
   OCRF_K_RASTER_BLEND_BWD = 15,  /* raster_blend_kernel<false, true> */
   OCRF_K_RASTER_PRE_BWD = 16,    /* raster_preprocess_backward_kernel */
+  OCRF_K_RASTER_PLAN_UPDATE = 17,  /* raster_plan_update_kernel */
+  OCRF_K_RASTER_BLEND_SORTED = 18, /* raster_blend_sorted_kernel<*> */
   OCRF_K_HOA_STATS = 20,         /* hoa_channel_stats_kernel */
   OCRF_K_HOA_MASK_GATE = 21,     /* hoa_mask_gate_kernel */
   OCRF_K_HOA_HEIGHT_MAX = 22,    /* hoa_height_max_kernel */

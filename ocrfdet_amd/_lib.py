@@ -93,6 +93,21 @@ def _declare(L):
     L.ocrf_rasterize_forward_sets.restype = c_int
     L.ocrf_rasterize_forward_sets.argtypes = ([c_int] * 5 + [c_void_p] * 4 + [c_float] + [c_void_p] * 4 +
                                               [c_int] + [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p])
+    L.ocrf_raster_plan_build_workspace_bytes.restype = c_size_t
+    L.ocrf_raster_plan_build_workspace_bytes.argtypes = [c_int, c_int]
+    L.ocrf_raster_plan_classify.restype = c_int
+    L.ocrf_raster_plan_classify.argtypes = [c_int] * 4 + [c_void_p] * 2 + [c_float] + [c_void_p] * 2 + [c_size_t, c_void_p]
+    L.ocrf_raster_plan_bytes.restype = c_size_t
+    L.ocrf_raster_plan_bytes.argtypes = [c_int, c_int, c_long]
+    L.ocrf_raster_plan_fill.restype = c_int
+    L.ocrf_raster_plan_fill.argtypes = ([c_int] * 4 + [c_void_p] * 2 + [c_float, c_void_p, c_long, c_int] +
+                                        [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p])
+    L.ocrf_rasterize_planned_workspace_bytes.restype = c_size_t
+    L.ocrf_rasterize_planned_workspace_bytes.argtypes = [c_long, c_int]
+    L.ocrf_rasterize_planned.restype = c_int
+    L.ocrf_rasterize_planned.argtypes = ([c_void_p, c_size_t, c_int, c_int, c_long] + [c_int] * 4 + [c_void_p] * 4 +
+                                         [c_float] + [c_void_p] * 2 + [c_int] + [c_void_p] * 6 + [c_size_t, c_int] +
+                                         [c_void_p] * 2 + [c_size_t, c_void_p])
     L.ocrf_lss_prepare.restype = c_int
     L.ocrf_lss_prepare.argtypes = ([c_int] * 5 + [c_void_p] * 4 + [c_int] * 3 + [c_void_p] * 6 +
                                    [c_void_p, c_size_t, c_void_p])
@@ -288,6 +303,7 @@ workspace = Workspace()
 K_BEV_POOL_FWD, K_BEV_POOL_FIXUP, K_BEV_POOL_INTERVAL, K_BEV_POOL_GRAD, K_BEV_POOL_NCHW = 1, 2, 3, 4, 5
 K_RASTER_PREPROCESS, K_RASTER_BLEND, K_RASTER_GATHER = 10, 11, 12
 K_RASTER_SCAN, K_RASTER_BLEND_BWD, K_RASTER_PRE_BWD = 13, 15, 16
+K_RASTER_PLAN_UPDATE, K_RASTER_BLEND_SORTED = 17, 18
 K_LSS_KEYS, K_RADIX_HIST, K_SCAN, K_RADIX_SCATTER, K_LSS_BOUNDS, K_LSS_EMIT, K_HT_COUNT, K_HT_EMIT = range(40, 48)
 K_HOA_STATS, K_HOA_MASK_GATE, K_HOA_HEIGHT_MAX, K_HOA_HEIGHT_GATE = 20, 21, 22, 23
 K_HOA_UNET_BLOCK, K_HOA_OUT_CONV, K_HOA1_ATTN, K_HOA1_KV = 24, 25, 26, 29

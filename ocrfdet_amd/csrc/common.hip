@@ -76,6 +76,8 @@ const char* ocrf_kernel_name(int kernel_id) {
     case OCRF_K_RASTER_BLEND_BWD: return "raster_blend_kernel<false, true, true>";
     case OCRF_K_RASTER_PRE_BWD: return "raster_preprocess_backward_kernel";
     case OCRF_K_RASTER_GATHER: return "raster_scatter_kernel";
+    case OCRF_K_RASTER_PLAN_UPDATE: return "raster_plan_update_kernel";
+    case OCRF_K_RASTER_BLEND_SORTED: return "raster_blend_sorted_kernel<*>";
     case OCRF_K_RASTER_SCAN: return "raster_bucket_scan_kernel";
     case OCRF_K_HOA_STATS: return "hoa_channel_stats_kernel";
     case OCRF_K_HOA_MASK_GATE: return "hoa_mask_gate_kernel";

@@ -556,7 +556,87 @@ inline void lss_layout(long n_pts, unsigned n_vox_total, LssWs* w) {
   w->bytes = off;
 }
 
+struct SortWs {
+  size_t keys_b, vals_a, vals_b, table, state, state_bytes, bytes;
+  long state_tiles;
+};
+
+inline void sort_layout(long n, SortWs* w) {
+  size_t off = 0;
+  auto take = [&](size_t b) { size_t o = off; off += align_up(b, 256); return o; };
+  const long n_wg = (n + kChunk - 1) / kChunk;
+  w->keys_b = take((size_t)n * 4);
+  w->vals_a = take((size_t)n * 4);
+  w->vals_b = take((size_t)n * 4);
+  w->table = take((size_t)kBins * n_wg * 4);
+  w->state_tiles = ((long)kBins * n_wg + kChunk - 1) / kChunk;
+  w->state = take(4 * lb_state_bytes(w->state_tiles));
+  w->state_bytes = off - w->state;
+  w->bytes = off;
+}
+
 }  // namespace
+
+namespace ocrf {
+
+// The radix sort of the LSS preparation as a service for the other translation units (raster_plan.hip sorts a
+// view's Gaussians by depth bits once per plan): stable, ids = original positions.
+size_t radix_sort_ids_bytes(int n) {
+  if (n <= 0) return 0;
+  SortWs w;
+  sort_layout(n, &w);
+  return w.bytes;
+}
+
+hipError_t radix_sort_ids(unsigned* keys, int n, int key_bits, void* scratch, size_t scratch_bytes,
+                          const unsigned** sorted_keys, const int** sorted_ids, hipStream_t stream) {
+  if (n <= 0 || key_bits <= 0 || key_bits > 32 || !keys || !scratch) return hipErrorInvalidValue;
+  SortWs w;
+  sort_layout(n, &w);
+  if (scratch_bytes < w.bytes) return hipErrorInvalidValue;
+  char* base = static_cast<char*>(scratch);
+  unsigned* kbuf[2] = {keys, reinterpret_cast<unsigned*>(base + w.keys_b)};
+  int* vbuf[2] = {reinterpret_cast<int*>(base + w.vals_a), reinterpret_cast<int*>(base + w.vals_b)};
+  int* table = reinterpret_cast<int*>(base + w.table);
+  auto* state = reinterpret_cast<unsigned long long*>(base + w.state);
+  const size_t st_words = lb_state_bytes(w.state_tiles) / 8;
+  hipError_t e = zero_async(state, w.state_bytes, stream);
+  if (e != hipSuccess) return e;
+  const int n_wg = (n + kChunk - 1) / kChunk;
+  const int passes = (key_bits + kRadixBits - 1) / kRadixBits;      // <= 4
+  int cur = 0;
+  for (int pass = 0; pass < passes; ++pass) {
+    const int shift = pass * kRadixBits;
+    launch(OCRF_K_RADIX_HIST, radix_hist_kernel, dim3(n_wg), dim3(kBlock), 0, stream,
+           static_cast<const unsigned*>(kbuf[cur]), n, shift, n_wg, table);
+    scan_exclusive_lookback(table, (long)kBins * n_wg, (int*)nullptr, state + pass * st_words, stream);
+    if (pass == 0)
+      launch(OCRF_K_RADIX_SCATTER, radix_scatter_kernel<true>, dim3(n_wg), dim3(kBlock), 0, stream,
+             static_cast<const unsigned*>(kbuf[cur]), static_cast<const int*>(nullptr), n, shift, n_wg,
+             static_cast<const int*>(table), kbuf[cur ^ 1], vbuf[cur ^ 1]);
+    else
+      launch(OCRF_K_RADIX_SCATTER, radix_scatter_kernel<false>, dim3(n_wg), dim3(kBlock), 0, stream,
+             static_cast<const unsigned*>(kbuf[cur]), static_cast<const int*>(vbuf[cur]), n, shift, n_wg,
+             static_cast<const int*>(table), kbuf[cur ^ 1], vbuf[cur ^ 1]);
+    cur ^= 1;
+  }
+  *sorted_keys = kbuf[cur];
+  *sorted_ids = vbuf[cur];
+  return hipGetLastError();
+}
+
+// in-place exclusive prefix sum of n non-negative ints (one look-back launch + the zero-fill of its state)
+size_t exclusive_scan_bytes(long n) { return n > 0 ? align_up(lb_state_bytes((n + kChunk - 1) / kChunk), 256) : 0; }
+
+hipError_t exclusive_scan_ints(int* data, long n, int* total, void* scratch, size_t scratch_bytes, hipStream_t stream) {
+  if (n <= 0 || !data || !scratch || scratch_bytes < exclusive_scan_bytes(n)) return hipErrorInvalidValue;
+  hipError_t e = zero_async(scratch, exclusive_scan_bytes(n), stream);
+  if (e != hipSuccess) return e;
+  scan_exclusive_lookback<int>(data, n, total, static_cast<unsigned long long*>(scratch), stream);
+  return hipGetLastError();
+}
+
+}  // namespace ocrf
 
 extern "C" {
 

@@ -30,4 +30,7 @@ inline void launch(int kernel_id, F kernel, dim3 grid, dim3 block, size_t lds, h
 // sequence).  A kernel is also cheaper than the memset path for these sizes (32-320 KB).
 hipError_t zero_async(void* dst, size_t bytes, hipStream_t stream);
 
+// raster_plan.hip: diagnostic knobs reached through ocrf_tune_set (keys 10-19)
+void raster_plan_tune(int key, int value);
+
 }  // namespace ocrf

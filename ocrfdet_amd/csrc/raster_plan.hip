@@ -1,0 +1,743 @@
+// Static render plans for the Gaussian rasteriser (MI355X, gfx950).
+//
+// In OcRFDet the Gaussian MEANS are the fixed voxel grid (view_transformer_ocrf.py:651-673,690-692) and the
+// cameras are fixed per calibration; only scales / rotations / opacities / colours change from step to step
+// (the S/R/A/C heads, :1130-1133).  Everything of the rasteriser's front end that depends on (mean, camera)
+// alone is therefore a constant of the calibration: the near-plane cull and view-space depth
+// (forward.cu:166-171 in_frustum, auxiliary.h:139-164), the projected centre (:196-199), the Jacobian of
+// computeCov2D (:83-98), and with them the whole front-to-back ORDER of a view's Gaussians — the reference's
+// sort key is (tile | depth bits), ties by Gaussian id (rasterizer_impl.cu:226-267, stable radix sort of
+// duplicateWithKeys' id-ordered output).
+//
+// A plan (built once per (means, cameras)) keeps, per view, the Gaussians that can ever be visible — in front
+// of the near plane and inside the frame for any world-space extent up to a stated bound — ALREADY SORTED by
+// (depth bits, id), with their static per-record data.  A step then is two launches:
+//   raster_plan_update_kernel   covariance -> conic / radius / tile rect of the kept records, in list order,
+//                               written as ready-to-blend records (+ the check that no Gaussian exceeds the
+//                               plan's extent bound: status bit 4);
+//   raster_blend_sorted_kernel  a tile pair filters the list by tile rect — the survivors arrive in the
+//                               reference's per-tile order, so there is no sort, no depth bucket, no carry —
+//                               and each of its four waves blends only the records whose alpha >= 1/255
+//                               ellipse reaches the wave's own 16x8 pixel block (exact conservative test at
+//                               staging, so a wave skips records by construction).
+// against zero-fill -> preprocess (all P x V pairs) -> bucket scan -> scatter -> blend (with an in-LDS bitonic
+// sort) of rasterize.hip.  Per-pixel arithmetic and its order are those of raster_blend_kernel: colour, depth
+// and final_T are bit-identical to the per-call pipeline (tests/test_raster_plan_gpu.py).
+#include <hip/hip_runtime.h>
+
+#include "launch.h"
+#include "ocrf_hip.h"
+#include "raster_common.h"
+
+namespace {
+
+using namespace rc;
+
+constexpr unsigned kPlanMagic = 0x4F435250u;      // "OCRP"
+constexpr int kHeaderInts = 16;                   // magic, P, V, H, W, gx, gy, bound bits, total lo, total hi, ...
+constexpr int kStageP = 256;                      // records staged per batch
+constexpr int kScanUnrollP = 4;                   // rect batches in flight in the scan
+constexpr int kCapPos = kStageP + kScanUnrollP * kBlock;
+constexpr unsigned kPosMask = 0x3FFFFFFFu;
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct PlanLayout {
+  size_t header, cams, g_mask, g_off, e_pos, e_q0, e_q1, s_id, s_key, s_pix, bytes;
+};
+
+inline void plan_layout(int P, int V, long T, PlanLayout* L) {
+  size_t off = 0;
+  auto take = [&](size_t b) { size_t o = off; off += align_up(b, 256); return o; };
+  L->header = take((size_t)(kHeaderInts + V + 1) * 4);
+  L->cams = take((size_t)V * sizeof(Camera));
+  L->g_mask = take((size_t)P * 4);          // per Gaussian: bit v = kept in view v
+  L->g_off = take((size_t)P * 4);           //               first record in Gaussian-major order
+  L->e_pos = take((size_t)T * 4);           // per record, Gaussian-major: position in the sorted lists,
+  L->e_q0 = take((size_t)T * 16);           //   (A00, A01, A02, A10) of A = J W,
+  L->e_q1 = take((size_t)T * 16);           //   (A11, A12, pixel x, pixel y)
+  L->s_id = take((size_t)T * 4);            // per record, sorted (view-major, depth bits then id): Gaussian id,
+  L->s_key = take((size_t)T * 4);           //   depth bits,
+  L->s_pix = take((size_t)T * 8);           //   pixel centre
+  L->bytes = off;
+}
+
+struct BuildLayout {      // workspace of the build
+  size_t keys, ids, inv, sort, scan, bytes;
+};
+
+inline void build_layout(int P, int V, BuildLayout* L) {
+  size_t off = 0;
+  auto take = [&](size_t b) { size_t o = off; off += align_up(b, 256); return o; };
+  L->keys = take((size_t)P * 4);                 // sort keys of one view at a time
+  L->ids = take((size_t)P * V * 4);              // sorted ids of every view
+  L->inv = take((size_t)P * V * 4);              // rank of Gaussian id in view v's list, or -1
+  L->sort = take(ocrf::radix_sort_ids_bytes(P));
+  L->scan = take(ocrf::exclusive_scan_bytes(P));
+  L->bytes = off;
+}
+
+struct DynLayout {        // per-call scratch of the planned render
+  size_t rect, con, flag, bytes;
+};
+
+inline void dyn_layout(long T, int n_sets, DynLayout* L) {
+  size_t off = 0;
+  auto take = [&](size_t bts) { size_t o = off; off += align_up(bts, 256); return o; };
+  const size_t n = (size_t)T * n_sets;
+  L->rect = take(n * sizeof(Rect));
+  L->con = take(n * 16);
+  L->flag = take(256);
+  L->bytes = off;
+}
+
+// ---------------------------------------------------------------------------------------------
+// build 1: sort key of every Gaussian of ONE view: depth bits if it can ever be visible, else ~0.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void plan_classify_kernel(int P, int gx, int gy, int W, int H,
+                                                               const float* __restrict__ means3D,
+                                                               const Camera* __restrict__ cam_, float bound,
+                                                               unsigned* __restrict__ keys, int* __restrict__ count) {
+  const int idx = blockIdx.x * kBlock + threadIdx.x;
+  unsigned key = 0xFFFFFFFFu;
+  if (idx < P) {
+    const Camera& cam = *cam_;
+    StaticPoint sp;
+    if (static_point(cam, means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2], &sp)) {
+      float A[2][3];
+      jacobian_rows(cam, sp.j00, sp.j02, sp.j11, sp.j12, A);
+      const float rb = radius_bound(A, bound);
+      const float fxp = ndc2pix(sp.projx, W), fyp = ndc2pix(sp.projy, H);
+      if (!surely_outside(fxp, fyp, rb, gx, gy)) key = __float_as_uint(sp.vz);      // vz > 0.2: bits order like the value
+    }
+    keys[idx] = key;
+  }
+  const unsigned long long m = __ballot(key != 0xFFFFFFFFu);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, __popcll(m));
+}
+
+__global__ __launch_bounds__(kBlock) void plan_copy_ids_kernel(int n, const int* __restrict__ src, int* __restrict__ dst) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(kBlock) void plan_fill_int_kernel(long n, int value, int* __restrict__ dst) {
+  const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) dst[i] = value;
+}
+
+// build 2: header (view offsets = exclusive prefix of the kept counts) + the camera block
+__global__ void plan_header_kernel(int P, int V, int H, int W, int gx, int gy, float bound, long capacity,
+                                   const int* __restrict__ counts, const float* __restrict__ cameras,
+                                   int* __restrict__ header, float* __restrict__ cams_out) {
+  if (threadIdx.x == 0) {
+    long run = 0;
+    int* view_off = header + kHeaderInts;
+    for (int v = 0; v < V; ++v) {
+      view_off[v] = (int)run;
+      run += counts[v];
+    }
+    view_off[V] = (int)run;
+    header[0] = (run <= capacity) ? (int)kPlanMagic : 0;       // a plan too small for its lists is unusable
+    header[1] = P; header[2] = V; header[3] = H; header[4] = W; header[5] = gx; header[6] = gy;
+    header[7] = __float_as_int(bound);
+    header[8] = (int)(run & 0xFFFFFFFFl); header[9] = (int)(run >> 32);
+  }
+  for (int i = threadIdx.x; i < V * 36; i += blockDim.x) cams_out[i] = cameras[i];
+}
+
+// build 3: the sorted lists (view-major) + the rank of every kept Gaussian in its view's list
+__global__ __launch_bounds__(kBlock) void plan_fill_sorted_kernel(int P, int W, int H, const float* __restrict__ means3D,
+                                                                  const Camera* __restrict__ cams,
+                                                                  const int* __restrict__ sorted_ids /*(V,P)*/,
+                                                                  const int* __restrict__ header,
+                                                                  unsigned* __restrict__ s_id, unsigned* __restrict__ s_key,
+                                                                  float2* __restrict__ s_pix, int* __restrict__ inv) {
+  if (header[0] != (int)kPlanMagic) return;
+  const int v = blockIdx.y;
+  const int* view_off = header + kHeaderInts;
+  const int off = view_off[v], n = view_off[v + 1] - off;
+  const Camera& cam = cams[v];
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const int id = sorted_ids[(long)v * P + i];
+    StaticPoint sp;
+    static_point(cam, means3D[3 * id], means3D[3 * id + 1], means3D[3 * id + 2], &sp);
+    s_id[off + i] = (unsigned)id;
+    s_key[off + i] = __float_as_uint(sp.vz);
+    s_pix[off + i] = make_float2(ndc2pix(sp.projx, W), ndc2pix(sp.projy, H));
+    inv[(long)v * P + id] = i;
+  }
+}
+
+// build 4: per Gaussian, the set of views that keep it and how many
+__global__ __launch_bounds__(kBlock) void plan_masks_kernel(int P, int V, const int* __restrict__ inv,
+                                                            unsigned* __restrict__ g_mask, int* __restrict__ g_cnt) {
+  const int id = blockIdx.x * kBlock + threadIdx.x;
+  if (id >= P) return;
+  unsigned m = 0;
+  for (int v = 0; v < V; ++v) m |= (inv[(long)v * P + id] >= 0) ? (1u << v) : 0u;
+  g_mask[id] = m;
+  g_cnt[id] = __popc(m);
+}
+
+// build 5 (after the exclusive scan of the counts): the records in Gaussian-major order
+__global__ __launch_bounds__(kBlock) void plan_fill_records_kernel(int P, int W, int H, const float* __restrict__ means3D,
+                                                                   const Camera* __restrict__ cams,
+                                                                   const int* __restrict__ header,
+                                                                   const int* __restrict__ inv,
+                                                                   const unsigned* __restrict__ g_mask,
+                                                                   const int* __restrict__ g_off,
+                                                                   unsigned* __restrict__ e_pos, float4* __restrict__ e_q0,
+                                                                   float4* __restrict__ e_q1) {
+  if (header[0] != (int)kPlanMagic) return;
+  const int id = blockIdx.x * kBlock + threadIdx.x;
+  if (id >= P) return;
+  unsigned m = g_mask[id];
+  int e = g_off[id];
+  const int* view_off = header + kHeaderInts;
+  const float px = means3D[3 * id], py = means3D[3 * id + 1], pz = means3D[3 * id + 2];
+  while (m) {
+    const int v = __ffs(m) - 1;
+    m &= m - 1;
+    const Camera& cam = cams[v];
+    StaticPoint sp;
+    static_point(cam, px, py, pz, &sp);
+    float A[2][3];
+    jacobian_rows(cam, sp.j00, sp.j02, sp.j11, sp.j12, A);
+    e_pos[e] = (unsigned)(view_off[v] + inv[(long)v * P + id]);
+    e_q0[e] = make_float4(A[0][0], A[0][1], A[0][2], A[1][0]);
+    e_q1[e] = make_float4(A[1][1], A[1][2], ndc2pix(sp.projx, W), ndc2pix(sp.projy, H));
+    ++e;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// step 1: the parameter-dependent half of preprocessCUDA (forward.cu:201-256), ONE THREAD PER GAUSSIAN of a set:
+// the parameters are read once (coalesced), the 3D covariance is built once, then every rendered view that keeps
+// the Gaussian gets its conic / radius / tile rect, dropped at the record's place in that view's sorted list.  The
+// same pass checks the Gaussian's extent against the plan's bound.
+//   d_rect[set][pos]  tile rect ((0,0,0,0): not rendered this step)
+//   d_con[set][pos]   (-0.5 conic.x, -0.5 conic.z, conic.y, opacity)
+// grid (ceil(P / 256), n_sets).  The items of one set name distinct plan views.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void raster_plan_update_kernel(
+    int P, int vps, long n_total, const int* __restrict__ header, const unsigned* __restrict__ g_mask,
+    const int* __restrict__ g_off, const unsigned* __restrict__ e_pos, const float4* __restrict__ e_q0,
+    const float4* __restrict__ e_q1, const int* __restrict__ view_sel, const float* __restrict__ opacities,
+    const float* __restrict__ scales, float scale_modifier, const float* __restrict__ rotations,
+    Rect* __restrict__ d_rect, float4* __restrict__ d_con, int* __restrict__ radii, int* __restrict__ status,
+    int* __restrict__ flag) {
+  __shared__ int l_v2i[32];
+  if (header[0] != (int)kPlanMagic) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) atomicOr(status, 8);
+    return;
+  }
+  const int V = header[2], gx = header[5], gy = header[6];
+  const int s = blockIdx.y;
+  if (threadIdx.x < 32) l_v2i[threadIdx.x] = -1;
+  __syncthreads();
+  if ((int)threadIdx.x < vps) {
+    const int v = view_sel ? view_sel[s * vps + threadIdx.x] : (int)threadIdx.x;
+    bool ok = v >= 0 && v < V;
+    if (ok) ok = atomicExch(&l_v2i[v], (int)threadIdx.x) == -1;       // a view named twice in one set: refused
+    if (!ok && blockIdx.x == 0) atomicOr(status, 8);
+  }
+  __syncthreads();
+  const int id = blockIdx.x * kBlock + threadIdx.x;
+  if (id >= P) return;
+  const long gi = (long)s * P + id;
+  const float sx = scale_modifier * scales[3 * gi], sy = scale_modifier * scales[3 * gi + 1],
+              sz = scale_modifier * scales[3 * gi + 2];
+  const float qr = rotations[4 * gi], qx = rotations[4 * gi + 1], qy = rotations[4 * gi + 2],
+              qz = rotations[4 * gi + 3];
+  const float rn = extent_bound(sx, sy, sz, qr, qx, qy, qz);
+  // the plan's static cull holds for extents <= bound; NaN / Inf anywhere counts as a violation (fmaxf drops NaNs)
+  const bool bad = !(rn <= __int_as_float(header[7])) || !(((sx + sy) + sz) * 0.f == 0.f);
+  if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) {
+    atomicOr(status, 4);
+    if (flag) atomicOr(flag, 1);
+  }
+  unsigned m = g_mask[id];
+  if (m == 0u) return;
+  float c3[6];
+  cov3d_from_scale_rot(sx, sy, sz, qr, qx, qy, qz, c3);
+  const float o = opacities[gi];
+  int e = g_off[id];
+  const long dyn = (long)s * n_total;
+  while (m) {
+    const int v = __ffs(m) - 1;
+    m &= m - 1;
+    const int cur = e++;
+    const int zi = l_v2i[v];
+    if (zi < 0) continue;                                   // this view is not rendered by this set
+    const unsigned pos = e_pos[cur];
+    const float4 q0 = e_q0[cur], q1 = e_q1[cur];
+    const float A[2][3] = {{q0.x, q0.y, q0.z}, {q0.w, q1.x, q1.y}};
+    Rect rect = Rect{0, 0, 0, 0};
+    int rad = 0;
+    if (!surely_outside(q1.z, q1.w, radius_bound(A, rn), gx, gy)) {
+      float cov_x, cov_y, cov_z, con_x, con_y, con_z;
+      cov2d(A, c3, &cov_x, &cov_y, &cov_z);
+      if (conic_radius_rect(cov_x, cov_y, cov_z, q1.z, q1.w, gx, gy, &con_x, &con_y, &con_z, &rad, &rect)) {
+        d_con[dyn + pos] = make_float4(-0.5f * con_x, -0.5f * con_z, con_y, o);
+      } else {
+        rect = Rect{0, 0, 0, 0};
+        rad = 0;
+      }
+    }
+    d_rect[dyn + pos] = rect;
+    if (radii) radii[((long)s * vps + zi) * P + id] = rad;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// step 2: blend of a sorted list (forward.cu:261-374 + w-depth README:5-11).
+// One workgroup = one vertical pair of 16x16 tiles of one rendered item; wave w owns the 16x8 pixel block of rows
+// [8w, 8w+8) of the pair (waves 0-1: upper tile, 2-3: lower tile), thread (lx, r) the pixels (lx, 8w + r) and
+// (lx, 8w + r + 4): same x, so dx and the dx-only part of the exponent are shared and the two pixels run as the
+// halves of packed fp32 ops.
+// ---------------------------------------------------------------------------------------------
+template <bool MEDIAN, bool WSKIP>
+__global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
+    int P, int W, int H, int gy, int vps, long n_total, const int* __restrict__ header, const int* __restrict__ view_sel,
+    const unsigned* __restrict__ s_id, const unsigned* __restrict__ s_key, const float2* __restrict__ s_pix,
+    const Rect* __restrict__ d_rect, const float4* __restrict__ d_con, const float* __restrict__ colors,
+    const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
+    float* __restrict__ out_final_T, const int* __restrict__ skip_if) {
+  if (skip_if && *skip_if != 0) return;      // the plan's bound does not hold this step: the armed per-call chain renders
+  __shared__ unsigned l_pos[kCapPos];
+  __shared__ float4 l_a[kStageP + 1], l_b[kStageP + 1], l_c[kStageP + 1];
+  __shared__ unsigned short l_list[4][kStageP + 8];
+  __shared__ int l_wtot[kScanUnrollP * 4];
+  __shared__ int l_lcnt[4][4];                // [source wave][destination wave]
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tx = blockIdx.x, z = blockIdx.z;
+  const int V = header[2];
+  const int v = view_sel ? view_sel[z] : z;
+  if (header[0] != (int)kPlanMagic || v < 0 || v >= V) return;      // reported by the update kernel (status bit 8)
+  const int set = z / vps;
+  const int tyA = 2 * blockIdx.y, tyB = tyA + 1;
+  const int* view_off = header + kHeaderInts;
+  const int off = view_off[v], nv = view_off[v + 1] - off;
+  const long dyn = (long)set * n_total + off;
+  const float* set_colors = colors + 3 * (long)set * P;
+  const int lx = lane & 15, r = lane >> 4;
+  const int pxi = tx * kTileX + lx;
+  const int py0 = tyA * kTileY + 8 * wave + r, py1 = py0 + 4;
+  const bool tile_ok = (tyA + (wave >> 1)) < gy;
+  const bool inside0 = tile_ok && pxi < W && py0 < H, inside1 = tile_ok && pxi < W && py1 < H;
+  const float pixf_x = (float)pxi;
+  const f2 pixf_y = f2{(float)py0, (float)py1};
+  // the wave's pixel block as float bounds (pixel centres are the integer coordinates, forward.cu:283)
+  const float bx0 = (float)(tx * kTileX), bx1 = bx0 + 15.f;
+
+  if (tid == 0) {      // slot kStageP: a record that changes nothing (opacity 0), pads odd list lengths
+    l_a[kStageP] = make_float4(0.f, 0.f, 0.f, 0.f);
+    l_b[kStageP] = make_float4(0.f, 0.f, 0.f, 0.f);
+    l_c[kStageP] = make_float4(0.f, 0.f, 0.f, INFINITY);
+  }
+
+  // T < 0 <=> the pixel has stopped (or lies outside the image); |T| is its final transmittance
+  f2 T = f2{inside0 ? 1.0f : -1.0f, inside1 ? 1.0f : -1.0f};
+  f2 C0 = splat(0.f), C1 = splat(0.f), C2 = splat(0.f);
+  f2 D = splat(MEDIAN ? 15.0f : 0.0f);
+
+  int scan = 0, npos = 0;
+  bool all_done = false;
+  while (!all_done) {
+    // ---- scan: positions of the records whose rect covers this tile pair, in list (= blend) order ----
+    while (scan < nv && npos < kStageP) {
+      const int n_u = (scan < 2 * kBlock) ? 1 : kScanUnrollP;
+      unsigned code[kScanUnrollP];
+      bool hit[kScanUnrollP];
+#pragma unroll
+      for (int u = 0; u < kScanUnrollP; ++u) {
+        const int i = scan + u * kBlock + tid;
+        hit[u] = false;
+        code[u] = 0u;
+        if (u < n_u && i < nv) {
+          const Rect rc = d_rect[dyn + i];
+          const bool cA = (tyA >= rc.y0) && (tyA < rc.y1), cB = (tyB >= rc.y0) && (tyB < rc.y1);
+          hit[u] = (tx >= rc.x0) && (tx < rc.x1) && (cA || cB);
+          code[u] = (unsigned)i | (cA ? 0x40000000u : 0u) | (cB ? 0x80000000u : 0u);
+        }
+      }
+      int rank[kScanUnrollP];
+#pragma unroll
+      for (int u = 0; u < kScanUnrollP; ++u) {
+        const unsigned long long m = __ballot(hit[u]);
+        rank[u] = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) l_wtot[u * 4 + wave] = __popcll(m);
+      }
+      __syncthreads();
+      int o = npos;
+#pragma unroll
+      for (int u = 0; u < kScanUnrollP; ++u) {
+        int mine = o;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const int c = l_wtot[u * 4 + w];
+          if (w < wave) mine += c;
+          o += c;
+        }
+        if (hit[u]) l_pos[mine + rank[u]] = code[u];
+      }
+      npos = o;
+      scan += n_u * kBlock;
+      __syncthreads();
+    }
+    if (npos == 0) break;                     // list exhausted
+    for (int s0 = 0; s0 < npos && !all_done; s0 += kStageP) {
+      const int ns = min(kStageP, npos - s0);
+      // ---- stage ns records; which waves can each one reach? ----
+      bool reach[4] = {false, false, false, false};
+      if (tid < ns) {
+        // staged record (slots chosen so that operands broadcast into packed ops sit in slots 0-2):
+        //   a = (x, y, -0.5 conic.z, -0.5 conic.x)   b = (opacity, r, g, conic.y)   c = (b, depth, 0, thr)
+        const unsigned code = l_pos[s0 + tid];
+        const int li = (int)(code & kPosMask);
+        const float4 con = d_con[dyn + li];
+        const float2 pix = s_pix[off + li];
+        const float* col = set_colors + 3 * (long)s_id[off + li];
+        const float o = con.w;
+        // the power below which alpha = o exp(power) is under 1/255 whatever the pixel (1 % margin for v_exp_f32
+        // and the log2(e) multiply); o <= 0: +inf (never rendered); NaN opacity: NaN (evaluated in full)
+        const float thr_ = (o > 0.f) ? (__logf(1.0f / (255.0f * o)) - 0.01f) : ((o <= 0.f) ? INFINITY : o);
+        const float4 a = make_float4(pix.x, pix.y, con.y, con.x);
+        const float4 b = make_float4(o, col[0], col[1], con.z);
+        const float4 c = make_float4(col[2], __uint_as_float(s_key[off + li]), 0.f, thr_);
+        l_a[tid] = a;
+        l_b[tid] = b;
+        l_c[tid] = c;
+        // alpha >= 1/255 needs power >= thr, i.e. Q(dx, dy) = 0.5 (A dx^2 + C dy^2) + B dx dy <= -thr.  The minimum of
+        // the convex Q over a wave's pixel block (a box in (dx, dy)) is 0 if the centre lies inside, else it is on
+        // the box's boundary: per edge a clamped 1-D minimiser.  The block is skipped only if that minimum exceeds
+        // -thr by more than the rounding of both evaluations (<= 1e-6 of the sum of the terms' magnitudes; 4e-6
+        // is allowed for) — so a skipped record has alpha < 1/255 at every pixel of the block, where the reference
+        // skips it too (forward.cu:331-333).  Anything unusual (NaN, non-convex conic) is evaluated in full.
+        const float thr = c.w;
+        const float qa = -2.f * a.w, qc = -2.f * a.z, qb = b.w;
+        const bool convex = (qa > 0.f) && (qc > 0.f) && (qa * qc - qb * qb > 0.f);
+        const bool never = thr >= 0.f;                         // opacity < 1/255: no pixel ever blends it
+        const float lim = -thr;
+        const float inv_a = 1.f / qa, inv_c = 1.f / qc;
+        const float dxlo = a.x - bx1, dxhi = a.x - bx0;
+        const float Dx = fmaxf(fabsf(dxlo), fabsf(dxhi));
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const bool cov = (w < 2) ? ((code & 0x40000000u) != 0u) : ((code & 0x80000000u) != 0u);
+          const float by0 = (float)(tyA * kTileY + 8 * w), by1 = by0 + 7.f;
+          const float dylo = a.y - by1, dyhi = a.y - by0;
+          const float Dy = fmaxf(fabsf(dylo), fabsf(dyhi));
+          bool skip = false;
+          if (convex && !(thr != thr)) {
+            const bool in_x = (dxlo <= 0.f) && (dxhi >= 0.f), in_y = (dylo <= 0.f) && (dyhi >= 0.f);
+            if (!(in_x && in_y)) {
+              auto Q = [&](float dx, float dy) { return 0.5f * (qa * dx * dx + qc * dy * dy) + qb * dx * dy; };
+              auto clampf = [](float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); };
+              const float q0 = Q(dxlo, clampf(-qb * dxlo * inv_c, dylo, dyhi));
+              const float q1 = Q(dxhi, clampf(-qb * dxhi * inv_c, dylo, dyhi));
+              const float q2 = Q(clampf(-qb * dylo * inv_a, dxlo, dxhi), dylo);
+              const float q3 = Q(clampf(-qb * dyhi * inv_a, dxlo, dxhi), dyhi);
+              const float qmin = fminf(fminf(q0, q1), fminf(q2, q3));
+              const float M = 0.5f * (qa * Dx * Dx + qc * Dy * Dy) + fabsf(qb) * Dx * Dy;
+              skip = (qmin - 4e-6f * M - 1e-3f) > lim;
+            }
+          }
+          reach[w] = cov && !never && !skip;
+        }
+      }
+      // ordered per-wave lists of staged indices
+      int lrank[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const unsigned long long m = __ballot(reach[w]);
+        lrank[w] = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) l_lcnt[wave][w] = __popcll(m);
+      }
+      __syncthreads();
+      int n_mine = 0;                          // length of THIS wave's list
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        int base = 0, tot = 0;
+#pragma unroll
+        for (int sw = 0; sw < 4; ++sw) {
+          const int c = l_lcnt[sw][w];
+          if (sw < wave) base += c;
+          tot += c;
+        }
+        if (reach[w]) l_list[w][base + lrank[w]] = (unsigned short)tid;
+        if (w == wave) n_mine = tot;
+        if (tid < 4 && tid == w) {             // pad: the loop reads two entries per trip
+          l_list[w][tot] = (unsigned short)kStageP;
+          l_list[w][tot + 1] = (unsigned short)kStageP;
+        }
+      }
+      __syncthreads();
+      n_mine = __builtin_amdgcn_readfirstlane(n_mine);
+
+      // ---- blend this wave's records front to back.  Every decision of forward.cu:320-352 is ONE compare feeding
+      // ONE select (see raster_blend_kernel in rasterize.hip for the derivation); same arithmetic, same order.
+      {
+        const unsigned short* mylist = l_list[wave];
+        f2 h = T - splat(0.5f);
+        for (int k = 0; k < n_mine; k += 2) {
+          if (__ballot((__float_as_int(T.x) & __float_as_int(T.y)) >= 0) == 0ull) break;      // every pixel stopped
+          const unsigned pair = *reinterpret_cast<const unsigned*>(mylist + k);
+          const int i0 = (int)(pair & 0xFFFFu), i1 = (int)(pair >> 16);
+          float4 ra[2], rb[2], rc4[2];
+          ra[0] = l_a[i0]; rb[0] = l_b[i0]; rc4[0] = l_c[i0];
+          ra[1] = l_a[i1]; rb[1] = l_b[i1]; rc4[1] = l_c[i1];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const float4 a = ra[u];
+            const float4 b = rb[u];
+            const float cr = b.y, cg = b.z, cb = rc4[u].x, dep = rc4[u].y;
+            // power = -0.5 (cxx dx dx + czz dy dy) - cxy dx dy, in the reference's order (forward.cu:320-323)
+            const float dx = a.x - pixf_x;
+            const float qx = (a.w * dx) * dx;
+            const float bx = b.w * dx;
+            const f2 dy = splat(a.y) - pixf_y;
+            const f2 qy = (splat(a.z) * dy) * dy;
+            const f2 power = (splat(qx) + qy) - splat(bx) * dy;          // qx, qy carry the -0.5 (staging)
+            if constexpr (WSKIP) {
+              const float thr = rc4[u].w;
+              if (__ballot(!((power.x <= thr) & (power.y <= thr))) == 0ull) continue;
+            }
+            const f2 p2 = power * splat(1.44269504088896340736f);       // __expf(x) = v_exp_f32(log2(e) x)
+            f2 G;
+            G.x = __builtin_amdgcn_exp2f(p2.x);
+            G.y = __builtin_amdgcn_exp2f(p2.y);
+            f2 alpha = splat(b.x) * G;
+            alpha.x = fminf(0.99f, alpha.x);
+            alpha.y = fminf(0.99f, alpha.y);
+            alpha.x = ((power.x > 0.0f) | (alpha.x < 1.0f / 255.0f)) ? 0.f : alpha.x;
+            alpha.y = ((power.y > 0.0f) | (alpha.y < 1.0f / 255.0f)) ? 0.f : alpha.y;
+            const f2 test_T = T * (splat(1.0f) - alpha);
+            const f2 aT = alpha * T;
+            const bool stop0 = test_T.x < 0.0001f, stop1 = test_T.y < 0.0001f;
+            f2 wgt;
+            wgt.x = stop0 ? 0.f : aT.x;
+            wgt.y = stop1 ? 0.f : aT.y;
+            C0 = fma2(splat(cr), wgt, C0);
+            C1 = fma2(splat(cg), wgt, C1);
+            C2 = fma2(splat(cb), wgt, C2);
+            if constexpr (MEDIAN) {
+              const f2 h2 = test_T - splat(0.5f);
+              const f2 cross = h * h2;
+              D.x = (cross.x < 0.f) ? dep : D.x;
+              D.y = (cross.y < 0.f) ? dep : D.y;
+              h = h2;
+            } else {
+              D = fma2(splat(dep), wgt, D);
+            }
+            T.x = stop0 ? -fabsf(T.x) : test_T.x;
+            T.y = stop1 ? -fabsf(T.y) : test_T.y;
+          }
+        }
+      }
+      // every pixel saturated -> stop (forward.cu:304-307)
+      all_done = __syncthreads_count((T.x < 0.f) && (T.y < 0.f)) == kBlock;
+    }
+    npos = 0;
+    if (scan >= nv) break;
+  }
+
+  const long npix = (long)W * H;
+  auto store = [&](bool inside, int py, float t, float c0, float c1, float c2, float d) {
+    if (!inside) return;
+    const long pix = (long)py * W + pxi;
+    out_final_T[z * npix + pix] = t;
+    out_color[((long)z * 3 + 0) * npix + pix] = c0 + t * bg[0];
+    out_color[((long)z * 3 + 1) * npix + pix] = c1 + t * bg[1];
+    out_color[((long)z * 3 + 2) * npix + pix] = c2 + t * bg[2];
+    out_depth[z * npix + pix] = d;
+  };
+  store(inside0, py0, fabsf(T.x), C0.x, C1.x, C2.x, D.x);
+  store(inside1, py1, fabsf(T.y), C0.y, C1.y, C2.y, D.y);
+}
+
+int g_plan_wskip = 0;       // ocrf_tune_set(OCRF_TUNE_PLAN_WSKIP): the pixel-exact wave skip inside the loop
+
+}  // namespace
+
+namespace ocrf {
+void raster_plan_tune(int key, int value) {
+  if (key == 10) g_plan_wskip = value != 0;
+}
+}
+
+extern "C" {
+
+size_t ocrf_raster_plan_build_workspace_bytes(int P, int n_views) {
+  if (P <= 0 || n_views <= 0 || n_views > 32) return 0;
+  BuildLayout L;
+  build_layout(P, n_views, &L);
+  return L.bytes;
+}
+
+int ocrf_raster_plan_classify(int P, int n_views, int H, int W, const float* means3D, const float* cameras,
+                              float extent_bound_, int* kept_counts, void* workspace, size_t workspace_bytes,
+                              ocrf_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (P <= 0 || n_views <= 0 || n_views > 32 || H <= 0 || W <= 0 || !means3D || !cameras || !kept_counts ||
+      !workspace || !(extent_bound_ >= 0.f))
+    return (int)hipErrorInvalidValue;
+  if ((long)P * n_views >= (1l << 30)) return (int)hipErrorInvalidValue;
+  BuildLayout L;
+  build_layout(P, n_views, &L);
+  if (workspace_bytes < L.bytes) return (int)hipErrorInvalidValue;
+  const int gx = (W + kTileX - 1) / kTileX, gy = (H + kTileY - 1) / kTileY;
+  if (gx > 65535 || gy > 65535) return (int)hipErrorInvalidValue;
+  char* base = static_cast<char*>(workspace);
+  auto* keys = reinterpret_cast<unsigned*>(base + L.keys);
+  auto* ids = reinterpret_cast<int*>(base + L.ids);
+  hipError_t e = ocrf::zero_async(kept_counts, (size_t)n_views * 4, stream);
+  if (e != hipSuccess) return (int)e;
+  const Camera* cams = reinterpret_cast<const Camera*>(cameras);
+  const dim3 grid((P + kBlock - 1) / kBlock);
+  for (int v = 0; v < n_views; ++v) {
+    hipLaunchKernelGGL(plan_classify_kernel, grid, dim3(kBlock), 0, stream, P, gx, gy, W, H, means3D, cams + v,
+                       extent_bound_, keys, kept_counts + v);
+    const unsigned* sk = nullptr;
+    const int* si = nullptr;
+    e = ocrf::radix_sort_ids(keys, P, 32, base + L.sort, L.scan - L.sort, &sk, &si, stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(plan_copy_ids_kernel, grid, dim3(kBlock), 0, stream, P, si, ids + (size_t)v * P);
+  }
+  return (int)hipGetLastError();
+}
+
+size_t ocrf_raster_plan_bytes(int P, int n_views, long total_kept) {
+  if (P <= 0 || n_views <= 0 || n_views > 32 || total_kept < 0) return 0;
+  PlanLayout L;
+  plan_layout(P, n_views, total_kept, &L);
+  return L.bytes;
+}
+
+int ocrf_raster_plan_fill(int P, int n_views, int H, int W, const float* means3D, const float* cameras,
+                          float extent_bound_, const int* kept_counts, long total_kept, int max_kept,
+                          void* workspace, size_t workspace_bytes, void* plan, size_t plan_bytes,
+                          ocrf_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (P <= 0 || n_views <= 0 || n_views > 32 || H <= 0 || W <= 0 || !means3D || !cameras || !kept_counts ||
+      !workspace || !plan || total_kept < 0 || total_kept >= (1l << 30) || max_kept < 0)
+    return (int)hipErrorInvalidValue;
+  PlanLayout L;
+  plan_layout(P, n_views, total_kept, &L);
+  BuildLayout B;
+  build_layout(P, n_views, &B);
+  if (plan_bytes < L.bytes || workspace_bytes < B.bytes) return (int)hipErrorInvalidValue;
+  const int gx = (W + kTileX - 1) / kTileX, gy = (H + kTileY - 1) / kTileY;
+  char* pb = static_cast<char*>(plan);
+  char* wb = static_cast<char*>(workspace);
+  int* header = reinterpret_cast<int*>(pb + L.header);
+  const Camera* cams = reinterpret_cast<const Camera*>(pb + L.cams);
+  int* inv = reinterpret_cast<int*>(wb + B.inv);
+  auto* g_mask = reinterpret_cast<unsigned*>(pb + L.g_mask);
+  int* g_off = reinterpret_cast<int*>(pb + L.g_off);
+  hipLaunchKernelGGL(plan_header_kernel, dim3(1), dim3(256), 0, stream, P, n_views, H, W, gx, gy, extent_bound_,
+                     total_kept, kept_counts, cameras, header, reinterpret_cast<float*>(pb + L.cams));
+  const long n_inv = (long)P * n_views;
+  hipLaunchKernelGGL(plan_fill_int_kernel, dim3((unsigned)((n_inv + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+                     n_inv, -1, inv);
+  if (max_kept > 0) {
+    const dim3 grid((max_kept + kBlock - 1) / kBlock, n_views);
+    hipLaunchKernelGGL(plan_fill_sorted_kernel, grid, dim3(kBlock), 0, stream, P, W, H, means3D, cams,
+                       reinterpret_cast<const int*>(wb + B.ids), static_cast<const int*>(header),
+                       reinterpret_cast<unsigned*>(pb + L.s_id), reinterpret_cast<unsigned*>(pb + L.s_key),
+                       reinterpret_cast<float2*>(pb + L.s_pix), inv);
+  }
+  const dim3 pgrid((P + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(plan_masks_kernel, pgrid, dim3(kBlock), 0, stream, P, n_views, static_cast<const int*>(inv), g_mask,
+                     g_off);
+  hipError_t e = ocrf::exclusive_scan_ints(g_off, P, nullptr, wb + B.scan, B.bytes - B.scan, stream);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(plan_fill_records_kernel, pgrid, dim3(kBlock), 0, stream, P, W, H, means3D, cams,
+                     static_cast<const int*>(header), static_cast<const int*>(inv),
+                     static_cast<const unsigned*>(g_mask), static_cast<const int*>(g_off),
+                     reinterpret_cast<unsigned*>(pb + L.e_pos), reinterpret_cast<float4*>(pb + L.e_q0),
+                     reinterpret_cast<float4*>(pb + L.e_q1));
+  return (int)hipGetLastError();
+}
+
+size_t ocrf_rasterize_planned_workspace_bytes(long total_kept, int n_sets) {
+  if (total_kept < 0 || n_sets <= 0) return 0;
+  DynLayout L;
+  dyn_layout(total_kept, n_sets, &L);
+  return L.bytes;
+}
+
+int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_plan_views, long total_kept, int H, int W,
+                           int n_sets, int n_items, const int* item_view, const float* colors,
+                           const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                           const float* bg, int depth_mode, float* out_color, float* out_depth, float* out_final_T,
+                           int* radii, int* status, void* workspace, size_t workspace_bytes, int guard,
+                           const float* means3D, void* chain_workspace, size_t chain_workspace_bytes,
+                           ocrf_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (!plan || P <= 0 || n_plan_views <= 0 || n_plan_views > 32 || total_kept < 0 || total_kept >= (1l << 30) ||
+      H <= 0 || W <= 0 || n_sets <= 0 || n_items <= 0 || n_items % n_sets || !colors || !opacities || !scales ||
+      !rotations || !bg || (depth_mode != 0 && depth_mode != 1) || !out_color || !out_depth || !out_final_T ||
+      !status || !workspace)
+    return (int)hipErrorInvalidValue;
+  const int vps = n_items / n_sets;
+  if (vps > n_plan_views || (!item_view && vps != n_plan_views)) return (int)hipErrorInvalidValue;
+  PlanLayout L;
+  plan_layout(P, n_plan_views, total_kept, &L);
+  DynLayout D;
+  dyn_layout(total_kept, n_sets, &D);
+  if (plan_bytes < L.bytes || workspace_bytes < D.bytes) return (int)hipErrorInvalidValue;
+  const int gx = (W + kTileX - 1) / kTileX, gy = (H + kTileY - 1) / kTileY;
+  const char* pb = static_cast<const char*>(plan);
+  char* wb = static_cast<char*>(workspace);
+  const int* header = reinterpret_cast<const int*>(pb + L.header);
+  const Camera* cams = reinterpret_cast<const Camera*>(pb + L.cams);
+  auto* d_rect = reinterpret_cast<Rect*>(wb + D.rect);
+  auto* d_con = reinterpret_cast<float4*>(wb + D.con);
+  int* flag = nullptr;
+  if (guard) {
+    if (!means3D || !radii || !chain_workspace ||
+        chain_workspace_bytes < ocrf_rasterize_workspace_bytes(P, n_items))
+      return (int)hipErrorInvalidValue;
+    flag = reinterpret_cast<int*>(wb + D.flag);
+    hipError_t e = ocrf::zero_async(flag, 4, stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (radii) {      // (view, Gaussian) pairs outside the lists are not visited: their radii are 0
+    hipError_t ze = ocrf::zero_async(radii, (size_t)n_items * P * sizeof(int), stream);
+    if (ze != hipSuccess) return (int)ze;
+  }
+  ocrf::launch(OCRF_K_RASTER_PLAN_UPDATE, raster_plan_update_kernel, dim3((P + kBlock - 1) / kBlock, n_sets),
+               dim3(kBlock), 0, stream, P, vps, total_kept, header, reinterpret_cast<const unsigned*>(pb + L.g_mask),
+               reinterpret_cast<const int*>(pb + L.g_off), reinterpret_cast<const unsigned*>(pb + L.e_pos),
+               reinterpret_cast<const float4*>(pb + L.e_q0), reinterpret_cast<const float4*>(pb + L.e_q1), item_view,
+               opacities, scales, scale_modifier, rotations, d_rect, d_con, radii, status, flag);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  const dim3 bgrid(gx, (gy + 1) / 2, n_items);
+#define OCRF_BLEND_SORTED(MED, WS)                                                                                  \
+  ocrf::launch(OCRF_K_RASTER_BLEND_SORTED, raster_blend_sorted_kernel<MED, WS>, bgrid, dim3(kBlock), 0, stream, P, W, \
+               H, gy, vps, total_kept, header, item_view, reinterpret_cast<const unsigned*>(pb + L.s_id),             \
+               reinterpret_cast<const unsigned*>(pb + L.s_key), reinterpret_cast<const float2*>(pb + L.s_pix),        \
+               static_cast<const Rect*>(d_rect), static_cast<const float4*>(d_con), colors, bg, out_color, out_depth, \
+               out_final_T, static_cast<const int*>(flag))
+  if (depth_mode == 0 && g_plan_wskip) OCRF_BLEND_SORTED(true, true);
+  else if (depth_mode == 0) OCRF_BLEND_SORTED(true, false);
+  else if (g_plan_wskip) OCRF_BLEND_SORTED(false, true);
+  else OCRF_BLEND_SORTED(false, false);
+#undef OCRF_BLEND_SORTED
+  e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  if (guard) {
+    // the per-call pipeline, armed: every kernel of it retires at once unless the extent check fired
+    return ocrf::raster_forward_chain(P, n_sets, vps, H, W, means3D, colors, opacities, scales, scale_modifier,
+                                      rotations, nullptr, reinterpret_cast<const float*>(cams), item_view, bg,
+                                      depth_mode, out_color, out_depth, out_final_T, nullptr, radii, nullptr, nullptr,
+                                      chain_workspace, chain_workspace_bytes, flag, true, stream);
+  }
+  return 0;
+}
+
+}  // extern "C"

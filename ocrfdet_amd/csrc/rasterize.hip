@@ -33,11 +33,20 @@
 
 #include "launch.h"
 #include "ocrf_hip.h"
+#include "raster_common.h"
 
 namespace {
 
-constexpr int kBlock = 256;
-constexpr int kTileX = 16, kTileY = 16;     // cuda_rasterizer/config.h:15-17
+using rc::kBlock;
+using rc::kTileX;
+using rc::kTileY;
+using rc::Camera;
+using rc::Rect;
+using rc::ndc2pix;
+using rc::f2;
+using rc::splat;
+using rc::fma2;
+
 constexpr int kBuckets = 8192;               // depth buckets per view
 constexpr int kBucketShift = 14;             // bucket = (depth bits >> 14) - base: 9 mantissa bits
 constexpr unsigned kBucketBase = 0x3E4CCCCDu >> kBucketShift;   // depth > 0.2f always (auxiliary.h:154)
@@ -48,22 +57,9 @@ constexpr int kStage = 256;                  // payload entries staged per blend
 constexpr int kScanUnroll = 4;               // rect batches in flight in the scan
 constexpr unsigned long long kPad = ~0ull;
 
-struct Camera {            // 36 floats per view, see ocrf_hip.h
-  float view[16];
-  float proj[16];
-  float tanfovx, tanfovy, focal_x, focal_y;
-};
-
-struct __attribute__((aligned(8))) Rect { unsigned short x0, y0, x1, y1; };
-
 __device__ __forceinline__ int bucket_of(unsigned key) {
   const int b = (int)(key >> kBucketShift) - (int)kBucketBase;
   return min(max(b, 0), kBuckets - 1);
-}
-
-// auxiliary.h:41-44 — the reference evaluates this in double precision (its literals are double)
-__device__ __forceinline__ float ndc2pix(float v, int S) {
-  return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -77,7 +73,9 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
     const Camera* __restrict__ cams, uint4* __restrict__ vis_rec, int* __restrict__ vis_count,
     Rect* __restrict__ rects, float2* __restrict__ xy, float4* __restrict__ conic_o,
-    int* __restrict__ radii, unsigned* __restrict__ tiles_touched, int* __restrict__ hist, int vps) {
+    int* __restrict__ radii, unsigned* __restrict__ tiles_touched, int* __restrict__ hist, int vps,
+    const int* __restrict__ view_sel, const int* __restrict__ gate, int means_stride) {
+  if (gate && *gate == 0) return;      // armed as a fallback that is not needed (raster_plan.hip)
   // One workgroup = kPreChunk consecutive Gaussians of one view.  Their depth buckets are counted in
   // an LDS histogram first and only the non-empty bins go to the global one: scattered global
   // atomics run at ~20 G/s chip-wide, and a depth slice of a regular grid puts thousands of
@@ -109,14 +107,15 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
   if (idx >= P) continue;
   const long o = (long)v * P + idx;
   const long gi = (long)(v / vps) * P + idx;      // Gaussian sets: view v renders set v / views_per_set
-  const Camera& cam = cams[v];
+  const Camera& cam = cams[view_sel ? view_sel[v] : v];
   const float* vm = cam.view;
   const float* pm = cam.proj;
   unsigned key = 0xFFFFFFFFu;
   int my_radii = 0;
   unsigned touched = 0;
 
-  const float px = means3D[3 * gi], py = means3D[3 * gi + 1], pz = means3D[3 * gi + 2];
+  const long mi = (long)(v / vps) * means_stride + idx;      // sets share one set of means when means_stride == 0
+  const float px = means3D[3 * mi], py = means3D[3 * mi + 1], pz = means3D[3 * mi + 2];
   // transformPoint4x3 (auxiliary.h:58-66)
   const float vx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
   const float vy = vm[1] * px + vm[5] * py + vm[9] * pz + vm[13];
@@ -291,7 +290,9 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
 __global__ __launch_bounds__(kBlock) void raster_bucket_scan_kernel(const int* __restrict__ hist,
                                                                     int* __restrict__ starts,
                                                                     int* __restrict__ cursor,
-                                                                    int* __restrict__ status) {
+                                                                    int* __restrict__ status,
+                                                                    const int* __restrict__ gate) {
+  if (gate && *gate == 0) return;
   __shared__ int s_sum[kBlock];
   constexpr int per = kBuckets / kBlock;
   const int v = blockIdx.x, tid = threadIdx.x;
@@ -322,7 +323,9 @@ __global__ __launch_bounds__(kBlock) void raster_bucket_scan_kernel(const int* _
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void raster_scatter_kernel(
     int P, const uint4* __restrict__ vis_rec, const int* __restrict__ vis_count,
-    int* __restrict__ cursor, Rect* __restrict__ b_rect, unsigned long long* __restrict__ b_comp) {
+    int* __restrict__ cursor, Rect* __restrict__ b_rect, unsigned long long* __restrict__ b_comp,
+    const int* __restrict__ gate) {
+  if (gate && *gate == 0) return;
   // Walks the compact visible records of one view (the launch is sized for P; workgroups past the
   // view's count retire at once): count in LDS, reserve one global range per non-empty bucket (ONE
   // returning global atomic per bucket per workgroup), hand out slots with LDS atomics.
@@ -473,11 +476,6 @@ struct BwdArgs {
   float* acc;                  // (V,P,9): mean2D x,y | conic x,y,z | opacity | colour r,g,b
 };
 
-typedef float f2 __attribute__((ext_vector_type(2)));   // maps to v_pk_{mul,add,fma}_f32 on gfx950
-
-__device__ __forceinline__ f2 splat(float x) { return f2{x, x}; }
-__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-
 // One workgroup = one PAIR of vertically adjacent 16x16 tiles (tile rows 2*by and 2*by+1) of one
 // view; thread (lx, ly) owns pixel (lx, ly) of both tiles — same x, y 16 apart.  The two pixels
 // share dx and the dx-only part of the exponent and run as the two halves of packed fp32 ops; the
@@ -493,7 +491,9 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
     const float2* __restrict__ xy, const float4* __restrict__ conic_o,
     const float* __restrict__ colors, const float* __restrict__ bg, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_final_T,
-    unsigned* __restrict__ out_n_contrib, int* __restrict__ status, BwdArgs bw, int vps) {
+    unsigned* __restrict__ out_n_contrib, int* __restrict__ status, BwdArgs bw, int vps,
+    const int* __restrict__ gate) {
+  if (gate && *gate == 0) return;
   extern __shared__ __attribute__((aligned(16))) unsigned long long rec[];
   float4* l_a = reinterpret_cast<float4*>(rec + kCapRec);          // x, y, conic.x, conic.y
   float4* l_b = l_a + kStage;                                      // BWD: conic.z, opacity, depth, r; fwd: see staging
@@ -1214,29 +1214,16 @@ inline void raster_layout(int P, int n_views, RasterWs* ws) {
 
 unsigned long long* g_stamps = nullptr;   // diagnostic: per-tile phase cycles (ocrf_diag_raster_stamps)
 
-extern "C" {
+namespace ocrf {
 
-// Diagnostic: when set (device buffer of tiles*views*8 u64), the next forwards run the stamped
-// build of the blend kernel.  Never used by the product path.
-int ocrf_diag_raster_stamps(unsigned long long* buf) { g_stamps = buf; return 0; }
-
-size_t ocrf_rasterize_workspace_bytes(int P, int n_views) {
-  if (P <= 0 || n_views <= 0) return 0;
-  RasterWs ws;
-  raster_layout(P, n_views, &ws);
-  return ws.total;
-}
-
-int ocrf_rasterize_forward_sets(int P, int n_sets, int views_per_set, int H, int W, const float* means3D,
-                           const float* colors, const float* opacities, const float* scales,
-                           float scale_modifier, const float* rotations, const float* cov3D_precomp,
-                           const float* cameras, const float* bg, int depth_mode, float* out_color,
-                           float* out_depth, float* out_final_T, uint32_t* out_n_contrib, int* radii,
-                           uint32_t* tiles_touched, int* status, void* workspace,
-                           size_t workspace_bytes, ocrf_stream_t stream_) {
+int raster_forward_chain(int P, int n_sets, int views_per_set, int H, int W, const float* means3D, const float* colors,
+                         const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                         const float* cov3D_precomp, const float* cameras, const int* view_sel, const float* bg,
+                         int depth_mode, float* out_color, float* out_depth, float* out_final_T,
+                         uint32_t* out_n_contrib, int* radii, uint32_t* tiles_touched, int* status, void* workspace,
+                         size_t workspace_bytes, const int* gate, bool shared_means, hipStream_t stream) {
   if (n_sets <= 0 || views_per_set <= 0) return (int)hipErrorInvalidValue;
   const int n_views = n_sets * views_per_set;
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (P < 0 || n_views <= 0 || H <= 0 || W <= 0 || (depth_mode != 0 && depth_mode != 1) ||
       !out_color || !out_depth || !out_final_T || !bg || !cameras)
     return (int)hipErrorInvalidValue;
@@ -1276,15 +1263,16 @@ int ocrf_rasterize_forward_sets(int P, int n_sets, int views_per_set, int H, int
   const dim3 xgrid((unsigned)((n_pre + 7) / 8 * 8 * n_views));         // (chunk, view) pairs, XCD-aware order
   ocrf::launch(OCRF_K_RASTER_PREPROCESS, raster_preprocess_kernel, xgrid, dim3(kBlock), 0, stream, P, n_views,
                n_pre, W, H, gx, gy, means3D, opacities, scales, scale_modifier, rotations, cov3D_precomp,
-               cams, vis_rec, vis_count, rects, xy, conic_o, radii, tiles_touched, hist, views_per_set);
+               cams, vis_rec, vis_count, rects, xy, conic_o, radii, tiles_touched, hist, views_per_set, view_sel, gate,
+               shared_means ? 0 : P);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   ocrf::launch(OCRF_K_RASTER_SCAN, raster_bucket_scan_kernel, dim3(n_views), dim3(kBlock), 0, stream,
-               static_cast<const int*>(hist), starts, cursor, st);
+               static_cast<const int*>(hist), starts, cursor, st, gate);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   ocrf::launch(OCRF_K_RASTER_GATHER, raster_scatter_kernel, pgrid, dim3(kBlock), 0, stream, P,
-               static_cast<const uint4*>(vis_rec), static_cast<const int*>(vis_count), cursor, b_rect, b_comp);
+               static_cast<const uint4*>(vis_rec), static_cast<const int*>(vis_count), cursor, b_rect, b_comp, gate);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   const size_t lds = (size_t)kCapRec * 8 + (size_t)kStage * (16 + 16 + 16);
@@ -1295,7 +1283,7 @@ int ocrf_rasterize_forward_sets(int P, int n_sets, int views_per_set, int H, int
                      W, H, gy, static_cast<const int*>(starts), static_cast<const Rect*>(rects),                    \
                      static_cast<const Rect*>(b_rect), static_cast<const unsigned long long*>(b_comp),              \
                      static_cast<const float2*>(xy), static_cast<const float4*>(conic_o), colors, bg, out_color,    \
-                     out_depth, out_final_T, out_n_contrib, st, BwdArgs{}, views_per_set)
+                     out_depth, out_final_T, out_n_contrib, st, BwdArgs{}, views_per_set, gate)
     if (out_n_contrib) OCRF_BLEND_STAMPED(true);
     else OCRF_BLEND_STAMPED(false);
 #undef OCRF_BLEND_STAMPED
@@ -1307,13 +1295,41 @@ int ocrf_rasterize_forward_sets(int P, int n_sets, int views_per_set, int H, int
                static_cast<const Rect*>(rects), static_cast<const Rect*>(b_rect),                                   \
                static_cast<const unsigned long long*>(b_comp), static_cast<const float2*>(xy),                      \
                static_cast<const float4*>(conic_o), colors, bg, out_color, out_depth, out_final_T, out_n_contrib,    \
-               st, BwdArgs{}, views_per_set)
+               st, BwdArgs{}, views_per_set, gate)
   if (depth_mode == 0 && out_n_contrib) OCRF_BLEND(true, true);
   else if (depth_mode == 0) OCRF_BLEND(true, false);
   else if (out_n_contrib) OCRF_BLEND(false, true);
   else OCRF_BLEND(false, false);
 #undef OCRF_BLEND
   return (int)hipGetLastError();
+}
+
+}  // namespace ocrf
+
+extern "C" {
+
+// Diagnostic: when set (device buffer of tiles*views*8 u64), the next forwards run the stamped
+// build of the blend kernel.  Never used by the product path.
+int ocrf_diag_raster_stamps(unsigned long long* buf) { g_stamps = buf; return 0; }
+
+size_t ocrf_rasterize_workspace_bytes(int P, int n_views) {
+  if (P <= 0 || n_views <= 0) return 0;
+  RasterWs ws;
+  raster_layout(P, n_views, &ws);
+  return ws.total;
+}
+
+int ocrf_rasterize_forward_sets(int P, int n_sets, int views_per_set, int H, int W, const float* means3D,
+                           const float* colors, const float* opacities, const float* scales,
+                           float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                           const float* cameras, const float* bg, int depth_mode, float* out_color,
+                           float* out_depth, float* out_final_T, uint32_t* out_n_contrib, int* radii,
+                           uint32_t* tiles_touched, int* status, void* workspace,
+                           size_t workspace_bytes, ocrf_stream_t stream_) {
+  return ocrf::raster_forward_chain(P, n_sets, views_per_set, H, W, means3D, colors, opacities, scales, scale_modifier,
+                                    rotations, cov3D_precomp, cameras, nullptr, bg, depth_mode, out_color, out_depth,
+                                    out_final_T, out_n_contrib, radii, tiles_touched, status, workspace,
+                                    workspace_bytes, nullptr, false, static_cast<hipStream_t>(stream_));
 }
 
 int ocrf_rasterize_forward(int P, int n_views, int H, int W, const float* means3D,
@@ -1378,11 +1394,12 @@ static int rasterize_backward_impl(int P, int n_views, int H, int W, const float
   const dim3 xgrid((unsigned)((n_pre + 7) / 8 * 8 * n_views));
   hipLaunchKernelGGL(raster_preprocess_kernel, xgrid, dim3(kBlock), 0, stream, P, n_views, n_pre, W, H, gx, gy,
                      means3D, opacities, scales, scale_modifier, rotations, cov3D_precomp, cams, vis_rec,
-                     vis_count, rects, xy, conic_o, radii, (unsigned*)nullptr, hist, n_views);
+                     vis_count, rects, xy, conic_o, radii, (unsigned*)nullptr, hist, n_views, (const int*)nullptr,
+                     (const int*)nullptr, P);
   hipLaunchKernelGGL(raster_bucket_scan_kernel, dim3(n_views), dim3(kBlock), 0, stream, static_cast<const int*>(hist),
-                     starts, cursor, st);
+                     starts, cursor, st, (const int*)nullptr);
   hipLaunchKernelGGL(raster_scatter_kernel, pgrid, dim3(kBlock), 0, stream, P, static_cast<const uint4*>(vis_rec),
-                     static_cast<const int*>(vis_count), cursor, b_rect, b_comp);
+                     static_cast<const int*>(vis_count), cursor, b_rect, b_comp, (const int*)nullptr);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   BwdArgs bw;
@@ -1394,7 +1411,7 @@ static int rasterize_backward_impl(int P, int n_views, int H, int W, const float
                static_cast<const Rect*>(rects), static_cast<const Rect*>(b_rect),
                static_cast<const unsigned long long*>(b_comp),
                static_cast<const float2*>(xy), static_cast<const float4*>(conic_o), colors, bg, (float*)nullptr,
-               (float*)nullptr, (float*)nullptr, (unsigned*)nullptr, st, bw, n_views);
+               (float*)nullptr, (float*)nullptr, (unsigned*)nullptr, st, bw, n_views, (const int*)nullptr);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   ocrf::launch(OCRF_K_RASTER_PRE_BWD, raster_preprocess_backward_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock),

@@ -12,7 +12,7 @@ import math
 import numpy as np
 import torch
 
-from . import bevpool, gaussian_renderer, hoa, index_prep, synthetic
+from . import bevpool, gaussian_renderer, hoa, index_prep, raster_plan, synthetic
 from .diff_gaussian_rasterization import pack_cameras, rasterize_views
 
 
@@ -55,12 +55,22 @@ def shared_stream(device, role):
 
 
 class HotPath:
-    def __init__(self, cfg, device, cams=None, index_prep_mode='cached', overlap=True, device_geometry=False):
+    def __init__(self, cfg, device, cams=None, index_prep_mode='cached', overlap=True, device_geometry=False,
+                 render_mode='planned', render_guard='host', frame_motion=True, frame_offset=0, plan_margin=1.5):
         """``cams``: optional list of camera indices this instance owns (camera sharding).
         ``index_prep_mode``: 'cached' — rank vectors computed once per calibration, the reference's
         ``accelerate=True`` intent; 'per_step' — recomputed inside every ``step()`` by the HIP index
-        preparation (csrc/index_prep.hip), what the reference does with ``accelerate=False``."""
+        preparation (csrc/index_prep.hip), what the reference does with ``accelerate=False``.
+        ``render_mode``: 'planned' — the render's calibration-only front end (cull, depth order, projected centres)
+        is cached per frame like the rank vectors (``raster_plan.RasterPlan``; the Gaussian means are the fixed voxel
+        grid, view_transformer_ocrf.py:651-673); 'per_call' — recomputed by every render (``rasterize_views``).
+        ``render_guard``: 'host' (the plan's extent bound is checked by ``check_render_plans()``) or 'device'.
+        ``frame_motion``: batch entry b is frame ``frame_offset + b`` of a multi-frame sample with its own ego pose
+        (``synthetic.ego_motion``) and its own Gaussian parameters, instead of every frame repeating frame 0."""
         self.cfg, self.device = cfg, torch.device(device)
+        assert render_mode in ('planned', 'per_call') and render_guard in ('host', 'device')
+        self.render_mode, self.render_guard, self.plan_margin = render_mode, render_guard, float(plan_margin)
+        self.frame_motion, self.frame_offset = bool(frame_motion), int(frame_offset)
         self.cams = list(range(cfg.n_cams)) if cams is None else list(cams)
         self.batch = cfg.batch * cfg.n_frames                  # frames ride along as batch entries
         assert index_prep_mode in ('cached', 'per_step')
@@ -79,7 +89,8 @@ class HotPath:
 
     def _prepare(self):
         cfg, dev = self.cfg, self.device
-        r = synthetic.rig(cfg.n_cams, cfg.input_size, self.batch)
+        r = synthetic.rig(cfg.n_cams, cfg.input_size, self.batch, frame_motion=self.frame_motion,
+                          frame_offset=self.frame_offset)
         sel = self.cams
         g = {k: torch.from_numpy(r[k][:, sel] if r[k].ndim >= 3 and k != 'bda' else r[k]).to(dev)
              for k in ('rots', 'trans', 'intrins', 'post_rots', 'post_trans', 'bda', 'c2w')}
@@ -143,10 +154,11 @@ class HotPath:
         cfg = self.cfg
         X, Y, _ = cfg.bev_xyz
         m = self.hoa_mods
-        # every frame shares the synthetic opacity volume; the reference loops samples (:1090).  The (B*P, 1)
+        # every frame has its own opacity volume; the reference loops samples (:1090).  The (B*P, 1)
         # layout A_MLP hands over (:1130) is an INPUT of this stage: laid out once, not per step
         if self._opac_flat is None:
-            self._opac_flat = self.gauss['opacity'].view(1, cfg.num_height, Y, X).expand(self.batch, -1, -1, -1).reshape(-1, 1).contiguous()
+            self._opac_flat = torch.stack([fg['opacity'].view(cfg.num_height, Y, X) for fg in self.frame_gauss]) \
+                .reshape(-1, 1).contiguous()
         oa = hoa.hoa1(m['dca'], self._opac_flat, self.alpha_lidar, cfg.num_height, Y, X)
         return m['v2b'](oa, self.bev_pos1)
 
@@ -159,7 +171,7 @@ class HotPath:
         return gated, opacity_bev
 
     def _prepare_render(self, r, convention='corrected', seed=0):
-        """Cameras + synthetic Gaussian parameters of the OcRF render.
+        """Cameras + synthetic Gaussian parameters of the OcRF render, per frame.
 
         convention 'reference': the reference's own set-up, quirks included
         (view_transformer_ocrf.py:1135-1152: unscaled 1600x900 intrinsics with the network-input
@@ -167,59 +179,86 @@ class HotPath:
         input and a proper world->view transform (the headline of SURVEY.md 8d)."""
         cfg, dev = self.cfg, self.device
         H, W = cfg.input_size
-        vms, pms, tfx, tfy = [], [], [], []
-        for n in self.cams:
-            K = r['intrins'][0, n].astype(np.float64)
-            c2w = r['c2w'][0, n].astype(np.float64)
-            if convention == 'corrected':
-                s, crop = r['resize'], r['crop_h']
-                K = np.array([[K[0, 0] * s, 0, K[0, 2] * s], [0, K[1, 1] * s, K[1, 2] * s - crop], [0, 0, 1.0]])
-                w2c = np.linalg.inv(c2w)
-                c2w_arg = np.eye(4)
-                c2w_arg[:3, :3] = c2w[:3, :3]          # getWorld2View2 transposes R itself
-                c2w_arg[:3, 3] = w2c[:3, 3]
-            else:
-                c2w_arg = c2w
-            cam = gaussian_renderer.camera_from_calibration(K.astype(np.float32), c2w_arg.astype(np.float32), H, W)
-            vms.append(cam['world_view_transform']), pms.append(cam['full_proj_transform'])
-            tfx.append(math.tan(float(cam['FovX']) * 0.5)), tfy.append(math.tan(float(cam['FovY']) * 0.5))
-        self.render_cams = dict(vm=torch.stack(vms).to(dev), pm=torch.stack(pms).to(dev), tfx=tfx, tfy=tfy)
-        # the rig is fixed: pack the C ABI's camera block once instead of on every render call
-        self.render_cams['packed'] = pack_cameras(self.render_cams['vm'], self.render_cams['pm'], tfx, tfy, H, W, dev)
+        self.frame_cams, self.frame_gauss = [], []
         P = self.voxel_xyz.shape[1] * self.voxel_xyz.shape[2]
-        rng = np.random.default_rng(seed)
-        q = rng.standard_normal((P, 4)).astype(np.float32)
-        q /= np.linalg.norm(q, axis=1, keepdims=True)
         t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
-        # ranges of the reference's Gaussian heads at seeded init (SURVEY.md 8d probe)
-        self.gauss = dict(scales=t(rng.uniform(0.69, 0.84, (P, 3)).astype(np.float32)), rotations=t(q),
-                          opacity=t(rng.uniform(0.35, 0.45, (P, 1)).astype(np.float32)),
-                          rgb=t(rng.uniform(0.0, 1.0, (P, 3)).astype(np.float32)))
+        for b in range(self.batch):
+            vms, pms, tfx, tfy = [], [], [], []
+            for n in self.cams:
+                K = r['intrins'][b, n].astype(np.float64)
+                c2w = r['c2w'][b, n].astype(np.float64)
+                if convention == 'corrected':
+                    s, crop = r['resize'], r['crop_h']
+                    K = np.array([[K[0, 0] * s, 0, K[0, 2] * s], [0, K[1, 1] * s, K[1, 2] * s - crop], [0, 0, 1.0]])
+                    w2c = np.linalg.inv(c2w)
+                    c2w_arg = np.eye(4)
+                    c2w_arg[:3, :3] = c2w[:3, :3]          # getWorld2View2 transposes R itself
+                    c2w_arg[:3, 3] = w2c[:3, 3]
+                else:
+                    c2w_arg = c2w
+                cam = gaussian_renderer.camera_from_calibration(K.astype(np.float32), c2w_arg.astype(np.float32), H, W)
+                vms.append(cam['world_view_transform']), pms.append(cam['full_proj_transform'])
+                tfx.append(math.tan(float(cam['FovX']) * 0.5)), tfy.append(math.tan(float(cam['FovY']) * 0.5))
+            rc = dict(vm=torch.stack(vms).to(dev), pm=torch.stack(pms).to(dev), tfx=tfx, tfy=tfy)
+            # the rig is fixed: pack the C ABI's camera block once instead of on every render call
+            rc['packed'] = pack_cameras(rc['vm'], rc['pm'], tfx, tfy, H, W, dev)
+            self.frame_cams.append(rc)
+            # Gaussian parameters of frame (frame_offset + b): ranges of the reference's heads at seeded init
+            # (SURVEY.md 8d probe); with frame_motion every frame draws its own
+            rng = np.random.default_rng(seed + (self.frame_offset + b if self.frame_motion else 0))
+            q = rng.standard_normal((P, 4)).astype(np.float32)
+            q /= np.linalg.norm(q, axis=1, keepdims=True)
+            self.frame_gauss.append(dict(scales=t(rng.uniform(0.69, 0.84, (P, 3)).astype(np.float32)), rotations=t(q),
+                                         opacity=t(rng.uniform(0.35, 0.45, (P, 1)).astype(np.float32)),
+                                         rgb=t(rng.uniform(0.0, 1.0, (P, 3)).astype(np.float32))))
+        self.render_cams, self.gauss = self.frame_cams[0], self.frame_gauss[0]       # frame 0 (tests, tools)
         self.bg = torch.zeros(3, device=dev)
         self.render_convention = convention
+        self.render_plans = None                 # raster_plan.RasterPlan per frame, built on first use
+        self._opac_flat = None
+
+    def _plans(self):
+        if self.render_plans is None:
+            H, W = self.cfg.input_size
+            self.render_plans = [
+                raster_plan.RasterPlan(self.voxel_xyz[b].reshape(-1, 3), self.frame_cams[b]['packed'], H, W,
+                                       scales=self.frame_gauss[b]['scales'], rotations=self.frame_gauss[b]['rotations'],
+                                       margin=self.plan_margin) for b in range(self.batch)]
+        return self.render_plans
+
+    def check_render_plans(self):
+        """Synchronising check of the render plans' extent bound (``render_guard='host'``): raises if a planned
+        render since the last check was not valid."""
+        for p in (self.render_plans or []):
+            p.check()
+
+    def _render_frame(self, b, want_n_contrib, tag):
+        cfg, rc, g = self.cfg, self.frame_cams[b], self.frame_gauss[b]
+        H, W = cfg.input_size
+        if self.render_mode == 'planned' and not want_n_contrib:
+            return self._plans()[b].render(g['rgb'], g['opacity'], g['scales'], g['rotations'], self.bg,
+                                           guard=self.render_guard)
+        xyz = self.voxel_xyz[b].reshape(-1, 3)
+        return rasterize_views(xyz, g['rgb'], g['opacity'], g['scales'], g['rotations'], rc['vm'], rc['pm'], rc['tfx'],
+                               rc['tfy'], H, W, self.bg, packed_cameras=rc['packed'], want_n_contrib=want_n_contrib,
+                               workspace_tag=tag)
 
     def render(self, streams=None, want_n_contrib=False):
-        """All owned cameras of every frame: list (one per frame) of dicts from rasterize_views.
+        """All owned cameras of every frame: list (one per frame) of dicts (``color``, ``depth``, ``final_T``, ...).
         ``streams``: a HIP stream per frame (frames on different streams get their own scratch buffer);
         the caller joins them.  One call per frame on purpose: a single 12-view call
         (``rasterize_sets``) is 7 % faster alone but 17 % slower beside the main stream's kernels — a
         4 224-workgroup blend leaves them no room to interleave.  The step is inference: the per-pixel contributor
-        index (read only by the backward) is not tracked unless ``want_n_contrib``."""
-        cfg, rc, g = self.cfg, self.render_cams, self.gauss
-        H, W = cfg.input_size
+        index (read only by the backward) is not tracked unless ``want_n_contrib`` (which renders per call)."""
+        if self.render_mode == 'planned' and not want_n_contrib:
+            self._plans()                     # built (one synchronisation each) before anything is enqueued on a side stream
         outs = []
         for b in range(self.batch):
-            xyz = self.voxel_xyz[b].reshape(-1, 3)
             if streams is None:
-                outs.append(rasterize_views(xyz, g['rgb'], g['opacity'], g['scales'], g['rotations'], rc['vm'],
-                                            rc['pm'], rc['tfx'], rc['tfy'], H, W, self.bg,
-                                            packed_cameras=rc['packed'], want_n_contrib=want_n_contrib))
+                outs.append(self._render_frame(b, want_n_contrib, 'raster'))
             else:
                 with torch.cuda.stream(streams[b]):
-                    outs.append(rasterize_views(xyz, g['rgb'], g['opacity'], g['scales'], g['rotations'], rc['vm'],
-                                                rc['pm'], rc['tfx'], rc['tfy'], H, W, self.bg,
-                                                packed_cameras=rc['packed'], want_n_contrib=want_n_contrib,
-                                                workspace_tag=f'raster{streams.index(streams[b])}'))
+                    outs.append(self._render_frame(b, want_n_contrib, f'raster{streams.index(streams[b])}'))
         return outs
 
     @property
@@ -353,7 +392,7 @@ class ShardedHotPath:
     (which do not read the pooled BEV) run beside them.  With ``world == 1`` it is ``HotPath`` with the same fused
     output buffer."""
 
-    def __init__(self, cfg, device, rank, world, index_prep_mode='cached'):
+    def __init__(self, cfg, device, rank, world, index_prep_mode='cached', render_mode='planned', render_guard='host'):
         from . import sharding
         self.cfg, self.device, self.rank, self.world = cfg, torch.device(device), rank, world
         X, Y, Z = cfg.bev_xyz
@@ -364,7 +403,8 @@ class ShardedHotPath:
         self.exchange = sharding.BevExchange(self.plan, rank, self.device, (Y, X))
         one = synthetic.PathConfig(**{**cfg.__dict__, 'batch': 1, 'n_frames': 1, 'hoa': False})
         self.subs = {f: HotPath(one, self.device, cams=self.plan.cams_of(rank, f), index_prep_mode=index_prep_mode,
-                                overlap=False) for f in self.plan.frames_of(rank)}
+                                overlap=False, frame_offset=f, render_mode=render_mode, render_guard=render_guard)
+                     for f in self.plan.frames_of(rank)}
         # HOA (replicated) needs the Gaussian opacities / alpha volume of every frame, not this rank's cameras
         self.base = HotPath(synthetic.PathConfig(**{**cfg.__dict__, 'render': cfg.render or cfg.hoa}), self.device,
                             cams=[0], index_prep_mode='cached', overlap=False) if cfg.hoa else None

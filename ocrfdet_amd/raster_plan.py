@@ -1,0 +1,164 @@
+"""Static render plans: the rasteriser's front end computed once per (Gaussian means, cameras).
+
+In OcRFDet the Gaussian means are the fixed voxel grid (``view_transformer_ocrf.py:651-673,690-692``) and the
+cameras are fixed per calibration; only the S/R/A/C heads' outputs change per step (``:1130-1133``).  A
+``RasterPlan`` keeps, per camera, the Gaussians that can ever be visible, already in the reference's blend order
+(depth bits, then id — ``rasterizer_impl.cu:226-267``), so a render is two launches
+(``csrc/raster_plan.hip``; C ABI ``ocrf_raster_plan_*`` / ``ocrf_rasterize_planned``).  Colour, depth and
+``final_T`` are bit-identical to ``rasterize_views`` (``tests/test_raster_plan_gpu.py``).
+
+The static cull is valid for Gaussians whose world-space extent ``scale_modifier * max|s| * |R(q)|_2`` stays within
+``extent_bound``.  ``guard='device'`` arms the per-call pipeline behind the planned one on the GPU (exact whatever
+the parameters do, graph-capturable); ``guard='host'`` only raises status bit 4, which ``check()`` turns into an
+exception — the caller decides when to pay that synchronisation.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .diff_gaussian_rasterization import _f32c
+
+__all__ = ['RasterPlan', 'extent_of']
+
+
+def extent_of(scales, rotations, scale_modifier=1.0):
+    """max over the Gaussians of ``scale_modifier * max_k |s_k| * (|1 - |q|^2| + |q|^2)`` — what a plan's
+    ``extent_bound`` must dominate (device scalar tensor)."""
+    qq = (rotations.float() ** 2).sum(-1)
+    return (float(scale_modifier) * scales.float().abs().amax(-1) * ((1.0 - qq).abs() + qq)).max()
+
+
+class RasterPlan:
+    """Plan for ``means3D`` (P,3) seen by the ``V`` cameras of ``packed_cameras`` (V,36; ``pack_cameras``).
+
+    ``extent_bound``: a float, or None to take ``margin`` x the extent of the example ``scales`` / ``rotations``.
+    Building synchronises once (the kept counts size the plan)."""
+
+    def __init__(self, means3D, packed_cameras, image_height, image_width, extent_bound=None, scales=None,
+                 rotations=None, scale_modifier=1.0, margin=2.0):
+        _lib.require_cuda(means3D, packed_cameras)
+        if means3D.dim() != 2 or means3D.size(1) != 3:
+            raise RuntimeError('means3D must have dimensions (num_points, 3)')
+        self.device = dev = means3D.device
+        self.means3D = _f32c(means3D)
+        self.cameras = _f32c(packed_cameras).reshape(-1, 36)
+        self.P, self.V = int(self.means3D.size(0)), int(self.cameras.size(0))
+        self.H, self.W = int(image_height), int(image_width)
+        if self.P == 0 or self.V == 0 or self.V > 32:
+            raise _lib.OcrfHipError('a render plan needs at least one Gaussian and 1..32 cameras')
+        if extent_bound is None:
+            if scales is None or rotations is None:
+                raise _lib.OcrfHipError('RasterPlan needs extent_bound or example scales / rotations')
+            extent_bound = float(margin) * float(extent_of(scales, rotations, scale_modifier))
+        self.extent_bound = float(extent_bound)
+        L = _lib.lib()
+        with _lib.on_device(dev):
+            ws = torch.empty(L.ocrf_raster_plan_build_workspace_bytes(self.P, self.V), dtype=torch.uint8, device=dev)
+            counts = torch.empty(self.V, dtype=torch.int32, device=dev)
+            _lib.check(L.ocrf_raster_plan_classify(
+                self.P, self.V, self.H, self.W, _lib.ptr(self.means3D), _lib.ptr(self.cameras),
+                ctypes.c_float(self.extent_bound), _lib.ptr(counts), _lib.ptr(ws), ctypes.c_size_t(ws.numel()),
+                _lib.stream_ptr(dev)), 'ocrf_raster_plan_classify')
+            host = counts.cpu()                                  # the build's one synchronisation
+            self.kept = [int(v) for v in host]
+            self.total_kept, self.max_kept = sum(self.kept), max(self.kept)
+            self.plan = torch.empty(max(int(L.ocrf_raster_plan_bytes(self.P, self.V, self.total_kept)), 256),
+                                    dtype=torch.uint8, device=dev)
+            _lib.check(L.ocrf_raster_plan_fill(
+                self.P, self.V, self.H, self.W, _lib.ptr(self.means3D), _lib.ptr(self.cameras),
+                ctypes.c_float(self.extent_bound), _lib.ptr(counts), ctypes.c_long(self.total_kept), self.max_kept,
+                _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.ptr(self.plan), ctypes.c_size_t(self.plan.numel()),
+                _lib.stream_ptr(dev)), 'ocrf_raster_plan_fill')
+        # sticky status word (bit 4: extent bound exceeded in some call, bit 8: bad view index / unusable plan)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._dyn = None                       # per-call scratch, owned by the plan (one stream at a time)
+        self._chain_ws = None
+
+    def _scratch(self, n_sets):
+        need = _lib.lib().ocrf_rasterize_planned_workspace_bytes(ctypes.c_long(self.total_kept), n_sets)
+        if self._dyn is None or self._dyn.numel() < need:
+            self._dyn = torch.empty(max(int(need), 256), dtype=torch.uint8, device=self.device)
+        return self._dyn
+
+    @torch.no_grad()
+    def render(self, colors, opacities, scales, rotations, bg, scale_modifier=1.0, depth_mode='median',
+               item_view=None, want_radii=False, guard='host', out=None):
+        """Render ``n_items = len(item_view)`` views: item z = plan view ``item_view[z]`` (int32 device tensor) with
+        Gaussian set ``z // (n_items // S)`` of the ``(S, P, .)`` (or ``(P, .)``) parameter tensors; without
+        ``item_view`` every set renders all ``V`` plan views in order.
+        -> dict ``color`` (n_items,3,H,W), ``depth`` (n_items,1,H,W), ``final_T`` (n_items,H,W) [, ``radii``
+        (n_items,P)], ``status`` (the plan's sticky device word)."""
+        _lib.require_cuda(colors, opacities, scales, rotations, bg)
+        dev, P = self.device, self.P
+        colors, sc, rot = _f32c(colors), _f32c(scales), _f32c(rotations)
+        S = 1 if colors.dim() == 2 else int(colors.size(0))
+        opac = _f32c(opacities).reshape(S, P)
+        if colors.numel() != S * P * 3 or sc.numel() != S * P * 3 or rot.numel() != S * P * 4:
+            raise _lib.OcrfHipError(f'parameter tensors do not match the plan ({S} sets of {P} Gaussians)')
+        if item_view is not None:
+            _lib.require_cuda(item_view)
+            if item_view.dtype != torch.int32 or not item_view.is_contiguous():
+                raise _lib.OcrfHipError('item_view must be a contiguous int32 device tensor')
+            n_items = int(item_view.numel())
+            if n_items == 0 or n_items % S:
+                raise _lib.OcrfHipError('the number of items must be a positive multiple of the number of Gaussian sets')
+        else:
+            n_items = S * self.V                                  # every set renders the plan's views in order
+            if S > 1:
+                if getattr(self, '_tiled_views', None) is None or self._tiled_views.numel() != n_items:
+                    self._tiled_views = (torch.arange(n_items, device=dev, dtype=torch.int32) % self.V).contiguous()
+                item_view = self._tiled_views
+        H, W = self.H, self.W
+        bg = _f32c(bg).reshape(3)
+        if out is None:
+            out = dict(color=torch.empty(n_items, 3, H, W, device=dev), depth=torch.empty(n_items, 1, H, W, device=dev),
+                       final_T=torch.empty(n_items, H, W, device=dev))
+        use_guard = {'host': 0, 'device': 1}[guard]
+        radii = None
+        if want_radii or use_guard:
+            radii = out.get('radii')
+            if radii is None:
+                radii = out['radii'] = torch.empty(n_items, P, dtype=torch.int32, device=dev)
+        L = _lib.lib()
+        with _lib.on_device(dev):
+            dyn = self._scratch(S)
+            chain = None
+            if use_guard:
+                need = L.ocrf_rasterize_workspace_bytes(P, n_items)
+                if self._chain_ws is None or self._chain_ws.numel() < need:
+                    self._chain_ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
+                chain = self._chain_ws
+            _lib.check(L.ocrf_rasterize_planned(
+                _lib.ptr(self.plan), ctypes.c_size_t(self.plan.numel()), P, self.V, ctypes.c_long(self.total_kept),
+                H, W, S, n_items, _lib.ptr(item_view), _lib.ptr(colors), _lib.ptr(opac), _lib.ptr(sc),
+                ctypes.c_float(scale_modifier), _lib.ptr(rot), _lib.ptr(bg), {'median': 0, 'mean': 1}[depth_mode],
+                _lib.ptr(out['color']), _lib.ptr(out['depth']), _lib.ptr(out['final_T']), _lib.ptr(radii),
+                _lib.ptr(self.status), _lib.ptr(dyn), ctypes.c_size_t(dyn.numel()), use_guard,
+                _lib.ptr(self.means3D), _lib.ptr(chain), ctypes.c_size_t(chain.numel() if chain is not None else 0),
+                _lib.stream_ptr(dev)), 'ocrf_rasterize_planned')
+        out['status'] = self.status
+        return out
+
+    def check(self):
+        """Synchronising read of the sticky status word: raises if any render since the last ``check`` ran with a
+        Gaussian beyond ``extent_bound`` (``guard='host'`` renders of such a call are invalid) or with a bad view
+        index.  Clears the word."""
+        st = int(self.status.item())
+        self.status.zero_()
+        if st & 8:
+            raise _lib.OcrfHipError('RasterPlan: a render used a view index outside the plan (or the plan is unusable)')
+        if st & 4:
+            raise _lib.OcrfHipError(
+                f'RasterPlan: a Gaussian exceeded the plan\'s extent bound {self.extent_bound:g} — renders with '
+                "guard='host' since the last check are invalid; rebuild the plan with a larger bound or render with "
+                "guard='device'")
+        return True
+
+    def exceeded(self):
+        """Like ``check`` but returns whether the extent bound was exceeded instead of raising for it."""
+        st = int(self.status.item())
+        self.status.zero_()
+        if st & 8:
+            raise _lib.OcrfHipError('RasterPlan: a render used a view index outside the plan (or the plan is unusable)')
+        return bool(st & 4)

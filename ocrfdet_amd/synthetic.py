@@ -76,9 +76,22 @@ CONFIGS = {
 }
 
 
-def rig(n_cams=6, input_size=(256, 704), batch=1, dtype=np.float32):
+def ego_motion(k):
+    """4x4 transform of frame k's ego into the key frame's (k = 0: identity): an adjacent frame of a
+    multi-frame sample was taken 4 m further back along the lane, 0.25 m to the side, yawed 1.5 degrees
+    (mmdet3d/models/detectors/bevdet.py:437-455 composes sensor2keyego the same way)."""
+    a = math.radians(1.5 * k)
+    T = np.eye(4)
+    T[:3, :3] = [[math.cos(a), -math.sin(a), 0], [math.sin(a), math.cos(a), 0], [0, 0, 1]]
+    T[:3, 3] = [-4.0 * k, 0.25 * k, 0.0]
+    return T
+
+
+def rig(n_cams=6, input_size=(256, 704), batch=1, dtype=np.float32, frame_motion=False, frame_offset=0):
     """-> dict of numpy arrays: rots (B,N,3,3), trans (B,N,3), intrins (B,N,3,3), post_rots
-    (B,N,3,3), post_trans (B,N,3), bda (B,3,3), c2w (B,N,4,4)."""
+    (B,N,3,3), post_trans (B,N,3), bda (B,3,3), c2w (B,N,4,4).  ``frame_motion``: batch entry b is frame
+    ``frame_offset + b`` of a multi-frame sample, its cameras expressed in the key frame's ego
+    (``ego_motion``); default: every entry is the key frame's rig."""
     H_in, W_in = input_size
     base = np.array([[0, 0, 1], [-1, 0, 0], [0, -1, 0]], dtype=np.float64)
     rots, trans, c2w = [], [], []
@@ -98,10 +111,19 @@ def rig(n_cams=6, input_size=(256, 704), batch=1, dtype=np.float32):
     post_tran = np.array([0.0, -float(crop_h), 0.0])
     rep = lambda a: np.broadcast_to(np.asarray(a, dtype=dtype), (batch,) + np.shape(a)).copy()  # noqa: E731
     N = n_cams
-    return dict(
+    out = dict(
         rots=rep(np.stack(rots)), trans=rep(np.stack(trans)), intrins=rep(np.stack([K] * N)),
         post_rots=rep(np.stack([post_rot] * N)), post_trans=rep(np.stack([post_tran] * N)),
         bda=rep(np.eye(3)), c2w=rep(np.stack(c2w)), resize=s, crop_h=crop_h)
+    if frame_motion:
+        for b in range(batch):
+            T = ego_motion(frame_offset + b)
+            for n in range(N):
+                M = T @ c2w[n]
+                out['rots'][b, n] = M[:3, :3].astype(dtype)
+                out['trans'][b, n] = M[:3, 3].astype(dtype)
+                out['c2w'][b, n] = M.astype(dtype)
+    return out
 
 
 def rig_tensors(cfg, device='cpu'):

@@ -77,8 +77,9 @@ def test_cfg4_rank_triples_pools_and_render_at_512x1408(cuda, oracle_lib):
 
 
 def test_cfg4_eight_frames_step_properties(cuda):
-    """The whole configs[4] step (8 frames x 6 cams, 48 rendered views): finite, frames agree with a one-frame
-    run (frames ride along as batch entries; the synthetic rig is the same for every frame)."""
+    """The whole configs[4] step (8 frames x 6 cams, 48 rendered views): finite, and a frame agrees bit for bit with a
+    one-frame run of that frame (frames ride along as batch entries; every frame has its own ego pose and its own
+    Gaussian parameters, synthetic.ego_motion)."""
     cfg = synthetic.PathConfig(**{**synthetic.CONFIGS[CFG4].__dict__, 'hoa': False})
     hp = hotpath.HotPath(cfg, cuda)
     depth, feat = hp.make_inputs(seed=4)
@@ -86,9 +87,16 @@ def test_cfg4_eight_frames_step_properties(cuda):
     torch.cuda.synchronize()
     assert lss.shape[0] == 8 and len(rendered) == 8
     assert torch.isfinite(lss).all() and torch.isfinite(ht).all()
-    one = hotpath.HotPath(_one_frame(CFG4), cuda)
-    l1, h1 = one.step(depth[3:4].contiguous(), feat[3:4].contiguous())[:2]
+    one = hotpath.HotPath(_one_frame(CFG4), cuda, frame_offset=3)
+    l1, h1, r1 = one.step(depth[3:4].contiguous(), feat[3:4].contiguous())[:3]
     assert torch.equal(l1[0], lss[3]) and torch.equal(h1[0], ht[3])
-    for o in rendered:
+    assert torch.equal(r1[0]['color'], rendered[3]['color']) and torch.equal(r1[0]['depth'], rendered[3]['depth'])
+    for k, o in enumerate(rendered):
         assert torch.isfinite(o['color']).all() and float(o['final_T'].min()) >= 0.0
-        assert torch.equal(o['color'], rendered[0]['color'])            # same Gaussians, same cameras
+        assert k == 0 or not torch.equal(o['color'], rendered[0]['color'])     # another pose, other Gaussians
+    hp.check_render_plans()
+    # the planned renders of the step equal the per-call pipeline's
+    per_call = hotpath.HotPath(cfg, cuda, render_mode='per_call').render()
+    for a, b in zip(rendered, per_call):
+        assert torch.equal(a['color'], b['color']) and torch.equal(a['depth'], b['depth']) and \
+            torch.equal(a['final_T'], b['final_T'])

@@ -1,0 +1,213 @@
+"""GPU parity of the static render plans (csrc/raster_plan.hip, ocrfdet_amd/raster_plan.py).
+
+The planned render must reproduce the per-call pipeline (``rasterize_views``, itself checked against the C
+oracle in tests/test_rasterize_gpu.py) BIT FOR BIT in colour, depth and final_T, and in radii: it blends the same
+records in the same order with the same arithmetic; what it leaves out (Gaussians culled statically, records a
+wave's pixel block cannot reach) contributes exactly nothing in the reference either
+(forward.cu:166-171,236-238,331-333)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from ocrfdet_amd import diff_gaussian_rasterization as dgr
+from ocrfdet_amd import gaussian_renderer as gr
+from ocrfdet_amd import raster_plan as rp
+from ocrfdet_amd import synthetic
+from tests import helpers
+from tests.test_rasterize_gpu import _compare
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, cuda):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+
+def _scene(rng, n, cuda, **kw):
+    xyz, rgb, opac, sc, rot = helpers.random_gaussians(rng, n, **kw)
+    return tuple(_t(a, cuda) for a in (xyz, rgb, opac, sc, rot))
+
+
+def _cams(cuda, W, H, positions):
+    vms, pms, tfx, tfy = [], [], [], []
+    for p in positions:
+        view, full, tx, ty = helpers.simple_camera(W, H, cam_pos=p)
+        vms.append(torch.from_numpy(view)), pms.append(torch.from_numpy(full))
+        tfx.append(tx), tfy.append(ty)
+    return dgr.pack_cameras(torch.stack(vms).to(cuda), torch.stack(pms).to(cuda), tfx, tfy, H, W, cuda)
+
+
+def _same(a, b, keys=('color', 'depth', 'final_T')):
+    for k in keys:
+        assert torch.equal(a[k], b[k]), f'{k} differs: max |d| = {(a[k].float() - b[k].float()).abs().max().item()}'
+
+
+@pytest.mark.parametrize('n,seed', [(1, 0), (300, 1), (5000, 2), (40000, 3)])
+@pytest.mark.parametrize('mode', ['median', 'mean'])
+def test_planned_render_is_bit_identical_to_the_per_call_pipeline(cuda, n, seed, mode):
+    rng = np.random.default_rng(seed)
+    W, H = 176, 80                      # 11 x 5 tiles: the last tile pair has no lower tile
+    xyz, rgb, opac, sc, rot = _scene(rng, n, cuda)
+    cams = _cams(cuda, W, H, [(0, 0, 0), (1.5, -0.5, 2.0), (-3.0, 0.4, -1.0)])
+    bg = torch.tensor([0.1, 0.2, 0.3], device=cuda)
+    want = dgr.rasterize_views(xyz, rgb, opac, sc, rot, None, None, None, None, H, W, bg, depth_mode=mode,
+                               packed_cameras=cams, want_n_contrib=False)
+    plan = rp.RasterPlan(xyz, cams, H, W, scales=sc, rotations=rot)
+    got = plan.render(rgb, opac, sc, rot, bg, depth_mode=mode, want_radii=True)
+    torch.cuda.synchronize()
+    assert plan.check()
+    _same(want, got, ('color', 'depth', 'final_T', 'radii'))
+    assert sum(plan.kept) <= 3 * n
+
+
+def test_plan_matches_the_oracle(cuda, oracle_lib):
+    rng = np.random.default_rng(5)
+    W, H = 176, 64
+    view, full, tfx, tfy = helpers.simple_camera(W, H)
+    xyz, rgb, opac, sc, rot = helpers.random_gaussians(rng, 5000)
+    want = oracle_lib.rasterize_forward(xyz, rgb, opac, sc, rot, view, full, tfx, tfy, H, W, np.float32([0, 0, 0]))
+    cams = dgr.pack_cameras(_t(view, cuda).view(1, 4, 4), _t(full, cuda).view(1, 4, 4), [tfx], [tfy], H, W, cuda)
+    plan = rp.RasterPlan(_t(xyz, cuda), cams, H, W, scales=_t(sc, cuda), rotations=_t(rot, cuda))
+    got = plan.render(_t(rgb, cuda), _t(opac, cuda), _t(sc, cuda), _t(rot, cuda), torch.zeros(3, device=cuda),
+                      want_radii=True)
+    torch.cuda.synchronize()
+    g = {k: v.cpu().numpy() for k, v in got.items()}
+    # the shared comparison wants n_contrib / tiles_touched too: the plan path has neither, feed the oracle's own
+    g['n_contrib'] = want['n_contrib'][None].astype(np.int32)
+    g['tiles_touched'] = want['tiles_touched'][None].astype(np.int32)
+    _compare(want, g, H, W)
+
+
+def test_a_plan_outlives_its_parameters(cuda):
+    """One plan, many parameter sets within its bound — and every one equals the per-call render."""
+    rng = np.random.default_rng(7)
+    W, H = 128, 96
+    xyz, rgb, opac, sc, rot = _scene(rng, 8000, cuda)
+    cams = _cams(cuda, W, H, [(0, 0, 0), (0.5, 0.2, 1.0)])
+    bg = torch.zeros(3, device=cuda)
+    plan = rp.RasterPlan(xyz, cams, H, W, extent_bound=1.0)
+    for k in range(4):
+        g = torch.Generator(device='cpu').manual_seed(k)
+        sc_k = (torch.rand(8000, 3, generator=g) * 0.9 + 0.02).to(cuda)           # |s| <= 0.92 < bound
+        q = torch.randn(8000, 4, generator=g)
+        rot_k = (q / q.norm(dim=1, keepdim=True)).to(cuda)
+        opac_k = torch.rand(8000, 1, generator=g).to(cuda)
+        rgb_k = torch.rand(8000, 3, generator=g).to(cuda)
+        want = dgr.rasterize_views(xyz, rgb_k, opac_k, sc_k, rot_k, None, None, None, None, H, W, bg,
+                                   packed_cameras=cams, want_n_contrib=False)
+        got = plan.render(rgb_k, opac_k, sc_k, rot_k, bg, want_radii=True)
+        _same(want, got, ('color', 'depth', 'final_T', 'radii'))
+    torch.cuda.synchronize()
+    assert plan.check()
+
+
+def test_extent_bound_guards(cuda):
+    rng = np.random.default_rng(11)
+    W, H = 128, 96
+    xyz, rgb, opac, sc, rot = _scene(rng, 6000, cuda, scale=(0.05, 0.3))
+    cams = _cams(cuda, W, H, [(0, 0, 0), (2.0, 0.0, 0.0)])
+    bg = torch.tensor([0.3, 0.1, 0.0], device=cuda)
+    plan = rp.RasterPlan(xyz, cams, H, W, scales=sc, rotations=rot, margin=1.0)     # bound = the example's own extent
+    big = sc.clone()
+    big[::7] *= 9.0                                                                  # far beyond the bound
+    want = dgr.rasterize_views(xyz, rgb, opac, big, rot, None, None, None, None, H, W, bg, packed_cameras=cams,
+                               want_n_contrib=False)
+    # host guard: the call is flagged
+    plan.render(rgb, opac, big, rot, bg)
+    assert plan.exceeded()
+    # device guard: the armed per-call chain renders the call; results exact, flag raised
+    got = plan.render(rgb, opac, big, rot, bg, guard='device')
+    _same(want, got, ('color', 'depth', 'final_T', 'radii'))
+    assert plan.exceeded()
+    # within the bound the armed chain retires at once and the planned result stands
+    want0 = dgr.rasterize_views(xyz, rgb, opac, sc, rot, None, None, None, None, H, W, bg, packed_cameras=cams,
+                                want_n_contrib=False)
+    got0 = plan.render(rgb, opac, sc, rot, bg, guard='device')
+    _same(want0, got0, ('color', 'depth', 'final_T', 'radii'))
+    assert not plan.exceeded()
+    # a NaN scale counts as a violation
+    bad = sc.clone()
+    bad[5, 1] = float('nan')
+    plan.render(rgb, opac, bad, rot, bg)
+    assert plan.exceeded()
+
+
+def test_item_views_and_sets(cuda):
+    """The neck's shape: S samples with their own parameters, one (device-chosen) camera each."""
+    rng = np.random.default_rng(13)
+    W, H = 112, 64
+    S, n = 3, 4000
+    xyz = _t(helpers.random_gaussians(rng, n)[0], cuda)
+    cams = _cams(cuda, W, H, [(0, 0, 0), (1.0, 0.0, 0.5), (-1.0, 0.2, 0.0), (0.0, -0.5, 2.0)])
+    par = [_scene(rng, n, cuda)[1:] for _ in range(S)]
+    rgb, opac, sc, rot = (torch.stack([p[i] for p in par]) for i in range(4))
+    bg = torch.zeros(3, device=cuda)
+    plan = rp.RasterPlan(xyz, cams, H, W, extent_bound=1.0)
+    choice = torch.tensor([2, 0, 3], dtype=torch.int32, device=cuda)
+    got = plan.render(rgb, opac, sc, rot, bg, item_view=choice, want_radii=True)
+    for s in range(S):
+        v = int(choice[s])
+        want = dgr.rasterize_views(xyz, rgb[s], opac[s], sc[s], rot[s], None, None, None, None, H, W, bg,
+                                   packed_cameras=cams[v:v + 1], want_n_contrib=False)
+        for k in ('color', 'depth', 'final_T', 'radii'):
+            assert torch.equal(want[k][0], got[k][s]), (s, k)
+    # every set through every view, and the device guard with an item_view
+    got_all = plan.render(rgb, opac, sc, rot, bg)
+    assert got_all['color'].shape[0] == S * 4
+    want = dgr.rasterize_views(xyz, rgb[1], opac[1], sc[1], rot[1], None, None, None, None, H, W, bg,
+                               packed_cameras=cams, want_n_contrib=False)
+    assert torch.equal(got_all['color'][4:8], want['color'])
+    got_g = plan.render(rgb, opac, sc * 5.0, rot, bg, item_view=choice, guard='device')
+    for s in range(S):
+        v = int(choice[s])
+        want = dgr.rasterize_views(xyz, rgb[s], opac[s], sc[s] * 5.0, rot[s], None, None, None, None, H, W, bg,
+                                   packed_cameras=cams[v:v + 1], want_n_contrib=False)
+        assert torch.equal(want['color'][0], got_g['color'][s])
+    assert plan.exceeded()
+    with pytest.raises(Exception):
+        plan.render(rgb, opac, sc, rot, bg, item_view=torch.tensor([9, 0, 0], dtype=torch.int32, device=cuda))
+        plan.check()
+
+
+def test_opacity_edge_values_and_degenerate_inputs(cuda):
+    rng = np.random.default_rng(17)
+    W, H = 96, 64
+    xyz, rgb, opac, sc, rot = _scene(rng, 3000, cuda)
+    opac[::5] = 1.0 / 255.0
+    opac[1::5] = 0.0039
+    opac[2::5] = 0.0
+    opac[3::5] = 1.0
+    opac[7] = -0.3
+    sc[11] = 0.0                              # a point: cov2D = 0.3 I
+    rot[13] = 0.0                             # zero quaternion: R = I (unnormalised formula)
+    cams = _cams(cuda, W, H, [(0, 0, 0)])
+    bg = torch.tensor([1.0, 1.0, 1.0], device=cuda)
+    want = dgr.rasterize_views(xyz, rgb, opac, sc, rot, None, None, None, None, H, W, bg, packed_cameras=cams,
+                               want_n_contrib=False)
+    plan = rp.RasterPlan(xyz, cams, H, W, extent_bound=2.0)
+    got = plan.render(rgb, opac, sc, rot, bg, want_radii=True)
+    _same(want, got, ('color', 'depth', 'final_T', 'radii'))
+    assert plan.check()
+
+
+def test_full_size_ocrf_grid_both_conventions(cuda):
+    """cfg2's own scene: the 13 x 200 x 200 voxel-grid Gaussians through the six cameras at 256 x 704."""
+    from ocrfdet_amd import hotpath
+    cfg = synthetic.CONFIGS['cfg2_6cam_2frame_bev200x200_render_hoa']
+    hp = hotpath.HotPath(cfg, cuda)
+    for conv in ('corrected', 'reference'):
+        r = synthetic.rig(cfg.n_cams, cfg.input_size, hp.batch)
+        hp._prepare_render(r, convention=conv)
+        g, rc = hp.gauss, hp.render_cams
+        H, W = cfg.input_size
+        xyz = hp.voxel_xyz[0].reshape(-1, 3)
+        want = dgr.rasterize_views(xyz, g['rgb'], g['opacity'], g['scales'], g['rotations'], None, None, None, None,
+                                   H, W, hp.bg, packed_cameras=rc['packed'], want_n_contrib=False)
+        plan = rp.RasterPlan(xyz, rc['packed'], H, W, scales=g['scales'], rotations=g['rotations'])
+        got = plan.render(g['rgb'], g['opacity'], g['scales'], g['rotations'], hp.bg, want_radii=True)
+        torch.cuda.synchronize()
+        assert plan.check()
+        _same(want, got, ('color', 'depth', 'final_T', 'radii'))
+        assert plan.total_kept < 0.5 * xyz.shape[0] * 6
