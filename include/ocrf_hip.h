@@ -643,6 +643,20 @@ const char *ocrf_kernel_name(int kernel_id);           /* symbol as rocprofv3 pr
  * into *slot (device) when the stream reaches it — timelines inside a hipGraph replay, where host
  * events cannot be placed and the profiler's per-kernel signals perturb the overlap. */
 int ocrf_diag_stamp(unsigned long long *slot, void *stream);
+/* Diagnostic: n_blocks one-wave workgroups that each record where they ran: out[b] = XCC_ID << 16 | HW_ID[15:0]
+ * (CU_ID bits 11:8, SH_ID 12, SE_ID 15:13) after idling for spin_ticks of the 100 MHz clock — the compute units a
+ * CU-masked stream really owns. */
+/* Diagnostic: with a device buffer of (tile pairs x items x 4 waves x 8) u64 set, the next ocrf_rasterize_planned
+ * calls run an instrumented build of the sorted blend: per wave scan / stage / blend cycles (s_memtime) and the
+ * number of scanned, staged, listed and evaluated records.  NULL switches it off. */
+int ocrf_diag_plan_stats(unsigned long long *buf);
+int ocrf_diag_plan_resident(void); /* workgroups the persistent sorted blend launches (occupancy API x CUs) */
+int ocrf_diag_where(int n_blocks, unsigned *out, int spin_ticks, void *stream);
+/* HIP streams for the hot path's chains (host pointers): cu_mask (n_words x 32 bits, NULL = every CU) restricts the
+ * stream's kernels to those compute units (hipExtStreamCreateWithCUMask); without a mask `priority` is the HIP stream
+ * priority (lower = more urgent).  The stream is non-blocking w.r.t. the legacy default stream. */
+int ocrf_stream_create(const uint32_t *cu_mask, int n_words, int priority, void **stream_out);
+int ocrf_stream_destroy(void *stream);
 int ocrf_timer_create(int capacity, void **timer_out); /* host pointers */
 int ocrf_timer_arm(void *timer, int kernel_id);
 int ocrf_timer_read(void *timer, float *ms_out /* host */, int capacity, int *count_out /* host */);

@@ -194,8 +194,18 @@ def _declare(L):
     L.ocrf_hoa_dw3x3_wgrad.argtypes = [c_void_p] * 2 + [c_int] * 4 + [c_void_p] * 2
     L.ocrf_diag_stamp.restype = c_int
     L.ocrf_diag_stamp.argtypes = [c_void_p, c_void_p]
+    L.ocrf_diag_plan_stats.restype = c_int
+    L.ocrf_diag_plan_stats.argtypes = [c_void_p]
+    L.ocrf_diag_plan_resident.restype = c_int
+    L.ocrf_diag_plan_resident.argtypes = []
+    L.ocrf_diag_where.restype = c_int
+    L.ocrf_diag_where.argtypes = [c_int, c_void_p, c_int, c_void_p]
     L.ocrf_kernel_name.restype = ctypes.c_char_p
     L.ocrf_kernel_name.argtypes = [c_int]
+    L.ocrf_stream_create.restype = c_int
+    L.ocrf_stream_create.argtypes = [c_void_p, c_int, c_int, ctypes.POINTER(c_void_p)]
+    L.ocrf_stream_destroy.restype = c_int
+    L.ocrf_stream_destroy.argtypes = [c_void_p]
     L.ocrf_timer_create.restype = c_int
     L.ocrf_timer_create.argtypes = [c_int, ctypes.POINTER(c_void_p)]
     L.ocrf_timer_arm.restype = c_int
@@ -244,6 +254,26 @@ def require_cuda(*tensors):
 
 def ptr(t):
     return ctypes.c_void_p(t.data_ptr() if t is not None and t.numel() > 0 else 0)
+
+
+def masked_stream(device, cu_bits=None, priority=0):
+    """A torch stream object over a HIP stream limited to the compute units whose bits are set in ``cu_bits`` (an
+    iterable of CU indices; None: every CU, with HIP ``priority``).  The HIP stream lives for the process."""
+    h = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        if cu_bits is None:
+            check(lib().ocrf_stream_create(None, 0, int(priority), ctypes.byref(h)), 'ocrf_stream_create')
+        else:
+            bits = sorted(set(int(b) for b in cu_bits))
+            n_words = (max(bits) // 32) + 1
+            words = (ctypes.c_uint32 * n_words)()
+            for b in bits:
+                words[b // 32] |= 1 << (b % 32)
+            check(lib().ocrf_stream_create(ctypes.cast(words, c_void_p_t), n_words, 0, ctypes.byref(h)), 'ocrf_stream_create')
+    return torch.cuda.ExternalStream(h.value, device=device)
+
+
+c_void_p_t = ctypes.c_void_p
 
 
 def diag_stamp(stamps, index):

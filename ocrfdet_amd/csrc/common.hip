@@ -30,6 +30,17 @@ __global__ void zero_words_kernel(unsigned* __restrict__ dst, size_t n_words) {
 
 __global__ void diag_stamp_kernel(unsigned long long* __restrict__ slot) { *slot = wall_clock64(); }
 
+// where does a workgroup run?  out[b] = XCC_ID << 16 | HW_ID[15:0] (gfx9: CU_ID 11:8, SH_ID 12, SE_ID 15:13); each
+// workgroup spins a little so that the launch spreads over every CU its stream may use
+__global__ void diag_where_kernel(unsigned* __restrict__ out, int spin) {
+  unsigned xcc, hw;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < (unsigned long long)spin) __builtin_amdgcn_s_sleep(8);
+  if (threadIdx.x == 0) out[blockIdx.x] = ((xcc & 0xFu) << 16) | (hw & 0xFFFFu);
+}
+
 }  // namespace
 
 namespace ocrf {
@@ -63,6 +74,12 @@ const char* ocrf_version(void) { return "ocrf_hip 0.1 gfx950"; }
 
 int ocrf_diag_stamp(unsigned long long* slot, void* stream) {
   hipLaunchKernelGGL(diag_stamp_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), slot);
+  return (int)hipGetLastError();
+}
+
+int ocrf_diag_where(int n_blocks, unsigned* out, int spin_ticks, void* stream) {
+  if (n_blocks <= 0 || !out) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(diag_where_kernel, dim3(n_blocks), dim3(64), 0, static_cast<hipStream_t>(stream), out, spin_ticks);
   return (int)hipGetLastError();
 }
 
@@ -161,6 +178,27 @@ int ocrf_timer_read(void* timer, float* ms_out, int capacity, int* count_out) {
   }
   *count_out = n;
   return 0;
+}
+
+// A HIP stream restricted to a set of compute units (hipExtStreamCreateWithCUMask) and / or with a priority:
+// the hot path's two chains (VALU-bound renders, latency-bound pools + HOA) each get their own part of the chip
+// instead of interleaving workgroup by workgroup.  cu_mask may be null (all CUs).
+int ocrf_stream_create(const uint32_t* cu_mask, int n_words, int priority, void** stream_out) {
+  if (!stream_out || n_words < 0) return (int)hipErrorInvalidValue;
+  hipStream_t s = nullptr;
+  hipError_t e;
+  if (cu_mask && n_words > 0) {
+    e = hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, cu_mask);
+  } else {
+    e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority);
+  }
+  if (e != hipSuccess) return (int)e;
+  *stream_out = s;
+  return 0;
+}
+
+int ocrf_stream_destroy(void* stream) {
+  return stream ? (int)hipStreamDestroy(static_cast<hipStream_t>(stream)) : 0;
 }
 
 int ocrf_timer_destroy(void* timer) {

@@ -25,6 +25,8 @@
 // and final_T are bit-identical to the per-call pipeline (tests/test_raster_plan_gpu.py).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "launch.h"
 #include "ocrf_hip.h"
 #include "raster_common.h"
@@ -35,15 +37,25 @@ using namespace rc;
 
 constexpr unsigned kPlanMagic = 0x4F435250u;      // "OCRP"
 constexpr int kHeaderInts = 16;                   // magic, P, V, H, W, gx, gy, bound bits, total lo, total hi, ...
-constexpr int kStageP = 256;                      // records staged per batch
-constexpr int kScanUnrollP = 4;                   // rect batches in flight in the scan
+#ifndef OCRF_PLAN_STAGE
+#define OCRF_PLAN_STAGE 128
+#endif
+#ifndef OCRF_PLAN_SCAN
+#define OCRF_PLAN_SCAN 2
+#endif
+constexpr int kStageP = OCRF_PLAN_STAGE;          // records staged per batch (a tile pair saturates after ~110 at cfg2)
+constexpr int kScanUnrollP = OCRF_PLAN_SCAN;      // rect batches in flight in the scan
+constexpr int kStageParts = kBlock / kStageP;     // threads per staged record: each tests 4 / kStageParts waves
+constexpr int kReachPerThread = 4 / kStageParts;
+constexpr int kSrcWaves = kStageP / 64;           // waves that hold one copy of the staged batch
+static_assert(kStageP == 128 || kStageP == 256, "one or two threads per staged record");
 constexpr int kCapPos = kStageP + kScanUnrollP * kBlock;
 constexpr unsigned kPosMask = 0x3FFFFFFFu;
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct PlanLayout {
-  size_t header, cams, g_mask, g_off, e_pos, e_q0, e_q1, s_id, s_key, s_pix, bytes;
+  size_t header, cams, g_mask, g_off, e_pos, e_q0, e_q1, s_id, s_key, s_pix, s_e, bytes;
 };
 
 inline void plan_layout(int P, int V, long T, PlanLayout* L) {
@@ -58,7 +70,8 @@ inline void plan_layout(int P, int V, long T, PlanLayout* L) {
   L->e_q1 = take((size_t)T * 16);           //   (A11, A12, pixel x, pixel y)
   L->s_id = take((size_t)T * 4);            // per record, sorted (view-major, depth bits then id): Gaussian id,
   L->s_key = take((size_t)T * 4);           //   depth bits,
-  L->s_pix = take((size_t)T * 8);           //   pixel centre
+  L->s_pix = take((size_t)T * 8);           //   pixel centre,
+  L->s_e = take((size_t)T * 4);             //   the record's index in Gaussian-major order
   L->bytes = off;
 }
 
@@ -188,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void plan_fill_records_kernel(int P, int W,
                                                                    const unsigned* __restrict__ g_mask,
                                                                    const int* __restrict__ g_off,
                                                                    unsigned* __restrict__ e_pos, float4* __restrict__ e_q0,
-                                                                   float4* __restrict__ e_q1) {
+                                                                   float4* __restrict__ e_q1, unsigned* __restrict__ s_e) {
   if (header[0] != (int)kPlanMagic) return;
   const int id = blockIdx.x * kBlock + threadIdx.x;
   if (id >= P) return;
@@ -204,7 +217,9 @@ __global__ __launch_bounds__(kBlock) void plan_fill_records_kernel(int P, int W,
     static_point(cam, px, py, pz, &sp);
     float A[2][3];
     jacobian_rows(cam, sp.j00, sp.j02, sp.j11, sp.j12, A);
-    e_pos[e] = (unsigned)(view_off[v] + inv[(long)v * P + id]);
+    const unsigned pos = (unsigned)(view_off[v] + inv[(long)v * P + id]);
+    e_pos[e] = pos;
+    s_e[pos] = (unsigned)e;
     e_q0[e] = make_float4(A[0][0], A[0][1], A[0][2], A[1][0]);
     e_q1[e] = make_float4(A[1][1], A[1][2], ndc2pix(sp.projx, W), ndc2pix(sp.projy, H));
     ++e;
@@ -216,8 +231,11 @@ __global__ __launch_bounds__(kBlock) void plan_fill_records_kernel(int P, int W,
 // the parameters are read once (coalesced), the 3D covariance is built once, then every rendered view that keeps
 // the Gaussian gets its conic / radius / tile rect, dropped at the record's place in that view's sorted list.  The
 // same pass checks the Gaussian's extent against the plan's bound.
-//   d_rect[set][pos]  tile rect ((0,0,0,0): not rendered this step)
-//   d_con[set][pos]   (-0.5 conic.x, -0.5 conic.z, conic.y, opacity)
+//   d_rect[set][pos]  tile rect ((0,0,0,0): not rendered this step), at the record's place in the sorted list: the
+//                     blend scans it; the only scattered write (random 8-byte stores cost a memory-side read-modify-
+//                     write each: with the conic scattered too the pass took 27 us instead of 23 at cfg2)
+//   d_con[set][e]     (-0.5 conic.x, -0.5 conic.z, conic.y, opacity) in Gaussian-major order (coalesced); the blend
+//                     reaches it through the plan's static pos -> e map when it stages a record
 // grid (ceil(P / 256), n_sets).  The items of one set name distinct plan views.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void raster_plan_update_kernel(
@@ -226,8 +244,9 @@ __global__ __launch_bounds__(kBlock) void raster_plan_update_kernel(
     const float4* __restrict__ e_q1, const int* __restrict__ view_sel, const float* __restrict__ opacities,
     const float* __restrict__ scales, float scale_modifier, const float* __restrict__ rotations,
     Rect* __restrict__ d_rect, float4* __restrict__ d_con, int* __restrict__ radii, int* __restrict__ status,
-    int* __restrict__ flag) {
+    int* __restrict__ flag, int* __restrict__ queue) {
   __shared__ int l_v2i[32];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *queue = 0;      // ticket counter of the blend that follows
   if (header[0] != (int)kPlanMagic) {
     if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) atomicOr(status, 8);
     return;
@@ -279,7 +298,7 @@ __global__ __launch_bounds__(kBlock) void raster_plan_update_kernel(
       float cov_x, cov_y, cov_z, con_x, con_y, con_z;
       cov2d(A, c3, &cov_x, &cov_y, &cov_z);
       if (conic_radius_rect(cov_x, cov_y, cov_z, q1.z, q1.w, gx, gy, &con_x, &con_y, &con_z, &rad, &rect)) {
-        d_con[dyn + pos] = make_float4(-0.5f * con_x, -0.5f * con_z, con_y, o);
+        d_con[dyn + cur] = make_float4(-0.5f * con_x, -0.5f * con_z, con_y, o);      // Gaussian-major: coalesced
       } else {
         rect = Rect{0, 0, 0, 0};
         rad = 0;
@@ -297,32 +316,54 @@ __global__ __launch_bounds__(kBlock) void raster_plan_update_kernel(
 // (lx, 8w + r + 4): same x, so dx and the dx-only part of the exponent are shared and the two pixels run as the
 // halves of packed fp32 ops.
 // ---------------------------------------------------------------------------------------------
-template <bool MEDIAN, bool WSKIP>
+template <bool MEDIAN, bool WSKIP, bool STATS = false>
 __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
-    int P, int W, int H, int gy, int vps, long n_total, const int* __restrict__ header, const int* __restrict__ view_sel,
-    const unsigned* __restrict__ s_id, const unsigned* __restrict__ s_key, const float2* __restrict__ s_pix,
+    unsigned long long* __restrict__ stats, int P, int W, int H, int gx, int gy, int n_items, int vps, long n_total,
+    const int* __restrict__ header, const int* __restrict__ view_sel, const unsigned* __restrict__ s_id,
+    const unsigned* __restrict__ s_key, const float2* __restrict__ s_pix, const unsigned* __restrict__ s_e,
     const Rect* __restrict__ d_rect, const float4* __restrict__ d_con, const float* __restrict__ colors,
-    const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
-    float* __restrict__ out_final_T, const int* __restrict__ skip_if) {
+    const float* __restrict__ bg,
+    float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_final_T,
+    const int* __restrict__ skip_if, int* __restrict__ queue) {
   if (skip_if && *skip_if != 0) return;      // the plan's bound does not hold this step: the armed per-call chain renders
   __shared__ unsigned l_pos[kCapPos];
   __shared__ float4 l_a[kStageP + 1], l_b[kStageP + 1], l_c[kStageP + 1];
   __shared__ unsigned short l_list[4][kStageP + 8];
   __shared__ int l_wtot[kScanUnrollP * 4];
-  __shared__ int l_lcnt[4][4];                // [source wave][destination wave]
+  __shared__ int l_lcnt[kSrcWaves][4];        // [source wave of the batch copy][destination wave]
+  __shared__ int l_work;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int tx = blockIdx.x, z = blockIdx.z;
+  if (header[0] != (int)kPlanMagic) return;                           // reported by the update kernel (status bit 8)
   const int V = header[2];
-  const int v = view_sel ? view_sel[z] : z;
-  if (header[0] != (int)kPlanMagic || v < 0 || v >= V) return;      // reported by the update kernel (status bit 8)
-  const int set = z / vps;
-  const int tyA = 2 * blockIdx.y, tyB = tyA + 1;
   const int* view_off = header + kHeaderInts;
+  const int lx = lane & 15, r = lane >> 4;
+  const int gyp = (gy + 1) / 2;
+  const int n_work = gx * gyp * n_items;
+  if (tid == 0) {      // slot kStageP: a record that changes nothing (opacity 0), pads odd list lengths
+    l_a[kStageP] = make_float4(0.f, 0.f, 0.f, 0.f);
+    l_b[kStageP] = make_float4(0.f, 0.f, 0.f, 0.f);
+    l_c[kStageP] = make_float4(0.f, 0.f, 0.f, INFINITY);
+  }
+  // Persistent workgroups over a ticket queue: the grid is what the chip holds at once, every workgroup takes the next
+  // tile pair until none is left (2 112 pairs on 1 792 resident workgroups would otherwise run as a full round plus
+  // a nearly empty one).  Every wave reaches the exit: the ticket counter only grows.
+  for (;;) {
+  __syncthreads();                                                    // the previous pair's LDS traffic is over
+  if (tid == 0) l_work = atomicAdd(queue, 1);
+  __syncthreads();
+  const int work = l_work;
+  if (work >= n_work) break;
+  const int z = work / (gx * gyp);
+  const int tx = (work - z * gx * gyp) % gx, ty2 = (work - z * gx * gyp) / gx;
+  const int v = view_sel ? view_sel[z] : z;
+  if (v < 0 || v >= V) continue;                                      // reported by the update kernel (status bit 8)
+  const int set = z / vps;
+  const int tyA = 2 * ty2, tyB = tyA + 1;
   const int off = view_off[v], nv = view_off[v + 1] - off;
   const long dyn = (long)set * n_total + off;
+  const float4* set_con = d_con + (long)set * n_total;
   const float* set_colors = colors + 3 * (long)set * P;
-  const int lx = lane & 15, r = lane >> 4;
   const int pxi = tx * kTileX + lx;
   const int py0 = tyA * kTileY + 8 * wave + r, py1 = py0 + 4;
   const bool tile_ok = (tyA + (wave >> 1)) < gy;
@@ -332,12 +373,6 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
   // the wave's pixel block as float bounds (pixel centres are the integer coordinates, forward.cu:283)
   const float bx0 = (float)(tx * kTileX), bx1 = bx0 + 15.f;
 
-  if (tid == 0) {      // slot kStageP: a record that changes nothing (opacity 0), pads odd list lengths
-    l_a[kStageP] = make_float4(0.f, 0.f, 0.f, 0.f);
-    l_b[kStageP] = make_float4(0.f, 0.f, 0.f, 0.f);
-    l_c[kStageP] = make_float4(0.f, 0.f, 0.f, INFINITY);
-  }
-
   // T < 0 <=> the pixel has stopped (or lies outside the image); |T| is its final transmittance
   f2 T = f2{inside0 ? 1.0f : -1.0f, inside1 ? 1.0f : -1.0f};
   f2 C0 = splat(0.f), C1 = splat(0.f), C2 = splat(0.f);
@@ -345,10 +380,21 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
 
   int scan = 0, npos = 0;
   bool all_done = false;
+  // diagnostic build only: phase cycles and record counts of this workgroup
+  unsigned long long t_prev = 0, t_acc[3] = {0, 0, 0};
+  unsigned n_staged = 0, n_listed = 0, n_eval = 0;
+  auto stamp = [&](int slot) {
+    if constexpr (STATS) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      if (slot >= 0) t_acc[slot] += t - t_prev;
+      t_prev = t;
+    }
+  };
+  stamp(-1);
   while (!all_done) {
     // ---- scan: positions of the records whose rect covers this tile pair, in list (= blend) order ----
     while (scan < nv && npos < kStageP) {
-      const int n_u = (scan < 2 * kBlock) ? 1 : kScanUnrollP;
+      const int n_u = (scan < kBlock) ? 1 : kScanUnrollP;      // a dense tile pair fills its first batch from 256 rects
       unsigned code[kScanUnrollP];
       bool hit[kScanUnrollP];
 #pragma unroll
@@ -387,37 +433,42 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
       scan += n_u * kBlock;
       __syncthreads();
     }
+    stamp(0);
     if (npos == 0) break;                     // list exhausted
     for (int s0 = 0; s0 < npos && !all_done; s0 += kStageP) {
       const int ns = min(kStageP, npos - s0);
-      // ---- stage ns records; which waves can each one reach? ----
-      bool reach[4] = {false, false, false, false};
-      if (tid < ns) {
+      if constexpr (STATS) n_staged += ns;
+      // ---- stage ns records; which waves can each one reach?  kStageParts threads per record, each testing
+      // kReachPerThread of the four waves (the copies of the batch live in waves [part * kSrcWaves, ...)) ----
+      const int part = tid / kStageP, ri = tid % kStageP;
+      bool reach[kReachPerThread];
+#pragma unroll
+      for (int j = 0; j < kReachPerThread; ++j) reach[j] = false;
+      if (ri < ns) {
         // staged record (slots chosen so that operands broadcast into packed ops sit in slots 0-2):
         //   a = (x, y, -0.5 conic.z, -0.5 conic.x)   b = (opacity, r, g, conic.y)   c = (b, depth, 0, thr)
-        const unsigned code = l_pos[s0 + tid];
+        const unsigned code = l_pos[s0 + ri];
         const int li = (int)(code & kPosMask);
-        const float4 con = d_con[dyn + li];
+        const float4 con = set_con[s_e[off + li]];
         const float2 pix = s_pix[off + li];
-        const float* col = set_colors + 3 * (long)s_id[off + li];
         const float o = con.w;
         // the power below which alpha = o exp(power) is under 1/255 whatever the pixel (1 % margin for v_exp_f32
         // and the log2(e) multiply); o <= 0: +inf (never rendered); NaN opacity: NaN (evaluated in full)
-        const float thr_ = (o > 0.f) ? (__logf(1.0f / (255.0f * o)) - 0.01f) : ((o <= 0.f) ? INFINITY : o);
+        const float thr = (o > 0.f) ? (__logf(1.0f / (255.0f * o)) - 0.01f) : ((o <= 0.f) ? INFINITY : o);
         const float4 a = make_float4(pix.x, pix.y, con.y, con.x);
-        const float4 b = make_float4(o, col[0], col[1], con.z);
-        const float4 c = make_float4(col[2], __uint_as_float(s_key[off + li]), 0.f, thr_);
-        l_a[tid] = a;
-        l_b[tid] = b;
-        l_c[tid] = c;
+        if (part == 0) {
+          const float* col = set_colors + 3 * (long)s_id[off + li];
+          l_a[ri] = a;
+          l_b[ri] = make_float4(o, col[0], col[1], con.z);
+          l_c[ri] = make_float4(col[2], __uint_as_float(s_key[off + li]), 0.f, thr);
+        }
         // alpha >= 1/255 needs power >= thr, i.e. Q(dx, dy) = 0.5 (A dx^2 + C dy^2) + B dx dy <= -thr.  The minimum of
         // the convex Q over a wave's pixel block (a box in (dx, dy)) is 0 if the centre lies inside, else it is on
         // the box's boundary: per edge a clamped 1-D minimiser.  The block is skipped only if that minimum exceeds
         // -thr by more than the rounding of both evaluations (<= 1e-6 of the sum of the terms' magnitudes; 4e-6
         // is allowed for) — so a skipped record has alpha < 1/255 at every pixel of the block, where the reference
         // skips it too (forward.cu:331-333).  Anything unusual (NaN, non-convex conic) is evaluated in full.
-        const float thr = c.w;
-        const float qa = -2.f * a.w, qc = -2.f * a.z, qb = b.w;
+        const float qa = -2.f * a.w, qc = -2.f * a.z, qb = con.z;
         const bool convex = (qa > 0.f) && (qc > 0.f) && (qa * qc - qb * qb > 0.f);
         const bool never = thr >= 0.f;                         // opacity < 1/255: no pixel ever blends it
         const float lim = -thr;
@@ -425,7 +476,8 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
         const float dxlo = a.x - bx1, dxhi = a.x - bx0;
         const float Dx = fmaxf(fabsf(dxlo), fabsf(dxhi));
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int j = 0; j < kReachPerThread; ++j) {
+          const int w = part * kReachPerThread + j;
           const bool cov = (w < 2) ? ((code & 0x40000000u) != 0u) : ((code & 0x80000000u) != 0u);
           const float by0 = (float)(tyA * kTileY + 8 * w), by1 = by0 + 7.f;
           const float dylo = a.y - by1, dyhi = a.y - by0;
@@ -445,37 +497,42 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
               skip = (qmin - 4e-6f * M - 1e-3f) > lim;
             }
           }
-          reach[w] = cov && !never && !skip;
+          reach[j] = cov && !never && !skip;
         }
       }
-      // ordered per-wave lists of staged indices
-      int lrank[4];
+      // ordered per-wave lists of staged indices: the kSrcWaves waves of a part hold the batch in order
+      const int src = wave % kSrcWaves;
+      int lrank[kReachPerThread];
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const unsigned long long m = __ballot(reach[w]);
-        lrank[w] = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) l_lcnt[wave][w] = __popcll(m);
+      for (int j = 0; j < kReachPerThread; ++j) {
+        const unsigned long long m = __ballot(reach[j]);
+        lrank[j] = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) l_lcnt[src][part * kReachPerThread + j] = __popcll(m);
       }
       __syncthreads();
-      int n_mine = 0;                          // length of THIS wave's list
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
+      for (int j = 0; j < kReachPerThread; ++j) {
+        const int w = part * kReachPerThread + j;
         int base = 0, tot = 0;
 #pragma unroll
-        for (int sw = 0; sw < 4; ++sw) {
+        for (int sw = 0; sw < kSrcWaves; ++sw) {
           const int c = l_lcnt[sw][w];
-          if (sw < wave) base += c;
+          if (sw < src) base += c;
           tot += c;
         }
-        if (reach[w]) l_list[w][base + lrank[w]] = (unsigned short)tid;
-        if (w == wave) n_mine = tot;
-        if (tid < 4 && tid == w) {             // pad: the loop reads two entries per trip
+        if (reach[j]) l_list[w][base + lrank[j]] = (unsigned short)ri;
+        if (ri == 0) {                         // pad: the loop reads two entries per trip
           l_list[w][tot] = (unsigned short)kStageP;
           l_list[w][tot + 1] = (unsigned short)kStageP;
         }
       }
+      int n_mine = 0;                          // length of THIS wave's list
+#pragma unroll
+      for (int sw = 0; sw < kSrcWaves; ++sw) n_mine += l_lcnt[sw][wave];
       __syncthreads();
       n_mine = __builtin_amdgcn_readfirstlane(n_mine);
+      if constexpr (STATS) n_listed += n_mine;
+      stamp(1);
 
       // ---- blend this wave's records front to back.  Every decision of forward.cu:320-352 is ONE compare feeding
       // ONE select (see raster_blend_kernel in rasterize.hip for the derivation); same arithmetic, same order.
@@ -484,6 +541,7 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
         f2 h = T - splat(0.5f);
         for (int k = 0; k < n_mine; k += 2) {
           if (__ballot((__float_as_int(T.x) & __float_as_int(T.y)) >= 0) == 0ull) break;      // every pixel stopped
+          if constexpr (STATS) n_eval += 2;
           const unsigned pair = *reinterpret_cast<const unsigned*>(mylist + k);
           const int i0 = (int)(pair & 0xFFFFu), i1 = (int)(pair >> 16);
           float4 ra[2], rb[2], rc4[2];
@@ -539,9 +597,19 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
       }
       // every pixel saturated -> stop (forward.cu:304-307)
       all_done = __syncthreads_count((T.x < 0.f) && (T.y < 0.f)) == kBlock;
+      stamp(2);
     }
     npos = 0;
     if (scan >= nv) break;
+  }
+  if constexpr (STATS) {
+    // per wave: slot = workgroup * 4 + wave: scan, stage, blend cycles | scanned, staged, listed, evaluated records
+    if (lane == 0) {
+      const long w = (long)work * 4 + wave;
+      stats[w * 8 + 0] = t_acc[0]; stats[w * 8 + 1] = t_acc[1]; stats[w * 8 + 2] = t_acc[2];
+      stats[w * 8 + 3] = (unsigned long long)scan; stats[w * 8 + 4] = n_staged;
+      stats[w * 8 + 5] = n_listed; stats[w * 8 + 6] = n_eval; stats[w * 8 + 7] = 0;
+    }
   }
 
   const long npix = (long)W * H;
@@ -556,19 +624,45 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
   };
   store(inside0, py0, fabsf(T.x), C0.x, C1.x, C2.x, D.x);
   store(inside1, py1, fabsf(T.y), C0.y, C1.y, C2.y, D.y);
+  }   // ticket loop
 }
 
-int g_plan_wskip = 0;       // ocrf_tune_set(OCRF_TUNE_PLAN_WSKIP): the pixel-exact wave skip inside the loop
+// workgroups of `kernel` (256 threads, static LDS only) the device holds at once: the size of a persistent grid
+template <typename K>
+int resident_blocks(K kernel) {
+  static int cached[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // per device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 8) dev = 0;
+  if (cached[dev] == 0) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    cached[dev] = per_cu * cus;
+  }
+  return cached[dev];
+}
+
+int g_plan_wskip = 0;
+int g_plan_grid = 0;        // ocrf_tune_set(11, n): workgroups of the persistent blend (0 = what the device holds at once)
+unsigned long long* g_plan_stats = nullptr;      // ocrf_diag_plan_stats: the next planned blends run the STATS build       // ocrf_tune_set(OCRF_TUNE_PLAN_WSKIP): the pixel-exact wave skip inside the loop
 
 }  // namespace
 
 namespace ocrf {
 void raster_plan_tune(int key, int value) {
   if (key == 10) g_plan_wskip = value != 0;
+  if (key == 11) g_plan_grid = value > 0 ? value : 0;
 }
 }
 
 extern "C" {
+
+// Diagnostic: the size of the persistent blend's grid (median depth, no wave skip) as the occupancy API reports it
+int ocrf_diag_plan_resident(void) { return resident_blocks(raster_blend_sorted_kernel<true, false>); }
+
+// Diagnostic: when set (device buffer of tile pairs * items * 4 waves * 8 u64), the next planned renders run the
+// instrumented build of the sorted blend.  Never used by the product path.
+int ocrf_diag_plan_stats(unsigned long long* buf) { g_plan_stats = buf; return 0; }
 
 size_t ocrf_raster_plan_build_workspace_bytes(int P, int n_views) {
   if (P <= 0 || n_views <= 0 || n_views > 32) return 0;
@@ -658,7 +752,7 @@ int ocrf_raster_plan_fill(int P, int n_views, int H, int W, const float* means3D
                      static_cast<const int*>(header), static_cast<const int*>(inv),
                      static_cast<const unsigned*>(g_mask), static_cast<const int*>(g_off),
                      reinterpret_cast<unsigned*>(pb + L.e_pos), reinterpret_cast<float4*>(pb + L.e_q0),
-                     reinterpret_cast<float4*>(pb + L.e_q1));
+                     reinterpret_cast<float4*>(pb + L.e_q1), reinterpret_cast<unsigned*>(pb + L.s_e));
   return (int)hipGetLastError();
 }
 
@@ -696,6 +790,7 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
   const Camera* cams = reinterpret_cast<const Camera*>(pb + L.cams);
   auto* d_rect = reinterpret_cast<Rect*>(wb + D.rect);
   auto* d_con = reinterpret_cast<float4*>(wb + D.con);
+  int* queue = reinterpret_cast<int*>(wb + D.flag) + 16;
   int* flag = nullptr;
   if (guard) {
     if (!means3D || !radii || !chain_workspace ||
@@ -713,16 +808,31 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
                dim3(kBlock), 0, stream, P, vps, total_kept, header, reinterpret_cast<const unsigned*>(pb + L.g_mask),
                reinterpret_cast<const int*>(pb + L.g_off), reinterpret_cast<const unsigned*>(pb + L.e_pos),
                reinterpret_cast<const float4*>(pb + L.e_q0), reinterpret_cast<const float4*>(pb + L.e_q1), item_view,
-               opacities, scales, scale_modifier, rotations, d_rect, d_con, radii, status, flag);
+               opacities, scales, scale_modifier, rotations, d_rect, d_con, radii, status, flag, queue);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  const dim3 bgrid(gx, (gy + 1) / 2, n_items);
-#define OCRF_BLEND_SORTED(MED, WS)                                                                                  \
-  ocrf::launch(OCRF_K_RASTER_BLEND_SORTED, raster_blend_sorted_kernel<MED, WS>, bgrid, dim3(kBlock), 0, stream, P, W, \
-               H, gy, vps, total_kept, header, item_view, reinterpret_cast<const unsigned*>(pb + L.s_id),             \
-               reinterpret_cast<const unsigned*>(pb + L.s_key), reinterpret_cast<const float2*>(pb + L.s_pix),        \
-               static_cast<const Rect*>(d_rect), static_cast<const float4*>(d_con), colors, bg, out_color, out_depth, \
-               out_final_T, static_cast<const int*>(flag))
+  const int n_work = gx * ((gy + 1) / 2) * n_items;
+  if (g_plan_stats) {      // diagnostic build (median depth), never used by the product path
+    const dim3 sgrid((unsigned)std::min(n_work, resident_blocks(raster_blend_sorted_kernel<true, false, true>)));
+    hipLaunchKernelGGL((raster_blend_sorted_kernel<true, false, true>), sgrid, dim3(kBlock), 0, stream, g_plan_stats, P, W, H,
+                       gx, gy, n_items, vps, total_kept, header, item_view, reinterpret_cast<const unsigned*>(pb + L.s_id),
+                       reinterpret_cast<const unsigned*>(pb + L.s_key), reinterpret_cast<const float2*>(pb + L.s_pix),
+                       reinterpret_cast<const unsigned*>(pb + L.s_e), static_cast<const Rect*>(d_rect),
+                       static_cast<const float4*>(d_con), colors, bg, out_color, out_depth, out_final_T,
+                       static_cast<const int*>(flag), queue);
+    return (int)hipGetLastError();
+  }
+#define OCRF_BLEND_SORTED(MED, WS)                                                                                   \
+  ocrf::launch(OCRF_K_RASTER_BLEND_SORTED, raster_blend_sorted_kernel<MED, WS>,                                       \
+               dim3((unsigned)std::min(n_work, g_plan_grid ? g_plan_grid                                               \
+                                                            : resident_blocks(raster_blend_sorted_kernel<MED, WS>))),   \
+               dim3(kBlock), 0,                                                                                        \
+               stream, (unsigned long long*)nullptr, P, W, H, gx, gy, n_items, vps, total_kept, header, item_view,     \
+               reinterpret_cast<const unsigned*>(pb + L.s_id), reinterpret_cast<const unsigned*>(pb + L.s_key),        \
+               reinterpret_cast<const float2*>(pb + L.s_pix), reinterpret_cast<const unsigned*>(pb + L.s_e),           \
+               static_cast<const Rect*>(d_rect),                                                                       \
+               static_cast<const float4*>(d_con), colors, bg, out_color, out_depth, out_final_T,                       \
+               static_cast<const int*>(flag), queue)
   if (depth_mode == 0 && g_plan_wskip) OCRF_BLEND_SORTED(true, true);
   else if (depth_mode == 0) OCRF_BLEND_SORTED(true, false);
   else if (g_plan_wskip) OCRF_BLEND_SORTED(false, true);

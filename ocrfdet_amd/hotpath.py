@@ -56,7 +56,7 @@ def shared_stream(device, role):
 
 class HotPath:
     def __init__(self, cfg, device, cams=None, index_prep_mode='cached', overlap=True, device_geometry=False,
-                 render_mode='planned', render_guard='host', frame_motion=True, frame_offset=0, plan_margin=1.5):
+                 render_mode='planned', render_guard='host', frame_motion=True, frame_offset=0, plan_margin=1.25):
         """``cams``: optional list of camera indices this instance owns (camera sharding).
         ``index_prep_mode``: 'cached' — rank vectors computed once per calibration, the reference's
         ``accelerate=True`` intent; 'per_step' — recomputed inside every ``step()`` by the HIP index

@@ -1,0 +1,42 @@
+"""Diagnostic: what the sorted blend's workgroups do at cfg2 (frame 0, 6 views): per-wave phase cycles and record
+counts from the instrumented build (ocrf_diag_plan_stats).   python tools/diag_plan_blend.py"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ocrfdet_amd import _lib, hotpath, synthetic  # noqa: E402
+
+dev = torch.device('cuda:0')
+cfg = synthetic.CONFIGS['cfg2_6cam_2frame_bev200x200_render_hoa']
+hp = hotpath.HotPath(cfg, dev)
+H, W = cfg.input_size
+gx, gy = (W + 15) // 16, (H + 15) // 16
+n_wg = gx * ((gy + 1) // 2) * len(hp.cams)
+buf = torch.zeros(n_wg * 4 * 8, dtype=torch.int64, device=dev)
+hp.render()
+torch.cuda.synchronize()
+_lib.lib().ocrf_diag_plan_stats(_lib.ptr(buf))
+hp._render_frame(0, False, 'raster')
+torch.cuda.synchronize()
+_lib.lib().ocrf_diag_plan_stats(None)
+s = buf.cpu().numpy().reshape(n_wg, 4, 8).astype(np.float64)
+cyc = s[:, :, :3]
+tot = cyc.sum(2)
+print('workgroups', n_wg, ' kept per view', hp.render_plans[0].kept)
+print('cycles per wave (100 MHz ticks x ?): scan %.0f stage %.0f blend %.0f  -> shares %s' % (
+    cyc[..., 0].mean(), cyc[..., 1].mean(), cyc[..., 2].mean(), np.round(cyc.mean((0, 1)) / cyc.mean((0, 1)).sum(), 3)))
+wg_time = tot.max(1)
+print('workgroup time: mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f' % (
+    wg_time.mean(), *np.percentile(wg_time, [50, 90, 99]), wg_time.max()))
+scanned, staged, listed, evald = s[:, 0, 3], s[:, 0, 4], s[:, :, 5], s[:, :, 6]
+print('per workgroup: scanned %.0f  staged %.0f  | per wave listed %.1f  evaluated %.1f' % (
+    scanned.mean(), staged.mean(), listed.mean(), evald.mean()))
+print('listed / staged %.3f   evaluated / listed %.3f   max-wave evaluated / mean-wave evaluated %.3f' % (
+    listed.mean() / staged.mean(), evald.mean() / listed.mean(), evald.max(1).mean() / evald.mean()))
+print('pixel-records evaluated per launch %.3e (128 px per wave-record)' % (evald.sum() * 128))
+# blend-phase imbalance: time of the slowest wave vs the mean wave in a workgroup
+b = cyc[..., 2]
+print('blend cycles: slowest wave / mean wave per workgroup %.3f' % (b.max(1).mean() / b.mean()))

@@ -15,10 +15,11 @@ from ocrfdet_amd.diff_gaussian_rasterization import rasterize_views  # noqa: E40
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--config', default='cfg2_6cam_2frame_bev200x200_render_hoa')
-ap.add_argument('--wskip', type=int, default=1)
+ap.add_argument('--wskip', type=int, default=0)
 ap.add_argument('--guard', default='host')
 ap.add_argument('--iters', type=int, default=50)
-ap.add_argument('--margin', type=float, default=2.0)
+ap.add_argument('--margin', type=float, default=1.25)
+ap.add_argument('--grid', type=int, default=0)
 a = ap.parse_args()
 
 dev = torch.device('cuda:0')
@@ -28,6 +29,8 @@ g, rc = hp.gauss, hp.render_cams
 H, W = cfg.input_size
 xyz = hp.voxel_xyz[0].reshape(-1, 3)
 _lib.lib().ocrf_tune_set(10, a.wskip)
+_lib.lib().ocrf_tune_set(11, a.grid)
+print('resident workgroups by the occupancy API:', _lib.lib().ocrf_diag_plan_resident())
 
 
 def dyn():
