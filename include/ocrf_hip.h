@@ -262,6 +262,35 @@ int ocrf_rasterize_planned(const void *plan, size_t plan_bytes, int P, int n_pla
                            size_t chain_workspace_bytes, ocrf_stream_t stream);
 
 /*
+ * bev_pool_v2 forward as per-tile MFMA panels (csrc/bev_pool_mfma.hip): out[64 voxels x C] = W[64 x R] . F[R x C]
+ * with R the tile's UNIQUE feature rows, W[v][r] = the summed depth weights of the tile's points with voxel slot v
+ * and row slot r, on v_mfma_f32_16x16x4_f32 (f32 in / f32 accumulate: an exact fmaf chain, bitwise reproducible).
+ * Same result as ocrf_bev_pool_v2_nchw up to the summation order (reference semantics: bev_pool_cuda.cu:39-47).
+ * The rank-only part is a plan the caller builds once (ocrfdet_amd/bevpool.MfmaPoolPlan shows how), all device ints:
+ *   units (n_units x 4)      {tile, first panel, end panel, slice | n_slices << 16}: a tile's panels in groups; tiles
+ *                            without points have one unit with no panel (they are written as zeros); every tile of the
+ *                            (B*Z) planes x ceil(Y / 8) x ceil(X / 8) grid appears (tile = plane * tpp + ty * tx_count + tx)
+ *   unit_slab (n_units)      first slab of the unit's tile (tiles of several units), else anything
+ *   panel_rows (n_panels x R_p), panel_nrows (n_panels)   feature rows of a panel (R_p = ocrf_bev_pool_mfma_panel_rows())
+ *   panel_cell_off (n_panels + 1), cells (n_cells x 4): {v | r << 8 | points << 16, depth ranks of the (up to three)
+ *                            points in summation order}; a cell of more points: {v | r << 8 | 0xFFFF << 16, first
+ *                            index into rd_sorted, points, -}; rd_sorted: depth ranks of all points in cell order
+ *                            a unit holds at most ocrf_bev_pool_mfma_max_unit_panels() panels
+ *   arrive (n_tiles ints, zero before the first call; left zero), slabs (>= ocrf_bev_pool_mfma_slab_bytes(c, slices))
+ * C in {64, 80, 96, 128}; layouts as ocrf_bev_pool_v2_nchw (+ 2: rows (n_vox, C)).
+ */
+int ocrf_diag_pool_mfma_stamps(unsigned long long *buf); /* diagnostic: per-unit phase cycles of the next C = 80 calls */
+int ocrf_bev_pool_mfma_panel_rows(void);
+int ocrf_bev_pool_mfma_tile_side(void); /* tiles are side x side voxel blocks of a (b, z) plane, row-major; slot v = side * dy + dx */
+size_t ocrf_bev_pool_mfma_slab_bytes(int c, int n_slab_slices);
+int ocrf_bev_pool_mfma_max_unit_panels(void);
+int ocrf_bev_pool_v2_nchw_mfma(int c, int n_units, const int *units, const int *unit_slab, const int *panel_rows,
+                               const int *panel_nrows, const int *panel_cell_off, const int *cells,
+                               const int *rd_sorted, const float *depth, const float *feat,
+                               float *out, int B, int Z, int Y, int X, int layout, int *arrive, void *slabs,
+                               ocrf_stream_t stream);
+
+/*
  * Backward of the colour output of ocrf_rasterize_forward (the w-depth fork has no depth backward,
  * diff-gaussian-rasterization-w-depth/README.md:13).  Replaces RasterizeGaussiansBackwardCUDA
  * (rasterize_points.cu:117-196 -> rasterizer_impl.cu:338-434 -> cuda_rasterizer/backward.cu) for
@@ -597,6 +626,7 @@ enum {
   OCRF_K_BEV_POOL_INTERVAL = 3, /* bev_pool_interval_kernel */
   OCRF_K_BEV_POOL_GRAD = 4,     /* bev_pool_grad_vec_kernel */
   OCRF_K_BEV_POOL_NCHW = 5,     /* (retired: the tile kernel writes the final layout itself) */
+  OCRF_K_BEV_POOL_MFMA = 6,     /* bev_pool_mfma_kernel<C / 16> */
   OCRF_K_RASTER_PREPROCESS = 10, /* raster_preprocess_kernel */
   OCRF_K_RASTER_BLEND = 11,      /* raster_blend_kernel */
   OCRF_K_RASTER_GATHER = 12,     /* raster_scatter_kernel */

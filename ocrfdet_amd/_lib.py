@@ -77,6 +77,18 @@ def _declare(L):
     L.ocrf_bev_pool_v2_nchw_planned.restype = c_int
     L.ocrf_bev_pool_v2_nchw_planned.argtypes = ([c_int] * 2 + [c_void_p] * 6 + [c_int] * 5 +
                                                 [c_void_p, c_size_t, c_void_p])
+    L.ocrf_bev_pool_mfma_panel_rows.restype = c_int
+    L.ocrf_bev_pool_mfma_panel_rows.argtypes = []
+    L.ocrf_diag_pool_mfma_stamps.restype = c_int
+    L.ocrf_diag_pool_mfma_stamps.argtypes = [c_void_p]
+    L.ocrf_bev_pool_mfma_tile_side.restype = c_int
+    L.ocrf_bev_pool_mfma_tile_side.argtypes = []
+    L.ocrf_bev_pool_mfma_slab_bytes.restype = c_size_t
+    L.ocrf_bev_pool_mfma_slab_bytes.argtypes = [c_int, c_int]
+    L.ocrf_bev_pool_v2_nchw_mfma.restype = c_int
+    L.ocrf_bev_pool_mfma_max_unit_panels.restype = c_int
+    L.ocrf_bev_pool_mfma_max_unit_panels.argtypes = []
+    L.ocrf_bev_pool_v2_nchw_mfma.argtypes = [c_int, c_int] + [c_void_p] * 10 + [c_int] * 5 + [c_void_p] * 3
     L.ocrf_tune_set.restype = c_int
     L.ocrf_tune_set.argtypes = [c_int, c_int]
     L.ocrf_bev_pool_max_units.restype = c_int
@@ -331,6 +343,7 @@ workspace = Workspace()
 
 
 K_BEV_POOL_FWD, K_BEV_POOL_FIXUP, K_BEV_POOL_INTERVAL, K_BEV_POOL_GRAD, K_BEV_POOL_NCHW = 1, 2, 3, 4, 5
+K_BEV_POOL_MFMA = 6
 K_RASTER_PREPROCESS, K_RASTER_BLEND, K_RASTER_GATHER = 10, 11, 12
 K_RASTER_SCAN, K_RASTER_BLEND_BWD, K_RASTER_PRE_BWD = 13, 15, 16
 K_RASTER_PLAN_UPDATE, K_RASTER_BLEND_SORTED = 17, 18

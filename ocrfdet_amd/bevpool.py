@@ -262,17 +262,12 @@ class DevicePoolPlan:
     only depth, feat, ranks_depth and ranks_feat.  Forward only; a plan serves one stream at a time (it
     holds the arrival counters of the cut tiles)."""
 
-    _count = 0
-
     def __init__(self, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts, interval_lengths):
         _lib.require_cuda(ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths)
         B, Z, Y, X, C = (int(v) for v in bev_feat_shape)
         if not _fusable(C):
             raise _lib.OcrfHipError(f'pool plans need C % 4 == 0 and C <= 256, got {C}')
         self.shape = (B, Z, Y, X, C)
-        # the slabs of cut tiles live in the scratch: a plan of its own scratch can run beside another plan's launch
-        DevicePoolPlan._count += 1
-        self.scratch_tag = f'bev_pool_plan{DevicePoolPlan._count}'
         self.ranks_depth = ranks_depth.int().contiguous()
         self.ranks_feat = ranks_feat.int().contiguous()
         rb, st, ln = ranks_bev.int().contiguous(), interval_starts.int().contiguous(), interval_lengths.int().contiguous()
@@ -285,6 +280,10 @@ class DevicePoolPlan:
                                                   B, Z, Y, X, _lib.ptr(self.plan),
                                                   ctypes.c_size_t(self.plan.numel()), _lib.stream_ptr(dev)),
                        'ocrf_bev_pool_plan_build')
+            # the slabs of cut tiles: owned by the plan (its lifetime, not the process-wide grow-only workspace), so a
+            # plan can run beside another plan's launch and a dropped plan returns its memory
+            self.scratch = torch.empty(max(int(L.ocrf_bev_pool_planned_workspace_bytes(C, self.n_points)), 256),
+                                       dtype=torch.uint8, device=dev)
 
 
 @torch.no_grad()
@@ -305,12 +304,139 @@ def bev_pool_v2_planned(depth, feat, plan, layout=1, out=None):
         raise _lib.OcrfHipError('out must be a contiguous fp32 tensor of B*C*Z*Y*X elements on the inputs\' device')
     L = _lib.lib()
     with _lib.on_device(dev):
-        need = L.ocrf_bev_pool_planned_workspace_bytes(C, plan.n_points)
-        scratch = _lib.workspace.get(dev, need, plan.scratch_tag)
+        scratch = plan.scratch
         _lib.check(L.ocrf_bev_pool_v2_nchw_planned(
             C, plan.n_points, _lib.ptr(d32), _lib.ptr(f32), _lib.ptr(plan.ranks_depth),
             _lib.ptr(plan.ranks_feat), _lib.ptr(plan.plan), _lib.ptr(out), B, Z, Y, X, int(layout), _lib.ptr(scratch),
             ctypes.c_size_t(scratch.numel()), _lib.stream_ptr(dev)), 'ocrf_bev_pool_v2_nchw_planned')
+    return out
+
+
+class MfmaPoolPlan:
+    """Rank-only part of the MFMA panel pooling (csrc/bev_pool_mfma.hip): per 64-voxel tile its UNIQUE feature rows in
+    panels of 64, per panel its non-zero (voxel slot, row slot) cells with their points in summation order, and the
+    unit list (a tile's panels in groups of at most ``group``; heaviest units first; tiles of several units reduce
+    through slabs).  Built once per calibration from the rank vectors with device-side torch index algebra (sort /
+    unique / searchsorted — plan time, not step time); every point of the rank vectors is pooled into
+    ``ranks_bev[p]`` (what the reference's intervals amount to when they cover the point list: bev_pool.py:40-57)."""
+
+    def __init__(self, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, group=4):
+        _lib.require_cuda(ranks_depth, ranks_feat, ranks_bev)
+        B, Z, Y, X, C = (int(v) for v in bev_feat_shape)
+        if C not in (64, 80, 96, 128):
+            raise _lib.OcrfHipError(f'the MFMA pooling takes C in (64, 80, 96, 128), got {C}')
+        self.shape = (B, Z, Y, X, C)
+        dev = ranks_bev.device
+        L = _lib.lib()
+        KP = int(L.ocrf_bev_pool_mfma_panel_rows())
+        TS = int(L.ocrf_bev_pool_mfma_tile_side())
+        YX, TV = Y * X, TS * TS
+        tcx, tcy = (X + TS - 1) // TS, (Y + TS - 1) // TS
+        tpp = tcx * tcy
+        n_tiles = B * Z * tpp
+        rb, rf, rd = ranks_bev.long(), ranks_feat.long(), ranks_depth.long()
+        keep = (rb >= 0) & (rb < B * Z * YX)
+        rb, rf, rd = rb[keep], rf[keep], rd[keep]
+        self.n_points = int(rb.numel())
+        i32 = lambda t: t.to(torch.int32).contiguous()  # noqa: E731
+        if self.n_points:
+            plane, inpl = rb // YX, rb % YX
+            y, x = inpl // X, inpl % X
+            tile, v = plane * tpp + (y // TS) * tcx + x // TS, (y % TS) * TS + x % TS
+            n_rows = int(rf.max()) + 1
+            key = (tile * n_rows + rf) * TV + v
+            order = torch.argsort(key, stable=True)                 # points of a cell stay in list order
+            key_s = key[order]
+            first = torch.ones_like(key_s, dtype=torch.bool)
+            first[1:] = key_s[1:] != key_s[:-1]
+            cell_start = torch.nonzero(first).flatten()
+            cell_key = key_s[cell_start]
+            cell_pair, cell_v = cell_key // TV, cell_key % TV
+            pfirst = torch.ones_like(cell_pair, dtype=torch.bool)
+            pfirst[1:] = cell_pair[1:] != cell_pair[:-1]
+            pair_of_cell = torch.cumsum(pfirst.long(), 0) - 1
+            pair_key = cell_pair[pfirst]
+            pair_tile, pair_rf = pair_key // n_rows, pair_key % n_rows
+            tiles = torch.arange(n_tiles + 1, device=dev)
+            tile_pair_start = torch.searchsorted(pair_tile, tiles)                # first pair of every tile
+            rslot = torch.arange(pair_key.numel(), device=dev) - tile_pair_start[pair_tile]
+            n_pan_tile = (tile_pair_start[1:] - tile_pair_start[:-1] + KP - 1) // KP
+        else:
+            n_pan_tile = torch.zeros(n_tiles, dtype=torch.long, device=dev)
+        tile_panel_off = torch.cumsum(n_pan_tile, 0) - n_pan_tile
+        n_panels = int(n_pan_tile.sum())
+        if self.n_points:
+            pair_panel = tile_panel_off[pair_tile] + rslot // KP
+            pair_r = rslot % KP
+            panel_rows = torch.zeros(max(n_panels, 1) * KP, dtype=torch.long, device=dev)
+            panel_rows[pair_panel * KP + pair_r] = pair_rf
+            panel_nrows = torch.bincount(pair_panel, minlength=max(n_panels, 1))
+            cell_panel = pair_panel[pair_of_cell]
+            panel_cell_off = torch.searchsorted(cell_panel, torch.arange(n_panels + 1, device=dev))
+            rd_sorted = rd[order]
+            cell_end = torch.cat((cell_start[1:], torch.tensor([self.n_points], device=dev)))
+            npts = cell_end - cell_start
+            code = cell_v | (pair_r[pair_of_cell] << 8)
+            last = self.n_points - 1
+            inline = npts <= 3
+            rd0 = rd_sorted[cell_start]
+            rd1 = rd_sorted[torch.clamp(cell_start + 1, max=last)]
+            rd2 = rd_sorted[torch.clamp(cell_start + 2, max=last)]
+            cells = torch.stack((code | (torch.where(inline, npts, torch.full_like(npts, 0xFFFF)) << 16),
+                                 torch.where(inline, rd0, cell_start), torch.where(inline, rd1, npts),
+                                 torch.where(inline, rd2, torch.zeros_like(rd2))), 1)
+        else:
+            panel_rows = torch.zeros(KP, dtype=torch.long, device=dev)
+            panel_nrows = torch.zeros(1, dtype=torch.long, device=dev)
+            panel_cell_off = torch.zeros(2, dtype=torch.long, device=dev)
+            cells = torch.zeros(1, 4, dtype=torch.long, device=dev)
+            rd_sorted = torch.zeros(1, dtype=torch.long, device=dev)
+        # units: a tile's panels in groups of <= group; a tile without points is one unit without panels
+        G = max(1, min(int(group), int(L.ocrf_bev_pool_mfma_max_unit_panels())))
+        n_unit_tile = torch.clamp((n_pan_tile + G - 1) // G, min=1)
+        unit_tile = torch.repeat_interleave(torch.arange(n_tiles, device=dev), n_unit_tile)
+        unit_first = torch.cumsum(n_unit_tile, 0) - n_unit_tile
+        slice_ = torch.arange(unit_tile.numel(), device=dev) - unit_first[unit_tile]
+        p0 = tile_panel_off[unit_tile] + slice_ * G
+        p1 = torch.minimum(p0 + G, tile_panel_off[unit_tile] + n_pan_tile[unit_tile])
+        multi = n_unit_tile > 1
+        slab_first = torch.cumsum(torch.where(multi, n_unit_tile, torch.zeros_like(n_unit_tile)), 0) - \
+            torch.where(multi, n_unit_tile, torch.zeros_like(n_unit_tile))
+        self.n_slab_slices = int(torch.where(multi, n_unit_tile, torch.zeros_like(n_unit_tile)).sum())
+        units = torch.stack((unit_tile, p0, p1, slice_ | (n_unit_tile[unit_tile] << 16)), 1)
+        heavy_first = torch.argsort(p1 - p0, descending=True, stable=True)
+        self.units = i32(units[heavy_first])
+        self.unit_slab = i32(slab_first[unit_tile][heavy_first])
+        self.n_units = int(self.units.size(0))
+        self.panel_rows, self.panel_nrows, self.panel_cell_off = i32(panel_rows), i32(panel_nrows), i32(panel_cell_off)
+        self.cells, self.rd_sorted = i32(cells), i32(rd_sorted)
+        self.n_panels, self.n_cells, self.n_tiles = n_panels, int(cells.size(0)), n_tiles
+        self.unique_rows = int(panel_nrows.sum()) if self.n_points else 0
+        self.arrive = torch.zeros(n_tiles, dtype=torch.int32, device=dev)
+        self.slabs = torch.empty(int(L.ocrf_bev_pool_mfma_slab_bytes(C, self.n_slab_slices)), dtype=torch.uint8, device=dev)
+
+
+@torch.no_grad()
+def bev_pool_v2_mfma(depth, feat, plan, layout=1, out=None):
+    """The pooling of ``plan``'s rank vectors on the matrix cores: (B, Z*C, Y, X) (layout 1) or (B,C,Z,Y,X)
+    (layout 0); same result as ``bev_pool_v2_planned`` up to the summation order."""
+    B, Z, Y, X, C = plan.shape
+    d32, f32 = depth.float().contiguous(), feat.float().contiguous()
+    _lib.require_cuda(d32, f32)
+    if f32.size(-1) != C:
+        raise _lib.OcrfHipError(f'feat has {f32.size(-1)} channels, the plan was built for {C}')
+    dev = d32.device
+    shape = (B, C, Z, Y, X) if layout == 0 else (B, Z * C, Y, X)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=dev)
+    elif out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != B * C * Z * Y * X or out.device != dev:
+        raise _lib.OcrfHipError('out must be a contiguous fp32 tensor of B*C*Z*Y*X elements on the inputs\' device')
+    L = _lib.lib()
+    with _lib.on_device(dev):
+        _lib.check(L.ocrf_bev_pool_v2_nchw_mfma(
+            C, plan.n_units, _lib.ptr(plan.units), _lib.ptr(plan.unit_slab), _lib.ptr(plan.panel_rows),
+            _lib.ptr(plan.panel_nrows), _lib.ptr(plan.panel_cell_off), _lib.ptr(plan.cells), _lib.ptr(plan.rd_sorted), _lib.ptr(d32), _lib.ptr(f32), _lib.ptr(out), B, Z, Y, X, int(layout),
+            _lib.ptr(plan.arrive), _lib.ptr(plan.slabs), _lib.stream_ptr(dev)), 'ocrf_bev_pool_v2_nchw_mfma')
     return out
 
 

@@ -24,6 +24,7 @@ class PoolPlan:
         self.starts, self.lengths = starts, lengths
         self.bev_shape = tuple(int(v) for v in bev_shape)      # (B, Z, Y, X, C)
         self.device_plan = None                                # bevpool.DevicePoolPlan, built on first use
+        self.mfma_plan = None                                  # bevpool.MfmaPoolPlan, built on first use
 
     @property
     def n_points(self):
@@ -56,7 +57,8 @@ def shared_stream(device, role):
 
 class HotPath:
     def __init__(self, cfg, device, cams=None, index_prep_mode='cached', overlap=True, device_geometry=False,
-                 render_mode='planned', render_guard='host', frame_motion=True, frame_offset=0, plan_margin=1.25):
+                 render_mode='planned', render_guard='host', frame_motion=True, frame_offset=0, plan_margin=1.25,
+                 ht_pool_backend='mfma'):
         """``cams``: optional list of camera indices this instance owns (camera sharding).
         ``index_prep_mode``: 'cached' — rank vectors computed once per calibration, the reference's
         ``accelerate=True`` intent; 'per_step' — recomputed inside every ``step()`` by the HIP index
@@ -71,6 +73,11 @@ class HotPath:
         assert render_mode in ('planned', 'per_call') and render_guard in ('host', 'device')
         self.render_mode, self.render_guard, self.plan_margin = render_mode, render_guard, float(plan_margin)
         self.frame_motion, self.frame_offset = bool(frame_motion), int(frame_offset)
+        # 'mfma': the HT pooling (cached ranks) as per-tile MFMA panels (csrc/bev_pool_mfma.hip: 26 vs 32 us at cfg2);
+        # 'tile': the VALU tile kernel for both poolings.  The LSS ranks keep the tile kernel (its heavy tiles — a
+        # 3.2 m block beside the rig collects thousands of rows — make the per-tile MFMA chain the launch's tail).
+        assert ht_pool_backend in ('mfma', 'tile')
+        self.ht_pool_backend = ht_pool_backend
         self.cams = list(range(cfg.n_cams)) if cams is None else list(cams)
         self.batch = cfg.batch * cfg.n_frames                  # frames ride along as batch entries
         assert index_prep_mode in ('cached', 'per_step')
@@ -292,6 +299,12 @@ class HotPath:
             if out is not None:
                 out.view_as(res).copy_(res)
             return res
+        if plan is self.ht and self.ht_pool_backend == 'mfma' and plan.bev_shape[-1] in (64, 80, 96, 128):
+            # the height-sampling ranks (11 points per feature row and 8x8 tile, no heavy tiles): per-tile MFMA panels
+            if plan.mfma_plan is None:
+                plan.mfma_plan = bevpool.MfmaPoolPlan(plan.ranks_depth, plan.ranks_feat, plan.ranks_bev, plan.bev_shape,
+                                                      group=8)
+            return bevpool.bev_pool_v2_mfma(depth, feat, plan.mfma_plan, out=out)
         if plan.device_plan is None:
             plan.device_plan = bevpool.DevicePoolPlan(plan.ranks_depth, plan.ranks_feat, plan.ranks_bev, plan.bev_shape,
                                                       plan.starts, plan.lengths)
