@@ -37,7 +37,8 @@ FP32_PEAK_TFLOPS = 157.3        # ibid.: peak FP32 (vector) = 256 CU x 4 SIMD-32
 N_SIMD, CLOCK_HZ = 256 * 4, 2.4e9
 VALU_CYCLES_PER_INST = 2.0      # ibid.: a wave64 VALU op issues over 2 cycles on a SIMD-32
 BLEND_FLOPS_PER_PIXEL_RECORD = 20.0      # blend flops ~= 20 x sum_tiles len x 256
-PMC_FILE = os.path.join('profiles', 'r2_pmc_mean.csv')     # rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh)
+PMC_FILE = os.path.join('profiles', 'r3_pmc_mean.csv')     # rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh)
+PMC_META = os.path.join('profiles', 'r3_pmc_meta.json')    # what those passes ran: config, flags, hash of csrc/
 DEFAULT_CONFIG = 'cfg2_6cam_2frame_bev200x200_render_hoa'
 
 
@@ -47,6 +48,7 @@ def parse():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--config', default=DEFAULT_CONFIG)
+    ap.add_argument('--blocks', type=int, default=5, help='timed blocks of --steps steps (the median block is reported)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU-baseline sample budget')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--shard', choices=('camera_frames', 'samples', 'frames', 'cameras'), default='camera_frames')
@@ -65,6 +67,8 @@ def parse():
                     help="--scope neck --index-prep per_step: hand the calibration tensors over as HOST tensors (the "
                          "dataloader's copies) — the forward then has no device -> host read-back at all")
     ap.add_argument('--no-per-step', action='store_true', help='skip the second timed loop with the index preparation inside the step')
+    ap.add_argument('--dense-exchange', action='store_true',
+                    help="camera_frames: step 1 as the dense reduce_scatter instead of the wedge-sparse isend / irecv round")
     ap.add_argument('--render-mode', choices=('planned', 'per_call'), default='planned',
                     help="'planned': the render's calibration-only front end (near-plane / frustum cull, depth order, projected "
                          "centres) cached per frame like the rank vectors (static render plan); 'per_call': recomputed every render")
@@ -77,11 +81,20 @@ def parse():
     return ap.parse_args()
 
 
+def _hoa_params(hp):
+    p = {}
+    for prefix, m in hp.hoa_mods.items():
+        for k, v in m.state_dict().items():
+            p[f'{prefix}.{k}'] = v.detach().cpu().numpy()
+    return p
+
+
 def cpu_baseline(hp, depth, feat, budget_s):
-    """Times the C/OpenMP oracle on a bounded sample of the same step: the two pools of the whole
-    step (a few repetitions) and ONE rendered view (the reference-structured rasteriser sorts all
-    tile instances, so a full step of views would take minutes); the step time is assembled as
-    t_pools + views_per_step * t_view."""
+    """Times the C/OpenMP oracle (and, for HOA, the numpy oracle) on a bounded sample of the same step: the two pools
+    of the whole step (a few repetitions), a few rendered views of frame 0 (the reference-structured rasteriser sorts
+    all tile instances, so a full step of views would take minutes) and HOA-1/2/3 of ONE frame; the step time is
+    assembled as t_pools + views_per_step * t_view + frames * t_hoa.  The same sample on ONE thread (the scalar port)
+    is timed in a child process with a time limit."""
     import numpy as np
     import oracle
     oracle.build()
@@ -99,37 +112,110 @@ def cpu_baseline(hp, depth, feat, budget_s):
         pools()
         n += 1
         el = time.perf_counter() - t0
-        if el >= min(budget_s, 5.0) or n >= 200:
+        if el >= min(budget_s, 4.0) or n >= 200:
             break
     t_pools = el / n
-    t_view, n_views_timed, rendered = 0.0, 0, None
+    t_view, n_views_timed, rendered, view_args = 0.0, 0, None, None
     if hp.cfg.render:
         g = hp.gauss
         Himg, Wimg = hp.cfg.input_size
         args = (hp.voxel_xyz[0].reshape(-1, 3).cpu().numpy(), g['rgb'].cpu().numpy(), g['opacity'].cpu().numpy(),
                 g['scales'].cpu().numpy(), g['rotations'].cpu().numpy())
+        cams = hp.render_cams
+        view_args = dict(xyz=args[0], rgb=args[1], opacity=args[2], scales=args[3], rotations=args[4],
+                         vm=cams['vm'][0].cpu().numpy(), pm=cams['pm'][0].cpu().numpy(), tfx=np.float64(cams['tfx'][0]),
+                         tfy=np.float64(cams['tfy'][0]), H=np.int64(Himg), W=np.int64(Wimg))
         t0 = time.perf_counter()
         while True:
             v = n_views_timed % len(hp.cams)
-            r = oracle.rasterize_forward(*args, hp.render_cams['vm'][v].cpu().numpy(), hp.render_cams['pm'][v].cpu().numpy(),
-                                         hp.render_cams['tfx'][v], hp.render_cams['tfy'][v], Himg, Wimg,
-                                         np.zeros(3, np.float32))
+            r = oracle.rasterize_forward(*args, cams['vm'][v].cpu().numpy(), cams['pm'][v].cpu().numpy(),
+                                         cams['tfx'][v], cams['tfy'][v], Himg, Wimg, np.zeros(3, np.float32))
             rendered = r['num_rendered']
             n_views_timed += 1
             el = time.perf_counter() - t0
-            if el >= budget_s or n_views_timed >= 12:
+            if el >= 0.6 * budget_s or n_views_timed >= 12:
                 break
         t_view = el / n_views_timed
-    t_step = t_pools + hp.views_per_step * t_view
+    t_hoa, hoa_note = 0.0, 'no HOA in this configuration'
+    if hp.cfg.hoa:
+        from oracle import hoa as ohoa
+        X, Y, _ = hp.cfg.bev_xyz
+        p = _hoa_params(hp)
+        opac = hp.frame_gauss[0]['opacity'].cpu().numpy().astype(np.float32)
+        alpha = hp.alpha_lidar[:1].cpu().numpy()
+        pos = hp.bev_pos1[:1].cpu().numpy()
+        geom = np.zeros((1, hp.cfg.channels, Y, X), np.float32)
+        t0 = time.perf_counter()
+        oa, _ = ohoa.hoa1(opac, alpha, p, hp.cfg.num_height, Y, X)
+        ob = ohoa.opacity_voxel_to_bev(oa, pos, p)
+        m = ohoa.opacity_mask(geom, ob, p)
+        _ = geom * m
+        t_hoa = time.perf_counter() - t0
+        hoa_note = 'HOA-1/2/3 of one frame by the numpy oracle (oracle/hoa.py), once'
+    frames = hp.batch
+    t_step = t_pools + hp.views_per_step * t_view + frames * t_hoa
+    single = single_thread_sample(plans, d, f, view_args, limit_s=max(20.0, 2.0 * budget_s))
+    if single.get('ms_pools') is not None and single.get('ms_per_view') is not None:
+        single['ms_per_step'] = single['ms_pools'] + hp.views_per_step * single['ms_per_view'] + 1e3 * frames * t_hoa
+        single['value'] = hp.bev_voxels_per_step / (single['ms_per_step'] * 1e-3)
     return dict(value=hp.bev_voxels_per_step / t_step, unit='BEV voxels/s', cores=oracle.num_threads(),
                 cores_note='OpenMP threads of the pooling, of the per-Gaussian / per-tile loops and of the per-tile '
-                           'sorts of the tile instances (bucketed by tile first; the histogram pass is one thread)',
+                           'sorts of the tile instances (bucketed by tile first; the histogram pass is one thread); the '
+                           'numpy HOA leg uses whatever BLAS threads numpy has',
                 kind='port', ms_per_step=1e3 * t_step, ms_pools=1e3 * t_pools, ms_per_view=1e3 * t_view,
+                ms_hoa_per_frame=1e3 * t_hoa,
                 views_per_sec=(hp.views_per_step / t_step) if hp.views_per_step else 0.0,
+                single_thread=single,
                 sample=f'{n} x (LSS pool + HT pool of the whole step, same inputs and ranks as the GPU)'
-                       + (f' and {n_views_timed} rendered view(s) of frame 0 ({rendered} tile instances in the last), '
-                          f'step time assembled as pools + {hp.views_per_step} x view' if hp.cfg.render else '')
-                       + '; HOA (small torch convs) not included; C/OpenMP oracle')
+                       + (f', {n_views_timed} rendered view(s) of frame 0 ({rendered} tile instances in the last)'
+                          if hp.cfg.render else '') + f', {hoa_note}; step time assembled as pools + '
+                       f'{hp.views_per_step} x view + {frames} x HOA; C/OpenMP + numpy oracles')
+
+
+def single_thread_sample(plans, d, f, view_args, limit_s):
+    """The scalar port: the pools once and ONE rendered view on a single thread, in a child process that is stopped
+    after ``limit_s`` (a 520 k-Gaussian view takes the single-threaded reference-structured rasteriser tens of seconds)."""
+    import pickle
+    import subprocess
+    import tempfile
+    import numpy as np
+    out = dict(cores=1, ms_pools=None, ms_per_view=None, limit_s=limit_s)
+    with tempfile.TemporaryDirectory(dir='/tmp') as tmp:
+        blob = os.path.join(tmp, 'sample.pkl')
+        with open(blob, 'wb') as fo:
+            pickle.dump(dict(plans=plans, d=d, f=f, view=view_args), fo, protocol=4)
+        code = (
+            'import pickle, sys, time, json\n'
+            f'sys.path.insert(0, {ROOT!r})\n'
+            'import numpy as np, oracle\n'
+            'oracle.set_num_threads(1)\n'
+            f's = pickle.load(open({blob!r}, "rb"))\n'
+            't0 = time.perf_counter()\n'
+            'for rd, rf, rb, st, ln, shape in s["plans"]:\n'
+            '    oracle.bev_pool_v2(s["d"], s["f"], rd, rf, rb, shape, st, ln)\n'
+            'print(json.dumps({"ms_pools": 1e3 * (time.perf_counter() - t0)}), flush=True)\n'
+            'v = s["view"]\n'
+            'if v is not None:\n'
+            '    t0 = time.perf_counter()\n'
+            '    oracle.rasterize_forward(v["xyz"], v["rgb"], v["opacity"], v["scales"], v["rotations"], v["vm"], v["pm"],\n'
+            '                             float(v["tfx"]), float(v["tfy"]), int(v["H"]), int(v["W"]), np.zeros(3, np.float32))\n'
+            '    print(json.dumps({"ms_per_view": 1e3 * (time.perf_counter() - t0)}), flush=True)\n')
+        env = dict(os.environ, OMP_NUM_THREADS='1')
+        proc = subprocess.Popen([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True)
+        try:
+            txt, _ = proc.communicate(timeout=limit_s)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            txt, _ = proc.communicate()
+            out['note'] = f'stopped after {limit_s:.0f} s'
+        for line in (txt or '').splitlines():
+            try:
+                out.update(json.loads(line))
+            except Exception:       # noqa: BLE001
+                pass
+        if view_args is not None and out['ms_per_view'] is None:
+            out['ms_per_view_lower_bound'] = 1e3 * limit_s - (out['ms_pools'] or 0.0)
+    return out
 
 
 def bench_neck(args, cfg, dev, world, rank):
@@ -209,7 +295,7 @@ def bench_neck(args, cfg, dev, world, rank):
                             'note': 'kernel timed over an eager run of the same step right after the timed region '
                                     '(HIP events cannot bracket a launch inside a graph replay)'},
                'cpu_baseline': None}
-        print(json.dumps(out), flush=True)
+        emit(out)
     timer.close()
     if world > 1:
         try:
@@ -218,12 +304,42 @@ def bench_neck(args, cfg, dev, world, rank):
             pass
 
 
-def pmc_counters(kernel_prefix):
-    """Mean per launch of every counter rocprofv3 collected for one kernel (profiles/r2_pmc_mean.csv, written by
+def source_hash():
+    """sha256 over the library's sources (csrc/*.hip, *.h): the counters of a profile belong to ONE build."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'ocrfdet_amd', 'csrc', '*.hip')) +
+                    glob.glob(os.path.join(ROOT, 'ocrfdet_amd', 'csrc', '*.h'))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+_PMC_OK = None
+
+
+def pmc_valid(args):
+    """The committed counters are used only for the run they were collected on: same config, same render mode and
+    the same library sources (profiles/r3_pmc_meta.json); anything else reports no traffic / counters."""
+    global _PMC_OK
+    if _PMC_OK is None:
+        _PMC_OK = False
+        try:
+            meta = json.load(open(os.path.join(ROOT, PMC_META)))
+            _PMC_OK = (meta.get('config') == args.config and meta.get('render_mode') == args.render_mode and
+                       meta.get('source_hash') == source_hash())
+        except Exception:       # noqa: BLE001
+            _PMC_OK = False
+    return _PMC_OK
+
+
+def pmc_counters(kernel_prefix, args=None):
+    """Mean per launch of every counter rocprofv3 collected for one kernel (profiles/r3_pmc_mean.csv, written by
     tools/collect_profiles.sh from separate --pmc passes of this command with --no-overlap): {counter: mean}."""
     path = os.path.join(ROOT, PMC_FILE)
     out = {}
-    if not os.path.exists(path):
+    if not os.path.exists(path) or (args is not None and not pmc_valid(args)):
         return out
     import csv
     for r in csv.DictReader(open(path)):
@@ -254,6 +370,58 @@ def agree(ok, world):
     return bool(t.item())
 
 
+def _poll(done, seconds):
+    """True once done() says so, False after `seconds` — never blocks in a collective."""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        if done():
+            return True
+        time.sleep(0.01)
+    return False
+
+
+def rccl_probe(world, rank, dev, groups, seconds=30.0):
+    """Tiny collectives of every kind the camera-frame exchange uses, on the world and on this rank's frame group, each
+    waited for by POLLING with a time limit: -> (error text or None, hung).  An exception leaves RCCL usable for nobody
+    but harms nothing (every rank then agrees, over gloo, to run the samples layout, which has no data-path
+    collective); a collective that never completes leaves a kernel spinning on the device — the caller exits."""
+    import torch.distributed as dist
+    try:
+        t = torch.ones(256, device=dev)
+        w = dist.all_reduce(t, async_op=True)
+        if not _poll(w.is_completed, seconds):
+            return 'world all_reduce did not complete', True
+        if abs(float(t[0].item()) - world) > 1e-3:
+            return 'world all_reduce returned a wrong sum', False
+        out = torch.empty(256 * world, device=dev)
+        w = dist.all_gather_into_tensor(out, t, async_op=True)
+        if not _poll(w.is_completed, seconds):
+            return 'world all_gather did not complete', True
+        for ranks, group in groups.items():
+            if rank not in ranks:
+                continue
+            G = len(ranks)
+            src, dst = torch.ones(G * 64, device=dev), torch.empty(64, device=dev)
+            w = dist.reduce_scatter_tensor(dst, src, group=group, async_op=True)
+            if not _poll(w.is_completed, seconds):
+                return f'reduce_scatter in group {list(ranks)} did not complete', True
+            if abs(float(dst[0].item()) - G) > 1e-3:
+                return f'reduce_scatter in group {list(ranks)} returned a wrong sum', False
+            ops, bufs = [], []
+            for r in ranks:
+                if r != rank:
+                    bufs.append(torch.empty(64, device=dev))
+                    ops.append(dist.P2POp(dist.isend, src[:64], r, group))
+                    ops.append(dist.P2POp(dist.irecv, bufs[-1], r, group))
+            for q in (dist.batch_isend_irecv(ops) if ops else []):
+                if not _poll(q.is_completed, seconds):
+                    return f'isend / irecv in group {list(ranks)} did not complete', True
+        torch.cuda.synchronize()
+        return None, False
+    except Exception as e:       # noqa: BLE001
+        return f'{type(e).__name__}: {e}'[:300], False
+
+
 def timed(step, steps, world, dev):
     """steps x step() bracketed by a barrier + torch.cuda.synchronize() on both sides; the MAX over ranks."""
     import torch.distributed as dist
@@ -274,9 +442,28 @@ def timed(step, steps, world, dev):
     return elapsed
 
 
+_REAL_STDOUT = None
+
+
+def emit(obj):
+    """The ONE JSON line of the contract, on the process's real stdout."""
+    line = (json.dumps(obj) + '\n').encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line)
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    # Everything but the result line goes to stderr: gloo (the control group of N > 1 runs) reports its connections on
+    # the C-level stdout, torch.distributed.run forwards every rank's stdout — the contract is ONE line.
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     single_dev = os.environ.get('OCRF_BENCH_SINGLE_DEVICE') == '1'      # plumbing test: all ranks on cuda:0 (gloo)
@@ -288,11 +475,11 @@ def main():
         import datetime
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank),
-                                    timeout=datetime.timedelta(seconds=300))
+                                    timeout=datetime.timedelta(seconds=120))
         else:
             dist.init_process_group(args.backend)
         global CONTROL
-        CONTROL = dist.new_group(backend='gloo')
+        CONTROL = dist.new_group(backend='gloo', timeout=datetime.timedelta(seconds=120))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
@@ -312,14 +499,36 @@ def main():
     if shard == 'camera_frames':
         # the exchange has only ever run over gloo on the build box (one GPU): if RCCL refuses any part of it, every
         # rank falls back to the samples layout TOGETHER and the line says so, instead of one rank dying in a collective
+        hung = False
+        use_rccl = args.backend == 'nccl'
         try:
-            sp = hotpath.ShardedHotPath(cfg, dev, rank, world, index_prep_mode=args.index_prep, **rkw)
-            sp_inputs = sp.make_inputs(seed=0)
-            for _ in range(2):
-                sp.step(sp_inputs)
-            torch.cuda.synchronize()
+            if use_rccl:
+                # tiny collectives of every kind the exchange uses, polled with a time limit, BEFORE the first real one:
+                # the world first (the exchange's constructor tries its in-place gather on it), then the frame groups
+                shard_error, hung = rccl_probe(world, rank, dev, {})
+            if shard_error is None:
+                sp = hotpath.ShardedHotPath(cfg, dev, rank, world, index_prep_mode=args.index_prep,
+                                            sparse_exchange=not args.dense_exchange, **rkw)
+                if use_rccl:
+                    shard_error, hung = rccl_probe(world, rank, dev, sp.exchange.groups)
+            if shard_error is None:
+                sp_inputs = sp.make_inputs(seed=0)
+                for _ in range(2):
+                    sp.step(sp_inputs)
+                ev = torch.cuda.Event()
+                ev.record()
+                if not _poll(ev.query, 60.0):
+                    shard_error, hung = 'the camera-frame step did not complete within 60 s', True
         except Exception as e:       # noqa: BLE001
             shard_error = f'{type(e).__name__}: {e}'[:300]
+        # agreement over the gloo control group only (120 s timeout): never another RCCL call after a failure
+        any_hung = not agree(not hung, world)
+        if any_hung:
+            if rank == 0:
+                print(json.dumps({'error': 'a collective of the camera-frame exchange never completed; the device is left with '
+                                           'a spinning kernel, so no fallback layout can be timed in this process',
+                                  'detail': shard_error}), file=sys.stderr, flush=True)
+            os._exit(4)
         if not agree(shard_error is None, world):
             shard_error = shard_error or 'another rank failed in the camera-frame exchange'
             sp, shard = None, 'samples'
@@ -364,8 +573,13 @@ def main():
     for t in (t_blend, t_pool):
         if t is not None:
             t.arm()
-    elapsed = timed(step, args.steps, world, dev)
+    # K blocks of `steps` steps, each bracketed like the contract says; the reported block is the MEDIAN one
+    # (ms_per_step x steps = that block), min / max beside it.  The kernel timers cover the first block.
+    blocks = [timed(step, args.steps, world, dev)]
     _lib.KernelTimer.disarm_all()
+    for _ in range(max(1, args.blocks) - 1):
+        blocks.append(timed(step, args.steps, world, dev))
+    elapsed = sorted(blocks)[len(blocks) // 2]
     # planned renders with the host guard: ONE status read per plan verifies every render of the warm-up and the timed
     # region (raises if a Gaussian left the plans' extent bound: those renders would not be valid)
     hp.check_render_plans()
@@ -425,7 +639,7 @@ def main():
         pool_ms = t_pool.mean_ms()
         d_numel, f_numel = depth.numel(), feat.numel()
         pool_alg = 0.5 * (hp.lss.algorithmic_bytes(d_numel, f_numel) + hp.ht.algorithmic_bytes(d_numel, f_numel))
-        pool_c = pmc_counters('bev_pool_tile_kernel')
+        pool_c = pmc_counters('bev_pool_tile_kernel', args)
         pools = {'kernel': t_pool.kernel_name, 'bound': 'hbm',
                  'launches_per_pool': 1, 'avg_launch_us': 1e3 * pool_ms if pool_ms else None,
                  'launches_timed': t_pool.count(),
@@ -443,7 +657,7 @@ def main():
             # the blend is VALU-bound: flops = 20 per pixel.record, pixel.records counted as the
             # contributor index every pixel stopped at (a lower bound of what the kernel evaluates)
             evals = float(sum(int(o['n_contrib'].sum().item()) for o in hp.render(want_n_contrib=True))) / hp.batch
-            c = pmc_counters('raster_blend_sorted_kernel' if planned else 'raster_blend_kernel<false, false, true, false>')
+            c = pmc_counters('raster_blend_sorted_kernel' if planned else 'raster_blend_kernel<false, false, true, false>', args)
             cycles = blend_ms * 1e-3 * CLOCK_HZ
             tfl = BLEND_FLOPS_PER_PIXEL_RECORD * evals / (blend_ms * 1e-3) / 1e12
             traffic = hbm_traffic(c)
@@ -452,7 +666,7 @@ def main():
                 'achieved': tfl, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tfl / FP32_PEAK_TFLOPS,
                 'flops_per_pixel_record': BLEND_FLOPS_PER_PIXEL_RECORD, 'pixel_records_per_launch': evals,
                 'avg_launch_us': 1e3 * blend_ms, 'launches_timed': t_blend.count(),
-                'traffic': traffic, 'traffic_source': PMC_FILE if traffic else None,
+                'traffic': traffic, 'traffic_source': (PMC_FILE + ' (' + PMC_META + ' matches this run)') if traffic else None,
                 'hbm': ({'bytes_per_launch_pmc': traffic, 'achieved_GBs': traffic / (blend_ms * 1e-3) / 1e9,
                          'frac_of_peak': traffic / (blend_ms * 1e-3) / 1e9 / HBM_PEAK_GBS} if traffic else None),
                 'isolated': ({'avg_launch_us': 1e3 * iso_blend,
@@ -480,9 +694,12 @@ def main():
             ex = sp.exchange
             sharding_desc = {
                 'layout': sp.plan.describe(), 'rccl_ranks': world, 'idle_ranks': sp.plan.idle_ranks,
-                'collectives_per_step': (['reduce_scatter(sum) of the partial fused grid inside each frame group']
+                'collectives_per_step': ((['wedge-sparse step 1: batched isend / irecv of the touched strips of each member\'s plane '
+                                           'block inside a frame group, added in member order'] if ex.touched else
+                                          ['reduce_scatter(sum) of the (padded) partial fused grid inside each frame group'])
                                          if ex.partial else []) + ['all_gather of the finished plane blocks over the world'],
                 'bytes_received_per_rank_reduce_scatter': ex.bytes_reduce_scatter,
+                'bytes_received_per_rank_reduce_scatter_dense_form': ex.bytes_reduce_scatter_dense,
                 'bytes_received_per_rank_all_gather': ex.bytes_all_gather,
                 'in_place_all_gather': bool(ex.direct), 'overlap': 'collectives asynchronous beside the renders (side HIP '
                 'stream) and HOA-1/2; HOA-3 gate replicated on the gathered grid'}
@@ -496,7 +713,10 @@ def main():
             'value': voxels / elapsed, 'unit': 'BEV voxels/s',
             'rendered_views_per_sec': views / elapsed,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * elapsed / args.steps, 'per_step_ms': per_step_ms,
+            'ms_per_step': 1e3 * elapsed / args.steps,
+            'ms_per_step_blocks': {'n': len(blocks), 'median': 1e3 * elapsed / args.steps,
+                                   'min': 1e3 * min(blocks) / args.steps, 'max': 1e3 * max(blocks) / args.steps},
+            'per_step_ms': per_step_ms,
             'per_step_device_geometry_ms': per_step_devgeom_ms, 'higher_is_better': True,
             **({'sharding_fallback': 'camera_frames -> samples: ' + shard_error} if shard_error else {}),
             'scaling': 'strong' if strong else 'weak',
@@ -530,15 +750,19 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(hp, depth, feat, args.cpu_seconds)
             out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
-        print(json.dumps(out), flush=True)
+        emit(out)
     for t in (t_blend, t_pool):
         if t is not None:
             t.close()
     if world > 1:
         import torch.distributed as dist
+        if shard_error:
+            # a communicator that failed above may never shut down: leave without the teardown (the line is printed)
+            sys.stdout.flush()
+            os._exit(0)
         try:
             dist.destroy_process_group()
-        except Exception:       # noqa: BLE001  (a communicator that failed above may refuse to shut down cleanly)
+        except Exception:       # noqa: BLE001
             pass
 
 

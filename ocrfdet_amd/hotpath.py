@@ -405,7 +405,8 @@ class ShardedHotPath:
     (which do not read the pooled BEV) run beside them.  With ``world == 1`` it is ``HotPath`` with the same fused
     output buffer."""
 
-    def __init__(self, cfg, device, rank, world, index_prep_mode='cached', render_mode='planned', render_guard='host'):
+    def __init__(self, cfg, device, rank, world, index_prep_mode='cached', render_mode='planned', render_guard='host',
+                 sparse_exchange=True, collectives=None):
         from . import sharding
         self.cfg, self.device, self.rank, self.world = cfg, torch.device(device), rank, world
         X, Y, Z = cfg.bev_xyz
@@ -413,7 +414,7 @@ class ShardedHotPath:
         self.n_frames = cfg.batch * cfg.n_frames
         self.planes_lss = Z * C
         self.plan = sharding.CameraFramePlan(cfg.n_cams, self.n_frames, world, (Z + 1) * C)
-        self.exchange = sharding.BevExchange(self.plan, rank, self.device, (Y, X))
+        self.exchange = sharding.BevExchange(self.plan, rank, self.device, (Y, X), collectives=collectives)
         one = synthetic.PathConfig(**{**cfg.__dict__, 'batch': 1, 'n_frames': 1, 'hoa': False})
         self.subs = {f: HotPath(one, self.device, cams=self.plan.cams_of(rank, f), index_prep_mode=index_prep_mode,
                                 overlap=False, frame_offset=f, render_mode=render_mode, render_guard=render_guard)
@@ -422,6 +423,16 @@ class ShardedHotPath:
         self.base = HotPath(synthetic.PathConfig(**{**cfg.__dict__, 'render': cfg.render or cfg.hoa}), self.device,
                             cams=[0], index_prep_mode='cached', overlap=False) if cfg.hoa else None
         self._side = shared_stream(self.device, 'render') if self.device.type == 'cuda' and cfg.render else None
+        # wedge-sparse step 1: a member's partial grid is zero outside the strips its cameras' rank vectors touch
+        # (static per calibration) — only those strips of the other members' plane blocks cross xGMI
+        self.sparse_exchange = bool(sparse_exchange) and self.exchange.active and bool(self.exchange.partial)
+        if self.sparse_exchange or (sparse_exchange and self.exchange.partial):
+            ex, touched = self.exchange, {}
+            for f, sub in self.subs.items():
+                if f in ex.partial:
+                    yx = torch.cat((sub.lss.ranks_bev.long() % (Y * X), sub.ht.ranks_bev.long() % (Y * X)))
+                    touched[f] = torch.unique(ex.tile_of_voxel(yx))
+            ex.set_touched(touched)
 
     def make_inputs(self, seed=0):
         """Per owned frame: depth (1, n_owned_cams, D, H, W), feat (1, n_owned_cams, H, W, C) — the same values

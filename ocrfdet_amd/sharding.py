@@ -31,7 +31,7 @@ import torch
 import torch.distributed as dist
 
 __all__ = ['assign_units', 'choose_policy', 'frames_of_rank', 'cams_of_rank', 'reduce_partial_bev',
-           'gather_frames', 'CameraFramePlan', 'BevExchange']
+           'gather_frames', 'CameraFramePlan', 'BevExchange', 'Collectives', 'GlooCollectives', 'GlooEmulation']
 
 
 def choose_policy(n_frames, world_size):
@@ -118,16 +118,18 @@ class CameraFramePlan:
                 for c in range(n_cams):
                     self.units[ranks[c % G]].append((f, c))
                 self.group_of_frame.append(ranks)
-        # plane blocks: frame f's P planes in G_f blocks (sizes differ by at most one when G_f does not divide P)
+        # plane blocks: frame f's P planes in G_f blocks of cap_f = ceil(P / G_f) planes (the last one shorter when G_f
+        # does not divide P): equal-size blocks are what reduce_scatter moves, so a group of 3 (6 ranks x 2 frames,
+        # BASELINE configs[3]: P = 160) keeps the scatter form with two padding planes instead of a dense all_reduce
         self.block_owner = []
+        self.cap_of_frame = []
         for f, ranks in enumerate(self.group_of_frame):
             G = len(ranks)
-            q, rem = divmod(n_planes, G)
-            p0 = 0
+            cap = -(-n_planes // G)
+            self.cap_of_frame.append(cap)
             for i, r in enumerate(ranks):
-                n = q + (1 if i < rem else 0)
-                self.block_owner.append((f, p0, n, r))
-                p0 += n
+                p0 = min(i * cap, n_planes)
+                self.block_owner.append((f, p0, min(cap, n_planes - p0), r))
 
     def frames_of(self, rank):
         return sorted({f for f, _ in self.units[rank]})
@@ -149,28 +151,72 @@ class CameraFramePlan:
                 f'camera-frames per rank {[len(u) for u in self.units]}')
 
 
+class Collectives:
+    """The ``torch.distributed`` calls ``BevExchange`` issues, behind one seam: the CPU tests drive the exchange's RCCL
+    code paths (in-place gather, ``reduce_scatter_tensor``) over gloo through ``GlooEmulation``."""
+    native = True            # has reduce_scatter_tensor and the in-place all_gather (nccl = RCCL)
+
+    def reduce_scatter(self, dst, src, group):
+        return dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+    def all_gather(self, recv, send, in_place):
+        dist.all_gather_into_tensor(recv, send)
+
+    def exchange(self, ops):
+        return dist.batch_isend_irecv(ops) if ops else []
+
+
+class GlooCollectives(Collectives):
+    """gloo has no reduce_scatter and no in-place gather: step 1 is an all_reduce of the (padded) frame buffer followed
+    by taking the own block, and the gather is staged.  CPU plumbing only."""
+    native = False
+
+    def reduce_scatter(self, dst, src, group):
+        dist.all_reduce(src, op=dist.ReduceOp.SUM, group=group)
+        n = dst.shape[0]
+        i = dist.get_rank(group)
+        dst.copy_(src[i * n:(i + 1) * n])
+        return None
+
+
+class GlooEmulation(GlooCollectives):
+    """Test seam: reports itself as native so that ``BevExchange`` takes exactly the branches it takes on RCCL (views of
+    the fused grid as gather slots, ``reduce_scatter`` into them), with the two collectives gloo lacks emulated."""
+    native = True
+
+    def all_gather(self, recv, send, in_place):
+        dist.all_gather_into_tensor(recv, send.clone() if in_place else send)
+
+
 class BevExchange:
     """The collectives of a ``CameraFramePlan`` on this rank.
 
         ex = BevExchange(plan, rank, device, (Y, X))
         for f in plan.frames_of(rank): pool the owned cameras of frame f into ex.pool_target(f)   # (P, Y, X)
-        works = ex.start()            # reduce_scatter inside each frame group with > 1 rank (asynchronous)
+        works = ex.start()            # step 1 inside each frame group with > 1 rank (asynchronous)
         ... kernels that do not need the pooled BEV ...
         full = ex.finish(works)       # world all_gather -> (n_frames, P, Y, X), the same on every rank
 
     ``pool_target(f)`` is a full-size partial buffer when the frame's cameras are split over a group, and the
-    frame's final place inside ``full`` when this rank owns the whole frame (nothing is copied then).  Where the
-    plane blocks lie in rank order (world <= n_frames == world, or world a multiple of n_frames with P divisible
-    by the group size) the all_gather runs IN PLACE on ``full``; otherwise through a staging slot per rank.
-    Process groups are created collectively by every rank in the same order (constructor).  ``gloo`` has no
-    reduce_scatter and no in-place gather: there step 1 is an all_reduce of the frame buffer followed by taking
-    the own block, and the gather is staged (CPU tests only)."""
+    frame's final place inside ``full`` when this rank owns the whole frame (nothing is copied then).
+    Step 1, dense: ``reduce_scatter`` over equal plane blocks of ``cap = ceil(P / G)`` planes (the partial buffer carries
+    ``G cap - P`` zero padding planes, so any group size keeps the scatter form).  Step 1, wedge-sparse
+    (``set_touched``): a camera's frustum covers a wedge of the BEV, so a member's partial grid is zero outside the
+    strips its cameras' rank vectors touch (static per calibration); it sends every other member only the touched
+    strips of that member's plane block (one batched isend / irecv round: all links at once), and the receiver adds
+    the contributions in member order (deterministic).
+    Step 2: where the plane blocks lie in rank order (world == n_frames, or world a multiple of n_frames with P
+    divisible by the group size) the all_gather runs IN PLACE on ``full``; otherwise through a staging slot per rank.
+    Process groups are created collectively by every rank in the same order (constructor)."""
 
-    def __init__(self, plan, rank, device, plane_shape, dtype=torch.float32):
+    def __init__(self, plan, rank, device, plane_shape, dtype=torch.float32, collectives=None):
         self.plan, self.rank, self.device = plan, rank, torch.device(device)
         self.Y, self.X = plane_shape
         self.active = dist.is_initialized() and plan.world > 1
         self.backend = dist.get_backend() if self.active else None
+        if collectives is None:
+            collectives = GlooCollectives() if self.backend == 'gloo' else Collectives()
+        self.c = collectives
         self.groups = {}
         if self.active:
             for ranks in plan.group_of_frame:
@@ -179,16 +225,19 @@ class BevExchange:
                     self.groups[key] = dist.new_group(ranks=ranks)      # every rank calls this, members or not
         P, W = plan.n_planes, plan.world
         kw = dict(dtype=dtype, device=self.device)
+        # blocks of a rank sit in its gather slot at offsets of their CAPACITY (cap planes each; n <= cap are real)
         self.my_blocks = plan.blocks_of(rank)
-        self.slot = max(sum(n for _, _, n in plan.blocks_of(r)) for r in range(W))
+        cap_sum = lambda r: sum(plan.cap_of_frame[f] if len(plan.group_of_frame[f]) > 1 else n  # noqa: E731
+                                for f, _, n in plan.blocks_of(r))
+        self.slot = max(cap_sum(r) for r in range(W))
         self.full = torch.empty(plan.n_frames, P, self.Y, self.X, **kw)
-        # blocks in rank order == planes of `full` in memory order?
+        # blocks in rank order == planes of `full` in memory order (and no padding anywhere)?
         flat, ok = 0, (W * self.slot == plan.n_frames * P)
         for r in range(W):
             for f, p0, n in plan.blocks_of(r):
                 ok = ok and (f * P + p0 == flat)
                 flat += n
-        self.direct = ok and self.backend != 'gloo'
+        self.direct = ok and self.c.native
         if self.direct:
             self.recv = self.full.view(W * self.slot, self.Y, self.X)
             self.send = self.recv[rank * self.slot:(rank + 1) * self.slot]
@@ -199,11 +248,50 @@ class BevExchange:
             self.direct = False                  # staged gather: one extra copy of the grid, always valid
             self.send = torch.zeros(self.slot, self.Y, self.X, **kw)
             self.recv = torch.empty(W * self.slot, self.Y, self.X, **kw)
-        self.partial = {f: torch.empty(P, self.Y, self.X, **kw) for f in plan.frames_of(rank)
-                        if len(plan.group_of_frame[f]) > 1}
-        esz = self.full.element_size()
-        self.bytes_reduce_scatter = sum((len(plan.group_of_frame[f]) - 1) * (P // len(plan.group_of_frame[f])) *
-                                        self.Y * self.X * esz for f in self.partial)
+        # partial buffers of shared frames: G * cap planes, the padding planes stay zero (the pools write [:P])
+        self.partial = {f: torch.zeros(len(plan.group_of_frame[f]) * plan.cap_of_frame[f], self.Y, self.X, **kw)
+                        for f in plan.frames_of(rank) if len(plan.group_of_frame[f]) > 1}
+        self.touched = {}                        # frame -> list over the group's members of tile index tensors
+        self._flat = {}                          # frame -> list over the members of the tiles' flat voxel offsets
+        # sparsity granule: 8 x 8 voxel blocks of the (Y, X) plane (a camera wedge touches ~30 % of them), rows otherwise
+        self.tile_side = 8 if self.Y % 8 == 0 and self.X % 8 == 0 else 0
+        self.strip = 64 if self.tile_side else self.X            # voxels per tile
+        self.n_strips = self.Y * self.X // self.strip            # tiles per plane
+        self._account()
+
+    def tile_of_voxel(self, yx):
+        """Tile index of flattened (Y, X) voxel offsets (int64 tensor)."""
+        if self.tile_side:
+            y, x = yx // self.X, yx % self.X
+            return (y // 8) * (self.X // 8) + x // 8
+        return yx // self.X
+
+    def _voxels_of_tiles(self, tiles):
+        """(len(tiles) * strip,) flat voxel offsets of the given tiles, tile-major."""
+        t = tiles.long()
+        if self.tile_side:
+            ty, tx = t // (self.X // 8), t % (self.X // 8)
+            d = torch.arange(8, device=t.device)
+            yy = (ty[:, None, None] * 8 + d[None, :, None]) * self.X
+            xx = tx[:, None, None] * 8 + d[None, None, :]
+            return (yy + xx).reshape(-1)
+        return (t[:, None] * self.X + torch.arange(self.X, device=t.device)[None, :]).reshape(-1)
+
+    def _account(self):
+        plan, esz = self.plan, self.full.element_size()
+        W = plan.world
+        rs = 0
+        for f in self.partial:
+            G, cap = len(plan.group_of_frame[f]), plan.cap_of_frame[f]
+            if f in self.touched:
+                _, _, n_me = self._my_block(f)
+                me = plan.group_of_frame[f].index(self.rank)
+                rs += sum(int(t.numel()) for j, t in enumerate(self.touched[f]) if j != me) * self.strip * n_me * esz
+            else:
+                rs += (G - 1) * cap * self.Y * self.X * esz
+        self.bytes_reduce_scatter = rs
+        self.bytes_reduce_scatter_dense = sum((len(plan.group_of_frame[f]) - 1) * plan.cap_of_frame[f] * self.Y * self.X *
+                                              esz for f in self.partial)
         self.bytes_all_gather = (W - 1) * self.slot * self.Y * self.X * esz if W > 1 else 0
 
     def _in_place_gather_works(self):
@@ -211,7 +299,7 @@ class BevExchange:
         RCCL document as in-place) with known values, at construction; every rank reaches the same verdict."""
         try:
             self.send.fill_(float(self.rank + 1))
-            dist.all_gather_into_tensor(self.recv, self.send)
+            self.c.all_gather(self.recv, self.send, True)
             got = self.recv.view(self.plan.world, -1)[:, 0].float().cpu()
             ok = bool(torch.equal(got, torch.arange(1, self.plan.world + 1, dtype=torch.float32)))
         except Exception:
@@ -220,52 +308,119 @@ class BevExchange:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return bool(flag.item())
 
-    def _send_block(self, f):
+    def _my_block(self, f):
+        """-> (slot offset, first plane, real planes) of this rank's block of frame f."""
         off = 0
         for bf, p0, n in self.my_blocks:
+            shared = len(self.plan.group_of_frame[bf]) > 1
             if bf == f:
-                return self.send[off:off + n], p0, n
-            off += n
+                return off, p0, n
+            off += self.plan.cap_of_frame[bf] if shared else n
         raise KeyError(f)
 
     def pool_target(self, f):
         """(P, Y, X) tensor the pools of frame ``f`` on this rank write (LSS planes first, then HT)."""
+        P = self.plan.n_planes
         if f in self.partial:
-            return self.partial[f]
-        dst, p0, n = self._send_block(f)
-        assert p0 == 0 and n == self.plan.n_planes
-        return dst
+            return self.partial[f][:P]
+        off, p0, n = self._my_block(f)
+        assert p0 == 0 and n == P
+        return self.send[off:off + n]
+
+    def set_touched(self, touched):
+        """Switch step 1 to the wedge-sparse form.  ``touched``: {frame: 1-D int64 tensor of the tile indices
+        (``tile_of_voxel``: 8 x 8 voxel blocks of the (Y, X) plane, or rows when Y or X is no multiple of 8; ``ex.strip``
+        voxels each, ``ex.n_strips`` per plane) this rank's cameras of that frame can write} for every shared frame this
+        rank holds.  Collective over the world (the index lists
+        of a group's members are exchanged once: they are static per calibration)."""
+        mine = {int(f): torch.as_tensor(t).long().cpu().unique().tolist() for f, t in touched.items() if f in self.partial}
+        if self.active:
+            everyone = [None] * self.plan.world
+            dist.all_gather_object(everyone, mine)
+        else:
+            everyone = [mine]
+        self.touched = {}
+        for f in self.partial:
+            ranks = self.plan.group_of_frame[f]
+            lists = [everyone[r if self.active else 0].get(f) for r in ranks] if self.active else [mine.get(f)]
+            if any(x is None for x in lists):
+                raise ValueError(f'set_touched: a member of frame {f}\'s group gave no strip list')
+            self.touched[f] = [torch.tensor(x, dtype=torch.long, device=self.device) for x in lists]
+            self._flat[f] = [self._voxels_of_tiles(t) for t in self.touched[f]]
+        self._account()
 
     def start(self):
         """Step 1 for every frame whose cameras this rank shares with others.  -> outstanding works."""
         works = []
         for f, buf in self.partial.items():
             ranks = self.plan.group_of_frame[f]
-            dst, p0, n = self._send_block(f)
+            off, p0, n = self._my_block(f)
+            cap = self.plan.cap_of_frame[f]
+            dst = self.send[off:off + cap]
             if not self.active:
-                dst.copy_(buf[p0:p0 + n])
+                dst[:n].copy_(buf[p0:p0 + n])
                 continue
-            group, G = self.groups[tuple(ranks)], len(ranks)
-            if self.backend == 'gloo' or self.plan.n_planes % G != 0:
-                works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True), dst, buf[p0:p0 + n]))
+            group = self.groups[tuple(ranks)]
+            if f in self.touched:
+                works.append(self._start_sparse(f, buf, dst, ranks, group, cap))
             else:
-                works.append((dist.reduce_scatter_tensor(dst, buf, op=dist.ReduceOp.SUM, group=group, async_op=True),
-                              None, None))
+                works.append(('dense', self.c.reduce_scatter(dst, buf, group)))
         return works
+
+    def _start_sparse(self, f, buf, dst, ranks, group, cap):
+        me = ranks.index(self.rank)
+        L = self.strip
+        idx_me, flat_me = self.touched[f][me], self._flat[f][me]
+        P = self.plan.n_planes
+        ops, recv_bufs, keep = [], {}, []
+        for j, r in enumerate(ranks):
+            p0j = min(j * cap, P)
+            nj = min(cap, P - p0j)
+            if j == me or nj == 0 or idx_me.numel() == 0:
+                continue
+            chunk = buf[p0j:p0j + nj].view(nj, -1).index_select(1, flat_me)                 # touched tiles of j's block
+            keep.append(chunk)
+            ops.append(dist.P2POp(dist.isend, chunk, r, group))
+        p0 = min(me * cap, P)
+        n_me = min(cap, P - p0)
+        for j, r in enumerate(ranks):
+            tj = self.touched[f][j]
+            if j == me or n_me == 0 or tj.numel() == 0:
+                continue
+            recv_bufs[j] = torch.empty(n_me, int(tj.numel()) * L, dtype=buf.dtype, device=buf.device)
+            ops.append(dist.P2POp(dist.irecv, recv_bufs[j], r, group))
+        reqs = self.c.exchange(ops)
+        return ('sparse', reqs, f, buf, dst, me, p0, n_me, recv_bufs, keep)
+
+    def _finish_sparse(self, work):
+        _, reqs, f, buf, dst, me, p0, n_me, recv_bufs, _keep = work
+        for q in reqs:
+            q.wait()
+        if n_me == 0:
+            return
+        out = dst[:n_me].view(n_me, -1)
+        out.zero_()
+        for j, tj in enumerate(self.touched[f]):                 # member order: the sum is deterministic
+            if tj.numel() == 0:
+                continue
+            fj = self._flat[f][j]
+            src = buf[p0:p0 + n_me].view(n_me, -1).index_select(1, fj) if j == me else recv_bufs[j]
+            out.index_add_(1, fj, src)                           # a member's offsets are unique: no accumulation order inside
 
     def finish(self, works=()):
         """Waits for step 1 (on the current stream), then the world all_gather; -> (n_frames, P, Y, X)."""
-        for w, dst, src in works:
-            w.wait()
-            if dst is not None:
-                dst.copy_(src)
+        for w in works:
+            if w[0] == 'sparse':
+                self._finish_sparse(w)
+            elif w[1] is not None:
+                w[1].wait()
         if self.active:
-            dist.all_gather_into_tensor(self.recv, self.send)
+            self.c.all_gather(self.recv, self.send, self.direct)
         if not self.direct:
             slots = self.recv.view(self.plan.world, self.slot, self.Y, self.X) if self.active else self.send.unsqueeze(0)
             off = [0] * self.plan.world
             for f, p0, n, r in self.plan.block_owner:
                 if n:
                     self.full[f, p0:p0 + n].copy_(slots[r if self.active else 0, off[r]:off[r] + n])
-                off[r] += n
+                off[r] += self.plan.cap_of_frame[f] if len(self.plan.group_of_frame[f]) > 1 else n
         return self.full

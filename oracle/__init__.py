@@ -59,6 +59,11 @@ def num_threads():
     return int(lib().oracle_num_threads())
 
 
+def set_num_threads(n):
+    """OpenMP team size of the oracle's entry points from now on (1: the scalar port)."""
+    lib().oracle_set_num_threads(int(n))
+
+
 # ----------------------------------------------------------------------------------------------
 # bev_pool_v2
 # ----------------------------------------------------------------------------------------------

@@ -80,3 +80,13 @@ int oracle_num_threads(void)
     return 1;
 #endif
 }
+
+/* test / bench infrastructure: the OpenMP team size of every oracle entry point (1 = the scalar port) */
+void oracle_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

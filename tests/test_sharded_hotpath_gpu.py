@@ -28,7 +28,7 @@ def test_world1_equals_unsharded_step(cuda):
     assert torch.equal(full[:, :Z * cfg.channels], lss) and torch.equal(full[:, Z * cfg.channels:], ht)
 
 
-@pytest.mark.parametrize('world', [2, 4, 8])
+@pytest.mark.parametrize('world', [2, 4, 6, 8])
 def test_camera_split_partials_sum_to_the_whole(cuda, world):
     """Every rank's partial fused grid, summed the way the exchange sums them (emulated on one device), equals the
     unsharded pools."""
@@ -52,3 +52,26 @@ def test_camera_split_partials_sum_to_the_whole(cuda, world):
             sub.pool(sub.ht, d, ft, out=part[Z * cfg.channels:])
             total[f] += part
     torch.testing.assert_close(total, want, rtol=1e-4, atol=1e-4)
+
+
+def test_touched_strips_cover_every_nonzero_of_a_partial(cuda):
+    """The static strip lists of the wedge-sparse exchange (ShardedHotPath -> BevExchange.set_touched): outside them a
+    rank's partial grid is exactly zero, and a camera subset touches only a part of the BEV."""
+    cfg = _small_cfg()
+    X, Y, Z = cfg.bev_xyz
+    P = (Z + 1) * cfg.channels
+    for world, rank in ((4, 1), (6, 4), (8, 6)):
+        sp = hotpath.ShardedHotPath(cfg, cuda, rank, world)          # no process group: set_touched keeps the own lists
+        ex = sp.exchange
+        inputs = sp.make_inputs(seed=7)
+        for f, sub in sp.subs.items():
+            assert f in ex.touched
+            d, ft = inputs[f]
+            tgt = ex.pool_target(f)
+            sub.pool(sub.lss, d, ft, out=tgt[:Z * cfg.channels])
+            sub.pool(sub.ht, d, ft, out=tgt[Z * cfg.channels:])
+            inside = torch.zeros(Y * X, dtype=torch.bool, device=cuda)
+            inside[ex._flat[f][0]] = True
+            outside = tgt.view(P, Y * X)[:, ~inside]
+            assert outside.numel() == 0 or float(outside.abs().max()) == 0.0
+            assert 0 < int(ex.touched[f][0].numel()) < ex.n_strips

@@ -52,7 +52,7 @@ def test_camera_frame_plan_is_a_partition_over_all_ranks():
     assert sharding.CameraFramePlan(6, 1, 8, P).idle_ranks == [6, 7]      # 6 camera-frames cannot feed 8 ranks
 
 
-def _pool_cams(cfg, cams, seed):
+def _pool_cams(cfg, cams, seed, want_ranks=False):
     """Partial LSS BEV (C,Y,X) of one frame from a subset of cameras, via the oracle."""
     import oracle
     from oracle import index_prep as oip
@@ -69,7 +69,8 @@ def _pool_cams(cfg, cams, seed):
     f = feat.numpy().reshape(1, cfg.n_cams, cfg.channels, H, W)[:, cams].transpose(0, 1, 3, 4, 2)
     X, Y, Z = cfg.bev_xyz
     out = oracle.bev_pool_v2(np.ascontiguousarray(d), np.ascontiguousarray(f), rd, rf, rb, (1, Z, Y, X, cfg.channels), st, ln)
-    return out[0].reshape(cfg.channels * Z, Y, X)
+    out = out[0].reshape(cfg.channels * Z, Y, X)
+    return (out, rb) if want_ranks else out
 
 
 def _worker(rank, world, port, q):
@@ -99,9 +100,12 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def _worker_cf(rank, world, port, q, n_frames):
-    """CameraFramePlan + BevExchange on CPU tensors over gloo; per-rank partial pools from the oracle."""
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), OMP_NUM_THREADS='2')
+def _worker_cf(rank, world, port, q, n_frames, mode):
+    """CameraFramePlan + BevExchange on CPU tensors over gloo; per-rank partial pools from the oracle.
+    mode 'gloo': the plumbing form (all_reduce + staged gather); 'rccl_paths': the branches RCCL takes (in-place gather on
+    views of the fused grid, reduce_scatter into the gather slots) with the two missing collectives emulated over gloo
+    (sharding.GlooEmulation); 'sparse': the wedge-sparse step 1 (isend / irecv of the touched strips)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), OMP_NUM_THREADS='1')
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         n_cams = 4
@@ -110,41 +114,59 @@ def _worker_cf(rank, world, port, q, n_frames):
         X, Y, Z = cfg.bev_xyz
         P = cfg.channels * Z
         plan = sharding.CameraFramePlan(n_cams, n_frames, world, P)
-        ex = sharding.BevExchange(plan, rank, 'cpu', (Y, X))
+        coll = sharding.GlooEmulation() if mode in ('rccl_paths', 'sparse_rccl_paths') else None
+        ex = sharding.BevExchange(plan, rank, 'cpu', (Y, X), collectives=coll)
         errs = []
         for it in range(2):                                        # twice: buffers are reused across steps
+            touched = {}
             for f in plan.frames_of(rank):
-                ex.pool_target(f).copy_(torch.from_numpy(_pool_cams(cfg, plan.cams_of(rank, f), seed=f + 10 * it)))
+                part, rb = _pool_cams(cfg, plan.cams_of(rank, f), seed=f + 10 * it, want_ranks=True)
+                ex.pool_target(f).copy_(torch.from_numpy(part))
+                touched[f] = torch.unique(ex.tile_of_voxel(torch.from_numpy(rb.astype(np.int64) % (Y * X))))
+            if mode.startswith('sparse') and it == 0:
+                ex.set_touched(touched)
             full = ex.finish(ex.start())
             want = [torch.from_numpy(_pool_cams(cfg, list(range(n_cams)), seed=f + 10 * it)) for f in range(n_frames)]
             errs.append(max(float((full[f] - want[f]).abs().max()) for f in range(n_frames)))
-        q.put((rank, max(errs), tuple(full.shape), plan.describe()))
+        q.put((rank, max(errs), tuple(full.shape), plan.describe(),
+               dict(direct=bool(ex.direct), rs=ex.bytes_reduce_scatter, rs_dense=ex.bytes_reduce_scatter_dense)))
     except Exception as e:      # report instead of leaving the parent to time out
-        q.put((rank, repr(e), None, None))
+        q.put((rank, repr(e), None, None, None))
         raise
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize('world,n_frames', [(2, 2), (2, 1), (4, 2)])
-def test_camera_frame_exchange_gloo_matches_single_process(world, n_frames):
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('world,n_frames,mode', [
+    (2, 2, 'gloo'), (2, 1, 'gloo'), (4, 2, 'gloo'), (6, 2, 'gloo'),
+    (2, 2, 'rccl_paths'), (4, 2, 'rccl_paths'), (6, 2, 'rccl_paths'), (8, 2, 'rccl_paths'),
+    (2, 1, 'sparse'), (4, 2, 'sparse'), (6, 2, 'sparse_rccl_paths'), (8, 2, 'sparse_rccl_paths')])
+def test_camera_frame_exchange_gloo_matches_single_process(world, n_frames, mode):
     """world 2 x 2 frames: whole frames per rank, only the world all_gather; world 2 x 1 frame: the frame's
-    cameras split over both ranks (reduce step, then gather); world 4 x 2 frames: two groups of two."""
+    cameras split over both ranks (reduce step, then gather); world 4 x 2 frames: two groups of two; world 6 x 2
+    frames (BASELINE configs[3]): groups of THREE, P = 320 planes in blocks of 107 + 107 + 106 (uneven: the partial
+    buffer is padded so that the scatter form stays); world 8 x 2: groups of four, one camera per rank."""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 23000 + (os.getpid() * 7 + world * 13 + n_frames) % 4000
-    procs = [ctx.Process(target=_worker_cf, args=(r, world, port, q, n_frames)) for r in range(world)]
+    port = 23000 + (os.getpid() * 7 + world * 13 + n_frames + len(mode) * 101) % 4000
+    procs = [ctx.Process(target=_worker_cf, args=(r, world, port, q, n_frames, mode)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=480) for _ in procs]
+    res = [q.get(timeout=600) for _ in procs]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, err, shape, desc in res:
+    for rank, err, shape, desc, info in res:
         assert not isinstance(err, str), f'rank {rank} failed: {err}'
         assert err <= 1e-4, f'rank {rank}: sharded fused BEV differs by {err} ({desc})'
         assert shape[0] == n_frames
+        if mode == 'rccl_paths' and world in (2, 4, 8):
+            assert info['direct'], 'plane blocks in rank order: the gather must run in place on the fused grid'
+        if world == 6:
+            assert not info['direct']                       # padded blocks: staged gather
+        if mode.startswith('sparse') and world > n_frames:
+            assert 0 < info['rs'] < info['rs_dense'], info  # a camera wedge touches a fraction of the strips
 
 
 @pytest.mark.timeout(300)
