@@ -241,6 +241,10 @@ size_t ocrf_rasterize_workspace_bytes(int P, int n_views);
  *      extent check: all of its kernels retire at once when the bound holds, and render the call instead when it
  *      does not — exact results either way, no host involvement (hipGraph-capturable), at the price of five
  *      near-empty launches.  Needs means3D, radii and chain_workspace >= ocrf_rasterize_workspace_bytes(P, n_items).
+ *      blend_workgroups: size of the blend's persistent grid (its workgroups draw tile pairs from a ticket queue);
+ *      0 = as many as the device holds at once (fastest alone).  The blend is VALU-bound: two workgroups per CU keep
+ *      most of its speed and leave the other wave slots to kernels of other streams (the hot path renders beside its
+ *      latency-bound poolings with 2 x CUs: -13 % step time at cfg2).
  * Forward only (no n_contrib): training renders through ocrf_rasterize_forward / _backward.
  */
 size_t ocrf_raster_plan_build_workspace_bytes(int P, int n_views);
@@ -259,7 +263,7 @@ int ocrf_rasterize_planned(const void *plan, size_t plan_bytes, int P, int n_pla
                            const float *rotations, const float *bg, int depth_mode, float *out_color,
                            float *out_depth, float *out_final_T, int *radii, int *status, void *workspace,
                            size_t workspace_bytes, int guard, const float *means3D, void *chain_workspace,
-                           size_t chain_workspace_bytes, ocrf_stream_t stream);
+                           size_t chain_workspace_bytes, int blend_workgroups, ocrf_stream_t stream);
 
 /*
  * bev_pool_v2 forward as per-tile MFMA panels (csrc/bev_pool_mfma.hip): out[64 voxels x C] = W[64 x R] . F[R x C]

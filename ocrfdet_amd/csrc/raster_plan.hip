@@ -769,10 +769,11 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
                            const float* bg, int depth_mode, float* out_color, float* out_depth, float* out_final_T,
                            int* radii, int* status, void* workspace, size_t workspace_bytes, int guard,
                            const float* means3D, void* chain_workspace, size_t chain_workspace_bytes,
-                           ocrf_stream_t stream_) {
+                           int blend_workgroups, ocrf_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (!plan || P <= 0 || n_plan_views <= 0 || n_plan_views > 32 || total_kept < 0 || total_kept >= (1l << 30) ||
-      H <= 0 || W <= 0 || n_sets <= 0 || n_items <= 0 || n_items % n_sets || !colors || !opacities || !scales ||
+      H <= 0 || W <= 0 || n_sets <= 0 || n_items <= 0 || n_items % n_sets || blend_workgroups < 0 || !colors ||
+      !opacities || !scales ||
       !rotations || !bg || (depth_mode != 0 && depth_mode != 1) || !out_color || !out_depth || !out_final_T ||
       !status || !workspace)
     return (int)hipErrorInvalidValue;
@@ -812,6 +813,7 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   const int n_work = gx * ((gy + 1) / 2) * n_items;
+  const int want_grid = g_plan_grid ? g_plan_grid : blend_workgroups;      // the diagnostic knob wins
   if (g_plan_stats) {      // diagnostic build (median depth), never used by the product path
     const dim3 sgrid((unsigned)std::min(n_work, resident_blocks(raster_blend_sorted_kernel<true, false, true>)));
     hipLaunchKernelGGL((raster_blend_sorted_kernel<true, false, true>), sgrid, dim3(kBlock), 0, stream, g_plan_stats, P, W, H,
@@ -824,8 +826,8 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
   }
 #define OCRF_BLEND_SORTED(MED, WS)                                                                                   \
   ocrf::launch(OCRF_K_RASTER_BLEND_SORTED, raster_blend_sorted_kernel<MED, WS>,                                       \
-               dim3((unsigned)std::min(n_work, g_plan_grid ? g_plan_grid                                               \
-                                                            : resident_blocks(raster_blend_sorted_kernel<MED, WS>))),   \
+               dim3((unsigned)std::min(n_work, want_grid ? want_grid                                                   \
+                                                          : resident_blocks(raster_blend_sorted_kernel<MED, WS>))),     \
                dim3(kBlock), 0,                                                                                        \
                stream, (unsigned long long*)nullptr, P, W, H, gx, gy, n_items, vps, total_kept, header, item_view,     \
                reinterpret_cast<const unsigned*>(pb + L.s_id), reinterpret_cast<const unsigned*>(pb + L.s_key),        \

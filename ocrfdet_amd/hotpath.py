@@ -58,7 +58,7 @@ def shared_stream(device, role):
 class HotPath:
     def __init__(self, cfg, device, cams=None, index_prep_mode='cached', overlap=True, device_geometry=False,
                  render_mode='planned', render_guard='host', frame_motion=True, frame_offset=0, plan_margin=1.25,
-                 ht_pool_backend='mfma'):
+                 ht_pool_backend='mfma', fuse_frames=False, render_streams=1, blend_workgroups='auto'):
         """``cams``: optional list of camera indices this instance owns (camera sharding).
         ``index_prep_mode``: 'cached' — rank vectors computed once per calibration, the reference's
         ``accelerate=True`` intent; 'per_step' — recomputed inside every ``step()`` by the HIP index
@@ -78,6 +78,12 @@ class HotPath:
         # 3.2 m block beside the rig collects thousands of rows — make the per-tile MFMA chain the launch's tail).
         assert ht_pool_backend in ('mfma', 'tile')
         self.ht_pool_backend = ht_pool_backend
+        self.fuse_frames = bool(fuse_frames)      # planned renders: consecutive frames in one plan / one launch pair
+        self.render_streams = max(1, int(render_streams))      # side HIP streams the frames' renders are dealt over
+        # size of the planned blend's persistent grid per frame (int, or a sequence with one entry per frame; 0 = what
+        # the device holds).  'auto': beside the main chain (overlap) the VALU-bound blend takes two workgroups per CU
+        # and leaves the other wave slots to the latency-bound poolings / HOA of the main stream (cfg2: 0.344 -> 0.30 ms)
+        self.blend_workgroups = blend_workgroups
         self.cams = list(range(cfg.n_cams)) if cams is None else list(cams)
         self.batch = cfg.batch * cfg.n_frames                  # frames ride along as batch entries
         assert index_prep_mode in ('cached', 'per_step')
@@ -225,47 +231,74 @@ class HotPath:
         self._opac_flat = None
 
     def _plans(self):
+        """Render plans: every frame sees the SAME Gaussian means (the voxel grid) through its own cameras with its own
+        parameter set, so consecutive frames share one plan of up to 32 views (``raster_plan.RasterPlan`` with one
+        Gaussian set per frame): one update launch and one persistent blend launch for all of them instead of a pair
+        per frame.  -> list of (plan, first frame, n frames, stacked parameters)."""
         if self.render_plans is None:
             H, W = self.cfg.input_size
-            self.render_plans = [
-                raster_plan.RasterPlan(self.voxel_xyz[b].reshape(-1, 3), self.frame_cams[b]['packed'], H, W,
-                                       scales=self.frame_gauss[b]['scales'], rotations=self.frame_gauss[b]['rotations'],
-                                       margin=self.plan_margin) for b in range(self.batch)]
+            n_cam = len(self.cams)
+            same = all(torch.equal(self.voxel_xyz[b], self.voxel_xyz[0]) for b in range(1, self.batch))
+            per = max(1, 32 // n_cam) if (same and self.fuse_frames) else 1
+            self.render_plans = []
+            for f0 in range(0, self.batch, per):
+                fr = list(range(f0, min(f0 + per, self.batch)))
+                cams = torch.cat([self.frame_cams[b]['packed'] for b in fr])
+                g = {k: torch.stack([self.frame_gauss[b][k] for b in fr]).contiguous() for k in ('rgb', 'opacity', 'scales', 'rotations')}
+                plan = raster_plan.RasterPlan(self.voxel_xyz[f0].reshape(-1, 3), cams, H, W, scales=g['scales'],
+                                              rotations=g['rotations'], margin=self.plan_margin)
+                # item z = view z of the plan (frame-major), rendered with the parameter set of its frame
+                g['item_view'] = torch.arange(len(fr) * n_cam, dtype=torch.int32, device=self.device)
+                self.render_plans.append((plan, f0, len(fr), g))
         return self.render_plans
 
     def check_render_plans(self):
         """Synchronising check of the render plans' extent bound (``render_guard='host'``): raises if a planned
         render since the last check was not valid."""
         for p in (self.render_plans or []):
-            p.check()
+            p[0].check()
 
-    def _render_frame(self, b, want_n_contrib, tag):
+    def _render_per_call(self, b, want_n_contrib, tag):
         cfg, rc, g = self.cfg, self.frame_cams[b], self.frame_gauss[b]
         H, W = cfg.input_size
-        if self.render_mode == 'planned' and not want_n_contrib:
-            return self._plans()[b].render(g['rgb'], g['opacity'], g['scales'], g['rotations'], self.bg,
-                                           guard=self.render_guard)
         xyz = self.voxel_xyz[b].reshape(-1, 3)
         return rasterize_views(xyz, g['rgb'], g['opacity'], g['scales'], g['rotations'], rc['vm'], rc['pm'], rc['tfx'],
                                rc['tfy'], H, W, self.bg, packed_cameras=rc['packed'], want_n_contrib=want_n_contrib,
                                workspace_tag=tag)
 
+    def _render_planned(self, entry):
+        plan, f0, nf, g = entry
+        bw = self.blend_workgroups
+        if bw == 'auto':
+            bw = 2 * torch.cuda.get_device_properties(self.device).multi_processor_count if self.overlap else 0
+        elif not isinstance(bw, int):
+            bw = int(bw[min(f0, len(bw) - 1)])
+        out = plan.render(g['rgb'], g['opacity'], g['scales'], g['rotations'], self.bg, guard=self.render_guard,
+                          item_view=g['item_view'] if nf > 1 else None, blend_workgroups=bw)
+        n = len(self.cams)
+        return [{k: (v[i * n:(i + 1) * n] if k != 'status' else v) for k, v in out.items()} for i in range(nf)]
+
     def render(self, streams=None, want_n_contrib=False):
         """All owned cameras of every frame: list (one per frame) of dicts (``color``, ``depth``, ``final_T``, ...).
-        ``streams``: a HIP stream per frame (frames on different streams get their own scratch buffer);
-        the caller joins them.  One call per frame on purpose: a single 12-view call
-        (``rasterize_sets``) is 7 % faster alone but 17 % slower beside the main stream's kernels — a
-        4 224-workgroup blend leaves them no room to interleave.  The step is inference: the per-pixel contributor
-        index (read only by the backward) is not tracked unless ``want_n_contrib`` (which renders per call)."""
-        if self.render_mode == 'planned' and not want_n_contrib:
-            self._plans()                     # built (one synchronisation each) before anything is enqueued on a side stream
+        ``streams``: a HIP stream per frame (frames on different streams get their own scratch buffer); the caller
+        joins them.  The step is inference: the per-pixel contributor index (read only by the backward) is not
+        tracked unless ``want_n_contrib`` (which renders per call, one call per frame)."""
+        planned = self.render_mode == 'planned' and not want_n_contrib
         outs = []
+        if planned:
+            for entry in self._plans():       # built (one synchronisation each) before anything is enqueued
+                if streams is None:
+                    outs.extend(self._render_planned(entry))
+                else:
+                    with torch.cuda.stream(streams[entry[1]]):
+                        outs.extend(self._render_planned(entry))
+            return outs
         for b in range(self.batch):
             if streams is None:
-                outs.append(self._render_frame(b, want_n_contrib, 'raster'))
+                outs.append(self._render_per_call(b, want_n_contrib, 'raster'))
             else:
                 with torch.cuda.stream(streams[b]):
-                    outs.append(self._render_frame(b, want_n_contrib, f'raster{streams.index(streams[b])}'))
+                    outs.append(self._render_per_call(b, want_n_contrib, f'raster{streams.index(streams[b])}'))
         return outs
 
     @property
@@ -353,10 +386,11 @@ class HotPath:
         if fork:
             cur = torch.cuda.current_stream(self.device)
             if not self._side:
-                self._side.append(shared_stream(self.device, 'render'))
-            side = self._side[0]
-            side.wait_stream(cur)                     # inputs (and last step's consumers) are ordered before
-            rendered = self.render([side] * self.batch)
+                self._side = [shared_stream(self.device, 'render' if k == 0 else f'render{k}')
+                              for k in range(self.render_streams)]
+            for side in self._side:
+                side.wait_stream(cur)                 # inputs (and last step's consumers) are ordered before
+            rendered = self.render([self._side[b % len(self._side)] for b in range(self.batch)])
         # HOA-1/2 do not read the pooled BEV and are latency chains of small kernels: issued FIRST, they run in the
         # shadow of the render stream's chip-filling preprocess instead of the poolings competing with it
         # (cfg2 step 0.402 -> 0.388 ms; on a stream of their own: 0.41-0.47 ms)
@@ -387,7 +421,8 @@ class HotPath:
             # the pools and HOA-3 are MIOpen territory, not part of this path
             out.extend(self.hoa_step(ht, ob))
         if fork:
-            cur.wait_stream(side)                     # join: everything the step returns is ordered on `cur`
+            for side in self._side:
+                cur.wait_stream(side)                 # join: everything the step returns is ordered on `cur`
         return tuple(out)
 
     @property

@@ -53,7 +53,7 @@ def test_cfg2_render_both_camera_conventions(cuda, oracle_lib, convention):
 def test_cfg4_rank_triples_pools_and_render_at_512x1408(cuda, oracle_lib):
     cfg = _one_frame(CFG4)
     assert cfg.feat_hw == (32, 88)
-    hp = hotpath.HotPath(cfg, cuda)
+    hp = hotpath.HotPath(cfg, cuda, ht_pool_backend='tile')      # the per-step path below pools with the tile kernel
     depth, feat = hp.make_inputs(seed=2)
     lss, ht, rendered = hp.step(depth, feat)[:3]
     torch.cuda.synchronize()

@@ -1,0 +1,42 @@
+"""Diagnostic: the cfg2 step time under library knobs (ocrf_tune_set key=value pairs), one process per setting:
+    python tools/ab_step_knobs.py 11=768 [10=1 ...] [--ht tile|mfma] [--steps 200]"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ocrfdet_amd import _lib, hotpath, synthetic  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('knobs', nargs='*')
+ap.add_argument('--steps', type=int, default=200)
+ap.add_argument('--ht', default='mfma')
+ap.add_argument('--render-mode', default='planned')
+ap.add_argument('--fuse', type=int, default=0)
+ap.add_argument('--rstreams', type=int, default=1)
+ap.add_argument('--bw', default='auto', help="blend workgroups: auto | n | n0,n1 (per frame)")
+a = ap.parse_args()
+for kv in a.knobs:
+    k, v = kv.split('=')
+    _lib.check(_lib.lib().ocrf_tune_set(int(k), int(v)), 'tune')
+dev = torch.device('cuda:0')
+cfg = synthetic.CONFIGS['cfg2_6cam_2frame_bev200x200_render_hoa']
+hp = hotpath.HotPath(cfg, dev, ht_pool_backend=a.ht, render_mode=a.render_mode, fuse_frames=bool(a.fuse), render_streams=a.rstreams,
+                     blend_workgroups=('auto' if a.bw == 'auto' else (int(a.bw) if ',' not in a.bw else [int(x) for x in a.bw.split(',')])))
+depth, feat = hp.make_inputs(0)
+for _ in range(30):
+    hp.step(depth, feat)
+torch.cuda.synchronize()
+ts = []
+for _ in range(5):
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        hp.step(depth, feat)
+    torch.cuda.synchronize()
+    ts.append((time.perf_counter() - t0) / a.steps * 1e3)
+hp.check_render_plans()
+ts.sort()
+print(f'{" ".join(a.knobs) or "defaults":20s} ht={a.ht} render={a.render_mode} fuse={a.fuse} rstreams={a.rstreams} bw={a.bw}: median {ts[2]:.4f} min {ts[0]:.4f} max {ts[-1]:.4f} ms/step', flush=True)

@@ -11,7 +11,7 @@ from ocrfdet_amd import _lib, hotpath, synthetic  # noqa: E402
 
 dev = torch.device('cuda:0')
 cfg = synthetic.CONFIGS['cfg2_6cam_2frame_bev200x200_render_hoa']
-hp = hotpath.HotPath(cfg, dev)
+hp = hotpath.HotPath(cfg, dev, fuse_frames=False)
 H, W = cfg.input_size
 gx, gy = (W + 15) // 16, (H + 15) // 16
 n_wg = gx * ((gy + 1) // 2) * len(hp.cams)
@@ -19,13 +19,13 @@ buf = torch.zeros(n_wg * 4 * 8, dtype=torch.int64, device=dev)
 hp.render()
 torch.cuda.synchronize()
 _lib.lib().ocrf_diag_plan_stats(_lib.ptr(buf))
-hp._render_frame(0, False, 'raster')
+hp._render_planned(hp.render_plans[0])
 torch.cuda.synchronize()
 _lib.lib().ocrf_diag_plan_stats(None)
 s = buf.cpu().numpy().reshape(n_wg, 4, 8).astype(np.float64)
 cyc = s[:, :, :3]
 tot = cyc.sum(2)
-print('workgroups', n_wg, ' kept per view', hp.render_plans[0].kept)
+print('workgroups', n_wg, ' kept per view', hp.render_plans[0][0].kept)
 print('cycles per wave (100 MHz ticks x ?): scan %.0f stage %.0f blend %.0f  -> shares %s' % (
     cyc[..., 0].mean(), cyc[..., 1].mean(), cyc[..., 2].mean(), np.round(cyc.mean((0, 1)) / cyc.mean((0, 1)).sum(), 3)))
 wg_time = tot.max(1)
