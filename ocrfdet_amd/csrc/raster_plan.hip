@@ -521,9 +521,9 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
           tot += c;
         }
         if (reach[j]) l_list[w][base + lrank[j]] = (unsigned short)ri;
-        if (ri == 0) {                         // pad: the loop reads two entries per trip
-          l_list[w][tot] = (unsigned short)kStageP;
-          l_list[w][tot + 1] = (unsigned short)kStageP;
+        if (ri == 0) {                         // pad: the loop reads two entries per trip, two trips ahead
+#pragma unroll
+          for (int q = 0; q < 6; ++q) l_list[w][tot + q] = (unsigned short)kStageP;
         }
       }
       int n_mine = 0;                          // length of THIS wave's list
@@ -537,16 +537,31 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
       // ---- blend this wave's records front to back.  Every decision of forward.cu:320-352 is ONE compare feeding
       // ONE select (see raster_blend_kernel in rasterize.hip for the derivation); same arithmetic, same order.
       {
+        // software pipeline, two deep: the records of the NEXT trip and the list entries of the one after it are
+        // requested before this trip's arithmetic (index -> record is two dependent LDS reads; with two workgroups per
+        // CU there are too few waves to hide them otherwise).  The list is padded with no-op entries.
         const unsigned short* mylist = l_list[wave];
         f2 h = T - splat(0.5f);
+        float4 na[2], nb[2], nc[2];
+        {
+          const unsigned p0 = *reinterpret_cast<const unsigned*>(mylist);
+          const int i0 = (int)(p0 & 0xFFFFu), i1 = (int)(p0 >> 16);
+          na[0] = l_a[i0]; nb[0] = l_b[i0]; nc[0] = l_c[i0];
+          na[1] = l_a[i1]; nb[1] = l_b[i1]; nc[1] = l_c[i1];
+        }
+        unsigned pair_next = *reinterpret_cast<const unsigned*>(mylist + 2);
         for (int k = 0; k < n_mine; k += 2) {
           if (__ballot((__float_as_int(T.x) & __float_as_int(T.y)) >= 0) == 0ull) break;      // every pixel stopped
           if constexpr (STATS) n_eval += 2;
-          const unsigned pair = *reinterpret_cast<const unsigned*>(mylist + k);
-          const int i0 = (int)(pair & 0xFFFFu), i1 = (int)(pair >> 16);
           float4 ra[2], rb[2], rc4[2];
-          ra[0] = l_a[i0]; rb[0] = l_b[i0]; rc4[0] = l_c[i0];
-          ra[1] = l_a[i1]; rb[1] = l_b[i1]; rc4[1] = l_c[i1];
+          ra[0] = na[0]; rb[0] = nb[0]; rc4[0] = nc[0];
+          ra[1] = na[1]; rb[1] = nb[1]; rc4[1] = nc[1];
+          {
+            const int i0 = (int)(pair_next & 0xFFFFu), i1 = (int)(pair_next >> 16);
+            na[0] = l_a[i0]; nb[0] = l_b[i0]; nc[0] = l_c[i0];
+            na[1] = l_a[i1]; nb[1] = l_b[i1]; nc[1] = l_c[i1];
+            pair_next = *reinterpret_cast<const unsigned*>(mylist + k + 4);
+          }
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             const float4 a = ra[u];

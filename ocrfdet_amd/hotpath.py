@@ -407,10 +407,17 @@ class HotPath:
             self._prep_stream.wait_stream(cur0)
             with torch.cuda.stream(self._prep_stream):
                 prepared = self.prepare_indices_hip(sync=False)
-        ob = self.hoa_opacity_bev() if self.cfg.hoa else None
+        # HOA-1/2 need nothing of the poolings and the poolings nothing of them: with the planned render (a memory-bound
+        # update kernel, then the VALU-bound blend on two workgroups per CU) the poolings go FIRST — they meet the
+        # side stream's update and the start of its blend instead of its middle (cfg2: 0.305 -> 0.292 ms); with the
+        # per-call render, whose chip-filling preprocess opens the side stream, HOA-1/2 first was better (round 2)
+        hoa_first = getattr(self, 'hoa_first', self.render_mode != 'planned')
+        ob = self.hoa_opacity_bev() if (self.cfg.hoa and hoa_first) else None
         if prepared is not None:
             torch.cuda.current_stream(self.device).wait_stream(self._prep_stream)
         lss, ht = self.pool_step(depth, feat, prepared)
+        if self.cfg.hoa and not hoa_first:
+            ob = self.hoa_opacity_bev()
         out = [lss, ht]
         if fork:
             out.append(rendered)
