@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "launch.h"
 #include "ocrf_hip.h"
@@ -45,6 +46,11 @@ constexpr int kHeaderInts = 16;                   // magic, P, V, H, W, gx, gy, 
 #endif
 constexpr int kStageP = OCRF_PLAN_STAGE;          // records staged per batch (a tile pair saturates after ~110 at cfg2)
 constexpr int kScanUnrollP = OCRF_PLAN_SCAN;      // rect batches in flight in the scan
+#ifndef OCRF_PLAN_TRIP
+#define OCRF_PLAN_TRIP 2
+#endif
+constexpr int kTrip = OCRF_PLAN_TRIP;             // records per trip of the blend loop (2 or 4)
+static_assert(kTrip == 2 || kTrip == 4, "records per trip");
 constexpr int kStageParts = kBlock / kStageP;     // threads per staged record: each tests 4 / kStageParts waves
 constexpr int kReachPerThread = 4 / kStageParts;
 constexpr int kSrcWaves = kStageP / 64;           // waves that hold one copy of the staged batch
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
   if (skip_if && *skip_if != 0) return;      // the plan's bound does not hold this step: the armed per-call chain renders
   __shared__ unsigned l_pos[kCapPos];
   __shared__ float4 l_a[kStageP + 1], l_b[kStageP + 1], l_c[kStageP + 1];
-  __shared__ unsigned short l_list[4][kStageP + 8];
+  __shared__ unsigned short l_list[4][kStageP + 3 * kTrip + 2];
   __shared__ int l_wtot[kScanUnrollP * 4];
   __shared__ int l_lcnt[kSrcWaves][4];        // [source wave of the batch copy][destination wave]
   __shared__ int l_work;
@@ -377,6 +383,7 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
   f2 T = f2{inside0 ? 1.0f : -1.0f, inside1 ? 1.0f : -1.0f};
   f2 C0 = splat(0.f), C1 = splat(0.f), C2 = splat(0.f);
   f2 D = splat(MEDIAN ? 15.0f : 0.0f);
+  f2 h = splat(0.5f);                          // T - 0.5 carried from record to record while the median test is live
 
   int scan = 0, npos = 0;
   bool all_done = false;
@@ -394,7 +401,11 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
   while (!all_done) {
     // ---- scan: positions of the records whose rect covers this tile pair, in list (= blend) order ----
     while (scan < nv && npos < kStageP) {
+#ifdef OCRF_PLAN_SCAN_WIDE_FIRST
+      const int n_u = kScanUnrollP;
+#else
       const int n_u = (scan < kBlock) ? 1 : kScanUnrollP;      // a dense tile pair fills its first batch from 256 rects
+#endif
       unsigned code[kScanUnrollP];
       bool hit[kScanUnrollP];
 #pragma unroll
@@ -442,6 +453,7 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
       // kReachPerThread of the four waves (the copies of the batch live in waves [part * kSrcWaves, ...)) ----
       const int part = tid / kStageP, ri = tid % kStageP;
       bool reach[kReachPerThread];
+      bool simple = false;                     // see the blend loop: no min(0.99, .) and no `power > 0` test needed
 #pragma unroll
       for (int j = 0; j < kReachPerThread; ++j) reach[j] = false;
       if (ri < ns) {
@@ -470,6 +482,7 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
         // skips it too (forward.cu:331-333).  Anything unusual (NaN, non-convex conic) is evaluated in full.
         const float qa = -2.f * a.w, qc = -2.f * a.z, qb = con.z;
         const bool convex = (qa > 0.f) && (qc > 0.f) && (qa * qc - qb * qb > 0.f);
+        simple = (o <= 0.99f) && (qa > 0.f) && (qc > 0.f) && (qb * qb <= 0.9990234375f * (qa * qc));
         const bool never = thr >= 0.f;                         // opacity < 1/255: no pixel ever blends it
         const float lim = -thr;
         const float inv_a = 1.f / qa, inv_c = 1.f / qc;
@@ -520,10 +533,10 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
           if (sw < src) base += c;
           tot += c;
         }
-        if (reach[j]) l_list[w][base + lrank[j]] = (unsigned short)ri;
+        if (reach[j]) l_list[w][base + lrank[j]] = (unsigned short)(ri | (simple ? 0x8000 : 0));
         if (ri == 0) {                         // pad: the loop reads two entries per trip, two trips ahead
 #pragma unroll
-          for (int q = 0; q < 6; ++q) l_list[w][tot + q] = (unsigned short)kStageP;
+          for (int q = 0; q < 3 * kTrip; ++q) l_list[w][tot + q] = (unsigned short)kStageP;
         }
       }
       int n_mine = 0;                          // length of THIS wave's list
@@ -536,78 +549,119 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
 
       // ---- blend this wave's records front to back.  Every decision of forward.cu:320-352 is ONE compare feeding
       // ONE select (see raster_blend_kernel in rasterize.hip for the derivation); same arithmetic, same order.
+      // Measured issue costs on gfx950 (tools/ubench/valu_cost.hip; plain VALU = 1): packed f32 1.4 (for two
+      // pixels), v_exp_f32 2.4, a compare + select pair 2.5 — the selects are 40 % of a record's cost, so the loop
+      // leaves out every decision whose outcome is known for the whole wave:
+      //   * SIMPLE records (flag in the list entry, set at staging): opacity <= 0.99, so min(0.99, alpha) is the
+      //     identity (exp2 of a non-positive power is <= 1), and a conic with B^2 <= (1 - 2^-10) A C, for which the
+      //     computed power is <= 0 at every pixel (its rounding error is ~1e-3 of that margin): no `power > 0` test;
+      //   * the median-depth test runs only while some pixel of the wave still has T > 0.5 (T never rises).
       {
-        // software pipeline, two deep: the records of the NEXT trip and the list entries of the one after it are
-        // requested before this trip's arithmetic (index -> record is two dependent LDS reads; with two workgroups per
-        // CU there are too few waves to hide them otherwise).  The list is padded with no-op entries.
-        const unsigned short* mylist = l_list[wave];
-        f2 h = T - splat(0.5f);
-        float4 na[2], nb[2], nc[2];
-        {
-          const unsigned p0 = *reinterpret_cast<const unsigned*>(mylist);
-          const int i0 = (int)(p0 & 0xFFFFu), i1 = (int)(p0 >> 16);
-          na[0] = l_a[i0]; nb[0] = l_b[i0]; nc[0] = l_c[i0];
-          na[1] = l_a[i1]; nb[1] = l_b[i1]; nc[1] = l_c[i1];
-        }
-        unsigned pair_next = *reinterpret_cast<const unsigned*>(mylist + 2);
-        for (int k = 0; k < n_mine; k += 2) {
-          if (__ballot((__float_as_int(T.x) & __float_as_int(T.y)) >= 0) == 0ull) break;      // every pixel stopped
-          if constexpr (STATS) n_eval += 2;
-          float4 ra[2], rb[2], rc4[2];
-          ra[0] = na[0]; rb[0] = nb[0]; rc4[0] = nc[0];
-          ra[1] = na[1]; rb[1] = nb[1]; rc4[1] = nc[1];
-          {
-            const int i0 = (int)(pair_next & 0xFFFFu), i1 = (int)(pair_next >> 16);
-            na[0] = l_a[i0]; nb[0] = l_b[i0]; nc[0] = l_c[i0];
-            na[1] = l_a[i1]; nb[1] = l_b[i1]; nc[1] = l_c[i1];
-            pair_next = *reinterpret_cast<const unsigned*>(mylist + k + 4);
+        auto blend_one = [&](auto med_tag, auto simple_tag, const float4 a, const float4 b, const float4 c) {
+          constexpr bool MED = decltype(med_tag)::value, SIMPLE = decltype(simple_tag)::value;
+          const float cr = b.y, cg = b.z, cb = c.x, dep = c.y;
+          // power = -0.5 (cxx dx dx + czz dy dy) - cxy dx dy, in the reference's order (forward.cu:320-323)
+          const float dx = a.x - pixf_x;
+          const float qx = (a.w * dx) * dx;
+          const float bx = b.w * dx;
+          const f2 dy = splat(a.y) - pixf_y;
+          const f2 qy = (splat(a.z) * dy) * dy;
+          const f2 power = (splat(qx) + qy) - splat(bx) * dy;          // qx, qy carry the -0.5 (staging)
+          if constexpr (WSKIP) {
+            const float thr = c.w;
+            if (__ballot(!((power.x <= thr) & (power.y <= thr))) == 0ull) return;
           }
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const float4 a = ra[u];
-            const float4 b = rb[u];
-            const float cr = b.y, cg = b.z, cb = rc4[u].x, dep = rc4[u].y;
-            // power = -0.5 (cxx dx dx + czz dy dy) - cxy dx dy, in the reference's order (forward.cu:320-323)
-            const float dx = a.x - pixf_x;
-            const float qx = (a.w * dx) * dx;
-            const float bx = b.w * dx;
-            const f2 dy = splat(a.y) - pixf_y;
-            const f2 qy = (splat(a.z) * dy) * dy;
-            const f2 power = (splat(qx) + qy) - splat(bx) * dy;          // qx, qy carry the -0.5 (staging)
-            if constexpr (WSKIP) {
-              const float thr = rc4[u].w;
-              if (__ballot(!((power.x <= thr) & (power.y <= thr))) == 0ull) continue;
-            }
-            const f2 p2 = power * splat(1.44269504088896340736f);       // __expf(x) = v_exp_f32(log2(e) x)
-            f2 G;
-            G.x = __builtin_amdgcn_exp2f(p2.x);
-            G.y = __builtin_amdgcn_exp2f(p2.y);
-            f2 alpha = splat(b.x) * G;
+          const f2 p2 = power * splat(1.44269504088896340736f);       // __expf(x) = v_exp_f32(log2(e) x)
+          f2 G;
+          G.x = __builtin_amdgcn_exp2f(p2.x);
+          G.y = __builtin_amdgcn_exp2f(p2.y);
+          f2 alpha = splat(b.x) * G;
+          if constexpr (SIMPLE) {
+            alpha.x = (alpha.x < 1.0f / 255.0f) ? 0.f : alpha.x;
+            alpha.y = (alpha.y < 1.0f / 255.0f) ? 0.f : alpha.y;
+          } else {
             alpha.x = fminf(0.99f, alpha.x);
             alpha.y = fminf(0.99f, alpha.y);
             alpha.x = ((power.x > 0.0f) | (alpha.x < 1.0f / 255.0f)) ? 0.f : alpha.x;
             alpha.y = ((power.y > 0.0f) | (alpha.y < 1.0f / 255.0f)) ? 0.f : alpha.y;
-            const f2 test_T = T * (splat(1.0f) - alpha);
-            const f2 aT = alpha * T;
-            const bool stop0 = test_T.x < 0.0001f, stop1 = test_T.y < 0.0001f;
-            f2 wgt;
-            wgt.x = stop0 ? 0.f : aT.x;
-            wgt.y = stop1 ? 0.f : aT.y;
-            C0 = fma2(splat(cr), wgt, C0);
-            C1 = fma2(splat(cg), wgt, C1);
-            C2 = fma2(splat(cb), wgt, C2);
-            if constexpr (MEDIAN) {
+          }
+          const f2 test_T = T * (splat(1.0f) - alpha);
+          const f2 aT = alpha * T;
+          const bool stop0 = test_T.x < 0.0001f, stop1 = test_T.y < 0.0001f;
+          f2 wgt;
+          wgt.x = stop0 ? 0.f : aT.x;
+          wgt.y = stop1 ? 0.f : aT.y;
+          C0 = fma2(splat(cr), wgt, C0);
+          C1 = fma2(splat(cg), wgt, C1);
+          C2 = fma2(splat(cb), wgt, C2);
+          if constexpr (MEDIAN) {
+            if constexpr (MED) {
               const f2 h2 = test_T - splat(0.5f);
               const f2 cross = h * h2;
               D.x = (cross.x < 0.f) ? dep : D.x;
               D.y = (cross.y < 0.f) ? dep : D.y;
               h = h2;
-            } else {
-              D = fma2(splat(dep), wgt, D);
             }
-            T.x = stop0 ? -fabsf(T.x) : test_T.x;
-            T.y = stop1 ? -fabsf(T.y) : test_T.y;
+          } else {
+            D = fma2(splat(dep), wgt, D);
           }
+          T.x = stop0 ? -fabsf(T.x) : test_T.x;
+          T.y = stop1 ? -fabsf(T.y) : test_T.y;
+        };
+        // software pipeline, two deep: the records of the NEXT trip and the list entries of the one after it are
+        // requested before this trip's arithmetic (index -> record is two dependent LDS reads; with two workgroups per
+        // CU there are too few waves to hide them otherwise).  The list is padded with no-op entries.
+        const unsigned short* mylist = l_list[wave];
+        constexpr int TR = kTrip;                // records per trip: independent exponent / alpha chains in flight
+        float4 na[TR], nb[TR], nc[TR];
+        unsigned fl_next[TR / 2];
+        auto fetch = [&](const unsigned* pairs) {
+#pragma unroll
+          for (int u = 0; u < TR / 2; ++u) {
+            const unsigned pair = pairs[u];
+            const int i0 = (int)(pair & 0x1FFu), i1 = (int)((pair >> 16) & 0x1FFu);
+            na[2 * u] = l_a[i0]; nb[2 * u] = l_b[i0]; nc[2 * u] = l_c[i0];
+            na[2 * u + 1] = l_a[i1]; nb[2 * u + 1] = l_b[i1]; nc[2 * u + 1] = l_c[i1];
+            fl_next[u] = pair;
+          }
+        };
+        unsigned pair_next[TR / 2];
+#pragma unroll
+        for (int u = 0; u < TR / 2; ++u) pair_next[u] = *reinterpret_cast<const unsigned*>(mylist + 2 * u);
+        fetch(pair_next);
+#pragma unroll
+        for (int u = 0; u < TR / 2; ++u) pair_next[u] = *reinterpret_cast<const unsigned*>(mylist + TR + 2 * u);
+        auto trip = [&](auto med_tag, int k) {
+          if constexpr (STATS) n_eval += TR;
+          float4 ra[TR], rb[TR], rc4[TR];
+          unsigned fl[TR / 2];
+#pragma unroll
+          for (int u = 0; u < TR; ++u) { ra[u] = na[u]; rb[u] = nb[u]; rc4[u] = nc[u]; }
+#pragma unroll
+          for (int u = 0; u < TR / 2; ++u) fl[u] = __builtin_amdgcn_readfirstlane(fl_next[u]);
+          fetch(pair_next);
+#pragma unroll
+          for (int u = 0; u < TR / 2; ++u) pair_next[u] = *reinterpret_cast<const unsigned*>(mylist + k + 2 * TR + 2 * u);
+#pragma unroll
+          for (int u = 0; u < TR; ++u) {
+            const bool simple_rec = (fl[u / 2] >> ((u & 1) ? 31 : 15)) & 1u;
+            if (simple_rec) blend_one(med_tag, std::true_type{}, ra[u], rb[u], rc4[u]);
+            else blend_one(med_tag, std::false_type{}, ra[u], rb[u], rc4[u]);
+          }
+        };
+        int k = 0;
+        if constexpr (MEDIAN) {
+          h = T - splat(0.5f);
+          for (; k < n_mine; k += TR) {
+            // live <=> sign bit of T clear; the median test is needed while some pixel is still above 0.5
+            if (__ballot((__float_as_int(T.x) & __float_as_int(T.y)) >= 0) == 0ull) { k = n_mine; break; }
+            if (__ballot((T.x > 0.5f) | (T.y > 0.5f)) == 0ull) break;
+            trip(std::true_type{}, k);
+          }
+        }
+        for (; k < n_mine; k += TR) {
+          if (__ballot((__float_as_int(T.x) & __float_as_int(T.y)) >= 0) == 0ull) break;      // every pixel stopped
+          trip(std::false_type{}, k);
         }
       }
       // every pixel saturated -> stop (forward.cu:304-307)
@@ -830,7 +884,7 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
   const int n_work = gx * ((gy + 1) / 2) * n_items;
   const int want_grid = g_plan_grid ? g_plan_grid : blend_workgroups;      // the diagnostic knob wins
   if (g_plan_stats) {      // diagnostic build (median depth), never used by the product path
-    const dim3 sgrid((unsigned)std::min(n_work, resident_blocks(raster_blend_sorted_kernel<true, false, true>)));
+    const dim3 sgrid((unsigned)std::min(n_work, want_grid ? want_grid : resident_blocks(raster_blend_sorted_kernel<true, false, true>)));
     hipLaunchKernelGGL((raster_blend_sorted_kernel<true, false, true>), sgrid, dim3(kBlock), 0, stream, g_plan_stats, P, W, H,
                        gx, gy, n_items, vps, total_kept, header, item_view, reinterpret_cast<const unsigned*>(pb + L.s_id),
                        reinterpret_cast<const unsigned*>(pb + L.s_key), reinterpret_cast<const float2*>(pb + L.s_pix),

@@ -129,7 +129,7 @@ def bev_pool_v2_backward(out_grad, depth, feat, ranks_depth, ranks_feat, ranks_b
 # ----------------------------------------------------------------------------------------------
 def rasterize_forward(means3D, colors_precomp, opacities, scales, rotations, viewmatrix,
                       projmatrix, tanfovx, tanfovy, image_height, image_width, bg,
-                      scale_modifier=1.0, depth_mode="median"):
+                      scale_modifier=1.0, depth_mode="median", ambiguity=None):
     """Forward of ``GaussianRasterizer`` with ``colors_precomp`` and (scales, rotations)
     (rasterize_points.cu:35-115 -> rasterizer_impl.cu:198-336).  Returns a dict with
     ``color`` (3,H,W), ``depth`` (1,H,W), ``final_T`` (H,W), ``n_contrib`` (H,W), ``radii`` (P),
@@ -149,12 +149,21 @@ def rasterize_forward(means3D, colors_precomp, opacities, scales, rotations, vie
         depths=np.zeros((P,), np.float32), conic_opacity=np.zeros((P, 4), np.float32),
         tiles_touched=np.zeros((P,), np.uint32))
     mode = {"median": 0, "mean": 1}[depth_mode]
+    amb = None
+    if ambiguity is not None:
+        # (tol_alpha, tol_T): also return ``ambiguous`` (H,W) uint8 — pixels one of whose decisions lies within
+        # these relative tolerances of its threshold (an exp of another rounding may decide them the other way)
+        amb = np.zeros((H, W), np.uint8)
+        lib().oracle_set_ambiguity_map(_p(amb), ctypes.c_float(ambiguity[0]), ctypes.c_float(ambiguity[1]))
     R = lib().oracle_rasterize_forward(
         ctypes.c_int(P), _p(bg), ctypes.c_int(W), ctypes.c_int(H), _p(means3D), _p(colors),
         _p(opac), _p(scales), ctypes.c_float(scale_modifier), _p(rots), _p(vm), _p(pm),
         ctypes.c_float(tanfovx), ctypes.c_float(tanfovy), ctypes.c_int(mode), _p(out["color"]),
         _p(out["depth"]), _p(out["final_T"]), _p(out["n_contrib"]), _p(out["radii"]),
         _p(out["means2D"]), _p(out["depths"]), _p(out["conic_opacity"]), _p(out["tiles_touched"]))
+    if amb is not None:
+        lib().oracle_set_ambiguity_map(None, ctypes.c_float(0.0), ctypes.c_float(0.0))
+        out["ambiguous"] = amb
     if R < 0:
         raise MemoryError("oracle_rasterize_forward: allocation failed")
     out["num_rendered"] = int(R)

@@ -70,6 +70,18 @@ static inline void transformPoint4x4(const float *p, const float *m, float *o)
 
 /* forward.cu:118-152.  Quaternion (r,x,y,z) is NOT normalised (:127).  glm::mat3 literals are
  * column-major, so with R the usual rotation matrix of q:  Sigma = R diag(s^2) R^T. */
+/* Test infrastructure (tests/test_rasterize_gpu.py): when set, forward marks the pixels one of whose decisions
+ * (power > 0, alpha < 1/255, alpha clamp, T < 1e-4, median crossing of 0.5) lies within the given relative
+ * tolerances of its threshold. */
+static unsigned char *g_ambiguous = 0;
+static float g_tol_alpha = 0.0f, g_tol_T = 0.0f;
+void oracle_set_ambiguity_map(unsigned char *buf, float tol_alpha, float tol_T)
+{
+    g_ambiguous = buf;
+    g_tol_alpha = tol_alpha;
+    g_tol_T = tol_T;
+}
+
 static void computeCov3D(const float *scale, float mod, const float *rot, float *cov3D)
 {
     const float sx = mod * scale[0], sy = mod * scale[1], sz = mod * scale[2];
@@ -314,6 +326,18 @@ static long forward_impl(int P, const float *background, int W, int H, const flo
                     const float dy = means2D[2 * (size_t)id + 1] - pixf[1];
                     const float *co = conic_opacity + 4 * (size_t)id;
                     const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    if (g_ambiguous) {
+                        /* test infrastructure: is one of this pixel's DECISIONS within rounding of its threshold?
+                         * (another exp implementation — the GPU's v_exp_f32 — may then decide the other way) */
+                        const float a_raw = co[3] * expf(power > 0.0f ? 0.0f : power);
+                        const float tt = T * (1 - fminf_(0.99f, a_raw));
+                        if (fabsf(power) <= g_tol_alpha || fabsf(a_raw - 1.0f / 255.0f) <= g_tol_alpha * (1.0f / 255.0f) ||
+                            fabsf(a_raw - 0.99f) <= g_tol_alpha ||
+                            (a_raw >= 1.0f / 255.0f * (1 - g_tol_alpha) &&
+                             (fabsf(tt - 0.0001f) <= g_tol_T * 0.0001f ||
+                              (depth_mode == 0 && (fabsf(tt - 0.5f) <= g_tol_T * 0.5f || fabsf(T - 0.5f) <= g_tol_T * 0.5f)))))
+                            g_ambiguous[pix_id] = 1;
+                    }
                     if (power > 0.0f) continue;
                     const float alpha = fminf_(0.99f, co[3] * expf(power));
                     if (alpha < 1.0f / 255.0f) continue;

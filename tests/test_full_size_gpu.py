@@ -9,7 +9,7 @@ import torch
 
 from ocrfdet_amd import hotpath, synthetic
 from tests import helpers
-from tests.test_rasterize_gpu import _compare
+from tests.test_rasterize_gpu import AMBIGUITY, _compare
 
 pytestmark = pytest.mark.gpu
 CFG2 = 'cfg2_6cam_2frame_bev200x200_render_hoa'
@@ -20,7 +20,7 @@ def _one_frame(key):
     return synthetic.PathConfig(**{**synthetic.CONFIGS[key].__dict__, 'n_frames': 1, 'hoa': False})
 
 
-def _render_vs_oracle(hp, oracle_lib, views, max_outlier_frac=2e-4):
+def _render_vs_oracle(hp, oracle_lib, views, max_outlier_frac=2e-5):
     g, rc = hp.gauss, hp.render_cams
     H, W = hp.cfg.input_size
     xyz = hp.voxel_xyz[0].reshape(-1, 3)
@@ -32,10 +32,10 @@ def _render_vs_oracle(hp, oracle_lib, views, max_outlier_frac=2e-4):
         want = oracle_lib.rasterize_forward(xyz.cpu().numpy(), g['rgb'].cpu().numpy(), g['opacity'].cpu().numpy(),
                                             g['scales'].cpu().numpy(), g['rotations'].cpu().numpy(),
                                             rc['vm'][v].cpu().numpy(), rc['pm'][v].cpu().numpy(), rc['tfx'][v], rc['tfy'][v],
-                                            H, W, np.zeros(3, np.float32))
+                                            H, W, np.zeros(3, np.float32), ambiguity=AMBIGUITY)
         one = {k: got[k][v:v + 1].cpu().numpy() for k in ('color', 'depth', 'final_T', 'n_contrib', 'radii')}
         one['tiles_touched'] = want['tiles_touched'][None]        # not returned by the batched call: radii pin the rects
-        _compare(want, one, H, W, max_outlier_frac)
+        _compare(want, one, H, W, max_outlier_frac, label=f'{hp.cfg.name} view {v} ({hp.render_convention})')
         rendered.append(want['num_rendered'])
     return rendered
 

@@ -9,7 +9,12 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ocrfdet_amd import _lib, hotpath, synthetic  # noqa: E402
 
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument('--grid', type=int, default=0)
+a = ap.parse_args()
 dev = torch.device('cuda:0')
+_lib.lib().ocrf_tune_set(11, a.grid)
 cfg = synthetic.CONFIGS['cfg2_6cam_2frame_bev200x200_render_hoa']
 hp = hotpath.HotPath(cfg, dev, fuse_frames=False)
 H, W = cfg.input_size
