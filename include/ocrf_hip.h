@@ -245,6 +245,9 @@ size_t ocrf_rasterize_workspace_bytes(int P, int n_views);
  *      0 = as many as the device holds at once (fastest alone).  The blend is VALU-bound: two workgroups per CU keep
  *      most of its speed and leave the other wave slots to kernels of other streams (the hot path renders beside its
  *      latency-bound poolings with 2 x CUs: -13 % step time at cfg2).
+ *      phase: 0 = both launches; 1 = only the update, 2 = only the blend of a call whose update already ran (guard 0
+ *      only) — the two may then sit on different streams (the update is memory-bound, the blend VALU-bound: frame
+ *      n + 1's update runs under frame n's blend), ordered by the caller's events.
  * Forward only (no n_contrib): training renders through ocrf_rasterize_forward / _backward.
  */
 size_t ocrf_raster_plan_build_workspace_bytes(int P, int n_views);
@@ -263,7 +266,7 @@ int ocrf_rasterize_planned(const void *plan, size_t plan_bytes, int P, int n_pla
                            const float *rotations, const float *bg, int depth_mode, float *out_color,
                            float *out_depth, float *out_final_T, int *radii, int *status, void *workspace,
                            size_t workspace_bytes, int guard, const float *means3D, void *chain_workspace,
-                           size_t chain_workspace_bytes, int blend_workgroups, ocrf_stream_t stream);
+                           size_t chain_workspace_bytes, int blend_workgroups, int phase, ocrf_stream_t stream);
 
 /*
  * bev_pool_v2 forward as per-tile MFMA panels (csrc/bev_pool_mfma.hip): out[64 voxels x C] = W[64 x R] . F[R x C]

@@ -838,10 +838,11 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
                            const float* bg, int depth_mode, float* out_color, float* out_depth, float* out_final_T,
                            int* radii, int* status, void* workspace, size_t workspace_bytes, int guard,
                            const float* means3D, void* chain_workspace, size_t chain_workspace_bytes,
-                           int blend_workgroups, ocrf_stream_t stream_) {
+                           int blend_workgroups, int phase, ocrf_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (!plan || P <= 0 || n_plan_views <= 0 || n_plan_views > 32 || total_kept < 0 || total_kept >= (1l << 30) ||
-      H <= 0 || W <= 0 || n_sets <= 0 || n_items <= 0 || n_items % n_sets || blend_workgroups < 0 || !colors ||
+      H <= 0 || W <= 0 || n_sets <= 0 || n_items <= 0 || n_items % n_sets || blend_workgroups < 0 || phase < 0 ||
+      phase > 2 || (phase != 0 && guard) || !colors ||
       !opacities || !scales ||
       !rotations || !bg || (depth_mode != 0 && depth_mode != 1) || !out_color || !out_depth || !out_final_T ||
       !status || !workspace)
@@ -870,6 +871,7 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
     hipError_t e = ocrf::zero_async(flag, 4, stream);
     if (e != hipSuccess) return (int)e;
   }
+  if (phase != 2) {
   if (radii) {      // (view, Gaussian) pairs outside the lists are not visited: their radii are 0
     hipError_t ze = ocrf::zero_async(radii, (size_t)n_items * P * sizeof(int), stream);
     if (ze != hipSuccess) return (int)ze;
@@ -879,8 +881,10 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
                reinterpret_cast<const int*>(pb + L.g_off), reinterpret_cast<const unsigned*>(pb + L.e_pos),
                reinterpret_cast<const float4*>(pb + L.e_q0), reinterpret_cast<const float4*>(pb + L.e_q1), item_view,
                opacities, scales, scale_modifier, rotations, d_rect, d_con, radii, status, flag, queue);
+  }   // phase != 2
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
+  if (phase == 1) return 0;
   const int n_work = gx * ((gy + 1) / 2) * n_items;
   const int want_grid = g_plan_grid ? g_plan_grid : blend_workgroups;      // the diagnostic knob wins
   if (g_plan_stats) {      // diagnostic build (median depth), never used by the product path

@@ -266,7 +266,7 @@ class HotPath:
                                rc['tfy'], H, W, self.bg, packed_cameras=rc['packed'], want_n_contrib=want_n_contrib,
                                workspace_tag=tag)
 
-    def _render_planned(self, entry):
+    def _render_planned(self, entry, phase='both', out=None):
         plan, f0, nf, g = entry
         bw = self.blend_workgroups
         if bw == 'auto':
@@ -274,7 +274,9 @@ class HotPath:
         elif not isinstance(bw, int):
             bw = int(bw[min(f0, len(bw) - 1)])
         out = plan.render(g['rgb'], g['opacity'], g['scales'], g['rotations'], self.bg, guard=self.render_guard,
-                          item_view=g['item_view'] if nf > 1 else None, blend_workgroups=bw)
+                          item_view=g['item_view'] if nf > 1 else None, blend_workgroups=bw, phase=phase, out=out)
+        if phase == 'update':
+            return out
         n = len(self.cams)
         return [{k: (v[i * n:(i + 1) * n] if k != 'status' else v) for k, v in out.items()} for i in range(nf)]
 
