@@ -692,6 +692,10 @@ int ocrf_diag_where(int n_blocks, unsigned *out, int spin_ticks, void *stream);
 /* HIP streams for the hot path's chains (host pointers): cu_mask (n_words x 32 bits, NULL = every CU) restricts the
  * stream's kernels to those compute units (hipExtStreamCreateWithCUMask); without a mask `priority` is the HIP stream
  * priority (lower = more urgent).  The stream is non-blocking w.r.t. the legacy default stream. */
+/* Node census of a captured hipGraph (hipGraph_t; host pointers).  Graphs with memset nodes fault on replay after an
+ * intervening hipMemcpyAsync on ROCm 7.2 / gfx950: this library zero-fills with a kernel, and owners of captured graphs
+ * (GraphedNeck) refuse a graph whose census shows a memset node (e.g. a torch.zeros added inside the captured region). */
+int ocrf_graph_node_census(void *graph, int *n_kernel, int *n_memset, int *n_memcpy, int *n_other);
 int ocrf_stream_create(const uint32_t *cu_mask, int n_words, int priority, void **stream_out);
 int ocrf_stream_destroy(void *stream);
 int ocrf_timer_create(int capacity, void **timer_out); /* host pointers */

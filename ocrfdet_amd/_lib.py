@@ -214,6 +214,8 @@ def _declare(L):
     L.ocrf_diag_where.argtypes = [c_int, c_void_p, c_int, c_void_p]
     L.ocrf_kernel_name.restype = ctypes.c_char_p
     L.ocrf_kernel_name.argtypes = [c_int]
+    L.ocrf_graph_node_census.restype = c_int
+    L.ocrf_graph_node_census.argtypes = [c_void_p] + [ctypes.POINTER(c_int)] * 4
     L.ocrf_stream_create.restype = c_int
     L.ocrf_stream_create.argtypes = [c_void_p, c_int, c_int, ctypes.POINTER(c_void_p)]
     L.ocrf_stream_destroy.restype = c_int
@@ -266,6 +268,14 @@ def require_cuda(*tensors):
 
 def ptr(t):
     return ctypes.c_void_p(t.data_ptr() if t is not None and t.numel() > 0 else 0)
+
+
+def graph_census(cuda_graph):
+    """{kernel, memset, memcpy, other} node counts of a ``torch.cuda.CUDAGraph`` built with ``keep_graph=True``."""
+    k, ms, mc, o = (ctypes.c_int(0) for _ in range(4))
+    check(lib().ocrf_graph_node_census(ctypes.c_void_p(int(cuda_graph.raw_cuda_graph())), ctypes.byref(k), ctypes.byref(ms),
+                                       ctypes.byref(mc), ctypes.byref(o)), 'ocrf_graph_node_census')
+    return dict(kernel=k.value, memset=ms.value, memcpy=mc.value, other=o.value)
 
 
 def masked_stream(device, cu_bits=None, priority=0):

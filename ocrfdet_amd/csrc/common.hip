@@ -198,6 +198,32 @@ int ocrf_stream_create(const uint32_t* cu_mask, int n_words, int priority, void*
   return 0;
 }
 
+// Node census of a captured hipGraph (host call): kernels, memsets, memcpys, everything else.  Replaying a graph that
+// holds MEMSET nodes after an intervening hipMemcpyAsync faults on ROCm 7.2 / gfx950 (launch.h: zero_async), so the
+// owners of captured graphs refuse them.
+int ocrf_graph_node_census(void* graph, int* n_kernel, int* n_memset, int* n_memcpy, int* n_other) {
+  if (!graph || !n_kernel || !n_memset || !n_memcpy || !n_other) return (int)hipErrorInvalidValue;
+  size_t n = 0;
+  hipError_t e = hipGraphGetNodes(static_cast<hipGraph_t>(graph), nullptr, &n);
+  if (e != hipSuccess) return (int)e;
+  std::vector<hipGraphNode_t> nodes(n);
+  if (n) {
+    e = hipGraphGetNodes(static_cast<hipGraph_t>(graph), nodes.data(), &n);
+    if (e != hipSuccess) return (int)e;
+  }
+  *n_kernel = *n_memset = *n_memcpy = *n_other = 0;
+  for (size_t i = 0; i < n; ++i) {
+    hipGraphNodeType t;
+    e = hipGraphNodeGetType(nodes[i], &t);
+    if (e != hipSuccess) return (int)e;
+    if (t == hipGraphNodeTypeKernel) ++*n_kernel;
+    else if (t == hipGraphNodeTypeMemset) ++*n_memset;
+    else if (t == hipGraphNodeTypeMemcpy) ++*n_memcpy;
+    else ++*n_other;
+  }
+  return 0;
+}
+
 int ocrf_stream_destroy(void* stream) {
   return stream ? (int)hipStreamDestroy(static_cast<hipStream_t>(stream)) : 0;
 }

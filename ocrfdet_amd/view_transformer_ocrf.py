@@ -460,7 +460,8 @@ class _Geometry:
     """Everything ``view_transform_core`` derives from the calibration alone: both rank-vector sets,
     voxel centres, pillar projections and their validity (view_transformer.py:108-147,197-255;
     view_transformer_ocrf.py:651-740,785-852)."""
-    __slots__ = ('lss', 'ht', 'voxel', 'pix', 'mask', 'calib', 'c2w', 'cam_rows', 'plans', 'cam_rows_dev', 'rank_vectors')
+    __slots__ = ('lss', 'ht', 'voxel', 'pix', 'mask', 'calib', 'c2w', 'cam_rows', 'plans', 'cam_rows_dev', 'rank_vectors',
+                 'raster_plan')
 
 
 class OcRFViewTransformerFull(nn.Module):
@@ -514,6 +515,9 @@ class OcRFViewTransformerFull(nn.Module):
             dim=13, dim_head=8, heads=1, dropout=0.1, downsample_factor=4, offset_scale=4, offset_groups=None,
             offset_kernel_size=6)
         self._geo, self._tmpl, self._bg = None, None, None
+        # cached geometry (accelerate=True): render through a static plan with an on-device guard (see _render_sets);
+        # the plan's extent bound = margin x the largest Gaussian extent of the forward that builds it
+        self.render_plan, self.render_plan_margin = True, 2.0
         # forward-only mode: per-forward calibration algebra on the GPU (ocrf_geometry_blocks) when the calibration
         # tensors arrive there — no device read-back, no synchronisation in the forward (see ``_geometry``)
         self.device_geometry = False
@@ -567,6 +571,7 @@ class OcRFViewTransformerFull(nn.Module):
         B, N, _, Hf, Wf = x.shape
         geo = _Geometry()
         geo.cam_rows, geo.plans, geo.cam_rows_dev = {}, {}, None
+        geo.raster_plan = None
         on_dev = all(torch.is_tensor(t) and t.is_cuda for t in list(input[1:7]) + [input[11]])
         if getattr(self, 'device_geometry', False) and not sync and on_dev:
             # forward-only path with the calibration already on the GPU: the tiny per-camera algebra runs there
@@ -922,7 +927,7 @@ class OcRFViewTransformerFull(nn.Module):
         # staged camera rows (the reference loops samples, :1090-1153)
         if self._bg is None or self._bg.device != dev:
             self._bg = torch.zeros(3, device=dev)
-        o = rasterize_sets(voxel_coor, color, opacity, scaling, rotation, cameras['packed'], H, W, self._bg)
+        o = self._render_sets(geo, voxel_coor, color, opacity, scaling, rotation, cameras, H, W)
         render_image_G_all, render_depth_G_all = o['color'], o['depth']
         mark(8)
         if fork_at == 'render':
@@ -944,6 +949,47 @@ class OcRFViewTransformerFull(nn.Module):
         return geom_feat, depth, bev_mask_logit, [render_image, gt_images, render_image_G_all, render_N,
                                                   opacity_alpha_view, cam_idx_list, render_depth, render_depth_G_all,
                                                   render_depth_N]
+
+    def _render_sets(self, geo, voxel_coor, color, opacity, scaling, rotation, cameras, H, W):
+        """One rendered view per sample.  With CACHED geometry (``accelerate=True``) the rasteriser's calibration-only
+        front end is cached too: the Gaussian means are the voxel grid and every (sample, camera) pair a fixed view, so a
+        static render plan over all of them (``raster_plan.RasterPlan``) leaves two launches per forward; the sample's
+        random camera is a device-side index into the plan, and the plan's extent bound is guarded ON THE DEVICE (the
+        per-call pipeline is armed behind it), so the result is exact whatever the scale head emits and the forward
+        stays free of host reads (graph-capturable).  Otherwise: the per-call pipeline (``rasterize_sets``)."""
+        B, N = voxel_coor.shape[0], 6
+        state = getattr(geo, 'raster_plan', None)
+        if (state is None and self.render_plan and self.accelerate and geo is self._geo and B * N <= 32
+                and not torch.cuda.is_current_stream_capturing()):
+            state = geo.raster_plan = self._build_raster_plan(geo, voxel_coor, scaling, rotation, B, N, H, W)
+        if not state:            # not eligible (per-forward geometry, > 32 views, samples with different means)
+            return rasterize_sets(voxel_coor, color, opacity, scaling, rotation, cameras['packed'], H, W, self._bg)
+        plan, base = geo.raster_plan
+        item_view = (base + cameras['cam_sel'].to(torch.int32)).contiguous()
+        return plan.render(color, opacity, scaling, rotation, self._bg, item_view=item_view, guard='device')
+
+    def _build_raster_plan(self, geo, voxel_coor, scaling, rotation, B, N, H, W):
+        """-> (RasterPlan over the B*N (sample, camera) views, int32 view offsets b*N) or False when the samples do not
+        share one set of means.  Runs once per cached geometry (host work + one synchronisation)."""
+        from .raster_plan import RasterPlan
+        dev = voxel_coor.device
+        if any(not torch.equal(voxel_coor[b], voxel_coor[0]) for b in range(1, B)):
+            return False
+        if geo.cam_rows_dev is not None:
+            rows = geo.cam_rows_dev.reshape(B * N, 36).contiguous()
+        else:
+            host = []
+            for bs in range(B):
+                for c in range(N):
+                    if (bs, c) not in geo.cam_rows:
+                        cam = self._camera(geo, bs, c)
+                        geo.cam_rows[(bs, c)] = pack_cameras(
+                            cam['world_view_transform'][None], cam['full_proj_transform'][None],
+                            math.tan(float(cam['FovX']) * 0.5), math.tan(float(cam['FovY']) * 0.5), H, W, 'cpu')
+                    host.append(geo.cam_rows[(bs, c)])
+            rows = torch.cat(host, 0).to(dev)
+        plan = RasterPlan(voxel_coor[0], rows, H, W, scales=scaling, rotations=rotation, margin=self.render_plan_margin)
+        return plan, torch.arange(B, device=dev, dtype=torch.int32) * N
 
     def _neck_torch(self, input, geo, ht_feat, cam_idx_list):
         """Training mode: the reference's op sequence (:1051-1133) as differentiable torch ops."""
@@ -1094,9 +1140,23 @@ class GraphedNeck:
                         self._body(self._cams)
                 torch.cuda.current_stream(dev).wait_stream(side)
                 torch.cuda.synchronize(dev)
-                self._graph = torch.cuda.CUDAGraph()
+                try:
+                    self._graph = torch.cuda.CUDAGraph(keep_graph=True)      # the raw graph stays inspectable
+                    inspect = True
+                except TypeError:
+                    self._graph, inspect = torch.cuda.CUDAGraph(), False
                 with torch.cuda.graph(self._graph, stream=capture_stream):
                     self._static_out = self._body(self._cams)
+                if inspect:
+                    # ROCm 7.2: a graph with memset nodes faults on replay after any hipMemcpyAsync on the stream (and
+                    # every replay() stages the camera choice with one): refuse it here, loudly, instead of there
+                    self.census = _lib.graph_census(self._graph)
+                    if self.census['memset']:
+                        raise _lib.OcrfHipError(
+                            f"the captured neck graph holds {self.census['memset']} memset node(s) (a torch.zeros / "
+                            '.zero_() / hipMemsetAsync inside the captured region): replaying it would fault on ROCm 7.2; '
+                            'zero-fill with a kernel (e.g. tensor.fill_(0) on a non-empty tensor) or outside the graph')
+                    self._graph.instantiate()
                 # the graph has the raw pointers of the library's scratch buffers baked in: keep those
                 # buffers alive for the graph's lifetime, whatever later eager calls make of their tags
                 self._scratch = _lib.workspace.hold(dev)

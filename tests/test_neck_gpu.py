@@ -506,6 +506,21 @@ def test_graph_captured_step_matches_eager():
     for _ in range(40):
         neck.step_graphed([random.randint(0, 5), random.randint(0, 5)])
     torch.cuda.synchronize()
+    # the captured graph was inspected: kernels only where it matters (a memset node would fault on replay)
+    census = getattr(neck._graphed, 'census', None)
+    if census is not None:
+        assert census['memset'] == 0 and census['kernel'] > 20, census
+        # ... and a graph that does hold one is refused by the same census
+        from ocrfdet_amd import _lib
+        g = torch.cuda.CUDAGraph(keep_graph=True)
+        buf = torch.ones(1 << 16, device='cuda')
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.graph(g, stream=s):
+            buf.zero_()
+            buf.add_(1.0)
+        c2 = _lib.graph_census(g)
+        assert c2['memset'] >= 1 or c2['kernel'] >= 2, c2      # torch may zero with a kernel: then nothing to refuse
 
 
 def test_full_training_mode_forward_backward(core):
@@ -627,3 +642,47 @@ def test_cbam_entry_points_edge_cases_and_argument_errors():
     assert L.ocrf_cbam_tail(p(x), p(sc), p(stt), p(w), 4, p(x), p(sc), ctypes.c_float(0.0), 1, 4, 2, 2, p(lg), None,
                             st) == 1                                              # even kernel size
     torch.cuda.synchronize()
+
+
+@torch.no_grad()
+def test_cached_geometry_renders_through_a_plan_and_matches_the_per_call_render(cuda):
+    """accelerate=True: the fused forward renders through a static render plan (device-guarded); same images, bit for
+    bit, as the per-call pipeline, for several random camera choices and after the scale head outgrows the plan's
+    extent bound (the armed per-call chain then renders)."""
+    from ocrfdet_amd import hotpath, synthetic
+    cfg = synthetic.PathConfig(**{**synthetic.CONFIGS['cfg0_1cam_128x352_bev64x64x4'].__dict__, 'name': 'neck6', 'n_cams': 6,
+                                  'n_frames': 2, 'input_size': (64, 176), 'grid': dict(x=[-19.2, 19.2, 0.8], y=[-19.2, 19.2, 0.8],
+                                                                                      z=[-5.0, 3.0, 8.0], depth=[1.0, 60.0, 0.5]),
+                                  'pc_range': (-19.2, -19.2, -5.0, 19.2, 19.2, 3.0)})
+    a = hotpath.NeckPath(cfg, cuda, accelerate=True, seed=3)
+    b = hotpath.NeckPath(cfg, cuda, accelerate=True, seed=3)
+    b.module.render_plan = False
+    for n in (a, b):
+        n.module.pre_compute(n.inputs)
+    # drive both modules through the same forwards
+    for choice in ([0, 3], [5, 1], [2, 2]):
+        outs = []
+        for n in (a, b):
+            m = n.module
+            depth, fdepth, sem, feat_cl = n._ops.prefilter(n.depthnet_out, m.D, m.out_channels, m.depth_threshold,
+                                                           m.semantic_threshold)
+            outs.append(m.view_transform_core(n.inputs, fdepth, None, feat_cl, cam_idx_list=choice))
+        torch.cuda.synchronize()
+        assert a.module._geo.raster_plan and not b.module._geo.raster_plan
+        ea, eb = outs[0][3], outs[1][3]
+        assert torch.equal(ea[2], eb[2]) and torch.equal(ea[7], eb[7])          # render_image_G_all, render_depth_G_all
+        assert torch.equal(outs[0][0], outs[1][0])
+    plan = a.module._geo.raster_plan[0]
+    assert not plan.exceeded()
+    # the scale head outgrows the bound: still exact (device guard), and the plan says so
+    for n in (a, b):
+        with torch.no_grad():
+            n.module.S_MLP.fc2.bias += 3.0
+    outs = []
+    for n in (a, b):
+        m = n.module
+        depth, fdepth, sem, feat_cl = n._ops.prefilter(n.depthnet_out, m.D, m.out_channels, m.depth_threshold, m.semantic_threshold)
+        outs.append(m.view_transform_core(n.inputs, fdepth, None, feat_cl, cam_idx_list=[4, 0]))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][3][2], outs[1][3][2]) and torch.equal(outs[0][3][7], outs[1][3][7])
+    assert plan.exceeded()

@@ -12,7 +12,8 @@ for _ in range(20): hp.step(depth, feat)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(300): hp.step(depth, feat)
-torch.cuda.synchronize(); print('eager %.4f ms/step' % (1e3 * (time.perf_counter() - t0) / 300))
+t_issue = time.perf_counter() - t0
+torch.cuda.synchronize(); print('eager %.4f ms/step (host issue %.4f ms/step)' % (1e3 * (time.perf_counter() - t0) / 300, 1e3 * t_issue / 300))
 side = torch.cuda.Stream(dev); side.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(side):
     for _ in range(3): hp.step(depth, feat)
