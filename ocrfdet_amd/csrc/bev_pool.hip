@@ -168,7 +168,7 @@ __device__ __forceinline__ int block_scan_1024(int v, int* s_w, int& total) {
 }
 
 __global__ __launch_bounds__(1024) void bev_pool_units_kernel(
-    int n_tiles, int Q, int max_units, const int* __restrict__ tile_cnt, Header* __restrict__ hdr,
+    int n_tiles, int Q, int max_units, int max_slabs, const int* __restrict__ tile_cnt, Header* __restrict__ hdr,
     int2* __restrict__ tinfo, int4* __restrict__ units) {
   // Unit list: XCD x owns units [xs[x], xs[x+1]) = a contiguous range of tiles (cost-balanced: the tiles of one
   // BEV region gather the same feat rows and share that XCD's L2); inside a range the slices of cut tiles come
@@ -205,8 +205,12 @@ __global__ __launch_bounds__(1024) void bev_pool_units_kernel(
     const long cb = cost_base + block_scan_1024(cost, s_w, tot_c);
     if (t < n_tiles) {
       const int x = (int)min(7L, cb * 8 / cost_total);
-      tinfo[t] = make_int2(ns > 1 ? sb : -1, x);
-      if (ns > 1) atomicAdd(&s_split[x], ns);
+      // The slab buffer is sized for tile counts that sum to n_points; duplicate / overlapping intervals can inflate
+      // them.  A cut tile whose slabs would not fit is NOT cut (-2: one long unit, still correct) and the status says so.
+      const bool fits = sb + ns <= max_slabs;
+      if (ns > 1 && !fits) atomicOr(&hdr->status, 1);
+      tinfo[t] = make_int2(ns > 1 ? (fits ? sb : -2) : -1, x);
+      if (ns > 1 && fits) atomicAdd(&s_split[x], ns);
       else atomicAdd(&s_whole[x], 1);
     }
     slab_base += tot_s;
@@ -223,14 +227,14 @@ __global__ __launch_bounds__(1024) void bev_pool_units_kernel(
   // pass 3: hand out the slots
   for (int t = tid; t < n_tiles; t += 1024) {
     const int cnt = tile_cnt[t];
-    const int ns = slices_of(cnt);
     const int2 ti = tinfo[t];
+    const int ns = (ti.x == -2) ? 1 : slices_of(cnt);
     const int x = ti.y;
     const int slot = (ns > 1) ? s_base[x] + atomicAdd(&s_cur_split[x], ns)
                               : s_base[x] + s_split[x] + atomicAdd(&s_cur_whole[x], 1);
     for (int s = 0; s < ns; ++s) {
       if (slot + s >= max_units) { atomicOr(&hdr->status, 1); break; }   // only inconsistent tile counts get here
-      units[2 * (slot + s)] = make_int4(t, s * Q, min(cnt, (s + 1) * Q), s);
+      units[2 * (slot + s)] = make_int4(t, s * Q, ns == 1 ? cnt : min(cnt, (s + 1) * Q), s);
       units[2 * (slot + s) + 1] = make_int4(ns, ti.x, 0, 0);
     }
   }
@@ -724,7 +728,7 @@ int launch_prep(int c, int n_intervals, int n_points, const int* counts, const G
     if (err != hipSuccess) return (int)err;
   }
   hipLaunchKernelGGL(bev_pool_units_kernel, dim3(1), dim3(1024), 0, stream, vg.n_tiles, pg.Q, L.max_units,
-                     reinterpret_cast<const int*>(p + L.cnt_off), hdr, reinterpret_cast<int2*>(p + L.tinfo_off),
+                     (int)(2 * ((long)n_points / pg.Q) + 2), reinterpret_cast<const int*>(p + L.cnt_off), hdr, reinterpret_cast<int2*>(p + L.tinfo_off),
                      reinterpret_cast<int4*>(p + L.units_off));
   return (int)hipGetLastError();
 }

@@ -202,7 +202,14 @@ __device__ __forceinline__ unsigned long long lb_tile_prefix(unsigned long long*
       // Every tile this one waits for holds a smaller ticket and is running, so the wait ends within microseconds —
       // unless the state words are being overwritten, e.g. by a second call sharing this scratch on another stream.
       // A wave must not spin on a shared GPU for ever: after ~a second the kernel traps (the launch fails loudly).
-      if (++spins > (1 << 20)) __builtin_trap();
+      // A wave must not spin on a shared GPU for ever, and a trap would take the whole process down: after ~a second
+      // the tile gives up, raises the error bit of the state block (bit 63 of word 0; the ticket counter is the low
+      // half) and carries on with what it has — the call's last kernel turns the bit into counts = -1, which the
+      // poolings read as "no points" and the host wrappers as an OcrfHipError.
+      if (++spins > (1 << 20)) {
+        if (tid == 0) atomicOr(state, 1ull << 63);
+        break;
+      }
       __builtin_amdgcn_s_sleep(2);
       continue;                                       // something nearer than `first` is unpublished: read again
     }
@@ -359,13 +366,22 @@ __global__ __launch_bounds__(kBlock) void lss_emit_ranks_kernel(const unsigned* 
                                                                 const int* __restrict__ sorted_pts,
                                                                 const int* __restrict__ counts, int DHW, int HW,
                                                                 int* __restrict__ ranks_bev, int* __restrict__ ranks_depth,
-                                                                int* __restrict__ ranks_feat) {
+                                                                int* __restrict__ ranks_feat,
+                                                                const unsigned long long* __restrict__ state, int st_words,
+                                                                int n_states, int* __restrict__ counts_rw) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= counts[0]) return;
-  const int p = sorted_pts[i];
-  ranks_bev[i] = (int)sorted_keys[i];
-  ranks_depth[i] = p;                                   // the point's own flat index (:232-236)
-  ranks_feat[i] = (p / DHW) * HW + p % HW;              // (b*N + n)*H*W + h*W + w
+  const int n = counts[0];
+  if (i < n) {
+    const int p = sorted_pts[i];
+    ranks_bev[i] = (int)sorted_keys[i];
+    ranks_depth[i] = p;                                   // the point's own flat index (:232-236)
+    ranks_feat[i] = (p / DHW) * HW + p % HW;              // (b*N + n)*H*W + h*W + w
+  }
+  if (i == 0) {                                           // a look-back scan of this call gave up: say so in counts
+    bool failed = false;
+    for (int k = 0; k < n_states; ++k) failed = failed || (state[(size_t)k * st_words] >> 63);
+    if (failed) { counts_rw[0] = -1; counts_rw[1] = -1; }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -521,9 +537,11 @@ __global__ __launch_bounds__(kBlock) void ht_emit_kernel(HtParams q, const float
   }
 }
 
-__global__ void ht_counts_kernel(const long long* __restrict__ total, int* __restrict__ counts) {
-  counts[0] = (int)(*total >> 31);
-  counts[1] = (int)(*total & 0x7FFFFFFFll);
+__global__ void ht_counts_kernel(const long long* __restrict__ total, int* __restrict__ counts,
+                                 const unsigned long long* __restrict__ state) {
+  const bool failed = (state[0] >> 63) != 0;             // the look-back scan gave up (lb_tile_prefix)
+  counts[0] = failed ? -1 : (int)(*total >> 31);
+  counts[1] = failed ? -1 : (int)(*total & 0x7FFFFFFFll);
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -705,7 +723,8 @@ int ocrf_lss_prepare(int B, int N, int D, int H, int W, const float* frustum, co
                state + 4 * st_words);
   ocrf::launch(OCRF_K_LSS_EMIT, lss_emit_ranks_kernel, dim3((n_pts + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
                static_cast<const unsigned*>(keys[cur]), static_cast<const int*>(vals[cur]), static_cast<const int*>(counts),
-               D * H * W, H * W, ranks_bev, ranks_depth, ranks_feat);
+               D * H * W, H * W, ranks_bev, ranks_depth, ranks_feat, static_cast<const unsigned long long*>(state),
+               (int)st_words, 5, counts);
   return (int)hipGetLastError();
 }
 
@@ -905,7 +924,8 @@ int ocrf_ht_prepare(int B, int N, int Z, int n_pillars, int Wf, int Hf, int D, c
   ocrf::launch(OCRF_K_HT_EMIT, ht_emit_kernel, cgrid, dim3(kBlock), 0, stream, q, ref_points, hc,
                static_cast<const unsigned*>(valid_bits), static_cast<const long long*>(cnt_flag), ranks_bev, ranks_depth,
                ranks_feat, interval_starts, interval_lengths);
-  hipLaunchKernelGGL(ht_counts_kernel, dim3(1), dim3(1), 0, stream, static_cast<const long long*>(total), counts);
+  hipLaunchKernelGGL(ht_counts_kernel, dim3(1), dim3(1), 0, stream, static_cast<const long long*>(total), counts,
+                     static_cast<const unsigned long long*>(state));
   return (int)hipGetLastError();
 }
 

@@ -244,8 +244,17 @@ class _RankBuffers:
         return self.bufs
 
 
+def _prep_tag(dev):
+    """Scratch tag of the index preparations: per STREAM, because the scratch holds cross-workgroup state (the
+    look-back words of the prefix sums) — two preparations in flight on different streams must not share it."""
+    return f'index_prep@{_lib.stream_ptr(dev).value or 0}'
+
+
 def _trim(bufs, counts_host):
     n_p, n_v = int(counts_host[0]), int(counts_host[1])
+    if n_p < 0:
+        raise _lib.OcrfHipError('index preparation: a look-back prefix sum gave up waiting (its scratch was overwritten '
+                                'while in use — two preparations sharing one scratch buffer?); the rank vectors are not valid')
     if n_p == 0:
         return None, None, None, None, None
     return bufs[0][:n_p], bufs[1][:n_p], bufs[2][:n_p], bufs[3][:n_v], bufs[4][:n_v]
@@ -270,7 +279,7 @@ def voxel_pooling_prepare_v2_hip(frustum, cam_block, B, N, grid_lower_bound, gri
     L = _lib.lib()
     with _lib.on_device(dev):
         need = L.ocrf_lss_prepare_workspace_bytes(B, N, D, H, W, gx, gy, gz)
-        ws = _lib.workspace.get(dev, need, 'index_prep')
+        ws = _lib.workspace.get(dev, need, _prep_tag(dev))
         _lib.check(L.ocrf_lss_prepare(
             B, N, D, H, W, _lib.ptr(frustum.contiguous()), _lib.ptr(cam_block), ctypes.c_void_p(lower.data_ptr()),
             ctypes.c_void_p(interval.data_ptr()), gx, gy, gz, *[_lib.ptr(b) for b in bufs], _lib.ptr(ws),
@@ -296,7 +305,7 @@ def fast_sample_prepare_hip(ref_template, cam_block, B, N, pc_range, image_shape
     L = _lib.lib()
     with _lib.on_device(dev):
         need = L.ocrf_ht_prepare_workspace_bytes(B, Nq)
-        ws = _lib.workspace.get(dev, need, 'index_prep')
+        ws = _lib.workspace.get(dev, need, _prep_tag(dev))
         _lib.check(L.ocrf_ht_prepare(
             B, N, Z, Nq, int(W), int(H), int(D), _lib.ptr(ref_template.contiguous()), _lib.ptr(cam_block),
             ctypes.c_void_p(pc.data_ptr()), ctypes.c_float(image_shapes[1]), ctypes.c_float(image_shapes[0]),

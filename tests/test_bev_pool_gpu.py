@@ -183,6 +183,30 @@ def test_heavy_tiles_are_cut_and_recombined_deterministically(cuda, oracle_lib):
         np.testing.assert_array_equal(a, _run(cuda, d5, f5, rd, rf, vox, shape, st, ln))
 
 
+def test_duplicate_intervals_cannot_overrun_the_slabs(cuda, oracle_lib):
+    """Hundreds of copies of one long interval: the voxel table keeps one of them (they are identical, so any winner
+    equals the reference), but every copy counts into its tile, which then "needs" far more slices than the slab buffer
+    (sized for n_points) holds.  Such a tile is pooled as ONE long unit instead of being cut — no slab is written out
+    of bounds — and the result still equals the reference."""
+    rng = np.random.default_rng(33)
+    c = 80
+    n_pts = 3000
+    rd = rng.integers(0, 400, n_pts).astype(np.int32)
+    rf = rng.integers(0, 90, n_pts).astype(np.int32)
+    rb = np.full(n_pts, 37, np.int32)
+    rb[2000:] = 150                                                   # two voxels, in tiles 0 and 2
+    depth = rng.random(400, dtype=np.float32)
+    feat = rng.standard_normal((90, c)).astype(np.float32)
+    st = np.concatenate((np.zeros(300, np.int32), np.full(5, 2000, np.int32)))
+    ln = np.concatenate((np.full(300, 2000, np.int32), np.full(5, 1000, np.int32)))
+    shape = (1, 1, 4, 64, c)
+    d5, f5 = depth.reshape(1, 1, -1, 1, 1), feat.reshape(1, 1, 1, -1, c)
+    want = oracle_lib.bev_pool_v2(d5, f5, rd, rf, rb, shape, st[[0, 300]], ln[[0, 300]])
+    got = _run(cuda, d5, f5, rd, rf, rb, shape, st, ln)
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
+    np.testing.assert_array_equal(got, _run(cuda, d5, f5, rd, rf, rb, shape, st, ln))
+
+
 def test_empty_inputs(cuda):
     e = torch.zeros(0, dtype=torch.int32, device=cuda)
     out = bevpool.bev_pool_v2(torch.zeros(1, 1, 2, 2, 2, device=cuda), torch.zeros(1, 1, 2, 2, 80, device=cuda),
