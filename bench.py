@@ -733,8 +733,12 @@ def main():
                                                 else 'guarded on the device (per-call pipeline armed behind every render)'))
                                             if planned else 'per call (preprocess + depth-bucket scatter every render)'),
                        'frames': 'each frame its own ego pose and Gaussian parameters (synthetic.ego_motion)',
-                       'streams': ('main: pools + HOA; side HIP stream: renders' if hp.overlap and cfg.render
-                                   else 'single stream'),
+                       'streams': ('main: pools, then HOA; side HIP stream: per frame render update + blend; the blend (VALU-bound) '
+                                   'runs as a persistent grid of 2 workgroups per CU so that the latency-bound kernels of the '
+                                   'main stream keep wave slots (DESIGN.md section 5)' if hp.overlap and cfg.render and planned
+                                   else ('main: HOA-1/2, pools, HOA-3; side HIP stream: renders' if hp.overlap and cfg.render
+                                         else 'single stream')),
+                       'ht_pool': getattr(hp, 'ht_pool_backend', None),
                        'index_prep': 'cached (accelerate=True semantics); per_step_ms = the same step with the HIP index '
                                      'preparation inside (accelerate=False semantics, the reference\'s working mode), calibration '
                                      'algebra on the host as the reference\'s own torch calls (rank vectors bit-exact); '

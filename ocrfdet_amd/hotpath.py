@@ -417,8 +417,18 @@ class HotPath:
         ob = self.hoa_opacity_bev() if (self.cfg.hoa and hoa_first) else None
         if prepared is not None:
             torch.cuda.current_stream(self.device).wait_stream(self._prep_stream)
+        hoa_side = None
+        if self.cfg.hoa and not hoa_first and getattr(self, 'hoa_stream', False) and self.overlap:
+            # HOA-1/2 (ten small kernels, 16-338 workgroups each) on a stream of their own beside the poolings
+            hoa_side = shared_stream(self.device, 'hoa')
+            hoa_side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(hoa_side):
+                ob = self.hoa_opacity_bev()
         lss, ht = self.pool_step(depth, feat, prepared)
-        if self.cfg.hoa and not hoa_first:
+        if hoa_side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(hoa_side)
+            ob.record_stream(torch.cuda.current_stream(self.device))
+        elif self.cfg.hoa and not hoa_first:
             ob = self.hoa_opacity_bev()
         out = [lss, ht]
         if fork:
