@@ -413,7 +413,8 @@ class HotPath:
         # update kernel, then the VALU-bound blend on two workgroups per CU) the poolings go FIRST — they meet the
         # side stream's update and the start of its blend instead of its middle (cfg2: 0.305 -> 0.292 ms); with the
         # per-call render, whose chip-filling preprocess opens the side stream, HOA-1/2 first was better (round 2)
-        hoa_first = getattr(self, 'hoa_first', self.render_mode != 'planned')
+        # (per-step index preparation: HOA-1/2 first, beside the preparation the poolings have to wait for anyway)
+        hoa_first = getattr(self, 'hoa_first', self.render_mode != 'planned' or self.index_prep_mode == 'per_step')
         ob = self.hoa_opacity_bev() if (self.cfg.hoa and hoa_first) else None
         if prepared is not None:
             torch.cuda.current_stream(self.device).wait_stream(self._prep_stream)
