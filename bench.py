@@ -98,6 +98,10 @@ def cpu_baseline(hp, depth, feat, budget_s):
     import numpy as np
     import oracle
     oracle.build()
+    # a one-GPU box hands this process a share of the host (16 cores here), not all the cores the node shows: more
+    # OpenMP threads than that only oversubscribe it (measured: 128 threads render a view slower than one)
+    share = int(os.environ.get('OCRF_CPU_THREADS', 0)) or min(len(os.sched_getaffinity(0)), 16)
+    oracle.set_num_threads(min(oracle.num_threads(), share))
     d, f = depth.cpu().numpy(), feat.cpu().numpy()
     plans = []
     for p in (hp.lss, hp.ht):
@@ -661,11 +665,19 @@ def main():
             cycles = blend_ms * 1e-3 * CLOCK_HZ
             tfl = BLEND_FLOPS_PER_PIXEL_RECORD * evals / (blend_ms * 1e-3) / 1e12
             traffic = hbm_traffic(c)
+            grid_note = None
+            if planned and getattr(hp, 'overlap', False) and getattr(hp, 'blend_workgroups', None) == 'auto':
+                cus = torch.cuda.get_device_properties(dev).multi_processor_count
+                grid_note = {'workgroups_timed_region': 2 * cus, 'workgroups_isolated': _lib.lib().ocrf_diag_plan_resident(),
+                             'note': 'beside the pooling / HOA stream the persistent blend is launched on two workgroups '
+                                     'per CU of the four the chip holds (DESIGN 5: step 0.344 -> 0.300 ms); "frac" prices '
+                                     'that half-occupancy launch against the whole chip\'s peak, "isolated" is the full grid'}
             roofline = {
                 'bound': 'valu', 'kernel': t_blend.kernel_name,
                 'achieved': tfl, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tfl / FP32_PEAK_TFLOPS,
                 'flops_per_pixel_record': BLEND_FLOPS_PER_PIXEL_RECORD, 'pixel_records_per_launch': evals,
                 'avg_launch_us': 1e3 * blend_ms, 'launches_timed': t_blend.count(),
+                'grid': grid_note,
                 'traffic': traffic, 'traffic_source': (PMC_FILE + ' (' + PMC_META + ' matches this run)') if traffic else None,
                 'hbm': ({'bytes_per_launch_pmc': traffic, 'achieved_GBs': traffic / (blend_ms * 1e-3) / 1e9,
                          'frac_of_peak': traffic / (blend_ms * 1e-3) / 1e9 / HBM_PEAK_GBS} if traffic else None),

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
   bool all_done = false;
   // diagnostic build only: phase cycles and record counts of this workgroup
   unsigned long long t_prev = 0, t_acc[3] = {0, 0, 0};
-  unsigned n_staged = 0, n_listed = 0, n_eval = 0;
+  unsigned n_staged = 0, n_listed = 0, n_eval = 0, n_newstop = 0;
   auto stamp = [&](int slot) {
     if constexpr (STATS) {
       const unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -588,6 +588,9 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
           const f2 test_T = T * (splat(1.0f) - alpha);
           const f2 aT = alpha * T;
           const bool stop0 = test_T.x < 0.0001f, stop1 = test_T.y < 0.0001f;
+          if constexpr (STATS) {      // records at which some pixel of the wave stops (diagnostic)
+            if (__ballot((stop0 && T.x > 0.f) || (stop1 && T.y > 0.f)) != 0ull) ++n_newstop;
+          }
           f2 wgt;
           wgt.x = stop0 ? 0.f : aT.x;
           wgt.y = stop1 ? 0.f : aT.y;
@@ -677,7 +680,7 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
       const long w = (long)work * 4 + wave;
       stats[w * 8 + 0] = t_acc[0]; stats[w * 8 + 1] = t_acc[1]; stats[w * 8 + 2] = t_acc[2];
       stats[w * 8 + 3] = (unsigned long long)scan; stats[w * 8 + 4] = n_staged;
-      stats[w * 8 + 5] = n_listed; stats[w * 8 + 6] = n_eval; stats[w * 8 + 7] = 0;
+      stats[w * 8 + 5] = n_listed; stats[w * 8 + 6] = n_eval; stats[w * 8 + 7] = n_newstop;
     }
   }
 
@@ -712,6 +715,7 @@ int resident_blocks(K kernel) {
 }
 
 int g_plan_wskip = 0;
+int g_update_lds = 0;       // ocrf_tune_set(12, bytes): dynamic LDS padding of the update kernel = an occupancy cap (diagnostic)
 int g_plan_grid = 0;        // ocrf_tune_set(11, n): workgroups of the persistent blend (0 = what the device holds at once)
 unsigned long long* g_plan_stats = nullptr;      // ocrf_diag_plan_stats: the next planned blends run the STATS build       // ocrf_tune_set(OCRF_TUNE_PLAN_WSKIP): the pixel-exact wave skip inside the loop
 
@@ -721,6 +725,7 @@ namespace ocrf {
 void raster_plan_tune(int key, int value) {
   if (key == 10) g_plan_wskip = value != 0;
   if (key == 11) g_plan_grid = value > 0 ? value : 0;
+  if (key == 12) g_update_lds = value > 0 ? value : 0;
 }
 }
 
@@ -877,7 +882,7 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
     if (ze != hipSuccess) return (int)ze;
   }
   ocrf::launch(OCRF_K_RASTER_PLAN_UPDATE, raster_plan_update_kernel, dim3((P + kBlock - 1) / kBlock, n_sets),
-               dim3(kBlock), 0, stream, P, vps, total_kept, header, reinterpret_cast<const unsigned*>(pb + L.g_mask),
+               dim3(kBlock), (size_t)g_update_lds, stream, P, vps, total_kept, header, reinterpret_cast<const unsigned*>(pb + L.g_mask),
                reinterpret_cast<const int*>(pb + L.g_off), reinterpret_cast<const unsigned*>(pb + L.e_pos),
                reinterpret_cast<const float4*>(pb + L.e_q0), reinterpret_cast<const float4*>(pb + L.e_q1), item_view,
                opacities, scales, scale_modifier, rotations, d_rect, d_con, radii, status, flag, queue);

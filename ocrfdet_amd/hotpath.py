@@ -255,7 +255,7 @@ class HotPath:
     def check_render_plans(self):
         """Synchronising check of the render plans' extent bound (``render_guard='host'``): raises if a planned
         render since the last check was not valid."""
-        for p in (self.render_plans or []):
+        for p in (getattr(self, 'render_plans', None) or []):
             p[0].check()
 
     def _render_per_call(self, b, want_n_contrib, tag):

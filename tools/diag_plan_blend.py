@@ -45,3 +45,6 @@ print('pixel-records evaluated per launch %.3e (128 px per wave-record)' % (eval
 # blend-phase imbalance: time of the slowest wave vs the mean wave in a workgroup
 b = cyc[..., 2]
 print('blend cycles: slowest wave / mean wave per workgroup %.3f' % (b.max(1).mean() / b.mean()))
+newstop = s[:, :, 7]
+print('records in which some pixel of the wave stops: %.1f per wave = %.3f of the evaluated' % (
+    newstop.mean(), newstop.sum() / max(evald.sum(), 1)))
