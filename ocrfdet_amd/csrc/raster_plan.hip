@@ -287,6 +287,10 @@ __global__ __launch_bounds__(kBlock) void raster_plan_update_kernel(
   float c3[6];
   cov3d_from_scale_rot(sx, sy, sz, qr, qx, qy, qz, c3);
   const float o = opacities[gi];
+  // alpha = min(0.99, o exp(power)) with power <= 0 (forward.cu:327-333): under 1/255 at EVERY pixel when o is
+  // (NaN compares false: evaluated in full).  Such a Gaussian gets an empty rect — no tile pair ever scans into it —
+  // and, unless its radius is asked for, no covariance work either.  Free space in a trained OcRF is mostly this.
+  const bool unseen = o < 1.0f / 255.0f;
   int e = g_off[id];
   const long dyn = (long)s * n_total;
   while (m) {
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void raster_plan_update_kernel(
     const float A[2][3] = {{q0.x, q0.y, q0.z}, {q0.w, q1.x, q1.y}};
     Rect rect = Rect{0, 0, 0, 0};
     int rad = 0;
-    if (!surely_outside(q1.z, q1.w, radius_bound(A, rn), gx, gy)) {
+    if ((!unseen || radii) && !surely_outside(q1.z, q1.w, radius_bound(A, rn), gx, gy)) {
       float cov_x, cov_y, cov_z, con_x, con_y, con_z;
       cov2d(A, c3, &cov_x, &cov_y, &cov_z);
       if (conic_radius_rect(cov_x, cov_y, cov_z, q1.z, q1.w, gx, gy, &con_x, &con_y, &con_z, &rad, &rect)) {
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(kBlock) void raster_plan_update_kernel(
         rad = 0;
       }
     }
-    d_rect[dyn + pos] = rect;
+    d_rect[dyn + pos] = unseen ? Rect{0, 0, 0, 0} : rect;
     if (radii) radii[((long)s * vps + zi) * P + id] = rad;
   }
 }

@@ -180,6 +180,7 @@ def test_opacity_edge_values_and_degenerate_inputs(cuda):
     opac[2::5] = 0.0
     opac[3::5] = 1.0
     opac[7] = -0.3
+    opac[9] = float('nan')
     sc[11] = 0.0                              # a point: cov2D = 0.3 I
     rot[13] = 0.0                             # zero quaternion: R = I (unnormalised formula)
     cams = _cams(cuda, W, H, [(0, 0, 0)])
@@ -189,6 +190,26 @@ def test_opacity_edge_values_and_degenerate_inputs(cuda):
     plan = rp.RasterPlan(xyz, cams, H, W, extent_bound=2.0)
     got = plan.render(rgb, opac, sc, rot, bg, want_radii=True)
     _same(want, got, ('color', 'depth', 'final_T', 'radii'))
+    # without radii the update kernel skips the covariance work of Gaussians no pixel can blend (opacity < 1/255)
+    _same(want, plan.render(rgb, opac, sc, rot, bg))
+    assert plan.check()
+
+
+def test_mostly_transparent_scene(cuda):
+    """Free space: 90 % of the Gaussians under the 1/255 opacity threshold (their rects are emptied by the update
+    kernel, so no tile pair scans into them) — same images as the per-call pipeline, with and without radii."""
+    rng = np.random.default_rng(23)
+    W, H = 176, 80
+    xyz, rgb, opac, sc, rot = _scene(rng, 20000, cuda)
+    faint = torch.from_numpy(rng.random(20000) < 0.9).to(cuda)
+    opac[faint] = opac[faint] * 0.0039
+    cams = _cams(cuda, W, H, [(0, 0, 0), (1.5, -0.5, 2.0)])
+    bg = torch.tensor([0.2, 0.1, 0.0], device=cuda)
+    want = dgr.rasterize_views(xyz, rgb, opac, sc, rot, None, None, None, None, H, W, bg, packed_cameras=cams,
+                               want_n_contrib=False)
+    plan = rp.RasterPlan(xyz, cams, H, W, scales=sc, rotations=rot)
+    _same(want, plan.render(rgb, opac, sc, rot, bg))
+    _same(want, plan.render(rgb, opac, sc, rot, bg, want_radii=True), ('color', 'depth', 'final_T', 'radii'))
     assert plan.check()
 
 
