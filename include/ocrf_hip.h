@@ -239,8 +239,12 @@ size_t ocrf_rasterize_workspace_bytes(int P, int n_views);
  *      ocrf_rasterize_forward or rebuilds the plan with a larger bound).
  *      guard = 1: the per-call pipeline of ocrf_rasterize_forward is enqueued behind the planned one, armed by the
  *      extent check: all of its kernels retire at once when the bound holds, and render the call instead when it
- *      does not — exact results either way, no host involvement (hipGraph-capturable), at the price of five
- *      near-empty launches.  Needs means3D, radii and chain_workspace >= ocrf_rasterize_workspace_bytes(P, n_items).
+ *      does not — exact results either way, no host involvement (hipGraph-capturable), at the price of four
+ *      near-empty launches (no memsets: the flag is raised by the update kernel and lowered by the armed blend, the
+ *      chain's histograms are cleared by the planned blend when the flag is up, radii zeros come from the update
+ *      kernel).  Needs means3D, radii and chain_workspace >= ocrf_rasterize_workspace_bytes(P, n_items); `workspace`
+ *      must be zero-filled when it is allocated and belong to this plan alone (it carries the flag between calls; a
+ *      stale non-zero flag costs one slow, still exact, call).
  *      blend_workgroups: size of the blend's persistent grid (its workgroups draw tile pairs from a ticket queue);
  *      0 = as many as the device holds at once (fastest alone).  The blend is VALU-bound: two workgroups per CU keep
  *      most of its speed and leave the other wave slots to kernels of other streams (the hot path renders beside its

@@ -168,7 +168,9 @@ namespace ocrf {
 
 // rasterize.hip: the per-call pipeline (zero -> preprocess -> scan -> scatter -> blend) with two additions the
 // plan path needs when it arms the pipeline as its on-device fallback:
-//   gate      device int or null: every kernel of the chain retires at once unless *gate != 0;
+//   gate      device int[2] or null: every kernel of the chain retires at once unless gate[0] != 0; when it is, the
+//             last workgroup of the blend to arrive lowers it again (gate[1] = arrival counter, zero on entry);
+//   hist_is_zero  the caller has cleared raster_chain_hist() itself (no zero launch at the head of the chain);
 //   view_sel  device ints or null: item z renders camera view_sel[z] of `cameras`;
 //   shared_means  means3D is (P,3) for every set instead of (n_sets,P,3).
 int raster_forward_chain(int P, int n_sets, int views_per_set, int H, int W, const float* means3D, const float* colors,
@@ -176,7 +178,8 @@ int raster_forward_chain(int P, int n_sets, int views_per_set, int H, int W, con
                          const float* cov3D_precomp, const float* cameras, const int* view_sel, const float* bg,
                          int depth_mode, float* out_color, float* out_depth, float* out_final_T,
                          uint32_t* out_n_contrib, int* radii, uint32_t* tiles_touched, int* status, void* workspace,
-                         size_t workspace_bytes, const int* gate, bool shared_means, hipStream_t stream);
+                         size_t workspace_bytes, int* gate, bool shared_means, bool hist_is_zero, hipStream_t stream);
+int* raster_chain_hist(void* workspace, int P, int n_views, size_t* n_words);
 
 // index_prep.hip: stable LSD radix sort of n 32-bit keys carrying their original index (ids ascending among equal
 // keys).  `keys` is clobbered; the sorted keys / ids are returned through the two pointers (they point into

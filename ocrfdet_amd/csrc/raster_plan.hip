@@ -252,7 +252,10 @@ __global__ __launch_bounds__(kBlock) void raster_plan_update_kernel(
     Rect* __restrict__ d_rect, float4* __restrict__ d_con, int* __restrict__ radii, int* __restrict__ status,
     int* __restrict__ flag, int* __restrict__ queue) {
   __shared__ int l_v2i[32];
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *queue = 0;      // ticket counter of the blend that follows
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    *queue = 0;                  // ticket counter of the blend that follows
+    if (flag) flag[1] = 0;       // arrival counter of the armed per-call blend (rasterize.hip)
+  }
   if (header[0] != (int)kPlanMagic) {
     if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) atomicOr(status, 8);
     return;
@@ -283,6 +286,13 @@ __global__ __launch_bounds__(kBlock) void raster_plan_update_kernel(
     if (flag) atomicOr(flag, 1);
   }
   unsigned m = g_mask[id];
+  if (radii) {      // (item, Gaussian) pairs outside the lists are not visited below: their radii are 0 (no memset launch)
+    for (int zi = 0; zi < vps; ++zi) {
+      const int v = view_sel ? view_sel[s * vps + zi] : zi;
+      const bool listed = v >= 0 && v < V && ((m >> v) & 1u) != 0u && l_v2i[v] == zi;
+      if (!listed) radii[((long)s * vps + zi) * P + id] = 0;
+    }
+  }
   if (m == 0u) return;
   float c3[6];
   cov3d_from_scale_rot(sx, sy, sz, qr, qx, qy, qz, c3);
@@ -334,8 +344,13 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
     const Rect* __restrict__ d_rect, const float4* __restrict__ d_con, const float* __restrict__ colors,
     const float* __restrict__ bg,
     float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_final_T,
-    const int* __restrict__ skip_if, int* __restrict__ queue) {
-  if (skip_if && *skip_if != 0) return;      // the plan's bound does not hold this step: the armed per-call chain renders
+    const int* __restrict__ skip_if, int* __restrict__ queue, int* __restrict__ chain_hist, int chain_hist_words) {
+  if (skip_if && *skip_if != 0) {
+    // the plan's bound does not hold this step: the armed per-call chain renders.  Its bucket histograms are cleared
+    // here — by the kernel that sits in front of it anyway — instead of by a launch of their own in every call.
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < chain_hist_words; i += gridDim.x * kBlock) chain_hist[i] = 0;
+    return;
+  }
   __shared__ unsigned l_pos[kCapPos];
   __shared__ float4 l_a[kStageP + 1], l_b[kStageP + 1], l_c[kStageP + 1];
   __shared__ unsigned short l_list[4][kStageP + 3 * kTrip + 2];
@@ -872,19 +887,20 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
   auto* d_con = reinterpret_cast<float4*>(wb + D.con);
   int* queue = reinterpret_cast<int*>(wb + D.flag) + 16;
   int* flag = nullptr;
+  int* chain_hist = nullptr;
+  size_t chain_hist_words = 0;
   if (guard) {
     if (!means3D || !radii || !chain_workspace ||
         chain_workspace_bytes < ocrf_rasterize_workspace_bytes(P, n_items))
       return (int)hipErrorInvalidValue;
+    // flag[0]: "the extent check fired".  No memset per call: the update kernel only RAISES it, the armed blend lowers
+    // it after a call that fired, so it is zero on entry unless a fired call was cut short — then this call takes the
+    // exact per-call path once more and lowers it.  (The scratch is zero-filled when it is allocated; any other first
+    // value only costs one slow call.)  flag[1]: arrival counter of that blend, zeroed by the update kernel.
     flag = reinterpret_cast<int*>(wb + D.flag);
-    hipError_t e = ocrf::zero_async(flag, 4, stream);
-    if (e != hipSuccess) return (int)e;
+    chain_hist = ocrf::raster_chain_hist(chain_workspace, P, n_items, &chain_hist_words);
   }
   if (phase != 2) {
-  if (radii) {      // (view, Gaussian) pairs outside the lists are not visited: their radii are 0
-    hipError_t ze = ocrf::zero_async(radii, (size_t)n_items * P * sizeof(int), stream);
-    if (ze != hipSuccess) return (int)ze;
-  }
   ocrf::launch(OCRF_K_RASTER_PLAN_UPDATE, raster_plan_update_kernel, dim3((P + kBlock - 1) / kBlock, n_sets),
                dim3(kBlock), (size_t)g_update_lds, stream, P, vps, total_kept, header, reinterpret_cast<const unsigned*>(pb + L.g_mask),
                reinterpret_cast<const int*>(pb + L.g_off), reinterpret_cast<const unsigned*>(pb + L.e_pos),
@@ -903,7 +919,7 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
                        reinterpret_cast<const unsigned*>(pb + L.s_key), reinterpret_cast<const float2*>(pb + L.s_pix),
                        reinterpret_cast<const unsigned*>(pb + L.s_e), static_cast<const Rect*>(d_rect),
                        static_cast<const float4*>(d_con), colors, bg, out_color, out_depth, out_final_T,
-                       static_cast<const int*>(flag), queue);
+                       static_cast<const int*>(flag), queue, chain_hist, (int)chain_hist_words);
     return (int)hipGetLastError();
   }
 #define OCRF_BLEND_SORTED(MED, WS)                                                                                   \
@@ -916,7 +932,7 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
                reinterpret_cast<const float2*>(pb + L.s_pix), reinterpret_cast<const unsigned*>(pb + L.s_e),           \
                static_cast<const Rect*>(d_rect),                                                                       \
                static_cast<const float4*>(d_con), colors, bg, out_color, out_depth, out_final_T,                       \
-               static_cast<const int*>(flag), queue)
+               static_cast<const int*>(flag), queue, chain_hist, (int)chain_hist_words)
   if (depth_mode == 0 && g_plan_wskip) OCRF_BLEND_SORTED(true, true);
   else if (depth_mode == 0) OCRF_BLEND_SORTED(true, false);
   else if (g_plan_wskip) OCRF_BLEND_SORTED(false, true);
@@ -925,11 +941,13 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   if (guard) {
-    // the per-call pipeline, armed: every kernel of it retires at once unless the extent check fired
+    // the per-call pipeline, armed: every kernel of it retires at once unless the extent check fired (measured: on a
+    // side stream beside the blend the four launches do not get cheaper — their workgroups wait for the persistent
+    // blend's slots — so they stay in the caller's stream)
     return ocrf::raster_forward_chain(P, n_sets, vps, H, W, means3D, colors, opacities, scales, scale_modifier,
                                       rotations, nullptr, reinterpret_cast<const float*>(cams), item_view, bg,
                                       depth_mode, out_color, out_depth, out_final_T, nullptr, radii, nullptr, nullptr,
-                                      chain_workspace, chain_workspace_bytes, flag, true, stream);
+                                      chain_workspace, chain_workspace_bytes, flag, true, true, stream);
   }
   return 0;
 }

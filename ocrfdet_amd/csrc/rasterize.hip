@@ -492,8 +492,18 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
     const float* __restrict__ colors, const float* __restrict__ bg, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_final_T,
     unsigned* __restrict__ out_n_contrib, int* __restrict__ status, BwdArgs bw, int vps,
-    const int* __restrict__ gate) {
-  if (gate && *gate == 0) return;
+    int* __restrict__ gate) {
+  if (gate) {
+    if (*gate == 0) return;
+    // Armed AND fired (raster_plan.hip): this is the last kernel that reads the flag, and every workgroup gets here
+    // having read it — the last arriver lowers it for the next call (no memset launch per call; the arrival counter
+    // gate[1] is zeroed by the plan's update kernel).  The barrier keeps this workgroup's own reads ahead of its arrival.
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int total = (int)(gridDim.x * gridDim.y * gridDim.z);
+      if (atomicAdd(gate + 1, 1) == total - 1) gate[0] = 0;
+    }
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned long long rec[];
   float4* l_a = reinterpret_cast<float4*>(rec + kCapRec);          // x, y, conic.x, conic.y
   float4* l_b = l_a + kStage;                                      // BWD: conic.z, opacity, depth, r; fwd: see staging
@@ -1216,12 +1226,22 @@ unsigned long long* g_stamps = nullptr;   // diagnostic: per-tile phase cycles (
 
 namespace ocrf {
 
+// the bucket histograms (+ per-view visible counts) inside a chain workspace: what a caller that arms the chain
+// (hist_is_zero) has to clear itself before the chain's first kernel
+int* raster_chain_hist(void* workspace, int P, int n_views, size_t* n_words) {
+  RasterWs ws;
+  raster_layout(P, n_views, &ws);
+  *n_words = (size_t)n_views * (kBuckets + 1);
+  return reinterpret_cast<int*>(static_cast<char*>(workspace) + ws.hist);
+}
+
 int raster_forward_chain(int P, int n_sets, int views_per_set, int H, int W, const float* means3D, const float* colors,
                          const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                          const float* cov3D_precomp, const float* cameras, const int* view_sel, const float* bg,
                          int depth_mode, float* out_color, float* out_depth, float* out_final_T,
                          uint32_t* out_n_contrib, int* radii, uint32_t* tiles_touched, int* status, void* workspace,
-                         size_t workspace_bytes, const int* gate, bool shared_means, hipStream_t stream) {
+                         size_t workspace_bytes, int* gate, bool shared_means, bool hist_is_zero,
+                         hipStream_t stream) {
   if (n_sets <= 0 || views_per_set <= 0) return (int)hipErrorInvalidValue;
   const int n_views = n_sets * views_per_set;
   if (P < 0 || n_views <= 0 || H <= 0 || W <= 0 || (depth_mode != 0 && depth_mode != 1) ||
@@ -1256,7 +1276,8 @@ int raster_forward_chain(int P, int n_sets, int views_per_set, int H, int W, con
   const Camera* cams = reinterpret_cast<const Camera*>(cameras);
 
   int* vis_count = hist + (size_t)n_views * kBuckets;
-  hipError_t e = ocrf::zero_async(hist, (size_t)n_views * (kBuckets + 1) * sizeof(int), stream);
+  hipError_t e = hipSuccess;
+  if (!hist_is_zero) e = ocrf::zero_async(hist, (size_t)n_views * (kBuckets + 1) * sizeof(int), stream);
   if (e != hipSuccess) return (int)e;
   const int n_chunks = (P + kChunk - 1) / kChunk, n_pre = (P + kPreChunk - 1) / kPreChunk;
   const dim3 pgrid(n_chunks, n_views);
@@ -1329,7 +1350,7 @@ int ocrf_rasterize_forward_sets(int P, int n_sets, int views_per_set, int H, int
   return ocrf::raster_forward_chain(P, n_sets, views_per_set, H, W, means3D, colors, opacities, scales, scale_modifier,
                                     rotations, cov3D_precomp, cameras, nullptr, bg, depth_mode, out_color, out_depth,
                                     out_final_T, out_n_contrib, radii, tiles_touched, status, workspace,
-                                    workspace_bytes, nullptr, false, static_cast<hipStream_t>(stream_));
+                                    workspace_bytes, nullptr, false, false, static_cast<hipStream_t>(stream_));
 }
 
 int ocrf_rasterize_forward(int P, int n_views, int H, int W, const float* means3D,
@@ -1411,7 +1432,7 @@ static int rasterize_backward_impl(int P, int n_views, int H, int W, const float
                static_cast<const Rect*>(rects), static_cast<const Rect*>(b_rect),
                static_cast<const unsigned long long*>(b_comp),
                static_cast<const float2*>(xy), static_cast<const float4*>(conic_o), colors, bg, (float*)nullptr,
-               (float*)nullptr, (float*)nullptr, (unsigned*)nullptr, st, bw, n_views, (const int*)nullptr);
+               (float*)nullptr, (float*)nullptr, (unsigned*)nullptr, st, bw, n_views, (int*)nullptr);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   ocrf::launch(OCRF_K_RASTER_PRE_BWD, raster_preprocess_backward_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock),

@@ -78,7 +78,8 @@ class RasterPlan:
     def _scratch(self, n_sets):
         need = _lib.lib().ocrf_rasterize_planned_workspace_bytes(ctypes.c_long(self.total_kept), n_sets)
         if self._dyn is None or self._dyn.numel() < need:
-            self._dyn = torch.empty(max(int(need), 256), dtype=torch.uint8, device=self.device)
+            # zero-filled: the guard flag lives in it between calls (include/ocrf_hip.h, ocrf_rasterize_planned)
+            self._dyn = torch.zeros(max(int(need), 256), dtype=torch.uint8, device=self.device)
         return self._dyn
 
     @torch.no_grad()

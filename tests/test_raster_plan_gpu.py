@@ -127,6 +127,16 @@ def test_extent_bound_guards(cuda):
     got0 = plan.render(rgb, opac, sc, rot, bg, guard='device')
     _same(want0, got0, ('color', 'depth', 'final_T', 'radii'))
     assert not plan.exceeded()
+    # the flag is lowered by the call that fired (no memset per call): fired, fired, quiet, fired, quiet — each exact
+    for scales, ref, fired in ((big, want, True), (big, want, True), (sc, want0, False), (big, want, True),
+                               (sc, want0, False), (sc, want0, False)):
+        got = plan.render(rgb, opac, scales, rot, bg, guard='device')
+        _same(ref, got, ('color', 'depth', 'final_T', 'radii'))
+        assert plan.exceeded() == fired
+    # a host-guarded call that exceeds the bound leaves the flag alone (it is raised only for guarded calls)
+    plan.render(rgb, opac, big, rot, bg)
+    assert plan.exceeded()
+    _same(want0, plan.render(rgb, opac, sc, rot, bg, guard='device'), ('color', 'depth', 'final_T', 'radii'))
     # a NaN scale counts as a violation
     bad = sc.clone()
     bad[5, 1] = float('nan')
