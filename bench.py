@@ -660,7 +660,8 @@ def main():
         if cfg.render:
             # the blend is VALU-bound: flops = 20 per pixel.record, pixel.records counted as the
             # contributor index every pixel stopped at (a lower bound of what the kernel evaluates)
-            evals = float(sum(int(o['n_contrib'].sum().item()) for o in hp.render(want_n_contrib=True))) / hp.batch
+            n_launch = len(hp._plans()) if planned else hp.batch      # a planned launch blends every frame of its plan
+            evals = float(sum(int(o['n_contrib'].sum().item()) for o in hp.render(want_n_contrib=True))) / n_launch
             c = pmc_counters('raster_blend_sorted_kernel' if planned else 'raster_blend_kernel<false, false, true, false>', args)
             cycles = blend_ms * 1e-3 * CLOCK_HZ
             tfl = BLEND_FLOPS_PER_PIXEL_RECORD * evals / (blend_ms * 1e-3) / 1e12

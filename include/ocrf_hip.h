@@ -249,6 +249,10 @@ size_t ocrf_rasterize_workspace_bytes(int P, int n_views);
  *      0 = as many as the device holds at once (fastest alone).  The blend is VALU-bound: two workgroups per CU keep
  *      most of its speed and leave the other wave slots to kernels of other streams (the hot path renders beside its
  *      latency-bound poolings with 2 x CUs: -13 % step time at cfg2).
+ *      yield_if (device int or NULL): a scheduling hint.  With it the blend is launched on every slot the device has
+ *      and the workgroups beyond `blend_workgroups` leave at once while *yield_if != 0 — the caller raises the word
+ *      (ocrf_stream_write_value32) while another stream's chain should keep those wave slots and lowers it when that
+ *      chain is done, so that later renders of the same step take the whole chip.  Any value renders the same image.
  *      phase: 0 = both launches; 1 = only the update, 2 = only the blend of a call whose update already ran (guard 0
  *      only) — the two may then sit on different streams (the update is memory-bound, the blend VALU-bound: frame
  *      n + 1's update runs under frame n's blend), ordered by the caller's events.
@@ -270,7 +274,8 @@ int ocrf_rasterize_planned(const void *plan, size_t plan_bytes, int P, int n_pla
                            const float *rotations, const float *bg, int depth_mode, float *out_color,
                            float *out_depth, float *out_final_T, int *radii, int *status, void *workspace,
                            size_t workspace_bytes, int guard, const float *means3D, void *chain_workspace,
-                           size_t chain_workspace_bytes, int blend_workgroups, int phase, ocrf_stream_t stream);
+                           size_t chain_workspace_bytes, int blend_workgroups, const int *yield_if, int phase,
+                           ocrf_stream_t stream);
 
 /*
  * bev_pool_v2 forward as per-tile MFMA panels (csrc/bev_pool_mfma.hip): out[64 voxels x C] = W[64 x R] . F[R x C]
@@ -701,6 +706,8 @@ int ocrf_diag_where(int n_blocks, unsigned *out, int spin_ticks, void *stream);
  * (GraphedNeck) refuse a graph whose census shows a memset node (e.g. a torch.zeros added inside the captured region). */
 int ocrf_graph_node_census(void *graph, int *n_kernel, int *n_memset, int *n_memcpy, int *n_other);
 int ocrf_stream_create(const uint32_t *cu_mask, int n_words, int priority, void **stream_out);
+/* value -> *ptr (device int) in stream order, no kernel launch (hipStreamWriteValue32). */
+int ocrf_stream_write_value32(int *ptr, int value, ocrf_stream_t stream);
 int ocrf_stream_destroy(void *stream);
 int ocrf_timer_create(int capacity, void **timer_out); /* host pointers */
 int ocrf_timer_arm(void *timer, int kernel_id);

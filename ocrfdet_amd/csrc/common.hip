@@ -198,6 +198,13 @@ int ocrf_stream_create(const uint32_t* cu_mask, int n_words, int priority, void*
   return 0;
 }
 
+// A 32-bit value written to device memory in stream order WITHOUT a kernel launch (hipStreamWriteValue32): the hot
+// path's "main chain busy" hint for the persistent blend (ocrf_rasterize_planned, yield_if).
+int ocrf_stream_write_value32(int* ptr, int value, ocrf_stream_t stream) {
+  if (!ptr) return (int)hipErrorInvalidValue;
+  return (int)hipStreamWriteValue32(static_cast<hipStream_t>(stream), ptr, (uint32_t)value, 0);
+}
+
 // Node census of a captured hipGraph (host call): kernels, memsets, memcpys, everything else.  Replaying a graph that
 // holds MEMSET nodes after an intervening hipMemcpyAsync faults on ROCm 7.2 / gfx950 (launch.h: zero_async), so the
 // owners of captured graphs refuse them.

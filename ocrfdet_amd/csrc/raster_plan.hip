@@ -344,13 +344,18 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
     const Rect* __restrict__ d_rect, const float4* __restrict__ d_con, const float* __restrict__ colors,
     const float* __restrict__ bg,
     float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_final_T,
-    const int* __restrict__ skip_if, int* __restrict__ queue, int* __restrict__ chain_hist, int chain_hist_words) {
+    const int* __restrict__ skip_if, int* __restrict__ queue, int* __restrict__ chain_hist, int chain_hist_words,
+    const int* __restrict__ yield_if, int base_grid) {
   if (skip_if && *skip_if != 0) {
     // the plan's bound does not hold this step: the armed per-call chain renders.  Its bucket histograms are cleared
     // here — by the kernel that sits in front of it anyway — instead of by a launch of their own in every call.
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < chain_hist_words; i += gridDim.x * kBlock) chain_hist[i] = 0;
     return;
   }
+  // A scheduling hint, not a dependency: launched on every slot the device has, the workgroups beyond `base_grid`
+  // leave at once while *yield_if says another stream's chain is still running (it wants those wave slots); the
+  // ticket queue makes any number of participants render the same image.
+  if (yield_if && (int)blockIdx.x >= base_grid && *yield_if != 0) return;
   __shared__ unsigned l_pos[kCapPos];
   __shared__ float4 l_a[kStageP + 1], l_b[kStageP + 1], l_c[kStageP + 1];
   __shared__ unsigned short l_list[4][kStageP + 3 * kTrip + 2];
@@ -862,7 +867,7 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
                            const float* bg, int depth_mode, float* out_color, float* out_depth, float* out_final_T,
                            int* radii, int* status, void* workspace, size_t workspace_bytes, int guard,
                            const float* means3D, void* chain_workspace, size_t chain_workspace_bytes,
-                           int blend_workgroups, int phase, ocrf_stream_t stream_) {
+                           int blend_workgroups, const int* yield_if, int phase, ocrf_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (!plan || P <= 0 || n_plan_views <= 0 || n_plan_views > 32 || total_kept < 0 || total_kept >= (1l << 30) ||
       H <= 0 || W <= 0 || n_sets <= 0 || n_items <= 0 || n_items % n_sets || blend_workgroups < 0 || phase < 0 ||
@@ -911,7 +916,9 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
   if (e != hipSuccess) return (int)e;
   if (phase == 1) return 0;
   const int n_work = gx * ((gy + 1) / 2) * n_items;
-  const int want_grid = g_plan_grid ? g_plan_grid : blend_workgroups;      // the diagnostic knob wins
+  // yield_if: the grid is everything the device holds, `blend_workgroups` of it stay whatever the hint says
+  const int base_grid = (yield_if && blend_workgroups > 0) ? blend_workgroups : (1 << 30);
+  const int want_grid = g_plan_grid ? g_plan_grid : ((yield_if && blend_workgroups > 0) ? 0 : blend_workgroups);      // the diagnostic knob wins
   if (g_plan_stats) {      // diagnostic build (median depth), never used by the product path
     const dim3 sgrid((unsigned)std::min(n_work, want_grid ? want_grid : resident_blocks(raster_blend_sorted_kernel<true, false, true>)));
     hipLaunchKernelGGL((raster_blend_sorted_kernel<true, false, true>), sgrid, dim3(kBlock), 0, stream, g_plan_stats, P, W, H,
@@ -919,7 +926,7 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
                        reinterpret_cast<const unsigned*>(pb + L.s_key), reinterpret_cast<const float2*>(pb + L.s_pix),
                        reinterpret_cast<const unsigned*>(pb + L.s_e), static_cast<const Rect*>(d_rect),
                        static_cast<const float4*>(d_con), colors, bg, out_color, out_depth, out_final_T,
-                       static_cast<const int*>(flag), queue, chain_hist, (int)chain_hist_words);
+                       static_cast<const int*>(flag), queue, chain_hist, (int)chain_hist_words, yield_if, base_grid);
     return (int)hipGetLastError();
   }
 #define OCRF_BLEND_SORTED(MED, WS)                                                                                   \
@@ -932,7 +939,7 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
                reinterpret_cast<const float2*>(pb + L.s_pix), reinterpret_cast<const unsigned*>(pb + L.s_e),           \
                static_cast<const Rect*>(d_rect),                                                                       \
                static_cast<const float4*>(d_con), colors, bg, out_color, out_depth, out_final_T,                       \
-               static_cast<const int*>(flag), queue, chain_hist, (int)chain_hist_words)
+               static_cast<const int*>(flag), queue, chain_hist, (int)chain_hist_words, yield_if, base_grid)
   if (depth_mode == 0 && g_plan_wskip) OCRF_BLEND_SORTED(true, true);
   else if (depth_mode == 0) OCRF_BLEND_SORTED(true, false);
   else if (g_plan_wskip) OCRF_BLEND_SORTED(false, true);

@@ -12,7 +12,7 @@ import math
 import numpy as np
 import torch
 
-from . import bevpool, gaussian_renderer, hoa, index_prep, raster_plan, synthetic
+from . import _lib, bevpool, gaussian_renderer, hoa, index_prep, raster_plan, synthetic
 from .diff_gaussian_rasterization import pack_cameras, rasterize_views
 
 
@@ -58,7 +58,7 @@ def shared_stream(device, role):
 class HotPath:
     def __init__(self, cfg, device, cams=None, index_prep_mode='cached', overlap=True, device_geometry=False,
                  render_mode='planned', render_guard='host', frame_motion=True, frame_offset=0, plan_margin=1.25,
-                 ht_pool_backend='mfma', fuse_frames=False, render_streams=1, blend_workgroups='auto'):
+                 ht_pool_backend='mfma', fuse_frames='auto', render_streams=1, blend_workgroups='auto'):
         """``cams``: optional list of camera indices this instance owns (camera sharding).
         ``index_prep_mode``: 'cached' — rank vectors computed once per calibration, the reference's
         ``accelerate=True`` intent; 'per_step' — recomputed inside every ``step()`` by the HIP index
@@ -78,12 +78,16 @@ class HotPath:
         # 3.2 m block beside the rig collects thousands of rows — make the per-tile MFMA chain the launch's tail).
         assert ht_pool_backend in ('mfma', 'tile')
         self.ht_pool_backend = ht_pool_backend
-        self.fuse_frames = bool(fuse_frames)      # planned renders: consecutive frames in one plan / one launch pair
+        # planned renders: consecutive frames in one plan / one launch pair.  'auto': when ALL frames fit one plan
+        # (<= 32 views; cfg2: 0.300 -> 0.285 ms — one update -> blend hand-over and one drain of the persistent grid
+        # less); with more frames a launch pair per frame is faster (cfg4: 3.08 vs 3.18 ms in groups of five)
+        self.fuse_frames = fuse_frames
         self.render_streams = max(1, int(render_streams))      # side HIP streams the frames' renders are dealt over
         # size of the planned blend's persistent grid per frame (int, or a sequence with one entry per frame; 0 = what
         # the device holds).  'auto': beside the main chain (overlap) the VALU-bound blend takes two workgroups per CU
         # and leaves the other wave slots to the latency-bound poolings / HOA of the main stream (cfg2: 0.344 -> 0.30 ms)
         self.blend_workgroups = blend_workgroups
+        self._busy = torch.zeros(1, dtype=torch.int32, device=self.device) if self.device.type == 'cuda' else None
         self.cams = list(range(cfg.n_cams)) if cams is None else list(cams)
         self.batch = cfg.batch * cfg.n_frames                  # frames ride along as batch entries
         assert index_prep_mode in ('cached', 'per_step')
@@ -239,7 +243,8 @@ class HotPath:
             H, W = self.cfg.input_size
             n_cam = len(self.cams)
             same = all(torch.equal(self.voxel_xyz[b], self.voxel_xyz[0]) for b in range(1, self.batch))
-            per = max(1, 32 // n_cam) if (same and self.fuse_frames) else 1
+            fuse = (self.batch * n_cam <= 32) if self.fuse_frames == 'auto' else bool(self.fuse_frames)
+            per = max(1, 32 // n_cam) if (same and fuse) else 1
             self.render_plans = []
             for f0 in range(0, self.batch, per):
                 fr = list(range(f0, min(f0 + per, self.batch)))
@@ -266,6 +271,18 @@ class HotPath:
                                rc['tfy'], H, W, self.bg, packed_cameras=rc['packed'], want_n_contrib=want_n_contrib,
                                workspace_tag=tag)
 
+    def _use_busy(self):
+        # the hint pays when a step has several blend launches (cfg4: one per frame, 3.08 -> 2.70 ms); with ONE
+        # launch per step every extra workgroup would leave at once anyway, and the two stream writes are not free
+        # (cfg2: 0.288 -> 0.301 ms)
+        plans = getattr(self, 'render_plans', None)
+        return bool(self.overlap and self._busy is not None and plans is not None and len(plans) > 1)
+
+    def _set_busy(self, value):
+        if self._use_busy():
+            _lib.check(_lib.lib().ocrf_stream_write_value32(_lib.ptr(self._busy), int(value), _lib.stream_ptr(self.device)),
+                       'ocrf_stream_write_value32')
+
     def _render_planned(self, entry, phase='both', out=None):
         plan, f0, nf, g = entry
         bw = self.blend_workgroups
@@ -274,7 +291,8 @@ class HotPath:
         elif not isinstance(bw, int):
             bw = int(bw[min(f0, len(bw) - 1)])
         out = plan.render(g['rgb'], g['opacity'], g['scales'], g['rotations'], self.bg, guard=self.render_guard,
-                          item_view=g['item_view'] if nf > 1 else None, blend_workgroups=bw, phase=phase, out=out)
+                          item_view=g['item_view'] if nf > 1 else None, blend_workgroups=bw, phase=phase, out=out,
+                          yield_if=self._busy if (bw and self._use_busy()) else None)
         if phase == 'update':
             return out
         n = len(self.cams)
@@ -387,6 +405,9 @@ class HotPath:
         fork = self.overlap and self.cfg.render
         if fork:
             cur = torch.cuda.current_stream(self.device)
+            # "the main chain is running": the persistent blends of the render stream keep to two workgroups per CU
+            # while it is up and take the whole chip once it is down (cfg4: the renders outlast the poolings + HOA)
+            self._set_busy(1)
             if not self._side:
                 self._side = [shared_stream(self.device, 'render' if k == 0 else f'render{k}')
                               for k in range(self.render_streams)]
@@ -441,6 +462,7 @@ class HotPath:
             # the pools and HOA-3 are MIOpen territory, not part of this path
             out.extend(self.hoa_step(ht, ob))
         if fork:
+            self._set_busy(0)
             for side in self._side:
                 cur.wait_stream(side)                 # join: everything the step returns is ordered on `cur`
         return tuple(out)

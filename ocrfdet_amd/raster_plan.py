@@ -84,13 +84,16 @@ class RasterPlan:
 
     @torch.no_grad()
     def render(self, colors, opacities, scales, rotations, bg, scale_modifier=1.0, depth_mode='median',
-               item_view=None, want_radii=False, guard='host', out=None, blend_workgroups=0, phase='both'):
+               item_view=None, want_radii=False, guard='host', out=None, blend_workgroups=0, phase='both',
+               yield_if=None):
         """Render ``n_items = len(item_view)`` views: item z = plan view ``item_view[z]`` (int32 device tensor) with
         Gaussian set ``z // (n_items // S)`` of the ``(S, P, .)`` (or ``(P, .)``) parameter tensors; without
         ``item_view`` every set renders all ``V`` plan views in order.
         -> dict ``color`` (n_items,3,H,W), ``depth`` (n_items,1,H,W), ``final_T`` (n_items,H,W) [, ``radii``
         (n_items,P)], ``status`` (the plan's sticky device word).  ``blend_workgroups``: size of the blend's persistent
         grid; 0 = what the device holds at once (fastest alone), ~2 per CU when other streams should run beside it.
+        ``yield_if``: int32 device word — with it the blend takes every slot of the device and the workgroups beyond
+        ``blend_workgroups`` leave at once while the word is non-zero (a scheduling hint: same image either way).
         ``phase``: 'both', or 'update' then (same arguments, same ``out``) 'blend' — possibly on another stream, ordered by
         the caller's events (``guard='host'`` only)."""
         _lib.require_cuda(colors, opacities, scales, rotations, bg)
@@ -140,7 +143,8 @@ class RasterPlan:
                 _lib.ptr(out['color']), _lib.ptr(out['depth']), _lib.ptr(out['final_T']), _lib.ptr(radii),
                 _lib.ptr(self.status), _lib.ptr(dyn), ctypes.c_size_t(dyn.numel()), use_guard,
                 _lib.ptr(self.means3D), _lib.ptr(chain), ctypes.c_size_t(chain.numel() if chain is not None else 0),
-                int(blend_workgroups), {'both': 0, 'update': 1, 'blend': 2}[phase], _lib.stream_ptr(dev)),
+                int(blend_workgroups), _lib.ptr(yield_if), {'both': 0, 'update': 1, 'blend': 2}[phase],
+                _lib.stream_ptr(dev)),
                 'ocrf_rasterize_planned')
         out['status'] = self.status
         return out
