@@ -15,9 +15,9 @@ ap.add_argument('knobs', nargs='*')
 ap.add_argument('--steps', type=int, default=200)
 ap.add_argument('--ht', default='mfma')
 ap.add_argument('--render-mode', default='planned')
-ap.add_argument('--fuse', type=int, default=0)
+ap.add_argument('--fuse', type=int, default=1)
 ap.add_argument('--rstreams', type=int, default=1)
-ap.add_argument('--hoa-first', type=int, default=1)
+ap.add_argument('--hoa-first', type=int, default=0)
 ap.add_argument('--hoa-stream', type=int, default=0)
 ap.add_argument('--bw', default='auto', help="blend workgroups: auto | n | n0,n1 (per frame)")
 a = ap.parse_args()

@@ -24,7 +24,7 @@ for _ in range(10):
 torch.cuda.synchronize()
 side = hotpath.shared_stream(dev, 'render')
 cur = torch.cuda.current_stream(dev)
-names = ['start', 'hoa12 (after the pools)', 'lss', 'ht', 'hoa3', 's_start', 'upd0+blend0', 'upd1+blend1']
+names = ['start', 'hoa12 (after the pools)', 'lss', 'ht', 'hoa3', 's_start', 'update (fused) | upd0+blend0', 'blend (fused) | upd1+blend1']
 N = 60
 stamps = torch.zeros(N, len(names), dtype=torch.int64, device=dev)
 for it in range(N):
@@ -33,11 +33,16 @@ for it in range(N):
     side.wait_stream(cur)
     with torch.cuda.stream(side):
         _lib.diag_stamp(row, 5)
-        plans = hp._plans()
-        hp._render_planned(plans[0])
-        _lib.diag_stamp(row, 6)
-        hp._render_planned(plans[1])
-        _lib.diag_stamp(row, 7)
+        plans = hp._plans()               # one fused plan (both frames) by default, or one per frame
+        for k, entry in enumerate(plans):
+            if len(plans) == 1:
+                o = hp._render_planned(entry, phase='update')
+                _lib.diag_stamp(row, 6)
+                hp._render_planned(entry, phase='blend', out=o)
+                _lib.diag_stamp(row, 7)
+            else:
+                hp._render_planned(entry)
+                _lib.diag_stamp(row, 6 + k)
     lss = hp.pool(hp.lss, depth, feat)
     _lib.diag_stamp(row, 2)
     ht = hp.pool(hp.ht, depth, feat)
@@ -53,5 +58,5 @@ rel = (s - s[:, :1]) / 100.0        # us at 100 MHz
 med = np.median(rel[20:], 0)
 print('steady-state period %.1f us' % np.median(np.diff(s[20:, 0]) / 100.0))
 for n, v in zip(names, med):
-    print(f'{n:24s} {v:8.1f} us')
+    print(f'{n:32s} {v:8.1f} us')
 print('step end       %8.1f us' % max(med[4], med[7]))
