@@ -721,6 +721,11 @@ def main():
                              'samples': f'{world} ranks x 1 sample (6 cams x {cfg.n_frames} frames) each, no data-path collective',
                              'frames': f'{world} x {cfg.n_frames} frames of one sequence, one RCCL all_gather of the fused BEV per step',
                              'cameras': f'1 sample, cameras over {min(world, cfg.n_cams)} of {world} ranks, one RCCL all_reduce of the fused BEV per step'}[shard]
+        plan_note = 'one plan per frame'
+        plans_built = getattr(hp, 'render_plans', None)
+        if planned and plans_built:
+            plan_note = (f'{len(plans_built)} plan(s) for {hp.batch} frame(s): frames that fit a 32-view plan share one '
+                         'update + one blend launch')
         out = {
             'metric': 'BEV voxels/sec + rendered views/sec, 6-cam 256x704',
             'value': voxels / elapsed, 'unit': 'BEV voxels/s',
@@ -740,15 +745,16 @@ def main():
                        'views_per_step': hp.views_per_step if sp is None else cfg.batch * cfg.n_frames * cfg.n_cams,
                        'render_camera': getattr(hp, 'render_convention', None),
                        'render_front_end': (None if not cfg.render else
-                                            ('static render plan per frame (cull, depth order, projected centres cached per calibration '
-                                             'like the rank vectors; Gaussian means = the fixed voxel grid); extent bound '
+                                            ('static render plan (cull, depth order, projected centres cached per calibration like the rank '
+                                             'vectors; Gaussian means = the fixed voxel grid; ' + plan_note + '); extent bound '
                                              + ('verified by one status read after the timed region' if args.render_guard == 'host'
                                                 else 'guarded on the device (per-call pipeline armed behind every render)'))
                                             if planned else 'per call (preprocess + depth-bucket scatter every render)'),
                        'frames': 'each frame its own ego pose and Gaussian parameters (synthetic.ego_motion)',
-                       'streams': ('main: pools, then HOA; side HIP stream: per frame render update + blend; the blend (VALU-bound) '
+                       'streams': ('main: pools, then HOA; side HIP stream: render update + blend per plan; the blend (VALU-bound) '
                                    'runs as a persistent grid of 2 workgroups per CU so that the latency-bound kernels of the '
-                                   'main stream keep wave slots (DESIGN.md section 5)' if hp.overlap and cfg.render and planned
+                                   'main stream keep wave slots (with several blends per step the rest of the grid joins once '
+                                   'the main chain is done; DESIGN.md section 5)' if hp.overlap and cfg.render and planned
                                    else ('main: HOA-1/2, pools, HOA-3; side HIP stream: renders' if hp.overlap and cfg.render
                                          else 'single stream')),
                        'ht_pool': getattr(hp, 'ht_pool_backend', None),
