@@ -101,7 +101,7 @@ class HotPath:
         # worse: two blends at once slow each other more than the overlap returns (0.66 vs 0.60 ms)
         self.overlap = bool(overlap) and self.device.type == 'cuda'
         self._side = []
-        self._prep_stream = None
+        self._prep_stream = self._prep_stream2 = None
         self._prepare()
 
     def _prepare(self):
@@ -363,6 +363,28 @@ class HotPath:
                                                       plan.starts, plan.lengths)
         return bevpool.bev_pool_v2_planned(depth, feat, plan.device_plan, out=out)
 
+    def _camera_blocks(self):
+        cfg, dev, args = self.cfg, self.device, self._calib_host
+        if self.device_geometry and hasattr(self, '_calib_dev'):
+            lss_block, ht_block, _ = index_prep.geometry_blocks_hip(*self._calib_dev, None, cfg.input_size)
+        else:
+            lss_block = index_prep.lss_camera_block(*args).to(dev, non_blocking=True)
+            lidar2img, img_aug, _, _ = index_prep.get_projection(*args)
+            ht_block = index_prep.ht_camera_block(lidar2img, img_aug).to(dev, non_blocking=True)
+        return lss_block, ht_block
+
+    def _prepare_lss(self, lss_block):
+        B, N = self._calib_host[1].shape[:2]
+        return index_prep.voxel_pooling_prepare_v2_hip(self._frustum_dev, lss_block, B, N, *self._grid,
+                                                       buffers=self._lss_bufs, sync=False)
+
+    def _prepare_ht(self, ht_block):
+        cfg = self.cfg
+        B, N = self._calib_host[1].shape[:2]
+        Hf, Wf = cfg.feat_hw
+        return index_prep.fast_sample_prepare_hip(self._ref_template, ht_block, B, N, list(cfg.pc_range), cfg.input_size,
+                                                  cfg.grid['depth'], Wf, Hf, cfg.D, buffers=self._ht_bufs, sync=False)
+
     def prepare_indices_hip(self, sync=True):
         """Rank vectors of both poolings from the calibration, on the device (view_transformer.py:108-147,
         197-255; view_transformer_ocrf.py:675-740,785-852): tiny per-camera algebra on the host, one
@@ -372,16 +394,9 @@ class HotPath:
         Hf, Wf = cfg.feat_hw
         args = self._calib_host
         B, N = args[1].shape[:2]
-        if self.device_geometry and hasattr(self, '_calib_dev'):
-            lss_block, ht_block, _ = index_prep.geometry_blocks_hip(*self._calib_dev, None, cfg.input_size)
-        else:
-            lss_block = index_prep.lss_camera_block(*args).to(dev, non_blocking=True)
-            lidar2img, img_aug, _, _ = index_prep.get_projection(*args)
-            ht_block = index_prep.ht_camera_block(lidar2img, img_aug).to(dev, non_blocking=True)
-        lss = index_prep.voxel_pooling_prepare_v2_hip(self._frustum_dev, lss_block, B, N, *self._grid,
-                                                      buffers=self._lss_bufs, sync=False)
-        ht = index_prep.fast_sample_prepare_hip(self._ref_template, ht_block, B, N, list(cfg.pc_range), cfg.input_size,
-                                                cfg.grid['depth'], Wf, Hf, cfg.D, buffers=self._ht_bufs, sync=False)
+        lss_block, ht_block = self._camera_blocks()
+        lss = self._prepare_lss(lss_block)
+        ht = self._prepare_ht(ht_block)
         if not sync:
             return lss, ht                                      # ((five capacity vectors), counts) each
         counts = torch.stack((lss[1], ht[1])).cpu()           # ONE device->host read for both (4 ints)
@@ -424,12 +439,25 @@ class HotPath:
             # beside them; the poolings wait for it.  Only with the calibration algebra on the device: the host
             # formulation uploads its blocks from pageable memory, and that copy would make the host wait for the
             # previous step at the top of this one
+            # The two preparations are independent chains of ~ 10 / 5 launches (89 / 62 us alone): one stream each
+            # (their look-back scratch is per stream, index_prep._prep_tag), the calibration blocks computed once on
+            # the first and handed over by an event; each pooling waits only for its own ranks.
             cur0 = torch.cuda.current_stream(self.device)
             if self._prep_stream is None:
                 self._prep_stream = shared_stream(self.device, 'prep')
-            self._prep_stream.wait_stream(cur0)
-            with torch.cuda.stream(self._prep_stream):
-                prepared = self.prepare_indices_hip(sync=False)
+                self._prep_stream2 = shared_stream(self.device, 'prep2')
+            p1, p2 = self._prep_stream, self._prep_stream2
+            p1.wait_stream(cur0)
+            p2.wait_stream(cur0)
+            with torch.cuda.stream(p1):
+                lss_block, ht_block = self._camera_blocks()
+                blocks_ready = torch.cuda.Event()
+                blocks_ready.record(p1)
+                ht_block.record_stream(p2)
+                lss_prepared = self._prepare_lss(lss_block)
+            p2.wait_event(blocks_ready)
+            with torch.cuda.stream(p2):
+                prepared = (lss_prepared, self._prepare_ht(ht_block))
         # HOA-1/2 need nothing of the poolings and the poolings nothing of them: with the planned render (a memory-bound
         # update kernel, then the VALU-bound blend on two workgroups per CU) the poolings go FIRST — they meet the
         # side stream's update and the start of its blend instead of its middle (cfg2: 0.305 -> 0.292 ms); with the
@@ -437,8 +465,6 @@ class HotPath:
         # (per-step index preparation: HOA-1/2 first, beside the preparation the poolings have to wait for anyway)
         hoa_first = getattr(self, 'hoa_first', self.render_mode != 'planned' or self.index_prep_mode == 'per_step')
         ob = self.hoa_opacity_bev() if (self.cfg.hoa and hoa_first) else None
-        if prepared is not None:
-            torch.cuda.current_stream(self.device).wait_stream(self._prep_stream)
         hoa_side = None
         if self.cfg.hoa and not hoa_first and getattr(self, 'hoa_stream', False) and self.overlap:
             # HOA-1/2 (ten small kernels, 16-338 workgroups each) on a stream of their own beside the poolings
@@ -446,7 +472,15 @@ class HotPath:
             hoa_side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(hoa_side):
                 ob = self.hoa_opacity_bev()
-        lss, ht = self.pool_step(depth, feat, prepared)
+        if prepared is not None:
+            main = torch.cuda.current_stream(self.device)
+            (lv, lc), (hv, hc) = prepared
+            main.wait_stream(self._prep_stream)
+            lss = bevpool.bev_pool_v2_device_counts(depth, feat, lv[1], lv[2], lv[0], self.lss.bev_shape, lv[3], lv[4], lc)
+            main.wait_stream(self._prep_stream2)
+            ht = bevpool.bev_pool_v2_device_counts(depth, feat, hv[1], hv[2], hv[0], self.ht.bev_shape, hv[3], hv[4], hc)
+        else:
+            lss, ht = self.pool_step(depth, feat, prepared)
         if hoa_side is not None:
             torch.cuda.current_stream(self.device).wait_stream(hoa_side)
             ob.record_stream(torch.cuda.current_stream(self.device))

@@ -136,6 +136,31 @@ def test_per_step_path_without_host_reads_equals_cached_path(cuda, key):
         assert torch.equal(g, w)
 
 
+def test_per_step_path_on_two_preparation_streams_equals_cached_path(cuda):
+    """The whole cfg2 step with the index preparation inside AND the calibration algebra on the device: the two
+    preparations run on a stream each beside HOA-1/2, every pooling waits for its own ranks only — pooled BEVs, HOA
+    outputs and renders equal the single-stream step's bit for bit, step after step (the look-back scratch is per
+    stream, the buffers are reused)."""
+    from ocrfdet_amd import hotpath
+    cfg = synthetic.CONFIGS['cfg2_6cam_2frame_bev200x200_render_hoa']
+    # the same step on ONE stream (device geometry may move a borderline HT sample by one cell against the host
+    # algebra, tests/test_device_geometry_gpu.py: the reference here is the device-geometry step itself)
+    a = hotpath.HotPath(cfg, cuda, index_prep_mode='per_step', device_geometry=True, overlap=False)
+    b = hotpath.HotPath(cfg, cuda, index_prep_mode='per_step', device_geometry=True)
+    assert hasattr(b, '_calib_dev')
+    depth, feat = a.make_inputs(seed=3)
+    want = a.step(depth, feat)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        got = b.step(depth, feat)
+        torch.cuda.synchronize()
+        assert b._prep_stream2 is not None
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])                 # LSS, HT
+        for g, w in zip(got[2], want[2]):                                                    # renders per frame
+            assert torch.equal(g['color'], w['color']) and torch.equal(g['depth'], w['depth'])
+        assert torch.equal(got[3], want[3]) and torch.equal(got[4], want[4])                 # gated BEV, opacity BEV
+
+
 SWEEP = [  # (B, N, input H, W, BEV Y, X, z cells, heights): one-tile grids, ragged tiles, several scan tiles, empty cameras
     (1, 1, 32, 48, 4, 4, 1, 5), (1, 2, 64, 96, 9, 17, 2, 6), (2, 3, 64, 176, 33, 31, 1, 13), (3, 1, 128, 160, 64, 64, 4, 7),
     (1, 6, 96, 128, 130, 70, 1, 13), (2, 2, 48, 64, 257, 3, 1, 8)]

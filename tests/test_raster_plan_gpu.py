@@ -205,6 +205,29 @@ def test_opacity_edge_values_and_degenerate_inputs(cuda):
     assert plan.check()
 
 
+def test_blend_grid_and_yield_hint_do_not_change_the_image(cuda):
+    """The sorted blend is a persistent grid over a ticket queue: any number of workgroups renders the same image, and
+    the ``yield_if`` hint (workgroups beyond ``blend_workgroups`` leave while the word is up) only changes who does
+    the work.  The word is written in stream order without a launch (ocrf_stream_write_value32)."""
+    from ocrfdet_amd import _lib
+    rng = np.random.default_rng(29)
+    W, H = 176, 80
+    xyz, rgb, opac, sc, rot = _scene(rng, 20000, cuda)
+    cams = _cams(cuda, W, H, [(0, 0, 0), (1.5, -0.5, 2.0), (-3.0, 0.4, -1.0)])
+    bg = torch.tensor([0.0, 0.3, 0.6], device=cuda)
+    plan = rp.RasterPlan(xyz, cams, H, W, scales=sc, rotations=rot)
+    want = {k: v.clone() for k, v in plan.render(rgb, opac, sc, rot, bg).items()}
+    word = torch.zeros(1, dtype=torch.int32, device=cuda)
+    for grid in (1, 7, 64, 4096):
+        _same(want, plan.render(rgb, opac, sc, rot, bg, blend_workgroups=grid))
+        for busy in (1, 0, 5):
+            _lib.check(_lib.lib().ocrf_stream_write_value32(_lib.ptr(word), busy, _lib.stream_ptr(cuda)), 'write_value32')
+            got = plan.render(rgb, opac, sc, rot, bg, blend_workgroups=grid, yield_if=word)
+            assert int(word.item()) == busy
+            _same(want, got)
+    assert plan.check()
+
+
 def test_mostly_transparent_scene(cuda):
     """Free space: 90 % of the Gaussians under the 1/255 opacity threshold (their rects are emptied by the update
     kernel, so no tile pair scans into them) — same images as the per-call pipeline, with and without radii."""
