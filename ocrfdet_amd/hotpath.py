@@ -435,10 +435,10 @@ class HotPath:
         prepared = None
         if (self.index_prep_mode == 'per_step' and self.cfg.hoa and self.overlap and self.device_geometry
                 and hasattr(self, '_calib_dev')):
-            # the index preparation (~ 20 launches, 0.17 ms) needs nothing HOA-1/2 produce: on a stream of its own
-            # beside them; the poolings wait for it.  Only with the calibration algebra on the device: the host
-            # formulation uploads its blocks from pageable memory, and that copy would make the host wait for the
-            # previous step at the top of this one
+            # the index preparation (~ 20 launches, 0.17 ms) needs nothing HOA-1/2 produce: on streams of its own
+            # beside them; the poolings wait for it.  Only with the calibration algebra on the device: with the host
+            # formulation the step is bound by the host (its ~ 20 small CPU torch ops + ~ 60 launches), and the extra
+            # stream / event calls cost more than the overlap returns (measured with pinned upload slots: 0.55 -> 0.61-0.70 ms)
             # The two preparations are independent chains of ~ 10 / 5 launches (89 / 62 us alone): one stream each
             # (their look-back scratch is per stream, index_prep._prep_tag), the calibration blocks computed once on
             # the first and handed over by an event; each pooling waits only for its own ranks.
