@@ -525,12 +525,25 @@ __global__ __launch_bounds__(kBlock, 5) void bev_pool_tile_kernel(TileArgs a, un
         float4* s0 = a.slabs + (long)ti.y * kTV * c4;
         const auto srs = __builtin_amdgcn_make_buffer_rsrc(s0, 0, ti.x * kTV * c4 * (int)sizeof(float4), 0x00020000);
         if (gi < gpw) {
+          // slice order for the sums, but four slab loads in flight per lane (they do not depend on each other)
+          constexpr int kSB = 4;
           for (int v = gb; v < nv; v += gpb) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int s = 0; s < ti.x; ++s) {
-              const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(srs, ((s * kTV + v) * c4 + lg) * (int)sizeof(float4), 0, 17);
-              const float4 x = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
-              acc = s == 0 ? x : add4(acc, x);
+            for (int s0 = 0; s0 < ti.x; s0 += kSB) {
+              u32x4 r[kSB];
+#pragma unroll
+              for (int k = 0; k < kSB; ++k) {
+                const int s = min(s0 + k, ti.x - 1);
+                r[k] = __builtin_amdgcn_raw_buffer_load_b128(srs, ((s * kTV + v) * c4 + lg) * (int)sizeof(float4), 0, 17);
+              }
+#pragma unroll
+              for (int k = 0; k < kSB; ++k) {
+                if (s0 + k < ti.x) {
+                  const float4 x = make_float4(__uint_as_float(r[k].x), __uint_as_float(r[k].y), __uint_as_float(r[k].z),
+                                               __uint_as_float(r[k].w));
+                  acc = (s0 + k == 0) ? x : add4(acc, x);
+                }
+              }
             }
             tile[v * ldq + lg] = acc;
           }

@@ -58,7 +58,8 @@ def shared_stream(device, role):
 class HotPath:
     def __init__(self, cfg, device, cams=None, index_prep_mode='cached', overlap=True, device_geometry=False,
                  render_mode='planned', render_guard='host', frame_motion=True, frame_offset=0, plan_margin=1.25,
-                 ht_pool_backend='mfma', fuse_frames='auto', render_streams=1, blend_workgroups='auto'):
+                 ht_pool_backend='mfma', fuse_frames='auto', render_streams=1, blend_workgroups='auto',
+                 lss_pool_backend='tile', lss_mfma_group=2):
         """``cams``: optional list of camera indices this instance owns (camera sharding).
         ``index_prep_mode``: 'cached' — rank vectors computed once per calibration, the reference's
         ``accelerate=True`` intent; 'per_step' — recomputed inside every ``step()`` by the HIP index
@@ -76,8 +77,9 @@ class HotPath:
         # 'mfma': the HT pooling (cached ranks) as per-tile MFMA panels (csrc/bev_pool_mfma.hip: 26 vs 32 us at cfg2);
         # 'tile': the VALU tile kernel for both poolings.  The LSS ranks keep the tile kernel (its heavy tiles — a
         # 3.2 m block beside the rig collects thousands of rows — make the per-tile MFMA chain the launch's tail).
-        assert ht_pool_backend in ('mfma', 'tile')
+        assert ht_pool_backend in ('mfma', 'tile') and lss_pool_backend in ('mfma', 'tile')
         self.ht_pool_backend = ht_pool_backend
+        self.lss_pool_backend, self.lss_mfma_group = lss_pool_backend, int(lss_mfma_group)
         # planned renders: consecutive frames in one plan / one launch pair.  'auto': when ALL frames fit one plan
         # (<= 32 views; cfg2: 0.300 -> 0.285 ms — one update -> blend hand-over and one drain of the persistent grid
         # less); with more frames a launch pair per frame is faster (cfg4: 3.08 vs 3.18 ms in groups of five)
@@ -352,11 +354,13 @@ class HotPath:
             if out is not None:
                 out.view_as(res).copy_(res)
             return res
-        if plan is self.ht and self.ht_pool_backend == 'mfma' and plan.bev_shape[-1] in (64, 80, 96, 128):
-            # the height-sampling ranks (11 points per feature row and 8x8 tile, no heavy tiles): per-tile MFMA panels
+        mfma = ((plan is self.ht and self.ht_pool_backend == 'mfma') or (plan is self.lss and self.lss_pool_backend == 'mfma'))
+        if mfma and plan.bev_shape[-1] in (64, 80, 96, 128):
+            # per-tile MFMA panels.  The height-sampling ranks have no heavy tiles (11 points per feature row and 8x8
+            # tile): units of up to 8 panels; the LSS ranks do (the block beside the rig): short units, more slabs
             if plan.mfma_plan is None:
                 plan.mfma_plan = bevpool.MfmaPoolPlan(plan.ranks_depth, plan.ranks_feat, plan.ranks_bev, plan.bev_shape,
-                                                      group=8)
+                                                      group=8 if plan is self.ht else self.lss_mfma_group)
             return bevpool.bev_pool_v2_mfma(depth, feat, plan.mfma_plan, out=out)
         if plan.device_plan is None:
             plan.device_plan = bevpool.DevicePoolPlan(plan.ranks_depth, plan.ranks_feat, plan.ranks_bev, plan.bev_shape,

@@ -16,7 +16,7 @@ ap.add_argument('--iters', type=int, default=50)
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 cfg = synthetic.PathConfig(**{**synthetic.CONFIGS[a.config].__dict__, 'render': False, 'hoa': False})
-hp = hotpath.HotPath(cfg, dev)
+hp = hotpath.HotPath(cfg, dev, ht_pool_backend='tile')      # hp.pool = the VALU tile kernel for both rank sets
 depth, feat = hp.make_inputs(0)
 
 
@@ -57,3 +57,7 @@ for name, pl in (('lss', hp.lss), ('ht', hp.ht)):
           % (*st[:, :6].mean(0), tot.mean(), *np.percentile(tot, [50, 99]), tot.max()))
     print('   panels per unit: mean %.2f max %d; per panel: F+zero %.0f cells %.0f mfma %.0f' % (
         st[:, 6].mean(), st[:, 6].max(), st[:, 0].sum() / st[:, 6].sum(), st[:, 1].sum() / st[:, 6].sum(), st[:, 2].sum() / st[:, 6].sum()))
+    top = np.argsort(-tot)[:5]
+    for u in top:
+        print('   unit %5d: total %.0f = F+zero %.0f cells %.0f mfma %.0f tile->lds %.0f slab %.0f write %.0f | panels %d slices of its tile %d'
+              % (u, tot[u], *st[u, :6], st[u, 6], st[u, 7]))
