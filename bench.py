@@ -592,13 +592,14 @@ def main():
 
     strong = shard in ('cameras', 'camera_frames')
     # ---- the same kernels alone on the device (renders on the main stream) ------------------------------------
-    iso_blend = iso_pool = None
+    iso_blend = iso_pool = iso_mfma = None
     if shard in ('none', 'samples', 'frames'):
         was = hp.overlap
         hp.overlap = False
         ib = _lib.KernelTimer(k_blend, 64) if cfg.render else None
         ip = _lib.KernelTimer(_lib.K_BEV_POOL_FWD, 64)
-        for t in (ib, ip):
+        im = _lib.KernelTimer(_lib.K_BEV_POOL_MFMA, 64)
+        for t in (ib, ip, im):
             if t is not None:
                 t.arm()
         torch.cuda.synchronize()
@@ -608,6 +609,8 @@ def main():
         _lib.KernelTimer.disarm_all()
         iso_blend = ib.mean_ms() if ib is not None else None
         iso_pool = ip.mean_ms()
+        iso_mfma = im.mean_ms()          # None when no pooling ran on the matrix cores
+        im.close()
         for t in (ib, ip):
             if t is not None:
                 t.close()
@@ -654,6 +657,20 @@ def main():
                  'traffic': hbm_traffic(pool_c), 'traffic_source': PMC_FILE if pool_c else None,
                  'isolated_avg_launch_us': 1e3 * iso_pool if iso_pool else None,
                  'isolated_frac': pool_alg / (iso_pool * 1e-3) / 1e9 / HBM_PEAK_GBS if iso_pool else None}
+        if iso_mfma:
+            # the HT pooling on the matrix cores: duration alone on the chip, MFMA counters of the PMC file
+            mc = pmc_counters('bev_pool_mfma_kernel', args)
+            simd_cycles = 1024 * iso_mfma * 1e-3 * CLOCK_HZ
+            pools['mfma'] = {'kernel': 'bev_pool_mfma_kernel<*>', 'pooling': 'HT (height-sampling ranks)',
+                             'isolated_avg_launch_us': 1e3 * iso_mfma,
+                             'SQ_INSTS_VALU_MFMA_MOPS_F32': mc.get('SQ_INSTS_VALU_MFMA_MOPS_F32'),
+                             'SQ_VALU_MFMA_BUSY_CYCLES': mc.get('SQ_VALU_MFMA_BUSY_CYCLES'),
+                             'mfma_busy_frac': (mc['SQ_VALU_MFMA_BUSY_CYCLES'] / simd_cycles
+                                                if mc.get('SQ_VALU_MFMA_BUSY_CYCLES') else None),
+                             'traffic': hbm_traffic(mc), 'source': PMC_FILE if mc else None,
+                             'note': 'per 8x8-voxel tile out[64xC] = W[64xR].F[RxC] on v_mfma_f32_16x16x4_f32; busy = '
+                                     'SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles at 2.4 GHz): the matrix pipes '
+                                     'are mostly idle, a panel is a latency chain (rows, depth gathers, two barriers)'}
         if sp is not None:
             pools['note'] = ('camera-sharded pools: each launch pools this rank\'s cameras of one frame into a full-size '
                              'partial grid; algorithmic bytes are those of the whole-sample pools, for reference only')
