@@ -288,13 +288,19 @@ class HotPath:
     def _render_planned(self, entry, phase='both', out=None):
         plan, f0, nf, g = entry
         bw = self.blend_workgroups
+        # the "other chain still running" word: this path's own (several blends per step), or the one an owner that
+        # renders this path on ITS side stream hands in (ShardedHotPath)
+        word = getattr(self, '_yield_word', None)
+        if word is None and self._use_busy():
+            word = self._busy
         if bw == 'auto':
-            bw = 2 * torch.cuda.get_device_properties(self.device).multi_processor_count if self.overlap else 0
+            bw = (2 * torch.cuda.get_device_properties(self.device).multi_processor_count
+                  if (self.overlap or getattr(self, '_yield_word', None) is not None) else 0)
         elif not isinstance(bw, int):
             bw = int(bw[min(f0, len(bw) - 1)])
         out = plan.render(g['rgb'], g['opacity'], g['scales'], g['rotations'], self.bg, guard=self.render_guard,
                           item_view=g['item_view'] if nf > 1 else None, blend_workgroups=bw, phase=phase, out=out,
-                          yield_if=self._busy if (bw and self._use_busy()) else None)
+                          yield_if=word if bw else None)
         if phase == 'update':
             return out
         n = len(self.cams)
@@ -538,6 +544,14 @@ class ShardedHotPath:
         self.base = HotPath(synthetic.PathConfig(**{**cfg.__dict__, 'render': cfg.render or cfg.hoa}), self.device,
                             cams=[0], index_prep_mode='cached', overlap=False) if cfg.hoa else None
         self._side = shared_stream(self.device, 'render') if self.device.type == 'cuda' and cfg.render else None
+        # the renders run on the side stream beside this rank's poolings, the exchange and HOA: their persistent blends
+        # keep to two workgroups per CU while that chain is running and take the whole chip once it is done (the same
+        # occupancy split as HotPath.step; a hint, the images do not depend on it)
+        self._busy = None
+        if self._side is not None and render_mode == 'planned':
+            self._busy = torch.zeros(1, dtype=torch.int32, device=self.device)
+            for sub in self.subs.values():
+                sub._yield_word = self._busy
         # wedge-sparse step 1: a member's partial grid is zero outside the strips its cameras' rank vectors touch
         # (static per calibration) — only those strips of the other members' plane blocks cross xGMI
         self.sparse_exchange = bool(sparse_exchange) and self.exchange.active and bool(self.exchange.partial)
@@ -574,6 +588,7 @@ class ShardedHotPath:
         cur = torch.cuda.current_stream(self.device) if self._side is not None else None
         rendered = []
         if self._side is not None:
+            self._set_busy(1)
             self._side.wait_stream(cur)
             for f, sub in self.subs.items():
                 rendered.append(sub.render([self._side]))
@@ -591,8 +606,14 @@ class ShardedHotPath:
             gated = [self.base.hoa_step(full[f:f + 1, self.planes_lss:], opacity_bev[f:f + 1])[0]
                      for f in range(self.n_frames)]
         if self._side is not None:
+            self._set_busy(0)
             cur.wait_stream(self._side)
         return full, rendered, gated, opacity_bev
+
+    def _set_busy(self, value):
+        if self._busy is not None:
+            _lib.check(_lib.lib().ocrf_stream_write_value32(_lib.ptr(self._busy), int(value), _lib.stream_ptr(self.device)),
+                       'ocrf_stream_write_value32')
 
     @property
     def bev_voxels_per_step(self):
