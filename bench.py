@@ -75,6 +75,9 @@ def parse():
     ap.add_argument('--render-guard', choices=('host', 'device'), default='host',
                     help="planned renders: 'host' = the plan's extent bound is verified by one status read after the timed region; "
                          "'device' = the per-call pipeline is armed behind every planned render on the GPU")
+    ap.add_argument('--blend-workgroups', default='auto',
+                    help="planned renders beside the main stream: workgroups of the persistent blend that stay while the main "
+                         "chain runs ('auto' = 2 per CU; DESIGN.md section 5)")
     ap.add_argument('--index-prep', choices=('cached', 'per_step'), default='cached',
                     help="'per_step': rank vectors recomputed by the HIP index preparation inside every step "
                          "(the reference with accelerate=False); 'cached': once per calibration (accelerate=True)")
@@ -544,7 +547,8 @@ def main():
         hp = hotpath.HotPath(cfg, dev, cams=my_cams, index_prep_mode=args.index_prep, overlap=not args.no_overlap, **rkw)
     else:
         # whole-sample instance: the N = 1 step, the 'samples' / 'frames' layouts, and every layout's kernel figures
-        hp = hotpath.HotPath(cfg, dev, index_prep_mode=args.index_prep, overlap=not args.no_overlap, **rkw)
+        hp = hotpath.HotPath(cfg, dev, index_prep_mode=args.index_prep, overlap=not args.no_overlap,
+                             blend_workgroups='auto' if args.blend_workgroups == 'auto' else int(args.blend_workgroups), **rkw)
     depth, feat = hp.make_inputs(seed=0 if shard in ('cameras', 'camera_frames') else rank)
 
     def step_whole():
