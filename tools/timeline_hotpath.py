@@ -14,10 +14,13 @@ from ocrfdet_amd import _lib, hotpath, synthetic  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument('--bw', default='auto')
 ap.add_argument('--ht', default='mfma')
+ap.add_argument('--lss', default='tile')
+ap.add_argument('--lss-group', type=int, default=2)
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 cfg = synthetic.CONFIGS['cfg2_6cam_2frame_bev200x200_render_hoa']
-hp = hotpath.HotPath(cfg, dev, ht_pool_backend=a.ht, blend_workgroups='auto' if a.bw == 'auto' else int(a.bw))
+hp = hotpath.HotPath(cfg, dev, ht_pool_backend=a.ht, blend_workgroups='auto' if a.bw == 'auto' else int(a.bw),
+                     lss_pool_backend=a.lss, lss_mfma_group=a.lss_group)
 depth, feat = hp.make_inputs(0)
 for _ in range(10):
     hp.step(depth, feat)
