@@ -75,6 +75,8 @@ def parse():
     ap.add_argument('--render-guard', choices=('host', 'device'), default='host',
                     help="planned renders: 'host' = the plan's extent bound is verified by one status read after the timed region; "
                          "'device' = the per-call pipeline is armed behind every planned render on the GPU")
+    ap.add_argument('--lss-pool', choices=('tile', 'mfma'), default='tile',
+                    help="kernel of the LSS pooling with cached ranks: the VALU tile kernel or the MFMA panel kernel (DESIGN.md 4.1b)")
     ap.add_argument('--blend-workgroups', default='auto',
                     help="planned renders beside the main stream: workgroups of the persistent blend that stay while the main "
                          "chain runs ('auto' = 2 per CU; DESIGN.md section 5)")
@@ -548,7 +550,8 @@ def main():
     else:
         # whole-sample instance: the N = 1 step, the 'samples' / 'frames' layouts, and every layout's kernel figures
         hp = hotpath.HotPath(cfg, dev, index_prep_mode=args.index_prep, overlap=not args.no_overlap,
-                             blend_workgroups='auto' if args.blend_workgroups == 'auto' else int(args.blend_workgroups), **rkw)
+                             blend_workgroups='auto' if args.blend_workgroups == 'auto' else int(args.blend_workgroups),
+                             lss_pool_backend=args.lss_pool, **rkw)
     depth, feat = hp.make_inputs(seed=0 if shard in ('cameras', 'camera_frames') else rank)
 
     def step_whole():
