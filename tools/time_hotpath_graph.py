@@ -1,6 +1,6 @@
 """Diagnostic: the hot-path step (pools + renders on the side stream + HOA) issued eagerly vs replayed as one
-hipGraph.  The step is device-bound, not launch-bound: the replay is no faster (0.500 vs 0.485 ms at cfg2),
-so bench.py keeps issuing it kernel by kernel (which also lets it time the dominant kernel in the region)."""
+hipGraph.  The step is device-bound, not launch-bound: the replay is no faster (round 3: 0.326 vs 0.289 ms eager at cfg2, host
+issue 0.23 ms), so bench.py keeps issuing it kernel by kernel (which also lets it time the dominant kernel in the region)."""
 import sys, os, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ocrfdet_amd import hotpath, synthetic
