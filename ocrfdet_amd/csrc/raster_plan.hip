@@ -61,7 +61,7 @@ constexpr unsigned kPosMask = 0x3FFFFFFFu;
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct PlanLayout {
-  size_t header, cams, g_mask, g_off, e_pos, e_q0, e_q1, s_id, s_key, s_pix, s_e, bytes;
+  size_t header, cams, g_mask, g_off, e_q0, e_q1, s_id, s_key, s_pix, s_e, bytes;
 };
 
 inline void plan_layout(int P, int V, long T, PlanLayout* L) {
@@ -71,8 +71,7 @@ inline void plan_layout(int P, int V, long T, PlanLayout* L) {
   L->cams = take((size_t)V * sizeof(Camera));
   L->g_mask = take((size_t)P * 4);          // per Gaussian: bit v = kept in view v
   L->g_off = take((size_t)P * 4);           //               first record in Gaussian-major order
-  L->e_pos = take((size_t)T * 4);           // per record, Gaussian-major: position in the sorted lists,
-  L->e_q0 = take((size_t)T * 16);           //   (A00, A01, A02, A10) of A = J W,
+  L->e_q0 = take((size_t)T * 16);           // per record, Gaussian-major: (A00, A01, A02, A10) of A = J W,
   L->e_q1 = take((size_t)T * 16);           //   (A11, A12, pixel x, pixel y)
   L->s_id = take((size_t)T * 4);            // per record, sorted (view-major, depth bits then id): Gaussian id,
   L->s_key = take((size_t)T * 4);           //   depth bits,
@@ -206,7 +205,7 @@ __global__ __launch_bounds__(kBlock) void plan_fill_records_kernel(int P, int W,
                                                                    const int* __restrict__ inv,
                                                                    const unsigned* __restrict__ g_mask,
                                                                    const int* __restrict__ g_off,
-                                                                   unsigned* __restrict__ e_pos, float4* __restrict__ e_q0,
+                                                                   float4* __restrict__ e_q0,
                                                                    float4* __restrict__ e_q1, unsigned* __restrict__ s_e) {
   if (header[0] != (int)kPlanMagic) return;
   const int id = blockIdx.x * kBlock + threadIdx.x;
@@ -224,7 +223,6 @@ __global__ __launch_bounds__(kBlock) void plan_fill_records_kernel(int P, int W,
     float A[2][3];
     jacobian_rows(cam, sp.j00, sp.j02, sp.j11, sp.j12, A);
     const unsigned pos = (unsigned)(view_off[v] + inv[(long)v * P + id]);
-    e_pos[e] = pos;
     s_e[pos] = (unsigned)e;
     e_q0[e] = make_float4(A[0][0], A[0][1], A[0][2], A[1][0]);
     e_q1[e] = make_float4(A[1][1], A[1][2], ndc2pix(sp.projx, W), ndc2pix(sp.projy, H));
@@ -235,18 +233,19 @@ __global__ __launch_bounds__(kBlock) void plan_fill_records_kernel(int P, int W,
 // ---------------------------------------------------------------------------------------------
 // step 1: the parameter-dependent half of preprocessCUDA (forward.cu:201-256), ONE THREAD PER GAUSSIAN of a set:
 // the parameters are read once (coalesced), the 3D covariance is built once, then every rendered view that keeps
-// the Gaussian gets its conic / radius / tile rect, dropped at the record's place in that view's sorted list.  The
-// same pass checks the Gaussian's extent against the plan's bound.
-//   d_rect[set][pos]  tile rect ((0,0,0,0): not rendered this step), at the record's place in the sorted list: the
-//                     blend scans it; the only scattered write (random 8-byte stores cost a memory-side read-modify-
-//                     write each: with the conic scattered too the pass took 27 us instead of 23 at cfg2)
-//   d_con[set][e]     (-0.5 conic.x, -0.5 conic.z, conic.y, opacity) in Gaussian-major order (coalesced); the blend
-//                     reaches it through the plan's static pos -> e map when it stages a record
+// the Gaussian gets its conic / radius / tile rect.  The same pass checks the Gaussian's extent against the plan's
+// bound.  Everything it writes is in GAUSSIAN-MAJOR record order e (coalesced); the blend reaches a record of its
+// depth-ordered list through the plan's static list position -> e map (s_e):
+//   d_rect[set][e]    tile rect ((0,0,0,0): not rendered this step), gathered by the blend's scan.  Written at the
+//                     record's place in the sorted list instead, the scan read it coalesced but the writes were random
+//                     8-byte stores — a memory-side read-modify-write each, and the pass ran beside the LSS pooling's
+//                     gathers: 21.5 -> 15.2 us alone, cfg2 step 0.290 -> 0.277 ms, for + 3 % on the blend;
+//   d_con[set][e]     (-0.5 conic.x, -0.5 conic.z, conic.y, opacity), read when a record is staged
 // grid (ceil(P / 256), n_sets).  The items of one set name distinct plan views.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void raster_plan_update_kernel(
     int P, int vps, long n_total, const int* __restrict__ header, const unsigned* __restrict__ g_mask,
-    const int* __restrict__ g_off, const unsigned* __restrict__ e_pos, const float4* __restrict__ e_q0,
+    const int* __restrict__ g_off, const float4* __restrict__ e_q0,
     const float4* __restrict__ e_q1, const int* __restrict__ view_sel, const float* __restrict__ opacities,
     const float* __restrict__ scales, float scale_modifier, const float* __restrict__ rotations,
     Rect* __restrict__ d_rect, float4* __restrict__ d_con, int* __restrict__ radii, int* __restrict__ status,
@@ -309,7 +308,6 @@ __global__ __launch_bounds__(kBlock) void raster_plan_update_kernel(
     const int cur = e++;
     const int zi = l_v2i[v];
     if (zi < 0) continue;                                   // this view is not rendered by this set
-    const unsigned pos = e_pos[cur];
     const float4 q0 = e_q0[cur], q1 = e_q1[cur];
     const float A[2][3] = {{q0.x, q0.y, q0.z}, {q0.w, q1.x, q1.y}};
     Rect rect = Rect{0, 0, 0, 0};
@@ -324,7 +322,7 @@ __global__ __launch_bounds__(kBlock) void raster_plan_update_kernel(
         rad = 0;
       }
     }
-    d_rect[dyn + pos] = unseen ? Rect{0, 0, 0, 0} : rect;
+    d_rect[dyn + cur] = unseen ? Rect{0, 0, 0, 0} : rect;
     if (radii) radii[((long)s * vps + zi) * P + id] = rad;
   }
 }
@@ -391,8 +389,8 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
   const int set = z / vps;
   const int tyA = 2 * ty2, tyB = tyA + 1;
   const int off = view_off[v], nv = view_off[v + 1] - off;
-  const long dyn = (long)set * n_total + off;
   const float4* set_con = d_con + (long)set * n_total;
+  const Rect* set_rect = d_rect + (long)set * n_total;
   const float* set_colors = colors + 3 * (long)set * P;
   const int pxi = tx * kTileX + lx;
   const int py0 = tyA * kTileY + 8 * wave + r, py1 = py0 + 4;
@@ -438,7 +436,7 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
         hit[u] = false;
         code[u] = 0u;
         if (u < n_u && i < nv) {
-          const Rect rc = d_rect[dyn + i];
+          const Rect rc = set_rect[s_e[off + i]];      // list order -> the record's Gaussian-major slot
           const bool cA = (tyA >= rc.y0) && (tyA < rc.y1), cB = (tyB >= rc.y0) && (tyB < rc.y1);
           hit[u] = (tx >= rc.x0) && (tx < rc.x1) && (cA || cB);
           code[u] = (unsigned)i | (cA ? 0x40000000u : 0u) | (cB ? 0x80000000u : 0u);
@@ -849,7 +847,7 @@ int ocrf_raster_plan_fill(int P, int n_views, int H, int W, const float* means3D
   hipLaunchKernelGGL(plan_fill_records_kernel, pgrid, dim3(kBlock), 0, stream, P, W, H, means3D, cams,
                      static_cast<const int*>(header), static_cast<const int*>(inv),
                      static_cast<const unsigned*>(g_mask), static_cast<const int*>(g_off),
-                     reinterpret_cast<unsigned*>(pb + L.e_pos), reinterpret_cast<float4*>(pb + L.e_q0),
+                     reinterpret_cast<float4*>(pb + L.e_q0),
                      reinterpret_cast<float4*>(pb + L.e_q1), reinterpret_cast<unsigned*>(pb + L.s_e));
   return (int)hipGetLastError();
 }
@@ -908,7 +906,7 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
   if (phase != 2) {
   ocrf::launch(OCRF_K_RASTER_PLAN_UPDATE, raster_plan_update_kernel, dim3((P + kBlock - 1) / kBlock, n_sets),
                dim3(kBlock), (size_t)g_update_lds, stream, P, vps, total_kept, header, reinterpret_cast<const unsigned*>(pb + L.g_mask),
-               reinterpret_cast<const int*>(pb + L.g_off), reinterpret_cast<const unsigned*>(pb + L.e_pos),
+               reinterpret_cast<const int*>(pb + L.g_off),
                reinterpret_cast<const float4*>(pb + L.e_q0), reinterpret_cast<const float4*>(pb + L.e_q1), item_view,
                opacities, scales, scale_modifier, rotations, d_rect, d_con, radii, status, flag, queue);
   }   // phase != 2

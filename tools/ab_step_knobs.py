@@ -45,4 +45,4 @@ for _ in range(5):
     ts.append((time.perf_counter() - t0) / a.steps * 1e3)
 hp.check_render_plans()
 ts.sort()
-print(f'{" ".join(a.knobs) or "defaults":20s} ht={a.ht} render={a.render_mode} fuse={a.fuse} rstreams={a.rstreams} bw={a.bw} hoa_first={a.hoa_first} hoa_stream={a.hoa_stream} lss={a.lss}/{a.lss_group}: median {ts[2]:.4f} min {ts[0]:.4f} max {ts[-1]:.4f} ms/step', flush=True)
+print([round(t,4) for t in ts], end=" "); print(f'{" ".join(a.knobs) or "defaults":20s} ht={a.ht} render={a.render_mode} fuse={a.fuse} rstreams={a.rstreams} bw={a.bw} hoa_first={a.hoa_first} hoa_stream={a.hoa_stream} lss={a.lss}/{a.lss_group}: median {ts[2]:.4f} min {ts[0]:.4f} max {ts[-1]:.4f} ms/step', flush=True)
