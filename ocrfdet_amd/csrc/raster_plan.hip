@@ -12,9 +12,10 @@
 // A plan (built once per (means, cameras)) keeps, per view, the Gaussians that can ever be visible — in front
 // of the near plane and inside the frame for any world-space extent up to a stated bound — ALREADY SORTED by
 // (depth bits, id), with their static per-record data.  A step then is two launches:
-//   raster_plan_update_kernel   covariance -> conic / radius / tile rect of the kept records, in list order,
-//                               written as ready-to-blend records (+ the check that no Gaussian exceeds the
-//                               plan's extent bound: status bit 4);
+//   raster_plan_update_kernel   one thread per Gaussian: covariance -> conic / radius / tile rect of its kept
+//                               records, written in Gaussian-major record order (coalesced; the blend reaches a
+//                               list entry's record through the plan's static list -> record map), + the check
+//                               that no Gaussian exceeds the plan's extent bound (status bit 4);
 //   raster_blend_sorted_kernel  a tile pair filters the list by tile rect — the survivors arrive in the
 //                               reference's per-tile order, so there is no sort, no depth bucket, no carry —
 //                               and each of its four waves blends only the records whose alpha >= 1/255
