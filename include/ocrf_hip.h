@@ -227,7 +227,8 @@ size_t ocrf_rasterize_workspace_bytes(int P, int n_views);
  * quaternion) of every Gaussian the plan will be rendered with; a plan stays valid for ANY parameters within it.
  *
  *   3. ocrf_rasterize_planned     one render = two launches: one thread per Gaussian builds its 3D covariance once
- *      and drops conic / tile rect at its place in every rendered view's list; then the blend of the sorted lists.
+ *      and writes conic / tile rect of every rendered view's record (record order: coalesced; the blend walks a view's
+ *      depth-ordered list through the plan's static list -> record map); then the blend of the sorted lists.
  *      n_items views are rendered; item z renders plan view item_view[z] (device ints; NULL = z, then n_items /
  *      n_sets must equal the plan's view count) with Gaussian set z / (n_items / n_sets) of the (n_sets, P, .)
  *      parameter arrays; the items of one set name distinct views.  Outputs as
