@@ -62,10 +62,13 @@ __global__ __launch_bounds__(kBlock) void hoa_mask_gate_kernel(
     const float* __restrict__ conv_w, int k_rt, int C, int Y, int X, int groups, int n_rows,
     float* __restrict__ mask, float* __restrict__ gated) {
   const int k = KT ? KT : k_rt;
-  extern __shared__ float s_dyn[];        // 2*k*k weights, then 2 planes of n_rows x (X + k - 1), zero padded
-  const int r = k / 2, tw = X + k - 1;
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];      // weights, then 2 planes of n_rows x tw, zero padded
+  // VEC = 4: rows padded to a multiple of 4 floats and the planes 16-byte aligned behind the weights — a thread's
+  // (k + 3)-wide window is then three ds_read_b128 (lanes 16 B apart: conflict-free) instead of ten ds_read_b32 whose
+  // lanes, 4 floats apart, hit 8 banks (5.1 bank conflicts per LDS instruction by PMC)
+  const int r = k / 2, tw = (VEC == 4) ? ((X + k - 1 + 3) & ~3) : (X + k - 1);
   float* s_w = s_dyn;
-  float* s_s = s_dyn + 2 * k * k;
+  float* s_s = s_dyn + ((VEC == 4) ? ((2 * k * k + 3) & ~3) : 2 * k * k);
   const long plane = (long)Y * X;
   const int b = blockIdx.z / groups, g = blockIdx.z % groups;
   const long p0 = (long)blockIdx.x * kBlock * VEC;
@@ -117,9 +120,18 @@ __global__ __launch_bounds__(kBlock) void hoa_mask_gate_kernel(
       for (int i = 0; i < KT; ++i) {
         const float* row = s_s + (ch * n_rows + ly + i) * tw + xx;
         const float* wr = s_w + (ch * KT + i) * KT;
-        float win[KT + VEC - 1];                          // the k-wide windows of adjacent pixels overlap
+        float win[(KT + VEC - 1 + 3) & ~3];               // the k-wide windows of adjacent pixels overlap
+        if constexpr (VEC == 4) {
+          const float4* row4 = reinterpret_cast<const float4*>(row);      // xx, tw and the plane base: multiples of 4 floats
 #pragma unroll
-        for (int j = 0; j < KT + VEC - 1; ++j) win[j] = row[j];
+          for (int j = 0; j < (KT + VEC - 1 + 3) / 4; ++j) {
+            const float4 q4 = row4[j];
+            win[4 * j] = q4.x; win[4 * j + 1] = q4.y; win[4 * j + 2] = q4.z; win[4 * j + 3] = q4.w;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < KT + VEC - 1; ++j) win[j] = row[j];
+        }
 #pragma unroll
         for (int j = 0; j < KT; ++j) {
           const float w = wr[j];
@@ -364,7 +376,8 @@ int ocrf_hoa_opacity_mask_gate(const float* x, const float* stats, const float* 
   const int per_wg = kBlock * (vec4 ? 4 : 1);
   // rows a run of per_wg consecutive pixels can touch (it may start mid-row) plus the k - 1 halo rows
   const int n_rows = (per_wg + X - 2) / X + 1 + (k - 1);
-  const size_t lds = (size_t)(2 * k * k + 2 * n_rows * (X + k - 1)) * sizeof(float);
+  const int tw = vec4 ? ((X + k - 1 + 3) & ~3) : (X + k - 1);
+  const size_t lds = (size_t)((vec4 ? ((2 * k * k + 3) & ~3) : 2 * k * k) + 2 * n_rows * tw) * sizeof(float);
   if (lds > 64 * 1024) return (int)hipErrorInvalidValue;             // X beyond ~1 000: not a BEV plane
   const int groups = gated ? ((C >= 40) ? 4 : (C >= 16 ? 2 : 1)) : 1;
   const dim3 grid((unsigned)((plane + per_wg - 1) / per_wg), 1, (unsigned)(B * groups));
