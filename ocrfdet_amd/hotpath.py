@@ -554,8 +554,12 @@ class ShardedHotPath:
                 sub._yield_word = self._busy
         # wedge-sparse step 1: a member's partial grid is zero outside the strips its cameras' rank vectors touch
         # (static per calibration) — only those strips of the other members' plane blocks cross xGMI
-        self.sparse_exchange = bool(sparse_exchange) and self.exchange.active and bool(self.exchange.partial)
-        if self.sparse_exchange or (sparse_exchange and self.exchange.partial):
+        # The decision is a function of the PLAN (the same on every rank), never of this rank's own buffers: set_touched
+        # is a world collective, so idle ranks and owners of whole frames take part with an empty dict.  Only with cached
+        # rank vectors: with per-step index preparation (the reference's accelerate=False, calibration per sample) a new
+        # calibration may touch tiles outside a stale list and its contributions would be dropped from the sum.
+        self.sparse_exchange = bool(sparse_exchange) and self.plan.any_shared and index_prep_mode == 'cached'
+        if self.sparse_exchange:
             ex, touched = self.exchange, {}
             for f, sub in self.subs.items():
                 if f in ex.partial:

@@ -141,6 +141,11 @@ class CameraFramePlan:
         return [(f, p0, n) for f, p0, n, r in self.block_owner if r == rank]
 
     @property
+    def any_shared(self):
+        """True when some frame's cameras are split over several ranks (a function of the plan: the same on every rank)."""
+        return any(len(g) > 1 for g in self.group_of_frame)
+
+    @property
     def idle_ranks(self):
         return [r for r in range(self.world) if not self.units[r]]
 
@@ -218,7 +223,11 @@ class BevExchange:
             collectives = GlooCollectives() if self.backend == 'gloo' else Collectives()
         self.c = collectives
         self.groups = {}
+        self.ctrl = None
         if self.active:
+            # control plane: a gloo group of its own for host-side agreement (flags, index lists), so that a verdict about
+            # a data-path collective never travels over the communicator that collective may just have failed on
+            self.ctrl = dist.new_group(backend='gloo')
             for ranks in plan.group_of_frame:
                 key = tuple(ranks)
                 if len(ranks) > 1 and key not in self.groups:
@@ -304,8 +313,8 @@ class BevExchange:
             ok = bool(torch.equal(got, torch.arange(1, self.plan.world + 1, dtype=torch.float32)))
         except Exception:
             ok = False
-        flag = torch.tensor([1 if ok else 0], device=self.device, dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)              # host tensor, gloo control group
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.ctrl)
         return bool(flag.item())
 
     def _my_block(self, f):
@@ -331,12 +340,13 @@ class BevExchange:
         """Switch step 1 to the wedge-sparse form.  ``touched``: {frame: 1-D int64 tensor of the tile indices
         (``tile_of_voxel``: 8 x 8 voxel blocks of the (Y, X) plane, or rows when Y or X is no multiple of 8; ``ex.strip``
         voxels each, ``ex.n_strips`` per plane) this rank's cameras of that frame can write} for every shared frame this
-        rank holds.  Collective over the world (the index lists
-        of a group's members are exchanged once: they are static per calibration)."""
+        rank holds — an EMPTY dict on a rank that shares no frame (idle ranks, owners of whole frames).  Collective over
+        the world on the gloo control group: EVERY rank of the job calls it (the index lists of a group's members are
+        exchanged once: they are static per calibration)."""
         mine = {int(f): torch.as_tensor(t).long().cpu().unique().tolist() for f, t in touched.items() if f in self.partial}
         if self.active:
             everyone = [None] * self.plan.world
-            dist.all_gather_object(everyone, mine)
+            dist.all_gather_object(everyone, mine, group=self.ctrl)
         else:
             everyone = [mine]
         self.touched = {}

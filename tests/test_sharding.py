@@ -141,12 +141,15 @@ def _worker_cf(rank, world, port, q, n_frames, mode):
 @pytest.mark.parametrize('world,n_frames,mode', [
     (2, 2, 'gloo'), (2, 1, 'gloo'), (4, 2, 'gloo'), (6, 2, 'gloo'),
     (2, 2, 'rccl_paths'), (4, 2, 'rccl_paths'), (6, 2, 'rccl_paths'), (8, 2, 'rccl_paths'),
-    (2, 1, 'sparse'), (4, 2, 'sparse'), (6, 2, 'sparse_rccl_paths'), (8, 2, 'sparse_rccl_paths')])
+    (2, 1, 'sparse'), (4, 2, 'sparse'), (6, 2, 'sparse_rccl_paths'), (8, 2, 'sparse_rccl_paths'),
+    (8, 1, 'sparse'), (3, 2, 'sparse'), (3, 2, 'sparse_rccl_paths')])
 def test_camera_frame_exchange_gloo_matches_single_process(world, n_frames, mode):
     """world 2 x 2 frames: whole frames per rank, only the world all_gather; world 2 x 1 frame: the frame's
     cameras split over both ranks (reduce step, then gather); world 4 x 2 frames: two groups of two; world 6 x 2
     frames (BASELINE configs[3]): groups of THREE, P = 320 planes in blocks of 107 + 107 + 106 (uneven: the partial
-    buffer is padded so that the scatter form stays); world 8 x 2: groups of four, one camera per rank."""
+    buffer is padded so that the scatter form stays); world 8 x 2: groups of four, one camera per rank.
+    world 8 x 1 frame (4 cameras): ranks 4-7 are IDLE, world 3 x 2 frames: rank 2 owns a whole frame — both hold no
+    partial buffer and still take part in ``set_touched`` (a world collective) with an empty dict."""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = 23000 + (os.getpid() * 7 + world * 13 + n_frames + len(mode) * 101) % 4000
@@ -165,8 +168,10 @@ def test_camera_frame_exchange_gloo_matches_single_process(world, n_frames, mode
             assert info['direct'], 'plane blocks in rank order: the gather must run in place on the fused grid'
         if world == 6:
             assert not info['direct']                       # padded blocks: staged gather
-        if mode.startswith('sparse') and world > n_frames:
+        if mode.startswith('sparse') and world > n_frames and info['rs_dense'] > 0:
             assert 0 < info['rs'] < info['rs_dense'], info  # a camera wedge touches a fraction of the strips
+    if mode.startswith('sparse') and (world, n_frames) in ((8, 1), (3, 2)):
+        assert sum(1 for r in res if r[4]['rs_dense'] == 0) >= 1      # the ranks without a shared frame were there
 
 
 @pytest.mark.timeout(300)
