@@ -471,13 +471,16 @@ int ocrf_hoa_unet_block(const float *src0, const float *gate0, int C0, int H0, i
                         float *partial_max, int B, int H, int W, ocrf_stream_t stream);
 int ocrf_hoa_unet_tiles(int H, int W);
 /* The whole converter of the architecture OcRFDet instantiates (input_channel = 13: 13 -> 4 -> 8 -> 16 -> 8 -> 4 -> 1,
- * ratio-1 HeightAttention gates, view_transformer_ocrf.py:463-518) as ONE call of six launches: the five blocks
- * above, each computing the gates of its producers in its own prologue from the per-tile maxima they left, and the
- * gated output conv.  x (B,13,H,W), position (B,4,H,W), out (B,1,H,W); H and W multiples of 4.  `weights`:
+ * ratio-1 HeightAttention gates, view_transformer_ocrf.py:463-518) as ONE call of six launches (csrc/hoa_v2b.hip:
+ * latency-shaped forms of the five blocks above on 16 x 4 pixel tiles, each computing the gates of its producers in
+ * its own prologue from the per-tile maxima they left, and the gated output conv; bit-identical to the block-wise
+ * calls).  x (B,13,H,W), position (B,4,H,W), out (B,1,H,W); H and W multiples of 4.  `weights` (16-byte aligned):
  * ocrf_hoa_v2b_weights_len() floats — per block (encoder1, encoder2, bottleneck, decoder2, decoder1): dw_w (Cin,9),
  * dw_b (Cin), pw_w (Cout,Cin) and pw_b (Cout) with BatchNorm folded, the block's gate w1 (4,hid,q), w2 (4,q,hid);
- * then upconv2 w (16,8,2,2), b (8), upconv1 w (8,4,2,2), b (4), output conv w (4), b (1).
- * workspace >= ocrf_hoa_v2b_workspace_bytes(B, H, W) bytes (the five intermediates and their tile maxima). */
+ * then upconv2 w (16,8,2,2), b (8), upconv1 w (8,4,2,2), b (4), output conv w (4), b (1); zero-padded to a whole
+ * number of 16-byte words (the kernels copy it to LDS with 16-byte loads).
+ * workspace (16-byte aligned) >= ocrf_hoa_v2b_workspace_bytes(B, H, W) bytes (the five intermediates and their tile
+ * maxima). */
 int ocrf_hoa_v2b_weights_len(void);
 size_t ocrf_hoa_v2b_workspace_bytes(int B, int H, int W);
 int ocrf_hoa_v2b_forward(const float *x, const float *position, const float *weights, int B, int H, int W,

@@ -865,114 +865,11 @@ int launch_unet_block(const UnetBlockArgs& a, int B, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-// packed weights of the whole converter (floats), in this order
-struct V2bOffsets {
-  int dw_w[5], dw_b[5], pw_w[5], pw_b[5], g_w1[5], g_w2[5], up_w[2], up_b[2], out_w, out_b, total;
-};
-constexpr int kV2bCin[5] = {13, 4, 8, 16, 8}, kV2bCout[5] = {4, 8, 16, 8, 4};     // e1, e2, bottleneck, d2, d1
-inline V2bOffsets v2b_offsets() {
-  V2bOffsets o;
-  int p = 0;
-  for (int k = 0; k < 5; ++k) {
-    const int ci = kV2bCin[k], co = kV2bCout[k], q = co / 4;
-    o.dw_w[k] = p; p += ci * 9;
-    o.dw_b[k] = p; p += ci;
-    o.pw_w[k] = p; p += co * ci;
-    o.pw_b[k] = p; p += co;
-    o.g_w1[k] = p; p += 4 * q * q;       // HeightAttention(co, co, ratio = 1): hid = q
-    o.g_w2[k] = p; p += 4 * q * q;
-  }
-  o.up_w[0] = p; p += 16 * 8 * 4;  o.up_b[0] = p; p += 8;      // upconv2
-  o.up_w[1] = p; p += 8 * 4 * 4;   o.up_b[1] = p; p += 4;      // upconv1
-  o.out_w = p; p += 4;
-  o.out_b = p; p += 1;
-  o.total = p;
-  return o;
-}
 }  // namespace
 
 extern "C" {
 
-int ocrf_hoa_v2b_weights_len(void) { return v2b_offsets().total; }
-
-size_t ocrf_hoa_v2b_workspace_bytes(int B, int H, int W) {
-  if (B <= 0 || H < 4 || W < 4 || (H % 4) || (W % 4)) return 0;
-  size_t n = 0;
-  const int hs[5] = {H, H / 2, H / 4, H / 2, H}, wsz[5] = {W, W / 2, W / 4, W / 2, W};
-  for (int k = 0; k < 5; ++k) {
-    const size_t tiles = (size_t)((wsz[k] + kUT - 1) / kUT) * ((hs[k] + kUT - 1) / kUT);
-    n += (size_t)B * kV2bCout[k] * hs[k] * wsz[k] + (size_t)B * kV2bCout[k] * tiles;
-  }
-  return (n * sizeof(float) + 255) / 256 * 256;
-}
-
-// The whole OpacityVoxelToBEVConverter.forward (view_transformer_ocrf.py:497-518) of the architecture OcRFDet
-// instantiates (13 -> 4 -> 8 -> 16 -> 8 -> 4 -> 1, ratio-1 HeightAttention gates) as SIX launches in one call:
-// five conv blocks, each computing its producers' channel gates in its own prologue from the per-tile maxima they
-// left, and the gated output conv.  x (B,13,H,W), position (B,4,H,W), out (B,1,H,W); H, W multiples of 4.
-int ocrf_hoa_v2b_forward(const float* x, const float* position, const float* weights, int B, int H, int W,
-                         void* workspace, size_t workspace_bytes, float* out, ocrf_stream_t stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (!x || !position || !weights || !out || !workspace || B <= 0 || H < 4 || W < 4 || (H % 4) || (W % 4) ||
-      workspace_bytes < ocrf_hoa_v2b_workspace_bytes(B, H, W))
-    return (int)hipErrorInvalidValue;
-  const V2bOffsets o = v2b_offsets();
-  const int hs[5] = {H, H / 2, H / 4, H / 2, H}, wsz[5] = {W, W / 2, W / 4, W / 2, W};
-  float* act[5];
-  float* pm[5];
-  int tiles[5];
-  float* p = static_cast<float*>(workspace);
-  for (int k = 0; k < 5; ++k) {
-    tiles[k] = ((wsz[k] + kUT - 1) / kUT) * ((hs[k] + kUT - 1) / kUT);
-    act[k] = p; p += (size_t)B * kV2bCout[k] * hs[k] * wsz[k];
-    pm[k] = p; p += (size_t)B * kV2bCout[k] * tiles[k];
-  }
-  // block k: source 0 (producer index, mode, up-conv index or -1), skip source (producer index or -1)
-  const int src0[5] = {-1, 0, 1, 2, 3}, mode[5] = {0, 1, 1, 2, 2}, up[5] = {-1, -1, -1, 0, 1}, skip[5] = {-1, -1, -1, 1, 0};
-  for (int k = 0; k < 5; ++k) {
-    UnetBlockArgs a;
-    const int s0 = src0[k];
-    a.src0 = s0 < 0 ? x : act[s0];
-    a.gate0 = nullptr;
-    a.C0 = kV2bCin[k] - (skip[k] >= 0 ? kV2bCout[skip[k]] : 0);
-    if (mode[k] == 2) a.C0 = kV2bCout[s0];
-    a.H0 = s0 < 0 ? H : hs[s0];
-    a.W0 = s0 < 0 ? W : wsz[s0];
-    a.mode = mode[k];
-    a.up_w = up[k] >= 0 ? weights + o.up_w[up[k]] : nullptr;
-    a.up_b = up[k] >= 0 ? weights + o.up_b[up[k]] : nullptr;
-    a.Cup = up[k] >= 0 ? kV2bCout[k] : 0;
-    a.src1 = skip[k] >= 0 ? act[skip[k]] : nullptr;
-    a.gate1 = nullptr;
-    a.C1 = skip[k] >= 0 ? kV2bCout[skip[k]] : 0;
-    a.dw_w = weights + o.dw_w[k]; a.dw_b = weights + o.dw_b[k];
-    a.pw_w = weights + o.pw_w[k]; a.pw_b = weights + o.pw_b[k];
-    a.Cout = kV2bCout[k];
-    a.addend = k == 0 ? position : nullptr;
-    a.out = act[k]; a.partial_max = pm[k];
-    a.H = hs[k]; a.W = wsz[k];
-    a.tiles_x = (wsz[k] + kUT - 1) / kUT; a.tiles_y = (hs[k] + kUT - 1) / kUT;
-    a.pm0 = s0 < 0 ? nullptr : pm[s0];
-    a.g0w1 = s0 < 0 ? nullptr : weights + o.g_w1[s0];
-    a.g0w2 = s0 < 0 ? nullptr : weights + o.g_w2[s0];
-    a.g0hid = s0 < 0 ? 0 : kV2bCout[s0] / 4;
-    a.g0tiles = s0 < 0 ? 0 : tiles[s0];
-    const int s1 = skip[k];
-    a.pm1 = s1 < 0 ? nullptr : pm[s1];
-    a.g1w1 = s1 < 0 ? nullptr : weights + o.g_w1[s1];
-    a.g1w2 = s1 < 0 ? nullptr : weights + o.g_w2[s1];
-    a.g1hid = s1 < 0 ? 0 : kV2bCout[s1] / 4;
-    a.g1tiles = s1 < 0 ? 0 : tiles[s1];
-    const int rc = launch_unet_block(a, B, stream);
-    if (rc != 0) return rc;
-  }
-  const long plane = (long)H * W;
-  ocrf::launch(OCRF_K_HOA_OUT_CONV, hoa_gated_conv1x1_kernel, dim3((unsigned)((plane + kBlock - 1) / kBlock), B),
-               dim3(kBlock), 0, stream, static_cast<const float*>(act[4]), (const float*)nullptr, 4, plane,
-               weights + o.out_w, weights + o.out_b, out, static_cast<const float*>(pm[4]), weights + o.g_w1[4],
-               weights + o.g_w2[4], 1, tiles[4]);
-  return (int)hipGetLastError();
-}
+// ocrf_hoa_v2b_weights_len / _workspace_bytes / _forward (the whole converter as six launches): csrc/hoa_v2b.hip
 
 int ocrf_hoa_unet_tiles(int H, int W) { return ((W + kUT - 1) / kUT) * ((H + kUT - 1) / kUT); }
 
@@ -1022,139 +919,162 @@ constexpr int oQ = 0, oDW = oQ + 8 * 13, oDB = oDW + 8 * 36, oPW = oDB + 8, oK =
               oO = oV + 104, oOB = oO + 104, oC0W = oOB + 13, oC0B = oC0W + 6, oC1W = oC0B + 3, oC1B = oC1W + 9,
               oC2W = oC1B + 3, oC2B = oC2W + 3, kHoaWeights = oC2B + 1;
 
-// F.interpolate(..., mode='bilinear', align_corners=True) sample of one channel plane
-__device__ __forceinline__ float bilinear_ac(const float* __restrict__ p, int H, int W, float sy, float sx) {
-  const int y0 = min((int)sy, H - 1), x0 = min((int)sx, W - 1);
-  const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
-  const float ly = sy - (float)y0, lx = sx - (float)x0;
-  const float top = p[(long)y0 * W + x0] * (1.f - lx) + p[(long)y0 * W + x1] * lx;
-  const float bot = p[(long)y1 * W + x0] * (1.f - lx) + p[(long)y1 * W + x1] * lx;
+// F.interpolate(..., mode='bilinear', align_corners=True) sample of one channel plane at (sy, sx): the four corner taps
+// and their mix, separately — corner q of a sample is one load, the mix happens once they are all back
+struct AcTaps { int y0, y1, x0, x1; float ly, lx; };
+__device__ __forceinline__ AcTaps ac_taps(int H, int W, float sy, float sx) {
+  AcTaps a;
+  a.y0 = min((int)sy, H - 1); a.x0 = min((int)sx, W - 1);
+  a.y1 = min(a.y0 + 1, H - 1); a.x1 = min(a.x0 + 1, W - 1);
+  a.ly = sy - (float)a.y0; a.lx = sx - (float)a.x0;
+  return a;
+}
+__device__ __forceinline__ float ac_mix(float p00, float p01, float p10, float p11, float ly, float lx) {
+  const float top = p00 * (1.f - lx) + p01 * lx;
+  const float bot = p10 * (1.f - lx) + p11 * lx;
   return top * (1.f - ly) + bot * ly;
 }
 
-// kv tokens of one batch entry (one workgroup): offsets (depthwise 6x6 stride 4 pad 1 -> GELU ->
-// 1x1 -> tanh -> * scale), sampling grid, bilinear sample (zeros padding, align_corners=False) of
-// downsample(alpha), k and v.  kvbuf (B, nkv, 18) = k[8] | v[8] | grid[2].
+constexpr int kHoaWLoads = (kHoaWeights + kBlock - 1) / kBlock;      // 3
+constexpr int kHoaWLds = kHoaWLoads * kBlock;    // LDS copy of the packed weights: every thread stores every word it loaded
+
+// ONE kv token per workgroup (grid (nkv, B): 128 workgroups at 2 x 200 x 200, where one workgroup per 8 tokens left
+// the chip to 16): offsets (depthwise 6x6 stride 4 pad 1 -> GELU -> 1x1 -> tanh -> * scale), sampling grid, bilinear
+// sample (zeros padding, align_corners=False) of downsample(alpha), k and v.  kvbuf (B, nkv, 18) = k[8] | v[8] | grid[2].
+// The token's offset conv reads the 6 x 6 window of the query map (hq, wq) at rows 4 ky - 1 .., columns 4 kx - 1 ..:
+// q is rebuilt for exactly those 36 tokens straight from the full-resolution opacity volume (no q launch, no q buffer).
+// A latency chain with two memory round trips: (1) weights + the 36 x 13 x 4 corner taps of the window, one
+// (token, channel) sample per thread and trip, all issued before the first wait; (2) the 13 x 4 x 4 corner taps of the
+// sampled alpha, ONE load per thread.  Arithmetic per value as in the eight-tokens-per-workgroup form it replaces.
 __global__ __launch_bounds__(kBlock) void hoa1_kv_kernel(const float* __restrict__ opacity,
                                                          const float* __restrict__ alpha,
                                                          const float* __restrict__ wts, int Y, int X, int hq, int wq,
-                                                         int hk, int wk, float offset_scale, int q_rows_cap,
+                                                         int hk, int wk, float offset_scale,
                                                          float* __restrict__ kvbuf) {
-  extern __shared__ float sm[];
-  float* s_w = sm;                                  // kHoaWeights
-  float* s_q = s_w + ((kHoaWeights + 3) & ~3);      // [rows of the q map this workgroup's offset conv reads][wq][8]
-  const int nkv = hk * wk;
-  float* s_gl = s_q + q_rows_cap * wq * kHI;        // [nkv][8] GELU(offset conv)
-  float* s_f = s_gl + nkv * kHI;                    // [nkv][2] sampling position in the (hq,wq) map
-  float* s_kv = s_f + nkv * 2;                      // [nkv][13] sampled alpha
-  // grid (G, B): workgroup g of a sample owns kv tokens [j0, j1) — the phases are latency chains (36-tap
-  // LDS convolution, 16 dependent global taps per sampled value), so B workgroups left the chip idle for 20 us
-  const int tid = threadIdx.x, b = blockIdx.y;
-  const int per = (hk * wk + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int j0 = blockIdx.x * per, j1 = min(j0 + per, hk * wk), nj = j1 - j0;
-  if (nj <= 0) return;
+  __shared__ float s_w[kHoaWLds];
+  __shared__ float s_tok[36 * kHD];                 // window token (u, v): bilinear sample of the 13 opacity planes
+  __shared__ float s_q[36 * kHI];
+  __shared__ float s_gl[kHI];
+  __shared__ float s_f[2];
+  __shared__ float s_tap[kHD * 16];                 // [channel][tap][corner]
+  __shared__ float s_kv[kHD];
+  const int tid = threadIdx.x, j = blockIdx.x, b = blockIdx.y;
+  const int ky = j / wk, kx = j % wk, nkv = hk * wk;
   const long plane = (long)Y * X;
-  const float* al = alpha + (long)b * kHD * plane;
-  float* out = kvbuf + (long)b * nkv * 18;
-  for (int i = tid; i < kHoaWeights; i += kBlock) s_w[i] = wts[i];
-  // the 6x6 stride-4 offset conv of kv rows [j0 / wk, (j1 - 1) / wk] reads q rows [4 ky - 1, 4 ky + 4]: q is rebuilt
-  // here for exactly those rows (no q launch, no q buffer); 6 of 33 rows for one kv row at BEV 200 x 200.  The
-  // taps of the first batch of tokens are in flight together with the weights (one memory round trip, not two).
-  const int qy_lo = max(0, (j0 / wk) * 4 - 1), qy_hi = min(hq - 1, ((j1 - 1) / wk) * 4 + 4);
   const float* op = opacity + (long)b * kHD * plane;
+  const float* al = alpha + (long)b * kHD * plane;
+  float* out = kvbuf + ((long)b * nkv + j) * 18;
   const float ry = hq > 1 ? (float)(Y - 1) / (float)(hq - 1) : 0.f, rx = wq > 1 ? (float)(X - 1) / (float)(wq - 1) : 0.f;
-  const int nq = (qy_hi - qy_lo + 1) * wq;
-  for (int i0 = 0; i0 < nq; i0 += kBlock) {
-    const int i = i0 + tid;
-    float tok[kHD];
-    if (i < nq) {
+  // ---- round trip 1: weights + window samples (tokens outside the map are read at the clamped position: their
+  // conv weight is 0, as in the reference's zero padding) ----
+  float wv[kHoaWLoads];
 #pragma unroll
-      for (int c = 0; c < kHD; ++c)
-        tok[c] = bilinear_ac(op + c * plane, Y, X, ry * (float)(qy_lo + i / wq), rx * (float)(i % wq));
-    }
-    if (i0 == 0) __syncthreads();          // weights
-    if (i < nq) {
-      float q[kHI];
+  for (int i = 0; i < kHoaWLoads; ++i) wv[i] = wts[min(tid + i * kBlock, kHoaWeights - 1)];
+  float p00[2], p01[2], p10[2], p11[2], sly[2], slx[2];
 #pragma unroll
-      for (int d = 0; d < kHI; ++d) q[d] = 0.f;
+  for (int i = 0; i < 2; ++i) {
+    const int it = min(tid + i * kBlock, 36 * kHD - 1);
+    const int wi = it / kHD, c = it % kHD;
+    const int qy = min(max(ky * 4 - 1 + wi / 6, 0), hq - 1), qx = min(max(kx * 4 - 1 + wi % 6, 0), wq - 1);
+    const AcTaps a = ac_taps(Y, X, ry * (float)qy, rx * (float)qx);
+    const float* p = op + c * plane;
+    p00[i] = p[(long)a.y0 * X + a.x0]; p01[i] = p[(long)a.y0 * X + a.x1];
+    p10[i] = p[(long)a.y1 * X + a.x0]; p11[i] = p[(long)a.y1 * X + a.x1];
+    sly[i] = a.ly; slx[i] = a.lx;
+  }
 #pragma unroll
-      for (int c = 0; c < kHD; ++c) {
+  for (int i = 0; i < kHoaWLoads; ++i) s_w[tid + i * kBlock] = wv[i];
 #pragma unroll
-        for (int d = 0; d < kHI; ++d) q[d] = fmaf(s_w[oQ + d * kHD + c], tok[c], q[d]);
-      }
+  for (int i = 0; i < 2; ++i) {
+    const int it = min(tid + i * kBlock, 36 * kHD - 1);            // (the clamped duplicates store the same value)
+    s_tok[it] = ac_mix(p00[i], p01[i], p10[i], p11[i], sly[i], slx[i]);
+  }
+  __syncthreads();
+  // ---- to_q of the 36 window tokens ----
 #pragma unroll
-      for (int d = 0; d < kHI; ++d) s_q[i * kHI + d] = q[d];
+  for (int i = 0; i < 2; ++i) {
+    const int it = tid + i * kBlock;
+    if (it < 36 * kHI) {
+      const int wi = it / kHI, d = it % kHI;
+      float q = 0.f;
+#pragma unroll
+      for (int c = 0; c < kHD; ++c) q = fmaf(s_w[oQ + d * kHD + c], s_tok[wi * kHD + c], q);
+      s_q[it] = q;
     }
   }
   __syncthreads();
-  for (int i = tid; i < nj * kHI; i += kBlock) {           // one (kv token, channel) per thread
-    const int j = j0 + i / kHI, d = i % kHI;
-    const int ky = j / wk, kx = j % wk;
+  // ---- offset conv (36 taps in order, weight 0 outside the map) -> GELU ----
+  if (tid < kHI) {
+    const int d = tid;
     float a = s_w[oDB + d];
-    // zero padding: a tap outside the map is read at a clamped position with weight 0 (a + 0 = a), which keeps the
-    // 36 LDS reads independent of the bounds tests and in flight together
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
       const int yy = ky * 4 - 1 + u;
       const bool yin = yy >= 0 && yy < hq;
-      const int yc = min(max(yy, qy_lo), qy_hi) - qy_lo;
 #pragma unroll
       for (int v = 0; v < 6; ++v) {
         const int xx = kx * 4 - 1 + v;
         const bool in = yin && xx >= 0 && xx < wq;
         const float w = in ? s_w[oDW + d * 36 + u * 6 + v] : 0.f;
-        a = fmaf(w, s_q[(yc * wq + min(max(xx, 0), wq - 1)) * kHI + d], a);
+        a = fmaf(w, s_q[(u * 6 + v) * kHI + d], a);
       }
     }
-    s_gl[j * kHI + d] = 0.5f * a * (1.f + erff(a * 0.70710678118654752f));            // nn.GELU (exact)
+    s_gl[d] = 0.5f * a * (1.f + erff(a * 0.70710678118654752f));            // nn.GELU (exact)
   }
   __syncthreads();
-  for (int j = j0 + tid; j < j1; j += kBlock) {
-    const int ky = j / wk, kx = j % wk;
+  if (tid == 0) {
     float ox = 0.f, oy = 0.f;
 #pragma unroll
     for (int d = 0; d < kHI; ++d) {
-      ox = fmaf(s_w[oPW + d], s_gl[j * kHI + d], ox);
-      oy = fmaf(s_w[oPW + 8 + d], s_gl[j * kHI + d], oy);
+      ox = fmaf(s_w[oPW + d], s_gl[d], ox);
+      oy = fmaf(s_w[oPW + 8 + d], s_gl[d], oy);
     }
     const float vx = (float)kx + tanhf(ox) * offset_scale, vy = (float)ky + tanhf(oy) * offset_scale;
     // normalize_grid as written (cross_attention_2d.py:30-38): channel 0 over (h-1), 1 over (w-1)
     const float gx = 2.0f * vx / (float)max(hk - 1, 1) - 1.0f, gy = 2.0f * vy / (float)max(wk - 1, 1) - 1.0f;
-    out[j * 18 + 16] = gx;
-    out[j * 18 + 17] = gy;
-    s_f[j * 2] = ((gx + 1.f) * (float)wq - 1.f) * 0.5f;
-    s_f[j * 2 + 1] = ((gy + 1.f) * (float)hq - 1.f) * 0.5f;
+    out[16] = gx;
+    out[17] = gy;
+    s_f[0] = ((gx + 1.f) * (float)wq - 1.f) * 0.5f;
+    s_f[1] = ((gy + 1.f) * (float)hq - 1.f) * 0.5f;
   }
   __syncthreads();
-  for (int i = tid; i < nj * kHD; i += kBlock) {           // one (kv token, alpha channel) per thread
-    const int j = j0 + i / kHD, c = i % kHD;
-    const float fx = s_f[j * 2], fy = s_f[j * 2 + 1];
-    const int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
-    // zeros padding: a tap outside the map is read at a clamped position with weight 0 (the sum is unchanged:
-    // the volumes are finite), so that the 16 loads of the four taps are independent
+  // ---- round trip 2: one corner of one tap of one alpha channel per thread (taps outside the map: clamped position,
+  // weight 0 below) ----
+  const float fx = s_f[0], fy = s_f[1];
+  const int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
+  {
+    const int it = min(tid, kHD * 16 - 1);
+    const int c = it >> 4, tp = (it >> 2) & 3, cr = it & 3;
+    const int xi = min(max(x0 + (tp & 1), 0), wq - 1), yi = min(max(y0 + (tp >> 1), 0), hq - 1);
+    const AcTaps a = ac_taps(Y, X, ry * (float)yi, rx * (float)xi);
+    const float v = al[c * plane + (long)((cr >> 1) ? a.y1 : a.y0) * X + ((cr & 1) ? a.x1 : a.x0)];
+    if (tid < kHD * 16) s_tap[tid] = v;
+  }
+  __syncthreads();
+  if (tid < kHD) {
+    const int c = tid;
     float val[4], wt[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
+    for (int tp = 0; tp < 4; ++tp) {
+      const int xi = x0 + (tp & 1), yi = y0 + (tp >> 1);
       const bool in = xi >= 0 && xi < wq && yi >= 0 && yi < hq;
-      wt[t] = in ? (1.f - fabsf(fx - (float)xi)) * (1.f - fabsf(fy - (float)yi)) : 0.f;
-      val[t] = bilinear_ac(al + c * plane, Y, X, ry * (float)min(max(yi, 0), hq - 1), rx * (float)min(max(xi, 0), wq - 1));
+      wt[tp] = in ? (1.f - fabsf(fx - (float)xi)) * (1.f - fabsf(fy - (float)yi)) : 0.f;
+      const AcTaps a = ac_taps(Y, X, ry * (float)min(max(yi, 0), hq - 1), rx * (float)min(max(xi, 0), wq - 1));
+      const float* q = s_tap + c * 16 + tp * 4;
+      val[tp] = ac_mix(q[0], q[1], q[2], q[3], a.ly, a.lx);
     }
     float acc = 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc = fmaf(val[t], wt[t], acc);
-    s_kv[j * kHD + c] = acc;
+    for (int tp = 0; tp < 4; ++tp) acc = fmaf(val[tp], wt[tp], acc);
+    s_kv[c] = acc;
   }
   __syncthreads();
-  for (int i = tid; i < nj * kHI; i += kBlock) {
-    const int j = j0 + i / kHI, d = i % kHI;
-    float a = 0.f, bb = 0.f;
-    for (int c = 0; c < kHD; ++c) {
-      a = fmaf(s_w[oK + d * kHD + c], s_kv[j * kHD + c], a);
-      bb = fmaf(s_w[oV + d * kHD + c], s_kv[j * kHD + c], bb);
-    }
-    out[j * 18 + d] = a;
-    out[j * 18 + 8 + d] = bb;
+  if (tid < 2 * kHI) {
+    const int d = tid % kHI, o = tid < kHI ? oK : oV;
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < kHD; ++c) a = fmaf(s_w[o + d * kHD + c], s_kv[c], a);
+    out[tid] = a;                                   // k[8] | v[8]
   }
 }
 
@@ -1167,6 +1087,7 @@ __global__ __launch_bounds__(kBlock) void hoa1_kv_kernel(const float* __restrict
 // it cannot fill (338 workgroups at 2 x 200 x 200), so every global load — the token's 52 bilinear taps, the pixel's
 // 13 residual values, weights and kv tokens — is issued before the first barrier.
 constexpr int kAttSplit = 8, kTP = 16, kTT = 5;
+constexpr int kKvLoads = (kHMaxKV * 9 + kBlock - 1) / kBlock;       // 8-byte words of the kv tokens per thread (5)
 constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppMirror8 = 0x141;   // quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror
 template <int CTRL>
 __device__ __forceinline__ float hoa_dpp(float x) {
@@ -1176,9 +1097,9 @@ __device__ __forceinline__ float hoa_dpp(float x) {
 __global__ __launch_bounds__(kBlock) void hoa1_attention_upsample_kernel(
     const float* __restrict__ opacity, const float* __restrict__ kvbuf, const float* __restrict__ wts, int Y, int X,
     int hq, int wq, int nkv, float* __restrict__ out) {
-  extern __shared__ float sm[];
-  float* s_w = sm;                                  // kHoaWeights
-  float* s_kv = s_w + ((kHoaWeights + 3) & ~3);     // [nkv][18]
+  __shared__ float s_w[kHoaWLds];
+  __shared__ __attribute__((aligned(8))) float s_kv[kKvLoads * kBlock * 2];      // [nkv][18], padded to whole trips
+  __shared__ float s_tok[kTT * kTT * kHD];
   __shared__ float s_att[kTT * kTT * kHD];
   const int tid = threadIdx.x, b = blockIdx.z;
   const long plane = (long)Y * X;
@@ -1195,13 +1116,28 @@ __global__ __launch_bounds__(kBlock) void hoa1_attention_upsample_kernel(
   const int lt = has ? tl : 0;                               // idle lanes of a live wave run token 0
   const int ty = ty0 + lt / ntx, tx = tx0 + lt % ntx;
   const float ry = hq > 1 ? (float)(Y - 1) / (float)(hq - 1) : 0.f, rx = wq > 1 ? (float)(X - 1) / (float)(wq - 1) : 0.f;
-  // ---- all global loads ----
-  float tok[kHD];
+  // ---- all global loads, unconditional (clamped), before the first wait: weights, kv tokens, the window tokens'
+  // bilinear samples — one (token, channel) sample of four corner taps per thread and trip instead of every one of
+  // a token's eight lanes loading all 52 — and the pixel's residual ----
+  float wv[kHoaWLoads];
 #pragma unroll
-  for (int c = 0; c < kHD; ++c) tok[c] = 0.f;
-  if (tl < kTT * kTT) {
+  for (int i = 0; i < kHoaWLoads; ++i) wv[i] = wts[min(tid + i * kBlock, kHoaWeights - 1)];
+  float2 kvv[kKvLoads];
+  {
+    const float2* kv2 = reinterpret_cast<const float2*>(kvbuf + (long)b * nkv * 18);      // 18 floats per token: 8-byte aligned
 #pragma unroll
-    for (int c = 0; c < kHD; ++c) tok[c] = bilinear_ac(op + c * plane, Y, X, ry * (float)ty, rx * (float)tx);
+    for (int i = 0; i < kKvLoads; ++i) kvv[i] = kv2[min(tid + i * kBlock, nkv * 9 - 1)];
+  }
+  float p00[2], p01[2], p10[2], p11[2], sly[2], slx[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int it = min(tid + i * kBlock, nty * ntx * kHD - 1);
+    const int wi = it / kHD, c = it % kHD;
+    const AcTaps a = ac_taps(Y, X, ry * (float)(ty0 + wi / ntx), rx * (float)(tx0 + wi % ntx));
+    const float* p = op + c * plane;
+    p00[i] = p[(long)a.y0 * X + a.x0]; p01[i] = p[(long)a.y0 * X + a.x1];
+    p10[i] = p[(long)a.y1 * X + a.x0]; p11[i] = p[(long)a.y1 * X + a.x1];
+    sly[i] = a.ly; slx[i] = a.lx;
   }
   const int y = py0 + tid / kTP, x = px0 + tid % kTP;
   const bool inside = y < Y && x < X;
@@ -1209,9 +1145,19 @@ __global__ __launch_bounds__(kBlock) void hoa1_attention_upsample_kernel(
   float res[kHD];
 #pragma unroll
   for (int c = 0; c < kHD; ++c) res[c] = op[c * plane + pix];
-  for (int i = tid; i < kHoaWeights; i += kBlock) s_w[i] = wts[i];
-  for (int i = tid; i < nkv * 18; i += kBlock) s_kv[i] = kvbuf[(long)b * nkv * 18 + i];
+#pragma unroll
+  for (int i = 0; i < kHoaWLoads; ++i) s_w[tid + i * kBlock] = wv[i];
+#pragma unroll
+  for (int i = 0; i < kKvLoads; ++i) reinterpret_cast<float2*>(s_kv)[tid + i * kBlock] = kvv[i];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int it = min(tid + i * kBlock, nty * ntx * kHD - 1);    // (clamped duplicates store the same value)
+    s_tok[it] = ac_mix(p00[i], p01[i], p10[i], p11[i], sly[i], slx[i]);
+  }
   __syncthreads();
+  float tok[kHD];
+#pragma unroll
+  for (int c = 0; c < kHD; ++c) tok[c] = s_tok[lt * kHD + c];
   // ---- attention of the window's tokens: kAttSplit adjacent lanes per token ----
   if (tl < kTT * kTT) {          // wave-uniform up to the last wave
     const float scale = 0.35355339059327373f;               // dim_head ** -0.5
@@ -1310,17 +1256,12 @@ int ocrf_hoa1_forward(const float* opacity, const float* alpha, const float* wei
   if (ntok > kHMaxTok || nkv > kHMaxKV) return (int)hipErrorInvalidValue;
   // (the workspace keeps round 1's layout att | q | kv; only the kv part is used now)
   float* kvbuf = att_workspace + (size_t)B * kHD * ntok + (size_t)B * ntok * kHI;
-  const int n_kv_wg = min(nkv, 8);
-  const int per = (nkv + n_kv_wg - 1) / n_kv_wg;
-  const int q_rows = min(hq, ((per + wk - 1) / wk + 1) * 4 + 6);       // upper bound of a workgroup's q-row window
-  const size_t lds_kv = (size_t)(((kHoaWeights + 3) & ~3) + q_rows * wq * kHI + nkv * (kHI + 2 + kHD)) * sizeof(float);
-  ocrf::launch(OCRF_K_HOA1_KV, hoa1_kv_kernel, dim3(n_kv_wg, B), dim3(kBlock), lds_kv, stream, opacity, alpha, weights,
-               Y, X, hq, wq, hk, wk, offset_scale, q_rows, kvbuf);
+  ocrf::launch(OCRF_K_HOA1_KV, hoa1_kv_kernel, dim3(nkv, B), dim3(kBlock), 0, stream, opacity, alpha, weights, Y, X, hq, wq,
+               hk, wk, offset_scale, kvbuf);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  const size_t lds_at = (size_t)(((kHoaWeights + 3) & ~3) + nkv * 18) * sizeof(float);
   ocrf::launch(OCRF_K_HOA1_ATTN, hoa1_attention_upsample_kernel, dim3((X + kTP - 1) / kTP, (Y + kTP - 1) / kTP, B),
-               dim3(kBlock), lds_at, stream, opacity, static_cast<const float*>(kvbuf), weights, Y, X, hq, wq, nkv, out);
+               dim3(kBlock), 0, stream, opacity, static_cast<const float*>(kvbuf), weights, Y, X, hq, wq, nkv, out);
   return (int)hipGetLastError();
 }
 

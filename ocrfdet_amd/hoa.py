@@ -296,7 +296,7 @@ class OpacityVoxelToBEVConverter(nn.Module):
 
     def _packed_v2b(self):
         """All weights of the converter as ONE float vector in the order ``ocrf_hoa_v2b_forward`` reads them
-        (csrc/hoa.hip ``v2b_offsets``): per block (encoder1, encoder2, bottleneck, decoder2, decoder1) the folded
+        (csrc/hoa_v2b.hip ``v2b_offsets``): per block (encoder1, encoder2, bottleneck, decoder2, decoder1) the folded
         depthwise / pointwise weights and that block's HeightAttention w1, w2; the two up-convolutions; the output
         conv.  Cached until a parameter or buffer changes."""
         cache = self.__dict__.get('_plan_cache')
@@ -318,8 +318,10 @@ class OpacityVoxelToBEVConverter(nn.Module):
             for up in (self.upconv2, self.upconv1):
                 parts.extend((up.weight.detach().float().reshape(-1), up.bias.detach().float().reshape(-1)))
             parts.extend((self.output_conv.weight.detach().float().reshape(-1), self.output_conv.bias.detach().float().reshape(-1)))
-            packed = torch.cat([t.float() for t in parts]).contiguous()
-        assert packed.numel() == _lib.lib().ocrf_hoa_v2b_weights_len()
+            packed = torch.cat([t.float() for t in parts])
+            n = _lib.lib().ocrf_hoa_v2b_weights_len()           # the vector zero-padded to whole 16-byte words
+            assert 0 <= n - packed.numel() < 4, (n, packed.numel())
+            packed = torch.cat((packed, packed.new_zeros(n - packed.numel()))).contiguous()
         cache['packed'] = (key, packed)
         return packed
 
@@ -328,7 +330,7 @@ class OpacityVoxelToBEVConverter(nn.Module):
         return (e1.in_channels == 13 and self.ca1.hid == self.ca1.q_in == 1 and self.ca_bottleneck.hid == 4)
 
     def _forward_fused(self, x, position):
-        """Eval-mode forward as ONE C call of six launches (csrc/hoa.hip, ``ocrf_hoa_v2b_forward``): five fused
+        """Eval-mode forward as ONE C call of six launches (csrc/hoa_v2b.hip, ``ocrf_hoa_v2b_forward``): five fused
         block kernels, each computing the HeightAttention gates of its producers in its own prologue, and the gated
         output conv; no intermediate pooled / upsampled / concatenated / gated tensor is ever written.  The
         intermediates live in the library's 'hoa_v2b' scratch buffer: one forward at a time per stream."""

@@ -121,6 +121,24 @@ def test_opacity_voxel_to_bev_fused_vs_blockwise_and_oracle(cuda, g):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('B,H,W', [(1, 16, 16), (1, 36, 52), (3, 100, 60), (2, 128, 128), (1, 44, 236), (1, 264, 260)])
+def test_opacity_voxel_to_bev_six_launch_form_on_other_map_sizes(cuda, g, B, H, W):
+    """csrc/hoa_v2b.hip (16 x 4 pixel tiles, gates rebuilt from per-tile maxima, DPP reductions) against the block-wise
+    eleven-launch form (16 x 16 tiles, gate kernels in between), bit for bit, on maps whose three levels end in ragged
+    tiles in x, in y, in both, on the smallest map a tile covers and on one beyond 256 x 256 (more than four rounds of
+    tile maxima per thread)."""
+    m = hoa.OpacityVoxelToBEVConverter(13).to(cuda).eval()
+    m.load_state_dict(_sd(g, 'v2b'))
+    rng = np.random.default_rng(H * 1000 + W)
+    xt = torch.from_numpy(rng.random((B, 13, H, W), dtype=np.float32)).to(cuda)
+    pt = torch.from_numpy((rng.standard_normal((B, 4, H, W)) * 0.1).astype(np.float32)).to(cuda)
+    with torch.no_grad():
+        six = m(xt, pt)
+        eleven = m._forward_blocks(xt, pt)
+    assert torch.equal(six, eleven)
+
+
+@pytest.mark.gpu
 def test_hoa1_gpu(cuda, g):
     m = hoa.DeformableAttention2D(dim=13, dim_head=8, heads=1, dropout=0.1, downsample_factor=4, offset_scale=4,
                                   offset_groups=None, offset_kernel_size=6).to(cuda).eval()
