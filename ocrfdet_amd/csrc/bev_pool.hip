@@ -804,6 +804,7 @@ void bev_pool_v2(int c, int n_intervals, const float* depth, const float* feat,
 // they were built: change a knob only between independent runs.
 int ocrf_tune_set(int key, int value) {
   if (key >= 10 && key < 20) { ocrf::raster_plan_tune(key, value); return 0; }      // raster_plan.hip
+  if (key >= 20 && key < 30) { ocrf::hoa_tune(key, value); return 0; }              // hoa.hip
   if (key == 0 && value >= 1 && value <= 64) { g_rounds = value; return 0; }
   if (key == 1 && (value == 0 || value == 1)) { g_xcd = value; return 0; }
   if (key == 2 && value >= 0) { g_grid = value; return 0; }

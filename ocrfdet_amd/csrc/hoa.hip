@@ -11,19 +11,22 @@
 // MLPs + sigmoid recomputed per workgroup and applied to x in the same pass.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "launch.h"
 #include "ocrf_hip.h"
 
 namespace {
 
 constexpr int kBlock = 256;
+int g_mg_groups = 0, g_mg_threads = kBlock, g_stats_threads = kBlock;       // ocrf::hoa_tune
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
 // (1) mean and max over channels: one thread per pixel, channel loop with coalesced rows.
 __global__ __launch_bounds__(kBlock) void hoa_channel_stats_kernel(const float* __restrict__ x, int C,
                                                                    long plane, float* __restrict__ stats) {
-  const long pix = (long)blockIdx.x * kBlock + threadIdx.x;
+  const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int b = blockIdx.y;
   if (pix >= plane) return;
   const float* p = x + (long)b * C * plane + pix;
@@ -56,24 +59,29 @@ __global__ __launch_bounds__(kBlock) void hoa_channel_stats_kernel(const float* 
 // of one row — 16-byte loads and stores of x / gated, and the k-wide windows of adjacent pixels share their reads.
 // KT = k when it is known at compile time (7, the only size OcRFDet uses: the tap loops unroll and their LDS reads
 // pipeline instead of paying one LDS latency per tap), 0 = runtime k.
-template <int VEC, int KT>
+// FAST (VEC = 4, X <= 256): the statistic rows are staged as 16-byte words, one row = 64 word slots (no index
+// divisions: the generic staging spends ~ 80 integer divisions per thread, more than the convolution), at clamped
+// addresses without a branch; a staged row carries 4 zero columns on the left (3 would do: 4 keeps the words aligned).
+template <int VEC, int KT, bool FAST = false>
 __global__ __launch_bounds__(kBlock) void hoa_mask_gate_kernel(
     const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ opacity_bev,
     const float* __restrict__ conv_w, int k_rt, int C, int Y, int X, int groups, int n_rows,
     float* __restrict__ mask, float* __restrict__ gated) {
   const int k = KT ? KT : k_rt;
+  const int nt = (int)blockDim.x;              // 256, or fewer for more and shorter workgroups (ocrf_hoa_opacity_mask_gate)
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];      // weights, then 2 planes of n_rows x tw, zero padded
   // VEC = 4: rows padded to a multiple of 4 floats and the planes 16-byte aligned behind the weights — a thread's
   // (k + 3)-wide window is then three ds_read_b128 (lanes 16 B apart: conflict-free) instead of ten ds_read_b32 whose
   // lanes, 4 floats apart, hit 8 banks (5.1 bank conflicts per LDS instruction by PMC)
-  const int r = k / 2, tw = (VEC == 4) ? ((X + k - 1 + 3) & ~3) : (X + k - 1);
+  const int r = k / 2, tw = FAST ? X + 8 : ((VEC == 4) ? ((X + k - 1 + 3) & ~3) : (X + k - 1));
+  constexpr int PL = FAST ? 1 : 0;             // extra zero columns on the left of a staged row
   float* s_w = s_dyn;
   float* s_s = s_dyn + ((VEC == 4) ? ((2 * k * k + 3) & ~3) : 2 * k * k);
   const long plane = (long)Y * X;
   const int b = blockIdx.z / groups, g = blockIdx.z % groups;
-  const long p0 = (long)blockIdx.x * kBlock * VEC;
+  const long p0 = (long)blockIdx.x * nt * VEC;
   const int row0 = (int)(p0 / X) - r;                      // first staged row (may be negative: zeros)
-  for (int i = threadIdx.x; i < 2 * k * k; i += kBlock) s_w[i] = conv_w[i];
+  for (int i = threadIdx.x; i < 2 * k * k; i += nt) s_w[i] = conv_w[i];
   // the first batch of this thread's x values is on its way while the mask is computed
   const long pix_e = p0 + (long)threadIdx.x * VEC;
   const int cpg_e = (C + groups - 1) / groups;
@@ -87,13 +95,38 @@ __global__ __launch_bounds__(kBlock) void hoa_mask_gate_kernel(
       for (int u = 0; u < 5; ++u) first[u] = *reinterpret_cast<const float4*>(pe + (long)(c0_e + u) * plane);
     }
   }
+  if constexpr (FAST) {
+    const int n_items = 2 * n_rows * 64, x4 = X >> 2;
+    float4* s_s4 = reinterpret_cast<float4*>(s_s);
+    const int tw4 = tw >> 2;
+    for (int i0 = 0; i0 < n_items; i0 += 8 * nt) {       // one trip at 200 x 200 (26 rows)
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = min(i0 + u * nt + (int)threadIdx.x, n_items - 1);
+        const int rp = i >> 6, c4 = min(i & 63, x4 - 1);
+        const int ch = rp >= n_rows ? 1 : 0, y = row0 + rp - ch * n_rows;
+        v[u] = *reinterpret_cast<const float4*>(stats + ((long)b * 2 + ch) * plane + (long)min(max(y, 0), Y - 1) * X + 4 * c4);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * nt + (int)threadIdx.x;
+        const int rp = i >> 6, c4 = i & 63;
+        const int ch = rp >= n_rows ? 1 : 0, y = row0 + rp - ch * n_rows;
+        const bool in = y >= 0 && y < Y;
+        if (i < n_items && c4 < x4) s_s4[rp * tw4 + 1 + c4] = in ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    for (int i = threadIdx.x; i < 2 * n_rows * 2; i += nt)      // the zero words left and right of every row
+      s_s4[(i >> 1) * tw4 + ((i & 1) ? 1 + x4 : 0)] = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
   // the statistic rows: all of a thread's loads are issued before any is stored
   const int n_stage = 2 * n_rows * tw;
-  for (int i0 = 0; i0 < n_stage; i0 += 8 * kBlock) {
+  for (int i0 = 0; i0 < n_stage; i0 += 8 * nt) {
     float v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int i = i0 + u * kBlock + threadIdx.x;
+      const int i = i0 + u * nt + threadIdx.x;
       const int ch = i / (n_rows * tw), rem = i % (n_rows * tw);
       const int y = row0 + rem / tw, xx = rem % tw - r;
       v[u] = (i < n_stage && y >= 0 && y < Y && xx >= 0 && xx < X)
@@ -101,9 +134,10 @@ __global__ __launch_bounds__(kBlock) void hoa_mask_gate_kernel(
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int i = i0 + u * kBlock + threadIdx.x;
+      const int i = i0 + u * nt + threadIdx.x;
       if (i < n_stage) s_s[i] = v[u];
     }
+  }
   }
   __syncthreads();
   const long pix = p0 + (long)threadIdx.x * VEC;
@@ -136,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void hoa_mask_gate_kernel(
         for (int j = 0; j < KT; ++j) {
           const float w = wr[j];
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) acc[e] = fmaf(win[j + e], w, acc[e]);
+          for (int e = 0; e < VEC; ++e) acc[e] = fmaf(win[j + e + PL], w, acc[e]);
         }
       }
     }
@@ -333,6 +367,16 @@ __global__ __launch_bounds__(kBlock) void hoa_dw3x3_wgrad_kernel(const float* __
 
 }  // namespace
 
+namespace ocrf {
+// diagnostic knobs reached through ocrf_tune_set (keys 20-29): 20 = channel groups of the mask-gate launch (0 = by C),
+// 21 = threads per workgroup of it (64 | 128 | 256), 22 = threads per workgroup of the channel statistics
+void hoa_tune(int key, int value) {
+  if (key == 20 && value >= 0) g_mg_groups = value;
+  if (key == 21 && (value == 64 || value == 128 || value == 256)) g_mg_threads = value;
+  if (key == 22 && (value == 64 || value == 128 || value == 256)) g_stats_threads = value;
+}
+}  // namespace ocrf
+
 extern "C" {
 
 int ocrf_hoa_dw3x3(const float* x, const float* w, const float* bias, int B, int C, int Y, int X, float* y,
@@ -358,8 +402,9 @@ int ocrf_hoa_channel_stats(const float* x, int B, int C, int Y, int X, float* st
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (!x || !stats || B <= 0 || C <= 0 || Y <= 0 || X <= 0) return (int)hipErrorInvalidValue;
   const long plane = (long)Y * X;
-  ocrf::launch(OCRF_K_HOA_STATS, hoa_channel_stats_kernel, dim3((unsigned)((plane + kBlock - 1) / kBlock), B),
-               dim3(kBlock), 0, stream, x, C, plane, stats);
+  const int nt = g_stats_threads;
+  ocrf::launch(OCRF_K_HOA_STATS, hoa_channel_stats_kernel, dim3((unsigned)((plane + nt - 1) / nt), B), dim3(nt), 0, stream,
+               x, C, plane, stats);
   return (int)hipGetLastError();
 }
 
@@ -373,21 +418,25 @@ int ocrf_hoa_opacity_mask_gate(const float* x, const float* stats, const float* 
   const long plane = (long)Y * X;
   const bool vec4 = (X % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gated)) & 15u) == 0 &&
                     (X + 6) * 14 * 2 * 4 <= 60 * 1024;
-  const int per_wg = kBlock * (vec4 ? 4 : 1);
+  const int threads = g_mg_threads;
+  const int per_wg = threads * (vec4 ? 4 : 1);
   // rows a run of per_wg consecutive pixels can touch (it may start mid-row) plus the k - 1 halo rows
   const int n_rows = (per_wg + X - 2) / X + 1 + (k - 1);
-  const int tw = vec4 ? ((X + k - 1 + 3) & ~3) : (X + k - 1);
+  const bool fast = vec4 && k == 7 && X <= 256 && (reinterpret_cast<uintptr_t>(stats) & 15u) == 0;
+  const int tw = fast ? X + 8 : (vec4 ? ((X + k - 1 + 3) & ~3) : (X + k - 1));
   const size_t lds = (size_t)((vec4 ? ((2 * k * k + 3) & ~3) : 2 * k * k) + 2 * n_rows * tw) * sizeof(float);
   if (lds > 64 * 1024) return (int)hipErrorInvalidValue;             // X beyond ~1 000: not a BEV plane
-  const int groups = gated ? ((C >= 40) ? 4 : (C >= 16 ? 2 : 1)) : 1;
+  int groups = gated ? ((C >= 40) ? 4 : (C >= 16 ? 2 : 1)) : 1;
+  if (gated && g_mg_groups > 0) groups = std::min(g_mg_groups, C);
   const dim3 grid((unsigned)((plane + per_wg - 1) / per_wg), 1, (unsigned)(B * groups));
-#define OCRF_MASK_GATE(V, K)                                                                                       \
-  ocrf::launch(OCRF_K_HOA_MASK_GATE, hoa_mask_gate_kernel<V, K>, grid, dim3(kBlock), lds, stream, x, stats, opacity_bev, \
+#define OCRF_MASK_GATE(V, K, F)                                                                                       \
+  ocrf::launch(OCRF_K_HOA_MASK_GATE, hoa_mask_gate_kernel<V, K, F>, grid, dim3(threads), lds, stream, x, stats, opacity_bev, \
                conv_w, k, C, Y, X, groups, n_rows, mask, gated)
-  if (vec4 && k == 7) OCRF_MASK_GATE(4, 7);
-  else if (vec4) OCRF_MASK_GATE(4, 0);
-  else if (k == 7) OCRF_MASK_GATE(1, 7);
-  else OCRF_MASK_GATE(1, 0);
+  if (fast) OCRF_MASK_GATE(4, 7, true);
+  else if (vec4 && k == 7) OCRF_MASK_GATE(4, 7, false);
+  else if (vec4) OCRF_MASK_GATE(4, 0, false);
+  else if (k == 7) OCRF_MASK_GATE(1, 7, false);
+  else OCRF_MASK_GATE(1, 0, false);
 #undef OCRF_MASK_GATE
   return (int)hipGetLastError();
 }

@@ -32,5 +32,7 @@ hipError_t zero_async(void* dst, size_t bytes, hipStream_t stream);
 
 // raster_plan.hip: diagnostic knobs reached through ocrf_tune_set (keys 10-19)
 void raster_plan_tune(int key, int value);
+// hoa.hip: keys 20-29
+void hoa_tune(int key, int value);
 
 }  // namespace ocrf
