@@ -100,3 +100,54 @@ def test_cfg4_eight_frames_step_properties(cuda):
     for a, b in zip(rendered, per_call):
         assert torch.equal(a['color'], b['color']) and torch.equal(a['depth'], b['depth']) and \
             torch.equal(a['final_T'], b['final_T'])
+
+
+def _pool_oracle(oracle_lib, plan, d, f):
+    want = oracle_lib.bev_pool_v2(d, f, plan.ranks_depth.cpu().numpy(), plan.ranks_feat.cpu().numpy(),
+                                  plan.ranks_bev.cpu().numpy(), plan.bev_shape, plan.starts.cpu().numpy(),
+                                  plan.lengths.cpu().numpy())
+    return np.concatenate([want[:, :, z] for z in range(want.shape[2])], 1)
+
+
+def test_cfg2_step_as_benched_against_per_call_renders_and_oracles(cuda, oracle_lib):
+    """The step ``bench.py`` times at N = 1, built exactly as it builds it (``HotPath(cfg2)`` with every default: both
+    frames rendered through ONE fused 12-view plan with ``item_view`` on a 512-workgroup persistent grid of the side
+    stream, the HT pooling on the matrix cores, HOA-1/2 as the six + two latency kernels) — every output of it:
+    renders bit-equal to the per-call pipeline, pooled BEVs within 1e-4 of the C oracle, opacity BEV and gated BEV
+    against the numpy HOA oracle, plan extent check clean."""
+    from oracle import hoa as ohoa
+    cfg = synthetic.CONFIGS[CFG2]
+    hp = hotpath.HotPath(cfg, cuda)
+    depth, feat = hp.make_inputs(seed=0)
+    for _ in range(2):                                   # the second step reuses every persistent buffer
+        lss, ht, rendered, gated, ob = hp.step(depth, feat)
+    torch.cuda.synchronize()
+    hp.check_render_plans()
+    assert len(hp.render_plans) == 1 and hp.render_plans[0][2] == 2       # one plan, two frames: the fused form
+    # renders: the planned path of the step == the per-call pipeline, bit for bit, both frames, all six views
+    per_call = hotpath.HotPath(cfg, cuda, render_mode='per_call', overlap=False).render()
+    assert len(rendered) == 2 and rendered[0]['color'].shape == (6, 3, *cfg.input_size)
+    for f in range(2):
+        for k in ('color', 'depth', 'final_T'):
+            assert torch.equal(rendered[f][k], per_call[f][k]), f'frame {f}: planned {k} differs from the per-call render'
+    assert not torch.equal(rendered[0]['color'], rendered[1]['color'])
+    # pooled BEVs (LSS: tile kernel, HT: MFMA panels) vs the C oracle
+    d, ft = depth.cpu().numpy(), feat.cpu().numpy()
+    for name, plan, got in (('lss', hp.lss, lss), ('ht', hp.ht, ht)):
+        err = float(np.abs(got.cpu().numpy() - _pool_oracle(oracle_lib, plan, d, ft)).max())
+        assert err <= 1e-4, f'{name}: {err}'
+    # HOA-1/2 -> opacity BEV, HOA-3 -> gated BEV vs the numpy oracle (per sample, as the reference loops)
+    X, Y, _ = cfg.bev_xyz
+    Zh = cfg.num_height
+    p = {f'{pre}.{k}': v.detach().cpu().numpy() for pre, m in hp.hoa_mods.items() for k, v in m.state_dict().items()}
+    errs = []
+    for b in range(hp.batch):
+        op = hp.frame_gauss[b]['opacity'].cpu().numpy().astype(np.float32)
+        oa, _ = ohoa.hoa1(op, hp.alpha_lidar[b:b + 1].cpu().numpy(), p, Zh, Y, X, prefix='dca')
+        want_ob = ohoa.opacity_voxel_to_bev(oa, hp.bev_pos1[b:b + 1].cpu().numpy(), p, 'v2b')
+        want_mask = ohoa.opacity_mask(ht[b:b + 1].cpu().numpy(), want_ob, p, 'mask')
+        e_ob = float(np.abs(ob[b:b + 1].cpu().numpy() - want_ob).max())
+        e_g = float(np.abs(gated[b:b + 1].cpu().numpy() - ht[b:b + 1].cpu().numpy() * want_mask).max())
+        errs.append((e_ob, e_g))
+        assert e_ob <= 1e-5 and e_g <= 1e-5, (b, e_ob, e_g)
+    print('cfg2 benched step: max|opacity_bev err|, max|gated err| per frame', errs)

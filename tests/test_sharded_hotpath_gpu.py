@@ -75,3 +75,42 @@ def test_touched_strips_cover_every_nonzero_of_a_partial(cuda):
             outside = tgt.view(P, Y * X)[:, ~inside]
             assert outside.numel() == 0 or float(outside.abs().max()) == 0.0
             assert 0 < int(ex.touched[f][0].numel()) < ex.n_strips
+
+
+@pytest.mark.parametrize('rank', [0, 3])
+def test_cfg2_rank_of_six_partial_grid_and_renders_at_full_size(cuda, oracle_lib, rank):
+    """BASELINE configs[3] (6 cameras x 2 frames over 6 ranks: groups of three per frame, two camera-frames per rank) at
+    its real size, the single-GPU half of it: the rank's partial fused 200 x 200 grid against the C oracle pooled over
+    the rank's cameras, its non-zeros inside the touched tiles the wedge-sparse exchange would send, and its planned
+    renders bit-equal to the per-call pipeline.  (The collectives are covered over gloo in tests/test_sharding.py.)"""
+    cfg = synthetic.CONFIGS['cfg2_6cam_2frame_bev200x200_render_hoa']
+    X, Y, Z = cfg.bev_xyz
+    P = (Z + 1) * cfg.channels
+    sp = hotpath.ShardedHotPath(cfg, cuda, rank, 6)                  # no process group: collectives inactive
+    plan = sp.plan
+    assert [len(g) for g in plan.group_of_frame] == [3, 3] and sum(len(plan.cams_of(rank, f)) for f in plan.frames_of(rank)) == 2
+    ex = sp.exchange
+    inputs = sp.make_inputs(seed=0)
+    for f, sub in sp.subs.items():
+        d, ft = inputs[f]
+        tgt = ex.pool_target(f)
+        sub.pool(sub.lss, d, ft, out=tgt[:Z * cfg.channels])
+        sub.pool(sub.ht, d, ft, out=tgt[Z * cfg.channels:])
+        torch.cuda.synchronize()
+        dn, fn = d.cpu().numpy(), ft.cpu().numpy()
+        for name, pl, got in (('lss', sub.lss, tgt[:Z * cfg.channels]), ('ht', sub.ht, tgt[Z * cfg.channels:])):
+            want = oracle_lib.bev_pool_v2(dn, fn, pl.ranks_depth.cpu().numpy(), pl.ranks_feat.cpu().numpy(),
+                                          pl.ranks_bev.cpu().numpy(), pl.bev_shape, pl.starts.cpu().numpy(),
+                                          pl.lengths.cpu().numpy())
+            want = np.concatenate([want[0, :, z] for z in range(want.shape[2])], 0)
+            assert float(np.abs(got.cpu().numpy() - want).max()) <= 1e-4, name
+        me = plan.group_of_frame[f].index(rank) if ex.active else 0
+        inside = torch.zeros(Y * X, dtype=torch.bool, device=cuda)
+        inside[ex._flat[f][me]] = True
+        outside = tgt.view(P, Y * X)[:, ~inside]
+        assert float(outside.abs().max()) == 0.0 and 0 < int(ex.touched[f][me].numel()) < ex.n_strips
+        got = sub.render()[0]
+        ref = hotpath.HotPath(sub.cfg, cuda, cams=sub.cams, overlap=False, frame_offset=f, render_mode='per_call').render()[0]
+        for k in ('color', 'depth', 'final_T'):
+            assert torch.equal(got[k], ref[k]), k
+        sub.check_render_plans()
