@@ -212,16 +212,21 @@ size_t ocrf_rasterize_workspace_bytes(int P, int n_views);
  * the Jacobian of computeCov2D (forward.cu:83-98,196-199), hence the whole (depth bits, id) blend order the
  * reference obtains by sorting every step (rasterizer_impl.cu:226-267) — is computed ONCE:
  *
- *   1. ocrf_raster_plan_classify  per view (n_views <= 32): sort key of every Gaussian (depth bits, or "never
- *      visible": behind the near plane, or outside the frame for every world-space extent <= extent_bound), stable
- *      radix sort; leaves the sorted ids in `workspace` (>= ocrf_raster_plan_build_workspace_bytes(P, n_views)) and
- *      the kept counts in kept_counts (device, n_views ints).  The caller reads the counts (its one
- *      synchronisation), then
- *   2. ocrf_raster_plan_fill      (same workspace) writes the plan (device, >= ocrf_raster_plan_bytes(P, n_views,
- *      total_kept) bytes, 256-byte aligned): header, cameras; per view the kept records in blend order (id, depth
- *      bits, pixel centre); per Gaussian the views that keep it and, per (Gaussian, view), the record's place in
- *      that order with the rows of J W (forward.cu:83-98).  total_kept = sum of the counts, max_kept = their
- *      maximum.
+ *   1. ocrf_raster_plan_count     (sizing, optional) how many (Gaussian, view) records a plan for these cameras keeps:
+ *      counts (device, 33 ints) = kept per view in [0, n_views), their sum in [32].  The caller reads the sum once
+ *      and chooses a record CAPACITY (with headroom if the plan will be rebuilt for other poses).
+ *   2. ocrf_raster_plan_build     writes the plan (device, >= ocrf_raster_plan_bytes(P, n_views, capacity) bytes,
+ *      256-byte aligned): header, cameras; per view the kept records in blend order (id, depth bits, pixel centre);
+ *      per Gaussian the views that keep it (never visible = behind the near plane, or outside the frame for every
+ *      world-space extent <= extent_bound) and, per (Gaussian, view), the record's place in that order with the rows
+ *      of J W (forward.cu:83-98).  NO host read and kernels only (hipGraph-capturable): classify all views ->
+ *      exclusive scan -> records + one 32-bit sort key per record (view << 27 | depth bits - 0x3E000000: view-space
+ *      depths in [0.125, 8191) m) -> ONE stable radix sort -> gather.  It may be called again on the same buffers
+ *      with other cameras — the reference recomputes the render cameras from the dataloader's c2w for every sample
+ *      (view_transformer_ocrf.py:1140-1152) — a rebuild per sample is ~ 20 launches.  A plan whose records exceed
+ *      `capacity`, a depth outside the key range or a scan that gave up leave the plan marked unusable ON THE DEVICE
+ *      (every render of it raises status bit 8).  workspace >= ocrf_raster_plan_build_workspace_bytes(P, n_views,
+ *      capacity).
  *
  * extent_bound bounds scale_modifier * max_k |s_k| * |R(q)|_2 (|R(q)|_2 = |1 - |q|^2| + |q|^2: 1 for a normalised
  * quaternion) of every Gaussian the plan will be rendered with; a plan stays valid for ANY parameters within it.
@@ -233,7 +238,12 @@ size_t ocrf_rasterize_workspace_bytes(int P, int n_views);
  *      n_sets must equal the plan's view count) with Gaussian set z / (n_items / n_sets) of the (n_sets, P, .)
  *      parameter arrays; the items of one set name distinct views.  Outputs as
  *      ocrf_rasterize_forward, indexed by item; colour / depth / final_T are bit-identical to it.  radii
- *      (n_items, P) or NULL.  workspace >= ocrf_rasterize_planned_workspace_bytes(total_kept, n_sets).
+ *      (n_items, P) or NULL.  `capacity`: the plan's record capacity (as given to the build).
+ *      workspace >= ocrf_rasterize_planned_workspace_bytes(capacity, n_sets).
+ *      call_cameras (device, n_plan_views x 36 floats, or NULL): the cameras THIS call means to render with.  The
+ *      update kernel compares them with the plan's, bit for bit, on the device; a difference raises status bit 4
+ *      (value 16) and — with guard = 1 — hands the call to the armed per-call pipeline, which then renders with
+ *      call_cameras: a stale plan can not silently render another pose.
  *      status (device int, NOT written unless something is wrong: zero it once): bit 2 (value 4) = some Gaussian
  *      exceeded extent_bound this call, bit 3 (value 8) = bad item_view / unusable plan.
  *      guard = 0: with bit 2 set the outputs of that call are not valid (the caller re-renders with
@@ -259,24 +269,24 @@ size_t ocrf_rasterize_workspace_bytes(int P, int n_views);
  *      n + 1's update runs under frame n's blend), ordered by the caller's events.
  * Forward only (no n_contrib): training renders through ocrf_rasterize_forward / _backward.
  */
-size_t ocrf_raster_plan_build_workspace_bytes(int P, int n_views);
-int ocrf_raster_plan_classify(int P, int n_views, int H, int W, const float *means3D, const float *cameras,
-                              float extent_bound, int *kept_counts, void *workspace, size_t workspace_bytes,
-                              ocrf_stream_t stream);
-size_t ocrf_raster_plan_bytes(int P, int n_views, long total_kept);
-int ocrf_raster_plan_fill(int P, int n_views, int H, int W, const float *means3D, const float *cameras,
-                          float extent_bound, const int *kept_counts, long total_kept, int max_kept,
-                          void *workspace, size_t workspace_bytes, void *plan, size_t plan_bytes,
-                          ocrf_stream_t stream);
-size_t ocrf_rasterize_planned_workspace_bytes(long total_kept, int n_sets);
-int ocrf_rasterize_planned(const void *plan, size_t plan_bytes, int P, int n_plan_views, long total_kept,
+size_t ocrf_raster_plan_count_workspace_bytes(int P);
+int ocrf_raster_plan_count(int P, int n_views, int H, int W, const float *means3D, const float *cameras,
+                           float extent_bound, int *counts, void *workspace, size_t workspace_bytes,
+                           ocrf_stream_t stream);
+size_t ocrf_raster_plan_build_workspace_bytes(int P, int n_views, long capacity);
+size_t ocrf_raster_plan_bytes(int P, int n_views, long capacity);
+int ocrf_raster_plan_build(int P, int n_views, int H, int W, const float *means3D, const float *cameras,
+                           float extent_bound, long capacity, void *workspace, size_t workspace_bytes, void *plan,
+                           size_t plan_bytes, ocrf_stream_t stream);
+size_t ocrf_rasterize_planned_workspace_bytes(long capacity, int n_sets);
+int ocrf_rasterize_planned(const void *plan, size_t plan_bytes, int P, int n_plan_views, long capacity,
                            int H, int W, int n_sets, int n_items, const int *item_view,
                            const float *colors, const float *opacities, const float *scales, float scale_modifier,
                            const float *rotations, const float *bg, int depth_mode, float *out_color,
                            float *out_depth, float *out_final_T, int *radii, int *status, void *workspace,
                            size_t workspace_bytes, int guard, const float *means3D, void *chain_workspace,
                            size_t chain_workspace_bytes, int blend_workgroups, const int *yield_if, int phase,
-                           ocrf_stream_t stream);
+                           const float *call_cameras, ocrf_stream_t stream);
 
 /*
  * bev_pool_v2 forward as per-tile MFMA panels (csrc/bev_pool_mfma.hip): out[64 voxels x C] = W[64 x R] . F[R x C]

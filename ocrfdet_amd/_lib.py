@@ -105,21 +105,23 @@ def _declare(L):
     L.ocrf_rasterize_forward_sets.restype = c_int
     L.ocrf_rasterize_forward_sets.argtypes = ([c_int] * 5 + [c_void_p] * 4 + [c_float] + [c_void_p] * 4 +
                                               [c_int] + [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p])
+    L.ocrf_raster_plan_count_workspace_bytes.restype = c_size_t
+    L.ocrf_raster_plan_count_workspace_bytes.argtypes = [c_int]
+    L.ocrf_raster_plan_count.restype = c_int
+    L.ocrf_raster_plan_count.argtypes = [c_int] * 4 + [c_void_p] * 2 + [c_float] + [c_void_p] * 2 + [c_size_t, c_void_p]
     L.ocrf_raster_plan_build_workspace_bytes.restype = c_size_t
-    L.ocrf_raster_plan_build_workspace_bytes.argtypes = [c_int, c_int]
-    L.ocrf_raster_plan_classify.restype = c_int
-    L.ocrf_raster_plan_classify.argtypes = [c_int] * 4 + [c_void_p] * 2 + [c_float] + [c_void_p] * 2 + [c_size_t, c_void_p]
+    L.ocrf_raster_plan_build_workspace_bytes.argtypes = [c_int, c_int, c_long]
     L.ocrf_raster_plan_bytes.restype = c_size_t
     L.ocrf_raster_plan_bytes.argtypes = [c_int, c_int, c_long]
-    L.ocrf_raster_plan_fill.restype = c_int
-    L.ocrf_raster_plan_fill.argtypes = ([c_int] * 4 + [c_void_p] * 2 + [c_float, c_void_p, c_long, c_int] +
-                                        [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p])
+    L.ocrf_raster_plan_build.restype = c_int
+    L.ocrf_raster_plan_build.argtypes = ([c_int] * 4 + [c_void_p] * 2 + [c_float, c_long] +
+                                         [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p])
     L.ocrf_rasterize_planned_workspace_bytes.restype = c_size_t
     L.ocrf_rasterize_planned_workspace_bytes.argtypes = [c_long, c_int]
     L.ocrf_rasterize_planned.restype = c_int
     L.ocrf_rasterize_planned.argtypes = ([c_void_p, c_size_t, c_int, c_int, c_long] + [c_int] * 4 + [c_void_p] * 4 +
                                          [c_float] + [c_void_p] * 2 + [c_int] + [c_void_p] * 6 + [c_size_t, c_int] +
-                                         [c_void_p] * 2 + [c_size_t, c_int, c_void_p, c_int, c_void_p])
+                                         [c_void_p] * 2 + [c_size_t, c_int, c_void_p, c_int, c_void_p, c_void_p])
     L.ocrf_stream_write_value32.restype = c_int
     L.ocrf_stream_write_value32.argtypes = [c_void_p, c_int, c_void_p]
     L.ocrf_lss_prepare.restype = c_int

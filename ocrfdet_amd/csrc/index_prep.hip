@@ -643,6 +643,17 @@ hipError_t radix_sort_ids(unsigned* keys, int n, int key_bits, void* scratch, si
   return hipGetLastError();
 }
 
+// where a radix_sort_ids(.., n, key_bits, scratch, ..) call leaves the state blocks of its look-back scans (one per
+// pass): bit 63 of a block's first word says that scan gave up (the caller's last kernel checks them on the device)
+void radix_sort_states(void* scratch, int n, int key_bits, const unsigned long long** states, int* n_states,
+                       long* stride_words) {
+  SortWs w;
+  sort_layout(n, &w);
+  *states = reinterpret_cast<const unsigned long long*>(static_cast<char*>(scratch) + w.state);
+  *n_states = (key_bits + kRadixBits - 1) / kRadixBits;
+  *stride_words = (long)(lb_state_bytes(w.state_tiles) / 8);
+}
+
 // in-place exclusive prefix sum of n non-negative ints (one look-back launch + the zero-fill of its state)
 size_t exclusive_scan_bytes(long n) { return n > 0 ? align_up(lb_state_bytes((n + kChunk - 1) / kChunk), 256) : 0; }
 

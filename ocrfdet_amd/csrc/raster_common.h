@@ -187,6 +187,9 @@ int* raster_chain_hist(void* workspace, int P, int n_views, size_t* n_words);
 size_t radix_sort_ids_bytes(int n);
 hipError_t radix_sort_ids(unsigned* keys, int n, int key_bits, void* scratch, size_t scratch_bytes,
                           const unsigned** sorted_keys, const int** sorted_ids, hipStream_t stream);
+// the state blocks of that call's look-back scans (bit 63 of a block's first word: the scan gave up)
+void radix_sort_states(void* scratch, int n, int key_bits, const unsigned long long** states, int* n_states,
+                       long* stride_words);
 
 
 // index_prep.hip: in-place exclusive prefix sum of n non-negative ints (*total = their sum, may be null)

@@ -82,16 +82,18 @@ inline void plan_layout(int P, int V, long T, PlanLayout* L) {
 }
 
 struct BuildLayout {      // workspace of the build
-  size_t keys, ids, inv, sort, scan, bytes;
+  size_t keys, rec_id, counts, sort, scan, bytes;
 };
 
-inline void build_layout(int P, int V, BuildLayout* L) {
+constexpr int kCountInts = 32 + 4;               // per-view kept counts | total | "a depth outside the key range" | -, -
+
+inline void build_layout(int P, long T, BuildLayout* L) {
   size_t off = 0;
   auto take = [&](size_t b) { size_t o = off; off += align_up(b, 256); return o; };
-  L->keys = take((size_t)P * 4);                 // sort keys of one view at a time
-  L->ids = take((size_t)P * V * 4);              // sorted ids of every view
-  L->inv = take((size_t)P * V * 4);              // rank of Gaussian id in view v's list, or -1
-  L->sort = take(ocrf::radix_sort_ids_bytes(P));
+  L->keys = take((size_t)T * 4);                 // sort key of every record (Gaussian-major): view | depth bits
+  L->rec_id = take((size_t)T * 4);               // Gaussian id of every record
+  L->counts = take((size_t)kCountInts * 4);
+  L->sort = take(ocrf::radix_sort_ids_bytes((int)T));
   L->scan = take(ocrf::exclusive_scan_bytes(P));
   L->bytes = off;
 }
@@ -111,110 +113,72 @@ inline void dyn_layout(long T, int n_sets, DynLayout* L) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// build 1: sort key of every Gaussian of ONE view: depth bits if it can ever be visible, else ~0.
+// The build, without a host read anywhere (a plan per SAMPLE — the reference recomputes the render cameras from the
+// dataloader's c2w for every sample, view_transformer_ocrf.py:1140-1152 — is five kernels + one radix sort into
+// buffers of a fixed record CAPACITY; hipGraph-capturable):
+//   1. classify       one thread per Gaussian, all views: the set of views that can ever see it (bit mask) and how
+//                     many — in front of the near plane and inside the frame for every world-space extent <= bound
+//   2. exclusive scan of the per-Gaussian counts -> the Gaussian's first record, in GAUSSIAN-MAJOR record order e
+//   3. fill records   per record: the rows of J W and the pixel centre (static per (mean, camera)), its Gaussian id and
+//                     its sort key (view << 27 | depth bits - 0x3E000000): depths in [0.125, 8191) m order by their
+//                     27 low-order-relevant bits, so ONE 32-bit key sorts every view's list at once
+//   4. stable radix sort of the keys (index_prep.hip), 4 passes.  Equal (view, depth) keep their Gaussian-major order
+//                     = ascending id: the reference's order (stable sort of duplicateWithKeys' id-ordered output,
+//                     rasterizer_impl.cu:226-267).  Records beyond the total carry the key ~0 and stay at the end.
+//   5. gather         sorted position -> (record, id, depth bits, pixel centre); header: view offsets, magic.
+// The magic word is written LAST and only if everything held: total <= capacity, every depth inside the key range,
+// no look-back scan gave up.  A plan without it is refused by every render (status bit 8).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void plan_classify_kernel(int P, int gx, int gy, int W, int H,
+constexpr unsigned kKeyBase = 0x3E000000u, kKeyDepthBits = 27, kKeyDepthMask = (1u << kKeyDepthBits) - 1u;
+
+__global__ __launch_bounds__(kBlock) void plan_classify_kernel(int P, int V, int gx, int gy, int W, int H,
                                                                const float* __restrict__ means3D,
-                                                               const Camera* __restrict__ cam_, float bound,
-                                                               unsigned* __restrict__ keys, int* __restrict__ count) {
-  const int idx = blockIdx.x * kBlock + threadIdx.x;
-  unsigned key = 0xFFFFFFFFu;
-  if (idx < P) {
-    const Camera& cam = *cam_;
+                                                               const Camera* __restrict__ cams, float bound,
+                                                               unsigned* __restrict__ g_mask, int* __restrict__ g_cnt,
+                                                               int* __restrict__ counts) {
+  const int id = blockIdx.x * kBlock + threadIdx.x;
+  const bool live = id < P;
+  const int idc = live ? id : P - 1;
+  const float px = means3D[3 * idc], py = means3D[3 * idc + 1], pz = means3D[3 * idc + 2];
+  unsigned m = 0;
+  for (int v = 0; v < V; ++v) {
+    const Camera& cam = cams[v];
     StaticPoint sp;
-    if (static_point(cam, means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2], &sp)) {
+    bool keep = false;
+    if (static_point(cam, px, py, pz, &sp)) {
       float A[2][3];
       jacobian_rows(cam, sp.j00, sp.j02, sp.j11, sp.j12, A);
       const float rb = radius_bound(A, bound);
-      const float fxp = ndc2pix(sp.projx, W), fyp = ndc2pix(sp.projy, H);
-      if (!surely_outside(fxp, fyp, rb, gx, gy)) key = __float_as_uint(sp.vz);      // vz > 0.2: bits order like the value
+      keep = live && !surely_outside(ndc2pix(sp.projx, W), ndc2pix(sp.projy, H), rb, gx, gy);
     }
-    keys[idx] = key;
+    m |= keep ? (1u << v) : 0u;
+    const unsigned long long bal = __ballot(keep);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(counts + v, __popcll(bal));
   }
-  const unsigned long long m = __ballot(key != 0xFFFFFFFFu);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, __popcll(m));
-}
-
-__global__ __launch_bounds__(kBlock) void plan_copy_ids_kernel(int n, const int* __restrict__ src, int* __restrict__ dst) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i < n) dst[i] = src[i];
-}
-
-__global__ __launch_bounds__(kBlock) void plan_fill_int_kernel(long n, int value, int* __restrict__ dst) {
-  const long i = (long)blockIdx.x * kBlock + threadIdx.x;
-  if (i < n) dst[i] = value;
-}
-
-// build 2: header (view offsets = exclusive prefix of the kept counts) + the camera block
-__global__ void plan_header_kernel(int P, int V, int H, int W, int gx, int gy, float bound, long capacity,
-                                   const int* __restrict__ counts, const float* __restrict__ cameras,
-                                   int* __restrict__ header, float* __restrict__ cams_out) {
-  if (threadIdx.x == 0) {
-    long run = 0;
-    int* view_off = header + kHeaderInts;
-    for (int v = 0; v < V; ++v) {
-      view_off[v] = (int)run;
-      run += counts[v];
-    }
-    view_off[V] = (int)run;
-    header[0] = (run <= capacity) ? (int)kPlanMagic : 0;       // a plan too small for its lists is unusable
-    header[1] = P; header[2] = V; header[3] = H; header[4] = W; header[5] = gx; header[6] = gy;
-    header[7] = __float_as_int(bound);
-    header[8] = (int)(run & 0xFFFFFFFFl); header[9] = (int)(run >> 32);
-  }
-  for (int i = threadIdx.x; i < V * 36; i += blockDim.x) cams_out[i] = cameras[i];
-}
-
-// build 3: the sorted lists (view-major) + the rank of every kept Gaussian in its view's list
-__global__ __launch_bounds__(kBlock) void plan_fill_sorted_kernel(int P, int W, int H, const float* __restrict__ means3D,
-                                                                  const Camera* __restrict__ cams,
-                                                                  const int* __restrict__ sorted_ids /*(V,P)*/,
-                                                                  const int* __restrict__ header,
-                                                                  unsigned* __restrict__ s_id, unsigned* __restrict__ s_key,
-                                                                  float2* __restrict__ s_pix, int* __restrict__ inv) {
-  if (header[0] != (int)kPlanMagic) return;
-  const int v = blockIdx.y;
-  const int* view_off = header + kHeaderInts;
-  const int off = view_off[v], n = view_off[v + 1] - off;
-  const Camera& cam = cams[v];
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const int id = sorted_ids[(long)v * P + i];
-    StaticPoint sp;
-    static_point(cam, means3D[3 * id], means3D[3 * id + 1], means3D[3 * id + 2], &sp);
-    s_id[off + i] = (unsigned)id;
-    s_key[off + i] = __float_as_uint(sp.vz);
-    s_pix[off + i] = make_float2(ndc2pix(sp.projx, W), ndc2pix(sp.projy, H));
-    inv[(long)v * P + id] = i;
+  if (live) {
+    g_mask[id] = m;
+    g_cnt[id] = __popc(m);
   }
 }
 
-// build 4: per Gaussian, the set of views that keep it and how many
-__global__ __launch_bounds__(kBlock) void plan_masks_kernel(int P, int V, const int* __restrict__ inv,
-                                                            unsigned* __restrict__ g_mask, int* __restrict__ g_cnt) {
-  const int id = blockIdx.x * kBlock + threadIdx.x;
-  if (id >= P) return;
-  unsigned m = 0;
-  for (int v = 0; v < V; ++v) m |= (inv[(long)v * P + id] >= 0) ? (1u << v) : 0u;
-  g_mask[id] = m;
-  g_cnt[id] = __popc(m);
-}
-
-// build 5 (after the exclusive scan of the counts): the records in Gaussian-major order
-__global__ __launch_bounds__(kBlock) void plan_fill_records_kernel(int P, int W, int H, const float* __restrict__ means3D,
+__global__ __launch_bounds__(kBlock) void plan_fill_records_kernel(int P, int W, int H, long cap,
+                                                                   const float* __restrict__ means3D,
                                                                    const Camera* __restrict__ cams,
-                                                                   const int* __restrict__ header,
-                                                                   const int* __restrict__ inv,
                                                                    const unsigned* __restrict__ g_mask,
                                                                    const int* __restrict__ g_off,
-                                                                   float4* __restrict__ e_q0,
-                                                                   float4* __restrict__ e_q1, unsigned* __restrict__ s_e) {
-  if (header[0] != (int)kPlanMagic) return;
+                                                                   const int* __restrict__ counts,
+                                                                   float4* __restrict__ e_q0, float4* __restrict__ e_q1,
+                                                                   unsigned* __restrict__ keys, int* __restrict__ rec_id,
+                                                                   int* __restrict__ bad) {
   const int id = blockIdx.x * kBlock + threadIdx.x;
+  const long total = counts[32];
+  // keys of the unused tail of the capacity: sorted behind every record
+  for (long e = total + (long)blockIdx.x * kBlock + threadIdx.x; e < cap; e += (long)gridDim.x * kBlock) keys[e] = 0xFFFFFFFFu;
   if (id >= P) return;
   unsigned m = g_mask[id];
-  int e = g_off[id];
-  const int* view_off = header + kHeaderInts;
+  long e = g_off[id];
   const float px = means3D[3 * id], py = means3D[3 * id + 1], pz = means3D[3 * id + 2];
+  bool out_of_range = false;
   while (m) {
     const int v = __ffs(m) - 1;
     m &= m - 1;
@@ -223,11 +187,61 @@ __global__ __launch_bounds__(kBlock) void plan_fill_records_kernel(int P, int W,
     static_point(cam, px, py, pz, &sp);
     float A[2][3];
     jacobian_rows(cam, sp.j00, sp.j02, sp.j11, sp.j12, A);
-    const unsigned pos = (unsigned)(view_off[v] + inv[(long)v * P + id]);
-    s_e[pos] = (unsigned)e;
-    e_q0[e] = make_float4(A[0][0], A[0][1], A[0][2], A[1][0]);
-    e_q1[e] = make_float4(A[1][1], A[1][2], ndc2pix(sp.projx, W), ndc2pix(sp.projy, H));
+    const unsigned bits = __float_as_uint(sp.vz);                  // vz > 0.2: bits order like the value
+    out_of_range |= !(bits >= kKeyBase && bits - kKeyBase < kKeyDepthMask);
+    if (e < cap) {
+      e_q0[e] = make_float4(A[0][0], A[0][1], A[0][2], A[1][0]);
+      e_q1[e] = make_float4(A[1][1], A[1][2], ndc2pix(sp.projx, W), ndc2pix(sp.projy, H));
+      keys[e] = ((unsigned)v << kKeyDepthBits) | ((bits - kKeyBase) & kKeyDepthMask);
+      rec_id[e] = id;
+    }
     ++e;
+  }
+  if (out_of_range) atomicOr(bad, 1);
+}
+
+// `states`: the look-back state blocks of the build's scans (n_states blocks, stride_words apart; bit 63 of a block's
+// first word = that scan gave up)
+__global__ __launch_bounds__(kBlock) void plan_gather_kernel(int P, int V, int H, int W, int gx, int gy, float bound,
+                                                             long cap, const int* __restrict__ counts,
+                                                             const float* __restrict__ cameras,
+                                                             const unsigned* __restrict__ sorted_keys,
+                                                             const int* __restrict__ sorted_e,
+                                                             const int* __restrict__ rec_id,
+                                                             const float4* __restrict__ e_q1,
+                                                             const unsigned long long* __restrict__ sort_states,
+                                                             int n_sort_states, long sort_stride,
+                                                             const unsigned long long* __restrict__ scan_state,
+                                                             int* __restrict__ header, float* __restrict__ cams_out,
+                                                             unsigned* __restrict__ s_id, unsigned* __restrict__ s_key,
+                                                             float2* __restrict__ s_pix, unsigned* __restrict__ s_e) {
+  const long total = counts[32];
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) {
+      long run = 0;
+      int* view_off = header + kHeaderInts;
+      for (int v = 0; v < V; ++v) {
+        view_off[v] = (int)run;
+        run += counts[v];
+      }
+      view_off[V] = (int)run;
+      bool ok = run == total && total <= cap && counts[33] == 0 && (scan_state[0] >> 63) == 0;
+      for (int i = 0; i < n_sort_states; ++i) ok = ok && (sort_states[i * sort_stride] >> 63) == 0;
+      header[1] = P; header[2] = V; header[3] = H; header[4] = W; header[5] = gx; header[6] = gy;
+      header[7] = __float_as_int(bound);
+      header[8] = (int)(total & 0xFFFFFFFFl); header[9] = (int)(total >> 32);
+      header[0] = ok ? (int)kPlanMagic : 0;                       // a plan that did not fit (or failed) is unusable
+    }
+    for (int i = threadIdx.x; i < V * 36; i += kBlock) cams_out[i] = cameras[i];
+  }
+  const long n = total < cap ? total : cap;
+  for (long pos = (long)blockIdx.x * kBlock + threadIdx.x; pos < n; pos += (long)gridDim.x * kBlock) {
+    const int e = sorted_e[pos];
+    const float4 q1 = e_q1[e];
+    s_e[pos] = (unsigned)e;
+    s_id[pos] = (unsigned)rec_id[e];
+    s_key[pos] = (sorted_keys[pos] & kKeyDepthMask) + kKeyBase;
+    s_pix[pos] = make_float2(q1.z, q1.w);
   }
 }
 
@@ -250,14 +264,28 @@ __global__ __launch_bounds__(kBlock) void raster_plan_update_kernel(
     const float4* __restrict__ e_q1, const int* __restrict__ view_sel, const float* __restrict__ opacities,
     const float* __restrict__ scales, float scale_modifier, const float* __restrict__ rotations,
     Rect* __restrict__ d_rect, float4* __restrict__ d_con, int* __restrict__ radii, int* __restrict__ status,
-    int* __restrict__ flag, int* __restrict__ queue) {
+    int* __restrict__ flag, int* __restrict__ queue, const unsigned* __restrict__ call_cams,
+    const unsigned* __restrict__ plan_cams) {
   __shared__ int l_v2i[32];
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     *queue = 0;                  // ticket counter of the blend that follows
     if (flag) flag[1] = 0;       // arrival counter of the armed per-call blend (rasterize.hip)
   }
-  if (header[0] != (int)kPlanMagic) {
-    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) atomicOr(status, 8);
+  if (call_cams && blockIdx.x == 0 && blockIdx.y == 0) {
+    // the plan is keyed by its cameras ON THE DEVICE: a call that means other cameras (another pose) is not rendered
+    // from this plan — status bit 4 (value 16), and the armed per-call chain (guard) takes the call over
+    bool differ = false;
+    for (int i = threadIdx.x; i < header[2] * 36; i += kBlock) differ |= call_cams[i] != plan_cams[i];
+    if (__ballot(differ) != 0ull && (threadIdx.x & 63) == 0) {
+      atomicOr(status, 16);
+      if (flag) atomicOr(flag, 1);
+    }
+  }
+  if (header[0] != (int)kPlanMagic) {      // unusable plan (capacity, key range, failed scan): the armed chain renders
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+      atomicOr(status, 8);
+      if (flag) atomicOr(flag, 1);
+    }
     return;
   }
   const int V = header[2], gx = header[5], gy = header[6];
@@ -761,95 +789,116 @@ int ocrf_diag_plan_resident(void) { return resident_blocks(raster_blend_sorted_k
 // instrumented build of the sorted blend.  Never used by the product path.
 int ocrf_diag_plan_stats(unsigned long long* buf) { g_plan_stats = buf; return 0; }
 
-size_t ocrf_raster_plan_build_workspace_bytes(int P, int n_views) {
-  if (P <= 0 || n_views <= 0 || n_views > 32) return 0;
+size_t ocrf_raster_plan_build_workspace_bytes(int P, int n_views, long capacity) {
+  if (P <= 0 || n_views <= 0 || n_views > 32 || capacity <= 0 || capacity >= (1l << 30)) return 0;
   BuildLayout L;
-  build_layout(P, n_views, &L);
+  build_layout(P, capacity, &L);
   return L.bytes;
 }
 
-int ocrf_raster_plan_classify(int P, int n_views, int H, int W, const float* means3D, const float* cameras,
-                              float extent_bound_, int* kept_counts, void* workspace, size_t workspace_bytes,
-                              ocrf_stream_t stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (P <= 0 || n_views <= 0 || n_views > 32 || H <= 0 || W <= 0 || !means3D || !cameras || !kept_counts ||
-      !workspace || !(extent_bound_ >= 0.f))
-    return (int)hipErrorInvalidValue;
-  if ((long)P * n_views >= (1l << 30)) return (int)hipErrorInvalidValue;
-  BuildLayout L;
-  build_layout(P, n_views, &L);
-  if (workspace_bytes < L.bytes) return (int)hipErrorInvalidValue;
+size_t ocrf_raster_plan_bytes(int P, int n_views, long capacity) {
+  if (P <= 0 || n_views <= 0 || n_views > 32 || capacity < 0) return 0;
+  PlanLayout L;
+  plan_layout(P, n_views, capacity, &L);
+  return L.bytes;
+}
+
+namespace {
+// steps 1 + 2 of the build; counts (device): [0, 32) per view, [32] total, [33] depth-range flag
+hipError_t plan_count(int P, int V, int H, int W, const float* means3D, const float* cameras, float bound,
+                      unsigned* g_mask, int* g_off, int* counts, void* scan_ws, size_t scan_bytes, hipStream_t stream) {
   const int gx = (W + kTileX - 1) / kTileX, gy = (H + kTileY - 1) / kTileY;
-  if (gx > 65535 || gy > 65535) return (int)hipErrorInvalidValue;
-  char* base = static_cast<char*>(workspace);
-  auto* keys = reinterpret_cast<unsigned*>(base + L.keys);
-  auto* ids = reinterpret_cast<int*>(base + L.ids);
-  hipError_t e = ocrf::zero_async(kept_counts, (size_t)n_views * 4, stream);
-  if (e != hipSuccess) return (int)e;
-  const Camera* cams = reinterpret_cast<const Camera*>(cameras);
-  const dim3 grid((P + kBlock - 1) / kBlock);
-  for (int v = 0; v < n_views; ++v) {
-    hipLaunchKernelGGL(plan_classify_kernel, grid, dim3(kBlock), 0, stream, P, gx, gy, W, H, means3D, cams + v,
-                       extent_bound_, keys, kept_counts + v);
-    const unsigned* sk = nullptr;
-    const int* si = nullptr;
-    e = ocrf::radix_sort_ids(keys, P, 32, base + L.sort, L.scan - L.sort, &sk, &si, stream);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(plan_copy_ids_kernel, grid, dim3(kBlock), 0, stream, P, si, ids + (size_t)v * P);
-  }
-  return (int)hipGetLastError();
+  hipError_t e = ocrf::zero_async(counts, (size_t)kCountInts * 4, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(plan_classify_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, P, V, gx, gy, W, H,
+                     means3D, reinterpret_cast<const Camera*>(cameras), bound, g_mask, g_off, counts);
+  return ocrf::exclusive_scan_ints(g_off, P, counts + 32, scan_ws, scan_bytes, stream);
 }
+}  // namespace
 
-size_t ocrf_raster_plan_bytes(int P, int n_views, long total_kept) {
-  if (P <= 0 || n_views <= 0 || n_views > 32 || total_kept < 0) return 0;
-  PlanLayout L;
-  plan_layout(P, n_views, total_kept, &L);
-  return L.bytes;
-}
-
-int ocrf_raster_plan_fill(int P, int n_views, int H, int W, const float* means3D, const float* cameras,
-                          float extent_bound_, const int* kept_counts, long total_kept, int max_kept,
-                          void* workspace, size_t workspace_bytes, void* plan, size_t plan_bytes,
-                          ocrf_stream_t stream_) {
+// Sizing pass: the records a plan for (means3D, cameras, extent_bound) holds.  counts (device, 33 ints): kept per view
+// in [0, n_views), their sum in [32].  workspace >= ocrf_raster_plan_build_workspace_bytes(P, n_views, 1).
+int ocrf_raster_plan_count(int P, int n_views, int H, int W, const float* means3D, const float* cameras,
+                           float extent_bound_, int* counts, void* workspace, size_t workspace_bytes,
+                           ocrf_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (P <= 0 || n_views <= 0 || n_views > 32 || H <= 0 || W <= 0 || !means3D || !cameras || !kept_counts ||
-      !workspace || !plan || total_kept < 0 || total_kept >= (1l << 30) || max_kept < 0)
+  if (P <= 0 || n_views <= 0 || n_views > 32 || H <= 0 || W <= 0 || !means3D || !cameras || !counts || !workspace ||
+      !(extent_bound_ >= 0.f) || (long)P * n_views >= (1l << 30))
+    return (int)hipErrorInvalidValue;
+  // scratch: mask | count per Gaussian, the scan's state, the count block
+  const size_t need = align_up((size_t)P * 4, 256) * 2 + ocrf::exclusive_scan_bytes(P) + align_up(kCountInts * 4, 256);
+  if (workspace_bytes < need) return (int)hipErrorInvalidValue;
+  char* base = static_cast<char*>(workspace);
+  auto* g_mask = reinterpret_cast<unsigned*>(base);
+  int* g_off = reinterpret_cast<int*>(base + align_up((size_t)P * 4, 256));
+  char* scan_ws = base + 2 * align_up((size_t)P * 4, 256);
+  int* cnt = reinterpret_cast<int*>(scan_ws + ocrf::exclusive_scan_bytes(P));
+  hipError_t e = plan_count(P, n_views, H, W, means3D, cameras, extent_bound_, g_mask, g_off, cnt, scan_ws,
+                            ocrf::exclusive_scan_bytes(P), stream);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemcpyAsync(counts, cnt, 33 * sizeof(int), hipMemcpyDeviceToDevice, stream);
+  return (int)e;
+}
+
+size_t ocrf_raster_plan_count_workspace_bytes(int P) {
+  if (P <= 0) return 0;
+  return align_up((size_t)P * 4, 256) * 2 + ocrf::exclusive_scan_bytes(P) + align_up(kCountInts * 4, 256);
+}
+
+// The build proper: no host read, kernels only (hipGraph-capturable), into a plan of `capacity` records
+// (>= ocrf_raster_plan_bytes(P, n_views, capacity) bytes).  A plan whose records do not fit is marked unusable on the
+// device (status bit 8 at render time).  `cameras` may be a different calibration on every call: a rebuild per sample.
+int ocrf_raster_plan_build(int P, int n_views, int H, int W, const float* means3D, const float* cameras,
+                           float extent_bound_, long capacity, void* workspace, size_t workspace_bytes, void* plan,
+                           size_t plan_bytes, ocrf_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (P <= 0 || n_views <= 0 || n_views > 32 || H <= 0 || W <= 0 || !means3D || !cameras || !workspace || !plan ||
+      capacity <= 0 || capacity >= (1l << 30) || !(extent_bound_ >= 0.f) || (long)P * n_views >= (1l << 30))
     return (int)hipErrorInvalidValue;
   PlanLayout L;
-  plan_layout(P, n_views, total_kept, &L);
+  plan_layout(P, n_views, capacity, &L);
   BuildLayout B;
-  build_layout(P, n_views, &B);
+  build_layout(P, capacity, &B);
   if (plan_bytes < L.bytes || workspace_bytes < B.bytes) return (int)hipErrorInvalidValue;
   const int gx = (W + kTileX - 1) / kTileX, gy = (H + kTileY - 1) / kTileY;
+  if (gx > 65535 || gy > 65535) return (int)hipErrorInvalidValue;
   char* pb = static_cast<char*>(plan);
   char* wb = static_cast<char*>(workspace);
   int* header = reinterpret_cast<int*>(pb + L.header);
-  const Camera* cams = reinterpret_cast<const Camera*>(pb + L.cams);
-  int* inv = reinterpret_cast<int*>(wb + B.inv);
   auto* g_mask = reinterpret_cast<unsigned*>(pb + L.g_mask);
   int* g_off = reinterpret_cast<int*>(pb + L.g_off);
-  hipLaunchKernelGGL(plan_header_kernel, dim3(1), dim3(256), 0, stream, P, n_views, H, W, gx, gy, extent_bound_,
-                     total_kept, kept_counts, cameras, header, reinterpret_cast<float*>(pb + L.cams));
-  const long n_inv = (long)P * n_views;
-  hipLaunchKernelGGL(plan_fill_int_kernel, dim3((unsigned)((n_inv + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
-                     n_inv, -1, inv);
-  if (max_kept > 0) {
-    const dim3 grid((max_kept + kBlock - 1) / kBlock, n_views);
-    hipLaunchKernelGGL(plan_fill_sorted_kernel, grid, dim3(kBlock), 0, stream, P, W, H, means3D, cams,
-                       reinterpret_cast<const int*>(wb + B.ids), static_cast<const int*>(header),
-                       reinterpret_cast<unsigned*>(pb + L.s_id), reinterpret_cast<unsigned*>(pb + L.s_key),
-                       reinterpret_cast<float2*>(pb + L.s_pix), inv);
-  }
-  const dim3 pgrid((P + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(plan_masks_kernel, pgrid, dim3(kBlock), 0, stream, P, n_views, static_cast<const int*>(inv), g_mask,
-                     g_off);
-  hipError_t e = ocrf::exclusive_scan_ints(g_off, P, nullptr, wb + B.scan, B.bytes - B.scan, stream);
+  auto* e_q0 = reinterpret_cast<float4*>(pb + L.e_q0);
+  auto* e_q1 = reinterpret_cast<float4*>(pb + L.e_q1);
+  auto* keys = reinterpret_cast<unsigned*>(wb + B.keys);
+  int* rec_id = reinterpret_cast<int*>(wb + B.rec_id);
+  int* counts = reinterpret_cast<int*>(wb + B.counts);
+  const Camera* cams = reinterpret_cast<const Camera*>(cameras);
+  // the magic word falls first: a render that races a failed or interrupted rebuild sees an unusable plan
+  hipError_t e = ocrf::zero_async(header, 4, stream);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(plan_fill_records_kernel, pgrid, dim3(kBlock), 0, stream, P, W, H, means3D, cams,
-                     static_cast<const int*>(header), static_cast<const int*>(inv),
+  e = plan_count(P, n_views, H, W, means3D, cameras, extent_bound_, g_mask, g_off, counts, wb + B.scan, B.bytes - B.scan,
+                 stream);
+  if (e != hipSuccess) return (int)e;
+  const dim3 pgrid((P + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(plan_fill_records_kernel, pgrid, dim3(kBlock), 0, stream, P, W, H, capacity, means3D, cams,
                      static_cast<const unsigned*>(g_mask), static_cast<const int*>(g_off),
-                     reinterpret_cast<float4*>(pb + L.e_q0),
-                     reinterpret_cast<float4*>(pb + L.e_q1), reinterpret_cast<unsigned*>(pb + L.s_e));
+                     static_cast<const int*>(counts), e_q0, e_q1, keys, rec_id, counts + 33);
+  const unsigned* sk = nullptr;
+  const int* se = nullptr;
+  e = ocrf::radix_sort_ids(keys, (int)capacity, 32, wb + B.sort, B.scan - B.sort, &sk, &se, stream);
+  if (e != hipSuccess) return (int)e;
+  const unsigned long long* sort_states = nullptr;
+  int n_states = 0;
+  long stride = 0;
+  ocrf::radix_sort_states(wb + B.sort, (int)capacity, 32, &sort_states, &n_states, &stride);
+  const unsigned ggrid = (unsigned)std::min<long>((capacity + kBlock - 1) / kBlock, 4096);
+  hipLaunchKernelGGL(plan_gather_kernel, dim3(ggrid), dim3(kBlock), 0, stream, P, n_views, H, W, gx, gy, extent_bound_,
+                     capacity, static_cast<const int*>(counts), cameras, sk, se, static_cast<const int*>(rec_id),
+                     static_cast<const float4*>(e_q1), sort_states, n_states, stride,
+                     reinterpret_cast<const unsigned long long*>(wb + B.scan), header,
+                     reinterpret_cast<float*>(pb + L.cams), reinterpret_cast<unsigned*>(pb + L.s_id),
+                     reinterpret_cast<unsigned*>(pb + L.s_key), reinterpret_cast<float2*>(pb + L.s_pix),
+                     reinterpret_cast<unsigned*>(pb + L.s_e));
   return (int)hipGetLastError();
 }
 
@@ -866,7 +915,8 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
                            const float* bg, int depth_mode, float* out_color, float* out_depth, float* out_final_T,
                            int* radii, int* status, void* workspace, size_t workspace_bytes, int guard,
                            const float* means3D, void* chain_workspace, size_t chain_workspace_bytes,
-                           int blend_workgroups, const int* yield_if, int phase, ocrf_stream_t stream_) {
+                           int blend_workgroups, const int* yield_if, int phase, const float* call_cameras,
+                           ocrf_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (!plan || P <= 0 || n_plan_views <= 0 || n_plan_views > 32 || total_kept < 0 || total_kept >= (1l << 30) ||
       H <= 0 || W <= 0 || n_sets <= 0 || n_items <= 0 || n_items % n_sets || blend_workgroups < 0 || phase < 0 ||
@@ -909,7 +959,8 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
                dim3(kBlock), (size_t)g_update_lds, stream, P, vps, total_kept, header, reinterpret_cast<const unsigned*>(pb + L.g_mask),
                reinterpret_cast<const int*>(pb + L.g_off),
                reinterpret_cast<const float4*>(pb + L.e_q0), reinterpret_cast<const float4*>(pb + L.e_q1), item_view,
-               opacities, scales, scale_modifier, rotations, d_rect, d_con, radii, status, flag, queue);
+               opacities, scales, scale_modifier, rotations, d_rect, d_con, radii, status, flag, queue,
+               reinterpret_cast<const unsigned*>(call_cameras), reinterpret_cast<const unsigned*>(cams));
   }   // phase != 2
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
@@ -951,7 +1002,8 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
     // side stream beside the blend the four launches do not get cheaper — their workgroups wait for the persistent
     // blend's slots — so they stay in the caller's stream)
     return ocrf::raster_forward_chain(P, n_sets, vps, H, W, means3D, colors, opacities, scales, scale_modifier,
-                                      rotations, nullptr, reinterpret_cast<const float*>(cams), item_view, bg,
+                                      rotations, nullptr, call_cameras ? call_cameras : reinterpret_cast<const float*>(cams),
+                                      item_view, bg,
                                       depth_mode, out_color, out_depth, out_final_T, nullptr, radii, nullptr, nullptr,
                                       chain_workspace, chain_workspace_bytes, flag, true, true, stream);
   }

@@ -10,7 +10,8 @@ cameras are fixed per calibration; only the S/R/A/C heads' outputs change per st
 The static cull is valid for Gaussians whose world-space extent ``scale_modifier * max|s| * |R(q)|_2`` stays within
 ``extent_bound``.  ``guard='device'`` arms the per-call pipeline behind the planned one on the GPU (exact whatever
 the parameters do, graph-capturable); ``guard='host'`` only raises status bit 4, which ``check()`` turns into an
-exception — the caller decides when to pay that synchronisation.
+exception — the caller decides when to pay that synchronisation.  A plan is also keyed by its cameras on the device:
+a call that passes the cameras it means (``render(cameras=...)``) is checked against the plan's there.
 """
 import ctypes
 
@@ -33,16 +34,21 @@ class RasterPlan:
     """Plan for ``means3D`` (P,3) seen by the ``V`` cameras of ``packed_cameras`` (V,36; ``pack_cameras``).
 
     ``extent_bound``: a float, or None to take ``margin`` x the extent of the example ``scales`` / ``rotations``.
-    Building synchronises once (the kept counts size the plan)."""
+    ``capacity``: records (kept (Gaussian, view) pairs) the plan's buffers hold; None = one synchronising count of
+    what these cameras keep, times ``headroom`` (poses of later ``rebuild`` calls keep a few per cent more or fewer).
+    The build itself (``rebuild``) never reads anything back: ~ 20 launches, hipGraph-capturable — the reference
+    recomputes the render cameras from the dataloader's ``c2w`` for EVERY sample
+    (``view_transformer_ocrf.py:1140-1152``), so a plan per sample is a supported mode, not only a plan per
+    calibration."""
 
     def __init__(self, means3D, packed_cameras, image_height, image_width, extent_bound=None, scales=None,
-                 rotations=None, scale_modifier=1.0, margin=2.0):
+                 rotations=None, scale_modifier=1.0, margin=2.0, capacity=None, headroom=1.25):
         _lib.require_cuda(means3D, packed_cameras)
         if means3D.dim() != 2 or means3D.size(1) != 3:
             raise RuntimeError('means3D must have dimensions (num_points, 3)')
         self.device = dev = means3D.device
         self.means3D = _f32c(means3D)
-        self.cameras = _f32c(packed_cameras).reshape(-1, 36)
+        self.cameras = _f32c(packed_cameras).reshape(-1, 36).clone()      # owned: ``rebuild`` overwrites it in place
         self.P, self.V = int(self.means3D.size(0)), int(self.cameras.size(0))
         self.H, self.W = int(image_height), int(image_width)
         if self.P == 0 or self.V == 0 or self.V > 32:
@@ -53,30 +59,63 @@ class RasterPlan:
             extent_bound = float(margin) * float(extent_of(scales, rotations, scale_modifier))
         self.extent_bound = float(extent_bound)
         L = _lib.lib()
+        self.kept = None                       # per-view counts of the sizing pass (None when a capacity was given)
+        if capacity is None:
+            self.kept = self.count()                               # the one synchronisation
+            capacity = int(sum(self.kept) * float(headroom)) + 1024
+        self.capacity = max(1, min(int(capacity), self.P * self.V))
+        self.total_kept = self.capacity        # (name kept for the tools: strides and scratch sizes follow the capacity)
         with _lib.on_device(dev):
-            ws = torch.empty(L.ocrf_raster_plan_build_workspace_bytes(self.P, self.V), dtype=torch.uint8, device=dev)
-            counts = torch.empty(self.V, dtype=torch.int32, device=dev)
-            _lib.check(L.ocrf_raster_plan_classify(
-                self.P, self.V, self.H, self.W, _lib.ptr(self.means3D), _lib.ptr(self.cameras),
-                ctypes.c_float(self.extent_bound), _lib.ptr(counts), _lib.ptr(ws), ctypes.c_size_t(ws.numel()),
-                _lib.stream_ptr(dev)), 'ocrf_raster_plan_classify')
-            host = counts.cpu()                                  # the build's one synchronisation
-            self.kept = [int(v) for v in host]
-            self.total_kept, self.max_kept = sum(self.kept), max(self.kept)
-            self.plan = torch.empty(max(int(L.ocrf_raster_plan_bytes(self.P, self.V, self.total_kept)), 256),
+            self._build_ws = torch.empty(int(L.ocrf_raster_plan_build_workspace_bytes(self.P, self.V, self.capacity)),
+                                         dtype=torch.uint8, device=dev)
+            self.plan = torch.empty(max(int(L.ocrf_raster_plan_bytes(self.P, self.V, self.capacity)), 256),
                                     dtype=torch.uint8, device=dev)
-            _lib.check(L.ocrf_raster_plan_fill(
-                self.P, self.V, self.H, self.W, _lib.ptr(self.means3D), _lib.ptr(self.cameras),
-                ctypes.c_float(self.extent_bound), _lib.ptr(counts), ctypes.c_long(self.total_kept), self.max_kept,
-                _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.ptr(self.plan), ctypes.c_size_t(self.plan.numel()),
-                _lib.stream_ptr(dev)), 'ocrf_raster_plan_fill')
-        # sticky status word (bit 4: extent bound exceeded in some call, bit 8: bad view index / unusable plan)
+        # sticky status word (bit 4: extent bound exceeded in some call, bit 8: bad view index / unusable plan,
+        # bit 16: a call's cameras were not the plan's)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         self._dyn = None                       # per-call scratch, owned by the plan (one stream at a time)
         self._chain_ws = None
+        self._host_guarded = False             # a render with guard='host' happened since the last check()
+        self.rebuild()
+
+    def count(self, packed_cameras=None):
+        """Synchronising: kept (Gaussian, view) records per view for ``packed_cameras`` (default: the plan's)."""
+        L = _lib.lib()
+        cams = self.cameras if packed_cameras is None else _f32c(packed_cameras).reshape(-1, 36)
+        with _lib.on_device(self.device):
+            ws = torch.empty(int(L.ocrf_raster_plan_count_workspace_bytes(self.P)), dtype=torch.uint8, device=self.device)
+            counts = torch.empty(33, dtype=torch.int32, device=self.device)
+            _lib.check(L.ocrf_raster_plan_count(self.P, self.V, self.H, self.W, _lib.ptr(self.means3D), _lib.ptr(cams),
+                                                ctypes.c_float(self.extent_bound), _lib.ptr(counts), _lib.ptr(ws),
+                                                ctypes.c_size_t(ws.numel()), _lib.stream_ptr(self.device)),
+                       'ocrf_raster_plan_count')
+        return [int(v) for v in counts[:self.V].cpu()]
+
+    @torch.no_grad()
+    def rebuild(self, packed_cameras=None, means3D=None):
+        """(Re)build the plan on the current stream for new cameras (same count) and / or means — no host read, no
+        allocation, kernels only.  A plan that does not fit the capacity is marked unusable on the device: renders of
+        it raise status bit 8 (``check()``), with ``guard='device'`` they are taken over by the per-call pipeline."""
+        if packed_cameras is not None:
+            cams = _f32c(packed_cameras).reshape(-1, 36)
+            if cams.shape != self.cameras.shape:
+                raise _lib.OcrfHipError('rebuild: the camera count of a plan is fixed')
+            self.cameras.copy_(cams, non_blocking=True)
+        if means3D is not None:
+            if means3D.shape != self.means3D.shape:
+                raise _lib.OcrfHipError('rebuild: the Gaussian count of a plan is fixed')
+            self.means3D.copy_(_f32c(means3D), non_blocking=True)
+        L = _lib.lib()
+        with _lib.on_device(self.device):
+            _lib.check(L.ocrf_raster_plan_build(
+                self.P, self.V, self.H, self.W, _lib.ptr(self.means3D), _lib.ptr(self.cameras),
+                ctypes.c_float(self.extent_bound), ctypes.c_long(self.capacity), _lib.ptr(self._build_ws),
+                ctypes.c_size_t(self._build_ws.numel()), _lib.ptr(self.plan), ctypes.c_size_t(self.plan.numel()),
+                _lib.stream_ptr(self.device)), 'ocrf_raster_plan_build')
+        return self
 
     def _scratch(self, n_sets):
-        need = _lib.lib().ocrf_rasterize_planned_workspace_bytes(ctypes.c_long(self.total_kept), n_sets)
+        need = _lib.lib().ocrf_rasterize_planned_workspace_bytes(ctypes.c_long(self.capacity), n_sets)
         if self._dyn is None or self._dyn.numel() < need:
             # zero-filled: the guard flag lives in it between calls (include/ocrf_hip.h, ocrf_rasterize_planned)
             self._dyn = torch.zeros(max(int(need), 256), dtype=torch.uint8, device=self.device)
@@ -85,7 +124,7 @@ class RasterPlan:
     @torch.no_grad()
     def render(self, colors, opacities, scales, rotations, bg, scale_modifier=1.0, depth_mode='median',
                item_view=None, want_radii=False, guard='host', out=None, blend_workgroups=0, phase='both',
-               yield_if=None):
+               yield_if=None, cameras=None):
         """Render ``n_items = len(item_view)`` views: item z = plan view ``item_view[z]`` (int32 device tensor) with
         Gaussian set ``z // (n_items // S)`` of the ``(S, P, .)`` (or ``(P, .)``) parameter tensors; without
         ``item_view`` every set renders all ``V`` plan views in order.
@@ -95,7 +134,10 @@ class RasterPlan:
         ``yield_if``: int32 device word — with it the blend takes every slot of the device and the workgroups beyond
         ``blend_workgroups`` leave at once while the word is non-zero (a scheduling hint: same image either way).
         ``phase``: 'both', or 'update' then (same arguments, same ``out``) 'blend' — possibly on another stream, ordered by
-        the caller's events (``guard='host'`` only)."""
+        the caller's events (``guard='host'`` only).
+        ``cameras``: the (V,36) packed cameras this call means to render with (what the reference's ``render`` gets per
+        call).  Compared with the plan's on the device: a difference raises status bit 16 and, with
+        ``guard='device'``, the call is rendered by the per-call pipeline with these cameras instead."""
         _lib.require_cuda(colors, opacities, scales, rotations, bg)
         dev, P = self.device, self.P
         colors, sc, rot = _f32c(colors), _f32c(scales), _f32c(rotations)
@@ -122,6 +164,12 @@ class RasterPlan:
             out = dict(color=torch.empty(n_items, 3, H, W, device=dev), depth=torch.empty(n_items, 1, H, W, device=dev),
                        final_T=torch.empty(n_items, H, W, device=dev))
         use_guard = {'host': 0, 'device': 1}[guard]
+        self._host_guarded = self._host_guarded or not use_guard
+        if cameras is not None:
+            _lib.require_cuda(cameras)
+            cameras = _f32c(cameras).reshape(-1, 36)
+            if cameras.shape != self.cameras.shape:
+                raise _lib.OcrfHipError('cameras must be the plan\'s (V, 36) block')
         radii = None
         if want_radii or use_guard:
             radii = out.get('radii')
@@ -137,37 +185,46 @@ class RasterPlan:
                     self._chain_ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
                 chain = self._chain_ws
             _lib.check(L.ocrf_rasterize_planned(
-                _lib.ptr(self.plan), ctypes.c_size_t(self.plan.numel()), P, self.V, ctypes.c_long(self.total_kept),
+                _lib.ptr(self.plan), ctypes.c_size_t(self.plan.numel()), P, self.V, ctypes.c_long(self.capacity),
                 H, W, S, n_items, _lib.ptr(item_view), _lib.ptr(colors), _lib.ptr(opac), _lib.ptr(sc),
                 ctypes.c_float(scale_modifier), _lib.ptr(rot), _lib.ptr(bg), {'median': 0, 'mean': 1}[depth_mode],
                 _lib.ptr(out['color']), _lib.ptr(out['depth']), _lib.ptr(out['final_T']), _lib.ptr(radii),
                 _lib.ptr(self.status), _lib.ptr(dyn), ctypes.c_size_t(dyn.numel()), use_guard,
                 _lib.ptr(self.means3D), _lib.ptr(chain), ctypes.c_size_t(chain.numel() if chain is not None else 0),
                 int(blend_workgroups), _lib.ptr(yield_if), {'both': 0, 'update': 1, 'blend': 2}[phase],
-                _lib.stream_ptr(dev)),
+                _lib.ptr(cameras), _lib.stream_ptr(dev)),
                 'ocrf_rasterize_planned')
         out['status'] = self.status
         return out
 
-    def check(self):
-        """Synchronising read of the sticky status word: raises if any render since the last ``check`` ran with a
-        Gaussian beyond ``extent_bound`` (``guard='host'`` renders of such a call are invalid) or with a bad view
-        index.  Clears the word."""
+    def _read_status(self):
         st = int(self.status.item())
         self.status.zero_()
+        host_guarded, self._host_guarded = self._host_guarded, False
         if st & 8:
-            raise _lib.OcrfHipError('RasterPlan: a render used a view index outside the plan (or the plan is unusable)')
-        if st & 4:
+            raise _lib.OcrfHipError('RasterPlan: a render used a view index outside the plan, or the plan is unusable '
+                                    '(its records exceeded the capacity, a view-space depth lay outside [0.125, 8191) m, '
+                                    'or a scan of the build gave up): rebuild with a larger capacity')
+        return st, host_guarded
+
+    def check(self):
+        """Synchronising read of the sticky status word: raises if a render since the last ``check`` was NOT valid — a
+        Gaussian beyond ``extent_bound`` or cameras other than the plan's in a call with ``guard='host'``, a bad view
+        index, an unusable plan.  The same events in calls with ``guard='device'`` were rendered exactly by the per-call
+        pipeline: informational (``exceeded()``).  Clears the word."""
+        st, host_guarded = self._read_status()
+        if (st & 4) and host_guarded:
             raise _lib.OcrfHipError(
                 f'RasterPlan: a Gaussian exceeded the plan\'s extent bound {self.extent_bound:g} — renders with '
                 "guard='host' since the last check are invalid; rebuild the plan with a larger bound or render with "
                 "guard='device'")
+        if (st & 16) and host_guarded:
+            raise _lib.OcrfHipError("RasterPlan: a call's cameras were not the plan's — renders with guard='host' since the "
+                                    "last check show the PLAN's pose; rebuild(cameras) first or render with guard='device'")
         return True
 
     def exceeded(self):
-        """Like ``check`` but returns whether the extent bound was exceeded instead of raising for it."""
-        st = int(self.status.item())
-        self.status.zero_()
-        if st & 8:
-            raise _lib.OcrfHipError('RasterPlan: a render used a view index outside the plan (or the plan is unusable)')
-        return bool(st & 4)
+        """Like ``check`` but returns whether the extent bound was exceeded (or a call's cameras differed) instead of
+        raising for it."""
+        st, _ = self._read_status()
+        return bool(st & (4 | 16))

@@ -264,4 +264,88 @@ def test_full_size_ocrf_grid_both_conventions(cuda):
         torch.cuda.synchronize()
         assert plan.check()
         _same(want, got, ('color', 'depth', 'final_T', 'radii'))
-        assert plan.total_kept < 0.5 * xyz.shape[0] * 6
+        assert sum(plan.kept) < 0.5 * xyz.shape[0] * 6
+
+
+def test_rebuild_for_another_pose_without_a_host_read(cuda):
+    """A plan per SAMPLE (the reference builds the render cameras from the dataloader's c2w per sample,
+    view_transformer_ocrf.py:1140-1152): ``rebuild(cameras)`` between two renders gives the per-call image of the new
+    pose bit for bit — enqueued while the device is still busy and captured into a hipGraph, i.e. without any host read
+    or allocation inside — and a rebuild back gives the first pose's image again."""
+    rng = np.random.default_rng(21)
+    W, H = 176, 96
+    xyz, rgb, opac, sc, rot = _scene(rng, 20000, cuda)
+    bg = torch.tensor([0.0, 0.1, 0.2], device=cuda)
+    poses = [[(0, 0, 0), (1.5, -0.5, 2.0)], [(0.4, 0.1, -0.3), (1.1, -0.2, 2.6)], [(-0.8, 0.0, 0.5), (2.0, 0.3, 1.0)]]
+    cams = [_cams(cuda, W, H, p) for p in poses]
+    want = [dgr.rasterize_views(xyz, rgb, opac, sc, rot, None, None, None, None, H, W, bg, packed_cameras=c,
+                                want_n_contrib=False) for c in cams]
+    plan = rp.RasterPlan(xyz, cams[0], H, W, scales=sc, rotations=rot, headroom=1.5)
+    _same(want[0], plan.render(rgb, opac, sc, rot, bg, want_radii=True), ('color', 'depth', 'final_T', 'radii'))
+    for k in (1, 2, 0, 2):
+        plan.rebuild(cams[k])
+        got = plan.render(rgb, opac, sc, rot, bg, want_radii=True, cameras=cams[k])
+        _same(want[k], got, ('color', 'depth', 'final_T', 'radii'))
+    assert plan.check()
+    # captured: rebuild + render as one hipGraph on a side stream, replayed for two poses through a static camera block
+    static_cams = cams[1].clone()
+    out = plan.render(rgb, opac, sc, rot, bg)
+    side = torch.cuda.Stream(cuda)
+    side.wait_stream(torch.cuda.current_stream(cuda))
+    with torch.cuda.stream(side):
+        plan.rebuild(static_cams)
+        plan.render(rgb, opac, sc, rot, bg, out=out)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            plan.rebuild(static_cams)
+            plan.render(rgb, opac, sc, rot, bg, out=out, cameras=static_cams)
+    torch.cuda.current_stream(cuda).wait_stream(side)
+    for k in (2, 1, 0):
+        static_cams.copy_(cams[k])
+        g.replay()
+        _same(want[k], out)
+    torch.cuda.synchronize()
+    assert plan.check()
+
+
+def test_a_plan_is_keyed_by_its_cameras_on_the_device(cuda):
+    """``render(cameras=...)`` with cameras that are not the plan's: status bit 16; with ``guard='device'`` the per-call
+    pipeline renders the call with THOSE cameras (exact), with ``guard='host'`` ``check()`` raises."""
+    rng = np.random.default_rng(22)
+    W, H = 128, 96
+    xyz, rgb, opac, sc, rot = _scene(rng, 8000, cuda)
+    bg = torch.zeros(3, device=cuda)
+    a, b = _cams(cuda, W, H, [(0, 0, 0), (2.0, 0.0, 0.0)]), _cams(cuda, W, H, [(0.3, 0.1, 0.0), (2.0, 0.0, 0.4)])
+    want_b = dgr.rasterize_views(xyz, rgb, opac, sc, rot, None, None, None, None, H, W, bg, packed_cameras=b,
+                                 want_n_contrib=False)
+    want_a = dgr.rasterize_views(xyz, rgb, opac, sc, rot, None, None, None, None, H, W, bg, packed_cameras=a,
+                                 want_n_contrib=False)
+    plan = rp.RasterPlan(xyz, a, H, W, scales=sc, rotations=rot)
+    _same(want_a, plan.render(rgb, opac, sc, rot, bg, guard='device', cameras=a), ('color', 'depth', 'final_T', 'radii'))
+    assert not plan.exceeded()
+    got = plan.render(rgb, opac, sc, rot, bg, guard='device', cameras=b)       # a stale plan: the call is still exact
+    _same(want_b, got, ('color', 'depth', 'final_T', 'radii'))
+    assert plan.check()                                                         # ... and that is not an error
+    _same(want_a, plan.render(rgb, opac, sc, rot, bg, guard='device', cameras=a), ('color', 'depth', 'final_T', 'radii'))
+    plan.render(rgb, opac, sc, rot, bg, cameras=b)                              # host guard: flagged, check() raises
+    with pytest.raises(Exception, match='cameras'):
+        plan.check()
+
+
+def test_a_plan_beyond_its_capacity_is_refused_on_the_device(cuda):
+    rng = np.random.default_rng(23)
+    W, H = 128, 96
+    xyz, rgb, opac, sc, rot = _scene(rng, 8000, cuda)
+    bg = torch.zeros(3, device=cuda)
+    cams = _cams(cuda, W, H, [(0, 0, 0), (2.0, 0.0, 0.0)])
+    full = rp.RasterPlan(xyz, cams, H, W, scales=sc, rotations=rot)
+    need = sum(full.kept)
+    small = rp.RasterPlan(xyz, cams, H, W, scales=sc, rotations=rot, capacity=need // 2)
+    want = dgr.rasterize_views(xyz, rgb, opac, sc, rot, None, None, None, None, H, W, bg, packed_cameras=cams,
+                               want_n_contrib=False)
+    small.render(rgb, opac, sc, rot, bg)
+    with pytest.raises(Exception, match='capacity'):
+        small.check()
+    exact = rp.RasterPlan(xyz, cams, H, W, scales=sc, rotations=rot, capacity=need)      # not one record to spare
+    _same(want, exact.render(rgb, opac, sc, rot, bg))
+    assert exact.check()

@@ -39,7 +39,7 @@ def dyn():
 
 
 plan = raster_plan.RasterPlan(xyz, rc['packed'], H, W, scales=g['scales'], rotations=g['rotations'], margin=a.margin)
-print('plan: kept per view', plan.kept, 'of', plan.P, 'total', plan.total_kept, 'bound', plan.extent_bound)
+print('plan: kept per view', plan.kept, 'of', plan.P, 'total', sum(plan.kept), 'capacity', plan.capacity, 'bound', plan.extent_bound)
 
 
 def planned():
