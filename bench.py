@@ -636,6 +636,64 @@ def main():
             hp3.step(depth, feat)
         per_step_devgeom_ms = 1e3 * timed(lambda: hp3.step(depth, feat), n2, world, dev) / n2
         del hp3
+    # ---- the step of a sample whose POSE is new too: nothing calibration- or pose-dependent cached.  Two ways to render
+    # such a sample: (a) the per-call pipeline (preprocess + depth buckets + in-LDS sort, no plan at all); (b) the render
+    # plan rebuilt on the device inside the step.  Both without a host read anywhere; `per_sample_ms` is the faster. ------
+    per_sample = None
+    if shard in ('none', 'samples') and cfg.render and not args.no_per_step:
+        n2 = max(5, min(args.steps, 50))
+
+        def variant(**kw):
+            h = hotpath.HotPath(cfg, dev, index_prep_mode='per_step', overlap=not args.no_overlap, device_geometry=True,
+                                render_guard=args.render_guard, **kw)
+            for _ in range(3):
+                h.step(depth, feat)
+            res = {'eager_ms': 1e3 * timed(lambda: h.step(depth, feat), n2, world, dev) / n2}
+            h.check_render_plans()
+            # the same step replayed as ONE hipGraph (nothing in it reads back or allocates)
+            try:
+                cap_stream = torch.cuda.Stream(dev)
+                cap_stream.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(cap_stream):
+                    for _ in range(2):
+                        h.step(depth, feat)
+                torch.cuda.current_stream(dev).wait_stream(cap_stream)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out_g = h.step(depth, feat)
+                torch.cuda.synchronize()
+                for _ in range(3):
+                    graph.replay()
+                res['graph_ms'] = 1e3 * timed(graph.replay, n2, world, dev) / n2
+                ref = h.step(depth, feat)
+                torch.cuda.synchronize()
+                res['graph_outputs_equal_eager'] = bool(torch.equal(ref[0], out_g[0]) and
+                                                        torch.equal(ref[2][0]['color'], out_g[2][0]['color']))
+                h.check_render_plans()
+                del graph, out_g, ref
+            except Exception as e:       # noqa: BLE001
+                res['graph_ms'], res['graph_outputs_equal_eager'] = None, f'{type(e).__name__}: {e}'[:200]
+            return h, res
+
+        h_pc, r_pc = variant(render_mode='per_call')
+        del h_pc
+        per_sample = {'per_call_render': r_pc}
+        if planned:
+            h_pl, r_pl = variant(render_mode='planned', plan_rebuild='per_step')
+            plans4 = h_pl._plans()
+
+            def rebuild_all():
+                for entry in plans4:
+                    entry[0].rebuild(entry[3]['cams'])
+            for _ in range(3):
+                rebuild_all()
+            r_pl['render_plan_build_ms'] = 1e3 * timed(rebuild_all, n2, world, dev) / n2
+            r_pl['plan_records'] = {'kept': [int(sum(e[0].kept)) if e[0].kept else None for e in plans4],
+                                    'capacity': [int(e[0].capacity) for e in plans4], 'views': [int(e[0].V) for e in plans4]}
+            per_sample['plan_rebuilt_per_step'] = r_pl
+            del h_pl, plans4
+        per_sample['per_sample_ms'] = min(x for r in list(per_sample.values()) for x in (r['eager_ms'], r.get('graph_ms')) if x)
     # ---- weak-scaling secondary of the sharded default: every rank a whole sample ---------------------------
     samples_layout = None
     if shard == 'camera_frames':
@@ -759,7 +817,24 @@ def main():
             'ms_per_step_blocks': {'n': len(blocks), 'median': 1e3 * elapsed / args.steps,
                                    'min': 1e3 * min(blocks) / args.steps, 'max': 1e3 * max(blocks) / args.steps},
             'per_step_ms': per_step_ms,
-            'per_step_device_geometry_ms': per_step_devgeom_ms, 'higher_is_better': True,
+            'per_step_device_geometry_ms': per_step_devgeom_ms,
+            # a sample with a NEW POSE (the reference's only working mode: cameras per sample, accelerate=False): rank
+            # vectors by the device index preparation, renders per call or from a plan rebuilt on the device, every step
+            'per_sample_ms': per_sample['per_sample_ms'] if per_sample else None,
+            'render_plan_build_ms': (per_sample.get('plan_rebuilt_per_step', {}).get('render_plan_build_ms')
+                                     if per_sample else None),
+            'per_sample': (None if per_sample is None else {
+                **per_sample,
+                'what': 'HotPath(index_prep_mode="per_step", device_geometry=True, ...).step: nothing calibration- or '
+                        'pose-dependent is cached and nothing is read back; per_call_render = preprocess + depth buckets + '
+                        'in-LDS sort every render (no plan); plan_rebuilt_per_step = RasterPlan.rebuild (classify -> scan -> '
+                        'records -> one radix sort -> gather) + update + sorted blend; graph_ms = the same step captured once '
+                        'and replayed as one hipGraph; per_sample_ms = the fastest of the four',
+                'amortisation': 'ms_per_step (headline) builds plan and rank vectors once per calibration; '
+                                'per_sample_ms - ms_per_step is what a per-sample calibration adds; a plan pays off after '
+                                'render_plan_build_ms / (per-call - planned render time) renders of one pose',
+                'reference': 'view_transformer_ocrf.py:1140-1152, detectors/ocrfdet.py:215-223'}),
+            'higher_is_better': True,
             **({'sharding_fallback': 'camera_frames -> samples: ' + shard_error} if shard_error else {}),
             'scaling': 'strong' if strong else 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',

@@ -213,8 +213,8 @@ size_t ocrf_rasterize_workspace_bytes(int P, int n_views);
  * reference obtains by sorting every step (rasterizer_impl.cu:226-267) — is computed ONCE:
  *
  *   1. ocrf_raster_plan_count     (sizing, optional) how many (Gaussian, view) records a plan for these cameras keeps:
- *      counts (device, 33 ints) = kept per view in [0, n_views), their sum in [32].  The caller reads the sum once
- *      and chooses a record CAPACITY (with headroom if the plan will be rebuilt for other poses).
+ *      g_mask (device, P words; bit v = view v keeps the Gaussian) and their number in *total (device).  The caller
+ *      reads the total once and chooses a record CAPACITY (with headroom if the plan will be rebuilt for other poses).
  *   2. ocrf_raster_plan_build     writes the plan (device, >= ocrf_raster_plan_bytes(P, n_views, capacity) bytes,
  *      256-byte aligned): header, cameras; per view the kept records in blend order (id, depth bits, pixel centre);
  *      per Gaussian the views that keep it (never visible = behind the near plane, or outside the frame for every
@@ -271,8 +271,8 @@ size_t ocrf_rasterize_workspace_bytes(int P, int n_views);
  */
 size_t ocrf_raster_plan_count_workspace_bytes(int P);
 int ocrf_raster_plan_count(int P, int n_views, int H, int W, const float *means3D, const float *cameras,
-                           float extent_bound, int *counts, void *workspace, size_t workspace_bytes,
-                           ocrf_stream_t stream);
+                           float extent_bound, unsigned *g_mask, int *total, void *workspace,
+                           size_t workspace_bytes, ocrf_stream_t stream);
 size_t ocrf_raster_plan_build_workspace_bytes(int P, int n_views, long capacity);
 size_t ocrf_raster_plan_bytes(int P, int n_views, long capacity);
 int ocrf_raster_plan_build(int P, int n_views, int H, int W, const float *means3D, const float *cameras,

@@ -108,7 +108,7 @@ def _declare(L):
     L.ocrf_raster_plan_count_workspace_bytes.restype = c_size_t
     L.ocrf_raster_plan_count_workspace_bytes.argtypes = [c_int]
     L.ocrf_raster_plan_count.restype = c_int
-    L.ocrf_raster_plan_count.argtypes = [c_int] * 4 + [c_void_p] * 2 + [c_float] + [c_void_p] * 2 + [c_size_t, c_void_p]
+    L.ocrf_raster_plan_count.argtypes = [c_int] * 4 + [c_void_p] * 2 + [c_float] + [c_void_p] * 3 + [c_size_t, c_void_p]
     L.ocrf_raster_plan_build_workspace_bytes.restype = c_size_t
     L.ocrf_raster_plan_build_workspace_bytes.argtypes = [c_int, c_int, c_long]
     L.ocrf_raster_plan_bytes.restype = c_size_t

@@ -134,8 +134,7 @@ constexpr unsigned kKeyBase = 0x3E000000u, kKeyDepthBits = 27, kKeyDepthMask = (
 __global__ __launch_bounds__(kBlock) void plan_classify_kernel(int P, int V, int gx, int gy, int W, int H,
                                                                const float* __restrict__ means3D,
                                                                const Camera* __restrict__ cams, float bound,
-                                                               unsigned* __restrict__ g_mask, int* __restrict__ g_cnt,
-                                                               int* __restrict__ counts) {
+                                                               unsigned* __restrict__ g_mask, int* __restrict__ g_cnt) {
   const int id = blockIdx.x * kBlock + threadIdx.x;
   const bool live = id < P;
   const int idc = live ? id : P - 1;
@@ -151,10 +150,8 @@ __global__ __launch_bounds__(kBlock) void plan_classify_kernel(int P, int V, int
       const float rb = radius_bound(A, bound);
       keep = live && !surely_outside(ndc2pix(sp.projx, W), ndc2pix(sp.projy, H), rb, gx, gy);
     }
-    m |= keep ? (1u << v) : 0u;
-    const unsigned long long bal = __ballot(keep);
-    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(counts + v, __popcll(bal));
-  }
+    m |= keep ? (1u << v) : 0u;      // (per-view counts: from the sorted keys, plan_gather_kernel — 8 000 waves adding
+  }                                  // to one word per view cost 450 us in atomics)
   if (live) {
     g_mask[id] = m;
     g_cnt[id] = __popc(m);
@@ -217,15 +214,23 @@ __global__ __launch_bounds__(kBlock) void plan_gather_kernel(int P, int V, int H
                                                              float2* __restrict__ s_pix, unsigned* __restrict__ s_e) {
   const long total = counts[32];
   if (blockIdx.x == 0) {
-    if (threadIdx.x == 0) {
-      long run = 0;
-      int* view_off = header + kHeaderInts;
-      for (int v = 0; v < V; ++v) {
-        view_off[v] = (int)run;
-        run += counts[v];
+    __shared__ int s_off[33];
+    const long nn = total < cap ? total : cap;
+    if (threadIdx.x <= (unsigned)V) {
+      // first sorted position whose key belongs to view >= v (the keys are view-major): V + 1 binary searches
+      const unsigned long long want = (unsigned long long)threadIdx.x << kKeyDepthBits;
+      long lo = 0, hi = nn;
+      while (lo < hi) {
+        const long mid = (lo + hi) >> 1;
+        if ((unsigned long long)sorted_keys[mid] < want) lo = mid + 1; else hi = mid;
       }
-      view_off[V] = (int)run;
-      bool ok = run == total && total <= cap && counts[33] == 0 && (scan_state[0] >> 63) == 0;
+      s_off[threadIdx.x] = (int)(threadIdx.x == (unsigned)V ? nn : lo);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int* view_off = header + kHeaderInts;
+      for (int v = 0; v <= V; ++v) view_off[v] = s_off[v];
+      bool ok = total <= cap && counts[33] == 0 && (scan_state[0] >> 63) == 0;
       for (int i = 0; i < n_sort_states; ++i) ok = ok && (sort_states[i * sort_stride] >> 63) == 0;
       header[1] = P; header[2] = V; header[3] = H; header[4] = W; header[5] = gx; header[6] = gy;
       header[7] = __float_as_int(bound);
@@ -811,38 +816,34 @@ hipError_t plan_count(int P, int V, int H, int W, const float* means3D, const fl
   hipError_t e = ocrf::zero_async(counts, (size_t)kCountInts * 4, stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(plan_classify_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, P, V, gx, gy, W, H,
-                     means3D, reinterpret_cast<const Camera*>(cameras), bound, g_mask, g_off, counts);
+                     means3D, reinterpret_cast<const Camera*>(cameras), bound, g_mask, g_off);
   return ocrf::exclusive_scan_ints(g_off, P, counts + 32, scan_ws, scan_bytes, stream);
 }
 }  // namespace
 
-// Sizing pass: the records a plan for (means3D, cameras, extent_bound) holds.  counts (device, 33 ints): kept per view
-// in [0, n_views), their sum in [32].  workspace >= ocrf_raster_plan_build_workspace_bytes(P, n_views, 1).
+// Sizing pass: the records a plan for (means3D, cameras, extent_bound) holds.  g_mask (device, P words): bit v = view v
+// keeps the Gaussian; total (device int): their number.  workspace >= ocrf_raster_plan_count_workspace_bytes(P).
 int ocrf_raster_plan_count(int P, int n_views, int H, int W, const float* means3D, const float* cameras,
-                           float extent_bound_, int* counts, void* workspace, size_t workspace_bytes,
+                           float extent_bound_, unsigned* g_mask, int* total, void* workspace, size_t workspace_bytes,
                            ocrf_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (P <= 0 || n_views <= 0 || n_views > 32 || H <= 0 || W <= 0 || !means3D || !cameras || !counts || !workspace ||
-      !(extent_bound_ >= 0.f) || (long)P * n_views >= (1l << 30))
+  if (P <= 0 || n_views <= 0 || n_views > 32 || H <= 0 || W <= 0 || !means3D || !cameras || !g_mask || !total ||
+      !workspace || !(extent_bound_ >= 0.f) || (long)P * n_views >= (1l << 30) ||
+      workspace_bytes < ocrf_raster_plan_count_workspace_bytes(P))
     return (int)hipErrorInvalidValue;
-  // scratch: mask | count per Gaussian, the scan's state, the count block
-  const size_t need = align_up((size_t)P * 4, 256) * 2 + ocrf::exclusive_scan_bytes(P) + align_up(kCountInts * 4, 256);
-  if (workspace_bytes < need) return (int)hipErrorInvalidValue;
   char* base = static_cast<char*>(workspace);
-  auto* g_mask = reinterpret_cast<unsigned*>(base);
-  int* g_off = reinterpret_cast<int*>(base + align_up((size_t)P * 4, 256));
-  char* scan_ws = base + 2 * align_up((size_t)P * 4, 256);
+  int* g_off = reinterpret_cast<int*>(base);
+  char* scan_ws = base + align_up((size_t)P * 4, 256);
   int* cnt = reinterpret_cast<int*>(scan_ws + ocrf::exclusive_scan_bytes(P));
   hipError_t e = plan_count(P, n_views, H, W, means3D, cameras, extent_bound_, g_mask, g_off, cnt, scan_ws,
                             ocrf::exclusive_scan_bytes(P), stream);
   if (e != hipSuccess) return (int)e;
-  e = hipMemcpyAsync(counts, cnt, 33 * sizeof(int), hipMemcpyDeviceToDevice, stream);
-  return (int)e;
+  return (int)hipMemcpyAsync(total, cnt + 32, sizeof(int), hipMemcpyDeviceToDevice, stream);
 }
 
 size_t ocrf_raster_plan_count_workspace_bytes(int P) {
   if (P <= 0) return 0;
-  return align_up((size_t)P * 4, 256) * 2 + ocrf::exclusive_scan_bytes(P) + align_up(kCountInts * 4, 256);
+  return align_up((size_t)P * 4, 256) + ocrf::exclusive_scan_bytes(P) + align_up(kCountInts * 4, 256);
 }
 
 // The build proper: no host read, kernels only (hipGraph-capturable), into a plan of `capacity` records

@@ -59,7 +59,7 @@ class HotPath:
     def __init__(self, cfg, device, cams=None, index_prep_mode='cached', overlap=True, device_geometry=False,
                  render_mode='planned', render_guard='host', frame_motion=True, frame_offset=0, plan_margin=1.25,
                  ht_pool_backend='mfma', fuse_frames='auto', render_streams=1, blend_workgroups='auto',
-                 lss_pool_backend='tile', lss_mfma_group=2):
+                 lss_pool_backend='tile', lss_mfma_group=2, plan_rebuild='never'):
         """``cams``: optional list of camera indices this instance owns (camera sharding).
         ``index_prep_mode``: 'cached' — rank vectors computed once per calibration, the reference's
         ``accelerate=True`` intent; 'per_step' — recomputed inside every ``step()`` by the HIP index
@@ -68,10 +68,16 @@ class HotPath:
         is cached per frame like the rank vectors (``raster_plan.RasterPlan``; the Gaussian means are the fixed voxel
         grid, view_transformer_ocrf.py:651-673); 'per_call' — recomputed by every render (``rasterize_views``).
         ``render_guard``: 'host' (the plan's extent bound is checked by ``check_render_plans()``) or 'device'.
+        ``plan_rebuild``: 'never' — a render plan lives as long as its calibration; 'per_step' — every step rebuilds it
+        on the device from the sample's camera block before rendering (``RasterPlan.rebuild``: no host read), what a
+        per-SAMPLE pose costs: the reference builds the render cameras from the dataloader's c2w for every sample
+        (view_transformer_ocrf.py:1140-1152, detectors/ocrfdet.py:215-223).
         ``frame_motion``: batch entry b is frame ``frame_offset + b`` of a multi-frame sample with its own ego pose
         (``synthetic.ego_motion``) and its own Gaussian parameters, instead of every frame repeating frame 0."""
         self.cfg, self.device = cfg, torch.device(device)
         assert render_mode in ('planned', 'per_call') and render_guard in ('host', 'device')
+        assert plan_rebuild in ('never', 'per_step')
+        self.plan_rebuild = plan_rebuild
         self.render_mode, self.render_guard, self.plan_margin = render_mode, render_guard, float(plan_margin)
         self.frame_motion, self.frame_offset = bool(frame_motion), int(frame_offset)
         # 'mfma': the HT pooling (cached ranks) as per-tile MFMA panels (csrc/bev_pool_mfma.hip: 26 vs 32 us at cfg2);
@@ -252,10 +258,12 @@ class HotPath:
                 fr = list(range(f0, min(f0 + per, self.batch)))
                 cams = torch.cat([self.frame_cams[b]['packed'] for b in fr])
                 g = {k: torch.stack([self.frame_gauss[b][k] for b in fr]).contiguous() for k in ('rgb', 'opacity', 'scales', 'rotations')}
+                # record capacity: what these cameras keep + 10 % (a per-step rebuild sees poses that keep a few more)
                 plan = raster_plan.RasterPlan(self.voxel_xyz[f0].reshape(-1, 3), cams, H, W, scales=g['scales'],
-                                              rotations=g['rotations'], margin=self.plan_margin)
+                                              rotations=g['rotations'], margin=self.plan_margin, headroom=1.1)
                 # item z = view z of the plan (frame-major), rendered with the parameter set of its frame
                 g['item_view'] = torch.arange(len(fr) * n_cam, dtype=torch.int32, device=self.device)
+                g['cams'] = plan.cameras                 # the sample's camera block: a per-step rebuild reads it in place
                 self.render_plans.append((plan, f0, len(fr), g))
         return self.render_plans
 
@@ -298,9 +306,14 @@ class HotPath:
                   if (self.overlap or getattr(self, '_yield_word', None) is not None) else 0)
         elif not isinstance(bw, int):
             bw = int(bw[min(f0, len(bw) - 1)])
+        call_cams = None
+        if self.plan_rebuild == 'per_step':
+            if phase != 'blend':
+                plan.rebuild(g['cams'])
+            call_cams = g['cams']                       # ... and the call is checked against the plan's cameras on the device
         out = plan.render(g['rgb'], g['opacity'], g['scales'], g['rotations'], self.bg, guard=self.render_guard,
                           item_view=g['item_view'] if nf > 1 else None, blend_workgroups=bw, phase=phase, out=out,
-                          yield_if=word if bw else None)
+                          yield_if=word if bw else None, cameras=call_cams)
         if phase == 'update':
             return out
         n = len(self.cams)
@@ -428,6 +441,8 @@ class HotPath:
     def step(self, depth, feat):
         """One pass of the hot path: pools (+ render + HOA where the configuration has them)."""
         fork = self.overlap and self.cfg.render
+        if self.cfg.render and self.render_mode == 'planned':
+            self._plans()             # first step: built on the caller's stream BEFORE the side streams branch off it
         if fork:
             cur = torch.cuda.current_stream(self.device)
             # "the main chain is running": the persistent blends of the render stream keep to two workgroups per CU

@@ -84,12 +84,16 @@ class RasterPlan:
         cams = self.cameras if packed_cameras is None else _f32c(packed_cameras).reshape(-1, 36)
         with _lib.on_device(self.device):
             ws = torch.empty(int(L.ocrf_raster_plan_count_workspace_bytes(self.P)), dtype=torch.uint8, device=self.device)
-            counts = torch.empty(33, dtype=torch.int32, device=self.device)
+            mask = torch.empty(self.P, dtype=torch.int32, device=self.device)
+            total = torch.empty(1, dtype=torch.int32, device=self.device)
             _lib.check(L.ocrf_raster_plan_count(self.P, self.V, self.H, self.W, _lib.ptr(self.means3D), _lib.ptr(cams),
-                                                ctypes.c_float(self.extent_bound), _lib.ptr(counts), _lib.ptr(ws),
-                                                ctypes.c_size_t(ws.numel()), _lib.stream_ptr(self.device)),
+                                                ctypes.c_float(self.extent_bound), _lib.ptr(mask), _lib.ptr(total),
+                                                _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_ptr(self.device)),
                        'ocrf_raster_plan_count')
-        return [int(v) for v in counts[:self.V].cpu()]
+        per_view = torch.stack([((mask >> v) & 1).sum() for v in range(self.V)]).cpu()
+        kept = [int(v) for v in per_view]
+        assert sum(kept) == int(total.item())
+        return kept
 
     @torch.no_grad()
     def rebuild(self, packed_cameras=None, means3D=None):
@@ -100,7 +104,8 @@ class RasterPlan:
             cams = _f32c(packed_cameras).reshape(-1, 36)
             if cams.shape != self.cameras.shape:
                 raise _lib.OcrfHipError('rebuild: the camera count of a plan is fixed')
-            self.cameras.copy_(cams, non_blocking=True)
+            if cams.data_ptr() != self.cameras.data_ptr():       # (a caller may write new poses into plan.cameras itself)
+                self.cameras.copy_(cams, non_blocking=True)
         if means3D is not None:
             if means3D.shape != self.means3D.shape:
                 raise _lib.OcrfHipError('rebuild: the Gaussian count of a plan is fixed')
@@ -112,6 +117,9 @@ class RasterPlan:
                 ctypes.c_float(self.extent_bound), ctypes.c_long(self.capacity), _lib.ptr(self._build_ws),
                 ctypes.c_size_t(self._build_ws.numel()), _lib.ptr(self.plan), ctypes.c_size_t(self.plan.numel()),
                 _lib.stream_ptr(self.device)), 'ocrf_raster_plan_build')
+        # renders issued on ANOTHER stream must not overtake the build (a half-built plan holds wild record indices)
+        self._built = (torch.cuda.Event(), torch.cuda.current_stream(self.device))
+        self._built[0].record(self._built[1])
         return self
 
     def _scratch(self, n_sets):
@@ -176,6 +184,8 @@ class RasterPlan:
             if radii is None:
                 radii = out['radii'] = torch.empty(n_items, P, dtype=torch.int32, device=dev)
         L = _lib.lib()
+        if self._built[1] != torch.cuda.current_stream(dev):
+            torch.cuda.current_stream(dev).wait_event(self._built[0])
         with _lib.on_device(dev):
             dyn = self._scratch(S)
             chain = None
