@@ -751,10 +751,10 @@ def main():
             grid_note = None
             if planned and getattr(hp, 'overlap', False) and getattr(hp, 'blend_workgroups', None) == 'auto':
                 cus = torch.cuda.get_device_properties(dev).multi_processor_count
-                grid_note = {'workgroups_timed_region': 2 * cus, 'workgroups_isolated': _lib.lib().ocrf_diag_plan_resident(),
-                             'note': 'beside the pooling / HOA stream the persistent blend is launched on two workgroups '
-                                     'per CU of the four the chip holds (DESIGN 5: step 0.344 -> 0.300 ms); "frac" prices '
-                                     'that half-occupancy launch against the whole chip\'s peak, "isolated" is the full grid'}
+                grid_note = {'workgroups_timed_region': 5 * cus // 2, 'workgroups_isolated': _lib.lib().ocrf_diag_plan_resident(),
+                             'note': 'beside the pooling / HOA stream the persistent blend is launched on 2.5 workgroups '
+                                     'per CU of the four the chip holds (DESIGN 5); "frac" prices that partial-occupancy '
+                                     'launch against the whole chip\'s peak, "isolated" is the full grid'}
             roofline = {
                 'bound': 'valu', 'kernel': t_blend.kernel_name,
                 'achieved': tfl, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tfl / FP32_PEAK_TFLOPS,

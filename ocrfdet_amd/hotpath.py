@@ -302,7 +302,9 @@ class HotPath:
         if word is None and self._use_busy():
             word = self._busy
         if bw == 'auto':
-            bw = (2 * torch.cuda.get_device_properties(self.device).multi_processor_count
+            # beside the other chain: 2.5 workgroups per CU (round 3: 2; the main chain got shorter in round 4 and the
+            # blend is the longer chain now: 512 -> 640 workgroups, cfg2 0.269 -> 0.262 ms)
+            bw = (5 * torch.cuda.get_device_properties(self.device).multi_processor_count // 2
                   if (self.overlap or getattr(self, '_yield_word', None) is not None) else 0)
         elif not isinstance(bw, int):
             bw = int(bw[min(f0, len(bw) - 1)])
@@ -439,24 +441,49 @@ class HotPath:
         return self.pool(self.lss, depth, feat), self.pool(self.ht, depth, feat)
 
     def step(self, depth, feat):
-        """One pass of the hot path: pools (+ render + HOA where the configuration has them)."""
+        """One pass of the hot path: pools (+ render + HOA where the configuration has them).
+        -> (lss, ht[, rendered][, gated, opacity_bev]), everything ordered on the caller's stream."""
         fork = self.overlap and self.cfg.render
         if self.cfg.render and self.render_mode == 'planned':
             self._plans()             # first step: built on the caller's stream BEFORE the side streams branch off it
-        if fork:
-            cur = torch.cuda.current_stream(self.device)
-            # "the main chain is running": the persistent blends of the render stream keep to two workgroups per CU
-            # while it is up and take the whole chip once it is down (cfg4: the renders outlast the poolings + HOA)
+        if not fork:
+            main = self._main_chain(depth, feat)
+            rendered = [self.render()] if self.cfg.render else []
+            return tuple(main[:2]) + tuple(rendered) + tuple(main[2:])
+        cur = torch.cuda.current_stream(self.device)
+        if getattr(self, 'render_on_caller_stream', False):
+            # The other arrangement: the render chain (update -> persistent blend) on the caller's stream, the pools + HOA
+            # chain on the branch.  Measured WORSE at cfg2 (0.298 vs 0.270 ms, tools/sweep_r4.sh): the twelve dependent
+            # launches of the pools + HOA chain run slower from a side stream than the two launches of the render chain do.
+            chain = shared_stream(self.device, 'chain')
+            chain.wait_stream(cur)
             self._set_busy(1)
-            if not self._side:
-                self._side = [shared_stream(self.device, 'render' if k == 0 else f'render{k}')
-                              for k in range(self.render_streams)]
-            for side in self._side:
-                side.wait_stream(cur)                 # inputs (and last step's consumers) are ordered before
-            rendered = self.render([self._side[b % len(self._side)] for b in range(self.batch)])
-        # HOA-1/2 do not read the pooled BEV and are latency chains of small kernels: issued FIRST, they run in the
-        # shadow of the render stream's chip-filling preprocess instead of the poolings competing with it
-        # (cfg2 step 0.402 -> 0.388 ms; on a stream of their own: 0.41-0.47 ms)
+            rendered = self.render()
+            with torch.cuda.stream(chain):
+                main = self._main_chain(depth, feat)
+                self._set_busy(0)
+            cur.wait_stream(chain)
+            for t in main:
+                t.record_stream(cur)      # allocated on the branch, handed to the caller's stream
+            return tuple(main[:2]) + (rendered,) + tuple(main[2:])
+        # "the main chain is running": the persistent blends of the render stream keep to two workgroups per CU
+        # while it is up and take the whole chip once it is down (cfg4: the renders outlast the poolings + HOA)
+        self._set_busy(1)
+        if not self._side:
+            self._side = [shared_stream(self.device, 'render' if k == 0 else f'render{k}')
+                          for k in range(self.render_streams)]
+        for side in self._side:
+            side.wait_stream(cur)                 # inputs (and last step's consumers) are ordered before
+        rendered = self.render([self._side[b % len(self._side)] for b in range(self.batch)])
+        main = self._main_chain(depth, feat)
+        self._set_busy(0)
+        for side in self._side:
+            cur.wait_stream(side)                 # join: everything the step returns is ordered on `cur`
+        return tuple(main[:2]) + (rendered,) + tuple(main[2:])
+
+    def _main_chain(self, depth, feat):
+        """Pools + HOA on the current stream -> (lss, ht[, gated, opacity_bev])."""
+        # HOA-1/2 do not read the pooled BEV and are latency chains of small kernels
         prepared = None
         if (self.index_prep_mode == 'per_step' and self.cfg.hoa and self.overlap and self.device_geometry
                 and hasattr(self, '_calib_dev')):
@@ -484,15 +511,16 @@ class HotPath:
             with torch.cuda.stream(p2):
                 prepared = (lss_prepared, self._prepare_ht(ht_block))
         # HOA-1/2 need nothing of the poolings and the poolings nothing of them: with the planned render (a memory-bound
-        # update kernel, then the VALU-bound blend on two workgroups per CU) the poolings go FIRST — they meet the
-        # side stream's update and the start of its blend instead of its middle (cfg2: 0.305 -> 0.292 ms); with the
-        # per-call render, whose chip-filling preprocess opens the side stream, HOA-1/2 first was better (round 2)
-        # (per-step index preparation: HOA-1/2 first, beside the preparation the poolings have to wait for anyway)
+        # update kernel, then the VALU-bound blend) the poolings go FIRST — they meet the side stream's update and the
+        # start of its blend instead of its middle; with the per-call render, whose chip-filling preprocess opens the
+        # side stream, and with the per-step index preparation (which the poolings have to wait for anyway) HOA-1/2
+        # first.  (Round 4, HOA-1/2 shortened to 55 us: pools first + a 640-workgroup blend 0.262 ms, HOA first + 512
+        # workgroups 0.270, tools/sweep_r4.sh.)
         hoa_first = getattr(self, 'hoa_first', self.render_mode != 'planned' or self.index_prep_mode == 'per_step')
         ob = self.hoa_opacity_bev() if (self.cfg.hoa and hoa_first) else None
         hoa_side = None
         if self.cfg.hoa and not hoa_first and getattr(self, 'hoa_stream', False) and self.overlap:
-            # HOA-1/2 (ten small kernels, 16-338 workgroups each) on a stream of their own beside the poolings
+            # HOA-1/2 (eight small kernels) on a stream of their own beside the poolings
             hoa_side = shared_stream(self.device, 'hoa')
             hoa_side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(hoa_side):
@@ -512,19 +540,11 @@ class HotPath:
         elif self.cfg.hoa and not hoa_first:
             ob = self.hoa_opacity_bev()
         out = [lss, ht]
-        if fork:
-            out.append(rendered)
-        elif self.cfg.render:
-            out.append(self.render())
         if self.cfg.hoa:
             # stand-in for geom_feat: the HT BEV has its shape (B,C,Y,X); the fusion convs between
             # the pools and HOA-3 are MIOpen territory, not part of this path
             out.extend(self.hoa_step(ht, ob))
-        if fork:
-            self._set_busy(0)
-            for side in self._side:
-                cur.wait_stream(side)                 # join: everything the step returns is ordered on `cur`
-        return tuple(out)
+        return out
 
     @property
     def bev_voxels_per_step(self):
