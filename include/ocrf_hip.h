@@ -240,6 +240,10 @@ size_t ocrf_rasterize_workspace_bytes(int P, int n_views);
  *      ocrf_rasterize_forward, indexed by item; colour / depth / final_T are bit-identical to it.  radii
  *      (n_items, P) or NULL.  `capacity`: the plan's record capacity (as given to the build).
  *      workspace >= ocrf_rasterize_planned_workspace_bytes(capacity, n_sets).
+ *      views_disjoint = 1: the caller states that every plan view is rendered by at most ONE set of this call (frames
+ *      of a sample sharing a plan, each with its own parameter set): all sets then share one copy of the per-call
+ *      record arrays (workspace >= ocrf_rasterize_planned_workspace_bytes(capacity, 1)), every line of which is
+ *      written once; a view named by two sets raises status bit 3 (value 8).  0: a copy per set.
  *      call_cameras (device, n_plan_views x 36 floats, or NULL): the cameras THIS call means to render with.  The
  *      update kernel compares them with the plan's, bit for bit, on the device; a difference raises status bit 4
  *      (value 16) and — with guard = 1 — hands the call to the armed per-call pipeline, which then renders with
@@ -286,7 +290,7 @@ int ocrf_rasterize_planned(const void *plan, size_t plan_bytes, int P, int n_pla
                            float *out_depth, float *out_final_T, int *radii, int *status, void *workspace,
                            size_t workspace_bytes, int guard, const float *means3D, void *chain_workspace,
                            size_t chain_workspace_bytes, int blend_workgroups, const int *yield_if, int phase,
-                           const float *call_cameras, ocrf_stream_t stream);
+                           const float *call_cameras, int views_disjoint, ocrf_stream_t stream);
 
 /*
  * bev_pool_v2 forward as per-tile MFMA panels (csrc/bev_pool_mfma.hip): out[64 voxels x C] = W[64 x R] . F[R x C]

@@ -121,7 +121,7 @@ def _declare(L):
     L.ocrf_rasterize_planned.restype = c_int
     L.ocrf_rasterize_planned.argtypes = ([c_void_p, c_size_t, c_int, c_int, c_long] + [c_int] * 4 + [c_void_p] * 4 +
                                          [c_float] + [c_void_p] * 2 + [c_int] + [c_void_p] * 6 + [c_size_t, c_int] +
-                                         [c_void_p] * 2 + [c_size_t, c_int, c_void_p, c_int, c_void_p, c_void_p])
+                                         [c_void_p] * 2 + [c_size_t, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p])
     L.ocrf_stream_write_value32.restype = c_int
     L.ocrf_stream_write_value32.argtypes = [c_void_p, c_int, c_void_p]
     L.ocrf_lss_prepare.restype = c_int

@@ -251,32 +251,41 @@ __global__ __launch_bounds__(kBlock) void plan_gather_kernel(int P, int V, int H
 }
 
 // ---------------------------------------------------------------------------------------------
-// step 1: the parameter-dependent half of preprocessCUDA (forward.cu:201-256), ONE THREAD PER GAUSSIAN of a set:
-// the parameters are read once (coalesced), the 3D covariance is built once, then every rendered view that keeps
-// the Gaussian gets its conic / radius / tile rect.  The same pass checks the Gaussian's extent against the plan's
-// bound.  Everything it writes is in GAUSSIAN-MAJOR record order e (coalesced); the blend reaches a record of its
-// depth-ordered list through the plan's static list position -> e map (s_e):
-//   d_rect[set][e]    tile rect ((0,0,0,0): not rendered this step), gathered by the blend's scan.  Written at the
-//                     record's place in the sorted list instead, the scan read it coalesced but the writes were random
-//                     8-byte stores — a memory-side read-modify-write each, and the pass ran beside the LSS pooling's
-//                     gathers: 21.5 -> 15.2 us alone, cfg2 step 0.290 -> 0.277 ms, for + 3 % on the blend;
-//   d_con[set][e]     (-0.5 conic.x, -0.5 conic.z, conic.y, opacity), read when a record is staged
-// grid (ceil(P / 256), n_sets).  The items of one set name distinct plan views.
+// step 1: the parameter-dependent half of preprocessCUDA (forward.cu:201-256), ONE THREAD PER GAUSSIAN for EVERY
+// parameter set of the call: per set the parameters are read once (coalesced), the extent is checked against the
+// plan's bound, the 3D covariance is built once, then every view the set renders that keeps the Gaussian gets its
+// conic / radius / tile rect.  Everything it writes is in GAUSSIAN-MAJOR record order e (coalesced); the blend reaches
+// a record of its depth-ordered list through the plan's static list position -> e map (s_e):
+//   d_rect[set * set_stride + e]   tile rect ((0,0,0,0): not rendered this step), gathered by the blend's scan.  Written
+//                     at the record's place in the sorted list instead, the scan read it coalesced but the writes were
+//                     random 8-byte stores — a memory-side read-modify-write each: 21.5 -> 15.2 us alone in round 3;
+//   d_con[set * set_stride + e]    (-0.5 conic.x, -0.5 conic.z, conic.y, opacity), read when a record is staged.
+// set_stride = 0 when every plan view is rendered by at most ONE set of the call (the hot path: frames of a sample
+// share a plan, frame f renders its own six views with its own parameters) — one dynamic array for all sets, every
+// line of it written once, by one workgroup; else the plan's record capacity (a set per copy).
+// Round 3 ran one workgroup per (256 Gaussians, set): a Gaussian's records of the two frames interleave in memory, so
+// the two workgroups (on different XCDs: separate L2s) each fetched every record line and each wrote half of every
+// output line — 216 MB of HBM traffic for 120 MB algorithmic (PMC), 42.8 us.  The items of one set name distinct views.
 // ---------------------------------------------------------------------------------------------
+constexpr int kMaxSets = 32;
+
 __global__ __launch_bounds__(kBlock) void raster_plan_update_kernel(
-    int P, int vps, long n_total, const int* __restrict__ header, const unsigned* __restrict__ g_mask,
+    int P, int vps, int n_sets, long set_stride, long n_cap, const int* __restrict__ header,
+    const unsigned* __restrict__ g_mask,
     const int* __restrict__ g_off, const float4* __restrict__ e_q0,
     const float4* __restrict__ e_q1, const int* __restrict__ view_sel, const float* __restrict__ opacities,
     const float* __restrict__ scales, float scale_modifier, const float* __restrict__ rotations,
     Rect* __restrict__ d_rect, float4* __restrict__ d_con, int* __restrict__ radii, int* __restrict__ status,
     int* __restrict__ flag, int* __restrict__ queue, const unsigned* __restrict__ call_cams,
     const unsigned* __restrict__ plan_cams) {
-  __shared__ int l_v2i[32];
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+  __shared__ int l_v2i[kMaxSets * 32];             // [set][plan view] -> item of the set that renders it, or -1
+  __shared__ unsigned l_setmask[kMaxSets];         // [set] -> plan views the set renders
+  __shared__ int l_owner[32];                      // disjoint mode: the set that renders a plan view
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     *queue = 0;                  // ticket counter of the blend that follows
     if (flag) flag[1] = 0;       // arrival counter of the armed per-call blend (rasterize.hip)
   }
-  if (call_cams && blockIdx.x == 0 && blockIdx.y == 0) {
+  if (call_cams && blockIdx.x == 0) {
     // the plan is keyed by its cameras ON THE DEVICE: a call that means other cameras (another pose) is not rendered
     // from this plan — status bit 4 (value 16), and the armed per-call chain (guard) takes the call over
     bool differ = false;
@@ -287,77 +296,119 @@ __global__ __launch_bounds__(kBlock) void raster_plan_update_kernel(
     }
   }
   if (header[0] != (int)kPlanMagic) {      // unusable plan (capacity, key range, failed scan): the armed chain renders
-    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
       atomicOr(status, 8);
       if (flag) atomicOr(flag, 1);
     }
     return;
   }
   const int V = header[2], gx = header[5], gy = header[6];
-  const int s = blockIdx.y;
-  if (threadIdx.x < 32) l_v2i[threadIdx.x] = -1;
+  for (int i = threadIdx.x; i < n_sets * 32; i += kBlock) l_v2i[i] = -1;
+  if (threadIdx.x < 32) l_owner[threadIdx.x] = -1;
+  if ((int)threadIdx.x < n_sets) l_setmask[threadIdx.x] = 0u;
   __syncthreads();
-  if ((int)threadIdx.x < vps) {
-    const int v = view_sel ? view_sel[s * vps + threadIdx.x] : (int)threadIdx.x;
+  for (int it = threadIdx.x; it < n_sets * vps; it += kBlock) {
+    const int s = it / vps, zi = it % vps;
+    const int v = view_sel ? view_sel[it] : zi;
     bool ok = v >= 0 && v < V;
-    if (ok) ok = atomicExch(&l_v2i[v], (int)threadIdx.x) == -1;       // a view named twice in one set: refused
+    if (ok) ok = atomicExch(&l_v2i[s * 32 + v], zi) == -1;            // a view named twice in one set: refused
+    if (ok && set_stride == 0) ok = atomicExch(&l_owner[v], s) == -1;  // ... or by two sets that share the dynamic arrays
+    if (ok) atomicOr(&l_setmask[s], 1u << v);
     if (!ok && blockIdx.x == 0) atomicOr(status, 8);
   }
   __syncthreads();
   const int id = blockIdx.x * kBlock + threadIdx.x;
   if (id >= P) return;
-  const long gi = (long)s * P + id;
-  const float sx = scale_modifier * scales[3 * gi], sy = scale_modifier * scales[3 * gi + 1],
-              sz = scale_modifier * scales[3 * gi + 2];
-  const float qr = rotations[4 * gi], qx = rotations[4 * gi + 1], qy = rotations[4 * gi + 2],
-              qz = rotations[4 * gi + 3];
-  const float rn = extent_bound(sx, sy, sz, qr, qx, qy, qz);
-  // the plan's static cull holds for extents <= bound; NaN / Inf anywhere counts as a violation (fmaxf drops NaNs)
-  const bool bad = !(rn <= __int_as_float(header[7])) || !(((sx + sy) + sz) * 0.f == 0.f);
-  if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) {
-    atomicOr(status, 4);
-    if (flag) atomicOr(flag, 1);
-  }
-  unsigned m = g_mask[id];
-  if (radii) {      // (item, Gaussian) pairs outside the lists are not visited below: their radii are 0 (no memset launch)
-    for (int zi = 0; zi < vps; ++zi) {
-      const int v = view_sel ? view_sel[s * vps + zi] : zi;
-      const bool listed = v >= 0 && v < V && ((m >> v) & 1u) != 0u && l_v2i[v] == zi;
-      if (!listed) radii[((long)s * vps + zi) * P + id] = 0;
+  const unsigned m = g_mask[id];
+  const int e0 = g_off[id];
+  const float bound = __int_as_float(header[7]);
+  // the parameters of the next set are requested before this set's arithmetic
+  float sx, sy, sz, qr, qx, qy, qz, o;
+  auto load = [&](int s) {
+    const long gi = (long)s * P + id;
+    sx = scales[3 * gi]; sy = scales[3 * gi + 1]; sz = scales[3 * gi + 2];
+    qr = rotations[4 * gi]; qx = rotations[4 * gi + 1]; qy = rotations[4 * gi + 2]; qz = rotations[4 * gi + 3];
+    o = opacities[gi];
+  };
+  load(0);
+  // The Gaussian's first kPre records (it has 2.7 on average over the twelve views of cfg2) are requested NOW, whatever
+  // set they belong to, at clamped indices: one memory round trip for all of them instead of one per record inside the
+  // loops below (a thread's records used to be a chain of load -> arithmetic -> store -> load ...).
+  constexpr int kPre = 4;
+  float4 pq0[kPre], pq1[kPre];
+  int pv[kPre];
+  {
+    unsigned mm = m;
+#pragma unroll
+    for (int j = 0; j < kPre; ++j) {
+      pv[j] = mm ? __ffs(mm) - 1 : -1;
+      mm &= mm - 1;                                            // (0 stays 0)
+      const long idx = min((long)e0 + j, n_cap - 1);
+      pq0[j] = e_q0[idx];
+      pq1[j] = e_q1[idx];
     }
   }
-  if (m == 0u) return;
-  float c3[6];
-  cov3d_from_scale_rot(sx, sy, sz, qr, qx, qy, qz, c3);
-  const float o = opacities[gi];
-  // alpha = min(0.99, o exp(power)) with power <= 0 (forward.cu:327-333): under 1/255 at EVERY pixel when o is
-  // (NaN compares false: evaluated in full).  Such a Gaussian gets an empty rect — no tile pair ever scans into it —
-  // and, unless its radius is asked for, no covariance work either.  Free space in a trained OcRF is mostly this.
-  const bool unseen = o < 1.0f / 255.0f;
-  int e = g_off[id];
-  const long dyn = (long)s * n_total;
-  while (m) {
-    const int v = __ffs(m) - 1;
-    m &= m - 1;
-    const int cur = e++;
-    const int zi = l_v2i[v];
-    if (zi < 0) continue;                                   // this view is not rendered by this set
-    const float4 q0 = e_q0[cur], q1 = e_q1[cur];
-    const float A[2][3] = {{q0.x, q0.y, q0.z}, {q0.w, q1.x, q1.y}};
-    Rect rect = Rect{0, 0, 0, 0};
-    int rad = 0;
-    if ((!unseen || radii) && !surely_outside(q1.z, q1.w, radius_bound(A, rn), gx, gy)) {
-      float cov_x, cov_y, cov_z, con_x, con_y, con_z;
-      cov2d(A, c3, &cov_x, &cov_y, &cov_z);
-      if (conic_radius_rect(cov_x, cov_y, cov_z, q1.z, q1.w, gx, gy, &con_x, &con_y, &con_z, &rad, &rect)) {
-        d_con[dyn + cur] = make_float4(-0.5f * con_x, -0.5f * con_z, con_y, o);      // Gaussian-major: coalesced
-      } else {
-        rect = Rect{0, 0, 0, 0};
-        rad = 0;
+  bool any_bad = false;
+  for (int s = 0; s < n_sets; ++s) {
+    const float csx = scale_modifier * sx, csy = scale_modifier * sy, csz = scale_modifier * sz;
+    const float cqr = qr, cqx = qx, cqy = qy, cqz = qz, co = o;
+    if (s + 1 < n_sets) load(s + 1);
+    const float rn = extent_bound(csx, csy, csz, cqr, cqx, cqy, cqz);
+    // the plan's static cull holds for extents <= bound; NaN / Inf anywhere counts as a violation (fmaxf drops NaNs)
+    any_bad |= !(rn <= bound) || !(((csx + csy) + csz) * 0.f == 0.f);
+    const unsigned mset = m & l_setmask[s];
+    if (radii) {      // (item, Gaussian) pairs outside the lists are not visited below: their radii are 0 (no memset launch)
+      for (int zi = 0; zi < vps; ++zi) {
+        const int v = view_sel ? view_sel[s * vps + zi] : zi;
+        const bool listed = v >= 0 && v < V && ((mset >> v) & 1u) != 0u && l_v2i[s * 32 + v] == zi;
+        if (!listed) radii[((long)s * vps + zi) * P + id] = 0;
       }
     }
-    d_rect[dyn + cur] = unseen ? Rect{0, 0, 0, 0} : rect;
-    if (radii) radii[((long)s * vps + zi) * P + id] = rad;
+    if (mset == 0u) continue;
+    float c3[6];
+    cov3d_from_scale_rot(csx, csy, csz, cqr, cqx, cqy, cqz, c3);
+    // alpha = min(0.99, o exp(power)) with power <= 0 (forward.cu:327-333): under 1/255 at EVERY pixel when o is
+    // (NaN compares false: evaluated in full).  Such a Gaussian gets an empty rect — no tile pair ever scans into it —
+    // and, unless its radius is asked for, no covariance work either.  Free space in a trained OcRF is mostly this.
+    const bool unseen = co < 1.0f / 255.0f;
+    const long dyn = (long)s * set_stride;
+    auto record = [&](int v, int cur, const float4 q0, const float4 q1) {
+      const int zi = l_v2i[s * 32 + v];
+      const float A[2][3] = {{q0.x, q0.y, q0.z}, {q0.w, q1.x, q1.y}};
+      Rect rect = Rect{0, 0, 0, 0};
+      int rad = 0;
+      if ((!unseen || radii) && !surely_outside(q1.z, q1.w, radius_bound(A, rn), gx, gy)) {
+        float cov_x, cov_y, cov_z, con_x, con_y, con_z;
+        cov2d(A, c3, &cov_x, &cov_y, &cov_z);
+        if (conic_radius_rect(cov_x, cov_y, cov_z, q1.z, q1.w, gx, gy, &con_x, &con_y, &con_z, &rad, &rect)) {
+          d_con[dyn + cur] = make_float4(-0.5f * con_x, -0.5f * con_z, con_y, co);      // Gaussian-major: coalesced
+        } else {
+          rect = Rect{0, 0, 0, 0};
+          rad = 0;
+        }
+      }
+      d_rect[dyn + cur] = unseen ? Rect{0, 0, 0, 0} : rect;
+      if (radii) radii[((long)s * vps + zi) * P + id] = rad;
+    };
+#pragma unroll
+    for (int j = 0; j < kPre; ++j)                              // record j of the Gaussian = its j-th kept view (ascending)
+      if (pv[j] >= 0 && ((mset >> pv[j]) & 1u) != 0u) record(pv[j], e0 + j, pq0[j], pq1[j]);
+    if (__popc(m) > kPre) {                                     // rare: a Gaussian kept by more than kPre views
+      unsigned mm = m;
+#pragma unroll
+      for (int j = 0; j < kPre; ++j) mm &= mm - 1;
+      int cur = e0 + kPre;
+      while (mm) {
+        const int v = __ffs(mm) - 1;
+        mm &= mm - 1;
+        if ((mset >> v) & 1u) record(v, cur, e_q0[cur], e_q1[cur]);
+        ++cur;
+      }
+    }
+  }
+  if (__ballot(any_bad) != 0ull && (threadIdx.x & 63) == 0) {
+    atomicOr(status, 4);
+    if (flag) atomicOr(flag, 1);
   }
 }
 
@@ -370,7 +421,7 @@ __global__ __launch_bounds__(kBlock) void raster_plan_update_kernel(
 // ---------------------------------------------------------------------------------------------
 template <bool MEDIAN, bool WSKIP, bool STATS = false>
 __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
-    unsigned long long* __restrict__ stats, int P, int W, int H, int gx, int gy, int n_items, int vps, long n_total,
+    unsigned long long* __restrict__ stats, int P, int W, int H, int gx, int gy, int n_items, int vps, long set_stride,
     const int* __restrict__ header, const int* __restrict__ view_sel, const unsigned* __restrict__ s_id,
     const unsigned* __restrict__ s_key, const float2* __restrict__ s_pix, const unsigned* __restrict__ s_e,
     const Rect* __restrict__ d_rect, const float4* __restrict__ d_con, const float* __restrict__ colors,
@@ -423,8 +474,8 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
   const int set = z / vps;
   const int tyA = 2 * ty2, tyB = tyA + 1;
   const int off = view_off[v], nv = view_off[v + 1] - off;
-  const float4* set_con = d_con + (long)set * n_total;
-  const Rect* set_rect = d_rect + (long)set * n_total;
+  const float4* set_con = d_con + (long)set * set_stride;
+  const Rect* set_rect = d_rect + (long)set * set_stride;
   const float* set_colors = colors + 3 * (long)set * P;
   const int pxi = tx * kTileX + lx;
   const int py0 = tyA * kTileY + 8 * wave + r, py1 = py0 + 4;
@@ -917,10 +968,11 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
                            int* radii, int* status, void* workspace, size_t workspace_bytes, int guard,
                            const float* means3D, void* chain_workspace, size_t chain_workspace_bytes,
                            int blend_workgroups, const int* yield_if, int phase, const float* call_cameras,
-                           ocrf_stream_t stream_) {
+                           int views_disjoint, ocrf_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (!plan || P <= 0 || n_plan_views <= 0 || n_plan_views > 32 || total_kept < 0 || total_kept >= (1l << 30) ||
-      H <= 0 || W <= 0 || n_sets <= 0 || n_items <= 0 || n_items % n_sets || blend_workgroups < 0 || phase < 0 ||
+      H <= 0 || W <= 0 || n_sets <= 0 || n_sets > kMaxSets || n_items <= 0 || n_items % n_sets || blend_workgroups < 0 ||
+      phase < 0 ||
       phase > 2 || (phase != 0 && guard) || !colors ||
       !opacities || !scales ||
       !rotations || !bg || (depth_mode != 0 && depth_mode != 1) || !out_color || !out_depth || !out_final_T ||
@@ -930,8 +982,11 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
   if (vps > n_plan_views || (!item_view && vps != n_plan_views)) return (int)hipErrorInvalidValue;
   PlanLayout L;
   plan_layout(P, n_plan_views, total_kept, &L);
+  // views_disjoint: every plan view is rendered by at most one set of this call (checked on the device: status bit 8) —
+  // all sets share ONE copy of the dynamic arrays
+  const long set_stride = views_disjoint ? 0 : total_kept;
   DynLayout D;
-  dyn_layout(total_kept, n_sets, &D);
+  dyn_layout(total_kept, views_disjoint ? 1 : n_sets, &D);
   if (plan_bytes < L.bytes || workspace_bytes < D.bytes) return (int)hipErrorInvalidValue;
   const int gx = (W + kTileX - 1) / kTileX, gy = (H + kTileY - 1) / kTileY;
   const char* pb = static_cast<const char*>(plan);
@@ -956,8 +1011,9 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
     chain_hist = ocrf::raster_chain_hist(chain_workspace, P, n_items, &chain_hist_words);
   }
   if (phase != 2) {
-  ocrf::launch(OCRF_K_RASTER_PLAN_UPDATE, raster_plan_update_kernel, dim3((P + kBlock - 1) / kBlock, n_sets),
-               dim3(kBlock), (size_t)g_update_lds, stream, P, vps, total_kept, header, reinterpret_cast<const unsigned*>(pb + L.g_mask),
+  ocrf::launch(OCRF_K_RASTER_PLAN_UPDATE, raster_plan_update_kernel, dim3((P + kBlock - 1) / kBlock),
+               dim3(kBlock), (size_t)g_update_lds, stream, P, vps, n_sets, set_stride, total_kept, header,
+               reinterpret_cast<const unsigned*>(pb + L.g_mask),
                reinterpret_cast<const int*>(pb + L.g_off),
                reinterpret_cast<const float4*>(pb + L.e_q0), reinterpret_cast<const float4*>(pb + L.e_q1), item_view,
                opacities, scales, scale_modifier, rotations, d_rect, d_con, radii, status, flag, queue,
@@ -973,7 +1029,7 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
   if (g_plan_stats) {      // diagnostic build (median depth), never used by the product path
     const dim3 sgrid((unsigned)std::min(n_work, want_grid ? want_grid : resident_blocks(raster_blend_sorted_kernel<true, false, true>)));
     hipLaunchKernelGGL((raster_blend_sorted_kernel<true, false, true>), sgrid, dim3(kBlock), 0, stream, g_plan_stats, P, W, H,
-                       gx, gy, n_items, vps, total_kept, header, item_view, reinterpret_cast<const unsigned*>(pb + L.s_id),
+                       gx, gy, n_items, vps, set_stride, header, item_view, reinterpret_cast<const unsigned*>(pb + L.s_id),
                        reinterpret_cast<const unsigned*>(pb + L.s_key), reinterpret_cast<const float2*>(pb + L.s_pix),
                        reinterpret_cast<const unsigned*>(pb + L.s_e), static_cast<const Rect*>(d_rect),
                        static_cast<const float4*>(d_con), colors, bg, out_color, out_depth, out_final_T,
@@ -985,7 +1041,7 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
                dim3((unsigned)std::min(n_work, want_grid ? want_grid                                                   \
                                                           : resident_blocks(raster_blend_sorted_kernel<MED, WS>))),     \
                dim3(kBlock), 0,                                                                                        \
-               stream, (unsigned long long*)nullptr, P, W, H, gx, gy, n_items, vps, total_kept, header, item_view,     \
+               stream, (unsigned long long*)nullptr, P, W, H, gx, gy, n_items, vps, set_stride, header, item_view,     \
                reinterpret_cast<const unsigned*>(pb + L.s_id), reinterpret_cast<const unsigned*>(pb + L.s_key),        \
                reinterpret_cast<const float2*>(pb + L.s_pix), reinterpret_cast<const unsigned*>(pb + L.s_e),           \
                static_cast<const Rect*>(d_rect),                                                                       \

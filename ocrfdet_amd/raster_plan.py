@@ -122,6 +122,19 @@ class RasterPlan:
         self._built[0].record(self._built[1])
         return self
 
+    def _views_disjoint(self, item_view, S):
+        """Does every plan view appear at most once among the items?  (One host read per distinct index tensor, cached: the
+        hot path's item list is static.)  Sets then share one copy of the per-call record arrays."""
+        if S == 1:
+            return True
+        if item_view is None:
+            return False                                   # every set renders every view
+        key = (item_view.data_ptr(), item_view._version, int(item_view.numel()))
+        hit = getattr(self, '_disjoint_cache', None)
+        if hit is None or hit[0] != key:
+            self._disjoint_cache = hit = (key, bool(torch.unique(item_view).numel() == item_view.numel()))
+        return hit[1]
+
     def _scratch(self, n_sets):
         need = _lib.lib().ocrf_rasterize_planned_workspace_bytes(ctypes.c_long(self.capacity), n_sets)
         if self._dyn is None or self._dyn.numel() < need:
@@ -186,8 +199,9 @@ class RasterPlan:
         L = _lib.lib()
         if self._built[1] != torch.cuda.current_stream(dev):
             torch.cuda.current_stream(dev).wait_event(self._built[0])
+        disjoint = self._views_disjoint(item_view, S)
         with _lib.on_device(dev):
-            dyn = self._scratch(S)
+            dyn = self._scratch(1 if disjoint else S)
             chain = None
             if use_guard:
                 need = L.ocrf_rasterize_workspace_bytes(P, n_items)
@@ -202,7 +216,7 @@ class RasterPlan:
                 _lib.ptr(self.status), _lib.ptr(dyn), ctypes.c_size_t(dyn.numel()), use_guard,
                 _lib.ptr(self.means3D), _lib.ptr(chain), ctypes.c_size_t(chain.numel() if chain is not None else 0),
                 int(blend_workgroups), _lib.ptr(yield_if), {'both': 0, 'update': 1, 'blend': 2}[phase],
-                _lib.ptr(cameras), _lib.stream_ptr(dev)),
+                _lib.ptr(cameras), int(disjoint), _lib.stream_ptr(dev)),
                 'ocrf_rasterize_planned')
         out['status'] = self.status
         return out

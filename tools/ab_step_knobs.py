@@ -17,8 +17,8 @@ ap.add_argument('--ht', default='mfma')
 ap.add_argument('--render-mode', default='planned')
 ap.add_argument('--fuse', type=int, default=1)
 ap.add_argument('--rstreams', type=int, default=1)
-ap.add_argument('--hoa-first', type=int, default=1)
-ap.add_argument('--caller', type=int, default=1, help='render chain on the caller stream (1) or on the side stream (0)')
+ap.add_argument('--hoa-first', type=int, default=None, help='default: what HotPath chooses')
+ap.add_argument('--caller', type=int, default=None, help='render chain on the caller stream (1) or on the side stream (0; HotPath default)')
 ap.add_argument('--hoa-stream', type=int, default=0)
 ap.add_argument('--lss', default='tile')
 ap.add_argument('--lss-group', type=int, default=2)
@@ -31,8 +31,10 @@ dev = torch.device('cuda:0')
 cfg = synthetic.CONFIGS['cfg2_6cam_2frame_bev200x200_render_hoa']
 hp = hotpath.HotPath(cfg, dev, ht_pool_backend=a.ht, render_mode=a.render_mode, fuse_frames=bool(a.fuse), render_streams=a.rstreams, lss_pool_backend=a.lss, lss_mfma_group=a.lss_group,
                      blend_workgroups=('auto' if a.bw == 'auto' else (int(a.bw) if ',' not in a.bw else [int(x) for x in a.bw.split(',')])))
-hp.hoa_first = bool(a.hoa_first)
-hp.render_on_caller_stream = bool(a.caller)
+if a.hoa_first is not None:
+    hp.hoa_first = bool(a.hoa_first)
+if a.caller is not None:
+    hp.render_on_caller_stream = bool(a.caller)
 hp.hoa_stream = bool(a.hoa_stream)
 depth, feat = hp.make_inputs(0)
 for _ in range(30):
