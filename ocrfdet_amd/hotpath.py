@@ -466,6 +466,10 @@ class HotPath:
             for t in main:
                 t.record_stream(cur)      # allocated on the branch, handed to the caller's stream
             return tuple(main[:2]) + (rendered,) + tuple(main[2:])
+        plans = self._plans() if (self.cfg.render and self.render_mode == 'planned') else []
+        if (getattr(self, 'schedule', 'overlap') == 'phased' and len(plans) == 1
+                and self.render_guard == 'host' and self.index_prep_mode == 'cached'):
+            return self._step_phased(depth, feat, plans[0], cur)
         # "the main chain is running": the persistent blends of the render stream keep to two workgroups per CU
         # while it is up and take the whole chip once it is down (cfg4: the renders outlast the poolings + HOA)
         self._set_busy(1)
@@ -480,6 +484,51 @@ class HotPath:
         for side in self._side:
             cur.wait_stream(side)                 # join: everything the step returns is ordered on `cur`
         return tuple(main[:2]) + (rendered,) + tuple(main[2:])
+
+    def _step_phased(self, depth, feat, entry, cur):
+        """The step in two phases instead of two free-running chains.  The poolings are latency-bound and live on
+        occupancy (five 96-VGPR waves per SIMD): beside the persistent blend (118 VGPRs per wave) a SIMD holds two of
+        them and they take 2.5 x as long (LSS 37 -> 97 us, HT 30 -> 74 us in the round-4 timeline), which made them the
+        step's critical chain.  So: phase 1 = the poolings alone on the chip, with only the memory-bound plan update
+        beside them (side stream); phase 2 = the VALU-bound blend on three workgroups per CU (where it saturates:
+        144 us vs 180 us on two) with the small HOA kernels beside it.  One extra event: the blend waits for the
+        poolings.  MEASURED SLOWER than the two free-running chains at cfg2 (0.270 vs 0.255 ms, tools/sweep_r4.sh; HOA-1/2
+        on a third stream 0.30): the ten small HOA launches crawl beside a three-workgroup-per-CU blend.  Kept as
+        ``hp.schedule = 'phased'`` for the A/B, not used by default."""
+        side = shared_stream(self.device, 'render')
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            upd = self._render_planned(entry, phase='update')
+        hoa_side = None
+        ob = None
+        if self.cfg.hoa and getattr(self, 'hoa_stream', False):
+            # HOA-1/2 read nothing of the poolings: eight small kernels on a stream of their own, beside phase 1
+            hoa_side = shared_stream(self.device, 'hoa')
+            hoa_side.wait_stream(cur)
+            with torch.cuda.stream(hoa_side):
+                ob = self.hoa_opacity_bev()
+        lss, ht = self.pool_step(depth, feat, None)
+        pooled = torch.cuda.Event()
+        pooled.record(cur)
+        side.wait_event(pooled)
+        bw_was = self.blend_workgroups
+        if bw_was == 'auto':
+            self.blend_workgroups = 3 * torch.cuda.get_device_properties(self.device).multi_processor_count
+        try:
+            with torch.cuda.stream(side):
+                rendered = self._render_planned(entry, phase='blend', out=upd)
+        finally:
+            self.blend_workgroups = bw_was
+        out = [lss, ht, rendered]
+        if self.cfg.hoa:
+            if hoa_side is not None:
+                cur.wait_stream(hoa_side)
+                ob.record_stream(cur)
+            else:
+                ob = self.hoa_opacity_bev()
+            out.extend(self.hoa_step(ht, ob))
+        cur.wait_stream(side)
+        return tuple(out)
 
     def _main_chain(self, depth, feat):
         """Pools + HOA on the current stream -> (lss, ht[, gated, opacity_bev])."""

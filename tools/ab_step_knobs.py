@@ -22,6 +22,7 @@ ap.add_argument('--caller', type=int, default=None, help='render chain on the ca
 ap.add_argument('--hoa-stream', type=int, default=0)
 ap.add_argument('--lss', default='tile')
 ap.add_argument('--lss-group', type=int, default=2)
+ap.add_argument('--schedule', default=None, help='phased | overlap (default: what HotPath chooses)')
 ap.add_argument('--bw', default='auto', help="blend workgroups: auto | n | n0,n1 (per frame)")
 a = ap.parse_args()
 for kv in a.knobs:
@@ -33,6 +34,8 @@ hp = hotpath.HotPath(cfg, dev, ht_pool_backend=a.ht, render_mode=a.render_mode, 
                      blend_workgroups=('auto' if a.bw == 'auto' else (int(a.bw) if ',' not in a.bw else [int(x) for x in a.bw.split(',')])))
 if a.hoa_first is not None:
     hp.hoa_first = bool(a.hoa_first)
+if a.schedule is not None:
+    hp.schedule = a.schedule
 if a.caller is not None:
     hp.render_on_caller_stream = bool(a.caller)
 hp.hoa_stream = bool(a.hoa_stream)
@@ -49,4 +52,4 @@ for _ in range(5):
     ts.append((time.perf_counter() - t0) / a.steps * 1e3)
 hp.check_render_plans()
 ts.sort()
-print([round(t,4) for t in ts], end=" "); print(f'{" ".join(a.knobs) or "defaults":20s} ht={a.ht} render={a.render_mode} fuse={a.fuse} rstreams={a.rstreams} bw={a.bw} caller={a.caller} hoa_first={a.hoa_first} hoa_stream={a.hoa_stream} lss={a.lss}/{a.lss_group}: median {ts[2]:.4f} min {ts[0]:.4f} max {ts[-1]:.4f} ms/step', flush=True)
+print([round(t,4) for t in ts], end=" "); print(f'{" ".join(a.knobs) or "defaults":20s} ht={a.ht} render={a.render_mode} fuse={a.fuse} rstreams={a.rstreams} bw={a.bw} schedule={a.schedule} caller={a.caller} hoa_first={a.hoa_first} hoa_stream={a.hoa_stream} lss={a.lss}/{a.lss_group}: median {ts[2]:.4f} min {ts[0]:.4f} max {ts[-1]:.4f} ms/step', flush=True)
