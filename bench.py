@@ -16,8 +16,10 @@ N > 1 (`--shard`):
       world / n_frames ranks per frame with the frame's cameras dealt over it); partial fused BEVs are summed by
       a reduce_scatter inside each frame group and ONE world all_gather leaves the fused grid everywhere, both
       asynchronous beside the renders and HOA-1/2; HOA-3 replicated.  Strong scaling (the sample is fixed).
-      The same line carries `samples_layout`: every rank a whole sample (the reference's DDP layout, no
-      data-path collective), weak scaling, timed right after.
+      The same line carries `pipelined_camera_frames`: the same split with step k's collectives run on a
+      communication stream under step k + 1's poolings and renders (outputs one step late; strong scaling, the form
+      of this split that is not bound by its own exchange latency), and `samples_layout`: every rank a whole sample
+      (the reference's DDP layout, no data-path collective), weak scaling; both timed right after.
   samples — only that weak-scaling layout;  frames — one (world x n_frames)-frame sequence, one all_gather;
   cameras — round 1's layout: cameras over min(world, n_cams) ranks, one dense all_reduce.
 """
@@ -694,6 +696,28 @@ def main():
             per_sample['plan_rebuilt_per_step'] = r_pl
             del h_pl, plans4
         per_sample['per_sample_ms'] = min(x for r in list(per_sample.values()) for x in (r['eager_ms'], r.get('graph_ms')) if x)
+    # ---- the sharded default with its exchange pipelined ACROSS steps (step k's collectives under step k + 1's
+    # poolings and renders; outputs one step late): the form of the camera-frame split that can scale ----------
+    pipelined_layout = None
+    if shard == 'camera_frames' and sp is not None:
+        try:
+            for _ in range(min(args.warmup, 5)):
+                sp.step_pipelined(sp_inputs)
+            sp.flush_pipelined()
+
+            def run_pipelined():
+                sp.step_pipelined(sp_inputs)
+            ep = timed(run_pipelined, args.steps, world, dev)
+            sp.flush_pipelined()
+            pipelined_layout = {'value': sp.bev_voxels_per_step * args.steps / ep, 'unit': 'BEV voxels/s',
+                                'rendered_views_per_sec': cfg.batch * cfg.n_frames * cfg.n_cams * args.steps / ep,
+                                'ms_per_step': 1e3 * ep / args.steps, 'scaling': 'strong',
+                                'latency_steps': 2,
+                                'sharding': 'camera-frames over all ranks as in the headline; step k\'s reduce_scatter + '
+                                            'all_gather run on a communication stream under step k + 1\'s poolings and '
+                                            'renders (two buffer sets); HOA-3 and the outputs of a step come one call late'}
+        except Exception as e:       # noqa: BLE001
+            pipelined_layout = {'error': f'{type(e).__name__}: {e}'[:300]}
     # ---- weak-scaling secondary of the sharded default: every rank a whole sample ---------------------------
     samples_layout = None
     if shard == 'camera_frames':
@@ -869,6 +893,8 @@ def main():
             out['pools'] = pools
         if samples_layout is not None:
             out['samples_layout'] = samples_layout
+        if pipelined_layout is not None:
+            out['pipelined_camera_frames'] = pipelined_layout
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(hp, depth, feat, args.cpu_seconds)
             out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']

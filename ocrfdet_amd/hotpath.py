@@ -698,6 +698,57 @@ class ShardedHotPath:
             cur.wait_stream(self._side)
         return full, rendered, gated, opacity_bev
 
+    def step_pipelined(self, inputs):
+        """The same step with the exchange taken off its critical path (``sharding.PipelinedExchange``): this call pools
+        and renders step k and starts its exchange on a communication stream; it RETURNS step k - 1 — (fused BEV, rendered
+        list, gated, opacity_bev) as ``step`` does, ``None`` for the first call — whose exchange ran under this call's
+        poolings and renders.  ``flush_pipelined()`` hands out the last step.  A rank's throughput is then
+        max(own compute, exchange) instead of their sum; the price is one step of latency, and the returned tensors of
+        step k - 1 are overwritten two calls later."""
+        from . import sharding
+        if getattr(self, 'pipe', None) is None:
+            self.pipe = sharding.PipelinedExchange(self.plan, self.rank, self.device, (self.exchange.Y, self.exchange.X),
+                                                   first=self.exchange)
+            self._held = None
+        pipe = self.pipe
+        cur = torch.cuda.current_stream(self.device) if self._side is not None else None
+        rendered = []
+        if self._side is not None:
+            self._set_busy(1)
+            self._side.wait_stream(cur)
+            for f, sub in self.subs.items():
+                rendered.append(sub.render([self._side]))
+        for f, sub in self.subs.items():
+            depth, feat = inputs[f]
+            tgt = pipe.pool_target(f)
+            sub.pool(sub.lss, depth, feat, out=tgt[:self.planes_lss])
+            sub.pool(sub.ht, depth, feat, out=tgt[self.planes_lss:])
+        full_prev = pipe.submit()                  # step k's collectives start; step k - 1's grid is complete
+        opacity_bev = self.base.hoa_opacity_bev() if self.base is not None else None
+        held, self._held = self._held, (rendered, opacity_bev)
+        out = self._finish_pipelined(full_prev, held)
+        if self._side is not None:
+            self._set_busy(0)
+            cur.wait_stream(self._side)
+        return out
+
+    def flush_pipelined(self):
+        """-> the last step submitted by ``step_pipelined`` (None if nothing is pending)."""
+        if getattr(self, 'pipe', None) is None:
+            return None
+        held, self._held = self._held, None
+        return self._finish_pipelined(self.pipe.flush(), held)
+
+    def _finish_pipelined(self, full, held):
+        if full is None or held is None:
+            return None
+        rendered, opacity_bev = held
+        gated = None
+        if self.base is not None:
+            gated = [self.base.hoa_step(full[f:f + 1, self.planes_lss:], opacity_bev[f:f + 1])[0]
+                     for f in range(self.n_frames)]
+        return full, rendered, gated, opacity_bev
+
     def _set_busy(self, value):
         if self._busy is not None:
             _lib.check(_lib.lib().ocrf_stream_write_value32(_lib.ptr(self._busy), int(value), _lib.stream_ptr(self.device)),

@@ -31,7 +31,8 @@ import torch
 import torch.distributed as dist
 
 __all__ = ['assign_units', 'choose_policy', 'frames_of_rank', 'cams_of_rank', 'reduce_partial_bev',
-           'gather_frames', 'CameraFramePlan', 'BevExchange', 'Collectives', 'GlooCollectives', 'GlooEmulation']
+           'gather_frames', 'CameraFramePlan', 'BevExchange', 'PipelinedExchange', 'Collectives', 'GlooCollectives',
+           'GlooEmulation']
 
 
 def choose_policy(n_frames, world_size):
@@ -214,17 +215,21 @@ class BevExchange:
     divisible by the group size) the all_gather runs IN PLACE on ``full``; otherwise through a staging slot per rank.
     Process groups are created collectively by every rank in the same order (constructor)."""
 
-    def __init__(self, plan, rank, device, plane_shape, dtype=torch.float32, collectives=None):
+    def __init__(self, plan, rank, device, plane_shape, dtype=torch.float32, collectives=None, share=None):
+        """``share``: another ``BevExchange`` of the same plan whose process groups (and in-place-gather verdict) this one
+        reuses instead of creating its own — a second set of BUFFERS on the same communicators (``PipelinedExchange``)."""
         self.plan, self.rank, self.device = plan, rank, torch.device(device)
         self.Y, self.X = plane_shape
         self.active = dist.is_initialized() and plan.world > 1
         self.backend = dist.get_backend() if self.active else None
         if collectives is None:
-            collectives = GlooCollectives() if self.backend == 'gloo' else Collectives()
+            collectives = share.c if share is not None else (GlooCollectives() if self.backend == 'gloo' else Collectives())
         self.c = collectives
         self.groups = {}
         self.ctrl = None
-        if self.active:
+        if share is not None:
+            self.groups, self.ctrl = share.groups, share.ctrl
+        elif self.active:
             # control plane: a gloo group of its own for host-side agreement (flags, index lists), so that a verdict about
             # a data-path collective never travels over the communicator that collective may just have failed on
             self.ctrl = dist.new_group(backend='gloo')
@@ -253,7 +258,7 @@ class BevExchange:
         else:
             self.send = torch.zeros(self.slot, self.Y, self.X, **kw)
             self.recv = torch.empty(W * self.slot, self.Y, self.X, **kw)
-        if self.direct and self.active and not self._in_place_gather_works():
+        if self.direct and self.active and not (share.direct if share is not None else self._in_place_gather_works()):
             self.direct = False                  # staged gather: one extra copy of the grid, always valid
             self.send = torch.zeros(self.slot, self.Y, self.X, **kw)
             self.recv = torch.empty(W * self.slot, self.Y, self.X, **kw)
@@ -335,6 +340,12 @@ class BevExchange:
         off, p0, n = self._my_block(f)
         assert p0 == 0 and n == P
         return self.send[off:off + n]
+
+    def adopt_touched(self, other):
+        """Take over another exchange's (same plan, same rank) touched-tile lists without a second collective."""
+        self.touched = {f: [t.clone() for t in ts] for f, ts in other.touched.items()}
+        self._flat = {f: [self._voxels_of_tiles(t) for t in ts] for f, ts in self.touched.items()}
+        self._account()
 
     def set_touched(self, touched):
         """Switch step 1 to the wedge-sparse form.  ``touched``: {frame: 1-D int64 tensor of the tile indices
@@ -434,3 +445,82 @@ class BevExchange:
                     self.full[f, p0:p0 + n].copy_(slots[r if self.active else 0, off[r]:off[r] + n])
                 off[r] += self.plan.cap_of_frame[f] if len(self.plan.group_of_frame[f]) > 1 else n
         return self.full
+
+
+class PipelinedExchange:
+    """The camera-frame exchange taken OFF a step's critical path: step k's two collectives run on a communication
+    stream while step k + 1 pools and renders; the caller receives step k's complete fused grid one call later.
+
+        pipe = PipelinedExchange(plan, rank, device, (Y, X))
+        for every step k:
+            pool the owned camera-frames of step k into pipe.pool_target(f)
+            full_prev = pipe.submit()        # starts step k's exchange; -> step k - 1's fused grid (None at k = 0)
+            ... consume full_prev (HOA-3, BEV encoder) before the NEXT submit ...
+        full_last = pipe.flush()
+
+    Why: inside a step the exchange is latency (reduce_scatter + all_gather over xGMI: ~ 0.1-0.2 ms by the cost model
+    of DESIGN 6) that nothing of the SAME step can hide — the pooled BEV is the last thing the poolings produce and the
+    first thing HOA-3 needs — so a strong-scaled step is pools / G + exchange + HOA-3 and barely beats one GPU.  Across
+    steps the dependency is gone: a rank's throughput becomes max(own compute, exchange) at the price of one step of
+    latency on the fused grid (renders and HOA-1/2 of step k are returned with it).  Two buffer sets alternate; both
+    ride on the same process groups.  On the CPU (gloo tests) the collectives complete inside ``submit``: same
+    results, no overlap."""
+
+    def __init__(self, plan, rank, device, plane_shape, dtype=torch.float32, collectives=None, first=None):
+        """``first``: an existing ``BevExchange`` of this plan to use as buffer set 0 (its process groups are shared)."""
+        if first is None:
+            first = BevExchange(plan, rank, device, plane_shape, dtype=dtype, collectives=collectives)
+        self.slots = [first, BevExchange(plan, rank, device, plane_shape, dtype=dtype, share=first)]
+        if first.touched:
+            self.slots[1].adopt_touched(first)
+        self.plan, self.rank, self.device = plan, rank, torch.device(device)
+        self.k = 0
+        self._pending = None                     # (full, event or None) of the step whose exchange is in flight
+        self._comm = torch.cuda.Stream(self.device) if self.device.type == 'cuda' else None
+
+    @property
+    def active(self):
+        return self.slots[0].active
+
+    @property
+    def current(self):
+        return self.slots[self.k % 2]
+
+    def set_touched(self, touched):
+        """World collective (once): the wedge-sparse step 1 for both buffer sets."""
+        self.slots[0].set_touched(touched)
+        self.slots[1].adopt_touched(self.slots[0])
+
+    def pool_target(self, f):
+        return self.current.pool_target(f)
+
+    def submit(self):
+        """Start the exchange of the step just pooled (its buffers must not be written again before the call after
+        next); -> the previous step's complete fused grid ``(n_frames, P, Y, X)`` ordered on the caller's stream, or
+        None for the first step.  The returned tensor is overwritten by the exchange two submits later."""
+        ex = self.current
+        if self._comm is not None:
+            cur = torch.cuda.current_stream(self.device)
+            self._comm.wait_stream(cur)                       # the poolings of this step
+            with torch.cuda.stream(self._comm):
+                full = ex.finish(ex.start())
+                done = torch.cuda.Event()
+                done.record(self._comm)
+        else:
+            full, done = ex.finish(ex.start()), None
+        prev, self._pending = self._pending, (full, done)
+        self.k += 1
+        return self._take(prev)
+
+    def flush(self):
+        """-> the fused grid of the last submitted step (None if there is none)."""
+        prev, self._pending = self._pending, None
+        return self._take(prev)
+
+    def _take(self, pending):
+        if pending is None:
+            return None
+        full, done = pending
+        if done is not None:
+            torch.cuda.current_stream(self.device).wait_event(done)
+        return full

@@ -114,3 +114,28 @@ def test_cfg2_rank_of_six_partial_grid_and_renders_at_full_size(cuda, oracle_lib
         for k in ('color', 'depth', 'final_T'):
             assert torch.equal(got[k], ref[k]), k
         sub.check_render_plans()
+
+
+def test_pipelined_step_returns_the_previous_step(cuda):
+    """``ShardedHotPath.step_pipelined`` (exchange taken off the step's critical path, outputs one call late): at world 1
+    the first call returns None, every later call the previous step — equal to ``step`` on the same inputs bit for bit,
+    for two different input sets alternating (the two buffer sets) — and ``flush_pipelined`` the last one."""
+    cfg = synthetic.PathConfig(**{**synthetic.CONFIGS['cfg0_1cam_128x352_bev64x64x4'].__dict__, 'name': 'small4cam_hoa',
+                                  'n_cams': 4, 'n_frames': 2, 'render': True, 'hoa': True})
+    sp = hotpath.ShardedHotPath(cfg, cuda, 0, 1)
+    ins = [sp.make_inputs(seed=s) for s in (1, 2)]
+    want = []
+    for i in range(2):
+        full, rendered, gated, ob = sp.step(ins[i])
+        want.append((full.clone(), [r[0]['color'].clone() for r in rendered], [g.clone() for g in gated], ob.clone()))
+    assert not torch.equal(want[0][0], want[1][0])
+    got = [sp.step_pipelined(ins[k % 2]) for k in range(4)]
+    got.append(sp.flush_pipelined())
+    assert got[0] is None and sp.flush_pipelined() is None
+    for k in range(1, 5):
+        full, rendered, gated, ob = got[k]
+        w = want[(k - 1) % 2]
+        torch.cuda.synchronize()
+        assert torch.equal(full, w[0]) and torch.equal(ob, w[3])
+        assert all(torch.equal(a, b) for a, b in zip(gated, w[2]))
+        assert all(torch.equal(r[0]['color'], c) for r, c in zip(rendered, w[1]))

@@ -191,3 +191,68 @@ def test_two_rank_gloo_exchange_matches_single_process():
         assert err_cam <= 1e-4, f'rank {rank}: camera-sharded reduce differs by {err_cam}'
         assert err_frame == 0.0, f'rank {rank}: frame gather differs'
         assert shape[0] == 2
+
+
+def _worker_pipe(rank, world, port, q, n_frames, mode):
+    """PipelinedExchange over gloo: three steps with different inputs; step k's fused grid arrives at submit k + 1 (the
+    last one at flush) and equals the single-process pools of step k."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), OMP_NUM_THREADS='1')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        n_cams = 4
+        cfg = synthetic.PathConfig(**{**synthetic.CONFIGS['cfg0_1cam_128x352_bev64x64x4'].__dict__, 'n_cams': n_cams,
+                                      'n_frames': n_frames})
+        X, Y, Z = cfg.bev_xyz
+        P = cfg.channels * Z
+        plan = sharding.CameraFramePlan(n_cams, n_frames, world, P)
+        coll = sharding.GlooEmulation() if 'rccl_paths' in mode else None
+        pipe = sharding.PipelinedExchange(plan, rank, 'cpu', (Y, X), collectives=coll)
+        errs, got_steps = [], []
+
+        def check(full, step):
+            want = [torch.from_numpy(_pool_cams(cfg, list(range(n_cams)), seed=f + 10 * step)) for f in range(n_frames)]
+            errs.append(max(float((full[f] - want[f]).abs().max()) for f in range(n_frames)))
+            got_steps.append(step)
+        n_steps = 3
+        for it in range(n_steps):
+            touched = {}
+            for f in plan.frames_of(rank):
+                part, rb = _pool_cams(cfg, plan.cams_of(rank, f), seed=f + 10 * it, want_ranks=True)
+                pipe.pool_target(f).copy_(torch.from_numpy(part))
+                touched[f] = torch.unique(pipe.current.tile_of_voxel(torch.from_numpy(rb.astype(np.int64) % (Y * X))))
+            if mode.startswith('sparse') and it == 0:
+                pipe.set_touched(touched)          # (the synthetic rig is static: the lists of step 0 hold for every step)
+            prev = pipe.submit()
+            assert (prev is None) == (it == 0)
+            if prev is not None:
+                check(prev, it - 1)
+        check(pipe.flush(), n_steps - 1)
+        assert pipe.flush() is None
+        q.put((rank, max(errs), got_steps, plan.describe()))
+    except Exception as e:      # report instead of leaving the parent to time out
+        q.put((rank, repr(e), None, None))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('world,n_frames,mode', [(2, 2, 'gloo'), (2, 1, 'rccl_paths'), (4, 2, 'rccl_paths'),
+                                                 (6, 2, 'sparse_rccl_paths'), (8, 2, 'sparse_rccl_paths'), (3, 2, 'sparse')])
+def test_pipelined_exchange_over_three_steps_matches_single_process(world, n_frames, mode):
+    """The cross-step pipelined form of the camera-frame exchange (two buffer sets on one set of process groups): over
+    three consecutive steps every step's fused grid — delivered one submit late — equals the unsharded pools at 1e-4."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 27000 + (os.getpid() * 11 + world * 17 + n_frames + len(mode) * 103) % 3000
+    procs = [ctx.Process(target=_worker_pipe, args=(r, world, port, q, n_frames, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, err, steps, desc in res:
+        assert not isinstance(err, str), f'rank {rank} failed: {err}'
+        assert err <= 1e-4, f'rank {rank}: pipelined fused BEV differs by {err} ({desc})'
+        assert steps == [0, 1, 2]
