@@ -105,10 +105,6 @@ def cpu_baseline(hp, depth, feat, budget_s):
     import numpy as np
     import oracle
     oracle.build()
-    # a one-GPU box hands this process a share of the host (16 cores here), not all the cores the node shows: more
-    # OpenMP threads than that only oversubscribe it (measured: 128 threads render a view slower than one)
-    share = int(os.environ.get('OCRF_CPU_THREADS', 0)) or min(len(os.sched_getaffinity(0)), 16)
-    oracle.set_num_threads(min(oracle.num_threads(), share))
     d, f = depth.cpu().numpy(), feat.cpu().numpy()
     plans = []
     for p in (hp.lss, hp.ht):
@@ -117,7 +113,24 @@ def cpu_baseline(hp, depth, feat, budget_s):
     def pools():
         for rd, rf, rb, st, ln, shape in plans:
             oracle.bev_pool_v2(d, f, rd, rf, rb, shape, st, ln)     # includes the wrapper's permute
-    pools()                                                          # warm-up
+    # Thread count: the comparator gets the BEST of what this process may use — every core of its affinity set, and the
+    # 16-core share a one-GPU box of this pool really hands out (on such a box the node shows 128+ cores but more threads
+    # than the share only oversubscribe it: 128 threads rendered a view slower than one).  OCRF_CPU_THREADS pins it.
+    max_threads = oracle.num_threads()
+    affinity = len(os.sched_getaffinity(0))
+    pinned = int(os.environ.get('OCRF_CPU_THREADS', 0))
+    candidates = [pinned] if pinned else sorted({min(max_threads, affinity), min(max_threads, affinity, 16)})
+    tried = {}
+    for c in candidates:
+        oracle.set_num_threads(c)
+        pools()                                                      # warm-up
+        t0 = time.perf_counter()
+        reps = 0
+        while reps < 3 or time.perf_counter() - t0 < 0.5:
+            pools()
+            reps += 1
+        tried[c] = (time.perf_counter() - t0) / reps
+    oracle.set_num_threads(min(tried, key=tried.get))
     n, t0 = 0, time.perf_counter()
     while True:
         pools()
@@ -170,6 +183,9 @@ def cpu_baseline(hp, depth, feat, budget_s):
         single['ms_per_step'] = single['ms_pools'] + hp.views_per_step * single['ms_per_view'] + 1e3 * frames * t_hoa
         single['value'] = hp.bev_voxels_per_step / (single['ms_per_step'] * 1e-3)
     return dict(value=hp.bev_voxels_per_step / t_step, unit='BEV voxels/s', cores=oracle.num_threads(),
+                threads_tried={str(k): 1e3 * v for k, v in tried.items()},
+                threads_note='OpenMP thread counts tried on the pooling leg (ms per pair of pools): the fastest is used for '
+                             'every leg; affinity set = %d cores' % affinity,
                 cores_note='OpenMP threads of the pooling, of the per-Gaussian / per-tile loops and of the per-tile '
                            'sorts of the tile instances (bucketed by tile first; the histogram pass is one thread); the '
                            'numpy HOA leg uses whatever BLAS threads numpy has',
@@ -583,7 +599,8 @@ def main():
     # device duration of the kernels of interest, HIP events on their launch stream inside the timed region
     t_blend = _lib.KernelTimer(k_blend, 2 * args.steps + 8) if cfg.render else None
     t_pool = _lib.KernelTimer(_lib.K_BEV_POOL_FWD, 2 * (cfg.batch * cfg.n_frames if sp else 1) * args.steps + 8)
-    for t in (t_blend, t_pool):
+    t_mfma = _lib.KernelTimer(_lib.K_BEV_POOL_MFMA, 2 * (cfg.batch * cfg.n_frames if sp else 1) * args.steps + 8)
+    for t in (t_blend, t_pool, t_mfma):
         if t is not None:
             t.arm()
     # K blocks of `steps` steps, each bracketed like the contract says; the reported block is the MEDIAN one
@@ -734,18 +751,39 @@ def main():
         blend_ms = t_blend.mean_ms() if t_blend is not None else None
         pool_ms = t_pool.mean_ms()
         d_numel, f_numel = depth.numel(), feat.numel()
-        pool_alg = 0.5 * (hp.lss.algorithmic_bytes(d_numel, f_numel) + hp.ht.algorithmic_bytes(d_numel, f_numel))
-        pool_c = pmc_counters('bev_pool_tile_kernel', args)
-        pools = {'kernel': t_pool.kernel_name, 'bound': 'hbm',
-                 'launches_per_pool': 1, 'avg_launch_us': 1e3 * pool_ms if pool_ms else None,
-                 'launches_timed': t_pool.count(),
-                 'algorithmic_bytes_per_launch': pool_alg,
-                 'algorithmic_bytes_formula': '4*(B*N*D*H*W + B*N*H*W*C + 3*Np + 2*Nv + B*Z*Y*X*C), mean of the LSS and HT pool (SURVEY 8d)',
-                 'achieved': pool_alg / (pool_ms * 1e-3) / 1e9 if pool_ms else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                 'frac': pool_alg / (pool_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pool_ms else None,
-                 'traffic': hbm_traffic(pool_c), 'traffic_source': PMC_FILE if pool_c else None,
-                 'isolated_avg_launch_us': 1e3 * iso_pool if iso_pool else None,
-                 'isolated_frac': pool_alg / (iso_pool * 1e-3) / 1e9 / HBM_PEAK_GBS if iso_pool else None}
+        # one entry per pooling, each with its OWN algorithmic bytes and its own in-step launch duration: with the
+        # default backends the LSS ranks run the tile kernel (K_BEV_POOL_FWD), the HT ranks the MFMA panels (K_BEV_POOL_MFMA)
+        mfma_ms = t_mfma.mean_ms()
+        lss_on_mfma = getattr(hp, 'lss_pool_backend', 'tile') == 'mfma'
+        ht_on_mfma = getattr(hp, 'ht_pool_backend', 'tile') == 'mfma' and mfma_ms
+
+        def pool_entry(name, plan, kernel, in_step_ms, iso_ms, counters):
+            alg = plan.algorithmic_bytes(d_numel, f_numel)
+            return {'pooling': name, 'kernel': kernel, 'bound': 'hbm', 'algorithmic_bytes_per_launch': alg,
+                    'avg_launch_us': 1e3 * in_step_ms if in_step_ms else None,
+                    'achieved': alg / (in_step_ms * 1e-3) / 1e9 if in_step_ms else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': alg / (in_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if in_step_ms else None,
+                    'isolated_avg_launch_us': 1e3 * iso_ms if iso_ms else None,
+                    'isolated_frac': alg / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if iso_ms else None,
+                    'traffic': hbm_traffic(counters), 'traffic_source': PMC_FILE if counters else None}
+        tile_c, mfma_c = pmc_counters('bev_pool_tile_kernel', args), pmc_counters('bev_pool_mfma_kernel', args)
+        both_tile = not lss_on_mfma and not ht_on_mfma      # one timer, two launches per step: the mean of both
+        pools = {'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBS,
+                 'algorithmic_bytes_formula': '4*(B*N*D*H*W + B*N*H*W*C + 3*Np + 2*Nv + B*Z*Y*X*C) per pooling (SURVEY 8d)',
+                 'lss': pool_entry('LSS (frustum ranks)', hp.lss, 'bev_pool_mfma_kernel<*>' if lss_on_mfma else t_pool.kernel_name,
+                                   mfma_ms if lss_on_mfma else pool_ms, iso_mfma if lss_on_mfma else iso_pool,
+                                   mfma_c if lss_on_mfma else tile_c),
+                 'ht': pool_entry('HT (height-sampling ranks)', hp.ht, 'bev_pool_mfma_kernel<*>' if ht_on_mfma else t_pool.kernel_name,
+                                  mfma_ms if ht_on_mfma else pool_ms, iso_mfma if ht_on_mfma else iso_pool,
+                                  mfma_c if ht_on_mfma else tile_c),
+                 'launches_timed': {'tile': t_pool.count(), 'mfma': t_mfma.count()},
+                 'note': ('both poolings on the tile kernel: its timer holds both launches of a step, the durations above '
+                          'are their mean' if both_tile else
+                          'a kernel timer per backend: the durations are those of the named pooling alone '
+                          '(both on one backend: their mean)')}
+        # (kept for readers of the earlier rounds' lines: the LSS launch under the old top-level keys)
+        pools.update({k: pools['lss'][k] for k in ('kernel', 'avg_launch_us', 'achieved', 'frac', 'traffic',
+                                                     'isolated_avg_launch_us', 'isolated_frac', 'algorithmic_bytes_per_launch')})
         if iso_mfma:
             # the HT pooling on the matrix cores: duration alone on the chip, MFMA counters of the PMC file
             mc = pmc_counters('bev_pool_mfma_kernel', args)
@@ -770,6 +808,31 @@ def main():
             evals = float(sum(int(o['n_contrib'].sum().item()) for o in hp.render(want_n_contrib=True))) / n_launch
             c = pmc_counters('raster_blend_sorted_kernel' if planned else 'raster_blend_kernel<false, false, true, false>', args)
             cycles = blend_ms * 1e-3 * CLOCK_HZ
+            # The planned kernel's OWN count: a wave of it evaluates only the records whose ellipse reaches its 16 x 8
+            # pixel block (fewer than a tile's list up to the stop index, which is what n_contrib counts): the
+            # instrumented build of the same kernel (one extra launch, after the timed region) reports the wave-records
+            # each wave evaluated; x 128 pixels.  The roofline prices THAT work; the reference count stays beside it.
+            reference_evals, executed = evals, None
+            if planned and sp is None:
+                try:
+                    Himg, Wimg = cfg.input_size
+                    tiles = ((Wimg + 15) // 16) * ((((Himg + 15) // 16) + 1) // 2)
+                    executed = 0.0
+                    for entry in hp._plans():
+                        n_wg = tiles * entry[2] * len(hp.cams)
+                        buf = torch.zeros(n_wg * 4 * 8, dtype=torch.int64, device=dev)
+                        torch.cuda.synchronize()
+                        _lib.lib().ocrf_diag_plan_stats(_lib.ptr(buf))
+                        try:
+                            hp._render_planned(entry)
+                            torch.cuda.synchronize()
+                        finally:
+                            _lib.lib().ocrf_diag_plan_stats(None)
+                        executed += float(buf.view(n_wg, 4, 8)[:, :, 6].sum().item()) * 128.0
+                    executed /= n_launch
+                    evals = executed
+                except Exception:       # noqa: BLE001
+                    executed = None
             tfl = BLEND_FLOPS_PER_PIXEL_RECORD * evals / (blend_ms * 1e-3) / 1e12
             traffic = hbm_traffic(c)
             grid_note = None
@@ -783,6 +846,10 @@ def main():
                 'bound': 'valu', 'kernel': t_blend.kernel_name,
                 'achieved': tfl, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tfl / FP32_PEAK_TFLOPS,
                 'flops_per_pixel_record': BLEND_FLOPS_PER_PIXEL_RECORD, 'pixel_records_per_launch': evals,
+                'pixel_records_source': ('executed: wave-records the planned blend evaluated (its instrumented build, one launch '
+                                         'after the timed region) x 128 pixels' if executed is not None else
+                                         'reference: sum over pixels of the contributor index they stopped at (n_contrib)'),
+                'reference_pixel_records_per_launch': reference_evals,
                 'avg_launch_us': 1e3 * blend_ms, 'launches_timed': t_blend.count(),
                 'grid': grid_note,
                 'traffic': traffic, 'traffic_source': (PMC_FILE + ' (' + PMC_META + ' matches this run)') if traffic else None,
@@ -899,7 +966,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(hp, depth, feat, args.cpu_seconds)
             out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
         emit(out)
-    for t in (t_blend, t_pool):
+    for t in (t_blend, t_pool, t_mfma):
         if t is not None:
             t.close()
     if world > 1:
