@@ -838,9 +838,9 @@ def main():
             grid_note = None
             if planned and getattr(hp, 'overlap', False) and getattr(hp, 'blend_workgroups', None) == 'auto':
                 cus = torch.cuda.get_device_properties(dev).multi_processor_count
-                grid_note = {'workgroups_timed_region': 5 * cus // 2, 'workgroups_isolated': _lib.lib().ocrf_diag_plan_resident(),
-                             'note': 'beside the pooling / HOA stream the persistent blend is launched on 2.5 workgroups '
-                                     'per CU of the four the chip holds (DESIGN 5); "frac" prices that partial-occupancy '
+                grid_note = {'workgroups_timed_region': 7 * cus // 2, 'workgroups_isolated': _lib.lib().ocrf_diag_plan_resident(),
+                             'note': 'beside the pooling / HOA stream the persistent blend is launched on 3.5 workgroups '
+                                     'per CU of the five the chip holds (DESIGN 5); "frac" prices that partial-occupancy '
                                      'launch against the whole chip\'s peak, "isolated" is the full grid'}
             roofline = {
                 'bound': 'valu', 'kernel': t_blend.kernel_name,

@@ -419,8 +419,13 @@ __global__ __launch_bounds__(kBlock) void raster_plan_update_kernel(
 // (lx, 8w + r + 4): same x, so dx and the dx-only part of the exponent are shared and the two pixels run as the
 // halves of packed fp32 ops.
 // ---------------------------------------------------------------------------------------------
+#ifdef OCRF_PLAN_WAVES
+#define OCRF_BLEND_BOUNDS __launch_bounds__(kBlock, OCRF_PLAN_WAVES)      // A/B build: waves per SIMD asked of the compiler
+#else
+#define OCRF_BLEND_BOUNDS __launch_bounds__(kBlock)
+#endif
 template <bool MEDIAN, bool WSKIP, bool STATS = false>
-__global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
+__global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(
     unsigned long long* __restrict__ stats, int P, int W, int H, int gx, int gy, int n_items, int vps, long set_stride,
     const int* __restrict__ header, const int* __restrict__ view_sel, const unsigned* __restrict__ s_id,
     const unsigned* __restrict__ s_key, const float2* __restrict__ s_pix, const unsigned* __restrict__ s_e,
@@ -718,11 +723,12 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
           T.x = stop0 ? -fabsf(T.x) : test_T.x;
           T.y = stop1 ? -fabsf(T.y) : test_T.y;
         };
-        // software pipeline, two deep: the records of the NEXT trip and the list entries of the one after it are
-        // requested before this trip's arithmetic (index -> record is two dependent LDS reads; with two workgroups per
-        // CU there are too few waves to hide them otherwise).  The list is padded with no-op entries.
+        // The list is padded with no-op entries (a trip reads TR entries whatever the list's length).
         const unsigned short* mylist = l_list[wave];
         constexpr int TR = kTrip;                // records per trip: independent exponent / alpha chains in flight
+#ifdef OCRF_PLAN_PIPELINE
+        // (A/B build) software pipeline, two deep: the records of the NEXT trip and the list entries of the one after
+        // it are requested before this trip's arithmetic (index -> record is two dependent LDS reads)
         float4 na[TR], nb[TR], nc[TR];
         unsigned fl_next[TR / 2];
         auto fetch = [&](const unsigned* pairs) {
@@ -741,10 +747,26 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
         fetch(pair_next);
 #pragma unroll
         for (int u = 0; u < TR / 2; ++u) pair_next[u] = *reinterpret_cast<const unsigned*>(mylist + TR + 2 * u);
+#endif
         auto trip = [&](auto med_tag, int k) {
           if constexpr (STATS) n_eval += TR;
           float4 ra[TR], rb[TR], rc4[TR];
           unsigned fl[TR / 2];
+#ifndef OCRF_PLAN_PIPELINE
+          // No software pipeline: a trip reads its own records.  Round 3 prefetched the next trip's records and the list
+          // entries of the one after it (24 more VGPRs: 118, four waves per SIMD) because two workgroups per CU left too
+          // few waves to hide the two dependent LDS reads; at 95 VGPRs a SIMD holds FIVE waves, which hide them better
+          // than the prefetch did: 6 views alone 145 -> 132 us, cfg2 step 0.256 -> 0.246 ms (-DOCRF_PLAN_PIPELINE builds
+          // the old form for the A/B; asking the compiler for 6 / 8 waves spills and loses: tools/sweep_r4.sh)
+#pragma unroll
+          for (int u = 0; u < TR / 2; ++u) {
+            const unsigned pair = *reinterpret_cast<const unsigned*>(mylist + k + 2 * u);
+            const int i0 = (int)(pair & 0x1FFu), i1 = (int)((pair >> 16) & 0x1FFu);
+            ra[2 * u] = l_a[i0]; rb[2 * u] = l_b[i0]; rc4[2 * u] = l_c[i0];
+            ra[2 * u + 1] = l_a[i1]; rb[2 * u + 1] = l_b[i1]; rc4[2 * u + 1] = l_c[i1];
+            fl[u] = __builtin_amdgcn_readfirstlane(pair);
+          }
+#else
 #pragma unroll
           for (int u = 0; u < TR; ++u) { ra[u] = na[u]; rb[u] = nb[u]; rc4[u] = nc[u]; }
 #pragma unroll
@@ -752,6 +774,7 @@ __global__ __launch_bounds__(kBlock) void raster_blend_sorted_kernel(
           fetch(pair_next);
 #pragma unroll
           for (int u = 0; u < TR / 2; ++u) pair_next[u] = *reinterpret_cast<const unsigned*>(mylist + k + 2 * TR + 2 * u);
+#endif
 #pragma unroll
           for (int u = 0; u < TR; ++u) {
             const bool simple_rec = (fl[u / 2] >> ((u & 1) ? 31 : 15)) & 1u;

@@ -302,9 +302,10 @@ class HotPath:
         if word is None and self._use_busy():
             word = self._busy
         if bw == 'auto':
-            # beside the other chain: 2.5 workgroups per CU (round 3: 2; the main chain got shorter in round 4 and the
-            # blend is the longer chain now: 512 -> 640 workgroups, cfg2 0.269 -> 0.262 ms)
-            bw = (5 * torch.cuda.get_device_properties(self.device).multi_processor_count // 2
+            # beside the other chain: 3.5 workgroups per CU of the five the chip holds (round 3: 2 of 4 with the 118-VGPR
+            # blend; round 4: the 95-VGPR blend leaves room for the other chain's waves at 3.5 — cfg2 step at 704 / 768 /
+            # 832 / 896 / 960 workgroups: 0.251 / 0.246 / 0.242 / 0.237 / 0.242 ms, tools/sweep_r4.sh)
+            bw = (7 * torch.cuda.get_device_properties(self.device).multi_processor_count // 2
                   if (self.overlap or getattr(self, '_yield_word', None) is not None) else 0)
         elif not isinstance(bw, int):
             bw = int(bw[min(f0, len(bw) - 1)])
@@ -315,7 +316,7 @@ class HotPath:
             call_cams = g['cams']                       # ... and the call is checked against the plan's cameras on the device
         out = plan.render(g['rgb'], g['opacity'], g['scales'], g['rotations'], self.bg, guard=self.render_guard,
                           item_view=g['item_view'] if nf > 1 else None, blend_workgroups=bw, phase=phase, out=out,
-                          yield_if=word if bw else None, cameras=call_cams)
+                          yield_if=word if bw else None, cameras=call_cams, views_disjoint=True)
         if phase == 'update':
             return out
         n = len(self.cams)

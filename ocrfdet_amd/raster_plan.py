@@ -122,19 +122,6 @@ class RasterPlan:
         self._built[0].record(self._built[1])
         return self
 
-    def _views_disjoint(self, item_view, S):
-        """Does every plan view appear at most once among the items?  (One host read per distinct index tensor, cached: the
-        hot path's item list is static.)  Sets then share one copy of the per-call record arrays."""
-        if S == 1:
-            return True
-        if item_view is None:
-            return False                                   # every set renders every view
-        key = (item_view.data_ptr(), item_view._version, int(item_view.numel()))
-        hit = getattr(self, '_disjoint_cache', None)
-        if hit is None or hit[0] != key:
-            self._disjoint_cache = hit = (key, bool(torch.unique(item_view).numel() == item_view.numel()))
-        return hit[1]
-
     def _scratch(self, n_sets):
         need = _lib.lib().ocrf_rasterize_planned_workspace_bytes(ctypes.c_long(self.capacity), n_sets)
         if self._dyn is None or self._dyn.numel() < need:
@@ -145,7 +132,7 @@ class RasterPlan:
     @torch.no_grad()
     def render(self, colors, opacities, scales, rotations, bg, scale_modifier=1.0, depth_mode='median',
                item_view=None, want_radii=False, guard='host', out=None, blend_workgroups=0, phase='both',
-               yield_if=None, cameras=None):
+               yield_if=None, cameras=None, views_disjoint=False):
         """Render ``n_items = len(item_view)`` views: item z = plan view ``item_view[z]`` (int32 device tensor) with
         Gaussian set ``z // (n_items // S)`` of the ``(S, P, .)`` (or ``(P, .)``) parameter tensors; without
         ``item_view`` every set renders all ``V`` plan views in order.
@@ -156,6 +143,9 @@ class RasterPlan:
         ``blend_workgroups`` leave at once while the word is non-zero (a scheduling hint: same image either way).
         ``phase``: 'both', or 'update' then (same arguments, same ``out``) 'blend' — possibly on another stream, ordered by
         the caller's events (``guard='host'`` only).
+        ``views_disjoint``: the caller states that every plan view is rendered by at most ONE set of this call (frames
+        or samples that share a plan, each with its own views): the sets then share one copy of the per-call record
+        arrays, every line of which is written once.  Checked on the device (status bit 8 if two sets name one view).
         ``cameras``: the (V,36) packed cameras this call means to render with (what the reference's ``render`` gets per
         call).  Compared with the plan's on the device: a difference raises status bit 16 and, with
         ``guard='device'``, the call is rendered by the per-call pipeline with these cameras instead."""
@@ -197,9 +187,11 @@ class RasterPlan:
             if radii is None:
                 radii = out['radii'] = torch.empty(n_items, P, dtype=torch.int32, device=dev)
         L = _lib.lib()
-        if self._built[1] != torch.cuda.current_stream(dev):
+        if self._built[1] != torch.cuda.current_stream(dev) and not torch.cuda.is_current_stream_capturing():
+            # (inside a hipGraph capture the build is either part of the capture, on this branch, or long finished: a wait
+            # on an event of a stream outside the capture would drag that stream into it)
             torch.cuda.current_stream(dev).wait_event(self._built[0])
-        disjoint = self._views_disjoint(item_view, S)
+        disjoint = S == 1 or (bool(views_disjoint) and item_view is not None)
         with _lib.on_device(dev):
             dyn = self._scratch(1 if disjoint else S)
             chain = None

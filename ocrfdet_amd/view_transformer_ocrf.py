@@ -966,7 +966,9 @@ class OcRFViewTransformerFull(nn.Module):
             return rasterize_sets(voxel_coor, color, opacity, scaling, rotation, cameras['packed'], H, W, self._bg)
         plan, base = geo.raster_plan
         item_view = (base + cameras['cam_sel'].to(torch.int32)).contiguous()
-        return plan.render(color, opacity, scaling, rotation, self._bg, item_view=item_view, guard='device')
+        # (sample b renders one of ITS OWN N plan views: no view is named by two sets)
+        return plan.render(color, opacity, scaling, rotation, self._bg, item_view=item_view, guard='device',
+                           views_disjoint=True)
 
     def _build_raster_plan(self, geo, voxel_coor, scaling, rotation, B, N, H, W):
         """-> (RasterPlan over the B*N (sample, camera) views, int32 view offsets b*N) or False when the samples do not

@@ -48,3 +48,16 @@ print('blend cycles: slowest wave / mean wave per workgroup %.3f' % (b.max(1).me
 newstop = s[:, :, 7]
 print('records in which some pixel of the wave stops: %.1f per wave = %.3f of the evaluated' % (
     newstop.mean(), newstop.sum() / max(evald.sum(), 1)))
+# wall time of the instrumented launch vs the cycles its workgroups report: effective clock x slot utilisation
+_lib.lib().ocrf_diag_plan_stats(_lib.ptr(buf))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda.synchronize()
+e0.record()
+hp._render_planned(hp.render_plans[0], phase='both')
+e1.record()
+torch.cuda.synchronize()
+_lib.lib().ocrf_diag_plan_stats(None)
+ms = e0.elapsed_time(e1)
+slots = a.grid or int(_lib.lib().ocrf_diag_plan_resident())
+print('instrumented update + blend: %.1f us; sum of workgroup cycles / %d slots = %.0f cycles -> %.2f GHz-equivalents if the slots were busy throughout'
+      % (1e3 * ms, slots, tot.max(1).sum() / slots, tot.max(1).sum() / slots / (1e3 * ms) / 1e3))
