@@ -304,6 +304,7 @@ struct TileArgs {
 
 template <bool STAMP, int kTV>
 __global__ __launch_bounds__(kBlock, 5) void bev_pool_tile_kernel(TileArgs a, unsigned long long* __restrict__ stamps) {
+  OCRF_POOL_PRIO();
   extern __shared__ __attribute__((aligned(16))) int smem[];
   const int tid = threadIdx.x;
   const int c4 = a.c4, gpw = a.gpw, ldq = a.ldq;

@@ -76,6 +76,7 @@ __device__ __forceinline__ float cell_sum_many(const int* __restrict__ rd_sorted
 
 template <int NB, bool STAMP = false>
 __global__ __launch_bounds__(kBlock) void bev_pool_mfma_kernel(MfmaArgs a, unsigned long long* __restrict__ stamps) {
+  OCRF_POOL_PRIO();
   constexpr int C = 16 * NB, c4 = C / 4;
   constexpr int kLdf = C + ((16 - C % 32) + 32) % 32;        // F pitch (floats) = 16 mod 32: conflict-free B reads
   constexpr int ldq = c4 | 1;                                 // output tile pitch in float4

@@ -26,6 +26,7 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __ex
 // (1) mean and max over channels: one thread per pixel, channel loop with coalesced rows.
 __global__ __launch_bounds__(kBlock) void hoa_channel_stats_kernel(const float* __restrict__ x, int C,
                                                                    long plane, float* __restrict__ stats) {
+  OCRF_MAIN_CHAIN_PRIO();
   const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int b = blockIdx.y;
   if (pix >= plane) return;
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(kBlock) void hoa_mask_gate_kernel(
     const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ opacity_bev,
     const float* __restrict__ conv_w, int k_rt, int C, int Y, int X, int groups, int n_rows,
     float* __restrict__ mask, float* __restrict__ gated) {
+  OCRF_MAIN_CHAIN_PRIO();
   const int k = KT ? KT : k_rt;
   const int nt = (int)blockDim.x;              // 256, or fewer for more and shorter workgroups (ocrf_hoa_opacity_mask_gate)
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];      // weights, then 2 planes of n_rows x tw, zero padded
@@ -1000,6 +1002,7 @@ __global__ __launch_bounds__(kBlock) void hoa1_kv_kernel(const float* __restrict
                                                          const float* __restrict__ wts, int Y, int X, int hq, int wq,
                                                          int hk, int wk, float offset_scale,
                                                          float* __restrict__ kvbuf) {
+  OCRF_MAIN_CHAIN_PRIO();
   __shared__ float s_w[kHoaWLds];
   __shared__ float s_tok[36 * kHD];                 // window token (u, v): bilinear sample of the 13 opacity planes
   __shared__ float s_q[36 * kHI];
@@ -1146,6 +1149,7 @@ __device__ __forceinline__ float hoa_dpp(float x) {
 __global__ __launch_bounds__(kBlock) void hoa1_attention_upsample_kernel(
     const float* __restrict__ opacity, const float* __restrict__ kvbuf, const float* __restrict__ wts, int Y, int X,
     int hq, int wq, int nkv, float* __restrict__ out) {
+  OCRF_MAIN_CHAIN_PRIO();
   __shared__ float s_w[kHoaWLds];
   __shared__ __attribute__((aligned(8))) float s_kv[kKvLoads * kBlock * 2];      // [nkv][18], padded to whole trips
   __shared__ float s_tok[kTT * kTT * kHD];

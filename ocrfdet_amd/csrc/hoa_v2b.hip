@@ -191,6 +191,7 @@ __device__ __forceinline__ int lane_row(int lane) { return ((lane >> 4) & 1) * 2
 // producer, concatenated with the gated skip tensor).
 template <int K>
 __global__ __launch_bounds__(kBlock) void hoa_v2b_block_kernel(V2bArgs a) {
+  OCRF_MAIN_CHAIN_PRIO();
   constexpr int MODE = K == 0 ? 0 : (K <= 2 ? 1 : 2);
   constexpr int S0 = K >= 1 ? K - 1 : 0;                         // producer of src0
   constexpr int S1 = K == 3 ? 1 : 0;                             // producer of the skip tensor (K >= 3)
@@ -409,6 +410,7 @@ __global__ __launch_bounds__(kBlock) void hoa_v2b_block_kernel(V2bArgs a) {
 __global__ __launch_bounds__(kBlock) void hoa_v2b_out_kernel(const float* __restrict__ x, const float* __restrict__ pm,
                                                              int tiles, const float* __restrict__ weights, long plane,
                                                              float* __restrict__ out) {
+  OCRF_MAIN_CHAIN_PRIO();
   constexpr int C = 4;
   __shared__ __attribute__((aligned(16))) float s_w[kWLds];
   __shared__ __attribute__((aligned(16))) float s_red[16 * C];

@@ -8,6 +8,21 @@
 
 #include "ocrf_hip.h"
 
+// A latency-bound kernel of the step's main chain may put its waves in front of the render stream's persistent blend in
+// the SIMDs' issue arbitration (priority, then AGE: the blend's waves are always the oldest and always ready).
+// -DOCRF_MAIN_PRIO=n builds it in (A/B, tools/build_variant.sh); measured in round 4: see DESIGN 5.
+#ifdef OCRF_MAIN_PRIO
+#define OCRF_MAIN_CHAIN_PRIO() __builtin_amdgcn_s_setprio(OCRF_MAIN_PRIO)
+#else
+#define OCRF_MAIN_CHAIN_PRIO() ((void)0)
+#endif
+
+#ifdef OCRF_POOL_PRIO_LEVEL
+#define OCRF_POOL_PRIO() __builtin_amdgcn_s_setprio(OCRF_POOL_PRIO_LEVEL)
+#else
+#define OCRF_POOL_PRIO() ((void)0)
+#endif
+
 namespace ocrf {
 
 bool timer_next(int kernel_id, hipEvent_t* start, hipEvent_t* stop);

@@ -1,13 +1,11 @@
 #!/bin/bash
-# round 4: the blend's share of the chip with the 95-VGPR blend; four records per trip
+# round 4: wave priority of the main-chain kernels (A/B in one call, two passes)
 cd "$(dirname "$0")/.."
-for bw in 704 768 832 896 960; do
-  python3 tools/ab_step_knobs.py --bw $bw --steps 100 2>&1 | tail -1 | cut -c1-45,100-112,190-260
+for pass in 1 2; do
+for v in base prio_hoa prio_hoa1 prio_all; do
+  if [ $v = base ]; then unset OCRF_HIP_SO; else export OCRF_HIP_SO=$PWD/_ab/$v/libocrf_hip.so; fi
+  for bw in 896 1024; do
+    echo -n "$v bw=$bw: "; python3 tools/ab_step_knobs.py --bw $bw --steps 200 2>&1 | tail -1 | cut -c1-45,190-260
+  done
 done
-python3 tools/ab_step_knobs.py --bw 768 --hoa-first 1 --steps 100 2>&1 | tail -1 | cut -c1-45,100-112,190-260
-export OCRF_HIP_SO=$PWD/_ab/trip4/libocrf_hip.so
-echo "== trip4"
-python3 tools/chains_r4.py 2>&1 | grep "render chain alone bw=0"
-for bw in 768 896; do
-  python3 tools/ab_step_knobs.py --bw $bw --steps 100 2>&1 | tail -1 | cut -c1-45,100-112,190-260
 done
