@@ -39,8 +39,8 @@ FP32_PEAK_TFLOPS = 157.3        # ibid.: peak FP32 (vector) = 256 CU x 4 SIMD-32
 N_SIMD, CLOCK_HZ = 256 * 4, 2.4e9
 VALU_CYCLES_PER_INST = 2.0      # ibid.: a wave64 VALU op issues over 2 cycles on a SIMD-32
 BLEND_FLOPS_PER_PIXEL_RECORD = 20.0      # blend flops ~= 20 x sum_tiles len x 256
-PMC_FILE = os.path.join('profiles', 'r3_pmc_mean.csv')     # rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh)
-PMC_META = os.path.join('profiles', 'r3_pmc_meta.json')    # what those passes ran: config, flags, hash of csrc/
+PMC_FILE = os.path.join('profiles', 'r4_pmc_mean.csv')     # rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh)
+PMC_META = os.path.join('profiles', 'r4_pmc_meta.json')    # what those passes ran: config, flags, hash of csrc/
 DEFAULT_CONFIG = 'cfg2_6cam_2frame_bev200x200_render_hoa'
 
 
@@ -348,7 +348,7 @@ _PMC_OK = None
 
 def pmc_valid(args):
     """The committed counters are used only for the run they were collected on: same config, same render mode and
-    the same library sources (profiles/r3_pmc_meta.json); anything else reports no traffic / counters."""
+    the same library sources (profiles/r4_pmc_meta.json); anything else reports no traffic / counters."""
     global _PMC_OK
     if _PMC_OK is None:
         _PMC_OK = False
@@ -362,7 +362,7 @@ def pmc_valid(args):
 
 
 def pmc_counters(kernel_prefix, args=None):
-    """Mean per launch of every counter rocprofv3 collected for one kernel (profiles/r3_pmc_mean.csv, written by
+    """Mean per launch of every counter rocprofv3 collected for one kernel (profiles/r4_pmc_mean.csv, written by
     tools/collect_profiles.sh from separate --pmc passes of this command with --no-overlap): {counter: mean}."""
     path = os.path.join(ROOT, PMC_FILE)
     out = {}

@@ -1,11 +1,12 @@
 #!/bin/bash
-# round 4: wave priority of the main-chain kernels (A/B in one call, two passes)
+# bench.py's timed region vs tools/ab_step_knobs.py in one call
 cd "$(dirname "$0")/.."
-for pass in 1 2; do
-for v in base prio_hoa prio_hoa1 prio_all; do
-  if [ $v = base ]; then unset OCRF_HIP_SO; else export OCRF_HIP_SO=$PWD/_ab/$v/libocrf_hip.so; fi
-  for bw in 896 1024; do
-    echo -n "$v bw=$bw: "; python3 tools/ab_step_knobs.py --bw $bw --steps 200 2>&1 | tail -1 | cut -c1-45,190-260
-  done
-done
+for i in 1 2; do
+  timeout -k 5 200 python3 bench.py --no-cpu-baseline --no-per-step 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench 200x5', d['ms_per_step_blocks'])"
+  timeout -k 5 200 python3 bench.py --no-cpu-baseline --no-per-step --steps 20 --warmup 5 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench 20x5 ', d['ms_per_step_blocks'])"
+  timeout -k 5 120 python3 tools/ab_step_knobs.py --steps 200 2>&1 | tail -1 | cut -c1-45,190-260
 done
