@@ -499,6 +499,15 @@ int ocrf_hoa_v2b_weights_len(void);
 size_t ocrf_hoa_v2b_workspace_bytes(int B, int H, int W);
 int ocrf_hoa_v2b_forward(const float *x, const float *position, const float *weights, int B, int H, int W,
                          void *workspace, size_t workspace_bytes, float *out, ocrf_stream_t stream);
+/* out == NULL above DEFERS the output conv: the five block launches leave the gated decoder-1 activations and their
+ * per-tile maxima in `workspace`, and this call — the HOA-3 gate (ocrf_hoa_opacity_mask_gate, k = 7) with the output conv
+ * (view_transformer_ocrf.py:516) folded into its prologue — finishes both: opacity_bev_out (B,1,Y,X) is what
+ * ocrf_hoa_v2b_forward would have written (same bits), mask / gated as ocrf_hoa_opacity_mask_gate.  `v2b_workspace` /
+ * `v2b_weights` are the deferred call's; nothing else may use that workspace in between.  Needs X % 4 == 0, X <= 256,
+ * 16-byte aligned x / stats / gated (else hipErrorInvalidValue: run the two calls separately). */
+int ocrf_hoa_opacity_mask_gate_v2b(const float *x, const float *stats, const void *v2b_workspace,
+                                   const float *v2b_weights, const float *conv_w, int k, int B, int C, int Y, int X,
+                                   float *opacity_bev_out, float *mask, float *gated, ocrf_stream_t stream);
 int ocrf_hoa_height_gate_from_tiles(int B, int C, int hid, int n_tiles, const float *partial_max,
                                     const float *w1, const float *w2, float *gate, ocrf_stream_t stream);
 int ocrf_hoa_gated_conv1x1(const float *x, const float *gate, int B, int C, int H, int W, const float *w,

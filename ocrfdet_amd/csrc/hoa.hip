@@ -13,6 +13,7 @@
 
 #include <algorithm>
 
+#include "hoa_gate.h"
 #include "launch.h"
 #include "ocrf_hip.h"
 
@@ -63,11 +64,20 @@ __global__ __launch_bounds__(kBlock) void hoa_channel_stats_kernel(const float* 
 // FAST (VEC = 4, X <= 256): the statistic rows are staged as 16-byte words, one row = 64 word slots (no index
 // divisions: the generic staging spends ~ 80 integer divisions per thread, more than the convolution), at clamped
 // addresses without a branch; a staged row carries 4 zero columns on the left (3 would do: 4 keeps the words aligned).
-template <int VEC, int KT, bool FAST = false>
+// D1 (with FAST): opacity_bev does not exist yet — it is HOA-2's output conv (view_transformer_ocrf.py:516) of the gated
+// decoder1 activations, folded in here: `d1` (B,4,Y,X) + decoder1's per-tile channel maxima `d1_pm` -> the
+// HeightAttention gate in the prologue (hoa_gate.h), opacity = out_b + sum_c fma(d1_c g_c, out_w_c, .) per pixel in the
+// arithmetic of hoa_v2b_out_kernel; channel group 0 also writes it to `opacity_out`.  One launch (and its ~ 4.5 us floor
+// plus the gap in front of it) less on the step's main chain; same bits.  d1_w: out_w[4], out_b, gate w1[4], w2[4].
+struct MaskGateD1 {
+  const float* d1; const float* pm; const float* out_w; const float* out_b; const float* g_w1; const float* g_w2;
+  float* opacity_out; int tiles;
+};
+template <int VEC, int KT, bool FAST = false, bool D1 = false>
 __global__ __launch_bounds__(kBlock) void hoa_mask_gate_kernel(
     const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ opacity_bev,
     const float* __restrict__ conv_w, int k_rt, int C, int Y, int X, int groups, int n_rows,
-    float* __restrict__ mask, float* __restrict__ gated) {
+    float* __restrict__ mask, float* __restrict__ gated, MaskGateD1 dd) {
   OCRF_MAIN_CHAIN_PRIO();
   const int k = KT ? KT : k_rt;
   const int nt = (int)blockDim.x;              // 256, or fewer for more and shorter workgroups (ocrf_hoa_opacity_mask_gate)
@@ -96,6 +106,21 @@ __global__ __launch_bounds__(kBlock) void hoa_mask_gate_kernel(
 #pragma unroll
       for (int u = 0; u < 5; ++u) first[u] = *reinterpret_cast<const float4*>(pe + (long)(c0_e + u) * plane);
     }
+  }
+  // D1: decoder1's activations of this thread's four pixels, its per-tile maxima and the 13 weights, all in flight now
+  __shared__ __attribute__((aligned(16))) float s_red[16 * 4];
+  __shared__ float s_g[4], s_ow[16];
+  float4 d1v[D1 ? 4 : 1];
+  float4 pmv[hoa_gate::kPmRounds];
+  float owv = 0.f;
+  if constexpr (D1) {
+    const long pc = pix_e < plane ? pix_e : plane - VEC;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) d1v[c] = *reinterpret_cast<const float4*>(dd.d1 + ((long)b * 4 + c) * plane + pc);
+    hoa_gate::pm_issue<4>(dd.pm, b, dd.tiles, (int)threadIdx.x, pmv);
+    const int t = (int)threadIdx.x & 15;                       // out_w[0..3] | out_b | w1[0..3] | w2[0..3]
+    const float* src = t < 4 ? dd.out_w + t : (t == 4 ? dd.out_b : (t < 9 ? dd.g_w1 + (t - 5) : dd.g_w2 + (min(t, 12) - 9)));
+    owv = *src;
   }
   if constexpr (FAST) {
     const int n_items = 2 * n_rows * 64, x4 = X >> 2;
@@ -141,7 +166,18 @@ __global__ __launch_bounds__(kBlock) void hoa_mask_gate_kernel(
     }
   }
   }
+  if constexpr (D1) {
+    if (threadIdx.x < 16) s_ow[threadIdx.x] = owv;
+    hoa_gate::pm_reduce_rows<4>(dd.pm, b, dd.tiles, (int)threadIdx.x, pmv, s_red);
+  }
   __syncthreads();
+  if constexpr (D1) {
+    if (threadIdx.x < 64) {                                   // decoder1's HeightAttention gate (q = hid = 1)
+      const float gt = hoa_gate::gate_of_lane<4>(s_red, s_ow + 5, s_ow + 9, (int)threadIdx.x);
+      if (threadIdx.x < 4) s_g[threadIdx.x] = gt;
+    }
+    __syncthreads();
+  }
   const long pix = p0 + (long)threadIdx.x * VEC;
   if (pix >= plane) return;
   const int yy = (int)(pix / X), xx = (int)(pix % X);
@@ -189,8 +225,21 @@ __global__ __launch_bounds__(kBlock) void hoa_mask_gate_kernel(
       }
   }
   float m[VEC];
+  if constexpr (D1) {
+    const float dv[4][4] = {{d1v[0].x, d1v[0].y, d1v[0].z, d1v[0].w}, {d1v[1].x, d1v[1].y, d1v[1].z, d1v[1].w},
+                            {d1v[2].x, d1v[2].y, d1v[2].z, d1v[2].w}, {d1v[3].x, d1v[3].y, d1v[3].z, d1v[3].w}};
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) m[e] = sigmoidf_(acc[e] + opacity_bev[(long)b * plane + pix + e]);
+    for (int e = 0; e < VEC; ++e) {
+      float o = s_ow[4];                                       // hoa_v2b_out_kernel's arithmetic
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o = fmaf(dv[c][e] * s_g[c], s_ow[c], o);
+      if (g == 0) dd.opacity_out[(long)b * plane + pix + e] = o;
+      m[e] = sigmoidf_(acc[e] + o);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) m[e] = sigmoidf_(acc[e] + opacity_bev[(long)b * plane + pix + e]);
+  }
   if (g == 0) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) mask[(long)b * plane + pix + e] = m[e];
@@ -432,14 +481,45 @@ int ocrf_hoa_opacity_mask_gate(const float* x, const float* stats, const float* 
   if (gated && g_mg_groups > 0) groups = std::min(g_mg_groups, C);
   const dim3 grid((unsigned)((plane + per_wg - 1) / per_wg), 1, (unsigned)(B * groups));
 #define OCRF_MASK_GATE(V, K, F)                                                                                       \
-  ocrf::launch(OCRF_K_HOA_MASK_GATE, hoa_mask_gate_kernel<V, K, F>, grid, dim3(threads), lds, stream, x, stats, opacity_bev, \
-               conv_w, k, C, Y, X, groups, n_rows, mask, gated)
+  ocrf::launch(OCRF_K_HOA_MASK_GATE, hoa_mask_gate_kernel<V, K, F, false>, grid, dim3(threads), lds, stream, x, stats, opacity_bev, \
+               conv_w, k, C, Y, X, groups, n_rows, mask, gated, MaskGateD1{})
   if (fast) OCRF_MASK_GATE(4, 7, true);
   else if (vec4 && k == 7) OCRF_MASK_GATE(4, 7, false);
   else if (vec4) OCRF_MASK_GATE(4, 0, false);
   else if (k == 7) OCRF_MASK_GATE(1, 7, false);
   else OCRF_MASK_GATE(1, 0, false);
 #undef OCRF_MASK_GATE
+  return (int)hipGetLastError();
+}
+
+// HOA-2's output conv folded into the HOA-3 gate (csrc/hoa_v2b.hip: ocrf_hoa_v2b_forward with out == NULL leaves the
+// gated decoder1 activations and their per-tile maxima in its workspace).  Needs the 16-byte path of the gate kernel
+// (k = 7, X a multiple of 4 and <= 256, 16-byte aligned tensors, Y X a multiple of 4); else hipErrorInvalidValue —
+// the caller then runs the two calls separately.
+int ocrf_hoa_opacity_mask_gate_v2b(const float* x, const float* stats, const void* v2b_workspace, const float* v2b_weights,
+                                   const float* conv_w, int k, int B, int C, int Y, int X, float* opacity_bev_out,
+                                   float* mask, float* gated, ocrf_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (!x || !stats || !v2b_workspace || !v2b_weights || !conv_w || !opacity_bev_out || !mask || !gated || k != 7 ||
+      B <= 0 || C <= 0 || Y < 4 || X < 4 || (Y % 4) || (X % 4) || X > 256)
+    return (int)hipErrorInvalidValue;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gated) | reinterpret_cast<uintptr_t>(stats)) & 15u)
+    return (int)hipErrorInvalidValue;
+  MaskGateD1 dd;
+  ocrf::v2b_deferred_pointers(v2b_workspace, v2b_weights, B, Y, X, &dd.d1, &dd.pm, &dd.tiles, &dd.out_w, &dd.out_b,
+                              &dd.g_w1, &dd.g_w2);
+  dd.opacity_out = opacity_bev_out;
+  const long plane = (long)Y * X;
+  const int threads = kBlock, per_wg = threads * 4;        // (the gate prologue's reductions are laid out for 256 threads)
+  const int n_rows = (per_wg + X - 2) / X + 1 + (k - 1);
+  const int tw = X + 8;
+  const size_t lds = (size_t)(((2 * k * k + 3) & ~3) + 2 * n_rows * tw) * sizeof(float);
+  if (lds > 60 * 1024) return (int)hipErrorInvalidValue;
+  int groups = (C >= 40) ? 4 : (C >= 16 ? 2 : 1);
+  if (g_mg_groups > 0) groups = std::min(g_mg_groups, C);
+  const dim3 grid((unsigned)((plane + per_wg - 1) / per_wg), 1, (unsigned)(B * groups));
+  ocrf::launch(OCRF_K_HOA_MASK_GATE, hoa_mask_gate_kernel<4, 7, true, true>, grid, dim3(threads), lds, stream, x, stats,
+               static_cast<const float*>(nullptr), conv_w, k, C, Y, X, groups, n_rows, mask, gated, dd);
   return (int)hipGetLastError();
 }
 

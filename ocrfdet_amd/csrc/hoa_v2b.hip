@@ -25,12 +25,14 @@
 
 #include <type_traits>
 
+#include "hoa_gate.h"
 #include "launch.h"
 #include "ocrf_hip.h"
 
 namespace {
 
-constexpr int kBlock = 256;
+using namespace hoa_gate;
+
 constexpr int kTW = 16, kTH = 4;                 // output tile: 64 pixels = the lanes of a wave
 constexpr int kHW = kTW + 2, kHH = kTH + 2;      // with the 3x3 halo
 constexpr int kHaloN = kHW * kHH;                // 108
@@ -70,110 +72,6 @@ constexpr V2bOffsets kOff = v2b_offsets();
 constexpr int kW4 = kOff.padded / 4;                         // float4 words of the weight vector
 constexpr int kW4PerThread = (kW4 + kBlock - 1) / kBlock;    // 2
 constexpr int kWLds = kW4PerThread * kBlock * 4;              // LDS copy, padded so that every thread stores every word it loaded
-
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
-
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ float dpp_mov(float x) {          // lanes without a source keep their own value
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, ROW_MASK, 0xf, false));
-}
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ float dpp_max(float x) { return fmaxf(x, dpp_mov<CTRL, ROW_MASK>(x)); }
-constexpr int kRowShr = 0x110, kRowBcast15 = 0x142, kRowBcast31 = 0x143;
-
-// maximum over the 64 lanes of a wave; valid in lane 63
-__device__ __forceinline__ float wave_max_to_lane63(float v) {
-  v = dpp_max<kRowShr + 1>(v);
-  v = dpp_max<kRowShr + 2>(v);
-  v = dpp_max<kRowShr + 4>(v);
-  v = dpp_max<kRowShr + 8>(v);                    // lane 15 of every row: the row's maximum
-  v = dpp_max<kRowBcast15, 0xa>(v);               // rows 1, 3 take in lane 15 of rows 0, 2
-  v = dpp_max<kRowBcast31, 0xc>(v);               // rows 2, 3 take in lane 31
-  return v;
-}
-
-__device__ __forceinline__ float4 max4(float4 a, float4 b) {
-  return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
-}
-
-// Per-tile channel maxima of a producer, (tiles, C) floats per batch entry, as 16-byte words: thread t keeps words
-// t, t + 256, ... — its channel quad (word index mod C / 4) is the same in every round because 256 is a multiple of it.
-// kPmRounds words are in flight per thread; maps beyond 256 x 256 take further trips.
-constexpr int kPmRounds = 4;
-template <int C>
-__device__ __forceinline__ void pm_issue(const float* __restrict__ pm, int b, int tiles, int t, float4 (&v)[kPmRounds]) {
-  const float4* p4 = reinterpret_cast<const float4*>(pm) + (long)b * tiles * (C / 4);
-  const int n4 = tiles * (C / 4);
-#pragma unroll
-  for (int u = 0; u < kPmRounds; ++u) {
-    const int idx = u * kBlock + t;
-    v[u] = p4[idx < n4 ? idx : t % (C / 4)];      // a repeated word of the same quad does not change a maximum
-  }
-}
-// ... reduced over the workgroup's threads as far as a 16-lane row goes, then left in s_red[16 rows][C]
-template <int C>
-__device__ __forceinline__ void pm_reduce_rows(const float* __restrict__ pm, int b, int tiles, int t,
-                                               const float4 (&v)[kPmRounds], float* s_red) {
-  float4 m = v[0];
-#pragma unroll
-  for (int u = 1; u < kPmRounds; ++u) m = max4(m, v[u]);
-  const int n4 = tiles * (C / 4);
-  if (n4 > kPmRounds * kBlock) {                  // not at any size OcRFDet uses
-    const float4* p4 = reinterpret_cast<const float4*>(pm) + (long)b * tiles * (C / 4);
-    for (int idx = kPmRounds * kBlock + t; idx < n4; idx += kBlock) m = max4(m, p4[idx]);
-  }
-  constexpr int S = C / 4;                        // lanes S apart hold the same channel quad
-  auto step = [&](auto tag) {
-    constexpr int N = decltype(tag)::value;
-    if constexpr (N >= S && N % S == 0) {
-      m.x = dpp_max<kRowShr + N>(m.x); m.y = dpp_max<kRowShr + N>(m.y);
-      m.z = dpp_max<kRowShr + N>(m.z); m.w = dpp_max<kRowShr + N>(m.w);
-    }
-  };
-  step(std::integral_constant<int, 1>{});
-  step(std::integral_constant<int, 2>{});
-  step(std::integral_constant<int, 4>{});
-  step(std::integral_constant<int, 8>{});
-  const int l16 = t & 15;
-  if (l16 >= 16 - S)                              // the last S lanes of a row: one per quad
-    *reinterpret_cast<float4*>(s_red + (t >> 4) * C + (l16 - (16 - S)) * 4) = m;
-}
-
-// HeightAttention gate (view_transformer_ocrf.py:447-461: global max-pool per channel, per height quarter
-// q -> hid = q -> q without bias, sigmoid) of channel c = lane (clamped) from the row maxima; every lane of the wave
-// runs it (the quarter's maxima come from the neighbouring lanes by quad_perm).  Same arithmetic order as
-// hoa_height_gate_from_tiles_kernel.
-template <int C>
-__device__ __forceinline__ float gate_of_lane(const float* s_red, const float* s_w1, const float* s_w2, int lane) {
-  constexpr int Q = C / 4;
-  const int c = lane < C ? lane : C - 1;
-  float m = s_red[c];
-#pragma unroll
-  for (int r = 1; r < 16; ++r) m = fmaxf(m, s_red[r * C + c]);
-  float mx[Q];
-  if constexpr (Q == 1) {
-    mx[0] = m;
-  } else if constexpr (Q == 2) {
-    mx[0] = dpp_mov<0xA0>(m);                     // quad_perm [0,0,2,2]
-    mx[1] = dpp_mov<0xF5>(m);                     // quad_perm [1,1,3,3]
-  } else {
-    static_assert(Q == 4, "channel counts of the reference converter");
-    mx[0] = dpp_mov<0x00>(m); mx[1] = dpp_mov<0x55>(m); mx[2] = dpp_mov<0xAA>(m); mx[3] = dpp_mov<0xFF>(m);
-  }
-  const int gq = c / Q, o = c % Q;
-  float hid[Q];
-#pragma unroll
-  for (int h = 0; h < Q; ++h) {
-    float acc = 0.f;
-#pragma unroll
-    for (int i = 0; i < Q; ++i) acc = fmaf(s_w1[(gq * Q + h) * Q + i], mx[i], acc);
-    hid[h] = fmaxf(acc, 0.f);
-  }
-  float acc = 0.f;
-#pragma unroll
-  for (int h = 0; h < Q; ++h) acc = fmaf(s_w2[(gq * Q + o) * Q + h], hid[h], acc);
-  return sigmoidf_(acc);
-}
 
 struct V2bArgs {
   const float* src0; const float* src1; const float* pm0; const float* pm1;
@@ -450,6 +348,21 @@ inline int tiles_of(int h, int w) { return ((w + kTW - 1) / kTW) * ((h + kTH - 1
 
 }  // namespace
 
+namespace ocrf {
+void v2b_deferred_pointers(const void* workspace, const float* weights, int B, int H, int W, const float** d1,
+                           const float** pm, int* tiles, const float** out_w, const float** out_b, const float** g_w1,
+                           const float** g_w2) {
+  const int hs[5] = {H, H / 2, H / 4, H / 2, H}, wsz[5] = {W, W / 2, W / 4, W / 2, W};
+  const float* p = static_cast<const float*>(workspace);
+  for (int k = 0; k < 4; ++k) p += (size_t)B * kCout[k] * hs[k] * wsz[k] + (size_t)B * kCout[k] * tiles_of(hs[k], wsz[k]);
+  *d1 = p;
+  *pm = p + (size_t)B * kCout[4] * H * W;
+  *tiles = tiles_of(H, W);
+  *out_w = weights + kOff.out_w; *out_b = weights + kOff.out_b;
+  *g_w1 = weights + kOff.g_w1[4]; *g_w2 = weights + kOff.g_w2[4];
+}
+}  // namespace ocrf
+
 extern "C" {
 
 // length of the packed weight vector ocrf_hoa_v2b_forward reads: the converter's weights in v2b_offsets() order,
@@ -466,12 +379,13 @@ size_t ocrf_hoa_v2b_workspace_bytes(int B, int H, int W) {
 }
 
 // The whole OpacityVoxelToBEVConverter.forward (view_transformer_ocrf.py:497-518) of the architecture OcRFDet
-// instantiates as SIX launches in one call.  x (B,13,H,W), position (B,4,H,W), out (B,1,H,W); H, W multiples of 4;
+// instantiates as SIX launches in one call (FIVE with out == NULL: the output conv is then left to
+// ocrf_hoa_opacity_mask_gate_v2b).  x (B,13,H,W), position (B,4,H,W), out (B,1,H,W); H, W multiples of 4;
 // weights: ocrf_hoa_v2b_weights_len() floats, 16-byte aligned; workspace 16-byte aligned.
 int ocrf_hoa_v2b_forward(const float* x, const float* position, const float* weights, int B, int H, int W,
                          void* workspace, size_t workspace_bytes, float* out, ocrf_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (!x || !position || !weights || !out || !workspace || B <= 0 || B > 65535 || H < 4 || W < 4 || (H % 4) || (W % 4) ||
+  if (!x || !position || !weights || !workspace || B <= 0 || B > 65535 || H < 4 || W < 4 || (H % 4) || (W % 4) ||
       workspace_bytes < ocrf_hoa_v2b_workspace_bytes(B, H, W) ||
       ((reinterpret_cast<uintptr_t>(weights) | reinterpret_cast<uintptr_t>(workspace)) & 15u))
     return (int)hipErrorInvalidValue;
@@ -510,6 +424,7 @@ int ocrf_hoa_v2b_forward(const float* x, const float* position, const float* wei
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
+  if (!out) return 0;        // deferred: the output conv runs inside ocrf_hoa_opacity_mask_gate_v2b (csrc/hoa.hip)
   const long plane = (long)H * W;
   ocrf::launch(OCRF_K_HOA_OUT_CONV, hoa_v2b_out_kernel, dim3((unsigned)((plane + kBlock - 1) / kBlock), B), dim3(kBlock), 0,
                stream, static_cast<const float*>(act[4]), static_cast<const float*>(pm[4]), tiles[4], weights, plane, out);

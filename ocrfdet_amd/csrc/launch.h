@@ -49,5 +49,10 @@ hipError_t zero_async(void* dst, size_t bytes, hipStream_t stream);
 void raster_plan_tune(int key, int value);
 // hoa.hip: keys 20-29
 void hoa_tune(int key, int value);
+// hoa_v2b.hip: where a deferred ocrf_hoa_v2b_forward (out == NULL) left decoder1's activations (B,4,H,W) and per-tile
+// maxima (B,tiles,4) in its workspace, and the output conv / decoder1 gate weights inside the packed weight vector
+void v2b_deferred_pointers(const void* workspace, const float* weights, int B, int H, int W, const float** d1,
+                           const float** pm, int* tiles, const float** out_w, const float** out_b, const float** g_w1,
+                           const float** g_w2);
 
 }  // namespace ocrf

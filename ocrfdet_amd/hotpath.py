@@ -173,7 +173,7 @@ class HotPath:
         self.bev_pos1 = (torch.randn(self.batch, 4, Y, X, generator=g) * 0.1).to(dev)
 
     @torch.no_grad()
-    def hoa_opacity_bev(self):
+    def hoa_opacity_bev(self, defer=False):
         """HOA-1/2 (view_transformer_ocrf.py:1159-1161, 1196): opacity BEV (B,1,Y,X).  Independent of the pooled
         BEV (it reads the Gaussian opacities and the NeRF-branch alpha volume)."""
         cfg = self.cfg
@@ -185,14 +185,23 @@ class HotPath:
             self._opac_flat = torch.stack([fg['opacity'].view(cfg.num_height, Y, X) for fg in self.frame_gauss]) \
                 .reshape(-1, 1).contiguous()
         oa = hoa.hoa1(m['dca'], self._opac_flat, self.alpha_lidar, cfg.num_height, Y, X)
+        if defer and getattr(self, 'fuse_out_conv', False):
+            # HOA-2 one launch short: its output conv runs in the prologue of the HOA-3 gate (hoa_step).  Built, bit-identical
+            # (tests/test_hoa_modules.py) and measured: one launch less, but the gate kernel's longer prologue (decoder1's
+            # tile maxima, two more barriers) in front of its 51 MB stream costs the step more than the launch did —
+            # cfg2 0.2438 / 0.2416 / 0.2452 ms folded against 0.2399 / 0.2414 / 0.2386 separate, three A/B passes in one
+            # session (tools/ab_step_knobs.py --fuse-out).  Off by default.
+            return m['v2b'].forward_deferred(oa, self.bev_pos1)
         return m['v2b'](oa, self.bev_pos1)
 
     @torch.no_grad()
     def hoa_step(self, geom_feat, opacity_bev=None):
         """HOA-1/2/3 (view_transformer_ocrf.py:1159-1161, 1196-1199): -> (gated BEV, opacity BEV)."""
         if opacity_bev is None:
-            opacity_bev = self.hoa_opacity_bev()
+            opacity_bev = self.hoa_opacity_bev(defer=True)
         _, gated = self.hoa_mods['mask'].gate(geom_feat, opacity_bev)
+        if isinstance(opacity_bev, hoa.DeferredOpacityBEV):
+            opacity_bev = opacity_bev.value
         return gated, opacity_bev
 
     def _prepare_render(self, r, convention='corrected', seed=0):
@@ -567,7 +576,7 @@ class HotPath:
         # first.  (Round 4, HOA-1/2 shortened to 55 us: pools first + a 640-workgroup blend 0.262 ms, HOA first + 512
         # workgroups 0.270, tools/sweep_r4.sh.)
         hoa_first = getattr(self, 'hoa_first', self.render_mode != 'planned' or self.index_prep_mode == 'per_step')
-        ob = self.hoa_opacity_bev() if (self.cfg.hoa and hoa_first) else None
+        ob = self.hoa_opacity_bev(defer=True) if (self.cfg.hoa and hoa_first) else None
         hoa_side = None
         if self.cfg.hoa and not hoa_first and getattr(self, 'hoa_stream', False) and self.overlap:
             # HOA-1/2 (eight small kernels) on a stream of their own beside the poolings
@@ -588,7 +597,7 @@ class HotPath:
             torch.cuda.current_stream(self.device).wait_stream(hoa_side)
             ob.record_stream(torch.cuda.current_stream(self.device))
         elif self.cfg.hoa and not hoa_first:
-            ob = self.hoa_opacity_bev()
+            ob = self.hoa_opacity_bev(defer=True)
         out = [lss, ht]
         if self.cfg.hoa:
             # stand-in for geom_feat: the HT BEV has its shape (B,C,Y,X); the fusion convs between

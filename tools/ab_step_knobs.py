@@ -23,6 +23,7 @@ ap.add_argument('--hoa-stream', type=int, default=0)
 ap.add_argument('--lss', default='tile')
 ap.add_argument('--lss-group', type=int, default=2)
 ap.add_argument('--schedule', default=None, help='phased | overlap (default: what HotPath chooses)')
+ap.add_argument('--fuse-out', type=int, default=None, help="HOA-2's output conv inside the HOA-3 gate (1, HotPath default) or as its own launch (0)")
 ap.add_argument('--bw', default='auto', help="blend workgroups: auto | n | n0,n1 (per frame)")
 a = ap.parse_args()
 for kv in a.knobs:
@@ -36,6 +37,8 @@ if a.hoa_first is not None:
     hp.hoa_first = bool(a.hoa_first)
 if a.schedule is not None:
     hp.schedule = a.schedule
+if a.fuse_out is not None:
+    hp.fuse_out_conv = bool(a.fuse_out)
 if a.caller is not None:
     hp.render_on_caller_stream = bool(a.caller)
 hp.hoa_stream = bool(a.hoa_stream)
@@ -52,4 +55,4 @@ for _ in range(5):
     ts.append((time.perf_counter() - t0) / a.steps * 1e3)
 hp.check_render_plans()
 ts.sort()
-print([round(t,4) for t in ts], end=" "); print(f'{" ".join(a.knobs) or "defaults":20s} ht={a.ht} render={a.render_mode} fuse={a.fuse} rstreams={a.rstreams} bw={a.bw} schedule={a.schedule} caller={a.caller} hoa_first={a.hoa_first} hoa_stream={a.hoa_stream} lss={a.lss}/{a.lss_group}: median {ts[2]:.4f} min {ts[0]:.4f} max {ts[-1]:.4f} ms/step', flush=True)
+print([round(t,4) for t in ts], end=" "); print(f'{" ".join(a.knobs) or "defaults":20s} ht={a.ht} render={a.render_mode} fuse={a.fuse} rstreams={a.rstreams} bw={a.bw} fuse_out={a.fuse_out} schedule={a.schedule} caller={a.caller} hoa_first={a.hoa_first} hoa_stream={a.hoa_stream} lss={a.lss}/{a.lss_group}: median {ts[2]:.4f} min {ts[0]:.4f} max {ts[-1]:.4f} ms/step', flush=True)

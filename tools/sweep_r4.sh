@@ -1,12 +1,10 @@
 #!/bin/bash
-# bench.py's timed region vs tools/ab_step_knobs.py in one call
+# round 4: HOA-2's output conv folded into the HOA-3 gate, A/B in one call (two passes)
 cd "$(dirname "$0")/.."
-for i in 1 2; do
-  timeout -k 5 200 python3 bench.py --no-cpu-baseline --no-per-step 2>/dev/null | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench 200x5', d['ms_per_step_blocks'])"
-  timeout -k 5 200 python3 bench.py --no-cpu-baseline --no-per-step --steps 20 --warmup 5 2>/dev/null | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench 20x5 ', d['ms_per_step_blocks'])"
-  timeout -k 5 120 python3 tools/ab_step_knobs.py --steps 200 2>&1 | tail -1 | cut -c1-45,190-260
+run() { timeout -k 5 120 python3 tools/ab_step_knobs.py "$@" --steps 200 2>&1 | tail -1 | cut -c1-45,100-125,200-270; }
+for pass in 1 2 3; do
+  for fo in 1 0; do
+    for bw in 896 1024; do run --fuse-out $fo --bw $bw; done
+  done
 done
+python3 tools/time_hoa.py 2>&1 | grep -v amdgpu
