@@ -756,7 +756,7 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(
           // No software pipeline: a trip reads its own records.  Round 3 prefetched the next trip's records and the list
           // entries of the one after it (24 more VGPRs: 118, four waves per SIMD) because two workgroups per CU left too
           // few waves to hide the two dependent LDS reads; at 95 VGPRs a SIMD holds FIVE waves, which hide them better
-          // than the prefetch did: 6 views alone 145 -> 132 us, cfg2 step 0.256 -> 0.246 ms (-DOCRF_PLAN_PIPELINE builds
+          // than the prefetch did: the 12 views of cfg2 alone 145 -> 136 us, cfg2 step 0.256 -> 0.246 ms (-DOCRF_PLAN_PIPELINE builds
           // the old form for the A/B; asking the compiler for 6 / 8 waves spills and loses: tools/sweep_r4.sh)
 #pragma unroll
           for (int u = 0; u < TR / 2; ++u) {
