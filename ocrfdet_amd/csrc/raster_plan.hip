@@ -377,7 +377,14 @@ __global__ __launch_bounds__(kBlock) void raster_plan_update_kernel(
       const float A[2][3] = {{q0.x, q0.y, q0.z}, {q0.w, q1.x, q1.y}};
       Rect rect = Rect{0, 0, 0, 0};
       int rad = 0;
+      // (No conservative early-out by the Gaussian's own radius bound here, unlike the per-call preprocess: the plan's
+      // static cull already removed what can never be seen, so the test rarely fired and its square root cost every
+      // record; conic_radius_rect finds an empty rect itself, with the same outputs: 16.5 -> 15.6 us per six views.)
+#ifdef OCRF_UPDATE_EARLY_OUT
       if ((!unseen || radii) && !surely_outside(q1.z, q1.w, radius_bound(A, rn), gx, gy)) {
+#else
+      if (!unseen || radii) {
+#endif
         float cov_x, cov_y, cov_z, con_x, con_y, con_z;
         cov2d(A, c3, &cov_x, &cov_y, &cov_z);
         if (conic_radius_rect(cov_x, cov_y, cov_z, q1.z, q1.w, gx, gy, &con_x, &con_y, &con_z, &rad, &rect)) {

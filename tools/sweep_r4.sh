@@ -1,10 +1,9 @@
 #!/bin/bash
-# round 4: HOA-2's output conv folded into the HOA-3 gate, A/B in one call (two passes)
+# round 4: the update kernel without its conservative early-out
 cd "$(dirname "$0")/.."
-run() { timeout -k 5 120 python3 tools/ab_step_knobs.py "$@" --steps 200 2>&1 | tail -1 | cut -c1-45,100-125,200-270; }
-for pass in 1 2 3; do
-  for fo in 1 0; do
-    for bw in 896 1024; do run --fuse-out $fo --bw $bw; done
-  done
+for pass in 1 2; do
+for v in base noearly; do
+  if [ $v = base ]; then unset OCRF_HIP_SO; else export OCRF_HIP_SO=$PWD/_ab/$v/libocrf_hip.so; fi
+  echo -n "$v: "; python3 tools/time_render_plan.py 2>&1 | grep "planned chain"
 done
-python3 tools/time_hoa.py 2>&1 | grep -v amdgpu
+done
