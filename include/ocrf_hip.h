@@ -322,6 +322,26 @@ int ocrf_bev_pool_v2_nchw_mfma(int c, int n_units, const int *units, const int *
                                ocrf_stream_t stream);
 
 /*
+ * The same plan as a latency kernel (csrc/bev_pool_panel.hip): the cells' depth weights are summed by a pre-pass
+ * (ocrf_bev_pool_cell_weights: one thread per cell, up to two cell lists per launch — the LSS and the height-sampling
+ * plan of a step read the same depth tensor; either list may be empty); in the pooling kernel a lane is a voxel slot
+ * (a wave a quarter of the channels) and walks its cells out of LDS: acc = fma(F[r], w(v, r), acc) with rows ascending,
+ * panel after panel — the k order of the MFMA form, bit-identical to it on finite inputs; bitwise reproducible.
+ * Extra plan arrays (device): the cells of a panel are stored VOXEL-major (v ascending, then r —
+ * ocrf_bev_pool_v2_nchw_mfma does not depend on the order inside a panel),
+ *   panel_voff (n_panels x 64)   first cell of voxel slot v, relative to the panel's first cell
+ *   cell_code (n_cells u16)      row slot | voxel slot << 8;     cw (n_cells floats)  the pre-pass's output
+ */
+int ocrf_diag_pool_panel_stamps(unsigned long long *buf); /* diagnostic: per-unit phase cycles of the next C = 80 calls */
+int ocrf_bev_pool_cell_weights(int n_cells0, const int *cells0, const int *rd_sorted0, float *cw0, int n_cells1,
+                               const int *cells1, const int *rd_sorted1, float *cw1, const float *depth,
+                               ocrf_stream_t stream);
+int ocrf_bev_pool_v2_nchw_panel(int c, int n_units, const int *units, const int *unit_slab, const int *panel_rows,
+                                const int *panel_nrows, const int *panel_cell_off, const int *panel_voff,
+                                const unsigned short *cell_code, const float *cw, const float *feat, float *out, int B,
+                                int Z, int Y, int X, int layout, int *arrive, void *slabs, ocrf_stream_t stream);
+
+/*
  * Backward of the colour output of ocrf_rasterize_forward (the w-depth fork has no depth backward,
  * diff-gaussian-rasterization-w-depth/README.md:13).  Replaces RasterizeGaussiansBackwardCUDA
  * (rasterize_points.cu:117-196 -> rasterizer_impl.cu:338-434 -> cuda_rasterizer/backward.cu) for
@@ -670,6 +690,8 @@ enum {
   OCRF_K_BEV_POOL_GRAD = 4,     /* bev_pool_grad_vec_kernel */
   OCRF_K_BEV_POOL_NCHW = 5,     /* (retired: the tile kernel writes the final layout itself) */
   OCRF_K_BEV_POOL_MFMA = 6,     /* bev_pool_mfma_kernel<C / 16> */
+  OCRF_K_BEV_POOL_PANEL = 7,    /* bev_pool_panel_kernel<C / 4> */
+  OCRF_K_BEV_POOL_CELL_WEIGHTS = 8, /* bev_pool_cell_weights_kernel */
   OCRF_K_RASTER_PREPROCESS = 10, /* raster_preprocess_kernel */
   OCRF_K_RASTER_BLEND = 11,      /* raster_blend_kernel */
   OCRF_K_RASTER_GATHER = 12,     /* raster_scatter_kernel */

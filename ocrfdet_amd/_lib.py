@@ -87,6 +87,12 @@ def _declare(L):
     L.ocrf_bev_pool_mfma_slab_bytes.argtypes = [c_int, c_int]
     L.ocrf_bev_pool_v2_nchw_mfma.restype = c_int
     L.ocrf_bev_pool_mfma_max_unit_panels.restype = c_int
+    L.ocrf_diag_pool_panel_stamps.restype = c_int
+    L.ocrf_diag_pool_panel_stamps.argtypes = [c_void_p]
+    L.ocrf_bev_pool_cell_weights.restype = c_int
+    L.ocrf_bev_pool_cell_weights.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    L.ocrf_bev_pool_v2_nchw_panel.restype = c_int
+    L.ocrf_bev_pool_v2_nchw_panel.argtypes = [c_int, c_int] + [c_void_p] * 10 + [c_int] * 5 + [c_void_p] * 3
     L.ocrf_bev_pool_mfma_max_unit_panels.argtypes = []
     L.ocrf_bev_pool_v2_nchw_mfma.argtypes = [c_int, c_int] + [c_void_p] * 10 + [c_int] * 5 + [c_void_p] * 3
     L.ocrf_tune_set.restype = c_int

@@ -320,7 +320,7 @@ class MfmaPoolPlan:
     unique / searchsorted — plan time, not step time); every point of the rank vectors is pooled into
     ``ranks_bev[p]`` (what the reference's intervals amount to when they cover the point list: bev_pool.py:40-57)."""
 
-    def __init__(self, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, group=4):
+    def __init__(self, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, group=4, unit_cost=None):
         _lib.require_cuda(ranks_depth, ranks_feat, ranks_bev)
         B, Z, Y, X, C = (int(v) for v in bev_feat_shape)
         if C not in (64, 80, 96, 128):
@@ -377,6 +377,14 @@ class MfmaPoolPlan:
             cell_end = torch.cat((cell_start[1:], torch.tensor([self.n_points], device=dev)))
             npts = cell_end - cell_start
             code = cell_v | (pair_r[pair_of_cell] << 8)
+            # cells of a panel voxel-major (v, then row slot): bev_pool_panel.hip walks a voxel's cells in row order —
+            # the k order of the MFMA form, which itself does not depend on the order inside a panel
+            vm = torch.argsort((cell_panel * TV + cell_v) * KP + pair_r[pair_of_cell])
+            cell_start, cell_end, npts, code, cell_v = cell_start[vm], cell_end[vm], npts[vm], code[vm], cell_v[vm]
+            # voxel slot v of panel p owns the cells [voff[p][v], voff[p][v + 1]) (relative to the panel's first cell)
+            panel_voff = torch.searchsorted(cell_panel * TV + cell_v, torch.arange(n_panels * TV, device=dev)) - \
+                torch.repeat_interleave(panel_cell_off[:-1], TV)
+            cell_code = ((code >> 8) | ((code & 0xFF) << 8)).to(torch.int16).contiguous()      # row slot | voxel slot << 8 (< 2^14)
             last = self.n_points - 1
             inline = npts <= 3
             rd0 = rd_sorted[cell_start]
@@ -389,16 +397,50 @@ class MfmaPoolPlan:
             panel_rows = torch.zeros(KP, dtype=torch.long, device=dev)
             panel_nrows = torch.zeros(1, dtype=torch.long, device=dev)
             panel_cell_off = torch.zeros(2, dtype=torch.long, device=dev)
+            panel_voff = torch.zeros(TV, dtype=torch.long, device=dev)
+            cell_code = torch.zeros(1, dtype=torch.int16, device=dev)
             cells = torch.zeros(1, 4, dtype=torch.long, device=dev)
             rd_sorted = torch.zeros(1, dtype=torch.long, device=dev)
-        # units: a tile's panels in groups of <= group; a tile without points is one unit without panels
+        # units: consecutive panels of a tile, at most `group` of them and — with `unit_cost` — about that much estimated
+        # time (cost of a panel = 1 + its longest voxel run / 8: what a panel of bev_pool_panel.hip takes, its row fetch
+        # plus one trip per cell of the longest run); a tile without points is one unit without panels.  The few
+        # tiles beside the rig (hundreds of rows, runs of 30-48 cells) are cut finely, the ordinary ones not at all.
         G = max(1, min(int(group), int(L.ocrf_bev_pool_mfma_max_unit_panels())))
-        n_unit_tile = torch.clamp((n_pan_tile + G - 1) // G, min=1)
-        unit_tile = torch.repeat_interleave(torch.arange(n_tiles, device=dev), n_unit_tile)
-        unit_first = torch.cumsum(n_unit_tile, 0) - n_unit_tile
-        slice_ = torch.arange(unit_tile.numel(), device=dev) - unit_first[unit_tile]
-        p0 = tile_panel_off[unit_tile] + slice_ * G
-        p1 = torch.minimum(p0 + G, tile_panel_off[unit_tile] + n_pan_tile[unit_tile])
+        tiles_i = torch.arange(n_tiles, device=dev)
+        if self.n_points and n_panels:
+            pan_tile = torch.repeat_interleave(tiles_i, n_pan_tile)
+            pan_idx = torch.arange(n_panels, device=dev) - tile_panel_off[pan_tile]          # index of the panel in its tile
+            if unit_cost is not None:
+                ends = torch.cat((panel_voff.reshape(n_panels, TV), (panel_cell_off[1:] - panel_cell_off[:-1])[:, None]), 1)
+                longest = (ends[:, 1:] - ends[:, :-1]).max(1).values
+                cost = 1.0 + longest.double() / 8.0
+                cum = torch.cumsum(cost, 0)
+                excl = cum - cost
+                excl = excl - excl[tile_panel_off[pan_tile]]                                   # exclusive prefix inside the tile
+                bucket = torch.floor(excl / float(unit_cost)).long()
+            else:
+                bucket = torch.zeros(n_panels, dtype=torch.long, device=dev)
+            # a new unit starts where the bucket changes, and every G panels inside a bucket
+            bfirst = torch.ones(n_panels, dtype=torch.bool, device=dev)
+            bfirst[1:] = (bucket[1:] != bucket[:-1]) | (pan_tile[1:] != pan_tile[:-1])
+            bstart = torch.cummax(torch.where(bfirst, torch.arange(n_panels, device=dev), torch.zeros_like(pan_idx)), 0).values
+            ufirst = bfirst | ((torch.arange(n_panels, device=dev) - bstart) % G == 0)
+            unit_p0 = torch.nonzero(ufirst).flatten()
+            unit_p1 = torch.cat((unit_p0[1:], torch.tensor([n_panels], device=dev)))
+            unit_tile_np = pan_tile[unit_p0]
+            n_unit_tile = torch.bincount(unit_tile_np, minlength=n_tiles)
+            empty = n_unit_tile == 0
+            # empty tiles: one unit without panels each
+            e_tiles = tiles_i[empty]
+            unit_tile = torch.cat((unit_tile_np, e_tiles))
+            p0 = torch.cat((unit_p0, torch.zeros_like(e_tiles)))
+            p1 = torch.cat((unit_p1, torch.zeros_like(e_tiles)))
+            first_unit_of_tile = torch.searchsorted(unit_tile_np, tiles_i)
+            slice_ = torch.cat((torch.arange(unit_p0.numel(), device=dev) - first_unit_of_tile[unit_tile_np], torch.zeros_like(e_tiles)))
+            n_unit_tile = torch.clamp(n_unit_tile, min=1)
+        else:
+            n_unit_tile = torch.ones(n_tiles, dtype=torch.long, device=dev)
+            unit_tile, p0, p1, slice_ = tiles_i, torch.zeros_like(tiles_i), torch.zeros_like(tiles_i), torch.zeros_like(tiles_i)
         multi = n_unit_tile > 1
         slab_first = torch.cumsum(torch.where(multi, n_unit_tile, torch.zeros_like(n_unit_tile)), 0) - \
             torch.where(multi, n_unit_tile, torch.zeros_like(n_unit_tile))
@@ -410,6 +452,8 @@ class MfmaPoolPlan:
         self.n_units = int(self.units.size(0))
         self.panel_rows, self.panel_nrows, self.panel_cell_off = i32(panel_rows), i32(panel_nrows), i32(panel_cell_off)
         self.cells, self.rd_sorted = i32(cells), i32(rd_sorted)
+        self.panel_voff, self.cell_code = i32(panel_voff), cell_code
+        self.cw = torch.zeros(int(cells.size(0)), dtype=torch.float32, device=dev)      # bev_pool_cell_weights' output
         self.n_panels, self.n_cells, self.n_tiles = n_panels, int(cells.size(0)), n_tiles
         self.unique_rows = int(panel_nrows.sum()) if self.n_points else 0
         self.arrive = torch.zeros(n_tiles, dtype=torch.int32, device=dev)
@@ -437,6 +481,52 @@ def bev_pool_v2_mfma(depth, feat, plan, layout=1, out=None):
             C, plan.n_units, _lib.ptr(plan.units), _lib.ptr(plan.unit_slab), _lib.ptr(plan.panel_rows),
             _lib.ptr(plan.panel_nrows), _lib.ptr(plan.panel_cell_off), _lib.ptr(plan.cells), _lib.ptr(plan.rd_sorted), _lib.ptr(d32), _lib.ptr(f32), _lib.ptr(out), B, Z, Y, X, int(layout),
             _lib.ptr(plan.arrive), _lib.ptr(plan.slabs), _lib.stream_ptr(dev)), 'ocrf_bev_pool_v2_nchw_mfma')
+    return out
+
+
+@torch.no_grad()
+def bev_pool_cell_weights(depth, plan, plan2=None):
+    """Pre-pass of ``bev_pool_v2_panel``: the summed depth weight of every cell of ``plan`` (and of ``plan2`` — the LSS
+    and the height-sampling plan of a step read the same depth tensor) in ONE launch -> ``plan.cw`` (``plan2.cw``)."""
+    d32 = depth.float().contiguous()
+    _lib.require_cuda(d32)
+    L = _lib.lib()
+    n2 = plan2.n_cells if (plan2 is not None and plan2.n_points) else 0
+    n1 = plan.n_cells if plan.n_points else 0
+    null = ctypes.c_void_p(0)
+    with _lib.on_device(d32.device):
+        _lib.check(L.ocrf_bev_pool_cell_weights(
+            n1, _lib.ptr(plan.cells), _lib.ptr(plan.rd_sorted), _lib.ptr(plan.cw),
+            n2, _lib.ptr(plan2.cells) if n2 else null, _lib.ptr(plan2.rd_sorted) if n2 else null,
+            _lib.ptr(plan2.cw) if n2 else null, _lib.ptr(d32), _lib.stream_ptr(d32.device)), 'ocrf_bev_pool_cell_weights')
+    return d32
+
+
+@torch.no_grad()
+def bev_pool_v2_panel(depth, feat, plan, layout=1, out=None, weights_ready=False):
+    """The pooling of ``plan``'s rank vectors cell by cell out of LDS (csrc/bev_pool_panel.hip): same plan and same
+    result as ``bev_pool_v2_mfma`` (bit for bit on finite inputs).  ``weights_ready``: ``bev_pool_cell_weights`` has
+    already run for this ``depth`` on this stream (one launch for both poolings of a step)."""
+    B, Z, Y, X, C = plan.shape
+    f32 = feat.float().contiguous()
+    _lib.require_cuda(f32)
+    if f32.size(-1) != C:
+        raise _lib.OcrfHipError(f'feat has {f32.size(-1)} channels, the plan was built for {C}')
+    if not weights_ready:
+        bev_pool_cell_weights(depth, plan)
+    dev = f32.device
+    shape = (B, C, Z, Y, X) if layout == 0 else (B, Z * C, Y, X)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=dev)
+    elif out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != B * C * Z * Y * X or out.device != dev:
+        raise _lib.OcrfHipError('out must be a contiguous fp32 tensor of B*C*Z*Y*X elements on the inputs\' device')
+    L = _lib.lib()
+    with _lib.on_device(dev):
+        _lib.check(L.ocrf_bev_pool_v2_nchw_panel(
+            C, plan.n_units, _lib.ptr(plan.units), _lib.ptr(plan.unit_slab), _lib.ptr(plan.panel_rows),
+            _lib.ptr(plan.panel_nrows), _lib.ptr(plan.panel_cell_off), _lib.ptr(plan.panel_voff), _lib.ptr(plan.cell_code),
+            _lib.ptr(plan.cw), _lib.ptr(f32), _lib.ptr(out), B, Z, Y, X, int(layout),
+            _lib.ptr(plan.arrive), _lib.ptr(plan.slabs), _lib.stream_ptr(dev)), 'ocrf_bev_pool_v2_nchw_panel')
     return out
 
 

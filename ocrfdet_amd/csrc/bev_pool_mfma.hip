@@ -18,6 +18,7 @@
 // 16w..16w+15) | the 64 x C tile leaves through LDS in the caller's layout, 256-byte runs per channel.
 #include <hip/hip_runtime.h>
 
+#include "bev_pool_tile_out.h"
 #include "launch.h"
 #include "ocrf_hip.h"
 
@@ -75,7 +76,7 @@ __device__ __forceinline__ float cell_sum_many(const int* __restrict__ rd_sorted
 }
 
 template <int NB, bool STAMP = false>
-__global__ __launch_bounds__(kBlock) void bev_pool_mfma_kernel(MfmaArgs a, unsigned long long* __restrict__ stamps) {
+__global__ __launch_bounds__(kBlock, NB <= 5 ? 5 : 4) void bev_pool_mfma_kernel(MfmaArgs a, unsigned long long* __restrict__ stamps) {
   OCRF_POOL_PRIO();
   constexpr int C = 16 * NB, c4 = C / 4;
   constexpr int kLdf = C + ((16 - C % 32) + 32) % 32;        // F pitch (floats) = 16 mod 32: conflict-free B reads
@@ -92,7 +93,6 @@ __global__ __launch_bounds__(kBlock) void bev_pool_mfma_kernel(MfmaArgs a, unsig
   const int tileid = unit.x, n_slices = unit.w >> 16, slice = unit.w & 0xFFFF;
   const int plane = tileid / a.tpp, kt = tileid % a.tpp;
   const int y0 = (kt / a.tx) * kTS, x0 = (kt % a.tx) * kTS;
-  const long YX = (long)a.Y * a.X;
 
   f32x4 acc[NB];
 #pragma unroll
@@ -220,87 +220,10 @@ __global__ __launch_bounds__(kBlock) void bev_pool_mfma_kernel(MfmaArgs a, unsig
       }
     }
   };
-  const int gpw = 64 / c4, gi = lane / c4, lg = lane % c4, gpb = gpw * 4, gb = wave * gpw + gi;
-  bool write_tile = true;
-  if (n_slices > 1) {
-    // write-through slab (sc1) -> vmcnt drain -> ticket; the last arriver adds the slabs in slice order
-    float4* slab = a.slabs + (long)(a.unit_slab[blockIdx.x] + slice) * kTV * c4;
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(slab, 0, kTV * c4 * (int)sizeof(float4), 0x00020000);
-    if (gi < gpw) {
-      for (int v = gb; v < kTV; v += gpb) {
-        const float4 x = tile[v * ldq + lg];
-        const u32x4 bits = {__float_as_uint(x.x), __float_as_uint(x.y), __float_as_uint(x.z), __float_as_uint(x.w)};
-        __builtin_amdgcn_raw_buffer_store_b128(bits, rsrc, (v * c4 + lg) * (int)sizeof(float4), 0, 16);      // aux 16 = sc1
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      const int old = __hip_atomic_fetch_add(&a.arrive[tileid], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *s_flag = (old == n_slices - 1) ? 1 : 0;
-    }
-    __syncthreads();
-    write_tile = *s_flag != 0;
-    if (write_tile) {
-      if (tid == 0) __hip_atomic_store(&a.arrive[tileid], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      float4* s0 = a.slabs + (long)a.unit_slab[blockIdx.x] * kTV * c4;
-      const auto srs = __builtin_amdgcn_make_buffer_rsrc(s0, 0, n_slices * kTV * c4 * (int)sizeof(float4), 0x00020000);
-      if (gi < gpw) {
-        // the slabs of a heavy tile (up to ~30) are added in slice order, but their loads do not depend on each other:
-        // eight in flight per lane instead of one round trip past the L2 per slab
-        constexpr int kSB = 8;
-        for (int v = gb; v < kTV; v += gpb) {
-          float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-          for (int s0 = 0; s0 < n_slices; s0 += kSB) {
-            u32x4 r[kSB];
-#pragma unroll
-            for (int k = 0; k < kSB; ++k) {
-              const int s = min(s0 + k, n_slices - 1);
-              r[k] = __builtin_amdgcn_raw_buffer_load_b128(srs, ((s * kTV + v) * c4 + lg) * (int)sizeof(float4), 0, 17);
-            }
-#pragma unroll
-            for (int k = 0; k < kSB; ++k) {
-              if (s0 + k < n_slices) {
-                const float4 x = make_float4(__uint_as_float(r[k].x), __uint_as_float(r[k].y), __uint_as_float(r[k].z),
-                                             __uint_as_float(r[k].w));
-                sum = (s0 + k == 0) ? x : make_float4(sum.x + x.x, sum.y + x.y, sum.z + x.z, sum.w + x.w);
-              }
-            }
-          }
-          tile[v * ldq + lg] = sum;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  stamp(4);
-  if (!write_tile) { leave(); return; }
-  // voxel slot v = 8 (y - y0) + (x - x0)
-  if (a.layout == 2) {
-    float4* o = reinterpret_cast<float4*>(a.out);
-    if (gi < gpw)
-      for (int v = gb; v < kTV; v += gpb) {
-        const int y = y0 + (v >> 3), x = x0 + (v & 7);
-        if (y < a.Y && x < a.X) o[((long)plane * YX + (long)y * a.X + x) * c4 + lg] = tile[v * ldq + lg];
-      }
-  } else {
-    const int b = plane / a.Z, z = plane % a.Z;
-    const long base0 = (a.layout == 0) ? (((long)b * C * a.Z + z) * YX) : ((long)plane * C * YX);
-    const long cstride = (a.layout == 0) ? (long)a.Z * YX : YX;
-    // a wave instruction writes eight 32-byte runs (the tile's rows) of one channel plane
-    const int y = y0 + (lane >> 3), x = x0 + (lane & 7);
-    if (y < a.Y && x < a.X) {
-      float* o = a.out + base0 + (long)y * a.X + x;
-      for (int q = wave; q < c4; q += 4) {
-        const float4 t = tile[lane * ldq + q];
-        float* oc = o + (long)(4 * q) * cstride;
-        oc[0] = t.x;
-        oc[cstride] = t.y;
-        oc[2 * cstride] = t.z;
-        oc[3 * cstride] = t.w;
-      }
-    }
-  }
+  // slab + ticket for tiles of several units, then the tile in the caller's layout: shared with bev_pool_panel.hip
+  pool_out::Dest d;
+  d.C = C; d.Y = a.Y; d.X = a.X; d.Z = a.Z; d.layout = a.layout; d.out = a.out; d.slabs = a.slabs; d.arrive = a.arrive;
+  pool_out::leave<c4>(tile, s_flag, d, tileid, plane, y0, x0, n_slices, slice, n_slices > 1 ? a.unit_slab[blockIdx.x] : 0);
   stamp(5);
   leave();
 }

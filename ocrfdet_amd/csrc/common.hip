@@ -88,6 +88,8 @@ const char* ocrf_kernel_name(int kernel_id) {
     case OCRF_K_BEV_POOL_FWD: return "bev_pool_tile_kernel<false>";
     case OCRF_K_BEV_POOL_INTERVAL: return "bev_pool_interval_kernel";
     case OCRF_K_BEV_POOL_MFMA: return "bev_pool_mfma_kernel<*>";
+    case OCRF_K_BEV_POOL_PANEL: return "bev_pool_panel_kernel<*>";
+    case OCRF_K_BEV_POOL_CELL_WEIGHTS: return "bev_pool_cell_weights_kernel";
     case OCRF_K_BEV_POOL_GRAD: return "bev_pool_grad_vec_kernel";
     case OCRF_K_RASTER_PREPROCESS: return "raster_preprocess_kernel";
     case OCRF_K_RASTER_BLEND: return "raster_blend_kernel<false, false, *>";

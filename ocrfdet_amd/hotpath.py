@@ -83,7 +83,8 @@ class HotPath:
         # 'mfma': the HT pooling (cached ranks) as per-tile MFMA panels (csrc/bev_pool_mfma.hip: 26 vs 32 us at cfg2);
         # 'tile': the VALU tile kernel for both poolings.  The LSS ranks keep the tile kernel (its heavy tiles — a
         # 3.2 m block beside the rig collects thousands of rows — make the per-tile MFMA chain the launch's tail).
-        assert ht_pool_backend in ('mfma', 'tile') and lss_pool_backend in ('mfma', 'tile')
+        assert ht_pool_backend in ('mfma', 'tile', 'panel') and lss_pool_backend in ('mfma', 'tile', 'panel')
+        self.lss_panel_unit_cost = 8.0
         self.ht_pool_backend = ht_pool_backend
         self.lss_pool_backend, self.lss_mfma_group = lss_pool_backend, int(lss_mfma_group)
         # planned renders: consecutive frames in one plan / one launch pair.  'auto': when ALL frames fit one plan
@@ -375,7 +376,19 @@ class HotPath:
         feat = feat.permute(0, 1, 3, 4, 2).contiguous()
         return depth.to(self.device), feat.to(self.device)
 
-    def pool(self, plan, depth, feat, out=None):
+    def _panel_plan(self, plan):
+        if plan.mfma_plan is None:
+            backend = self.ht_pool_backend if plan is self.ht else self.lss_pool_backend
+            if plan is self.ht:
+                kw = dict(group=8)
+            elif backend == 'panel':
+                kw = dict(group=8, unit_cost=self.lss_panel_unit_cost)
+            else:
+                kw = dict(group=self.lss_mfma_group)
+            plan.mfma_plan = bevpool.MfmaPoolPlan(plan.ranks_depth, plan.ranks_feat, plan.ranks_bev, plan.bev_shape, **kw)
+        return plan.mfma_plan
+
+    def pool(self, plan, depth, feat, out=None, weights_ready=False):
         """-> (B, Z*C, Y, X): pooled BEV with Z collapsed into channels (view_transformer.py:194).  The
         rank vectors are cached, so the rank-only half of the pooling is too (bevpool.DevicePoolPlan).
         ``out``: contiguous fp32 tensor to write into (a slice of a fused buffer)."""
@@ -385,14 +398,17 @@ class HotPath:
             if out is not None:
                 out.view_as(res).copy_(res)
             return res
-        mfma = ((plan is self.ht and self.ht_pool_backend == 'mfma') or (plan is self.lss and self.lss_pool_backend == 'mfma'))
-        if mfma and plan.bev_shape[-1] in (64, 80, 96, 128):
-            # per-tile MFMA panels.  The height-sampling ranks have no heavy tiles (11 points per feature row and 8x8
-            # tile): units of up to 8 panels; the LSS ranks do (the block beside the rig): short units, more slabs
-            if plan.mfma_plan is None:
-                plan.mfma_plan = bevpool.MfmaPoolPlan(plan.ranks_depth, plan.ranks_feat, plan.ranks_bev, plan.bev_shape,
-                                                      group=8 if plan is self.ht else self.lss_mfma_group)
-            return bevpool.bev_pool_v2_mfma(depth, feat, plan.mfma_plan, out=out)
+        backend = self.ht_pool_backend if plan is self.ht else (self.lss_pool_backend if plan is self.lss else 'tile')
+        if backend in ('mfma', 'panel') and plan.bev_shape[-1] in (64, 80, 96, 128):
+            # the panel plan (unique feature rows of an 8 x 8 tile in panels of 48; cells = (voxel, row) pairs).  'panel':
+            # cells walked out of LDS after a weight pre-pass (csrc/bev_pool_panel.hip); 'mfma': dense W . F panels on the
+            # matrix cores (csrc/bev_pool_mfma.hip).  The height-sampling ranks have no heavy tiles (11 points per feature
+            # row and 8x8 tile): units of up to 8 panels; the LSS ranks do (the block beside the rig): units cut by
+            # estimated cost ('panel') / short units ('mfma'), more slabs
+            self._panel_plan(plan)
+            if backend == 'mfma':
+                return bevpool.bev_pool_v2_mfma(depth, feat, plan.mfma_plan, out=out)
+            return bevpool.bev_pool_v2_panel(depth, feat, plan.mfma_plan, out=out, weights_ready=weights_ready)
         if plan.device_plan is None:
             plan.device_plan = bevpool.DevicePoolPlan(plan.ranks_depth, plan.ranks_feat, plan.ranks_bev, plan.bev_shape,
                                                       plan.starts, plan.lengths)
@@ -448,6 +464,12 @@ class HotPath:
             lss = bevpool.bev_pool_v2_device_counts(depth, feat, lv[1], lv[2], lv[0], self.lss.bev_shape, lv[3], lv[4], lc)
             ht = bevpool.bev_pool_v2_device_counts(depth, feat, hv[1], hv[2], hv[0], self.ht.bev_shape, hv[3], hv[4], hc)
             return lss, ht
+        C = self.lss.bev_shape[-1]
+        if (self.lss_pool_backend == 'panel' and self.ht_pool_backend == 'panel' and C in (64, 80, 96, 128)
+                and self.lss.n_points and self.ht.n_points):
+            # both poolings read the same depth tensor: ONE launch sums the cell weights of both plans
+            bevpool.bev_pool_cell_weights(depth, self._panel_plan(self.lss), self._panel_plan(self.ht))
+            return self.pool(self.lss, depth, feat, weights_ready=True), self.pool(self.ht, depth, feat, weights_ready=True)
         return self.pool(self.lss, depth, feat), self.pool(self.ht, depth, feat)
 
     def step(self, depth, feat):

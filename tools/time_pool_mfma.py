@@ -53,11 +53,11 @@ for name, pl in (('lss', hp.lss), ('ht', hp.ht)):
     _lib.lib().ocrf_diag_pool_mfma_stamps(None)
     st = buf.cpu().numpy().reshape(-1, 8).astype(np.float64)
     tot = st[:, :6].sum(1)
-    print('   stamps (cycles per unit): F+zero %.0f cells %.0f mfma %.0f tile->lds %.0f slab %.0f write %.0f | unit total mean %.0f p50 %.0f p99 %.0f max %.0f'
+    print('   stamps (cycles per unit): F+zero %.0f cells %.0f mfma %.0f tile->lds %.0f (-) %.0f slab + write %.0f | unit total mean %.0f p50 %.0f p99 %.0f max %.0f'
           % (*st[:, :6].mean(0), tot.mean(), *np.percentile(tot, [50, 99]), tot.max()))
     print('   panels per unit: mean %.2f max %d; per panel: F+zero %.0f cells %.0f mfma %.0f' % (
         st[:, 6].mean(), st[:, 6].max(), st[:, 0].sum() / st[:, 6].sum(), st[:, 1].sum() / st[:, 6].sum(), st[:, 2].sum() / st[:, 6].sum()))
     top = np.argsort(-tot)[:5]
     for u in top:
-        print('   unit %5d: total %.0f = F+zero %.0f cells %.0f mfma %.0f tile->lds %.0f slab %.0f write %.0f | panels %d slices of its tile %d'
+        print('   unit %5d: total %.0f = F+zero %.0f cells %.0f mfma %.0f tile->lds %.0f (-) %.0f slab + write %.0f | panels %d slices of its tile %d'
               % (u, tot[u], *st[u, :6], st[u, 6], st[u, 7]))
