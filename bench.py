@@ -510,7 +510,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
-    from ocrfdet_amd import _lib, hotpath, sharding, synthetic
+    from ocrfdet_amd import _lib, bevpool, hotpath, sharding, synthetic
     _lib.lib()                      # raises if libocrf_hip.so is missing — no fallback
     cfg = synthetic.CONFIGS[args.config]
     shard = args.shard if world > 1 else 'none'
@@ -811,6 +811,51 @@ def main():
                              'note': 'per 8x8-voxel tile out[64xC] = W[64xR].F[RxC] on v_mfma_f32_16x16x4_f32; busy = '
                                      'SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles at 2.4 GHz): the matrix pipes '
                                      'are mostly idle, a panel is a latency chain (rows, depth gathers, two barriers)'}
+        if sp is None and shard == 'none' and hp.lss.n_points and hp.ht.n_points and cfg.channels in (64, 80, 96, 128):
+            # the three pooling kernels alone on the device, back-to-back launches between two events (no kernel timer:
+            # these launches include their launch gap, ~1 us over the kernel alone at these sizes)
+            try:
+                def alone(fn, n=30):
+                    for _ in range(3):
+                        fn()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.synchronize()
+                    e0.record()
+                    for _ in range(n):
+                        fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    return 1e3 * e0.elapsed_time(e1) / n
+                alt = {}
+                pplans = {}
+                for nm, pl in (('lss', hp.lss), ('ht', hp.ht)):
+                    dplan = pl.device_plan or bevpool.DevicePoolPlan(pl.ranks_depth, pl.ranks_feat, pl.ranks_bev, pl.bev_shape,
+                                                                     pl.starts, pl.lengths)
+                    mplan = bevpool.MfmaPoolPlan(pl.ranks_depth, pl.ranks_feat, pl.ranks_bev, pl.bev_shape,
+                                                 group=8 if nm == 'ht' else 2)
+                    pplan = pplans[nm] = bevpool.MfmaPoolPlan(pl.ranks_depth, pl.ranks_feat, pl.ranks_bev, pl.bev_shape, group=8,
+                                                              unit_cost=None if nm == 'ht' else 8.0)
+                    alt[nm] = {'tile': alone(lambda: bevpool.bev_pool_v2_planned(depth, feat, dplan)),
+                               'mfma': alone(lambda: bevpool.bev_pool_v2_mfma(depth, feat, mplan)),
+                               'panel': alone(lambda: bevpool.bev_pool_v2_panel(depth, feat, pplan, weights_ready=True))}
+                    del mplan
+
+                def both_panel():
+                    bevpool.bev_pool_cell_weights(depth, pplans['lss'], pplans['ht'])
+                    bevpool.bev_pool_v2_panel(depth, feat, pplans['lss'], weights_ready=True)
+                    bevpool.bev_pool_v2_panel(depth, feat, pplans['ht'], weights_ready=True)
+                alt['panel_weight_prepass_both_plans'] = alone(lambda: bevpool.bev_pool_cell_weights(depth, pplans['lss'], pplans['ht']))
+                alt['both_poolings_panel'] = alone(both_panel)
+                alt['both_poolings_as_in_step'] = alone(lambda: hp.pool_step(depth, feat))
+                alt['note'] = ('us per call, each kernel alone on the device: tile = bev_pool_tile_kernel, mfma = bev_pool_mfma_kernel, '
+                               'panel = bev_pool_panel_kernel with its cell weights ready (+ the pre-pass, one launch for both '
+                               'plans).  The step uses ' + str(getattr(hp, 'lss_pool_backend', 'tile')) + ' (LSS) / ' +
+                               str(getattr(hp, 'ht_pool_backend', 'tile')) + ' (HT): beside the persistent blend the panel form '
+                               'ties with them (DESIGN.md 4.1c)')
+                pools['backends_alone_us'] = alt
+                del pplans
+            except Exception as e:      # a diagnostic must not cost the line
+                pools['backends_alone_us'] = {'error': repr(e)}
         if sp is not None:
             pools['note'] = ('camera-sharded pools: each launch pools this rank\'s cameras of one frame into a full-size '
                              'partial grid; algorithmic bytes are those of the whole-sample pools, for reference only')
