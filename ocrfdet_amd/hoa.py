@@ -404,22 +404,39 @@ class DeferredOpacityBEV:
         self.value = None
 
 
-def spatial_gate(weight, x, addend, want_gated):
+def channel_stats(x):
+    """[mean_c(x), max_c(x)] (B,2,Y,X): the first of the two HIP kernels of ``spatial_gate``.  It reads nothing but x, so a
+    caller may issue it early, on another stream, and hand the result to ``spatial_gate(..., stats=...)``."""
+    _lib.require_cuda(x)
+    B, C, Y, X = x.shape
+    x = _f32c(x)
+    stats = torch.empty(B, 2, Y, X, device=x.device)
+    with _lib.on_device(x.device):
+        _lib.check(_lib.lib().ocrf_hoa_channel_stats(_lib.ptr(x), B, C, Y, X, _lib.ptr(stats), _lib.stream_ptr(x.device)),
+                   'ocrf_hoa_channel_stats')
+    return stats
+
+
+def spatial_gate(weight, x, addend, want_gated, stats=None):
     """mask = sigmoid(conv_kxk([mean_c(x), max_c(x)]; weight (1,2,k,k)) + addend (B,1,Y,X)) and,
     optionally, x * mask — the shared form of ObatinOpacityMask (view_transformer_ocrf.py:230-242,
-    :1197-1199) and BEVGeomAttention (:215-228, :1190), as two HIP kernels (csrc/hoa.hip)."""
+    :1197-1199) and BEVGeomAttention (:215-228, :1190), as two HIP kernels (csrc/hoa.hip).  ``stats``: the result of
+    ``channel_stats(x)`` if the caller already has it (ordered before this call on the current stream)."""
     _lib.require_cuda(x, addend)
     B, C, Y, X = x.shape
     x, ob = _f32c(x), _f32c(addend)
     w = _f32c(weight)
     k = w.shape[-1]
-    stats = torch.empty(B, 2, Y, X, device=x.device)
+    if stats is not None and (tuple(stats.shape) != (B, 2, Y, X) or stats.dtype != torch.float32 or not stats.is_contiguous()):
+        raise _lib.OcrfHipError('stats must be the contiguous fp32 (B,2,Y,X) result of channel_stats(x)')
     mask = torch.empty(B, 1, Y, X, device=x.device)
     gated = torch.empty_like(x) if want_gated else None
     L = _lib.lib()
     with _lib.on_device(x.device):
         st = _lib.stream_ptr(x.device)
-        _lib.check(L.ocrf_hoa_channel_stats(_lib.ptr(x), B, C, Y, X, _lib.ptr(stats), st), 'ocrf_hoa_channel_stats')
+        if stats is None:
+            stats = torch.empty(B, 2, Y, X, device=x.device)
+            _lib.check(L.ocrf_hoa_channel_stats(_lib.ptr(x), B, C, Y, X, _lib.ptr(stats), st), 'ocrf_hoa_channel_stats')
         _lib.check(L.ocrf_hoa_opacity_mask_gate(_lib.ptr(x), _lib.ptr(stats), _lib.ptr(ob), _lib.ptr(w), k, B, C,
                                                 Y, X, _lib.ptr(mask), _lib.ptr(gated), st),
                    'ocrf_hoa_opacity_mask_gate')
@@ -432,7 +449,7 @@ class ObatinOpacityMask(nn.Module):          # sic: the reference's spelling
         self.conv = nn.Conv2d(2, 1, kernel_size, padding=kernel_size // 2, bias=False)
         self.sigmoid = nn.Sigmoid()
 
-    def _run(self, x, opacity_bev, want_gated):
+    def _run(self, x, opacity_bev, want_gated, stats=None):
         if isinstance(opacity_bev, DeferredOpacityBEV):
             return self._run_deferred(x, opacity_bev, want_gated)
         _lib.require_cuda(x, opacity_bev)
@@ -441,7 +458,7 @@ class ObatinOpacityMask(nn.Module):          # sic: the reference's spelling
             stats = torch.cat((x.mean(1, keepdim=True), x.amax(1, keepdim=True)), 1)
             mask = self.sigmoid(self.conv(stats) + opacity_bev)
             return mask, (x * mask if want_gated else None)
-        return spatial_gate(self.conv.weight, x, opacity_bev, want_gated)
+        return spatial_gate(self.conv.weight, x, opacity_bev, want_gated, stats=stats)
 
     @torch.no_grad()
     def _run_deferred(self, x, deferred, want_gated):
@@ -469,9 +486,10 @@ class ObatinOpacityMask(nn.Module):          # sic: the reference's spelling
     def forward(self, x, opacity_bev):
         return self._run(x, opacity_bev, False)[0]
 
-    def gate(self, x, opacity_bev):
-        """-> (mask, x * mask): view_transformer_ocrf.py:1197-1199 in two HBM passes."""
-        return self._run(x, opacity_bev, True)
+    def gate(self, x, opacity_bev, stats=None):
+        """-> (mask, x * mask): view_transformer_ocrf.py:1197-1199 in two HBM passes.  ``stats``: ``channel_stats(x)`` if
+        the caller issued it already (it reads only x: HotPath runs it beside HOA-1/2)."""
+        return self._run(x, opacity_bev, True, stats=stats)
 
 
 # ------------------------------------------------------------------------------------------------

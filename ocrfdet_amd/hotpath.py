@@ -196,11 +196,11 @@ class HotPath:
         return m['v2b'](oa, self.bev_pos1)
 
     @torch.no_grad()
-    def hoa_step(self, geom_feat, opacity_bev=None):
+    def hoa_step(self, geom_feat, opacity_bev=None, stats=None):
         """HOA-1/2/3 (view_transformer_ocrf.py:1159-1161, 1196-1199): -> (gated BEV, opacity BEV)."""
         if opacity_bev is None:
             opacity_bev = self.hoa_opacity_bev(defer=True)
-        _, gated = self.hoa_mods['mask'].gate(geom_feat, opacity_bev)
+        _, gated = self.hoa_mods['mask'].gate(geom_feat, opacity_bev, stats=stats)
         if isinstance(opacity_bev, hoa.DeferredOpacityBEV):
             opacity_bev = opacity_bev.value
         return gated, opacity_bev
@@ -615,6 +615,22 @@ class HotPath:
             ht = bevpool.bev_pool_v2_device_counts(depth, feat, hv[1], hv[2], hv[0], self.ht.bev_shape, hv[3], hv[4], hc)
         else:
             lss, ht = self.pool_step(depth, feat, prepared)
+        # HOA-3's channel statistics read only the pooled BEV: issued on another stream as soon as the HT pooling is
+        # through, they run beside HOA-1/2 instead of after them (one launch and its gap off the end of the main chain,
+        # where nothing else is left to hide it).  'render': behind the blend on the render stream (idle by then);
+        # 'own': a stream of their own.
+        stats, stats_stream = None, None
+        where = getattr(self, 'stats_stream', None)
+        if self.cfg.hoa and where and self.overlap and not hoa_first and not getattr(self, 'fuse_out_conv', False):
+            main = torch.cuda.current_stream(self.device)
+            stats_stream = (self._side[0] if (where == 'render' and getattr(self, '_side', None))
+                            else shared_stream(self.device, 'stats'))
+            pooled = torch.cuda.Event()
+            pooled.record(main)
+            stats_stream.wait_event(pooled)
+            with torch.cuda.stream(stats_stream):
+                stats = hoa.channel_stats(ht)
+            ht.record_stream(stats_stream)
         if hoa_side is not None:
             torch.cuda.current_stream(self.device).wait_stream(hoa_side)
             ob.record_stream(torch.cuda.current_stream(self.device))
@@ -622,9 +638,12 @@ class HotPath:
             ob = self.hoa_opacity_bev(defer=True)
         out = [lss, ht]
         if self.cfg.hoa:
+            if stats_stream is not None:
+                torch.cuda.current_stream(self.device).wait_stream(stats_stream)
+                stats.record_stream(torch.cuda.current_stream(self.device))
             # stand-in for geom_feat: the HT BEV has its shape (B,C,Y,X); the fusion convs between
             # the pools and HOA-3 are MIOpen territory, not part of this path
-            out.extend(self.hoa_step(ht, ob))
+            out.extend(self.hoa_step(ht, ob, stats=stats))
         return out
 
     @property
