@@ -151,3 +151,31 @@ def test_cfg2_step_as_benched_against_per_call_renders_and_oracles(cuda, oracle_
         errs.append((e_ob, e_g))
         assert e_ob <= 1e-5 and e_g <= 1e-5, (b, e_ob, e_g)
     print('cfg2 benched step: max|opacity_bev err|, max|gated err| per frame', errs)
+
+
+def test_cfg2_step_options_give_the_same_outputs(cuda):
+    """Schedules and pooling back ends that were measured against the default: same results — HOA-3's channel
+    statistics on another stream bit for bit, the panel poolings within the summation-order tolerance of the LSS grid
+    (the HT grid: bit-identical to the MFMA form)."""
+    cfg = synthetic.CONFIGS[CFG2]
+    ref_hp = hotpath.HotPath(cfg, cuda)
+    depth, feat = ref_hp.make_inputs(seed=1)
+    ref = ref_hp.step(depth, feat)
+    torch.cuda.synchronize()
+    for where in ('own', 'render'):
+        hp = hotpath.HotPath(cfg, cuda)
+        hp.stats_stream = where
+        for _ in range(2):
+            out = hp.step(depth, feat)
+        torch.cuda.synchronize()
+        for a, b in ((out[0], ref[0]), (out[1], ref[1]), (out[3], ref[3]), (out[4], ref[4])):
+            assert torch.equal(a, b), where
+        assert torch.equal(out[2][1]['color'], ref[2][1]['color'])
+    hp = hotpath.HotPath(cfg, cuda, lss_pool_backend='panel', ht_pool_backend='panel')
+    for _ in range(2):
+        out = hp.step(depth, feat)
+    torch.cuda.synchronize()
+    assert hp.lss.mfma_plan is not None and hp.ht.mfma_plan is not None
+    torch.testing.assert_close(out[0], ref[0], rtol=1e-5, atol=1e-5)        # LSS: tile kernel vs panel plan (another order)
+    assert torch.equal(out[1], ref[1])                                        # HT: the MFMA form's bits
+    assert torch.equal(out[3], ref[3]) and torch.equal(out[4], ref[4])

@@ -69,6 +69,24 @@ def test_opacity_mask_gate_gpu(cuda, g):
 
 
 @pytest.mark.gpu
+def test_channel_statistics_as_an_op_of_their_own(cuda, g):
+    """``hoa.channel_stats`` (the first of the gate's two kernels) handed to ``gate(..., stats=...)``: the same bits as the
+    gate computing them itself; a mis-shaped ``stats`` is refused."""
+    torch.manual_seed(3)
+    m = hoa.ObatinOpacityMask().to(cuda)
+    x = torch.randn(2, 80, 40, 56, device=cuda)
+    ob = torch.randn(2, 1, 40, 56, device=cuda)
+    with torch.no_grad():
+        mask, gated = m.gate(x, ob)
+        st = hoa.channel_stats(x)
+        torch.testing.assert_close(st[:, 0], x.mean(1), rtol=1e-5, atol=1e-6)
+        assert torch.equal(st[:, 1], x.amax(1))
+        mask2, gated2 = m.gate(x, ob, stats=st)
+    assert torch.equal(mask, mask2) and torch.equal(gated, gated2)
+    with pytest.raises(Exception), torch.no_grad():
+        m.gate(x, ob, stats=st[:, :1])
+
+
 def test_height_attention_gpu(cuda, g):
     for ch in (4, 8, 16):
         m = hoa.HeightAttention(ch, ch, 1).to(cuda)

@@ -11,7 +11,9 @@ from ocrfdet_amd import hotpath, synthetic  # noqa: E402
 
 cfg = synthetic.CONFIGS['cfg2_6cam_2frame_bev200x200_render_hoa']
 dev = torch.device('cuda:0')
-hp = hotpath.HotPath(cfg, dev)
+backend = sys.argv[1] if len(sys.argv) > 1 else None
+hp = hotpath.HotPath(cfg, dev, **({'lss_pool_backend': backend, 'ht_pool_backend': backend} if backend else {}))
+print('pooling back end:', backend or 'default (tile LSS, MFMA HT)')
 depth, feat = hp.make_inputs()
 for _ in range(20):
     hp.step(depth, feat)
