@@ -68,6 +68,8 @@ def parse():
     ap.add_argument('--host-calibration', action='store_true',
                     help="--scope neck --index-prep per_step: hand the calibration tensors over as HOST tensors (the "
                          "dataloader's copies) — the forward then has no device -> host read-back at all")
+    ap.add_argument('--no-pool-backends', action='store_true',
+                    help='skip pools.backends_alone_us (the three pooling kernels alone: extra launches a kernel trace should not hold)')
     ap.add_argument('--no-per-step', action='store_true', help='skip the second timed loop with the index preparation inside the step')
     ap.add_argument('--dense-exchange', action='store_true',
                     help="camera_frames: step 1 as the dense reduce_scatter instead of the wedge-sparse isend / irecv round")
@@ -811,7 +813,8 @@ def main():
                              'note': 'per 8x8-voxel tile out[64xC] = W[64xR].F[RxC] on v_mfma_f32_16x16x4_f32; busy = '
                                      'SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles at 2.4 GHz): the matrix pipes '
                                      'are mostly idle, a panel is a latency chain (rows, depth gathers, two barriers)'}
-        if sp is None and shard == 'none' and hp.lss.n_points and hp.ht.n_points and cfg.channels in (64, 80, 96, 128):
+        if (sp is None and shard == 'none' and hp.lss.n_points and hp.ht.n_points and cfg.channels in (64, 80, 96, 128)
+                and not args.no_pool_backends):
             # the three pooling kernels alone on the device, back-to-back launches between two events (no kernel timer:
             # these launches include their launch gap, ~1 us over the kernel alone at these sizes)
             try:

@@ -17,7 +17,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 STEPS=${STEPS:-20}
-B="$ROOT/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline $EXTRA"
+B="$ROOT/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-pool-backends $EXTRA"
 
 echo "[collect] kernel trace, serial" && date
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_serial" -o x -- python3 $B --no-overlap > "$OUT/trace_serial.log" 2>&1

@@ -32,6 +32,9 @@ python3 tools/diag_plan_blend.py --grid 896 > $O/${TAG}_blend_stats_grid896.txt 
 python3 tools/time_hoa.py > $O/${TAG}_time_hoa.txt 2>&1 || true
 python3 tools/time_plan_build.py 50 > $O/${TAG}_time_plan_build.txt 2>&1 || true
 python3 tools/chains_r4.py > $O/${TAG}_chains.txt 2>&1 || true
+python3 tools/time_pool_panel.py --group 8 --unit-cost 8 > $O/${TAG}_time_pool_panel.txt 2>&1 || true
+python3 tools/host_cost_sections.py > $O/${TAG}_host_cost.txt 2>&1 || true
+python3 tools/time_step_blocks.py > $O/${TAG}_step_blocks.txt 2>&1 || true
 OCRF_BENCH_SINGLE_DEVICE=1 timeout -k 10 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --backend gloo --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_2rank_gloo.log 2>&1 || true
 grep '^{' $O/${TAG}_bench_2rank_gloo.log | tail -1 > $O/${TAG}_bench_2rank_gloo.json || true
 python3 -m pytest tests/test_rasterize_gpu.py tests/test_full_size_gpu.py -q -s 2>&1 | grep "rasteriser parity" > $O/${TAG}_raster_parity_counts.txt || true
