@@ -87,6 +87,7 @@ def test_channel_statistics_as_an_op_of_their_own(cuda, g):
         m.gate(x, ob, stats=st[:, :1])
 
 
+@pytest.mark.gpu
 def test_height_attention_gpu(cuda, g):
     for ch in (4, 8, 16):
         m = hoa.HeightAttention(ch, ch, 1).to(cuda)
