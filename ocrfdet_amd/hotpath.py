@@ -510,8 +510,15 @@ class HotPath:
                           for k in range(self.render_streams)]
         for side in self._side:
             side.wait_stream(cur)                 # inputs (and last step's consumers) are ordered before
+        # host issue order (the render call is ~60 us of host work, a pooling ~14): 'render_first' puts the update alone on
+        # the chip for its 33 us before anything of the main chain arrives; 'lss_first' / 'pools_first' issue the LSS pooling /
+        # both poolings before the render call (A/B: tools/ab_step_knobs.py --issue)
+        order = getattr(self, 'issue_order', 'render_first')
+        early = None
+        if order in ('lss_first', 'pools_first') and self.index_prep_mode == 'cached':
+            early = [self.pool(self.lss, depth, feat), self.pool(self.ht, depth, feat) if order == 'pools_first' else None]
         rendered = self.render([self._side[b % len(self._side)] for b in range(self.batch)])
-        main = self._main_chain(depth, feat)
+        main = self._main_chain(depth, feat, early)
         self._set_busy(0)
         for side in self._side:
             cur.wait_stream(side)                 # join: everything the step returns is ordered on `cur`
@@ -562,7 +569,7 @@ class HotPath:
         cur.wait_stream(side)
         return tuple(out)
 
-    def _main_chain(self, depth, feat):
+    def _main_chain(self, depth, feat, early=None):
         """Pools + HOA on the current stream -> (lss, ht[, gated, opacity_bev])."""
         # HOA-1/2 do not read the pooled BEV and are latency chains of small kernels
         prepared = None
@@ -614,7 +621,10 @@ class HotPath:
             main.wait_stream(self._prep_stream2)
             ht = bevpool.bev_pool_v2_device_counts(depth, feat, hv[1], hv[2], hv[0], self.ht.bev_shape, hv[3], hv[4], hc)
         else:
-            lss, ht = self.pool_step(depth, feat, prepared)
+            if early is not None:
+                lss, ht = early[0], (early[1] if early[1] is not None else self.pool(self.ht, depth, feat))
+            else:
+                lss, ht = self.pool_step(depth, feat, prepared)
         # HOA-3's channel statistics read only the pooled BEV: issued on another stream as soon as the HT pooling is
         # through, they run beside HOA-1/2 instead of after them (one launch and its gap off the end of the main chain,
         # where nothing else is left to hide it).  'render': behind the blend on the render stream (idle by then);

@@ -21,6 +21,7 @@ ap.add_argument('--hoa-first', type=int, default=None, help='default: what HotPa
 ap.add_argument('--caller', type=int, default=None, help='render chain on the caller stream (1) or on the side stream (0; HotPath default)')
 ap.add_argument('--hoa-stream', type=int, default=0)
 ap.add_argument('--lss', default='tile')
+ap.add_argument('--issue', default=None, help='host issue order: render_first (default) | lss_first | pools_first')
 ap.add_argument('--stats-stream', default=None, help="HOA-3's channel statistics beside HOA-1/2: render | own (default: on the main chain)")
 ap.add_argument('--lss-group', type=int, default=2)
 ap.add_argument('--schedule', default=None, help='phased | overlap (default: what HotPath chooses)')
@@ -43,6 +44,8 @@ if a.fuse_out is not None:
 if a.caller is not None:
     hp.render_on_caller_stream = bool(a.caller)
 hp.hoa_stream = bool(a.hoa_stream)
+if a.issue:
+    hp.issue_order = a.issue
 if a.stats_stream:
     hp.stats_stream = a.stats_stream
 depth, feat = hp.make_inputs(0)
@@ -58,4 +61,4 @@ for _ in range(5):
     ts.append((time.perf_counter() - t0) / a.steps * 1e3)
 hp.check_render_plans()
 ts.sort()
-print([round(t,4) for t in ts], end=" "); print(f'{" ".join(a.knobs) or "defaults":20s} ht={a.ht} render={a.render_mode} fuse={a.fuse} rstreams={a.rstreams} bw={a.bw} fuse_out={a.fuse_out} schedule={a.schedule} caller={a.caller} hoa_first={a.hoa_first} hoa_stream={a.hoa_stream} lss={a.lss}/{a.lss_group} stats_stream={a.stats_stream}: median {ts[2]:.4f} min {ts[0]:.4f} max {ts[-1]:.4f} ms/step', flush=True)
+print([round(t,4) for t in ts], end=" "); print(f'{" ".join(a.knobs) or "defaults":20s} ht={a.ht} render={a.render_mode} fuse={a.fuse} rstreams={a.rstreams} bw={a.bw} fuse_out={a.fuse_out} schedule={a.schedule} caller={a.caller} hoa_first={a.hoa_first} hoa_stream={a.hoa_stream} lss={a.lss}/{a.lss_group} stats_stream={a.stats_stream} issue={a.issue}: median {ts[2]:.4f} min {ts[0]:.4f} max {ts[-1]:.4f} ms/step', flush=True)
