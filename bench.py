@@ -83,7 +83,7 @@ def parse():
                     help="kernel of the LSS pooling with cached ranks: the VALU tile kernel or the MFMA panel kernel (DESIGN.md 4.1b)")
     ap.add_argument('--blend-workgroups', default='auto',
                     help="planned renders beside the main stream: workgroups of the persistent blend that stay while the main "
-                         "chain runs ('auto' = 2 per CU; DESIGN.md section 5)")
+                         "chain runs ('auto' = 3.5 per CU; DESIGN.md section 5)")
     ap.add_argument('--index-prep', choices=('cached', 'per_step'), default='cached',
                     help="'per_step': rank vectors recomputed by the HIP index preparation inside every step "
                          "(the reference with accelerate=False); 'cached': once per calibration (accelerate=True)")
@@ -1003,7 +1003,7 @@ def main():
                                             if planned else 'per call (preprocess + depth-bucket scatter every render)'),
                        'frames': 'each frame its own ego pose and Gaussian parameters (synthetic.ego_motion)',
                        'streams': ('main: pools, then HOA; side HIP stream: render update + blend per plan; the blend (VALU-bound) '
-                                   'runs as a persistent grid of 2 workgroups per CU so that the latency-bound kernels of the '
+                                   'runs as a persistent grid of 3.5 workgroups per CU so that the latency-bound kernels of the '
                                    'main stream keep wave slots (with several blends per step the rest of the grid joins once '
                                    'the main chain is done; DESIGN.md section 5)' if hp.overlap and cfg.render and planned
                                    else ('main: HOA-1/2, pools, HOA-3; side HIP stream: renders' if hp.overlap and cfg.render

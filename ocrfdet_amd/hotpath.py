@@ -93,7 +93,7 @@ class HotPath:
         self.fuse_frames = fuse_frames
         self.render_streams = max(1, int(render_streams))      # side HIP streams the frames' renders are dealt over
         # size of the planned blend's persistent grid per frame (int, or a sequence with one entry per frame; 0 = what
-        # the device holds).  'auto': beside the main chain (overlap) the VALU-bound blend takes two workgroups per CU
+        # the device holds).  'auto': beside the main chain (overlap) the VALU-bound blend takes 3.5 workgroups per CU
         # and leaves the other wave slots to the latency-bound poolings / HOA of the main stream (cfg2: 0.344 -> 0.30 ms)
         self.blend_workgroups = blend_workgroups
         self._busy = torch.zeros(1, dtype=torch.int32, device=self.device) if self.device.type == 'cuda' else None
@@ -502,7 +502,7 @@ class HotPath:
         if (getattr(self, 'schedule', 'overlap') == 'phased' and len(plans) == 1
                 and self.render_guard == 'host' and self.index_prep_mode == 'cached'):
             return self._step_phased(depth, feat, plans[0], cur)
-        # "the main chain is running": the persistent blends of the render stream keep to two workgroups per CU
+        # "the main chain is running": the persistent blends of the render stream keep to 3.5 workgroups per CU
         # while it is up and take the whole chip once it is down (cfg4: the renders outlast the poolings + HOA)
         self._set_busy(1)
         if not self._side:
@@ -690,7 +690,7 @@ class ShardedHotPath:
                             cams=[0], index_prep_mode='cached', overlap=False) if cfg.hoa else None
         self._side = shared_stream(self.device, 'render') if self.device.type == 'cuda' and cfg.render else None
         # the renders run on the side stream beside this rank's poolings, the exchange and HOA: their persistent blends
-        # keep to two workgroups per CU while that chain is running and take the whole chip once it is done (the same
+        # keep to 3.5 workgroups per CU while that chain is running and take the whole chip once it is done (the same
         # occupancy split as HotPath.step; a hint, the images do not depend on it)
         self._busy = None
         if self._side is not None and render_mode == 'planned':
