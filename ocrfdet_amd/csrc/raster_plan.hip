@@ -676,8 +676,9 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(
       //     computed power is <= 0 at every pixel (its rounding error is ~1e-3 of that margin): no `power > 0` test;
       //   * the median-depth test runs only while some pixel of the wave still has T > 0.5 (T never rises).
       {
-        auto blend_one = [&](auto med_tag, auto simple_tag, const float4 a, const float4 b, const float4 c) {
+        auto blend_one = [&](auto med_tag, auto nostop_tag, auto simple_tag, const float4 a, const float4 b, const float4 c) {
           constexpr bool MED = decltype(med_tag)::value, SIMPLE = decltype(simple_tag)::value;
+          constexpr bool NOSTOP = decltype(nostop_tag)::value;
           const float cr = b.y, cg = b.z, cb = c.x, dep = c.y;
           // power = -0.5 (cxx dx dx + czz dy dy) - cxy dx dy, in the reference's order (forward.cu:320-323)
           const float dx = a.x - pixf_x;
@@ -706,13 +707,19 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(
           }
           const f2 test_T = T * (splat(1.0f) - alpha);
           const f2 aT = alpha * T;
-          const bool stop0 = test_T.x < 0.0001f, stop1 = test_T.y < 0.0001f;
-          if constexpr (STATS) {      // records at which some pixel of the wave stops (diagnostic)
-            if (__ballot((stop0 && T.x > 0.f) || (stop1 && T.y > 0.f)) != 0ull) ++n_newstop;
+          // NOSTOP trips: every pixel of the wave inside the image has T > kNoStopT, so test_T >= T (1 - 0.99f) > 1.2e-4
+          // and the stop test (forward.cu:341-345) is false whatever the record: no compare, no selects
+          bool stop0 = false, stop1 = false;
+          f2 wgt = aT;
+          if constexpr (!NOSTOP) {
+            stop0 = test_T.x < 0.0001f;
+            stop1 = test_T.y < 0.0001f;
+            if constexpr (STATS) {      // records at which some pixel of the wave stops (diagnostic)
+              if (__ballot((stop0 && T.x > 0.f) || (stop1 && T.y > 0.f)) != 0ull) ++n_newstop;
+            }
+            wgt.x = stop0 ? 0.f : aT.x;
+            wgt.y = stop1 ? 0.f : aT.y;
           }
-          f2 wgt;
-          wgt.x = stop0 ? 0.f : aT.x;
-          wgt.y = stop1 ? 0.f : aT.y;
           C0 = fma2(splat(cr), wgt, C0);
           C1 = fma2(splat(cg), wgt, C1);
           C2 = fma2(splat(cb), wgt, C2);
@@ -727,8 +734,12 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(
           } else {
             D = fma2(splat(dep), wgt, D);
           }
-          T.x = stop0 ? -fabsf(T.x) : test_T.x;
-          T.y = stop1 ? -fabsf(T.y) : test_T.y;
+          if constexpr (NOSTOP) {
+            T = test_T;
+          } else {
+            T.x = stop0 ? -fabsf(T.x) : test_T.x;
+            T.y = stop1 ? -fabsf(T.y) : test_T.y;
+          }
         };
         // The list is padded with no-op entries (a trip reads TR entries whatever the list's length).
         const unsigned short* mylist = l_list[wave];
@@ -755,7 +766,7 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(
 #pragma unroll
         for (int u = 0; u < TR / 2; ++u) pair_next[u] = *reinterpret_cast<const unsigned*>(mylist + TR + 2 * u);
 #endif
-        auto trip = [&](auto med_tag, int k) {
+        auto trip = [&](auto med_tag, auto nostop_tag, int k) {
           if constexpr (STATS) n_eval += TR;
           float4 ra[TR], rb[TR], rc4[TR];
           unsigned fl[TR / 2];
@@ -785,23 +796,37 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(
 #pragma unroll
           for (int u = 0; u < TR; ++u) {
             const bool simple_rec = (fl[u / 2] >> ((u & 1) ? 31 : 15)) & 1u;
-            if (simple_rec) blend_one(med_tag, std::true_type{}, ra[u], rb[u], rc4[u]);
-            else blend_one(med_tag, std::false_type{}, ra[u], rb[u], rc4[u]);
+            if (simple_rec) blend_one(med_tag, nostop_tag, std::true_type{}, ra[u], rb[u], rc4[u]);
+            else blend_one(med_tag, nostop_tag, std::false_type{}, ra[u], rb[u], rc4[u]);
           }
         };
         int k = 0;
+        // "some pixel of the wave could stop at the next record": a pixel inside the image at or below kNoStopT (stopped
+        // pixels carry T < 0).  It only ever turns true: the loops run in the order (median, no stop) -> (median, stop) ->
+        // (no median, no stop) -> (no median, stop), each leaving when its own condition ends.
+        constexpr float kNoStopT = 0.0125f;     // T > 1/80 and alpha <= 0.99  =>  T (1 - alpha) > 1.2e-4 > the 1e-4 of the stop test
+        auto may_stop = [&]() { return __ballot((inside0 & !(T.x > kNoStopT)) | (inside1 & !(T.y > kNoStopT))) != 0ull; };
         if constexpr (MEDIAN) {
           h = T - splat(0.5f);
+          for (; k < n_mine; k += TR) {
+            if (may_stop()) break;
+            if (__ballot((T.x > 0.5f) | (T.y > 0.5f)) == 0ull) break;
+            trip(std::true_type{}, std::true_type{}, k);
+          }
           for (; k < n_mine; k += TR) {
             // live <=> sign bit of T clear; the median test is needed while some pixel is still above 0.5
             if (__ballot((__float_as_int(T.x) & __float_as_int(T.y)) >= 0) == 0ull) { k = n_mine; break; }
             if (__ballot((T.x > 0.5f) | (T.y > 0.5f)) == 0ull) break;
-            trip(std::true_type{}, k);
+            trip(std::true_type{}, std::false_type{}, k);
           }
         }
         for (; k < n_mine; k += TR) {
+          if (may_stop()) break;
+          trip(std::false_type{}, std::true_type{}, k);
+        }
+        for (; k < n_mine; k += TR) {
           if (__ballot((__float_as_int(T.x) & __float_as_int(T.y)) >= 0) == 0ull) break;      // every pixel stopped
-          trip(std::false_type{}, k);
+          trip(std::false_type{}, std::false_type{}, k);
         }
       }
       // every pixel saturated -> stop (forward.cu:304-307)
