@@ -629,9 +629,12 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
         const int ns4 = (ns + 3) & ~3;
         f2 h = T - splat(0.5f);
         constexpr int kTrip = 2;
-        for (int j0 = 0; j0 < ns4; j0 += kTrip) {
-          // live <=> sign bit of T clear (T is never +-0: a live T is >= 1e-4, a stopped one is -|T|)
-          if (__ballot((__float_as_int(T.x) & __float_as_int(T.y)) >= 0) == 0ull) break;
+        // NOSTOP trips: while every pixel of the wave inside the image has T > kNoStopT, test_T = T (1 - alpha) >=
+        // T (1 - 0.99f) > 1.2e-4 whatever the record, so the stop test (forward.cu:340-344) is false: no compare, no
+        // selects.  The condition only ever turns false (T never rises, a stopped pixel carries T < 0): one loop per phase.
+        constexpr float kNoStopT = 0.0125f;
+        auto trip = [&](auto nostop_tag, int j0) __attribute__((always_inline)) {
+          constexpr bool NOSTOP = decltype(nostop_tag)::value;
           float4 ra[kTrip], rb[kTrip], rc4[kTrip];
 #pragma unroll
           for (int u = 0; u < kTrip; ++u) {
@@ -676,10 +679,14 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
             alpha.y = ((power.y > 0.0f) | (alpha.y < 1.0f / 255.0f)) ? 0.f : alpha.y;
             const f2 test_T = T * (splat(1.0f) - alpha);
             const f2 aT = alpha * T;
-            const bool stopA = test_T.x < 0.0001f, stopB = test_T.y < 0.0001f;
-            f2 wgt;
-            wgt.x = stopA ? 0.f : aT.x;
-            wgt.y = stopB ? 0.f : aT.y;
+            bool stopA = false, stopB = false;
+            f2 wgt = aT;
+            if constexpr (!NOSTOP) {
+              stopA = test_T.x < 0.0001f;
+              stopB = test_T.y < 0.0001f;
+              wgt.x = stopA ? 0.f : aT.x;
+              wgt.y = stopB ? 0.f : aT.y;
+            }
             C0 = fma2(splat(cr), wgt, C0);
             C1 = fma2(splat(cg), wgt, C1);
             C2 = fma2(splat(cb), wgt, C2);
@@ -702,9 +709,23 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
               lastA = (wgt.x > 0.f) ? (unsigned)jA : lastA;       // alpha T > 0 <=> this Gaussian was blended
               lastB = (wgt.y > 0.f) ? (unsigned)jB : lastB;
             }
-            T.x = stopA ? -fabsf(T.x) : test_T.x;
-            T.y = stopB ? -fabsf(T.y) : test_T.y;
+            if constexpr (NOSTOP) {
+              T = test_T;
+            } else {
+              T.x = stopA ? -fabsf(T.x) : test_T.x;
+              T.y = stopB ? -fabsf(T.y) : test_T.y;
+            }
           }
+        };
+        int j0 = 0;
+        for (; j0 < ns4; j0 += kTrip) {
+          if (__ballot((insideA & !(T.x > kNoStopT)) | (insideB & !(T.y > kNoStopT))) != 0ull) break;
+          trip(std::true_type{}, j0);
+        }
+        for (; j0 < ns4; j0 += kTrip) {
+          // live <=> sign bit of T clear (T is never +-0: a live T is >= 1e-4, a stopped one is -|T|)
+          if (__ballot((__float_as_int(T.x) & __float_as_int(T.y)) >= 0) == 0ull) break;
+          trip(std::false_type{}, j0);
         }
         doneA = T.x < 0.f;
         doneB = T.y < 0.f;
