@@ -43,7 +43,7 @@ constexpr int kHeaderInts = 16;                   // magic, P, V, H, W, gx, gy, 
 #define OCRF_PLAN_STAGE 128
 #endif
 #ifndef OCRF_PLAN_SCAN
-#define OCRF_PLAN_SCAN 2
+#define OCRF_PLAN_SCAN 1      // 256 rects per scan round (2: 256, then 512 per round — 126.8 vs 122.8 us for cfg2's 12 views; 3: 133.0)
 #endif
 constexpr int kStageP = OCRF_PLAN_STAGE;          // records staged per batch (a tile pair saturates after ~110 at cfg2)
 constexpr int kScanUnrollP = OCRF_PLAN_SCAN;      // rect batches in flight in the scan
