@@ -50,7 +50,9 @@ def parse():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--config', default=DEFAULT_CONFIG)
-    ap.add_argument('--blocks', type=int, default=5, help='timed blocks of --steps steps (the median block is reported)')
+    ap.add_argument('--blocks', type=int, default=0,
+                    help='timed blocks of --steps steps (the median block is reported); 0 = 9 blocks of up to 50 steps, else 5: a short '
+                         'block is 5 ms of device time and one noisy neighbour on the host moves it by 10 %')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU-baseline sample budget')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--shard', choices=('camera_frames', 'samples', 'frames', 'cameras'), default='camera_frames')
@@ -609,7 +611,8 @@ def main():
     # (ms_per_step x steps = that block), min / max beside it.  The kernel timers cover the first block.
     blocks = [timed(step, args.steps, world, dev)]
     _lib.KernelTimer.disarm_all()
-    for _ in range(max(1, args.blocks) - 1):
+    n_blocks = args.blocks if args.blocks > 0 else (9 if args.steps <= 50 else 5)
+    for _ in range(max(1, n_blocks) - 1):
         blocks.append(timed(step, args.steps, world, dev))
     elapsed = sorted(blocks)[len(blocks) // 2]
     # planned renders with the host guard: ONE status read per plan verifies every render of the warm-up and the timed
