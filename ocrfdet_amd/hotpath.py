@@ -508,8 +508,13 @@ class HotPath:
         if not self._side:
             self._side = [shared_stream(self.device, 'render' if k == 0 else f'render{k}')
                           for k in range(self.render_streams)]
+        # (wait_stream = create an event + record + wait: the events are kept and reused, ~5 us of host time per call)
+        if getattr(self, '_fork_ev', None) is None:
+            self._fork_ev = torch.cuda.Event()
+            self._join_ev = [torch.cuda.Event() for _ in self._side]
+        self._fork_ev.record(cur)
         for side in self._side:
-            side.wait_stream(cur)                 # inputs (and last step's consumers) are ordered before
+            side.wait_event(self._fork_ev)        # inputs (and last step's consumers) are ordered before
         # host issue order (the render call is ~60 us of host work, a pooling ~14): 'render_first' puts the update alone on
         # the chip for its 33 us before anything of the main chain arrives; 'lss_first' / 'pools_first' issue the LSS pooling /
         # both poolings before the render call (A/B: tools/ab_step_knobs.py --issue)
@@ -520,8 +525,9 @@ class HotPath:
         rendered = self.render([self._side[b % len(self._side)] for b in range(self.batch)])
         main = self._main_chain(depth, feat, early)
         self._set_busy(0)
-        for side in self._side:
-            cur.wait_stream(side)                 # join: everything the step returns is ordered on `cur`
+        for side, ev in zip(self._side, self._join_ev):
+            ev.record(side)
+            cur.wait_event(ev)                    # join: everything the step returns is ordered on `cur`
         return tuple(main[:2]) + (rendered,) + tuple(main[2:])
 
     def _step_phased(self, depth, feat, entry, cur):

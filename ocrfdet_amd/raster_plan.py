@@ -120,6 +120,7 @@ class RasterPlan:
         # renders issued on ANOTHER stream must not overtake the build (a half-built plan holds wild record indices)
         self._built = (torch.cuda.Event(), torch.cuda.current_stream(self.device))
         self._built[0].record(self._built[1])
+        self._ordered_after_build = set()        # streams that already waited for this build (one wait per stream is enough)
         return self
 
     def _scratch(self, n_sets):
@@ -187,10 +188,15 @@ class RasterPlan:
             if radii is None:
                 radii = out['radii'] = torch.empty(n_items, P, dtype=torch.int32, device=dev)
         L = _lib.lib()
-        if self._built[1] != torch.cuda.current_stream(dev) and not torch.cuda.is_current_stream_capturing():
+        cur = torch.cuda.current_stream(dev)
+        if self._built[1] != cur and cur.cuda_stream not in self._ordered_after_build \
+                and not torch.cuda.is_current_stream_capturing():
             # (inside a hipGraph capture the build is either part of the capture, on this branch, or long finished: a wait
-            # on an event of a stream outside the capture would drag that stream into it)
-            torch.cuda.current_stream(dev).wait_event(self._built[0])
+            # on an event of a stream outside the capture would drag that stream into it.)  Once per stream and build: a
+            # stream's later work is ordered after its own earlier wait, and a wait per render is a barrier packet at the
+            # head of the render chain of every step.
+            cur.wait_event(self._built[0])
+            self._ordered_after_build.add(cur.cuda_stream)
         disjoint = S == 1 or (bool(views_disjoint) and item_view is not None)
         with _lib.on_device(dev):
             dyn = self._scratch(1 if disjoint else S)
