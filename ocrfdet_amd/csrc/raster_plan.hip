@@ -31,6 +31,7 @@
 
 #include "launch.h"
 #include "ocrf_hip.h"
+#include "raster_blend_math.h"
 #include "raster_common.h"
 
 namespace {
@@ -47,11 +48,7 @@ constexpr int kHeaderInts = 16;                   // magic, P, V, H, W, gx, gy, 
 #endif
 constexpr int kStageP = OCRF_PLAN_STAGE;          // records staged per batch (a tile pair saturates after ~110 at cfg2)
 constexpr int kScanUnrollP = OCRF_PLAN_SCAN;      // rect batches in flight in the scan
-#ifndef OCRF_PLAN_TRIP
-#define OCRF_PLAN_TRIP 2
-#endif
-constexpr int kTrip = OCRF_PLAN_TRIP;             // records per trip of the blend loop (2 or 4)
-static_assert(kTrip == 2 || kTrip == 4, "records per trip");
+constexpr int kTrip = 2;                          // records per trip of the blend loop (the no-stop bound is per pair)
 constexpr int kStageParts = kBlock / kStageP;     // threads per staged record: each tests 4 / kStageParts waves
 constexpr int kReachPerThread = 4 / kStageParts;
 constexpr int kSrcWaves = kStageP / 64;           // waves that hold one copy of the staged batch
@@ -108,7 +105,7 @@ inline void dyn_layout(long T, int n_sets, DynLayout* L) {
   const size_t n = (size_t)T * n_sets;
   L->rect = take(n * sizeof(Rect));
   L->con = take(n * 16);
-  L->flag = take(256);
+  L->flag = take(512);                            // control words (kCtl*): guard flag, ticket queue, heads, reach
   L->bytes = off;
 }
 
@@ -420,75 +417,272 @@ __global__ __launch_bounds__(kBlock) void raster_plan_update_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// The parameter-dependent half of ONE record (forward.cu:201-256): conic / tile rect from the Gaussian's parameters and
+// the plan's rows of J W.  The same inline arithmetic as raster_plan_update_kernel (raster_common.h): same bits.
+//   con = (-0.5 conic.x, -0.5 conic.z, conic.y, opacity); rect (0,0,0,0): not rendered this step.
+// ---------------------------------------------------------------------------------------------
+struct SetParams {
+  const float* opacities;      // (n_sets, P)
+  const float* scales;         // (n_sets, P, 3)
+  const float* rotations;      // (n_sets, P, 4)
+  float scale_modifier;
+};
+
+__device__ __forceinline__ void dyn_record(const SetParams& sp, long gi, const float4 q0, const float4 q1, int gx, int gy,
+                                           Rect* rect, float4* con) {
+  *rect = Rect{0, 0, 0, 0};
+  *con = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float o = sp.opacities[gi];
+  if (o < 1.0f / 255.0f) return;                   // under 1/255 at every pixel (NaN compares false: evaluated)
+  const float sx = sp.scale_modifier * sp.scales[3 * gi], sy = sp.scale_modifier * sp.scales[3 * gi + 1],
+              sz = sp.scale_modifier * sp.scales[3 * gi + 2];
+  float c3[6];
+  cov3d_from_scale_rot(sx, sy, sz, sp.rotations[4 * gi], sp.rotations[4 * gi + 1], sp.rotations[4 * gi + 2],
+                       sp.rotations[4 * gi + 3], c3);
+  const float A[2][3] = {{q0.x, q0.y, q0.z}, {q0.w, q1.x, q1.y}};
+  float cov_x, cov_y, cov_z, con_x, con_y, con_z;
+  cov2d(A, c3, &cov_x, &cov_y, &cov_z);
+  int rad = 0;
+  Rect r;
+  if (conic_radius_rect(cov_x, cov_y, cov_z, q1.z, q1.w, gx, gy, &con_x, &con_y, &con_z, &rad, &r)) {
+    *rect = r;
+    *con = make_float4(-0.5f * con_x, -0.5f * con_z, con_y, o);
+  }
+}
+
+// Control words of a plan's per-call scratch (ints, zero when the scratch is allocated):
+//   [0] guard flag  [1] arrival counter of the armed per-call blend  [16] ticket queue of the blend  [17] its arrival
+//   counter  [32, 64) head[v]: list entries of plan view v the head kernel prepares (0: never rendered — the default)
+//   [64, 96) reach[v]: how far into view v's list the tile pairs of the running blend scanned
+constexpr int kCtlQueue = 16, kCtlArrive = 17, kCtlHead = 32, kCtlReach = 64;      // (the region is 512 bytes: dyn_layout)
+constexpr int kHeadDefault = 4096;               // list entries per view prepared before anything is known
+constexpr int kHeadMax = 16384;                  // ... at most (the head kernel's grid is sized for it)
+
+// head of view v's list this step: `force` > 0: that many, < 0: none (diagnostic / tests), 0: what the last blend wrote
+__device__ __forceinline__ int head_of(const int* ctl, int v, int nv, int force) {
+  int k = force > 0 ? force : (force < 0 ? 0 : ctl[kCtlHead + v]);
+  if (force == 0 && k == 0) k = kHeadDefault;
+  return min(min(k, kHeadMax), nv);
+}
+
+// ---------------------------------------------------------------------------------------------
+// step 1 (no radii asked): the HEAD of every rendered view's list + the extent check, one launch.
+// A tile pair stops scanning its view's depth-ordered list as soon as all its pixels are saturated — at cfg2 after
+// ~500 of 120 000 entries — so computing conic / rect of EVERY record in front of the blend (raster_plan_update_kernel:
+// 120 MB, 32 us, and the blend cannot start before it) prepares a hundred times what is read.  Here only the first
+// head[v] entries of each rendered view are prepared, in LIST order (the blend's scan reads them coalesced, no list ->
+// record indirection); beyond them the blend computes a record itself when it gets there (same inline arithmetic, same
+// bits).  head[v] follows what the previous blend of the view needed (reach[v] + 25 %): no host read, self-adjusting,
+// and never a correctness matter.
+//   blocks [0, nb_check)      one thread per Gaussian, all sets: world-space extent <= the plan's bound (status bit 4);
+//                             block 0: the call's bookkeeping (ticket queue, plan usable, cameras = the plan's, items
+//                             name valid and distinct views)
+//   blocks [nb_check, ...)    per (item z, 256 list entries): the dynamic arrays d_rect / d_con at [dyn + off + i]
+// ---------------------------------------------------------------------------------------------
+struct HeadArgs {
+  int P, vps, n_sets, n_items, nb_check, blocks_per_item, force_head;
+  long set_stride;
+  const int* header;
+  const int* view_sel;
+  const unsigned* s_id;
+  const unsigned* s_e;
+  const float4* e_q0;
+  const float4* e_q1;
+  SetParams sp;
+  Rect* d_rect;
+  float4* d_con;
+  int* status;
+  int* ctl;
+  int guard;
+  const unsigned* call_cams;
+  const unsigned* plan_cams;
+};
+
+__global__ __launch_bounds__(kBlock) void raster_plan_head_kernel(HeadArgs a) {
+  const int* header = a.header;
+  int* flag = a.guard ? a.ctl : nullptr;
+  if (blockIdx.x == 0) {
+    __shared__ int l_owner[32];
+    __shared__ int l_seen[kMaxSets * 32];
+    if (threadIdx.x == 0) {
+      a.ctl[kCtlQueue] = 0;                        // ticket counter of the blend that follows
+      if (flag) flag[1] = 0;                       // arrival counter of the armed per-call blend (rasterize.hip)
+    }
+    if (a.call_cams) {
+      bool differ = false;
+      for (int i = threadIdx.x; i < header[2] * 36; i += kBlock) differ |= a.call_cams[i] != a.plan_cams[i];
+      if (__ballot(differ) != 0ull && (threadIdx.x & 63) == 0) {
+        atomicOr(a.status, 16);
+        if (flag) atomicOr(flag, 1);
+      }
+    }
+    if (header[0] != (int)kPlanMagic && threadIdx.x == 0) {
+      atomicOr(a.status, 8);
+      if (flag) atomicOr(flag, 1);
+    }
+    // a view named twice in one set, or by two sets that share the dynamic arrays: refused (status bit 8)
+    for (int i = threadIdx.x; i < a.n_sets * 32; i += kBlock) l_seen[i] = -1;
+    if (threadIdx.x < 32) l_owner[threadIdx.x] = -1;
+    __syncthreads();
+    const int V = header[2];
+    for (int it = threadIdx.x; it < a.n_items; it += kBlock) {
+      const int s = it / a.vps;
+      const int v = a.view_sel ? a.view_sel[it] : it % a.vps;
+      bool ok = v >= 0 && v < V;
+      if (ok) ok = atomicExch(&l_seen[s * 32 + v], it) == -1;
+      if (ok && a.set_stride == 0) ok = atomicExch(&l_owner[v], s) == -1;
+      if (!ok) atomicOr(a.status, 8);
+    }
+  }
+  if (header[0] != (int)kPlanMagic) return;
+  if ((int)blockIdx.x < a.nb_check) {
+    const int id = blockIdx.x * kBlock + threadIdx.x;
+    const float bound = __int_as_float(header[7]);
+    bool bad = false;
+    if (id < a.P) {
+      for (int s = 0; s < a.n_sets; ++s) {
+        const long gi = (long)s * a.P + id;
+        const float m = a.sp.scale_modifier;
+        const float sx = m * a.sp.scales[3 * gi], sy = m * a.sp.scales[3 * gi + 1], sz = m * a.sp.scales[3 * gi + 2];
+        const float rn = extent_bound(sx, sy, sz, a.sp.rotations[4 * gi], a.sp.rotations[4 * gi + 1],
+                                      a.sp.rotations[4 * gi + 2], a.sp.rotations[4 * gi + 3]);
+        // the plan's static cull holds for extents <= bound; NaN / Inf anywhere counts as a violation
+        bad |= !(rn <= bound) || !(((sx + sy) + sz) * 0.f == 0.f);
+      }
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) {
+      atomicOr(a.status, 4);
+      if (flag) atomicOr(flag, 1);
+    }
+    return;
+  }
+  const int b = blockIdx.x - a.nb_check;
+  const int z = b / a.blocks_per_item, i = (b % a.blocks_per_item) * kBlock + threadIdx.x;
+  const int V = header[2], gx = header[5], gy = header[6];
+  const int v = a.view_sel ? a.view_sel[z] : z % a.vps;
+  if (v < 0 || v >= V) return;
+  const int* view_off = header + kHeaderInts;
+  const int off = view_off[v], nv = view_off[v + 1] - off;
+  if (i >= head_of(a.ctl, v, nv, a.force_head)) return;
+  const int set = z / a.vps;
+  const unsigned id = a.s_id[off + i], e = a.s_e[off + i];
+  Rect rect;
+  float4 con;
+  dyn_record(a.sp, (long)set * a.P + id, a.e_q0[e], a.e_q1[e], gx, gy, &rect, &con);
+  const long d = (long)set * a.set_stride + off + i;
+  a.d_rect[d] = rect;
+  a.d_con[d] = con;
+}
+
+// ---------------------------------------------------------------------------------------------
 // step 2: blend of a sorted list (forward.cu:261-374 + w-depth README:5-11).
 // One workgroup = one vertical pair of 16x16 tiles of one rendered item; wave w owns the 16x8 pixel block of rows
 // [8w, 8w+8) of the pair (waves 0-1: upper tile, 2-3: lower tile), thread (lx, r) the pixels (lx, 8w + r) and
-// (lx, 8w + r + 4): same x, so dx and the dx-only part of the exponent are shared and the two pixels run as the
-// halves of packed fp32 ops.
+// (lx, 8w + r + 4): same x, so the dx-only part of the exponent is shared and the two pixels run as the halves of
+// packed fp32 ops.  Per-record arithmetic: raster_blend_math.h (shared with the per-call kernel).
 // ---------------------------------------------------------------------------------------------
-#ifdef OCRF_PLAN_WAVES
-#define OCRF_BLEND_BOUNDS __launch_bounds__(kBlock, OCRF_PLAN_WAVES)      // A/B build: waves per SIMD asked of the compiler
-#else
-#define OCRF_BLEND_BOUNDS __launch_bounds__(kBlock)
+// five waves per SIMD (<= 96 VGPRs): left alone hipcc takes 121 for the per-tile-pair prologue (staging, list extension);
+// with the bound the record loops still hold everything in registers (no scratch)
+#ifndef OCRF_PLAN_WAVES
+#define OCRF_PLAN_WAVES 5
 #endif
-template <bool MEDIAN, bool WSKIP, bool STATS = false>
-__global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(
-    unsigned long long* __restrict__ stats, int P, int W, int H, int gx, int gy, int n_items, int vps, long set_stride,
-    const int* __restrict__ header, const int* __restrict__ view_sel, const unsigned* __restrict__ s_id,
-    const unsigned* __restrict__ s_key, const float2* __restrict__ s_pix, const unsigned* __restrict__ s_e,
-    const Rect* __restrict__ d_rect, const float4* __restrict__ d_con, const float* __restrict__ colors,
-    const float* __restrict__ bg,
-    float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_final_T,
-    const int* __restrict__ skip_if, int* __restrict__ queue, int* __restrict__ chain_hist, int chain_hist_words,
-    const int* __restrict__ yield_if, int base_grid) {
-  if (skip_if && *skip_if != 0) {
+#define OCRF_BLEND_BOUNDS __launch_bounds__(kBlock, OCRF_PLAN_WAVES)
+
+struct BlendArgs {
+  unsigned long long* stats;     // STATS build only
+  int P, W, H, gx, gy, n_items, vps;
+  long set_stride;
+  const int* header;
+  const int* view_sel;
+  const unsigned* s_id;
+  const unsigned* s_key;
+  const float2* s_pix;
+  const unsigned* s_e;
+  const float4* e_q0;
+  const float4* e_q1;
+  Rect* d_rect;                  // dynamic arrays: read; extended beyond the head by the tile pairs that get there
+  float4* d_con;
+  const float* colors;
+  SetParams sp;
+  const float* bg;
+  float* out_color;
+  float* out_depth;
+  float* out_final_T;
+  const int* skip_if;
+  int* ctl;
+  int* chain_hist;
+  int chain_hist_words;
+  const int* yield_if;
+  int base_grid;
+  int full;                      // 1: raster_plan_update_kernel prepared EVERY record, in Gaussian-major order
+  int force_head;
+  int variant;                   // diagnostic (ocrf_tune_set 14): bit 0 = no no-stop loops, bit 1 = the GENERIC loop only
+};
+
+template <bool MEDIAN, bool STATS = false>
+__global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(BlendArgs g) {
+  __shared__ unsigned l_pos[kCapPos];
+  __shared__ float4 l_a[kStageP + 1], l_b[kStageP + 1], l_c[kStageP + 1];
+  // (aligned: a trip reads an entry PAIR as one 32-bit word; rows are 268 bytes)
+  __shared__ __attribute__((aligned(16))) unsigned short l_list[4][kStageP + 2 * kTrip + 2];
+  __shared__ int l_wtot[kScanUnrollP * 4];
+  __shared__ int l_lcnt[kSrcWaves][4];        // [source wave of the batch copy][destination wave]
+  __shared__ int l_generic[4];                // [wave]: its list of this batch holds a GENERIC record
+  __shared__ int l_fmax[4];                   // [wave]: largest need factor (float bits) of its list of this batch
+  __shared__ int l_work;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  int* const ctl = g.ctl;
+  bool run = true;
+  if (g.skip_if && *g.skip_if != 0) {
     // the plan's bound does not hold this step: the armed per-call chain renders.  Its bucket histograms are cleared
     // here — by the kernel that sits in front of it anyway — instead of by a launch of their own in every call.
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < chain_hist_words; i += gridDim.x * kBlock) chain_hist[i] = 0;
-    return;
+    for (int i = blockIdx.x * kBlock + tid; i < g.chain_hist_words; i += gridDim.x * kBlock) g.chain_hist[i] = 0;
+    run = false;
   }
   // A scheduling hint, not a dependency: launched on every slot the device has, the workgroups beyond `base_grid`
   // leave at once while *yield_if says another stream's chain is still running (it wants those wave slots); the
   // ticket queue makes any number of participants render the same image.
-  if (yield_if && (int)blockIdx.x >= base_grid && *yield_if != 0) return;
-  __shared__ unsigned l_pos[kCapPos];
-  __shared__ float4 l_a[kStageP + 1], l_b[kStageP + 1], l_c[kStageP + 1];
-  __shared__ unsigned short l_list[4][kStageP + 3 * kTrip + 2];
-  __shared__ int l_wtot[kScanUnrollP * 4];
-  __shared__ int l_lcnt[kSrcWaves][4];        // [source wave of the batch copy][destination wave]
-  __shared__ int l_work;
-
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  if (header[0] != (int)kPlanMagic) return;                           // reported by the update kernel (status bit 8)
+  if (g.yield_if && (int)blockIdx.x >= g.base_grid && *g.yield_if != 0) run = false;
+  const int* header = g.header;
+  if (header[0] != (int)kPlanMagic) run = false;                      // reported by step 1 (status bit 8)
   const int V = header[2];
   const int* view_off = header + kHeaderInts;
   const int lx = lane & 15, r = lane >> 4;
+  const int gx = g.gx, gy = g.gy, W = g.W, H = g.H;
   const int gyp = (gy + 1) / 2;
-  const int n_work = gx * gyp * n_items;
-  if (tid == 0) {      // slot kStageP: a record that changes nothing (opacity 0), pads odd list lengths
-    l_a[kStageP] = make_float4(0.f, 0.f, 0.f, 0.f);
-    l_b[kStageP] = make_float4(0.f, 0.f, 0.f, 0.f);
-    l_c[kStageP] = make_float4(0.f, 0.f, 0.f, INFINITY);
+  const int n_work = gx * gyp * g.n_items;
+  if (tid == 0) {      // slot kStageP: a record that changes nothing, pads odd list lengths
+    const rb::Staged st = rb::stage_noop();
+    l_a[kStageP] = st.a;
+    l_b[kStageP] = st.b;
+    l_c[kStageP] = st.c;
   }
+  rb::Consts kc = rb::consts();
+  asm volatile("" : "+v"(kc.neg_k255), "+v"(kc.neg_half));      // kept in VGPR pairs (else re-materialised per trip)
   // Persistent workgroups over a ticket queue: the grid is what the chip holds at once, every workgroup takes the next
-  // tile pair until none is left (2 112 pairs on 1 792 resident workgroups would otherwise run as a full round plus
-  // a nearly empty one).  Every wave reaches the exit: the ticket counter only grows.
-  for (;;) {
+  // tile pair until none is left.  Every wave reaches the exit: the ticket counter only grows.
+  while (run) {
   __syncthreads();                                                    // the previous pair's LDS traffic is over
-  if (tid == 0) l_work = atomicAdd(queue, 1);
+  if (tid == 0) l_work = atomicAdd(ctl + kCtlQueue, 1);
   __syncthreads();
   const int work = l_work;
   if (work >= n_work) break;
   const int z = work / (gx * gyp);
   const int tx = (work - z * gx * gyp) % gx, ty2 = (work - z * gx * gyp) / gx;
-  const int v = view_sel ? view_sel[z] : z;
-  if (v < 0 || v >= V) continue;                                      // reported by the update kernel (status bit 8)
-  const int set = z / vps;
+  const int v = g.view_sel ? g.view_sel[z] : z % g.vps;
+  if (v < 0 || v >= V) continue;                                      // reported by step 1 (status bit 8)
+  const int set = z / g.vps;
   const int tyA = 2 * ty2, tyB = tyA + 1;
   const int off = view_off[v], nv = view_off[v + 1] - off;
-  const float4* set_con = d_con + (long)set * set_stride;
-  const Rect* set_rect = d_rect + (long)set * set_stride;
-  const float* set_colors = colors + 3 * (long)set * P;
+  // list entries [0, head) have their conic / rect in the dynamic arrays (list order; Gaussian-major through s_e after
+  // the full update).  A tile pair that scans beyond them EXTENDS the arrays itself, 256 entries at a time, before it
+  // reads them (same inline arithmetic as the head kernel; several workgroups may write an entry: the same bytes)
+  const int head = g.full ? nv : head_of(ctl, v, nv, g.force_head);
+  const long dyn = (long)set * g.set_stride;
+  const float* set_colors = g.colors + 3 * (long)set * g.P;
+  auto dyn_index = [&](int i) { return dyn + (g.full ? (long)g.s_e[off + i] : (long)(off + i)); };
+  int ready = head;                            // list entries [0, ready) have their record in the dynamic arrays
   const int pxi = tx * kTileX + lx;
   const int py0 = tyA * kTileY + 8 * wave + r, py1 = py0 + 4;
   const bool tile_ok = (tyA + (wave >> 1)) < gy;
@@ -498,17 +692,17 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(
   // the wave's pixel block as float bounds (pixel centres are the integer coordinates, forward.cu:283)
   const float bx0 = (float)(tx * kTileX), bx1 = bx0 + 15.f;
 
-  // T < 0 <=> the pixel has stopped (or lies outside the image); |T| is its final transmittance
-  f2 T = f2{inside0 ? 1.0f : -1.0f, inside1 ? 1.0f : -1.0f};
-  f2 C0 = splat(0.f), C1 = splat(0.f), C2 = splat(0.f);
-  f2 D = splat(MEDIAN ? 15.0f : 0.0f);
-  f2 h = splat(0.5f);                          // T - 0.5 carried from record to record while the median test is live
+  rb::Px px;
+  px.T = f2{inside0 ? 1.0f : -1.0f, inside1 ? 1.0f : -1.0f};
+  px.C0 = splat(0.f); px.C1 = splat(0.f); px.C2 = splat(0.f);
+  px.D = splat(MEDIAN ? 15.0f : 0.0f);
+  px.cnt = splat(0.f);
 
   int scan = 0, npos = 0;
   bool all_done = false;
   // diagnostic build only: phase cycles and record counts of this workgroup
   unsigned long long t_prev = 0, t_acc[3] = {0, 0, 0};
-  unsigned n_staged = 0, n_listed = 0, n_eval = 0, n_newstop = 0;
+  unsigned n_staged = 0, n_listed = 0, n_eval = 0;
   auto stamp = [&](int slot) {
     if constexpr (STATS) {
       const unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -525,6 +719,20 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(
 #else
       const int n_u = (scan < kBlock) ? 1 : kScanUnrollP;      // a dense tile pair fills its first batch from 256 rects
 #endif
+      const int want = min(nv, scan + n_u * kBlock);
+      while (ready < want) {                       // (uniform; never in `full` mode: ready = nv)
+        const int i = ready + tid;
+        if (i < nv) {
+          const unsigned id = g.s_id[off + i], e = g.s_e[off + i];
+          Rect rc;
+          float4 con;
+          dyn_record(g.sp, (long)set * g.P + id, g.e_q0[e], g.e_q1[e], gx, gy, &rc, &con);
+          g.d_rect[dyn + off + i] = rc;
+          g.d_con[dyn + off + i] = con;
+        }
+        ready += kBlock;
+        __syncthreads();                           // the workgroup's own stores are visible to all its waves
+      }
       unsigned code[kScanUnrollP];
       bool hit[kScanUnrollP];
 #pragma unroll
@@ -533,7 +741,7 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(
         hit[u] = false;
         code[u] = 0u;
         if (u < n_u && i < nv) {
-          const Rect rc = set_rect[s_e[off + i]];      // list order -> the record's Gaussian-major slot
+          const Rect rc = g.d_rect[dyn_index(i)];
           const bool cA = (tyA >= rc.y0) && (tyA < rc.y1), cB = (tyB >= rc.y0) && (tyB < rc.y1);
           hit[u] = (tx >= rc.x0) && (tx < rc.x1) && (cA || cB);
           code[u] = (unsigned)i | (cA ? 0x40000000u : 0u) | (cB ? 0x80000000u : 0u);
@@ -572,47 +780,53 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(
       // kReachPerThread of the four waves (the copies of the batch live in waves [part * kSrcWaves, ...)) ----
       const int part = tid / kStageP, ri = tid % kStageP;
       bool reach[kReachPerThread];
-      bool simple = false;                     // see the blend loop: no min(0.99, .) and no `power > 0` test needed
+      bool simple = true;
+      float nfac = 0.f;
 #pragma unroll
       for (int j = 0; j < kReachPerThread; ++j) reach[j] = false;
+      if (tid < 4) {
+        l_generic[tid] = 0;
+        l_fmax[tid] = 0;
+      }
       if (ri < ns) {
-        // staged record (slots chosen so that operands broadcast into packed ops sit in slots 0-2):
-        //   a = (x, y, -0.5 conic.z, -0.5 conic.x)   b = (opacity, r, g, conic.y)   c = (b, depth, 0, thr)
         const unsigned code = l_pos[s0 + ri];
         const int li = (int)(code & kPosMask);
-        const float4 con = set_con[s_e[off + li]];
-        const float2 pix = s_pix[off + li];
+        const float4 con = g.d_con[dyn_index(li)];
+        const float2 pix = g.s_pix[off + li];
         const float o = con.w;
         // the power below which alpha = o exp(power) is under 1/255 whatever the pixel (1 % margin for v_exp_f32
         // and the log2(e) multiply); o <= 0: +inf (never rendered); NaN opacity: NaN (evaluated in full)
         const float thr = (o > 0.f) ? (__logf(1.0f / (255.0f * o)) - 0.01f) : ((o <= 0.f) ? INFINITY : o);
-        const float4 a = make_float4(pix.x, pix.y, con.y, con.x);
+        simple = rb::is_simple(con);
+        nfac = rb::need_factor(o, simple);
         if (part == 0) {
-          const float* col = set_colors + 3 * (long)s_id[off + li];
-          l_a[ri] = a;
-          l_b[ri] = make_float4(o, col[0], col[1], con.z);
-          l_c[ri] = make_float4(col[2], __uint_as_float(s_key[off + li]), 0.f, thr);
+          const float* col = set_colors + 3 * (long)g.s_id[off + li];
+          const rb::Staged st = rb::stage(con, pix.x, pix.y, col[0], col[1], col[2],
+                                          __uint_as_float(g.s_key[off + li]), simple);
+          l_a[ri] = st.a;
+          l_b[ri] = st.b;
+          l_c[ri] = st.c;
         }
         // alpha >= 1/255 needs power >= thr, i.e. Q(dx, dy) = 0.5 (A dx^2 + C dy^2) + B dx dy <= -thr.  The minimum of
         // the convex Q over a wave's pixel block (a box in (dx, dy)) is 0 if the centre lies inside, else it is on
         // the box's boundary: per edge a clamped 1-D minimiser.  The block is skipped only if that minimum exceeds
         // -thr by more than the rounding of both evaluations (<= 1e-6 of the sum of the terms' magnitudes; 4e-6
-        // is allowed for) — so a skipped record has alpha < 1/255 at every pixel of the block, where the reference
-        // skips it too (forward.cu:331-333).  Anything unusual (NaN, non-convex conic) is evaluated in full.
-        const float qa = -2.f * a.w, qc = -2.f * a.z, qb = con.z;
+        // is allowed for, and 1e-3 absolute: more than the difference between the two evaluation orders of
+        // raster_blend_math.h) — so a skipped record has alpha < 1/255 at every pixel of the block, where the
+        // reference skips it too (forward.cu:331-333).  Anything unusual (NaN, non-convex conic) is evaluated in full.
+        const float qa = -2.f * con.x, qc = -2.f * con.y, qb = con.z;
         const bool convex = (qa > 0.f) && (qc > 0.f) && (qa * qc - qb * qb > 0.f);
-        simple = (o <= 0.99f) && (qa > 0.f) && (qc > 0.f) && (qb * qb <= 0.9990234375f * (qa * qc));
         const bool never = thr >= 0.f;                         // opacity < 1/255: no pixel ever blends it
         const float lim = -thr;
         const float inv_a = 1.f / qa, inv_c = 1.f / qc;
-        const float dxlo = a.x - bx1, dxhi = a.x - bx0;
+        const float dxlo = pix.x - bx1, dxhi = pix.x - bx0;
         const float Dx = fmaxf(fabsf(dxlo), fabsf(dxhi));
 #pragma unroll
         for (int j = 0; j < kReachPerThread; ++j) {
           const int w = part * kReachPerThread + j;
           const bool cov = (w < 2) ? ((code & 0x40000000u) != 0u) : ((code & 0x80000000u) != 0u);
           const float by0 = (float)(tyA * kTileY + 8 * w), by1 = by0 + 7.f;
-          const float dylo = a.y - by1, dyhi = a.y - by0;
+          const float dylo = pix.y - by1, dyhi = pix.y - by0;
           const float Dy = fmaxf(fabsf(dylo), fabsf(dyhi));
           bool skip = false;
           if (convex && !(thr != thr)) {
@@ -652,10 +866,16 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(
           if (sw < src) base += c;
           tot += c;
         }
-        if (reach[j]) l_list[w][base + lrank[j]] = (unsigned short)(ri | (simple ? 0x8000 : 0));
-        if (ri == 0) {                         // pad: the loop reads two entries per trip, two trips ahead
+        if (reach[j]) {
+          // entry = the record's byte offset in the staged arrays | SIMPLE flag
+          l_list[w][base + lrank[j]] = (unsigned short)((ri << 4) | (simple ? 0x8000 : 0));
+          if (!simple) l_generic[w] = 1;
+          // positive floats order like their bits; a NaN factor (NaN opacity) wins: "may stop" throughout
+          atomicMax(&l_fmax[w], __float_as_int(nfac));
+        }
+        if (ri == 0) {                         // pad: a trip reads kTrip entries whatever the list's length
 #pragma unroll
-          for (int q = 0; q < 3 * kTrip; ++q) l_list[w][tot + q] = (unsigned short)kStageP;
+          for (int q = 0; q < 2 * kTrip; ++q) l_list[w][tot + q] = (unsigned short)((kStageP << 4) | 0x8000);
         }
       }
       int n_mine = 0;                          // length of THIS wave's list
@@ -663,174 +883,130 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(
       for (int sw = 0; sw < kSrcWaves; ++sw) n_mine += l_lcnt[sw][wave];
       __syncthreads();
       n_mine = __builtin_amdgcn_readfirstlane(n_mine);
+      const bool generic_batch = __builtin_amdgcn_readfirstlane(l_generic[wave]) != 0 || (g.variant & 2);
+      // no record of this wave's list can trip the stop test while every pixel inside the image has T > need
+      // (raster_blend_math.h: no_stop_need, with the list's largest factor for both records of a trip)
+      const float fmax_w = __int_as_float(__builtin_amdgcn_readfirstlane(l_fmax[wave]));
+      const float need = rb::no_stop_need(fmax_w, fmax_w);
       if constexpr (STATS) n_listed += n_mine;
       stamp(1);
 
-      // ---- blend this wave's records front to back.  Every decision of forward.cu:320-352 is ONE compare feeding
-      // ONE select (see raster_blend_kernel in rasterize.hip for the derivation); same arithmetic, same order.
-      // Measured issue costs on gfx950 (tools/ubench/valu_cost.hip; plain VALU = 1): packed f32 1.4 (for two
-      // pixels), v_exp_f32 2.4, a compare + select pair 2.5 — the selects are 40 % of a record's cost, so the loop
-      // leaves out every decision whose outcome is known for the whole wave:
-      //   * SIMPLE records (flag in the list entry, set at staging): opacity <= 0.99, so min(0.99, alpha) is the
-      //     identity (exp2 of a non-positive power is <= 1), and a conic with B^2 <= (1 - 2^-10) A C, for which the
-      //     computed power is <= 0 at every pixel (its rounding error is ~1e-3 of that margin): no `power > 0` test;
-      //   * the median-depth test runs only while some pixel of the wave still has T > 0.5 (T never rises).
+      // ---- blend this wave's records front to back (raster_blend_math.h), two records per trip: two independent
+      // exponent / alpha chains in flight.  Measured issue costs on gfx950 (tools/ubench/valu_cost.hip; plain VALU = 1):
+      // packed f32 1.4 (for two pixels), v_exp_f32 2.4, a compare + select pair 2.5 — so the loop carries no decision
+      // whose outcome is known for the whole wave: the loops run in the order (median count, no stop) -> (median
+      // count, stop) -> (no count, no stop) -> (no count, stop), each leaving when its own condition ends.  A SIMD
+      // holds five waves of this kernel; they hide the two dependent LDS reads of a trip (list entry -> record).
       {
-        auto blend_one = [&](auto med_tag, auto nostop_tag, auto simple_tag, const float4 a, const float4 b, const float4 c) {
-          constexpr bool MED = decltype(med_tag)::value, SIMPLE = decltype(simple_tag)::value;
-          constexpr bool NOSTOP = decltype(nostop_tag)::value;
-          const float cr = b.y, cg = b.z, cb = c.x, dep = c.y;
-          // power = -0.5 (cxx dx dx + czz dy dy) - cxy dx dy, in the reference's order (forward.cu:320-323)
-          const float dx = a.x - pixf_x;
-          const float qx = (a.w * dx) * dx;
-          const float bx = b.w * dx;
-          const f2 dy = splat(a.y) - pixf_y;
-          const f2 qy = (splat(a.z) * dy) * dy;
-          const f2 power = (splat(qx) + qy) - splat(bx) * dy;          // qx, qy carry the -0.5 (staging)
-          if constexpr (WSKIP) {
-            const float thr = c.w;
-            if (__ballot(!((power.x <= thr) & (power.y <= thr))) == 0ull) return;
-          }
-          const f2 p2 = power * splat(1.44269504088896340736f);       // __expf(x) = v_exp_f32(log2(e) x)
-          f2 G;
-          G.x = __builtin_amdgcn_exp2f(p2.x);
-          G.y = __builtin_amdgcn_exp2f(p2.y);
-          f2 alpha = splat(b.x) * G;
-          if constexpr (SIMPLE) {
-            alpha.x = (alpha.x < 1.0f / 255.0f) ? 0.f : alpha.x;
-            alpha.y = (alpha.y < 1.0f / 255.0f) ? 0.f : alpha.y;
-          } else {
-            alpha.x = fminf(0.99f, alpha.x);
-            alpha.y = fminf(0.99f, alpha.y);
-            alpha.x = ((power.x > 0.0f) | (alpha.x < 1.0f / 255.0f)) ? 0.f : alpha.x;
-            alpha.y = ((power.y > 0.0f) | (alpha.y < 1.0f / 255.0f)) ? 0.f : alpha.y;
-          }
-          const f2 test_T = T * (splat(1.0f) - alpha);
-          const f2 aT = alpha * T;
-          // NOSTOP trips: every pixel of the wave inside the image has T > kNoStopT, so test_T >= T (1 - 0.99f) > 1.2e-4
-          // and the stop test (forward.cu:341-345) is false whatever the record: no compare, no selects
-          bool stop0 = false, stop1 = false;
-          f2 wgt = aT;
-          if constexpr (!NOSTOP) {
-            stop0 = test_T.x < 0.0001f;
-            stop1 = test_T.y < 0.0001f;
-            if constexpr (STATS) {      // records at which some pixel of the wave stops (diagnostic)
-              if (__ballot((stop0 && T.x > 0.f) || (stop1 && T.y > 0.f)) != 0ull) ++n_newstop;
-            }
-            wgt.x = stop0 ? 0.f : aT.x;
-            wgt.y = stop1 ? 0.f : aT.y;
-          }
-          C0 = fma2(splat(cr), wgt, C0);
-          C1 = fma2(splat(cg), wgt, C1);
-          C2 = fma2(splat(cb), wgt, C2);
-          if constexpr (MEDIAN) {
-            if constexpr (MED) {
-              const f2 h2 = test_T - splat(0.5f);
-              const f2 cross = h * h2;
-              D.x = (cross.x < 0.f) ? dep : D.x;
-              D.y = (cross.y < 0.f) ? dep : D.y;
-              h = h2;
-            }
-          } else {
-            D = fma2(splat(dep), wgt, D);
-          }
-          if constexpr (NOSTOP) {
-            T = test_T;
-          } else {
-            T.x = stop0 ? -fabsf(T.x) : test_T.x;
-            T.y = stop1 ? -fabsf(T.y) : test_T.y;
-          }
-        };
-        // The list is padded with no-op entries (a trip reads TR entries whatever the list's length).
         const unsigned short* mylist = l_list[wave];
-        constexpr int TR = kTrip;                // records per trip: independent exponent / alpha chains in flight
-#ifdef OCRF_PLAN_PIPELINE
-        // (A/B build) software pipeline, two deep: the records of the NEXT trip and the list entries of the one after
-        // it are requested before this trip's arithmetic (index -> record is two dependent LDS reads)
-        float4 na[TR], nb[TR], nc[TR];
-        unsigned fl_next[TR / 2];
-        auto fetch = [&](const unsigned* pairs) {
-#pragma unroll
-          for (int u = 0; u < TR / 2; ++u) {
-            const unsigned pair = pairs[u];
-            const int i0 = (int)(pair & 0x1FFu), i1 = (int)((pair >> 16) & 0x1FFu);
-            na[2 * u] = l_a[i0]; nb[2 * u] = l_b[i0]; nc[2 * u] = l_c[i0];
-            na[2 * u + 1] = l_a[i1]; nb[2 * u + 1] = l_b[i1]; nc[2 * u + 1] = l_c[i1];
-            fl_next[u] = pair;
+        const char* la = reinterpret_cast<const char*>(l_a);
+        const char* lb = reinterpret_cast<const char*>(l_b);
+        const char* lc = reinterpret_cast<const char*>(l_c);
+        struct Rec { float4 a, b; float L, dep; };
+        auto load1 = [&](unsigned byte_off, Rec* q) {
+          q->a = *reinterpret_cast<const float4*>(la + byte_off);
+          q->b = *reinterpret_cast<const float4*>(lb + byte_off);
+          if constexpr (MEDIAN) {
+            q->L = *reinterpret_cast<const float*>(lc + byte_off);
+            q->dep = 0.f;
+          } else {
+            const float4 c = *reinterpret_cast<const float4*>(lc + byte_off);
+            q->L = c.x;
+            q->dep = c.z;
           }
         };
-        unsigned pair_next[TR / 2];
-#pragma unroll
-        for (int u = 0; u < TR / 2; ++u) pair_next[u] = *reinterpret_cast<const unsigned*>(mylist + 2 * u);
-        fetch(pair_next);
-#pragma unroll
-        for (int u = 0; u < TR / 2; ++u) pair_next[u] = *reinterpret_cast<const unsigned*>(mylist + TR + 2 * u);
-#endif
-        auto trip = [&](auto med_tag, auto nostop_tag, int k) {
-          if constexpr (STATS) n_eval += TR;
-          float4 ra[TR], rb[TR], rc4[TR];
-          unsigned fl[TR / 2];
-#ifndef OCRF_PLAN_PIPELINE
-          // No software pipeline: a trip reads its own records.  Round 3 prefetched the next trip's records and the list
-          // entries of the one after it (24 more VGPRs: 118, four waves per SIMD) because two workgroups per CU left too
-          // few waves to hide the two dependent LDS reads; at 95 VGPRs a SIMD holds FIVE waves, which hide them better
-          // than the prefetch did: the 12 views of cfg2 alone 145 -> 136 us, cfg2 step 0.256 -> 0.246 ms (-DOCRF_PLAN_PIPELINE builds
-          // the old form for the A/B; asking the compiler for 6 / 8 waves spills and loses: tools/sweep_r4.sh)
-#pragma unroll
-          for (int u = 0; u < TR / 2; ++u) {
-            const unsigned pair = *reinterpret_cast<const unsigned*>(mylist + k + 2 * u);
-            const int i0 = (int)(pair & 0x1FFu), i1 = (int)((pair >> 16) & 0x1FFu);
-            ra[2 * u] = l_a[i0]; rb[2 * u] = l_b[i0]; rc4[2 * u] = l_c[i0];
-            ra[2 * u + 1] = l_a[i1]; rb[2 * u + 1] = l_b[i1]; rc4[2 * u + 1] = l_c[i1];
-            fl[u] = __builtin_amdgcn_readfirstlane(pair);
-          }
-#else
-#pragma unroll
-          for (int u = 0; u < TR; ++u) { ra[u] = na[u]; rb[u] = nb[u]; rc4[u] = nc[u]; }
-#pragma unroll
-          for (int u = 0; u < TR / 2; ++u) fl[u] = __builtin_amdgcn_readfirstlane(fl_next[u]);
-          fetch(pair_next);
-#pragma unroll
-          for (int u = 0; u < TR / 2; ++u) pair_next[u] = *reinterpret_cast<const unsigned*>(mylist + k + 2 * TR + 2 * u);
-#endif
-#pragma unroll
-          for (int u = 0; u < TR; ++u) {
-            const bool simple_rec = (fl[u / 2] >> ((u & 1) ? 31 : 15)) & 1u;
-            if (simple_rec) blend_one(med_tag, nostop_tag, std::true_type{}, ra[u], rb[u], rc4[u]);
-            else blend_one(med_tag, nostop_tag, std::false_type{}, ra[u], rb[u], rc4[u]);
-          }
+        auto load = [&](int k, Rec* rec) {
+          const unsigned pair = *reinterpret_cast<const unsigned*>(mylist + k);
+          load1(pair & 0x7FF0u, &rec[0]);
+          load1((pair >> 16) & 0x7FF0u, &rec[1]);
         };
+        auto one = [&](auto med_tag, auto nostop_tag, auto generic_tag, const Rec& q, bool simple_rec) {
+          constexpr bool MED = decltype(med_tag)::value, NOSTOP = decltype(nostop_tag)::value;
+          constexpr bool GEN = decltype(generic_tag)::value;
+          const float dx = q.a.w - pixf_x;
+          const f2 dy = splat(q.a.x) - pixf_y;
+          f2 alpha, s;
+          auto fast = [&]() {
+            const float t = q.b.z * dx;
+            const float nb = q.b.w * dx;
+            const float qxl = __builtin_fmaf(t, dx, q.L);
+            rb::alpha_simple(nb, q.a.y, splat(qxl), dy, kc, &alpha, &s);
+          };
+          if constexpr (GEN) {
+            if (simple_rec) fast();
+            else rb::alpha_generic(dx, q.b.z, q.b.w, q.a.y, splat(q.L), dy, &alpha, &s);
+          } else {
+            fast();
+          }
+          rb::chain<MEDIAN && MED, !MEDIAN, NOSTOP>(px, alpha, s, q.a.z, q.b.x, q.b.y, q.dep, kc);
+        };
+        // wave-level tests, each two compares on the VALU and scalar logic (a ballot of a combined predicate costs a
+        // select + a compare more).  Stopped and outside pixels carry T < 0: as integers their bits are negative.
+        const unsigned long long in0 = __ballot(inside0), in1 = __ballot(inside1);
+        auto may_stop = [&]() {
+          return ((__ballot(!(px.T.x > need)) & in0) | (__ballot(!(px.T.y > need)) & in1)) != 0ull || (g.variant & 1);
+        };
+        auto any_above_half = [&]() {
+          return __ballot(max(__float_as_int(px.T.x), __float_as_int(px.T.y)) > 0x3F000000) != 0ull;
+        };
+        auto any_alive = [&]() { return __ballot((__float_as_int(px.T.x) & __float_as_int(px.T.y)) >= 0) != 0ull; };
         int k = 0;
-        // "some pixel of the wave could stop at the next record": a pixel inside the image at or below kNoStopT (stopped
-        // pixels carry T < 0).  It only ever turns true: the loops run in the order (median, no stop) -> (median, stop) ->
-        // (no median, no stop) -> (no median, stop), each leaving when its own condition ends.
-        constexpr float kNoStopT = 0.0125f;     // T > 1/80 and alpha <= 0.99  =>  T (1 - alpha) > 1.2e-4 > the 1e-4 of the stop test
-        auto may_stop = [&]() { return __ballot((inside0 & !(T.x > kNoStopT)) | (inside1 & !(T.y > kNoStopT))) != 0ull; };
-        if constexpr (MEDIAN) {
-          h = T - splat(0.5f);
-          for (; k < n_mine; k += TR) {
+        Rec rec[kTrip];
+        if (generic_batch) {
+          // rare (an opacity above 0.99, a nearly singular conic, NaNs): one loop, one record per trip, every decision
+          // per record (a second record in flight here costs the whole kernel a wave per SIMD in registers)
+          for (; k < n_mine; ++k) {
+            if (!any_alive()) break;
+            if constexpr (STATS) n_eval += 1;
+            const unsigned ent = __builtin_amdgcn_readfirstlane((unsigned)mylist[k]);
+            Rec q;
+            load1(ent & 0x7FF0u, &q);
+            if constexpr (MEDIAN) q.dep = 0.f;
+            one(std::true_type{}, std::false_type{}, std::true_type{}, q, (ent & 0x8000u) != 0u);
+          }
+        } else {
+          if constexpr (MEDIAN) {
+            for (; k < n_mine; k += kTrip) {
+              if (!any_above_half() || may_stop()) break;
+              if constexpr (STATS) n_eval += kTrip;
+              load(k, rec);
+              one(std::true_type{}, std::true_type{}, std::false_type{}, rec[0], true);
+              one(std::true_type{}, std::true_type{}, std::false_type{}, rec[1], true);
+            }
+            for (; k < n_mine; k += kTrip) {
+              if (!any_alive()) { k = n_mine; break; }
+              if (!any_above_half()) break;
+              if constexpr (STATS) n_eval += kTrip;
+              load(k, rec);
+              one(std::true_type{}, std::false_type{}, std::false_type{}, rec[0], true);
+              one(std::true_type{}, std::false_type{}, std::false_type{}, rec[1], true);
+            }
+          }
+          for (; k < n_mine; k += kTrip) {
             if (may_stop()) break;
-            if (__ballot((T.x > 0.5f) | (T.y > 0.5f)) == 0ull) break;
-            trip(std::true_type{}, std::true_type{}, k);
+            if constexpr (STATS) n_eval += kTrip;
+            load(k, rec);
+            one(std::false_type{}, std::true_type{}, std::false_type{}, rec[0], true);
+            one(std::false_type{}, std::true_type{}, std::false_type{}, rec[1], true);
           }
-          for (; k < n_mine; k += TR) {
-            // live <=> sign bit of T clear; the median test is needed while some pixel is still above 0.5
-            if (__ballot((__float_as_int(T.x) & __float_as_int(T.y)) >= 0) == 0ull) { k = n_mine; break; }
-            if (__ballot((T.x > 0.5f) | (T.y > 0.5f)) == 0ull) break;
-            trip(std::true_type{}, std::false_type{}, k);
+          for (; k < n_mine; k += kTrip) {
+            if (!any_alive()) break;                                        // every pixel stopped
+            if constexpr (STATS) n_eval += kTrip;
+            load(k, rec);
+            one(std::false_type{}, std::false_type{}, std::false_type{}, rec[0], true);
+            one(std::false_type{}, std::false_type{}, std::false_type{}, rec[1], true);
           }
         }
-        for (; k < n_mine; k += TR) {
-          if (may_stop()) break;
-          trip(std::false_type{}, std::true_type{}, k);
-        }
-        for (; k < n_mine; k += TR) {
-          if (__ballot((__float_as_int(T.x) & __float_as_int(T.y)) >= 0) == 0ull) break;      // every pixel stopped
-          trip(std::false_type{}, std::false_type{}, k);
+        if constexpr (MEDIAN) {
+          // the record at which a pixel crossed 0.5 in this batch, if it did: looked up once (raster_blend_math.h)
+          const int m0 = rb::median_index(px.cnt.x, px.T.x), m1 = rb::median_index(px.cnt.y, px.T.y);
+          if (m0 >= 0) px.D.x = l_c[(mylist[m0] & 0x7FF0u) >> 4].z;
+          if (m1 >= 0) px.D.y = l_c[(mylist[m1] & 0x7FF0u) >> 4].z;
+          px.cnt = splat(0.f);
         }
       }
       // every pixel saturated -> stop (forward.cu:304-307)
-      all_done = __syncthreads_count((T.x < 0.f) && (T.y < 0.f)) == kBlock;
+      all_done = __syncthreads_count(rb::dead(px.T.x) && rb::dead(px.T.y)) == kBlock;
       stamp(2);
     }
     npos = 0;
@@ -840,25 +1016,46 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(
     // per wave: slot = workgroup * 4 + wave: scan, stage, blend cycles | scanned, staged, listed, evaluated records
     if (lane == 0) {
       const long w = (long)work * 4 + wave;
-      stats[w * 8 + 0] = t_acc[0]; stats[w * 8 + 1] = t_acc[1]; stats[w * 8 + 2] = t_acc[2];
-      stats[w * 8 + 3] = (unsigned long long)scan; stats[w * 8 + 4] = n_staged;
-      stats[w * 8 + 5] = n_listed; stats[w * 8 + 6] = n_eval; stats[w * 8 + 7] = n_newstop;
+      g.stats[w * 8 + 0] = t_acc[0]; g.stats[w * 8 + 1] = t_acc[1]; g.stats[w * 8 + 2] = t_acc[2];
+      g.stats[w * 8 + 3] = (unsigned long long)scan; g.stats[w * 8 + 4] = n_staged;
+      g.stats[w * 8 + 5] = n_listed; g.stats[w * 8 + 6] = n_eval; g.stats[w * 8 + 7] = 0;
     }
+  }
+  // how far this tile pair read into the view's list: the next call's head (the read is a hint: a stale value only
+  // costs an atomic)
+  if (tid == 0 && !g.full) {
+    const int reached = min(scan, nv);
+    if (reached > ctl[kCtlReach + v]) atomicMax(ctl + kCtlReach + v, reached);
   }
 
   const long npix = (long)W * H;
   auto store = [&](bool inside, int py, float t, float c0, float c1, float c2, float d) {
     if (!inside) return;
     const long pix = (long)py * W + pxi;
-    out_final_T[z * npix + pix] = t;
-    out_color[((long)z * 3 + 0) * npix + pix] = c0 + t * bg[0];
-    out_color[((long)z * 3 + 1) * npix + pix] = c1 + t * bg[1];
-    out_color[((long)z * 3 + 2) * npix + pix] = c2 + t * bg[2];
-    out_depth[z * npix + pix] = d;
+    g.out_final_T[z * npix + pix] = t;
+    g.out_color[((long)z * 3 + 0) * npix + pix] = c0 + t * g.bg[0];
+    g.out_color[((long)z * 3 + 1) * npix + pix] = c1 + t * g.bg[1];
+    g.out_color[((long)z * 3 + 2) * npix + pix] = c2 + t * g.bg[2];
+    g.out_depth[z * npix + pix] = d;
   };
-  store(inside0, py0, fabsf(T.x), C0.x, C1.x, C2.x, D.x);
-  store(inside1, py1, fabsf(T.y), C0.y, C1.y, C2.y, D.y);
+  store(inside0, py0, fabsf(px.T.x), px.C0.x, px.C1.x, px.C2.x, px.D.x);
+  store(inside1, py1, fabsf(px.T.y), px.C0.y, px.C1.y, px.C2.y, px.D.y);
   }   // ticket loop
+  // The last workgroup to leave closes the call: next call's heads from this call's reach, counters back to zero (the
+  // ticket queue too: a call needs no reset in front of it).  Every workgroup arrives, whichever way it left the loop.
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    if (atomicAdd(ctl + kCtlArrive, 1) == (int)gridDim.x - 1) {
+      __threadfence();
+      for (int vv = 0; vv < 32; ++vv) {
+        const int reached = atomicExch(ctl + kCtlReach + vv, 0);
+        if (reached > 0) ctl[kCtlHead + vv] = min(kHeadMax, (reached + reached / 4 + 2 * kBlock - 1) / kBlock * kBlock);
+      }
+      atomicExch(ctl + kCtlArrive, 0);
+      atomicExch(ctl + kCtlQueue, 0);
+    }
+  }
 }
 
 // workgroups of `kernel` (256 threads, static LDS only) the device holds at once: the size of a persistent grid
@@ -876,25 +1073,27 @@ int resident_blocks(K kernel) {
   return cached[dev];
 }
 
-int g_plan_wskip = 0;
 int g_update_lds = 0;       // ocrf_tune_set(12, bytes): dynamic LDS padding of the update kernel = an occupancy cap (diagnostic)
 int g_plan_grid = 0;        // ocrf_tune_set(11, n): workgroups of the persistent blend (0 = what the device holds at once)
-unsigned long long* g_plan_stats = nullptr;      // ocrf_diag_plan_stats: the next planned blends run the STATS build       // ocrf_tune_set(OCRF_TUNE_PLAN_WSKIP): the pixel-exact wave skip inside the loop
+int g_blend_variant = 0;    // ocrf_tune_set(14, bits): diagnostic loop selection of the planned blend
+int g_head_force = 0;       // ocrf_tune_set(13, n): list entries per view the head kernel prepares (n > 0), none (n < 0), adaptive (0)
+unsigned long long* g_plan_stats = nullptr;      // ocrf_diag_plan_stats: the next planned blends run the STATS build
 
 }  // namespace
 
 namespace ocrf {
 void raster_plan_tune(int key, int value) {
-  if (key == 10) g_plan_wskip = value != 0;
   if (key == 11) g_plan_grid = value > 0 ? value : 0;
   if (key == 12) g_update_lds = value > 0 ? value : 0;
+  if (key == 13) g_head_force = value;
+  if (key == 14) g_blend_variant = value;
 }
 }
 
 extern "C" {
 
 // Diagnostic: the size of the persistent blend's grid (median depth, no wave skip) as the occupancy API reports it
-int ocrf_diag_plan_resident(void) { return resident_blocks(raster_blend_sorted_kernel<true, false>); }
+int ocrf_diag_plan_resident(void) { return resident_blocks(raster_blend_sorted_kernel<true>); }
 
 // Diagnostic: when set (device buffer of tile pairs * items * 4 waves * 8 u64), the next planned renders run the
 // instrumented build of the sorted blend.  Never used by the product path.
@@ -1050,7 +1249,8 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
   const Camera* cams = reinterpret_cast<const Camera*>(pb + L.cams);
   auto* d_rect = reinterpret_cast<Rect*>(wb + D.rect);
   auto* d_con = reinterpret_cast<float4*>(wb + D.con);
-  int* queue = reinterpret_cast<int*>(wb + D.flag) + 16;
+  int* ctl = reinterpret_cast<int*>(wb + D.flag);
+  int* queue = ctl + kCtlQueue;
   int* flag = nullptr;
   int* chain_hist = nullptr;
   size_t chain_hist_words = 0;
@@ -1058,21 +1258,45 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
     if (!means3D || !radii || !chain_workspace ||
         chain_workspace_bytes < ocrf_rasterize_workspace_bytes(P, n_items))
       return (int)hipErrorInvalidValue;
-    // flag[0]: "the extent check fired".  No memset per call: the update kernel only RAISES it, the armed blend lowers
+    // flag[0]: "the extent check fired".  No memset per call: step 1 only RAISES it, the armed blend lowers
     // it after a call that fired, so it is zero on entry unless a fired call was cut short — then this call takes the
     // exact per-call path once more and lowers it.  (The scratch is zero-filled when it is allocated; any other first
-    // value only costs one slow call.)  flag[1]: arrival counter of that blend, zeroed by the update kernel.
-    flag = reinterpret_cast<int*>(wb + D.flag);
+    // value only costs one slow call.)  flag[1]: arrival counter of that blend, zeroed by step 1.
+    flag = ctl;
     chain_hist = ocrf::raster_chain_hist(chain_workspace, P, n_items, &chain_hist_words);
   }
+  // radii asked for (or the armed chain needs them): EVERY record is prepared, one thread per Gaussian, in Gaussian-major
+  // order (raster_plan_update_kernel); else only the head of each rendered view's list, in list order
+  const bool full = radii != nullptr;
+  const SetParams sp{opacities, scales, rotations, scale_modifier};
   if (phase != 2) {
-  ocrf::launch(OCRF_K_RASTER_PLAN_UPDATE, raster_plan_update_kernel, dim3((P + kBlock - 1) / kBlock),
-               dim3(kBlock), (size_t)g_update_lds, stream, P, vps, n_sets, set_stride, total_kept, header,
-               reinterpret_cast<const unsigned*>(pb + L.g_mask),
-               reinterpret_cast<const int*>(pb + L.g_off),
-               reinterpret_cast<const float4*>(pb + L.e_q0), reinterpret_cast<const float4*>(pb + L.e_q1), item_view,
-               opacities, scales, scale_modifier, rotations, d_rect, d_con, radii, status, flag, queue,
-               reinterpret_cast<const unsigned*>(call_cameras), reinterpret_cast<const unsigned*>(cams));
+    if (full) {
+      ocrf::launch(OCRF_K_RASTER_PLAN_UPDATE, raster_plan_update_kernel, dim3((P + kBlock - 1) / kBlock),
+                   dim3(kBlock), (size_t)g_update_lds, stream, P, vps, n_sets, set_stride, total_kept, header,
+                   reinterpret_cast<const unsigned*>(pb + L.g_mask),
+                   reinterpret_cast<const int*>(pb + L.g_off),
+                   reinterpret_cast<const float4*>(pb + L.e_q0), reinterpret_cast<const float4*>(pb + L.e_q1), item_view,
+                   opacities, scales, scale_modifier, rotations, d_rect, d_con, radii, status, flag, queue,
+                   reinterpret_cast<const unsigned*>(call_cameras), reinterpret_cast<const unsigned*>(cams));
+    } else {
+      HeadArgs a;
+      a.P = P; a.vps = vps; a.n_sets = n_sets; a.n_items = n_items;
+      a.nb_check = (P + kBlock - 1) / kBlock;
+      const long head_cap = std::min<long>(g_head_force > 0 ? g_head_force : kHeadMax, std::min<long>(kHeadMax, total_kept));
+      a.blocks_per_item = g_head_force < 0 ? 0 : (int)((head_cap + kBlock - 1) / kBlock);
+      a.force_head = g_head_force;
+      a.set_stride = set_stride;
+      a.header = header; a.view_sel = item_view;
+      a.s_id = reinterpret_cast<const unsigned*>(pb + L.s_id);
+      a.s_e = reinterpret_cast<const unsigned*>(pb + L.s_e);
+      a.e_q0 = reinterpret_cast<const float4*>(pb + L.e_q0);
+      a.e_q1 = reinterpret_cast<const float4*>(pb + L.e_q1);
+      a.sp = sp; a.d_rect = d_rect; a.d_con = d_con; a.status = status; a.ctl = ctl; a.guard = 0;
+      a.call_cams = reinterpret_cast<const unsigned*>(call_cameras);
+      a.plan_cams = reinterpret_cast<const unsigned*>(cams);
+      ocrf::launch(OCRF_K_RASTER_PLAN_UPDATE, raster_plan_head_kernel,
+                   dim3((unsigned)(a.nb_check + n_items * a.blocks_per_item)), dim3(kBlock), 0, stream, a);
+    }
   }   // phase != 2
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
@@ -1081,31 +1305,31 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
   // yield_if: the grid is everything the device holds, `blend_workgroups` of it stay whatever the hint says
   const int base_grid = (yield_if && blend_workgroups > 0) ? blend_workgroups : (1 << 30);
   const int want_grid = g_plan_grid ? g_plan_grid : ((yield_if && blend_workgroups > 0) ? 0 : blend_workgroups);      // the diagnostic knob wins
+  BlendArgs g;
+  g.stats = g_plan_stats;
+  g.P = P; g.W = W; g.H = H; g.gx = gx; g.gy = gy; g.n_items = n_items; g.vps = vps;
+  g.set_stride = set_stride; g.header = header; g.view_sel = item_view;
+  g.s_id = reinterpret_cast<const unsigned*>(pb + L.s_id);
+  g.s_key = reinterpret_cast<const unsigned*>(pb + L.s_key);
+  g.s_pix = reinterpret_cast<const float2*>(pb + L.s_pix);
+  g.s_e = reinterpret_cast<const unsigned*>(pb + L.s_e);
+  g.e_q0 = reinterpret_cast<const float4*>(pb + L.e_q0);
+  g.e_q1 = reinterpret_cast<const float4*>(pb + L.e_q1);
+  g.d_rect = d_rect; g.d_con = d_con; g.colors = colors; g.sp = sp; g.bg = bg;
+  g.out_color = out_color; g.out_depth = out_depth; g.out_final_T = out_final_T;
+  g.skip_if = flag; g.ctl = ctl; g.chain_hist = chain_hist; g.chain_hist_words = (int)chain_hist_words;
+  g.yield_if = yield_if; g.base_grid = base_grid; g.full = full ? 1 : 0; g.force_head = g_head_force; g.variant = g_blend_variant;
   if (g_plan_stats) {      // diagnostic build (median depth), never used by the product path
-    const dim3 sgrid((unsigned)std::min(n_work, want_grid ? want_grid : resident_blocks(raster_blend_sorted_kernel<true, false, true>)));
-    hipLaunchKernelGGL((raster_blend_sorted_kernel<true, false, true>), sgrid, dim3(kBlock), 0, stream, g_plan_stats, P, W, H,
-                       gx, gy, n_items, vps, set_stride, header, item_view, reinterpret_cast<const unsigned*>(pb + L.s_id),
-                       reinterpret_cast<const unsigned*>(pb + L.s_key), reinterpret_cast<const float2*>(pb + L.s_pix),
-                       reinterpret_cast<const unsigned*>(pb + L.s_e), static_cast<const Rect*>(d_rect),
-                       static_cast<const float4*>(d_con), colors, bg, out_color, out_depth, out_final_T,
-                       static_cast<const int*>(flag), queue, chain_hist, (int)chain_hist_words, yield_if, base_grid);
+    const dim3 sgrid((unsigned)std::min(n_work, want_grid ? want_grid : resident_blocks(raster_blend_sorted_kernel<true, true>)));
+    hipLaunchKernelGGL((raster_blend_sorted_kernel<true, true>), sgrid, dim3(kBlock), 0, stream, g);
     return (int)hipGetLastError();
   }
-#define OCRF_BLEND_SORTED(MED, WS)                                                                                   \
-  ocrf::launch(OCRF_K_RASTER_BLEND_SORTED, raster_blend_sorted_kernel<MED, WS>,                                       \
-               dim3((unsigned)std::min(n_work, want_grid ? want_grid                                                   \
-                                                          : resident_blocks(raster_blend_sorted_kernel<MED, WS>))),     \
-               dim3(kBlock), 0,                                                                                        \
-               stream, (unsigned long long*)nullptr, P, W, H, gx, gy, n_items, vps, set_stride, header, item_view,     \
-               reinterpret_cast<const unsigned*>(pb + L.s_id), reinterpret_cast<const unsigned*>(pb + L.s_key),        \
-               reinterpret_cast<const float2*>(pb + L.s_pix), reinterpret_cast<const unsigned*>(pb + L.s_e),           \
-               static_cast<const Rect*>(d_rect),                                                                       \
-               static_cast<const float4*>(d_con), colors, bg, out_color, out_depth, out_final_T,                       \
-               static_cast<const int*>(flag), queue, chain_hist, (int)chain_hist_words, yield_if, base_grid)
-  if (depth_mode == 0 && g_plan_wskip) OCRF_BLEND_SORTED(true, true);
-  else if (depth_mode == 0) OCRF_BLEND_SORTED(true, false);
-  else if (g_plan_wskip) OCRF_BLEND_SORTED(false, true);
-  else OCRF_BLEND_SORTED(false, false);
+#define OCRF_BLEND_SORTED(MED)                                                                                         \
+  ocrf::launch(OCRF_K_RASTER_BLEND_SORTED, raster_blend_sorted_kernel<MED>,                                            \
+               dim3((unsigned)std::min(n_work, want_grid ? want_grid : resident_blocks(raster_blend_sorted_kernel<MED>))), \
+               dim3(kBlock), 0, stream, g)
+  if (depth_mode == 0) OCRF_BLEND_SORTED(true);
+  else OCRF_BLEND_SORTED(false);
 #undef OCRF_BLEND_SORTED
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;

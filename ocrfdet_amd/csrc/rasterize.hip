@@ -33,6 +33,7 @@
 
 #include "launch.h"
 #include "ocrf_hip.h"
+#include "raster_blend_math.h"
 #include "raster_common.h"
 
 namespace {
@@ -483,8 +484,10 @@ struct BwdArgs {
 // exactly its own list: a record carries two coverage bits (rect covers tile A / tile B), a pixel
 // ignores records that do not cover its tile, and the contributor index of each tile is a scalar
 // counter of its covered records.
+// (forward: five waves per SIMD asked of the compiler — 28 KB of LDS hold five workgroups per CU; left alone hipcc takes
+// 110 VGPRs for the staging and the record loops keep everything in registers at 96 too)
 template <bool STAMP, bool BWD, bool MEDIAN, bool CONTRIB = true>
-__global__ __launch_bounds__(kBlock) void raster_blend_kernel(
+__global__ __launch_bounds__(kBlock, (BWD || STAMP) ? 1 : 5) void raster_blend_kernel(
     unsigned long long* __restrict__ stamps,
     int P, int W, int H, int gy, const int* __restrict__ starts, const Rect* __restrict__ rects,
     const Rect* __restrict__ b_rect, const unsigned long long* __restrict__ b_comp,
@@ -512,6 +515,7 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
   float* l_g = reinterpret_cast<float*>(l_id + kStage);           // BWD only: [kStage][9]
   __shared__ int l_wtot[kScanUnroll * (kBlock / 64)];
   __shared__ int l_ready;
+  __shared__ int l_fmax, l_generic;      // forward: largest need factor (float bits) / a GENERIC record in the staged batch
 
   const int tid = threadIdx.x;
   const int tx = blockIdx.x, v = blockIdx.z;
@@ -537,6 +541,11 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
   unsigned lastA = 0, lastB = 0;
   f2 C0 = splat(0.f), C1 = splat(0.f), C2 = splat(0.f);
   f2 D = splat(MEDIAN ? 15.0f : 0.0f);
+  // forward: the two pixels' running state and the loop constants of raster_blend_math.h
+  rb::Px px;
+  px.T = T; px.C0 = C0; px.C1 = C1; px.C2 = C2; px.D = D; px.cnt = splat(0.f);
+  rb::Consts kc = rb::consts();
+  if constexpr (!BWD) asm volatile("" : "+v"(kc.neg_k255), "+v"(kc.neg_half));      // kept in VGPR pairs
   // backward-only per-pixel state
   f2 dL0 = splat(0.f), dL1 = splat(0.f), dL2 = splat(0.f), S0 = splat(0.f), S1 = splat(0.f), S2 = splat(0.f);
   f2 Tfin = splat(0.f), bgdot = splat(0.f);
@@ -573,6 +582,13 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
   auto blend_records = [&](int n) {
     for (int s0 = 0; s0 < n && !all_done; s0 += kStage) {
       const int ns = min(kStage, n - s0);
+      if constexpr (!BWD) {
+        if (tid == 0) {
+          l_fmax = 0;
+          l_generic = 0;
+        }
+        __syncthreads();
+      }
       if (tid < ns) {
         const unsigned long long c = rec[s0 + tid];
         const unsigned id = (unsigned)(c & 0xFFFFFFFFull);
@@ -589,146 +605,122 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
 #pragma unroll
           for (int k = 0; k < 9; ++k) l_g[tid * 9 + k] = 0.f;
         } else {
-          // forward: the conic's diagonal is staged as -0.5 * c (exact: a power of two commutes with every
-          // rounding of (c dx) dx and of the sum), which removes the -0.5 multiply from the per-record chain;
-          // a record that does not cover one of the two tiles is staged with opacity 0 FOR THAT TILE: its alpha
-          // is 0 there, below the 1/255 cut, so the pixel loop needs no coverage test at all
-          // slot order: values that are broadcast into packed ops sit in slots 0-2 of a 16-byte read (hipcc copies a
-          // broadcast operand out of slot 3, one v_mov per record), per-record scalars (cxx, cxy, depth) in slot 3
-          l_a[tid] = make_float4(p.x, p.y, -0.5f * co.z, -0.5f * co.x);
-          l_b[tid] = make_float4((cov & 1u) ? co.w : 0.f, (cov & 2u) ? co.w : 0.f, col[0], co.y);
-          // slot w: the power below which this record's alpha is under 1/255 for BOTH tiles whatever the pixel
-          // (alpha = o exp(power) < 1/255  <=  power < ln(1 / (255 o)); 1 % margin for v_exp_f32 and the
-          // log2(e) multiply) with the two coverage bits in its lowest mantissa bits.  o <= 0 gives +inf (never
-          // above 1/255), a NaN opacity gives NaN (the test below fails: evaluated in full).
-          const float omax = (cov == 3u) ? co.w : ((cov != 0u) ? co.w : 0.f);
-          const float thr = (omax > 0.f) ? (__logf(1.0f / (255.0f * omax)) - 0.01f) : ((omax <= 0.f) ? INFINITY : omax);
-          l_c[tid] = make_float4(col[1], col[2], __uint_as_float((unsigned)(c >> 32)),
-                                 __uint_as_float((__float_as_uint(thr) & ~3u) | cov));
+          // forward: the staged form of raster_blend_math.h; the record's tile coverage is in its per-pixel constant
+          // term — pixel A (tile A) / pixel B (tile B) see L = log2(opacity) (GENERIC: the opacity) only if the record
+          // covers their tile, else -inf (0): alpha 0 there, below the 1/255 cut — the loop needs no coverage test
+          const float4 con = make_float4(-0.5f * co.x, -0.5f * co.z, co.y, co.w);
+          const bool simple = rb::is_simple(con);
+          const rb::Staged st = rb::stage(con, p.x, p.y, col[0], col[1], col[2], __uint_as_float((unsigned)(c >> 32)), simple);
+          const float none = simple ? -INFINITY : 0.f;
+          l_a[tid] = st.a;
+          l_b[tid] = st.b;
+          // slot w: coverage bits | SIMPLE flag (bit 2)
+          l_c[tid] = make_float4((cov & 1u) ? st.c.x : none, (cov & 2u) ? st.c.x : none, st.c.z,
+                                 __uint_as_float(cov | (simple ? 4u : 0u)));
+          if (!simple) l_generic = 1;
+          // positive floats order like their bits; a NaN factor (NaN opacity) wins: "may stop" throughout
+          if (cov != 0u) atomicMax(&l_fmax, __float_as_int(st.c.y));
         }
       } else if (!BWD && tid < ((ns + 3) & ~3)) {
-        // pad the batch to a multiple of four records with no-ops (opacity 0): the loop reads 4 per trip
+        // pad the batch to a multiple of four records with no-ops (SIMPLE, alpha 0): the loop reads two per trip
         l_a[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
         l_b[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-        l_c[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        l_c[tid] = make_float4(-INFINITY, -INFINITY, 0.f, __uint_as_float(4u));
       }
       __syncthreads();
       if constexpr (!BWD) {
-        // Forward: a per-record update with NO mask algebra.  Every decision of forward.cu:320-352 is ONE compare
-        // that feeds ONE select (v_cmp -> v_cndmask), the rest is packed arithmetic on the two pixels:
-        //   * coverage is in the staged per-tile opacities (above);
-        //   * alpha is zeroed where the reference skips the Gaussian (power > 0, alpha < 1/255): then
-        //     test_T = T * 1 = T and the weight alpha * T = 0 exactly — "not valid" needs no predicate;
-        //   * a live pixel has T >= 1e-4 (else it would have stopped), so test_T < 1e-4 alone means "stop"
-        //     (forward.cu:340-344: this Gaussian is not blended); a stopped pixel keeps -|T|: its test_T <= 0
-        //     "stops" again, which changes nothing;
-        //   * median depth: T > 0.5 and test_T < 0.5 can only hold for a blended Gaussian (alpha <= 0.99).
-        // Same arithmetic, same order and therefore the same bits as the mask formulation it replaces
-        // (tools/render_hash.py); 2 records per trip (87 VGPRs: 5 workgroups per CU; 4 per trip needs 111 = 4
-        // workgroups and is 2 % slower), wave-level early exit.
+        // Forward: the per-record arithmetic of raster_blend_math.h (shared with the planned kernel: same bits for the
+        // same record sequence).  Two records per trip; a record whose alpha is under 1/255 at every pixel of the WAVE is
+        // skipped as a whole (about a third of a tile pair's records lie in the corners of their 3-sigma square or
+        // beyond the wave's rows); NOSTOP trips: while every pixel of the wave inside the image has T above
+        // `need` (from the batch's largest opacity: rb::no_stop_need) no record can trip the stop test — no compare,
+        // no selects.  The condition only ever turns false: one loop per phase.
         const int ns4 = (ns + 3) & ~3;
-        f2 h = T - splat(0.5f);
         constexpr int kTrip = 2;
-        // NOSTOP trips: while every pixel of the wave inside the image has T > kNoStopT, test_T = T (1 - alpha) >=
-        // T (1 - 0.99f) > 1.2e-4 whatever the record, so the stop test (forward.cu:340-344) is false: no compare, no
-        // selects.  The condition only ever turns false (T never rises, a stopped pixel carries T < 0): one loop per phase.
-        constexpr float kNoStopT = 0.0125f;
-        auto trip = [&](auto nostop_tag, int j0) __attribute__((always_inline)) {
-          constexpr bool NOSTOP = decltype(nostop_tag)::value;
-          float4 ra[kTrip], rb[kTrip], rc4[kTrip];
+        const float fmax_b = __int_as_float(l_fmax);
+        const float need = rb::no_stop_need(fmax_b, fmax_b);
+        const bool generic_batch = l_generic != 0;
+        auto trip = [&](auto nostop_tag, auto generic_tag, int j0) __attribute__((always_inline)) {
+          constexpr bool NOSTOP = decltype(nostop_tag)::value, GEN = decltype(generic_tag)::value;
+          float4 ra[kTrip], rb4[kTrip], rc4[kTrip];
 #pragma unroll
           for (int u = 0; u < kTrip; ++u) {
             ra[u] = l_a[j0 + u];
-            rb[u] = l_b[j0 + u];
+            rb4[u] = l_b[j0 + u];
             rc4[u] = l_c[j0 + u];
           }
 #pragma unroll
           for (int u = 0; u < kTrip; ++u) {
             const float4 a = ra[u];
-            const float4 b = rb[u];
-            const float cr = b.z, cg = rc4[u].x, cb = rc4[u].y, dep = rc4[u].z;
-            // power = -0.5 (cxx dx dx + czz dy dy) - cxy dx dy, in the reference's order (forward.cu:320-323)
-            const float dx = a.x - pixf_x;
-            const float qx = (a.w * dx) * dx;
-            const float bx = b.w * dx;
-            const f2 dy = splat(a.y) - pixf_y;
-            const f2 qy = (splat(a.z) * dy) * dy;
-            const f2 power = (splat(qx) + qy) - splat(bx) * dy;          // qx, qy carry the -0.5 (staging)
-            // Wave-uniform skip: if no pixel of the wave can reach alpha >= 1/255 on this record, everything below
-            // leaves the state as it is (alpha = 0: weight 0, test_T = T, no median crossing) — about a third of a
-            // tile pair's records lie in the corners of their 3-sigma square or beyond the wave's rows.  A NaN
-            // power fails the test and is evaluated in full, like the reference (min(0.99, NaN) = 0.99).
-            const float thr = rc4[u].w;
-            if (__ballot(!((power.x <= thr) & (power.y <= thr))) == 0ull) {
-              if constexpr (CONTRIB) {
-                const unsigned cov = __builtin_amdgcn_readfirstlane(__float_as_uint(rc4[u].w));
-                jA += (int)(cov & 1u);
-                jB += (int)((cov >> 1) & 1u);
+            const float4 b = rb4[u];
+            const unsigned bits = __builtin_amdgcn_readfirstlane(__float_as_uint(rc4[u].w));
+            const float dx = a.w - pixf_x;
+            const f2 dy = splat(a.x) - pixf_y;
+            f2 alpha, s;
+            bool skipped = false;
+            auto fast = [&]() {
+              const float t = b.z * dx;
+              const float nb = b.w * dx;
+              const f2 qxl = f2{__builtin_fmaf(t, dx, rc4[u].x), __builtin_fmaf(t, dx, rc4[u].y)};
+              const f2 p2 = rb::p2_simple(nb, a.y, qxl, dy);
+              if (__ballot(!((p2.x <= rb::kSkipP2) & (p2.y <= rb::kSkipP2))) == 0ull) {
+                skipped = true;                     // alpha < 1/255 at every pixel of the wave: nothing changes
+                return;
               }
-              continue;
-            }
-            const f2 p2 = power * splat(1.44269504088896340736f);       // __expf(x) = v_exp_f32(log2(e) x)
-            f2 G;
-            G.x = __builtin_amdgcn_exp2f(p2.x);
-            G.y = __builtin_amdgcn_exp2f(p2.y);
-            f2 alpha = f2{b.x, b.y} * G;
-            alpha.x = fminf(0.99f, alpha.x);
-            alpha.y = fminf(0.99f, alpha.y);
-            // the two "skip this Gaussian" tests share one select: two compares, one 64-bit scalar OR, one v_cndmask
-            alpha.x = ((power.x > 0.0f) | (alpha.x < 1.0f / 255.0f)) ? 0.f : alpha.x;
-            alpha.y = ((power.y > 0.0f) | (alpha.y < 1.0f / 255.0f)) ? 0.f : alpha.y;
-            const f2 test_T = T * (splat(1.0f) - alpha);
-            const f2 aT = alpha * T;
-            bool stopA = false, stopB = false;
-            f2 wgt = aT;
-            if constexpr (!NOSTOP) {
-              stopA = test_T.x < 0.0001f;
-              stopB = test_T.y < 0.0001f;
-              wgt.x = stopA ? 0.f : aT.x;
-              wgt.y = stopB ? 0.f : aT.y;
-            }
-            C0 = fma2(splat(cr), wgt, C0);
-            C1 = fma2(splat(cg), wgt, C1);
-            C2 = fma2(splat(cb), wgt, C2);
-            if constexpr (MEDIAN) {
-              // T > 0.5 and test_T < 0.5  <=>  (T - 0.5)(test_T - 0.5) < 0: T never rises, a stopped pixel's -|T| and its
-              // test_T are both below 0.5, and a non-zero |x - 0.5| is >= 2^-25, so the product cannot underflow.  h is
-              // carried: the next record's T is this record's test_T unless the pixel stops, and then both are < 0.5.
-              const f2 h2 = test_T - splat(0.5f);
-              const f2 cross = h * h2;
-              D.x = (cross.x < 0.f) ? dep : D.x;
-              D.y = (cross.y < 0.f) ? dep : D.y;
-              h = h2;
+              rb::alpha_of_p2(p2, kc, &alpha, &s);
+            };
+            if constexpr (GEN) {
+              if (bits & 4u) fast();
+              else rb::alpha_generic(dx, b.z, b.w, a.y, f2{rc4[u].x, rc4[u].y}, dy, &alpha, &s);
             } else {
-              D = fma2(splat(dep), wgt, D);
+              fast();
             }
             if constexpr (CONTRIB) {
-              const unsigned cov = __builtin_amdgcn_readfirstlane(__float_as_uint(rc4[u].w));
-              jA += (int)(cov & 1u);
-              jB += (int)((cov >> 1) & 1u);
+              jA += (int)(bits & 1u);
+              jB += (int)((bits >> 1) & 1u);
+            }
+            if (skipped) {
+              if constexpr (MEDIAN) rb::count_above_half(px, kc);
+              continue;
+            }
+            const f2 wgt = rb::chain<MEDIAN, !MEDIAN, NOSTOP>(px, alpha, s, a.z, b.x, b.y, rc4[u].z, kc);
+            if constexpr (CONTRIB) {
               lastA = (wgt.x > 0.f) ? (unsigned)jA : lastA;       // alpha T > 0 <=> this Gaussian was blended
               lastB = (wgt.y > 0.f) ? (unsigned)jB : lastB;
             }
-            if constexpr (NOSTOP) {
-              T = test_T;
-            } else {
-              T.x = stopA ? -fabsf(T.x) : test_T.x;
-              T.y = stopB ? -fabsf(T.y) : test_T.y;
-            }
           }
         };
+        const unsigned long long inA = __ballot(insideA), inB = __ballot(insideB);
+        auto may_stop = [&]() {
+          return ((__ballot(!(px.T.x > need)) & inA) | (__ballot(!(px.T.y > need)) & inB)) != 0ull;
+        };
+        // live <=> sign bit of T clear
+        auto any_alive = [&]() { return __ballot((__float_as_int(px.T.x) & __float_as_int(px.T.y)) >= 0) != 0ull; };
         int j0 = 0;
-        for (; j0 < ns4; j0 += kTrip) {
-          if (__ballot((insideA & !(T.x > kNoStopT)) | (insideB & !(T.y > kNoStopT))) != 0ull) break;
-          trip(std::true_type{}, j0);
+        if (!generic_batch) {
+          for (; j0 < ns4; j0 += kTrip) {
+            if (may_stop()) break;
+            trip(std::true_type{}, std::false_type{}, j0);
+          }
+          for (; j0 < ns4; j0 += kTrip) {
+            if (!any_alive()) break;
+            trip(std::false_type{}, std::false_type{}, j0);
+          }
+        } else {
+          for (; j0 < ns4; j0 += kTrip) {
+            if (!any_alive()) break;
+            trip(std::false_type{}, std::true_type{}, j0);
+          }
         }
-        for (; j0 < ns4; j0 += kTrip) {
-          // live <=> sign bit of T clear (T is never +-0: a live T is >= 1e-4, a stopped one is -|T|)
-          if (__ballot((__float_as_int(T.x) & __float_as_int(T.y)) >= 0) == 0ull) break;
-          trip(std::false_type{}, j0);
+        if constexpr (MEDIAN) {
+          // the record at which a pixel crossed 0.5 in this batch, if it did (raster_blend_math.h)
+          const int mA = rb::median_index(px.cnt.x, px.T.x), mB = rb::median_index(px.cnt.y, px.T.y);
+          if (mA >= 0) px.D.x = l_c[mA].z;
+          if (mB >= 0) px.D.y = l_c[mB].z;
+          px.cnt = splat(0.f);
         }
-        doneA = T.x < 0.f;
-        doneB = T.y < 0.f;
+        doneA = rb::dead(px.T.x);
+        doneB = rb::dead(px.T.y);
       } else {
       // Branch-free per-record update so that the LDS reads of the next records can be issued
       // ahead (4 records per trip); a wave leaves the batch as soon as its 128 pixels are done.
@@ -1053,8 +1045,8 @@ __global__ __launch_bounds__(kBlock) void raster_blend_kernel(
       out_color[(v * 3 + 2) * npix + pix] = c2 + t * bg[2];
       out_depth[v * npix + pix] = d;
     };
-    store(insideA, pyA, fabsf(T.x), lastA, C0.x, C1.x, C2.x, D.x);
-    store(insideB, pyB, fabsf(T.y), lastB, C0.y, C1.y, C2.y, D.y);
+    store(insideA, pyA, fabsf(px.T.x), lastA, px.C0.x, px.C1.x, px.C2.x, px.D.x);
+    store(insideB, pyB, fabsf(px.T.y), lastB, px.C0.y, px.C1.y, px.C2.y, px.D.y);
   }
 }
 

@@ -62,6 +62,63 @@ def test_planned_render_is_bit_identical_to_the_per_call_pipeline(cuda, n, seed,
     assert sum(plan.kept) <= 3 * n
 
 
+def _head_mode(n):
+    """ocrf_tune_set(13, n): list entries per view the head kernel prepares — n > 0 fixed, n < 0 none (every record is
+    computed by the tile pair that scans to it), 0 adaptive (the product default)."""
+    from ocrfdet_amd import _lib
+    _lib.check(_lib.lib().ocrf_tune_set(13, int(n)), 'ocrf_tune_set')
+
+
+@pytest.mark.parametrize('n,seed', [(300, 1), (5000, 2), (40000, 3)])
+@pytest.mark.parametrize('mode', ['median', 'mean'])
+def test_head_of_the_list_however_long_gives_the_same_image(cuda, n, seed, mode):
+    """Without radii a render prepares only the HEAD of every view's list in front of the blend (raster_plan_head_kernel);
+    a tile pair that scans further extends the arrays itself.  Whatever the split — nothing prepared, 256 entries, the
+    adaptive default (twice: the second call uses what the first one reached), everything (the full update, which
+    `want_radii` takes) — the images are the per-call pipeline's, bit for bit."""
+    rng = np.random.default_rng(seed)
+    W, H = 176, 80
+    xyz, rgb, opac, sc, rot = _scene(rng, n, cuda)
+    cams = _cams(cuda, W, H, [(0, 0, 0), (1.5, -0.5, 2.0), (-3.0, 0.4, -1.0)])
+    bg = torch.tensor([0.1, 0.2, 0.3], device=cuda)
+    want = dgr.rasterize_views(xyz, rgb, opac, sc, rot, None, None, None, None, H, W, bg, depth_mode=mode,
+                               packed_cameras=cams, want_n_contrib=False)
+    plan = rp.RasterPlan(xyz, cams, H, W, scales=sc, rotations=rot)
+    try:
+        for head in (-1, 256, 0, 0, 1 << 20):
+            _head_mode(head)
+            got = plan.render(rgb, opac, sc, rot, bg, depth_mode=mode)
+            _same(want, got)
+    finally:
+        _head_mode(0)
+    _same(want, plan.render(rgb, opac, sc, rot, bg, depth_mode=mode, want_radii=True))
+    torch.cuda.synchronize()
+    assert plan.check()
+
+
+def test_head_path_checks_extent_cameras_and_views(cuda):
+    """The head kernel carries the call's checks when no radii are asked: extent bound (status bit 4), the call's cameras
+    against the plan's (bit 16), a view named twice (bit 8)."""
+    rng = np.random.default_rng(13)
+    W, H = 128, 96
+    xyz, rgb, opac, sc, rot = _scene(rng, 3000, cuda, scale=(0.05, 0.3))
+    cams = _cams(cuda, W, H, [(0, 0, 0), (2.0, 0.0, 0.0)])
+    bg = torch.zeros(3, device=cuda)
+    plan = rp.RasterPlan(xyz, cams, H, W, scales=sc, rotations=rot, margin=1.0)
+    plan.render(rgb, opac, sc, rot, bg)
+    assert not plan.exceeded()
+    big = sc.clone()
+    big[5] *= 50.0
+    plan.render(rgb, opac, big, rot, bg)
+    assert plan.exceeded()
+    other = _cams(cuda, W, H, [(0, 0, 0), (2.5, 0.0, 0.0)])
+    plan.render(rgb, opac, sc, rot, bg, cameras=other)
+    assert plan.exceeded()
+    plan.render(rgb, opac, sc, rot, bg, item_view=torch.tensor([1, 1], dtype=torch.int32, device=cuda))
+    with pytest.raises(Exception):
+        plan.check()
+
+
 def test_plan_matches_the_oracle(cuda, oracle_lib):
     rng = np.random.default_rng(5)
     W, H = 176, 64

@@ -85,6 +85,41 @@ def test_single_gaussian_matches_oracle_exactly_in_state(cuda, oracle_lib):
     assert got['color'][0][:, 0, 0] == pytest.approx([0.1, 0.2, 0.3])      # background where T = 1
 
 
+@pytest.mark.parametrize('opacity,n_stack', [(0.99, 3), (0.995, 4), (0.97, 6), (0.9, 12)])
+def test_stacked_opaque_gaussians_stop_where_the_reference_stops(cuda, oracle_lib, opacity, n_stack):
+    """Consecutive records of opacity ~0.99 centred on one pixel: T goes 1 -> 0.01 -> 1e-4 -> ... inside ONE
+    trip of the blend loop, so the stop test (forward.cu:340-345: T (1 - alpha) < 1e-4 -> done, record not blended) must
+    be decided per record.  final_T and colour against the oracle, which loops like the reference."""
+    W, H = 64, 48
+    view, full, tfx, tfy = helpers.simple_camera(W, H)
+    rng = np.random.default_rng(17)
+    # a stack on the optical axis (pixel centre 32, 24), 2 cm apart in depth, then a bright wall behind it
+    xyz = [[0.0, 0.0, 4.0 + 0.02 * i] for i in range(n_stack)] + [[0.0, 0.0, 6.0]]
+    # ... beside another stack whose opacities alternate low / high (pairs of a trip with very different bounds)
+    xyz += [[0.8, 0.3, 3.0 + 0.02 * i] for i in range(2 * n_stack)]
+    n = len(xyz)
+    opac = [opacity] * n_stack + [0.9] + [0.2 if i % 2 else opacity for i in range(2 * n_stack)]
+    sc = np.full((n, 3), 0.25, np.float32)
+    sc[n_stack] = 2.0
+    q = np.tile(np.float32([1, 0, 0, 0]), (n, 1))
+    rgb = rng.uniform(0.2, 1.0, (n, 3)).astype(np.float32)
+    for mode in ('median', 'mean'):
+        want, got = _both(oracle_lib, cuda, np.float32(xyz), rgb, np.float32(opac).reshape(-1, 1), sc, q, view, full, tfx,
+                          tfy, H, W, bg=(0.3, 0.6, 0.9), depth_mode=mode)
+        _compare(want, got, H, W, label=f'stack of {n_stack} x {opacity}')
+        # the centre pixel of the stack: the transmittance the reference leaves, not 100 x less
+        np.testing.assert_allclose(got['final_T'][0][24, 32], want['final_T'][24, 32], rtol=1e-3, atol=1e-7)
+        # ... and the planned render (its own loop over the same shared arithmetic) agrees bit for bit
+        from ocrfdet_amd import raster_plan as rp
+        cams = dgr.pack_cameras(_t(view, cuda).view(1, 4, 4), _t(full, cuda).view(1, 4, 4), [tfx], [tfy], H, W, cuda)
+        plan = rp.RasterPlan(_t(np.float32(xyz), cuda), cams, H, W, extent_bound=4.0)
+        pl = plan.render(_t(rgb, cuda), _t(np.float32(opac).reshape(-1, 1), cuda), _t(sc, cuda), _t(q, cuda),
+                         _t(np.float32((0.3, 0.6, 0.9)), cuda), depth_mode=mode)
+        torch.cuda.synchronize()
+        for key in ('color', 'depth', 'final_T'):
+            np.testing.assert_array_equal(pl[key].cpu().numpy().reshape(got[key].shape), got[key])
+
+
 @pytest.mark.parametrize('n,seed', [(300, 0), (5000, 1), (20000, 2)])
 def test_random_scene_parity(cuda, oracle_lib, n, seed):
     rng = np.random.default_rng(seed)
@@ -120,7 +155,13 @@ def test_reference_shape_ocrf_grid_and_camera_convention(cuda, oracle_lib):
     tfx, tfy = math.tan(float(cam['FovX']) * 0.5), math.tan(float(cam['FovY']) * 0.5)
     want, got = _both(oracle_lib, cuda, xyz, rgb, opac, sc, q, view, full, tfx, tfy, H, W)
     assert want['num_rendered'] > 1000
-    _compare(want, got, H, W)
+    # Round 5: the blend evaluates the exponent of a SIMPLE record as two packed FMAs over a conic pre-multiplied by
+    # log2(e) with log2(opacity) as the constant term (csrc/raster_blend_math.h) instead of in forward.cu's order.  The
+    # quadratic form cancels (its three terms are several times its value), so BOTH orders carry ~1e-6..1e-5 of relative
+    # rounding in alpha — they just carry different ones (as does nvcc's own FMA contraction of forward.cu:320-323), and
+    # a few more of the pixels whose T lands within that distance of 0.5 / 1e-4 decide the other way: 6 of 180 224 here
+    # (3.3e-5), every one of them inside the oracle's threshold-ambiguity map.  Cap: 5e-5 of the image.
+    _compare(want, got, H, W, max_outlier_frac=5e-5, label='reference shape 256x704')
 
 
 def test_one_depth_bucket_larger_than_the_lds_sort(cuda, oracle_lib):
