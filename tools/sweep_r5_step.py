@@ -1,0 +1,39 @@
+"""Diagnostic: the cfg2 step under HotPath options, one process (median of blocks of 100 steps each).
+    python tools/sweep_r5_step.py"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ocrfdet_amd import _lib, hotpath, synthetic  # noqa: E402
+
+dev = torch.device('cuda:0')
+cfg = synthetic.CONFIGS['cfg2_6cam_2frame_bev200x200_render_hoa']
+
+
+def timed(hp, depth, feat, blocks=5, steps=100):
+    for _ in range(20):
+        hp.step(depth, feat)
+    torch.cuda.synchronize()
+    out = []
+    for _ in range(blocks):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            hp.step(depth, feat)
+        torch.cuda.synchronize()
+        out.append((time.perf_counter() - t0) / steps * 1e3)
+    return float(np.median(out)), min(out)
+
+
+variants = [dict(blend_workgroups=b) for b in (512, 640, 768, 896, 1024)]
+variants += [dict(blend_workgroups=b, lss_pool_backend='panel', ht_pool_backend='panel') for b in (640, 768, 896)]
+for kw in variants:
+    hp = hotpath.HotPath(cfg, dev, **kw)
+    depth, feat = hp.make_inputs()
+    med, mn = timed(hp, depth, feat)
+    hp.check_render_plans()
+    print(kw, 'median %.4f ms  min %.4f ms' % (med, mn), flush=True)
+    del hp
