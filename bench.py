@@ -81,8 +81,10 @@ def parse():
     ap.add_argument('--render-guard', choices=('host', 'device'), default='host',
                     help="planned renders: 'host' = the plan's extent bound is verified by one status read after the timed region; "
                          "'device' = the per-call pipeline is armed behind every planned render on the GPU")
-    ap.add_argument('--lss-pool', choices=('tile', 'mfma'), default='tile',
-                    help="kernel of the LSS pooling with cached ranks: the VALU tile kernel or the MFMA panel kernel (DESIGN.md 4.1b)")
+    ap.add_argument('--lss-pool', choices=('auto', 'tile', 'mfma', 'panel'), default='auto',
+                    help="kernel of the LSS pooling with cached ranks: the VALU tile kernel, the MFMA panel kernel (DESIGN.md "
+                         "4.1b) or the panel latency kernel (4.1c); auto = HotPath's choice (tile beside the persistent "
+                         "blend, panel where nothing VALU-bound runs beside the poolings)")
     ap.add_argument('--blend-workgroups', default='auto',
                     help="planned renders beside the main stream: workgroups of the persistent blend that stay while the main "
                          "chain runs ('auto' = 3.5 per CU; DESIGN.md section 5)")
@@ -573,7 +575,7 @@ def main():
         # whole-sample instance: the N = 1 step, the 'samples' / 'frames' layouts, and every layout's kernel figures
         hp = hotpath.HotPath(cfg, dev, index_prep_mode=args.index_prep, overlap=not args.no_overlap,
                              blend_workgroups='auto' if args.blend_workgroups == 'auto' else int(args.blend_workgroups),
-                             lss_pool_backend=args.lss_pool, **rkw)
+                             lss_pool_backend=None if args.lss_pool == 'auto' else args.lss_pool, **rkw)
     depth, feat = hp.make_inputs(seed=0 if shard in ('cameras', 'camera_frames') else rank)
 
     def step_whole():
@@ -604,7 +606,9 @@ def main():
     t_blend = _lib.KernelTimer(k_blend, 2 * args.steps + 8) if cfg.render else None
     t_pool = _lib.KernelTimer(_lib.K_BEV_POOL_FWD, 2 * (cfg.batch * cfg.n_frames if sp else 1) * args.steps + 8)
     t_mfma = _lib.KernelTimer(_lib.K_BEV_POOL_MFMA, 2 * (cfg.batch * cfg.n_frames if sp else 1) * args.steps + 8)
-    for t in (t_blend, t_pool, t_mfma):
+    t_panel = _lib.KernelTimer(_lib.K_BEV_POOL_PANEL, 2 * (cfg.batch * cfg.n_frames if sp else 1) * args.steps + 8)
+    t_cw = _lib.KernelTimer(_lib.K_BEV_POOL_CELL_WEIGHTS, 2 * (cfg.batch * cfg.n_frames if sp else 1) * args.steps + 8)
+    for t in (t_blend, t_pool, t_mfma, t_panel, t_cw):
         if t is not None:
             t.arm()
     # K blocks of `steps` steps, each bracketed like the contract says; the reported block is the MEDIAN one
@@ -623,14 +627,15 @@ def main():
 
     strong = shard in ('cameras', 'camera_frames')
     # ---- the same kernels alone on the device (renders on the main stream) ------------------------------------
-    iso_blend = iso_pool = iso_mfma = None
+    iso_blend = iso_pool = iso_mfma = iso_panel = iso_cw = None
     if shard in ('none', 'samples', 'frames'):
         was = hp.overlap
         hp.overlap = False
         ib = _lib.KernelTimer(k_blend, 64) if cfg.render else None
         ip = _lib.KernelTimer(_lib.K_BEV_POOL_FWD, 64)
         im = _lib.KernelTimer(_lib.K_BEV_POOL_MFMA, 64)
-        for t in (ib, ip, im):
+        ipn, icw = _lib.KernelTimer(_lib.K_BEV_POOL_PANEL, 64), _lib.KernelTimer(_lib.K_BEV_POOL_CELL_WEIGHTS, 64)
+        for t in (ib, ip, im, ipn, icw):
             if t is not None:
                 t.arm()
         torch.cuda.synchronize()
@@ -641,7 +646,8 @@ def main():
         iso_blend = ib.mean_ms() if ib is not None else None
         iso_pool = ip.mean_ms()
         iso_mfma = im.mean_ms()          # None when no pooling ran on the matrix cores
-        im.close()
+        iso_panel, iso_cw = ipn.read_ms(), icw.mean_ms()      # the panel launches alternate LSS, HT
+        im.close(), ipn.close(), icw.close()
         for t in (ib, ip):
             if t is not None:
                 t.close()
@@ -774,6 +780,21 @@ def main():
         mfma_ms = t_mfma.mean_ms()
         lss_on_mfma = getattr(hp, 'lss_pool_backend', 'tile') == 'mfma'
         ht_on_mfma = getattr(hp, 'ht_pool_backend', 'tile') == 'mfma' and mfma_ms
+        # the panel latency kernel (the default where nothing VALU-bound runs beside the poolings): its timer holds the LSS
+        # and the HT launch of every step in turn; the shared weight pre-pass has a timer of its own
+        panel_all = t_panel.read_ms()
+        on_panel = {nm: getattr(hp, nm + '_pool_backend', 'tile') == 'panel' and len(panel_all) > 0 for nm in ('lss', 'ht')}
+        both_panel = on_panel['lss'] and on_panel['ht']
+
+        def mean(v):
+            return sum(v) / len(v) if v else None
+
+        def panel_ms(which, series):
+            if not series:
+                return None
+            if both_panel:
+                return mean(series[0::2] if which == 'lss' else series[1::2])
+            return mean(series)
 
         def pool_entry(name, plan, kernel, in_step_ms, iso_ms, counters):
             alg = plan.algorithmic_bytes(d_numel, f_numel)
@@ -788,13 +809,22 @@ def main():
         both_tile = not lss_on_mfma and not ht_on_mfma      # one timer, two launches per step: the mean of both
         pools = {'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBS,
                  'algorithmic_bytes_formula': '4*(B*N*D*H*W + B*N*H*W*C + 3*Np + 2*Nv + B*Z*Y*X*C) per pooling (SURVEY 8d)',
-                 'lss': pool_entry('LSS (frustum ranks)', hp.lss, 'bev_pool_mfma_kernel<*>' if lss_on_mfma else t_pool.kernel_name,
-                                   mfma_ms if lss_on_mfma else pool_ms, iso_mfma if lss_on_mfma else iso_pool,
-                                   mfma_c if lss_on_mfma else tile_c),
-                 'ht': pool_entry('HT (height-sampling ranks)', hp.ht, 'bev_pool_mfma_kernel<*>' if ht_on_mfma else t_pool.kernel_name,
-                                  mfma_ms if ht_on_mfma else pool_ms, iso_mfma if ht_on_mfma else iso_pool,
-                                  mfma_c if ht_on_mfma else tile_c),
-                 'launches_timed': {'tile': t_pool.count(), 'mfma': t_mfma.count()},
+                 'lss': (pool_entry('LSS (frustum ranks)', hp.lss, t_panel.kernel_name, panel_ms('lss', panel_all),
+                                    panel_ms('lss', iso_panel), pmc_counters('bev_pool_panel_kernel', args)) if on_panel['lss'] else
+                         pool_entry('LSS (frustum ranks)', hp.lss, 'bev_pool_mfma_kernel<*>' if lss_on_mfma else t_pool.kernel_name,
+                                    mfma_ms if lss_on_mfma else pool_ms, iso_mfma if lss_on_mfma else iso_pool,
+                                    mfma_c if lss_on_mfma else tile_c)),
+                 'ht': (pool_entry('HT (height-sampling ranks)', hp.ht, t_panel.kernel_name, panel_ms('ht', panel_all),
+                                   panel_ms('ht', iso_panel), pmc_counters('bev_pool_panel_kernel', args)) if on_panel['ht'] else
+                        pool_entry('HT (height-sampling ranks)', hp.ht, 'bev_pool_mfma_kernel<*>' if ht_on_mfma else t_pool.kernel_name,
+                                   mfma_ms if ht_on_mfma else pool_ms, iso_mfma if ht_on_mfma else iso_pool,
+                                   mfma_c if ht_on_mfma else tile_c)),
+                 'cell_weights_prepass': ({'kernel': t_cw.kernel_name, 'avg_launch_us': 1e3 * t_cw.mean_ms(),
+                                           'isolated_avg_launch_us': 1e3 * iso_cw if iso_cw else None,
+                                           'note': 'one launch per step sums the cell weights of BOTH panel plans (they read '
+                                                   'the same depth tensor); the panel poolings above start from them'}
+                                          if (on_panel['lss'] or on_panel['ht']) and t_cw.mean_ms() else None),
+                 'launches_timed': {'tile': t_pool.count(), 'mfma': t_mfma.count(), 'panel': len(panel_all)},
                  'note': ('both poolings on the tile kernel: its timer holds both launches of a step, the durations above '
                           'are their mean' if both_tile else
                           'a kernel timer per backend: the durations are those of the named pooling alone '
@@ -902,8 +932,8 @@ def main():
             grid_note = None
             if planned and getattr(hp, 'overlap', False) and getattr(hp, 'blend_workgroups', None) == 'auto':
                 cus = torch.cuda.get_device_properties(dev).multi_processor_count
-                grid_note = {'workgroups_timed_region': 7 * cus // 2, 'workgroups_isolated': _lib.lib().ocrf_diag_plan_resident(),
-                             'note': 'beside the pooling / HOA stream the persistent blend is launched on 3.5 workgroups '
+                grid_note = {'workgroups_timed_region': 11 * cus // 4, 'workgroups_isolated': _lib.lib().ocrf_diag_plan_resident(),
+                             'note': 'beside the pooling / HOA stream the persistent blend is launched on 2.75 workgroups '
                                      'per CU of the five the chip holds (DESIGN 5); "frac" prices that partial-occupancy '
                                      'launch against the whole chip\'s peak, "isolated" is the full grid'}
             roofline = {
@@ -1030,7 +1060,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(hp, depth, feat, args.cpu_seconds)
             out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
         emit(out)
-    for t in (t_blend, t_pool, t_mfma):
+    for t in (t_blend, t_pool, t_mfma, t_panel, t_cw):
         if t is not None:
             t.close()
     if world > 1:

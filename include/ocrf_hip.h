@@ -755,6 +755,38 @@ int ocrf_diag_where(int n_blocks, unsigned *out, int spin_ticks, void *stream);
  * (GraphedNeck) refuse a graph whose census shows a memset node (e.g. a torch.zeros added inside the captured region). */
 int ocrf_graph_node_census(void *graph, int *n_kernel, int *n_memset, int *n_memcpy, int *n_other);
 int ocrf_stream_create(const uint32_t *cu_mask, int n_words, int priority, void **stream_out);
+/*
+ * One host call per step (csrc/step.hip).  The reference's boundary is one pybind call per op
+ * (mmdet3d/ops/bev_pool_v2/src/bev_pool.cpp:30-57); a step of the hot path here is ~18 launches behind seven of the
+ * entry points above on two HIP streams, and issuing them from Python costs the host as long as the device needs to
+ * run them.  An ocrf_step holds the calls of ONE step — entry point + argument values, recorded once while the step ran
+ * eagerly — and the fork / join points between its streams; ocrf_hotpath_step replays them from C on the caller's
+ * streams: the same entry points with the same arguments, launched eagerly (no hipGraph).  Pointer arguments are used as
+ * recorded: the caller keeps inputs, outputs and scratch alive and in place, as for a captured graph.
+ *   ocrf_step_fn_id(name)    id of an entry point a step can hold (-1: not supported — issue the step call by call):
+ *                            ocrf_bev_pool_v2_nchw_planned / _mfma / _panel, ocrf_bev_pool_cell_weights,
+ *                            ocrf_rasterize_planned, ocrf_raster_plan_build, ocrf_hoa1_forward, ocrf_hoa_v2b_forward,
+ *                            ocrf_hoa_channel_stats, ocrf_hoa_opacity_mask_gate, ocrf_stream_write_value32
+ *   ocrf_step_add_call       args: the entry point's arguments WITHOUT its trailing stream, one 64-bit word each —
+ *                            pointers / sizes / ints (sign-extended) as such, a float as its bit pattern in the low word;
+ *                            slot: which of the streams handed to the replay the call goes to (< 8)
+ *   ocrf_step_add_fork/_join stream slot `to` continues only after what slot `from` holds so far (an event record +
+ *                            wait; the events belong to the step object)
+ *   ocrf_step_run            replay on `streams[0 .. n_streams)`; ocrf_hotpath_step: slot 0 = main, slot 1 = side.
+ * All host pointers; not thread-safe per object; returns the first non-zero status of a replayed call.
+ */
+typedef struct ocrf_step ocrf_step;
+int ocrf_step_fn_id(const char *name);
+int ocrf_step_fn_args(int fn);
+int ocrf_step_create(ocrf_step **out);
+void ocrf_step_destroy(ocrf_step *step);
+int ocrf_step_add_call(ocrf_step *step, int fn, int slot, int n_args, const uint64_t *args);
+int ocrf_step_add_fork(ocrf_step *step, int from, int to);
+int ocrf_step_add_join(ocrf_step *step, int from, int to);
+int ocrf_step_size(const ocrf_step *step);
+int ocrf_step_run(ocrf_step *step, const ocrf_stream_t *streams, int n_streams);
+int ocrf_hotpath_step(ocrf_step *step, ocrf_stream_t main_stream, ocrf_stream_t side_stream);
+
 /* value -> *ptr (device int) in stream order, no kernel launch (hipStreamWriteValue32). */
 int ocrf_stream_write_value32(int *ptr, int value, ocrf_stream_t stream);
 int ocrf_stream_destroy(void *stream);

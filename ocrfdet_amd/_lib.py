@@ -44,6 +44,9 @@ def lib():
         except OSError as e:  # pragma: no cover
             raise OcrfHipError(f"cannot load {_SO}: {e}") from e
         _declare(_LIB)
+        _declare_step(_LIB)
+    if _RECORDER is not None:
+        return _RecordingLib(_LIB, _RECORDER)
     return _LIB
 
 
@@ -242,6 +245,169 @@ def _declare(L):
     L.ocrf_timer_destroy.argtypes = [c_void_p]
 
 
+def _declare_step(L):
+    c_int, c_void_p = ctypes.c_int, ctypes.c_void_p
+    L.ocrf_step_fn_id.restype = c_int
+    L.ocrf_step_fn_id.argtypes = [ctypes.c_char_p]
+    L.ocrf_step_fn_args.restype = c_int
+    L.ocrf_step_fn_args.argtypes = [c_int]
+    L.ocrf_step_create.restype = c_int
+    L.ocrf_step_create.argtypes = [ctypes.POINTER(c_void_p)]
+    L.ocrf_step_destroy.restype = None
+    L.ocrf_step_destroy.argtypes = [c_void_p]
+    L.ocrf_step_add_call.restype = c_int
+    L.ocrf_step_add_call.argtypes = [c_void_p, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_uint64)]
+    L.ocrf_step_add_fork.restype = c_int
+    L.ocrf_step_add_fork.argtypes = [c_void_p, c_int, c_int]
+    L.ocrf_step_add_join.restype = c_int
+    L.ocrf_step_add_join.argtypes = [c_void_p, c_int, c_int]
+    L.ocrf_step_size.restype = c_int
+    L.ocrf_step_size.argtypes = [c_void_p]
+    L.ocrf_step_run.restype = c_int
+    L.ocrf_step_run.argtypes = [c_void_p, ctypes.POINTER(c_void_p), c_int]
+    L.ocrf_hotpath_step.restype = c_int
+    L.ocrf_hotpath_step.argtypes = [c_void_p, c_void_p, c_void_p]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# One host call per step (csrc/step.hip): the library calls of a step are recorded once, while the step runs eagerly,
+# and replayed from C afterwards.
+# ---------------------------------------------------------------------------------------------------------------
+_RECORDER = None
+# entry points that enqueue nothing (sizes, lengths, knobs, timers): passed through while a step is being recorded
+_QUERY_SUFFIXES = ('_bytes', '_len', '_rows', '_side', '_panels', '_tiles', '_bands', '_resident', '_version', '_name',
+                   '_max_units')
+_QUERY_PREFIXES = ('ocrf_timer_', 'ocrf_tune_', 'ocrf_step_', 'ocrf_diag_', 'ocrf_kernel_')
+
+
+class StepNotRecordable(OcrfHipError):
+    pass
+
+
+class StepRecorder:
+    """Records the library calls of ONE step while it is issued eagerly: ``with recorder: step()``.  ``streams``: the
+    torch streams of the step in slot order (slot 0 = the caller's); a call on any other stream, or of an entry point
+    ``ocrf_step_fn_id`` does not know, makes the step not recordable (``ok`` False — keep issuing it call by call).
+    The owner marks the fork / join points itself (``fork`` / ``join``: it is the one that issues the torch events).
+    ``build()`` -> a ``CompiledStep``.  Everything a recorded call points at has to stay alive and in place."""
+
+    def __init__(self, streams):
+        self.slots = {int(st.cuda_stream): i for i, st in enumerate(streams)}
+        self.items = []
+        self.ok = True
+        self.why = None
+
+    def __enter__(self):
+        global _RECORDER
+        if _RECORDER is not None:
+            raise OcrfHipError('a step is already being recorded')
+        lib()
+        _RECORDER = self
+        return self
+
+    def __exit__(self, *exc):
+        global _RECORDER
+        _RECORDER = None
+        return False
+
+    def fail(self, why):
+        if self.ok:
+            self.ok, self.why = False, why
+
+    def fork(self, frm, to):
+        self.items.append(('fork', frm, to))
+
+    def join(self, frm, to):
+        self.items.append(('join', frm, to))
+
+    def on_call(self, name, fn, args):
+        L = _LIB
+        fid = L.ocrf_step_fn_id(name.encode())
+        if fid < 0:
+            return self.fail(f'{name} cannot be held by a step object')
+        types = fn.argtypes
+        if types is None or len(types) != len(args) or L.ocrf_step_fn_args(fid) != len(args) - 1:
+            return self.fail(f'{name}: argument list does not match its declaration')
+        raw = args[-1]
+        raw = raw.value if isinstance(raw, ctypes._SimpleCData) else raw
+        slot = self.slots.get(int(raw or 0))
+        if slot is None:
+            return self.fail(f'{name} was issued on a stream the step does not know')
+        words = []
+        for a, t in zip(args[:-1], types[:-1]):
+            v = a.value if isinstance(a, ctypes._SimpleCData) else a
+            if t is ctypes.c_float:
+                import struct
+                words.append(struct.unpack('<I', struct.pack('<f', float(v)))[0])
+            else:
+                words.append((0 if v is None else int(v)) & 0xFFFFFFFFFFFFFFFF)
+        self.items.append(('call', fid, slot, words))
+
+    def build(self):
+        if not self.ok:
+            raise StepNotRecordable(self.why)
+        return CompiledStep(self.items)
+
+
+class _RecordingLib:
+    """What ``lib()`` hands out while a step is recorded: every enqueueing entry point is logged, then called."""
+
+    def __init__(self, L, rec):
+        self._L, self._rec = L, rec
+
+    def __getattr__(self, name):
+        fn = getattr(self._L, name)
+        if (not name.startswith('ocrf_') or name.endswith(_QUERY_SUFFIXES) or name.startswith(_QUERY_PREFIXES)):
+            return fn
+        rec = self._rec
+
+        def logged(*args):
+            rec.on_call(name, fn, args)
+            return fn(*args)
+        return logged
+
+
+class CompiledStep:
+    """The calls of one step inside the library (``ocrf_step``): ``run(main, side, ...)`` issues all of them with one
+    host call."""
+
+    def __init__(self, items):
+        L = lib()
+        self._h = ctypes.c_void_p()
+        check(L.ocrf_step_create(ctypes.byref(self._h)), 'ocrf_step_create')
+        self.n_calls = 0
+        for it in items:
+            if it[0] == 'call':
+                _, fid, slot, words = it
+                arr = (ctypes.c_uint64 * len(words))(*words)
+                check(L.ocrf_step_add_call(self._h, fid, slot, len(words), arr), 'ocrf_step_add_call')
+                self.n_calls += 1
+            elif it[0] == 'fork':
+                check(L.ocrf_step_add_fork(self._h, it[1], it[2]), 'ocrf_step_add_fork')
+            else:
+                check(L.ocrf_step_add_join(self._h, it[1], it[2]), 'ocrf_step_add_join')
+        self._run2 = L.ocrf_hotpath_step
+        self._runn = L.ocrf_step_run
+
+    def run(self, *raw_streams):
+        """``raw_streams``: hipStream_t values (ints) in slot order."""
+        if len(raw_streams) == 2:
+            err = self._run2(self._h, raw_streams[0], raw_streams[1])
+        else:
+            arr = (ctypes.c_void_p * len(raw_streams))(*raw_streams)
+            err = self._runn(self._h, arr, len(raw_streams))
+        if err != 0:
+            raise OcrfHipError(f'ocrf_hotpath_step failed with hipError_t {err}')
+
+    def __del__(self):
+        try:
+            if self._h:
+                _LIB.ocrf_step_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
 def check(err, what):
     if err != 0:
         raise OcrfHipError(f"{what} failed with hipError_t {err}")
@@ -365,7 +531,7 @@ workspace = Workspace()
 
 
 K_BEV_POOL_FWD, K_BEV_POOL_FIXUP, K_BEV_POOL_INTERVAL, K_BEV_POOL_GRAD, K_BEV_POOL_NCHW = 1, 2, 3, 4, 5
-K_BEV_POOL_MFMA = 6
+K_BEV_POOL_MFMA, K_BEV_POOL_PANEL, K_BEV_POOL_CELL_WEIGHTS = 6, 7, 8
 K_RASTER_PREPROCESS, K_RASTER_BLEND, K_RASTER_GATHER = 10, 11, 12
 K_RASTER_SCAN, K_RASTER_BLEND_BWD, K_RASTER_PRE_BWD = 13, 15, 16
 K_RASTER_PLAN_UPDATE, K_RASTER_BLEND_SORTED = 17, 18

@@ -58,8 +58,8 @@ def shared_stream(device, role):
 class HotPath:
     def __init__(self, cfg, device, cams=None, index_prep_mode='cached', overlap=True, device_geometry=False,
                  render_mode='planned', render_guard='host', frame_motion=True, frame_offset=0, plan_margin=1.25,
-                 ht_pool_backend='mfma', fuse_frames='auto', render_streams=1, blend_workgroups='auto',
-                 lss_pool_backend='tile', lss_mfma_group=2, plan_rebuild='never'):
+                 ht_pool_backend=None, fuse_frames='auto', render_streams=1, blend_workgroups='auto',
+                 lss_pool_backend=None, lss_mfma_group=2, plan_rebuild='never', hoa_first=None, one_call=True):
         """``cams``: optional list of camera indices this instance owns (camera sharding).
         ``index_prep_mode``: 'cached' — rank vectors computed once per calibration, the reference's
         ``accelerate=True`` intent; 'per_step' — recomputed inside every ``step()`` by the HIP index
@@ -73,7 +73,17 @@ class HotPath:
         per-SAMPLE pose costs: the reference builds the render cameras from the dataloader's c2w for every sample
         (view_transformer_ocrf.py:1140-1152, detectors/ocrfdet.py:215-223).
         ``frame_motion``: batch entry b is frame ``frame_offset + b`` of a multi-frame sample with its own ego pose
-        (``synthetic.ego_motion``) and its own Gaussian parameters, instead of every frame repeating frame 0."""
+        (``synthetic.ego_motion``) and its own Gaussian parameters, instead of every frame repeating frame 0.
+        ``lss_pool_backend`` / ``ht_pool_backend``: 'tile' | 'mfma' | 'panel'; None = 'panel', the latency kernel of
+        csrc/bev_pool_panel.hip: 13-30 % faster than tile / mfma alone on the device, and — since round 5, with the host
+        out of the step's way and the blend on 2.75 workgroups per CU — also beside the blend (cfg2 step 0.200 vs 0.208 /
+        0.212 ms with tile LSS / mfma HT, tools/sweep_r5_step.py).
+        ``hoa_first``: HOA-1/2 before the poolings (None: with the per-call render or the per-step index preparation).
+        ``one_call``: after its first, recorded, issue a step is ONE host call (``ocrf_hotpath_step``: the library calls
+        of the step replayed from C, ``_lib.StepRecorder``) instead of ~14 ctypes calls + torch stream / event calls
+        (225 -> ~60 us of host work at cfg2).  The step's outputs are then the SAME tensors every step (overwritten by
+        the next one, like a replayed graph's), and ``depth`` / ``feat`` have to be the tensors of the recorded call
+        (another pair is recorded anew)."""
         self.cfg, self.device = cfg, torch.device(device)
         assert render_mode in ('planned', 'per_call') and render_guard in ('host', 'device')
         assert plan_rebuild in ('never', 'per_step')
@@ -83,10 +93,20 @@ class HotPath:
         # 'mfma': the HT pooling (cached ranks) as per-tile MFMA panels (csrc/bev_pool_mfma.hip: 26 vs 32 us at cfg2);
         # 'tile': the VALU tile kernel for both poolings.  The LSS ranks keep the tile kernel (its heavy tiles — a
         # 3.2 m block beside the rig collects thousands of rows — make the per-tile MFMA chain the launch's tail).
+        self.overlap = bool(overlap) and self.device.type == 'cuda'
+        if lss_pool_backend is None:
+            lss_pool_backend = 'panel'
+        if ht_pool_backend is None:
+            ht_pool_backend = 'panel'
         assert ht_pool_backend in ('mfma', 'tile', 'panel') and lss_pool_backend in ('mfma', 'tile', 'panel')
         self.lss_panel_unit_cost = 8.0
         self.ht_pool_backend = ht_pool_backend
         self.lss_pool_backend, self.lss_mfma_group = lss_pool_backend, int(lss_mfma_group)
+        self.hoa_first = hoa_first
+        self.one_call = bool(one_call) and self.device.type == 'cuda'
+        self._compiled = None                  # (key, _lib.CompiledStep, outputs, memory pool) of the recorded step
+        self._one_call_ok = True
+        self._warm_key = None
         # planned renders: consecutive frames in one plan / one launch pair.  'auto': when ALL frames fit one plan
         # (<= 32 views; cfg2: 0.300 -> 0.285 ms — one update -> blend hand-over and one drain of the persistent grid
         # less); with more frames a launch pair per frame is faster (cfg4: 3.08 vs 3.18 ms in groups of five)
@@ -108,7 +128,6 @@ class HotPath:
         # beside the pools + HOA of the main stream (the blend is VALU-bound with a ragged tail, the pools
         # and the small HOA kernels are latency / L2-bound: they interleave).  One stream per frame was
         # worse: two blends at once slow each other more than the overlap returns (0.66 vs 0.60 ms)
-        self.overlap = bool(overlap) and self.device.type == 'cuda'
         self._side = []
         self._prep_stream = self._prep_stream2 = None
         self._prepare()
@@ -174,7 +193,7 @@ class HotPath:
         self.bev_pos1 = (torch.randn(self.batch, 4, Y, X, generator=g) * 0.1).to(dev)
 
     @torch.no_grad()
-    def hoa_opacity_bev(self, defer=False):
+    def hoa_opacity_bev(self):
         """HOA-1/2 (view_transformer_ocrf.py:1159-1161, 1196): opacity BEV (B,1,Y,X).  Independent of the pooled
         BEV (it reads the Gaussian opacities and the NeRF-branch alpha volume)."""
         cfg = self.cfg
@@ -186,23 +205,14 @@ class HotPath:
             self._opac_flat = torch.stack([fg['opacity'].view(cfg.num_height, Y, X) for fg in self.frame_gauss]) \
                 .reshape(-1, 1).contiguous()
         oa = hoa.hoa1(m['dca'], self._opac_flat, self.alpha_lidar, cfg.num_height, Y, X)
-        if defer and getattr(self, 'fuse_out_conv', False):
-            # HOA-2 one launch short: its output conv runs in the prologue of the HOA-3 gate (hoa_step).  Built, bit-identical
-            # (tests/test_hoa_modules.py) and measured: one launch less, but the gate kernel's longer prologue (decoder1's
-            # tile maxima, two more barriers) in front of its 51 MB stream costs the step more than the launch did —
-            # cfg2 0.2438 / 0.2416 / 0.2452 ms folded against 0.2399 / 0.2414 / 0.2386 separate, three A/B passes in one
-            # session (tools/ab_step_knobs.py --fuse-out).  Off by default.
-            return m['v2b'].forward_deferred(oa, self.bev_pos1)
         return m['v2b'](oa, self.bev_pos1)
 
     @torch.no_grad()
-    def hoa_step(self, geom_feat, opacity_bev=None, stats=None):
+    def hoa_step(self, geom_feat, opacity_bev=None):
         """HOA-1/2/3 (view_transformer_ocrf.py:1159-1161, 1196-1199): -> (gated BEV, opacity BEV)."""
         if opacity_bev is None:
-            opacity_bev = self.hoa_opacity_bev(defer=True)
-        _, gated = self.hoa_mods['mask'].gate(geom_feat, opacity_bev, stats=stats)
-        if isinstance(opacity_bev, hoa.DeferredOpacityBEV):
-            opacity_bev = opacity_bev.value
+            opacity_bev = self.hoa_opacity_bev()
+        _, gated = self.hoa_mods['mask'].gate(geom_feat, opacity_bev)
         return gated, opacity_bev
 
     def _prepare_render(self, r, convention='corrected', seed=0):
@@ -312,10 +322,11 @@ class HotPath:
         if word is None and self._use_busy():
             word = self._busy
         if bw == 'auto':
-            # beside the other chain: 3.5 workgroups per CU of the five the chip holds (round 3: 2 of 4 with the 118-VGPR
-            # blend; round 4: the 95-VGPR blend leaves room for the other chain's waves at 3.5 — cfg2 step at 704 / 768 /
-            # 832 / 896 / 960 workgroups: 0.251 / 0.246 / 0.242 / 0.237 / 0.242 ms, tools/sweep_r4.sh)
-            bw = (7 * torch.cuda.get_device_properties(self.device).multi_processor_count // 2
+            # beside the other chain: 2.75 workgroups per CU of the five the chip holds (round 4: 3.5 with the heavier blend
+            # behind a 32-us update; round 5, one host call per step and a blend of half the instructions: cfg2 step at
+            # 448 / 512 / 576 / 640 / 704 / 768 / 896 workgroups 0.225 / 0.218 / 0.209 / 0.203 / 0.200 / 0.208 / 0.224 ms,
+            # tools/sweep_r5_step.py)
+            bw = (11 * torch.cuda.get_device_properties(self.device).multi_processor_count // 4
                   if (self.overlap or getattr(self, '_yield_word', None) is not None) else 0)
         elif not isinstance(bw, int):
             bw = int(bw[min(f0, len(bw) - 1)])
@@ -474,34 +485,59 @@ class HotPath:
 
     def step(self, depth, feat):
         """One pass of the hot path: pools (+ render + HOA where the configuration has them).
-        -> (lss, ht[, rendered][, gated, opacity_bev]), everything ordered on the caller's stream."""
-        fork = self.overlap and self.cfg.render
+        -> (lss, ht[, rendered][, gated, opacity_bev]), everything ordered on the caller's stream.  With ``one_call``
+        the returned tensors are the same objects every step (see ``__init__``)."""
         if self.cfg.render and self.render_mode == 'planned':
             self._plans()             # first step: built on the caller's stream BEFORE the side streams branch off it
+        if not (self.one_call and self._one_call_ok) or torch.cuda.is_current_stream_capturing():
+            return self._step_eager(depth, feat)
+        cur = torch.cuda.current_stream(self.device)
+        key = (depth.data_ptr(), feat.data_ptr(), self.index_prep_mode, self.plan_rebuild, self.overlap, self.blend_workgroups
+               if isinstance(self.blend_workgroups, (int, str)) else tuple(self.blend_workgroups))
+        if self._compiled is None or self._compiled[0] != key:
+            if self._warm_key != key:
+                # the first step of a (tensors, mode) builds plans and scratch (launches that belong to no later step):
+                # issued call by call, the next one is recorded
+                self._warm_key = key
+                return self._step_eager(depth, feat)
+            return self._record_step(depth, feat, key, cur)
+        _, compiled, out, _pool = self._compiled
+        raw = [cur.cuda_stream] + [st.cuda_stream for st in self._side] if self._forks() else [cur.cuda_stream]
+        compiled.run(*raw)
+        for entry in (self.render_plans or []) if self.cfg.render and self.render_mode == 'planned' else []:
+            entry[0]._host_guarded = entry[0]._host_guarded or self.render_guard == 'host'
+        return out
+
+    def _forks(self):
+        return self.overlap and self.cfg.render
+
+    def _record_step(self, depth, feat, key, cur):
+        """Issue the step eagerly once more, with the library calls logged (``_lib.StepRecorder``) and every tensor it
+        allocates drawn from a memory pool of its own (the recorded pointers stay valid: the pool is kept)."""
+        if self._forks() and not self._side:
+            self._side = [shared_stream(self.device, 'render' if k == 0 else f'render{k}')
+                          for k in range(self.render_streams)]
+        rec = _lib.StepRecorder([cur] + (list(self._side) if self._forks() else []))
+        pool = torch.cuda.MemPool()
+        with torch.cuda.use_mem_pool(pool, self.device), rec:
+            out = self._step_eager(depth, feat, rec)
+        if (not rec.ok or self.index_prep_mode != 'cached' or (self.cfg.render and self.render_mode != 'planned')
+                or self.render_guard != 'host'):
+            # a step with launches outside the recordable entry points (per-step index preparation, the per-call or the
+            # device-guarded render): keep issuing it call by call
+            self._one_call_ok = False
+            self.one_call_refused = rec.why or 'a step of this mode is issued call by call'
+            return out
+        self._compiled = (key, rec.build(), out, pool)
+        return out
+
+    def _step_eager(self, depth, feat, rec=None):
+        fork = self._forks()
         if not fork:
             main = self._main_chain(depth, feat)
             rendered = [self.render()] if self.cfg.render else []
             return tuple(main[:2]) + tuple(rendered) + tuple(main[2:])
         cur = torch.cuda.current_stream(self.device)
-        if getattr(self, 'render_on_caller_stream', False):
-            # The other arrangement: the render chain (update -> persistent blend) on the caller's stream, the pools + HOA
-            # chain on the branch.  Measured WORSE at cfg2 (0.298 vs 0.270 ms, tools/sweep_r4.sh): the twelve dependent
-            # launches of the pools + HOA chain run slower from a side stream than the two launches of the render chain do.
-            chain = shared_stream(self.device, 'chain')
-            chain.wait_stream(cur)
-            self._set_busy(1)
-            rendered = self.render()
-            with torch.cuda.stream(chain):
-                main = self._main_chain(depth, feat)
-                self._set_busy(0)
-            cur.wait_stream(chain)
-            for t in main:
-                t.record_stream(cur)      # allocated on the branch, handed to the caller's stream
-            return tuple(main[:2]) + (rendered,) + tuple(main[2:])
-        plans = self._plans() if (self.cfg.render and self.render_mode == 'planned') else []
-        if (getattr(self, 'schedule', 'overlap') == 'phased' and len(plans) == 1
-                and self.render_guard == 'host' and self.index_prep_mode == 'cached'):
-            return self._step_phased(depth, feat, plans[0], cur)
         # "the main chain is running": the persistent blends of the render stream keep to 3.5 workgroups per CU
         # while it is up and take the whole chip once it is down (cfg4: the renders outlast the poolings + HOA)
         self._set_busy(1)
@@ -513,69 +549,28 @@ class HotPath:
             self._fork_ev = torch.cuda.Event()
             self._join_ev = [torch.cuda.Event() for _ in self._side]
         self._fork_ev.record(cur)
-        for side in self._side:
+        for k, side in enumerate(self._side):
             side.wait_event(self._fork_ev)        # inputs (and last step's consumers) are ordered before
-        # host issue order (the render call is ~60 us of host work, a pooling ~14): 'render_first' puts the update alone on
-        # the chip for its 33 us before anything of the main chain arrives; 'lss_first' / 'pools_first' issue the LSS pooling /
-        # both poolings before the render call (A/B: tools/ab_step_knobs.py --issue)
-        order = getattr(self, 'issue_order', 'render_first')
-        early = None
-        if order in ('lss_first', 'pools_first') and self.index_prep_mode == 'cached':
-            early = [self.pool(self.lss, depth, feat), self.pool(self.ht, depth, feat) if order == 'pools_first' else None]
+            if rec is not None:
+                rec.fork(0, 1 + k)
+        # host issue order: the render call first (measured against the LSS pooling / both poolings first: within 1 %)
         rendered = self.render([self._side[b % len(self._side)] for b in range(self.batch)])
-        main = self._main_chain(depth, feat, early)
+        main = self._main_chain(depth, feat)
         self._set_busy(0)
-        for side, ev in zip(self._side, self._join_ev):
+        for k, (side, ev) in enumerate(zip(self._side, self._join_ev)):
             ev.record(side)
             cur.wait_event(ev)                    # join: everything the step returns is ordered on `cur`
+            if rec is not None:
+                rec.join(1 + k, 0)
+        # the rendered images were allocated while a side stream was current and are consumed on the caller's: the caching
+        # allocator must not hand their blocks to the next side-stream render while the caller still reads them
+        for frame in rendered:
+            for v in frame.values():
+                if torch.is_tensor(v):
+                    v.record_stream(cur)
         return tuple(main[:2]) + (rendered,) + tuple(main[2:])
 
-    def _step_phased(self, depth, feat, entry, cur):
-        """The step in two phases instead of two free-running chains.  The poolings are latency-bound and live on
-        occupancy (five 96-VGPR waves per SIMD): beside the persistent blend (118 VGPRs per wave) a SIMD holds two of
-        them and they take 2.5 x as long (LSS 37 -> 97 us, HT 30 -> 74 us in the round-4 timeline), which made them the
-        step's critical chain.  So: phase 1 = the poolings alone on the chip, with only the memory-bound plan update
-        beside them (side stream); phase 2 = the VALU-bound blend on three workgroups per CU (where it saturates:
-        144 us vs 180 us on two) with the small HOA kernels beside it.  One extra event: the blend waits for the
-        poolings.  MEASURED SLOWER than the two free-running chains at cfg2 (0.270 vs 0.255 ms, tools/sweep_r4.sh; HOA-1/2
-        on a third stream 0.30): the ten small HOA launches crawl beside a three-workgroup-per-CU blend.  Kept as
-        ``hp.schedule = 'phased'`` for the A/B, not used by default."""
-        side = shared_stream(self.device, 'render')
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            upd = self._render_planned(entry, phase='update')
-        hoa_side = None
-        ob = None
-        if self.cfg.hoa and getattr(self, 'hoa_stream', False):
-            # HOA-1/2 read nothing of the poolings: eight small kernels on a stream of their own, beside phase 1
-            hoa_side = shared_stream(self.device, 'hoa')
-            hoa_side.wait_stream(cur)
-            with torch.cuda.stream(hoa_side):
-                ob = self.hoa_opacity_bev()
-        lss, ht = self.pool_step(depth, feat, None)
-        pooled = torch.cuda.Event()
-        pooled.record(cur)
-        side.wait_event(pooled)
-        bw_was = self.blend_workgroups
-        if bw_was == 'auto':
-            self.blend_workgroups = 3 * torch.cuda.get_device_properties(self.device).multi_processor_count
-        try:
-            with torch.cuda.stream(side):
-                rendered = self._render_planned(entry, phase='blend', out=upd)
-        finally:
-            self.blend_workgroups = bw_was
-        out = [lss, ht, rendered]
-        if self.cfg.hoa:
-            if hoa_side is not None:
-                cur.wait_stream(hoa_side)
-                ob.record_stream(cur)
-            else:
-                ob = self.hoa_opacity_bev()
-            out.extend(self.hoa_step(ht, ob))
-        cur.wait_stream(side)
-        return tuple(out)
-
-    def _main_chain(self, depth, feat, early=None):
+    def _main_chain(self, depth, feat):
         """Pools + HOA on the current stream -> (lss, ht[, gated, opacity_bev])."""
         # HOA-1/2 do not read the pooled BEV and are latency chains of small kernels
         prepared = None
@@ -604,21 +599,14 @@ class HotPath:
             p2.wait_event(blocks_ready)
             with torch.cuda.stream(p2):
                 prepared = (lss_prepared, self._prepare_ht(ht_block))
-        # HOA-1/2 need nothing of the poolings and the poolings nothing of them: with the planned render (a memory-bound
-        # update kernel, then the VALU-bound blend) the poolings go FIRST — they meet the side stream's update and the
-        # start of its blend instead of its middle; with the per-call render, whose chip-filling preprocess opens the
-        # side stream, and with the per-step index preparation (which the poolings have to wait for anyway) HOA-1/2
-        # first.  (Round 4, HOA-1/2 shortened to 55 us: pools first + a 640-workgroup blend 0.262 ms, HOA first + 512
-        # workgroups 0.270, tools/sweep_r4.sh.)
-        hoa_first = getattr(self, 'hoa_first', self.render_mode != 'planned' or self.index_prep_mode == 'per_step')
-        ob = self.hoa_opacity_bev(defer=True) if (self.cfg.hoa and hoa_first) else None
-        hoa_side = None
-        if self.cfg.hoa and not hoa_first and getattr(self, 'hoa_stream', False) and self.overlap:
-            # HOA-1/2 (eight small kernels) on a stream of their own beside the poolings
-            hoa_side = shared_stream(self.device, 'hoa')
-            hoa_side.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(hoa_side):
-                ob = self.hoa_opacity_bev()
+        # HOA-1/2 need nothing of the poolings and the poolings nothing of them: with the planned render the poolings go
+        # FIRST — they meet the start of the side stream's blend instead of its middle; with the per-call render, whose
+        # chip-filling preprocess opens the side stream, and with the per-step index preparation (which the poolings have
+        # to wait for anyway) HOA-1/2 first.
+        hoa_first = self.hoa_first
+        if hoa_first is None:
+            hoa_first = self.render_mode != 'planned' or self.index_prep_mode == 'per_step'
+        ob = self.hoa_opacity_bev() if (self.cfg.hoa and hoa_first) else None
         if prepared is not None:
             main = torch.cuda.current_stream(self.device)
             (lv, lc), (hv, hc) = prepared
@@ -627,39 +615,14 @@ class HotPath:
             main.wait_stream(self._prep_stream2)
             ht = bevpool.bev_pool_v2_device_counts(depth, feat, hv[1], hv[2], hv[0], self.ht.bev_shape, hv[3], hv[4], hc)
         else:
-            if early is not None:
-                lss, ht = early[0], (early[1] if early[1] is not None else self.pool(self.ht, depth, feat))
-            else:
-                lss, ht = self.pool_step(depth, feat, prepared)
-        # HOA-3's channel statistics read only the pooled BEV: issued on another stream as soon as the HT pooling is
-        # through, they run beside HOA-1/2 instead of after them (one launch and its gap off the end of the main chain,
-        # where nothing else is left to hide it).  'render': behind the blend on the render stream (idle by then);
-        # 'own': a stream of their own.
-        stats, stats_stream = None, None
-        where = getattr(self, 'stats_stream', None)
-        if self.cfg.hoa and where and self.overlap and not hoa_first and not getattr(self, 'fuse_out_conv', False):
-            main = torch.cuda.current_stream(self.device)
-            stats_stream = (self._side[0] if (where == 'render' and getattr(self, '_side', None))
-                            else shared_stream(self.device, 'stats'))
-            pooled = torch.cuda.Event()
-            pooled.record(main)
-            stats_stream.wait_event(pooled)
-            with torch.cuda.stream(stats_stream):
-                stats = hoa.channel_stats(ht)
-            ht.record_stream(stats_stream)
-        if hoa_side is not None:
-            torch.cuda.current_stream(self.device).wait_stream(hoa_side)
-            ob.record_stream(torch.cuda.current_stream(self.device))
-        elif self.cfg.hoa and not hoa_first:
-            ob = self.hoa_opacity_bev(defer=True)
+            lss, ht = self.pool_step(depth, feat, prepared)
+        if self.cfg.hoa and not hoa_first:
+            ob = self.hoa_opacity_bev()
         out = [lss, ht]
         if self.cfg.hoa:
-            if stats_stream is not None:
-                torch.cuda.current_stream(self.device).wait_stream(stats_stream)
-                stats.record_stream(torch.cuda.current_stream(self.device))
             # stand-in for geom_feat: the HT BEV has its shape (B,C,Y,X); the fusion convs between
             # the pools and HOA-3 are MIOpen territory, not part of this path
-            out.extend(self.hoa_step(ht, ob, stats=stats))
+            out.extend(self.hoa_step(ht, ob))
         return out
 
     @property

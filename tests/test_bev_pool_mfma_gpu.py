@@ -82,7 +82,8 @@ def test_hot_path_ht_pool_backends_agree(cuda):
     from ocrfdet_amd import hotpath
     cfg = synthetic.PathConfig(**{**synthetic.CONFIGS['cfg2_6cam_2frame_bev200x200_render_hoa'].__dict__,
                                   'render': False, 'hoa': False})
-    a, b = hotpath.HotPath(cfg, cuda, ht_pool_backend='mfma'), hotpath.HotPath(cfg, cuda, ht_pool_backend='tile')
+    a = hotpath.HotPath(cfg, cuda, lss_pool_backend='tile', ht_pool_backend='mfma')
+    b = hotpath.HotPath(cfg, cuda, lss_pool_backend='tile', ht_pool_backend='tile')
     depth, feat = a.make_inputs(3)
     la, ha = a.step(depth, feat)[:2]
     lb, hb = b.step(depth, feat)[:2]

@@ -53,7 +53,7 @@ def test_cfg2_render_both_camera_conventions(cuda, oracle_lib, convention):
 def test_cfg4_rank_triples_pools_and_render_at_512x1408(cuda, oracle_lib):
     cfg = _one_frame(CFG4)
     assert cfg.feat_hw == (32, 88)
-    hp = hotpath.HotPath(cfg, cuda, ht_pool_backend='tile')      # the per-step path below pools with the tile kernel
+    hp = hotpath.HotPath(cfg, cuda, lss_pool_backend='tile', ht_pool_backend='tile')      # the per-step path below pools with the tile kernel
     depth, feat = hp.make_inputs(seed=2)
     lss, ht, rendered = hp.step(depth, feat)[:3]
     torch.cuda.synchronize()
@@ -154,24 +154,17 @@ def test_cfg2_step_as_benched_against_per_call_renders_and_oracles(cuda, oracle_
 
 
 def test_cfg2_step_options_give_the_same_outputs(cuda):
-    """Schedules and pooling back ends that were measured against the default: same results — HOA-3's channel
-    statistics on another stream bit for bit, the panel poolings within the summation-order tolerance of the LSS grid
-    (the HT grid: bit-identical to the MFMA form)."""
+    """Pooling back ends that were measured against the default: the panel poolings within the
+    summation-order tolerance of the LSS grid (the HT grid: bit-identical to the MFMA form).  And the step issued by ONE
+    host call (``ocrf_hotpath_step``: its library calls recorded once, replayed from C) equals the step issued call by
+    call, bit for bit — after EVERY input of the step has been changed in place, so that a replay that missed a launch
+    (or a torch op between the library's own) would show stale values."""
     cfg = synthetic.CONFIGS[CFG2]
-    ref_hp = hotpath.HotPath(cfg, cuda)
+    ref_hp = hotpath.HotPath(cfg, cuda, one_call=False)
     depth, feat = ref_hp.make_inputs(seed=1)
     ref = ref_hp.step(depth, feat)
     torch.cuda.synchronize()
-    for where in ('own', 'render'):
-        hp = hotpath.HotPath(cfg, cuda)
-        hp.stats_stream = where
-        for _ in range(2):
-            out = hp.step(depth, feat)
-        torch.cuda.synchronize()
-        for a, b in ((out[0], ref[0]), (out[1], ref[1]), (out[3], ref[3]), (out[4], ref[4])):
-            assert torch.equal(a, b), where
-        assert torch.equal(out[2][1]['color'], ref[2][1]['color'])
-    hp = hotpath.HotPath(cfg, cuda, lss_pool_backend='panel', ht_pool_backend='panel')
+    hp = hotpath.HotPath(cfg, cuda, lss_pool_backend='panel', ht_pool_backend='panel', one_call=False)
     for _ in range(2):
         out = hp.step(depth, feat)
     torch.cuda.synchronize()
@@ -179,3 +172,36 @@ def test_cfg2_step_options_give_the_same_outputs(cuda):
     torch.testing.assert_close(out[0], ref[0], rtol=1e-5, atol=1e-5)        # LSS: tile kernel vs panel plan (another order)
     assert torch.equal(out[1], ref[1])                                        # HT: the MFMA form's bits
     assert torch.equal(out[3], ref[3]) and torch.equal(out[4], ref[4])
+    del hp
+
+    one = hotpath.HotPath(cfg, cuda)                   # one_call=True is the default
+    d1, f1 = depth.clone(), feat.clone()
+    one.step(d1, f1)                                   # issued call by call (builds plans and scratch)
+    one.step(d1, f1)                                   # recorded (issued call by call once more, its library calls logged)
+    one.step(d1, f1)                                   # replayed: one host call
+    assert one._compiled is not None and one._compiled[1].n_calls >= 7
+    # new values everywhere, same tensors: inputs of the poolings, of the renders, of HOA
+    d2, f2 = ref_hp.make_inputs(seed=5)
+    d1.copy_(d2), f1.copy_(f2)
+    X, Y, _ = cfg.bev_xyz
+    for hpx in (one, ref_hp):
+        g = torch.Generator(device='cpu').manual_seed(11)
+        for fg in hpx.frame_gauss:
+            fg['opacity'].copy_((torch.rand(fg['opacity'].shape, generator=g) * 0.3 + 0.3).to(cuda))
+            fg['rgb'].copy_(torch.rand(fg['rgb'].shape, generator=g).to(cuda))
+            fg['scales'].copy_((torch.rand(fg['scales'].shape, generator=g) * 0.1 + 0.7).to(cuda))
+        hpx.alpha_lidar.copy_(torch.rand(hpx.alpha_lidar.shape, generator=g).to(cuda))
+        # the step reads the STACKED parameter tensors of its plans and the flat opacity volume of HOA-1: in place too
+        for plan, f0, nf, gg in hpx._plans():
+            for k in ('rgb', 'opacity', 'scales', 'rotations'):
+                gg[k].copy_(torch.stack([hpx.frame_gauss[b][k] for b in range(f0, f0 + nf)]))
+        hpx._opac_flat.copy_(torch.stack([fg['opacity'].view(cfg.num_height, Y, X) for fg in hpx.frame_gauss]).reshape(-1, 1))
+    want = ref_hp.step(d2, f2)
+    got = one.step(d1, f1)
+    torch.cuda.synchronize()
+    for i in (0, 1, 3, 4):
+        assert torch.equal(got[i], want[i]), i
+    for fr_g, fr_w in zip(got[2], want[2]):
+        for k in ('color', 'depth', 'final_T'):
+            assert torch.equal(fr_g[k], fr_w[k]), k
+    one.check_render_plans()

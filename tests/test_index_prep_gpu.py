@@ -126,7 +126,7 @@ def test_per_step_path_without_host_reads_equals_cached_path(cuda, key):
     from ocrfdet_amd import hotpath
     cfg = synthetic.CONFIGS[key]
     cfg = synthetic.PathConfig(**{**cfg.__dict__, 'render': False, 'hoa': False})
-    a = hotpath.HotPath(cfg, cuda, ht_pool_backend='tile')      # the per-step path pools with the tile kernel
+    a = hotpath.HotPath(cfg, cuda, lss_pool_backend='tile', ht_pool_backend='tile')      # the per-step path pools with the tile kernel
     b = hotpath.HotPath(cfg, cuda, index_prep_mode='per_step')
     depth, feat = a.make_inputs(seed=1)
     want = a.step(depth, feat)
