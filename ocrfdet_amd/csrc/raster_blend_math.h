@@ -82,7 +82,7 @@ struct Staged { float4 a, b, c; };
 // `need factor`: sqrt(1.25e-4) / (1 - amax), amax >= every alpha this record can produce (see no_stop_need)
 __device__ __forceinline__ float need_factor(float o, bool simple) {
   const float amax = simple ? o : fminf(0.99f, o);               // NaN opacity -> NaN factor -> "may stop"
-  return 0.011180340f / (1.0f - amax);
+  return 0.011180340f * __frcp_rn(1.0f - amax);
 }
 
 __device__ __forceinline__ Staged stage(const float4 con, float px, float py, float r, float g, float b, float depth,
@@ -92,7 +92,7 @@ __device__ __forceinline__ Staged stage(const float4 con, float px, float py, fl
   const float A = simple ? con.x * kLog2e : con.x;
   const float C = simple ? con.y * kLog2e : con.y;
   const float B = simple ? -(con.z * kLog2e) : con.z;
-  const float L = simple ? log2f(o) : o;
+  const float L = simple ? __log2f(o) : o;                       // v_log_f32: 1 ulp, one instruction (libm's log2f: ~20)
   s.a = make_float4(py, C, r, px);
   s.b = make_float4(g, b, A, B);
   s.c = make_float4(L, need_factor(o, simple), depth, 0.f);
@@ -108,9 +108,10 @@ __device__ __forceinline__ Staged stage_noop() {
 }
 
 // While every pixel of a wave (inside the image) has T > need0 need1 = 1.25e-4 / ((1 - amax0)(1 - amax1)), neither of
-// the trip's two records can trip the stop test: after the first T >= T (1 - amax0) (1 - 2^-22), after the second
-// T' >= T (1 - amax0)(1 - amax1)(1 - 2^-21) > 1.2e-4 > 1e-4.  The product is formed per TRIP from the factors of its
-// two records (a per-trip test against a constant is wrong for two records).
+// a trip's two records can trip the stop test: after the first T >= T (1 - amax0) (1 - 2^-22), after the second
+// T' >= T (1 - amax0)(1 - amax1)(1 - 2^-21) > 1.2e-4 > 1e-4.  (a per-trip test against the constant
+// 1/80, which covers ONE record of alpha <= 0.99, is wrong for two.)  The kernels use the largest factor of a wave's
+// list (of a staged batch) for both records: one number per batch, no per-trip operand.
 __device__ __forceinline__ float no_stop_need(float f0, float f1) { return f0 * f1; }
 
 // exponent (base 2, log2(opacity) included) of a SIMPLE record at the lane's two pixels.

@@ -28,12 +28,7 @@ def timed(hp, depth, feat, blocks=5, steps=100):
     return float(np.median(out)), min(out)
 
 
-P = dict(lss_pool_backend='panel', ht_pool_backend='panel')
-variants = [dict(blend_workgroups=b, **P) for b in (448, 512, 576, 640, 704)]
-variants += [dict(blend_workgroups=b, hoa_first=True, **P) for b in (576, 640)]
-variants += [dict(blend_workgroups=b, lss_pool_backend='panel', ht_pool_backend='mfma') for b in (576, 640)]
-variants += [dict(blend_workgroups=b, lss_pool_backend='tile', ht_pool_backend='panel') for b in (576, 640)]
-variants += [dict(blend_workgroups=640, one_call=False, **P)]
+variants = [dict(blend_workgroups=b) for b in (640, 704, 768, 896)]
 for kw in variants:
     hp = hotpath.HotPath(cfg, dev, **kw)
     depth, feat = hp.make_inputs()
