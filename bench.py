@@ -982,7 +982,12 @@ def main():
                 'bytes_received_per_rank_reduce_scatter_dense_form': ex.bytes_reduce_scatter_dense,
                 'bytes_received_per_rank_all_gather': ex.bytes_all_gather,
                 'in_place_all_gather': bool(ex.direct), 'overlap': 'collectives asynchronous beside the renders (side HIP '
-                'stream) and HOA-1/2; HOA-3 gate replicated on the gathered grid'}
+                'stream) and HOA-1/2',
+                'hoa': 'sharded by frame: a rank runs HOA-1/2 only for the frames it has a part in (' +
+                       str(len(sp.my_frames)) + ' of ' + str(sp.n_frames) + ' here) and HOA-3 in place on its own plane '
+                       'blocks between the two collectives (sharding.gate_blocks: per-block channel statistics, one small '
+                       'all_gather inside the frame group); the world all_gather carries LSS planes + GATED HT planes + '
+                       'the opacity BEV plane'}
         else:
             sharding_desc = {'none': 'none',
                              'samples': f'{world} ranks x 1 sample (6 cams x {cfg.n_frames} frames) each, no data-path collective',

@@ -417,20 +417,25 @@ def channel_stats(x):
     return stats
 
 
-def spatial_gate(weight, x, addend, want_gated, stats=None):
+def spatial_gate(weight, x, addend, want_gated, stats=None, in_place=False):
     """mask = sigmoid(conv_kxk([mean_c(x), max_c(x)]; weight (1,2,k,k)) + addend (B,1,Y,X)) and,
     optionally, x * mask — the shared form of ObatinOpacityMask (view_transformer_ocrf.py:230-242,
     :1197-1199) and BEVGeomAttention (:215-228, :1190), as two HIP kernels (csrc/hoa.hip).  ``stats``: the result of
-    ``channel_stats(x)`` if the caller already has it (ordered before this call on the current stream)."""
+    ``channel_stats(x)`` if the caller already has it (ordered before this call on the current stream) — or the statistics
+    of a LARGER channel set x is a slice of (camera-frame sharding: a rank gates its plane block with the group's
+    combined statistics).  ``in_place``: x * mask overwrites x (every element is read by the thread that writes it, before
+    it writes: the kernel's x and gated may be the same tensor)."""
     _lib.require_cuda(x, addend)
     B, C, Y, X = x.shape
+    if in_place and (x.dtype != torch.float32 or not x.is_contiguous()):
+        raise _lib.OcrfHipError('in_place gating needs a contiguous fp32 tensor')
     x, ob = _f32c(x), _f32c(addend)
     w = _f32c(weight)
     k = w.shape[-1]
     if stats is not None and (tuple(stats.shape) != (B, 2, Y, X) or stats.dtype != torch.float32 or not stats.is_contiguous()):
         raise _lib.OcrfHipError('stats must be the contiguous fp32 (B,2,Y,X) result of channel_stats(x)')
     mask = torch.empty(B, 1, Y, X, device=x.device)
-    gated = torch.empty_like(x) if want_gated else None
+    gated = (x if in_place else torch.empty_like(x)) if want_gated else None
     L = _lib.lib()
     with _lib.on_device(x.device):
         st = _lib.stream_ptr(x.device)
@@ -449,7 +454,7 @@ class ObatinOpacityMask(nn.Module):          # sic: the reference's spelling
         self.conv = nn.Conv2d(2, 1, kernel_size, padding=kernel_size // 2, bias=False)
         self.sigmoid = nn.Sigmoid()
 
-    def _run(self, x, opacity_bev, want_gated, stats=None):
+    def _run(self, x, opacity_bev, want_gated, stats=None, in_place=False):
         if isinstance(opacity_bev, DeferredOpacityBEV):
             return self._run_deferred(x, opacity_bev, want_gated)
         _lib.require_cuda(x, opacity_bev)
@@ -458,7 +463,7 @@ class ObatinOpacityMask(nn.Module):          # sic: the reference's spelling
             stats = torch.cat((x.mean(1, keepdim=True), x.amax(1, keepdim=True)), 1)
             mask = self.sigmoid(self.conv(stats) + opacity_bev)
             return mask, (x * mask if want_gated else None)
-        return spatial_gate(self.conv.weight, x, opacity_bev, want_gated, stats=stats)
+        return spatial_gate(self.conv.weight, x, opacity_bev, want_gated, stats=stats, in_place=in_place)
 
     @torch.no_grad()
     def _run_deferred(self, x, deferred, want_gated):
@@ -486,10 +491,10 @@ class ObatinOpacityMask(nn.Module):          # sic: the reference's spelling
     def forward(self, x, opacity_bev):
         return self._run(x, opacity_bev, False)[0]
 
-    def gate(self, x, opacity_bev, stats=None):
-        """-> (mask, x * mask): view_transformer_ocrf.py:1197-1199 in two HBM passes.  ``stats``: ``channel_stats(x)`` if
-        the caller issued it already (it reads only x: HotPath runs it beside HOA-1/2)."""
-        return self._run(x, opacity_bev, True, stats=stats)
+    def gate(self, x, opacity_bev, stats=None, in_place=False):
+        """-> (mask, x * mask): view_transformer_ocrf.py:1197-1199 in two HBM passes.  ``stats``: ``channel_stats`` of x
+        — or of the whole channel set x is a block of — if the caller has it already; ``in_place``: x is overwritten."""
+        return self._run(x, opacity_bev, True, stats=stats, in_place=in_place)
 
 
 # ------------------------------------------------------------------------------------------------

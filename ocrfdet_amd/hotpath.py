@@ -634,11 +634,19 @@ class HotPath:
 class ShardedHotPath:
     """The hot path of ONE sample with its camera-frames sharded over the ranks of a ``torch.distributed`` job
     (``sharding.CameraFramePlan``; BASELINE.json north_star, configs[3] / [4]): this rank pools and renders only
-    the camera-frames it owns, the partial fused BEVs are summed inside each frame's group (reduce_scatter over
-    plane blocks) and ONE world all_gather leaves the complete fused grid ``(n_frames, Z*C + C, Y, X)`` on every
-    rank; HOA runs replicated on it.  The collectives are asynchronous: the renders (side HIP stream) and HOA-1/2
-    (which do not read the pooled BEV) run beside them.  With ``world == 1`` it is ``HotPath`` with the same fused
-    output buffer."""
+    the camera-frames it owns and runs HOA only for the frames it has a part in.  Per step:
+      renders (side HIP stream) | pools of the owned cameras into the fused grid's plane blocks
+      step 1 of the exchange: the partial grids are summed inside each frame's group (reduce_scatter over plane blocks)
+      HOA-1/2 of the OWN frames (they read nothing of the pooled BEV: issued beside step 1)
+      HOA-3 on the rank's finished plane blocks, in place (``sharding.gate_blocks``: per-block channel statistics, one
+        small all_gather inside the group, the gate of the own channels) — the opacity BEV goes into an extra plane
+      step 2: ONE world all_gather — it carries the LSS planes, the GATED height-sampling planes and the opacity BEVs:
+        the complete fused grid ``(n_frames, Z*C + C + 1, Y, X)`` on every rank.
+    HOA is a per-sample loop in the reference (view_transformer_ocrf.py:1090-1161,1196-1199) and frames are independent
+    until the concat (detectors/ocrfdet.py:274): at configs[4] on 8 ranks (whole frames per rank, no reduce) a rank runs the
+    ten HOA launches of ONE frame, not of eight; with groups, HOA-1/2 are replicated inside a frame's group only and
+    HOA-3 is split over it.  The collectives are asynchronous: the renders and HOA-1/2 run beside them.  With
+    ``world == 1`` it is ``HotPath`` with the same fused output buffer, bit for bit."""
 
     def __init__(self, cfg, device, rank, world, index_prep_mode='cached', render_mode='planned', render_guard='host',
                  sparse_exchange=True, collectives=None):
@@ -648,18 +656,33 @@ class ShardedHotPath:
         C = cfg.channels
         self.n_frames = cfg.batch * cfg.n_frames
         self.planes_lss = Z * C
-        self.plan = sharding.CameraFramePlan(cfg.n_cams, self.n_frames, world, (Z + 1) * C)
+        self.planes_pool = (Z + 1) * C                          # LSS planes, then HT planes: what the poolings write
+        # the frame's opacity BEV rides along as one more plane of the fused grid (written by the rank whose block holds it)
+        self.opacity_plane = self.planes_pool if cfg.hoa else None
+        self.plan = sharding.CameraFramePlan(cfg.n_cams, self.n_frames, world, self.planes_pool + (1 if cfg.hoa else 0))
         self.exchange = sharding.BevExchange(self.plan, rank, self.device, (Y, X), collectives=collectives)
         one = synthetic.PathConfig(**{**cfg.__dict__, 'batch': 1, 'n_frames': 1, 'hoa': False})
         self.subs = {f: HotPath(one, self.device, cams=self.plan.cams_of(rank, f), index_prep_mode=index_prep_mode,
-                                overlap=False, frame_offset=f, render_mode=render_mode, render_guard=render_guard)
+                                overlap=False, frame_offset=f, render_mode=render_mode, render_guard=render_guard,
+                                one_call=False)
                      for f in self.plan.frames_of(rank)}
-        # HOA (replicated) needs the Gaussian opacities / alpha volume of every frame, not this rank's cameras
-        self.base = HotPath(synthetic.PathConfig(**{**cfg.__dict__, 'render': cfg.render or cfg.hoa}), self.device,
-                            cams=[0], index_prep_mode='cached', overlap=False) if cfg.hoa else None
+        # HOA weights and inputs: drawn for ALL frames exactly as the unsharded HotPath draws them (one generator), then
+        # only the own frames' slices are kept on the device for the steps
+        self.my_frames = self.plan.frames_of(rank)
+        self.base = None
+        if cfg.hoa:
+            self.base = HotPath(synthetic.PathConfig(**{**cfg.__dict__, 'render': cfg.render or cfg.hoa}), self.device,
+                                cams=[0], index_prep_mode='cached', overlap=False, one_call=False)
+            fr = self.my_frames
+            Zh = cfg.num_height
+            self._hoa_in = None
+            if fr:
+                opac = torch.stack([self.base.frame_gauss[f]['opacity'].view(Zh, Y, X) for f in fr]).reshape(-1, 1).contiguous()
+                self._hoa_in = (opac, self.base.alpha_lidar[fr].contiguous(), self.base.bev_pos1[fr].contiguous())
+        self.hoa_launch_frames = 0                              # frames whose HOA-1/2 this rank issued in its last step
         self._side = shared_stream(self.device, 'render') if self.device.type == 'cuda' and cfg.render else None
         # the renders run on the side stream beside this rank's poolings, the exchange and HOA: their persistent blends
-        # keep to 3.5 workgroups per CU while that chain is running and take the whole chip once it is done (the same
+        # keep to a part of the chip while that chain is running and take the whole chip once it is done (the same
         # occupancy split as HotPath.step; a hint, the images do not depend on it)
         self._busy = None
         if self._side is not None and render_mode == 'planned':
@@ -699,10 +722,45 @@ class ShardedHotPath:
     def views_per_step(self):
         return sum(len(s.cams) for s in self.subs.values()) if self.cfg.render else 0
 
-    def step(self, inputs):
-        """-> (fused BEV (n_frames, Z*C + C, Y, X) complete on every rank, rendered list, gated, opacity_bev)."""
+    # ---- HOA, sharded by frame ----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _hoa12(self):
+        """HOA-1/2 of the frames this rank has a part in -> {frame: (Y,X) opacity BEV} (empty on an idle rank)."""
+        self.hoa_launch_frames = 0
+        if self.base is None or not self.my_frames:
+            return {}
         cfg = self.cfg
-        ex = self.exchange
+        X, Y, _ = cfg.bev_xyz
+        opac, alpha, pos = self._hoa_in
+        m = self.base.hoa_mods
+        ob = m['v2b'](hoa.hoa1(m['dca'], opac, alpha, cfg.num_height, Y, X), pos)        # (len(my_frames), 1, Y, X)
+        self.hoa_launch_frames = len(self.my_frames)
+        return {f: ob[i, 0] for i, f in enumerate(self.my_frames)}
+
+    def _gate(self, ex, ob):
+        """HOA-3 on this rank's finished plane blocks, in place (``sharding.gate_blocks``)."""
+        from . import sharding
+        if self.base is None:
+            return
+        X, Y, _ = self.cfg.bev_xyz
+        mask = self.base.hoa_mods['mask']
+
+        def stats_fn(x):
+            return hoa.channel_stats(x.unsqueeze(0))[0]
+
+        def gate_fn(x, stats, opacity):
+            mask.gate(x.unsqueeze(0), opacity.reshape(1, 1, Y, X), stats=stats.unsqueeze(0).contiguous(), in_place=True)
+        with torch.no_grad():
+            sharding.gate_blocks(ex, self.planes_lss, self.cfg.channels, self.opacity_plane, ob, stats_fn, gate_fn)
+
+    def _outputs(self, full, rendered):
+        gated = opacity_bev = None
+        if self.base is not None:
+            gated = [full[f:f + 1, self.planes_lss:self.planes_pool] for f in range(self.n_frames)]
+            opacity_bev = full[:, self.planes_pool:self.planes_pool + 1]
+        return full, rendered, gated, opacity_bev
+
+    def _pool_and_render(self, inputs, target_of):
         cur = torch.cuda.current_stream(self.device) if self._side is not None else None
         rendered = []
         if self._side is not None:
@@ -712,72 +770,75 @@ class ShardedHotPath:
                 rendered.append(sub.render([self._side]))
         for f, sub in self.subs.items():
             depth, feat = inputs[f]
-            tgt = ex.pool_target(f)
+            tgt = target_of(f)
             sub.pool(sub.lss, depth, feat, out=tgt[:self.planes_lss])
-            sub.pool(sub.ht, depth, feat, out=tgt[self.planes_lss:])
-        works = ex.start()
-        opacity_bev = self.base.hoa_opacity_bev() if self.base is not None else None
-        full = ex.finish(works)
-        gated = None
-        if self.base is not None:
-            # per frame: a frame's HT planes are contiguous inside the fused grid, the batch of them is not
-            gated = [self.base.hoa_step(full[f:f + 1, self.planes_lss:], opacity_bev[f:f + 1])[0]
-                     for f in range(self.n_frames)]
+            sub.pool(sub.ht, depth, feat, out=tgt[self.planes_lss:self.planes_pool])
+        return cur, rendered
+
+    def _join_renders(self, cur, rendered):
         if self._side is not None:
             self._set_busy(0)
             cur.wait_stream(self._side)
-        return full, rendered, gated, opacity_bev
+            for per_sub in rendered:          # allocated while the side stream was current, consumed on the caller's
+                for frame in per_sub:
+                    for v in frame.values():
+                        if torch.is_tensor(v):
+                            v.record_stream(cur)
+
+    def step(self, inputs):
+        """-> (fused BEV (n_frames, Z*C + C [+ 1], Y, X) complete on every rank — LSS planes, GATED height-sampling planes,
+        opacity BEV —, rendered list, gated (views of the fused grid, per frame), opacity_bev (view))."""
+        if getattr(self, 'pipe', None) is not None and self.pipe._pending is not None:
+            raise _lib.OcrfHipError('a pipelined step is pending on the shared exchange buffers: flush_pipelined() first')
+        ex = self.exchange
+        cur, rendered = self._pool_and_render(inputs, ex.pool_target)
+        works = ex.start()
+        ob = self._hoa12()
+        ex.finish_reduce(works)
+        self._gate(ex, ob)
+        full = ex.gather()
+        self._join_renders(cur, rendered)
+        return self._outputs(full, rendered)
 
     def step_pipelined(self, inputs):
         """The same step with the exchange taken off its critical path (``sharding.PipelinedExchange``): this call pools
-        and renders step k and starts its exchange on a communication stream; it RETURNS step k - 1 — (fused BEV, rendered
-        list, gated, opacity_bev) as ``step`` does, ``None`` for the first call — whose exchange ran under this call's
-        poolings and renders.  ``flush_pipelined()`` hands out the last step.  A rank's throughput is then
-        max(own compute, exchange) instead of their sum; the price is one step of latency, and the returned tensors of
-        step k - 1 are overwritten two calls later."""
+        and renders step k, runs its HOA-1/2 and starts its exchange — step 1, the in-place HOA-3 of the own blocks, step 2
+        — on a communication stream; it RETURNS step k - 1 (as ``step`` does; ``None`` for the first call), whose exchange
+        ran under this call's poolings and renders.  ``flush_pipelined()`` hands out the last step.  A rank's throughput
+        is then max(own compute, exchange) instead of their sum; the price is one step of latency, and the returned
+        tensors of step k - 1 are overwritten two calls later.  The pipeline has two buffer sets of its own on the process
+        groups of ``self.exchange``."""
         from . import sharding
         if getattr(self, 'pipe', None) is None:
+            ex0 = sharding.BevExchange(self.plan, self.rank, self.device, (self.exchange.Y, self.exchange.X),
+                                       share=self.exchange)
+            if self.exchange.touched:
+                ex0.adopt_touched(self.exchange)
             self.pipe = sharding.PipelinedExchange(self.plan, self.rank, self.device, (self.exchange.Y, self.exchange.X),
-                                                   first=self.exchange)
+                                                   first=ex0)
             self._held = None
         pipe = self.pipe
-        cur = torch.cuda.current_stream(self.device) if self._side is not None else None
-        rendered = []
-        if self._side is not None:
-            self._set_busy(1)
-            self._side.wait_stream(cur)
-            for f, sub in self.subs.items():
-                rendered.append(sub.render([self._side]))
-        for f, sub in self.subs.items():
-            depth, feat = inputs[f]
-            tgt = pipe.pool_target(f)
-            sub.pool(sub.lss, depth, feat, out=tgt[:self.planes_lss])
-            sub.pool(sub.ht, depth, feat, out=tgt[self.planes_lss:])
-        full_prev = pipe.submit()                  # step k's collectives start; step k - 1's grid is complete
-        opacity_bev = self.base.hoa_opacity_bev() if self.base is not None else None
-        held, self._held = self._held, (rendered, opacity_bev)
-        out = self._finish_pipelined(full_prev, held)
-        if self._side is not None:
-            self._set_busy(0)
-            cur.wait_stream(self._side)
-        return out
+        cur, rendered = self._pool_and_render(inputs, pipe.pool_target)
+        ob = self._hoa12()
+        if pipe._comm is not None:
+            for t in ob.values():
+                t.record_stream(pipe._comm)
+        full_prev = pipe.submit(between=lambda ex: self._gate(ex, ob))      # step k's exchange starts; step k - 1's grid is complete
+        held, self._held = self._held, rendered
+        self._join_renders(cur, rendered)
+        if full_prev is None or held is None:
+            return None
+        return self._outputs(full_prev, held)
 
     def flush_pipelined(self):
         """-> the last step submitted by ``step_pipelined`` (None if nothing is pending)."""
         if getattr(self, 'pipe', None) is None:
             return None
         held, self._held = self._held, None
-        return self._finish_pipelined(self.pipe.flush(), held)
-
-    def _finish_pipelined(self, full, held):
+        full = self.pipe.flush()
         if full is None or held is None:
             return None
-        rendered, opacity_bev = held
-        gated = None
-        if self.base is not None:
-            gated = [self.base.hoa_step(full[f:f + 1, self.planes_lss:], opacity_bev[f:f + 1])[0]
-                     for f in range(self.n_frames)]
-        return full, rendered, gated, opacity_bev
+        return self._outputs(full, held)
 
     def _set_busy(self, value):
         if self._busy is not None:

@@ -31,7 +31,7 @@ import torch
 import torch.distributed as dist
 
 __all__ = ['assign_units', 'choose_policy', 'frames_of_rank', 'cams_of_rank', 'reduce_partial_bev',
-           'gather_frames', 'CameraFramePlan', 'BevExchange', 'PipelinedExchange', 'Collectives', 'GlooCollectives',
+           'gather_frames', 'CameraFramePlan', 'BevExchange', 'PipelinedExchange', 'gate_blocks', 'Collectives', 'GlooCollectives',
            'GlooEmulation']
 
 
@@ -430,11 +430,38 @@ class BevExchange:
 
     def finish(self, works=()):
         """Waits for step 1 (on the current stream), then the world all_gather; -> (n_frames, P, Y, X)."""
+        self.finish_reduce(works)
+        return self.gather()
+
+    def finish_reduce(self, works=()):
+        """Waits for step 1 on the current stream: this rank's plane blocks (``block_views``) hold their final sums."""
         for w in works:
             if w[0] == 'sparse':
                 self._finish_sparse(w)
             elif w[1] is not None:
                 w[1].wait()
+
+    def block_views(self):
+        """-> [(frame, first plane, n planes, (n, Y, X) view)]: this rank's finished plane blocks where the world
+        all_gather will pick them up — what is written there (a gate applied in place, an extra plane filled in) travels."""
+        out = []
+        for f, p0, n in self.my_blocks:
+            off, _, _ = self._my_block(f)
+            out.append((f, p0, n, self.send[off:off + n]))
+        return out
+
+    def group_gather(self, f, t):
+        """all_gather of a small tensor inside frame f's group -> (G, *t.shape), members in block order (G = 1, or no
+        process group: the tensor alone)."""
+        ranks = self.plan.group_of_frame[f]
+        if not self.active or len(ranks) == 1:
+            return t.unsqueeze(0)
+        out = torch.empty((len(ranks),) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=self.groups[tuple(ranks)])      # (flat: both backends)
+        return out
+
+    def gather(self):
+        """Step 2: the world all_gather of every rank's plane blocks; -> (n_frames, P, Y, X), the same on every rank."""
         if self.active:
             self.c.all_gather(self.recv, self.send, self.direct)
         if not self.direct:
@@ -445,6 +472,56 @@ class BevExchange:
                     self.full[f, p0:p0 + n].copy_(slots[r if self.active else 0, off[r]:off[r] + n])
                 off[r] += self.plan.cap_of_frame[f] if len(self.plan.group_of_frame[f]) > 1 else n
         return self.full
+
+
+def gate_blocks(ex, first_plane, n_channels, opacity_plane, opacity_of_frame, stats_fn, gate_fn):
+    """HOA-3 on a camera-frame-sharded grid, BETWEEN the two steps of the exchange (``ex.finish_reduce`` done,
+    ``ex.gather`` to come): every rank gates the channels it holds, in place, so that the world all_gather carries the
+    GATED planes — no rank runs the gate for a frame it has no part in, and inside a frame's group the gate's work is
+    split by plane block instead of replicated.
+
+    The gate of a frame (view_transformer_ocrf.py:230-242,1197-1199) is mask = sigmoid(conv7x7([mean_c x, max_c x]) +
+    opacity_bev), x * mask: the per-pixel statistics run over ALL ``n_channels`` channels of the frame's gated planes
+    ``[first_plane, first_plane + n_channels)``, which a group's members hold in blocks.  So: each member reduces its
+    own channels — ``stats_fn(x (c,Y,X)) -> (2,Y,X) = [mean, max] over its c channels`` —, the group all_gathers these
+    (2 x Y x X floats per member: 320 KB at 200 x 200) and combines them in member order with the weights c_j / C the
+    plan fixes (deterministic, the same on every member; a member that holds ALL channels gets its own statistics back
+    bit for bit), then gates its channels with the combined statistics — ``gate_fn(x, stats (2,Y,X), opacity (Y,X))``,
+    in place.  The member whose block holds ``opacity_plane`` (an extra plane of the fused grid, or None) stores the
+    frame's opacity BEV there: it travels with the gather too.  ``opacity_of_frame``: {frame: (Y,X) tensor} for the
+    frames this rank has blocks of.  Frames are independent (mmdet3d/models/detectors/ocrfdet.py:274)."""
+    plan = ex.plan
+    P = plan.n_planes
+    for f, p0, n, view in ex.block_views():
+        c0, c1 = max(p0, first_plane), min(p0 + n, first_plane + n_channels)
+        x = view[c0 - p0:c1 - p0] if c1 > c0 else view[:0]
+        if x.shape[0] > 0:
+            part = stats_fn(x)
+        else:
+            part = torch.stack((torch.zeros(ex.Y, ex.X, dtype=view.dtype, device=view.device),
+                                torch.full((ex.Y, ex.X), float('-inf'), dtype=view.dtype, device=view.device)))
+        parts = ex.group_gather(f, part)
+        # channels every member of the group holds: a function of the plan (equal blocks of cap planes)
+        ranks, cap = plan.group_of_frame[f], plan.cap_of_frame[f]
+        held = []
+        for j in range(len(ranks)):
+            q0 = min(j * cap, P) if len(ranks) > 1 else 0
+            qn = min(cap, P - q0) if len(ranks) > 1 else P
+            held.append(max(0, min(q0 + qn, first_plane + n_channels) - max(q0, first_plane)))
+        assert parts.shape[0] == len(held) or parts.shape[0] == 1
+        if parts.shape[0] == 1:
+            held = [x.shape[0]]
+        mean, smax = None, None
+        for j, cj in enumerate(held):                           # member order: every member forms the same sums
+            if cj == 0:
+                continue
+            term = parts[j, 0] * (float(cj) / float(n_channels)) if cj != n_channels else parts[j, 0]
+            mean = term.clone() if mean is None else mean + term
+            smax = parts[j, 1].clone() if smax is None else torch.maximum(smax, parts[j, 1])
+        if x.shape[0] > 0:
+            gate_fn(x, torch.stack((mean, smax)), opacity_of_frame[f])
+        if opacity_plane is not None and p0 <= opacity_plane < p0 + n:
+            view[opacity_plane - p0].copy_(opacity_of_frame[f])
 
 
 class PipelinedExchange:
@@ -494,20 +571,28 @@ class PipelinedExchange:
     def pool_target(self, f):
         return self.current.pool_target(f)
 
-    def submit(self):
+    def submit(self, between=None):
         """Start the exchange of the step just pooled (its buffers must not be written again before the call after
         next); -> the previous step's complete fused grid ``(n_frames, P, Y, X)`` ordered on the caller's stream, or
-        None for the first step.  The returned tensor is overwritten by the exchange two submits later."""
+        None for the first step.  The returned tensor is overwritten by the exchange two submits later.
+        ``between(ex)``: work on this rank's finished plane blocks between the two collectives (``gate_blocks``), issued on
+        the communication stream."""
         ex = self.current
+
+        def exchange():
+            ex.finish_reduce(ex.start())
+            if between is not None:
+                between(ex)
+            return ex.gather()
         if self._comm is not None:
             cur = torch.cuda.current_stream(self.device)
-            self._comm.wait_stream(cur)                       # the poolings of this step
+            self._comm.wait_stream(cur)                       # the poolings (and HOA-1/2) of this step
             with torch.cuda.stream(self._comm):
-                full = ex.finish(ex.start())
+                full = exchange()
                 done = torch.cuda.Event()
                 done.record(self._comm)
         else:
-            full, done = ex.finish(ex.start()), None
+            full, done = exchange(), None
         prev, self._pending = self._pending, (full, done)
         self.k += 1
         return self._take(prev)

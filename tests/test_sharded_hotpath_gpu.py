@@ -95,10 +95,10 @@ def test_cfg2_rank_of_six_partial_grid_and_renders_at_full_size(cuda, oracle_lib
         d, ft = inputs[f]
         tgt = ex.pool_target(f)
         sub.pool(sub.lss, d, ft, out=tgt[:Z * cfg.channels])
-        sub.pool(sub.ht, d, ft, out=tgt[Z * cfg.channels:])
+        sub.pool(sub.ht, d, ft, out=tgt[Z * cfg.channels:P])
         torch.cuda.synchronize()
         dn, fn = d.cpu().numpy(), ft.cpu().numpy()
-        for name, pl, got in (('lss', sub.lss, tgt[:Z * cfg.channels]), ('ht', sub.ht, tgt[Z * cfg.channels:])):
+        for name, pl, got in (('lss', sub.lss, tgt[:Z * cfg.channels]), ('ht', sub.ht, tgt[Z * cfg.channels:P])):
             want = oracle_lib.bev_pool_v2(dn, fn, pl.ranks_depth.cpu().numpy(), pl.ranks_feat.cpu().numpy(),
                                           pl.ranks_bev.cpu().numpy(), pl.bev_shape, pl.starts.cpu().numpy(),
                                           pl.lengths.cpu().numpy())
@@ -107,7 +107,7 @@ def test_cfg2_rank_of_six_partial_grid_and_renders_at_full_size(cuda, oracle_lib
         me = plan.group_of_frame[f].index(rank) if ex.active else 0
         inside = torch.zeros(Y * X, dtype=torch.bool, device=cuda)
         inside[ex._flat[f][me]] = True
-        outside = tgt.view(P, Y * X)[:, ~inside]
+        outside = tgt[:P].reshape(P, Y * X)[:, ~inside]
         assert float(outside.abs().max()) == 0.0 and 0 < int(ex.touched[f][me].numel()) < ex.n_strips
         got = sub.render()[0]
         ref = hotpath.HotPath(sub.cfg, cuda, cams=sub.cams, overlap=False, frame_offset=f, render_mode='per_call').render()[0]
@@ -139,3 +139,86 @@ def test_pipelined_step_returns_the_previous_step(cuda):
         assert torch.equal(full, w[0]) and torch.equal(ob, w[3])
         assert all(torch.equal(a, b) for a, b in zip(gated, w[2]))
         assert all(torch.equal(r[0]['color'], c) for r, c in zip(rendered, w[1]))
+
+
+def test_world1_with_hoa_equals_unsharded_step_bitwise(cuda):
+    """HOA sharded by frame, world 1: the fused grid holds the LSS planes, the GATED height-sampling planes and the opacity
+    BEV plane — the unsharded ``HotPath.step``'s lss, gated and opacity_bev bit for bit (one member holds all channels:
+    its statistics come back from ``gate_blocks`` unchanged)."""
+    cfg = synthetic.PathConfig(**{**synthetic.CONFIGS['cfg0_1cam_128x352_bev64x64x4'].__dict__, 'name': 'small4cam_hoa',
+                                  'n_cams': 4, 'n_frames': 2, 'render': True, 'hoa': True})
+    hp = hotpath.HotPath(cfg, cuda, overlap=False, one_call=False)
+    depth, feat = hp.make_inputs(seed=3)
+    lss, ht, rendered, gated, ob = hp.step(depth, feat)
+    sp = hotpath.ShardedHotPath(cfg, cuda, 0, 1)
+    full, rendered_s, gated_s, ob_s = sp.step(sp.make_inputs(seed=3))
+    torch.cuda.synchronize()
+    X, Y, Z = cfg.bev_xyz
+    C = cfg.channels
+    assert full.shape == (2, (Z + 1) * C + 1, Y, X) and sp.hoa_launch_frames == 2
+    assert torch.equal(full[:, :Z * C], lss)
+    assert torch.equal(full[:, Z * C:(Z + 1) * C], gated) and torch.equal(torch.cat(gated_s), gated)
+    assert torch.equal(ob_s, ob) and torch.equal(full[:, (Z + 1) * C:], ob)
+    for a, b in zip(rendered_s, rendered):
+        assert torch.equal(a[0]['color'], b['color'])
+
+
+@pytest.mark.parametrize('world,rank', [(2, 1), (4, 2), (6, 4)])
+def test_a_rank_runs_hoa_only_for_its_frames_and_gates_its_own_block(cuda, world, rank):
+    """No process group (collectives inactive): what ONE rank of a sharded job does on its own — HOA-1/2 for the frames it
+    has a part in only, and after its step the gated planes of its block are x * mask with the mask of ITS channels'
+    statistics alone (what gate_blocks computes when the group's gather returns only this member) — checked against the
+    numpy oracle of HOA-3 on the same block; the opacity plane is written iff the block holds it."""
+    from oracle import hoa as ohoa
+    cfg = synthetic.PathConfig(**{**synthetic.CONFIGS['cfg0_1cam_128x352_bev64x64x4'].__dict__, 'name': 'small4cam_hoa',
+                                  'n_cams': 4, 'n_frames': 2, 'render': False, 'hoa': True})
+    sp = hotpath.ShardedHotPath(cfg, cuda, rank, world)
+    assert sp.my_frames == sp.plan.frames_of(rank) and len(sp.my_frames) == (1 if world >= 2 else 2)
+    ex = sp.exchange
+    inputs = sp.make_inputs(seed=4)
+    # the rank's reduced blocks as they are before the gate: its own partial pools (no peers here)
+    cur, rendered = sp._pool_and_render(inputs, ex.pool_target)
+    ex.finish_reduce(ex.start())
+    before = {(f, p0): v.clone() for f, p0, n, v in ex.block_views()}
+    ob = sp._hoa12()
+    assert sorted(ob) == sp.my_frames and sp.hoa_launch_frames == len(sp.my_frames)
+    sp._gate(ex, ob)
+    torch.cuda.synchronize()
+    X, Y, Z = cfg.bev_xyz
+    C = cfg.channels
+    w = sp.base.hoa_mods['mask'].conv.weight.detach().cpu().numpy()
+    for f, p0, n, v in ex.block_views():
+        x0 = before[(f, p0)].cpu().numpy()
+        c0, c1 = max(p0, Z * C), min(p0 + n, (Z + 1) * C)
+        got = v.cpu().numpy()
+        if c1 > c0:
+            xb = x0[c0 - p0:c1 - p0]
+            mask = ohoa.opacity_mask(xb[None], ob[f].cpu().numpy()[None, None], {'mask.conv.weight': w})[0, 0]
+            np.testing.assert_allclose(got[c0 - p0:c1 - p0], xb * mask, rtol=1e-5, atol=1e-5)
+        np.testing.assert_array_equal(got[:max(0, min(n, Z * C - p0))], x0[:max(0, min(n, Z * C - p0))])      # LSS planes untouched
+        if p0 <= (Z + 1) * C < p0 + n:
+            np.testing.assert_array_equal(got[(Z + 1) * C - p0], ob[f].cpu().numpy())
+
+
+def test_cfg4_rank_of_eight_runs_the_hoa_of_one_frame(cuda):
+    """BASELINE configs[4] (6 cameras x 8 frames, 512 x 1408) over 8 ranks: a frame per rank, no reduce at all — the rank
+    issues the HOA launches of ONE frame (the unsharded step: of eight), gates its frame in place and fills its opacity
+    plane.  (No process group here: the world all_gather that would carry the other frames in is inactive.)"""
+    cfg = synthetic.CONFIGS['cfg4_6cam_8frame_512x1408_bev200x200']
+    sp = hotpath.ShardedHotPath(cfg, cuda, 3, 8)
+    assert sp.my_frames == [3] and list(sp.subs) == [3] and len(sp.subs[3].cams) == 6
+    full, rendered, gated, ob = sp.step(sp.make_inputs(seed=0))
+    torch.cuda.synchronize()
+    X, Y, Z = cfg.bev_xyz
+    C = cfg.channels
+    assert sp.hoa_launch_frames == 1
+    assert full.shape == (8, (Z + 1) * C + 1, Y, X) and len(gated) == 8 and ob.shape == (8, 1, Y, X)
+    own = full[3]
+    assert bool(torch.isfinite(own).all()) and float(own[:Z * C].abs().max()) > 0 and float(own[(Z + 1) * C].abs().max()) > 0
+    # the gate was applied: |gated| <= |x| with the mask in (0, 1)
+    d, ft = sp.make_inputs(seed=0)[3]
+    ht = torch.empty(C, Y, X, device=cuda)
+    sp.subs[3].pool(sp.subs[3].ht, d, ft, out=ht)
+    ratio = (own[Z * C:(Z + 1) * C].abs().sum() / ht.abs().sum()).item()
+    assert 0.0 < ratio < 1.0
+    sp.subs[3].check_render_plans()

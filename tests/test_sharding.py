@@ -174,6 +174,99 @@ def test_camera_frame_exchange_gloo_matches_single_process(world, n_frames, mode
         assert sum(1 for r in res if r[4]['rs_dense'] == 0) >= 1      # the ranks without a shared frame were there
 
 
+def _gate_reference(x, ob, w):
+    """torch stand-in of HOA-3 on the CPU (view_transformer_ocrf.py:230-242,1197-1199): x (C,Y,X), ob (Y,X) -> x * mask."""
+    stats = torch.stack((x.mean(0), x.amax(0)))[None]
+    mask = torch.sigmoid(torch.nn.functional.conv2d(stats, w, padding=w.shape[-1] // 2)[0, 0] + ob)
+    return x * mask
+
+
+def _worker_gate(rank, world, port, q, n_frames, mode):
+    """HOA sharded by frame (sharding.gate_blocks between the two steps of the exchange) over gloo, CPU tensors: the
+    fused grid every rank ends up with — plain planes, GATED planes, the opacity plane — against the unsharded
+    computation.  The kernels' stand-ins are torch ops (the product hands gate_blocks its HIP ops)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), OMP_NUM_THREADS='1')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        n_cams = 4
+        cfg = synthetic.PathConfig(**{**synthetic.CONFIGS['cfg0_1cam_128x352_bev64x64x4'].__dict__, 'n_cams': n_cams,
+                                      'n_frames': n_frames})
+        X, Y, Z = cfg.bev_xyz
+        n_pool = cfg.channels * Z                    # 320 pooled planes: the first half stays plain, the second is gated
+        first, C = n_pool // 2, n_pool - n_pool // 2
+        P = n_pool + 1                               # + the opacity plane
+        plan = sharding.CameraFramePlan(n_cams, n_frames, world, P)
+        coll = sharding.GlooEmulation() if 'rccl_paths' in mode else None
+        ex = sharding.BevExchange(plan, rank, 'cpu', (Y, X), collectives=coll)
+        g = torch.Generator().manual_seed(5)
+        w = torch.randn(1, 2, 7, 7, generator=g) * 0.2
+        obs = [torch.rand(Y, X, generator=g) - 0.5 for _ in range(n_frames)]      # the same on every rank
+        calls = dict(stats=0, gate=0)
+
+        def stats_fn(x):
+            calls['stats'] += 1
+            return torch.stack((x.mean(0), x.amax(0)))
+
+        def gate_fn(x, stats, ob):
+            calls['gate'] += 1
+            mask = torch.sigmoid(torch.nn.functional.conv2d(stats[None], w, padding=3)[0, 0] + ob)
+            x.mul_(mask)
+        errs = []
+        for it in range(2):                                        # twice: buffers are reused across steps
+            touched = {}
+            for f in plan.frames_of(rank):
+                part, rb = _pool_cams(cfg, plan.cams_of(rank, f), seed=f + 10 * it, want_ranks=True)
+                ex.pool_target(f)[:n_pool].copy_(torch.from_numpy(part))
+                touched[f] = torch.unique(ex.tile_of_voxel(torch.from_numpy(rb.astype(np.int64) % (Y * X))))
+            if mode.startswith('sparse') and it == 0:
+                ex.set_touched(touched)
+            ex.finish_reduce(ex.start())
+            sharding.gate_blocks(ex, first, C, n_pool, {f: obs[f] for f in plan.frames_of(rank)}, stats_fn, gate_fn)
+            full = ex.gather()
+            for f in range(n_frames):
+                want = torch.from_numpy(_pool_cams(cfg, list(range(n_cams)), seed=f + 10 * it))
+                errs.append(float((full[f, :first] - want[:first]).abs().max()))
+                errs.append(float((full[f, first:n_pool] - _gate_reference(want[first:], obs[f], w)).abs().max()))
+                errs.append(float((full[f, n_pool] - obs[f]).abs().max()))
+        # a rank gates only blocks of the frames it has a part in: one stats + at most one gate call per own block and step
+        n_blocks = len(plan.blocks_of(rank))
+        q.put((rank, max(errs), tuple(full.shape), plan.describe(), dict(calls=calls, blocks=n_blocks,
+                                                                          frames=len(plan.frames_of(rank)))))
+    except Exception as e:      # report instead of leaving the parent to time out
+        q.put((rank, repr(e), None, None, None))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('world,n_frames,mode', [(2, 2, 'gloo'), (6, 2, 'rccl_paths'), (6, 2, 'sparse'), (8, 8, 'rccl_paths'),
+                                                 (4, 8, 'gloo'), (8, 2, 'sparse_rccl_paths'), (3, 2, 'gloo')])
+def test_hoa_sharded_by_frame_gloo_matches_single_process(world, n_frames, mode):
+    """(frames, world) = (2,2) whole frames per rank; (2,6) BASELINE configs[3]: groups of three, the gated planes of a
+    frame split over members 1 and 2, member 0 holds plain planes only and still takes part in the group's statistics
+    gather; (8,8) configs[4]: a frame per rank, no reduce — a rank gates ONE frame; (8,4) two frames per rank; (2,8)
+    groups of four; (2,3): a group of two beside a whole-frame owner.  ``full`` (plain planes), ``gated`` and the opacity
+    plane equal the unsharded computation at 1e-4 on every rank."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 25000 + (os.getpid() * 5 + world * 19 + n_frames * 3 + len(mode) * 107) % 2000
+    procs = [ctx.Process(target=_worker_gate, args=(r, world, port, q, n_frames, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, err, shape, desc, info in res:
+        assert not isinstance(err, str), f'rank {rank} failed: {err}'
+        assert err <= 1e-4, f'rank {rank}: frame-sharded gated grid differs by {err} ({desc})'
+        assert shape[0] == n_frames
+        assert info['calls']['stats'] <= 2 * info['blocks'] and info['calls']['gate'] <= 2 * info['blocks']
+        if world >= n_frames:
+            assert info['frames'] == 1                    # never more HOA than one frame's on a rank
+
+
 @pytest.mark.timeout(300)
 def test_two_rank_gloo_exchange_matches_single_process():
     ctx = mp.get_context('spawn')
