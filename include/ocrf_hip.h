@@ -231,9 +231,14 @@ size_t ocrf_rasterize_workspace_bytes(int P, int n_views);
  * extent_bound bounds scale_modifier * max_k |s_k| * |R(q)|_2 (|R(q)|_2 = |1 - |q|^2| + |q|^2: 1 for a normalised
  * quaternion) of every Gaussian the plan will be rendered with; a plan stays valid for ANY parameters within it.
  *
- *   3. ocrf_rasterize_planned     one render = two launches: one thread per Gaussian builds its 3D covariance once
- *      and writes conic / tile rect of every rendered view's record (record order: coalesced; the blend walks a view's
- *      depth-ordered list through the plan's static list -> record map); then the blend of the sorted lists.
+ *   3. ocrf_rasterize_planned     one render = the front end + the blend of the sorted lists.  Front end, when radii
+ *      are an output (radii != NULL with guard 0, or guard bit 1): one thread per Gaussian builds its 3D covariance once
+ *      and writes conic / tile rect of EVERY rendered view's record (record order: coalesced; the blend walks a view's
+ *      depth-ordered list through the plan's static list -> record map).  Else (round 5): only the HEAD of every rendered
+ *      view's list is prepared, in list order (a tile pair stops scanning once its pixels are saturated — at cfg2 after
+ *      ~500 of 120 000 entries); a tile pair that scans further extends the arrays itself, and the head's length
+ *      follows what the previous call needed (kept in `workspace`, no host read).  The extent check of all Gaussians
+ *      then runs behind the blend (a status bit) — or in front of it with the device guard.
  *      n_items views are rendered; item z renders plan view item_view[z] (device ints; NULL = z, then n_items /
  *      n_sets must equal the plan's view count) with Gaussian set z / (n_items / n_sets) of the (n_sets, P, .)
  *      parameter arrays; the items of one set name distinct views.  Outputs as
@@ -252,7 +257,8 @@ size_t ocrf_rasterize_workspace_bytes(int P, int n_views);
  *      exceeded extent_bound this call, bit 3 (value 8) = bad item_view / unusable plan.
  *      guard = 0: with bit 2 set the outputs of that call are not valid (the caller re-renders with
  *      ocrf_rasterize_forward or rebuilds the plan with a larger bound).
- *      guard = 1: the per-call pipeline of ocrf_rasterize_forward is enqueued behind the planned one, armed by the
+ *      guard = 1 (+ 2: the radii are an output too; without it the radii buffer is the armed chain's scratch only):
+ *      the per-call pipeline of ocrf_rasterize_forward is enqueued behind the planned one, armed by the
  *      extent check: all of its kernels retire at once when the bound holds, and render the call instead when it
  *      does not — exact results either way, no host involvement (hipGraph-capturable), at the price of four
  *      near-empty launches (no memsets: the flag is raised by the update kernel and lowered by the armed blend, the

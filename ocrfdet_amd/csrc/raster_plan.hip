@@ -561,7 +561,7 @@ __global__ __launch_bounds__(kBlock) void raster_plan_head_kernel(HeadArgs a) {
 __global__ __launch_bounds__(kBlock) void raster_plan_check_kernel(long n_pairs, const int* __restrict__ header,
                                                                    const float* __restrict__ scales, float scale_modifier,
                                                                    const float* __restrict__ rotations,
-                                                                   int* __restrict__ status) {
+                                                                   int* __restrict__ status, int* __restrict__ flag) {
   if (header[0] != (int)kPlanMagic) return;
   const long gi = (long)blockIdx.x * kBlock + threadIdx.x;
   const float bound = __int_as_float(header[7]);
@@ -573,7 +573,10 @@ __global__ __launch_bounds__(kBlock) void raster_plan_check_kernel(long n_pairs,
                                   rotations[4 * gi + 3]);
     bad = !(rn <= bound) || !(((sx + sy) + sz) * 0.f == 0.f);
   }
-  if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(status, 4);
+  if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) {
+    atomicOr(status, 4);
+    if (flag) atomicOr(flag, 1);                 // device guard: the armed per-call chain renders this call
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1283,9 +1286,11 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
     flag = ctl;
     chain_hist = ocrf::raster_chain_hist(chain_workspace, P, n_items, &chain_hist_words);
   }
-  // radii asked for (or the armed chain needs them): EVERY record is prepared, one thread per Gaussian, in Gaussian-major
-  // order (raster_plan_update_kernel); else only the head of each rendered view's list, in list order
-  const bool full = radii != nullptr;
+  // radii asked for as an OUTPUT (guard bit 1, or radii without a guard): EVERY record is prepared, one thread per
+  // Gaussian, in Gaussian-major order (raster_plan_update_kernel); else only the head of each rendered view's list, in list
+  // order — with the device guard (its radii buffer is the armed chain's own) the extent check then runs FIRST: the
+  // blend has to know whether to leave the call to the chain
+  const bool full = radii != nullptr && (guard == 0 || (guard & 2) != 0);
   const SetParams sp{opacities, scales, rotations, scale_modifier};
   if (phase != 2) {
     if (full) {
@@ -1297,6 +1302,11 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
                    opacities, scales, scale_modifier, rotations, d_rect, d_con, radii, status, flag, queue,
                    reinterpret_cast<const unsigned*>(call_cameras), reinterpret_cast<const unsigned*>(cams));
     } else {
+      if (guard) {      // (behind the blend otherwise: there it is a status bit only)
+        const long n_pairs = (long)n_sets * P;
+        hipLaunchKernelGGL(raster_plan_check_kernel, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                           stream, n_pairs, header, scales, scale_modifier, rotations, status, flag);
+      }
       HeadArgs a;
       a.P = P; a.vps = vps; a.n_sets = n_sets; a.n_items = n_items;
       const long head_cap = std::min<long>(g_head_force > 0 ? g_head_force : kHeadMax, std::min<long>(kHeadMax, total_kept));
@@ -1308,7 +1318,7 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
       a.s_e = reinterpret_cast<const unsigned*>(pb + L.s_e);
       a.e_q0 = reinterpret_cast<const float4*>(pb + L.e_q0);
       a.e_q1 = reinterpret_cast<const float4*>(pb + L.e_q1);
-      a.sp = sp; a.d_rect = d_rect; a.d_con = d_con; a.status = status; a.ctl = ctl; a.guard = 0;
+      a.sp = sp; a.d_rect = d_rect; a.d_con = d_con; a.status = status; a.ctl = ctl; a.guard = guard ? 1 : 0;
       a.call_cams = reinterpret_cast<const unsigned*>(call_cameras);
       a.plan_cams = reinterpret_cast<const unsigned*>(cams);
       ocrf::launch(OCRF_K_RASTER_PLAN_UPDATE, raster_plan_head_kernel,
@@ -1351,10 +1361,10 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
 #undef OCRF_BLEND_SORTED
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  if (!full) {
+  if (!full && !guard) {
     const long n_pairs = (long)n_sets * P;
     hipLaunchKernelGGL(raster_plan_check_kernel, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
-                       n_pairs, header, scales, scale_modifier, rotations, status);
+                       n_pairs, header, scales, scale_modifier, rotations, status, static_cast<int*>(nullptr));
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }

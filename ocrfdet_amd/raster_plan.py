@@ -132,7 +132,7 @@ class RasterPlan:
 
     @torch.no_grad()
     def render(self, colors, opacities, scales, rotations, bg, scale_modifier=1.0, depth_mode='median',
-               item_view=None, want_radii=False, guard='host', out=None, blend_workgroups=0, phase='both',
+               item_view=None, want_radii=None, guard='host', out=None, blend_workgroups=0, phase='both',
                yield_if=None, cameras=None, views_disjoint=False):
         """Render ``n_items = len(item_view)`` views: item z = plan view ``item_view[z]`` (int32 device tensor) with
         Gaussian set ``z // (n_items // S)`` of the ``(S, P, .)`` (or ``(P, .)``) parameter tensors; without
@@ -142,6 +142,10 @@ class RasterPlan:
         grid; 0 = what the device holds at once (fastest alone), ~2 per CU when other streams should run beside it.
         ``yield_if``: int32 device word — with it the blend takes every slot of the device and the workgroups beyond
         ``blend_workgroups`` leave at once while the word is non-zero (a scheduling hint: same image either way).
+        ``want_radii``: the per-(item, Gaussian) radii as an output ``radii`` (n_items,P) — the call then prepares EVERY
+        record in front of the blend (the full update kernel) instead of the head of each view's list.  None: yes with
+        ``guard='device'`` (what a fired guard's per-call chain writes anyway), no with the host guard; a device-guarded
+        caller that does not read them passes False and keeps the short front end.
         ``phase``: 'both', or 'update' then (same arguments, same ``out``) 'blend' — possibly on another stream, ordered by
         the caller's events (``guard='host'`` only).
         ``views_disjoint``: the caller states that every plan view is rendered by at most ONE set of this call (frames
@@ -175,7 +179,11 @@ class RasterPlan:
         if out is None:
             out = dict(color=torch.empty(n_items, 3, H, W, device=dev), depth=torch.empty(n_items, 1, H, W, device=dev),
                        final_T=torch.empty(n_items, H, W, device=dev))
-        use_guard = {'host': 0, 'device': 1}[guard]
+        if want_radii is None:
+            want_radii = guard == 'device'
+        # 1: device guard; + 2: the radii are an OUTPUT of the call (every record is then prepared by the full update
+        # kernel); a device-guarded call without want_radii hands the armed chain a radii buffer of its own only
+        use_guard = {'host': 0, 'device': 1}[guard] | (2 if (want_radii and guard == 'device') else 0)
         self._host_guarded = self._host_guarded or not use_guard
         if cameras is not None:
             _lib.require_cuda(cameras)
@@ -183,10 +191,15 @@ class RasterPlan:
             if cameras.shape != self.cameras.shape:
                 raise _lib.OcrfHipError('cameras must be the plan\'s (V, 36) block')
         radii = None
-        if want_radii or use_guard:
+        if want_radii:
             radii = out.get('radii')
             if radii is None:
                 radii = out['radii'] = torch.empty(n_items, P, dtype=torch.int32, device=dev)
+        elif use_guard:
+            # scratch of the armed per-call chain only (owned by the plan, not an output)
+            if getattr(self, '_chain_radii', None) is None or self._chain_radii.numel() < n_items * P:
+                self._chain_radii = torch.empty(n_items * P, dtype=torch.int32, device=dev)
+            radii = self._chain_radii
         L = _lib.lib()
         cur = torch.cuda.current_stream(dev)
         if self._built[1] != cur and cur.cuda_stream not in self._ordered_after_build \

@@ -762,9 +762,18 @@ class OcRFViewTransformerFull(nn.Module):
         if (geo is self._geo and len(ranks) == 5 and ranks[0] is not None and not torch.is_grad_enabled()
                 and bevpool._fusable(bev_shape[-1])):
             plan = geo.plans.get(which)
-            if plan is None or plan.shape != tuple(bev_shape):
+            panel = bev_shape[-1] in (64, 80, 96, 128)
+            if plan is None or plan.shape != tuple(int(v) for v in bev_shape):
                 rb, rd, rf, st, ln = ranks
-                plan = geo.plans[which] = bevpool.DevicePoolPlan(rd, rf, rb, bev_shape, st, ln)
+                if panel:
+                    # the same back end as HotPath's default: the panel latency kernel (csrc/bev_pool_panel.hip), 13-30 %
+                    # faster than the tile kernel; heavy LSS tiles cut by estimated cost
+                    plan = bevpool.MfmaPoolPlan(rd, rf, rb, bev_shape, group=8, unit_cost=8.0 if which == 'lss' else None)
+                else:
+                    plan = bevpool.DevicePoolPlan(rd, rf, rb, bev_shape, st, ln)
+                geo.plans[which] = plan
+            if panel:
+                return bevpool.bev_pool_v2_panel(depth, feat_cl, plan)
             return bevpool.bev_pool_v2_planned(depth, feat_cl, plan)
         return self._pool(ranks, depth, feat_cl, bev_shape)
 
@@ -968,7 +977,7 @@ class OcRFViewTransformerFull(nn.Module):
         item_view = (base + cameras['cam_sel'].to(torch.int32)).contiguous()
         # (sample b renders one of ITS OWN N plan views: no view is named by two sets)
         return plan.render(color, opacity, scaling, rotation, self._bg, item_view=item_view, guard='device',
-                           views_disjoint=True)
+                           views_disjoint=True, want_radii=False)
 
     def _build_raster_plan(self, geo, voxel_coor, scaling, rotation, B, N, H, W):
         """-> (RasterPlan over the B*N (sample, camera) views, int32 view offsets b*N) or False when the samples do not
