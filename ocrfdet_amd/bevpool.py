@@ -293,6 +293,7 @@ def bev_pool_v2_planned(depth, feat, plan, layout=1, out=None):
     tensor of that many elements to write into (e.g. a slice of a fused multi-frame buffer)."""
     B, Z, Y, X, C = plan.shape
     d32, f32 = depth.float().contiguous(), feat.float().contiguous()
+    _check_32bit_offsets(d32, f32)
     _lib.require_cuda(d32, f32)
     if f32.size(-1) != C:
         raise _lib.OcrfHipError(f'feat has {f32.size(-1)} channels, the plan was built for {C}')
@@ -310,6 +311,15 @@ def bev_pool_v2_planned(depth, feat, plan, layout=1, out=None):
             _lib.ptr(plan.ranks_feat), _lib.ptr(plan.plan), _lib.ptr(out), B, Z, Y, X, int(layout), _lib.ptr(scratch),
             ctypes.c_size_t(scratch.numel()), _lib.stream_ptr(dev)), 'ocrf_bev_pool_v2_nchw_planned')
     return out
+
+
+def _check_32bit_offsets(*tensors):
+    """The tile / MFMA / panel pooling kernels address their operands with 32-bit byte offsets (raw buffer loads whose
+    resource covers 2^31 - 1 bytes: a load beyond returns 0 silently).  A tensor of 2 GiB or more is refused here."""
+    for t in tensors:
+        if t is not None and t.numel() * t.element_size() >= (1 << 31):
+            raise _lib.OcrfHipError(f'a pooling operand of {t.numel() * t.element_size()} bytes exceeds the 2 GiB the '
+                                    'kernels\' 32-bit offsets cover: split the batch')
 
 
 class MfmaPoolPlan:
@@ -466,6 +476,7 @@ def bev_pool_v2_mfma(depth, feat, plan, layout=1, out=None):
     (layout 0); same result as ``bev_pool_v2_planned`` up to the summation order."""
     B, Z, Y, X, C = plan.shape
     d32, f32 = depth.float().contiguous(), feat.float().contiguous()
+    _check_32bit_offsets(d32, f32)
     _lib.require_cuda(d32, f32)
     if f32.size(-1) != C:
         raise _lib.OcrfHipError(f'feat has {f32.size(-1)} channels, the plan was built for {C}')
@@ -489,6 +500,7 @@ def bev_pool_cell_weights(depth, plan, plan2=None):
     """Pre-pass of ``bev_pool_v2_panel``: the summed depth weight of every cell of ``plan`` (and of ``plan2`` — the LSS
     and the height-sampling plan of a step read the same depth tensor) in ONE launch -> ``plan.cw`` (``plan2.cw``)."""
     d32 = depth.float().contiguous()
+    _check_32bit_offsets(d32)
     _lib.require_cuda(d32)
     L = _lib.lib()
     n2 = plan2.n_cells if (plan2 is not None and plan2.n_points) else 0
@@ -509,6 +521,7 @@ def bev_pool_v2_panel(depth, feat, plan, layout=1, out=None, weights_ready=False
     already run for this ``depth`` on this stream (one launch for both poolings of a step)."""
     B, Z, Y, X, C = plan.shape
     f32 = feat.float().contiguous()
+    _check_32bit_offsets(f32)
     _lib.require_cuda(f32)
     if f32.size(-1) != C:
         raise _lib.OcrfHipError(f'feat has {f32.size(-1)} channels, the plan was built for {C}')

@@ -652,7 +652,20 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(BlendArgs g) {
   // ticket queue makes any number of participants render the same image.
   if (g.yield_if && (int)blockIdx.x >= g.base_grid && *g.yield_if != 0) run = false;
   const int* header = g.header;
-  if (header[0] != (int)kPlanMagic) run = false;                      // reported by step 1 (status bit 8)
+  if (header[0] != (int)kPlanMagic) {                                 // reported by step 1 (status bit 8)
+    // an unusable plan (a rebuild for a pose that keeps more records than the capacity): nothing is rendered — the
+    // images are zero-filled rather than left as they were allocated (a host-guarded caller may
+    // consume them before it reads the status word)
+    if (run && !(g.skip_if && *g.skip_if != 0)) {
+      const long npix = (long)g.W * g.H * g.n_items;
+      for (long i = (long)blockIdx.x * kBlock + tid; i < npix; i += (long)gridDim.x * kBlock) {
+        g.out_final_T[i] = 0.f;
+        g.out_depth[i] = 0.f;
+        g.out_color[3 * i] = 0.f; g.out_color[3 * i + 1] = 0.f; g.out_color[3 * i + 2] = 0.f;
+      }
+    }
+    run = false;
+  }
   const int V = header[2];
   const int* view_off = header + kHeaderInts;
   const int lx = lane & 15, r = lane >> 4;

@@ -278,9 +278,12 @@ class HotPath:
                 fr = list(range(f0, min(f0 + per, self.batch)))
                 cams = torch.cat([self.frame_cams[b]['packed'] for b in fr])
                 g = {k: torch.stack([self.frame_gauss[b][k] for b in fr]).contiguous() for k in ('rgb', 'opacity', 'scales', 'rotations')}
-                # record capacity: what these cameras keep + 10 % (a per-step rebuild sees poses that keep a few more)
+                # record capacity: what these cameras keep + 10 % — + 25 % when the plan is rebuilt per step for poses that
+                # may keep more (a plan beyond its capacity is refused on the device: status bit 8, zero images; read
+                # check_render_plans() before the images are consumed, or render with render_guard='device')
                 plan = raster_plan.RasterPlan(self.voxel_xyz[f0].reshape(-1, 3), cams, H, W, scales=g['scales'],
-                                              rotations=g['rotations'], margin=self.plan_margin, headroom=1.1)
+                                              rotations=g['rotations'], margin=self.plan_margin,
+                                              headroom=1.25 if self.plan_rebuild == 'per_step' else 1.1)
                 # item z = view z of the plan (frame-major), rendered with the parameter set of its frame
                 g['item_view'] = torch.arange(len(fr) * n_cam, dtype=torch.int32, device=self.device)
                 g['cams'] = plan.cameras                 # the sample's camera block: a per-step rebuild reads it in place

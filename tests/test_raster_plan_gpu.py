@@ -194,6 +194,13 @@ def test_extent_bound_guards(cuda):
     plan.render(rgb, opac, big, rot, bg)
     assert plan.exceeded()
     _same(want0, plan.render(rgb, opac, sc, rot, bg, guard='device'), ('color', 'depth', 'final_T', 'radii'))
+    # the device guard WITHOUT the radii as an output (the neck module's call): the short front end — extent check, head of
+    # every list — and the armed chain behind the blend; exact when the bound is exceeded, the planned images when not
+    for scales, ref, fired in ((big, want, True), (sc, want0, False), (big, want, True), (sc, want0, False)):
+        got = plan.render(rgb, opac, scales, rot, bg, guard='device', want_radii=False)
+        assert 'radii' not in got
+        _same(ref, got)
+        assert plan.exceeded() == fired
     # a NaN scale counts as a violation
     bad = sc.clone()
     bad[5, 1] = float('nan')
@@ -400,9 +407,11 @@ def test_a_plan_beyond_its_capacity_is_refused_on_the_device(cuda):
     small = rp.RasterPlan(xyz, cams, H, W, scales=sc, rotations=rot, capacity=need // 2)
     want = dgr.rasterize_views(xyz, rgb, opac, sc, rot, None, None, None, None, H, W, bg, packed_cameras=cams,
                                want_n_contrib=False)
-    small.render(rgb, opac, sc, rot, bg)
+    out = small.render(rgb, opac, sc, rot, bg)
     with pytest.raises(Exception, match='capacity'):
         small.check()
+    # nothing was rendered from the unusable plan: the images are zeros, not whatever the allocation held
+    assert all(float(out[k].abs().max()) == 0.0 for k in ('color', 'depth', 'final_T'))
     exact = rp.RasterPlan(xyz, cams, H, W, scales=sc, rotations=rot, capacity=need)      # not one record to spare
     _same(want, exact.render(rgb, opac, sc, rot, bg))
     assert exact.check()
