@@ -28,7 +28,7 @@ def timed(hp, depth, feat, blocks=5, steps=100):
     return float(np.median(out)), min(out)
 
 
-variants = [dict(blend_workgroups=b) for b in (640, 704, 768, 896)]
+variants = [dict(blend_workgroups=b) for b in (640, 704, 768, 832, 896)]
 for kw in variants:
     hp = hotpath.HotPath(cfg, dev, **kw)
     depth, feat = hp.make_inputs()

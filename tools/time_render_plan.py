@@ -28,7 +28,7 @@ hp = hotpath.HotPath(cfg, dev)
 g, rc = hp.gauss, hp.render_cams
 H, W = cfg.input_size
 xyz = hp.voxel_xyz[0].reshape(-1, 3)
-_lib.lib().ocrf_tune_set(10, a.wskip)
+# (the in-loop wave skip knob of round 3 is gone: the planned blend culls by wave at staging)
 _lib.lib().ocrf_tune_set(11, a.grid)
 print('resident workgroups by the occupancy API:', _lib.lib().ocrf_diag_plan_resident())
 
