@@ -39,8 +39,8 @@ FP32_PEAK_TFLOPS = 157.3        # ibid.: peak FP32 (vector) = 256 CU x 4 SIMD-32
 N_SIMD, CLOCK_HZ = 256 * 4, 2.4e9
 VALU_CYCLES_PER_INST = 2.0      # ibid.: a wave64 VALU op issues over 2 cycles on a SIMD-32
 BLEND_FLOPS_PER_PIXEL_RECORD = 20.0      # blend flops ~= 20 x sum_tiles len x 256
-PMC_FILE = os.path.join('profiles', 'r4_pmc_mean.csv')     # rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh)
-PMC_META = os.path.join('profiles', 'r4_pmc_meta.json')    # what those passes ran: config, flags, hash of csrc/
+PMC_FILE = os.path.join('profiles', 'r5_pmc_mean.csv')     # rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh)
+PMC_META = os.path.join('profiles', 'r5_pmc_meta.json')    # what those passes ran: config, flags, hash of csrc/
 DEFAULT_CONFIG = 'cfg2_6cam_2frame_bev200x200_render_hoa'
 
 
@@ -354,7 +354,7 @@ _PMC_OK = None
 
 def pmc_valid(args):
     """The committed counters are used only for the run they were collected on: same config, same render mode and
-    the same library sources (profiles/r4_pmc_meta.json); anything else reports no traffic / counters."""
+    the same library sources (profiles/r5_pmc_meta.json); anything else reports no traffic / counters."""
     global _PMC_OK
     if _PMC_OK is None:
         _PMC_OK = False
@@ -368,7 +368,7 @@ def pmc_valid(args):
 
 
 def pmc_counters(kernel_prefix, args=None):
-    """Mean per launch of every counter rocprofv3 collected for one kernel (profiles/r4_pmc_mean.csv, written by
+    """Mean per launch of every counter rocprofv3 collected for one kernel (profiles/r5_pmc_mean.csv, written by
     tools/collect_profiles.sh from separate --pmc passes of this command with --no-overlap): {counter: mean}."""
     path = os.path.join(ROOT, PMC_FILE)
     out = {}
@@ -997,7 +997,7 @@ def main():
         plans_built = getattr(hp, 'render_plans', None)
         if planned and plans_built:
             plan_note = (f'{len(plans_built)} plan(s) for {hp.batch} frame(s): frames that fit a 32-view plan share one '
-                         'update + one blend launch')
+                         'head + one blend launch')
         out = {
             'metric': 'BEV voxels/sec + rendered views/sec, 6-cam 256x704',
             'value': voxels / elapsed, 'unit': 'BEV voxels/s',
@@ -1040,13 +1040,16 @@ def main():
                                                 else 'guarded on the device (per-call pipeline armed behind every render)'))
                                             if planned else 'per call (preprocess + depth-bucket scatter every render)'),
                        'frames': 'each frame its own ego pose and Gaussian parameters (synthetic.ego_motion)',
-                       'streams': ('main: pools, then HOA; side HIP stream: render update + blend per plan; the blend (VALU-bound) '
-                                   'runs as a persistent grid of 3.5 workgroups per CU so that the latency-bound kernels of the '
-                                   'main stream keep wave slots (with several blends per step the rest of the grid joins once '
-                                   'the main chain is done; DESIGN.md section 5)' if hp.overlap and cfg.render and planned
+                       'streams': ('main: pools, then HOA; side HIP stream: per plan the head of every view\'s list, the blend, '
+                                   'the extent check; the blend runs as a persistent grid of 2.75 workgroups per CU so that the '
+                                   'latency-bound kernels of the main stream keep wave slots (with several blends per step the '
+                                   'rest of the grid joins once the main chain is done; DESIGN.md section 5)'
+                                   if hp.overlap and cfg.render and planned
                                    else ('main: HOA-1/2, pools, HOA-3; side HIP stream: renders' if hp.overlap and cfg.render
                                          else 'single stream')),
-                       'ht_pool': getattr(hp, 'ht_pool_backend', None),
+                       'ht_pool': getattr(hp, 'ht_pool_backend', None), 'lss_pool': getattr(hp, 'lss_pool_backend', None),
+                       'issue': ('one host call per step (ocrf_hotpath_step: the step\'s library calls recorded once, replayed '
+                                 'from C)' if getattr(hp, '_compiled', None) is not None else 'call by call from Python'),
                        'index_prep': 'cached (accelerate=True semantics); per_step_ms = the same step with the HIP index '
                                      'preparation inside (accelerate=False semantics, the reference\'s working mode), calibration '
                                      'algebra on the host as the reference\'s own torch calls (rank vectors bit-exact); '

@@ -1100,8 +1100,9 @@ int resident_blocks(K kernel) {
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    // four per CU even where five fit (96 VGPRs): the record loop is bound by the LDS pipe at five — cfg2's twelve views
-    // alone 129 us on 1 024 workgroups, 137 on 1 152, 142-149 on 1 280 (tools/time_blend_r5.py)
+    // four per CU even where five fit (96 VGPRs): measured — cfg2's twelve views alone 129 us on 1 024 workgroups, 137 on
+    // 1 152, 142-149 on 1 280 (tools/time_blend_r5.py): a fifth wave per SIMD adds more LDS / issue contention to the
+    // record loops than latency hiding
     cached[dev] = std::min(per_cu, 4) * cus;
   }
   return cached[dev];

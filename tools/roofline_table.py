@@ -21,7 +21,9 @@ pmc = {}
 for r in csv.DictReader(open(os.path.join(P, f'{tag}_pmc_mean.csv'))):
     pmc.setdefault(r['kernel'], {})[r['counter']] = (float(r['mean']), int(r['launches']))
 meta = json.load(open(os.path.join(P, f'{tag}_pmc_meta.json')))
-steps = max(int(r['calls']) for r in stats if 'bev_pool_tile' in r['kernel'])
+steps = max(int(r['calls']) for r in stats if 'raster_blend_sorted' in r['kernel'])
+# (+ the instrumented blend launch after the timed region)
+steps -= 1 if any('raster_blend_sorted' in r['kernel'] and ', true>' in r['kernel'] for r in stats) else 0
 
 print(f'# Kernels of one cfg2 step, each alone on the device (`profiles/{tag}_cfg2_kernel_stats_serial.csv` + '
       f'`{tag}_pmc_mean.csv`; sources {meta["source_hash"]}, {steps} steps traced)\n')
@@ -35,6 +37,8 @@ for r in stats:
     if calls < steps or calls - steps * round(calls / steps) not in (0, 1, 2):
         continue
     name = r['kernel']
+    if name.startswith(('rocprim::', 'at::native', 'void at::native', '__amd_rocclr')):      # torch's own (plan building of the bench's other legs)
+        continue
     us = float(r['mean_ns']) / 1e3
     per_step = round(calls / steps)
     total += us * per_step
