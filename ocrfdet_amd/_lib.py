@@ -294,6 +294,7 @@ class StepRecorder:
     def __init__(self, streams):
         self.slots = {int(st.cuda_stream): i for i, st in enumerate(streams)}
         self.items = []
+        self.names = []                  # every enqueueing entry point the step called, recordable or not
         self.ok = True
         self.why = None
 
@@ -322,6 +323,7 @@ class StepRecorder:
 
     def on_call(self, name, fn, args):
         L = _LIB
+        self.names.append(name)
         fid = L.ocrf_step_fn_id(name.encode())
         if fid < 0:
             return self.fail(f'{name} cannot be held by a step object')

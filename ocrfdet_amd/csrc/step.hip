@@ -32,6 +32,11 @@ enum Fn : int {
   kHoaMaskGate,
   kStreamWrite32,
   kRasterPlanBuild,
+  kRasterizeForward,
+  kPoolDyn,
+  kLssPrepare,
+  kHtPrepare,
+  kGeometryBlocks,
   kFnCount
 };
 
@@ -44,7 +49,9 @@ const FnInfo kFns[kFnCount] = {
     {"ocrf_bev_pool_v2_nchw_planned", 15}, {"ocrf_bev_pool_v2_nchw_mfma", 19},  {"ocrf_bev_pool_cell_weights", 9},
     {"ocrf_bev_pool_v2_nchw_panel", 19},   {"ocrf_rasterize_planned", 33},      {"ocrf_hoa1_forward", 9},
     {"ocrf_hoa_v2b_forward", 9},           {"ocrf_hoa_channel_stats", 6},       {"ocrf_hoa_opacity_mask_gate", 11},
-    {"ocrf_stream_write_value32", 2},      {"ocrf_raster_plan_build", 12},
+    {"ocrf_stream_write_value32", 2},      {"ocrf_raster_plan_build", 12},      {"ocrf_rasterize_forward", 23},
+    {"ocrf_bev_pool_v2_nchw_dyn", 19},     {"ocrf_lss_prepare", 20},            {"ocrf_ht_prepare", 22},
+    {"ocrf_geometry_blocks", 16},
 };
 
 constexpr int kMaxArgs = 40;
@@ -117,6 +124,35 @@ int call(const Cmd& c, ocrf_stream_t s) {
     case kRasterPlanBuild:
       return ocrf_raster_plan_build(I(a[0]), I(a[1]), I(a[2]), I(a[3]), P<const float*>(a[4]), P<const float*>(a[5]),
                                     F(a[6]), L(a[7]), P<void*>(a[8]), Z(a[9]), P<void*>(a[10]), Z(a[11]), s);
+    // the per-sample step (nothing calibration- or pose-dependent cached): index preparation, pooling on device-side
+    // counts, the per-call render.  Host-pointer arguments (grid bounds, pc_range) are read at replay like at the call:
+    // the caller keeps them alive (ocrfdet_amd.index_prep._host_floats)
+    case kRasterizeForward:
+      return ocrf_rasterize_forward(I(a[0]), I(a[1]), I(a[2]), I(a[3]), P<const float*>(a[4]), P<const float*>(a[5]),
+                                    P<const float*>(a[6]), P<const float*>(a[7]), F(a[8]), P<const float*>(a[9]),
+                                    P<const float*>(a[10]), P<const float*>(a[11]), P<const float*>(a[12]), I(a[13]),
+                                    P<float*>(a[14]), P<float*>(a[15]), P<float*>(a[16]), P<uint32_t*>(a[17]),
+                                    P<int*>(a[18]), P<uint32_t*>(a[19]), P<int*>(a[20]), P<void*>(a[21]), Z(a[22]), s);
+    case kPoolDyn:
+      return ocrf_bev_pool_v2_nchw_dyn(I(a[0]), I(a[1]), I(a[2]), P<const int*>(a[3]), P<const float*>(a[4]),
+                                       P<const float*>(a[5]), P<const int*>(a[6]), P<const int*>(a[7]), P<const int*>(a[8]),
+                                       P<const int*>(a[9]), P<const int*>(a[10]), P<float*>(a[11]), I(a[12]), I(a[13]),
+                                       I(a[14]), I(a[15]), I(a[16]), P<void*>(a[17]), Z(a[18]), s);
+    case kLssPrepare:
+      return ocrf_lss_prepare(I(a[0]), I(a[1]), I(a[2]), I(a[3]), I(a[4]), P<const float*>(a[5]), P<const float*>(a[6]),
+                              P<const float*>(a[7]), P<const float*>(a[8]), I(a[9]), I(a[10]), I(a[11]), P<int*>(a[12]),
+                              P<int*>(a[13]), P<int*>(a[14]), P<int*>(a[15]), P<int*>(a[16]), P<int*>(a[17]),
+                              P<void*>(a[18]), Z(a[19]), s);
+    case kHtPrepare:
+      return ocrf_ht_prepare(I(a[0]), I(a[1]), I(a[2]), I(a[3]), I(a[4]), I(a[5]), I(a[6]), P<const float*>(a[7]),
+                             P<const float*>(a[8]), P<const float*>(a[9]), F(a[10]), F(a[11]), F(a[12]), F(a[13]),
+                             P<int*>(a[14]), P<int*>(a[15]), P<int*>(a[16]), P<int*>(a[17]), P<int*>(a[18]),
+                             P<int*>(a[19]), P<void*>(a[20]), Z(a[21]), s);
+    case kGeometryBlocks:
+      return ocrf_geometry_blocks(I(a[0]), I(a[1]), P<const float*>(a[2]), P<const float*>(a[3]), P<const float*>(a[4]),
+                                  P<const float*>(a[5]), P<const float*>(a[6]), P<const float*>(a[7]),
+                                  P<const float*>(a[8]), I(a[9]), I(a[10]), F(a[11]), F(a[12]), P<float*>(a[13]),
+                                  P<float*>(a[14]), P<float*>(a[15]), s);
     default:
       return (int)hipErrorInvalidValue;
   }
@@ -126,7 +162,7 @@ int call(const Cmd& c, ocrf_stream_t s) {
 
 struct ocrf_step {
   std::vector<Cmd> cmds;
-  hipEvent_t events[kMaxStreams * 2];      // one per (fork | join, stream slot), created on first use
+  hipEvent_t events[2 * kMaxStreams * kMaxStreams];      // one per (fork | join, from, to), created on first use
   int device;
 };
 
@@ -195,7 +231,7 @@ int ocrf_step_run(ocrf_step* s, const ocrf_stream_t* streams, int n_streams) {
       if (e != 0) return e;
     } else {
       if (c.from >= n_streams || c.to >= n_streams) return (int)hipErrorInvalidValue;
-      hipEvent_t& ev = s->events[(c.kind - 1) * kMaxStreams + (c.kind == 1 ? c.to : c.from)];
+      hipEvent_t& ev = s->events[((c.kind - 1) * kMaxStreams + c.from) * kMaxStreams + c.to];
       if (!ev) {
         const hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
         if (e != hipSuccess) return (int)e;

@@ -157,7 +157,9 @@ class HotPath:
         self._grid = index_prep.grid_infos(cfg.grid)
         self._lss_bufs, self._ht_bufs = index_prep._RankBuffers(), index_prep._RankBuffers()
         self.lss, self.ht = self.prepare_indices_hip(sync=True)       # (host algebra: `_calib_dev` does not exist yet)
-        self._calib_dev = [t.to(dev) for t in self._calib_host]
+        # contiguous fp32 on the device: ocrf_geometry_blocks then reads THESE tensors (a conversion inside the per-step
+        # path would be a torch kernel per step — one that a recorded step would not replay)
+        self._calib_dev = [t.to(dev).float().contiguous() for t in self._calib_host]
         # cached plans must not alias the grow-only buffers the per-step preparation writes into
         for plan in (self.lss, self.ht):
             for name in ('ranks_bev', 'ranks_depth', 'ranks_feat', 'starts', 'lengths'):
@@ -505,8 +507,7 @@ class HotPath:
                 return self._step_eager(depth, feat)
             return self._record_step(depth, feat, key, cur)
         _, compiled, out, _pool = self._compiled
-        raw = [cur.cuda_stream] + [st.cuda_stream for st in self._side] if self._forks() else [cur.cuda_stream]
-        compiled.run(*raw)
+        compiled.run(*[st.cuda_stream for st in self._step_streams(cur)])
         for entry in (self.render_plans or []) if self.cfg.render and self.render_mode == 'planned' else []:
             entry[0]._host_guarded = entry[0]._host_guarded or self.render_guard == 'host'
         return out
@@ -514,28 +515,46 @@ class HotPath:
     def _forks(self):
         return self.overlap and self.cfg.render
 
+    def _prep_forks(self):
+        """The per-step index preparation on two streams of its own (``_main_chain``)."""
+        return (self.index_prep_mode == 'per_step' and self.cfg.hoa and self.overlap and self.device_geometry
+                and hasattr(self, '_calib_dev'))
+
+    def _step_streams(self, cur):
+        """The step's streams in slot order: the caller's, the render streams, the two index-preparation streams."""
+        st = [cur]
+        if self._forks():
+            if not self._side:
+                self._side = [shared_stream(self.device, 'render' if k == 0 else f'render{k}')
+                              for k in range(self.render_streams)]
+            st += list(self._side)
+        if self._prep_forks():
+            if self._prep_stream is None:
+                self._prep_stream = shared_stream(self.device, 'prep')
+                self._prep_stream2 = shared_stream(self.device, 'prep2')
+            st += [self._prep_stream, self._prep_stream2]
+        return st
+
     def _record_step(self, depth, feat, key, cur):
         """Issue the step eagerly once more, with the library calls logged (``_lib.StepRecorder``) and every tensor it
         allocates drawn from a memory pool of its own (the recorded pointers stay valid: the pool is kept)."""
-        if self._forks() and not self._side:
-            self._side = [shared_stream(self.device, 'render' if k == 0 else f'render{k}')
-                          for k in range(self.render_streams)]
-        rec = _lib.StepRecorder([cur] + (list(self._side) if self._forks() else []))
+        rec = _lib.StepRecorder(self._step_streams(cur))
         pool = torch.cuda.MemPool()
         with torch.cuda.use_mem_pool(pool, self.device), rec:
             out = self._step_eager(depth, feat, rec)
-        if (not rec.ok or self.index_prep_mode != 'cached' or (self.cfg.render and self.render_mode != 'planned')
-                or self.render_guard != 'host'):
-            # a step with launches outside the recordable entry points (per-step index preparation, the per-call or the
-            # device-guarded render): keep issuing it call by call
+        if not rec.ok or (self.index_prep_mode == 'per_step' and not (self.device_geometry and hasattr(self, '_calib_dev'))):
+            # a step with launches outside the recordable entry points — or the per-step index preparation with the
+            # calibration algebra on the HOST (torch CPU ops + uploads per step, which a replay would not repeat): keep
+            # issuing it call by call
             self._one_call_ok = False
-            self.one_call_refused = rec.why or 'a step of this mode is issued call by call'
+            self.one_call_refused = rec.why or 'per-step calibration algebra on the host is issued call by call'
             return out
         self._compiled = (key, rec.build(), out, pool)
         return out
 
     def _step_eager(self, depth, feat, rec=None):
         fork = self._forks()
+        self._rec = rec
         if not fork:
             main = self._main_chain(depth, feat)
             rendered = [self.render()] if self.cfg.render else []
@@ -577,8 +596,7 @@ class HotPath:
         """Pools + HOA on the current stream -> (lss, ht[, gated, opacity_bev])."""
         # HOA-1/2 do not read the pooled BEV and are latency chains of small kernels
         prepared = None
-        if (self.index_prep_mode == 'per_step' and self.cfg.hoa and self.overlap and self.device_geometry
-                and hasattr(self, '_calib_dev')):
+        if self._prep_forks():
             # the index preparation (~ 20 launches, 0.17 ms) needs nothing HOA-1/2 produce: on streams of its own
             # beside them; the poolings wait for it.  Only with the calibration algebra on the device: with the host
             # formulation the step is bound by the host (its ~ 20 small CPU torch ops + ~ 60 launches), and the extra
@@ -587,17 +605,22 @@ class HotPath:
             # (their look-back scratch is per stream, index_prep._prep_tag), the calibration blocks computed once on
             # the first and handed over by an event; each pooling waits only for its own ranks.
             cur0 = torch.cuda.current_stream(self.device)
-            if self._prep_stream is None:
-                self._prep_stream = shared_stream(self.device, 'prep')
-                self._prep_stream2 = shared_stream(self.device, 'prep2')
+            self._step_streams(cur0)                                 # (creates the two streams on first use)
             p1, p2 = self._prep_stream, self._prep_stream2
+            rec = getattr(self, '_rec', None)
+            s1 = 1 + (len(self._side) if self._forks() else 0)      # stream slots of p1, p2 (``_step_streams``)
             p1.wait_stream(cur0)
             p2.wait_stream(cur0)
+            if rec is not None:
+                rec.fork(0, s1)
+                rec.fork(0, s1 + 1)
             with torch.cuda.stream(p1):
                 lss_block, ht_block = self._camera_blocks()
                 blocks_ready = torch.cuda.Event()
                 blocks_ready.record(p1)
                 ht_block.record_stream(p2)
+                if rec is not None:
+                    rec.fork(s1, s1 + 1)                             # (recorded here: the event is taken before the LSS chain)
                 lss_prepared = self._prepare_lss(lss_block)
             p2.wait_event(blocks_ready)
             with torch.cuda.stream(p2):
@@ -613,9 +636,15 @@ class HotPath:
         if prepared is not None:
             main = torch.cuda.current_stream(self.device)
             (lv, lc), (hv, hc) = prepared
+            rec = getattr(self, '_rec', None)
+            s1 = 1 + (len(self._side) if self._forks() else 0)
             main.wait_stream(self._prep_stream)
+            if rec is not None:
+                rec.join(s1, 0)
             lss = bevpool.bev_pool_v2_device_counts(depth, feat, lv[1], lv[2], lv[0], self.lss.bev_shape, lv[3], lv[4], lc)
             main.wait_stream(self._prep_stream2)
+            if rec is not None:
+                rec.join(s1 + 1, 0)
             ht = bevpool.bev_pool_v2_device_counts(depth, feat, hv[1], hv[2], hv[0], self.ht.bev_shape, hv[3], hv[4], hc)
         else:
             lss, ht = self.pool_step(depth, feat, prepared)

@@ -244,6 +244,20 @@ class _RankBuffers:
         return self.bufs
 
 
+_HOST_FLOATS = {}
+
+
+def _host_floats(values):
+    """A host float32 tensor holding ``values`` that lives as long as the process: the C entry points read a few
+    floats through HOST pointers (grid bounds, pc_range), and a recorded step (``_lib.StepRecorder``) replays the call
+    with the pointer it saw."""
+    key = tuple(float(v) for v in values)
+    t = _HOST_FLOATS.get(key)
+    if t is None:
+        t = _HOST_FLOATS[key] = torch.tensor(key, dtype=torch.float32)
+    return t
+
+
 def _prep_tag(dev):
     """Scratch tag of the index preparations: per STREAM, because the scratch holds cross-workgroup state (the
     look-back words of the prefix sums) — two preparations in flight on different streams must not share it."""
@@ -272,8 +286,8 @@ def voxel_pooling_prepare_v2_hip(frustum, cam_block, B, N, grid_lower_bound, gri
     dev = frustum.device
     D, H, W, _ = frustum.shape
     gx, gy, gz = (int(v) for v in grid_size.tolist())
-    lower = grid_lower_bound.detach().float().cpu().contiguous()
-    interval = grid_interval.detach().float().cpu().contiguous()
+    lower = _host_floats(grid_lower_bound.detach().float().cpu().tolist())
+    interval = _host_floats(grid_interval.detach().float().cpu().tolist())
     n_pts = B * N * D * H * W
     bufs = (buffers if buffers is not None else _RankBuffers()).get(dev, n_pts, min(n_pts, B * gz * gy * gx))
     L = _lib.lib()
@@ -299,7 +313,7 @@ def fast_sample_prepare_hip(ref_template, cam_block, B, N, pc_range, image_shape
     _lib.require_cuda(ref_template, cam_block)
     dev = ref_template.device
     Z, Nq, _ = ref_template.shape
-    pc = torch.tensor([float(v) for v in pc_range], dtype=torch.float32)
+    pc = _host_floats(pc_range)
     n_pts = B * N * Z * Nq
     bufs = (buffers if buffers is not None else _RankBuffers()).get(dev, n_pts, B * Nq)
     L = _lib.lib()

@@ -205,3 +205,45 @@ def test_cfg2_step_options_give_the_same_outputs(cuda):
         for k in ('color', 'depth', 'final_T'):
             assert torch.equal(fr_g[k], fr_w[k]), k
     one.check_render_plans()
+
+
+@pytest.mark.parametrize('kw', [dict(render_mode='per_call'), dict(plan_rebuild='per_step')])
+def test_per_sample_step_by_one_host_call_equals_the_step_call_by_call(cuda, kw):
+    """The per-SAMPLE step (index preparation from the calibration on the device, pooling on device-side counts, the
+    per-call render or the plan rebuilt per step; four HIP streams) replayed by ONE host call equals the same step issued
+    call by call, bit for bit — after depth / features, the calibration (translations) and the Gaussian parameters were
+    changed in place, so that a replay that missed a launch would show stale values."""
+    cfg = synthetic.CONFIGS[CFG2]
+    mk = lambda one: hotpath.HotPath(cfg, cuda, index_prep_mode='per_step', device_geometry=True, one_call=one, **kw)  # noqa: E731
+    ref, one = mk(False), mk(True)
+    depth, feat = ref.make_inputs(seed=2)
+    d1, f1 = depth.clone(), feat.clone()
+    for _ in range(3):
+        one.step(d1, f1)                               # call by call, recorded, replayed
+    assert one._compiled is not None, getattr(one, 'one_call_refused', None)
+    before = [t.clone() for t in ref.step(depth, feat)[:2]]
+    d2, f2 = ref.make_inputs(seed=6)
+    d1.copy_(d2), f1.copy_(f2)
+    for hpx in (one, ref):
+        hpx._calib_dev[1].add_(0.05)                   # every camera 5 cm further along x, y, z: other rank vectors
+        g = torch.Generator(device='cpu').manual_seed(3)
+        for fg in hpx.frame_gauss:
+            fg['opacity'].copy_((torch.rand(fg['opacity'].shape, generator=g) * 0.3 + 0.3).to(cuda))
+            fg['rgb'].copy_(torch.rand(fg['rgb'].shape, generator=g).to(cuda))
+        if hpx.render_plans:
+            for plan, f0, nf, gg in hpx.render_plans:
+                for k in ('rgb', 'opacity'):
+                    gg[k].copy_(torch.stack([hpx.frame_gauss[b][k] for b in range(f0, f0 + nf)]))
+        X, Y, _ = cfg.bev_xyz
+        hpx._opac_flat.copy_(torch.stack([fg['opacity'].view(cfg.num_height, Y, X) for fg in hpx.frame_gauss]).reshape(-1, 1))
+    want = ref.step(d2, f2)
+    got = one.step(d1, f1)
+    torch.cuda.synchronize()
+    assert not torch.equal(want[0], before[0]) and not torch.equal(want[1], before[1])      # the inputs did change the step
+    for i in (0, 1, 3, 4):
+        assert torch.equal(got[i], want[i]), (i, float((got[i] - want[i]).abs().max()), int((got[i] != want[i]).sum()),
+                                              bool(torch.equal(got[i], before[i])) if i < 2 else None)
+    for fr_g, fr_w in zip(got[2], want[2]):
+        for k in ('color', 'depth', 'final_T'):
+            assert torch.equal(fr_g[k], fr_w[k]), k
+    one.check_render_plans(), ref.check_render_plans()
