@@ -37,6 +37,7 @@ enum Fn : int {
   kLssPrepare,
   kHtPrepare,
   kGeometryBlocks,
+  kRasterizeForwardSets,
   kFnCount
 };
 
@@ -51,7 +52,7 @@ const FnInfo kFns[kFnCount] = {
     {"ocrf_hoa_v2b_forward", 9},           {"ocrf_hoa_channel_stats", 6},       {"ocrf_hoa_opacity_mask_gate", 11},
     {"ocrf_stream_write_value32", 2},      {"ocrf_raster_plan_build", 12},      {"ocrf_rasterize_forward", 23},
     {"ocrf_bev_pool_v2_nchw_dyn", 19},     {"ocrf_lss_prepare", 20},            {"ocrf_ht_prepare", 22},
-    {"ocrf_geometry_blocks", 16},
+    {"ocrf_geometry_blocks", 16},          {"ocrf_rasterize_forward_sets", 24},
 };
 
 constexpr int kMaxArgs = 40;
@@ -133,6 +134,13 @@ int call(const Cmd& c, ocrf_stream_t s) {
                                     P<const float*>(a[10]), P<const float*>(a[11]), P<const float*>(a[12]), I(a[13]),
                                     P<float*>(a[14]), P<float*>(a[15]), P<float*>(a[16]), P<uint32_t*>(a[17]),
                                     P<int*>(a[18]), P<uint32_t*>(a[19]), P<int*>(a[20]), P<void*>(a[21]), Z(a[22]), s);
+    case kRasterizeForwardSets:
+      return ocrf_rasterize_forward_sets(I(a[0]), I(a[1]), I(a[2]), I(a[3]), I(a[4]), P<const float*>(a[5]),
+                                         P<const float*>(a[6]), P<const float*>(a[7]), P<const float*>(a[8]), F(a[9]),
+                                         P<const float*>(a[10]), P<const float*>(a[11]), P<const float*>(a[12]),
+                                         P<const float*>(a[13]), I(a[14]), P<float*>(a[15]), P<float*>(a[16]),
+                                         P<float*>(a[17]), P<uint32_t*>(a[18]), P<int*>(a[19]), P<uint32_t*>(a[20]),
+                                         P<int*>(a[21]), P<void*>(a[22]), Z(a[23]), s);
     case kPoolDyn:
       return ocrf_bev_pool_v2_nchw_dyn(I(a[0]), I(a[1]), I(a[2]), P<const int*>(a[3]), P<const float*>(a[4]),
                                        P<const float*>(a[5]), P<const int*>(a[6]), P<const int*>(a[7]), P<const int*>(a[8]),

@@ -7,13 +7,14 @@ path intends (``pre_compute``, view_transformer_ocrf.py:854-866).  ``bench.py``,
 ``__graft_entry__.smoke()`` and the sharded runner drive it; frames are treated as extra batch
 entries because they are independent until the channel concat (detectors/ocrfdet.py:274).
 """
+import contextlib
 import math
 
 import numpy as np
 import torch
 
 from . import _lib, bevpool, gaussian_renderer, hoa, index_prep, raster_plan, synthetic
-from .diff_gaussian_rasterization import pack_cameras, rasterize_views
+from .diff_gaussian_rasterization import pack_cameras, rasterize_sets, rasterize_views
 
 
 class PoolPlan:
@@ -342,7 +343,7 @@ class HotPath:
             call_cams = g['cams']                       # ... and the call is checked against the plan's cameras on the device
         out = plan.render(g['rgb'], g['opacity'], g['scales'], g['rotations'], self.bg, guard=self.render_guard,
                           item_view=g['item_view'] if nf > 1 else None, blend_workgroups=bw, phase=phase, out=out,
-                          yield_if=word if bw else None, cameras=call_cams, views_disjoint=True)
+                          yield_if=word if bw else None, cameras=call_cams, views_disjoint=True, want_radii=False)
         if phase == 'update':
             return out
         n = len(self.cams)
@@ -363,6 +364,19 @@ class HotPath:
                     with torch.cuda.stream(streams[entry[1]]):
                         outs.extend(self._render_planned(entry))
             return outs
+        one_stream = streams is None or all(st is streams[0] for st in streams)
+        if self.batch > 1 and one_stream and not want_n_contrib and self._per_call_sets() is not None:
+            # every frame its own Gaussian set and cameras, all on one stream: ONE set of launches for the batch
+            # (ocrf_rasterize_forward_sets: one preprocess / scan / scatter / blend over all frames' views — cfg2's two
+            # frames 2 x 5 launches -> 5, and one blend of twelve views fills the chip better than two of six)
+            g = self._per_call_sets()
+            H, W = self.cfg.input_size
+            ctx = torch.cuda.stream(streams[0]) if streams is not None else contextlib.nullcontext()
+            with ctx:
+                o = rasterize_sets(g['xyz'], g['rgb'], g['opacity'], g['scales'], g['rotations'], g['cams'], H, W, self.bg,
+                                   workspace_tag='raster_sets')
+            n = len(self.cams)
+            return [{k: (v[b * n:(b + 1) * n] if k != 'status' else v) for k, v in o.items()} for b in range(self.batch)]
         for b in range(self.batch):
             if streams is None:
                 outs.append(self._render_per_call(b, want_n_contrib, 'raster'))
@@ -370,6 +384,18 @@ class HotPath:
                 with torch.cuda.stream(streams[b]):
                     outs.append(self._render_per_call(b, want_n_contrib, f'raster{streams.index(streams[b])}'))
         return outs
+
+    def _per_call_sets(self):
+        """The frames' Gaussian sets stacked for one per-call render of the whole batch (built once; the per-frame
+        tensors of ``frame_gauss`` stay the inputs of the per-frame path)."""
+        if getattr(self, '_sets', None) is None:
+            self._sets = False
+            if self.batch * len(self.cams) <= 64:
+                g = {k: torch.stack([fg[k] for fg in self.frame_gauss]).contiguous() for k in ('rgb', 'opacity', 'scales', 'rotations')}
+                g['xyz'] = torch.stack([self.voxel_xyz[b].reshape(-1, 3) for b in range(self.batch)]).contiguous()
+                g['cams'] = torch.cat([rc['packed'] for rc in self.frame_cams]).contiguous()
+                self._sets = g
+        return self._sets or None
 
     @property
     def views_per_step(self):

@@ -234,6 +234,9 @@ def test_per_sample_step_by_one_host_call_equals_the_step_call_by_call(cuda, kw)
             for plan, f0, nf, gg in hpx.render_plans:
                 for k in ('rgb', 'opacity'):
                     gg[k].copy_(torch.stack([hpx.frame_gauss[b][k] for b in range(f0, f0 + nf)]))
+        if getattr(hpx, '_sets', None):                  # the per-call render of the batch reads the stacked sets
+            for k in ('rgb', 'opacity'):
+                hpx._sets[k].copy_(torch.stack([fg[k] for fg in hpx.frame_gauss]))
         X, Y, _ = cfg.bev_xyz
         hpx._opac_flat.copy_(torch.stack([fg['opacity'].view(cfg.num_height, Y, X) for fg in hpx.frame_gauss]).reshape(-1, 1))
     want = ref.step(d2, f2)

@@ -28,11 +28,13 @@ def timed(hp, depth, feat, blocks=5, steps=100):
     return float(np.median(out)), min(out)
 
 
-variants = [dict(blend_workgroups=b) for b in (640, 704, 768, 832, 896)]
+variants = [dict(render_mode='per_call'), dict(render_mode='per_call', lss_pool_backend='tile', ht_pool_backend='mfma'),
+            dict(render_mode='per_call', one_call=False), dict(render_guard='device'), dict(render_guard='device', one_call=False),
+            dict(render_guard='device', blend_workgroups=896)]
 for kw in variants:
     hp = hotpath.HotPath(cfg, dev, **kw)
     depth, feat = hp.make_inputs()
     med, mn = timed(hp, depth, feat)
     hp.check_render_plans()
-    print(kw, 'median %.4f ms  min %.4f ms' % (med, mn), flush=True)
+    print(kw, 'median %.4f ms  min %.4f ms' % (med, mn), 'one call' if hp._compiled is not None else getattr(hp, 'one_call_refused', 'call by call'), flush=True)
     del hp
