@@ -593,6 +593,10 @@ __global__ __launch_bounds__(kBlock) void raster_plan_check_kernel(long n_pairs,
 #endif
 #define OCRF_BLEND_BOUNDS __launch_bounds__(kBlock, OCRF_PLAN_WAVES)
 
+constexpr int kItemTable = 64;                   // items whose view the blend keeps in LDS (more: read per tile pair)
+// workgroup barrier that orders LDS traffic only (outstanding global stores are not waited for)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct BlendArgs {
   unsigned long long* stats;     // STATS build only
   int P, W, H, gx, gy, n_items, vps;
@@ -637,6 +641,9 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(BlendArgs g) {
   __shared__ int l_generic[4];                // [wave]: its list of this batch holds a GENERIC record
   __shared__ int l_fmax[4];                   // [wave]: largest need factor (float bits) of its list of this batch
   __shared__ int l_work;
+  // what a tile pair needs to know of its item, read from global memory ONCE per workgroup (a persistent workgroup
+  // renders ~ 6 tile pairs; item -> view -> list offsets -> head was three dependent round trips at the start of each)
+  __shared__ int l_voff[33], l_head[32], l_vsel[kItemTable];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   int* const ctl = g.ctl;
@@ -678,6 +685,18 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(BlendArgs g) {
     l_b[kStageP] = st.b;
     l_c[kStageP] = st.c;
   }
+  if (run) {
+    // (the heads are what the last blend's close-out left: nothing writes them while tile pairs are being rendered)
+    if (tid <= min(V, 32)) l_voff[tid] = view_off[tid];
+    if (tid >= 64 && tid < 96) {
+      const int v = tid - 64;
+      l_head[v] = (v < V && !g.full) ? head_of(ctl, v, view_off[v + 1] - view_off[v], g.force_head) : 0;
+    }
+    if (tid >= 128 && tid - 128 < min(g.n_items, kItemTable)) {
+      const int z = tid - 128;
+      l_vsel[z] = g.view_sel ? g.view_sel[z] : z % g.vps;
+    }
+  }
   rb::Consts kc = rb::consts();
   asm volatile("" : "+v"(kc.neg_k255), "+v"(kc.neg_half));      // kept in VGPR pairs (else re-materialised per trip)
   // Persistent workgroups over a ticket queue: the grid is what the chip holds at once, every workgroup takes the next
@@ -687,23 +706,24 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(BlendArgs g) {
   int next_ticket = 0;
   if (run && tid == 0) next_ticket = atomicAdd(ctl + kCtlQueue, 1);
   while (run) {
-  __syncthreads();                                                    // the previous pair's LDS traffic is over
+  // (barriers that order LDS only: a __syncthreads() here would also wait for the previous pair's image stores)
+  lds_barrier();                                                      // the previous pair's LDS traffic is over
   if (tid == 0) l_work = next_ticket;
-  __syncthreads();
+  lds_barrier();
   const int work = l_work;
   if (work >= n_work) break;
   if (tid == 0) next_ticket = atomicAdd(ctl + kCtlQueue, 1);
   const int z = work / (gx * gyp);
   const int tx = (work - z * gx * gyp) % gx, ty2 = (work - z * gx * gyp) / gx;
-  const int v = g.view_sel ? g.view_sel[z] : z % g.vps;
+  const int v = z < kItemTable ? l_vsel[z] : (g.view_sel ? g.view_sel[z] : z % g.vps);
   if (v < 0 || v >= V) continue;                                      // reported by step 1 (status bit 8)
   const int set = z / g.vps;
   const int tyA = 2 * ty2, tyB = tyA + 1;
-  const int off = view_off[v], nv = view_off[v + 1] - off;
+  const int off = l_voff[v], nv = l_voff[v + 1] - off;
   // list entries [0, head) have their conic / rect in the dynamic arrays (list order; Gaussian-major through s_e after
   // the full update).  A tile pair that scans beyond them EXTENDS the arrays itself, 256 entries at a time, before it
   // reads them (same inline arithmetic as the head kernel; several workgroups may write an entry: the same bytes)
-  const int head = g.full ? nv : head_of(ctl, v, nv, g.force_head);
+  const int head = g.full ? nv : l_head[v];
   const long dyn = (long)set * g.set_stride;
   const float* set_colors = g.colors + 3 * (long)set * g.P;
   auto dyn_index = [&](int i) { return dyn + (g.full ? (long)g.s_e[off + i] : (long)(off + i)); };
@@ -1052,10 +1072,10 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(BlendArgs g) {
   // Reported by the tile pairs that came within a chunk of the end of the prepared head (or beyond it), and by every
   // 16th tile pair whatever it read — the sample lets the head shrink again.  (Every tile pair reporting is 4 224 atomics
   // on 12 words per launch: they serialise at the memory side and cost the launch 60 us.)
+  // (no look at the word first: the read's round trip would sit in front of the next tile pair's first barrier)
   if (tid == 0 && !g.full) {
     const int reached = min(scan, nv);
-    if ((reached > head - kBlock || (work & 15) == 0) && reached > ctl[kCtlReach + v])
-      atomicMax(ctl + kCtlReach + v, reached);
+    if (reached > head - kBlock || (work & 15) == 0) atomicMax(ctl + kCtlReach + v, reached);
   }
 
   const long npix = (long)W * H;

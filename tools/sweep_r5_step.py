@@ -28,9 +28,10 @@ def timed(hp, depth, feat, blocks=5, steps=100):
     return float(np.median(out)), min(out)
 
 
-variants = [dict(render_mode='per_call'), dict(render_mode='per_call', lss_pool_backend='tile', ht_pool_backend='mfma'),
-            dict(render_mode='per_call', one_call=False), dict(render_guard='device'), dict(render_guard='device', one_call=False),
-            dict(render_guard='device', blend_workgroups=896)]
+variants = [dict(blend_workgroups=g) for g in (512, 576, 640, 704, 768, 1024)] if 'grid' in sys.argv[1:] else \
+    [dict(render_mode='per_call'), dict(render_mode='per_call', lss_pool_backend='tile', ht_pool_backend='mfma'),
+     dict(render_mode='per_call', one_call=False), dict(render_guard='device'), dict(render_guard='device', one_call=False),
+     dict(render_guard='device', blend_workgroups=896)]
 for kw in variants:
     hp = hotpath.HotPath(cfg, dev, **kw)
     depth, feat = hp.make_inputs()
