@@ -103,10 +103,14 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const unsigned* __re
   for (int i = threadIdx.x; i < kBins; i += kBlock) s_hist[i] = 0;
   __syncthreads();
   const int base = blockIdx.x * kChunk;
+  // the thread's keys in ONE round trip (clamped addresses; `if (i < n) load` per key was a branch and a wait per key)
+  unsigned key[kItems];
+#pragma unroll
+  for (int it = 0; it < kItems; ++it) key[it] = keys[min(base + it * kBlock + (int)threadIdx.x, n - 1)];
 #pragma unroll
   for (int it = 0; it < kItems; ++it) {
     const int i = base + it * kBlock + threadIdx.x;
-    if (i < n) atomicAdd(&s_hist[(keys[i] >> shift) & (kBins - 1)], 1);
+    if (i < n) atomicAdd(&s_hist[(key[it] >> shift) & (kBins - 1)], 1);
   }
   __syncthreads();
   for (int d = threadIdx.x; d < kBins; d += kBlock) table[(long)d * n_wg + blockIdx.x] = s_hist[d];
@@ -282,12 +286,19 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
   __syncthreads();
   const int wbase = blockIdx.x * kChunk + wave * (kChunk / (kBlock / 64));
   unsigned key[kItems];
+  int val[kItems];
   bool ok[kItems];
+  // keys (and values) of the thread in ONE round trip, at clamped addresses
 #pragma unroll
   for (int s = 0; s < kItems; ++s) {
     const int i = wbase + s * 64 + lane;
     ok[s] = i < n;
-    key[s] = ok[s] ? keys_in[i] : 0u;
+    key[s] = keys_in[min(i, n - 1)];
+    val[s] = IMPLICIT_VALS ? i : vals_in[min(i, n - 1)];
+  }
+#pragma unroll
+  for (int s = 0; s < kItems; ++s) {
+    if (!ok[s]) key[s] = 0u;
     if (ok[s]) atomicAdd(&s_pos[wave][(key[s] >> shift) & (kBins - 1)], 1);
   }
   __syncthreads();
@@ -314,9 +325,8 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     if (ok[s]) {
       const int rank = __popcll(same & ((1ull << lane) - 1ull));
       const int pos = s_pos[wave][digit] + rank;
-      const int i = wbase + s * 64 + lane;
       keys_out[pos] = key[s];
-      vals_out[pos] = IMPLICIT_VALS ? i : vals_in[i];
+      vals_out[pos] = val[s];
       if (rank == 0) s_pos[wave][digit] = pos + __popcll(same);      // leader advances the digit
     }
     __builtin_amdgcn_wave_barrier();

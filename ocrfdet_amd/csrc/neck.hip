@@ -142,45 +142,77 @@ __device__ __forceinline__ Tap make_tap(float px, float py, int H, int W) {
   return t;
 }
 
-__device__ __forceinline__ float tap_channel(const float* __restrict__ img, const Tap& t, int W) {
-  const float* r0 = img + (size_t)t.y0 * W + t.x0;
-  float acc = 0.0f;
-  if (t.in[0]) acc += r0[0] * t.w[0];
-  if (t.in[1]) acc += r0[1] * t.w[1];
-  if (t.in[2]) acc += r0[W] * t.w[2];
-  if (t.in[3]) acc += r0[W + 1] * t.w[3];
-  return acc;
-}
-
+// A latency kernel (one thread per voxel, <= 2 of the N cameras see it): THREE memory round trips per thread instead of
+// one per tap.  Round 4's form — `if (mask) load` per camera, `if (inside) load` per tap — compiled to a branch and an
+// s_waitcnt vmcnt(0) behind every one of its 112 loads (C = 3): up to 12 dependent round trips per valid camera.  Here
+// (1) the mask bytes of eight cameras, (2) the coordinates of the lane's next TWO valid cameras, (3) their 2 x 4 x C
+// taps at clamped addresses, every load of a round issued before the first use; what a tap outside the image (or a
+// lane without a second camera) contributes is selected away.  Same operations in the same order per output value.
 template <int C>
 __global__ __launch_bounds__(256) void neck_pillar_sample_mean_kernel(
     const float* __restrict__ imgs, const float2* __restrict__ pix, const unsigned char* __restrict__ mask,
     float* __restrict__ avg, int N, int Hi, int Wi, int ZQ) {
   const int q = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-  if (q >= ZQ) return;
+  const bool live = q < ZQ;
+  const int qc = live ? q : ZQ - 1;
+  const size_t plane = (size_t)Hi * Wi;
   float acc[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) acc[c] = 0.0f;
   int cnt = 0;
-  // cameras in batches of 8: every mask byte of the batch first, then the coordinates of the valid
-  // ones, then their taps — three rounds of independent loads instead of a dependent chain per camera
   for (int n0 = 0; n0 < N; n0 += 8) {
     unsigned char m[8];
-    float2 uv[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) m[j] = (n0 + j < N) ? mask[((size_t)b * N + n0 + j) * ZQ + q] : 0;
+    for (int j = 0; j < 8; ++j) m[j] = mask[((size_t)b * N + min(n0 + j, N - 1)) * ZQ + qc];
+    unsigned rem = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) uv[j] = m[j] ? pix[((size_t)b * N + n0 + j) * ZQ + q] : make_float2(0.f, 0.f);
+    for (int j = 0; j < 8; ++j) rem |= (live && n0 + j < N && m[j]) ? (1u << j) : 0u;
+    cnt += __popc(rem);
+    while (__ballot(rem != 0u) != 0ull) {          // (wave-uniform trip count: at most 4, one for most waves)
+      bool ok[2];
+      const float* img[2];
+      float2 uv[2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (!m[j]) continue;
-      ++cnt;
-      const Tap t = make_tap(uv[j].x, uv[j].y, Hi, Wi);
-      const float* img = imgs + ((size_t)b * N + n0 + j) * C * Hi * Wi;
+      for (int k = 0; k < 2; ++k) {
+        ok[k] = rem != 0u;
+        const int cam = n0 + (ok[k] ? __ffs((int)rem) - 1 : 0);       // cameras in ascending order, as the loop had them
+        rem &= rem - 1u;
+        uv[k] = pix[((size_t)b * N + cam) * ZQ + qc];
+        img[k] = imgs + ((size_t)b * N + cam) * C * plane;
+      }
+      Tap t[2];
+      float v[2][C][4];
 #pragma unroll
-      for (int c = 0; c < C; ++c) acc[c] += tap_channel(img + (size_t)c * Hi * Wi, t, Wi);
+      for (int k = 0; k < 2; ++k) {
+        t[k] = make_tap(uv[k].x, uv[k].y, Hi, Wi);
+        const int ya = min(max(t[k].y0, 0), Hi - 1), yb = min(max(t[k].y0 + 1, 0), Hi - 1);
+        const int xa = min(max(t[k].x0, 0), Wi - 1), xb = min(max(t[k].x0 + 1, 0), Wi - 1);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float* pl = img[k] + (size_t)c * plane;
+          v[k][c][0] = pl[(size_t)ya * Wi + xa];
+          v[k][c][1] = pl[(size_t)ya * Wi + xb];
+          v[k][c][2] = pl[(size_t)yb * Wi + xa];
+          v[k][c][3] = pl[(size_t)yb * Wi + xb];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          float a = 0.0f;                              // one camera's bilinear sample, term by term
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float s = a + v[k][c][i] * t[k].w[i];
+            a = t[k].in[i] ? s : a;
+          }
+          const float s = acc[c] + a;
+          acc[c] = ok[k] ? s : acc[c];
+        }
+      }
     }
   }
+  if (!live) return;
   const float den = cnt ? (float)cnt : 1.0f;
   float* o = avg + ((size_t)b * ZQ + q) * C;
 #pragma unroll

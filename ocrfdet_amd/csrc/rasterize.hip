@@ -338,9 +338,14 @@ __global__ __launch_bounds__(kBlock) void raster_scatter_kernel(
   __syncthreads();
   uint4 rec[kChunk / kBlock];
 #pragma unroll
+  for (int it = 0; it < kChunk / kBlock; ++it) {      // the thread's records in ONE round trip (clamped addresses)
+    const int i = blockIdx.x * kChunk + it * kBlock + tid;
+    rec[it] = vis_rec[(long)v * P + min(i, n - 1)];
+  }
+#pragma unroll
   for (int it = 0; it < kChunk / kBlock; ++it) {
     const int i = blockIdx.x * kChunk + it * kBlock + tid;
-    rec[it] = i < n ? vis_rec[(long)v * P + i] : make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+    if (i >= n) rec[it] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
     if (rec[it].x != 0xFFFFFFFFu) atomicAdd(&s_cnt[bucket_of(rec[it].x)], 1);
   }
   __syncthreads();

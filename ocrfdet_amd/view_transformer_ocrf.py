@@ -526,7 +526,6 @@ class OcRFViewTransformerFull(nn.Module):
         # module under its own stream discipline should opt in
         self.parallel_branches, self._transient = False, hoa._LaunchCache()     # streams: not module state
         self.fork_c_after = 'pools'
-        self.hoa12_at = 'end'            # where HOA-1/2 are issued in the fused eval step (see _core_fused)
         self._rank_bufs = (index_prep._RankBuffers(), index_prep._RankBuffers())
         self._packs = {}
 
@@ -923,31 +922,16 @@ class OcRFViewTransformerFull(nn.Module):
         # Where strand C is forked: C needs only the poolings.  Round 3 forked it behind the heads (beside MIOpen's
         # convolutions of C the heads took 355 us instead of 64); with the panel poolings and the head-of-list render
         # front end of round 5 the early fork is the faster one again (tools/ab_neck_r5.py, one box session, two
-        # captures each: 'pools' 0.7005 / 0.7008 ms, 'heads' 0.738 / 0.743, 'render' 0.757).  HOA-1/2 stay where the
-        # reference has them: issued behind the heads or on B's stream the captured graph replays slower and, from
-        # capture to capture, unevenly (0.71 - 0.86 ms).
+        # captures each: 'pools' 0.7005 / 0.7008 ms, 'heads' 0.738 / 0.743, 'render' 0.757).  Everything else tried on
+        # the captured graph replays slower (profiles/r5_neck_schedule_ab.txt): HOA-1/2 behind the heads or on B's
+        # stream (0.71 - 0.86 ms, uneven from capture to capture), the wait for B's colours in front of the heads
+        # instead of the poolings (0.79), the step cut along its outputs into a main chain, a Gaussian strand and a
+        # render strand (0.72 - 0.75: the executor put the render strand on the main chain's queue, behind it).
         fork_at = self.fork_c_after
         if fork_at == 'pools':
             bev_mask_logit, geom_feat = strand_c()
         opacity, scaling, rotation, color = neck_ops.gauss_heads(ht_feat, avg_rgb, self._head_params(), Zh)
         mark(7)
-        # HOA-1/2 read the heads' opacities and strand B's alpha volume, nothing of the render or of strand C.
-        # ``hoa12_at``: 'end' = behind the render and the weighted images (where the reference has them), 'heads' =
-        # on this strand right behind the heads (B joined here instead of behind the render), 'b' = on B's stream
-        hoa12_at = self.hoa12_at if par else 'end'
-        def hoa12():
-            oa = hoa.hoa1(self.defor_cross_attention, opacity.reshape(-1, 1), alpha_lidar, Zh, Y, X)
-            mark(10)
-            return self.OpacityVoxelToBEV(oa, self._pos('positional_encoding1', B, x))
-        if hoa12_at == 'b':
-            heads_done = torch.cuda.Event()
-            heads_done.record(cur)
-            sB.wait_event(heads_done)
-            with torch.cuda.stream(sB):
-                opacity_alpha_view = hoa12()
-        elif hoa12_at == 'heads':
-            cur.wait_stream(sB)
-            opacity_alpha_view = hoa12()
         if fork_at == 'heads':
             bev_mask_logit, geom_feat = strand_c()
         # ---- strand A, second half.  (Forking again behind the heads — render + weighted images beside
@@ -968,8 +952,9 @@ class OcRFViewTransformerFull(nn.Module):
         render_depth = self.LinearWeightedDepth(render_depth_G_all, render_depth_N)
         mark(9)
         # HOA-1 for the whole batch (the reference loops samples, :1159-1161), HOA-2
-        if hoa12_at == 'end':
-            opacity_alpha_view = hoa12()
+        opacity_alpha = hoa.hoa1(self.defor_cross_attention, opacity.reshape(-1, 1), alpha_lidar, Zh, Y, X)
+        mark(10)
+        opacity_alpha_view = self.OpacityVoxelToBEV(opacity_alpha, self._pos('positional_encoding1', B, x))
         mark(11)
         if par:
             cur.wait_stream(sC)

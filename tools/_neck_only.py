@@ -11,6 +11,9 @@ dev = torch.device('cuda:0')
 cfg = synthetic.CONFIGS['cfg2_6cam_2frame_bev200x200_render_hoa']
 mode = sys.argv[1] if len(sys.argv) > 1 else 'graph'
 nk = hotpath.NeckPath(cfg, dev)
+for kv in os.environ.get('NECK_OPTS', '').split():          # module schedule options, e.g. NECK_OPTS="schedule=two"
+    k, v = kv.split('=')
+    setattr(nk.module, k, int(v) if v.isdigit() else v)
 for _ in range(3):
     nk.step()
 if mode == 'graph':

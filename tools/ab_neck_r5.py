@@ -1,5 +1,5 @@
 """Diagnostic: the drop-in neck (cached geometry, one hipGraph replay per step) under the module's schedule options.
-    python tools/ab_neck_r5.py [name=value ...]       e.g.  hoa12_at=heads fork_c_after=pools
+    python tools/ab_neck_r5.py [name=value ...]       e.g.  fork_c_after=heads
 Every line: one freshly built and captured module, median of 5 blocks of 100 replays."""
 import itertools
 import os
@@ -50,5 +50,5 @@ if len(sys.argv) > 1:
     print(opts, '%.4f ms' % one(**opts))
 else:
     for rep in range(2):
-        for hb, fc in itertools.product(('end', 'heads', 'b'), ('heads', 'pools')):
-            print('hoa12_at=%-5s fork_c_after=%-6s  %.4f ms' % (hb, fc, one(hoa12_at=hb, fork_c_after=fc)), flush=True)
+        for fc in ('pools', 'heads', 'render'):
+            print('fork_c_after=%-6s  %.4f ms' % (fc, one(fork_c_after=fc)), flush=True)

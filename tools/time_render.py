@@ -6,7 +6,7 @@ from ocrfdet_amd import _lib, hotpath, synthetic
 name = sys.argv[1] if len(sys.argv) > 1 else 'cfg2_6cam_2frame_bev200x200_render_hoa'
 cfg = synthetic.CONFIGS[name]
 dev = torch.device('cuda:0')
-hp = hotpath.HotPath(cfg, dev)
+hp = hotpath.HotPath(cfg, dev, render_mode='per_call')      # (the per-call chain's kernels are what is timed)
 r = synthetic.rig(cfg.n_cams, cfg.input_size, hp.batch)
 for conv in ('reference', 'corrected'):
     hp._prepare_render(r, conv)
