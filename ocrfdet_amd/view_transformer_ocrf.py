@@ -853,6 +853,97 @@ class OcRFViewTransformerFull(nn.Module):
                                                   opacity_alpha_view, cam_idx_list, render_depth, render_depth_G_all,
                                                   render_depth_N]
 
+    def _core_segments(self, input, geo, depth, depth5, feat_cl, cameras, voxel_coor, mark=lambda i: None):
+        """The eval-mode step on the HIP kernels as its SEGMENTS: closures that read and write one dict of tensors, each
+        running on whatever stream is current.  Who needs whom:
+            b1 colours            <- inputs                       a1 poolings            <- inputs
+            b2 NeRF branch, alpha <- inputs                       c  fusion, ProbNet, GA <- a1
+            a2 Gaussian heads     <- a1, b1                       a3 render              <- a2
+            a4 weighted images    <- a3, b2                       a5 HOA-1/2             <- a2, b2
+            a6 HOA-3 gate (the module's main output)              <- c, a5
+        ``_core_fused`` runs them on up to three streams in one pass (what the captured graph replays).  (Every segment
+        as a linear graph of its own, replayed on four explicit streams with events between them, was measured too:
+        0.77 - 0.84 ms against the one graph's 0.68 — every graph launch on the critical chain adds ~ 25 us of
+        latency; profiles/r5_neck_schedule_ab.txt.)
+        -> (segments, result) with result() the module's return value."""
+        x, imgs_wo_norm = input[0], input[9]
+        dev = x.device
+        B, N, _, Hf, Wf = x.shape
+        Zh, Y, X = self.num_height, self.bev_h, self.bev_w
+        H, W = self.input_size
+        cam_idx_list, cam_sel = cameras['cam_idx_list'], cameras['cam_sel']
+        T = {}
+
+        def b1():
+            T['avg_rgb'] = neck_ops.pillar_sample_mean(imgs_wo_norm, geo.pix, geo.mask)             # (B,Zh,YX,3)
+            mark(1)
+
+        def b2():
+            sparse = neck_ops.retain_valid_pixels(imgs_wo_norm, geo.pix, geo.mask, cam_sel)        # (B,3,H,W)
+            w_s, c_s, nerf_block = self._nerf_params()
+            z = self.image_feat_resize.stem(x.reshape(B * N, -1, Hf, Wf).float())
+            alpha = neck_ops.nerf_alpha(z, w_s, c_s)                                                # (B*N,H,W)
+            T['render_N'], T['render_depth_N'] = neck_ops.nerf_render(z, cam_sel, alpha, sparse, nerf_block, N)
+            # the reference views the (6,H,W,1) stack as (1,6,1,W,H) before sampling it (:1123)
+            alpha_lidar = neck_ops.pillar_sample_mean(alpha.view(B, N, 1, H, W), geo.pix, geo.mask, view_hw=(W, H))
+            T['alpha_lidar'] = alpha_lidar.view(B, Zh, Y, X)
+            T['gt_images'] = imgs_wo_norm[torch.arange(B, device=dev), cam_sel.long()] / 255.0
+            mark(2)
+
+        def a1():
+            if geo.lss is None:
+                # per-forward geometry: beside strand B (see _geometry).  The two preparations stay on ONE stream: they
+                # share the 'index_prep' scratch (and its look-back states)
+                geo.lss, geo.ht = geo.rank_vectors()
+            T['lss_feat'] = self.get_lss_bev_feat(geo, depth5, feat_cl)
+            T['ht_feat'] = self.get_ht_bev_feat(geo, depth5, feat_cl)
+            mark(3)
+
+        def c():
+            channel_feat = self.fuser(T['lss_feat'], T['ht_feat'])
+            mark(4)
+            T['bev_mask_logit'] = self.prob(self._pos('positional_encoding', B, x) + channel_feat)
+            mark(5)
+            T['geom_feat'] = self.geom_att.gate(channel_feat, T['bev_mask_logit'])
+            mark(6)
+
+        def a2():
+            T['opacity'], T['scaling'], T['rotation'], T['color'] = neck_ops.gauss_heads(
+                T['ht_feat'], T['avg_rgb'], self._head_params(), Zh)
+            mark(7)
+
+        def a3():
+            # every sample is a Gaussian set with one camera: ONE rasteriser call for the batch, fed with the
+            # staged camera rows (the reference loops samples, :1090-1153)
+            if self._bg is None or self._bg.device != dev:
+                self._bg = torch.zeros(3, device=dev)
+            o = self._render_sets(geo, voxel_coor, T['color'], T['opacity'], T['scaling'], T['rotation'], cameras, H, W)
+            T['render_image_G_all'], T['render_depth_G_all'] = o['color'], o['depth']
+            mark(8)
+
+        def a4():
+            T['render_image'] = self.LinearWeightedImage(T['render_image_G_all'], T['render_N'])
+            T['render_depth'] = self.LinearWeightedDepth(T['render_depth_G_all'], T['render_depth_N'])
+            mark(9)
+
+        def a5():
+            # HOA-1 for the whole batch (the reference loops samples, :1159-1161), HOA-2
+            oa = hoa.hoa1(self.defor_cross_attention, T['opacity'].reshape(-1, 1), T['alpha_lidar'], Zh, Y, X)
+            mark(10)
+            T['opacity_alpha_view'] = self.OpacityVoxelToBEV(oa, self._pos('positional_encoding1', B, x))
+            mark(11)
+
+        def a6():
+            T['bev_feat'] = self.ObatinOpacityMask.gate(T['geom_feat'], T['opacity_alpha_view'])[1]     # HOA-3
+            mark(12)
+
+        def result():
+            return T['bev_feat'], depth, T['bev_mask_logit'], [
+                T['render_image'], T['gt_images'], T['render_image_G_all'], T['render_N'], T['opacity_alpha_view'],
+                cam_idx_list, T['render_depth'], T['render_depth_G_all'], T['render_depth_N']]
+
+        return dict(b1=b1, b2=b2, a1=a1, c=c, a2=a2, a3=a3, a4=a4, a5=a5, a6=a6), result
+
     def _core_fused(self, input, geo, depth, depth5, feat_cl, cameras, voxel_coor):
         """Eval-mode ``view_transform_core`` on the HIP kernels.  The step has three independent strands
         until HOA joins them — (A) poolings -> Gaussian heads -> render, (B) colour sampling + NeRF branch
@@ -860,12 +951,7 @@ class OcRFViewTransformerFull(nn.Module):
         only the pooled BEVs).  With ``parallel_branches`` B and C run on two side HIP streams (captured as
         parallel branches of the graph): the many small kernels of C and the MIOpen convolutions of B fill
         the gaps of A instead of queueing behind it."""
-        x, imgs_wo_norm = input[0], input[9]
-        dev, dtype = x.device, x.dtype
-        B, N, _, Hf, Wf = x.shape
-        Zh, Y, X = self.num_height, self.bev_h, self.bev_w
-        H, W = self.input_size
-        cam_idx_list, cam_sel = cameras['cam_idx_list'], cameras['cam_sel']
+        dev = input[0].device
         par = self.parallel_branches
         cur = torch.cuda.current_stream(dev)
         if par:
@@ -877,48 +963,27 @@ class OcRFViewTransformerFull(nn.Module):
         on = (lambda s: torch.cuda.stream(s)) if par else (lambda s: contextlib.nullcontext())
         stamps = self._transient.get('stamps')     # diagnostic timeline (tools/timeline_neck.py)
         mark = (lambda i: _lib.diag_stamp(stamps, i)) if stamps is not None else (lambda i: None)
+        seg, result = self._core_segments(input, geo, depth, depth5, feat_cl, cameras, voxel_coor, mark)
         mark(0)
         # ---- strand B
         with on(sB if par else None):
-            avg_rgb = neck_ops.pillar_sample_mean(imgs_wo_norm, geo.pix, geo.mask)                 # (B,Zh,YX,3)
-            mark(1)
+            seg['b1']()
             if par:
                 rgb_ready = torch.cuda.Event()
                 rgb_ready.record(sB)
-            sparse = neck_ops.retain_valid_pixels(imgs_wo_norm, geo.pix, geo.mask, cam_sel)        # (B,3,H,W)
-            w_s, c_s, nerf_block = self._nerf_params()
-            z = self.image_feat_resize.stem(x.reshape(B * N, -1, Hf, Wf).float())
-            alpha = neck_ops.nerf_alpha(z, w_s, c_s)                                                # (B*N,H,W)
-            render_N, render_depth_N = neck_ops.nerf_render(z, cam_sel, alpha, sparse, nerf_block, N)
-            # the reference views the (6,H,W,1) stack as (1,6,1,W,H) before sampling it (:1123)
-            alpha_lidar = neck_ops.pillar_sample_mean(alpha.view(B, N, 1, H, W), geo.pix, geo.mask, view_hw=(W, H))
-            alpha_lidar = alpha_lidar.view(B, Zh, Y, X)
-            gt_images = imgs_wo_norm[torch.arange(B, device=dev), cam_sel.long()] / 255.0
-            mark(2)
+            seg['b2']()
         # ---- strand A, first half.  The wait for B's colours sits in FRONT of the poolings although only the
         # heads need them: ROCm 7.2's graph executor serialises the two branches forked after a node (C, A)
         # when one of them starts with a second, cross-branch dependency (tools/diag_graph_parallel.py:
         # 8.2 instead of 5 kernel times); with the dependency ahead of the fork they overlap.
-        if geo.lss is None:
-            # per-forward geometry: beside strand B (see _geometry).  The two preparations stay on ONE stream: they
-            # share the 'index_prep' scratch (and its look-back states)
-            geo.lss, geo.ht = geo.rank_vectors()
         if par:
             cur.wait_event(rgb_ready)
-        lss_feat = self.get_lss_bev_feat(geo, depth5, feat_cl)
-        ht_feat = self.get_ht_bev_feat(geo, depth5, feat_cl)
-        mark(3)
+        seg['a1']()
         def strand_c():
             if par:
                 sC.wait_stream(cur)
             with on(sC if par else None):
-                channel_feat = self.fuser(lss_feat, ht_feat)
-                mark(4)
-                logit = self.prob(self._pos('positional_encoding', B, x) + channel_feat)
-                mark(5)
-                gated = self.geom_att.gate(channel_feat, logit)
-                mark(6)
-            return logit, gated
+                seg['c']()
         # Where strand C is forked: C needs only the poolings.  Round 3 forked it behind the heads (beside MIOpen's
         # convolutions of C the heads took 355 us instead of 64); with the panel poolings and the head-of-list render
         # front end of round 5 the early fork is the faster one again (tools/ab_neck_r5.py, one box session, two
@@ -929,40 +994,24 @@ class OcRFViewTransformerFull(nn.Module):
         # render strand (0.72 - 0.75: the executor put the render strand on the main chain's queue, behind it).
         fork_at = self.fork_c_after
         if fork_at == 'pools':
-            bev_mask_logit, geom_feat = strand_c()
-        opacity, scaling, rotation, color = neck_ops.gauss_heads(ht_feat, avg_rgb, self._head_params(), Zh)
-        mark(7)
+            strand_c()
+        seg['a2']()
         if fork_at == 'heads':
-            bev_mask_logit, geom_feat = strand_c()
+            strand_c()
         # ---- strand A, second half.  (Forking again behind the heads — render + weighted images beside
         # HOA-1/2 — needs B joined in front of the heads to keep single-parent branches, and that wait costs
         # more than the overlap returns: 0.84 vs 0.80 ms, tools/ab_neck_graph.py.)
-        # every sample is a Gaussian set with one camera: ONE rasteriser call for the batch, fed with the
-        # staged camera rows (the reference loops samples, :1090-1153)
-        if self._bg is None or self._bg.device != dev:
-            self._bg = torch.zeros(3, device=dev)
-        o = self._render_sets(geo, voxel_coor, color, opacity, scaling, rotation, cameras, H, W)
-        render_image_G_all, render_depth_G_all = o['color'], o['depth']
-        mark(8)
+        seg['a3']()
         if fork_at == 'render':
-            bev_mask_logit, geom_feat = strand_c()
+            strand_c()
         if par:
             cur.wait_stream(sB)
-        render_image = self.LinearWeightedImage(render_image_G_all, render_N)
-        render_depth = self.LinearWeightedDepth(render_depth_G_all, render_depth_N)
-        mark(9)
-        # HOA-1 for the whole batch (the reference loops samples, :1159-1161), HOA-2
-        opacity_alpha = hoa.hoa1(self.defor_cross_attention, opacity.reshape(-1, 1), alpha_lidar, Zh, Y, X)
-        mark(10)
-        opacity_alpha_view = self.OpacityVoxelToBEV(opacity_alpha, self._pos('positional_encoding1', B, x))
-        mark(11)
+        seg['a4']()
+        seg['a5']()
         if par:
             cur.wait_stream(sC)
-        geom_feat = self.ObatinOpacityMask.gate(geom_feat, opacity_alpha_view)[1]                   # HOA-3
-        mark(12)
-        return geom_feat, depth, bev_mask_logit, [render_image, gt_images, render_image_G_all, render_N,
-                                                  opacity_alpha_view, cam_idx_list, render_depth, render_depth_G_all,
-                                                  render_depth_N]
+        seg['a6']()
+        return result()
 
     def _render_sets(self, geo, voxel_coor, color, opacity, scaling, rotation, cameras, H, W):
         """One rendered view per sample.  With CACHED geometry (``accelerate=True``) the rasteriser's calibration-only
