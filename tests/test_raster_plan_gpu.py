@@ -245,6 +245,29 @@ def test_item_views_and_sets(cuda):
         plan.check()
 
 
+def test_more_items_than_the_blends_item_table(cuda):
+    """The blend keeps the view of the first 64 rendered items in LDS (one read per workgroup instead of one per tile
+    pair); items beyond that are looked up per tile pair: 9 sets x 8 views = 72 items, every one against the per-call
+    pipeline, on the head path (no radii)."""
+    rng = np.random.default_rng(23)
+    W, H = 64, 48
+    S, n = 9, 700
+    xyz = _t(helpers.random_gaussians(rng, n)[0], cuda)
+    cams = _cams(cuda, W, H, [(0.3 * k, 0.1 * (k % 3), 0.2 * k) for k in range(8)])
+    par = [_scene(rng, n, cuda)[1:] for _ in range(S)]
+    rgb, opac, sc, rot = (torch.stack([p[i] for p in par]) for i in range(4))
+    bg = torch.tensor([0.2, 0.1, 0.0], device=cuda)
+    plan = rp.RasterPlan(xyz, cams, H, W, extent_bound=1.0)
+    got = plan.render(rgb, opac, sc, rot, bg, want_radii=False)
+    torch.cuda.synchronize()
+    assert plan.check() and got['color'].shape[0] == S * 8
+    for s in range(S):
+        want = dgr.rasterize_views(xyz, rgb[s], opac[s], sc[s], rot[s], None, None, None, None, H, W, bg,
+                                   packed_cameras=cams, want_n_contrib=False)
+        for k in ('color', 'depth', 'final_T'):
+            assert torch.equal(want[k], got[k][8 * s:8 * s + 8]), (s, k)
+
+
 def test_opacity_edge_values_and_degenerate_inputs(cuda):
     rng = np.random.default_rng(17)
     W, H = 96, 64

@@ -34,6 +34,9 @@ t time_hoa tools/time_hoa.py
 t time_plan_build tools/time_plan_build.py 50
 t time_pool_panel tools/time_pool_panel.py --group 8 --unit-cost 8
 t time_render_plan tools/time_render_plan.py
+t time_render_per_call tools/time_render.py
+t time_index_prep tools/time_index_prep.py
+t modes tools/modes_r5.py neck
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d $ROOT/$O/${TAG}_trace_step -o x -- python3 $ROOT/tools/_steps_only.py > $ROOT/$O/${TAG}_trace_step.log 2>&1 ) || true
 python3 tools/step_timeline.py $O/${TAG}_trace_step/x_kernel_trace.csv > $O/${TAG}_timeline_hotpath.txt 2>&1 || true
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/${TAG}_trace_neck -o x -- python3 $ROOT/tools/_neck_only.py graph 30 > $ROOT/$O/${TAG}_trace_neck.log 2>&1 ) || true
