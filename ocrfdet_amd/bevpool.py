@@ -227,11 +227,13 @@ def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev,
 
 @torch.no_grad()
 def bev_pool_v2_device_counts(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape,
-                              interval_starts, interval_lengths, counts, layout=1):
+                              interval_starts, interval_lengths, counts, layout=1, scratch_tag='bev_pool_nchw'):
     """Forward-only pooling on rank vectors whose lengths live on the device: the five vectors are
     passed at their CAPACITY (as ``index_prep.*_hip(sync=False)`` returns them) together with
     ``counts`` = int32 device tensor [n_points, n_intervals], so that nothing between the index
-    preparation and the pooling reads the device.  ``layout`` as in ``_FusedPool``."""
+    preparation and the pooling reads the device.  ``layout`` as in ``_FusedPool``.  ``scratch_tag``: the call's scratch
+    (voxel table, unit list, slabs) is one buffer per tag — two poolings that run at the same time on two streams need
+    two tags."""
     B, Z, Y, X, C = (int(v) for v in bev_feat_shape)
     if not _fusable(C):
         raise _lib.OcrfHipError(f'bev_pool_v2_device_counts needs C % 4 == 0 and C <= 256, got {C}')
@@ -246,7 +248,7 @@ def bev_pool_v2_device_counts(depth, feat, ranks_depth, ranks_feat, ranks_bev, b
     L = _lib.lib()
     with _lib.on_device(dev):
         need = L.ocrf_bev_pool_v2_nchw_workspace_bytes(C, cap_iv, cap_pts, B, Z, Y, X)
-        scratch = _lib.workspace.get(dev, need, 'bev_pool_nchw')
+        scratch = _lib.workspace.get(dev, need, scratch_tag)
         _lib.check(L.ocrf_bev_pool_v2_nchw_dyn(
             C, cap_iv, cap_pts, _lib.ptr(counts), _lib.ptr(d32), _lib.ptr(f32), _lib.ptr(ranks_depth),
             _lib.ptr(ranks_feat), _lib.ptr(ranks_bev), _lib.ptr(interval_starts), _lib.ptr(interval_lengths),

@@ -664,6 +664,11 @@ class HotPath:
             (lv, lc), (hv, hc) = prepared
             rec = getattr(self, '_rec', None)
             s1 = 1 + (len(self._side) if self._forks() else 0)
+            # each pooling right behind its own preparation: the HT pooling on the HT preparation's stream, beside the LSS
+            # pooling on this one (own scratch) — in a row on this stream they were 107 us of its critical path
+            with torch.cuda.stream(self._prep_stream2):
+                ht = bevpool.bev_pool_v2_device_counts(depth, feat, hv[1], hv[2], hv[0], self.ht.bev_shape, hv[3], hv[4], hc,
+                                                       scratch_tag='bev_pool_nchw_b')
             main.wait_stream(self._prep_stream)
             if rec is not None:
                 rec.join(s1, 0)
@@ -671,7 +676,7 @@ class HotPath:
             main.wait_stream(self._prep_stream2)
             if rec is not None:
                 rec.join(s1 + 1, 0)
-            ht = bevpool.bev_pool_v2_device_counts(depth, feat, hv[1], hv[2], hv[0], self.ht.bev_shape, hv[3], hv[4], hc)
+            ht.record_stream(main)
         else:
             lss, ht = self.pool_step(depth, feat, prepared)
         if self.cfg.hoa and not hoa_first:
