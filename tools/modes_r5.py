@@ -32,6 +32,10 @@ modes = dict(cached={}, per_call=dict(render_mode='per_call'), guard_device=dict
              per_step_devgeom=dict(index_prep_mode='per_step', device_geometry=True),
              per_sample=dict(index_prep_mode='per_step', device_geometry=True, render_mode='per_call'),
              per_sample_plan=dict(index_prep_mode='per_step', device_geometry=True, plan_rebuild='per_step'))
+if 'extra' in sys.argv[1:]:
+    modes = dict(per_sample=modes['per_sample'],
+                 per_sample_2_render_streams=dict(modes['per_sample'], render_streams=2),
+                 per_call=modes['per_call'], per_call_2_render_streams=dict(modes['per_call'], render_streams=2))
 for name, kw in modes.items():
     hp = hotpath.HotPath(cfg, dev, **kw)
     depth, feat = hp.make_inputs()
