@@ -718,12 +718,12 @@ enum {
   OCRF_K_HOA1_KV = 29,           /* hoa1_kv_kernel */
   OCRF_K_HOA_DW3X3 = 30,         /* hoa_dw3x3_kernel */
   OCRF_K_HOA_DW3X3_WGRAD = 31,   /* hoa_dw3x3_wgrad_kernel */
-  OCRF_K_LSS_KEYS = 40,          /* lss_keys_kernel */
+  OCRF_K_LSS_KEYS = 40,          /* lss_keys_hist_kernel (keys + the first radix histogram) */
   OCRF_K_RADIX_HIST = 41,        /* radix_hist_kernel */
   OCRF_K_SCAN = 42,              /* scan_apply_kernel<T> */
   OCRF_K_RADIX_SCATTER = 43,     /* radix_scatter_kernel<*> */
-  OCRF_K_LSS_BOUNDS = 44,        /* lower_bound_kernel */
-  OCRF_K_LSS_EMIT = 45,          /* lss_emit_ranks_kernel */
+  OCRF_K_LSS_BOUNDS = 44,        /* lss_intervals_kernel */
+  OCRF_K_LSS_EMIT = 45,          /* unused since round 5 (the last radix pass scatters into the rank vectors) */
   OCRF_K_HT_COUNT = 46,          /* ht_valid_kernel */
   OCRF_K_HT_EMIT = 47,           /* ht_emit_kernel */
   OCRF_K_HT_PROJECT = 48,        /* ht_project_kernel */

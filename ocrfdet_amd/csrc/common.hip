@@ -111,12 +111,12 @@ const char* ocrf_kernel_name(int kernel_id) {
     case OCRF_K_HOA1_KV: return "hoa1_kv_kernel";
     case OCRF_K_HOA_DW3X3: return "hoa_dw3x3_kernel";
     case OCRF_K_HOA_DW3X3_WGRAD: return "hoa_dw3x3_wgrad_kernel";
-    case OCRF_K_LSS_KEYS: return "lss_keys_kernel";
+    case OCRF_K_LSS_KEYS: return "lss_keys_hist_kernel";
     case OCRF_K_RADIX_HIST: return "radix_hist_kernel";
     case OCRF_K_SCAN: return "scan_apply_kernel<*>";
     case OCRF_K_RADIX_SCATTER: return "radix_scatter_kernel<*>";
-    case OCRF_K_LSS_BOUNDS: return "lower_bound_kernel";
-    case OCRF_K_LSS_EMIT: return "lss_emit_ranks_kernel";
+    case OCRF_K_LSS_BOUNDS: return "lss_intervals_kernel";
+    case OCRF_K_LSS_EMIT: return "(unused)";
     case OCRF_K_HT_COUNT: return "ht_valid_kernel";
     case OCRF_K_HT_EMIT: return "ht_emit_kernel";
     case OCRF_K_HT_PROJECT: return "ht_project_kernel";

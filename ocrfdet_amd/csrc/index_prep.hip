@@ -52,14 +52,17 @@ __device__ __forceinline__ long long trunc_ll(float x) {
 
 // ---------------------------------------------------------------------------------------------
 // LSS: voxel key per frustum point.  key = b*Z*Y*X + cz*Y*X + cy*X + cx, or n_vox_total if the
-// point falls outside the grid.  One workgroup = 1024 consecutive points (mostly one camera).
+// point falls outside the grid.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void lss_keys_kernel(
-    int n_pts, int N, int DHW, const float* __restrict__ frustum, const LssCam* __restrict__ cams,
-    float lx, float ly, float lz, float ix, float iy, float iz, int gx, int gy, int gz,
-    unsigned n_vox_total, unsigned* __restrict__ keys) {
-  const int p = blockIdx.x * kBlock + threadIdx.x;
-  if (p >= n_pts) return;
+struct LssGrid {
+  float lx, ly, lz, ix, iy, iz;
+  int gx, gy, gz;
+};
+
+__device__ __forceinline__ unsigned lss_key_of(int p, int N, int DHW, const float* __restrict__ frustum,
+                                               const LssCam* __restrict__ cams, const LssGrid& q, unsigned n_vox_total) {
+  const float lx = q.lx, ly = q.ly, lz = q.lz, ix = q.ix, iy = q.iy, iz = q.iz;
+  const int gx = q.gx, gy = q.gy, gz = q.gz;
   const int cam = p / DHW;                 // b*N + n
   const int cell_i = p - cam * DHW;        // (d*H + h)*W + w
   const LssCam& c = cams[cam];
@@ -90,7 +93,30 @@ __global__ __launch_bounds__(kBlock) void lss_keys_kernel(
     const int b = cam / N;
     key = (unsigned)(((long long)b * gz + cz) * gy * gx + cy * gx + cx);
   }
-  keys[p] = key;
+  return key;
+}
+
+// The keys of one sort chunk (kChunk consecutive points, kItems per thread) AND the chunk's histogram of the first radix
+// digit in one launch: the first pass of the sort used to read the 4 MB of keys back for it (one launch and ~ 6 us of
+// the preparation's chain less).  table[d * n_wg + workgroup] as radix_hist_kernel leaves it.
+__global__ __launch_bounds__(kBlock) void lss_keys_hist_kernel(
+    int n_pts, int N, int DHW, const float* __restrict__ frustum, const LssCam* __restrict__ cams, LssGrid q,
+    unsigned n_vox_total, unsigned* __restrict__ keys, int n_wg, int* __restrict__ table) {
+  __shared__ int s_hist[kBins];
+  for (int i = threadIdx.x; i < kBins; i += kBlock) s_hist[i] = 0;
+  __syncthreads();
+  const int base = blockIdx.x * kChunk;
+#pragma unroll
+  for (int it = 0; it < kItems; ++it) {
+    const int p = base + it * kBlock + threadIdx.x;
+    if (p < n_pts) {
+      const unsigned key = lss_key_of(p, N, DHW, frustum, cams, q, n_vox_total);
+      keys[p] = key;
+      atomicAdd(&s_hist[key & (kBins - 1)], 1);
+    }
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < kBins; d += kBlock) table[(long)d * n_wg + blockIdx.x] = s_hist[d];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -276,10 +302,14 @@ inline void scan_exclusive_lookback(T* data, long n, T* total, unsigned long lon
 // Stable scatter of one pass.  A wave owns 512 consecutive keys of the workgroup's chunk and walks
 // them 64 at a time in order; the rank of a key among equal digits of its step is a ballot match,
 // running per-digit positions live in LDS (LDS operations of one wave execute in order).
-template <bool IMPLICIT_VALS>
+// EMIT (the LAST pass of the LSS preparation): the sorted (voxel, point) pairs leave as the three rank vectors at once —
+// ranks_bev = key, ranks_depth = the point's flat index (view_transformer.py:232-236), ranks_feat = (b*N + n)*H*W + h*W + w
+// — instead of as keys / values that one more launch turned into them.
+template <bool IMPLICIT_VALS, bool EMIT = false>
 __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in, int n, int shift, int n_wg,
-    const int* __restrict__ table, unsigned* __restrict__ keys_out, int* __restrict__ vals_out) {
+    const int* __restrict__ table, unsigned* __restrict__ keys_out, int* __restrict__ vals_out,
+    int* __restrict__ ranks_feat, int DHW, int HW) {
   __shared__ int s_pos[kBlock / 64][kBins];
   const int tid = threadIdx.x, wave = tid / 64, lane = tid % 64;
   for (int i = tid; i < (kBlock / 64) * kBins; i += kBlock) (&s_pos[0][0])[i] = 0;
@@ -327,6 +357,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
       const int pos = s_pos[wave][digit] + rank;
       keys_out[pos] = key[s];
       vals_out[pos] = val[s];
+      if constexpr (EMIT) ranks_feat[pos] = (val[s] / DHW) * HW + val[s] % HW;
       if (rank == 0) s_pos[wave][digit] = pos + __popcll(same);      // leader advances the digit
     }
     __builtin_amdgcn_wave_barrier();
@@ -338,7 +369,9 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
 __global__ __launch_bounds__(kBlock) void lss_intervals_kernel(const unsigned* __restrict__ sorted, int n,
                                                                unsigned n_vox_total, int* __restrict__ starts,
                                                                int* __restrict__ lengths, int* __restrict__ counts,
-                                                               unsigned long long* __restrict__ state) {
+                                                               unsigned long long* __restrict__ state,
+                                                               const unsigned long long* __restrict__ all_states,
+                                                               int st_words, int n_states) {
   __shared__ int s_lo[kBlock + 1];
   __shared__ int s_wave[kBlock / 64];
   __shared__ int s_tile;
@@ -367,30 +400,11 @@ __global__ __launch_bounds__(kBlock) void lss_intervals_kernel(const unsigned* _
     lengths[k] = len;
   }
   if (tile == (int)gridDim.x - 1 && threadIdx.x == 0) {
-    counts[0] = lower_bound(n_vox_total);          // keys of dropped points are >= n_vox_total
-    counts[1] = (int)prefix + tot;
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void lss_emit_ranks_kernel(const unsigned* __restrict__ sorted_keys,
-                                                                const int* __restrict__ sorted_pts,
-                                                                const int* __restrict__ counts, int DHW, int HW,
-                                                                int* __restrict__ ranks_bev, int* __restrict__ ranks_depth,
-                                                                int* __restrict__ ranks_feat,
-                                                                const unsigned long long* __restrict__ state, int st_words,
-                                                                int n_states, int* __restrict__ counts_rw) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  const int n = counts[0];
-  if (i < n) {
-    const int p = sorted_pts[i];
-    ranks_bev[i] = (int)sorted_keys[i];
-    ranks_depth[i] = p;                                   // the point's own flat index (:232-236)
-    ranks_feat[i] = (p / DHW) * HW + p % HW;              // (b*N + n)*H*W + h*W + w
-  }
-  if (i == 0) {                                           // a look-back scan of this call gave up: say so in counts
-    bool failed = false;
-    for (int k = 0; k < n_states; ++k) failed = failed || (state[(size_t)k * st_words] >> 63);
-    if (failed) { counts_rw[0] = -1; counts_rw[1] = -1; }
+    // (the tile with the last ticket has every other tile's prefix behind it: no look-back of this call is still waiting)
+    bool failed = false;                           // a look-back scan of this call gave up: say so in counts
+    for (int k = 0; k < n_states; ++k) failed = failed || (all_states[(size_t)k * st_words] >> 63);
+    counts[0] = failed ? -1 : lower_bound(n_vox_total);          // keys of dropped points are >= n_vox_total
+    counts[1] = failed ? -1 : (int)prefix + tot;
   }
 }
 
@@ -641,11 +655,11 @@ hipError_t radix_sort_ids(unsigned* keys, int n, int key_bits, void* scratch, si
     if (pass == 0)
       launch(OCRF_K_RADIX_SCATTER, radix_scatter_kernel<true>, dim3(n_wg), dim3(kBlock), 0, stream,
              static_cast<const unsigned*>(kbuf[cur]), static_cast<const int*>(nullptr), n, shift, n_wg,
-             static_cast<const int*>(table), kbuf[cur ^ 1], vbuf[cur ^ 1]);
+             static_cast<const int*>(table), kbuf[cur ^ 1], vbuf[cur ^ 1], static_cast<int*>(nullptr), 1, 1);
     else
       launch(OCRF_K_RADIX_SCATTER, radix_scatter_kernel<false>, dim3(n_wg), dim3(kBlock), 0, stream,
              static_cast<const unsigned*>(kbuf[cur]), static_cast<const int*>(vbuf[cur]), n, shift, n_wg,
-             static_cast<const int*>(table), kbuf[cur ^ 1], vbuf[cur ^ 1]);
+             static_cast<const int*>(table), kbuf[cur ^ 1], vbuf[cur ^ 1], static_cast<int*>(nullptr), 1, 1);
     cur ^= 1;
   }
   *sorted_keys = kbuf[cur];
@@ -717,35 +731,39 @@ int ocrf_lss_prepare(int B, int N, int D, int H, int W, const float* frustum, co
   const size_t st_words = lb_state_bytes(w.state_tiles_table) / 8;
   hipError_t ze = ocrf::zero_async(state, w.state_bytes, stream);
   if (ze != hipSuccess) return (int)ze;
-  ocrf::launch(OCRF_K_LSS_KEYS, lss_keys_kernel, dim3((n_pts + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, n_pts, N,
-               D * H * W, frustum, reinterpret_cast<const LssCam*>(cams), lx, ly, lz, ix, iy, iz, gx, gy, gz, n_vox_total,
-               keys[0]);
   const int passes = radix_passes(n_vox_total);
   if (passes > 4) return (int)hipErrorInvalidValue;
+  // keys + the first pass's histogram in one launch; the last pass scatters straight into the rank vectors
+  const LssGrid grid{lx, ly, lz, ix, iy, iz, gx, gy, gz};
+  ocrf::launch(OCRF_K_LSS_KEYS, lss_keys_hist_kernel, dim3(n_wg), dim3(kBlock), 0, stream, n_pts, N, D * H * W, frustum,
+               reinterpret_cast<const LssCam*>(cams), grid, n_vox_total, keys[0], n_wg, table);
   int cur = 0;
+  unsigned* const rb_keys = reinterpret_cast<unsigned*>(ranks_bev);
+  const int DHW = D * H * W, HW = H * W;
   for (int pass = 0; pass < passes; ++pass) {
     const int shift = pass * kRadixBits;
-    ocrf::launch(OCRF_K_RADIX_HIST, radix_hist_kernel, dim3(n_wg), dim3(kBlock), 0, stream,
-                 static_cast<const unsigned*>(keys[cur]), n_pts, shift, n_wg, table);
+    const bool last = pass == passes - 1;
+    if (pass > 0)
+      ocrf::launch(OCRF_K_RADIX_HIST, radix_hist_kernel, dim3(n_wg), dim3(kBlock), 0, stream,
+                   static_cast<const unsigned*>(keys[cur]), n_pts, shift, n_wg, table);
     scan_exclusive_lookback(table, (long)kBins * n_wg, (int*)nullptr, state + pass * st_words, stream);
-    if (pass == 0)
-      ocrf::launch(OCRF_K_RADIX_SCATTER, radix_scatter_kernel<true>, dim3(n_wg), dim3(kBlock), 0, stream,
-                   static_cast<const unsigned*>(keys[cur]), static_cast<const int*>(nullptr), n_pts, shift, n_wg,
-                   static_cast<const int*>(table), keys[cur ^ 1], vals[cur ^ 1]);
-    else
-      ocrf::launch(OCRF_K_RADIX_SCATTER, radix_scatter_kernel<false>, dim3(n_wg), dim3(kBlock), 0, stream,
-                   static_cast<const unsigned*>(keys[cur]), static_cast<const int*>(vals[cur]), n_pts, shift, n_wg,
-                   static_cast<const int*>(table), keys[cur ^ 1], vals[cur ^ 1]);
+#define OCRF_LSS_SCATTER(IMPL, EMIT, KOUT, VOUT)                                                                        \
+  ocrf::launch(OCRF_K_RADIX_SCATTER, radix_scatter_kernel<IMPL, EMIT>, dim3(n_wg), dim3(kBlock), 0, stream,             \
+               static_cast<const unsigned*>(keys[cur]), static_cast<const int*>(IMPL ? nullptr : vals[cur]), n_pts,     \
+               shift, n_wg, static_cast<const int*>(table), KOUT, VOUT, ranks_feat, DHW, HW)
+    if (pass == 0 && last) OCRF_LSS_SCATTER(true, true, rb_keys, ranks_depth);
+    else if (pass == 0) OCRF_LSS_SCATTER(true, false, keys[cur ^ 1], vals[cur ^ 1]);
+    else if (last) OCRF_LSS_SCATTER(false, true, rb_keys, ranks_depth);
+    else OCRF_LSS_SCATTER(false, false, keys[cur ^ 1], vals[cur ^ 1]);
+#undef OCRF_LSS_SCATTER
     cur ^= 1;
   }
   const int vgrid = (int)((n_vox_total + 1 + kBlock - 1) / kBlock);
+  // the interval vectors from the sorted keys (= ranks_bev); its last tile also turns a look-back scan that gave up —
+  // any of the sort's or its own — into counts = -1
   ocrf::launch(OCRF_K_LSS_BOUNDS, lss_intervals_kernel, dim3(vgrid), dim3(kBlock), 0, stream,
-               static_cast<const unsigned*>(keys[cur]), n_pts, n_vox_total, interval_starts, interval_lengths, counts,
-               state + 4 * st_words);
-  ocrf::launch(OCRF_K_LSS_EMIT, lss_emit_ranks_kernel, dim3((n_pts + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
-               static_cast<const unsigned*>(keys[cur]), static_cast<const int*>(vals[cur]), static_cast<const int*>(counts),
-               D * H * W, H * W, ranks_bev, ranks_depth, ranks_feat, static_cast<const unsigned long long*>(state),
-               (int)st_words, 5, counts);
+               static_cast<const unsigned*>(rb_keys), n_pts, n_vox_total, interval_starts, interval_lengths, counts,
+               state + 4 * st_words, static_cast<const unsigned long long*>(state), (int)st_words, 5);
   return (int)hipGetLastError();
 }
 

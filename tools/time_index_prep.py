@@ -33,7 +33,7 @@ print('two uploads per call %.1f us' % ((t1 - t0) / 50 * 1e6))
 torch.cuda.synchronize()
 print('counts lss', lc.tolist(), 'capacity', lv[0].numel(), lv[3].numel(), '| ht', hc.tolist(), 'capacity', hv[0].numel(), hv[3].numel())
 for kid, nm in ((_lib.K_LSS_KEYS, 'lss_keys'), (_lib.K_RADIX_HIST, 'radix_hist'), (_lib.K_RADIX_SCATTER, 'radix_scatter'), (_lib.K_SCAN, 'scan_apply'),
-                (_lib.K_LSS_BOUNDS, 'lss_bounds'), (_lib.K_LSS_EMIT, 'lss_emit'), (_lib.K_HT_COUNT, 'ht_count'), (_lib.K_HT_EMIT, 'ht_emit')):
+                (_lib.K_LSS_BOUNDS, 'lss_bounds'), (_lib.K_HT_COUNT, 'ht_count'), (_lib.K_HT_EMIT, 'ht_emit')):
     t = _lib.KernelTimer(kid, 100); torch.cuda.synchronize(); t.arm()
     for _ in range(10): hp.prepare_indices_hip(sync=False)
     torch.cuda.synchronize(); t.disarm(); ms = t.read_ms(); t.close()
