@@ -290,25 +290,43 @@ __global__ __launch_bounds__(64) void neck_gauss_heads_kernel(
 #pragma unroll
     for (int k = 0; k < 8; ++k) hid[h][k] = f32x2{0.0f, 0.0f};
   const float* bp = bev + (size_t)b * C * YX + q;
-  // 8 channel reads in flight per lane: with one or two waves per SIMD nothing else hides the latency
+  // 8 channel reads in flight per lane, requested one batch AHEAD of the batch being accumulated (with two or three waves
+  // per SIMD nothing else hides their latency: a batch's 560 VALU instructions take about as long as its loads)
   constexpr int kAhead = 8;
-  for (int c0 = 0; c0 < C; c0 += kAhead) {
-    float vv[kAhead];
+  float vv[kAhead], nx[kAhead];
+  f32x2 w[8];
 #pragma unroll
-    for (int j = 0; j < kAhead; ++j) vv[j] = (c0 + j < C) ? bp[(size_t)(c0 + j) * YX] : 0.0f;
+  for (int k = 0; k < 8; ++k) w[k] = W1t[k];
+#pragma unroll
+  for (int j = 0; j < kAhead; ++j) nx[j] = bp[(size_t)min(j, C - 1) * YX];
+  for (int c0 = 0; c0 < C; c0 += kAhead) {
+#pragma unroll
+    for (int j = 0; j < kAhead; ++j) vv[j] = nx[j];
+#pragma unroll
+    for (int j = 0; j < kAhead; ++j) nx[j] = bp[(size_t)min(c0 + kAhead + j, C - 1) * YX];      // (clamped: no branch)
 #pragma unroll
     for (int j = 0; j < kAhead; ++j) {
-      if (c0 + j >= C) break;
-      f32x2 w[8];
+      // the NEXT channel's 16 weights (one wave-uniform 64-byte scalar load) are requested before this channel's
+      // arithmetic: loaded where they are used, every channel waited ~ 0.3 us for its own load — 80 times per wave
+      f32x2 wn[8];
+      // (scalar loads return out of order: any wait for one is a wait for all.  This channel's weights are therefore
+      // waited for HERE, before the next channel's are requested — else the first use below waits for both)
+      asm volatile("" ::"s"(w[0].x));
+      const int cn = min(c0 + j + 1, C - 1);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) w[k] = W1t[(c0 + j) * 8 + k];
+      for (int k = 0; k < 8; ++k) wn[k] = W1t[cn * 8 + k];
+      __builtin_amdgcn_sched_barrier(0);       // (left alone the scheduler sinks the load back to its first use)
+      if (c0 + j < C) {
 #pragma unroll
-      for (int h = 0; h < HG; ++h) {
-        const float f = fmaxf(fmaf(la[h], vv[j], lb[h]), 0.0f);
-        const f32x2 ff = {f, f};
+        for (int h = 0; h < HG; ++h) {
+          const float f = fmaxf(fmaf(la[h], vv[j], lb[h]), 0.0f);
+          const f32x2 ff = {f, f};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) hid[h][k] = __builtin_elementwise_fma(w[k], ff, hid[h][k]);
+          for (int k = 0; k < 8; ++k) hid[h][k] = __builtin_elementwise_fma(w[k], ff, hid[h][k]);
+        }
       }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) w[k] = wn[k];
     }
   }
   // epilogue.  The 3-float rows of rgb / scales / colour go through an LDS transposition (one wave =

@@ -100,6 +100,15 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
   __syncthreads();
   unsigned key_of[kPreChunk / kBlock];
   Rect rect_of[kPreChunk / kBlock];
+  // the view's camera (wave-uniform: scalar registers) is read ONCE per workgroup: read where it is used, every one of a
+  // thread's four Gaussians re-fetched it in four to five dependent scalar round trips (view index -> row -> fields)
+  float vm[16], pm[16], cam_tanx, cam_tany, cam_fx, cam_fy;
+  {
+    const Camera& cam = cams[view_sel ? view_sel[v] : v];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { vm[i] = cam.view[i]; pm[i] = cam.proj[i]; }
+    cam_tanx = cam.tanfovx; cam_tany = cam.tanfovy; cam_fx = cam.focal_x; cam_fy = cam.focal_y;
+  }
 #pragma unroll
   for (int it = 0; it < kPreChunk / kBlock; ++it) {
   const int idx = chunk * kPreChunk + it * kBlock + threadIdx.x;
@@ -108,9 +117,6 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
   if (idx >= P) continue;
   const long o = (long)v * P + idx;
   const long gi = (long)(v / vps) * P + idx;      // Gaussian sets: view v renders set v / views_per_set
-  const Camera& cam = cams[view_sel ? view_sel[v] : v];
-  const float* vm = cam.view;
-  const float* pm = cam.proj;
   unsigned key = 0xFFFFFFFFu;
   int my_radii = 0;
   unsigned touched = 0;
@@ -135,12 +141,12 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
     // what the early exit leaves; the bound only ever over-estimates the radius:
     //   lambda_max(A Sigma A^T + 0.3 I) <= 0.3 + |A|_F^2 |Sigma|_2,  Sigma = R diag(s^2) R^T,
     //   R = (1 - |q|^2) I + |q|^2 Rot(q/|q|)  =>  |R|_2 <= |1 - |q|^2| + |q|^2.
-    const float limx = 1.3f * cam.tanfovx, limy = 1.3f * cam.tanfovy;
+    const float limx = 1.3f * cam_tanx, limy = 1.3f * cam_tany;
     const float txtz = vx / vz, tytz = vy / vz;
     const float tx = fminf(limx, fmaxf(-limx, txtz)) * vz;
     const float ty = fminf(limy, fmaxf(-limy, tytz)) * vz;
-    const float j00 = cam.focal_x / vz, j02 = -(cam.focal_x * tx) / (vz * vz);
-    const float j11 = cam.focal_y / vz, j12 = -(cam.focal_y * ty) / (vz * vz);
+    const float j00 = cam_fx / vz, j02 = -(cam_fx * tx) / (vz * vz);
+    const float j11 = cam_fy / vz, j12 = -(cam_fy * ty) / (vz * vz);
     float A[2][3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
