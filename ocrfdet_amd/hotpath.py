@@ -274,7 +274,9 @@ class HotPath:
             H, W = self.cfg.input_size
             n_cam = len(self.cams)
             same = all(torch.equal(self.voxel_xyz[b], self.voxel_xyz[0]) for b in range(1, self.batch))
-            fuse = (self.batch * n_cam <= 32) if self.fuse_frames == 'auto' else bool(self.fuse_frames)
+            # (round 5: also when the batch needs several plans — cfg4's 48 views as 30 + 18 instead of 8 x 6: every
+            # launch less is a head kernel, an extent check and a blend tail less on the render stream, 2.156 -> 1.865 ms)
+            fuse = True if self.fuse_frames == 'auto' else bool(self.fuse_frames)
             per = max(1, 32 // n_cam) if (same and fuse) else 1
             self.render_plans = []
             for f0 in range(0, self.batch, per):
