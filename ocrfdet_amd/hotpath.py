@@ -334,7 +334,12 @@ class HotPath:
             # behind a 32-us update; round 5, one host call per step and a blend of half the instructions: cfg2 step at
             # 448 / 512 / 576 / 640 / 704 / 768 / 896 workgroups 0.225 / 0.218 / 0.209 / 0.203 / 0.200 / 0.208 / 0.224 ms,
             # tools/sweep_r5_step.py)
-            bw = (11 * torch.cuda.get_device_properties(self.device).multi_processor_count // 4
+            # Where the render outweighs the other chain by far (configs[4]: 721 k pixels per view against cfg2's 180 k, the
+            # same poolings + HOA per frame) the optimum is 3.25 per CU: 768 / 800 / 832 / 864 / 896 / 960 workgroups
+            # 1.806 / 1.783 / 1.777 / 1.787 / 1.820 / 1.889 ms against 1.879 at 704 (tools/sweep_cfg4_grid.py).
+            H, W = self.cfg.input_size
+            per_cu_x4 = 13 if H * W >= 512 * 1024 else 11
+            bw = (per_cu_x4 * torch.cuda.get_device_properties(self.device).multi_processor_count // 4
                   if (self.overlap or getattr(self, '_yield_word', None) is not None) else 0)
         elif not isinstance(bw, int):
             bw = int(bw[min(f0, len(bw) - 1)])
