@@ -57,3 +57,64 @@ def test_ops_refuse_cpu_tensors():
     r = torch.zeros(4, dtype=torch.int32)
     with pytest.raises(_lib.OcrfHipError):
         bevpool.bev_pool_v2(d, f, r, r, r, (1, 1, 2, 2, 4), r[:1], r[:1])
+
+
+def test_step_object_host_logic():
+    """csrc/step.hip on the host side only: the table of entry points a step can hold agrees with the ctypes
+    declarations (one argument word per declared argument, the trailing stream excluded), calls with a wrong argument
+    count / slot / id are refused, forks and joins are counted, a step is not run on fewer streams than it names."""
+    L = _lib.lib()
+    names = ['ocrf_bev_pool_v2_nchw_planned', 'ocrf_bev_pool_v2_nchw_mfma', 'ocrf_bev_pool_cell_weights',
+             'ocrf_bev_pool_v2_nchw_panel', 'ocrf_rasterize_planned', 'ocrf_hoa1_forward', 'ocrf_hoa_v2b_forward',
+             'ocrf_hoa_channel_stats', 'ocrf_hoa_opacity_mask_gate', 'ocrf_stream_write_value32', 'ocrf_raster_plan_build',
+             'ocrf_rasterize_forward', 'ocrf_bev_pool_v2_nchw_dyn', 'ocrf_lss_prepare', 'ocrf_ht_prepare',
+             'ocrf_geometry_blocks', 'ocrf_rasterize_forward_sets']
+    for name in names:
+        fid = L.ocrf_step_fn_id(name.encode())
+        assert fid >= 0, name
+        fn = getattr(L, name)
+        assert fn.argtypes is not None, f'{name} has no ctypes declaration'
+        assert L.ocrf_step_fn_args(fid) == len(fn.argtypes) - 1, name
+    assert L.ocrf_step_fn_id(b'ocrf_version') == -1 and L.ocrf_step_fn_args(-1) == -1 and L.ocrf_step_fn_args(999) == -1
+    h = ctypes.c_void_p()
+    assert L.ocrf_step_create(ctypes.byref(h)) == 0 and L.ocrf_step_size(h) == 0
+    fid = L.ocrf_step_fn_id(b'ocrf_stream_write_value32')
+    words = (ctypes.c_uint64 * 2)(0, 1)
+    assert L.ocrf_step_add_call(h, fid, 0, 2, words) == 0
+    assert L.ocrf_step_add_call(h, fid, 0, 3, words) != 0            # wrong argument count
+    assert L.ocrf_step_add_call(h, fid, 8, 2, words) != 0            # no such stream slot
+    assert L.ocrf_step_add_call(h, 999, 0, 2, words) != 0            # no such entry point
+    assert L.ocrf_step_add_fork(h, 0, 1) == 0 and L.ocrf_step_add_join(h, 1, 0) == 0
+    assert L.ocrf_step_add_fork(h, 0, 0) != 0 and L.ocrf_step_add_join(h, 0, 9) != 0
+    assert L.ocrf_step_size(h) == 3
+    streams = (ctypes.c_void_p * 1)(None)
+    assert L.ocrf_step_run(h, streams, 0) != 0                       # no streams
+    L.ocrf_step_destroy(h)
+
+
+def test_step_recorder_encodes_arguments(monkeypatch):
+    """_lib.StepRecorder.on_call (no launch): floats as their bit pattern, negative ints as 64-bit two's complement, a
+    call on an unknown stream or of an entry point a step cannot hold makes the step not recordable."""
+    import struct
+    L = _lib.lib()
+    rec = _lib.StepRecorder.__new__(_lib.StepRecorder)
+    rec.slots, rec.items, rec.names, rec.ok, rec.why = {0: 0, 77: 1}, [], [], True, None
+    fn = L.ocrf_stream_write_value32
+    rec.on_call('ocrf_stream_write_value32', fn, (ctypes.c_void_p(4096), -2, ctypes.c_void_p(77)))
+    assert rec.ok and rec.items == [('call', L.ocrf_step_fn_id(b'ocrf_stream_write_value32'), 1, [4096, (1 << 64) - 2])]
+    rec.on_call('ocrf_stream_write_value32', fn, (ctypes.c_void_p(4096), 1, ctypes.c_void_p(5)))
+    assert not rec.ok and 'stream' in rec.why
+    rec2 = _lib.StepRecorder.__new__(_lib.StepRecorder)
+    rec2.slots, rec2.items, rec2.names, rec2.ok, rec2.why = {0: 0}, [], [], True, None
+    rec2.on_call('ocrf_hoa_dw3x3', L.ocrf_hoa_dw3x3, tuple([0] * len(L.ocrf_hoa_dw3x3.argtypes)))
+    assert not rec2.ok and 'cannot be held' in rec2.why
+    # a float argument travels as its bit pattern
+    planned = L.ocrf_rasterize_planned
+    fpos = [i for i, t in enumerate(planned.argtypes) if t is ctypes.c_float]
+    assert fpos, 'ocrf_rasterize_planned has a float argument (scale_modifier)'
+    args = [0] * len(planned.argtypes)
+    args[fpos[0]] = ctypes.c_float(1.5)
+    rec3 = _lib.StepRecorder.__new__(_lib.StepRecorder)
+    rec3.slots, rec3.items, rec3.names, rec3.ok, rec3.why = {0: 0}, [], [], True, None
+    rec3.on_call('ocrf_rasterize_planned', planned, tuple(args))
+    assert rec3.ok and rec3.items[0][3][fpos[0]] == struct.unpack('<I', struct.pack('<f', 1.5))[0]
