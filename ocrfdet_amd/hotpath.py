@@ -719,9 +719,14 @@ class ShardedHotPath:
     ``world == 1`` it is ``HotPath`` with the same fused output buffer, bit for bit."""
 
     def __init__(self, cfg, device, rank, world, index_prep_mode='cached', render_mode='planned', render_guard='host',
-                 sparse_exchange=True, collectives=None):
+                 sparse_exchange=True, collectives=None, one_call=True):
         from . import sharding
         self.cfg, self.device, self.rank, self.world = cfg, torch.device(device), rank, world
+        # one_call: the rank's COMPUTE between the collectives — (poolings + renders) and (HOA-1/2) — is recorded once and
+        # replayed by one host call each (``_lib.StepRecorder``, as ``HotPath.step``): a rank of eight has ~ 0.1 ms of
+        # device work per step and would otherwise spend ~ 0.2 ms issuing its ~ 16 library calls through ctypes
+        self.one_call = bool(one_call) and self.device.type == 'cuda' and index_prep_mode == 'cached'
+        self._segments, self._segment_seen, self.one_call_refused = {}, {}, None
         X, Y, Z = cfg.bev_xyz
         C = cfg.channels
         self.n_frames = cfg.batch * cfg.n_frames
@@ -803,7 +808,14 @@ class ShardedHotPath:
         X, Y, _ = cfg.bev_xyz
         opac, alpha, pos = self._hoa_in
         m = self.base.hoa_mods
-        ob = m['v2b'](hoa.hoa1(m['dca'], opac, alpha, cfg.num_height, Y, X), pos)        # (len(my_frames), 1, Y, X)
+
+        def body(rec):
+            return m['v2b'](hoa.hoa1(m['dca'], opac, alpha, cfg.num_height, Y, X), pos)      # (len(my_frames), 1, Y, X)
+        if self.device.type == 'cuda':
+            ob = self._segment('hoa12', (opac.data_ptr(), alpha.data_ptr(), pos.data_ptr()),
+                               [torch.cuda.current_stream(self.device)], body)
+        else:
+            ob = body(None)
         self.hoa_launch_frames = len(self.my_frames)
         return {f: ob[i, 0] for i, f in enumerate(self.my_frames)}
 
@@ -820,8 +832,23 @@ class ShardedHotPath:
 
         def gate_fn(x, stats, opacity):
             mask.gate(x.unsqueeze(0), opacity.reshape(1, 1, Y, X), stats=stats.unsqueeze(0).contiguous(), in_place=True)
+        def body(rec):
+            with torch.no_grad():
+                sharding.gate_blocks(ex, self.planes_lss, self.cfg.channels, None, ob, stats_fn, gate_fn)
+        # a rank whose frames are all its own (no group to gather statistics from) gates without a collective inside:
+        # one more recorded segment
+        alone = all(len(self.plan.group_of_frame[f]) == 1 or not ex.active for f, _, _ in ex.my_blocks)
+        if alone and self.device.type == 'cuda':
+            key = (id(ex),) + tuple(t.data_ptr() for t in ob.values())
+            self._segment('gate', key, [torch.cuda.current_stream(self.device)], body)
+        else:
+            body(None)
+        # the frame's opacity BEV into its plane of the fused grid (the member whose block holds that plane): it travels
+        # with the gather (a torch copy: not part of a recorded segment)
         with torch.no_grad():
-            sharding.gate_blocks(ex, self.planes_lss, self.cfg.channels, self.opacity_plane, ob, stats_fn, gate_fn)
+            for f, p0, n, view in ex.block_views():
+                if p0 <= self.opacity_plane < p0 + n:
+                    view[self.opacity_plane - p0].copy_(ob[f])
 
     def _outputs(self, full, rendered):
         gated = opacity_bev = None
@@ -830,20 +857,53 @@ class ShardedHotPath:
             opacity_bev = full[:, self.planes_pool:self.planes_pool + 1]
         return full, rendered, gated, opacity_bev
 
+    def _segment(self, name, key, streams, fn):
+        """``fn(rec)`` — library calls only, on ``streams`` (slot 0 = the caller's) — by ONE host call from the third time
+        ``key`` (the pointers it works on) is seen: first eagerly (plans and scratch are built), then recorded with its
+        allocations in a memory pool of its own, then replayed.  -> what ``fn`` returned (the same tensors every replay)."""
+        if not self.one_call or torch.cuda.is_current_stream_capturing():
+            return fn(None)
+        hit = self._segments.get((name, key))
+        if hit is not None:
+            hit[0].run(*[st.cuda_stream for st in streams])
+            return hit[1]
+        if (name, key) not in self._segment_seen:
+            self._segment_seen[(name, key)] = True
+            return fn(None)
+        rec, pool = _lib.StepRecorder(streams), torch.cuda.MemPool()
+        with torch.cuda.use_mem_pool(pool, self.device), rec:
+            out = fn(rec)
+        if not rec.ok:
+            self.one_call, self.one_call_refused = False, rec.why
+            return out
+        self._segments[(name, key)] = (rec.build(), out, pool)
+        return out
+
     def _pool_and_render(self, inputs, target_of):
         cur = torch.cuda.current_stream(self.device) if self._side is not None else None
-        rendered = []
-        if self._side is not None:
-            self._set_busy(1)
-            self._side.wait_stream(cur)
+        targets = {f: target_of(f) for f in self.subs}
+
+        def body(rec):
+            rendered = []
+            if self._side is not None:
+                self._set_busy(1)
+                self._side.wait_stream(cur)
+                if rec is not None:
+                    rec.fork(0, 1)
+                for f, sub in self.subs.items():
+                    rendered.append(sub.render([self._side]))
             for f, sub in self.subs.items():
-                rendered.append(sub.render([self._side]))
-        for f, sub in self.subs.items():
-            depth, feat = inputs[f]
-            tgt = target_of(f)
-            sub.pool(sub.lss, depth, feat, out=tgt[:self.planes_lss])
-            sub.pool(sub.ht, depth, feat, out=tgt[self.planes_lss:self.planes_pool])
-        return cur, rendered
+                depth, feat = inputs[f]
+                tgt = targets[f]
+                sub.pool(sub.lss, depth, feat, out=tgt[:self.planes_lss])
+                sub.pool(sub.ht, depth, feat, out=tgt[self.planes_lss:self.planes_pool])
+            return rendered
+        if self.device.type != 'cuda' or not self.subs:
+            return cur, body(None)
+        key = tuple((f, inputs[f][0].data_ptr(), inputs[f][1].data_ptr(), targets[f].data_ptr()) for f in self.subs)
+        main = cur if cur is not None else torch.cuda.current_stream(self.device)
+        streams = [main] + ([self._side] if self._side is not None else [])
+        return cur, self._segment('pool_render', key, streams, body)
 
     def _join_renders(self, cur, rendered):
         if self._side is not None:

