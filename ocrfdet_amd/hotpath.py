@@ -868,6 +868,10 @@ class ShardedHotPath:
             hit[0].run(*[st.cuda_stream for st in streams])
             return hit[1]
         if (name, key) not in self._segment_seen:
+            # (bounded: a caller that hands over NEW tensors every step never repeats a key — it runs call by call, and
+            # these tables must not grow with it)
+            if len(self._segment_seen) >= 32:
+                self._segment_seen.clear()
             self._segment_seen[(name, key)] = True
             return fn(None)
         rec, pool = _lib.StepRecorder(streams), torch.cuda.MemPool()
@@ -876,6 +880,8 @@ class ShardedHotPath:
         if not rec.ok:
             self.one_call, self.one_call_refused = False, rec.why
             return out
+        while len(self._segments) >= 12:                    # (three segments x two buffer sets, with room)
+            self._segments.pop(next(iter(self._segments)))
         self._segments[(name, key)] = (rec.build(), out, pool)
         return out
 
