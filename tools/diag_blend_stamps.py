@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ocrfdet_amd import _lib, hotpath, synthetic
 cfg = synthetic.CONFIGS['cfg2_6cam_2frame_bev200x200_render_hoa']
 dev = torch.device('cuda:0')
-hp = hotpath.HotPath(cfg, dev)
+hp = hotpath.HotPath(cfg, dev, render_mode='per_call')
 r = synthetic.rig(cfg.n_cams, cfg.input_size, hp.batch)
 L = _lib.lib()
 ntile = 44 * 8 * 6      # one workgroup per vertical pair of 16x16 tiles
