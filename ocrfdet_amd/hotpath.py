@@ -310,9 +310,9 @@ class HotPath:
                                workspace_tag=tag)
 
     def _use_busy(self):
-        # the hint pays when a step has several blend launches (cfg4: one per frame, 3.08 -> 2.70 ms); with ONE
-        # launch per step every extra workgroup would leave at once anyway, and the two stream writes are not free
-        # (cfg2: 0.288 -> 0.301 ms)
+        # the hint pays when a step has several blend launches (cfg4: two plans of 30 + 18 views; with one plan per frame
+        # in round 3: 3.08 -> 2.70 ms); with ONE launch per step every extra workgroup would leave at once anyway, and the
+        # two stream writes are not free (cfg2: 0.288 -> 0.301 ms)
         plans = getattr(self, 'render_plans', None)
         return bool(self.overlap and self._busy is not None and plans is not None and len(plans) > 1)
 
@@ -593,7 +593,7 @@ class HotPath:
             rendered = [self.render()] if self.cfg.render else []
             return tuple(main[:2]) + tuple(rendered) + tuple(main[2:])
         cur = torch.cuda.current_stream(self.device)
-        # "the main chain is running": the persistent blends of the render stream keep to 3.5 workgroups per CU
+        # "the main chain is running": the persistent blends of the render stream keep to 2.75 - 3.25 workgroups per CU
         # while it is up and take the whole chip once it is down (cfg4: the renders outlast the poolings + HOA)
         self._set_busy(1)
         if not self._side:
