@@ -26,6 +26,7 @@
 
 #include "launch.h"
 #include "ocrf_hip.h"
+#include "radix_emit.h"
 
 namespace {
 
@@ -305,11 +306,17 @@ inline void scan_exclusive_lookback(T* data, long n, T* total, unsigned long lon
 // EMIT (the LAST pass of the LSS preparation): the sorted (voxel, point) pairs leave as the three rank vectors at once —
 // ranks_bev = key, ranks_depth = the point's flat index (view_transformer.py:232-236), ranks_feat = (b*N + n)*H*W + h*W + w
 // — instead of as keys / values that one more launch turned into them.
-template <bool IMPLICIT_VALS, bool EMIT = false>
+// EMIT 2 (the last pass of a render-plan build's sort): besides the sorted keys, the plan's per-view list arrays
+// (ocrf::RadixPlanEmit) — the gather launch that read the pairs back to write them is gone.
+struct ScatterExtra {
+  int* ranks_feat;
+  int DHW, HW;
+  ocrf::RadixPlanEmit plan;
+};
+template <bool IMPLICIT_VALS, int EMIT = 0>
 __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in, int n, int shift, int n_wg,
-    const int* __restrict__ table, unsigned* __restrict__ keys_out, int* __restrict__ vals_out,
-    int* __restrict__ ranks_feat, int DHW, int HW) {
+    const int* __restrict__ table, unsigned* __restrict__ keys_out, int* __restrict__ vals_out, ScatterExtra x) {
   __shared__ int s_pos[kBlock / 64][kBins];
   const int tid = threadIdx.x, wave = tid / 64, lane = tid % 64;
   for (int i = tid; i < (kBlock / 64) * kBins; i += kBlock) (&s_pos[0][0])[i] = 0;
@@ -325,6 +332,19 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     ok[s] = i < n;
     key[s] = keys_in[min(i, n - 1)];
     val[s] = IMPLICIT_VALS ? i : vals_in[min(i, n - 1)];
+  }
+  // EMIT 2: what the value points at, requested now (a gather per key inside the ordered walk below would be a round
+  // trip per step)
+  int e_id[EMIT == 2 ? kItems : 1];
+  float2 e_pix[EMIT == 2 ? kItems : 1];
+  if constexpr (EMIT == 2) {
+#pragma unroll
+    for (int s = 0; s < kItems; ++s) {
+      const int e = val[s];
+      e_id[s] = x.plan.rec_id[e];
+      const float4 q1 = x.plan.e_q1[e];
+      e_pix[s] = make_float2(q1.z, q1.w);
+    }
   }
 #pragma unroll
   for (int s = 0; s < kItems; ++s) {
@@ -356,8 +376,14 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
       const int rank = __popcll(same & ((1ull << lane) - 1ull));
       const int pos = s_pos[wave][digit] + rank;
       keys_out[pos] = key[s];
-      vals_out[pos] = val[s];
-      if constexpr (EMIT) ranks_feat[pos] = (val[s] / DHW) * HW + val[s] % HW;
+      if constexpr (EMIT != 2) vals_out[pos] = val[s];
+      if constexpr (EMIT == 1) x.ranks_feat[pos] = (val[s] / x.DHW) * x.HW + val[s] % x.HW;
+      if constexpr (EMIT == 2) {
+        x.plan.s_e[pos] = (unsigned)val[s];
+        x.plan.s_id[pos] = (unsigned)e_id[s];
+        x.plan.s_key[pos] = (key[s] & x.plan.depth_mask) + x.plan.key_base;
+        x.plan.s_pix[pos] = e_pix[s];
+      }
       if (rank == 0) s_pos[wave][digit] = pos + __popcll(same);      // leader advances the digit
     }
     __builtin_amdgcn_wave_barrier();
@@ -631,7 +657,8 @@ size_t radix_sort_ids_bytes(int n) {
 }
 
 hipError_t radix_sort_ids(unsigned* keys, int n, int key_bits, void* scratch, size_t scratch_bytes,
-                          const unsigned** sorted_keys, const int** sorted_ids, hipStream_t stream) {
+                          const unsigned** sorted_keys, const int** sorted_ids, hipStream_t stream,
+                          const RadixPlanEmit* plan_emit) {
   if (n <= 0 || key_bits <= 0 || key_bits > 32 || !keys || !scratch) return hipErrorInvalidValue;
   SortWs w;
   sort_layout(n, &w);
@@ -652,18 +679,25 @@ hipError_t radix_sort_ids(unsigned* keys, int n, int key_bits, void* scratch, si
     launch(OCRF_K_RADIX_HIST, radix_hist_kernel, dim3(n_wg), dim3(kBlock), 0, stream,
            static_cast<const unsigned*>(kbuf[cur]), n, shift, n_wg, table);
     scan_exclusive_lookback(table, (long)kBins * n_wg, (int*)nullptr, state + pass * st_words, stream);
+    ScatterExtra x{};
+    const bool emit = plan_emit != nullptr && pass == passes - 1 && pass > 0;
+    if (emit) x.plan = *plan_emit;
     if (pass == 0)
       launch(OCRF_K_RADIX_SCATTER, radix_scatter_kernel<true>, dim3(n_wg), dim3(kBlock), 0, stream,
              static_cast<const unsigned*>(kbuf[cur]), static_cast<const int*>(nullptr), n, shift, n_wg,
-             static_cast<const int*>(table), kbuf[cur ^ 1], vbuf[cur ^ 1], static_cast<int*>(nullptr), 1, 1);
+             static_cast<const int*>(table), kbuf[cur ^ 1], vbuf[cur ^ 1], x);
+    else if (emit)        // the consumer's arrays instead of the values (the sorted keys are still written)
+      launch(OCRF_K_RADIX_SCATTER, radix_scatter_kernel<false, 2>, dim3(n_wg), dim3(kBlock), 0, stream,
+             static_cast<const unsigned*>(kbuf[cur]), static_cast<const int*>(vbuf[cur]), n, shift, n_wg,
+             static_cast<const int*>(table), kbuf[cur ^ 1], vbuf[cur ^ 1], x);
     else
       launch(OCRF_K_RADIX_SCATTER, radix_scatter_kernel<false>, dim3(n_wg), dim3(kBlock), 0, stream,
              static_cast<const unsigned*>(kbuf[cur]), static_cast<const int*>(vbuf[cur]), n, shift, n_wg,
-             static_cast<const int*>(table), kbuf[cur ^ 1], vbuf[cur ^ 1], static_cast<int*>(nullptr), 1, 1);
+             static_cast<const int*>(table), kbuf[cur ^ 1], vbuf[cur ^ 1], x);
     cur ^= 1;
   }
   *sorted_keys = kbuf[cur];
-  *sorted_ids = vbuf[cur];
+  *sorted_ids = (plan_emit != nullptr && passes > 1) ? nullptr : vbuf[cur];      // (not written with an emit)
   return hipGetLastError();
 }
 
@@ -747,14 +781,16 @@ int ocrf_lss_prepare(int B, int N, int D, int H, int W, const float* frustum, co
       ocrf::launch(OCRF_K_RADIX_HIST, radix_hist_kernel, dim3(n_wg), dim3(kBlock), 0, stream,
                    static_cast<const unsigned*>(keys[cur]), n_pts, shift, n_wg, table);
     scan_exclusive_lookback(table, (long)kBins * n_wg, (int*)nullptr, state + pass * st_words, stream);
+    ScatterExtra sx{};
+    sx.ranks_feat = ranks_feat; sx.DHW = DHW; sx.HW = HW;
 #define OCRF_LSS_SCATTER(IMPL, EMIT, KOUT, VOUT)                                                                        \
   ocrf::launch(OCRF_K_RADIX_SCATTER, radix_scatter_kernel<IMPL, EMIT>, dim3(n_wg), dim3(kBlock), 0, stream,             \
                static_cast<const unsigned*>(keys[cur]), static_cast<const int*>(IMPL ? nullptr : vals[cur]), n_pts,     \
-               shift, n_wg, static_cast<const int*>(table), KOUT, VOUT, ranks_feat, DHW, HW)
-    if (pass == 0 && last) OCRF_LSS_SCATTER(true, true, rb_keys, ranks_depth);
-    else if (pass == 0) OCRF_LSS_SCATTER(true, false, keys[cur ^ 1], vals[cur ^ 1]);
-    else if (last) OCRF_LSS_SCATTER(false, true, rb_keys, ranks_depth);
-    else OCRF_LSS_SCATTER(false, false, keys[cur ^ 1], vals[cur ^ 1]);
+               shift, n_wg, static_cast<const int*>(table), KOUT, VOUT, sx)
+    if (pass == 0 && last) OCRF_LSS_SCATTER(true, 1, rb_keys, ranks_depth);
+    else if (pass == 0) OCRF_LSS_SCATTER(true, 0, keys[cur ^ 1], vals[cur ^ 1]);
+    else if (last) OCRF_LSS_SCATTER(false, 1, rb_keys, ranks_depth);
+    else OCRF_LSS_SCATTER(false, 0, keys[cur ^ 1], vals[cur ^ 1]);
 #undef OCRF_LSS_SCATTER
     cur ^= 1;
   }

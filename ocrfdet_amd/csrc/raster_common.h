@@ -185,8 +185,12 @@ int* raster_chain_hist(void* workspace, int P, int n_views, size_t* n_words);
 // keys).  `keys` is clobbered; the sorted keys / ids are returned through the two pointers (they point into
 // `scratch`, >= radix_sort_ids_bytes(n) bytes, or at `keys`).
 size_t radix_sort_ids_bytes(int n);
+// `plan_emit` (radix_emit.h): the last pass writes the render plan's per-view list arrays itself; *sorted_ids is then
+// null (the values are not written).
+struct RadixPlanEmit;
 hipError_t radix_sort_ids(unsigned* keys, int n, int key_bits, void* scratch, size_t scratch_bytes,
-                          const unsigned** sorted_keys, const int** sorted_ids, hipStream_t stream);
+                          const unsigned** sorted_keys, const int** sorted_ids, hipStream_t stream,
+                          const RadixPlanEmit* plan_emit = nullptr);
 // the state blocks of that call's look-back scans (bit 63 of a block's first word: the scan gave up)
 void radix_sort_states(void* scratch, int n, int key_bits, const unsigned long long** states, int* n_states,
                        long* stride_words);

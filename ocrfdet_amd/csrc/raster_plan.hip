@@ -32,6 +32,7 @@
 #include "launch.h"
 #include "ocrf_hip.h"
 #include "raster_blend_math.h"
+#include "radix_emit.h"
 #include "raster_common.h"
 
 namespace {
@@ -236,6 +237,8 @@ __global__ __launch_bounds__(kBlock) void plan_gather_kernel(int P, int V, int H
     }
     for (int i = threadIdx.x; i < V * 36; i += kBlock) cams_out[i] = cameras[i];
   }
+  // (the per-view list arrays — s_e, s_id, s_key, s_pix — are written by the sort's last pass: ocrf::RadixPlanEmit)
+  if (sorted_e == nullptr) return;
   const long n = total < cap ? total : cap;
   for (long pos = (long)blockIdx.x * kBlock + threadIdx.x; pos < n; pos += (long)gridDim.x * kBlock) {
     const int e = sorted_e[pos];
@@ -1246,13 +1249,21 @@ int ocrf_raster_plan_build(int P, int n_views, int H, int W, const float* means3
                      static_cast<const int*>(counts), e_q0, e_q1, keys, rec_id, counts + 33);
   const unsigned* sk = nullptr;
   const int* se = nullptr;
-  e = ocrf::radix_sort_ids(keys, (int)capacity, 32, wb + B.sort, B.scan - B.sort, &sk, &se, stream);
+  // the sort's last pass writes the per-view lists itself (one launch over the capacity and 46 us less than a gather
+  // that read the sorted pairs back)
+  ocrf::RadixPlanEmit emit;
+  emit.rec_id = rec_id; emit.e_q1 = e_q1;
+  emit.s_e = reinterpret_cast<unsigned*>(pb + L.s_e); emit.s_id = reinterpret_cast<unsigned*>(pb + L.s_id);
+  emit.s_key = reinterpret_cast<unsigned*>(pb + L.s_key); emit.s_pix = reinterpret_cast<float2*>(pb + L.s_pix);
+  emit.depth_mask = kKeyDepthMask; emit.key_base = kKeyBase;
+  e = ocrf::radix_sort_ids(keys, (int)capacity, 32, wb + B.sort, B.scan - B.sort, &sk, &se, stream, &emit);
   if (e != hipSuccess) return (int)e;
   const unsigned long long* sort_states = nullptr;
   int n_states = 0;
   long stride = 0;
   ocrf::radix_sort_states(wb + B.sort, (int)capacity, 32, &sort_states, &n_states, &stride);
-  const unsigned ggrid = (unsigned)std::min<long>((capacity + kBlock - 1) / kBlock, 4096);
+  // header, view offsets, cameras (one workgroup); with se == nullptr the lists are already in place
+  const unsigned ggrid = se ? (unsigned)std::min<long>((capacity + kBlock - 1) / kBlock, 4096) : 1u;
   hipLaunchKernelGGL(plan_gather_kernel, dim3(ggrid), dim3(kBlock), 0, stream, P, n_views, H, W, gx, gy, extent_bound_,
                      capacity, static_cast<const int*>(counts), cameras, sk, se, static_cast<const int*>(rec_id),
                      static_cast<const float4*>(e_q1), sort_states, n_states, stride,
