@@ -664,26 +664,33 @@ class OcRFViewTransformerFull(nn.Module):
             rows.append(geo.cam_rows[(bs, c)])
         packed = torch.cat(rows, 0)
         sel = torch.tensor(list(cam_idx_list), dtype=torch.int32)
+        n = len(cam_idx_list)
         if out is None:
-            return dict(cam_sel=sel.to(device), packed=packed.to(device), cam_idx_list=list(cam_idx_list))
+            # ONE device buffer behind both tensors (the B x 36 rows, then B int32 words): a refresh is one copy
+            buf = torch.empty(n * 37, dtype=torch.float32, device=device)
+            host = torch.empty(n * 37, dtype=torch.float32)
+            host[:36 * n].copy_(packed.reshape(-1))
+            host[36 * n:].view(torch.int32).copy_(sel)
+            buf.copy_(host)
+            return dict(cam_sel=buf[36 * n:].view(torch.int32), packed=buf[:36 * n].view(n, 36),
+                        cam_idx_list=list(cam_idx_list), _buf=buf)
         # static device tensors of a captured graph: refresh through PINNED host slots (an asynchronous
         # copy out of a pageable temporary may still be reading it after the temporary is gone), each
         # slot guarded by an event so that it is not rewritten while its copy is in flight
         ring = out.setdefault('_ring', [])
         if not ring:
             for _ in range(4):
-                ring.append([torch.empty_like(sel).pin_memory(), torch.empty_like(packed).pin_memory(), None])
+                ring.append([torch.empty(n * 37, dtype=torch.float32).pin_memory(), None])
             out['_slot'] = 0
         slot = ring[out['_slot']]
         out['_slot'] = (out['_slot'] + 1) % len(ring)
-        if slot[2] is not None:
-            slot[2].synchronize()
-        slot[0].copy_(sel)
-        slot[1].copy_(packed)
-        out['cam_sel'].copy_(slot[0], non_blocking=True)
-        out['packed'].copy_(slot[1], non_blocking=True)
-        slot[2] = torch.cuda.Event()
-        slot[2].record(torch.cuda.current_stream(device))
+        if slot[1] is not None:
+            slot[1].synchronize()
+        slot[0][:36 * n].copy_(packed.reshape(-1))
+        slot[0][36 * n:].view(torch.int32).copy_(sel)
+        out['_buf'].copy_(slot[0], non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream(device))
         out['cam_idx_list'] = list(cam_idx_list)
         return out
 
