@@ -651,6 +651,12 @@ int ocrf_nerf_render_params_len(void);
  */
 int ocrf_dual_feat_fusion(const float *x1, const float *x2, const float *params, const float *global_vec,
                           float *out, int B, int C, int M, int YX, ocrf_stream_t stream);
+/* ... and, in the same pass, out_plus = addend + out (addend, out_plus (B,C,YX)): the fused map with the positional
+ * encoding ProbNet's first convolution reads it with (view_transformer_ocrf.py:1188) — one more store per element
+ * instead of an elementwise launch over the map. */
+int ocrf_dual_feat_fusion_plus(const float *x1, const float *x2, const float *params, const float *global_vec,
+                               float *out, const float *addend, float *out_plus, int B, int C, int M, int YX,
+                               ocrf_stream_t stream);
 
 /*
  * CBAM / ProbNet tail (view_transformer_ocrf.py:68-137 ChannelAttention, SpatialAttention, ResCBAMBlock;
@@ -671,6 +677,10 @@ int ocrf_dual_feat_fusion(const float *x1, const float *x2, const float *params,
  */
 int ocrf_plane_bias_act_stats(float *y, const float *bias, int B, int C, int YX, int relu, int write, int S,
                               int out_C, int c_off, float *psum, float *pmax, ocrf_stream_t stream);
+/* the statistics of TWO tensors y1 (B,C1,YX), y2 (B,C2,YX) as if concatenated along the channels, in ONE launch:
+ * psum / pmax (B, C1 + C2, S) (MS_CAM's global branch pools cat(x1, x2) :50-58; 16-byte aligned inputs) */
+int ocrf_plane_stats_pair(const float *y1, const float *y2, int B, int C1, int C2, int YX, int S, float *psum,
+                          float *pmax, ocrf_stream_t stream);
 int ocrf_channel_mlp(const float *psum, const float *pmax, int B, int K, int S, float inv_n, const float *W1,
                      const float *b1, const float *W2, const float *b2, int M, int N, int use_max, int do_sigmoid,
                      float *out, ocrf_stream_t stream);

@@ -205,6 +205,10 @@ def _declare(L):
     L.ocrf_nerf_render_params_len.argtypes = []
     L.ocrf_dual_feat_fusion.restype = c_int
     L.ocrf_dual_feat_fusion.argtypes = [c_void_p] * 5 + [c_int] * 4 + [c_void_p]
+    L.ocrf_dual_feat_fusion_plus.restype = c_int
+    L.ocrf_dual_feat_fusion_plus.argtypes = [c_void_p] * 7 + [c_int] * 4 + [c_void_p]
+    L.ocrf_plane_stats_pair.restype = c_int
+    L.ocrf_plane_stats_pair.argtypes = [c_void_p] * 2 + [c_int] * 5 + [c_void_p] * 3
     L.ocrf_plane_bias_act_stats.restype = c_int
     L.ocrf_plane_bias_act_stats.argtypes = [c_void_p] * 2 + [c_int] * 8 + [c_void_p] * 3
     L.ocrf_channel_mlp.restype = c_int

@@ -502,7 +502,8 @@ __global__ __launch_bounds__(256) void neck_nerf_render_kernel(
 template <int C, int M>
 __global__ __launch_bounds__(256) void neck_dual_fusion_kernel(
     const float* __restrict__ x1, const float* __restrict__ x2, const float* __restrict__ prm,
-    const float* __restrict__ gvec, float* __restrict__ out, int YX) {
+    const float* __restrict__ gvec, float* __restrict__ out, int YX, const float* __restrict__ addend,
+    float* __restrict__ out_plus) {
   // workgroup = 64 pixels x 4 waves; wave g owns hidden units [g*M/4, (g+1)*M/4) in the first layer
   // and output channels [g*C/4, (g+1)*C/4) in the second, the hidden vector crosses through LDS.
   // (One wave per 64 pixels left ~1 wave per SIMD, each streaming all 38 KB of weights through the
@@ -550,12 +551,17 @@ __global__ __launch_bounds__(256) void neck_dual_fusion_kernel(
 #pragma unroll
   for (int m = 0; m < M / 2; ++m) hh[m] = f32x2{s_h[2 * m][lane], s_h[2 * m + 1][lane]};
   float* po = out + (size_t)b * C * YX + qc;
+  // out_plus = out + addend (the positional encoding ProbNet's first convolution reads the fused map with,
+  // view_transformer_ocrf.py:1188: one more store here instead of an elementwise launch over the map)
+  const float* pa = addend ? addend + (size_t)b * C * YX + qc : nullptr;
+  float* pp = out_plus ? out_plus + (size_t)b * C * YX + qc : nullptr;
   for (int c0 = grp * CQ; c0 < (grp + 1) * CQ; c0 += kAhead / 2) {
-    float va[kAhead / 2], vb[kAhead / 2];
+    float va[kAhead / 2], vb[kAhead / 2], vc[kAhead / 2];
 #pragma unroll
     for (int j = 0; j < kAhead / 2; ++j) {
       va[j] = p1[(size_t)(c0 + j) * YX];
       vb[j] = p2[(size_t)(c0 + j) * YX];
+      vc[j] = pa ? pa[(size_t)(c0 + j) * YX] : 0.0f;
     }
 #pragma unroll
     for (int j = 0; j < kAhead / 2; ++j) {
@@ -567,6 +573,7 @@ __global__ __launch_bounds__(256) void neck_dual_fusion_kernel(
       const float cf = sigmoidf(acc.x + acc.y);
       const float o = cf * va[j] + (1.0f - cf) * vb[j];
       if (live) po[(size_t)c * YX] = o;
+      if (live && pp) pp[(size_t)c * YX] = vc[j] + o;
     }
   }
 }
@@ -580,16 +587,20 @@ __global__ __launch_bounds__(256) void neck_dual_fusion_kernel(
 // One pass over every (b, c) plane: y += bias[c] (BatchNorm folded by the caller), optional ReLU,
 // written back in place (WRITE), and / or partial sum + max of the result per plane chunk (STATS):
 // grid (S, B*C); partials land at [(b * out_C + c_off + c) * S + chunk].
+// `y2` (statistics only): the channels [C1, C) of the pass are the planes of a SECOND tensor (B, C - C1, plane) — the pooled
+// vector of cat(x1, x2) in one launch without the cat (ocrf_plane_stats_pair); y2 == null: C1 = C.
 template <bool WRITE, bool RELU, bool STATS>
 __global__ __launch_bounds__(256) void neck_plane_pass_kernel(float* __restrict__ y, const float* __restrict__ bias,
                                                               int C, long plane, int S, int out_C, int c_off,
-                                                              float* __restrict__ psum, float* __restrict__ pmax) {
+                                                              float* __restrict__ psum, float* __restrict__ pmax,
+                                                              float* __restrict__ y2, int C1) {
   __shared__ float s_sum[4], s_max[4];
   const long bc = blockIdx.y;
   const int b = (int)(bc / C), c = (int)(bc % C);
   const long chunk = (((plane + S - 1) / S) + 3) & ~3L;
   const long lo = (long)blockIdx.x * chunk, hi = min(lo + chunk, plane);
-  float* p = y + bc * plane;
+  float* p = (y2 != nullptr && c >= C1) ? y2 + ((long)b * (C - C1) + (c - C1)) * plane
+                                        : y + ((long)b * C1 + c) * plane;
   const float bv = bias ? bias[c] : 0.f;
   float sum = 0.f, mx = -INFINITY;
   if ((plane & 3) == 0) {
@@ -878,19 +889,32 @@ int ocrf_nerf_render(const float* z, const int* cam_sel, const float* alpha, con
   return last_error();
 }
 
-int ocrf_dual_feat_fusion(const float* x1, const float* x2, const float* params, const float* global_vec, float* out,
-                          int B, int C, int M, int YX, ocrf_stream_t stream) {
-  if (B <= 0 || YX <= 0 || !x1 || !x2 || !params || !global_vec || !out) return (int)hipErrorInvalidValue;
+static int dual_feat_fusion(const float* x1, const float* x2, const float* params, const float* global_vec, float* out,
+                            int B, int C, int M, int YX, const float* addend, float* out_plus, ocrf_stream_t stream) {
+  if (B <= 0 || YX <= 0 || !x1 || !x2 || !params || !global_vec || !out || ((addend == nullptr) != (out_plus == nullptr)))
+    return (int)hipErrorInvalidValue;
   if (reinterpret_cast<uintptr_t>(params) & 7) return (int)hipErrorInvalidValue;
   if (C == 80 && M == 40)        // the reference's numC_Trans = 80 (configs/ocrfdet/ocrfdet.py:41)
     ocrf::launch(OCRF_K_NECK_FUSION, neck_dual_fusion_kernel<80, 40>, dim3((YX + 63) / 64, B), dim3(256), 0,
-                 (hipStream_t)stream, x1, x2, params, global_vec, out, YX);
+                 (hipStream_t)stream, x1, x2, params, global_vec, out, YX, addend, out_plus);
   else if (C == 64 && M == 32)   // LSSViewTransformer's default out_channels
     ocrf::launch(OCRF_K_NECK_FUSION, neck_dual_fusion_kernel<64, 32>, dim3((YX + 63) / 64, B), dim3(256), 0,
-                 (hipStream_t)stream, x1, x2, params, global_vec, out, YX);
+                 (hipStream_t)stream, x1, x2, params, global_vec, out, YX, addend, out_plus);
   else
     return (int)hipErrorInvalidValue;
   return last_error();
+}
+
+int ocrf_dual_feat_fusion(const float* x1, const float* x2, const float* params, const float* global_vec, float* out,
+                          int B, int C, int M, int YX, ocrf_stream_t stream) {
+  return dual_feat_fusion(x1, x2, params, global_vec, out, B, C, M, YX, nullptr, nullptr, stream);
+}
+
+// ... and out_plus = addend + out in the same pass (addend, out_plus (B, C, YX)): the fused map and the map ProbNet reads
+int ocrf_dual_feat_fusion_plus(const float* x1, const float* x2, const float* params, const float* global_vec, float* out,
+                               const float* addend, float* out_plus, int B, int C, int M, int YX, ocrf_stream_t stream) {
+  if (!addend || !out_plus) return (int)hipErrorInvalidValue;
+  return dual_feat_fusion(x1, x2, params, global_vec, out, B, C, M, YX, addend, out_plus, stream);
 }
 
 int ocrf_plane_bias_act_stats(float* y, const float* bias, int B, int C, int YX, int relu, int write, int S,
@@ -905,7 +929,7 @@ int ocrf_plane_bias_act_stats(float* y, const float* bias, int B, int C, int YX,
   const long plane = YX;
 #define OCRF_PLANE_PASS(W, R, T)                                                                                  \
   ocrf::launch(OCRF_K_NECK_PLANE_PASS, neck_plane_pass_kernel<W, R, T>, grid, block, 0, st, y, bias, C, plane, S, \
-               out_C, c_off, psum, pmax)
+               out_C, c_off, psum, pmax, static_cast<float*>(nullptr), C)
   if (write && relu && stats) OCRF_PLANE_PASS(true, true, true);
   else if (write && relu) OCRF_PLANE_PASS(true, true, false);
   else if (write && stats) OCRF_PLANE_PASS(true, false, true);
@@ -913,6 +937,21 @@ int ocrf_plane_bias_act_stats(float* y, const float* bias, int B, int C, int YX,
   else if (relu) OCRF_PLANE_PASS(false, true, true);
   else OCRF_PLANE_PASS(false, false, true);
 #undef OCRF_PLANE_PASS
+  return last_error();
+}
+
+// Partial sums / maxima of every plane of TWO tensors y1 (B, C1, YX), y2 (B, C2, YX) as if they were concatenated along the
+// channels: psum / pmax (B, C1 + C2, S).  One launch (MS_CAM's global branch pools cat(x1, x2): view_transformer_ocrf.py:50-58).
+int ocrf_plane_stats_pair(const float* y1, const float* y2, int B, int C1, int C2, int YX, int S, float* psum, float* pmax,
+                          ocrf_stream_t stream) {
+  if (!y1 || !y2 || !psum || !pmax || B <= 0 || C1 <= 0 || C2 <= 0 || YX <= 0 || S <= 0 || S > 65535 ||
+      (long)B * (C1 + C2) > 65535)
+    return (int)hipErrorInvalidValue;
+  if ((reinterpret_cast<uintptr_t>(y1) | reinterpret_cast<uintptr_t>(y2)) & 15) return (int)hipErrorInvalidValue;
+  const int C = C1 + C2;
+  ocrf::launch(OCRF_K_NECK_PLANE_PASS, neck_plane_pass_kernel<false, false, true>, dim3(S, (unsigned)(B * C)), dim3(256), 0,
+               (hipStream_t)stream, const_cast<float*>(y1), static_cast<const float*>(nullptr), C, (long)YX, S, C, 0, psum,
+               pmax, const_cast<float*>(y2), C1);
   return last_error();
 }
 

@@ -235,9 +235,10 @@ def pack_fusion_params(ms_cam):
         return torch.cat((w1.t().reshape(-1), b1, w2.reshape(-1), b2)).float().contiguous()
 
 
-def dual_feat_fusion(x1, x2, params, global_vec, hidden):
+def dual_feat_fusion(x1, x2, params, global_vec, hidden, addend=None):
     """``DualFeatFusion.forward`` (view_transformer_ocrf.py:203-213), eval mode, in one pass.
-    x1, x2 (B,C,Y,X); ``global_vec`` (B,C) = MS_CAM's global branch; -> (B,C,Y,X)."""
+    x1, x2 (B,C,Y,X); ``global_vec`` (B,C) = MS_CAM's global branch; -> (B,C,Y,X).  With ``addend`` (B,C,Y,X):
+    -> (out, addend + out), both written by the same pass."""
     _lib.require_cuda(x1, x2, params, global_vec)
     B, C, Y, X = x1.shape
     x1, x2, gv = _f32c(x1), _f32c(x2), _f32c(global_vec).reshape(B, C)
@@ -245,6 +246,15 @@ def dual_feat_fusion(x1, x2, params, global_vec, hidden):
         raise ValueError('dual_feat_fusion: parameter block does not match (C, hidden)')
     out = torch.empty_like(x1)
     with _lib.on_device(x1.device):
+        if addend is not None:
+            if tuple(addend.shape) != tuple(x1.shape):
+                raise ValueError('dual_feat_fusion: addend must have the shape of the inputs')
+            add, plus = _f32c(addend), torch.empty_like(x1)
+            _lib.check(_lib.lib().ocrf_dual_feat_fusion_plus(_lib.ptr(x1), _lib.ptr(x2), _lib.ptr(params), _lib.ptr(gv),
+                                                             _lib.ptr(out), _lib.ptr(add), _lib.ptr(plus), B, C, hidden,
+                                                             Y * X, _lib.stream_ptr(x1.device)),
+                       'ocrf_dual_feat_fusion_plus')
+            return out, plus
         _lib.check(_lib.lib().ocrf_dual_feat_fusion(_lib.ptr(x1), _lib.ptr(x2), _lib.ptr(params), _lib.ptr(gv),
                                                     _lib.ptr(out), B, C, hidden, Y * X, _lib.stream_ptr(x1.device)),
                    'ocrf_dual_feat_fusion')
@@ -331,8 +341,9 @@ def global_att_vector(x1, x2, packed):
     x1, x2 = _f32c(x1), _f32c(x2)
     psum = torch.empty(B, 2 * C, _SPLITS, device=x1.device)
     pmax = torch.empty_like(psum)
-    plane_bias_act_stats(x1, write=False, stats=(psum, pmax), c_off=0)
-    plane_bias_act_stats(x2, write=False, stats=(psum, pmax), c_off=C)
+    with _lib.on_device(x1.device):          # both inputs in ONE launch (no cat: the kernel reads the second tensor itself)
+        _lib.check(_lib.lib().ocrf_plane_stats_pair(_lib.ptr(x1), _lib.ptr(x2), B, C, C, Y * X, _SPLITS, _lib.ptr(psum),
+                                                    _lib.ptr(pmax), _lib.stream_ptr(x1.device)), 'ocrf_plane_stats_pair')
     w1, b1, w2, b2 = packed
     return channel_mlp(psum, None, 1.0 / (Y * X), w1, b1, w2, b2, use_max=False, sigmoid=False)
 

@@ -220,7 +220,8 @@ class DualFeatFusion(nn.Module):
         return (x1.is_cuda and not self.training and not torch.is_grad_enabled() and la[0].in_channels == 2 * c
                 and (c, m) in ((80, 40), (64, 32)))
 
-    def forward(self, x1, x2):
+    def forward(self, x1, x2, addend=None):
+        """``addend`` (eval mode on the GPU only): also return ``addend + out``, written by the same pass."""
         if self._fusable(x1):
             ca = self.ca
             ts = _tensors_of(self, 'fuser', (ca.local_att, ca.global_att))
@@ -230,9 +231,10 @@ class DualFeatFusion(nn.Module):
                 self.__dict__['_pack_key'] = key
             local, glob = self.__dict__['_pack']
             g = neck_ops.global_att_vector(x1, x2, glob)
-            return neck_ops.dual_feat_fusion(x1, x2, local, g, ca.local_att[0].out_channels)
+            return neck_ops.dual_feat_fusion(x1, x2, local, g, ca.local_att[0].out_channels, addend=addend)
         cf = self.ca(torch.cat((x1, x2), 1))
-        return cf * x1 + (1 - cf) * x2
+        out = cf * x1 + (1 - cf) * x2
+        return out if addend is None else (out, addend + out)
 
 
 class BEVGeomAttention(nn.Module):
@@ -926,9 +928,10 @@ class OcRFViewTransformerFull(nn.Module):
             mark(3)
 
         def c():
-            channel_feat = self.fuser(T['lss_feat'], T['ht_feat'])
+            # the fused map and the map ProbNet reads (fused map + positional encoding) leave the fusion kernel together
+            channel_feat, with_pos = self.fuser(T['lss_feat'], T['ht_feat'], addend=self._pos('positional_encoding', B, x))
             mark(4)
-            T['bev_mask_logit'] = self.prob(self._pos('positional_encoding', B, x) + channel_feat)
+            T['bev_mask_logit'] = self.prob(with_pos)
             mark(5)
             T['geom_feat'] = self.geom_att.gate(channel_feat, T['bev_mask_logit'])
             mark(6)
