@@ -88,6 +88,12 @@ def parse():
     ap.add_argument('--blend-workgroups', default='auto',
                     help="planned renders beside the main stream: workgroups of the persistent blend that stay while the main "
                          "chain runs ('auto' = 3.5 per CU; DESIGN.md section 5)")
+    ap.add_argument('--gaussians', choices=('init', 'stress', 'objects'), default='init',
+                    help='synthetic Gaussian parameter set of the headline step (synthetic.grid_gaussians): init = the '
+                         'reference heads at seeded init (every pixel saturates early: the best case), stress = SURVEY 8d\'s '
+                         'second set, objects = object-centric opacity with new parameters every step.  Whatever the headline '
+                         'uses, the default line carries all three under gaussian_sets')
+    ap.add_argument('--no-gaussian-sets', action='store_true', help='skip the gaussian_sets leg of the default line')
     ap.add_argument('--index-prep', choices=('cached', 'per_step'), default='cached',
                     help="'per_step': rank vectors recomputed by the HIP index preparation inside every step "
                          "(the reference with accelerate=False); 'cached': once per calibration (accelerate=True)")
@@ -337,6 +343,89 @@ def bench_neck(args, cfg, dev, world, rank):
             pass
 
 
+def gaussian_set_figures(cfg, dev, kind, depth, feat, steps=20, blocks=5, hp_kw=None):
+    """The planned step on Gaussian set ``kind`` with NEW parameters every step (two parameter sets per frame taken in
+    turn: the blend's adaptive head always works from what the OTHER set needed) -> dict: ms_per_step (median block),
+    blend_us (HIP events on the blend's stream inside those steps), and from the instrumented build of the same kernel
+    (one launch after the timed region, parameters of phase 0 behind a phase-1 step): list entries scanned / records staged /
+    wave-records evaluated per tile pair, p50 / p99 / max of the entries a tile pair scanned (its reach into the view's
+    list), the per-view heads the blend left behind, executed pixel.records."""
+    import numpy as np
+    from ocrfdet_amd import _lib, hotpath
+    hp = hotpath.HotPath(cfg, dev, gaussians=kind, alternate=True, **(hp_kw or {}))
+    k = [0]
+
+    def step():
+        hp.set_phase(k[0] & 1)
+        k[0] += 1
+        return hp.step(depth, feat)
+    for _ in range(8):
+        step()
+    torch.cuda.synchronize()
+    tb = _lib.KernelTimer(_lib.K_RASTER_BLEND_SORTED, 2 * steps + 8)
+    tb.arm()
+    ts = [timed(step, steps, 1, dev)]
+    _lib.KernelTimer.disarm_all()
+    blend_ms = tb.mean_ms()
+    tb.close()
+    for _ in range(blocks - 1):
+        ts.append(timed(step, steps, 1, dev))
+    hp.check_render_plans()
+    out = {'ms_per_step': 1e3 * sorted(ts)[len(ts) // 2] / steps, 'blend_us': 1e3 * blend_ms if blend_ms else None,
+           'one_call': bool(hp._compiled), 'parameters': 'two sets per frame, alternating every step'}
+    # the same kernel alone (no other stream beside it)
+    was = hp.overlap
+    hp.overlap = False
+    ib = _lib.KernelTimer(_lib.K_RASTER_BLEND_SORTED, 64)
+    ib.arm()
+    for _ in range(12):
+        step()
+    torch.cuda.synchronize()
+    _lib.KernelTimer.disarm_all()
+    out['blend_alone_us'] = 1e3 * ib.mean_ms() if ib.mean_ms() else None
+    ib.close()
+    hp.overlap = was
+    H, W = cfg.input_size
+    tiles = ((W + 15) // 16) * ((((H + 15) // 16) + 1) // 2)
+    scanned, staged, evald, heads, phases = [], [], 0.0, [], []
+    hp.set_phase(1)
+    hp.step(depth, feat)
+    hp.set_phase(0)
+    for entry in hp._plans():
+        plan = entry[0]
+        n_wg = tiles * entry[2] * len(hp.cams)
+        buf = torch.zeros(n_wg * 4 * 8, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        _lib.lib().ocrf_diag_plan_stats(_lib.ptr(buf))
+        try:
+            hp._render_planned(entry)
+            torch.cuda.synchronize()
+        finally:
+            _lib.lib().ocrf_diag_plan_stats(None)
+        st = buf.view(n_wg, 4, 8).cpu().numpy().astype(np.float64)
+        scanned.append(st[:, 0, 3])
+        staged.append(st[:, 0, 4])
+        phases.append(st[:, :, :3].reshape(-1, 3))
+        evald += float(st[:, :, 6].sum())
+        ctl = plan._dyn[plan._dyn.numel() - 512:].view(torch.int32).cpu().numpy()      # control words (raster_plan.hip kCtl*)
+        heads += [int(v) for v in ctl[32:32 + plan.V]]
+    hp.check_render_plans()
+    sc, sg = np.concatenate(scanned), np.concatenate(staged)
+    n_launch = len(hp._plans())
+    out.update({'scanned_per_tile_pair': float(sc.mean()), 'staged_per_tile_pair': float(sg.mean()),
+                'evaluated_wave_records_per_tile_pair': evald / len(sc),
+                'reach_p50': float(np.percentile(sc, 50)), 'reach_p99': float(np.percentile(sc, 99)), 'reach_max': float(sc.max()),
+                'head': heads, 'list_entries_per_view': [int(v) for e in hp._plans() for v in (e[0].kept or [])],
+                'executed_pixel_records_per_launch': evald * 128.0 / n_launch})
+    ph = np.concatenate(phases)
+    out['tile_pair_us'] = float(ph.sum(1).mean()) / 100.0            # (s_memrealtime: 100 MHz)
+    out['phase_shares_scan_stage_blend'] = [round(float(x), 3) for x in ph.mean(0) / ph.mean(0).sum()]
+    if out['blend_alone_us']:
+        out['blend_alone_ns_per_kilo_pixel_record'] = 1e6 * out['blend_alone_us'] / out['executed_pixel_records_per_launch']
+    del hp
+    return out
+
+
 def source_hash():
     """sha256 over the library's sources (csrc/*.hip, *.h): the counters of a profile belong to ONE build."""
     import glob
@@ -581,10 +670,16 @@ def main():
         # whole-sample instance: the N = 1 step, the 'samples' / 'frames' layouts, and every layout's kernel figures
         hp = hotpath.HotPath(cfg, dev, index_prep_mode=args.index_prep, overlap=not args.no_overlap,
                              blend_workgroups='auto' if args.blend_workgroups == 'auto' else int(args.blend_workgroups),
-                             lss_pool_backend=None if args.lss_pool == 'auto' else args.lss_pool, **rkw)
+                             lss_pool_backend=None if args.lss_pool == 'auto' else args.lss_pool,
+                             gaussians=args.gaussians, **rkw)
     depth, feat = hp.make_inputs(seed=0 if shard in ('cameras', 'camera_frames') else rank)
 
+    step_k = [0]
+
     def step_whole():
+        if hp.alternate:                       # new Gaussian parameters every step (--gaussians objects)
+            hp.set_phase(step_k[0] & 1)
+            step_k[0] += 1
         out = hp.step(depth, feat)
         if shard == 'frames':
             fused = torch.cat((out[0], out[-2] if cfg.hoa else out[1]), 1)       # (frames, Z*C + C, Y, X)
@@ -730,6 +825,16 @@ def main():
             per_sample['plan_rebuilt_per_step'] = r_pl
             del h_pl, plans4
         per_sample['per_sample_ms'] = min(x for r in list(per_sample.values()) for x in (r['eager_ms'], r.get('graph_ms')) if x)
+    # ---- the render on Gaussian sets that are NOT its best case: SURVEY 8d's stress set and an
+    # object-centric one, parameters new every step ---------------------------------------------------------------
+    gaussian_sets = None
+    if shard == 'none' and planned and not args.no_gaussian_sets and not args.no_per_step:
+        gaussian_sets = {}
+        for kind in ('init', 'stress', 'objects'):
+            try:
+                gaussian_sets[kind] = gaussian_set_figures(cfg, dev, kind, depth, feat, steps=max(5, min(args.steps, 50)))
+            except Exception as e:       # noqa: BLE001
+                gaussian_sets[kind] = {'error': f'{type(e).__name__}: {e}'[:300]}
     # ---- weak-scaling secondary of the sharded default: every rank a whole sample ---------------------------
     samples_layout = None
     if shard == 'camera_frames':
@@ -1055,7 +1160,7 @@ def main():
                                          else 'single stream')),
                        'ht_pool': getattr(hp, 'ht_pool_backend', None), 'lss_pool': getattr(hp, 'lss_pool_backend', None),
                        'issue': ('one host call per step (ocrf_hotpath_step: the step\'s library calls recorded once, replayed '
-                                 'from C)' if getattr(hp, '_compiled', None) is not None else 'call by call from Python'),
+                                 'from C)' if getattr(hp, '_compiled', None) else 'call by call from Python'),
                        'index_prep': 'cached (accelerate=True semantics); per_step_ms = the same step with the HIP index '
                                      'preparation inside (accelerate=False semantics, the reference\'s working mode), calibration '
                                      'algebra on the host as the reference\'s own torch calls (rank vectors bit-exact); '
@@ -1066,6 +1171,9 @@ def main():
         }
         if cfg.render:
             out['pools'] = pools
+        if gaussian_sets is not None:
+            out['gaussian_sets'] = gaussian_sets
+        out['config']['gaussians'] = getattr(hp, 'gaussians', None)
         if samples_layout is not None:
             out['samples_layout'] = samples_layout
         if pipelined_layout is not None:

@@ -296,7 +296,30 @@ int ocrf_rasterize_planned(const void *plan, size_t plan_bytes, int P, int n_pla
                            float *out_depth, float *out_final_T, int *radii, int *status, void *workspace,
                            size_t workspace_bytes, int guard, const float *means3D, void *chain_workspace,
                            size_t chain_workspace_bytes, int blend_workgroups, const int *yield_if, int phase,
-                           const float *call_cameras, int views_disjoint, ocrf_stream_t stream);
+                           const float *call_cameras, int views_disjoint, const void *bins, size_t bins_bytes,
+                           int bin_w, int bin_h, long cand_capacity, ocrf_stream_t stream);
+/*
+ * Candidate lists of a built plan — the static part of what the reference builds per call as its per-tile lists
+ * (cuda_rasterizer/rasterizer_impl.cu:70-138 duplicateWithKeys + identifyTileRanges, consumed forward.cu:261-374): per
+ * (plan view, bin of bin_w x bin_h tile PAIRS, i.e. bin_w x 2 bin_h tiles of 16 x 16 px) the positions, ascending (= blend
+ * order), of the view's records whose tile rect for ANY parameters within the plan's extent bound reaches the bin.  With
+ * them (bins != NULL in ocrf_rasterize_planned; bin_w / bin_h / cand_capacity as given to the build) a tile pair tests the
+ * rects of its bin's candidates instead of the view's whole list: its cost is O(own records).  Same images bit for bit.
+ *   ocrf_raster_plan_bins_build: `plan` built on this stream before; no host read, kernels only.  cand_capacity = 0 is a
+ *   sizing pass (only *total_out, a device int, is written); lists that do not fit the capacity leave `bins` unusable — it
+ *   is then ignored by renders (whole lists are walked), never wrong.  workspace >=
+ *   ocrf_raster_plan_bins_workspace_bytes(...), bins >= ocrf_raster_plan_bins_bytes(...).
+ * A planned render runs in two passes of the blend: the first renders every tile pair as far as the PREPARED head of its
+ * view's list reaches (the head follows what the last call needed, up to the whole list) and hands the tile pairs that
+ * need more to the second; between them the records behind the heads are prepared ONCE (inside the extent-check launch),
+ * only if a tile pair asked.  A tile pair never prepares records itself.
+ */
+size_t ocrf_raster_plan_bins_bytes(int n_views, int H, int W, int bin_w, int bin_h, long cand_capacity);
+size_t ocrf_raster_plan_bins_workspace_bytes(int P, int n_views, int H, int W, int bin_w, int bin_h, long capacity);
+int ocrf_raster_plan_bins_build(const void *plan, size_t plan_bytes, int P, int n_views, long capacity, int H, int W,
+                                float extent_bound, int bin_w, int bin_h, long cand_capacity, void *bins,
+                                size_t bins_bytes, int *total_out, void *workspace, size_t workspace_bytes,
+                                ocrf_stream_t stream);
 
 /*
  * bev_pool_v2 forward as per-tile MFMA panels (csrc/bev_pool_mfma.hip): out[64 voxels x C] = W[64 x R] . F[R x C]
@@ -715,7 +738,8 @@ enum {
   OCRF_K_RASTER_BLEND_BWD = 15,  /* raster_blend_kernel<false, true> */
   OCRF_K_RASTER_PRE_BWD = 16,    /* raster_preprocess_backward_kernel */
   OCRF_K_RASTER_PLAN_UPDATE = 17,  /* raster_plan_update_kernel */
-  OCRF_K_RASTER_BLEND_SORTED = 18, /* raster_blend_sorted_kernel<*> */
+  OCRF_K_RASTER_BLEND_SORTED = 18, /* raster_blend_sorted_kernel<*>, first pass */
+  OCRF_K_RASTER_BLEND_SECOND = 19, /* raster_blend_sorted_kernel<*>, second pass (tile pairs handed over by the first) */
   OCRF_K_HOA_STATS = 20,         /* hoa_channel_stats_kernel */
   OCRF_K_HOA_MASK_GATE = 21,     /* hoa_mask_gate_kernel */
   OCRF_K_HOA_HEIGHT_MAX = 22,    /* hoa_height_max_kernel */

@@ -130,7 +130,15 @@ def _declare(L):
     L.ocrf_rasterize_planned.restype = c_int
     L.ocrf_rasterize_planned.argtypes = ([c_void_p, c_size_t, c_int, c_int, c_long] + [c_int] * 4 + [c_void_p] * 4 +
                                          [c_float] + [c_void_p] * 2 + [c_int] + [c_void_p] * 6 + [c_size_t, c_int] +
-                                         [c_void_p] * 2 + [c_size_t, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p])
+                                         [c_void_p] * 2 + [c_size_t, c_int, c_void_p, c_int, c_void_p, c_int] +
+                                         [c_void_p, c_size_t, c_int, c_int, c_long, c_void_p])
+    L.ocrf_raster_plan_bins_bytes.restype = c_size_t
+    L.ocrf_raster_plan_bins_bytes.argtypes = [c_int] * 5 + [c_long]
+    L.ocrf_raster_plan_bins_workspace_bytes.restype = c_size_t
+    L.ocrf_raster_plan_bins_workspace_bytes.argtypes = [c_int] * 6 + [c_long]
+    L.ocrf_raster_plan_bins_build.restype = c_int
+    L.ocrf_raster_plan_bins_build.argtypes = ([c_void_p, c_size_t, c_int, c_int, c_long, c_int, c_int, c_float, c_int, c_int,
+                                               c_long, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p])
     L.ocrf_stream_write_value32.restype = c_int
     L.ocrf_stream_write_value32.argtypes = [c_void_p, c_int, c_void_p]
     L.ocrf_lss_prepare.restype = c_int
@@ -507,6 +515,7 @@ class Workspace:
     def __init__(self):
         self._bufs = {}
         self._users = {}                       # key -> raw hipStream_t values that asked for the tag
+        self._generation = {}                  # device index -> number of buffers REPLACED so far
 
     def get(self, device, nbytes, tag="default"):
         idx = device.index if device.index is not None else torch.cuda.current_device()
@@ -519,6 +528,9 @@ class Workspace:
             users.add(_raw_stream(idx))
         if buf is None or buf.numel() < nbytes:
             if buf is not None:
+                # whoever baked the old buffer's address into a recorded step (HotPath._compiled, ShardedHotPath._segments)
+                # sees the generation move and records anew instead of replaying into freed memory
+                self._generation[idx] = self._generation.get(idx, 0) + 1
                 for raw in self._users.get(key, ()):
                     if raw:                    # 0 = the legacy default stream, the allocator's own
                         buf.record_stream(torch.cuda.ExternalStream(raw, device=buf.device))
@@ -526,6 +538,12 @@ class Workspace:
             buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
             self._bufs[key] = buf
         return buf
+
+    def generation(self, device):
+        """Number of scratch buffers of ``device`` replaced so far: a recorded step (raw pointers baked in) is valid
+        while this has not moved since it was recorded."""
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        return self._generation.get(idx, 0)
 
     def hold(self, device):
         """Strong references to every scratch buffer of ``device`` as of now (see the class docstring)."""
@@ -540,7 +558,7 @@ K_BEV_POOL_FWD, K_BEV_POOL_FIXUP, K_BEV_POOL_INTERVAL, K_BEV_POOL_GRAD, K_BEV_PO
 K_BEV_POOL_MFMA, K_BEV_POOL_PANEL, K_BEV_POOL_CELL_WEIGHTS = 6, 7, 8
 K_RASTER_PREPROCESS, K_RASTER_BLEND, K_RASTER_GATHER = 10, 11, 12
 K_RASTER_SCAN, K_RASTER_BLEND_BWD, K_RASTER_PRE_BWD = 13, 15, 16
-K_RASTER_PLAN_UPDATE, K_RASTER_BLEND_SORTED = 17, 18
+K_RASTER_PLAN_UPDATE, K_RASTER_BLEND_SORTED, K_RASTER_BLEND_SECOND = 17, 18, 19
 K_LSS_KEYS, K_RADIX_HIST, K_SCAN, K_RADIX_SCATTER, K_LSS_BOUNDS, K_LSS_EMIT, K_HT_COUNT, K_HT_EMIT = range(40, 48)
 K_HOA_STATS, K_HOA_MASK_GATE, K_HOA_HEIGHT_MAX, K_HOA_HEIGHT_GATE = 20, 21, 22, 23
 K_HOA_UNET_BLOCK, K_HOA_OUT_CONV, K_HOA1_ATTN, K_HOA1_KV = 24, 25, 26, 29

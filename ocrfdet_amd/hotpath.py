@@ -60,7 +60,8 @@ class HotPath:
     def __init__(self, cfg, device, cams=None, index_prep_mode='cached', overlap=True, device_geometry=False,
                  render_mode='planned', render_guard='host', frame_motion=True, frame_offset=0, plan_margin=1.25,
                  ht_pool_backend=None, fuse_frames='auto', render_streams=1, blend_workgroups='auto',
-                 lss_pool_backend=None, lss_mfma_group=2, plan_rebuild='never', hoa_first=None, one_call=True):
+                 lss_pool_backend=None, lss_mfma_group=2, plan_rebuild='never', hoa_first=None, one_call=True,
+                 gaussians='init', alternate=None):
         """``cams``: optional list of camera indices this instance owns (camera sharding).
         ``index_prep_mode``: 'cached' — rank vectors computed once per calibration, the reference's
         ``accelerate=True`` intent; 'per_step' — recomputed inside every ``step()`` by the HIP index
@@ -80,6 +81,10 @@ class HotPath:
         out of the step's way and the blend on 2.75 workgroups per CU — also beside the blend (cfg2 step 0.200 vs 0.208 /
         0.212 ms with tile LSS / mfma HT, tools/sweep_r5_step.py).
         ``hoa_first``: HOA-1/2 before the poolings (None: with the per-call render or the per-step index preparation).
+        ``gaussians``: the synthetic Gaussian parameter set (``synthetic.grid_gaussians``): 'init' | 'stress' | 'objects'.
+        ``alternate``: draw TWO parameter sets per frame and let the caller switch between them from step to step
+        (``set_phase``; default: only for 'objects') — new parameters every step, as a network's heads produce them: the
+        planned render's adaptive head then always works from the OTHER set's reach.
         ``one_call``: after its first, recorded, issue a step is ONE host call (``ocrf_hotpath_step``: the library calls
         of the step replayed from C, ``_lib.StepRecorder``) instead of ~14 ctypes calls + torch stream / event calls
         (225 -> ~60 us of host work at cfg2).  The step's outputs are then the SAME tensors every step (overwritten by
@@ -89,6 +94,11 @@ class HotPath:
         assert render_mode in ('planned', 'per_call') and render_guard in ('host', 'device')
         assert plan_rebuild in ('never', 'per_step')
         self.plan_rebuild = plan_rebuild
+        assert gaussians in synthetic.GAUSSIAN_SETS
+        self.gaussians = gaussians
+        self.plan_bins = (4, 2)                # candidate lists of the render plans: bins of 4 x 2 tile pairs (64 x 64 px)
+        self.alternate = (gaussians == 'objects') if alternate is None else bool(alternate)
+        self.phase = 0
         self.render_mode, self.render_guard, self.plan_margin = render_mode, render_guard, float(plan_margin)
         self.frame_motion, self.frame_offset = bool(frame_motion), int(frame_offset)
         # 'mfma': the HT pooling (cached ranks) as per-tile MFMA panels (csrc/bev_pool_mfma.hip: 26 vs 32 us at cfg2);
@@ -105,9 +115,9 @@ class HotPath:
         self.lss_pool_backend, self.lss_mfma_group = lss_pool_backend, int(lss_mfma_group)
         self.hoa_first = hoa_first
         self.one_call = bool(one_call) and self.device.type == 'cuda'
-        self._compiled = None                  # (key, _lib.CompiledStep, outputs, memory pool) of the recorded step
+        self._compiled = {}                    # key -> (_lib.CompiledStep, outputs, memory pool, scratch hold) of a recorded step
         self._one_call_ok = True
-        self._warm_key = None
+        self._warm_keys = set()
         # planned renders: consecutive frames in one plan / one launch pair.  'auto': when ALL frames fit one plan
         # (<= 32 views; cfg2: 0.300 -> 0.285 ms — one update -> blend hand-over and one drain of the persistent grid
         # less); with more frames a launch pair per frame is faster (cfg4: 3.08 vs 3.18 ms in groups of five)
@@ -205,8 +215,9 @@ class HotPath:
         # every frame has its own opacity volume; the reference loops samples (:1090).  The (B*P, 1)
         # layout A_MLP hands over (:1130) is an INPUT of this stage: laid out once, not per step
         if self._opac_flat is None:
-            self._opac_flat = torch.stack([fg['opacity'].view(cfg.num_height, Y, X) for fg in self.frame_gauss]) \
-                .reshape(-1, 1).contiguous()
+            self._opac_flats = [torch.stack([fg['opacity'].view(cfg.num_height, Y, X) for fg in fgs]).reshape(-1, 1).contiguous()
+                                for fgs in self.frame_gauss_sets]
+            self._opac_flat = self._opac_flats[self.phase]
         oa = hoa.hoa1(m['dca'], self._opac_flat, self.alpha_lidar, cfg.num_height, Y, X)
         return m['v2b'](oa, self.bev_pos1)
 
@@ -227,7 +238,9 @@ class HotPath:
         input and a proper world->view transform (the headline of SURVEY.md 8d)."""
         cfg, dev = self.cfg, self.device
         H, W = cfg.input_size
-        self.frame_cams, self.frame_gauss = [], []
+        self.frame_cams = []
+        n_sets = 2 if self.alternate else 1
+        self.frame_gauss_sets = [[] for _ in range(n_sets)]      # [phase][frame] -> parameter dict
         P = self.voxel_xyz.shape[1] * self.voxel_xyz.shape[2]
         t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
         for b in range(self.batch):
@@ -253,12 +266,12 @@ class HotPath:
             self.frame_cams.append(rc)
             # Gaussian parameters of frame (frame_offset + b): ranges of the reference's heads at seeded init
             # (SURVEY.md 8d probe); with frame_motion every frame draws its own
-            rng = np.random.default_rng(seed + (self.frame_offset + b if self.frame_motion else 0))
-            q = rng.standard_normal((P, 4)).astype(np.float32)
-            q /= np.linalg.norm(q, axis=1, keepdims=True)
-            self.frame_gauss.append(dict(scales=t(rng.uniform(0.69, 0.84, (P, 3)).astype(np.float32)), rotations=t(q),
-                                         opacity=t(rng.uniform(0.35, 0.45, (P, 1)).astype(np.float32)),
-                                         rgb=t(rng.uniform(0.0, 1.0, (P, 3)).astype(np.float32))))
+            xyz_np = self.voxel_xyz[b].reshape(-1, 3).cpu().numpy()
+            for ph in range(n_sets):
+                gs = synthetic.grid_gaussians(self.gaussians, xyz_np,
+                                              seed + (self.frame_offset + b if self.frame_motion else 0) + 1000 * ph)
+                self.frame_gauss_sets[ph].append({k: t(v) for k, v in gs.items()})
+        self.frame_gauss = self.frame_gauss_sets[0]
         self.render_cams, self.gauss = self.frame_cams[0], self.frame_gauss[0]       # frame 0 (tests, tools)
         self.bg = torch.zeros(3, device=dev)
         self.render_convention = convention
@@ -282,16 +295,25 @@ class HotPath:
             for f0 in range(0, self.batch, per):
                 fr = list(range(f0, min(f0 + per, self.batch)))
                 cams = torch.cat([self.frame_cams[b]['packed'] for b in fr])
-                g = {k: torch.stack([self.frame_gauss[b][k] for b in fr]).contiguous() for k in ('rgb', 'opacity', 'scales', 'rotations')}
+                alts = [{k: torch.stack([fgs[b][k] for b in fr]).contiguous() for k in ('rgb', 'opacity', 'scales', 'rotations')}
+                        for fgs in self.frame_gauss_sets]
+                g = alts[0]
+                # (the extent bound has to hold for every parameter set the plan will render)
+                ext_sc = torch.cat([a['scales'].reshape(-1, 3) for a in alts])
+                ext_rot = torch.cat([a['rotations'].reshape(-1, 4) for a in alts])
                 # record capacity: what these cameras keep + 10 % — + 25 % when the plan is rebuilt per step for poses that
                 # may keep more (a plan beyond its capacity is refused on the device: status bit 8, zero images; read
                 # check_render_plans() before the images are consumed, or render with render_guard='device')
-                plan = raster_plan.RasterPlan(self.voxel_xyz[f0].reshape(-1, 3), cams, H, W, scales=g['scales'],
-                                              rotations=g['rotations'], margin=self.plan_margin,
-                                              headroom=1.25 if self.plan_rebuild == 'per_step' else 1.1)
+                plan = raster_plan.RasterPlan(self.voxel_xyz[f0].reshape(-1, 3), cams, H, W, scales=ext_sc,
+                                              rotations=ext_rot, margin=self.plan_margin,
+                                              headroom=1.25 if self.plan_rebuild == 'per_step' else 1.1,
+                                              # a plan rebuilt per SAMPLE does not build candidate lists every step
+                                              bins=None if self.plan_rebuild == 'per_step' else self.plan_bins)
                 # item z = view z of the plan (frame-major), rendered with the parameter set of its frame
-                g['item_view'] = torch.arange(len(fr) * n_cam, dtype=torch.int32, device=self.device)
-                g['cams'] = plan.cameras                 # the sample's camera block: a per-step rebuild reads it in place
+                for a in alts:
+                    a['item_view'] = torch.arange(len(fr) * n_cam, dtype=torch.int32, device=self.device) if a is g else g['item_view']
+                    a['cams'] = plan.cameras             # the sample's camera block: a per-step rebuild reads it in place
+                g['alt'] = alts                          # [phase] -> parameter dict (alts[0] is g)
                 self.render_plans.append((plan, f0, len(fr), g))
         return self.render_plans
 
@@ -323,6 +345,7 @@ class HotPath:
 
     def _render_planned(self, entry, phase='both', out=None):
         plan, f0, nf, g = entry
+        g = g['alt'][self.phase]
         bw = self.blend_workgroups
         # the "other chain still running" word: this path's own (several blends per step), or the one an owner that
         # renders this path on ITS side stream hands in (ShardedHotPath)
@@ -398,11 +421,31 @@ class HotPath:
         if getattr(self, '_sets', None) is None:
             self._sets = False
             if self.batch * len(self.cams) <= 64:
-                g = {k: torch.stack([fg[k] for fg in self.frame_gauss]).contiguous() for k in ('rgb', 'opacity', 'scales', 'rotations')}
-                g['xyz'] = torch.stack([self.voxel_xyz[b].reshape(-1, 3) for b in range(self.batch)]).contiguous()
-                g['cams'] = torch.cat([rc['packed'] for rc in self.frame_cams]).contiguous()
-                self._sets = g
+                self._sets_by_phase = []
+                for fgs in self.frame_gauss_sets:
+                    g = {k: torch.stack([fg[k] for fg in fgs]).contiguous() for k in ('rgb', 'opacity', 'scales', 'rotations')}
+                    if self._sets_by_phase:
+                        g['xyz'], g['cams'] = self._sets_by_phase[0]['xyz'], self._sets_by_phase[0]['cams']
+                    else:
+                        g['xyz'] = torch.stack([self.voxel_xyz[b].reshape(-1, 3) for b in range(self.batch)]).contiguous()
+                        g['cams'] = torch.cat([rc['packed'] for rc in self.frame_cams]).contiguous()
+                    self._sets_by_phase.append(g)
+                self._sets = self._sets_by_phase[self.phase]
         return self._sets or None
+
+    def set_phase(self, phase):
+        """Switch to parameter set ``phase`` of every frame (``alternate``): the next step renders (and HOA reads) the
+        other tensors — new parameters, as a network's heads hand them over every step.  A recorded step is per phase."""
+        phase = int(phase) % len(self.frame_gauss_sets)
+        if phase == self.phase:
+            return
+        self.phase = phase
+        self.frame_gauss = self.frame_gauss_sets[phase]
+        self.gauss = self.frame_gauss[0]
+        if getattr(self, '_opac_flat', None) is not None:
+            self._opac_flat = self._opac_flats[phase]
+        if getattr(self, '_sets', None):
+            self._sets = self._sets_by_phase[phase]
 
     @property
     def views_per_step(self):
@@ -530,20 +573,36 @@ class HotPath:
         if not (self.one_call and self._one_call_ok) or torch.cuda.is_current_stream_capturing():
             return self._step_eager(depth, feat)
         cur = torch.cuda.current_stream(self.device)
-        key = (depth.data_ptr(), feat.data_ptr(), self.index_prep_mode, self.plan_rebuild, self.overlap, self.blend_workgroups
-               if isinstance(self.blend_workgroups, (int, str)) else tuple(self.blend_workgroups))
-        if self._compiled is None or self._compiled[0] != key:
-            if self._warm_key != key:
+        key = self._step_key(depth, feat)
+        hit = self._compiled.get(key)
+        if hit is not None and hit[3] != _lib.workspace.generation(self.device):
+            # a scratch buffer the recording baked in was replaced since (a larger request for its tag, by anyone in the
+            # process): its pointers are stale — record anew
+            del self._compiled[key]
+            hit = None
+        if hit is None:
+            if key not in self._warm_keys:
                 # the first step of a (tensors, mode) builds plans and scratch (launches that belong to no later step):
                 # issued call by call, the next one is recorded
-                self._warm_key = key
+                if len(self._warm_keys) >= 16:
+                    self._warm_keys.clear()
+                self._warm_keys.add(key)
                 return self._step_eager(depth, feat)
             return self._record_step(depth, feat, key, cur)
-        _, compiled, out, _pool = self._compiled
+        compiled, out, _pool, _gen = hit
         compiled.run(*[st.cuda_stream for st in self._step_streams(cur)])
         for entry in (self.render_plans or []) if self.cfg.render and self.render_mode == 'planned' else []:
             entry[0]._host_guarded = entry[0]._host_guarded or self.render_guard == 'host'
         return out
+
+    def _step_key(self, depth, feat):
+        """Everything ``_step_eager`` reads that decides WHICH launches a step is (a recorded step must not
+        outlive a changed mode attribute): the input tensors (address, shape, dtype), the parameter phase and the modes."""
+        bw = self.blend_workgroups
+        return (depth.data_ptr(), feat.data_ptr(), tuple(depth.shape), tuple(feat.shape), depth.dtype, feat.dtype, self.phase,
+                self.index_prep_mode, self.plan_rebuild, self.overlap, bw if isinstance(bw, (int, str)) else tuple(bw),
+                self.render_mode, self.render_guard, self.hoa_first, self.lss_pool_backend, self.ht_pool_backend,
+                self.render_streams, self.fuse_frames, self.device_geometry)
 
     def _forks(self):
         return self.overlap and self.cfg.render
@@ -582,7 +641,9 @@ class HotPath:
             self._one_call_ok = False
             self.one_call_refused = rec.why or 'per-step calibration algebra on the host is issued call by call'
             return out
-        self._compiled = (key, rec.build(), out, pool)
+        while len(self._compiled) >= 4:                    # (two phases x two input pairs, with room)
+            self._compiled.pop(next(iter(self._compiled)))
+        self._compiled[key] = (rec.build(), out, pool, _lib.workspace.generation(self.device))
         return out
 
     def _step_eager(self, depth, feat, rec=None):
@@ -799,8 +860,11 @@ class ShardedHotPath:
 
     # ---- HOA, sharded by frame ----------------------------------------------------------------------------------
     @torch.no_grad()
-    def _hoa12(self):
-        """HOA-1/2 of the frames this rank has a part in -> {frame: (Y,X) opacity BEV} (empty on an idle rank)."""
+    def _hoa12(self, slot=0):
+        """HOA-1/2 of the frames this rank has a part in -> {frame: (Y,X) opacity BEV} (empty on an idle rank).
+        ``slot``: which output buffer set a REPLAYED segment writes — the pipelined step alternates two, because step k's
+        HOA-3 gate reads these tensors on the communication stream while step k + 1's replay would already rewrite them on
+        the caller's (a write-after-read race that constant test inputs hid)."""
         self.hoa_launch_frames = 0
         if self.base is None or not self.my_frames:
             return {}
@@ -812,7 +876,7 @@ class ShardedHotPath:
         def body(rec):
             return m['v2b'](hoa.hoa1(m['dca'], opac, alpha, cfg.num_height, Y, X), pos)      # (len(my_frames), 1, Y, X)
         if self.device.type == 'cuda':
-            ob = self._segment('hoa12', (opac.data_ptr(), alpha.data_ptr(), pos.data_ptr()),
+            ob = self._segment('hoa12', (opac.data_ptr(), alpha.data_ptr(), pos.data_ptr(), int(slot)),
                                [torch.cuda.current_stream(self.device)], body)
         else:
             ob = body(None)
@@ -864,6 +928,9 @@ class ShardedHotPath:
         if not self.one_call or torch.cuda.is_current_stream_capturing():
             return fn(None)
         hit = self._segments.get((name, key))
+        if hit is not None and hit[3] != _lib.workspace.generation(self.device):
+            del self._segments[(name, key)]          # a scratch buffer it baked in was replaced: record anew
+            hit = None
         if hit is not None:
             hit[0].run(*[st.cuda_stream for st in streams])
             return hit[1]
@@ -880,9 +947,9 @@ class ShardedHotPath:
         if not rec.ok:
             self.one_call, self.one_call_refused = False, rec.why
             return out
-        while len(self._segments) >= 12:                    # (three segments x two buffer sets, with room)
+        while len(self._segments) >= 16:                    # (four segments x two buffer sets, with room)
             self._segments.pop(next(iter(self._segments)))
-        self._segments[(name, key)] = (rec.build(), out, pool)
+        self._segments[(name, key)] = (rec.build(), out, pool, _lib.workspace.generation(self.device))
         return out
 
     def _pool_and_render(self, inputs, target_of):
@@ -955,7 +1022,8 @@ class ShardedHotPath:
             self._held = None
         pipe = self.pipe
         cur, rendered = self._pool_and_render(inputs, pipe.pool_target)
-        ob = self._hoa12()
+        self._pipe_k = getattr(self, '_pipe_k', 0) + 1
+        ob = self._hoa12(slot=self._pipe_k % 2)
         if pipe._comm is not None:
             for t in ob.values():
                 t.record_stream(pipe._comm)

@@ -39,10 +39,16 @@ class RasterPlan:
     The build itself (``rebuild``) never reads anything back: ~ 20 launches, hipGraph-capturable — the reference
     recomputes the render cameras from the dataloader's ``c2w`` for EVERY sample
     (``view_transformer_ocrf.py:1140-1152``), so a plan per sample is a supported mode, not only a plan per
-    calibration."""
+    calibration.
+    ``bins``: ``(bin_w, bin_h)`` — candidate lists per bin of ``bin_w`` x ``bin_h`` tile PAIRS (default 4 x 2 = 64 x 64 px):
+    the static part of the reference's per-tile lists (``rasterizer_impl.cu:70-138``), so that a tile pair tests the rects
+    of its own candidates instead of the view's whole list; ``None``: no lists (every ``rebuild`` is then shorter — what a
+    plan rebuilt per SAMPLE wants).  ``cand_capacity``: candidates the lists hold; None = one more synchronising count,
+    times ``headroom``.  Lists that do not fit after a ``rebuild`` are ignored by the renders (slower, never wrong)."""
 
     def __init__(self, means3D, packed_cameras, image_height, image_width, extent_bound=None, scales=None,
-                 rotations=None, scale_modifier=1.0, margin=2.0, capacity=None, headroom=1.25):
+                 rotations=None, scale_modifier=1.0, margin=2.0, capacity=None, headroom=1.25, bins=(4, 2),
+                 cand_capacity=None):
         _lib.require_cuda(means3D, packed_cameras)
         if means3D.dim() != 2 or means3D.size(1) != 3:
             raise RuntimeError('means3D must have dimensions (num_points, 3)')
@@ -76,7 +82,29 @@ class RasterPlan:
         self._dyn = None                       # per-call scratch, owned by the plan (one stream at a time)
         self._chain_ws = None
         self._host_guarded = False             # a render with guard='host' happened since the last check()
+        self.bins = None if bins is None else (int(bins[0]), int(bins[1]))
+        self._bins_buf = self._bins_ws = None
+        self.cand_capacity = 0
         self.rebuild()
+        if self.bins is not None:
+            bw, bh = self.bins
+            with _lib.on_device(dev):
+                need = int(L.ocrf_raster_plan_bins_workspace_bytes(self.P, self.V, self.H, self.W, bw, bh,
+                                                                   ctypes.c_long(self.capacity)))
+                if need == 0:
+                    raise _lib.OcrfHipError(f'RasterPlan: bins {self.bins} do not fit this image (at most 255 bins per axis)')
+                self._bins_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                if cand_capacity is None:
+                    total = torch.zeros(1, dtype=torch.int32, device=dev)
+                    self._build_bins(sizing=total)
+                    self.candidates = int(total.item())           # the second synchronisation
+                    cand_capacity = int(self.candidates * float(headroom)) + 4096
+                self.cand_capacity = max(1, int(cand_capacity))
+                self._bins_buf = torch.zeros(int(L.ocrf_raster_plan_bins_bytes(self.V, self.H, self.W, bw, bh,
+                                                                               ctypes.c_long(self.cand_capacity))),
+                                             dtype=torch.uint8, device=dev)
+            self._build_bins()
+            self._record_built()
 
     def count(self, packed_cameras=None):
         """Synchronising: kept (Gaussian, view) records per view for ``packed_cameras`` (default: the plan's)."""
@@ -94,6 +122,25 @@ class RasterPlan:
         kept = [int(v) for v in per_view]
         assert sum(kept) == int(total.item())
         return kept
+
+    def _build_bins(self, sizing=None):
+        L = _lib.lib()
+        bw, bh = self.bins
+        with _lib.on_device(self.device):
+            _lib.check(L.ocrf_raster_plan_bins_build(
+                _lib.ptr(self.plan), ctypes.c_size_t(self.plan.numel()), self.P, self.V, ctypes.c_long(self.capacity),
+                self.H, self.W, ctypes.c_float(self.extent_bound), bw, bh,
+                ctypes.c_long(0 if sizing is not None else self.cand_capacity),
+                _lib.ptr(None if sizing is not None else self._bins_buf),
+                ctypes.c_size_t(0 if sizing is not None else self._bins_buf.numel()), _lib.ptr(sizing),
+                _lib.ptr(self._bins_ws), ctypes.c_size_t(self._bins_ws.numel()), _lib.stream_ptr(self.device)),
+                'ocrf_raster_plan_bins_build')
+
+    def _record_built(self):
+        # renders issued on ANOTHER stream must not overtake the build (a half-built plan holds wild record indices)
+        self._built = (torch.cuda.Event(), torch.cuda.current_stream(self.device))
+        self._built[0].record(self._built[1])
+        self._ordered_after_build = set()        # streams that already waited for this build (one wait per stream is enough)
 
     @torch.no_grad()
     def rebuild(self, packed_cameras=None, means3D=None):
@@ -117,10 +164,9 @@ class RasterPlan:
                 ctypes.c_float(self.extent_bound), ctypes.c_long(self.capacity), _lib.ptr(self._build_ws),
                 ctypes.c_size_t(self._build_ws.numel()), _lib.ptr(self.plan), ctypes.c_size_t(self.plan.numel()),
                 _lib.stream_ptr(self.device)), 'ocrf_raster_plan_build')
-        # renders issued on ANOTHER stream must not overtake the build (a half-built plan holds wild record indices)
-        self._built = (torch.cuda.Event(), torch.cuda.current_stream(self.device))
-        self._built[0].record(self._built[1])
-        self._ordered_after_build = set()        # streams that already waited for this build (one wait per stream is enough)
+        if self._bins_buf is not None:
+            self._build_bins()                   # the candidate lists belong to THESE lists (stale ones would be wrong)
+        self._record_built()
         return self
 
     def _scratch(self, n_sets):
@@ -227,7 +273,10 @@ class RasterPlan:
                 _lib.ptr(self.status), _lib.ptr(dyn), ctypes.c_size_t(dyn.numel()), use_guard,
                 _lib.ptr(self.means3D), _lib.ptr(chain), ctypes.c_size_t(chain.numel() if chain is not None else 0),
                 int(blend_workgroups), _lib.ptr(yield_if), {'both': 0, 'update': 1, 'blend': 2}[phase],
-                _lib.ptr(cameras), int(disjoint), _lib.stream_ptr(dev)),
+                _lib.ptr(cameras), int(disjoint), _lib.ptr(self._bins_buf),
+                ctypes.c_size_t(self._bins_buf.numel() if self._bins_buf is not None else 0),
+                self.bins[0] if self.bins else 0, self.bins[1] if self.bins else 0, ctypes.c_long(self.cand_capacity),
+                _lib.stream_ptr(dev)),
                 'ocrf_rasterize_planned')
         out['status'] = self.status
         return out

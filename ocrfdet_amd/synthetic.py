@@ -148,6 +148,54 @@ def depth_and_feat(cfg, seed=0, device='cpu'):
     return torch.from_numpy(p).to(device), torch.from_numpy(feat).to(device)
 
 
+GAUSSIAN_SETS = ('init', 'stress', 'objects')
+
+
+def grid_gaussians(kind, xyz, seed=0):
+    """Parameters for Gaussians whose means are the fixed voxel grid ``xyz`` (P,3) numpy (the OcRF render's means,
+    view_transformer_ocrf.py:651-673,690-692) -> dict of numpy float32 arrays ``scales`` (P,3), ``rotations`` (P,4),
+    ``opacity`` (P,1), ``rgb`` (P,3).
+
+    ``init``    what the reference's S/R/A/C heads give at seeded init (SURVEY §8d probe): scales U(0.69,0.84) m, opacity
+                U(0.35,0.45) on EVERY voxel — each pixel saturates after ~80 records: the rasteriser's best case.
+    ``stress``  SURVEY §8d's second set on the same means: scales U(0.2,1.0), opacity U(0.05,0.95), random unit quaternions.
+    ``objects`` object-centric, what a trained ``A_MLP`` (sigmoid under a foreground-mask loss, :177-201,1130) gives:
+                ~30 boxes of 4 x 2 x 1.5 m (random place / yaw, standing on the ground) whose voxels carry opacity
+                U(0.6,0.95); every other voxel sigmoid(U(-7,-4)) — half of them under 1/255 (never blended), half faint
+                above it.  Most pixels never saturate, so nothing ends a tile's list early."""
+    assert kind in GAUSSIAN_SETS
+    rng = np.random.default_rng(seed)
+    P = int(xyz.shape[0])
+    q = rng.standard_normal((P, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    if kind == 'init':
+        # (draw order kept from rounds 1-5: the committed figures and tests were made with these values)
+        scales = rng.uniform(0.69, 0.84, (P, 3)).astype(np.float32)
+        opacity = rng.uniform(0.35, 0.45, (P, 1)).astype(np.float32)
+        rgb = rng.uniform(0.0, 1.0, (P, 3)).astype(np.float32)
+    elif kind == 'stress':
+        scales = rng.uniform(0.2, 1.0, (P, 3)).astype(np.float32)
+        opacity = rng.uniform(0.05, 0.95, (P, 1)).astype(np.float32)
+        rgb = rng.uniform(0.0, 1.0, (P, 3)).astype(np.float32)
+    else:
+        scales = rng.uniform(0.69, 0.84, (P, 3)).astype(np.float32)
+        rgb = rng.uniform(0.0, 1.0, (P, 3)).astype(np.float32)
+        logit = rng.uniform(-7.0, -4.0, (P, 1))
+        opacity = (1.0 / (1.0 + np.exp(-logit))).astype(np.float32)
+        lim = float(np.abs(xyz[:, :2]).max()) - 5.0
+        inside = np.zeros(P, dtype=bool)
+        for _ in range(30):
+            c = np.array([rng.uniform(-lim, lim), rng.uniform(-lim, lim), rng.uniform(-1.6, -0.8)])
+            yaw = rng.uniform(0.0, math.pi)
+            d = xyz.astype(np.float64) - c
+            u = d[:, 0] * math.cos(yaw) + d[:, 1] * math.sin(yaw)
+            w = -d[:, 0] * math.sin(yaw) + d[:, 1] * math.cos(yaw)
+            inside |= (np.abs(u) <= 2.0) & (np.abs(w) <= 1.0) & (np.abs(d[:, 2]) <= 0.75)
+        n_in = int(inside.sum())
+        opacity[inside] = rng.uniform(0.6, 0.95, (n_in, 1)).astype(np.float32)
+    return dict(scales=scales, rotations=q, opacity=opacity, rgb=rgb)
+
+
 def stress_gaussians(n, seed=0, extent=40.0, device='cpu'):
     """The 'stress' Gaussian set of SURVEY §8d: scales U(0.2,1.0), opacity U(0.05,0.95), random unit
     quaternions, RGB U(0,1), centres uniform in a +-extent box (z in [-4.5, 2.5])."""

@@ -38,5 +38,5 @@ for kw in variants:
     depth, feat = hp.make_inputs()
     med, mn = timed(hp, depth, feat)
     hp.check_render_plans()
-    print(kw, 'median %.4f ms  min %.4f ms' % (med, mn), 'one call' if hp._compiled is not None else getattr(hp, 'one_call_refused', 'call by call'), flush=True)
+    print(kw, 'median %.4f ms  min %.4f ms' % (med, mn), 'one call' if hp._compiled else getattr(hp, 'one_call_refused', 'call by call'), flush=True)
     del hp
