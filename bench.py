@@ -343,7 +343,7 @@ def bench_neck(args, cfg, dev, world, rank):
             pass
 
 
-def gaussian_set_figures(cfg, dev, kind, depth, feat, steps=20, blocks=5, hp_kw=None):
+def gaussian_set_figures(cfg, dev, kind, depth, feat, steps=20, blocks=5, hp_kw=None, plan_bins='default'):
     """The planned step on Gaussian set ``kind`` with NEW parameters every step (two parameter sets per frame taken in
     turn: the blend's adaptive head always works from what the OTHER set needed) -> dict: ms_per_step (median block),
     blend_us (HIP events on the blend's stream inside those steps), and from the instrumented build of the same kernel
@@ -353,6 +353,8 @@ def gaussian_set_figures(cfg, dev, kind, depth, feat, steps=20, blocks=5, hp_kw=
     import numpy as np
     from ocrfdet_amd import _lib, hotpath
     hp = hotpath.HotPath(cfg, dev, gaussians=kind, alternate=True, **(hp_kw or {}))
+    if plan_bins != 'default':
+        hp.plan_bins = plan_bins
     k = [0]
 
     def step():

@@ -118,7 +118,10 @@ size_t ocrf_bev_pool_planned_workspace_bytes(int c, int n_points);
 int ocrf_bev_pool_v2_nchw_planned(int c, int n_points, const float *depth, const float *feat,
                                   const int *ranks_depth, const int *ranks_feat, void *plan, float *out,
                                   int B, int Z, int Y, int X, int layout, void *workspace,
-                                  size_t workspace_bytes, ocrf_stream_t stream);
+                                  size_t workspace_bytes, size_t depth_bytes, size_t feat_bytes, ocrf_stream_t stream);
+/* depth_bytes / feat_bytes: the sizes of the two operand tensors in bytes (0: not stated).  The kernels address them with
+ * 32-bit byte offsets (the reference indexes with int, bev_pool_cuda.cu:39-47): an operand or an output of 2 GiB or more is
+ * refused (hipErrorInvalidValue), and a stated feat_bytes bounds the kernel's feature loads (a rank beyond it reads 0). */
 
 /* Same, for rank vectors whose lengths were produced on the device (ocrf_lss_prepare /
  * ocrf_ht_prepare): the vectors are passed at their capacities and `counts` (device, int32) holds
@@ -368,7 +371,8 @@ int ocrf_bev_pool_cell_weights(int n_cells0, const int *cells0, const int *rd_so
 int ocrf_bev_pool_v2_nchw_panel(int c, int n_units, const int *units, const int *unit_slab, const int *panel_rows,
                                 const int *panel_nrows, const int *panel_cell_off, const int *panel_voff,
                                 const unsigned short *cell_code, const float *cw, const float *feat, float *out, int B,
-                                int Z, int Y, int X, int layout, int *arrive, void *slabs, ocrf_stream_t stream);
+                                int Z, int Y, int X, int layout, int *arrive, void *slabs, size_t feat_bytes,
+                                ocrf_stream_t stream); /* feat_bytes: as for ocrf_bev_pool_v2_nchw_planned */
 
 /*
  * Backward of the colour output of ocrf_rasterize_forward (the w-depth fork has no depth backward,

@@ -79,7 +79,7 @@ def _declare(L):
     L.ocrf_bev_pool_planned_workspace_bytes.argtypes = [c_int, c_int]
     L.ocrf_bev_pool_v2_nchw_planned.restype = c_int
     L.ocrf_bev_pool_v2_nchw_planned.argtypes = ([c_int] * 2 + [c_void_p] * 6 + [c_int] * 5 +
-                                                [c_void_p, c_size_t, c_void_p])
+                                                [c_void_p, c_size_t, c_size_t, c_size_t, c_void_p])
     L.ocrf_bev_pool_mfma_panel_rows.restype = c_int
     L.ocrf_bev_pool_mfma_panel_rows.argtypes = []
     L.ocrf_diag_pool_mfma_stamps.restype = c_int
@@ -95,7 +95,7 @@ def _declare(L):
     L.ocrf_bev_pool_cell_weights.restype = c_int
     L.ocrf_bev_pool_cell_weights.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     L.ocrf_bev_pool_v2_nchw_panel.restype = c_int
-    L.ocrf_bev_pool_v2_nchw_panel.argtypes = [c_int, c_int] + [c_void_p] * 10 + [c_int] * 5 + [c_void_p] * 3
+    L.ocrf_bev_pool_v2_nchw_panel.argtypes = [c_int, c_int] + [c_void_p] * 10 + [c_int] * 5 + [c_void_p] * 2 + [c_size_t, c_void_p]
     L.ocrf_bev_pool_mfma_max_unit_panels.argtypes = []
     L.ocrf_bev_pool_v2_nchw_mfma.argtypes = [c_int, c_int] + [c_void_p] * 10 + [c_int] * 5 + [c_void_p] * 3
     L.ocrf_tune_set.restype = c_int

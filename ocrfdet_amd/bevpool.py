@@ -311,7 +311,8 @@ def bev_pool_v2_planned(depth, feat, plan, layout=1, out=None):
         _lib.check(L.ocrf_bev_pool_v2_nchw_planned(
             C, plan.n_points, _lib.ptr(d32), _lib.ptr(f32), _lib.ptr(plan.ranks_depth),
             _lib.ptr(plan.ranks_feat), _lib.ptr(plan.plan), _lib.ptr(out), B, Z, Y, X, int(layout), _lib.ptr(scratch),
-            ctypes.c_size_t(scratch.numel()), _lib.stream_ptr(dev)), 'ocrf_bev_pool_v2_nchw_planned')
+            ctypes.c_size_t(scratch.numel()), ctypes.c_size_t(d32.numel() * 4), ctypes.c_size_t(f32.numel() * 4),
+            _lib.stream_ptr(dev)), 'ocrf_bev_pool_v2_nchw_planned')
     return out
 
 
@@ -541,7 +542,8 @@ def bev_pool_v2_panel(depth, feat, plan, layout=1, out=None, weights_ready=False
             C, plan.n_units, _lib.ptr(plan.units), _lib.ptr(plan.unit_slab), _lib.ptr(plan.panel_rows),
             _lib.ptr(plan.panel_nrows), _lib.ptr(plan.panel_cell_off), _lib.ptr(plan.panel_voff), _lib.ptr(plan.cell_code),
             _lib.ptr(plan.cw), _lib.ptr(f32), _lib.ptr(out), B, Z, Y, X, int(layout),
-            _lib.ptr(plan.arrive), _lib.ptr(plan.slabs), _lib.stream_ptr(dev)), 'ocrf_bev_pool_v2_nchw_panel')
+            _lib.ptr(plan.arrive), _lib.ptr(plan.slabs), ctypes.c_size_t(f32.numel() * 4), _lib.stream_ptr(dev)),
+            'ocrf_bev_pool_v2_nchw_panel')
     return out
 
 

@@ -295,6 +295,7 @@ struct TileArgs {
   int* arrive;
   const float* depth;
   const float4* feat4;
+  int feat_records;              // bytes the feature tensor holds (the buffer resource's bound; 0x7fffffff: not stated)
   const int* ranks_depth;
   const int* ranks_feat;
   float* out;
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(kBlock, 5) void bev_pool_tile_kernel(TileArgs a, un
   const int gb = wave * gpw + gi;
   const int n_points = a.counts ? a.counts[0] : a.n_points;
   // whole 4 GB window from the feat base: row offsets are 32-bit byte offsets (the host checks nothing larger is needed)
-  const __amdgpu_buffer_rsrc_t feat_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.feat4), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t feat_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.feat4), 0, a.feat_records, 0x00020000);
   const int lg16 = lg * 16;
   const int row_bytes = c4 * 16;
 
@@ -749,7 +750,7 @@ int launch_prep(int c, int n_intervals, int n_points, const int* counts, const G
 
 int launch_tiles(int c, int n_points, const int* counts, const Geometry& vg, int Z, int layout, const float* depth,
                  const float* feat, const int* ranks_depth, const int* ranks_feat, const void* prep, float* out,
-                 void* slabs, hipStream_t stream, unsigned long long* stamps = nullptr) {
+                 void* slabs, hipStream_t stream, unsigned long long* stamps = nullptr, size_t feat_bytes = 0) {
   const PoolGeom pg = pool_geom(c);
   const PrepLayout L = prep_layout(vg, pg, n_points);
   const char* p = static_cast<const char*>(prep);
@@ -764,6 +765,9 @@ int launch_tiles(int c, int n_points, const int* counts, const Geometry& vg, int
   a.arrive = reinterpret_cast<int*>(const_cast<char*>(p) + L.arrive_off);
   a.depth = depth;
   a.feat4 = reinterpret_cast<const float4*>(feat);
+  // the kernel reads features through a buffer resource (32-bit byte offsets): its bound is the tensor's real size when
+  // the caller states it — a rank beyond it then reads 0 instead of someone else's memory
+  a.feat_records = feat_bytes ? (int)std::min<size_t>(feat_bytes, 0x7fffffffu) : 0x7fffffff;
   a.ranks_depth = ranks_depth;
   a.ranks_feat = ranks_feat;
   a.out = out;
@@ -935,10 +939,14 @@ size_t ocrf_bev_pool_planned_workspace_bytes(int c, int n_points) {
 int ocrf_bev_pool_v2_nchw_planned(int c, int n_points, const float* depth, const float* feat,
                                   const int* ranks_depth, const int* ranks_feat, void* plan, float* out,
                                   int B, int Z, int Y, int X, int layout, void* workspace,
-                                  size_t workspace_bytes, ocrf_stream_t stream_) {
+                                  size_t workspace_bytes, size_t depth_bytes, size_t feat_bytes, ocrf_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (!vec_ok(c) || n_points <= 0 || B <= 0 || Z <= 0 || Y <= 0 || X <= 0 ||
       (layout != 0 && layout != 1) || !out || !plan || !depth || !feat || !ranks_depth || !ranks_feat)
+    return (int)hipErrorInvalidValue;
+  // 32-bit byte offsets into the operands (bev_pool_cuda.cu:39-47 indexes with int): 2 GiB or more is refused HERE, at
+  // the boundary a caller links against, not only in the Python wrapper
+  if (depth_bytes >= (1ull << 31) || feat_bytes >= (1ull << 31) || (size_t)B * Z * Y * X * c * 4 >= (1ull << 31))
     return (int)hipErrorInvalidValue;
   const Geometry vg = make_geometry((long)B * Z, (long)Y * X);
   if (vg.n_vox > 0x3fffffffL) return (int)hipErrorInvalidValue;
@@ -946,7 +954,7 @@ int ocrf_bev_pool_v2_nchw_planned(int c, int n_points, const float* depth, const
       !aligned16(feat) || !aligned16(plan))
     return (int)hipErrorInvalidValue;
   return launch_tiles(c, n_points, nullptr, vg, Z, layout, depth, feat, ranks_depth, ranks_feat, plan, out, workspace,
-                      stream);
+                      stream, nullptr, feat_bytes);
 }
 
 // Diagnostic build of the pooling kernel that accumulates s_memtime per phase and unit into stamps[max_units][8]

@@ -51,6 +51,7 @@ struct PanelArgs {
   const unsigned short* cell_code;   // [n_cells] row slot | voxel slot << 8 (cells of a panel: voxel-major, rows ascending)
   const float* cw;               // [n_cells] summed depth weight of the cell
   const float4* feat4;
+  int feat_records;              // bytes the feature tensor holds: the bound of its buffer resource (0x7fffffff: not stated)
   pool_out::Dest d;
 };
 
@@ -166,7 +167,7 @@ __global__ OCRF_PANEL_BOUNDS(C4) void bev_pool_panel_kernel(PanelArgs a, unsigne
   // become a branch with its own wait.
   // (buffer loads: a 32-bit byte offset per lane instead of a 64-bit address pair per load — the host checks that the
   // tensors stay below 2 GB)
-  const __amdgpu_buffer_rsrc_t feat_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.feat4), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t feat_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.feat4), 0, a.feat_records, 0x00020000);
   const __amdgpu_buffer_rsrc_t cw_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.cw), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t cc_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.cell_code), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t vo_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(a.panel_voff), 0, 0x7fffffff, 0x00020000);
@@ -299,9 +300,11 @@ int ocrf_bev_pool_cell_weights(int n_cells0, const int* cells0, const int* rd_so
 int ocrf_bev_pool_v2_nchw_panel(int c, int n_units, const int* units, const int* unit_slab, const int* panel_rows,
                                 const int* panel_nrows, const int* panel_cell_off, const int* panel_voff,
                                 const unsigned short* cell_code, const float* cw, const float* feat, float* out, int B, int Z,
-                                int Y, int X, int layout, int* arrive, void* slabs, ocrf_stream_t stream_) {
+                                int Y, int X, int layout, int* arrive, void* slabs, size_t feat_bytes, ocrf_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (c != 80 && c != 64 && c != 96 && c != 128) return (int)hipErrorInvalidValue;
+  // 32-bit byte offsets into feat and the output (bev_pool_cuda.cu:39-47 indexes with int): refused at the C boundary
+  if (feat_bytes >= (1ull << 31) || (size_t)B * Z * Y * X * c * 4 >= (1ull << 31)) return (int)hipErrorInvalidValue;
   if (n_units <= 0 || !units || !unit_slab || !panel_rows || !panel_nrows || !panel_cell_off || !panel_voff || !cell_code || !cw ||
       !feat || !out || !arrive || !slabs || B <= 0 || Z <= 0 || Y <= 0 || X <= 0 || layout < 0 || layout > 2)
     return (int)hipErrorInvalidValue;
@@ -313,6 +316,7 @@ int ocrf_bev_pool_v2_nchw_panel(int c, int n_units, const int* units, const int*
   a.panel_rows = panel_rows; a.panel_nrows = panel_nrows; a.panel_cell_off = panel_cell_off; a.panel_voff = panel_voff;
   a.cell_code = cell_code; a.cw = cw;
   a.feat4 = reinterpret_cast<const float4*>(feat);
+  a.feat_records = feat_bytes ? (int)feat_bytes : 0x7fffffff;      // (0: not stated — the reference's ABI has no sizes either)
   a.d.C = c; a.d.Y = Y; a.d.X = X; a.d.Z = Z; a.d.layout = layout;
   a.d.out = out; a.d.slabs = static_cast<float4*>(slabs); a.d.arrive = arrive;
   const dim3 grid((unsigned)n_units), block(kBlock);

@@ -18,8 +18,11 @@
 //   * median depth (T > 0.5 and T' < 0.5 -> this record's depth): the records whose INCOMING T is above 0.5 form a
 //     prefix of a pixel's sequence, and the last of them is the crossing record iff the pixel ends below 0.5.  The loop
 //     only COUNTS them (one packed clamp-FMA + one packed add); the depth is looked up once per batch (median_index).
-//     [A T' of exactly 0.5 is assigned the depth of the record that produced it; the reference's strict compares leave
-//     such a pixel at the default.  Measure zero.]
+//     [A T' of exactly 0.5 is assigned the depth of the record that produced it — wherever the batch boundaries of a
+//     kernel fall: median_index tests T <= 0.5 (round 6: with T < 0.5 a batch that ENDED on the exact tie lost the
+//     crossing, a batch that went on kept it — one pixel of cfg2's 1.08 M on the object-centric set differed between the
+//     planned and the per-call kernel).  The reference's strict compares leave such a pixel at the default: a tie of its
+//     OWN arithmetic, T (1 - alpha), which rounds differently anyway; the oracle's ambiguity map covers both.]
 //   * the stop test (T' < 1e-4 -> done, this record not blended; forward.cu:340-345) and the "stopped" state (sign of
 //     T) are compare + select, in the trips that can stop only: see no_stop_need().
 #pragma once
@@ -200,7 +203,7 @@ __device__ __forceinline__ f2 chain(Px& p, f2 alpha, f2 s, float cr, float cg, f
 // or -1.  cnt = records of the batch whose incoming T was above 0.5 (float, exact); T = the pixel's state now.
 __device__ __forceinline__ int median_index(float cnt, float T) {
   const int c = (int)cnt;
-  return (c > 0 && T < 0.5f) ? c - 1 : -1;
+  return (c > 0 && T <= 0.5f) ? c - 1 : -1;
 }
 
 }  // namespace rb

@@ -45,7 +45,10 @@ constexpr int kHeaderInts = 16;                   // magic, P, V, H, W, gx, gy, 
 #define OCRF_PLAN_STAGE 128
 #endif
 #ifndef OCRF_PLAN_SCAN
-#define OCRF_PLAN_SCAN 1      // 256 rects per scan round (2: 256, then 512 per round — 126.8 vs 122.8 us for cfg2's 12 views; 3: 133.0)
+#define OCRF_PLAN_SCAN 1      // 256 rects per scan round.  Measured on one box (tools/ab_gauss.sh), cfg2 step / blend alone: init
+                              // 0.215 ms / 137 us with 1, 0.219 / 141 with 2, 0.225 / 144 with 4 (the unrolled round's registers
+                              // and instructions are paid in the direct region too); objects 2.07 / 1.53 ms, 2.04 / 1.51, 2.00 / 1.49:
+                              // a candidate costs ~ 4 ns per workgroup whatever the round's width — issue-bound, not latency-bound
 #endif
 constexpr int kStageP = OCRF_PLAN_STAGE;          // records staged per batch (a tile pair saturates after ~110 at cfg2)
 constexpr int kScanUnrollP = OCRF_PLAN_SCAN;      // rect batches in flight in the scan
@@ -262,8 +265,8 @@ __global__ __launch_bounds__(kBlock) void plan_gather_kernel(int P, int V, int H
 // (conic_radius_rect with the call's parameters, tightened by its opacity) lies inside the inflated one, so a tile pair
 // that walks its bin's candidates sees every record the reference's tile list holds, in the same order, and tests O(own
 // records) rects instead of the view's whole list (cfg2: a 4 x 4-tile bin lists ~ 24 000 of a view's ~ 115 000 records).
-//   bins buffer: header (16 ints: magic, V, gx, gy, bw, bh, nbx, nby, total, capacity) | b_off (V * nbx * nby + 1 ints) |
-//   cand (capacity x u32).  The magic word is written last and only if the lists fit: a bins buffer without it is ignored
+//   bins buffer: header (16 ints: magic, V, gx, gy, bw, bh, nbx, nby, total, capacity) | b_tab (V * nbx * nby + 1 int
+//   pairs: the bin's first candidate, its candidates inside the direct region) | cand (capacity x u32).  The magic word is written last and only if the lists fit: a bins buffer without it is ignored
 //   (the blend then walks whole lists: slower, same image).
 // Build (no host read, kernels only): inflated bin range per list entry -> per (view, bin, segment) counts -> exclusive
 // scan -> ordered compaction of every segment into its bin's list.
@@ -271,6 +274,12 @@ __global__ __launch_bounds__(kBlock) void plan_gather_kernel(int P, int V, int H
 constexpr unsigned kBinsMagic = 0x4F435242u;      // "OCRB"
 constexpr int kBinsHeaderInts = 16;
 constexpr int kBinSeg = 8192;                     // list entries per (view, bin) workgroup of the count / fill kernels
+// The first kBinDirect entries of a view's list — its nearest records, each of which covers a good part of the image — are
+// tested by every tile pair directly, in list order (one memory round trip per 256 rects, no candidate indirection: a
+// scene whose pixels saturate early never gets past them); a bin's candidates are followed from the first one behind them
+// (b_tab[bin].y = how many of its candidates lie inside the direct region).
+constexpr int kBinDirect = 512;
+static_assert(kBinDirect % kBlock == 0 && kBinDirect <= kBinSeg, "the direct region is whole slices of the first segment");
 
 struct BinsLayout {
   size_t header, b_off, cand, bytes;
@@ -280,7 +289,7 @@ inline void bins_layout(int V, int nbx, int nby, long cand_cap, BinsLayout* L) {
   size_t off = 0;
   auto take = [&](size_t b) { size_t o = off; off += align_up(b, 256); return o; };
   L->header = take((size_t)kBinsHeaderInts * 4);
-  L->b_off = take(((size_t)V * nbx * nby + 1) * 4);
+  L->b_off = take(((size_t)V * nbx * nby + 1) * 8);
   L->cand = take((size_t)std::max<long>(cand_cap, 1) * 4);
   L->bytes = off;
 }
@@ -375,22 +384,22 @@ __global__ __launch_bounds__(kBlock) void plan_bin_count_kernel(const int* __res
 __global__ __launch_bounds__(kBlock) void plan_bin_fill_kernel(const int* __restrict__ header, int nbx, int n_seg,
                                                                long cand_cap, const unsigned* __restrict__ range,
                                                                const int* __restrict__ offsets,
-                                                               const int* __restrict__ total, int* __restrict__ b_off,
+                                                               const int* __restrict__ total, int2* __restrict__ b_tab,
                                                                unsigned* __restrict__ cand) {
   const int seg = blockIdx.x, bin = blockIdx.y, v = blockIdx.z;
   const int nbins = gridDim.y;
   if (header[0] != (int)kPlanMagic) return;
   const long slot = ((long)v * nbins + bin) * n_seg + seg;
-  if (seg == 0 && threadIdx.x == 0) {
-    b_off[v * nbins + bin] = offsets[slot];
-    if (bin == nbins - 1 && v == (int)gridDim.z - 1) b_off[v * nbins + bin + 1] = *total;
-  }
+  if (seg == 0 && threadIdx.x == 0 && bin == nbins - 1 && v == (int)gridDim.z - 1)
+    b_tab[v * nbins + bin + 1] = make_int2(*total, 0);
   if ((long)*total > cand_cap) return;            // the lists do not fit: nothing is written, the buffer stays without magic
   const int off = header[kHeaderInts + v], nv = header[kHeaderInts + v + 1] - off;
   const int bx = bin % nbx, by = bin / nbx;
   const int lo = seg * kBinSeg, hi = min(nv, lo + kBinSeg);
   __shared__ int l_w[4];
   int base = offsets[slot];
+  const int first = base;
+  int direct = 0;                                 // candidates of the bin inside the direct region (segment 0 only)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i0 = lo; i0 < hi; i0 += kBlock) {
     const int i = i0 + (int)threadIdx.x;
@@ -406,8 +415,10 @@ __global__ __launch_bounds__(kBlock) void plan_bin_fill_kernel(const int* __rest
     }
     if (hit) cand[mine + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)i;
     base += tot;
+    if (i0 < kBinDirect) direct += tot;
     __syncthreads();
   }
+  if (seg == 0 && threadIdx.x == 0) b_tab[v * nbins + bin] = make_int2(first, direct);
 }
 
 __global__ void plan_bins_header_kernel(const int* __restrict__ plan_header, const int* __restrict__ total, long cand_cap,
@@ -871,7 +882,7 @@ struct BlendArgs {
   // list (= blend) order, of the view's records whose BOUND-inflated rect reaches the bin; null: a tile pair walks the
   // view's whole list
   const int* bins_header;
-  const int* b_off;
+  const int2* b_tab;
   const unsigned* cand;
   int bw, bh, nbx, nbins;
   // two passes: the first renders a tile pair as far as the prepared head of its view's list reaches and hands it to the
@@ -899,6 +910,15 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(BlendArgs g) {
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   int* const ctl = g.ctl;
+  if (g.pass == 2 && ctl[kCtlDeferred] == 0) {
+    // the usual case: no tile pair of the first pass ran out of prepared records — workgroup 0 closes the call (next
+    // call's heads from this call's reach; the first pass left the ticket queue and the arrival counter at zero)
+    if (blockIdx.x == 0 && tid < 32) {
+      const int reached = atomicExch(ctl + kCtlReach + tid, 0);
+      if (reached > 0) ctl[kCtlHead + tid] = (int)min(1l << 30, ((long)reached + reached / 4 + 2 * kBlock - 1) / kBlock * kBlock);
+    }
+    return;
+  }
   bool run = true;
   if (g.skip_if && *g.skip_if != 0) {
     // the plan's bound does not hold this step: the armed per-call chain renders.  Its bucket histograms are cleared
@@ -984,14 +1004,20 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(BlendArgs g) {
   const long dyn = (long)set * g.set_stride;
   const float* set_colors = g.colors + 3 * (long)set * g.P;
   auto dyn_index = [&](int i) { return dyn + (g.full ? (long)g.s_e[off + i] : (long)(off + i)); };
-  // this tile pair's candidates: its bin's list (positions into the view's list, ascending), or the whole list
-  int c0 = 0, nc = nv;
+  // what this tile pair scans: the first n_direct entries of the view's list as they come, then its bin's candidates
+  // (positions into the view's list, ascending) from the first one behind them; without lists the whole list
+  // (read here, used behind the direct region.  Read only by the tile pairs that get there — most of a saturating scene's
+  // do not — the scan loop came out slower: 15.5 vs 14.5 us per tile pair at cfg2, tools/ab_gauss.sh)
+  int n_direct = nv, nc = nv;
+  const unsigned* cand = nullptr;
   if (use_bins) {
     const int bin = v * g.nbins + (ty2 / g.bh) * g.nbx + tx / g.bw;
-    c0 = __builtin_amdgcn_readfirstlane(g.b_off[bin]);
-    nc = __builtin_amdgcn_readfirstlane(g.b_off[bin + 1]) - c0;
+    const int2 t0 = g.b_tab[bin], t1 = g.b_tab[bin + 1];
+    n_direct = min(nv, kBinDirect);
+    const int first = __builtin_amdgcn_readfirstlane(t0.x) + __builtin_amdgcn_readfirstlane(t0.y);
+    nc = n_direct + (__builtin_amdgcn_readfirstlane(t1.x) - first);
+    cand = g.cand + first;
   }
-  const unsigned* cand = use_bins ? g.cand + c0 : nullptr;
   const int pxi = tx * kTileX + lx;
   const int py0 = tyA * kTileY + 8 * wave + r, py1 = py0 + 4;
   const bool tile_ok = (tyA + (wave >> 1)) < gy;
@@ -1024,11 +1050,9 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(BlendArgs g) {
   while (!all_done) {
     // ---- scan: positions of the candidates whose rect covers this tile pair, in list (= blend) order ----
     while (scan < nc && npos < kStageP && !blocked) {
-#ifdef OCRF_PLAN_SCAN_WIDE_FIRST
-      const int n_u = kScanUnrollP;
-#else
-      const int n_u = (scan < kBlock) ? 1 : kScanUnrollP;      // a dense tile pair fills its first batch from 256 rects
-#endif
+      // the direct region 256 rects at a time (a dense tile pair fills its first batch from them); behind it the
+      // candidates kScanUnrollP x 256 at a time: each round is two dependent memory round trips (candidate -> rect)
+      const int n_u = (scan < n_direct) ? 1 : kScanUnrollP;
       unsigned code[kScanUnrollP];
       bool hit[kScanUnrollP], valid[kScanUnrollP];
 #pragma unroll
@@ -1038,7 +1062,7 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(BlendArgs g) {
         valid[u] = false;
         code[u] = 0u;
         if (u < n_u && ic < nc) {
-          const int i = cand ? (int)cand[ic] : ic;
+          const int i = ic < n_direct ? ic : (int)cand[ic - n_direct];
           // candidates are ascending: the unprepared ones (i >= head) are a suffix of the round
           valid[u] = i < head;
           if (valid[u]) {
@@ -1411,6 +1435,7 @@ int resident_blocks(K kernel) {
 int g_update_lds = 0;       // ocrf_tune_set(12, bytes): dynamic LDS padding of the update kernel = an occupancy cap (diagnostic)
 int g_plan_grid = 0;        // ocrf_tune_set(11, n): workgroups of the persistent blend (0 = what the device holds at once)
 int g_blend_variant = 0;    // ocrf_tune_set(14, bits): diagnostic loop selection of the planned blend
+int g_single_pass = 0;      // ocrf_tune_set(15, 1): no second pass (diagnostic: what the two launches behind the first pass cost)
 int g_head_force = 0;       // ocrf_tune_set(13, n): list entries per view the head kernel prepares (n > 0), none (n < 0), adaptive (0)
 unsigned long long* g_plan_stats = nullptr;      // ocrf_diag_plan_stats: the next planned blends run the STATS build
 
@@ -1422,6 +1447,7 @@ void raster_plan_tune(int key, int value) {
   if (key == 12) g_update_lds = value > 0 ? value : 0;
   if (key == 13) g_head_force = value;
   if (key == 14) g_blend_variant = value;
+  if (key == 15) g_single_pass = value;
 }
 }
 
@@ -1635,7 +1661,7 @@ int ocrf_raster_plan_bins_build(const void* plan, size_t plan_bytes, int P, int 
   char* qb = static_cast<char*>(bins);
   hipLaunchKernelGGL(plan_bin_fill_kernel, dim3(n_seg, nbins, n_views), dim3(kBlock), 0, stream, header, nbx, n_seg,
                      cand_capacity, static_cast<const unsigned*>(range), static_cast<const int*>(counts),
-                     static_cast<const int*>(total), reinterpret_cast<int*>(qb + Q.b_off),
+                     static_cast<const int*>(total), reinterpret_cast<int2*>(qb + Q.b_off),
                      reinterpret_cast<unsigned*>(qb + Q.cand));
   hipLaunchKernelGGL(plan_bins_header_kernel, dim3(1), dim3(64), 0, stream, header, static_cast<const int*>(total),
                      cand_capacity, n_views, gx, gy, bin_w, bin_h, nbx, nby,
@@ -1692,7 +1718,7 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
   // candidate lists (optional; bin_w / bin_h / cand_capacity as given to ocrf_raster_plan_bins_build).  Whether the
   // buffer holds usable lists is read from ITS header on the device (the blend walks whole lists otherwise)
   const int* bins_header = nullptr;
-  const int* b_off = nullptr;
+  const int2* b_tab = nullptr;
   const unsigned* cand = nullptr;
   int nbx = 1, nbins = 1;
   if (bins) {
@@ -1703,7 +1729,7 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
     if (bins_bytes < Q.bytes) return (int)hipErrorInvalidValue;
     const char* qb = static_cast<const char*>(bins);
     bins_header = reinterpret_cast<const int*>(qb + Q.header);
-    b_off = reinterpret_cast<const int*>(qb + Q.b_off);
+    b_tab = reinterpret_cast<const int2*>(qb + Q.b_off);
     cand = reinterpret_cast<const unsigned*>(qb + Q.cand);
     nbins = nbx * nby;
   }
@@ -1782,14 +1808,15 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
   g.skip_if = flag; g.ctl = ctl; g.chain_hist = chain_hist; g.chain_hist_words = (int)chain_hist_words;
   g.yield_if = yield_if; g.base_grid = base_grid; g.full = full ? 1 : 0; g.force_head = g_head_force; g.variant = g_blend_variant;
   g.n_sets = n_sets; g.status = status;
-  g.bins_header = bins_header; g.b_off = b_off; g.cand = cand; g.bw = bin_w > 0 ? bin_w : 1; g.bh = bin_h > 0 ? bin_h : 1;
+  g.bins_header = bins_header; g.b_tab = b_tab; g.cand = cand; g.bw = bin_w > 0 ? bin_w : 1; g.bh = bin_h > 0 ? bin_h : 1;
   g.nbx = nbx; g.nbins = nbins;
   g.deferred = deferred;
   // `full`: every record was prepared in front of the blend — one pass.  Else two: the first as far as the prepared heads
   // reach; then the extent check, which also prepares the REST of the lists if a tile pair asked for it; then the second
   // pass over those tile pairs (it retires at once when there are none)
+  const bool two_pass = !full && !g_single_pass;
   g.pass = 1;
-  g.last_pass = full ? 1 : 0;
+  g.last_pass = two_pass ? 0 : 1;
   auto blend = [&](const BlendArgs& ga, bool first) -> hipError_t {
     if (g_plan_stats) {      // diagnostic build (median depth), never used by the product path
       const dim3 sgrid((unsigned)std::min(n_work, want_grid ? want_grid : resident_blocks(raster_blend_sorted_kernel<true, true>)));
@@ -1809,7 +1836,12 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
   };
   e = blend(g, true);
   if (e != hipSuccess) return (int)e;
-  if (!full) {
+  if (!full && !two_pass && !guard) {
+    const long n_pairs = (long)n_sets * P;
+    hipLaunchKernelGGL(raster_plan_check_kernel, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+                       n_pairs, header, scales, scale_modifier, rotations, status, static_cast<int*>(nullptr), h, 0);
+  }
+  if (two_pass) {
     const long n_pairs = (long)n_sets * P;
     // with the device guard the extent check ran first; this launch is then only the preparation of the rest
     hipLaunchKernelGGL(raster_plan_check_kernel, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,

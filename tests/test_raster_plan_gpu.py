@@ -333,6 +333,72 @@ def test_mostly_transparent_scene(cuda):
     assert plan.check()
 
 
+def _heads(plan):
+    """head[v] control words of the plan's per-call scratch (raster_plan.hip kCtlHead)."""
+    ctl = plan._dyn[plan._dyn.numel() - 512:].view(torch.int32).cpu().numpy()
+    return [int(x) for x in ctl[32:32 + plan.V]]
+
+
+@pytest.mark.parametrize('bins', [(4, 2), (1, 1), (2, 1), (3, 5), None])
+def test_candidate_lists_change_nothing(cuda, bins):
+    """The plan-time candidate lists (what a tile may see: rasterizer_impl.cu:70-138, here per bin and for every extent up
+    to the plan's bound) only shorten what a tile pair scans: the images are the per-call pipeline's bit for bit, whatever
+    the bin shape, for a scene that saturates and for one that is mostly transparent, with and without radii."""
+    rng = np.random.default_rng(31)
+    W, H = 176, 80
+    cams = _cams(cuda, W, H, [(0, 0, 0), (1.5, -0.5, 2.0), (-3.0, 0.4, -1.0)])
+    bg = torch.tensor([0.1, 0.2, 0.3], device=cuda)
+    for faint_frac in (0.0, 0.9):
+        xyz, rgb, opac, sc, rot = _scene(rng, 30000, cuda)
+        if faint_frac:
+            faint = torch.from_numpy(rng.random(30000) < faint_frac).to(cuda)
+            opac[faint] = opac[faint] * 0.012              # around the 1/255 threshold: tight alpha ellipses, empty rects
+        want = dgr.rasterize_views(xyz, rgb, opac, sc, rot, None, None, None, None, H, W, bg, packed_cameras=cams,
+                                   want_n_contrib=False)
+        plan = rp.RasterPlan(xyz, cams, H, W, scales=sc, rotations=rot, bins=bins)
+        try:
+            for head in (0, -1, 256, 0):
+                _head_mode(head)
+                _same(want, plan.render(rgb, opac, sc, rot, bg))
+        finally:
+            _head_mode(0)
+        _same(want, plan.render(rgb, opac, sc, rot, bg, want_radii=True), ('color', 'depth', 'final_T', 'radii'))
+        assert plan.check()
+        if bins is not None:
+            assert plan.candidates > 0 and plan.cand_capacity >= plan.candidates
+
+
+def test_lists_that_never_saturate_are_prepared_once_and_whole(cuda):
+    """An object-centric opacity field: most Gaussians faint, so most pixels never reach T < 1e-4 and a tile pair walks its
+    whole candidate list — far beyond round 5's 16 384-entry head.  The first call hands such tile pairs to the second pass
+    (the rest of the lists is prepared once in between), the head then covers the whole list; every call gives the per-call
+    pipeline's image bit for bit, and the head shrinks again when the scene saturates early."""
+    rng = np.random.default_rng(37)
+    W, H = 176, 80
+    n = 90000
+    xyz, rgb, opac, sc, rot = _scene(rng, n, cuda)
+    cams = _cams(cuda, W, H, [(0, 0, 0), (1.5, -0.5, 2.0)])
+    bg = torch.tensor([0.3, 0.2, 0.1], device=cuda)
+    faint = opac * 0.01                                    # every alpha a few times 1/255 at most
+    plan = rp.RasterPlan(xyz, cams, H, W, scales=sc, rotations=rot)
+    assert min(plan.kept) > 2 * 16384
+    want_faint = dgr.rasterize_views(xyz, rgb, faint, sc, rot, None, None, None, None, H, W, bg, packed_cameras=cams,
+                                     want_n_contrib=False)
+    want_dense = dgr.rasterize_views(xyz, rgb, opac, sc, rot, None, None, None, None, H, W, bg, packed_cameras=cams,
+                                     want_n_contrib=False)
+    assert float(want_faint['final_T'].max()) > 1e-3       # pixels that never saturate
+    _same(want_dense, plan.render(rgb, opac, sc, rot, bg))
+    dense_heads = _heads(plan)
+    _same(want_faint, plan.render(rgb, faint, sc, rot, bg))        # lagging head: second pass
+    grown = _heads(plan)
+    assert all(h >= k for h, k in zip(grown, plan.kept)), (grown, plan.kept)
+    _same(want_faint, plan.render(rgb, faint, sc, rot, bg))        # whole lists prepared by the head kernel
+    _same(want_dense, plan.render(rgb, opac, sc, rot, bg))
+    _same(want_dense, plan.render(rgb, opac, sc, rot, bg))
+    assert max(_heads(plan)) <= 4 * max(dense_heads) + 1024
+    assert plan.check()
+
+
 def test_full_size_ocrf_grid_both_conventions(cuda):
     """cfg2's own scene: the 13 x 200 x 200 voxel-grid Gaussians through the six cameras at 256 x 704."""
     from ocrfdet_amd import hotpath

@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--sets', default='init,stress,objects')
 ap.add_argument('--steps', type=int, default=20)
 ap.add_argument('--config', default=bench.DEFAULT_CONFIG)
+ap.add_argument('--bins', default='4x2', help="candidate lists of the render plans: WxH tile pairs, or 'none'")
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 cfg = synthetic.CONFIGS[a.config]
@@ -22,5 +23,6 @@ hp0 = hotpath.HotPath(synthetic.PathConfig(**{**cfg.__dict__, 'render': False, '
 depth, feat = hp0.make_inputs(seed=0)
 del hp0
 for kind in a.sets.split(','):
-    r = bench.gaussian_set_figures(cfg, dev, kind, depth, feat, steps=a.steps)
+    bins = None if a.bins == 'none' else tuple(int(x) for x in a.bins.split('x'))
+    r = bench.gaussian_set_figures(cfg, dev, kind, depth, feat, steps=a.steps, plan_bins=bins)
     print(kind, json.dumps(r), flush=True)
