@@ -39,8 +39,8 @@ FP32_PEAK_TFLOPS = 157.3        # ibid.: peak FP32 (vector) = 256 CU x 4 SIMD-32
 N_SIMD, CLOCK_HZ = 256 * 4, 2.4e9
 VALU_CYCLES_PER_INST = 2.0      # ibid.: a wave64 VALU op issues over 2 cycles on a SIMD-32
 BLEND_FLOPS_PER_PIXEL_RECORD = 20.0      # blend flops ~= 20 x sum_tiles len x 256
-PMC_FILE = os.path.join('profiles', 'r5_pmc_mean.csv')     # rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh)
-PMC_META = os.path.join('profiles', 'r5_pmc_meta.json')    # what those passes ran: config, flags, hash of csrc/
+PMC_FILE = os.path.join('profiles', 'r6_pmc_mean.csv')     # rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh)
+PMC_META = os.path.join('profiles', 'r6_pmc_meta.json')    # what those passes ran: config, flags, hash of csrc/
 DEFAULT_CONFIG = 'cfg2_6cam_2frame_bev200x200_render_hoa'
 
 
@@ -131,7 +131,9 @@ def cpu_baseline(hp, depth, feat, budget_s):
     max_threads = oracle.num_threads()
     affinity = len(os.sched_getaffinity(0))
     pinned = int(os.environ.get('OCRF_CPU_THREADS', 0))
-    candidates = [pinned] if pinned else sorted({min(max_threads, affinity), min(max_threads, affinity, 16)})
+    cap = min(max_threads, affinity)
+    # the best thread count PER LEG (the rasteriser leg is 84 % of the CPU step and was never swept)
+    candidates = [pinned] if pinned else sorted({cap, min(cap, 16), min(cap, 32), min(cap, 64)})
     tried = {}
     for c in candidates:
         oracle.set_num_threads(c)
@@ -142,7 +144,8 @@ def cpu_baseline(hp, depth, feat, budget_s):
             pools()
             reps += 1
         tried[c] = (time.perf_counter() - t0) / reps
-    oracle.set_num_threads(min(tried, key=tried.get))
+    pool_threads = min(tried, key=tried.get)
+    oracle.set_num_threads(pool_threads)
     n, t0 = 0, time.perf_counter()
     while True:
         pools()
@@ -151,7 +154,7 @@ def cpu_baseline(hp, depth, feat, budget_s):
         if el >= min(budget_s, 4.0) or n >= 200:
             break
     t_pools = el / n
-    t_view, n_views_timed, rendered, view_args = 0.0, 0, None, None
+    t_view, n_views_timed, rendered, view_args, view_threads, tried_view = 0.0, 0, None, None, None, {}
     if hp.cfg.render:
         g = hp.gauss
         Himg, Wimg = hp.cfg.input_size
@@ -161,15 +164,29 @@ def cpu_baseline(hp, depth, feat, budget_s):
         view_args = dict(xyz=args[0], rgb=args[1], opacity=args[2], scales=args[3], rotations=args[4],
                          vm=cams['vm'][0].cpu().numpy(), pm=cams['pm'][0].cpu().numpy(), tfx=np.float64(cams['tfx'][0]),
                          tfy=np.float64(cams['tfy'][0]), H=np.int64(Himg), W=np.int64(Wimg))
+
+        def one_view(v):
+            return oracle.rasterize_forward(*args, cams['vm'][v].cpu().numpy(), cams['pm'][v].cpu().numpy(),
+                                            cams['tfx'][v], cams['tfy'][v], Himg, Wimg, np.zeros(3, np.float32))
+        # the rasteriser leg's own sweep: one view per candidate (a view is ~ 0.2 s), the fastest renders the sample
+        tried_view = {}
+        for c in candidates:
+            oracle.set_num_threads(c)
+            t0 = time.perf_counter()
+            one_view(0)
+            tried_view[c] = time.perf_counter() - t0
+            if tried_view[c] > 0.25 * budget_s:          # (a count that oversubscribes the box's share: stop sweeping upwards)
+                break
+        view_threads = min(tried_view, key=tried_view.get)
+        oracle.set_num_threads(view_threads)
         t0 = time.perf_counter()
         while True:
             v = n_views_timed % len(hp.cams)
-            r = oracle.rasterize_forward(*args, cams['vm'][v].cpu().numpy(), cams['pm'][v].cpu().numpy(),
-                                         cams['tfx'][v], cams['tfy'][v], Himg, Wimg, np.zeros(3, np.float32))
+            r = one_view(v)
             rendered = r['num_rendered']
             n_views_timed += 1
             el = time.perf_counter() - t0
-            if el >= 0.6 * budget_s or n_views_timed >= 12:
+            if el >= 0.5 * budget_s or n_views_timed >= 12:
                 break
         t_view = el / n_views_timed
     t_hoa, hoa_note = 0.0, 'no HOA in this configuration'
@@ -194,10 +211,16 @@ def cpu_baseline(hp, depth, feat, budget_s):
     if single.get('ms_pools') is not None and single.get('ms_per_view') is not None:
         single['ms_per_step'] = single['ms_pools'] + hp.views_per_step * single['ms_per_view'] + 1e3 * frames * t_hoa
         single['value'] = hp.bev_voxels_per_step / (single['ms_per_step'] * 1e-3)
-    return dict(value=hp.bev_voxels_per_step / t_step, unit='BEV voxels/s', cores=oracle.num_threads(),
+    phys = physical_cores()
+    return dict(value=hp.bev_voxels_per_step / t_step, unit='BEV voxels/s',
+                cores=max(pool_threads, view_threads if hp.cfg.render else 0),
+                threads={'pooling_leg': pool_threads, 'rasteriser_leg': view_threads if hp.cfg.render else None,
+                         'hoa_leg': 'numpy / BLAS default'},
                 threads_tried={str(k): 1e3 * v for k, v in tried.items()},
-                threads_note='OpenMP thread counts tried on the pooling leg (ms per pair of pools): the fastest is used for '
-                             'every leg; affinity set = %d cores' % affinity,
+                threads_tried_rasteriser={str(k): 1e3 * v for k, v in (tried_view.items() if hp.cfg.render else ())},
+                box={'physical_cores': phys, 'logical_cpus': os.cpu_count(), 'affinity_set': affinity},
+                threads_note='OpenMP thread counts swept PER LEG (ms per pair of pools / ms per rendered view); each leg runs '
+                             'on its own fastest count; `cores` is the larger of the two',
                 cores_note='OpenMP threads of the pooling, of the per-Gaussian / per-tile loops and of the per-tile '
                            'sorts of the tile instances (bucketed by tile first; the histogram pass is one thread); the '
                            'numpy HOA leg uses whatever BLAS threads numpy has',
@@ -209,6 +232,24 @@ def cpu_baseline(hp, depth, feat, budget_s):
                        + (f', {n_views_timed} rendered view(s) of frame 0 ({rendered} tile instances in the last)'
                           if hp.cfg.render else '') + f', {hoa_note}; step time assembled as pools + '
                        f'{hp.views_per_step} x view + {frames} x HOA; C/OpenMP + numpy oracles')
+
+
+def physical_cores():
+    """Distinct (package, core) pairs of /proc/cpuinfo — the box's physical core count (None if it cannot be read)."""
+    try:
+        cores, pkg, core = set(), None, None
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('physical id'):
+                pkg = line.split(':')[1].strip()
+            elif line.startswith('core id'):
+                core = line.split(':')[1].strip()
+            elif not line.strip():
+                if pkg is not None and core is not None:
+                    cores.add((pkg, core))
+                pkg = core = None
+        return len(cores) or None
+    except OSError:
+        return None
 
 
 def single_thread_sample(plans, d, f, view_args, limit_s):
@@ -1049,8 +1090,21 @@ def main():
                              'note': 'beside the pooling / HOA stream the persistent blend is launched on 2.75 workgroups '
                                      'per CU of the five the chip holds (DESIGN 5); "frac" prices that partial-occupancy '
                                      'launch against the whole chip\'s peak, "isolated" is the full grid'}
+            # which resource bounds the kernel is read from the counters, not assumed: VALU busy share of the
+            # SIMDs over the kernel's span vs the share of wave cycles spent waiting; without counters of THIS build the
+            # round-5 finding stands (0.49 busy, 0.59 waiting: a latency / occupancy kernel priced against the VALU peak)
+            cyc_b = (iso_blend or blend_ms) * 1e-3 * CLOCK_HZ
+            valu_busy = (4.0 * c['SQ_ACTIVE_INST_VALU'] / (N_SIMD * cyc_b)) if c.get('SQ_ACTIVE_INST_VALU') else None
+            wait_share = (c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES']) if c.get('SQ_WAIT_ANY') and c.get('SQ_WAVE_CYCLES') else None
+            bound = 'valu' if (valu_busy is not None and valu_busy >= 0.6) else 'latency'
             roofline = {
-                'bound': 'valu', 'kernel': t_blend.kernel_name,
+                'bound': bound,
+                'bound_basis': {'valu_busy_frac': valu_busy, 'wave_wait_share': wait_share,
+                                'rule': 'valu if the SIMDs issue VALU work >= 0.6 of the kernel\'s span (PMC of this build), else '
+                                        'latency: achieved / peak / frac still price the executed flops against the fp32 '
+                                        'vector peak', 'source': PMC_FILE if valu_busy is not None else
+                                'no counters of this build: round 5 measured 0.49 busy / 0.59 waiting'},
+                'kernel': t_blend.kernel_name,
                 'achieved': tfl, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tfl / FP32_PEAK_TFLOPS,
                 'flops_per_pixel_record': BLEND_FLOPS_PER_PIXEL_RECORD, 'pixel_records_per_launch': evals,
                 'pixel_records_source': ('executed: wave-records the planned blend evaluated (its instrumented build, one launch '
@@ -1161,6 +1215,10 @@ def main():
                                    else ('main: HOA-1/2, pools, HOA-3; side HIP stream: renders' if hp.overlap and cfg.render
                                          else 'single stream')),
                        'ht_pool': getattr(hp, 'ht_pool_backend', None), 'lss_pool': getattr(hp, 'lss_pool_backend', None),
+                       # north_star asks for MFMA on the depth x feature outer product: the MFMA form of both poolings exists
+                       # (csrc/bev_pool_mfma.hip) and is timed alone below (pools.backends_alone_us.*.mfma); the default step
+                       # does NOT launch it — the panel form of the same plan is faster alone and in the step
+                       'pools_on_mfma': bool(lss_on_mfma or ht_on_mfma),
                        'issue': ('one host call per step (ocrf_hotpath_step: the step\'s library calls recorded once, replayed '
                                  'from C)' if getattr(hp, '_compiled', None) else 'call by call from Python'),
                        'index_prep': 'cached (accelerate=True semantics); per_step_ms = the same step with the HIP index '

@@ -253,7 +253,7 @@ size_t ocrf_rasterize_workspace_bytes(int P, int n_views);
  *      record arrays (workspace >= ocrf_rasterize_planned_workspace_bytes(capacity, 1)), every line of which is
  *      written once; a view named by two sets raises status bit 3 (value 8).  0: a copy per set.
  *      call_cameras (device, n_plan_views x 36 floats, or NULL): the cameras THIS call means to render with.  The
- *      update kernel compares them with the plan's, bit for bit, on the device; a difference raises status bit 4
+ *      head kernel compares them with the plan's, bit for bit, on the device; a difference raises status bit 4
  *      (value 16) and — with guard = 1 — hands the call to the armed per-call pipeline, which then renders with
  *      call_cameras: a stale plan can not silently render another pose.
  *      status (device int, NOT written unless something is wrong: zero it once): bit 2 (value 4) = some Gaussian
@@ -264,7 +264,7 @@ size_t ocrf_rasterize_workspace_bytes(int P, int n_views);
  *      the per-call pipeline of ocrf_rasterize_forward is enqueued behind the planned one, armed by the
  *      extent check: all of its kernels retire at once when the bound holds, and render the call instead when it
  *      does not — exact results either way, no host involvement (hipGraph-capturable), at the price of four
- *      near-empty launches (no memsets: the flag is raised by the update kernel and lowered by the armed blend, the
+ *      near-empty launches (no memsets: the flag is raised by the extent check / head kernel and lowered by the armed blend, the
  *      chain's histograms are cleared by the planned blend when the flag is up, radii zeros come from the update
  *      kernel).  Needs means3D, radii and chain_workspace >= ocrf_rasterize_workspace_bytes(P, n_items); `workspace`
  *      must be zero-filled when it is allocated and belong to this plan alone (it carries the flag between calls; a
@@ -552,15 +552,6 @@ int ocrf_hoa_v2b_weights_len(void);
 size_t ocrf_hoa_v2b_workspace_bytes(int B, int H, int W);
 int ocrf_hoa_v2b_forward(const float *x, const float *position, const float *weights, int B, int H, int W,
                          void *workspace, size_t workspace_bytes, float *out, ocrf_stream_t stream);
-/* out == NULL above DEFERS the output conv: the five block launches leave the gated decoder-1 activations and their
- * per-tile maxima in `workspace`, and this call — the HOA-3 gate (ocrf_hoa_opacity_mask_gate, k = 7) with the output conv
- * (view_transformer_ocrf.py:516) folded into its prologue — finishes both: opacity_bev_out (B,1,Y,X) is what
- * ocrf_hoa_v2b_forward would have written (same bits), mask / gated as ocrf_hoa_opacity_mask_gate.  `v2b_workspace` /
- * `v2b_weights` are the deferred call's; nothing else may use that workspace in between.  Needs X % 4 == 0, X <= 256,
- * 16-byte aligned x / stats / gated (else hipErrorInvalidValue: run the two calls separately). */
-int ocrf_hoa_opacity_mask_gate_v2b(const float *x, const float *stats, const void *v2b_workspace,
-                                   const float *v2b_weights, const float *conv_w, int k, int B, int C, int Y, int X,
-                                   float *opacity_bev_out, float *mask, float *gated, ocrf_stream_t stream);
 int ocrf_hoa_height_gate_from_tiles(int B, int C, int hid, int n_tiles, const float *partial_max,
                                     const float *w1, const float *w2, float *gate, ocrf_stream_t stream);
 int ocrf_hoa_gated_conv1x1(const float *x, const float *gate, int B, int C, int H, int W, const float *w,
@@ -741,7 +732,7 @@ enum {
   OCRF_K_RASTER_SCAN = 13,       /* raster_bucket_scan_kernel */
   OCRF_K_RASTER_BLEND_BWD = 15,  /* raster_blend_kernel<false, true> */
   OCRF_K_RASTER_PRE_BWD = 16,    /* raster_preprocess_backward_kernel */
-  OCRF_K_RASTER_PLAN_UPDATE = 17,  /* raster_plan_update_kernel */
+  OCRF_K_RASTER_PLAN_UPDATE = 17,  /* raster_plan_head_kernel (rounds 3-4: raster_plan_update_kernel) */
   OCRF_K_RASTER_BLEND_SORTED = 18, /* raster_blend_sorted_kernel<*>, first pass */
   OCRF_K_RASTER_BLEND_SECOND = 19, /* raster_blend_sorted_kernel<*>, second pass (tile pairs handed over by the first) */
   OCRF_K_HOA_STATS = 20,         /* hoa_channel_stats_kernel */

@@ -181,8 +181,6 @@ def _declare(L):
     L.ocrf_hoa_v2b_workspace_bytes.argtypes = [c_int] * 3
     L.ocrf_hoa_v2b_forward.restype = c_int
     L.ocrf_hoa_v2b_forward.argtypes = [c_void_p] * 3 + [c_int] * 3 + [c_void_p, c_size_t, c_void_p, c_void_p]
-    L.ocrf_hoa_opacity_mask_gate_v2b.restype = c_int
-    L.ocrf_hoa_opacity_mask_gate_v2b.argtypes = [c_void_p] * 5 + [c_int] * 5 + [c_void_p] * 4
     L.ocrf_hoa_unet_tiles.restype = c_int
     L.ocrf_hoa_unet_tiles.argtypes = [c_int, c_int]
     L.ocrf_hoa_height_gate_from_tiles.restype = c_int

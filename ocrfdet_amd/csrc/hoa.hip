@@ -492,36 +492,9 @@ int ocrf_hoa_opacity_mask_gate(const float* x, const float* stats, const float* 
   return (int)hipGetLastError();
 }
 
-// HOA-2's output conv folded into the HOA-3 gate (csrc/hoa_v2b.hip: ocrf_hoa_v2b_forward with out == NULL leaves the
-// gated decoder1 activations and their per-tile maxima in its workspace).  Needs the 16-byte path of the gate kernel
-// (k = 7, X a multiple of 4 and <= 256, 16-byte aligned tensors, Y X a multiple of 4); else hipErrorInvalidValue —
-// the caller then runs the two calls separately.
-int ocrf_hoa_opacity_mask_gate_v2b(const float* x, const float* stats, const void* v2b_workspace, const float* v2b_weights,
-                                   const float* conv_w, int k, int B, int C, int Y, int X, float* opacity_bev_out,
-                                   float* mask, float* gated, ocrf_stream_t stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (!x || !stats || !v2b_workspace || !v2b_weights || !conv_w || !opacity_bev_out || !mask || !gated || k != 7 ||
-      B <= 0 || C <= 0 || Y < 4 || X < 4 || (Y % 4) || (X % 4) || X > 256)
-    return (int)hipErrorInvalidValue;
-  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gated) | reinterpret_cast<uintptr_t>(stats)) & 15u)
-    return (int)hipErrorInvalidValue;
-  MaskGateD1 dd;
-  ocrf::v2b_deferred_pointers(v2b_workspace, v2b_weights, B, Y, X, &dd.d1, &dd.pm, &dd.tiles, &dd.out_w, &dd.out_b,
-                              &dd.g_w1, &dd.g_w2);
-  dd.opacity_out = opacity_bev_out;
-  const long plane = (long)Y * X;
-  const int threads = kBlock, per_wg = threads * 4;        // (the gate prologue's reductions are laid out for 256 threads)
-  const int n_rows = (per_wg + X - 2) / X + 1 + (k - 1);
-  const int tw = X + 8;
-  const size_t lds = (size_t)(((2 * k * k + 3) & ~3) + 2 * n_rows * tw) * sizeof(float);
-  if (lds > 60 * 1024) return (int)hipErrorInvalidValue;
-  int groups = (C >= 40) ? 4 : (C >= 16 ? 2 : 1);
-  if (g_mg_groups > 0) groups = std::min(g_mg_groups, C);
-  const dim3 grid((unsigned)((plane + per_wg - 1) / per_wg), 1, (unsigned)(B * groups));
-  ocrf::launch(OCRF_K_HOA_MASK_GATE, hoa_mask_gate_kernel<4, 7, true, true>, grid, dim3(threads), lds, stream, x, stats,
-               static_cast<const float*>(nullptr), conv_w, k, C, Y, X, groups, n_rows, mask, gated, dd);
-  return (int)hipGetLastError();
-}
+// (Rounds 4-5 also exported ocrf_hoa_opacity_mask_gate_v2b: HOA-2's output conv folded into this gate through the kernel's
+// D1 form — one launch less on the chain, but 288 VGPRs and not faster (DESIGN, round 4); nothing selected it, so the entry
+// point and its instantiation are gone.  The D1 branches of hoa_mask_gate_kernel are not instantiated.)
 
 size_t ocrf_hoa_height_attention_workspace_bytes(int B, int C) {
   return (size_t)B * C * 64 * sizeof(float);

@@ -11,16 +11,19 @@
 //
 // A plan (built once per (means, cameras)) keeps, per view, the Gaussians that can ever be visible — in front
 // of the near plane and inside the frame for any world-space extent up to a stated bound — ALREADY SORTED by
-// (depth bits, id), with their static per-record data.  A step then is two launches:
-//   raster_plan_update_kernel   one thread per Gaussian: covariance -> conic / radius / tile rect of its kept
-//                               records, written in Gaussian-major record order (coalesced; the blend reaches a
-//                               list entry's record through the plan's static list -> record map), + the check
-//                               that no Gaussian exceeds the plan's extent bound (status bit 4);
-//   raster_blend_sorted_kernel  a tile pair filters the list by tile rect — the survivors arrive in the
-//                               reference's per-tile order, so there is no sort, no depth bucket, no carry —
-//                               and each of its four waves blends only the records whose alpha >= 1/255
-//                               ellipse reaches the wave's own 16x8 pixel block (exact conservative test at
-//                               staging, so a wave skips records by construction).
+// (depth bits, id), with their static per-record data, and per bin of tiles the list positions of the records that
+// can ever reach it (candidate lists).  A render then is
+//   raster_plan_head_kernel     conic / tile rect (tightened by the opacity) of the HEAD of every rendered view's list, in
+//                               list order — as many entries as the last render of the view needed, up to all of them;
+//   raster_blend_sorted_kernel  (first pass) a tile pair filters the head of the list, then its bin's candidates, by tile
+//                               rect — the survivors arrive in the reference's per-tile order, so there is no sort, no
+//                               depth bucket, no carry — and each of its four waves blends only the records whose
+//                               alpha >= 1/255 ellipse reaches the wave's own 16x8 pixel block (exact conservative test
+//                               at staging, so a wave skips records by construction); a tile pair that needs records
+//                               behind the prepared head is handed to the second pass;
+//   raster_plan_check_kernel    the extent check of all Gaussians (status bit 4) and, only if a tile pair asked, the rest
+//                               of the lists — prepared ONCE, never per tile pair;
+//   raster_blend_sorted_kernel  (second pass) the tile pairs handed over (none in the steady state: it retires at once)
 // against zero-fill -> preprocess (all P x V pairs) -> bucket scan -> scatter -> blend (with an in-LDS bitonic
 // sort) of rasterize.hip.  Per-pixel arithmetic and its order are those of raster_blend_kernel: colour, depth
 // and final_T are bit-identical to the per-call pipeline (tests/test_raster_plan_gpu.py).
@@ -432,183 +435,13 @@ __global__ void plan_bins_header_kernel(const int* __restrict__ plan_header, con
   header[0] = ok ? (int)kBinsMagic : 0;
 }
 
-// ---------------------------------------------------------------------------------------------
-// step 1: the parameter-dependent half of preprocessCUDA (forward.cu:201-256), ONE THREAD PER GAUSSIAN for EVERY
-// parameter set of the call: per set the parameters are read once (coalesced), the extent is checked against the
-// plan's bound, the 3D covariance is built once, then every view the set renders that keeps the Gaussian gets its
-// conic / radius / tile rect.  Everything it writes is in GAUSSIAN-MAJOR record order e (coalesced); the blend reaches
-// a record of its depth-ordered list through the plan's static list position -> e map (s_e):
-//   d_rect[set * set_stride + e]   tile rect ((0,0,0,0): not rendered this step), gathered by the blend's scan.  Written
-//                     at the record's place in the sorted list instead, the scan read it coalesced but the writes were
-//                     random 8-byte stores — a memory-side read-modify-write each: 21.5 -> 15.2 us alone in round 3;
-//   d_con[set * set_stride + e]    (-0.5 conic.x, -0.5 conic.z, conic.y, opacity), read when a record is staged.
-// set_stride = 0 when every plan view is rendered by at most ONE set of the call (the hot path: frames of a sample
-// share a plan, frame f renders its own six views with its own parameters) — one dynamic array for all sets, every
-// line of it written once, by one workgroup; else the plan's record capacity (a set per copy).
-// Round 3 ran one workgroup per (256 Gaussians, set): a Gaussian's records of the two frames interleave in memory, so
-// the two workgroups (on different XCDs: separate L2s) each fetched every record line and each wrote half of every
-// output line — 216 MB of HBM traffic for 120 MB algorithmic (PMC), 42.8 us.  The items of one set name distinct views.
-// ---------------------------------------------------------------------------------------------
 constexpr int kMaxSets = 32;
-
-__device__ __forceinline__ void tighten_rect_fwd(float o, float cov_x, float cov_z, float pixx, float pixy, int gx, int gy,
-                                                 Rect* r);
-
-__global__ __launch_bounds__(kBlock) void raster_plan_update_kernel(
-    int P, int vps, int n_sets, long set_stride, long n_cap, const int* __restrict__ header,
-    const unsigned* __restrict__ g_mask,
-    const int* __restrict__ g_off, const float4* __restrict__ e_q0,
-    const float4* __restrict__ e_q1, const int* __restrict__ view_sel, const float* __restrict__ opacities,
-    const float* __restrict__ scales, float scale_modifier, const float* __restrict__ rotations,
-    Rect* __restrict__ d_rect, float4* __restrict__ d_con, int* __restrict__ radii, int* __restrict__ status,
-    int* __restrict__ flag, int* __restrict__ queue, const unsigned* __restrict__ call_cams,
-    const unsigned* __restrict__ plan_cams) {
-  __shared__ int l_v2i[kMaxSets * 32];             // [set][plan view] -> item of the set that renders it, or -1
-  __shared__ unsigned l_setmask[kMaxSets];         // [set] -> plan views the set renders
-  __shared__ int l_owner[32];                      // disjoint mode: the set that renders a plan view
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    *queue = 0;                  // ticket counter of the blend that follows
-    if (flag) flag[1] = 0;       // arrival counter of the armed per-call blend (rasterize.hip)
-  }
-  if (call_cams && blockIdx.x == 0) {
-    // the plan is keyed by its cameras ON THE DEVICE: a call that means other cameras (another pose) is not rendered
-    // from this plan — status bit 4 (value 16), and the armed per-call chain (guard) takes the call over
-    bool differ = false;
-    for (int i = threadIdx.x; i < header[2] * 36; i += kBlock) differ |= call_cams[i] != plan_cams[i];
-    if (__ballot(differ) != 0ull && (threadIdx.x & 63) == 0) {
-      atomicOr(status, 16);
-      if (flag) atomicOr(flag, 1);
-    }
-  }
-  if (header[0] != (int)kPlanMagic) {      // unusable plan (capacity, key range, failed scan): the armed chain renders
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-      atomicOr(status, 8);
-      if (flag) atomicOr(flag, 1);
-    }
-    return;
-  }
-  const int V = header[2], gx = header[5], gy = header[6];
-  for (int i = threadIdx.x; i < n_sets * 32; i += kBlock) l_v2i[i] = -1;
-  if (threadIdx.x < 32) l_owner[threadIdx.x] = -1;
-  if ((int)threadIdx.x < n_sets) l_setmask[threadIdx.x] = 0u;
-  __syncthreads();
-  for (int it = threadIdx.x; it < n_sets * vps; it += kBlock) {
-    const int s = it / vps, zi = it % vps;
-    const int v = view_sel ? view_sel[it] : zi;
-    bool ok = v >= 0 && v < V;
-    if (ok) ok = atomicExch(&l_v2i[s * 32 + v], zi) == -1;            // a view named twice in one set: refused
-    if (ok && set_stride == 0) ok = atomicExch(&l_owner[v], s) == -1;  // ... or by two sets that share the dynamic arrays
-    if (ok) atomicOr(&l_setmask[s], 1u << v);
-    if (!ok && blockIdx.x == 0) atomicOr(status, 8);
-  }
-  __syncthreads();
-  const int id = blockIdx.x * kBlock + threadIdx.x;
-  if (id >= P) return;
-  const unsigned m = g_mask[id];
-  const int e0 = g_off[id];
-  const float bound = __int_as_float(header[7]);
-  // the parameters of the next set are requested before this set's arithmetic
-  float sx, sy, sz, qr, qx, qy, qz, o;
-  auto load = [&](int s) {
-    const long gi = (long)s * P + id;
-    sx = scales[3 * gi]; sy = scales[3 * gi + 1]; sz = scales[3 * gi + 2];
-    qr = rotations[4 * gi]; qx = rotations[4 * gi + 1]; qy = rotations[4 * gi + 2]; qz = rotations[4 * gi + 3];
-    o = opacities[gi];
-  };
-  load(0);
-  // The Gaussian's first kPre records (it has 2.7 on average over the twelve views of cfg2) are requested NOW, whatever
-  // set they belong to, at clamped indices: one memory round trip for all of them instead of one per record inside the
-  // loops below (a thread's records used to be a chain of load -> arithmetic -> store -> load ...).
-  constexpr int kPre = 4;
-  float4 pq0[kPre], pq1[kPre];
-  int pv[kPre];
-  {
-    unsigned mm = m;
-#pragma unroll
-    for (int j = 0; j < kPre; ++j) {
-      pv[j] = mm ? __ffs(mm) - 1 : -1;
-      mm &= mm - 1;                                            // (0 stays 0)
-      const long idx = min((long)e0 + j, n_cap - 1);
-      pq0[j] = e_q0[idx];
-      pq1[j] = e_q1[idx];
-    }
-  }
-  bool any_bad = false;
-  for (int s = 0; s < n_sets; ++s) {
-    const float csx = scale_modifier * sx, csy = scale_modifier * sy, csz = scale_modifier * sz;
-    const float cqr = qr, cqx = qx, cqy = qy, cqz = qz, co = o;
-    if (s + 1 < n_sets) load(s + 1);
-    const float rn = extent_bound(csx, csy, csz, cqr, cqx, cqy, cqz);
-    // the plan's static cull holds for extents <= bound; NaN / Inf anywhere counts as a violation (fmaxf drops NaNs)
-    any_bad |= !(rn <= bound) || !(((csx + csy) + csz) * 0.f == 0.f);
-    const unsigned mset = m & l_setmask[s];
-    if (radii) {      // (item, Gaussian) pairs outside the lists are not visited below: their radii are 0 (no memset launch)
-      for (int zi = 0; zi < vps; ++zi) {
-        const int v = view_sel ? view_sel[s * vps + zi] : zi;
-        const bool listed = v >= 0 && v < V && ((mset >> v) & 1u) != 0u && l_v2i[s * 32 + v] == zi;
-        if (!listed) radii[((long)s * vps + zi) * P + id] = 0;
-      }
-    }
-    if (mset == 0u) continue;
-    float c3[6];
-    cov3d_from_scale_rot(csx, csy, csz, cqr, cqx, cqy, cqz, c3);
-    // alpha = min(0.99, o exp(power)) with power <= 0 (forward.cu:327-333): under 1/255 at EVERY pixel when o is
-    // (NaN compares false: evaluated in full).  Such a Gaussian gets an empty rect — no tile pair ever scans into it —
-    // and, unless its radius is asked for, no covariance work either.  Free space in a trained OcRF is mostly this.
-    const bool unseen = co < 1.0f / 255.0f;
-    const long dyn = (long)s * set_stride;
-    auto record = [&](int v, int cur, const float4 q0, const float4 q1) {
-      const int zi = l_v2i[s * 32 + v];
-      const float A[2][3] = {{q0.x, q0.y, q0.z}, {q0.w, q1.x, q1.y}};
-      Rect rect = Rect{0, 0, 0, 0};
-      int rad = 0;
-      // (No conservative early-out by the Gaussian's own radius bound here, unlike the per-call preprocess: the plan's
-      // static cull already removed what can never be seen, so the test rarely fired and its square root cost every
-      // record; conic_radius_rect finds an empty rect itself, with the same outputs: 16.5 -> 15.6 us per six views.)
-#ifdef OCRF_UPDATE_EARLY_OUT
-      if ((!unseen || radii) && !surely_outside(q1.z, q1.w, radius_bound(A, rn), gx, gy)) {
-#else
-      if (!unseen || radii) {
-#endif
-        float cov_x, cov_y, cov_z, con_x, con_y, con_z;
-        cov2d(A, c3, &cov_x, &cov_y, &cov_z);
-        if (conic_radius_rect(cov_x, cov_y, cov_z, q1.z, q1.w, gx, gy, &con_x, &con_y, &con_z, &rad, &rect)) {
-          d_con[dyn + cur] = make_float4(-0.5f * con_x, -0.5f * con_z, con_y, co);      // Gaussian-major: coalesced
-          if (!unseen) tighten_rect_fwd(co, cov_x, cov_z, q1.z, q1.w, gx, gy, &rect);      // (the radius stays the reference's)
-        } else {
-          rect = Rect{0, 0, 0, 0};
-          rad = 0;
-        }
-      }
-      d_rect[dyn + cur] = unseen ? Rect{0, 0, 0, 0} : rect;
-      if (radii) radii[((long)s * vps + zi) * P + id] = rad;
-    };
-#pragma unroll
-    for (int j = 0; j < kPre; ++j)                              // record j of the Gaussian = its j-th kept view (ascending)
-      if (pv[j] >= 0 && ((mset >> pv[j]) & 1u) != 0u) record(pv[j], e0 + j, pq0[j], pq1[j]);
-    if (__popc(m) > kPre) {                                     // rare: a Gaussian kept by more than kPre views
-      unsigned mm = m;
-#pragma unroll
-      for (int j = 0; j < kPre; ++j) mm &= mm - 1;
-      int cur = e0 + kPre;
-      while (mm) {
-        const int v = __ffs(mm) - 1;
-        mm &= mm - 1;
-        if ((mset >> v) & 1u) record(v, cur, e_q0[cur], e_q1[cur]);
-        ++cur;
-      }
-    }
-  }
-  if (__ballot(any_bad) != 0ull && (threadIdx.x & 63) == 0) {
-    atomicOr(status, 4);
-    if (flag) atomicOr(flag, 1);
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // The parameter-dependent half of ONE record (forward.cu:201-256): conic / tile rect from the Gaussian's parameters and
-// the plan's rows of J W.  The same inline arithmetic as raster_plan_update_kernel (raster_common.h): same bits.
-//   con = (-0.5 conic.x, -0.5 conic.z, conic.y, opacity); rect (0,0,0,0): not rendered this step.
+// the plan's rows of J W (raster_common.h: the per-call preprocess's arithmetic, same bits).
+//   con = (-0.5 conic.x, -0.5 conic.z, conic.y, opacity); rect (0,0,0,0): not rendered this step; *rad: the reference's
+//   integer radius (0: none) — computed for an invisible Gaussian (opacity < 1/255) only when the caller asks for it.
 // ---------------------------------------------------------------------------------------------
 // The tile rect of a record, tightened by its OPACITY.  alpha = min(0.99, o exp(power)) reaches 1/255 only where
 // power >= -ln(255 o), i.e. inside the ellipse d^T Sigma^-1 d <= k = 2 ln(255 o) around the projected centre, whose bounding
@@ -636,11 +469,6 @@ __device__ __forceinline__ void tighten_rect(float o, float cov_x, float cov_z, 
   r->x0 = (unsigned short)x0; r->y0 = (unsigned short)y0; r->x1 = (unsigned short)x1; r->y1 = (unsigned short)y1;
 }
 
-__device__ __forceinline__ void tighten_rect_fwd(float o, float cov_x, float cov_z, float pixx, float pixy, int gx, int gy,
-                                                 Rect* r) {
-  tighten_rect(o, cov_x, cov_z, pixx, pixy, gx, gy, r);
-}
-
 struct SetParams {
   const float* opacities;      // (n_sets, P)
   const float* scales;         // (n_sets, P, 3)
@@ -649,11 +477,16 @@ struct SetParams {
 };
 
 __device__ __forceinline__ void dyn_record(const SetParams& sp, long gi, const float4 q0, const float4 q1, int gx, int gy,
-                                           Rect* rect, float4* con) {
+                                           Rect* rect, float4* con, int* rad_out = nullptr) {
   *rect = Rect{0, 0, 0, 0};
   *con = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (rad_out) *rad_out = 0;
   const float o = sp.opacities[gi];
-  if (o < 1.0f / 255.0f) return;                   // under 1/255 at every pixel (NaN compares false: evaluated)
+  // alpha = min(0.99, o exp(power)) with power <= 0 (forward.cu:327-333): under 1/255 at EVERY pixel when o is (NaN
+  // compares false: evaluated in full).  Such a Gaussian gets an empty rect — no tile pair ever scans into it — and, unless
+  // its radius is asked for, no covariance work either.  Free space in a trained OcRF is mostly this.
+  const bool unseen = o < 1.0f / 255.0f;
+  if (unseen && !rad_out) return;
   const float sx = sp.scale_modifier * sp.scales[3 * gi], sy = sp.scale_modifier * sp.scales[3 * gi + 1],
               sz = sp.scale_modifier * sp.scales[3 * gi + 2];
   float c3[6];
@@ -665,6 +498,8 @@ __device__ __forceinline__ void dyn_record(const SetParams& sp, long gi, const f
   int rad = 0;
   Rect r;
   if (conic_radius_rect(cov_x, cov_y, cov_z, q1.z, q1.w, gx, gy, &con_x, &con_y, &con_z, &rad, &r)) {
+    if (rad_out) *rad_out = rad;                     // (the reference's radius: not tightened, not opacity-dependent)
+    if (unseen) return;
     tighten_rect(o, cov_x, cov_z, q1.z, q1.w, gx, gy, &r);
     *rect = r;
     *con = make_float4(-0.5f * con_x, -0.5f * con_z, con_y, o);
@@ -692,7 +527,7 @@ __device__ __forceinline__ int head_of(const int* ctl, int v, int nv, int force)
 // ---------------------------------------------------------------------------------------------
 // step 1 (no radii asked): the HEAD of every rendered view's list.
 // A tile pair stops scanning its view's depth-ordered list as soon as all its pixels are saturated — at cfg2 after
-// ~500 of 120 000 entries — so computing conic / rect of EVERY record in front of the blend (raster_plan_update_kernel:
+// ~500 of 120 000 entries — so computing conic / rect of EVERY record in front of the blend (rounds 3-4's update kernel:
 // 120 MB, 32 us, and the blend cannot start before it) prepares a hundred times what is read.  Here only the first
 // head[v] entries of each rendered view are prepared, in LIST order (the blend's scan reads them coalesced, no list ->
 // record indirection); beyond them the blend computes a record itself when it gets there (same inline arithmetic, same
@@ -720,6 +555,8 @@ struct HeadArgs {
   int guard;
   const unsigned* call_cams;
   const unsigned* plan_cams;
+  int* radii;                    // (n_items, P) or null: the radius of every listed (item, Gaussian) pair (zero-filled before)
+  int all;                       // 1: every entry of every rendered view's list (radii asked for as an output)
 };
 
 // entries [lo, hi) of item z's list (plan view v): conic / tile rect into the dynamic arrays, in list order; this
@@ -733,10 +570,12 @@ __device__ __forceinline__ void prepare_entries(const HeadArgs& a, int z, int v,
     const unsigned id = a.s_id[off + i], e = a.s_e[off + i];
     Rect rect;
     float4 con;
-    dyn_record(a.sp, (long)set * a.P + id, a.e_q0[e], a.e_q1[e], gx, gy, &rect, &con);
+    int rad;
+    dyn_record(a.sp, (long)set * a.P + id, a.e_q0[e], a.e_q1[e], gx, gy, &rect, &con, a.radii ? &rad : nullptr);
     const long d = (long)set * a.set_stride + off + i;
     a.d_rect[d] = rect;
     a.d_con[d] = con;
+    if (a.radii) a.radii[(long)z * a.P + id] = rad;
   }
 }
 
@@ -785,7 +624,7 @@ __global__ __launch_bounds__(kBlock) void raster_plan_head_kernel(HeadArgs a) {
   const int* view_off = header + kHeaderInts;
   const int nv = view_off[v + 1] - view_off[v];
   // entries [0, head) of the item's list, this workgroup every blocks_per_item-th chunk of 256
-  prepare_entries(a, z, v, 0, head_of(a.ctl, v, nv, a.force_head), b % a.blocks_per_item, a.blocks_per_item);
+  prepare_entries(a, z, v, 0, a.all ? nv : head_of(a.ctl, v, nv, a.force_head), b % a.blocks_per_item, a.blocks_per_item);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -873,7 +712,7 @@ struct BlendArgs {
   int chain_hist_words;
   const int* yield_if;
   int base_grid;
-  int full;                      // 1: raster_plan_update_kernel prepared EVERY record, in Gaussian-major order
+  int full;                      // 1: the head kernel prepared EVERY record of every rendered view (radii as an output)
   int force_head;
   int variant;                   // diagnostic (ocrf_tune_set 14): bit 0 = no no-stop loops, bit 1 = the GENERIC loop only
   int n_sets;
@@ -996,14 +835,12 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(BlendArgs g) {
   const int set = z / g.vps;
   const int tyA = 2 * ty2, tyB = tyA + 1;
   const int off = __builtin_amdgcn_readfirstlane(l_voff[v]), nv = __builtin_amdgcn_readfirstlane(l_voff[v + 1]) - off;
-  // list entries [0, head) have their conic / rect in the dynamic arrays (list order; Gaussian-major through s_e after
-  // the full update).  A tile pair that scans beyond them EXTENDS the arrays itself, 256 entries at a time, before it
-  // reads them (same inline arithmetic as the head kernel; several workgroups may write an entry: the same bytes)
-  // (first pass: a tile pair never prepares records itself — it is handed to the second pass when it needs one)
+  // list entries [0, head) have their conic / rect in the dynamic arrays, in list order.  First pass: a tile pair never
+  // prepares records itself — it is handed to the second pass when it needs one behind the head
   const int head = (g.full || g.pass == 2) ? nv : __builtin_amdgcn_readfirstlane(l_head[v]);
   const long dyn = (long)set * g.set_stride;
   const float* set_colors = g.colors + 3 * (long)set * g.P;
-  auto dyn_index = [&](int i) { return dyn + (g.full ? (long)g.s_e[off + i] : (long)(off + i)); };
+  auto dyn_index = [&](int i) { return dyn + (long)(off + i); };
   // what this tile pair scans: the first n_direct entries of the view's list as they come, then its bin's candidates
   // (positions into the view's list, ascending) from the first one behind them; without lists the whole list
   // (read here, used behind the direct region.  Read only by the tile pairs that get there — most of a saturating scene's
@@ -1432,7 +1269,6 @@ int resident_blocks(K kernel) {
   return cached[dev];
 }
 
-int g_update_lds = 0;       // ocrf_tune_set(12, bytes): dynamic LDS padding of the update kernel = an occupancy cap (diagnostic)
 int g_plan_grid = 0;        // ocrf_tune_set(11, n): workgroups of the persistent blend (0 = what the device holds at once)
 int g_blend_variant = 0;    // ocrf_tune_set(14, bits): diagnostic loop selection of the planned blend
 int g_single_pass = 0;      // ocrf_tune_set(15, 1): no second pass (diagnostic: what the two launches behind the first pass cost)
@@ -1444,7 +1280,6 @@ unsigned long long* g_plan_stats = nullptr;      // ocrf_diag_plan_stats: the ne
 namespace ocrf {
 void raster_plan_tune(int key, int value) {
   if (key == 11) g_plan_grid = value > 0 ? value : 0;
-  if (key == 12) g_update_lds = value > 0 ? value : 0;
   if (key == 13) g_head_force = value;
   if (key == 14) g_blend_variant = value;
   if (key == 15) g_single_pass = value;
@@ -1712,7 +1547,6 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
   auto* d_rect = reinterpret_cast<Rect*>(wb + D.rect);
   auto* d_con = reinterpret_cast<float4*>(wb + D.con);
   int* ctl = reinterpret_cast<int*>(wb + D.flag);
-  int* queue = ctl + kCtlQueue;
   int* deferred = reinterpret_cast<int*>(wb + D.deferred);
   if ((long)gx * ((gy + 1) / 2) * n_items > kMaxDeferred) return (int)hipErrorInvalidValue;
   // candidate lists (optional; bin_w / bin_h / cand_capacity as given to ocrf_raster_plan_bins_build).  Whether the
@@ -1747,10 +1581,11 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
     flag = ctl;
     chain_hist = ocrf::raster_chain_hist(chain_workspace, P, n_items, &chain_hist_words);
   }
-  // radii asked for as an OUTPUT (guard bit 1, or radii without a guard): EVERY record is prepared, one thread per
-  // Gaussian, in Gaussian-major order (raster_plan_update_kernel); else only the head of each rendered view's list, in list
-  // order — with the device guard (its radii buffer is the armed chain's own) the extent check then runs FIRST: the
-  // blend has to know whether to leave the call to the chain
+  // radii asked for as an OUTPUT (guard bit 1, or radii without a guard): EVERY record of every rendered view is prepared
+  // by the head kernel, which also writes the radius of every listed (item, Gaussian) pair into the zero-filled output
+  // (round 6: the one-thread-per-Gaussian update kernel of rounds 3-5 — 163 VGPRs, Gaussian-major arrays the blend read
+  // through an indirection — is gone); else only the head of each view's list.  With the device guard (its radii buffer
+  // is the armed chain's own) the extent check runs FIRST: the blend has to know whether to leave the call to the chain
   const bool full = radii != nullptr && (guard == 0 || (guard & 2) != 0);
   const SetParams sp{opacities, scales, rotations, scale_modifier};
   HeadArgs h;
@@ -1766,25 +1601,21 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
   h.sp = sp; h.d_rect = d_rect; h.d_con = d_con; h.status = status; h.ctl = ctl; h.guard = guard ? 1 : 0;
   h.call_cams = reinterpret_cast<const unsigned*>(call_cameras);
   h.plan_cams = reinterpret_cast<const unsigned*>(cams);
+  h.radii = full ? radii : nullptr;
+  h.all = full ? 1 : 0;
   if (phase != 2) {
-    if (full) {
-      ocrf::launch(OCRF_K_RASTER_PLAN_UPDATE, raster_plan_update_kernel, dim3((P + kBlock - 1) / kBlock),
-                   dim3(kBlock), (size_t)g_update_lds, stream, P, vps, n_sets, set_stride, total_kept, header,
-                   reinterpret_cast<const unsigned*>(pb + L.g_mask),
-                   reinterpret_cast<const int*>(pb + L.g_off),
-                   reinterpret_cast<const float4*>(pb + L.e_q0), reinterpret_cast<const float4*>(pb + L.e_q1), item_view,
-                   opacities, scales, scale_modifier, rotations, d_rect, d_con, radii, status, flag, queue,
-                   reinterpret_cast<const unsigned*>(call_cameras), reinterpret_cast<const unsigned*>(cams));
-    } else {
-      if (guard) {      // (behind the blend otherwise: there it is a status bit only)
-        const long n_pairs = (long)n_sets * P;
-        hipLaunchKernelGGL(raster_plan_check_kernel, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                           stream, n_pairs, header, scales, scale_modifier, rotations, status, flag, h, 0);
-      }
-      h.blocks_per_item = g_head_force < 0 ? 0 : kHeadBlocks;
-      ocrf::launch(OCRF_K_RASTER_PLAN_UPDATE, raster_plan_head_kernel,
-                   dim3((unsigned)std::max(1, n_items * h.blocks_per_item)), dim3(kBlock), 0, stream, h);
+    if (guard) {      // (behind the blend otherwise: there it is a status bit only)
+      const long n_pairs = (long)n_sets * P;
+      hipLaunchKernelGGL(raster_plan_check_kernel, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                         stream, n_pairs, header, scales, scale_modifier, rotations, status, flag, h, 0);
     }
+    if (full) {       // (item, Gaussian) pairs outside the lists: radius 0
+      const hipError_t ez = ocrf::zero_async(radii, (size_t)n_items * P * 4, stream);
+      if (ez != hipSuccess) return (int)ez;
+    }
+    h.blocks_per_item = (g_head_force < 0 && !full) ? 0 : kHeadBlocks;
+    ocrf::launch(OCRF_K_RASTER_PLAN_UPDATE, raster_plan_head_kernel,
+                 dim3((unsigned)std::max(1, n_items * h.blocks_per_item)), dim3(kBlock), 0, stream, h);
   }   // phase != 2
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
@@ -1836,7 +1667,7 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
   };
   e = blend(g, true);
   if (e != hipSuccess) return (int)e;
-  if (!full && !two_pass && !guard) {
+  if (!two_pass && !guard) {
     const long n_pairs = (long)n_sets * P;
     hipLaunchKernelGGL(raster_plan_check_kernel, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
                        n_pairs, header, scales, scale_modifier, rotations, status, static_cast<int*>(nullptr), h, 0);

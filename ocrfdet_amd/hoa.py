@@ -350,29 +350,6 @@ class OpacityVoxelToBEVConverter(nn.Module):
             return out
         return self._forward_blocks(x, position)
 
-    @torch.no_grad()
-    def forward_deferred(self, x, position):
-        """The eval-mode forward WITHOUT its last launch: five block kernels now; the output conv (:516) is left to the
-        HOA-3 gate kernel that consumes the opacity BEV (``ObatinOpacityMask.gate(x, deferred)`` ->
-        ``ocrf_hoa_opacity_mask_gate_v2b``): one dependent launch less on a latency chain, same bits.  -> a
-        ``DeferredOpacityBEV`` (its ``.value`` is the (B,1,H,W) opacity BEV once the gate has run), or the plain tensor
-        when the deferred form does not apply.  The library's 'hoa_v2b' scratch carries decoder1's activations until the
-        gate runs: no other converter forward on this device in between."""
-        B, _, H, W = x.shape
-        if (self.training or not x.is_cuda or not self._is_reference_architecture() or H % 4 or W % 4 or W > 256):
-            return self.forward(x, position)
-        _lib.require_cuda(x, position)
-        x, position = _f32c(x), _f32c(position)
-        dev = x.device
-        L = _lib.lib()
-        w = self._packed_v2b()
-        with _lib.on_device(dev):
-            ws = _lib.workspace.get(dev, L.ocrf_hoa_v2b_workspace_bytes(B, H, W), 'hoa_v2b')
-            _lib.check(L.ocrf_hoa_v2b_forward(_lib.ptr(x), _lib.ptr(position), _lib.ptr(w), B, H, W, _lib.ptr(ws),
-                                              ctypes.c_size_t(ws.numel()), None, _lib.stream_ptr(dev)),
-                       'ocrf_hoa_v2b_forward')
-        return DeferredOpacityBEV(ws, w, (B, H, W), dev)
-
     def _forward_blocks(self, x, position):
         """Any other channel configuration: block by block (5 block kernels + 5 gate kernels + the output conv)."""
         B, _, H, W = x.shape
@@ -393,15 +370,6 @@ class OpacityVoxelToBEVConverter(nn.Module):
                     _lib.check(L.ocrf_hoa_height_gate_from_tiles(*call[1], st), 'ocrf_hoa_height_gate_from_tiles')
             _lib.check(L.ocrf_hoa_gated_conv1x1(*plan['out_args'], _lib.ptr(out), st), 'ocrf_hoa_gated_conv1x1')
         return out
-
-
-class DeferredOpacityBEV:
-    """HOA-2's result one launch short (``OpacityVoxelToBEVConverter.forward_deferred``): the gate that consumes it
-    computes the opacity BEV in its prologue and stores it here as ``value``."""
-
-    def __init__(self, workspace, weights, shape, device):
-        self.workspace, self.weights, self.shape, self.device = workspace, weights, shape, device
-        self.value = None
 
 
 def channel_stats(x):
@@ -455,8 +423,6 @@ class ObatinOpacityMask(nn.Module):          # sic: the reference's spelling
         self.sigmoid = nn.Sigmoid()
 
     def _run(self, x, opacity_bev, want_gated, stats=None, in_place=False):
-        if isinstance(opacity_bev, DeferredOpacityBEV):
-            return self._run_deferred(x, opacity_bev, want_gated)
         _lib.require_cuda(x, opacity_bev)
         if torch.is_grad_enabled() and (x.requires_grad or opacity_bev.requires_grad or self.conv.weight.requires_grad):
             # forward-only HIP kernels: under autograd the reference's ops (:236-242), differentiable
@@ -464,29 +430,6 @@ class ObatinOpacityMask(nn.Module):          # sic: the reference's spelling
             mask = self.sigmoid(self.conv(stats) + opacity_bev)
             return mask, (x * mask if want_gated else None)
         return spatial_gate(self.conv.weight, x, opacity_bev, want_gated, stats=stats, in_place=in_place)
-
-    @torch.no_grad()
-    def _run_deferred(self, x, deferred, want_gated):
-        """HOA-2's output conv + HOA-3 in two launches (channel statistics, fused gate): ``deferred.value`` receives the
-        opacity BEV."""
-        _lib.require_cuda(x)
-        B, C, Y, X = x.shape
-        assert (B, Y, X) == tuple(deferred.shape), 'the deferred opacity BEV belongs to another map'
-        x = _f32c(x)
-        w = _f32c(self.conv.weight)
-        stats = torch.empty(B, 2, Y, X, device=x.device)
-        mask = torch.empty(B, 1, Y, X, device=x.device)
-        gated = torch.empty_like(x)
-        deferred.value = torch.empty(B, 1, Y, X, device=x.device)
-        L = _lib.lib()
-        with _lib.on_device(x.device):
-            st = _lib.stream_ptr(x.device)
-            _lib.check(L.ocrf_hoa_channel_stats(_lib.ptr(x), B, C, Y, X, _lib.ptr(stats), st), 'ocrf_hoa_channel_stats')
-            _lib.check(L.ocrf_hoa_opacity_mask_gate_v2b(_lib.ptr(x), _lib.ptr(stats), _lib.ptr(deferred.workspace),
-                                                        _lib.ptr(deferred.weights), _lib.ptr(w), int(w.shape[-1]), B, C, Y, X,
-                                                        _lib.ptr(deferred.value), _lib.ptr(mask), _lib.ptr(gated), st),
-                       'ocrf_hoa_opacity_mask_gate_v2b')
-        return mask, (gated if want_gated else None)
 
     def forward(self, x, opacity_bev):
         return self._run(x, opacity_bev, False)[0]

@@ -189,7 +189,7 @@ class RasterPlan:
         ``yield_if``: int32 device word — with it the blend takes every slot of the device and the workgroups beyond
         ``blend_workgroups`` leave at once while the word is non-zero (a scheduling hint: same image either way).
         ``want_radii``: the per-(item, Gaussian) radii as an output ``radii`` (n_items,P) — the call then prepares EVERY
-        record in front of the blend (the full update kernel) instead of the head of each view's list.  None: yes with
+        record in front of the blend (the head kernel over the whole lists) instead of the head of each view's list.  None: yes with
         ``guard='device'`` (what a fired guard's per-call chain writes anyway), no with the host guard; a device-guarded
         caller that does not read them passes False and keeps the short front end.
         ``phase``: 'both', or 'update' then (same arguments, same ``out``) 'blend' — possibly on another stream, ordered by
@@ -227,7 +227,7 @@ class RasterPlan:
                        final_T=torch.empty(n_items, H, W, device=dev))
         if want_radii is None:
             want_radii = guard == 'device'
-        # 1: device guard; + 2: the radii are an OUTPUT of the call (every record is then prepared by the full update
+        # 1: device guard; + 2: the radii are an OUTPUT of the call (every record is then prepared by the head
         # kernel); a device-guarded call without want_radii hands the armed chain a radii buffer of its own only
         use_guard = {'host': 0, 'device': 1}[guard] | (2 if (want_radii and guard == 'device') else 0)
         self._host_guarded = self._host_guarded or not use_guard

@@ -158,32 +158,6 @@ def test_opacity_voxel_to_bev_six_launch_form_on_other_map_sizes(cuda, g, B, H, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('B,H,W', [(2, 200, 200), (3, 100, 60), (1, 36, 52), (1, 16, 16), (2, 128, 256)])
-def test_output_conv_folded_into_the_hoa3_gate(cuda, g, B, H, W):
-    """``forward_deferred`` (HOA-2 without its last launch) + ``ObatinOpacityMask.gate(x, deferred)`` (the output conv in
-    the gate kernel's prologue) against the two separate calls: opacity BEV, mask and gated BEV bit for bit; maps wider
-    than 256 fall back to the separate calls."""
-    v2b = hoa.OpacityVoxelToBEVConverter(13).to(cuda).eval()
-    v2b.load_state_dict(_sd(g, 'v2b'))
-    torch.manual_seed(H + W)
-    mask_mod = hoa.ObatinOpacityMask().to(cuda).eval()
-    rng = np.random.default_rng(H * 7 + W)
-    xt = torch.from_numpy(rng.random((B, 13, H, W), dtype=np.float32)).to(cuda)
-    pt = torch.from_numpy((rng.standard_normal((B, 4, H, W)) * 0.1).astype(np.float32)).to(cuda)
-    feat = torch.from_numpy(rng.standard_normal((B, 80, H, W)).astype(np.float32)).to(cuda)
-    with torch.no_grad():
-        ob = v2b(xt, pt)
-        mask, gated = mask_mod.gate(feat, ob)
-        d = v2b.forward_deferred(xt, pt)
-        assert isinstance(d, hoa.DeferredOpacityBEV) and d.value is None
-        mask2, gated2 = mask_mod.gate(feat, d)
-    assert torch.equal(d.value, ob) and torch.equal(mask2, mask) and torch.equal(gated2, gated)
-    wide = torch.zeros(1, 13, 8, 260, device=cuda)
-    with torch.no_grad():
-        assert torch.is_tensor(v2b.forward_deferred(wide, torch.zeros(1, 4, 8, 260, device=cuda)))
-
-
-@pytest.mark.gpu
 def test_hoa1_gpu(cuda, g):
     m = hoa.DeformableAttention2D(dim=13, dim_head=8, heads=1, dropout=0.1, downsample_factor=4, offset_scale=4,
                                   offset_groups=None, offset_kernel_size=6).to(cuda).eval()
