@@ -34,6 +34,7 @@
 
 #include "launch.h"
 #include "ocrf_hip.h"
+#include "raster_blend_body.h"
 #include "raster_blend_math.h"
 #include "radix_emit.h"
 #include "raster_common.h"
@@ -44,22 +45,15 @@ using namespace rc;
 
 constexpr unsigned kPlanMagic = 0x4F435250u;      // "OCRP"
 constexpr int kHeaderInts = 16;                   // magic, P, V, H, W, gx, gy, bound bits, total lo, total hi, ...
-#ifndef OCRF_PLAN_STAGE
-#define OCRF_PLAN_STAGE 128
-#endif
 #ifndef OCRF_PLAN_SCAN
 #define OCRF_PLAN_SCAN 1      // 256 rects per scan round.  Measured on one box (tools/ab_gauss.sh), cfg2 step / blend alone: init
                               // 0.215 ms / 137 us with 1, 0.219 / 141 with 2, 0.225 / 144 with 4 (the unrolled round's registers
                               // and instructions are paid in the direct region too); objects 2.07 / 1.53 ms, 2.04 / 1.51, 2.00 / 1.49:
                               // a candidate costs ~ 4 ns per workgroup whatever the round's width — issue-bound, not latency-bound
 #endif
-constexpr int kStageP = OCRF_PLAN_STAGE;          // records staged per batch (a tile pair saturates after ~110 at cfg2)
+constexpr int kStageP = rbody::kStageB;           // records staged per batch (raster_blend_body.h)
 constexpr int kScanUnrollP = OCRF_PLAN_SCAN;      // rect batches in flight in the scan
-constexpr int kTrip = 2;                          // records per trip of the blend loop (the no-stop bound is per pair)
-constexpr int kStageParts = kBlock / kStageP;     // threads per staged record: each tests 4 / kStageParts waves
-constexpr int kReachPerThread = 4 / kStageParts;
-constexpr int kSrcWaves = kStageP / 64;           // waves that hold one copy of the staged batch
-static_assert(kStageP == 128 || kStageP == 256, "one or two threads per staged record");
+constexpr int kSrcWaves = rbody::kSrcWavesB;
 constexpr int kCapPos = kStageP + kScanUnrollP * kBlock;
 constexpr unsigned kPosMask = 0x3FFFFFFFu;
 
@@ -736,7 +730,7 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(BlendArgs g) {
   __shared__ unsigned l_pos[kCapPos];
   __shared__ float4 l_a[kStageP + 1], l_b[kStageP + 1], l_c[kStageP + 1];
   // (aligned: a trip reads an entry PAIR as one 32-bit word; rows are 268 bytes)
-  __shared__ __attribute__((aligned(16))) unsigned short l_list[4][kStageP + 2 * kTrip + 2];
+  __shared__ __attribute__((aligned(16))) unsigned short l_list[4][rbody::kListLen];
   __shared__ int l_wtot[kScanUnrollP * 4];
   __shared__ int l_lcnt[kSrcWaves][4];        // [source wave of the batch copy][destination wave]
   __shared__ int l_generic[4];                // [wave]: its list of this batch holds a GENERIC record
@@ -874,16 +868,24 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(BlendArgs g) {
   bool all_done = false;
   bool blocked = false;                        // the next candidate is not prepared (first pass only)
   // diagnostic build only: phase cycles and record counts of this workgroup
-  unsigned long long t_prev = 0, t_acc[3] = {0, 0, 0};
-  unsigned n_staged = 0, n_listed = 0, n_eval = 0;
-  auto stamp = [&](int slot) {
-    if constexpr (STATS) {
-      const unsigned long long t = __builtin_amdgcn_s_memrealtime()      /* 100 MHz */;
-      if (slot >= 0) t_acc[slot] += t - t_prev;
-      t_prev = t;
+  struct Diag {
+    unsigned long long t_prev = 0, t_acc[3] = {0, 0, 0};
+    unsigned n_staged = 0, n_listed = 0, n_eval = 0;
+    __device__ __forceinline__ void stamp(int slot) {
+      if constexpr (STATS) {
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime()      /* 100 MHz */;
+        if (slot >= 0) t_acc[slot] += t - t_prev;
+        t_prev = t;
+      }
     }
-  };
+  } diag;
+  auto stamp = [&](int slot) { diag.stamp(slot); };
   stamp(-1);
+  rbody::Tile tile;
+  tile.tyA = tyA; tile.wave = wave; tile.lane = lane; tile.tid = tid;
+  tile.pixf_x = pixf_x; tile.pixf_y = pixf_y; tile.inside0 = inside0; tile.inside1 = inside1;
+  tile.bx0 = bx0; tile.bx1 = bx1;
+  const rbody::Lds lds{l_a, l_b, l_c, l_list, l_lcnt, l_generic, l_fmax};
   while (!all_done) {
     // ---- scan: positions of the candidates whose rect covers this tile pair, in list (= blend) order ----
     while (scan < nc && npos < kStageP && !blocked) {
@@ -946,238 +948,20 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(BlendArgs g) {
     if (npos == 0) break;                     // list exhausted
     for (int s0 = 0; s0 < npos && !all_done; s0 += kStageP) {
       const int ns = min(kStageP, npos - s0);
-      if constexpr (STATS) n_staged += ns;
-      // ---- stage ns records; which waves can each one reach?  kStageParts threads per record, each testing
-      // kReachPerThread of the four waves (the copies of the batch live in waves [part * kSrcWaves, ...)) ----
-      const int part = tid / kStageP, ri = tid % kStageP;
-      bool reach[kReachPerThread];
-      bool simple = true;
-      float nfac = 0.f;
-#pragma unroll
-      for (int j = 0; j < kReachPerThread; ++j) reach[j] = false;
-      if (tid < 4) {
-        l_generic[tid] = 0;
-        l_fmax[tid] = 0;
-      }
-      if (ri < ns) {
+      // ---- stage ns records, build the four waves' lists, blend them (raster_blend_body.h) ----
+      auto fetch = [&](int ri) {
         const unsigned code = l_pos[s0 + ri];
         const int li = (int)(code & kPosMask);
-        const float4 con = g.d_con[dyn_index(li)];
-        const float2 pix = g.s_pix[off + li];
-        const float o = con.w;
-        // the power below which alpha = o exp(power) is under 1/255 whatever the pixel (1 % margin for v_exp_f32
-        // and the log2(e) multiply); o <= 0: +inf (never rendered); NaN opacity: NaN (evaluated in full)
-        const float thr = (o > 0.f) ? (__logf(1.0f / (255.0f * o)) - 0.01f) : ((o <= 0.f) ? INFINITY : o);
-        simple = rb::is_simple(con);
-        nfac = rb::need_factor(o, simple);
-        if (part == 0) {
-          const float* col = set_colors + 3 * (long)g.s_id[off + li];
-          const rb::Staged st = rb::stage(con, pix.x, pix.y, col[0], col[1], col[2],
-                                          __uint_as_float(g.s_key[off + li]), simple);
-          l_a[ri] = st.a;
-          l_b[ri] = st.b;
-          l_c[ri] = st.c;
-        }
-        // alpha >= 1/255 needs power >= thr, i.e. Q(dx, dy) = 0.5 (A dx^2 + C dy^2) + B dx dy <= -thr.  The minimum of
-        // the convex Q over a wave's pixel block (a box in (dx, dy)) is 0 if the centre lies inside, else it is on
-        // the box's boundary: per edge a clamped 1-D minimiser.  The block is skipped only if that minimum exceeds
-        // -thr by more than the rounding of both evaluations (<= 1e-6 of the sum of the terms' magnitudes; 4e-6
-        // is allowed for, and 1e-3 absolute: more than the difference between the two evaluation orders of
-        // raster_blend_math.h) — so a skipped record has alpha < 1/255 at every pixel of the block, where the
-        // reference skips it too (forward.cu:331-333).  Anything unusual (NaN, non-convex conic) is evaluated in full.
-        const float qa = -2.f * con.x, qc = -2.f * con.y, qb = con.z;
-        const bool convex = (qa > 0.f) && (qc > 0.f) && (qa * qc - qb * qb > 0.f);
-        const bool never = thr >= 0.f;                         // opacity < 1/255: no pixel ever blends it
-        const float lim = -thr;
-        const float inv_a = 1.f / qa, inv_c = 1.f / qc;
-        const float dxlo = pix.x - bx1, dxhi = pix.x - bx0;
-        const float Dx = fmaxf(fabsf(dxlo), fabsf(dxhi));
-#pragma unroll
-        for (int j = 0; j < kReachPerThread; ++j) {
-          const int w = part * kReachPerThread + j;
-          const bool cov = (w < 2) ? ((code & 0x40000000u) != 0u) : ((code & 0x80000000u) != 0u);
-          const float by0 = (float)(tyA * kTileY + 8 * w), by1 = by0 + 7.f;
-          const float dylo = pix.y - by1, dyhi = pix.y - by0;
-          const float Dy = fmaxf(fabsf(dylo), fabsf(dyhi));
-          bool skip = false;
-          if (convex && !(thr != thr)) {
-            const bool in_x = (dxlo <= 0.f) && (dxhi >= 0.f), in_y = (dylo <= 0.f) && (dyhi >= 0.f);
-            if (!(in_x && in_y)) {
-              auto Q = [&](float dx, float dy) { return 0.5f * (qa * dx * dx + qc * dy * dy) + qb * dx * dy; };
-              auto clampf = [](float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); };
-              const float q0 = Q(dxlo, clampf(-qb * dxlo * inv_c, dylo, dyhi));
-              const float q1 = Q(dxhi, clampf(-qb * dxhi * inv_c, dylo, dyhi));
-              const float q2 = Q(clampf(-qb * dylo * inv_a, dxlo, dxhi), dylo);
-              const float q3 = Q(clampf(-qb * dyhi * inv_a, dxlo, dxhi), dyhi);
-              const float qmin = fminf(fminf(q0, q1), fminf(q2, q3));
-              const float M = 0.5f * (qa * Dx * Dx + qc * Dy * Dy) + fabsf(qb) * Dx * Dy;
-              skip = (qmin - 4e-6f * M - 1e-3f) > lim;
-            }
-          }
-          reach[j] = cov && !never && !skip;
-        }
-      }
-      // ordered per-wave lists of staged indices: the kSrcWaves waves of a part hold the batch in order
-      const int src = wave % kSrcWaves;
-      int lrank[kReachPerThread];
-#pragma unroll
-      for (int j = 0; j < kReachPerThread; ++j) {
-        const unsigned long long m = __ballot(reach[j]);
-        lrank[j] = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) l_lcnt[src][part * kReachPerThread + j] = __popcll(m);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < kReachPerThread; ++j) {
-        const int w = part * kReachPerThread + j;
-        int base = 0, tot = 0;
-#pragma unroll
-        for (int sw = 0; sw < kSrcWaves; ++sw) {
-          const int c = l_lcnt[sw][w];
-          if (sw < src) base += c;
-          tot += c;
-        }
-        if (reach[j]) {
-          // entry = the record's byte offset in the staged arrays | SIMPLE flag
-          l_list[w][base + lrank[j]] = (unsigned short)((ri << 4) | (simple ? 0x8000 : 0));
-          if (!simple) l_generic[w] = 1;
-          // positive floats order like their bits; a NaN factor (NaN opacity) wins: "may stop" throughout
-          atomicMax(&l_fmax[w], __float_as_int(nfac));
-        }
-        if (ri == 0) {                         // pad: a trip reads kTrip entries whatever the list's length
-#pragma unroll
-          for (int q = 0; q < 2 * kTrip; ++q) l_list[w][tot + q] = (unsigned short)((kStageP << 4) | 0x8000);
-        }
-      }
-      int n_mine = 0;                          // length of THIS wave's list
-#pragma unroll
-      for (int sw = 0; sw < kSrcWaves; ++sw) n_mine += l_lcnt[sw][wave];
-      __syncthreads();
-      n_mine = __builtin_amdgcn_readfirstlane(n_mine);
-      const bool generic_batch = __builtin_amdgcn_readfirstlane(l_generic[wave]) != 0 || (g.variant & 2);
-      // no record of this wave's list can trip the stop test while every pixel inside the image has T > need
-      // (raster_blend_math.h: no_stop_need, with the list's largest factor for both records of a trip)
-      const float fmax_w = __int_as_float(__builtin_amdgcn_readfirstlane(l_fmax[wave]));
-      const float need = rb::no_stop_need(fmax_w, fmax_w);
-      if constexpr (STATS) n_listed += n_mine;
-      stamp(1);
-
-      // ---- blend this wave's records front to back (raster_blend_math.h), two records per trip: two independent
-      // exponent / alpha chains in flight.  Measured issue costs on gfx950 (tools/ubench/valu_cost.hip; plain VALU = 1):
-      // packed f32 1.4 (for two pixels), v_exp_f32 2.4, a compare + select pair 2.5 — so the loop carries no decision
-      // whose outcome is known for the whole wave: the loops run in the order (median count, no stop) -> (median
-      // count, stop) -> (no count, no stop) -> (no count, stop), each leaving when its own condition ends.  A SIMD
-      // holds five waves of this kernel; they hide the two dependent LDS reads of a trip (list entry -> record).
-      {
-        const unsigned short* mylist = l_list[wave];
-        const char* la = reinterpret_cast<const char*>(l_a);
-        const char* lb = reinterpret_cast<const char*>(l_b);
-        const char* lc = reinterpret_cast<const char*>(l_c);
-        struct Rec { float4 a, b; float L, dep; };
-        auto load1 = [&](unsigned byte_off, Rec* q) {
-          q->a = *reinterpret_cast<const float4*>(la + byte_off);
-          q->b = *reinterpret_cast<const float4*>(lb + byte_off);
-          if constexpr (MEDIAN) {
-            q->L = *reinterpret_cast<const float*>(lc + byte_off);
-            q->dep = 0.f;
-          } else {
-            const float4 c = *reinterpret_cast<const float4*>(lc + byte_off);
-            q->L = c.x;
-            q->dep = c.z;
-          }
-        };
-        auto load = [&](int k, Rec* rec) {
-          const unsigned pair = *reinterpret_cast<const unsigned*>(mylist + k);
-          load1(pair & 0x7FF0u, &rec[0]);
-          load1((pair >> 16) & 0x7FF0u, &rec[1]);
-        };
-        auto one = [&](auto med_tag, auto nostop_tag, auto generic_tag, const Rec& q, bool simple_rec) {
-          constexpr bool MED = decltype(med_tag)::value, NOSTOP = decltype(nostop_tag)::value;
-          constexpr bool GEN = decltype(generic_tag)::value;
-          const float dx = q.a.w - pixf_x;
-          const f2 dy = splat(q.a.x) - pixf_y;
-          f2 alpha, s;
-          auto fast = [&]() {
-            const float t = q.b.z * dx;
-            const float nb = q.b.w * dx;
-            const float qxl = __builtin_fmaf(t, dx, q.L);
-            rb::alpha_simple(nb, q.a.y, splat(qxl), dy, kc, &alpha, &s);
-          };
-          if constexpr (GEN) {
-            if (simple_rec) fast();
-            else rb::alpha_generic(dx, q.b.z, q.b.w, q.a.y, splat(q.L), dy, &alpha, &s);
-          } else {
-            fast();
-          }
-          rb::chain<MEDIAN && MED, !MEDIAN, NOSTOP>(px, alpha, s, q.a.z, q.b.x, q.b.y, q.dep, kc);
-        };
-        // wave-level tests, each two compares on the VALU and scalar logic (a ballot of a combined predicate costs a
-        // select + a compare more).  Stopped and outside pixels carry T < 0: as integers their bits are negative.
-        const unsigned long long in0 = __ballot(inside0), in1 = __ballot(inside1);
-        auto may_stop = [&]() {
-          return ((__ballot(!(px.T.x > need)) & in0) | (__ballot(!(px.T.y > need)) & in1)) != 0ull || (g.variant & 1);
-        };
-        auto any_above_half = [&]() {
-          return __ballot(max(__float_as_int(px.T.x), __float_as_int(px.T.y)) > 0x3F000000) != 0ull;
-        };
-        auto any_alive = [&]() { return __ballot((__float_as_int(px.T.x) & __float_as_int(px.T.y)) >= 0) != 0ull; };
-        int k = 0;
-        Rec rec[kTrip];
-        if (generic_batch) {
-          // rare (an opacity above 0.99, a nearly singular conic, NaNs): one loop, one record per trip, every decision
-          // per record (a second record in flight here costs the whole kernel a wave per SIMD in registers)
-          for (; k < n_mine; ++k) {
-            if (!any_alive()) break;
-            if constexpr (STATS) n_eval += 1;
-            const unsigned ent = __builtin_amdgcn_readfirstlane((unsigned)mylist[k]);
-            Rec q;
-            load1(ent & 0x7FF0u, &q);
-            if constexpr (MEDIAN) q.dep = 0.f;
-            one(std::true_type{}, std::false_type{}, std::true_type{}, q, (ent & 0x8000u) != 0u);
-          }
-        } else {
-          if constexpr (MEDIAN) {
-            for (; k < n_mine; k += kTrip) {
-              if (!any_above_half() || may_stop()) break;
-              if constexpr (STATS) n_eval += kTrip;
-              load(k, rec);
-              one(std::true_type{}, std::true_type{}, std::false_type{}, rec[0], true);
-              one(std::true_type{}, std::true_type{}, std::false_type{}, rec[1], true);
-            }
-            for (; k < n_mine; k += kTrip) {
-              if (!any_alive()) { k = n_mine; break; }
-              if (!any_above_half()) break;
-              if constexpr (STATS) n_eval += kTrip;
-              load(k, rec);
-              one(std::true_type{}, std::false_type{}, std::false_type{}, rec[0], true);
-              one(std::true_type{}, std::false_type{}, std::false_type{}, rec[1], true);
-            }
-          }
-          for (; k < n_mine; k += kTrip) {
-            if (may_stop()) break;
-            if constexpr (STATS) n_eval += kTrip;
-            load(k, rec);
-            one(std::false_type{}, std::true_type{}, std::false_type{}, rec[0], true);
-            one(std::false_type{}, std::true_type{}, std::false_type{}, rec[1], true);
-          }
-          for (; k < n_mine; k += kTrip) {
-            if (!any_alive()) break;                                        // every pixel stopped
-            if constexpr (STATS) n_eval += kTrip;
-            load(k, rec);
-            one(std::false_type{}, std::false_type{}, std::false_type{}, rec[0], true);
-            one(std::false_type{}, std::false_type{}, std::false_type{}, rec[1], true);
-          }
-        }
-        if constexpr (MEDIAN) {
-          // the record at which a pixel crossed 0.5 in this batch, if it did: looked up once (raster_blend_math.h)
-          const int m0 = rb::median_index(px.cnt.x, px.T.x), m1 = rb::median_index(px.cnt.y, px.T.y);
-          if (m0 >= 0) px.D.x = l_c[(mylist[m0] & 0x7FF0u) >> 4].z;
-          if (m1 >= 0) px.D.y = l_c[(mylist[m1] & 0x7FF0u) >> 4].z;
-          px.cnt = splat(0.f);
-        }
-      }
-      // every pixel saturated -> stop (forward.cu:304-307)
-      all_done = __syncthreads_count(rb::dead(px.T.x) && rb::dead(px.T.y)) == kBlock;
+        rbody::Fetched fr;
+        fr.con = g.d_con[dyn_index(li)];
+        fr.pix = g.s_pix[off + li];
+        fr.col = set_colors + 3 * (long)g.s_id[off + li];
+        fr.depth = __uint_as_float(g.s_key[off + li]);
+        fr.covA = (code & 0x40000000u) != 0u;
+        fr.covB = (code & 0x80000000u) != 0u;
+        return fr;
+      };
+      all_done = rbody::blend_batch<MEDIAN, STATS>(px, kc, tile, lds, ns, fetch, g.variant, diag);
       stamp(2);
     }
     npos = 0;
@@ -1200,10 +984,10 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(BlendArgs g) {
     // per wave: slot = workgroup * 4 + wave: scan, stage, blend cycles | scanned, staged, listed, evaluated records
     if (lane == 0) {
       const long w = (long)work * 4 + wave;
-      g.stats[w * 8 + 0] = t_acc[0]; g.stats[w * 8 + 1] = t_acc[1]; g.stats[w * 8 + 2] = t_acc[2];
-      g.stats[w * 8 + 3] = (unsigned long long)scan; g.stats[w * 8 + 4] = n_staged;
-      g.stats[w * 8 + 5] = n_listed; g.stats[w * 8 + 6] = n_eval;
-      g.stats[w * 8 + 7] = t_prev;                  // when this tile pair's last batch ended (100 MHz wall clock)
+      g.stats[w * 8 + 0] = diag.t_acc[0]; g.stats[w * 8 + 1] = diag.t_acc[1]; g.stats[w * 8 + 2] = diag.t_acc[2];
+      g.stats[w * 8 + 3] = (unsigned long long)scan; g.stats[w * 8 + 4] = diag.n_staged;
+      g.stats[w * 8 + 5] = diag.n_listed; g.stats[w * 8 + 6] = diag.n_eval;
+      g.stats[w * 8 + 7] = diag.t_prev;                  // when this tile pair's last batch ended (100 MHz wall clock)
     }
   }
   // how far this tile pair read into the view's list: the next call's head (the read is a hint: a stale value only
