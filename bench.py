@@ -64,6 +64,9 @@ def parse():
     ap.add_argument('--scope', choices=('hotpath', 'neck'), default='hotpath',
                     help="'hotpath': pools (+ one rendered view per camera + HOA) — the headline step; 'neck': the whole "
                          "OcRFViewTransformerFull.view_transform (one rendered view per sample, like the reference)")
+    ap.add_argument('--host-geometry', action='store_true',
+                    help='--scope neck: the per-forward calibration algebra on the HOST (the reference\'s own torch calls: rank '
+                         'vectors bit-exact) instead of the module\'s default, on the device when the calibration tensors are there')
     ap.add_argument('--device-geometry', action='store_true',
                     help="--scope neck --index-prep per_step: per-forward calibration algebra on the GPU (ocrf_geometry_blocks): "
                          "no device read-back, no synchronisation in the forward")
@@ -305,9 +308,15 @@ def bench_neck(args, cfg, dev, world, rank):
     from ocrfdet_amd import _lib, hotpath
     neck = hotpath.NeckPath(cfg, dev, accelerate=args.index_prep == 'cached', seed=rank,
                             host_calibration=args.host_calibration)
-    neck.module.device_geometry = bool(args.device_geometry)
+    # the module's default (round 6): calibration algebra on the device whenever the calibration tensors are there;
+    # --host-geometry opts out (rank vectors bit-exact with the reference's host formulation)
+    device_geometry = not args.host_geometry and not args.host_calibration
+    neck.module.device_geometry = None if device_geometry else False
+    args.device_geometry = device_geometry
+    if args.index_prep == 'cached':
+        neck.module.render_guard = args.render_guard      # 'host': the armed per-call chain is not issued; checked below
     # one hipGraph replay per step: cached geometry, or the per-forward geometry inside the graph (device geometry)
-    graphed = (args.index_prep == 'cached' or args.device_geometry) and not args.no_graph
+    graphed = (args.index_prep == 'cached' or device_geometry) and not args.no_graph
     for _ in range(args.warmup):
         neck.step()
     step = neck.step
@@ -328,6 +337,7 @@ def bench_neck(args, cfg, dev, world, rank):
     if world > 1:
         dist.barrier(group=CONTROL)
     elapsed = time.perf_counter() - t0
+    neck.module.check_render()        # render_guard='host': one status read verifies every render of the timed region
     # kernel events cannot bracket launches inside a graph replay: the pooling kernel is timed over a
     # short eager run of the same step right after the timed region
     timer = _lib.KernelTimer(_lib.K_BEV_POOL_FWD, 64)

@@ -33,6 +33,7 @@
 
 #include "launch.h"
 #include "ocrf_hip.h"
+#include "raster_blend_body.h"
 #include "raster_blend_math.h"
 #include "raster_common.h"
 
@@ -498,7 +499,7 @@ struct BwdArgs {
 // (forward: five waves per SIMD asked of the compiler — 28 KB of LDS hold five workgroups per CU; left alone hipcc takes
 // 110 VGPRs for the staging and the record loops keep everything in registers at 96 too)
 template <bool STAMP, bool BWD, bool MEDIAN, bool CONTRIB = true>
-__global__ __launch_bounds__(kBlock, (BWD || STAMP) ? 1 : 5) void raster_blend_kernel(
+__global__ __launch_bounds__(kBlock, (BWD || STAMP) ? 1 : (CONTRIB ? 5 : 4)) void raster_blend_kernel(
     unsigned long long* __restrict__ stamps,
     int P, int W, int H, int gy, const int* __restrict__ starts, const Rect* __restrict__ rects,
     const Rect* __restrict__ b_rect, const unsigned long long* __restrict__ b_comp,
@@ -527,19 +528,33 @@ __global__ __launch_bounds__(kBlock, (BWD || STAMP) ? 1 : 5) void raster_blend_k
   __shared__ int l_wtot[kScanUnroll * (kBlock / 64)];
   __shared__ int l_ready;
   __shared__ int l_fmax, l_generic;      // forward: largest need factor (float bits) / a GENERIC record in the staged batch
+  // LISTS — the inference forward (no contributor index): a batch is staged and blended by raster_blend_body.h, exactly
+  // as the planned kernel does it: wave w owns the 16 x 8 pixel block of rows [8 w, 8 w + 8) of the tile pair, every wave
+  // walks its OWN list of the records whose alpha >= 1/255 ellipse reaches that block (round 5 walked the whole staged
+  // batch per wave and skipped by a per-record test on the evaluated exponent: 162 us against the planned blend's 128 for
+  // the same views of cfg2).  The backward and the training forward (CONTRIB) keep thread (lx, ly) = pixel (lx, ly) of
+  // both tiles: the backward's DPP row reductions and contributor counters are laid out for it.
+  constexpr bool LISTS = !BWD && !CONTRIB;
+  __shared__ __attribute__((aligned(16))) unsigned short l_list[LISTS ? 4 : 1][rbody::kListLen];
+  __shared__ int l_lcnt[rbody::kSrcWavesB][4];
+  __shared__ int l_generic4[4], l_fmax4[4];
 
   const int tid = threadIdx.x;
+  const int wave = tid / 64, lane = tid % 64;
   const int tx = blockIdx.x, v = blockIdx.z;
   const int tyA = 2 * blockIdx.y, tyB = tyA + 1;      // tyB == gy: the pair has no second tile
-  const int lx = tid % kTileX, ly = tid / kTileX;
-  const int pxi = tx * kTileX + lx, pyA = tyA * kTileY + ly, pyB = tyB * kTileY + ly;
-  const bool insideA = pxi < W && pyA < H;
-  const bool insideB = tyB < gy && pxi < W && pyB < H;
+  const int lx = LISTS ? (lane & 15) : tid % kTileX, ly = tid / kTileX;
+  const int pxi = tx * kTileX + lx;
+  // LISTS: the lane's two pixels are 4 rows apart inside the wave's block (rows 8 w + r and 8 w + r + 4 of the pair)
+  const int pyA = LISTS ? tyA * kTileY + 8 * wave + (lane >> 4) : tyA * kTileY + ly;
+  const int pyB = LISTS ? pyA + 4 : tyB * kTileY + ly;
+  const bool tile_ok = (tyA + (wave >> 1)) < gy;       // (LISTS) the wave's tile exists
+  const bool insideA = LISTS ? (tile_ok && pxi < W && pyA < H) : (pxi < W && pyA < H);
+  const bool insideB = LISTS ? (tile_ok && pxi < W && pyB < H) : (tyB < gy && pxi < W && pyB < H);
   const float pixf_x = (float)pxi;
   const f2 pixf_y = f2{(float)pyA, (float)pyB};
   const long base = (long)v * P;
   const int nv = starts[(long)v * (kBuckets + 1) + kBuckets];
-  const int wave = tid / 64, lane = tid % 64;
 
   bool doneA = !insideA, doneB = !insideB;      // backward only; the forward keeps "stopped" in the sign of T
   f2 T = splat(1.0f);
@@ -589,8 +604,43 @@ __global__ __launch_bounds__(kBlock, (BWD || STAMP) ? 1 : 5) void raster_blend_k
   }
 
   bool all_done = false;
+  rbody::Tile tile;
+  tile.tyA = tyA; tile.wave = wave; tile.lane = lane; tile.tid = tid;
+  tile.pixf_x = pixf_x; tile.pixf_y = pixf_y; tile.inside0 = insideA; tile.inside1 = insideB;
+  tile.bx0 = (float)(tx * kTileX); tile.bx1 = tile.bx0 + 15.f;
+  const rbody::Lds lds{l_a, l_b, l_c, l_list, l_lcnt, l_generic4, l_fmax4};
+  rbody::NoStats no_stats;
+  if constexpr (LISTS) {
+    if (tid == 0) {      // slot kStageB: a record that changes nothing, pads odd list lengths (read after the scan's barriers)
+      const rb::Staged st = rb::stage_noop();
+      l_a[rbody::kStageB] = st.a;
+      l_b[rbody::kStageB] = st.b;
+      l_c[rbody::kStageB] = st.c;
+    }
+  }
   // blend rec[0, n) (sorted) front to back, kStage at a time; sets all_done
   auto blend_records = [&](int n) {
+    if constexpr (LISTS) {
+      for (int s0 = 0; s0 < n && !all_done; s0 += rbody::kStageB) {
+        const int ns = min(rbody::kStageB, n - s0);
+        auto fetch = [&](int ri) {
+          const unsigned long long c = rec[s0 + ri];
+          const unsigned id = (unsigned)(c & 0xFFFFFFFFull);
+          const float4 co = conic_o[base + id];
+          const Rect rc = rects[base + id];
+          rbody::Fetched fr;
+          fr.con = make_float4(-0.5f * co.x, -0.5f * co.z, co.y, co.w);
+          fr.pix = xy[base + id];
+          fr.col = colors + 3 * ((long)(v / vps) * P + id);     // the view's Gaussian set
+          fr.depth = __uint_as_float((unsigned)(c >> 32));
+          fr.covA = tyA >= rc.y0 && tyA < rc.y1;
+          fr.covB = tyB >= rc.y0 && tyB < rc.y1;
+          return fr;
+        };
+        all_done = rbody::blend_batch<MEDIAN, false>(px, kc, tile, lds, ns, fetch, 0, no_stats);
+      }
+      return;
+    }
     for (int s0 = 0; s0 < n && !all_done; s0 += kStage) {
       const int ns = min(kStage, n - s0);
       if constexpr (!BWD) {

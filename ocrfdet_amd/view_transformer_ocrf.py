@@ -521,9 +521,16 @@ class OcRFViewTransformerFull(nn.Module):
         # the plan's extent bound = margin x the largest Gaussian extent of the forward that builds it
         self.render_plan, self.render_plan_margin = True, 2.0
         # forward-only mode: per-forward calibration algebra on the GPU (ocrf_geometry_blocks) when the calibration
-        # tensors arrive there — no device read-back, no synchronisation in the forward (see ``_geometry``)
-        self.device_geometry = False
-        self._pin_ring = None
+        # tensors arrive there — no device read-back, no synchronisation in the forward (see ``_geometry``).
+        # None (default, round 6): automatically, whenever the forward is eval-mode / forward-only AND the seven
+        # calibration tensors are CUDA tensors — what a reference config gets without edits (1.75 -> 1.09 ms per forward
+        # at cfg2); False: the host formulation, whose rank vectors are the reference's bit for bit (the device algebra is
+        # ~1 ulp off: a 1e-5 fraction of border points may change cell, tests/test_device_geometry_gpu.py); True: as None
+        self.device_geometry = None
+        # guard of the cached render plan (accelerate=True): 'device' — exact whatever the scale head emits, the per-call
+        # pipeline armed behind every render (four near-empty launches, ~24 us at cfg2); 'host' — only a status bit is
+        # raised, ``check_render()`` (one synchronising read) turns it into an exception: the caller decides when to pay
+        self.render_guard = 'device'
         # eval-mode strands on side HIP streams (see _core_fused); off by default: a caller that runs the
         # module under its own stream discipline should opt in
         self.parallel_branches, self._transient = False, hoa._LaunchCache()     # streams: not module state
@@ -576,7 +583,7 @@ class OcRFViewTransformerFull(nn.Module):
         geo.cam_rows, geo.plans, geo.cam_rows_dev = {}, {}, None
         geo.raster_plan = None
         on_dev = all(torch.is_tensor(t) and t.is_cuda for t in list(input[1:7]) + [input[11]])
-        if getattr(self, 'device_geometry', False) and not sync and on_dev:
+        if getattr(self, 'device_geometry', None) is not False and not sync and on_dev:
             # forward-only path with the calibration already on the GPU: the tiny per-camera algebra runs there
             # too (ocrf_geometry_blocks) — nothing in the forward reads the device or waits for it.  ~1 ulp from
             # the host formulation below, which stays the default (and the one the rank fixtures pin bit for bit)
@@ -699,9 +706,12 @@ class OcRFViewTransformerFull(nn.Module):
     def _small_h2d(self, host_tensor, device):
         """A few host integers to the device without a hidden wait: through a ring of PINNED slots (an asynchronous
         copy out of pageable memory blocks the host until the stream reaches it), each guarded by an event."""
-        if self._pin_ring is None:
-            self._pin_ring = dict(slots=[[torch.empty(64, dtype=torch.int32).pin_memory(), None] for _ in range(8)], i=0)
-        ring = self._pin_ring
+        # (kept in ``_transient``: pinned slots and events are not module state — ``copy.deepcopy(module)`` after a forward
+        # on the device-geometry path, now the default, used to fail on the events)
+        ring = self._transient.get('pin_ring')
+        if ring is None:
+            ring = self._transient['pin_ring'] = dict(
+                slots=[[torch.empty(64, dtype=torch.int32).pin_memory(), None] for _ in range(8)], i=0)
         slot = ring['slots'][ring['i']]
         ring['i'] = (ring['i'] + 1) % len(ring['slots'])
         if slot[1] is not None:
@@ -1059,8 +1069,16 @@ class OcRFViewTransformerFull(nn.Module):
         plan, base = geo.raster_plan
         item_view = (base + cameras['cam_sel'].to(torch.int32)).contiguous()
         # (sample b renders one of ITS OWN N plan views: no view is named by two sets)
-        return plan.render(color, opacity, scaling, rotation, self._bg, item_view=item_view, guard='device',
-                           views_disjoint=True, want_radii=False)
+        return plan.render(color, opacity, scaling, rotation, self._bg, item_view=item_view,
+                           guard=getattr(self, 'render_guard', 'device'), views_disjoint=True, want_radii=False)
+
+    def check_render(self):
+        """``render_guard='host'``: synchronising check of the cached render plan's status word — raises if a render since
+        the last check had a Gaussian beyond the plan's extent bound (those images are not valid)."""
+        state = getattr(self._geo, 'raster_plan', None) if self._geo is not None else None
+        if state:
+            state[0].check()
+        return True
 
     def _build_raster_plan(self, geo, voxel_coor, scaling, rotation, B, N, H, W):
         """-> (RasterPlan over the B*N (sample, camera) views, int32 view offsets b*N) or False when the samples do not
@@ -1205,9 +1223,9 @@ class GraphedNeck:
                  capture_stream=None):
         calib_on_dev = all(torch.is_tensor(example_input[i]) and example_input[i].is_cuda for i in (1, 2, 3, 4, 5, 6, 11))
         self.per_forward_geometry = not module.accelerate
-        if self.per_forward_geometry and not (getattr(module, 'device_geometry', False) and calib_on_dev):
-            raise RuntimeError('GraphedNeck needs accelerate=True (geometry cached across calls), or '
-                               'module.device_geometry = True with the calibration tensors on the GPU (geometry inside '
+        if self.per_forward_geometry and not (getattr(module, 'device_geometry', None) is not False and calib_on_dev):
+            raise RuntimeError('GraphedNeck needs accelerate=True (geometry cached across calls), or the calibration '
+                               'tensors on the GPU with module.device_geometry not switched off (geometry inside '
                                'the graph): the host formulation of the calibration algebra cannot be captured')
         if module.training:
             raise RuntimeError('GraphedNeck is inference only: call module.eval() first')

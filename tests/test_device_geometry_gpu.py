@@ -109,8 +109,10 @@ def test_forward_with_device_geometry_does_not_synchronise(cuda):
     feat = pre[:, cfg.D + 2:].contiguous()
     cams = [int(c) for c in g['cam_idx_list']]
     with torch.no_grad():
+        assert m.device_geometry is None                  # the default: on the device whenever the calibration is there
+        m.device_geometry = False                         # ... opted out: the host formulation (bit-exact rank vectors)
         want = m.view_transform_core(inp, depth, feat, cam_idx_list=cams)
-        m.device_geometry = True
+        m.device_geometry = None
         m.view_transform_core(inp, depth, feat, cam_idx_list=cams)            # warm-up: allocations, packs
         torch.cuda.synchronize()
         torch.cuda.set_sync_debug_mode('error')
