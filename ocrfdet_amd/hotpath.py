@@ -708,6 +708,13 @@ class HotPath:
             if rec is not None:
                 rec.fork(0, s1)
                 rec.fork(0, s1 + 1)
+            # Issue order = the critical chain first (round 6, from the step's kernel timeline, tools/trace_mode.sh): the LSS
+            # preparation -> LSS pooling -> HOA-3 chain is the longest, and a step's ~ 45 launches cost the host ~ 4 us
+            # each.  So: LSS preparation AND its pooling on their stream, then the HT pair on theirs, then HOA-1/2 on the
+            # caller's (it only has to be done before HOA-3).  Round 5 pooled the LSS ranks on the caller's stream behind
+            # HOA-1/2: in the timeline the pooling started ~ 40 us after its ranks were ready.  Measured, one box: 0.375 ->
+            # 0.381 ms (per_step_devgeom 0.332 -> 0.338): neutral — beside the render's blend the step is bound by the
+            # chip's occupancy, not by this chain; kept because both poolings are now issued the same way.
             with torch.cuda.stream(p1):
                 lss_block, ht_block = self._camera_blocks()
                 blocks_ready = torch.cuda.Event()
@@ -715,10 +722,14 @@ class HotPath:
                 ht_block.record_stream(p2)
                 if rec is not None:
                     rec.fork(s1, s1 + 1)                             # (recorded here: the event is taken before the LSS chain)
-                lss_prepared = self._prepare_lss(lss_block)
+                lv, lc = self._prepare_lss(lss_block)
+                lss = bevpool.bev_pool_v2_device_counts(depth, feat, lv[1], lv[2], lv[0], self.lss.bev_shape, lv[3], lv[4], lc)
             p2.wait_event(blocks_ready)
             with torch.cuda.stream(p2):
-                prepared = (lss_prepared, self._prepare_ht(ht_block))
+                hv, hc = self._prepare_ht(ht_block)
+                ht = bevpool.bev_pool_v2_device_counts(depth, feat, hv[1], hv[2], hv[0], self.ht.bev_shape, hv[3], hv[4], hc,
+                                                       scratch_tag='bev_pool_nchw_b')
+            prepared = True
         # HOA-1/2 need nothing of the poolings and the poolings nothing of them: with the planned render the poolings go
         # FIRST — they meet the start of the side stream's blend instead of its middle; with the per-call render, whose
         # chip-filling preprocess opens the side stream, and with the per-step index preparation (which the poolings have
@@ -729,21 +740,15 @@ class HotPath:
         ob = self.hoa_opacity_bev() if (self.cfg.hoa and hoa_first) else None
         if prepared is not None:
             main = torch.cuda.current_stream(self.device)
-            (lv, lc), (hv, hc) = prepared
             rec = getattr(self, '_rec', None)
             s1 = 1 + (len(self._side) if self._forks() else 0)
-            # each pooling right behind its own preparation: the HT pooling on the HT preparation's stream, beside the LSS
-            # pooling on this one (own scratch) — in a row on this stream they were 107 us of its critical path
-            with torch.cuda.stream(self._prep_stream2):
-                ht = bevpool.bev_pool_v2_device_counts(depth, feat, hv[1], hv[2], hv[0], self.ht.bev_shape, hv[3], hv[4], hc,
-                                                       scratch_tag='bev_pool_nchw_b')
             main.wait_stream(self._prep_stream)
             if rec is not None:
                 rec.join(s1, 0)
-            lss = bevpool.bev_pool_v2_device_counts(depth, feat, lv[1], lv[2], lv[0], self.lss.bev_shape, lv[3], lv[4], lc)
             main.wait_stream(self._prep_stream2)
             if rec is not None:
                 rec.join(s1 + 1, 0)
+            lss.record_stream(main)
             ht.record_stream(main)
         else:
             lss, ht = self.pool_step(depth, feat, prepared)
