@@ -45,8 +45,9 @@ def lib():
             raise OcrfHipError(f"cannot load {_SO}: {e}") from e
         _declare(_LIB)
         _declare_step(_LIB)
-    if _RECORDER is not None:
-        return _RecordingLib(_LIB, _RECORDER)
+    rec = getattr(_RECORDER, 'rec', None)
+    if rec is not None:
+        return _RecordingLib(_LIB, rec)
     return _LIB
 
 
@@ -283,7 +284,10 @@ def _declare_step(L):
 # One host call per step (csrc/step.hip): the library calls of a step are recorded once, while the step runs eagerly,
 # and replayed from C afterwards.
 # ---------------------------------------------------------------------------------------------------------------
-_RECORDER = None
+import threading  # noqa: E402
+
+_RECORDER = threading.local()      # .rec: the StepRecorder of THIS thread (another thread calling lib()
+                                   # while a step is recorded must not get its calls spliced into that step)
 # entry points that enqueue nothing (sizes, lengths, knobs, timers): passed through while a step is being recorded
 _QUERY_SUFFIXES = ('_bytes', '_len', '_rows', '_side', '_panels', '_tiles', '_bands', '_resident', '_version', '_name',
                    '_max_units')
@@ -309,16 +313,14 @@ class StepRecorder:
         self.why = None
 
     def __enter__(self):
-        global _RECORDER
-        if _RECORDER is not None:
+        if getattr(_RECORDER, 'rec', None) is not None:
             raise OcrfHipError('a step is already being recorded')
         lib()
-        _RECORDER = self
+        _RECORDER.rec = self
         return self
 
     def __exit__(self, *exc):
-        global _RECORDER
-        _RECORDER = None
+        _RECORDER.rec = None
         return False
 
     def fail(self, why):

@@ -903,7 +903,8 @@ class ShardedHotPath:
             mask.gate(x.unsqueeze(0), opacity.reshape(1, 1, Y, X), stats=stats.unsqueeze(0).contiguous(), in_place=True)
         def body(rec):
             with torch.no_grad():
-                sharding.gate_blocks(ex, self.planes_lss, self.cfg.channels, None, ob, stats_fn, gate_fn)
+                sharding.gate_blocks(ex, self.planes_lss, self.cfg.channels, None, ob, stats_fn, gate_fn,
+                                     partial_ok=getattr(self, 'partial_statistics_ok', False))
         # a rank whose frames are all its own (no group to gather statistics from) gates without a collective inside:
         # one more recorded segment
         alone = all(len(self.plan.group_of_frame[f]) == 1 or not ex.active for f, _, _ in ex.my_blocks)

@@ -474,7 +474,7 @@ class BevExchange:
         return self.full
 
 
-def gate_blocks(ex, first_plane, n_channels, opacity_plane, opacity_of_frame, stats_fn, gate_fn):
+def gate_blocks(ex, first_plane, n_channels, opacity_plane, opacity_of_frame, stats_fn, gate_fn, partial_ok=False):
     """HOA-3 on a camera-frame-sharded grid, BETWEEN the two steps of the exchange (``ex.finish_reduce`` done,
     ``ex.gather`` to come): every rank gates the channels it holds, in place, so that the world all_gather carries the
     GATED planes — no rank runs the gate for a frame it has no part in, and inside a frame's group the gate's work is
@@ -515,8 +515,17 @@ def gate_blocks(ex, first_plane, n_channels, opacity_plane, opacity_of_frame, st
             q0 = min(j * cap, P) if len(ranks) > 1 else 0
             qn = min(cap, P - q0) if len(ranks) > 1 else P
             held.append(max(0, min(q0 + qn, first_plane + n_channels) - max(q0, first_plane)))
-        assert parts.shape[0] == len(held) or parts.shape[0] == 1
-        if parts.shape[0] == 1:
+        if parts.shape[0] != len(held):
+            # the gather returned only this rank's part (an inactive exchange: no process group) although the frame's
+            # channels are spread over a group: gating with the own channels' statistics alone is a wrong mask for the
+            # frame — refused unless the caller says that is what it wants (``partial_ok``: the
+            # single-process tests that look at ONE rank of a sharded job).  A rank that holds every channel took the
+            # branch above; one that holds none has nothing to gate
+            if x.shape[0] > 0 and not partial_ok:
+                from . import _lib
+                raise _lib.OcrfHipError(
+                    f'gate_blocks: frame {f} is held by {len(ranks)} ranks but only {parts.shape[0]} part(s) of its channel '
+                    f'statistics arrived and this rank holds {x.shape[0]} of {n_channels} channels: the exchange is not active')
             held = [x.shape[0]]
         mean, smax = None, None
         for j, cj in enumerate(held):                           # member order: every member forms the same sums

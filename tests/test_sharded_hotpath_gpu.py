@@ -141,6 +141,41 @@ def test_pipelined_step_returns_the_previous_step(cuda):
         assert all(torch.equal(r[0]['color'], c) for r, c in zip(rendered, w[1]))
 
 
+def test_pipelined_step_with_hoa_inputs_that_change_every_step(cuda):
+    """step k's HOA-3 gate (and the copy of its opacity plane) reads the HOA-1/2 outputs on the
+    communication stream while step k + 1's replayed HOA-1/2 segment already runs on the caller's — with ONE output buffer
+    per segment that is a write-after-read race that constant HOA inputs hid.  Here the opacity volume HOA-1 reads changes
+    IN PLACE before every pipelined step (replayed segments: same pointers, new values): every returned step must carry the
+    opacity BEV and the gated planes of ITS OWN inputs."""
+    cfg = synthetic.PathConfig(**{**synthetic.CONFIGS['cfg0_1cam_128x352_bev64x64x4'].__dict__, 'name': 'small4cam_hoa',
+                                  'n_cams': 4, 'n_frames': 2, 'render': True, 'hoa': True})
+    sp = hotpath.ShardedHotPath(cfg, cuda, 0, 1)
+    ref = hotpath.ShardedHotPath(cfg, cuda, 0, 1, one_call=False)
+    ins = sp.make_inputs(seed=1)
+    gen = torch.Generator(device='cpu').manual_seed(5)
+    volumes = [torch.rand(sp._hoa_in[0].shape, generator=gen).to(cuda) for _ in range(6)]
+    want = []
+    for v in volumes:                                 # the plain step, call by call, per volume
+        ref._hoa_in[0].copy_(v)
+        full, _, gated, ob = ref.step(ins)
+        want.append((full.clone(), [g.clone() for g in gated], ob.clone()))
+    assert not torch.equal(want[0][2], want[1][2])
+    def keep(out):                                    # (a returned step lives in one of TWO buffer sets: copied at once)
+        return None if out is None else (out[0].clone(), out[1], [g.clone() for g in out[2]], out[3].clone())
+    got = []
+    for v in volumes:
+        sp._hoa_in[0].copy_(v)                        # in place: the recorded segment's pointer, new values
+        got.append(keep(sp.step_pipelined(ins)))
+    got.append(keep(sp.flush_pipelined()))
+    torch.cuda.synchronize()
+    assert got[0] is None and sp.one_call
+    for k in range(1, len(got)):
+        full, _, gated, ob = got[k]
+        w = want[k - 1]
+        assert torch.equal(ob, w[2]), f'step {k - 1}: opacity BEV of another step'
+        assert torch.equal(full, w[0]) and all(torch.equal(a, b) for a, b in zip(gated, w[1])), k
+
+
 def test_world1_with_hoa_equals_unsharded_step_bitwise(cuda):
     """HOA sharded by frame, world 1: the fused grid holds the LSS planes, the GATED height-sampling planes and the opacity
     BEV plane — the unsharded ``HotPath.step``'s lss, gated and opacity_bev bit for bit (one member holds all channels:
@@ -173,6 +208,7 @@ def test_a_rank_runs_hoa_only_for_its_frames_and_gates_its_own_block(cuda, world
     cfg = synthetic.PathConfig(**{**synthetic.CONFIGS['cfg0_1cam_128x352_bev64x64x4'].__dict__, 'name': 'small4cam_hoa',
                                   'n_cams': 4, 'n_frames': 2, 'render': False, 'hoa': True})
     sp = hotpath.ShardedHotPath(cfg, cuda, rank, world)
+    sp.partial_statistics_ok = True      # ONE rank of a sharded job without its peers: its own channels' statistics (else refused)
     assert sp.my_frames == sp.plan.frames_of(rank) and len(sp.my_frames) == (1 if world >= 2 else 2)
     ex = sp.exchange
     inputs = sp.make_inputs(seed=4)
