@@ -437,32 +437,6 @@ constexpr int kMaxSets = 32;
 //   con = (-0.5 conic.x, -0.5 conic.z, conic.y, opacity); rect (0,0,0,0): not rendered this step; *rad: the reference's
 //   integer radius (0: none) — computed for an invisible Gaussian (opacity < 1/255) only when the caller asks for it.
 // ---------------------------------------------------------------------------------------------
-// The tile rect of a record, tightened by its OPACITY.  alpha = min(0.99, o exp(power)) reaches 1/255 only where
-// power >= -ln(255 o), i.e. inside the ellipse d^T Sigma^-1 d <= k = 2 ln(255 o) around the projected centre, whose bounding
-// box has the half-widths sqrt(k cov_x), sqrt(k cov_z) (Sigma = the dilated 2D covariance whose inverse the conic is).  A
-// tile of the reference's rect (a square around 3 sigma_max, whatever the opacity) that this box does not reach holds no
-// pixel with alpha >= 1/255: the reference skips the record at every one of them (forward.cu:331-333: no colour, no change
-// of T), so leaving the tile out changes nothing — and a faint Gaussian (a trained OcRF is mostly those) is listed in a
-// fraction of the tiles.  The margin (0.02 on the logarithm, i.e. 2 % on alpha, + 1e-4 relative + 0.01 px) dominates the
-// rounding of the conic, of v_exp_f32 and of the blend's folded exponent; NaN / Inf anywhere keep the reference's rect.
-__device__ __forceinline__ void tighten_rect(float o, float cov_x, float cov_z, float pixx, float pixy, int gx, int gy,
-                                             Rect* r) {
-  if (!(o > 0.f) || !(o < 3.0e38f)) return;
-  const float k = 2.f * (fmaxf(__logf(255.f * o), 0.f) + 0.02f);
-  const float hx = sqrtf(k * cov_x) * 1.0001f + 0.01f, hy = sqrtf(k * cov_z) * 1.0001f + 0.01f;
-  if (!(hx < 1.0e9f) || !(hy < 1.0e9f) || !(fabsf(pixx) < 1.0e9f) || !(fabsf(pixy) < 1.0e9f)) return;
-  const int tx0 = min(gx, max(0, (int)floorf((pixx - hx) * (1.f / kTileX))));
-  const int tx1 = min(gx, max(0, (int)floorf((pixx + hx) * (1.f / kTileX)) + 1));
-  const int ty0 = min(gy, max(0, (int)floorf((pixy - hy) * (1.f / kTileY))));
-  const int ty1 = min(gy, max(0, (int)floorf((pixy + hy) * (1.f / kTileY)) + 1));
-  const int x0 = max((int)r->x0, tx0), x1 = min((int)r->x1, tx1), y0 = max((int)r->y0, ty0), y1 = min((int)r->y1, ty1);
-  if (x1 <= x0 || y1 <= y0) {
-    *r = Rect{0, 0, 0, 0};
-    return;
-  }
-  r->x0 = (unsigned short)x0; r->y0 = (unsigned short)y0; r->x1 = (unsigned short)x1; r->y1 = (unsigned short)y1;
-}
-
 struct SetParams {
   const float* opacities;      // (n_sets, P)
   const float* scales;         // (n_sets, P, 3)

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
     const Camera* __restrict__ cams, uint4* __restrict__ vis_rec, int* __restrict__ vis_count,
     Rect* __restrict__ rects, float2* __restrict__ xy, float4* __restrict__ conic_o,
     int* __restrict__ radii, unsigned* __restrict__ tiles_touched, int* __restrict__ hist, int vps,
-    const int* __restrict__ view_sel, const int* __restrict__ gate, int means_stride) {
+    const int* __restrict__ view_sel, const int* __restrict__ gate, int means_stride, int tighten) {
   if (gate && *gate == 0) return;      // armed as a fallback that is not needed (raster_plan.hip)
   // One workgroup = kPreChunk consecutive Gaussians of one view.  Their depth buckets are counted in
   // an LDS histogram first and only the non-empty bins go to the global one: scattered global
@@ -230,16 +230,28 @@ __global__ __launch_bounds__(kBlock) void raster_preprocess_kernel(
       const int x1 = min(gx, max(0, (int)((pixx + (float)rad + (float)(kTileX - 1)) / (float)kTileX)));
       const int y1 = min(gy, max(0, (int)((pixy + (float)rad + (float)(kTileY - 1)) / (float)kTileY)));
       if ((x1 - x0) * (y1 - y0) != 0) {
-        key = __float_as_uint(vz);        // vz > 0.2: the raw bits order like the value
         my_radii = rad;
-        touched = (unsigned)((y1 - y0) * (x1 - x0));
+        touched = (unsigned)((y1 - y0) * (x1 - x0));      // (outputs: the reference's radius and tile count)
         Rect rc;
         rc.x0 = (unsigned short)x0; rc.y0 = (unsigned short)y0;
         rc.x1 = (unsigned short)x1; rc.y1 = (unsigned short)y1;
-        rects[o] = rc;
-        rect_of[it] = rc;
-        xy[o] = make_float2(pixx, pixy);
-        conic_o[o] = make_float4(con_x, con_y, con_z, opacities[gi]);
+        // what the blend lists the record under: the rect tightened by the OPACITY (raster_common.h, round 6) — a tile
+        // the alpha >= 1/255 ellipse does not reach holds no pixel the reference blends it at (forward.cu:331-333), and a
+        // Gaussian under 1/255 everywhere is not listed at all (a trained OcRF's free space: most of the grid)
+        // (inference forward only: with the contributor index — the training forward and the backward that walks the same
+        // lists — a tile's list is the reference's, record for record)
+        const float op = opacities[gi];
+        if (tighten) {
+          if (op < 1.0f / 255.0f) rc = Rect{0, 0, 0, 0};
+          else tighten_rect(op, cov_x, cov_z, pixx, pixy, gx, gy, &rc);
+        }
+        if (((int)rc.x1 - (int)rc.x0) * ((int)rc.y1 - (int)rc.y0) != 0) {
+          key = __float_as_uint(vz);        // vz > 0.2: the raw bits order like the value
+          rects[o] = rc;
+          rect_of[it] = rc;
+          xy[o] = make_float2(pixx, pixy);
+          conic_o[o] = make_float4(con_x, con_y, con_z, op);
+        }
       }
     }
     }   // !surely_empty
@@ -1359,7 +1371,7 @@ int raster_forward_chain(int P, int n_sets, int views_per_set, int H, int W, con
   ocrf::launch(OCRF_K_RASTER_PREPROCESS, raster_preprocess_kernel, xgrid, dim3(kBlock), 0, stream, P, n_views,
                n_pre, W, H, gx, gy, means3D, opacities, scales, scale_modifier, rotations, cov3D_precomp,
                cams, vis_rec, vis_count, rects, xy, conic_o, radii, tiles_touched, hist, views_per_set, view_sel, gate,
-               shared_means ? 0 : P);
+               shared_means ? 0 : P, out_n_contrib == nullptr ? 1 : 0);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   ocrf::launch(OCRF_K_RASTER_SCAN, raster_bucket_scan_kernel, dim3(n_views), dim3(kBlock), 0, stream,
@@ -1490,7 +1502,7 @@ static int rasterize_backward_impl(int P, int n_views, int H, int W, const float
   hipLaunchKernelGGL(raster_preprocess_kernel, xgrid, dim3(kBlock), 0, stream, P, n_views, n_pre, W, H, gx, gy,
                      means3D, opacities, scales, scale_modifier, rotations, cov3D_precomp, cams, vis_rec,
                      vis_count, rects, xy, conic_o, radii, (unsigned*)nullptr, hist, n_views, (const int*)nullptr,
-                     (const int*)nullptr, P);
+                     (const int*)nullptr, P, 0);
   hipLaunchKernelGGL(raster_bucket_scan_kernel, dim3(n_views), dim3(kBlock), 0, stream, static_cast<const int*>(hist),
                      starts, cursor, st, (const int*)nullptr);
   hipLaunchKernelGGL(raster_scatter_kernel, pgrid, dim3(kBlock), 0, stream, P, static_cast<const uint4*>(vis_rec),
