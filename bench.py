@@ -460,7 +460,7 @@ def gaussian_set_figures(cfg, dev, kind, depth, feat, steps=20, blocks=5, hp_kw=
         staged.append(st[:, 0, 4])
         phases.append(st[:, :, :3].reshape(-1, 3))
         evald += float(st[:, :, 6].sum())
-        ctl = plan._dyn[plan._dyn.numel() - 512:].view(torch.int32).cpu().numpy()      # control words (raster_plan.hip kCtl*)
+        ctl = plan._dyn[plan._dyn.numel() - 1024:].view(torch.int32).cpu().numpy()      # control words (raster_plan.hip kCtl*)
         heads += [int(v) for v in ctl[32:32 + plan.V]]
     hp.check_render_plans()
     sc, sg = np.concatenate(scanned), np.concatenate(staged)

@@ -300,7 +300,12 @@ int ocrf_rasterize_planned(const void *plan, size_t plan_bytes, int P, int n_pla
                            size_t workspace_bytes, int guard, const float *means3D, void *chain_workspace,
                            size_t chain_workspace_bytes, int blend_workgroups, const int *yield_if, int phase,
                            const float *call_cameras, int views_disjoint, const void *bins, size_t bins_bytes,
-                           int bin_w, int bin_h, long cand_capacity, ocrf_stream_t stream);
+                           int bin_w, int bin_h, long cand_capacity, int *hint, ocrf_stream_t stream);
+/* hint (or NULL): one int in memory BOTH the host and the device can address (pinned host memory: hipHostMalloc), zero at
+ * first.  The last workgroup of a render writes "some rendered view is deep" into it; the next call reads it ON THE HOST,
+ * without a copy or a wait, to choose between the two builds of the blend — the plain one, and the one that compacts the
+ * candidates of deep views per call (see ocrf_rasterize_planned_bins_workspace_bytes).  A stale value costs time, never
+ * correctness; a replayed step (ocrf_step_*) re-reads it at every replay. */
 /*
  * Candidate lists of a built plan — the static part of what the reference builds per call as its per-tile lists
  * (cuda_rasterizer/rasterizer_impl.cu:70-138 duplicateWithKeys + identifyTileRanges, consumed forward.cu:261-374): per
@@ -318,6 +323,15 @@ int ocrf_rasterize_planned(const void *plan, size_t plan_bytes, int P, int n_pla
  * only if a tile pair asked.  A tile pair never prepares records itself.
  */
 size_t ocrf_raster_plan_bins_bytes(int n_views, int H, int W, int bin_w, int bin_h, long cand_capacity);
+/* per-call scratch of ocrf_rasterize_planned when it is given candidate lists: as ocrf_rasterize_planned_workspace_bytes
+ * plus room for the per-call compaction of "deep" views — views whose last render walked 8 192 list entries or more
+ * (pixels that do not saturate early: an object-centric opacity field).  For those the head of the list is the whole
+ * list and, per segment of 1 024 candidates of a bin, the candidates whose rect of THIS call reaches the bin are moved to
+ * the front with the mask of the bin's tiles they cover (the per-call half of duplicateWithKeys,
+ * rasterizer_impl.cu:70-109), so that a tile pair reads only records that can concern it.  A workspace of the smaller
+ * size is accepted when bins == NULL. */
+size_t ocrf_rasterize_planned_bins_workspace_bytes(long capacity, int n_sets, int n_views, int H, int W, int bin_w,
+                                                   int bin_h, long cand_capacity);
 size_t ocrf_raster_plan_bins_workspace_bytes(int P, int n_views, int H, int W, int bin_w, int bin_h, long capacity);
 int ocrf_raster_plan_bins_build(const void *plan, size_t plan_bytes, int P, int n_views, long capacity, int H, int W,
                                 float extent_bound, int bin_w, int bin_h, long cand_capacity, void *bins,

@@ -132,7 +132,9 @@ def _declare(L):
     L.ocrf_rasterize_planned.argtypes = ([c_void_p, c_size_t, c_int, c_int, c_long] + [c_int] * 4 + [c_void_p] * 4 +
                                          [c_float] + [c_void_p] * 2 + [c_int] + [c_void_p] * 6 + [c_size_t, c_int] +
                                          [c_void_p] * 2 + [c_size_t, c_int, c_void_p, c_int, c_void_p, c_int] +
-                                         [c_void_p, c_size_t, c_int, c_int, c_long, c_void_p])
+                                         [c_void_p, c_size_t, c_int, c_int, c_long, c_void_p, c_void_p])
+    L.ocrf_rasterize_planned_bins_workspace_bytes.restype = c_size_t
+    L.ocrf_rasterize_planned_bins_workspace_bytes.argtypes = [c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_long]
     L.ocrf_raster_plan_bins_bytes.restype = c_size_t
     L.ocrf_raster_plan_bins_bytes.argtypes = [c_int] * 5 + [c_long]
     L.ocrf_raster_plan_bins_workspace_bytes.restype = c_size_t

@@ -97,19 +97,26 @@ inline void build_layout(int P, long T, BuildLayout* L) {
 }
 
 struct DynLayout {        // per-call scratch of the planned render
-  size_t rect, con, deferred, flag, bytes;
+  size_t rect, con, deferred, ccnt, ccand, flag, bytes;
 };
+
+constexpr int kSegC = 1024;                       // candidates per segment of the per-call compaction (deep views)
+inline long max_segments(long cand_cap, long n_bins_total) { return cand_cap / kSegC + n_bins_total + 1; }
 
 constexpr int kMaxDeferred = 1 << 20;             // tile pairs (of all items of a call) a second pass can take over
 
-inline void dyn_layout(long T, int n_sets, DynLayout* L) {
+inline void dyn_layout(long T, int n_sets, DynLayout* L, long cand_cap = 0, long n_bins_total = 0) {
   size_t off = 0;
   auto take = [&](size_t bts) { size_t o = off; off += align_up(bts, 256); return o; };
   const size_t n = (size_t)T * n_sets;
   L->rect = take(n * sizeof(Rect));
   L->con = take(n * 16);
   L->deferred = take((size_t)kMaxDeferred * 4);   // tile pairs that ran out of prepared records (second pass)
-  L->flag = take(512);                            // control words (kCtl*): guard flag, ticket queue, heads, reach — LAST
+  // deep views (raster_plan_compact_kernel): per segment of a bin's candidates how many reach the bin THIS call, and
+  // those — (list position, mask of the bin's tiles the record's rect covers) — at the front of the segment's range
+  L->ccnt = take(cand_cap > 0 ? (size_t)max_segments(cand_cap, n_bins_total) * 4 : 0);
+  L->ccand = take(cand_cap > 0 ? (size_t)cand_cap * 8 : 0);
+  L->flag = take(1024);                           // control words (kCtl*): guard flag, ticket queue, heads, reach — LAST
   L->bytes = off;
 }
 
@@ -279,14 +286,19 @@ constexpr int kBinDirect = 512;
 static_assert(kBinDirect % kBlock == 0 && kBinDirect <= kBinSeg, "the direct region is whole slices of the first segment");
 
 struct BinsLayout {
-  size_t header, b_off, cand, bytes;
+  size_t header, b_off, b_seg, seg_bin, cand, bytes;
 };
 
 inline void bins_layout(int V, int nbx, int nby, long cand_cap, BinsLayout* L) {
   size_t off = 0;
   auto take = [&](size_t b) { size_t o = off; off += align_up(b, 256); return o; };
+  const long nb = (long)V * nbx * nby;
   L->header = take((size_t)kBinsHeaderInts * 4);
-  L->b_off = take(((size_t)V * nbx * nby + 1) * 8);
+  L->b_off = take(((size_t)nb + 1) * 8);
+  // segments of kSegC candidates (behind the direct region) for the per-call compaction of deep views: a bin's first
+  // segment (b_seg, nb + 1 ints) and the bin of every segment (seg_bin)
+  L->b_seg = take(((size_t)nb + 1) * 4);
+  L->seg_bin = take((size_t)max_segments(std::max<long>(cand_cap, 1), nb) * 4);
   L->cand = take((size_t)std::max<long>(cand_cap, 1) * 4);
   L->bytes = off;
 }
@@ -418,6 +430,45 @@ __global__ __launch_bounds__(kBlock) void plan_bin_fill_kernel(const int* __rest
   if (seg == 0 && threadIdx.x == 0) b_tab[v * nbins + bin] = make_int2(first, direct);
 }
 
+// the segment tables (one workgroup: plan time).  A bin's candidates behind the direct region, in segments of kSegC.
+__global__ __launch_bounds__(kBlock) void plan_bins_segments_kernel(int nb, long max_segs, const int2* __restrict__ b_tab,
+                                                                    const int* __restrict__ total, long cand_cap,
+                                                                    int* __restrict__ b_seg, int* __restrict__ seg_bin) {
+  if ((long)*total > cand_cap) return;
+  __shared__ int l_carry;
+  if (threadIdx.x == 0) l_carry = 0;
+  __syncthreads();
+  // chunks of 256 bins: inclusive scan of their segment counts inside the workgroup (wave scans + carries)
+  __shared__ int l_w[4];
+  for (int b0 = 0; b0 < nb; b0 += kBlock) {
+    const int b = b0 + (int)threadIdx.x;
+    int n = 0;
+    if (b < nb) {
+      const int2 t0 = b_tab[b], t1 = b_tab[b + 1];
+      n = (max(0, t1.x - (t0.x + t0.y)) + kSegC - 1) / kSegC;
+    }
+    int inc = n;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int y = __shfl_up(inc, d);
+      if ((int)(threadIdx.x & 63) >= d) inc += y;
+    }
+    if ((threadIdx.x & 63) == 63) l_w[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    int base = l_carry;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += l_w[w];
+    const int first = base + inc - n;
+    if (b < nb) {
+      b_seg[b] = first;
+      for (int k = 0; k < n; ++k)
+        if ((long)first + k < max_segs) seg_bin[first + k] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == kBlock - 1) l_carry = base + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) b_seg[nb] = l_carry;
+}
+
 __global__ void plan_bins_header_kernel(const int* __restrict__ plan_header, const int* __restrict__ total, long cand_cap,
                                         int V, int gx, int gy, int bw, int bh, int nbx, int nby,
                                         const unsigned long long* __restrict__ scan_state, int* __restrict__ header) {
@@ -479,9 +530,36 @@ __device__ __forceinline__ void dyn_record(const SetParams& sp, long gi, const f
 //   counter  [18] tile pairs the first pass handed to the second  [32, 64) head[v]: list entries of plan view v the head
 //   kernel prepares (0: never rendered — the default)  [64, 96) reach[v]: how far into view v's list the tile pairs of the
 //   running blend scanned
-constexpr int kCtlQueue = 16, kCtlArrive = 17, kCtlDeferred = 18, kCtlHead = 32, kCtlReach = 64;      // (512 bytes: dyn_layout)
+//   [19] some view is deep  [96, 128) deep[v]: the last render of view v walked far into its list (>= kDeepReach entries:
+//   its pixels do not saturate early) — the head kernel then prepares the view's WHOLE list and the candidates of its bins
+//   are compacted per call (raster_plan_compact_kernel)
+//   [20] this call's compaction ran (written by raster_plan_compact_kernel)  [128, 134) its three tables' addresses (b_seg,
+//   ccnt, ccand as 64-bit words): the blend reads them from here only when a tile pair is deep — as kernel arguments they
+//   cost six more scalar registers everywhere, and the kernel already spills scalars (measured: +25 us on the init set)
+constexpr int kCtlQueue = 16, kCtlArrive = 17, kCtlDeferred = 18, kCtlAnyDeep = 19, kCtlCompacted = 20, kCtlHead = 32,
+              kCtlReach = 64, kCtlDeep = 96, kCtlTables = 128;      // (1024 bytes: dyn_layout)
+constexpr int kDeepReach = 8192;
 constexpr int kHeadDefault = 4096;               // list entries per view prepared before anything is known
 constexpr int kHeadBlocks = 64;                  // workgroups per item of the head kernel (each strides over the head)
+
+// what the last workgroup of a call leaves for the next one, per plan view (thread `v` of a wave): the head follows the
+// reach; a view whose tile pairs walked kDeepReach entries or more is marked deep
+__device__ __forceinline__ void close_view(int* ctl, int v) {
+  const int reached = atomicExch(ctl + kCtlReach + v, 0);
+  int deep = ctl[kCtlDeep + v];
+  if (reached > 0) {
+    ctl[kCtlHead + v] = (int)min(1l << 30, ((long)reached + reached / 4 + 2 * kBlock - 1) / kBlock * kBlock);
+    deep = reached >= kDeepReach ? 1 : 0;
+    ctl[kCtlDeep + v] = deep;
+  }
+  const unsigned long long any = __ballot(deep != 0);
+  if (v == 0) {
+    ctl[kCtlAnyDeep] = any != 0ull ? 1 : 0;
+    // ... and where the host can see it without a copy or a wait (pinned host memory, address left by the head kernel)
+    int* hint = reinterpret_cast<int*>(reinterpret_cast<unsigned long long*>(ctl + kCtlTables)[3]);
+    if (hint) *hint = any != 0ull ? 1 : 0;
+  }
+}
 
 // head of view v's list this step: `force` > 0: that many, < 0: none (diagnostic / tests), 0: what the last blend wrote.
 // No upper limit but the list's length: a scene whose pixels do not saturate (an object-centric opacity field) needs
@@ -489,6 +567,7 @@ constexpr int kHeadBlocks = 64;                  // workgroups per item of the h
 __device__ __forceinline__ int head_of(const int* ctl, int v, int nv, int force) {
   int k = force > 0 ? force : (force < 0 ? 0 : ctl[kCtlHead + v]);
   if (force == 0 && k == 0) k = kHeadDefault;
+  if (force == 0 && ctl[kCtlDeep + v] != 0) k = nv;
   return min(k, nv);
 }
 
@@ -525,6 +604,7 @@ struct HeadArgs {
   const unsigned* plan_cams;
   int* radii;                    // (n_items, P) or null: the radius of every listed (item, Gaussian) pair (zero-filled before)
   int all;                       // 1: every entry of every rendered view's list (radii asked for as an output)
+  int* hint;                     // host-visible word the blend's close-out writes "some view is deep" into (or null)
 };
 
 // entries [lo, hi) of item z's list (plan view v): conic / tile rect into the dynamic arrays, in list order; this
@@ -554,6 +634,7 @@ __global__ __launch_bounds__(kBlock) void raster_plan_head_kernel(HeadArgs a) {
     __shared__ int l_owner[32];
     __shared__ int l_seen[kMaxSets * 32];
     if (threadIdx.x == 0) {
+      reinterpret_cast<unsigned long long*>(a.ctl + kCtlTables)[3] = reinterpret_cast<unsigned long long>(a.hint);
       a.ctl[kCtlQueue] = 0;                        // ticket counter of the blend that follows
       if (flag) flag[1] = 0;                       // arrival counter of the armed per-call blend (rasterize.hip)
     }
@@ -593,6 +674,87 @@ __global__ __launch_bounds__(kBlock) void raster_plan_head_kernel(HeadArgs a) {
   const int nv = view_off[v + 1] - view_off[v];
   // entries [0, head) of the item's list, this workgroup every blocks_per_item-th chunk of 256
   prepare_entries(a, z, v, 0, a.all ? nv : head_of(a.ctl, v, nv, a.force_head), b % a.blocks_per_item, a.blocks_per_item);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Deep views — the last render walked far into the view's list: its pixels do not saturate early (an object-centric
+// opacity field: most Gaussians faint or invisible), so every tile pair tests most of its bin's candidates, and most of
+// those turn out not to reach it THIS call (cfg2, objects set: 21 000 candidates per tile pair, 1 200 hits).  For such a
+// view the head kernel has prepared the whole list; here, per segment of kSegC candidates of a bin, the candidates whose
+// opacity-tightened rect of this call reaches the bin at all are moved to the front of the segment's range — in order,
+// each with the mask of the bin's tiles its rect covers — so that the blend reads (position, mask) pairs coalesced: no
+// rect gather, no misses.  This is the per-call half of the reference's duplicateWithKeys (rasterizer_impl.cu:70-109),
+// paid only by views that need it.  One workgroup strides over the segments; all leave at once when no view is deep.
+// ---------------------------------------------------------------------------------------------
+struct CompactArgs {
+  const int* header;             // the plan's
+  const int* bins_header;
+  const int2* b_tab;
+  const int* b_seg;
+  const int* seg_bin;
+  const unsigned* cand;
+  const Rect* d_rect;            // list order (set_stride == 0: one copy)
+  int* ctl;
+  int* ccnt;
+  uint2* ccand;
+  int bw, bh, nbx, nbins;
+  const int* skip_if;
+};
+
+__global__ __launch_bounds__(kBlock) void raster_plan_compact_kernel(CompactArgs a) {
+  const bool on = a.ctl[kCtlAnyDeep] != 0 && !(a.skip_if && *a.skip_if != 0) && a.header[0] == (int)kPlanMagic &&
+                  a.bins_header[0] == (int)kBinsMagic;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a.ctl[kCtlCompacted] = on ? 1 : 0;
+    auto* tab = reinterpret_cast<unsigned long long*>(a.ctl + kCtlTables);
+    tab[0] = reinterpret_cast<unsigned long long>(a.b_seg);
+    tab[1] = reinterpret_cast<unsigned long long>(a.ccnt);
+    tab[2] = reinterpret_cast<unsigned long long>(a.ccand);
+  }
+  if (!on) return;
+  const int V = a.header[2];
+  const int n_seg_total = a.b_seg[V * a.nbins];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ int l_w[4];
+  for (int g = blockIdx.x; g < n_seg_total; g += gridDim.x) {
+    const int bin = a.seg_bin[g];
+    const int v = bin / a.nbins;
+    if (a.ctl[kCtlDeep + v] == 0) continue;
+    const int lb = bin - v * a.nbins;
+    const int tx0 = (lb % a.nbx) * a.bw, ty0 = (lb / a.nbx) * 2 * a.bh;      // the bin's first tile column / row
+    const int2 t0 = a.b_tab[bin], t1 = a.b_tab[bin + 1];
+    const int first = t0.x + t0.y + (g - a.b_seg[bin]) * kSegC;
+    const int end = min(first + kSegC, t1.x);
+    const int off = a.header[kHeaderInts + v];
+    int base = first;
+    for (int c0 = first; c0 < end; c0 += kBlock) {
+      const int c = c0 + (int)threadIdx.x;
+      unsigned pos = 0, mask = 0;
+      if (c < end) {
+        pos = a.cand[c];
+        const Rect rc = a.d_rect[off + (int)pos];
+        const int lx0 = max((int)rc.x0 - tx0, 0), lx1 = min((int)rc.x1 - tx0, a.bw);
+        const int ly0 = max((int)rc.y0 - ty0, 0), ly1 = min((int)rc.y1 - ty0, 2 * a.bh);
+        if (lx1 > lx0 && ly1 > ly0) {
+          const unsigned row = ((1u << (lx1 - lx0)) - 1u) << lx0;
+          for (int y = ly0; y < ly1; ++y) mask |= row << (y * a.bw);
+        }
+      }
+      const unsigned long long m = __ballot(mask != 0u);
+      if (lane == 0) l_w[wave] = __popcll(m);
+      __syncthreads();
+      int mine = base, tot = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        if (w < wave) mine += l_w[w];
+        tot += l_w[w];
+      }
+      if (mask != 0u) a.ccand[mine + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2(pos, mask);
+      base += tot;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) a.ccnt[g] = base - first;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -651,6 +813,7 @@ __global__ __launch_bounds__(kBlock) void raster_plan_check_kernel(long n_pairs,
 #define OCRF_BLEND_BOUNDS __launch_bounds__(kBlock, OCRF_PLAN_WAVES)
 
 constexpr int kItemTable = 64;                   // items whose view the blend keeps in LDS (more: read per tile pair)
+constexpr int kMaxSegTab = 128;                  // segments of a bin whose compacted counts a tile pair keeps in LDS
 // workgroup barrier that orders LDS traffic only (outstanding global stores are not waited for)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -699,8 +862,15 @@ struct BlendArgs {
   int last_pass;                 // this launch closes the call (heads from reach, counters back to zero)
 };
 
-template <bool MEDIAN, bool STATS = false>
-__global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(BlendArgs g) {
+// DEEP: the instantiation that carries the code for deep views (compacted candidates).  In the plain instantiation that
+// code — never executed on a scene that saturates early — cost every tile pair of every scene, wherever in the kernel it
+// stood and however little of it the plain path touched (cfg2, init set: step 0.208 -> 0.222-0.230 ms; a `continue` for
+// deep views, a start value of `blocked`, a zero head: all the same, tools/ab_libs.sh).  So WHICH instantiation a call
+// launches is decided on the host, from a word the last call's close-out wrote into host-visible memory (`hint`: stale by a
+// call or two at worst — either instantiation renders any view correctly, only faster or slower).
+// (DEEP at four waves per SIMD — what its grid asks for anyway: at five the extra state spills 12 VGPRs to scratch.)
+template <bool MEDIAN, bool STATS = false, bool DEEP = false>
+__global__ __launch_bounds__(kBlock, DEEP ? 4 : OCRF_PLAN_WAVES) void raster_blend_sorted_kernel(BlendArgs g) {
   __shared__ unsigned l_pos[kCapPos];
   __shared__ float4 l_a[kStageP + 1], l_b[kStageP + 1], l_c[kStageP + 1];
   // (aligned: a trip reads an entry PAIR as one 32-bit word; rows are 268 bytes)
@@ -714,16 +884,18 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(BlendArgs g) {
   // what a tile pair needs to know of its item, read from global memory ONCE per workgroup (a persistent workgroup
   // renders ~ 6 tile pairs; item -> view -> list offsets -> head was three dependent round trips at the start of each)
   __shared__ int l_voff[33], l_head[32], l_vsel[kItemTable];
+  __shared__ int l_deep[32];                  // [view]: its bins' candidates were compacted for this call
+  // deep tile pair, per WAVE (each wave builds its own copy: no workgroup barrier in the set-up): compacted candidates in
+  // front of each segment of its bin | its segments, its bin's first candidate behind the direct region, bit of tile A
+  __shared__ int l_segpre[DEEP ? 4 : 1][DEEP ? kMaxSegTab + 2 : 2];
+  __shared__ int l_tp[4][4];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   int* const ctl = g.ctl;
   if (g.pass == 2 && ctl[kCtlDeferred] == 0) {
     // the usual case: no tile pair of the first pass ran out of prepared records — workgroup 0 closes the call (next
     // call's heads from this call's reach; the first pass left the ticket queue and the arrival counter at zero)
-    if (blockIdx.x == 0 && tid < 32) {
-      const int reached = atomicExch(ctl + kCtlReach + tid, 0);
-      if (reached > 0) ctl[kCtlHead + tid] = (int)min(1l << 30, ((long)reached + reached / 4 + 2 * kBlock - 1) / kBlock * kBlock);
-    }
+    if (blockIdx.x == 0 && tid < 32) close_view(ctl, tid);
     return;
   }
   bool run = true;
@@ -772,6 +944,8 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(BlendArgs g) {
     if (tid >= 64 && tid < 96) {
       const int v = tid - 64;
       l_head[v] = (v < V && !g.full) ? head_of(ctl, v, view_off[v + 1] - view_off[v], g.force_head) : 0;
+      if constexpr (DEEP)
+        l_deep[v] = (v < V && use_bins && g.force_head == 0 && ctl[kCtlCompacted] != 0) ? ctl[kCtlDeep + v] : 0;
     }
     if (tid >= 128 && tid - 128 < min(g.n_items, kItemTable)) {
       const int z = tid - 128;
@@ -814,6 +988,7 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(BlendArgs g) {
   // (read here, used behind the direct region.  Read only by the tile pairs that get there — most of a saturating scene's
   // do not — the scan loop came out slower: 15.5 vs 14.5 us per tile pair at cfg2, tools/ab_gauss.sh)
   int n_direct = nv, nc = nv;
+  bool deep_view = false, deep_pair = false;      // compacted candidates behind the direct region (a deep view)
   const unsigned* cand = nullptr;
   if (use_bins) {
     const int bin = v * g.nbins + (ty2 / g.bh) * g.nbx + tx / g.bw;
@@ -822,6 +997,7 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(BlendArgs g) {
     const int first = __builtin_amdgcn_readfirstlane(t0.x) + __builtin_amdgcn_readfirstlane(t0.y);
     nc = n_direct + (__builtin_amdgcn_readfirstlane(t1.x) - first);
     cand = g.cand + first;
+    if constexpr (DEEP) deep_view = __builtin_amdgcn_readfirstlane(l_deep[v]) != 0;
   }
   const int pxi = tx * kTileX + lx;
   const int py0 = tyA * kTileY + 8 * wave + r, py1 = py0 + 4;
@@ -861,8 +1037,47 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(BlendArgs g) {
   tile.bx0 = bx0; tile.bx1 = bx1;
   const rbody::Lds lds{l_a, l_b, l_c, l_list, l_lcnt, l_generic, l_fmax};
   while (!all_done) {
+    if constexpr (DEEP) {
+    if (deep_view && !deep_pair && scan >= n_direct) {
+      // a deep view, and this tile pair has got past the direct region: this call's compacted candidates of its bin
+      // (position, tile mask), segment by segment.  (Set up HERE — between two scan phases, the first of which stops at
+      // the end of the direct region — and not inside the scan loop or in front of it: there the mere presence of this
+      // block cost every tile pair of every scene, 132 -> 160 us for cfg2's twelve views on the init set, tools/ab_libs.sh.)
+      deep_view = false;
+      const int bin = v * g.nbins + (ty2 / g.bh) * g.nbx + tx / g.bw;
+      const auto* tab = reinterpret_cast<const unsigned long long*>(ctl + kCtlTables);
+      const int* b_seg = reinterpret_cast<const int*>(tab[0]);
+      const int* ccnt = reinterpret_cast<const int*>(tab[1]);
+      const int s0 = __builtin_amdgcn_readfirstlane(b_seg[bin]);
+      const int ns = __builtin_amdgcn_readfirstlane(b_seg[bin + 1]) - s0;
+      if (ns <= kMaxSegTab) {
+        static_assert(kMaxSegTab <= 128, "two segments per lane");
+        const int l2 = 2 * lane;
+        const int ca = l2 < ns ? ccnt[s0 + l2] : 0, cb = l2 + 1 < ns ? ccnt[s0 + l2 + 1] : 0;
+        int inc = ca + cb;
+        for (int d = 1; d < 64; d <<= 1) {
+          const int y = __shfl_up(inc, d);
+          if (lane >= d) inc += y;
+        }
+        const int before = inc - (ca + cb);
+        l_segpre[wave][l2 + 1] = before + ca;            // (entries beyond ns: never read)
+        l_segpre[wave][l2 + 2] = before + ca + cb;
+        if (lane == 0) {
+          l_segpre[wave][0] = 0;
+          // (read back in the scan rounds: kept out of the scalar registers the record loops are short of)
+          l_tp[wave][0] = ns;
+          l_tp[wave][1] = (int)(cand - g.cand);
+          l_tp[wave][2] = ((tyA - (ty2 / g.bh) * 2 * g.bh) * g.bw) + (tx - (tx / g.bw) * g.bw);
+        }
+        deep_pair = true;
+        nc = n_direct + __builtin_amdgcn_readlane(inc, 63);
+      }
+    }
+    }
+    // (a deep view's first scan phase ends with the direct region: the compacted lists are set up above, next time round)
+    const int lim = deep_view ? n_direct : nc;
     // ---- scan: positions of the candidates whose rect covers this tile pair, in list (= blend) order ----
-    while (scan < nc && npos < kStageP && !blocked) {
+    while (scan < lim && npos < kStageP && !blocked) {
       // the direct region 256 rects at a time (a dense tile pair fills its first batch from them); behind it the
       // candidates kScanUnrollP x 256 at a time: each round is two dependent memory round trips (candidate -> rect)
       const int n_u = (scan < n_direct) ? 1 : kScanUnrollP;
@@ -874,7 +1089,22 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(BlendArgs g) {
         hit[u] = false;
         valid[u] = false;
         code[u] = 0u;
-        if (u < n_u && ic < nc) {
+        if (DEEP && u < n_u && ic < nc && deep_pair && ic >= n_direct) {
+          // deep: the j-th compacted candidate of the bin = entry j - pre[s] of segment s, pre[s] <= j < pre[s + 1]
+          const int j = ic - n_direct;
+          const int nseg = l_tp[wave][0], tail_first = l_tp[wave][1], bit_a = l_tp[wave][2];
+          int lo = 0, hi = nseg;
+          while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (l_segpre[wave][mid] <= j) lo = mid; else hi = mid;
+          }
+          const uint2* ccand = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned long long*>(ctl + kCtlTables)[2]);
+          const uint2 e = ccand[tail_first + lo * kSegC + (j - l_segpre[wave][lo])];
+          const bool cA = ((e.y >> bit_a) & 1u) != 0u, cB = ((e.y >> (bit_a + g.bw)) & 1u) != 0u;
+          valid[u] = true;                      // (a deep view's whole list is prepared)
+          hit[u] = cA || cB;
+          code[u] = e.x | (cA ? 0x40000000u : 0u) | (cB ? 0x80000000u : 0u);
+        } else if (u < n_u && ic < nc) {
           const int i = ic < n_direct ? ic : (int)cand[ic - n_direct];
           // candidates are ascending: the unprepared ones (i >= head) are a suffix of the round
           valid[u] = i < head;
@@ -919,7 +1149,10 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(BlendArgs g) {
       __syncthreads();
     }
     stamp(0);
-    if (npos == 0) break;                     // list exhausted
+    if (npos == 0) {
+      if (deep_view && !blocked && scan < nc) continue;      // nothing in the direct region: on to the compacted lists
+      break;                                  // list exhausted
+    }
     for (int s0 = 0; s0 < npos && !all_done; s0 += kStageP) {
       const int ns = min(kStageP, npos - s0);
       // ---- stage ns records, build the four waves' lists, blend them (raster_blend_body.h) ----
@@ -999,10 +1232,7 @@ __global__ OCRF_BLEND_BOUNDS void raster_blend_sorted_kernel(BlendArgs g) {
   __syncthreads();
   if (l_work) {
     __threadfence();
-    if (tid < 32 && g.last_pass) {                     // one memory round trip for all views, not 32 in a row
-      const int reached = atomicExch(ctl + kCtlReach + tid, 0);
-      if (reached > 0) ctl[kCtlHead + tid] = (int)min(1l << 30, ((long)reached + reached / 4 + 2 * kBlock - 1) / kBlock * kBlock);
-    }
+    if (tid < 32 && g.last_pass) close_view(ctl, tid);      // one memory round trip for all views, not 32 in a row
     if (tid == 32) atomicExch(ctl + kCtlArrive, 0);
     if (tid == 33) atomicExch(ctl + kCtlQueue, 0);
     if (tid == 34 && g.last_pass) atomicExch(ctl + kCtlDeferred, 0);
@@ -1256,6 +1486,10 @@ int ocrf_raster_plan_bins_build(const void* plan, size_t plan_bytes, int P, int 
                      cand_capacity, static_cast<const unsigned*>(range), static_cast<const int*>(counts),
                      static_cast<const int*>(total), reinterpret_cast<int2*>(qb + Q.b_off),
                      reinterpret_cast<unsigned*>(qb + Q.cand));
+  hipLaunchKernelGGL(plan_bins_segments_kernel, dim3(1), dim3(kBlock), 0, stream, n_views * nbins,
+                     max_segments(cand_capacity, (long)n_views * nbins), reinterpret_cast<const int2*>(qb + Q.b_off),
+                     static_cast<const int*>(total), cand_capacity, reinterpret_cast<int*>(qb + Q.b_seg),
+                     reinterpret_cast<int*>(qb + Q.seg_bin));
   hipLaunchKernelGGL(plan_bins_header_kernel, dim3(1), dim3(64), 0, stream, header, static_cast<const int*>(total),
                      cand_capacity, n_views, gx, gy, bin_w, bin_h, nbx, nby,
                      reinterpret_cast<const unsigned long long*>(wb + B.scan), reinterpret_cast<int*>(qb + Q.header));
@@ -1269,6 +1503,17 @@ size_t ocrf_rasterize_planned_workspace_bytes(long total_kept, int n_sets) {
   return L.bytes;
 }
 
+// ... with candidate lists (ocrf_raster_plan_bins_build): room for the per-call compaction of deep views too
+size_t ocrf_rasterize_planned_bins_workspace_bytes(long total_kept, int n_sets, int n_views, int H, int W, int bin_w, int bin_h,
+                                                   long cand_capacity) {
+  int gx, gy, nbx, nby;
+  if (total_kept < 0 || n_sets <= 0 || n_views <= 0 || cand_capacity <= 0 || !bins_shape(H, W, bin_w, bin_h, &gx, &gy, &nbx, &nby))
+    return 0;
+  DynLayout L;
+  dyn_layout(total_kept, n_sets, &L, cand_capacity, (long)n_views * nbx * nby);
+  return L.bytes;
+}
+
 int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_plan_views, long total_kept, int H, int W,
                            int n_sets, int n_items, const int* item_view, const float* colors,
                            const float* opacities, const float* scales, float scale_modifier, const float* rotations,
@@ -1277,7 +1522,7 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
                            const float* means3D, void* chain_workspace, size_t chain_workspace_bytes,
                            int blend_workgroups, const int* yield_if, int phase, const float* call_cameras,
                            int views_disjoint, const void* bins, size_t bins_bytes, int bin_w, int bin_h,
-                           long cand_capacity, ocrf_stream_t stream_) {
+                           long cand_capacity, int* hint, ocrf_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (!plan || P <= 0 || n_plan_views <= 0 || n_plan_views > 32 || total_kept < 0 || total_kept >= (1l << 30) ||
       H <= 0 || W <= 0 || n_sets <= 0 || n_sets > kMaxSets || n_items <= 0 || n_items % n_sets || blend_workgroups < 0 ||
@@ -1294,8 +1539,11 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
   // views_disjoint: every plan view is rendered by at most one set of this call (checked on the device: status bit 8) —
   // all sets share ONE copy of the dynamic arrays
   const long set_stride = views_disjoint ? 0 : total_kept;
+  int q_gx, q_gy, q_nbx = 1, q_nby = 1;
+  const bool have_bins = bins != nullptr && cand_capacity > 0 && bins_shape(H, W, bin_w, bin_h, &q_gx, &q_gy, &q_nbx, &q_nby);
   DynLayout D;
-  dyn_layout(total_kept, views_disjoint ? 1 : n_sets, &D);
+  dyn_layout(total_kept, views_disjoint ? 1 : n_sets, &D, have_bins ? cand_capacity : 0,
+             have_bins ? (long)n_plan_views * q_nbx * q_nby : 0);
   if (plan_bytes < L.bytes || workspace_bytes < D.bytes) return (int)hipErrorInvalidValue;
   const int gx = (W + kTileX - 1) / kTileX, gy = (H + kTileY - 1) / kTileY;
   const char* pb = static_cast<const char*>(plan);
@@ -1313,6 +1561,8 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
   const int2* b_tab = nullptr;
   const unsigned* cand = nullptr;
   int nbx = 1, nbins = 1;
+  CompactArgs comp{};
+  bool compact = false;
   if (bins) {
     int bgx, bgy, nby;
     if (!bins_shape(H, W, bin_w, bin_h, &bgx, &bgy, &nbx, &nby) || cand_capacity <= 0) return (int)hipErrorInvalidValue;
@@ -1324,6 +1574,18 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
     b_tab = reinterpret_cast<const int2*>(qb + Q.b_off);
     cand = reinterpret_cast<const unsigned*>(qb + Q.cand);
     nbins = nbx * nby;
+    // per-call compaction of deep views: one copy of the dynamic arrays (set_stride == 0) and a bin of <= 32 tiles
+    if (set_stride == 0 && bin_w * 2 * bin_h <= 32) {
+      comp.header = header; comp.bins_header = bins_header; comp.b_tab = b_tab;
+      comp.b_seg = reinterpret_cast<const int*>(qb + Q.b_seg);
+      comp.seg_bin = reinterpret_cast<const int*>(qb + Q.seg_bin);
+      comp.cand = cand; comp.d_rect = d_rect; comp.ctl = ctl;
+      comp.ccnt = reinterpret_cast<int*>(wb + D.ccnt);
+      comp.ccand = reinterpret_cast<uint2*>(wb + D.ccand);
+      comp.bw = bin_w; comp.bh = bin_h; comp.nbx = nbx; comp.nbins = nbins;
+      comp.skip_if = nullptr;
+      compact = true;
+    }
   }
   int* flag = nullptr;
   int* chain_hist = nullptr;
@@ -1361,6 +1623,9 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
   h.plan_cams = reinterpret_cast<const unsigned*>(cams);
   h.radii = full ? radii : nullptr;
   h.all = full ? 1 : 0;
+  // deep mode: the last call (or the one before) left "some view is deep" in the caller's host-visible word
+  compact = compact && !full && g_head_force == 0 && hint != nullptr && *reinterpret_cast<volatile int*>(hint) != 0;
+  h.hint = hint;
   if (phase != 2) {
     if (guard) {      // (behind the blend otherwise: there it is a status bit only)
       const long n_pairs = (long)n_sets * P;
@@ -1374,6 +1639,10 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
     h.blocks_per_item = (g_head_force < 0 && !full) ? 0 : kHeadBlocks;
     ocrf::launch(OCRF_K_RASTER_PLAN_UPDATE, raster_plan_head_kernel,
                  dim3((unsigned)std::max(1, n_items * h.blocks_per_item)), dim3(kBlock), 0, stream, h);
+    if (compact) {      // (behind the head kernel: it reads this call's rects; leaves at once unless a view is deep)
+      comp.skip_if = flag;
+      hipLaunchKernelGGL(raster_plan_compact_kernel, dim3(1024), dim3(kBlock), 0, stream, comp);
+    }
   }   // phase != 2
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
@@ -1409,17 +1678,20 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
   auto blend = [&](const BlendArgs& ga, bool first) -> hipError_t {
     if (g_plan_stats) {      // diagnostic build (median depth), never used by the product path
       const dim3 sgrid((unsigned)std::min(n_work, want_grid ? want_grid : resident_blocks(raster_blend_sorted_kernel<true, true>)));
-      hipLaunchKernelGGL((raster_blend_sorted_kernel<true, true>), sgrid, dim3(kBlock), 0, stream, ga);
+      if (!compact) hipLaunchKernelGGL((raster_blend_sorted_kernel<true, true, false>), sgrid, dim3(kBlock), 0, stream, ga);
+      else hipLaunchKernelGGL((raster_blend_sorted_kernel<true, true, true>), sgrid, dim3(kBlock), 0, stream, ga);
       return hipGetLastError();
     }
     // (the kernel timer of bench.py's roofline leg sees the FIRST pass; the second has an id of its own)
     const int kid = first ? OCRF_K_RASTER_BLEND_SORTED : OCRF_K_RASTER_BLEND_SECOND;
-#define OCRF_BLEND_SORTED(MED)                                                                                         \
-  ocrf::launch(kid, raster_blend_sorted_kernel<MED>,                                                                   \
-               dim3((unsigned)std::min(n_work, want_grid ? want_grid : resident_blocks(raster_blend_sorted_kernel<MED>))), \
+#define OCRF_BLEND_SORTED(MED, DEEPK)                                                                                  \
+  ocrf::launch(kid, raster_blend_sorted_kernel<MED, false, DEEPK>,                                                     \
+               dim3((unsigned)std::min(n_work, want_grid ? want_grid : resident_blocks(raster_blend_sorted_kernel<MED, false, DEEPK>))), \
                dim3(kBlock), 0, stream, ga)
-    if (depth_mode == 0) OCRF_BLEND_SORTED(true);
-    else OCRF_BLEND_SORTED(false);
+    if (depth_mode == 0 && !compact) OCRF_BLEND_SORTED(true, false);
+    else if (depth_mode == 0) OCRF_BLEND_SORTED(true, true);
+    else if (!compact) OCRF_BLEND_SORTED(false, false);
+    else OCRF_BLEND_SORTED(false, true);
 #undef OCRF_BLEND_SORTED
     return hipGetLastError();
   };

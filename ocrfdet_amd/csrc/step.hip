@@ -48,7 +48,7 @@ struct FnInfo {
 
 const FnInfo kFns[kFnCount] = {
     {"ocrf_bev_pool_v2_nchw_planned", 17}, {"ocrf_bev_pool_v2_nchw_mfma", 19},  {"ocrf_bev_pool_cell_weights", 9},
-    {"ocrf_bev_pool_v2_nchw_panel", 20},   {"ocrf_rasterize_planned", 38},      {"ocrf_hoa1_forward", 9},
+    {"ocrf_bev_pool_v2_nchw_panel", 20},   {"ocrf_rasterize_planned", 39},      {"ocrf_hoa1_forward", 9},
     {"ocrf_hoa_v2b_forward", 9},           {"ocrf_hoa_channel_stats", 6},       {"ocrf_hoa_opacity_mask_gate", 11},
     {"ocrf_stream_write_value32", 2},      {"ocrf_raster_plan_build", 12},      {"ocrf_rasterize_forward", 23},
     {"ocrf_bev_pool_v2_nchw_dyn", 19},     {"ocrf_lss_prepare", 20},            {"ocrf_ht_prepare", 22},
@@ -109,7 +109,7 @@ int call(const Cmd& c, ocrf_stream_t s) {
                                     P<int*>(a[21]), P<void*>(a[22]), Z(a[23]), I(a[24]), P<const float*>(a[25]),
                                     P<void*>(a[26]), Z(a[27]), I(a[28]), P<const int*>(a[29]), I(a[30]),
                                     P<const float*>(a[31]), I(a[32]), P<const void*>(a[33]), Z(a[34]), I(a[35]), I(a[36]),
-                                    L(a[37]), s);
+                                    L(a[37]), P<int*>(a[38]), s);
     case kHoa1:
       return ocrf_hoa1_forward(P<const float*>(a[0]), P<const float*>(a[1]), P<const float*>(a[2]), I(a[3]), I(a[4]),
                                I(a[5]), F(a[6]), P<float*>(a[7]), P<float*>(a[8]), s);

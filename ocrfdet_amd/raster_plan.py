@@ -83,6 +83,9 @@ class RasterPlan:
         self._chain_ws = None
         self._host_guarded = False             # a render with guard='host' happened since the last check()
         self.bins = None if bins is None else (int(bins[0]), int(bins[1]))
+        # one pinned host int the device writes ("some view is deep") and ocrf_rasterize_planned reads on the host — no copy,
+        # no wait — to choose the build of the blend (include/ocrf_hip.h)
+        self._hint = torch.zeros(1, dtype=torch.int32).pin_memory() if self.bins is not None else None
         self._bins_buf = self._bins_ws = None
         self.cand_capacity = 0
         self.rebuild()
@@ -170,7 +173,12 @@ class RasterPlan:
         return self
 
     def _scratch(self, n_sets):
-        need = _lib.lib().ocrf_rasterize_planned_workspace_bytes(ctypes.c_long(self.capacity), n_sets)
+        L = _lib.lib()
+        if self._bins_buf is not None:
+            need = L.ocrf_rasterize_planned_bins_workspace_bytes(ctypes.c_long(self.capacity), n_sets, self.V, self.H, self.W,
+                                                                 self.bins[0], self.bins[1], ctypes.c_long(self.cand_capacity))
+        else:
+            need = L.ocrf_rasterize_planned_workspace_bytes(ctypes.c_long(self.capacity), n_sets)
         if self._dyn is None or self._dyn.numel() < need:
             # zero-filled: the guard flag lives in it between calls (include/ocrf_hip.h, ocrf_rasterize_planned)
             self._dyn = torch.zeros(max(int(need), 256), dtype=torch.uint8, device=self.device)
@@ -276,7 +284,7 @@ class RasterPlan:
                 _lib.ptr(cameras), int(disjoint), _lib.ptr(self._bins_buf),
                 ctypes.c_size_t(self._bins_buf.numel() if self._bins_buf is not None else 0),
                 self.bins[0] if self.bins else 0, self.bins[1] if self.bins else 0, ctypes.c_long(self.cand_capacity),
-                _lib.stream_ptr(dev)),
+                ctypes.c_void_p(self._hint.data_ptr() if self._hint is not None else 0), _lib.stream_ptr(dev)),
                 'ocrf_rasterize_planned')
         out['status'] = self.status
         return out

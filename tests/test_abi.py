@@ -139,3 +139,15 @@ def test_pooling_entry_points_refuse_operands_of_two_gib_at_the_c_boundary():
                                            ok, ok, None) == invalid
     assert L.ocrf_bev_pool_v2_nchw_panel(80, 4, p, p, p, p, p, p, p, p, p, p, 1, 1, 8, 8, 1, p, p, two_gib, None) == invalid
     assert L.ocrf_bev_pool_v2_nchw_panel(80, 4, p, p, p, p, p, p, p, p, p, p, 8, 1, 1024, 1024, 1, p, p, ok, None) == invalid
+
+
+def test_candidate_list_size_queries_are_host_only():
+    """ocrf_raster_plan_bins_*: sizes from the shapes alone; a bin grid beyond 255 bins per axis is refused (0)."""
+    lib = _lib.lib()
+    n = lib.ocrf_raster_plan_bins_bytes(12, 256, 704, 4, 2, ctypes.c_long(1_000_000))
+    assert n >= 4 * 1_000_000 + 8 * (12 * 11 * 4 + 1)
+    assert lib.ocrf_raster_plan_bins_bytes(12, 256, 704, 4, 2, ctypes.c_long(2_000_000)) > n
+    assert lib.ocrf_raster_plan_bins_bytes(12, 16 * 300, 16 * 300, 1, 1, ctypes.c_long(1000)) == 0      # 300 x 150 bins
+    assert lib.ocrf_raster_plan_bins_bytes(33, 256, 704, 4, 2, ctypes.c_long(1000)) == 0                # > 32 views
+    assert lib.ocrf_raster_plan_bins_workspace_bytes(520000, 12, 256, 704, 4, 2, ctypes.c_long(1_500_000)) > 4 * 1_500_000
+    assert lib.ocrf_raster_plan_bins_workspace_bytes(520000, 12, 256, 704, 0, 2, ctypes.c_long(1_500_000)) == 0

@@ -335,7 +335,7 @@ def test_mostly_transparent_scene(cuda):
 
 def _heads(plan):
     """head[v] control words of the plan's per-call scratch (raster_plan.hip kCtlHead)."""
-    ctl = plan._dyn[plan._dyn.numel() - 512:].view(torch.int32).cpu().numpy()
+    ctl = plan._dyn[plan._dyn.numel() - 1024:].view(torch.int32).cpu().numpy()
     return [int(x) for x in ctl[32:32 + plan.V]]
 
 
@@ -368,11 +368,33 @@ def test_candidate_lists_change_nothing(cuda, bins):
             assert plan.candidates > 0 and plan.cand_capacity >= plan.candidates
 
 
-def test_lists_that_never_saturate_are_prepared_once_and_whole(cuda):
+def test_candidate_lists_that_do_not_fit_are_ignored(cuda):
+    """A candidate capacity too small for the lists (as after a ``rebuild`` for a pose that lists more): the build leaves
+    the buffer without its magic word and the renders walk whole lists — slower, the same image."""
+    rng = np.random.default_rng(41)
+    W, H = 176, 80
+    xyz, rgb, opac, sc, rot = _scene(rng, 20000, cuda)
+    cams = _cams(cuda, W, H, [(0, 0, 0), (1.5, -0.5, 2.0)])
+    bg = torch.tensor([0.1, 0.0, 0.3], device=cuda)
+    want = dgr.rasterize_views(xyz, rgb, opac, sc, rot, None, None, None, None, H, W, bg, packed_cameras=cams,
+                               want_n_contrib=False)
+    fits = rp.RasterPlan(xyz, cams, H, W, scales=sc, rotations=rot)
+    small = rp.RasterPlan(xyz, cams, H, W, scales=sc, rotations=rot, cand_capacity=fits.candidates // 3)
+    assert int(fits._bins_buf[:4].view(torch.int32).item()) != 0          # "OCRB"
+    assert int(small._bins_buf[:4].view(torch.int32).item()) == 0         # no magic: ignored
+    _same(want, fits.render(rgb, opac, sc, rot, bg))
+    _same(want, small.render(rgb, opac, sc, rot, bg))
+    assert small.check() and fits.check()
+
+
+@pytest.mark.parametrize('bins', [(4, 2), (8, 2), (1, 1), (6, 3)])
+def test_lists_that_never_saturate_are_prepared_once_and_whole(cuda, bins):
     """An object-centric opacity field: most Gaussians faint, so most pixels never reach T < 1e-4 and a tile pair walks its
     whole candidate list — far beyond round 5's 16 384-entry head.  The first call hands such tile pairs to the second pass
     (the rest of the lists is prepared once in between), the head then covers the whole list; every call gives the per-call
-    pipeline's image bit for bit, and the head shrinks again when the scene saturates early."""
+    pipeline's image bit for bit, and the head shrinks again when the scene saturates early.  From the second such call on the
+    views are "deep": the host-visible hint is up, the call compacts the bins' candidates for this call's rects and the
+    build of the blend that reads them renders (bins of up to 32 tiles; (6, 3) = 36 tiles: no compaction, same image)."""
     rng = np.random.default_rng(37)
     W, H = 176, 80
     n = 90000
@@ -380,7 +402,7 @@ def test_lists_that_never_saturate_are_prepared_once_and_whole(cuda):
     cams = _cams(cuda, W, H, [(0, 0, 0), (1.5, -0.5, 2.0)])
     bg = torch.tensor([0.3, 0.2, 0.1], device=cuda)
     faint = opac * 0.01                                    # every alpha a few times 1/255 at most
-    plan = rp.RasterPlan(xyz, cams, H, W, scales=sc, rotations=rot)
+    plan = rp.RasterPlan(xyz, cams, H, W, scales=sc, rotations=rot, bins=bins)
     assert min(plan.kept) > 2 * 16384
     want_faint = dgr.rasterize_views(xyz, rgb, faint, sc, rot, None, None, None, None, H, W, bg, packed_cameras=cams,
                                      want_n_contrib=False)
@@ -392,8 +414,13 @@ def test_lists_that_never_saturate_are_prepared_once_and_whole(cuda):
     _same(want_faint, plan.render(rgb, faint, sc, rot, bg))        # lagging head: second pass
     grown = _heads(plan)
     assert all(h >= k for h, k in zip(grown, plan.kept)), (grown, plan.kept)
-    _same(want_faint, plan.render(rgb, faint, sc, rot, bg))        # whole lists prepared by the head kernel
-    _same(want_dense, plan.render(rgb, opac, sc, rot, bg))
+    torch.cuda.synchronize()
+    assert int(plan._hint.item()) == 1                             # the close-out told the host: deep views
+    _same(want_faint, plan.render(rgb, faint, sc, rot, bg))        # whole lists prepared by the head kernel, candidates compacted
+    _same(want_faint, plan.render(0.5 * rgb, faint, sc, rot, bg), ('depth', 'final_T'))
+    _same(want_dense, plan.render(rgb, opac, sc, rot, bg))         # (a deep-mode call on a scene that is not deep any more)
+    torch.cuda.synchronize()
+    assert int(plan._hint.item()) == 0
     _same(want_dense, plan.render(rgb, opac, sc, rot, bg))
     assert max(_heads(plan)) <= 4 * max(dense_heads) + 1024
     assert plan.check()
