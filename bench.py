@@ -1064,7 +1064,9 @@ def main():
             # contributor index every pixel stopped at (a lower bound of what the kernel evaluates)
             n_launch = len(hp._plans()) if planned else hp.batch      # a planned launch blends every frame of its plan
             evals = float(sum(int(o['n_contrib'].sum().item()) for o in hp.render(want_n_contrib=True))) / n_launch
-            c = pmc_counters('raster_blend_sorted_kernel' if planned else 'raster_blend_kernel<false, false, true, false>', args)
+            # (the FIRST pass of the planned blend: the second — usually an empty launch — is a symbol of its own)
+            c = pmc_counters('raster_blend_sorted_kernel<true, false, false, false>' if planned else
+                             'raster_blend_kernel<false, false, true, false>', args)
             cycles = blend_ms * 1e-3 * CLOCK_HZ
             # The planned kernel's OWN count: a wave of it evaluates only the records whose ellipse reaches its 16 x 8
             # pixel block (fewer than a tile's list up to the stop index, which is what n_contrib counts): the

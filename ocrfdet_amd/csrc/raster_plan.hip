@@ -869,7 +869,9 @@ struct BlendArgs {
 // launches is decided on the host, from a word the last call's close-out wrote into host-visible memory (`hint`: stale by a
 // call or two at worst — either instantiation renders any view correctly, only faster or slower).
 // (DEEP at four waves per SIMD — what its grid asks for anyway: at five the extra state spills 12 VGPRs to scratch.)
-template <bool MEDIAN, bool STATS = false, bool DEEP = false>
+// SECOND: nothing but the kernel's NAME — the second pass (usually an empty launch) as a symbol of its own, so that a
+// profile's per-kernel means (rocprofv3 --stats, --pmc) are those of the first pass and not halved by the empty launches.
+template <bool MEDIAN, bool STATS = false, bool DEEP = false, bool SECOND = false>
 __global__ __launch_bounds__(kBlock, DEEP ? 4 : OCRF_PLAN_WAVES) void raster_blend_sorted_kernel(BlendArgs g) {
   __shared__ unsigned l_pos[kCapPos];
   __shared__ float4 l_a[kStageP + 1], l_b[kStageP + 1], l_c[kStageP + 1];
@@ -1678,20 +1680,24 @@ int ocrf_rasterize_planned(const void* plan, size_t plan_bytes, int P, int n_pla
   auto blend = [&](const BlendArgs& ga, bool first) -> hipError_t {
     if (g_plan_stats) {      // diagnostic build (median depth), never used by the product path
       const dim3 sgrid((unsigned)std::min(n_work, want_grid ? want_grid : resident_blocks(raster_blend_sorted_kernel<true, true>)));
-      if (!compact) hipLaunchKernelGGL((raster_blend_sorted_kernel<true, true, false>), sgrid, dim3(kBlock), 0, stream, ga);
-      else hipLaunchKernelGGL((raster_blend_sorted_kernel<true, true, true>), sgrid, dim3(kBlock), 0, stream, ga);
+      if (!compact && first) hipLaunchKernelGGL((raster_blend_sorted_kernel<true, true, false, false>), sgrid, dim3(kBlock), 0, stream, ga);
+      else if (!compact) hipLaunchKernelGGL((raster_blend_sorted_kernel<true, true, false, true>), sgrid, dim3(kBlock), 0, stream, ga);
+      else if (first) hipLaunchKernelGGL((raster_blend_sorted_kernel<true, true, true, false>), sgrid, dim3(kBlock), 0, stream, ga);
+      else hipLaunchKernelGGL((raster_blend_sorted_kernel<true, true, true, true>), sgrid, dim3(kBlock), 0, stream, ga);
       return hipGetLastError();
     }
     // (the kernel timer of bench.py's roofline leg sees the FIRST pass; the second has an id of its own)
     const int kid = first ? OCRF_K_RASTER_BLEND_SORTED : OCRF_K_RASTER_BLEND_SECOND;
-#define OCRF_BLEND_SORTED(MED, DEEPK)                                                                                  \
-  ocrf::launch(kid, raster_blend_sorted_kernel<MED, false, DEEPK>,                                                     \
-               dim3((unsigned)std::min(n_work, want_grid ? want_grid : resident_blocks(raster_blend_sorted_kernel<MED, false, DEEPK>))), \
+#define OCRF_BLEND_SORTED(MED, DEEPK, SEC)                                                                             \
+  ocrf::launch(kid, raster_blend_sorted_kernel<MED, false, DEEPK, SEC>,                                                \
+               dim3((unsigned)std::min(n_work, want_grid ? want_grid : resident_blocks(raster_blend_sorted_kernel<MED, false, DEEPK, SEC>))), \
                dim3(kBlock), 0, stream, ga)
-    if (depth_mode == 0 && !compact) OCRF_BLEND_SORTED(true, false);
-    else if (depth_mode == 0) OCRF_BLEND_SORTED(true, true);
-    else if (!compact) OCRF_BLEND_SORTED(false, false);
-    else OCRF_BLEND_SORTED(false, true);
+#define OCRF_BLEND_PASS(MED, DEEPK) do { if (first) OCRF_BLEND_SORTED(MED, DEEPK, false); else OCRF_BLEND_SORTED(MED, DEEPK, true); } while (0)
+    if (depth_mode == 0 && !compact) OCRF_BLEND_PASS(true, false);
+    else if (depth_mode == 0) OCRF_BLEND_PASS(true, true);
+    else if (!compact) OCRF_BLEND_PASS(false, false);
+    else OCRF_BLEND_PASS(false, true);
+#undef OCRF_BLEND_PASS
 #undef OCRF_BLEND_SORTED
     return hipGetLastError();
   };
