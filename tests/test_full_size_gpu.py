@@ -72,6 +72,36 @@ def test_cfg2_render_on_the_other_gaussian_sets(cuda, oracle_lib, gaussians):
     _render_vs_oracle(hp, oracle_lib, views=(1, 4), max_outlier_frac=2e-4 if gaussians == 'objects' else 5e-5)
 
 
+def test_replayed_step_follows_a_scene_that_turns_object_centric_and_back(cuda):
+    """The recorded step (one host call) re-reads the render plans' host-visible hint at EVERY replay: a scene whose opacity
+    field turns object-centric IN PLACE (same tensors, new values — what a network's heads do over a training run) is handed to
+    the second pass once, then rendered by the build of the blend that reads per-call compacted candidates, and goes back to the
+    plain build when the field saturates again; every step's renders equal the per-call pipeline's bit for bit."""
+    cfg = _one_frame(CFG2)
+    hp = hotpath.HotPath(cfg, cuda)                                   # init set, planned, one host call
+    ref = hotpath.HotPath(cfg, cuda, render_mode='per_call', one_call=False)
+    depth, feat = hp.make_inputs(seed=1)
+    xyz = hp.voxel_xyz[0].reshape(-1, 3).cpu().numpy()
+    sets = {k: synthetic.grid_gaussians(k, xyz, seed=7) for k in ('init', 'objects')}
+    hints = []
+    for kind in ('init', 'init', 'init', 'objects', 'objects', 'objects', 'objects', 'init', 'init', 'init'):
+        for h in (hp, ref):
+            for k, v in sets[kind].items():
+                h.frame_gauss[0][k].copy_(torch.from_numpy(v).to(cuda))
+        for plan, f0, nf, gg in hp._plans():
+            for k in ('rgb', 'opacity', 'scales', 'rotations'):
+                gg[k].copy_(torch.stack([hp.frame_gauss[b][k] for b in range(f0, f0 + nf)]))
+        got = hp.step(depth, feat)[2][0]
+        want = ref.render()[0]
+        torch.cuda.synchronize()
+        for k in ('color', 'depth', 'final_T'):
+            assert torch.equal(got[k], want[k]), (kind, k, len(hints))
+        hints.append(int(hp.render_plans[0][0]._hint.item()))
+    assert hp._compiled, getattr(hp, 'one_call_refused', None)
+    assert hints[:3] == [0, 0, 0] and hints[3:7] == [1, 1, 1, 1] and hints[-2:] == [0, 0], hints
+    hp.check_render_plans()
+
+
 def test_cfg4_rank_triples_pools_and_render_at_512x1408(cuda, oracle_lib):
     cfg = _one_frame(CFG4)
     assert cfg.feat_hw == (32, 88)
