@@ -641,10 +641,33 @@ class HotPath:
             self._one_call_ok = False
             self.one_call_refused = rec.why or 'per-step calibration algebra on the host is issued call by call'
             return out
+        compiled = rec.build()
+        # The recorder sees the library's calls only: a torch kernel issued inside the step (a ``zero_``, a ``copy_``, a
+        # hidden ``.contiguous()``) would be missing from the replay, silently.  So the FIRST replay is held
+        # to the step that was just issued call by call, bit for bit, on the same inputs — one synchronisation, at record
+        # time only; a recording that does not reproduce itself is dropped and the step stays call by call.
+        flat = [t for t in self._flat_outputs(out)]
+        want = [t.clone() for t in flat]
+        compiled.run(*[st.cuda_stream for st in self._step_streams(cur)])
+        torch.cuda.synchronize(self.device)
+        if not all(torch.equal(a, b) for a, b in zip(flat, want)):
+            self._one_call_ok = False
+            self.one_call_refused = 'the first replay of the recorded step did not reproduce the step issued call by call'
+            return self._step_eager(depth, feat)
         while len(self._compiled) >= 4:                    # (two phases x two input pairs, with room)
             self._compiled.pop(next(iter(self._compiled)))
-        self._compiled[key] = (rec.build(), out, pool, _lib.workspace.generation(self.device))
+        self._compiled[key] = (compiled, out, pool, _lib.workspace.generation(self.device))
         return out
+
+    @staticmethod
+    def _flat_outputs(out):
+        for o in out:
+            if torch.is_tensor(o):
+                yield o
+            elif isinstance(o, dict):
+                yield from (v for k, v in o.items() if torch.is_tensor(v) and k != 'status')
+            elif isinstance(o, (list, tuple)):
+                yield from HotPath._flat_outputs(o)
 
     def _step_eager(self, depth, feat, rec=None):
         fork = self._forks()

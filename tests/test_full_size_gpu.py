@@ -102,6 +102,27 @@ def test_replayed_step_follows_a_scene_that_turns_object_centric_and_back(cuda):
     hp.check_render_plans()
 
 
+def test_a_recording_that_misses_a_launch_is_refused(cuda):
+    """The recorder logs the library's entry points only.  A step with a torch kernel of its own in it (here: one added to the
+    pooled LSS volume after the fact) would replay WITHOUT that kernel: the first replay is held to the step issued call by
+    call, the recording is dropped and the step stays call by call — still with the right values."""
+    class Leaky(hotpath.HotPath):
+        def _step_eager(self, depth, feat, rec=None):
+            out = super()._step_eager(depth, feat, rec)
+            out[0].add_(1.0)                                          # a launch the recorder cannot see
+            return out
+
+    cfg = _one_frame(CFG2)
+    hp, ref = Leaky(cfg, cuda), hotpath.HotPath(cfg, cuda, one_call=False)
+    depth, feat = hp.make_inputs(seed=1)
+    want = ref.step(depth, feat)[0] + 1.0
+    for _ in range(4):
+        got = hp.step(depth, feat)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+    assert not hp._compiled and 'did not reproduce' in hp.one_call_refused
+
+
 def test_cfg4_rank_triples_pools_and_render_at_512x1408(cuda, oracle_lib):
     cfg = _one_frame(CFG4)
     assert cfg.feat_hw == (32, 88)
