@@ -655,6 +655,21 @@ int ocrf_gauss_heads(const float *bev, const float *rgb_avg, const float *params
 int ocrf_gauss_heads_params_len(int C, int Zh);
 
 /*
+ * Backward of ocrf_gauss_heads: what autograd does for the reference through VoxelFeatureExtractor (:520-531) and the four
+ * heads (:272-320, calls :1130-1133) on the (B,Zh,Y,X,C) voxel feature, here without that tensor (the lift and the hidden
+ * units are recomputed from bev).  g_* are the gradients of the four outputs (same shapes; NULL = zero); d_bev (B,C,YX) is
+ * zeroed and written here; d_params receives the gradient w.r.t. every entry of `params`, in the layout of `params`
+ * (lift_a / lift_b first: the caller owns the folding of Conv3d + BatchNorm3d — batch statistics in training — and
+ * differentiates through it).  No gradient for rgb_avg (sampled from the camera images, :1071).  Deterministic.
+ * workspace: ocrf_gauss_heads_backward_workspace_bytes(B, C, Zh, YX) bytes (0: unsupported shape).
+ */
+size_t ocrf_gauss_heads_backward_workspace_bytes(int B, int C, int Zh, int YX);
+int ocrf_gauss_heads_backward(const float *bev, const float *rgb_avg, const float *params, int B, int C, int Zh, int YX,
+                              const float *g_opacity, const float *g_scales, const float *g_rotations,
+                              const float *g_color, float *d_bev, float *d_params, void *workspace,
+                              size_t workspace_bytes, ocrf_stream_t stream);
+
+/*
  * NeRF branch (view_transformer_ocrf.py:1094-1121) from z (M,32,h2,w2) = ResizeNetwork.conv2's
  * output (:546); the caller composes upsample2 (k2 s2) -> upsample3 (k4 s4) -> first Linear of each
  * consumer into per-sub-position maps (64 positions of the 8x8 up-sampling cell):
@@ -780,7 +795,9 @@ enum {
   OCRF_K_NECK_PLANE_PASS = 67,   /* neck_plane_pass_kernel<WRITE, RELU, STATS> */
   OCRF_K_NECK_CHANNEL_MLP = 68,  /* neck_channel_mlp_kernel */
   OCRF_K_NECK_SCALED_STATS = 69, /* neck_scaled_channel_stats_kernel */
-  OCRF_K_NECK_CBAM_TAIL = 70     /* neck_cbam_tail_kernel */
+  OCRF_K_NECK_CBAM_TAIL = 70,    /* neck_cbam_tail_kernel */
+  OCRF_K_NECK_HEADS_BWD = 71,    /* neck_gauss_heads_backward_kernel */
+  OCRF_K_NECK_HEADS_BWD_SUM = 72 /* neck_partial_rows_sum_kernel (both stages) */
 };
 const char *ocrf_kernel_name(int kernel_id);           /* symbol as rocprofv3 prints it */
 /* Diagnostic: a one-thread kernel that stores the device's constant-rate clock (wall_clock64, 100 MHz)

@@ -206,6 +206,10 @@ def _declare(L):
     L.ocrf_gauss_heads.argtypes = [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 5
     L.ocrf_gauss_heads_params_len.restype = c_int
     L.ocrf_gauss_heads_params_len.argtypes = [c_int, c_int]
+    L.ocrf_gauss_heads_backward_workspace_bytes.restype = c_size_t
+    L.ocrf_gauss_heads_backward_workspace_bytes.argtypes = [c_int] * 4
+    L.ocrf_gauss_heads_backward.restype = c_int
+    L.ocrf_gauss_heads_backward.argtypes = [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 7 + [c_size_t, c_void_p]
     L.ocrf_nerf_alpha.restype = c_int
     L.ocrf_nerf_alpha.argtypes = [c_void_p] * 4 + [c_int] * 3 + [c_void_p]
     L.ocrf_nerf_render.restype = c_int

@@ -35,7 +35,7 @@ import torch.nn as nn
 from . import _lib
 
 __all__ = ['GaussianRasterizationSettings', 'GaussianRasterizer', 'rasterize_gaussians', 'rasterize_views', 'pack_cameras',
-           'rasterize_views_backward', 'rasterize_views_autograd']
+           'rasterize_views_backward', 'rasterize_views_autograd', 'rasterize_packed_autograd']
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -324,6 +324,38 @@ def rasterize_views_autograd(means3D, colors, opacities, scales, rotations, view
     depth (V,1,H,W), final_T (V,H,W), radii (V,P))."""
     cam = (viewmatrices, projmatrices, tanfovx, tanfovy, image_height, image_width, bg, scale_modifier)
     return _RasterizeViews.apply(means3D, colors, opacities, scales, rotations, cam)
+
+
+class _RasterizePacked(torch.autograd.Function):
+    """``_RasterizeViews`` for cameras already packed on the device ((V,36) rows of ``pack_cameras``): nothing of the call
+    touches the host's copy of the calibration (no matrix uploads, no focal arithmetic per call)."""
+
+    @staticmethod
+    def forward(ctx, means3D, colors, opacities, scales, rotations, packed, H, W, bg):
+        out = rasterize_views(means3D, colors, opacities, scales, rotations, None, None, None, None, H, W, bg,
+                              packed_cameras=packed)
+        ctx.cam = (packed, H, W, bg)
+        ctx.save_for_backward(means3D, colors, opacities, scales, rotations, out['color'], out['final_T'], out['n_contrib'])
+        ctx.mark_non_differentiable(out['depth'], out['radii'], out['final_T'])
+        return out['color'], out['depth'], out['final_T'], out['radii']
+
+    @staticmethod
+    def backward(ctx, grad_color, _d, _t, _r):
+        means3D, colors, opacities, scales, rotations, fwd_color, fwd_T, fwd_n = ctx.saved_tensors
+        packed, H, W, bg = ctx.cam
+        fwd = dict(color=fwd_color, final_T=fwd_T, n_contrib=fwd_n)
+        g = rasterize_views_backward(grad_color, fwd, means3D, colors, opacities, scales, rotations, None, None, None, None,
+                                     H, W, bg, packed_cameras=packed)
+        need = ctx.needs_input_grad
+        grads = (g['means3D'], g['colors'], g['opacities'].reshape(opacities.shape), g['scales'], g['rotations'])
+        return tuple(v if n else None for v, n in zip(grads, need)) + (None, None, None, None)
+
+
+def rasterize_packed_autograd(means3D, colors, opacities, scales, rotations, packed_cameras, image_height, image_width, bg):
+    """``rasterize_views_autograd`` with the cameras given as packed device rows (V,36):
+    -> (color (V,3,H,W), depth (V,1,H,W), final_T (V,H,W), radii (V,P)), autograd through the colour."""
+    return _RasterizePacked.apply(means3D, colors, opacities, scales, rotations, packed_cameras, int(image_height),
+                                  int(image_width), bg)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,

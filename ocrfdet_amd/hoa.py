@@ -26,6 +26,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib
+from .neck_ops import tall_linear
 
 __all__ = ['HeightAttention', 'OpacityVoxelToBEVConverter', 'ObatinOpacityMask', 'DeformableAttention2D',
            'CPB', 'hoa1', 'spatial_gate']
@@ -96,10 +97,20 @@ class HeightAttention(nn.Module):
         return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
 
     def _forward_torch(self, x):
-        q = self.q_in
-        outs = [conv(x[:, i * q:(i + 1) * q].amax((2, 3), keepdim=True))
-                for i, conv in enumerate((self.conv1, self.conv2, self.conv3, self.conv4))]
-        return self.tanh(torch.cat(outs, dim=1))
+        """The differentiable formulation (view_transformer_ocrf.py:499-514): per quarter of the channels a spatial maximum
+        and conv1x1 -> ReLU -> conv1x1 on the pooled (B,q,1,1) vector.  The eight 1 x 1 convolutions on 1 x 1 maps are two
+        batched matrix products here: as convolutions each took MIOpen's naive kernels — three launches forward + backward,
+        ~50 us of host time apiece, ~140 launches per training iteration of the neck."""
+        B, q = x.shape[0], self.q_in
+        convs = (self.conv1, self.conv2, self.conv3, self.conv4)
+        if not all(len(c) == 3 and c[0].bias is None and c[2].bias is None for c in convs):
+            outs = [conv(x[:, i * q:(i + 1) * q].amax((2, 3), keepdim=True)) for i, conv in enumerate(convs)]
+            return self.tanh(torch.cat(outs, dim=1))
+        pooled = x.reshape(B, 4, q, -1).amax(-1)                                             # (B,4,q)
+        w1 = torch.stack([c[0].weight.reshape(self.hid, q) for c in convs])                  # (4,hid,q)
+        w2 = torch.stack([c[2].weight.reshape(self.q_out, self.hid) for c in convs])         # (4,q_out,hid)
+        hidden = torch.relu(torch.einsum('bgq,ghq->bgh', pooled, w1))
+        return self.tanh(torch.einsum('bgh,goh->bgo', hidden, w2).reshape(B, 4 * self.q_out, 1, 1))
 
     def forward(self, x):
         _lib.require_cuda(x)               # GPU only, also for the differentiable formulation
@@ -483,8 +494,10 @@ class CPB(nn.Module):
         gk = grid_kv.reshape(grid_kv.shape[0], -1, grid_kv.shape[-1])
         pos = gq[:, :, None, :] - gk[:, None, :, :]
         bias = torch.sign(pos) * torch.log(pos.abs() + 1)
+        # (B x queries x keys rows — 139 392 at cfg2 — through Linear layers 2 / 3 columns wide: under autograd their weight
+        # gradients are tall reductions that hipBLASLt runs at 0.4-0.5 ms each; neck_ops.tall_linear splits K)
         for layer in self.mlp:
-            bias = layer(bias)
+            bias = torch.relu(tall_linear(layer[0], bias)) if isinstance(layer, nn.Sequential) else tall_linear(layer, bias)
         bg, i, j, o = bias.shape
         g = self.offset_groups
         return bias.view(bg // g, g, i, j, o).permute(0, 1, 4, 2, 3).reshape(bg // g, g * o, i, j)

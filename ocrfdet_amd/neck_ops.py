@@ -9,10 +9,13 @@ kernels read; they are pure torch and run anywhere.
 import ctypes
 
 import torch
+import torch.nn.functional as F
 
 from . import _lib
 
 __all__ = ['prefilter', 'pillar_sample_mean', 'retain_valid_pixels', 'gauss_heads', 'pack_gauss_head_params',
+           'lift_coefficients', 'pack_gauss_head_params_autograd', 'gauss_heads_train', 'gauss_heads_backward',
+           'TallLinear', 'tall_linear',
            'compose_nerf_maps', 'nerf_alpha', 'nerf_render', 'pack_fusion_params', 'dual_feat_fusion',
            'plane_bias_act_stats', 'channel_mlp', 'scaled_channel_stats', 'cbam_tail', 'pack_global_att',
            'pack_probnet', 'probnet_forward', 'global_att_vector']
@@ -137,6 +140,136 @@ def gauss_heads(bev, rgb_avg, params, num_height):
                                       _lib.ptr(op), _lib.ptr(sc), _lib.ptr(rot), _lib.ptr(col), _lib.stream_ptr(dev)),
                    'ocrf_gauss_heads')
     return op, sc, rot, col
+
+
+def lift_coefficients(vfe, x=None):
+    """``VoxelFeatureExtractor`` (view_transformer_ocrf.py:520-531) as ``relu(a_h x + b_h)`` per height h, WITH autograd:
+    channel h of the 1-channel ``Conv3d(k = 1)`` is ``w_h x + c_h``, so BatchNorm3d's statistics of it are
+    ``w_h mean(x) + c_h`` and ``w_h^2 var(x)``.  ``x`` given and the BatchNorm in training mode: the batch statistics of
+    ``x`` (differentiated through, and the running statistics take their momentum update); otherwise the running ones."""
+    conv, bn = vfe.conv[0], vfe.conv[1]
+    w = conv.weight.reshape(-1)
+    c = conv.bias if conv.bias is not None else torch.zeros_like(w)
+    if bn.training and x is not None:
+        n = x.numel()
+        var, mean = torch.var_mean(x.float(), unbiased=False)
+        mean_h, var_h = w * mean + c, w * w * var
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            bn.running_mean.mul_(1 - mom).add_(mean_h, alpha=mom)
+            bn.running_var.mul_(1 - mom).add_(var_h * (n / max(n - 1, 1)), alpha=mom)
+    else:
+        mean_h, var_h = bn.running_mean, bn.running_var
+    s = bn.weight * torch.rsqrt(var_h + bn.eps)
+    return s * w, s * (c - mean_h) + bn.bias
+
+
+def pack_gauss_head_params_autograd(vfe, s_mlp, r_mlp, a_mlp, c_mlp, x=None):
+    """``pack_gauss_head_params`` as differentiable torch ops (fp32): the gradient ``gauss_heads_train`` returns for the
+    packed block flows on to the modules' parameters — and, through the batch statistics, to ``x``."""
+    a, b = lift_coefficients(vfe, x)
+    C = s_mlp.fc1.in_features
+    w1 = torch.cat((s_mlp.fc1.weight, r_mlp.fc1.weight, a_mlp.fc1.weight, c_mlp.fc1.weight[:, :C]), 0)
+    parts = [a, b, w1.t().reshape(-1), c_mlp.fc1.weight[:, C:].reshape(-1),
+             s_mlp.fc1.bias, r_mlp.fc1.bias, a_mlp.fc1.bias, c_mlp.fc1.bias]
+    for m in (s_mlp, r_mlp, a_mlp, c_mlp):
+        parts += [m.fc2.weight.reshape(-1), m.fc2.bias]
+    return torch.cat([p.float().reshape(-1) for p in parts])
+
+
+class _GaussHeadsTrain(torch.autograd.Function):
+    """``ocrf_gauss_heads`` forward, ``ocrf_gauss_heads_backward`` backward: nothing is kept between the two but the inputs
+    (the (B,Zh,Y,X,C) voxel feature of the reference, 333 MB at cfg2, exists in neither)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, bev, rgb_avg, params, num_height):
+        bev, rgb_avg, params = _f32c(bev), _f32c(rgb_avg), _f32c(params)
+        ctx.save_for_backward(bev, rgb_avg, params)
+        ctx.num_height = num_height
+        return gauss_heads(bev, rgb_avg, params, num_height)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, g_op, g_sc, g_rot, g_col):
+        bev, rgb_avg, params = ctx.saved_tensors
+        d_bev, d_params = gauss_heads_backward(bev, rgb_avg, params, ctx.num_height, g_op, g_sc, g_rot, g_col)
+        return d_bev, None, d_params, None
+
+
+def gauss_heads_train(bev, rgb_avg, params, num_height):
+    """``gauss_heads`` under autograd (training mode of view_transformer_ocrf.py:1051, :1130-1133): gradients for ``bev``
+    and for the packed ``params`` (``pack_gauss_head_params_autograd``); none for ``rgb_avg``, which is sampled from the
+    camera images."""
+    return _GaussHeadsTrain.apply(bev, rgb_avg, params, num_height)
+
+
+def gauss_heads_backward(bev, rgb_avg, params, num_height, g_opacity=None, g_scales=None, g_rotations=None, g_color=None):
+    """-> (d_bev (B,C,Y,X), d_params (like params)) from the gradients of the four outputs (None = zero)."""
+    _lib.require_cuda(bev, rgb_avg, params)
+    B, C, Y, X = bev.shape
+    L = _lib.lib()
+    if params.numel() != L.ocrf_gauss_heads_params_len(C, num_height):
+        raise ValueError('gauss_heads_backward: parameter block does not match (C, num_height)')
+    dev, P = bev.device, num_height * Y * X
+    grads = []
+    for g, k in ((g_opacity, 1), (g_scales, 3), (g_rotations, 4), (g_color, 3)):
+        if g is not None:
+            if g.numel() != B * P * k:
+                raise ValueError('gauss_heads_backward: an output gradient does not match its output')
+            g = _f32c(g)
+        grads.append(g)
+    need = L.ocrf_gauss_heads_backward_workspace_bytes(B, C, num_height, Y * X)
+    if not need:
+        raise ValueError(f'gauss_heads_backward: num_height {num_height} has no register tile')
+    scratch = _lib.workspace.get(dev, need, 'gauss_heads_backward')
+    d_bev, d_params = torch.empty_like(bev), torch.empty_like(params)
+    with _lib.on_device(dev):
+        _lib.check(L.ocrf_gauss_heads_backward(
+            _lib.ptr(bev), _lib.ptr(rgb_avg), _lib.ptr(params), B, C, num_height, Y * X,
+            *[_lib.ptr(g) if g is not None else None for g in grads], _lib.ptr(d_bev), _lib.ptr(d_params),
+            _lib.ptr(scratch), scratch.numel(), _lib.stream_ptr(dev)), 'ocrf_gauss_heads_backward')
+    return d_bev, d_params
+
+
+class TallLinear(torch.autograd.Function):
+    """``F.linear`` whose weight gradient is a split-K batched GEMM.  The heads run on 10^6 rows with 4..83
+    columns; hipBLASLt computes ``dW = dY^T X`` (K = rows) as ONE tall reduction at 1-5 ms per layer (20 ms of an
+    84 ms neck forward + backward).  Chunks of 4096 rows through ``bmm`` + a sum are ~30x faster."""
+    CHUNK = 4096
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda')
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = g.matmul(weight)
+        g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
+        if ctx.needs_input_grad[1]:
+            r = TallLinear.CHUNK
+            n = g2.shape[0] // r
+            gw = torch.bmm(g2[:n * r].view(n, r, -1).transpose(1, 2), x2[:n * r].view(n, r, -1)).sum(0)
+            if n * r < g2.shape[0]:
+                gw = gw + g2[n * r:].t().mm(x2[n * r:])
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g2.sum(0)
+        return gx, gw, gb
+
+
+def tall_linear(lin, x):
+    """``lin(x)`` for an ``nn.Linear``; many-row inputs under autograd take the split-K weight gradient."""
+    if x.is_cuda and torch.is_grad_enabled() and x.numel() // x.shape[-1] >= 8 * TallLinear.CHUNK:
+        return TallLinear.apply(x, lin.weight, lin.bias)
+    return lin(x)
 
 
 def compose_nerf_maps(resize, sigma, c_mlp_nerf, img_feat_resize1, img_feat_resize2):

@@ -35,7 +35,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib, bevpool, gaussian_renderer, hoa, index_prep, neck_ops
-from .diff_gaussian_rasterization import pack_cameras, rasterize_sets
+from .diff_gaussian_rasterization import pack_cameras, rasterize_packed_autograd, rasterize_sets
 
 __all__ = ['OcRFViewTransformerFull', 'GraphedNeck', 'MS_CAM', 'ChannelAttention', 'SpatialAttention', 'ResCBAMBlock', 'ProbNet',
            'DualFeatFusion', 'BEVGeomAttention', 'ScaleFactorMLP', 'RotationFactorMLP', 'OpacityFactorMLP',
@@ -255,43 +255,7 @@ class BEVGeomAttention(nn.Module):
         return self.forward(x, bev_prob) * x
 
 
-class _TallLinear(torch.autograd.Function):
-    """``F.linear`` whose weight gradient is a split-K batched GEMM.  The heads run on 10^6 rows with 4..83
-    columns; hipBLASLt computes ``dW = dY^T X`` (K = rows) as ONE tall reduction at 1-5 ms per layer (20 ms of an
-    84 ms neck forward + backward).  Chunks of 4096 rows through ``bmm`` + a sum are ~30x faster."""
-    CHUNK = 4096
-
-    @staticmethod
-    @torch.amp.custom_fwd(device_type='cuda')
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
-        return F.linear(x, weight, bias)
-
-    @staticmethod
-    @torch.amp.custom_bwd(device_type='cuda')
-    def backward(ctx, g):
-        x, weight = ctx.saved_tensors
-        gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            gx = g.matmul(weight)
-        g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
-        if ctx.needs_input_grad[1]:
-            r = _TallLinear.CHUNK
-            n = g2.shape[0] // r
-            gw = torch.bmm(g2[:n * r].view(n, r, -1).transpose(1, 2), x2[:n * r].view(n, r, -1)).sum(0)
-            if n * r < g2.shape[0]:
-                gw = gw + g2[n * r:].t().mm(x2[n * r:])
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g2.sum(0)
-        return gx, gw, gb
-
-
-def _linear(lin, x):
-    """``lin(x)`` for an ``nn.Linear``; many-row inputs under autograd take the split-K weight gradient."""
-    if x.is_cuda and torch.is_grad_enabled() and x.numel() // x.shape[-1] >= 8 * _TallLinear.CHUNK:
-        return _TallLinear.apply(x, lin.weight, lin.bias)
-    return lin(x)
+_TallLinear, _linear = neck_ops.TallLinear, neck_ops.tall_linear
 
 
 class _Head(nn.Module):
@@ -531,6 +495,9 @@ class OcRFViewTransformerFull(nn.Module):
         # pipeline armed behind every render (four near-empty launches, ~24 us at cfg2); 'host' — only a status bit is
         # raised, ``check_render()`` (one synchronising read) turns it into an exception: the caller decides when to pay
         self.render_guard = 'device'
+        # training mode: the voxel lift + four Gaussian heads by the fused forward / backward kernels (csrc/neck_train.hip)
+        # instead of torch layers on the (B,Zh,Y,X,C) voxel feature; False keeps the reference's layer formulation
+        self.fused_heads_training = True
         # eval-mode strands on side HIP streams (see _core_fused); off by default: a caller that runs the
         # module under its own stream discipline should opt in
         self.parallel_branches, self._transient = False, hoa._LaunchCache()     # streams: not module state
@@ -848,13 +815,16 @@ class OcRFViewTransformerFull(nn.Module):
         ht_feat = self.get_ht_bev_feat(geo, depth5, feat_cl)
         (opacity, scaling, rotation, color, sparse, alpha_lidar, render_N,
          render_depth_N) = self._neck_torch(input, geo, ht_feat, cam_idx_list)
+        # one differentiable render per sample (:1135-1153) from the camera rows staged on the device above — the
+        # reference's per-sample camera set-up (matrix uploads, focal arithmetic: ~0.9 ms of host time per sample here)
+        # was already done once, for the whole batch, by stage_cameras
+        if self._bg is None or self._bg.device != x.device:
+            self._bg = torch.zeros(3, device=x.device)
         render_G, render_depth_G = [], []
         for bs in range(B):
-            cam = self._camera(geo, bs, cam_idx_list[bs])
-            cam = {k: (v.to(x.device) if torch.is_tensor(v) and v.dim() else v) for k, v in cam.items()}
-            img, dep = gaussian_renderer.render(cam, cam_idx_list[bs], voxel_coor[bs], color[bs], rotation[bs],
-                                                scaling[bs], opacity[bs], bg_color=[0, 0, 0])
-            render_G.append(img.unsqueeze(0)), render_depth_G.append(dep.unsqueeze(0))
+            img, dep, _, _ = rasterize_packed_autograd(voxel_coor[bs], color[bs], opacity[bs], scaling[bs], rotation[bs],
+                                                       cameras['packed'][bs:bs + 1], H, W, self._bg)
+            render_G.append(img), render_depth_G.append(dep)
         render_image_G_all, render_depth_G_all = torch.cat(render_G), torch.cat(render_depth_G)
         render_image = self.LinearWeightedImage(render_image_G_all, render_N)
         render_depth = self.LinearWeightedDepth(render_depth_G_all, render_depth_N)
@@ -1161,10 +1131,35 @@ class OcRFViewTransformerFull(nn.Module):
         a_sel = alpha.view(B, N, H, W, 1)[ar, sel]
         render_N = (a_sel * radiance).permute(0, 3, 1, 2)
         render_depth_N = (a_sel * radiance1).permute(0, 3, 1, 2)
+        if self.fused_heads_training and self._heads_fusable(ht_feat):
+            # lift + four heads forward by ocrf_gauss_heads, backward by ocrf_gauss_heads_backward: the (B,Zh,Y,X,C) voxel
+            # feature (333 MB at cfg2, read or written by ~100 torch kernels of an iteration) exists in neither; the
+            # modules' parameters — and ht_feat, also through the BatchNorm's batch statistics — get their gradients
+            # through the differentiable packing of the kernels' parameter block
+            heads = (self.S_MLP, self.R_MLP, self.A_MLP, self.C_MLP)
+            prm = neck_ops.pack_gauss_head_params_autograd(self.ObtainVoxelFeature, *heads, x=ht_feat)
+            opacity, scaling, rotation, color = neck_ops.gauss_heads_train(ht_feat, avg_rgb.reshape(B, Zh, Y * X, 3), prm, Zh)
+            return opacity, scaling, rotation, color, sparse, alpha_lidar, render_N, render_depth_N
         voxel_feat = self.ObtainVoxelFeature(ht_feat.permute(0, 2, 3, 1).unsqueeze(1)).reshape(B, Zh * Y * X, -1)
         rgb01 = avg_rgb.reshape(B, Zh * Y * X, 3) / 255.0
         return (self.A_MLP(voxel_feat), self.S_MLP(voxel_feat), self.R_MLP(voxel_feat),
                 self.C_MLP(torch.cat((voxel_feat, rgb01), -1)), sparse, alpha_lidar, render_N, render_depth_N)
+
+    def _heads_fusable(self, ht_feat):
+        """The shapes csrc/neck_train.hip has register tiles for, and exactly the reference's layer types (a converted
+        ``SyncBatchNorm`` needs cross-rank statistics and takes the layer path)."""
+        vfe = self.ObtainVoxelFeature
+        conv, bn = vfe.conv[0], vfe.conv[1]
+        C = ht_feat.shape[1]
+        heads = ((self.S_MLP, ScaleFactorMLP, C, 3), (self.R_MLP, RotationFactorMLP, C, 4),
+                 (self.A_MLP, OpacityFactorMLP, C, 1), (self.C_MLP, ColorFactorMLPGaussian, C + 3, 3))
+        return (ht_feat.is_cuda and ht_feat.dtype == torch.float32 and self.num_height in (1, 2, 4, 6, 8, 13)
+                and type(conv) is nn.Conv3d and conv.in_channels == 1 and conv.kernel_size == (1, 1, 1)
+                and conv.out_channels == self.num_height
+                and type(bn) is nn.BatchNorm3d and bn.affine and bn.track_running_stats
+                and all(type(m) is cls and m.fc1.in_features == cin and m.fc1.out_features == 4
+                        and m.fc2.out_features == cout and m.fc1.bias is not None and m.fc2.bias is not None
+                        for m, cls, cin, cout in heads))
 
     # -------------------------------------------------------------------------------- forward
     def forward(self, input, stereo_metas=None):

@@ -547,6 +547,44 @@ def test_full_training_mode_forward_backward(core):
     assert not missing, f'no / non-finite gradient for {missing[:8]}'
 
 
+def test_fused_heads_training_matches_layer_formulation(core):
+    """``module.train()``: the whole neck forward + backward with the voxel lift + four heads on the fused forward / backward
+    kernels (csrc/neck_train.hip, the default) against the reference's layer formulation on the (B,13,Y,X,80) voxel
+    feature (``fused_heads_training = False``) — loss, input gradients and every parameter gradient within 1e-4 of the
+    largest entry, BatchNorm running statistics alike."""
+    import copy
+    cfg, g = core['cfg'], core['g']
+    pre = torch.from_numpy(g['pre']).cuda()
+    got = {}
+    for fused in (True, False):
+        m = copy.deepcopy(core['m']).train()
+        m.fused_heads_training = fused
+        depth = pre[:, :cfg.D].softmax(1).requires_grad_(True)
+        feat = pre[:, cfg.D + 2:].clone().requires_grad_(True)
+        torch.manual_seed(0)
+        bev, _, logit, lst = m.view_transform_core(core['inp'], depth, feat, cam_idx_list=[1, 4])
+        loss = bev.square().mean() + logit.square().mean() + lst[0].mean() + lst[6].mean() + lst[4].square().mean()
+        loss.backward()
+        grads = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
+        grads['<depth>'], grads['<feat>'] = depth.grad, feat.grad
+        bn = m.ObtainVoxelFeature.conv[1]
+        got[fused] = (float(loss.detach()), grads, lst[2].detach(), (bn.running_mean.clone(), bn.running_var.clone()))
+    assert abs(got[True][0] - got[False][0]) <= 1e-5 * abs(got[False][0])
+    close(got[True][2], got[False][2].cpu().numpy(), 1e-5, 'Gaussian render, fused heads vs layers')
+    assert set(got[True][1]) == set(got[False][1])
+    # the convolution in front of a BatchNorm in training mode: its gradient is a residue of cancelling terms of the size
+    # of the BatchNorm weight's gradient (tests/test_neck_train_gpu.py), which is the scale it is held to
+    bn_scale = float(got[False][1]['ObtainVoxelFeature.conv.1.weight'].abs().max())
+    for n, want in got[False][1].items():
+        scale = bn_scale if n.startswith('ObtainVoxelFeature.conv.0') else float(want.abs().max())
+        err = float((got[True][1][n] - want).abs().max())
+        # (+ 1e-7: biases in front of a training-mode BatchNorm have gradients of ~1e-8 — rounding residue of sums that
+        # cancel, in either formulation)
+        assert err <= 1e-4 * scale + 1e-7, f'{n}: |err| {err:.3e} vs 1e-4 x {scale:.3e}'
+    for a, b in zip(got[True][3], got[False][3]):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+
+
 def test_parallel_branches_match_single_stream(core):
     """The three strands of the fused step on side HIP streams give the single-stream result, call
     after call (buffers of one call are recycled by the next)."""
