@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU-box session producing everything kept under profiles/ for round 5:
+# One GPU-box session producing everything kept under profiles/ for round 6:
 #   tools/final_round_r6.sh [tag]     -> gpurun_out/<tag>_*, gpurun_out/prof_<tag>/
 set -eo pipefail
 TAG=${1:-r6}
@@ -45,6 +45,9 @@ t time_render_plan tools/time_render_plan.py
 t time_render_per_call tools/time_render.py
 t time_index_prep tools/time_index_prep.py
 t modes tools/modes_r5.py neck
+t time_heads_train tools/time_heads_train.py
+t neck_train_cfg2_profile tools/time_neck_train.py --profile
+t neck_train_cfg2_layers tools/time_neck_train.py --layers
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d $ROOT/$O/${TAG}_trace_step -o x -- python3 $ROOT/tools/_steps_only.py > $ROOT/$O/${TAG}_trace_step.log 2>&1 ) || true
 python3 tools/step_timeline.py $O/${TAG}_trace_step/x_kernel_trace.csv > $O/${TAG}_timeline_hotpath.txt 2>&1 || true
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/${TAG}_trace_neck -o x -- python3 $ROOT/tools/_neck_only.py graph 30 > $ROOT/$O/${TAG}_trace_neck.log 2>&1 ) || true
