@@ -422,6 +422,22 @@ int ocrf_rasterize_backward_cov3d(int P, int n_views, int H, int W, const float 
                                   void *workspace, size_t workspace_bytes, ocrf_stream_t stream);
 size_t ocrf_rasterize_backward_workspace_bytes(int P, int n_views);
 
+/*
+ * Spherical-harmonics colours (the `shs` argument of the reference's rasteriser; computeColorFromSH,
+ * cuda_rasterizer/forward.cu:20-71, used by preprocessCUDA when colors_precomp is NULL, :240-247): for one camera centre
+ * `campos` (3 floats on the device), colors[g] = max(0.5 + sum_{i < (deg+1)^2} basis_i(dir_g) * shs[g][i], 0) with dir_g the
+ * unit vector from campos to means3D[g]; clamped (P,3) bytes record which channels were clamped (the backward zeroes their
+ * gradient, backward.cu:33-36).  shs (P, max_coeffs, 3), deg in 0..3, max_coeffs >= (deg+1)^2.  The (P,3) colours feed
+ * ocrf_rasterize_forward as its `colors` for that view.
+ * Backward (backward.cu:20-140): dL_dshs (P, max_coeffs, 3) is fully written (zero above the active degree); the
+ * direction's dependence on the mean is ADDED to dL_dmeans3D (P,3) (which already holds the rasteriser's part).
+ */
+int ocrf_sh_to_rgb(int P, int deg, int max_coeffs, const float *means3D, const float *campos, const float *shs,
+                   float *colors, unsigned char *clamped, ocrf_stream_t stream);
+int ocrf_sh_to_rgb_backward(int P, int deg, int max_coeffs, const float *means3D, const float *campos,
+                            const float *shs, const unsigned char *clamped, const float *dL_dcolors,
+                            float *dL_dmeans3D, float *dL_dshs, ocrf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Index preparation of the two poolings on the device (csrc/index_prep.hip).
  *
@@ -796,6 +812,8 @@ enum {
   OCRF_K_NECK_CHANNEL_MLP = 68,  /* neck_channel_mlp_kernel */
   OCRF_K_NECK_SCALED_STATS = 69, /* neck_scaled_channel_stats_kernel */
   OCRF_K_NECK_CBAM_TAIL = 70,    /* neck_cbam_tail_kernel */
+  OCRF_K_RASTER_SH = 50,         /* sh_colors_kernel */
+  OCRF_K_RASTER_SH_BWD = 51,     /* sh_colors_backward_kernel */
   OCRF_K_NECK_HEADS_BWD = 71,    /* neck_gauss_heads_backward_kernel */
   OCRF_K_NECK_HEADS_BWD_SUM = 72 /* neck_partial_rows_sum_kernel (both stages) */
 };

@@ -206,6 +206,10 @@ def _declare(L):
     L.ocrf_gauss_heads.argtypes = [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 5
     L.ocrf_gauss_heads_params_len.restype = c_int
     L.ocrf_gauss_heads_params_len.argtypes = [c_int, c_int]
+    L.ocrf_sh_to_rgb.restype = c_int
+    L.ocrf_sh_to_rgb.argtypes = [c_int] * 3 + [c_void_p] * 6
+    L.ocrf_sh_to_rgb_backward.restype = c_int
+    L.ocrf_sh_to_rgb_backward.argtypes = [c_int] * 3 + [c_void_p] * 8
     L.ocrf_gauss_heads_backward_workspace_bytes.restype = c_size_t
     L.ocrf_gauss_heads_backward_workspace_bytes.argtypes = [c_int] * 4
     L.ocrf_gauss_heads_backward.restype = c_int

@@ -23,8 +23,9 @@ Compute: ``csrc/rasterize.hip`` through the C ABI (``ocrf_rasterize_forward`` /
 ``ocrf_rasterize_backward``).  The backward covers what the fork's does — the colour output w.r.t.
 means3D, means2D (screen-space, for densification statistics), colours, opacities, scales, rotations;
 depth has no backward in the fork either (diff-gaussian-rasterization-w-depth/README.md:13).
-``cov3D_precomp`` has its own backward (gradient w.r.t. the six covariance entries).  SH colours are outside the path OcRFDet uses (``shs=None``
-at the call site) and raise ``NotImplementedError``.
+``cov3D_precomp`` has its own backward (gradient w.r.t. the six covariance entries).  SH colours (``shs`` (P,M,3) with
+``raster_settings.sh_degree`` / ``campos``; OcRFDet itself passes ``shs=None``) are evaluated by ``ocrf_sh_to_rgb`` into the
+(P,3) colours of the ordinary pipeline, forward and backward (``forward.cu:20-71``, ``backward.cu:20-140``).
 """
 import ctypes
 from typing import NamedTuple
@@ -35,7 +36,8 @@ import torch.nn as nn
 from . import _lib
 
 __all__ = ['GaussianRasterizationSettings', 'GaussianRasterizer', 'rasterize_gaussians', 'rasterize_views', 'pack_cameras',
-           'rasterize_views_backward', 'rasterize_views_autograd', 'rasterize_packed_autograd']
+           'rasterize_views_backward', 'rasterize_views_autograd', 'rasterize_packed_autograd', 'sh_to_rgb',
+           'sh_to_rgb_backward']
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -72,6 +74,44 @@ def pack_cameras(viewmatrices, projmatrices, tanfovx, tanfovy, H, W, dev):
     tf = torch.stack((tfx, tfy), 1).float()
     focal = torch.stack((torch.tensor(float(W)) / (2.0 * tf[:, 0]), torch.tensor(float(H)) / (2.0 * tf[:, 1])), 1)
     return torch.cat((vm, pm, tf.to(dev), focal.float().to(dev)), 1).contiguous()
+
+
+def sh_to_rgb(means3D, campos, shs, degree):
+    """View-dependent colours from spherical harmonics (``forward.cu:20-71``): means3D (P,3), campos (3,) the camera
+    centre, shs (P,M,3), ``degree`` 0..3 with M >= (degree+1)^2 -> (colors (P,3) float32, clamped (P,3) uint8)."""
+    _lib.require_cuda(means3D, campos, shs)
+    if shs.dim() != 3 or shs.size(2) != 3 or shs.size(0) != means3D.size(0):
+        raise RuntimeError('shs must have dimensions (num_points, num_coefficients, 3)')
+    P, M, degree = means3D.size(0), shs.size(1), int(degree)
+    if not 0 <= degree <= 3 or M < (degree + 1) ** 2:
+        raise RuntimeError(f'sh_degree {degree} needs 0 <= degree <= 3 and at least {(degree + 1) ** 2} coefficients, got {M}')
+    means3D, campos, shs = _f32c(means3D), _f32c(campos).reshape(3), _f32c(shs)
+    dev = means3D.device
+    colors = torch.empty(P, 3, device=dev)
+    clamped = torch.empty(P, 3, dtype=torch.uint8, device=dev)
+    with _lib.on_device(dev):
+        _lib.check(_lib.lib().ocrf_sh_to_rgb(P, degree, M, _lib.ptr(means3D), _lib.ptr(campos), _lib.ptr(shs),
+                                             _lib.ptr(colors), _lib.ptr(clamped), _lib.stream_ptr(dev)), 'ocrf_sh_to_rgb')
+    return colors, clamped
+
+
+def sh_to_rgb_backward(means3D, campos, shs, degree, clamped, dL_dcolors, dL_dmeans3D=None):
+    """Backward of ``sh_to_rgb`` (``backward.cu:20-140``) -> (dL_dmeans3D (P,3), dL_dshs (P,M,3)).  The means' part (the
+    view direction depends on the mean) is ADDED to ``dL_dmeans3D`` when one is given (in place), else returned alone."""
+    _lib.require_cuda(means3D, campos, shs, clamped, dL_dcolors)
+    P, M = means3D.size(0), shs.size(1)
+    means3D, campos, shs, g = _f32c(means3D), _f32c(campos).reshape(3), _f32c(shs), _f32c(dL_dcolors).reshape(P, 3)
+    dev = means3D.device
+    if dL_dmeans3D is None:
+        dL_dmeans3D = torch.zeros(P, 3, device=dev)
+    elif not (dL_dmeans3D.is_contiguous() and dL_dmeans3D.dtype == torch.float32 and dL_dmeans3D.numel() == 3 * P):
+        raise RuntimeError('dL_dmeans3D must be a contiguous float32 (P,3) tensor')
+    d_sh = torch.empty(P, M, 3, device=dev)
+    with _lib.on_device(dev):
+        _lib.check(_lib.lib().ocrf_sh_to_rgb_backward(
+            P, int(degree), M, _lib.ptr(means3D), _lib.ptr(campos), _lib.ptr(shs), _lib.ptr(clamped.contiguous()),
+            _lib.ptr(g), _lib.ptr(dL_dmeans3D), _lib.ptr(d_sh), _lib.stream_ptr(dev)), 'ocrf_sh_to_rgb_backward')
+    return dL_dmeans3D, d_sh
 
 
 def rasterize_views_backward(grad_color, fwd, means3D, colors, opacities, scales, rotations, viewmatrices,
@@ -247,9 +287,10 @@ class _RasterizeGaussians(torch.autograd.Function):
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                 cov3Ds_precomp, raster_settings):
         rs = raster_settings
-        if sh is not None and sh.numel() > 0:
-            raise NotImplementedError('SH colours are not on the OcRFDet path (shs=None, '
-                                      'gaussian_renderer/__init__.py:65); pass colors_precomp')
+        ctx.has_sh = sh is not None and sh.numel() > 0
+        if ctx.has_sh:
+            # colours of THIS view from the SH coefficients (forward.cu:240-247); everything after is the ordinary pipeline
+            colors_precomp, sh_clamped = sh_to_rgb(means3D, rs.campos, sh, rs.sh_degree)
         out = rasterize_views(means3D, colors_precomp, opacities, scales, rotations,
                               rs.viewmatrix.reshape(1, 4, 4), rs.projmatrix.reshape(1, 4, 4),
                               float(rs.tanfovx), float(rs.tanfovy), rs.image_height, rs.image_width,
@@ -269,7 +310,18 @@ class _RasterizeGaussians(torch.autograd.Function):
         else:
             ctx.save_for_backward(means3D, colors_precomp, opacities, scales, rotations, color, out['final_T'],
                                   out.get('n_contrib'))
+        ctx.sh_state = (sh, sh_clamped) if ctx.has_sh else None
         return color, radii, depth
+
+    @staticmethod
+    def _sh_grads(ctx, means3D, g):
+        """With SH colours: dL/dcolors goes on to the coefficients and, through the view direction, to the means."""
+        if not ctx.has_sh:
+            return g['means3D'], None, g['colors']
+        sh, clamped = ctx.sh_state
+        rs = ctx.raster_settings
+        d_means, d_sh = sh_to_rgb_backward(means3D, rs.campos, sh, rs.sh_degree, clamped, g['colors'], g['means3D'])
+        return d_means, d_sh.to(sh.dtype), None
 
     @staticmethod
     def backward(ctx, grad_color, _r, _d):
@@ -283,7 +335,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                                          rs.viewmatrix.reshape(1, 4, 4), rs.projmatrix.reshape(1, 4, 4),
                                          float(rs.tanfovx), float(rs.tanfovy), rs.image_height, rs.image_width, rs.bg,
                                          want_means2D=True, cov3D_precomp=cov)
-            grads = (g['means3D'], g['means2D'][0], None, g['colors'], g['opacities'].reshape(opacities.shape),
+            d_means, d_sh, d_col = _RasterizeGaussians._sh_grads(ctx, means3D, g)
+            grads = (d_means, g['means2D'][0], d_sh, d_col, g['opacities'].reshape(opacities.shape),
                      None, None, g['cov3D'].reshape(cov.shape), None)
             return tuple(v if need else None for v, need in zip(grads, ctx.needs_input_grad))
         means3D, colors, opacities, scales, rotations, fwd_color, fwd_T, fwd_n = ctx.saved_tensors
@@ -292,7 +345,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                                      rs.viewmatrix.reshape(1, 4, 4), rs.projmatrix.reshape(1, 4, 4),
                                      float(rs.tanfovx), float(rs.tanfovy), rs.image_height, rs.image_width, rs.bg,
                                      float(rs.scale_modifier), want_means2D=True)
-        grads = (g['means3D'], g['means2D'][0], None, g['colors'], g['opacities'].reshape(opacities.shape),
+        d_means, d_sh, d_col = _RasterizeGaussians._sh_grads(ctx, means3D, g)
+        grads = (d_means, g['means2D'][0], d_sh, d_col, g['opacities'].reshape(opacities.shape),
                  g['scales'], g['rotations'], None, None)
         # inputs that were not tensors needing a gradient (means2D=None from render()) must get None
         return tuple(v if need else None for v, need in zip(grads, ctx.needs_input_grad))

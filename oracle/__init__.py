@@ -9,6 +9,7 @@ Parts:
     native kernels of the reference restated loop-for-thread.
   * ``oracle.index_prep`` (numpy) — LSS / HT rank preparation.
   * ``oracle.hoa`` (numpy) — Height-aware Opacity-based Attention blocks.
+  * ``oracle.sh`` (numpy) — the rasteriser's spherical-harmonics colours and their backward.
 
 Each function cites the reference file:line it follows.  See DESIGN.md "Oracle" for what pins it.
 """
