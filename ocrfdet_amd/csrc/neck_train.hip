@@ -115,6 +115,11 @@ __global__ __launch_bounds__(64, 2) void neck_gauss_heads_backward_kernel(
     float vv[kAhead], nx[kAhead];
 #pragma unroll
     for (int j = 0; j < kAhead; ++j) nx[j] = bp[(size_t)min(j, C - 1) * YX];
+    // a channel's 16 first-layer weights are one wave-uniform 64-byte scalar load, requested ONE CHANNEL AHEAD of their
+    // use (as in the forward kernel: loaded where they are used, every channel waits ~0.3 us for its own load)
+    f32x2 w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = W1t[k];
     for (int c0 = 0; c0 < C; c0 += kAhead) {
 #pragma unroll
       for (int j = 0; j < kAhead; ++j) vv[j] = nx[j];
@@ -122,10 +127,13 @@ __global__ __launch_bounds__(64, 2) void neck_gauss_heads_backward_kernel(
       for (int j = 0; j < kAhead; ++j) nx[j] = bp[(size_t)min(c0 + kAhead + j, C - 1) * YX];
 #pragma unroll
       for (int j = 0; j < kAhead; ++j) {
-        if (c0 + j < C) {
-          f32x2 w[8];
+        f32x2 wn[8];
+        asm volatile("" ::"s"(w[0].x));          // this channel's weights have arrived before the next are requested
+        const int cn = min(c0 + j + 1, C - 1);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) w[k] = W1t[(c0 + j) * 8 + k];
+        for (int k = 0; k < 8; ++k) wn[k] = W1t[cn * 8 + k];
+        __builtin_amdgcn_sched_barrier(0);
+        if (c0 + j < C) {
 #pragma unroll
           for (int h = 0; h < HG; ++h) {
             const float f = fmaxf(fmaf(la[h], vv[j], lb[h]), 0.0f);
@@ -134,9 +142,8 @@ __global__ __launch_bounds__(64, 2) void neck_gauss_heads_backward_kernel(
             for (int k = 0; k < 8; ++k) hid[h][k] = __builtin_elementwise_fma(w[k], ff, hid[h][k]);
           }
         }
-        // (one channel at a time: left alone the scheduler hoists the 8 channels' scalar weight loads — 128 SGPRs — and
-        // interleaves their arithmetic: 518 SGPR spills and 348 VGPRs at 13 heights)
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] = wn[k];
       }
     }
   }
@@ -272,6 +279,9 @@ __global__ __launch_bounds__(64, 2) void neck_gauss_heads_backward_kernel(
     float vv[kAhead], nx[kAhead];
 #pragma unroll
     for (int j = 0; j < kAhead; ++j) nx[j] = bp[(size_t)min(j, C - 1) * YX];
+    f32x2 w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = W1t[k];
     for (int c0 = 0; c0 < C; c0 += kAhead) {
 #pragma unroll
       for (int j = 0; j < kAhead; ++j) vv[j] = nx[j];
@@ -280,10 +290,16 @@ __global__ __launch_bounds__(64, 2) void neck_gauss_heads_backward_kernel(
 #pragma unroll
       for (int j = 0; j < kAhead; ++j) {
         const int c = c0 + j;
-        if (c < C) {
-          f32x2 w[8], pp[8];
+        f32x2 wn[8];
+        asm volatile("" ::"s"(w[0].x));
+        const int cn = min(c + 1, C - 1);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) { w[k] = W1t[c * 8 + k]; pp[k] = f32x2{0.0f, 0.0f}; }
+        for (int k = 0; k < 8; ++k) wn[k] = W1t[cn * 8 + k];
+        __builtin_amdgcn_sched_barrier(0);
+        if (c < C) {
+          f32x2 pp[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) pp[k] = f32x2{0.0f, 0.0f};
           const float v = vv[j];
           float dv = 0.0f;
 #pragma unroll
@@ -309,7 +325,8 @@ __global__ __launch_bounds__(64, 2) void neck_gauss_heads_backward_kernel(
           const float s = halving_sum16(p, lane);
           if (lane < 16) part[2 * ZH + c * 16 + slot] = s;
         }
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] = wn[k];
       }
     }
   }
