@@ -674,7 +674,7 @@ int ocrf_gauss_heads_params_len(int C, int Zh);
  * Backward of ocrf_gauss_heads: what autograd does for the reference through VoxelFeatureExtractor (:520-531) and the four
  * heads (:272-320, calls :1130-1133) on the (B,Zh,Y,X,C) voxel feature, here without that tensor (the lift and the hidden
  * units are recomputed from bev).  g_* are the gradients of the four outputs (same shapes; NULL = zero); d_bev (B,C,YX) is
- * zeroed and written here; d_params receives the gradient w.r.t. every entry of `params`, in the layout of `params`
+ * fully written here; d_params receives the gradient w.r.t. every entry of `params`, in the layout of `params`
  * (lift_a / lift_b first: the caller owns the folding of Conv3d + BatchNorm3d — batch statistics in training — and
  * differentiates through it).  No gradient for rgb_avg (sampled from the camera images, :1071).  Deterministic.
  * workspace: ocrf_gauss_heads_backward_workspace_bytes(B, C, Zh, YX) bytes (0: unsupported shape).

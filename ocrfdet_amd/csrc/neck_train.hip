@@ -16,8 +16,8 @@
 //             values a lane carries: 8 + 4 + 2 + 1 exchanges instead of 16 x 6), and 16 lanes store one 64-byte row of the
 //             wave's partial.
 //
-// d(bev) takes one float atomic per (channel, pillar, height group) on a zeroed map: two groups at 13 heights, and a + b is
-// b + a, so the result does not depend on the order.  The parameter gradient is the sum of per-wave partial rows, taken by
+// d(bev): one plain store per (channel, pillar) into a map of the height group (four groups at 13 heights: 4 + 3 + 3 + 3),
+// summed afterwards in group order.  The parameter gradient is the sum of per-wave partial rows, taken by
 // a fixed-order two-stage reduction: the whole backward is deterministic.
 // The lift's coefficients (a_h, b_h) are INPUTS here (training: batch statistics folded by the caller, with autograd through
 // that folding; the gradient w.r.t. them leaves in the same packed layout as the parameters).
@@ -75,10 +75,13 @@ __device__ __forceinline__ int halving_slot(int lane) {
   return 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
 }
 
+#ifndef OCRF_HEADS_BWD_G13
+#define OCRF_HEADS_BWD_G13 4
+#endif
 constexpr int kSmall = 12 + 16 + 15 + 20 + 5 + 15;      // W1rgb | b1 | S | R | A | Col: everything after W1t
 
 template <int ZH, int HG>
-__global__ __launch_bounds__(64, 2) void neck_gauss_heads_backward_kernel(
+__global__ __launch_bounds__(64, HG <= 5 ? 3 : 2) void neck_gauss_heads_backward_kernel(
     const float* __restrict__ bev, const float* __restrict__ rgb_avg, const float* __restrict__ prm, int C, int YX,
     const float* __restrict__ g_op, const float* __restrict__ g_sc, const float* __restrict__ g_rot,
     const float* __restrict__ g_col, float* __restrict__ d_bev, float* __restrict__ partial, int L) {
@@ -87,7 +90,13 @@ __global__ __launch_bounds__(64, 2) void neck_gauss_heads_backward_kernel(
   const int q_raw = blockIdx.x * 64 + lane;
   const bool live = q_raw < YX;
   const int q = min(q_raw, YX - 1);                 // lanes past the end redo the last pillar with zero output gradients
-  const int b = blockIdx.y / kGroups, h0 = (blockIdx.y % kGroups) * HG;
+  // heights over the groups as evenly as they go (13 over 4 groups: 4 + 3 + 3 + 3): a group has HG or HG - 1 heights, and a
+  // wave of the shorter kind skips the last slot of its register tile (wave-uniform branches) instead of computing it for
+  // nothing
+  constexpr int kBase = ZH / kGroups, kRem = ZH % kGroups;
+  const int grp = blockIdx.y % kGroups;
+  const int b = blockIdx.y / kGroups, h0 = grp * kBase + min(grp, kRem), nh = kBase + (grp < kRem ? 1 : 0);
+  static_assert(kBase + (kRem ? 1 : 0) == HG, "groups of HG or HG - 1 heights");
   float* part = partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * L;
   float la[HG], lb[HG];
 #pragma unroll
@@ -136,6 +145,7 @@ __global__ __launch_bounds__(64, 2) void neck_gauss_heads_backward_kernel(
         if (c0 + j < C) {
 #pragma unroll
           for (int h = 0; h < HG; ++h) {
+            if (h == HG - 1 && nh < HG) break;
             const float f = fmaxf(fmaf(la[h], vv[j], lb[h]), 0.0f);
             const f32x2 ff = {f, f};
 #pragma unroll
@@ -160,8 +170,9 @@ __global__ __launch_bounds__(64, 2) void neck_gauss_heads_backward_kernel(
   float* aC = aA + 5;
 #pragma unroll
   for (int h = 0; h < HG; ++h) {
-    const bool on = live && (h0 + h < ZH);
-    const size_t g = ((size_t)b * ZH + min(h0 + h, ZH - 1)) * YX + q;
+    if (h == HG - 1 && nh < HG) break;             // (its dz1 slot stays zero and is never read)
+    const bool on = live;
+    const size_t g = ((size_t)b * ZH + h0 + h) * YX + q;
     constexpr float k255 = 1.0f / 255.0f;
     const float r01[3] = {rgb_avg[g * 3] * k255, rgb_avg[g * 3 + 1] * k255, rgb_avg[g * 3 + 2] * k255};
     float a[16], da[16];
@@ -304,6 +315,7 @@ __global__ __launch_bounds__(64, 2) void neck_gauss_heads_backward_kernel(
           float dv = 0.0f;
 #pragma unroll
           for (int h = 0; h < HG; ++h) {
+            if (h == HG - 1 && nh < HG) break;
             const float pre = fmaf(la[h], v, lb[h]);
             const float x = fmaxf(pre, 0.0f);
             const f32x2 xx = {x, x};
@@ -333,10 +345,10 @@ __global__ __launch_bounds__(64, 2) void neck_gauss_heads_backward_kernel(
 #pragma unroll
   for (int h = 0; h < HG; ++h) {
     const float sa = wave_sum(dla[h]), sb = wave_sum(dlb[h]);
-    if (lane == 0 && h0 + h < ZH) { part[h0 + h] = sa; part[ZH + h0 + h] = sb; }
+    if (lane == 0 && h < nh) { part[h0 + h] = sa; part[ZH + h0 + h] = sb; }
   }
   // the heights of the other groups: zero in this wave's row (the rows are summed whole)
-  if (lane < ZH && (lane < h0 || lane >= h0 + HG)) { part[lane] = 0.0f; part[ZH + lane] = 0.0f; }
+  if (lane < ZH && (lane < h0 || lane >= h0 + nh)) { part[lane] = 0.0f; part[ZH + lane] = 0.0f; }
 }
 
 // out[chunk][l] = sum of in[t][l] over the chunk's rows t, in order (fixed order: the same bits every run)
@@ -377,7 +389,7 @@ __global__ __launch_bounds__(256) void neck_sum_maps_kernel(const float* __restr
 
 inline int heads_group(int Zh) {
   switch (Zh) {
-    case 13: return 7;
+    case 13: return OCRF_HEADS_BWD_G13;
     case 8: return 4;
     case 6: return 3;
     case 4: return 4;
@@ -431,7 +443,7 @@ int ocrf_gauss_heads_backward(const float* bev, const float* rgb_avg, const floa
                  (hipStream_t)stream, bev, rgb_avg, params, C, YX, g_opacity, g_scales, g_rotations, g_color, maps,  \
                  partial, L);                                                                                         \
     break;
-    OCRF_HEADS_BWD_CASE(13, 7)
+    OCRF_HEADS_BWD_CASE(13, OCRF_HEADS_BWD_G13)
     OCRF_HEADS_BWD_CASE(8, 4)
     OCRF_HEADS_BWD_CASE(6, 3)
     OCRF_HEADS_BWD_CASE(4, 4)

@@ -94,7 +94,7 @@ def test_gauss_heads_backward_every_height_count(zh, training):
 
 def test_gauss_heads_backward_unused_outputs_and_determinism():
     """Outputs that took no part in the loss arrive as ``None`` (a NULL pointer at the C ABI = a zero gradient); the same
-    call twice gives the same bits (fixed-order sums, two-operand atomics)."""
+    call twice gives the same bits (fixed-order sums, no atomics)."""
     from ocrfdet_amd import neck_ops
     torch.manual_seed(5)
     dev = torch.device('cuda:0')
