@@ -1184,7 +1184,8 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps,
             'ms_per_step_blocks': {'n': len(blocks), 'median': 1e3 * elapsed / args.steps,
-                                   'min': 1e3 * min(blocks) / args.steps, 'max': 1e3 * max(blocks) / args.steps},
+                                   'min': 1e3 * min(blocks) / args.steps, 'max': 1e3 * max(blocks) / args.steps,
+                                   'in_order': [round(1e3 * b / args.steps, 5) for b in blocks]},
             'per_step_ms': per_step_ms,
             'per_step_device_geometry_ms': per_step_devgeom_ms,
             # a sample with a NEW POSE (the reference's only working mode: cameras per sample, accelerate=False): rank

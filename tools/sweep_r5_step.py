@@ -29,6 +29,7 @@ def timed(hp, depth, feat, blocks=5, steps=100):
 
 
 variants = [dict(blend_workgroups=g) for g in (512, 576, 640, 704, 768, 1024)] if 'grid' in sys.argv[1:] else \
+    [dict(blend_workgroups=g) for g in (608, 640, 672, 704, 736, 768)] * 2 if 'grid6' in sys.argv[1:] else \
     [dict(blend_workgroups=g, hoa_first=h) for h in (None, True) for g in (640, 672, 704)] * 2 if 'fine' in sys.argv[1:] else \
     [dict(render_mode='per_call'), dict(render_mode='per_call', lss_pool_backend='tile', ht_pool_backend='mfma'),
      dict(render_mode='per_call', one_call=False), dict(render_guard='device'), dict(render_guard='device', one_call=False),
