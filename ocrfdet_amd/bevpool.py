@@ -257,6 +257,51 @@ def bev_pool_v2_device_counts(depth, feat, ranks_depth, ranks_feat, ranks_bev, b
     return out
 
 
+class _FusedPoolCounts(torch.autograd.Function):
+    """``_FusedPool`` on rank vectors whose LENGTHS LIVE ON THE DEVICE (``index_prep.*_hip(sync=False)``: five vectors at
+    their capacity + ``counts`` = int32 [n_points, n_intervals]): forward by ``ocrf_bev_pool_v2_nchw_dyn``, backward by the
+    same kernel as ``_FusedPool`` — so a training forward reads nothing back from the device.  The backward regroups the
+    points by feature pixel like the reference (bev_pool.py:47-57); the entries past ``n_points`` (uninitialised) are given
+    a feature index past the last pixel first, so the stable sort puts them behind every run and no run covers them."""
+
+    @staticmethod
+    def forward(ctx, depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts, interval_lengths,
+                counts, layout, scratch_tag):
+        d32, f32 = depth.float().contiguous(), feat.float().contiguous()
+        with torch.no_grad():
+            out = bev_pool_v2_device_counts(d32, f32, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts,
+                                            interval_lengths, counts, layout=layout, scratch_tag=scratch_tag)
+        ctx.save_for_backward(ranks_bev, d32, f32, ranks_feat, ranks_depth, counts)
+        ctx.geom = tuple(int(v) for v in bev_feat_shape) + (int(layout),)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        rb, d32, f32, rf, rd, counts = ctx.saved_tensors
+        B, Z, Y, X, C, layout = ctx.geom
+        if layout == 0:
+            g = grad_out.permute(0, 2, 3, 4, 1)                       # (B,Z,Y,X,C)
+        else:
+            g = grad_out.view(B, Z, C, Y, X).permute(0, 1, 3, 4, 2)
+        n_pixels = f32.numel() // f32.size(-1)
+        live = torch.arange(rf.numel(), device=rf.device, dtype=torch.int32) < counts[0]
+        rf_sorted, perm = torch.sort(torch.where(live, rf, torch.full_like(rf, n_pixels)), stable=True)
+        starts_bp, lengths_bp = dense_runs(rf_sorted, n_pixels)
+        g_depth = torch.zeros_like(d32)
+        g_feat = torch.zeros_like(f32)
+        bev_pool_v2_ext.bev_pool_v2_backward(
+            g.contiguous().float(), g_depth, g_feat, d32, f32, rd[perm].contiguous(),
+            rf_sorted.contiguous(), rb[perm].contiguous(), lengths_bp, starts_bp)
+        return (g_depth, g_feat) + (None,) * 9
+
+
+def bev_pool_v2_device_counts_autograd(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts,
+                                       interval_lengths, counts, layout=1, scratch_tag='bev_pool_nchw'):
+    """``bev_pool_v2_device_counts`` with autograd for ``depth`` and ``feat`` (``_FusedPoolCounts``)."""
+    return _FusedPoolCounts.apply(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts,
+                                  interval_lengths, counts, int(layout), scratch_tag)
+
+
 class DevicePoolPlan:
     """The rank-only part of one pooling, built once for rank vectors that are cached across calls
     (C ABI ``ocrf_bev_pool_plan_build``): the dense voxel table, the list of work units (tiles, and slices

@@ -486,9 +486,9 @@ class OcRFViewTransformerFull(nn.Module):
         self.render_plan, self.render_plan_margin = True, 2.0
         # forward-only mode: per-forward calibration algebra on the GPU (ocrf_geometry_blocks) when the calibration
         # tensors arrive there — no device read-back, no synchronisation in the forward (see ``_geometry``).
-        # None (default, round 6): automatically, whenever the forward is eval-mode / forward-only AND the seven
-        # calibration tensors are CUDA tensors — what a reference config gets without edits (1.75 -> 1.09 ms per forward
-        # at cfg2); False: the host formulation, whose rank vectors are the reference's bit for bit (the device algebra is
+        # None (default, round 6): automatically, whenever the seven calibration tensors are CUDA tensors — eval-mode /
+        # forward-only (what a reference config gets without edits: 1.75 -> 1.09 ms per forward at cfg2) and, with
+        # per-forward geometry, under autograd as well (training: no read-back per iteration, 17.3 -> 15.2 ms); False: the host formulation, whose rank vectors are the reference's bit for bit (the device algebra is
         # ~1 ulp off: a 1e-5 fraction of border points may change cell, tests/test_device_geometry_gpu.py); True: as None
         self.device_geometry = None
         # guard of the cached render plan (accelerate=True): 'device' — exact whatever the scale head emits, the per-call
@@ -536,7 +536,7 @@ class OcRFViewTransformerFull(nn.Module):
             self._tmpl = (self.frustum.to(dev).contiguous(), ref.to(dev).contiguous())
         return self._tmpl
 
-    def _geometry(self, input, sync=True, lazy_ranks=False):
+    def _geometry(self, input, sync=True, lazy_ranks=False, fresh=False):
         """``sync=False`` (eval mode): the rank vectors stay at their capacity with their lengths on the
         device — nothing between the calibration and the pooled BEV reads the device.  Only that forward-only
         path writes into the module's persistent rank buffers: with ``sync=True`` the ranks reach autograd
@@ -574,12 +574,12 @@ class OcRFViewTransformerFull(nn.Module):
             if which in (None, 'lss'):
                 lss = index_prep.voxel_pooling_prepare_v2_hip(frustum, lss_block, B, N, self.grid_lower_bound,
                                                               self.grid_interval, self.grid_size,
-                                                              buffers=None if (self.accelerate or sync) else self._rank_bufs[0],
+                                                              buffers=None if (self.accelerate or sync or fresh) else self._rank_bufs[0],
                                                               sync=sync)
             if which in (None, 'ht'):
                 ht = index_prep.fast_sample_prepare_hip(tmpl, ht_block, B, N, list(self.pc_range), self.input_size,
                                                         self.grid_config['depth'], Wf, Hf, self.D,
-                                                        buffers=None if (self.accelerate or sync) else self._rank_bufs[1],
+                                                        buffers=None if (self.accelerate or sync or fresh) else self._rank_bufs[1],
                                                         sync=sync)
             return lss, ht
         geo.pix, geo.mask, geo.voxel = index_prep.ht_project_hip(tmpl, ht_block, B, N, list(self.pc_range),
@@ -735,8 +735,11 @@ class OcRFViewTransformerFull(nn.Module):
 
     # -------------------------------------------------------------------------------- pooling
     def _pool(self, ranks, depth, feat_cl, bev_shape, scratch_tag='bev_pool_nchw'):
-        if len(ranks) == 2:                       # ((five capacity vectors), device counts): forward only
+        if len(ranks) == 2:                       # ((five capacity vectors), device counts)
             (rb, rd, rf, st, ln), counts = ranks
+            if torch.is_grad_enabled() and (depth.requires_grad or feat_cl.requires_grad):
+                return bevpool.bev_pool_v2_device_counts_autograd(depth, feat_cl, rd, rf, rb, bev_shape, st, ln, counts,
+                                                                  scratch_tag=scratch_tag)
             return bevpool.bev_pool_v2_device_counts(depth, feat_cl, rd, rf, rb, bev_shape, st, ln, counts,
                                                      scratch_tag=scratch_tag)
         if ranks[0] is None:
@@ -793,8 +796,15 @@ class OcRFViewTransformerFull(nn.Module):
         # fused HIP kernels are forward-only and fold the BatchNorm running statistics: eval mode with
         # nothing recorded by autograd; anything else takes the differentiable torch formulation
         fused = not self.training and not self._recording(depth, tran_feat, feat_channels_last)
+        # Under autograd too the geometry stays on the device when the calibration is there (``device_geometry`` not False):
+        # the rank vectors at their capacity with device-side lengths, in tensors of THIS forward (an autograd Function saves
+        # them), the poolings differentiated by ``_FusedPoolCounts``, the cameras staged from the device rows — a training
+        # forward then reads nothing back (the reference synchronises at :1086-1088, and this module did, once per forward,
+        # until round 6: the GPU's tail of every iteration was exposed, ~1.5-2.4 ms at cfg2)
+        on_dev = all(torch.is_tensor(t) and t.is_cuda for t in list(input[1:7]) + [input[11]])
+        dev_train = not fused and self.device_geometry is not False and on_dev and not self.accelerate
         geo = self._geo if (self.accelerate and self._geo is not None) else \
-            self._geometry(input, sync=not fused, lazy_ranks=fused and not self.accelerate)
+            self._geometry(input, sync=not (fused or dev_train), lazy_ranks=fused and not self.accelerate, fresh=dev_train)
         depth5 = depth.reshape(B, N, self.D, Hf, Wf).float()
         if feat_channels_last is None:
             feat_channels_last = tran_feat.reshape(B, N, C, Hf, Wf).permute(0, 1, 3, 4, 2)
@@ -814,7 +824,7 @@ class OcRFViewTransformerFull(nn.Module):
         lss_feat = self.get_lss_bev_feat(geo, depth5, feat_cl)
         ht_feat = self.get_ht_bev_feat(geo, depth5, feat_cl)
         (opacity, scaling, rotation, color, sparse, alpha_lidar, render_N,
-         render_depth_N) = self._neck_torch(input, geo, ht_feat, cam_idx_list)
+         render_depth_N) = self._neck_torch(input, geo, ht_feat, cam_idx_list, cam_sel)
         # one differentiable render per sample (:1135-1153) from the camera rows staged on the device above — the
         # reference's per-sample camera set-up (matrix uploads, focal arithmetic: ~0.9 ms of host time per sample here)
         # was already done once, for the whole batch, by stage_cameras
@@ -1073,7 +1083,7 @@ class OcRFViewTransformerFull(nn.Module):
         plan = RasterPlan(voxel_coor[0], rows, H, W, scales=scaling, rotations=rotation, margin=self.render_plan_margin)
         return plan, torch.arange(B, device=dev, dtype=torch.int32) * N
 
-    def _neck_torch(self, input, geo, ht_feat, cam_idx_list):
+    def _neck_torch(self, input, geo, ht_feat, cam_idx_list, cam_sel=None):
         """Training mode: the reference's op sequence (:1051-1133) as differentiable torch ops."""
         x, imgs_wo_norm = input[0], input[9]
         B, N, _, Hf, Wf = x.shape
@@ -1092,7 +1102,7 @@ class OcRFViewTransformerFull(nn.Module):
             return v.sum(1) / cnt
         avg_rgb = sample(imgs_wo_norm, H, W)
         # retain_valid_pixels for the selected cameras, vectorised (:1004-1024)
-        sel = torch.tensor(cam_idx_list, device=x.device)
+        sel = cam_sel.long() if cam_sel is not None else torch.tensor(cam_idx_list, device=x.device)
         ar = torch.arange(B, device=x.device)
         pix_s, mask_s = geo.pix[ar, sel].reshape(B, -1, 2), geo.mask[ar, sel].reshape(B, -1)
         imgs_s = imgs_wo_norm[ar, sel].float()

@@ -427,3 +427,39 @@ def test_planned_pool_is_bit_identical(cuda, case):
         for _ in range(2):
             got = bevpool.bev_pool_v2_planned(d, f, plan, layout=layout)
             assert torch.equal(got, want), (case, layout)
+
+
+@pytest.mark.parametrize('which', ['lss', 'ht'])
+def test_pooling_with_device_side_lengths_under_autograd(cuda, which):
+    """``bev_pool_v2_device_counts_autograd`` (rank vectors at their CAPACITY, lengths on the device: what the index
+    preparation hands over without a read-back) against ``bev_pool_v2_collapsed`` on the exact-size vectors, cfg2 at full
+    size: the same pooled map and bit-identical gradients — the tail past the device-side count is uninitialised memory and
+    must not matter (filled with out-of-range garbage here), and nothing in forward or backward reads the device."""
+    cfg = synthetic.CONFIGS['cfg2_6cam_2frame_bev200x200_render_hoa']
+    depth, feat = helpers.pool_inputs(cfg)
+    rb, rd, rf, st, ln = helpers.lss_ranks(cfg) if which == 'lss' else helpers.ht_ranks(cfg)
+    X, Y, Z = cfg.bev_xyz
+    shape = (depth.shape[0], Z if which == 'lss' else 1, Y, X, cfg.channels)
+    t = lambda a: _dev(np.asarray(a, np.int32), cuda)                                          # noqa: E731
+    rng = np.random.default_rng(3)
+    pad_p, pad_i = 4097, 513
+    junk = lambda n: rng.integers(-2 ** 31, 2 ** 31 - 1, n, dtype=np.int64).astype(np.int32)   # noqa: E731
+    caps = [t(np.concatenate((v, junk(pad)))) for v, pad in ((rb, pad_p), (rd, pad_p), (rf, pad_p), (st, pad_i), (ln, pad_i))]
+    counts = t(np.array([len(rb), len(st)]))
+    og = _dev(rng.standard_normal((shape[0], shape[1] * shape[4], Y, X)).astype(np.float32), cuda)
+
+    d1, f1 = _dev(depth, cuda).requires_grad_(), _dev(feat, cuda).requires_grad_()
+    want = bevpool.bev_pool_v2_collapsed(d1, f1, t(rd), t(rf), t(rb), shape, t(st), t(ln))
+    want.backward(og)
+    d2, f2 = _dev(depth, cuda).requires_grad_(), _dev(feat, cuda).requires_grad_()
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode('error')
+    try:
+        got = bevpool.bev_pool_v2_device_counts_autograd(d2, f2, caps[1], caps[2], caps[0], shape, caps[3], caps[4], counts)
+        got.backward(og)
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+    torch.cuda.synchronize()
+    assert float((got - want).detach().abs().max()) <= 1e-4 * float(want.detach().abs().max())
+    assert torch.equal(d2.grad, d1.grad) and torch.equal(f2.grad, f1.grad)
+    assert float(d1.grad.abs().max()) > 0 and float(f1.grad.abs().max()) > 0

@@ -128,6 +128,64 @@ def test_forward_with_device_geometry_does_not_synchronise(cuda):
         assert frac <= 2e-3, f'{what}: {frac:.2e} of the elements differ by more than 1e-4'
 
 
+def _setup(cuda):
+    """The reference-shaped module on the core fixture's weights with every calibration tensor on the GPU."""
+    from ocrfdet_amd import view_transformer_ocrf as vto
+    from tests import helpers
+    cfg, g, state = helpers.core_fixture()
+    m = vto.OcRFViewTransformerFull(pc_range=list(cfg.pc_range), bev_h=48, bev_w=48, num_height=13, grid_config=cfg.grid,
+                                    input_size=cfg.input_size, downsample=16, in_channels=256, out_channels=80,
+                                    depth_net=torch.nn.Identity())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    m.cuda().eval()
+    B = int(g['batch'])
+    rig = synthetic.rig(cfg.n_cams, cfg.input_size, B)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()      # noqa: E731
+    raw = t(g['raw'].astype(np.float32))
+    inp = [t(g['x'].astype(np.float32))] + [t(rig[k]) for k in ('rots', 'trans', 'intrins', 'post_rots', 'post_trans', 'bda')]
+    inp += [torch.zeros(B, 6, 27).cuda(), raw.clone(), raw, raw.clone(), t(rig['c2w'])]
+    pre = t(g['pre'])
+    return cfg, m, inp, pre[:, :cfg.D].softmax(1), pre[:, cfg.D + 2:].contiguous()
+
+
+def test_training_forward_and_backward_read_nothing_back(cuda):
+    """``module.train()`` with the calibration on the GPU (``device_geometry`` auto): the geometry stays on the device
+    under autograd too — rank vectors at their capacity with device-side lengths in tensors of this forward, poolings
+    differentiated by ``_FusedPoolCounts``, cameras staged from the device rows — so forward + backward run without a single
+    synchronising call (the reference reads the calibration to the host once per forward, view_transformer_ocrf.py:1086-1088).
+    Against the opted-out host formulation: same loss and gradients up to the handful of border samples that change cell."""
+    cfg, m, inp, depth0, feat0 = _setup(cuda)
+    cams = [1, 4]
+
+    def run(mod):
+        depth = depth0.clone().requires_grad_(True)
+        feat = feat0.clone().requires_grad_(True)
+        torch.manual_seed(0)
+        bev, _, logit, lst = mod.view_transform_core(inp, depth, feat, cam_idx_list=cams)
+        loss = bev.square().mean() + logit.square().mean() + lst[0].mean() + lst[6].mean() + lst[4].square().mean()
+        loss.backward()
+        return loss.detach(), depth.grad, feat.grad
+
+    import copy
+    host = copy.deepcopy(m).train()
+    host.device_geometry = False
+    want = run(host)
+    dev = copy.deepcopy(m).train()
+    run(dev)                                                   # warm-up: allocations, packs
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode('error')
+    try:
+        got = run(dev)
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+    torch.cuda.synchronize()
+    assert abs(float(got[0]) - float(want[0])) <= 2e-3 * abs(float(want[0]))
+    for a, b, what in ((got[1], want[1], 'd depth'), (got[2], want[2], 'd feat')):
+        d = (a - b).abs()
+        frac = float((d > 1e-4 * float(b.abs().max())).float().mean())
+        assert frac <= 2e-3, f'{what}: {frac:.2e} of the entries differ by more than 1e-4 of the largest'
+
+
 def test_graph_with_the_geometry_inside_follows_the_calibration(cuda):
     """GraphedNeck on an ``accelerate=False`` module with ``device_geometry``: calibration algebra, both index
     preparations and the rest of the forward replay as ONE hipGraph launch, and the replay follows the calibration

@@ -48,6 +48,8 @@ t modes tools/modes_r5.py neck
 t time_heads_train tools/time_heads_train.py
 t neck_train_cfg2_profile tools/time_neck_train.py --profile
 t neck_train_cfg2_layers tools/time_neck_train.py --layers
+t neck_train_cfg2_hostgeom tools/time_neck_train.py --host-geometry
+t neck_train_cfg2_sources tools/prof_neck_train_sources.py
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d $ROOT/$O/${TAG}_trace_step -o x -- python3 $ROOT/tools/_steps_only.py > $ROOT/$O/${TAG}_trace_step.log 2>&1 ) || true
 python3 tools/step_timeline.py $O/${TAG}_trace_step/x_kernel_trace.csv > $O/${TAG}_timeline_hotpath.txt 2>&1 || true
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/${TAG}_trace_neck -o x -- python3 $ROOT/tools/_neck_only.py graph 30 > $ROOT/$O/${TAG}_trace_neck.log 2>&1 ) || true

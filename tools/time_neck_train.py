@@ -22,12 +22,15 @@ def main():
     ap.add_argument('--profile', action='store_true')
     ap.add_argument('--host', action='store_true', help='cProfile of the host side')
     ap.add_argument('--layers', action='store_true', help="the voxel heads as torch layers (fused_heads_training = False)")
+    ap.add_argument('--host-geometry', action='store_true', help='device_geometry = False: the calibration read to the host per forward')
     a = ap.parse_args()
     cfg = synthetic.CONFIGS[a.config]
     dev = torch.device('cuda:0')
     neck = hotpath.NeckPath(cfg, dev, accelerate=False)
     m = neck.module.train()
     m.fused_heads_training = not a.layers
+    if a.host_geometry:
+        m.device_geometry = False
     pre = neck.depthnet_out
     depth0 = pre[:, :cfg.D].softmax(1)
     feat0 = pre[:, cfg.D + 2:cfg.D + 2 + cfg.channels].clone()
