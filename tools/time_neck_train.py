@@ -22,10 +22,12 @@ def main():
     ap.add_argument('--profile', action='store_true')
     ap.add_argument('--host', action='store_true', help='cProfile of the host side')
     ap.add_argument('--layers', action='store_true', help="the voxel heads as torch layers (fused_heads_training = False)")
+    ap.add_argument('--cudnn-benchmark', action='store_true', help='torch.backends.cudnn.benchmark = True (MIOpen find mode)')
     ap.add_argument('--host-geometry', action='store_true', help='device_geometry = False: the calibration read to the host per forward')
     a = ap.parse_args()
     cfg = synthetic.CONFIGS[a.config]
     dev = torch.device('cuda:0')
+    torch.backends.cudnn.benchmark = bool(a.cudnn_benchmark)
     neck = hotpath.NeckPath(cfg, dev, accelerate=False)
     m = neck.module.train()
     m.fused_heads_training = not a.layers
