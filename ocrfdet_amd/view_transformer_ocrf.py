@@ -81,7 +81,9 @@ class ChannelAttention(nn.Module):
         self.sigmoid = nn.Sigmoid()
 
     def forward(self, x):
-        return self.sigmoid(self.fc(x.mean((2, 3), keepdim=True)) + self.fc(x.amax((2, 3), keepdim=True)))
+        # (the maximum with its index, as the reference's AdaptiveMaxPool2d(1), :72-83 — see hoa.HeightAttention._forward_torch)
+        peak = x.flatten(2).max(-1)[0].unsqueeze(-1).unsqueeze(-1)
+        return self.sigmoid(self.fc(x.mean((2, 3), keepdim=True)) + self.fc(peak))
 
 
 def _tensors_of(owner, name, modules, buffers=True):
@@ -119,7 +121,7 @@ def _zeros(shape, like):
 
 
 def _spatial_logits(x, conv):
-    return conv(torch.cat((x.mean(1, keepdim=True), x.amax(1, keepdim=True)), 1))
+    return conv(torch.cat((x.mean(1, keepdim=True), torch.max(x, dim=1, keepdim=True)[0]), 1))    # (:94-96: max with indices)
 
 
 class SpatialAttention(nn.Module):
